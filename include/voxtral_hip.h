@@ -1,0 +1,191 @@
+/*
+ * voxtral_hip.h -- C ABI of libvoxtral_hip.so: the MI355X (gfx950) implementation of the
+ * Voxtral-Mini realtime ASR hot path of TrevorS/voxtral-mini-realtime-rs (reference v0.2.0).
+ *
+ * This is the drop-in boundary: every entry point is what a Rust `-sys` crate for the
+ * reference's model-forward surface (src/audio, src/gguf, src/models) would bind.  The
+ * reference interface each function replaces is cited as file:line (paths relative to the
+ * reference repository).  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - every function returns int32_t status: 0 = VOX_OK, non-zero = error; the message is
+ *     available from vox_last_error() (thread-local).  Where the reference panics (shape
+ *     mismatch in q4_matmul, gguf/op.rs:92-100) or returns anyhow::Error, we return a status.
+ *   - opaque handles; caller-owned host buffers; plain pointers and sizes only.
+ *   - a vox_ctx binds one HIP device + one stream.  Handles created from a ctx are not
+ *     thread-safe; distinct ctxs are independent (one ctx per GPU for multi-GPU sharding).
+ *   - `mem_kind`: VOX_MEM_HOST = pointers are host memory (copied in/out, synchronous),
+ *     VOX_MEM_DEVICE = pointers are device memory on the ctx's device (asynchronous on the
+ *     ctx stream; call vox_ctx_synchronize before reading results from another stream).
+ *   - layouts follow the reference: weights [N,K] = [out,in] row-major (gguf/tensor.rs:32-34);
+ *     Q4_0 block = {f16 d; u8 qs[16]}, element i <-> low nibble of qs[i], element i+16 <-> high
+ *     nibble (gguf/tensor.rs:98-109); mel handed to the model as [128][T] (time fastest,
+ *     bin/transcribe.rs:295-305) while compute_log returns [T][128] (audio/mel.rs:128); ids are i32.
+ *   - there is NO CPU fallback anywhere behind this ABI: compute entry points fail with
+ *     VOX_ERR_HIP if no gfx950 device is usable.
+ */
+#ifndef VOXTRAL_HIP_H
+#define VOXTRAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOX_OK 0
+#define VOX_ERR_INVALID 1   /* bad argument / shape mismatch            */
+#define VOX_ERR_IO 2        /* file / GGUF parse error                  */
+#define VOX_ERR_HIP 3       /* HIP runtime error or no device           */
+#define VOX_ERR_NOTFOUND 4  /* tensor name not present                  */
+#define VOX_ERR_UNSUPPORTED 5
+
+#define VOX_MEM_HOST 0
+#define VOX_MEM_DEVICE 1
+
+typedef struct vox_ctx vox_ctx;
+typedef struct vox_gguf vox_gguf;
+typedef struct vox_q4 vox_q4;
+typedef struct vox_model vox_model;
+typedef struct vox_cache vox_cache;
+typedef struct vox_graph vox_graph;
+
+const char* vox_last_error(void);
+int32_t vox_abi_version(void);                      /* bumps on any signature change */
+int32_t vox_device_count(int32_t* n);
+
+/* ---- context (reference: the implicit `WgpuDevice::default()`, bin/transcribe.rs:67) ---- */
+int32_t vox_ctx_create(int32_t device, vox_ctx** out);
+int32_t vox_ctx_destroy(vox_ctx* ctx);
+int32_t vox_ctx_synchronize(vox_ctx* ctx);
+int32_t vox_ctx_stream(vox_ctx* ctx, void** hip_stream_out);   /* hipStream_t, for event timing */
+/* device memory helpers so non-HIP callers can use VOX_MEM_DEVICE */
+int32_t vox_dev_alloc(vox_ctx* ctx, size_t nbytes, void** out);
+int32_t vox_dev_free(vox_ctx* ctx, void* p);
+int32_t vox_dev_upload(vox_ctx* ctx, void* dst_dev, const void* src_host, size_t nbytes);
+int32_t vox_dev_download(vox_ctx* ctx, void* dst_host, const void* src_dev, size_t nbytes);
+
+/* ---- audio front-end (src/audio) ------------------------------------------------------- */
+/* AudioBuffer::peak_normalize, audio/io.rs:59-68 (host, in place) */
+int32_t vox_peak_normalize(float* samples, size_t n, float target_peak);
+
+/* PadConfig, audio/pad.rs:20-46 */
+typedef struct {
+    uint32_t sample_rate;             /* 16000 */
+    uint32_t n_left_pad_tokens;       /* 76    */
+    float    frame_rate;              /* 12.5  */
+    uint32_t extra_right_pad_tokens;  /* 17    */
+} vox_pad_cfg;
+int32_t vox_pad_cfg_voxtral(vox_pad_cfg* cfg);                                   /* PadConfig::voxtral, pad.rs:50-52 */
+int32_t vox_pad_len(size_t n, const vox_pad_cfg* cfg, size_t* out);              /* pad.rs:89-93 */
+int32_t vox_pad_audio(const float* in, size_t n, const vox_pad_cfg* cfg, float* out); /* pad_audio, pad.rs:89-103 */
+int32_t vox_num_audio_tokens(size_t n, const vox_pad_cfg* cfg, size_t* out);     /* pad.rs:106-108 */
+
+/* ChunkConfig / chunk_audio / needs_chunking, audio/chunk.rs:9-166 */
+typedef struct {
+    uint32_t max_mel_frames;  /* 1500; CLI default 1200 (bin/transcribe.rs:55-57) */
+    uint32_t hop_length;      /* 160 */
+    uint32_t sample_rate;     /* 16000 */
+    uint32_t overlap_frames;  /* 0 */
+} vox_chunk_cfg;
+typedef struct { size_t start_sample, end_sample, index; int32_t is_last; } vox_chunk;
+int32_t vox_needs_chunking(size_t n, const vox_chunk_cfg* cfg, int32_t* out);
+int32_t vox_chunk_plan(size_t n, const vox_chunk_cfg* cfg, vox_chunk* out, size_t cap, size_t* n_chunks);
+
+/* MelSpectrogram (MelConfig::voxtral), audio/mel.rs:63-350 */
+int32_t vox_mel_num_frames(size_t n_samples, size_t* out);                       /* mel.rs:175-182 */
+int32_t vox_mel_filterbank(float* out_128x201);                                  /* mel.rs:288-339 */
+int32_t vox_hann_window(int32_t length, float* out);                             /* mel.rs:345-349 */
+/* compute_log, mel.rs:128-165: samples (already padded by the caller) -> [T][128].  STFT + mel
+ * filterbank + log run on the GPU. */
+int32_t vox_mel_compute_log(vox_ctx* ctx, const float* samples, size_t n, float* out_Tx128, int32_t mem_kind);
+
+/* TimeEmbedding::embed, models/time_embedding.rs:41-71 (theta 10000) */
+int32_t vox_time_embedding(float t, int32_t dim, float* out);
+
+/* ---- GGUF reader (src/gguf/reader.rs:98-223) -------------------------------------------- */
+int32_t vox_gguf_open(const char* path, vox_gguf** out);                         /* GgufReader::open */
+int32_t vox_gguf_close(vox_gguf* g);
+int32_t vox_gguf_version(const vox_gguf* g, uint32_t* out);
+int32_t vox_gguf_tensor_count(const vox_gguf* g, uint64_t* out);
+int32_t vox_gguf_tensor_name(const vox_gguf* g, uint64_t index, const char** out); /* tensor_names */
+/* tensor_info: dims in file order (GGUF = reversed PyTorch order), dtype 0 F32 / 1 F16 / 2 Q4_0 */
+int32_t vox_gguf_tensor_info(const vox_gguf* g, const char* name, uint64_t dims[4], uint32_t* ndims,
+                             uint32_t* dtype, uint64_t* nbytes);
+int32_t vox_gguf_tensor_data(const vox_gguf* g, const char* name, void* dst, size_t cap); /* tensor_data */
+
+/* ---- Q4 operator boundary (src/gguf/tensor.rs, op.rs, linear.rs) ------------------------ */
+/* Q4Tensor::from_q4_bytes, gguf/tensor.rs:35-71: validates N*K % 32 == 0 and nbytes == blocks*18 */
+int32_t vox_q4_tensor_from_bytes(vox_ctx* ctx, const uint8_t* raw, size_t nbytes, int64_t N, int64_t K, vox_q4** out);
+int32_t vox_q4_tensor_shape(const vox_q4* q, int64_t* N, int64_t* K);            /* tensor.rs:74-76 */
+int32_t vox_q4_tensor_num_blocks(const vox_q4* q, int64_t* out);                 /* tensor.rs:79-81 */
+int32_t vox_q4_tensor_dequantize(vox_ctx* ctx, const vox_q4* q, float* out_NxK); /* tensor.rs:88-113 (host out) */
+int32_t vox_q4_tensor_free(vox_q4* q);
+/* q4_matmul, gguf/op.rs:86-137: out[B,M,N] = x[B,M,K] x W[N,K]^T, f32 accumulate.
+ * B*M <= 4 runs the GEMV kernel (reference: tiled shader), larger the MFMA GEMM (reference: naive). */
+int32_t vox_q4_matmul(vox_ctx* ctx, const vox_q4* w, const float* x, int32_t B, int32_t M, float* out, int32_t mem_kind);
+/* Q4Linear::forward, gguf/linear.rs:34-40: q4_matmul (+ bias[N], may be NULL; same mem_kind) */
+int32_t vox_q4_linear_forward(vox_ctx* ctx, const vox_q4* w, const float* bias_or_null, const float* x,
+                              int32_t B, int32_t M, float* out, int32_t mem_kind);
+
+/* ---- model-forward surface (src/gguf/loader.rs, src/gguf/model.rs) ---------------------- */
+typedef struct {
+    int32_t enc_layers, enc_dim, enc_heads, enc_head_dim, enc_ffn, enc_window;
+    int32_t dec_layers, dec_dim, dec_heads, dec_kv_heads, dec_head_dim, dec_ffn, dec_window, vocab;
+    int32_t n_mels, reshape_factor, t_cond_dim;
+    float rope_theta, norm_eps;
+} vox_model_cfg;
+
+/* Q4ModelLoader::from_file(..).load(), gguf/loader.rs:82-128 */
+int32_t vox_q4_model_load(vox_ctx* ctx, const char* gguf_path, vox_model** out);
+int32_t vox_model_free(vox_model* m);
+int32_t vox_model_config(const vox_model* m, vox_model_cfg* out);
+int32_t vox_model_weight_bytes(const vox_model* m, uint64_t* out);   /* device bytes of the weight arena */
+/* Multi-GPU: export / import the packed device weight arena so rank 0 can parse the GGUF once and
+ * the other ranks receive it with one RCCL broadcast over xGMI (no data-path collective). */
+int32_t vox_model_arena(const vox_model* m, void** dev_ptr, uint64_t* nbytes);
+
+/* the delay conditioning used by every decoder call: t_embed = TimeEmbedding(dec_dim).embed(delay)
+ * (bin/transcribe.rs:104-105).  Ada scales 1 + w2(gelu(w0 t_embed)) (gguf/model.rs:250-255) are
+ * loop-invariant and cached per t_embed. */
+int32_t vox_model_set_t_embed(vox_model* m, const float* t_embed_host);
+
+/* Q4VoxtralModel::encode_audio, gguf/model.rs:783-788: mel [128][T] -> [S][dec_dim]; *S = floor(S_enc/4) */
+int32_t vox_encode_audio(vox_model* m, const float* mel_128xT, int32_t T, float* out, int32_t cap_rows,
+                         int32_t* S, int32_t mem_kind);
+/* Q4VoxtralModel::transcribe_streaming, gguf/model.rs:873-963 -> ids, length S-38 (0 if S < 38).
+ * logits_or_null (host, [n_ids][vocab]) is a parity/debug tap for the per-step decoder logits. */
+int32_t vox_transcribe_streaming(vox_model* m, const float* mel_128xT, int32_t T, const float* t_embed,
+                                 int32_t* out_ids, int32_t cap, int32_t* n_ids, float* logits_or_null,
+                                 int32_t mem_kind);
+/* Whole hot path from 16 kHz samples: peak_normalize(0.95) -> pad -> log-mel -> transcribe_streaming
+ * (bin/e2e_bench.rs:98-232 un-chunked pipeline).  samples may be device-resident (VOX_MEM_DEVICE). */
+int32_t vox_transcribe_audio(vox_model* m, const float* samples, size_t n, const float* t_embed,
+                             int32_t* out_ids, int32_t cap, int32_t* n_ids, int32_t mem_kind);
+
+/* Q4LanguageModel pieces used directly by e2e-bench / WASM (gguf/model.rs:566,665,680,711) */
+int32_t vox_decoder_cache_create(vox_model* m, int32_t max_seq, vox_cache** out);   /* create_cache_preallocated */
+int32_t vox_cache_free(vox_cache* c);
+int32_t vox_cache_seq_len(const vox_cache* c, int32_t* out);                         /* KVCache::seq_len */
+int32_t vox_cache_reset(vox_cache* c);
+int32_t vox_embed_tokens_from_ids(vox_model* m, const int32_t* ids, int32_t n, float* out_nxD);      /* host out */
+int32_t vox_forward_hidden_with_cache(vox_model* m, const float* x_MxD, int32_t M, const float* t_embed,
+                                      vox_cache* cache, float* out_MxD);                              /* host in/out */
+int32_t vox_lm_head(vox_model* m, const float* hidden_MxD, int32_t M, float* logits_MxV);            /* host in/out */
+
+/* stage timers, BenchmarkResult parity (bin/e2e_bench.rs:62-74): ms of the last transcribe call */
+typedef struct { double preprocess_ms, encode_ms, decode_ms, total_ms; int32_t decode_tokens; int32_t graph_replays; } vox_timings;
+int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out);
+
+/* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -------- */
+/* Launch the decode-step Q4 GEMV of decoder layer `layer` (`which`: 0 qkv, 1 wo, 2 w1w3, 3 w2, 4 lm_head)
+ * `iters` times on the ctx stream, cycling layers so weights stay HBM-cold; returns the average
+ * launch duration measured with hipEvents on that stream and the algorithmic bytes per launch. */
+int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t iters, double* avg_us, double* bytes_per_launch,
+                              const char** kernel_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXTRAL_HIP_H */

@@ -1,0 +1,12 @@
+"""MI355X-native Voxtral-Mini realtime ASR hot path (gfx950 HIP kernels behind a C ABI).
+
+Python here is a thin ctypes mirror of the reference's Rust surface (src/audio, src/gguf,
+src/models); all compute lives in csrc/ -> libvoxtral_hip.so.  There is no CPU fallback:
+`lib()` raises if the HIP library is missing.
+"""
+from . import synth  # noqa: F401  (numpy-only tooling: synthetic GGUF / audio)
+from . import build  # noqa: F401
+from ._lib import lib, VoxError  # noqa: F401
+from .audio import (PadConfig, ChunkConfig, MelSpectrogram, pad_audio, chunk_audio, needs_chunking,  # noqa: F401
+                    peak_normalize, TimeEmbedding)
+from .gguf import (Context, GgufReader, Q4Tensor, Q4Linear, q4_matmul, Q4ModelLoader, Q4VoxtralModel)  # noqa: F401

@@ -1,0 +1,48 @@
+"""Builds libvoxtral_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libvoxtral_hip.so")
+SOURCES = ["vox_kernels.hip", "vox_api.cpp"]
+HEADERS = ["vox_kernels.h", os.path.join("..", "..", "include", "voxtral_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_all(verbose: bool = False, force: bool = False) -> str:
+    os.makedirs(os.path.join(PKG_DIR, "build"), exist_ok=True)
+    deps = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, jobs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(PKG_DIR, "build", src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp] + deps):
+            jobs.append([HIPCC, *FLAGS, "-x", "hip", "-c", sp, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB_PATH, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs])
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_all(verbose=True))

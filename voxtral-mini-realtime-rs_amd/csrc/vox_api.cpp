@@ -1,0 +1,1025 @@
+// vox_api.cpp -- C ABI of libvoxtral_hip.so (include/voxtral_hip.h): context, audio front-end helpers,
+// GGUF reader, Q4 operator boundary, model loader (GGUF -> packed device arena) and the model-forward
+// orchestration (encoder, prefill, hipGraph-captured sync-free decode step).
+//
+// Reference surface mirrored: src/audio/{io,pad,chunk,mel}.rs, src/gguf/{reader,tensor,op,linear,loader,model}.rs,
+// src/models/time_embedding.rs.  No code is shared with oracle/ and there is no CPU fallback for compute.
+#include "../../include/voxtral_hip.h"
+#include "vox_kernels.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace vox;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int32_t fail(int32_t code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(VOX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+#define VOXCHK(expr) do { int32_t _r = (expr); if (_r != VOX_OK) return _r; } while (0)
+#define ARGCHK(cond, ...) do { if (!(cond)) return fail(VOX_ERR_INVALID, __VA_ARGS__); } while (0)
+
+extern "C" const char* vox_last_error(void) { return g_err.c_str(); }
+extern "C" int32_t vox_abi_version(void) { return 1; }
+extern "C" int32_t vox_device_count(int32_t* n) {
+    ARGCHK(n, "null out pointer");
+    int c = 0; hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; (void)hipGetLastError(); return VOX_OK; }
+    *n = c; return VOX_OK;
+}
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct vox_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // mel tables (device)
+    float *d_window = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_fb = nullptr;
+    int *d_fb_lo = nullptr, *d_fb_hi = nullptr;
+    float* d_scale = nullptr;   // peak-normalise scale scratch
+    bool mel_ready = false;
+};
+
+static int32_t ctx_bind(const vox_ctx* c) { HIPCHK(hipSetDevice(c->device)); return VOX_OK; }
+
+extern "C" int32_t vox_ctx_create(int32_t device, vox_ctx** out) {
+    ARGCHK(out, "null out pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(VOX_ERR_HIP, "no HIP device available (libvoxtral_hip has no CPU fallback)"); }
+    ARGCHK(device >= 0 && device < n, "device %d out of range (have %d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    vox_ctx* c = new vox_ctx(); c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(VOX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = c; return VOX_OK;
+}
+extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
+    if (!c) return VOX_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (void* p : {(void*)c->d_window, (void*)c->d_cos, (void*)c->d_sin, (void*)c->d_fb, (void*)c->d_fb_lo, (void*)c->d_fb_hi, (void*)c->d_scale})
+        if (p) (void)hipFree(p);
+    (void)hipStreamDestroy(c->stream);
+    delete c; return VOX_OK;
+}
+extern "C" int32_t vox_ctx_synchronize(vox_ctx* c) { ARGCHK(c, "null ctx"); VOXCHK(ctx_bind(c)); HIPCHK(hipStreamSynchronize(c->stream)); return VOX_OK; }
+extern "C" int32_t vox_ctx_stream(vox_ctx* c, void** s) { ARGCHK(c && s, "null argument"); *s = (void*)c->stream; return VOX_OK; }
+extern "C" int32_t vox_dev_alloc(vox_ctx* c, size_t nbytes, void** out) { ARGCHK(c && out, "null argument"); VOXCHK(ctx_bind(c)); HIPCHK(hipMalloc(out, nbytes ? nbytes : 1)); return VOX_OK; }
+extern "C" int32_t vox_dev_free(vox_ctx* c, void* p) { ARGCHK(c, "null ctx"); VOXCHK(ctx_bind(c)); if (p) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(p)); } return VOX_OK; }
+extern "C" int32_t vox_dev_upload(vox_ctx* c, void* dst, const void* src, size_t n) {
+    ARGCHK(c && dst && src, "null argument"); VOXCHK(ctx_bind(c));
+    HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return VOX_OK;
+}
+extern "C" int32_t vox_dev_download(vox_ctx* c, void* dst, const void* src, size_t n) {
+    ARGCHK(c && dst && src, "null argument"); VOXCHK(ctx_bind(c));
+    HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return VOX_OK;
+}
+
+// small RAII device buffer for host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// audio front-end: host helpers (caller-side in the reference too)
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t vox_peak_normalize(float* s, size_t n, float target) {   // audio/io.rs:59-68
+    ARGCHK(s || n == 0, "null samples");
+    float mx = 0.f;
+    for (size_t i = 0; i < n; i++) mx = std::fmax(mx, std::fabs(s[i]));
+    if (mx < 1e-10f) return VOX_OK;
+    const float scale = target / mx;
+    for (size_t i = 0; i < n; i++) s[i] *= scale;
+    return VOX_OK;
+}
+extern "C" int32_t vox_pad_cfg_voxtral(vox_pad_cfg* c) {                     // audio/pad.rs:32-52
+    ARGCHK(c, "null cfg"); c->sample_rate = 16000; c->n_left_pad_tokens = 76; c->frame_rate = 12.5f; c->extra_right_pad_tokens = 17; return VOX_OK;
+}
+static size_t pad_spt(const vox_pad_cfg* c) { return (size_t)((float)c->sample_rate / c->frame_rate); }
+static size_t pad_left(const vox_pad_cfg* c) { return (size_t)c->n_left_pad_tokens * pad_spt(c); }
+static size_t pad_right(const vox_pad_cfg* c, size_t total) {                // audio/pad.rs:68-74
+    const size_t spt = pad_spt(c), rem = total % spt;
+    return (rem ? spt - rem : 0) + (size_t)c->extra_right_pad_tokens * spt;
+}
+extern "C" int32_t vox_pad_len(size_t n, const vox_pad_cfg* c, size_t* out) {
+    ARGCHK(c && out, "null argument"); ARGCHK(c->frame_rate > 0 && pad_spt(c) > 0, "bad pad config");
+    *out = pad_left(c) + n + pad_right(c, n + pad_left(c)); return VOX_OK;
+}
+extern "C" int32_t vox_pad_audio(const float* in, size_t n, const vox_pad_cfg* c, float* out) {   // audio/pad.rs:89-103
+    ARGCHK(c && out && (in || n == 0), "null argument");
+    size_t total; VOXCHK(vox_pad_len(n, c, &total));
+    std::memset(out, 0, total * sizeof(float));
+    if (n) std::memcpy(out + pad_left(c), in, n * sizeof(float));
+    return VOX_OK;
+}
+extern "C" int32_t vox_num_audio_tokens(size_t n, const vox_pad_cfg* c, size_t* out) { ARGCHK(c && out, "null argument"); *out = n / pad_spt(c); return VOX_OK; }
+
+extern "C" int32_t vox_needs_chunking(size_t n, const vox_chunk_cfg* c, int32_t* out) {   // audio/chunk.rs:164-166
+    ARGCHK(c && out, "null argument"); *out = n > (size_t)c->max_mel_frames * c->hop_length; return VOX_OK;
+}
+extern "C" int32_t vox_chunk_plan(size_t n, const vox_chunk_cfg* c, vox_chunk* out, size_t cap, size_t* n_chunks) {  // chunk.rs:120-161
+    ARGCHK(c && n_chunks, "null argument");
+    ARGCHK(c->max_mel_frames > c->overlap_frames && c->hop_length > 0, "overlap_frames must be < max_mel_frames");
+    const size_t max_s = (size_t)c->max_mel_frames * c->hop_length, step = (size_t)(c->max_mel_frames - c->overlap_frames) * c->hop_length;
+    size_t idx = 0;
+    for (size_t pos = 0; pos < n; pos += step, idx++) {
+        const size_t end = std::min(pos + max_s, n);
+        if (out && idx < cap) { out[idx].start_sample = pos; out[idx].end_sample = end; out[idx].index = idx; out[idx].is_last = end >= n; }
+    }
+    *n_chunks = idx; return VOX_OK;
+}
+
+// mel tables (audio/mel.rs:260-349), computed on the host exactly as the reference does (f32 math)
+static float hz_to_mel(float f) {
+    const float F_SP = 200.0f / 3.0f, MIN_LOG_HZ = 1000.0f, MIN_LOG_MEL = MIN_LOG_HZ / F_SP, LOGSTEP = 0.06875174f;
+    return f < MIN_LOG_HZ ? f / F_SP : MIN_LOG_MEL + std::log(f / MIN_LOG_HZ) / LOGSTEP;
+}
+static float mel_to_hz(float m) {
+    const float F_SP = 200.0f / 3.0f, MIN_LOG_HZ = 1000.0f, MIN_LOG_MEL = MIN_LOG_HZ / F_SP, LOGSTEP = 0.06875174f;
+    return m < MIN_LOG_MEL ? m * F_SP : MIN_LOG_HZ * std::exp((m - MIN_LOG_MEL) * LOGSTEP);
+}
+static void build_filterbank(float* fb) {
+    const int n_mels = 128, n_freqs = 201;
+    const float mel_min = hz_to_mel(0.0f), mel_max = hz_to_mel(8000.0f);
+    float hz[130], fr[201];
+    for (int i = 0; i <= n_mels + 1; i++) hz[i] = mel_to_hz(mel_min + (mel_max - mel_min) * (float)i / (float)(n_mels + 1));
+    for (int j = 0; j < n_freqs; j++) fr[j] = (float)j * 16000.0f / 400.0f;
+    std::memset(fb, 0, sizeof(float) * n_mels * n_freqs);
+    for (int i = 0; i < n_mels; i++) {
+        const float lo = hz[i], ce = hz[i + 1], up = hz[i + 2];
+        for (int j = 0; j < n_freqs; j++) {
+            if (fr[j] >= lo && fr[j] <= ce && ce > lo) fb[i * n_freqs + j] = (fr[j] - lo) / (ce - lo);
+            else if (fr[j] > ce && fr[j] <= up && up > ce) fb[i * n_freqs + j] = (up - fr[j]) / (up - ce);
+        }
+        const float bw = hz[i + 2] - hz[i];
+        if (bw > 0.0f) { const float en = 2.0f / bw; for (int j = 0; j < n_freqs; j++) fb[i * n_freqs + j] *= en; }
+    }
+}
+static void build_hann(int len, float* w) {
+    const float PI = 3.14159265358979323846f;
+    for (int i = 0; i < len; i++) w[i] = 0.5f * (1.0f - std::cos(2.0f * PI * (float)i / (float)len));
+}
+extern "C" int32_t vox_mel_num_frames(size_t n, size_t* out) { ARGCHK(out, "null out"); *out = (n + 400 - 400) / 160; return VOX_OK; }   // mel.rs:175-182
+extern "C" int32_t vox_mel_filterbank(float* out) { ARGCHK(out, "null out"); build_filterbank(out); return VOX_OK; }
+extern "C" int32_t vox_hann_window(int32_t len, float* out) { ARGCHK(out && len > 0, "bad argument"); build_hann(len, out); return VOX_OK; }
+
+static int32_t ctx_mel_tables(vox_ctx* c, MelTables* t) {
+    if (!c->mel_ready) {
+        std::vector<float> win(400), ct(400), st(400), fb(128 * 201);
+        std::vector<int> lo(128), hi(128);
+        build_hann(400, win.data()); build_filterbank(fb.data());
+        for (int m = 0; m < 400; m++) { ct[m] = (float)std::cos(2.0 * M_PI * m / 400.0); st[m] = (float)std::sin(2.0 * M_PI * m / 400.0); }
+        for (int i = 0; i < 128; i++) {
+            int a = 201, b = 0;
+            for (int j = 0; j < 201; j++) if (fb[i * 201 + j] != 0.0f) { a = std::min(a, j); b = std::max(b, j + 1); }
+            if (a > b) { a = 0; b = 0; }
+            lo[i] = a; hi[i] = b;
+        }
+        HIPCHK(hipMalloc((void**)&c->d_window, 400 * 4)); HIPCHK(hipMalloc((void**)&c->d_cos, 400 * 4)); HIPCHK(hipMalloc((void**)&c->d_sin, 400 * 4));
+        HIPCHK(hipMalloc((void**)&c->d_fb, 128 * 201 * 4)); HIPCHK(hipMalloc((void**)&c->d_fb_lo, 128 * 4)); HIPCHK(hipMalloc((void**)&c->d_fb_hi, 128 * 4));
+        HIPCHK(hipMalloc((void**)&c->d_scale, 16));
+        HIPCHK(hipMemcpy(c->d_window, win.data(), 400 * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_cos, ct.data(), 400 * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_sin, st.data(), 400 * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_fb, fb.data(), 128 * 201 * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_fb_lo, lo.data(), 128 * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_fb_hi, hi.data(), 128 * 4, hipMemcpyHostToDevice));
+        c->mel_ready = true;
+    }
+    t->window = c->d_window; t->cos_t = c->d_cos; t->sin_t = c->d_sin; t->fb = c->d_fb; t->fb_lo = c->d_fb_lo; t->fb_hi = c->d_fb_hi;
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_mel_compute_log(vox_ctx* c, const float* samples, size_t n, float* out, int32_t mem_kind) {
+    ARGCHK(c && out && (samples || n == 0), "null argument"); VOXCHK(ctx_bind(c));
+    const size_t T = n / 160;
+    if (T == 0) return VOX_OK;
+    MelTables t; VOXCHK(ctx_mel_tables(c, &t));
+    if (mem_kind == VOX_MEM_DEVICE) {
+        HIPCHK(launch_mel(samples, (long)n, 0, 0, nullptr, t, out, (int)T, 0, c->stream));
+        return VOX_OK;
+    }
+    DevBuf din, dout; HIPCHK(din.alloc(n * 4)); HIPCHK(dout.alloc(T * 128 * 4));
+    HIPCHK(hipMemcpyAsync(din.p, samples, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_mel(din.as<float>(), (long)n, 0, 0, nullptr, t, dout.as<float>(), (int)T, 0, c->stream));
+    HIPCHK(hipMemcpyAsync(out, dout.p, T * 128 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_time_embedding(float t, int32_t dim, float* out) {   // models/time_embedding.rs:41-71
+    ARGCHK(out && dim > 0 && dim % 2 == 0, "bad argument");
+    const int half = dim / 2; const float log_theta = std::log(10000.0f);
+    for (int i = 0; i < half; i++) {
+        const float freq = std::exp(-log_theta * (float)i / (float)half), ang = t * freq;
+        out[i] = std::cos(ang); out[half + i] = std::sin(ang);
+    }
+    return VOX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GGUF reader (gguf/reader.rs:13-223)
+// ------------------------------------------------------------------------------------------------
+struct GTensor { std::string name; uint32_t ndims = 0; uint64_t dims[4] = {0, 0, 0, 0}; uint32_t dtype = 0; uint64_t offset = 0, nbytes = 0; };
+struct vox_gguf {
+    uint8_t* map = nullptr; size_t size = 0; uint32_t version = 0;
+    std::vector<GTensor> tensors; std::map<std::string, size_t> index; uint64_t data_off = 0;
+    const GTensor* find(const std::string& n) const { auto it = index.find(n); return it == index.end() ? nullptr : &tensors[it->second]; }
+    const uint8_t* data(const GTensor* t) const { return map + data_off + t->offset; }
+};
+namespace {
+struct Cur {
+    const uint8_t* p; size_t pos, size; bool bad = false;
+    template <class T> T rd() { T v{}; if (pos + sizeof(T) > size) { bad = true; return v; } std::memcpy(&v, p + pos, sizeof(T)); pos += sizeof(T); return v; }
+    std::string str() { uint64_t len = rd<uint64_t>(); if (bad || len > size - pos) { bad = true; return {}; } std::string s((const char*)p + pos, len); pos += len; return s; }
+    void skip(size_t n) { if (n > size - pos) bad = true; else pos += n; }
+    int skip_value(uint32_t ty) {   // gguf/reader.rs:327-376
+        switch (ty) {
+        case 0: case 1: case 7: skip(1); break;
+        case 2: case 3: skip(2); break;
+        case 4: case 5: case 6: skip(4); break;
+        case 8: (void)str(); break;
+        case 9: { uint32_t et = rd<uint32_t>(); uint64_t cnt = rd<uint64_t>(); for (uint64_t i = 0; i < cnt && !bad; i++) if (skip_value(et)) return 1; break; }
+        case 10: case 11: case 12: skip(8); break;
+        default: return 1;
+        }
+        return 0;
+    }
+};
+}  // namespace
+
+extern "C" int32_t vox_gguf_close(vox_gguf* g) { if (g) { if (g->map) munmap(g->map, g->size); delete g; } return VOX_OK; }
+extern "C" int32_t vox_gguf_open(const char* path, vox_gguf** out) {
+    ARGCHK(path && out, "null argument");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(VOX_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+    struct stat st; fstat(fd, &st);
+    void* mp = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0); close(fd);
+    if (mp == MAP_FAILED) return fail(VOX_ERR_IO, "mmap of %s failed", path);
+    vox_gguf* g = new vox_gguf(); g->map = (uint8_t*)mp; g->size = st.st_size;
+    Cur c{g->map, 0, g->size};
+    const uint32_t magic = c.rd<uint32_t>();
+    if (c.bad || magic != 0x46554747u) { vox_gguf_close(g); return fail(VOX_ERR_IO, "Invalid GGUF magic: 0x%08X (expected 0x46554747)", magic); }
+    g->version = c.rd<uint32_t>();
+    if (g->version != 2 && g->version != 3) { uint32_t v = g->version; vox_gguf_close(g); return fail(VOX_ERR_IO, "Unsupported GGUF version: %u (expected 2 or 3)", v); }
+    const uint64_t nt = c.rd<uint64_t>(), nkv = c.rd<uint64_t>();
+    for (uint64_t i = 0; i < nkv && !c.bad; i++) {
+        (void)c.str(); const uint32_t ty = c.rd<uint32_t>();
+        if (c.skip_value(ty)) { vox_gguf_close(g); return fail(VOX_ERR_IO, "Unknown GGUF metadata value type"); }
+    }
+    if (c.bad || nt > (1u << 24)) { vox_gguf_close(g); return fail(VOX_ERR_IO, "Failed to parse GGUF metadata"); }
+    g->tensors.resize(nt);
+    for (uint64_t i = 0; i < nt; i++) {
+        GTensor& t = g->tensors[i];
+        t.name = c.str(); t.ndims = c.rd<uint32_t>();
+        if (c.bad || t.ndims > 4) { vox_gguf_close(g); return fail(VOX_ERR_IO, "Failed to read tensor %llu", (unsigned long long)i); }
+        uint64_t ne = 1; for (uint32_t d = 0; d < t.ndims; d++) { t.dims[d] = c.rd<uint64_t>(); ne *= t.dims[d]; }
+        t.dtype = c.rd<uint32_t>(); t.offset = c.rd<uint64_t>();
+        if (c.bad) { vox_gguf_close(g); return fail(VOX_ERR_IO, "Failed to read tensor %llu", (unsigned long long)i); }
+        if (t.dtype > 2) { uint32_t d = t.dtype; vox_gguf_close(g); return fail(VOX_ERR_IO, "Unsupported GGML dtype code: %u", d); }
+        t.nbytes = t.dtype == 0 ? ne * 4 : t.dtype == 1 ? ne * 2 : (ne / 32) * 18;     // reader.rs:37-48
+        g->index[t.name] = i;
+    }
+    g->data_off = (c.pos + 31) / 32 * 32;                                                // reader.rs:177-179
+    for (auto& t : g->tensors)
+        if (g->data_off + t.offset + t.nbytes > g->size) { std::string n = t.name; vox_gguf_close(g); return fail(VOX_ERR_IO, "tensor '%s' exceeds file size", n.c_str()); }
+    *out = g; return VOX_OK;
+}
+extern "C" int32_t vox_gguf_version(const vox_gguf* g, uint32_t* out) { ARGCHK(g && out, "null argument"); *out = g->version; return VOX_OK; }
+extern "C" int32_t vox_gguf_tensor_count(const vox_gguf* g, uint64_t* out) { ARGCHK(g && out, "null argument"); *out = g->tensors.size(); return VOX_OK; }
+extern "C" int32_t vox_gguf_tensor_name(const vox_gguf* g, uint64_t i, const char** out) {
+    ARGCHK(g && out, "null argument"); ARGCHK(i < g->tensors.size(), "tensor index out of range"); *out = g->tensors[i].name.c_str(); return VOX_OK;
+}
+extern "C" int32_t vox_gguf_tensor_info(const vox_gguf* g, const char* name, uint64_t dims[4], uint32_t* ndims, uint32_t* dtype, uint64_t* nbytes) {
+    ARGCHK(g && name && dims && ndims && dtype && nbytes, "null argument");
+    const GTensor* t = g->find(name);
+    if (!t) return fail(VOX_ERR_NOTFOUND, "Tensor '%s' not found in GGUF", name);
+    for (uint32_t d = 0; d < 4; d++) dims[d] = d < t->ndims ? t->dims[d] : 0;
+    *ndims = t->ndims; *dtype = t->dtype; *nbytes = t->nbytes; return VOX_OK;
+}
+extern "C" int32_t vox_gguf_tensor_data(const vox_gguf* g, const char* name, void* dst, size_t cap) {
+    ARGCHK(g && name && dst, "null argument");
+    const GTensor* t = g->find(name);
+    if (!t) return fail(VOX_ERR_NOTFOUND, "Tensor '%s' not found in GGUF", name);
+    ARGCHK(cap >= t->nbytes, "destination too small for '%s' (%zu < %llu)", name, cap, (unsigned long long)t->nbytes);
+    std::memcpy(dst, g->data(t), t->nbytes); return VOX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Q4 tensor + operator (gguf/tensor.rs, op.rs, linear.rs)
+// ------------------------------------------------------------------------------------------------
+struct vox_q4 { vox_ctx* ctx; Q4W w; void* qs_mem; void* sc_mem; };
+
+// upload raw 18-byte blocks and re-pack into (qs, sc) planes at [dst_row0 ..) of the destination planes
+static int32_t upload_repack(vox_ctx* c, const uint8_t* raw, int64_t n_blocks, int nb, uint4* qs, uint16_t* sc, int row_mul, int row_add,
+                             void* staging, size_t staging_cap) {
+    const size_t bytes = (size_t)n_blocks * 18;
+    DevBuf tmp; uint8_t* d_raw = (uint8_t*)staging;
+    if (!staging || staging_cap < bytes) { HIPCHK(tmp.alloc(bytes)); d_raw = tmp.as<uint8_t>(); }
+    HIPCHK(hipMemcpyAsync(d_raw, raw, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_q4_repack(d_raw, qs, sc, n_blocks, nb, row_mul, row_add, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_q4_tensor_from_bytes(vox_ctx* c, const uint8_t* raw, size_t nbytes, int64_t N, int64_t K, vox_q4** out) {
+    ARGCHK(c && raw && out, "null argument"); ARGCHK(N > 0 && K > 0, "bad shape"); VOXCHK(ctx_bind(c));
+    const int64_t ne = N * K;
+    ARGCHK(ne % 32 == 0, "Q4_0 requires element count divisible by 32, got %lld", (long long)ne);           // tensor.rs:38-41
+    const int64_t nblk = ne / 32;
+    ARGCHK((int64_t)nbytes == nblk * 18, "Q4_0 byte count mismatch: expected %lld for %lld blocks, got %zu", (long long)(nblk * 18), (long long)nblk, nbytes);
+    ARGCHK(K % 32 == 0, "Q4_0 rows must be a whole number of 32-element blocks (K=%lld)", (long long)K);
+    vox_q4* q = new vox_q4(); q->ctx = c; q->qs_mem = q->sc_mem = nullptr;
+    if (hipMalloc(&q->qs_mem, (size_t)nblk * 16) != hipSuccess || hipMalloc(&q->sc_mem, (size_t)nblk * 2) != hipSuccess) {
+        if (q->qs_mem) (void)hipFree(q->qs_mem); delete q; return fail(VOX_ERR_HIP, "hipMalloc failed for Q4 tensor");
+    }
+    q->w = Q4W{(const uint4*)q->qs_mem, (const uint16_t*)q->sc_mem, (int)N, (int)K, (int)(K / 32)};
+    int32_t r = upload_repack(c, raw, nblk, (int)(K / 32), (uint4*)q->qs_mem, (uint16_t*)q->sc_mem, 1, 0, nullptr, 0);
+    if (r != VOX_OK) { (void)hipFree(q->qs_mem); (void)hipFree(q->sc_mem); delete q; return r; }
+    *out = q; return VOX_OK;
+}
+extern "C" int32_t vox_q4_tensor_shape(const vox_q4* q, int64_t* N, int64_t* K) { ARGCHK(q && N && K, "null argument"); *N = q->w.N; *K = q->w.K; return VOX_OK; }
+extern "C" int32_t vox_q4_tensor_num_blocks(const vox_q4* q, int64_t* out) { ARGCHK(q && out, "null argument"); *out = (int64_t)q->w.N * q->w.nb; return VOX_OK; }
+extern "C" int32_t vox_q4_tensor_free(vox_q4* q) {
+    if (!q) return VOX_OK;
+    (void)hipSetDevice(q->ctx->device); (void)hipStreamSynchronize(q->ctx->stream);
+    (void)hipFree(q->qs_mem); (void)hipFree(q->sc_mem); delete q; return VOX_OK;
+}
+extern "C" int32_t vox_q4_tensor_dequantize(vox_ctx* c, const vox_q4* q, float* out) {
+    ARGCHK(c && q && out, "null argument"); VOXCHK(ctx_bind(c));
+    const size_t ne = (size_t)q->w.N * q->w.K;
+    DevBuf d; HIPCHK(d.alloc(ne * 4));
+    HIPCHK(launch_q4_dequant(q->w, d.as<float>(), c->stream));
+    HIPCHK(hipMemcpyAsync(out, d.p, ne * 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+    return VOX_OK;
+}
+
+// out[rows][N] = x[rows][K] * W^T (+bias), device pointers.  rows <= 4 -> fused GEMV, else MFMA GEMM (op.rs:144-150)
+static int32_t q4_linear_dev(vox_ctx* c, const Q4W& w, const float* bias, const float* x, int x_stride, int rows, float* out, int out_stride,
+                             int epi = EPI_STORE, const float* resid = nullptr, int resid_stride = 0) {
+    if (rows <= 4) {
+        GemvParams p{}; p.w = w; p.x = x; p.x_stride = x_stride; p.out = out; p.out_stride = out_stride; p.bias = bias;
+        p.resid = resid; p.resid_stride = resid_stride;
+        HIPCHK(launch_q4_gemv(p, rows, PRO_NONE, epi, q4_gemv_default_R(w.N, w.K, epi), c->stream));
+    } else {
+        GemmParams p{}; p.w = w; p.x = x; p.x_stride = x_stride; p.M = rows; p.out = out; p.out_stride = out_stride; p.bias = bias;
+        p.resid = resid; p.resid_stride = resid_stride;
+        HIPCHK(launch_q4_gemm(p, epi, c->stream));
+    }
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_q4_linear_forward(vox_ctx* c, const vox_q4* w, const float* bias, const float* x, int32_t B, int32_t M, float* out, int32_t mem_kind) {
+    ARGCHK(c && w && x && out, "null argument"); ARGCHK(B > 0 && M > 0, "bad batch/rows"); VOXCHK(ctx_bind(c));
+    const int rows = B * M, K = w->w.K, N = w->w.N;
+    if (mem_kind == VOX_MEM_DEVICE) return q4_linear_dev(c, w->w, bias, x, K, rows, out, N);
+    DevBuf dx, dy, db; HIPCHK(dx.alloc((size_t)rows * K * 4)); HIPCHK(dy.alloc((size_t)rows * N * 4));
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)rows * K * 4, hipMemcpyHostToDevice, c->stream));
+    if (bias) { HIPCHK(db.alloc((size_t)N * 4)); HIPCHK(hipMemcpyAsync(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice, c->stream)); }
+    VOXCHK(q4_linear_dev(c, w->w, bias ? db.as<float>() : nullptr, dx.as<float>(), K, rows, dy.as<float>(), N));
+    HIPCHK(hipMemcpyAsync(out, dy.p, (size_t)rows * N * 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+    return VOX_OK;
+}
+extern "C" int32_t vox_q4_matmul(vox_ctx* c, const vox_q4* w, const float* x, int32_t B, int32_t M, float* out, int32_t mem_kind) {
+    return vox_q4_linear_forward(c, w, nullptr, x, B, M, out, mem_kind);
+}
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct Lin { Q4W w{}; const float* bias = nullptr; };
+struct EncLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2; };
+struct DecLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2, ada0, ada2; float* ada_mul = nullptr; };
+
+struct vox_cache { vox_model* m; float *k = nullptr, *v = nullptr; int max_seq = 0, len = 0; };   // per layer: [n_kv][max_seq][hd]
+
+struct vox_model {
+    vox_ctx* ctx = nullptr; vox_model_cfg cfg{};
+    uint8_t* arena = nullptr; uint64_t arena_bytes = 0;
+    const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_norm = nullptr, *dec_norm = nullptr;
+    const float *enc_cos = nullptr, *enc_sin = nullptr, *dec_cos = nullptr, *dec_sin = nullptr;
+    int enc_rope_len = 4096, dec_rope_len = 16384;                         // gguf/loader.rs:196-198,284-286
+    std::vector<EncLayer> enc; std::vector<DecLayer> dec; Lin ad0, ad2, tok;
+    // derived (not in the arena)
+    float* ada_mul = nullptr; bool t_embed_set = false; std::vector<float> t_embed_host;
+    // workspaces
+    float* ws = nullptr; size_t ws_floats = 0;            // encoder / prefill workspace
+    float *d_audio = nullptr; int audio_cap = 0;          // [S][dec_dim]
+    float *d_mel = nullptr; size_t mel_cap = 0;           // [128][T]
+    float *d_samples = nullptr; size_t samples_cap = 0;
+    // decode state
+    vox_cache* cache = nullptr;                           // internal cache for transcribe_streaming
+    int *d_tokens = nullptr, *d_pos = nullptr; int tokens_cap = 0;
+    float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
+    int n_parts = 0;
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; const vox_cache* graph_cache = nullptr;
+    vox_timings timings{};
+};
+
+// arena layout planner: pass 1 (base == nullptr) only sizes, pass 2 hands out pointers
+struct Arena {
+    uint8_t* base = nullptr; uint64_t off = 0;
+    template <class T> T* take(size_t count) {
+        off = (off + 255) / 256 * 256;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+#define ENC_PFX "mm_streams_embeddings.embedding_module.whisper_encoder"       /* models/weights.rs:221 */
+#define EMB_PFX "mm_streams_embeddings.embedding_module"
+#define TOK_NAME EMB_PFX ".tok_embeddings.weight"                               /* models/weights.rs:225 */
+#define ADP_PFX EMB_PFX ".audio_language_projection"                            /* models/weights.rs:227 */
+
+namespace {
+struct Loader {
+    vox_model* m; const vox_gguf* g; Arena ar; bool fill; void* staging = nullptr; size_t staging_cap = 0;
+    std::string err;
+
+    bool setfail(const std::string& e) { if (err.empty()) err = e; return false; }
+    const GTensor* need(const std::string& name) { const GTensor* t = g->find(name); if (!t) setfail("Tensor '" + name + "' not found"); return t; }
+
+    // gguf/loader.rs:443-474: F32/F16 -> f32 device array
+    const float* f32(const std::string& name, bool required = true) {
+        const GTensor* t = g->find(name);
+        if (!t) { if (required) setfail("Tensor '" + name + "' not found"); return nullptr; }
+        if (t->dtype == 2) { setfail("Cannot load Q4_0 tensor '" + name + "' as f32"); return nullptr; }
+        uint64_t ne = 1; for (uint32_t d = 0; d < t->ndims; d++) ne *= t->dims[d];
+        float* dst = ar.take<float>(ne);
+        if (fill) {
+            std::vector<float> tmp;
+            const void* src = g->data(t);
+            if (t->dtype == 1) {
+                tmp.resize(ne); const uint16_t* h = (const uint16_t*)src;
+                for (uint64_t i = 0; i < ne; i++) {
+                    const uint16_t x = h[i]; const uint32_t sign = (uint32_t)(x & 0x8000u) << 16; uint32_t e = (x >> 10) & 0x1f, man = x & 0x3ffu, bits;
+                    if (e == 0) { if (!man) bits = sign; else { int k = -1; do { man <<= 1; k++; } while (!(man & 0x400u)); bits = sign | ((uint32_t)(112 - k) << 23) | ((man & 0x3ffu) << 13); } }
+                    else if (e == 31) bits = sign | 0x7f800000u | (man << 13); else bits = sign | ((e + 112) << 23) | (man << 13);
+                    std::memcpy(&tmp[i], &bits, 4);
+                }
+                src = tmp.data();
+            }
+            if (hipMemcpy(dst, src, ne * 4, hipMemcpyHostToDevice) != hipSuccess) setfail("hipMemcpy failed for '" + name + "'");
+        }
+        return dst;
+    }
+    // Q4 linear made of `parts` source tensors; rows concatenated (interleave=false) or interleaved pairwise (true)
+    bool q4(const std::vector<std::string>& parts, bool interleave, Lin* L) {
+        int64_t K = -1, Ntot = 0; std::vector<const GTensor*> ts;
+        for (auto& n : parts) {
+            const GTensor* t = need(n); if (!t) return false;
+            if (t->dtype != 2) return setfail("Expected Q4_0 for '" + n + "'");                    // gguf/loader.rs:393-395
+            if (t->ndims != 2) return setfail("Tensor '" + n + "' is not 2-D");
+            const int64_t k = (int64_t)t->dims[0], nn = (int64_t)t->dims[1];                      // reversed dims (:497-499)
+            if (k % 32) return setfail("Q4_0 tensor '" + n + "' has K not divisible by 32");
+            if (K < 0) K = k; else if (K != k) return setfail("fused Q4 tensors disagree on K");
+            if (interleave && !ts.empty() && nn != (int64_t)ts[0]->dims[1]) return setfail("interleaved Q4 tensors disagree on N");
+            Ntot += nn; ts.push_back(t);
+        }
+        const int nb = (int)(K / 32);
+        uint4* qs = ar.take<uint4>((size_t)Ntot * nb); uint16_t* sc = ar.take<uint16_t>((size_t)Ntot * nb);
+        L->w = Q4W{qs, sc, (int)Ntot, (int)K, nb};
+        if (fill) {
+            int64_t row0 = 0;
+            for (size_t i = 0; i < ts.size(); i++) {
+                const int64_t nn = (int64_t)ts[i]->dims[1];
+                const int mul = interleave ? (int)ts.size() : 1, add = interleave ? (int)i : (int)row0;
+                if (upload_repack(m->ctx, g->data(ts[i]), nn * nb, nb, qs, sc, mul, add, staging, staging_cap) != VOX_OK) return setfail(g_err);
+                row0 += nn;
+            }
+        }
+        return true;
+    }
+    // concatenated f32 bias (missing parts -> zeros); returns nullptr if none of the parts exist
+    const float* bias_cat(const std::vector<std::pair<std::string, int64_t>>& parts) {
+        bool any = false; int64_t tot = 0;
+        for (auto& p : parts) { if (!p.first.empty() && g->find(p.first)) any = true; tot += p.second; }
+        if (!any) return nullptr;
+        float* dst = ar.take<float>(tot);
+        if (fill) {
+            std::vector<float> host(tot, 0.0f); int64_t o = 0;
+            for (auto& p : parts) {
+                const GTensor* t = p.first.empty() ? nullptr : g->find(p.first);
+                if (t) {
+                    if (t->dtype == 0) std::memcpy(host.data() + o, g->data(t), (size_t)p.second * 4);
+                    else if (t->dtype == 1) { setfail("f16 bias not supported for fused projections"); }
+                }
+                o += p.second;
+            }
+            if (hipMemcpy(dst, host.data(), (size_t)tot * 4, hipMemcpyHostToDevice) != hipSuccess) setfail("hipMemcpy failed for bias");
+        }
+        return dst;
+    }
+    const float* rope(int hd, int len, float theta, bool sine) {   // models/layers/rope.rs:35-64 (f32 powf / cos / sin)
+        const int half = hd / 2; float* dst = ar.take<float>((size_t)len * half);
+        if (fill) {
+            std::vector<float> t((size_t)len * half);
+            for (int i = 0; i < len; i++)
+                for (int j = 0; j < half; j++) {
+                    const float inv = 1.0f / std::pow(theta, (float)(2 * j) / (float)hd), fr = (float)i * inv;
+                    t[(size_t)i * half + j] = sine ? std::sin(fr) : std::cos(fr);
+                }
+            if (hipMemcpy(dst, t.data(), t.size() * 4, hipMemcpyHostToDevice) != hipSuccess) setfail("hipMemcpy failed for rope table");
+        }
+        return dst;
+    }
+
+    bool run() {
+        vox_model_cfg& c = m->cfg; char a[320];
+        // defaults not derivable from shapes: models/config.rs:441-493
+        c.enc_head_dim = 64; c.dec_head_dim = 128; c.enc_window = 750; c.dec_window = 8192; c.rope_theta = 1e6f; c.norm_eps = 1e-5f; c.reshape_factor = 4;
+        int ne = 0, nd = 0;
+        for (;; ne++) { snprintf(a, sizeof a, ENC_PFX ".transformer.layers.%d.attention.wq.weight", ne); if (!g->find(a)) break; }
+        for (;; nd++) { snprintf(a, sizeof a, "layers.%d.attention.wq.weight", nd); if (!g->find(a)) break; }
+        if (ne == 0 || nd == 0) return setfail("GGUF has no encoder/decoder layers");
+        c.enc_layers = ne; c.dec_layers = nd; m->enc.resize(ne); m->dec.resize(nd);
+        const GTensor* cw = need(ENC_PFX ".conv_layers.0.conv.weight"); if (!cw) return false;
+        if (cw->ndims != 3 || cw->dims[0] != 3) return setfail("conv weight must be [out][in][3]");
+        c.n_mels = (int)cw->dims[1]; c.enc_dim = (int)cw->dims[2];
+        m->conv1_w = f32(ENC_PFX ".conv_layers.0.conv.weight"); m->conv1_b = f32(ENC_PFX ".conv_layers.0.conv.bias");
+        m->conv2_w = f32(ENC_PFX ".conv_layers.1.conv.weight"); m->conv2_b = f32(ENC_PFX ".conv_layers.1.conv.bias");
+        for (int i = 0; i < ne; i++) {                                                      // gguf/loader.rs:215-260
+            EncLayer& L = m->enc[i]; std::string p = std::string(ENC_PFX ".transformer.layers.") + std::to_string(i);
+            L.attn_norm = f32(p + ".attention_norm.weight"); L.ffn_norm = f32(p + ".ffn_norm.weight");
+            if (!q4({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight"}, false, &L.wqkv)) return false;
+            const int64_t hq = L.wqkv.w.N / 3;
+            L.wqkv.bias = bias_cat({{p + ".attention.wq.bias", hq}, {"", hq}, {p + ".attention.wv.bias", hq}});   // wk has no bias (:228)
+            if (!q4({p + ".attention.wo.weight"}, false, &L.wo)) return false;
+            L.wo.bias = bias_cat({{p + ".attention.wo.bias", L.wo.w.N}});
+            if (!q4({p + ".feed_forward.w1.weight", p + ".feed_forward.w3.weight"}, true, &L.w13)) return false;
+            if (!q4({p + ".feed_forward.w2.weight"}, false, &L.w2)) return false;
+            L.w2.bias = bias_cat({{p + ".feed_forward.w2.bias", L.w2.w.N}});
+        }
+        m->enc_norm = f32(ENC_PFX ".transformer.norm.weight");
+        if (!q4({ADP_PFX ".0.weight"}, false, &m->ad0) || !q4({ADP_PFX ".2.weight"}, false, &m->ad2)) return false;    // :378-383
+        if (!q4({TOK_NAME}, false, &m->tok)) return false;   // kept Q4 on device (the reference's WASM branch, gguf/model.rs:689)
+        for (int i = 0; i < nd; i++) {                                                      // gguf/loader.rs:329-375
+            DecLayer& L = m->dec[i]; std::string p = "layers." + std::to_string(i);
+            if (!q4({p + ".ada_rms_norm_t_cond.0.weight"}, false, &L.ada0) || !q4({p + ".ada_rms_norm_t_cond.2.weight"}, false, &L.ada2)) return false;
+            L.attn_norm = f32(p + ".attention_norm.weight"); L.ffn_norm = f32(p + ".ffn_norm.weight");
+            if (!q4({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight"}, false, &L.wqkv)) return false;
+            if (!q4({p + ".attention.wo.weight"}, false, &L.wo)) return false;
+            if (!q4({p + ".feed_forward.w1.weight", p + ".feed_forward.w3.weight"}, true, &L.w13)) return false;
+            if (!q4({p + ".feed_forward.w2.weight"}, false, &L.w2)) return false;
+        }
+        m->dec_norm = f32("norm.weight");
+        if (!err.empty()) return false;
+        // derived dims
+        const GTensor* ewq = g->find(std::string(ENC_PFX ".transformer.layers.0.attention.wq.weight"));
+        const GTensor* dwq = g->find("layers.0.attention.wq.weight"); const GTensor* dwk = g->find("layers.0.attention.wk.weight");
+        c.enc_heads = (int)(ewq->dims[1] / c.enc_head_dim); c.enc_ffn = m->enc[0].w13.w.N / 2;
+        c.dec_dim = (int)dwq->dims[0]; c.dec_heads = (int)(dwq->dims[1] / c.dec_head_dim); c.dec_kv_heads = (int)(dwk->dims[1] / c.dec_head_dim);
+        c.dec_ffn = m->dec[0].w13.w.N / 2; c.vocab = m->tok.w.N; c.t_cond_dim = m->dec[0].ada0.w.N;
+        if (ewq->dims[1] % c.enc_head_dim || dwq->dims[1] % c.dec_head_dim || dwk->dims[1] % c.dec_head_dim || c.dec_kv_heads == 0 || c.dec_heads % c.dec_kv_heads)
+            return setfail("attention projection shapes are not multiples of head_dim");
+        if ((int)ewq->dims[0] != c.enc_dim || m->ad0.w.K != c.enc_dim * c.reshape_factor || m->ad2.w.N != c.dec_dim || m->ad0.w.N != m->ad2.w.K || m->tok.w.K != c.dec_dim)
+            return setfail("inconsistent encoder / adapter / embedding shapes");
+        if (c.enc_dim % 32 || c.dec_dim % 32) return setfail("model dims must be multiples of 32");
+        m->enc_cos = rope(c.enc_head_dim, m->enc_rope_len, c.rope_theta, false); m->enc_sin = rope(c.enc_head_dim, m->enc_rope_len, c.rope_theta, true);
+        m->dec_cos = rope(c.dec_head_dim, m->dec_rope_len, c.rope_theta, false); m->dec_sin = rope(c.dec_head_dim, m->dec_rope_len, c.rope_theta, true);
+        return err.empty();
+    }
+};
+}  // namespace
+
+static void model_release(vox_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
+    if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
+    for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
+                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx})
+        if (p) (void)hipFree(p);
+    delete m;
+}
+extern "C" int32_t vox_model_free(vox_model* m) { model_release(m); return VOX_OK; }
+
+extern "C" int32_t vox_q4_model_load(vox_ctx* ctx, const char* path, vox_model** out) {
+    ARGCHK(ctx && path && out, "null argument"); VOXCHK(ctx_bind(ctx));
+    vox_gguf* g = nullptr; VOXCHK(vox_gguf_open(path, &g));
+    vox_model* m = new vox_model(); m->ctx = ctx;
+    Loader plan{m, g, Arena{}, false};
+    if (!plan.run()) { std::string e = plan.err; vox_gguf_close(g); model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
+    m->arena_bytes = plan.ar.off + 256;
+    if (hipMalloc((void**)&m->arena, m->arena_bytes) != hipSuccess) { vox_gguf_close(g); model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of %.1f MB weight arena failed", m->arena_bytes / 1e6); }
+    size_t max_q4 = 0; for (auto& t : g->tensors) if (t.dtype == 2) max_q4 = std::max<size_t>(max_q4, t.nbytes);
+    DevBuf staging; if (staging.alloc(max_q4) != hipSuccess) { vox_gguf_close(g); model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of staging buffer failed"); }
+    Loader fillr{m, g, Arena{m->arena, 0}, true, staging.p, max_q4};
+    if (!fillr.run()) { std::string e = fillr.err; vox_gguf_close(g); model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
+    vox_gguf_close(g);
+    const vox_model_cfg& c = m->cfg;
+    // decode-step buffers
+    const int qdim = c.dec_heads * c.dec_head_dim;
+    m->n_parts = (c.vocab + 31) / 32;
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n); };
+    A((void**)&m->ada_mul, (size_t)c.dec_layers * c.dec_dim * 4); A((void**)&m->d_pos, 64); A((void**)&m->d_h, (size_t)c.dec_dim * 4 * 4);
+    A((void**)&m->d_q, (size_t)qdim * 4 * 4); A((void**)&m->d_att, (size_t)qdim * 4 * 4); A((void**)&m->d_act, (size_t)c.dec_ffn * 4 * 4);
+    A((void**)&m->d_logits, (size_t)c.vocab * 4); A((void**)&m->d_part_val, (size_t)m->n_parts * 4 * 4); A((void**)&m->d_part_idx, (size_t)m->n_parts * 4 * 4);
+    if (e != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of decode buffers failed: %s", hipGetErrorString(e)); }
+    for (int i = 0; i < c.dec_layers; i++) m->dec[i].ada_mul = m->ada_mul + (size_t)i * c.dec_dim;
+    *out = m; return VOX_OK;
+}
+extern "C" int32_t vox_model_config(const vox_model* m, vox_model_cfg* out) { ARGCHK(m && out, "null argument"); *out = m->cfg; return VOX_OK; }
+extern "C" int32_t vox_model_weight_bytes(const vox_model* m, uint64_t* out) { ARGCHK(m && out, "null argument"); *out = m->arena_bytes; return VOX_OK; }
+extern "C" int32_t vox_model_arena(const vox_model* m, void** p, uint64_t* n) { ARGCHK(m && p && n, "null argument"); *p = m->arena; *n = m->arena_bytes; return VOX_OK; }
+
+// Ada scales: 1 + w2(gelu(w0 t_embed)) (gguf/model.rs:250-255) -- loop-invariant for a fixed delay, computed once.
+extern "C" int32_t vox_model_set_t_embed(vox_model* m, const float* t_embed) {
+    ARGCHK(m && t_embed, "null argument"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx;
+    if (m->t_embed_set && m->t_embed_host.size() == (size_t)c.dec_dim && !std::memcmp(m->t_embed_host.data(), t_embed, (size_t)c.dec_dim * 4)) return VOX_OK;
+    DevBuf dt, dh, ones; HIPCHK(dt.alloc((size_t)c.dec_dim * 4)); HIPCHK(dh.alloc((size_t)c.t_cond_dim * 4)); HIPCHK(ones.alloc((size_t)c.dec_dim * 4));
+    std::vector<float> one(c.dec_dim, 1.0f);
+    HIPCHK(hipMemcpyAsync(dt.p, t_embed, (size_t)c.dec_dim * 4, hipMemcpyHostToDevice, cx->stream));
+    HIPCHK(hipMemcpyAsync(ones.p, one.data(), (size_t)c.dec_dim * 4, hipMemcpyHostToDevice, cx->stream));
+    for (int i = 0; i < c.dec_layers; i++) {
+        VOXCHK(q4_linear_dev(cx, m->dec[i].ada0.w, nullptr, dt.as<float>(), c.dec_dim, 1, dh.as<float>(), c.t_cond_dim, EPI_GELU));
+        VOXCHK(q4_linear_dev(cx, m->dec[i].ada2.w, nullptr, dh.as<float>(), c.t_cond_dim, 1, m->dec[i].ada_mul, c.dec_dim, EPI_RESID, ones.as<float>(), c.dec_dim));
+    }
+    HIPCHK(hipStreamSynchronize(cx->stream));
+    m->t_embed_host.assign(t_embed, t_embed + c.dec_dim); m->t_embed_set = true;
+    return VOX_OK;
+}
+
+static int conv_len(int L) { return (L + 2 - 3) / 2 + 1; }   // models/layers/conv.rs:47-48
+
+static int32_t ensure(float** p, size_t* cap, size_t need) {
+    if (*cap >= need) return VOX_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    HIPCHK(hipMalloc((void**)p, need * sizeof(float))); *cap = need; return VOX_OK;
+}
+
+// ---- encoder + adapter (gguf/model.rs:425-434, 783-788) on device. mel [n_mels][T] device -> m->d_audio [S4][dec_dim]
+static int32_t encode_dev(vox_model* m, const float* d_mel, int T, int* S4_out) {
+    const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
+    const int T1 = conv_len(T), S = conv_len(T1), D = c.enc_dim, H = c.enc_heads, hd = c.enc_head_dim, QD = H * hd, F = c.enc_ffn;
+    const int S4 = S / c.reshape_factor;
+    *S4_out = S4;
+    if (S <= 0 || S4 <= 0) return VOX_OK;
+    ARGCHK(S <= m->enc_rope_len, "audio too long for the encoder RoPE table (%d > %d positions); chunk it (--max-mel-frames)", S, m->enc_rope_len);
+    const size_t need = (size_t)D * T1 + (size_t)S * D * 2 + (size_t)S * QD * 4 + (size_t)S * F + (size_t)S4 * m->ad0.w.N + 1024;
+    VOXCHK(ensure(&m->ws, &m->ws_floats, need));
+    float* c1 = m->ws; float* x = c1 + (size_t)D * T1; float* xn = x + (size_t)S * D; float* qkv = xn + (size_t)S * D;
+    float* att = qkv + (size_t)S * QD * 3; float* ffn = att + (size_t)S * QD; float* ah = ffn + (size_t)S * F;
+    { size_t cap = (size_t)m->audio_cap * c.dec_dim; VOXCHK(ensure(&m->d_audio, &cap, (size_t)S4 * c.dec_dim)); m->audio_cap = (int)(cap / c.dec_dim); }
+    HIPCHK(launch_conv1d_gelu(d_mel, c.n_mels, T, m->conv1_w, m->conv1_b, D, c1, 0, s));
+    HIPCHK(launch_conv1d_gelu(c1, D, T1, m->conv2_w, m->conv2_b, D, x, 1, s));      // token-major [S][D] (swap_dims, model.rs:427)
+    for (int l = 0; l < c.enc_layers; l++) {
+        const EncLayer& L = m->enc[l];
+        HIPCHK(launch_rms_norm(x, D, S, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
+        VOXCHK(q4_linear_dev(cx, L.wqkv.w, L.wqkv.bias, xn, D, S, qkv, 3 * QD));
+        HIPCHK(launch_rope(qkv, S, 3 * QD, 2 * QD, hd, 0, m->enc_cos, m->enc_sin, s));
+        AttnParams ap{}; ap.q = qkv; ap.q_stride = 3 * QD; ap.k = qkv + QD; ap.v = qkv + 2 * QD; ap.kv_row_stride = 3 * QD; ap.kv_head_stride = hd;
+        ap.out = att; ap.out_stride = QD; ap.M = S; ap.kv_len = S; ap.n_heads = H; ap.n_kv_heads = H; ap.offset = 0; ap.window = c.enc_window;
+        HIPCHK(launch_attn_prefill(ap, hd, s));
+        VOXCHK(q4_linear_dev(cx, L.wo.w, L.wo.bias, att, QD, S, x, D, EPI_RESID, x, D));
+        HIPCHK(launch_rms_norm(x, D, S, D, L.ffn_norm, nullptr, c.norm_eps, xn, D, s));
+        VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, S, ffn, F, EPI_SWIGLU));
+        VOXCHK(q4_linear_dev(cx, L.w2.w, L.w2.bias, ffn, F, S, x, D, EPI_RESID, x, D));
+    }
+    HIPCHK(launch_rms_norm(x, D, S, D, m->enc_norm, nullptr, c.norm_eps, xn, D, s));
+    // reshape_encoder_output (models/adapter.rs:108-122): rows [0, 4*S4) viewed as [S4][4D]; adapter (model.rs:745-749)
+    VOXCHK(q4_linear_dev(cx, m->ad0.w, nullptr, xn, D * c.reshape_factor, S4, ah, m->ad0.w.N, EPI_GELU));
+    VOXCHK(q4_linear_dev(cx, m->ad2.w, nullptr, ah, m->ad0.w.N, S4, m->d_audio, c.dec_dim));
+    return VOX_OK;
+}
+
+// ---- KV cache (models/layers/kv_cache.rs:52-65,221-234)
+static int32_t cache_alloc(vox_model* m, int max_seq, vox_cache** out) {
+    const vox_model_cfg& c = m->cfg;
+    ARGCHK(max_seq > 0 && max_seq <= m->dec_rope_len, "max_seq %d out of range (1..%d)", max_seq, m->dec_rope_len);
+    vox_cache* k = new vox_cache(); k->m = m; k->max_seq = max_seq;
+    const size_t n = (size_t)c.dec_layers * c.dec_kv_heads * max_seq * c.dec_head_dim * 4;
+    if (hipMalloc((void**)&k->k, n) != hipSuccess || hipMalloc((void**)&k->v, n) != hipSuccess) { if (k->k) (void)hipFree(k->k); delete k; return fail(VOX_ERR_HIP, "hipMalloc of KV cache failed"); }
+    HIPCHK(hipMemsetAsync(k->k, 0, n, m->ctx->stream)); HIPCHK(hipMemsetAsync(k->v, 0, n, m->ctx->stream));
+    *out = k; return VOX_OK;
+}
+extern "C" int32_t vox_decoder_cache_create(vox_model* m, int32_t max_seq, vox_cache** out) { ARGCHK(m && out, "null argument"); VOXCHK(ctx_bind(m->ctx)); return cache_alloc(m, max_seq, out); }
+extern "C" int32_t vox_cache_free(vox_cache* k) {
+    if (!k) return VOX_OK;
+    (void)hipSetDevice(k->m->ctx->device); (void)hipStreamSynchronize(k->m->ctx->stream);
+    if (k->m->graph_cache == k) k->m->graph_cache = nullptr;
+    (void)hipFree(k->k); (void)hipFree(k->v); delete k; return VOX_OK;
+}
+extern "C" int32_t vox_cache_seq_len(const vox_cache* k, int32_t* out) { ARGCHK(k && out, "null argument"); *out = k->len; return VOX_OK; }
+extern "C" int32_t vox_cache_reset(vox_cache* k) { ARGCHK(k, "null cache"); k->len = 0; return VOX_OK; }
+
+static size_t cache_layer_floats(const vox_model* m, const vox_cache* k) { return (size_t)m->cfg.dec_kv_heads * k->max_seq * m->cfg.dec_head_dim; }
+
+// ---- multi-row decoder forward (prefill): x [M][D] device, in place; positions off..off+M-1  (gguf/model.rs:370-387)
+static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc, int off) {
+    const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
+    const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, W = QD + 2 * KD, F = c.dec_ffn;
+    // workspace after the encoder region is reused: [xn | qkv | att | ffn]
+    const size_t need = (size_t)M * D + (size_t)M * W + (size_t)M * QD + (size_t)M * F + 1024;
+    VOXCHK(ensure(&m->ws, &m->ws_floats, need));
+    float* xn = m->ws; float* qkv = xn + (size_t)M * D; float* att = qkv + (size_t)M * W; float* ffn = att + (size_t)M * QD;
+    const size_t lf = cache_layer_floats(m, kc);
+    for (int l = 0; l < c.dec_layers; l++) {
+        const DecLayer& L = m->dec[l]; float* kl = kc->k + (size_t)l * lf; float* vl = kc->v + (size_t)l * lf;
+        HIPCHK(launch_rms_norm(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
+        VOXCHK(q4_linear_dev(cx, L.wqkv.w, nullptr, xn, D, M, qkv, W));
+        HIPCHK(launch_rope(qkv, M, W, QD + KD, hd, off, m->dec_cos, m->dec_sin, s));
+        HIPCHK(launch_kv_store(qkv, M, W, QD, KV, hd, off, kl, vl, kc->max_seq * hd, s));
+        AttnParams ap{}; ap.q = qkv; ap.q_stride = W; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd;
+        ap.out = att; ap.out_stride = QD; ap.M = M; ap.kv_len = off + M; ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = off; ap.window = c.dec_window;
+        HIPCHK(launch_attn_prefill(ap, hd, s));
+        VOXCHK(q4_linear_dev(cx, L.wo.w, nullptr, att, QD, M, x, D, EPI_RESID, x, D));
+        HIPCHK(launch_rms_norm(x, D, M, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));    // norm then Ada x*(1+s) (model.rs:382-385)
+        VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, M, ffn, F, EPI_SWIGLU));
+        VOXCHK(q4_linear_dev(cx, L.w2.w, nullptr, ffn, F, M, x, D, EPI_RESID, x, D));
+    }
+    return VOX_OK;
+}
+
+// ---- one decode step on device (Appendix B of SURVEY.md): 5 fused launches per layer.
+// h [D] in place. position = (pos_ptr ? *pos_ptr : 0) + pos_off.
+static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int* pos_ptr, int pos_off) {
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, F = c.dec_ffn;
+    const size_t lf = cache_layer_floats(m, kc);
+    for (int l = 0; l < c.dec_layers; l++) {
+        const DecLayer& L = m->dec[l]; float* kl = kc->k + (size_t)l * lf; float* vl = kc->v + (size_t)l * lf;
+        GemvParams p{};
+        p.w = L.wqkv.w; p.x = h; p.x_stride = D; p.out = m->d_q; p.out_stride = QD; p.gamma = L.attn_norm; p.eps = c.norm_eps;
+        p.pos_ptr = pos_ptr; p.pos_off = pos_off; p.rope_cos = m->dec_cos; p.rope_sin = m->dec_sin; p.hd = hd; p.n_q = QD; p.n_k = KD;
+        p.kcache = kl; p.vcache = vl; p.cache_head_stride = kc->max_seq * hd;
+        HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV, q4_gemv_default_R(p.w.N, p.w.K, EPI_ROPE_KV), s));
+        AttnParams ap{}; ap.q = m->d_q; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd; ap.out = m->d_att;
+        ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = pos_off; ap.window = c.dec_window; ap.pos_ptr = pos_ptr; ap.M = 1;
+        HIPCHK(launch_attn_decode(ap, hd, kc->max_seq, s));
+        GemvParams o{}; o.w = L.wo.w; o.x = m->d_att; o.x_stride = QD; o.out = h; o.out_stride = D; o.resid = h; o.resid_stride = D;
+        HIPCHK(launch_q4_gemv(o, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(o.w.N, o.w.K, EPI_RESID), s));
+        GemvParams f{}; f.w = L.w13.w; f.x = h; f.x_stride = D; f.out = m->d_act; f.out_stride = F; f.gamma = L.ffn_norm; f.mul = L.ada_mul; f.eps = c.norm_eps;
+        HIPCHK(launch_q4_gemv(f, 1, PRO_RMS, EPI_SWIGLU, q4_gemv_default_R(f.w.N, f.w.K, EPI_SWIGLU), s));
+        GemvParams d{}; d.w = L.w2.w; d.x = m->d_act; d.x_stride = F; d.out = h; d.out_stride = D; d.resid = h; d.resid_stride = D;
+        HIPCHK(launch_q4_gemv(d, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(d.w.N, d.w.K, EPI_RESID), s));
+    }
+    return VOX_OK;
+}
+
+// final RMSNorm + tied lm_head (Q4) + argmax partials (gguf/model.rs:676,680-691,922-923); logits_out optional [vocab]
+static int32_t lm_head_argmax_dev(vox_model* m, const float* h, float* logits_out) {
+    const vox_model_cfg& c = m->cfg;
+    ARGCHK(c.dec_dim <= 4096, "lm_head GEMV is instantiated for dec_dim <= 4096 (got %d)", c.dec_dim);
+    GemvParams p{}; p.w = m->tok.w; p.x = h; p.x_stride = c.dec_dim; p.out = logits_out; p.out_stride = c.vocab; p.gamma = m->dec_norm; p.eps = c.norm_eps;
+    p.part_val = m->d_part_val; p.part_idx = m->d_part_idx;
+    HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ARGMAX, 8, m->ctx->stream));
+    return VOX_OK;
+}
+
+static int32_t ensure_decode_state(vox_model* m, int S) {
+    if (!m->cache || m->cache->max_seq < S) {
+        int cap = std::max(S, 256); cap = std::min((cap + 255) / 256 * 256, m->dec_rope_len);
+        ARGCHK(S <= cap, "sequence of %d decoder positions exceeds the RoPE table (%d)", S, m->dec_rope_len);
+        if (m->cache) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; m->cache = nullptr; }
+        if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+        if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+        VOXCHK(cache_alloc(m, cap, &m->cache));
+    }
+    if (m->tokens_cap < S + 2) {
+        if (m->d_tokens) HIPCHK(hipFree(m->d_tokens));
+        m->tokens_cap = std::max(S + 2, 1024); HIPCHK(hipMalloc((void**)&m->d_tokens, (size_t)m->tokens_cap * 4));
+    }
+    return VOX_OK;
+}
+
+// one full sync-free decode step: embed(token[cur] + audio[cur]) -> 26 layers -> lm_head -> token[cur+1], cur++
+static int32_t decode_step_enqueue(vox_model* m, float* logits_out) {
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    HIPCHK(launch_embed(m->tok.w, m->d_tokens, 1, m->d_audio, c.dec_dim, m->d_pos, 0, 0, m->d_h, s));
+    VOXCHK(decoder_step_dev(m, m->d_h, m->cache, m->d_pos, 0));
+    VOXCHK(lm_head_argmax_dev(m, m->d_h, logits_out));
+    const int nwg = (c.vocab + 31) / 32;
+    HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, nwg, m->d_tokens, m->d_pos, 1, 1, s));
+    return VOX_OK;
+}
+
+// transcribe_streaming on device-resident mel [n_mels][T]  (gguf/model.rs:873-963)
+static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const float* t_embed, int32_t* out_ids, int32_t cap, int32_t* n_ids,
+                              float* logits_host) {
+    const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
+    const int PREFIX_LEN = 38, BOS = 1, STREAMING_PAD = 32;
+    VOXCHK(vox_model_set_t_embed(m, t_embed));
+    double t0 = now_ms();
+    int S = 0; VOXCHK(encode_dev(m, d_mel, T, &S));
+    HIPCHK(hipStreamSynchronize(s));                       // e2e_bench.rs:161-167 forces a sync here too
+    m->timings.encode_ms = now_ms() - t0; t0 = now_ms();
+    *n_ids = 0; m->timings.decode_tokens = 0; m->timings.graph_replays = 0;
+    if (S < PREFIX_LEN) { m->timings.decode_ms = 0; return VOX_OK; }               // model.rs:887-889
+    ARGCHK(cap >= S - PREFIX_LEN, "out_ids capacity %d < %d", cap, S - PREFIX_LEN);
+    VOXCHK(ensure_decode_state(m, S));
+    std::vector<int32_t> prefix(PREFIX_LEN, STREAMING_PAD); prefix[0] = BOS;      // model.rs:891-892
+    HIPCHK(hipMemcpyAsync(m->d_tokens, prefix.data(), PREFIX_LEN * 4, hipMemcpyHostToDevice, s));
+    m->cache->len = 0;
+    // prefix inputs = audio[:38] + embed(prefix)  (model.rs:896-902)
+    const size_t need = (size_t)PREFIX_LEN * c.dec_dim;
+    DevBuf px; HIPCHK(px.alloc(need * 4));
+    HIPCHK(launch_embed(m->tok.w, m->d_tokens, PREFIX_LEN, m->d_audio, c.dec_dim, nullptr, 0, 0, px.as<float>(), s));
+    VOXCHK(decoder_prefill_dev(m, px.as<float>(), PREFIX_LEN, m->cache, 0));
+    m->cache->len = PREFIX_LEN;
+    // lm_head on the last prefix row only (the reference computes all 38 and keeps the last, model.rs:916-923)
+    DevBuf dlog; float* d_logits_all = nullptr;
+    if (logits_host) { HIPCHK(dlog.alloc((size_t)(S - PREFIX_LEN) * c.vocab * 4)); d_logits_all = dlog.as<float>(); }
+    VOXCHK(lm_head_argmax_dev(m, px.as<float>() + (size_t)(PREFIX_LEN - 1) * c.dec_dim, d_logits_all));
+    const int pos_init = PREFIX_LEN;
+    HIPCHK(hipMemcpyAsync(m->d_pos, &pos_init, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, (c.vocab + 31) / 32, m->d_tokens, m->d_pos, 0, 0, s));   // tokens[38]
+    const int steps = S - PREFIX_LEN - 1;                                         // pos = 39 .. S-1 (model.rs:938)
+    if (logits_host) {
+        for (int i = 0; i < steps; i++) VOXCHK(decode_step_enqueue(m, d_logits_all + (size_t)(i + 1) * c.vocab));
+    } else if (steps > 0) {
+        if (!m->graph_exec || m->graph_cache != m->cache) {
+            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+            VOXCHK(decode_step_enqueue(m, nullptr));                               // eager first step (also warms function attributes)
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            int32_t r = decode_step_enqueue(m, nullptr);
+            hipError_t ce = hipStreamEndCapture(s, &m->graph);
+            if (r != VOX_OK) return r;
+            HIPCHK(ce);
+            HIPCHK(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+            m->graph_cache = m->cache;
+            for (int i = 1; i < steps; i++) HIPCHK(hipGraphLaunch(m->graph_exec, s));
+            m->timings.graph_replays = steps - 1;
+        } else {
+            for (int i = 0; i < steps; i++) HIPCHK(hipGraphLaunch(m->graph_exec, s));
+            m->timings.graph_replays = steps;
+        }
+    }
+    const int n = S - PREFIX_LEN;
+    HIPCHK(hipMemcpyAsync(out_ids, m->d_tokens + PREFIX_LEN, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (logits_host) HIPCHK(hipMemcpyAsync(logits_host, d_logits_all, (size_t)n * c.vocab * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    m->cache->len = S - 1;
+    *n_ids = n; m->timings.decode_tokens = n;
+    m->timings.decode_ms = now_ms() - t0;
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_encode_audio(vox_model* m, const float* mel, int32_t T, float* out, int32_t cap_rows, int32_t* S, int32_t mem_kind) {
+    ARGCHK(m && mel && out && S, "null argument"); ARGCHK(T > 0, "empty mel"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    const float* d_mel = mel;
+    if (mem_kind == VOX_MEM_HOST) {
+        VOXCHK(ensure(&m->d_mel, &m->mel_cap, (size_t)c.n_mels * T));
+        HIPCHK(hipMemcpyAsync(m->d_mel, mel, (size_t)c.n_mels * T * 4, hipMemcpyHostToDevice, s)); d_mel = m->d_mel;
+    }
+    int S4 = 0; VOXCHK(encode_dev(m, d_mel, T, &S4));
+    ARGCHK(cap_rows >= S4, "output capacity %d rows < %d", cap_rows, S4);
+    if (S4 > 0) HIPCHK(hipMemcpyAsync(out, m->d_audio, (size_t)S4 * c.dec_dim * 4, mem_kind == VOX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *S = S4; return VOX_OK;
+}
+
+extern "C" int32_t vox_transcribe_streaming(vox_model* m, const float* mel, int32_t T, const float* t_embed, int32_t* out_ids, int32_t cap,
+                                            int32_t* n_ids, float* logits, int32_t mem_kind) {
+    ARGCHK(m && mel && t_embed && out_ids && n_ids, "null argument"); ARGCHK(T > 0, "empty mel"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    const float* d_mel = mel;
+    m->timings = vox_timings{};
+    if (mem_kind == VOX_MEM_HOST) {
+        VOXCHK(ensure(&m->d_mel, &m->mel_cap, (size_t)c.n_mels * T));
+        HIPCHK(hipMemcpyAsync(m->d_mel, mel, (size_t)c.n_mels * T * 4, hipMemcpyHostToDevice, s)); d_mel = m->d_mel;
+    }
+    VOXCHK(transcribe_dev(m, d_mel, T, t_embed, out_ids, cap, n_ids, logits));
+    m->timings.total_ms = m->timings.preprocess_ms + m->timings.encode_ms + m->timings.decode_ms;
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_transcribe_audio(vox_model* m, const float* samples, size_t n, const float* t_embed, int32_t* out_ids, int32_t cap,
+                                        int32_t* n_ids, int32_t mem_kind) {
+    ARGCHK(m && samples && t_embed && out_ids && n_ids, "null argument"); ARGCHK(n > 0, "empty audio"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
+    ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
+    m->timings = vox_timings{};
+    const double t0 = now_ms();
+    const float* d_s = samples;
+    if (mem_kind == VOX_MEM_HOST) {
+        VOXCHK(ensure(&m->d_samples, &m->samples_cap, n));
+        HIPCHK(hipMemcpyAsync(m->d_samples, samples, n * 4, hipMemcpyHostToDevice, s)); d_s = m->d_samples;
+    }
+    vox_pad_cfg pc; vox_pad_cfg_voxtral(&pc);
+    const size_t left = pad_left(&pc), right = pad_right(&pc, n + left), total = left + n + right, T = total / 160;
+    MelTables t; VOXCHK(ctx_mel_tables(cx, &t));
+    VOXCHK(ensure(&m->d_mel, &m->mel_cap, (size_t)128 * T));
+    HIPCHK(launch_absmax(d_s, (long)n, 0.95f, cx->d_scale, s));                                  // peak_normalize(0.95), transcribe.rs:207
+    HIPCHK(launch_mel(d_s, (long)n, (long)left, (long)right, cx->d_scale, t, m->d_mel, (int)T, 1, s));   // pad + log-mel, [128][T]
+    HIPCHK(hipStreamSynchronize(s));
+    m->timings.preprocess_ms = now_ms() - t0;
+    VOXCHK(transcribe_dev(m, m->d_mel, (int)T, t_embed, out_ids, cap, n_ids, nullptr));
+    m->timings.total_ms = m->timings.preprocess_ms + m->timings.encode_ms + m->timings.decode_ms;
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_embed_tokens_from_ids(vox_model* m, const int32_t* ids, int32_t n, float* out) {
+    ARGCHK(m && ids && out && n > 0, "bad argument"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    for (int i = 0; i < n; i++) ARGCHK(ids[i] >= 0 && ids[i] < c.vocab, "token id %d out of range", ids[i]);
+    DevBuf di, dx; HIPCHK(di.alloc((size_t)n * 4)); HIPCHK(dx.alloc((size_t)n * c.dec_dim * 4));
+    HIPCHK(hipMemcpyAsync(di.p, ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(launch_embed(m->tok.w, di.as<int>(), n, nullptr, c.dec_dim, nullptr, 0, 0, dx.as<float>(), s));
+    HIPCHK(hipMemcpyAsync(out, dx.p, (size_t)n * c.dec_dim * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_forward_hidden_with_cache(vox_model* m, const float* x, int32_t M, const float* t_embed, vox_cache* kc, float* out) {
+    ARGCHK(m && x && t_embed && kc && out && M > 0, "bad argument"); ARGCHK(kc->m == m, "cache belongs to another model"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    ARGCHK(kc->len + M <= kc->max_seq, "KV cache overflow: %d + %d > %d", kc->len, M, kc->max_seq);
+    VOXCHK(vox_model_set_t_embed(m, t_embed));
+    DevBuf dx, dy; HIPCHK(dx.alloc((size_t)M * c.dec_dim * 4)); HIPCHK(dy.alloc((size_t)M * c.dec_dim * 4));
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)M * c.dec_dim * 4, hipMemcpyHostToDevice, s));
+    if (M == 1) VOXCHK(decoder_step_dev(m, dx.as<float>(), kc, nullptr, kc->len));
+    else VOXCHK(decoder_prefill_dev(m, dx.as<float>(), M, kc, kc->len));
+    kc->len += M;
+    HIPCHK(launch_rms_norm(dx.as<float>(), c.dec_dim, M, c.dec_dim, m->dec_norm, nullptr, c.norm_eps, dy.as<float>(), c.dec_dim, s));   // model.rs:676
+    HIPCHK(hipMemcpyAsync(out, dy.p, (size_t)M * c.dec_dim * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_lm_head(vox_model* m, const float* hidden, int32_t M, float* logits) {
+    ARGCHK(m && hidden && logits && M > 0, "bad argument"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    DevBuf dx, dy; HIPCHK(dx.alloc((size_t)M * c.dec_dim * 4)); HIPCHK(dy.alloc((size_t)M * c.vocab * 4));
+    HIPCHK(hipMemcpyAsync(dx.p, hidden, (size_t)M * c.dec_dim * 4, hipMemcpyHostToDevice, s));
+    VOXCHK(q4_linear_dev(m->ctx, m->tok.w, nullptr, dx.as<float>(), c.dec_dim, M, dy.as<float>(), c.vocab));
+    HIPCHK(hipMemcpyAsync(logits, dy.p, (size_t)M * c.vocab * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out) { ARGCHK(m && out, "null argument"); *out = m->timings; return VOX_OK; }
+
+// ---- measurement hook: average launch duration of one decode-step GEMV class, HIP events on the ctx stream
+extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t iters, double* avg_us, double* bytes_per_launch, const char** kernel_name) {
+    ARGCHK(m && avg_us && bytes_per_launch && iters > 0 && which >= 0 && which <= 4, "bad argument"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    VOXCHK(ensure_decode_state(m, 64));
+    const int zero = 0; HIPCHK(hipMemcpyAsync(m->d_pos, &zero, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(m->d_h, 0, (size_t)c.dec_dim * 4, s)); HIPCHK(hipMemsetAsync(m->d_att, 0, (size_t)c.dec_heads * c.dec_head_dim * 4, s));
+    HIPCHK(hipMemsetAsync(m->d_act, 0, (size_t)c.dec_ffn * 4, s));
+    if (!m->t_embed_set) { std::vector<float> te(c.dec_dim); vox_time_embedding(6.0f, c.dec_dim, te.data()); VOXCHK(vox_model_set_t_embed(m, te.data())); }
+    const int D = c.dec_dim, QD = c.dec_heads * c.dec_head_dim, KD = c.dec_kv_heads * c.dec_head_dim, F = c.dec_ffn, hd = c.dec_head_dim;
+    const size_t lf = cache_layer_floats(m, m->cache);
+    auto launch = [&](int l) -> int32_t {
+        const DecLayer& L = m->dec[l % c.dec_layers]; GemvParams p{};
+        switch (which) {
+        case 0: p.w = L.wqkv.w; p.x = m->d_h; p.x_stride = D; p.out = m->d_q; p.out_stride = QD; p.gamma = L.attn_norm; p.eps = c.norm_eps; p.pos_ptr = m->d_pos;
+                p.rope_cos = m->dec_cos; p.rope_sin = m->dec_sin; p.hd = hd; p.n_q = QD; p.n_k = KD; p.kcache = m->cache->k + (size_t)(l % c.dec_layers) * lf;
+                p.vcache = m->cache->v + (size_t)(l % c.dec_layers) * lf; p.cache_head_stride = m->cache->max_seq * hd;
+                HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV, q4_gemv_default_R(p.w.N, p.w.K, EPI_ROPE_KV), s)); break;
+        case 1: p.w = L.wo.w; p.x = m->d_att; p.x_stride = QD; p.out = m->d_h; p.out_stride = D; p.resid = m->d_h; p.resid_stride = D;
+                HIPCHK(launch_q4_gemv(p, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(p.w.N, p.w.K, EPI_RESID), s)); break;
+        case 2: p.w = L.w13.w; p.x = m->d_h; p.x_stride = D; p.out = m->d_act; p.out_stride = F; p.gamma = L.ffn_norm; p.mul = L.ada_mul; p.eps = c.norm_eps;
+                HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_SWIGLU, q4_gemv_default_R(p.w.N, p.w.K, EPI_SWIGLU), s)); break;
+        case 3: p.w = L.w2.w; p.x = m->d_act; p.x_stride = F; p.out = m->d_h; p.out_stride = D; p.resid = m->d_h; p.resid_stride = D;
+                HIPCHK(launch_q4_gemv(p, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(p.w.N, p.w.K, EPI_RESID), s)); break;
+        default: VOXCHK(lm_head_argmax_dev(m, m->d_h, nullptr)); break;
+        }
+        return VOX_OK;
+    };
+    const Q4W* w = which == 0 ? &m->dec[0].wqkv.w : which == 1 ? &m->dec[0].wo.w : which == 2 ? &m->dec[0].w13.w : which == 3 ? &m->dec[0].w2.w : &m->tok.w;
+    *bytes_per_launch = (double)w->N * w->nb * 18.0;     // algorithmic bytes: the Q4_0 blocks of the weight (18 B / 32 elements)
+    if (kernel_name) {
+        const int epi = which == 0 ? EPI_ROPE_KV : which == 2 ? EPI_SWIGLU : which == 4 ? EPI_ARGMAX : EPI_RESID;
+        const int pro = (which == 0 || which == 2 || which == 4) ? PRO_RMS : PRO_NONE;
+        *kernel_name = q4_gemv_kernel_name(w->K, pro, epi, which == 4 ? 8 : q4_gemv_default_R(w->N, w->K, epi));
+    }
+    for (int i = 0; i < std::min(iters, 8); i++) VOXCHK(launch(i));   // warm-up
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; i++) VOXCHK(launch(i));
+    HIPCHK(hipEventRecord(e1, s)); HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = (double)ms * 1000.0 / iters;
+    return VOX_OK;
+}

@@ -1,0 +1,94 @@
+// vox_kernels.h -- host-side launch interface of the gfx950 kernels (vox_kernels.hip).
+// Everything here is internal to libvoxtral_hip.so; the public boundary is include/voxtral_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vox {
+
+// Q4_0 weight [N][K] re-packed at load (bit-lossless) from the 18-byte AoS GGUF blocks
+// (gguf/tensor.rs:98-109) into two 16-byte-aligned planes so a wavefront streams coalesced
+// global_load_dwordx4:  qs[n][b] = the block's 16 nibble bytes (element i <-> low nibble of
+// byte i, element i+16 <-> high nibble), sc[n][b] = the block's f16 scale.
+struct Q4W {
+    const uint4* qs;
+    const uint16_t* sc;  // IEEE f16 bits
+    int N, K, nb;        // nb = K / 32
+};
+
+enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5 };
+enum Pro { PRO_NONE = 0, PRO_RMS = 1 };
+
+// ---- fused Q4 GEMV (decode, rows of x <= 4): out[y][n] = epi( sum_k pro(x[y])[k] * W[n][k] )
+struct GemvParams {
+    Q4W w;
+    const float* x; int x_stride;        // gridDim.y input rows
+    float* out; int out_stride;          // may be null for EPI_ARGMAX / EPI_ROPE_KV (q goes to out)
+    const float* bias;                   // [N] or null
+    const float* resid; int resid_stride;// EPI_RESID: out = resid + acc (+ bias)
+    const float* gamma; const float* mul; float eps;   // PRO_RMS: x <- (x / rms(x)) * gamma (* mul)
+    const int* pos_ptr; int pos_off;     // position = (pos_ptr ? *pos_ptr : 0) + pos_off
+    const float* rope_cos; const float* rope_sin; int hd;   // tables [max_pos][hd/2]
+    int n_q, n_k;                        // EPI_ROPE_KV: rows [0,n_q) q, [n_q,n_q+n_k) k, then v
+    float* kcache; float* vcache; int cache_head_stride;    // [kv_head][max_seq][hd]
+    float* part_val; int* part_idx;      // EPI_ARGMAX: per-workgroup (max, argmax)
+};
+// rows_per_wave R in {1,2,4,8}; K tiles of 2048 chosen from K. Returns hipError_t.
+hipError_t launch_q4_gemv(const GemvParams& p, int n_rows_x, int pro, int epi, int R, hipStream_t s);
+const char* q4_gemv_kernel_name(int K, int pro, int epi, int R);
+int q4_gemv_default_R(int N, int K, int epi);
+
+// ---- Q4 GEMM on MFMA (prefill / encoder, rows of x > 4): out[M][N'] = epi( x[M][K] * W^T )
+struct GemmParams {
+    Q4W w;
+    const float* x; int x_stride; int M;
+    float* out; int out_stride;
+    const float* bias;
+    const float* resid; int resid_stride;
+};
+hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);
+
+// ---- small fused ops
+hipError_t launch_q4_repack(const uint8_t* raw, uint4* qs, uint16_t* sc, int64_t n_blocks, int nb, int row_mul, int row_add, hipStream_t s);
+hipError_t launch_q4_dequant(Q4W w, float* out, hipStream_t s);                 // diagnostics (tensor.rs:88-113)
+hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul,
+                           float eps, float* out, int out_stride, hipStream_t s);
+// interleaved-pair RoPE in place on columns [0, n_rot) of buf[M][stride]; row m has position pos_off + m
+hipError_t launch_rope(float* buf, int M, int stride, int n_rot, int hd, int pos_off, const float* cos_t,
+                       const float* sin_t, hipStream_t s);
+// copy k (columns [k_col, k_col+n_kv*hd)) and v (next n_kv*hd columns) of buf rows into the cache at pos_off+m
+hipError_t launch_kv_store(const float* buf, int M, int stride, int k_col, int n_kv, int hd, int pos_off,
+                           float* kcache, float* vcache, int cache_head_stride, hipStream_t s);
+
+struct AttnParams {
+    const float* q; int q_stride;            // q[m][h*hd + d]
+    const float* k; const float* v;          // k[kvh*kv_head_stride + j*kv_row_stride + d]
+    int kv_row_stride, kv_head_stride;
+    float* out; int out_stride;              // out[m][h*hd + d]
+    int M, kv_len, n_heads, n_kv_heads, offset, window;   // query m at position offset+m; window<0: none
+    const int* pos_ptr;                      // decode: position = *pos_ptr + offset, kv_len = position+1
+};
+hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s);     // M > 1, causal (+window)
+hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s);  // M == 1
+
+// gelu(conv1d k3 s2 p1): in [Cin][L] -> out; out_token_major: out[t][co] else out[co][t]
+hipError_t launch_conv1d_gelu(const float* in, int Cin, int L, const float* w, const float* b, int Cout, float* out,
+                              int out_token_major, hipStream_t s);
+
+// log-mel: frames of the (virtually) padded signal zeros(left)+scale*audio+zeros(right); out layout
+// [T][128] (transposed=0) or [128][T] (transposed=1). scale_ptr may be null (scale 1).
+struct MelTables { const float* window; const float* cos_t; const float* sin_t; const float* fb; const int* fb_lo; const int* fb_hi; };
+hipError_t launch_mel(const float* audio, long n, long left, long right, const float* scale_ptr, MelTables t,
+                      float* out, int T, int transposed, hipStream_t s);
+hipError_t launch_absmax(const float* x, long n, float target_peak, float* scale_out, hipStream_t s);
+
+// h[i][:] = (audio ? audio[(a_base+i)][:] : 0) + dequant(tok[ids[id_base+i]]) ; bases add *pos_ptr if given
+hipError_t launch_embed(Q4W tok, const int* ids, int n, const float* audio, int D, const int* pos_ptr, int id_off,
+                        int a_off, float* out, hipStream_t s);
+// final argmax over per-workgroup partials (lowest index wins ties); writes tokens[*pos_ptr+tok_off], then *pos_ptr += inc
+hipError_t launch_argmax_final(const float* part_val, const int* part_idx, int n_parts, int* tokens, int* pos_ptr,
+                               int tok_off, int inc, hipStream_t s);
+hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
+hipError_t launch_gelu(float* x, long n, hipStream_t s);
+
+}  // namespace vox

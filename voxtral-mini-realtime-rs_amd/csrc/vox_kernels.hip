@@ -1,0 +1,969 @@
+// vox_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the Voxtral hot path.
+//
+// Design notes (see DESIGN.md for rooflines):
+//  * q4_gemv_kernel  : the decode-step operator (reference: gguf/shader.wgsl:41-133, M <= 4).
+//      HBM-bound.  One wave owns R consecutive weight rows; lanes split K in 16-byte Q4 chunks
+//      (global_load_dwordx4, non-temporal: every weight byte is read exactly once per token).
+//      All weight loads of the wave are issued before anything else; the activation vector is
+//      staged once per workgroup into LDS (XOR-swizzled so the per-lane ds_read_b128 of
+//      128-byte-strided chunks is bank-conflict free) with the RMSNorm(+Ada) prologue fused,
+//      and the epilogue fuses bias / residual / SwiGLU / RoPE+KV-cache write / argmax partials.
+//  * q4_gemm_kernel  : prefill + encoder operator (reference: gguf/shader_naive.wgsl:31-99, M > 4).
+//      MFMA-bound.  v_mfma_f32_16x16x32_bf16: one MFMA K-step == one Q4_0 block, so the integer
+//      weights (q-8, exact in bf16) go through the matrix core and the f16 block scale is applied
+//      to the 16x16 result in f32; activations are split hi+lo bf16 (2 MFMAs) for f32-class accuracy.
+//  * attention, conv, mel, norm, rope: wave64 shuffle / LDS kernels, f32.
+#include "vox_kernels.h"
+
+#include <hip/hip_fp16.h>
+
+namespace vox {
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_nt_u4(const uint4* p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// byte n of a dword -> f32 (the backend selects v_cvt_f32_ubyte{0..3} for these patterns)
+__device__ __forceinline__ float ub0(uint32_t w) { return (float)(w & 0xFFu); }
+__device__ __forceinline__ float ub1(uint32_t w) { return (float)((w >> 8) & 0xFFu); }
+__device__ __forceinline__ float ub2(uint32_t w) { return (float)((w >> 16) & 0xFFu); }
+__device__ __forceinline__ float ub3(uint32_t w) { return (float)(w >> 24); }
+
+// sum_k x[k] * nibble_k for one 16-byte Q4_0 chunk (32 elements). Element i <-> low nibble of byte i,
+// element 16+i <-> high nibble of byte i (gguf/tensor.rs:98-109). Offset -8 is applied by the caller
+// through the chunk sum: sum x*(q-8) = sum x*q - 8*sum x.
+__device__ __forceinline__ float q4_chunk_dot(const uint4 q, const float* __restrict__ x) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t lo = w[i] & 0x0F0F0F0Fu, hi = (w[i] >> 4) & 0x0F0F0F0Fu;
+        s0 = fmaf(x[4 * i + 0], ub0(lo), s0);
+        s1 = fmaf(x[4 * i + 1], ub1(lo), s1);
+        s0 = fmaf(x[4 * i + 2], ub2(lo), s0);
+        s1 = fmaf(x[4 * i + 3], ub3(lo), s1);
+        s0 = fmaf(x[16 + 4 * i + 0], ub0(hi), s0);
+        s1 = fmaf(x[16 + 4 * i + 1], ub1(hi), s1);
+        s0 = fmaf(x[16 + 4 * i + 2], ub2(hi), s0);
+        s1 = fmaf(x[16 + 4 * i + 3], ub3(hi), s1);
+    }
+    return s0 + s1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Q4 re-pack / dequant (load time + diagnostics)
+// ------------------------------------------------------------------------------------------------
+// source block b = (row, c) of an [rows][nb] tensor lands at destination row (row*row_mul + row_add): row_mul/row_add
+// implement the load-time fusions (wq|wk|wv concatenation, w1/w3 row interleave) without a second pass.
+__global__ void q4_repack_kernel(const uint8_t* __restrict__ raw, uint4* __restrict__ qs, uint16_t* __restrict__ sc,
+                                 int64_t n_blocks, int nb, int row_mul, int row_add) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint8_t* p = raw + b * 18;
+    const int64_t row = b / nb, c = b % nb, dst = (row * row_mul + row_add) * nb + c;
+    sc[dst] = (uint16_t)(p[0] | (p[1] << 8));
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        w[i] = (uint32_t)p[2 + 4 * i] | ((uint32_t)p[3 + 4 * i] << 8) | ((uint32_t)p[4 + 4 * i] << 16) | ((uint32_t)p[5 + 4 * i] << 24);
+    qs[dst] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+hipError_t launch_q4_repack(const uint8_t* raw, uint4* qs, uint16_t* sc, int64_t n_blocks, int nb, int row_mul, int row_add, hipStream_t s) {
+    if (n_blocks <= 0) return hipSuccess;
+    q4_repack_kernel<<<dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, s>>>(raw, qs, sc, n_blocks, nb, row_mul, row_add);
+    return hipGetLastError();
+}
+
+__global__ void q4_dequant_kernel(Q4W w, float* __restrict__ out) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (int64_t)w.N * w.nb) return;
+    const uint4 q = w.qs[b];
+    const float d = f16_bits_to_f32(w.sc[b]);
+    const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
+    float* o = out + b * 32;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t by = (ww[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        o[i] = ((float)(by & 0xF) - 8.0f) * d;
+        o[i + 16] = ((float)(by >> 4) - 8.0f) * d;
+    }
+}
+hipError_t launch_q4_dequant(Q4W w, float* out, hipStream_t s) {
+    int64_t nbk = (int64_t)w.N * w.nb;
+    q4_dequant_kernel<<<dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, s>>>(w, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused Q4 GEMV
+// ------------------------------------------------------------------------------------------------
+// LDS image of x: chunk c (32 floats) holds its eight 16-byte pieces at piece index j ^ ((c>>1)&7):
+// lanes of one ds_read_b128 service group then hit 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int xs_piece(int c, int j) { return c * 8 + (j ^ ((c >> 1) & 7)); }
+
+template <int KT, int R, int PRO, int EPI>
+__global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = p.w.K, nb = p.w.nb, N = p.w.N;
+    float4* xs = reinterpret_cast<float4*>(smem);  // K floats, swizzled
+    float* sxs = smem + K;                         // nb chunk sums
+    float* red = sxs + nb;                         // 16 floats scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * R;
+    const int y = blockIdx.y;
+    const float* __restrict__ xg = p.x + (size_t)y * p.x_stride;
+    const int npieces = K >> 2;
+
+    // (1) activation pieces first (they return first: VMEM returns in order) ...
+    float4 xp[2 * KT];
+#pragma unroll
+    for (int i = 0; i < 2 * KT; i++) {
+        const int pc = tid + 256 * i;
+        xp[i] = pc < npieces ? reinterpret_cast<const float4*>(xg)[pc] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // (2) ... then every weight byte this wave will ever need goes in flight at once.
+    uint4 q[R][KT];
+    uint16_t dh[R][KT];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int t = 0; t < KT; t++) {
+            const int c = lane + 64 * t;
+            const bool ok = (c < nb) && (row0 + r < N);
+            const size_t idx = (size_t)(row0 + r) * nb + c;
+            q[r][t] = ok ? ld_nt_u4(p.w.qs + idx) : make_uint4(0, 0, 0, 0);
+            dh[r][t] = ok ? __builtin_nontemporal_load(p.w.sc + idx) : (uint16_t)0;
+        }
+
+    // (3) prologue on the activation vector (RMSNorm (+Ada multiplier) fused), staged to LDS.
+    float rms = 1.0f;
+    if (PRO == PRO_RMS) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * KT; i++) ss += xp[i].x * xp[i].x + xp[i].y * xp[i].y + xp[i].z * xp[i].z + xp[i].w * xp[i].w;
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        ss = red[0] + red[1] + red[2] + red[3];
+        rms = sqrtf(ss / (float)K + p.eps);   // burn RmsNorm: sqrt(mean(x^2) + eps)
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * KT; i++) {
+        const int pc = tid + 256 * i;
+        if (pc < npieces) {
+            float4 v = xp[i];
+            if (PRO == PRO_RMS) {
+                const float4 g = reinterpret_cast<const float4*>(p.gamma)[pc];
+                v.x = (v.x / rms) * g.x; v.y = (v.y / rms) * g.y; v.z = (v.z / rms) * g.z; v.w = (v.w / rms) * g.w;
+                if (p.mul) {
+                    const float4 m = reinterpret_cast<const float4*>(p.mul)[pc];
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
+            const int c = pc >> 3, j = pc & 7;
+            float s4 = (v.x + v.y) + (v.z + v.w);
+            s4 += __shfl_xor(s4, 1, 64); s4 += __shfl_xor(s4, 2, 64); s4 += __shfl_xor(s4, 4, 64);
+            if (j == 0) sxs[c] = s4;
+            xs[xs_piece(c, j)] = v;
+        }
+    }
+    __syncthreads();
+
+    // (4) consume: per K tile read this lane's 32 activations once, reuse for the R rows.
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT; t++) {
+        const int c = lane + 64 * t;
+        if (c < nb) {
+            float xv[32];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float4 v = xs[xs_piece(c, j)];
+                xv[4 * j + 0] = v.x; xv[4 * j + 1] = v.y; xv[4 * j + 2] = v.z; xv[4 * j + 3] = v.w;
+            }
+            const float sx8 = 8.0f * sxs[c];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float d = f16_bits_to_f32(dh[r][t]);
+                acc[r] = fmaf(d, q4_chunk_dot(q[r][t], xv) - sx8, acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+
+    // (5) epilogue
+    if (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int n = row0 + r;
+            if (lane == r && n < N) {
+                float v = acc[r];
+                if (p.bias) v += p.bias[n];
+                if (EPI == EPI_RESID) v = v + p.resid[(size_t)y * p.resid_stride + n];
+                if (EPI == EPI_GELU) v = gelu_f(v);
+                p.out[(size_t)y * p.out_stride + n] = v;
+            }
+        }
+    } else if (EPI == EPI_SWIGLU) {
+        // rows interleaved at load: 2i = w1 row i (gate), 2i+1 = w3 row i (up)  (gguf/model.rs:220-224)
+#pragma unroll
+        for (int r = 0; r + 1 < R; r += 2) {
+            const int n = row0 + r;
+            if (lane == (r >> 1) && n + 1 < N) p.out[(size_t)y * p.out_stride + (n >> 1)] = silu_f(acc[r]) * acc[r + 1];
+        }
+    } else if (EPI == EPI_ROPE_KV) {
+        // fused rows [wq | wk | wv]; interleaved-pair RoPE on q,k (rope.rs:99-141), k/v written into the
+        // pre-allocated cache slot (kv_cache.rs:116-136), q to p.out.
+        const int pos = (p.pos_ptr ? *p.pos_ptr : 0) + p.pos_off;
+        const int hd = p.hd, half = hd >> 1;
+#pragma unroll
+        for (int r = 0; r + 1 < R; r += 2) {
+            const int n = row0 + r;
+            if (lane == (r >> 1) && n + 1 < N) {
+                const float a = acc[r], b = acc[r + 1];
+                if (n < p.n_q + p.n_k) {
+                    const int dd = n % hd;
+                    const float c = p.rope_cos[(size_t)pos * half + (dd >> 1)], sn = p.rope_sin[(size_t)pos * half + (dd >> 1)];
+                    const float ra = a * c - b * sn, rb = a * sn + b * c;
+                    if (n < p.n_q) { p.out[n] = ra; p.out[n + 1] = rb; }
+                    else {
+                        const int kn = n - p.n_q, kh = kn / hd;
+                        float* dst = p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd;
+                        dst[0] = ra; dst[1] = rb;
+                    }
+                } else {
+                    const int vn = n - p.n_q - p.n_k, vh = vn / hd, dd = vn % hd;
+                    float* dst = p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd;
+                    dst[0] = a; dst[1] = b;
+                }
+            }
+        }
+    } else if (EPI == EPI_ARGMAX) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int n = row0 + r;
+            if (n < N) {
+                if (p.out && lane == r) p.out[(size_t)y * p.out_stride + n] = acc[r];
+                if (acc[r] > best) { best = acc[r]; bi = n; }   // ascending n: first max wins
+            }
+        }
+        if (lane == 0) { red[4 + wave] = best; reinterpret_cast<int*>(red)[8 + wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float bv = red[4]; int bidx = reinterpret_cast<int*>(red)[8];
+            for (int wv = 1; wv < 4; wv++) {
+                const float v = red[4 + wv]; const int ii = reinterpret_cast<int*>(red)[8 + wv];
+                if (v > bv || (v == bv && ii < bidx)) { bv = v; bidx = ii; }
+            }
+            p.part_val[(size_t)y * gridDim.x + blockIdx.x] = bv;
+            p.part_idx[(size_t)y * gridDim.x + blockIdx.x] = bidx;
+        }
+    }
+}
+
+// raise the dynamic-LDS limit once per kernel (not on every launch: launches may be inside a graph capture)
+template <class Kern>
+static hipError_t ensure_dyn_lds(Kern kern, size_t lds, bool* done) {
+    if (lds <= 48 * 1024 || *done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) *done = true;
+    return e;
+}
+
+static inline int kt_for(int K) { return (K + 2047) / 2048; }
+
+int q4_gemv_default_R(int N, int K, int epi) {
+    if (epi == EPI_ARGMAX) return 8;
+    const int kt = kt_for(K);
+    if (epi == EPI_SWIGLU || epi == EPI_ROPE_KV) return kt <= 2 ? 4 : 2;
+    // plain rows: keep >= ~3 workgroups per CU while every wave has >= 4 loads in flight
+    if (kt >= 4) return 1;
+    if ((long)N >= 16384) return 4;
+    return 2;
+}
+
+template <int KT, int R, int PRO, int EPI>
+static hipError_t gemv_launch_t(const GemvParams& p, int ny, hipStream_t s) {
+    const int rows_per_wg = 4 * R;
+    dim3 grid((p.w.N + rows_per_wg - 1) / rows_per_wg, ny);
+    const size_t lds = (size_t)(p.w.K + p.w.nb + 16) * sizeof(float);
+    auto kern = q4_gemv_kernel<KT, R, PRO, EPI>;
+    static bool attr_done = false;
+    hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
+    if (e != hipSuccess) return e;
+    kern<<<grid, dim3(256), lds, s>>>(p);
+    return hipGetLastError();
+}
+
+template <int KT, int R>
+static hipError_t gemv_dispatch_pe(const GemvParams& p, int ny, int pro, int epi, hipStream_t s) {
+#define VOX_CASE(P, E) if (pro == P && epi == E) return gemv_launch_t<KT, R, P, E>(p, ny, s)
+    VOX_CASE(PRO_NONE, EPI_STORE); VOX_CASE(PRO_NONE, EPI_RESID); VOX_CASE(PRO_NONE, EPI_GELU);
+    VOX_CASE(PRO_RMS, EPI_STORE); VOX_CASE(PRO_RMS, EPI_ARGMAX);
+    if (R >= 2) {
+        constexpr int R2 = R >= 2 ? R : 2;
+        if (pro == PRO_RMS && epi == EPI_SWIGLU) return gemv_launch_t<KT, R2, PRO_RMS, EPI_SWIGLU>(p, ny, s);
+        if (pro == PRO_NONE && epi == EPI_SWIGLU) return gemv_launch_t<KT, R2, PRO_NONE, EPI_SWIGLU>(p, ny, s);
+        if (pro == PRO_RMS && epi == EPI_ROPE_KV) return gemv_launch_t<KT, R2, PRO_RMS, EPI_ROPE_KV>(p, ny, s);
+    }
+#undef VOX_CASE
+    return hipErrorInvalidValue;
+}
+
+template <int KT>
+static hipError_t gemv_dispatch_r(const GemvParams& p, int ny, int pro, int epi, int R, hipStream_t s) {
+    switch (R) {
+    case 1: return gemv_dispatch_pe<KT, 1>(p, ny, pro, epi, s);
+    case 2: return gemv_dispatch_pe<KT, 2>(p, ny, pro, epi, s);
+    case 4: return gemv_dispatch_pe<KT, 4>(p, ny, pro, epi, s);
+    case 8: if (KT <= 2) return gemv_dispatch_pe<(KT <= 2 ? KT : 1), 8>(p, ny, pro, epi, s); return gemv_dispatch_pe<KT, 4>(p, ny, pro, epi, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_q4_gemv(const GemvParams& p, int ny, int pro, int epi, int R, hipStream_t s) {
+    if (p.w.K % 32 || p.w.K <= 0 || p.w.N <= 0) return hipErrorInvalidValue;
+    const int kt = kt_for(p.w.K);
+    switch (kt) {
+    case 1: return gemv_dispatch_r<1>(p, ny, pro, epi, R, s);
+    case 2: return gemv_dispatch_r<2>(p, ny, pro, epi, R, s);
+    case 3: return gemv_dispatch_r<3>(p, ny, pro, epi, R > 4 ? 4 : R, s);
+    case 4: return gemv_dispatch_r<4>(p, ny, pro, epi, R > 2 ? 2 : R, s);
+    case 5: return gemv_dispatch_r<5>(p, ny, pro, epi, R > 2 ? 2 : R, s);
+    default: return hipErrorInvalidValue;   // K > 10240 is not a shape of this model family
+    }
+}
+
+const char* q4_gemv_kernel_name(int K, int pro, int epi, int R) {
+    static thread_local char buf[96];
+    snprintf(buf, sizeof buf, "q4_gemv_kernel<KT=%d,R=%d,PRO=%d,EPI=%d>", kt_for(K), R, pro, epi);
+    return buf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Q4 GEMM on MFMA (v_mfma_f32_16x16x32_bf16)
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float x) {   // round-to-nearest-even, finite inputs
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// 8 floats -> packed bf16 hi plane + bf16 lo plane (x ~= hi + lo, |err| <= 2^-17 |x|)
+__device__ __forceinline__ void split_bf16x8(const float* v, uint4& hi, uint4& lo) {
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        h[i] = bf16_rne_bits(v[i]);
+        const float rem = v[i] - __uint_as_float(h[i] << 16);
+        l[i] = bf16_rne_bits(rem);
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+// one dword of a Q4 chunk (bytes 4g..4g+3) -> 8 exact bf16 integers (q-8):
+// slots 0..3 = low nibbles (elements 4g..4g+3), slots 4..7 = high nibbles (elements 16+4g..16+4g+3)
+__device__ __forceinline__ uint4 q4_dword_to_bf16x8(uint32_t w) {
+    const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
+    float f[8];
+    f[0] = ub0(lo) - 8.0f; f[1] = ub1(lo) - 8.0f;
+    f[2] = ub2(lo) - 8.0f; f[3] = ub3(lo) - 8.0f;
+    f[4] = ub0(hi) - 8.0f; f[5] = ub1(hi) - 8.0f;
+    f[6] = ub2(hi) - 8.0f; f[7] = ub3(hi) - 8.0f;
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (__float_as_uint(f[2 * i]) >> 16) | (__float_as_uint(f[2 * i + 1]) & 0xFFFF0000u);
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
+    union { uint4 u; bf16x8 b; } c; c.u = v; return c.b;
+}
+
+// Workgroup tile: 64 rows of x (4 MFMA m-tiles) x 64 weight rows (wave w owns n-tile w).
+// A operand = activations (rows m, k = 8*(lane>>4)..+7), B operand = integer weights (cols n = lane&15),
+// D[m][n]: lane holds n = lane&15, m = 4*(lane>>4) + reg.  The K order inside one MFMA follows the Q4 chunk:
+// lane group g = lane>>4 contributes elements {4g..4g+3, 16+4g..16+4g+3} of the block.
+template <int EPI>
+__global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) uint4 lds[2][2][256];   // [buffer][hi/lo][mt*64 + lane]
+    const int K = p.w.K, nb = p.w.nb, N = p.w.N, M = p.M;
+    (void)K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    // staging role: thread -> (row sm, group sg)
+    const int sm = tid >> 2, sg = tid & 3;
+    const bool srow_ok = (m0 + sm) < M;
+    const float* xrow = p.x + (size_t)(srow_ok ? (m0 + sm) : 0) * p.x_stride;
+    const int slot = ((sm >> 4) * 4 + sg) * 16 + (sm & 15);   // == mt*64 + (g*16 + mi)
+    // MFMA role: weight row for this lane
+    const int wn = n0 + wave * 16 + (lane & 15), wg = lane >> 4;
+    const bool wrow_ok = wn < N;
+    const uint32_t* wq = reinterpret_cast<const uint32_t*>(p.w.qs) + (size_t)(wrow_ok ? wn : 0) * nb * 4 + wg;
+    const uint16_t* ws = p.w.sc + (size_t)(wrow_ok ? wn : 0) * nb;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 xa, xb; uint32_t wd; uint16_t wsc;
+    auto gload = [&](int b) {
+        if (srow_ok) {
+            xa = *reinterpret_cast<const float4*>(xrow + 32 * b + 4 * sg);
+            xb = *reinterpret_cast<const float4*>(xrow + 32 * b + 16 + 4 * sg);
+        } else { xa = make_float4(0, 0, 0, 0); xb = xa; }
+        wd = wrow_ok ? wq[(size_t)b * 4] : 0x88888888u;
+        wsc = wrow_ok ? ws[b] : (uint16_t)0;
+    };
+    auto stage = [&](int buf) {
+        const float v[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        uint4 hi, lo; split_bf16x8(v, hi, lo);
+        lds[buf][0][slot] = hi; lds[buf][1][slot] = lo;
+    };
+    gload(0); stage(0);
+    uint32_t cur_wd = wd; uint16_t cur_sc = wsc;
+    __syncthreads();
+    for (int b = 0; b < nb; b++) {
+        const int buf = b & 1;
+        if (b + 1 < nb) gload(b + 1);
+        const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8(cur_wd));
+        const float d = f16_bits_to_f32(cur_sc);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const bf16x8 ah = as_bf16x8(lds[buf][0][mt * 64 + lane]);
+            const bf16x8 al = as_bf16x8(lds[buf][1][mt * 64 + lane]);
+            f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bw, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw, t, 0, 0, 0);
+            acc[mt][0] = fmaf(d, t[0], acc[mt][0]); acc[mt][1] = fmaf(d, t[1], acc[mt][1]);
+            acc[mt][2] = fmaf(d, t[2], acc[mt][2]); acc[mt][3] = fmaf(d, t[3], acc[mt][3]);
+        }
+        if (b + 1 < nb) { stage(buf ^ 1); cur_wd = wd; cur_sc = wsc; }
+        __syncthreads();
+    }
+    // epilogue: lane holds D[m = m0 + mt*16 + 4*(lane>>4) + r][n = wn]
+    const float bias = (p.bias && wrow_ok) ? p.bias[wn] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = m0 + mt * 16 + 4 * (lane >> 4) + r;
+            float v = acc[mt][r] + bias;
+            if (EPI == EPI_SWIGLU) {
+                const float other = __shfl_xor(v, 1, 64);    // rows interleaved: even n = gate, odd n = up
+                if (m < M && wrow_ok && !(wn & 1)) p.out[(size_t)m * p.out_stride + (wn >> 1)] = silu_f(v) * other;
+            } else if (m < M && wrow_ok) {
+                if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + wn];
+                if (EPI == EPI_GELU) v = gelu_f(v);
+                p.out[(size_t)m * p.out_stride + wn] = v;
+            }
+        }
+}
+
+hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
+    if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
+    dim3 grid((p.w.N + 63) / 64, (p.M + 63) / 64);
+    switch (epi) {
+    case EPI_STORE: q4_gemm_kernel<EPI_STORE><<<grid, dim3(256), 0, s>>>(p); break;
+    case EPI_RESID: q4_gemm_kernel<EPI_RESID><<<grid, dim3(256), 0, s>>>(p); break;
+    case EPI_GELU: q4_gemm_kernel<EPI_GELU><<<grid, dim3(256), 0, s>>>(p); break;
+    case EPI_SWIGLU: q4_gemm_kernel<EPI_SWIGLU><<<grid, dim3(256), 0, s>>>(p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm rows (models/layers/rms_norm.rs:44-46): one wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rms_norm_kernel(const float* __restrict__ x, int x_stride, int rows, int dim,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mul,
+                                                       float eps, float* __restrict__ out, int out_stride) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * x_stride;
+    float ss = 0.f;
+    for (int i = lane; i < dim; i += 64) ss += xr[i] * xr[i];
+    ss = wave_sum(ss);
+    const float rms = sqrtf(ss / (float)dim + eps);
+    float* o = out + (size_t)row * out_stride;
+    for (int i = lane; i < dim; i += 64) {
+        float v = (xr[i] / rms) * gamma[i];
+        if (mul) v *= mul[i];
+        o[i] = v;
+    }
+}
+hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul, float eps,
+                           float* out, int out_stride, hipStream_t s) {
+    rms_norm_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(x, x_stride, rows, dim, gamma, mul, eps, out, out_stride);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE (interleaved pairs) + KV store for the multi-row paths
+// ------------------------------------------------------------------------------------------------
+__global__ void rope_kernel(float* __restrict__ buf, int M, int stride, int n_rot, int hd, int pos_off,
+                            const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
+    const int half_cols = n_rot >> 1;
+    const long total = (long)M * half_cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / half_cols), pc = (int)(i % half_cols);
+        const int col = pc * 2, j = (col % hd) >> 1;
+        const size_t ti = (size_t)(pos_off + m) * (hd >> 1) + j;
+        const float c = cos_t[ti], sn = sin_t[ti];
+        float* p = buf + (size_t)m * stride + col;
+        const float xr = p[0], xi = p[1];
+        p[0] = xr * c - xi * sn; p[1] = xr * sn + xi * c;
+    }
+}
+hipError_t launch_rope(float* buf, int M, int stride, int n_rot, int hd, int pos_off, const float* cos_t, const float* sin_t,
+                       hipStream_t s) {
+    const long total = (long)M * (n_rot / 2);
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    rope_kernel<<<dim3(blocks), dim3(256), 0, s>>>(buf, M, stride, n_rot, hd, pos_off, cos_t, sin_t);
+    return hipGetLastError();
+}
+
+__global__ void kv_store_kernel(const float* __restrict__ buf, int M, int stride, int k_col, int n_kv, int hd, int pos_off,
+                                float* __restrict__ kc, float* __restrict__ vc, int head_stride) {
+    const int w = n_kv * hd;
+    const long total = (long)M * w;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / w), c = (int)(i % w), h = c / hd, d = c % hd;
+        const size_t dst = (size_t)h * head_stride + (size_t)(pos_off + m) * hd + d;
+        kc[dst] = buf[(size_t)m * stride + k_col + c];
+        vc[dst] = buf[(size_t)m * stride + k_col + w + c];
+    }
+}
+hipError_t launch_kv_store(const float* buf, int M, int stride, int k_col, int n_kv, int hd, int pos_off, float* kc, float* vc,
+                           int head_stride, hipStream_t s) {
+    const long total = (long)M * n_kv * hd;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    kv_store_kernel<<<dim3(blocks), dim3(256), 0, s>>>(buf, M, stride, k_col, n_kv, hd, pos_off, kc, vc, head_stride);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// causal (+sliding window) attention for q_len > 1 (gguf/model.rs:100-120, masking.rs:9-107)
+// flash-style online softmax; K/V tiles of 64 keys through LDS; wave = 16 queries x 4 head-dim quarters
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnParams p) {
+    constexpr int DP = HD / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;            // [64][HD]
+    float* Vs = smem + 64 * HD;  // [64][HD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, kvh = h / (p.n_heads / p.n_kv_heads);
+    const int m0 = blockIdx.x * 64;
+    const int qi = lane & 15, part = lane >> 4;
+    const int m = m0 + wave * 16 + qi;
+    const bool q_ok = m < p.M;
+    const int pos = p.offset + (q_ok ? m : (p.M - 1));
+    const float scale = 1.0f / sqrtf((float)HD);      // head_dim^-0.5 (gguf/model.rs:65)
+
+    float qv[DP], o[DP];
+    {
+        const float* qp = p.q + (size_t)(q_ok ? m : 0) * p.q_stride + h * HD + part * DP;
+#pragma unroll
+        for (int e = 0; e < DP; e += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + e);
+            qv[e] = v.x; qv[e + 1] = v.y; qv[e + 2] = v.z; qv[e + 3] = v.w;
+        }
+#pragma unroll
+        for (int e = 0; e < DP; e++) o[e] = 0.f;
+    }
+    float mx = -INFINITY, l = 0.f;
+
+    const int last_m = min(m0 + 63, p.M - 1);
+    int j_lo = 0;
+    if (p.window >= 0) j_lo = max(0, p.offset + m0 - p.window);
+    const int j_hi = min(p.kv_len - 1, p.offset + last_m);   // inclusive
+    const float* kbase = p.k + (size_t)kvh * p.kv_head_stride;
+    const float* vbase = p.v + (size_t)kvh * p.kv_head_stride;
+
+    for (int j0 = (j_lo / 64) * 64; j0 <= j_hi; j0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * (HD / 4); i += 256) {
+            const int jj = i / (HD / 4), d4 = i % (HD / 4), j = j0 + jj;
+            float4 kk = make_float4(0, 0, 0, 0), vv = kk;
+            if (j < p.kv_len) {
+                kk = *reinterpret_cast<const float4*>(kbase + (size_t)j * p.kv_row_stride + d4 * 4);
+                vv = *reinterpret_cast<const float4*>(vbase + (size_t)j * p.kv_row_stride + d4 * 4);
+            }
+            reinterpret_cast<float4*>(Ks)[i] = kk;
+            reinterpret_cast<float4*>(Vs)[i] = vv;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < 64; jj += 4) {
+            float sc[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const float* kr = Ks + (jj + kk) * HD + part * DP;
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < DP; e += 4) {
+                    const float4 kv = *reinterpret_cast<const float4*>(kr + e);
+                    s = fmaf(qv[e], kv.x, s); s = fmaf(qv[e + 1], kv.y, s); s = fmaf(qv[e + 2], kv.z, s); s = fmaf(qv[e + 3], kv.w, s);
+                }
+                s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                const int j = j0 + jj + kk;
+                bool vis = (j < p.kv_len) && (j <= pos);
+                if (p.window >= 0) vis = vis && (pos - j <= p.window);
+                sc[kk] = vis ? s * scale : -INFINITY;
+            }
+            const float mnew = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), mx);
+            if (mnew > -INFINITY) {
+                const float alpha = expf(mx - mnew);     // mx = -inf -> 0
+                float pr[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) pr[kk] = expf(sc[kk] - mnew);
+                l = l * alpha + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+#pragma unroll
+                for (int e = 0; e < DP; e++) o[e] *= alpha;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const float* vr = Vs + (jj + kk) * HD + part * DP;
+#pragma unroll
+                    for (int e = 0; e < DP; e += 4) {
+                        const float4 vv = *reinterpret_cast<const float4*>(vr + e);
+                        o[e] = fmaf(pr[kk], vv.x, o[e]); o[e + 1] = fmaf(pr[kk], vv.y, o[e + 1]);
+                        o[e + 2] = fmaf(pr[kk], vv.z, o[e + 2]); o[e + 3] = fmaf(pr[kk], vv.w, o[e + 3]);
+                    }
+                }
+                mx = mnew;
+            }
+        }
+    }
+    if (q_ok) {
+        float* op = p.out + (size_t)m * p.out_stride + h * HD + part * DP;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int e = 0; e < DP; e += 4)
+            *reinterpret_cast<float4*>(op + e) = make_float4(o[e] * inv, o[e + 1] * inv, o[e + 2] * inv, o[e + 3] * inv);
+    }
+}
+hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s) {
+    dim3 grid((p.M + 63) / 64, p.n_heads);
+    const size_t lds = (size_t)2 * 64 * hd * sizeof(float);
+    if (hd == 64) {
+        attn_prefill_kernel<64><<<grid, dim3(256), lds, s>>>(p);
+    } else if (hd == 128) {
+        auto kern = attn_prefill_kernel<128>;
+        static bool attr_done = false;
+        hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
+        if (e != hipSuccess) return e;
+        kern<<<grid, dim3(256), lds, s>>>(p);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-query GQA attention against the cache (gguf/model.rs:125-174 with q_len == 1): one workgroup per
+// q-head, KV heads are NOT expanded (model.rs:177-197 materialises x4; here q-head h reads kv-head h/group).
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sc = smem;                 // scores, up to max_seq
+    __shared__ float red[8];
+    __shared__ float osum[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, kvh = h / (p.n_heads / p.n_kv_heads);
+    const int pos = (p.pos_ptr ? *p.pos_ptr : 0) + p.offset;
+    const int len = pos + 1;
+    const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0;
+    const int n = len - j_lo;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const float* kb = p.k + (size_t)kvh * p.kv_head_stride;
+    const float* vb = p.v + (size_t)kvh * p.kv_head_stride;
+    constexpr int PER = HD / 64;
+    float qv[PER];
+#pragma unroll
+    for (int e = 0; e < PER; e++) qv[e] = p.q[h * HD + lane * PER + e];
+    for (int j = j_lo + wave; j < len; j += 4) {
+        const float* kr = kb + (size_t)j * p.kv_row_stride + lane * PER;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < PER; e++) s = fmaf(qv[e], kr[e], s);
+        s = wave_sum(s);
+        if (lane == 0) sc[j - j_lo] = s * scale;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 256) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 256) { const float e = expf(sc[i] - mx); sc[i] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    // P.V : thread -> (key parity group, d)
+    constexpr int GROUPS = 256 / HD;
+    const int grp = tid / HD, d = tid % HD;
+    float o = 0.f;
+    for (int i = grp; i < n; i += GROUPS) o = fmaf(sc[i], vb[(size_t)(j_lo + i) * p.kv_row_stride + d], o);
+    osum[tid] = o;
+    __syncthreads();
+    if (tid < HD) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < GROUPS; g++) t += osum[g * HD + tid];
+        p.out[h * HD + tid] = t / sum;
+    }
+}
+hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s) {
+    const size_t lds = (size_t)max_seq * sizeof(float);
+    if (hd == 128) {
+        auto kern = attn_decode_kernel<128>;
+        static bool attr_done = false;
+        hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
+        if (e != hipSuccess) return e;
+        kern<<<dim3(p.n_heads), dim3(256), lds, s>>>(p);
+    } else if (hd == 64) {
+        auto kern = attn_decode_kernel<64>;
+        kern<<<dim3(p.n_heads), dim3(256), lds, s>>>(p);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv1d(k3, s2, p1) + exact-erf GELU (models/layers/conv.rs:78-83). f32, LDS-tiled:
+// workgroup = 64 output channels x 64 output positions, 16 input channels per step, 4x4 outputs / thread.
+// ------------------------------------------------------------------------------------------------
+template <int TOKEN_MAJOR>
+__global__ __launch_bounds__(256) void conv1d_gelu_kernel(const float* __restrict__ in, int Cin, int L,
+                                                          const float* __restrict__ w, const float* __restrict__ b, int Cout,
+                                                          int Lo, float* __restrict__ out) {
+    constexpr int CI = 16, TW = 2 * 64 + 1;    // input span for 64 outputs: positions 2*t0-1 .. 2*t0+127
+    __shared__ float ins[CI][TW + 3];
+    __shared__ float ws[CI][3][64 + 1];
+    const int tid = threadIdx.x;
+    const int co0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+    const int tc = tid & 15, tt = tid >> 4;    // thread: channels co0 + tc + 16*a, positions t0 + tt + 16*bq
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[a][q] = 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += CI) {
+        __syncthreads();
+        for (int i = tid; i < CI * TW; i += 256) {
+            const int ci = i / TW, x = i % TW, pos = 2 * t0 - 1 + x;
+            ins[ci][x] = (c0 + ci < Cin && pos >= 0 && pos < L) ? in[(size_t)(c0 + ci) * L + pos] : 0.f;
+        }
+        for (int i = tid; i < 64 * CI * 3; i += 256) {
+            const int co = i / (CI * 3), rem = i % (CI * 3), ci = rem / 3, kk = rem % 3;
+            ws[ci][kk][co] = (co0 + co < Cout && c0 + ci < Cin) ? w[((size_t)(co0 + co) * Cin + c0 + ci) * 3 + kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ci = 0; ci < CI; ci++) {
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                float wv[4], xv[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) wv[a] = ws[ci][kk][tc + 16 * a];
+#pragma unroll
+                for (int q = 0; q < 4; q++) xv[q] = ins[ci][2 * (tt + 16 * q) + kk];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[a][q] = fmaf(xv[q], wv[a], acc[a][q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int co = co0 + tc + 16 * a, t = t0 + tt + 16 * q;
+            if (co < Cout && t < Lo) {
+                const float v = gelu_f(acc[a][q] + (b ? b[co] : 0.f));
+                if (TOKEN_MAJOR) out[(size_t)t * Cout + co] = v; else out[(size_t)co * Lo + t] = v;
+            }
+        }
+}
+hipError_t launch_conv1d_gelu(const float* in, int Cin, int L, const float* w, const float* b, int Cout, float* out,
+                              int token_major, hipStream_t s) {
+    const int Lo = (L + 2 - 3) / 2 + 1;
+    dim3 grid((Lo + 63) / 64, (Cout + 63) / 64);
+    if (token_major) conv1d_gelu_kernel<1><<<grid, dim3(256), 0, s>>>(in, Cin, L, w, b, Cout, Lo, out);
+    else conv1d_gelu_kernel<0><<<grid, dim3(256), 0, s>>>(in, Cin, L, w, b, Cout, Lo, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-mel (audio/mel.rs:128-244): one workgroup per frame. Reflect-padded STFT frame * periodic Hann,
+// 400-point real DFT (201 bins) by table lookup, power, Slaney filterbank, log10 / floor / scale.
+// The padded signal zeros(left) + scale*audio + zeros(right) is never materialised.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audio, long n, long left, long right,
+                                                  const float* __restrict__ scale_ptr, MelTables t, float* __restrict__ out,
+                                                  int T, int transposed) {
+    __shared__ float fr[400];
+    __shared__ float ct[400], st[400];
+    __shared__ float pw[201 + 3];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const long plen = left + n + right;             // length of the padded signal handed to the STFT
+    const float scale = scale_ptr ? *scale_ptr : 1.0f;
+    for (int j = tid; j < 400; j += 256) {
+        long idx = (long)f * 160 + j - 200;          // index into the padded signal, before reflection (mel.rs:190-205)
+        if (idx < 0) { long r = -idx; long lim = plen > 0 ? plen - 1 : 0; idx = r < lim ? r : lim; }
+        else if (idx >= plen) { long i2 = idx - plen; long a = plen >= 2 ? plen - 2 : 0; idx = a >= i2 ? a - i2 : 0; }
+        const long ai = idx - left;
+        float v = 0.f;
+        if (plen > 0 && ai >= 0 && ai < n) { v = audio[ai]; if (scale_ptr) v *= scale; }
+        fr[j] = v * t.window[j];
+        ct[j] = t.cos_t[j]; st[j] = t.sin_t[j];
+    }
+    __syncthreads();
+    if (tid < 201) {
+        float re = 0.f, im = 0.f; int ph = 0;
+        for (int j = 0; j < 400; j++) {
+            const float v = fr[j];
+            re = fmaf(v, ct[ph], re); im = fmaf(-v, st[ph], im);
+            ph += tid; if (ph >= 400) ph -= 400;
+        }
+        pw[tid] = re * re + im * im;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int lo = t.fb_lo[tid], hi = t.fb_hi[tid];
+        const float* row = t.fb + tid * 201;
+        float acc = 0.f;
+        for (int j = lo; j < hi; j++) acc += row[j] * pw[j];
+        float v = log10f(fmaxf(acc, 1e-10f));
+        v = fmaxf(v, 1.5f - 8.0f);
+        v = (v + 4.0f) / 4.0f;
+        if (transposed) out[(size_t)tid * T + f] = v; else out[(size_t)f * 128 + tid] = v;
+    }
+}
+hipError_t launch_mel(const float* audio, long n, long left, long right, const float* scale_ptr, MelTables t, float* out, int T,
+                      int transposed, hipStream_t s) {
+    if (T <= 0) return hipSuccess;
+    mel_kernel<<<dim3(T), dim3(256), 0, s>>>(audio, n, left, right, scale_ptr, t, out, T, transposed);
+    return hipGetLastError();
+}
+
+// peak_normalize scale (audio/io.rs:59-68): scale = target / max|x| (1 if max < 1e-10). Single workgroup.
+__global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ x, long n, float target, float* __restrict__ scale_out) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; i++) m = fmaxf(m, red[i]);
+        *scale_out = m < 1e-10f ? 1.0f : target / m;
+    }
+}
+hipError_t launch_absmax(const float* x, long n, float target, float* scale_out, hipStream_t s) {
+    absmax_kernel<<<dim3(1), dim3(1024), 0, s>>>(x, n, target, scale_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// token embedding row dequant (+ audio embedding add) (gguf/model.rs:584-618, :898-902, :942-948)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(Q4W tok, const int* __restrict__ ids, const float* __restrict__ audio, int D,
+                                                    const int* __restrict__ pos_ptr, int id_off, int a_off, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    const int base = pos_ptr ? *pos_ptr : 0;
+    const int id = ids[base + id_off + i];
+    const float* arow = audio ? audio + (size_t)(base + a_off + i) * D : nullptr;
+    float* o = out + (size_t)i * D;
+    for (int c = threadIdx.x; c < tok.nb; c += 256) {
+        const uint4 q = tok.qs[(size_t)id * tok.nb + c];
+        const float d = f16_bits_to_f32(tok.sc[(size_t)id * tok.nb + c]);
+        const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t by = (ww[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            const float lo = ((float)(by & 0xF) - 8.0f) * d, hi = ((float)(by >> 4) - 8.0f) * d;
+            o[c * 32 + k] = arow ? arow[c * 32 + k] + lo : lo;
+            o[c * 32 + 16 + k] = arow ? arow[c * 32 + 16 + k] + hi : hi;
+        }
+    }
+}
+hipError_t launch_embed(Q4W tok, const int* ids, int n, const float* audio, int D, const int* pos_ptr, int id_off, int a_off,
+                        float* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    embed_kernel<<<dim3(n), dim3(256), 0, s>>>(tok, ids, audio, D, pos_ptr, id_off, a_off, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int n_parts,
+                                                           int* __restrict__ tokens, int* __restrict__ pos_ptr, int tok_off, int inc) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    float v = -INFINITY; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n_parts; i += 256) {
+        const float x = pv[i]; const int ii = pi[i];
+        if (x > v || (x == v && ii < idx)) { v = x; idx = ii; }
+    }
+    bv[threadIdx.x] = v; bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float x = bv[threadIdx.x + s]; const int ii = bi[threadIdx.x + s];
+            if (x > bv[threadIdx.x] || (x == bv[threadIdx.x] && ii < bi[threadIdx.x])) { bv[threadIdx.x] = x; bi[threadIdx.x] = ii; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int base = pos_ptr ? *pos_ptr : 0;
+        tokens[base + tok_off] = bi[0];
+        if (pos_ptr && inc) *pos_ptr = base + inc;
+    }
+}
+hipError_t launch_argmax_final(const float* pv, const int* pi, int n_parts, int* tokens, int* pos_ptr, int tok_off, int inc,
+                               hipStream_t s) {
+    argmax_final_kernel<<<dim3(1), dim3(256), 0, s>>>(pv, pi, n_parts, tokens, pos_ptr, tok_off, inc);
+    return hipGetLastError();
+}
+
+__global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    add_rows_kernel<<<dim3(blocks), dim3(256), 0, s>>>(a, b, out, n);
+    return hipGetLastError();
+}
+__global__ void gelu_kernel(float* __restrict__ x, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = gelu_f(x[i]);
+}
+hipError_t launch_gelu(float* x, long n, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    gelu_kernel<<<dim3(blocks), dim3(256), 0, s>>>(x, n);
+    return hipGetLastError();
+}
+
+}  // namespace vox

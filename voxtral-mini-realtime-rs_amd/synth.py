@@ -1,0 +1,222 @@
+"""Synthetic weights / audio in the reference's real on-disk layout.
+
+There is no network and no real ``voxtral-q4.gguf`` in the build or GPU containers, so the
+parity tests, ``smoke()`` and ``bench.py`` run on synthetic weights written as a genuine
+GGUF v3 file with the exact tensor names, reversed dims, dtypes and 32-byte alignment the
+reference loader expects (``src/gguf/reader.rs:105-188``, ``src/gguf/loader.rs:191-491``,
+name tables ``src/models/weights.rs:219-397``).  A real GGUF drops in
+unchanged.
+
+The Q4_0 codec here (``quantize_q4_0`` / ``dequantize_q4_0``) is the numpy twin of the
+reference's test quantiser (``src/gguf/tests.rs:24-87``); it is host-side tooling
+(SURVEY.md section 8f item 4), not part of the accelerated path.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, asdict
+
+import numpy as np
+
+ENC = "mm_streams_embeddings.embedding_module.whisper_encoder"
+EMB = "mm_streams_embeddings.embedding_module"
+TOK = EMB + ".tok_embeddings.weight"
+ADP = EMB + ".audio_language_projection"
+
+GGML_F32, GGML_F16, GGML_Q4_0 = 0, 1, 2
+
+
+@dataclass
+class ModelDims:
+    """Shapes of the model (defaults: ``src/models/config.rs:441-493``)."""
+    enc_layers: int = 32
+    enc_dim: int = 1280
+    enc_heads: int = 32          # head_dim fixed at 64
+    enc_ffn: int = 5120
+    dec_layers: int = 26
+    dec_dim: int = 3072
+    dec_heads: int = 32          # head_dim fixed at 128
+    dec_kv_heads: int = 8
+    dec_ffn: int = 9216
+    vocab: int = 131072
+    n_mels: int = 128
+    t_cond: int = 32
+    enc_bias: bool = True        # wq/wv/wo/w2 biases (gguf/loader.rs:226-232,248-249)
+
+    ENC_HD = 64
+    DEC_HD = 128
+
+    def as_dict(self):
+        return asdict(self)
+
+
+def tiny_dims(**kw) -> ModelDims:
+    """A small model with the real architecture (for parity tests that must finish in seconds)."""
+    d = dict(enc_layers=2, enc_dim=128, enc_heads=2, enc_ffn=256, dec_layers=2, dec_dim=256,
+             dec_heads=4, dec_kv_heads=2, dec_ffn=512, vocab=512, n_mels=128, t_cond=32)
+    d.update(kw)
+    return ModelDims(**d)
+
+
+def tensor_manifest(d: ModelDims):
+    """[(name, shape (PyTorch order), kind, sigma)] -- SURVEY.md Appendix A."""
+    out = []
+    out.append((f"{ENC}.conv_layers.0.conv.weight", (d.enc_dim, d.n_mels, 3), "f32", 0.05))
+    out.append((f"{ENC}.conv_layers.0.conv.bias", (d.enc_dim,), "f32", 0.01))
+    out.append((f"{ENC}.conv_layers.1.conv.weight", (d.enc_dim, d.enc_dim, 3), "f32", 0.02))
+    out.append((f"{ENC}.conv_layers.1.conv.bias", (d.enc_dim,), "f32", 0.01))
+    qd = d.enc_heads * d.ENC_HD
+    for i in range(d.enc_layers):
+        p = f"{ENC}.transformer.layers.{i}"
+        out.append((f"{p}.attention_norm.weight", (d.enc_dim,), "norm", 0.02))
+        out.append((f"{p}.ffn_norm.weight", (d.enc_dim,), "norm", 0.02))
+        for nm, shape, bias in (("attention.wq", (qd, d.enc_dim), True), ("attention.wk", (qd, d.enc_dim), False),
+                                ("attention.wv", (qd, d.enc_dim), True), ("attention.wo", (d.enc_dim, qd), True),
+                                ("feed_forward.w1", (d.enc_ffn, d.enc_dim), False),
+                                ("feed_forward.w2", (d.enc_dim, d.enc_ffn), True),
+                                ("feed_forward.w3", (d.enc_ffn, d.enc_dim), False)):
+            out.append((f"{p}.{nm}.weight", shape, "q4", 0.03))
+            if bias and d.enc_bias:
+                out.append((f"{p}.{nm}.bias", (shape[0],), "f32", 0.01))
+    out.append((f"{ENC}.transformer.norm.weight", (d.enc_dim,), "norm", 0.02))
+    out.append((f"{ADP}.0.weight", (d.dec_dim, d.enc_dim * 4), "q4", 0.02))
+    out.append((f"{ADP}.2.weight", (d.dec_dim, d.dec_dim), "q4", 0.02))
+    out.append((TOK, (d.vocab, d.dec_dim), "q4", 0.02))
+    for i in range(d.dec_layers):
+        p = f"layers.{i}"
+        out.append((f"{p}.ada_rms_norm_t_cond.0.weight", (d.t_cond, d.dec_dim), "q4", 0.02))
+        out.append((f"{p}.ada_rms_norm_t_cond.2.weight", (d.dec_dim, d.t_cond), "q4", 0.05))
+        out.append((f"{p}.attention_norm.weight", (d.dec_dim,), "norm", 0.02))
+        out.append((f"{p}.ffn_norm.weight", (d.dec_dim,), "norm", 0.02))
+        out.append((f"{p}.attention.wq.weight", (d.dec_heads * d.DEC_HD, d.dec_dim), "q4", 0.02))
+        out.append((f"{p}.attention.wk.weight", (d.dec_kv_heads * d.DEC_HD, d.dec_dim), "q4", 0.02))
+        out.append((f"{p}.attention.wv.weight", (d.dec_kv_heads * d.DEC_HD, d.dec_dim), "q4", 0.02))
+        out.append((f"{p}.attention.wo.weight", (d.dec_dim, d.dec_heads * d.DEC_HD), "q4", 0.02))
+        out.append((f"{p}.feed_forward.w1.weight", (d.dec_ffn, d.dec_dim), "q4", 0.02))
+        out.append((f"{p}.feed_forward.w2.weight", (d.dec_dim, d.dec_ffn), "q4", 0.02))
+        out.append((f"{p}.feed_forward.w3.weight", (d.dec_ffn, d.dec_dim), "q4", 0.02))
+    out.append(("norm.weight", (d.dec_dim,), "norm", 0.02))
+    return out
+
+
+# --------------------------------------------------------------------------- Q4_0 codec (numpy)
+
+def quantize_q4_0(data: np.ndarray) -> np.ndarray:
+    """Reference test quantiser, ``src/gguf/tests.rs:24-57``: d = amax/7, q = min(15, trunc(v/d + 8.5))."""
+    x = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 32)
+    amax = np.abs(x).max(axis=1)
+    d = (amax / np.float32(7.0)).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        inv = np.where(d != 0, np.float32(1.0) / d, np.float32(0.0)).astype(np.float32)
+    q = (x * inv[:, None] + np.float32(8.5)).astype(np.float32)
+    q = np.clip(np.trunc(q), 0, 15).astype(np.uint8)  # Rust `as u8` saturates; then .min(15)
+    out = np.empty((x.shape[0], 18), dtype=np.uint8)
+    out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:] = q[:, :16] | (q[:, 16:] << 4)
+    return out.reshape(-1)
+
+
+def dequantize_q4_0(raw: np.ndarray, n_elems: int) -> np.ndarray:
+    """``src/gguf/tensor.rs:88-113``."""
+    b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 18)
+    d = b[:, 0:2].copy().view(np.float16).astype(np.float32)  # [nb,1]
+    qs = b[:, 2:]
+    lo = (qs & 0x0F).astype(np.float32) - np.float32(8.0)
+    hi = (qs >> 4).astype(np.float32) - np.float32(8.0)
+    out = np.concatenate([lo * d, hi * d], axis=1)
+    return out.reshape(-1)[:n_elems]
+
+
+def synth_q4_blocks(rng: np.random.Generator, n_elems: int, sigma: float) -> np.ndarray:
+    """Random Q4_0 blocks generated directly in the quantised domain (fast enough for the 2.5 GB
+    full-size model): uniform nibbles, f16 scale d ~ sigma/4.61 * U(0.5, 1.5) so that the
+    dequantised weights have std ~ sigma."""
+    nb = n_elems // 32
+    out = np.empty((nb, 18), dtype=np.uint8)
+    out[:, 2:] = np.frombuffer(rng.bytes(nb * 16), dtype=np.uint8).reshape(nb, 16)
+    d = (np.float32(sigma / 4.61) * (np.float32(0.5) + rng.random(nb, dtype=np.float32))).astype(np.float16)
+    out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
+    return out.reshape(-1)
+
+
+# --------------------------------------------------------------------------- GGUF writer
+
+def _gguf_str(s: str) -> bytes:
+    b = s.encode()
+    return struct.pack("<Q", len(b)) + b
+
+
+def write_gguf(path: str, tensors, version: int = 3):
+    """tensors: iterable of (name, shape_pytorch_order, ggml_dtype, bytes-like or callable->bytes).
+    Layout per ``src/gguf/reader.rs:105-188`` (and the in-test builder ``src/gguf/tests.rs:90-168``):
+    magic, version, counts, one KV (general.architecture="voxtral"), tensor infos with REVERSED
+    dims, data section at the next 32-byte boundary; each tensor 32-byte aligned."""
+    tensors = list(tensors)
+    sizes = []
+    for name, shape, dt, _ in tensors:
+        ne = int(np.prod(shape))
+        sizes.append(ne * 4 if dt == GGML_F32 else ne * 2 if dt == GGML_F16 else ne // 32 * 18)
+    head = bytearray()
+    head += struct.pack("<IIQQ", 0x46554747, version, len(tensors), 1)
+    head += _gguf_str("general.architecture") + struct.pack("<I", 8) + _gguf_str("voxtral")
+    off = 0
+    offsets = []
+    for (name, shape, dt, _), sz in zip(tensors, sizes):
+        head += _gguf_str(name) + struct.pack("<I", len(shape))
+        for dim in reversed(shape):
+            head += struct.pack("<Q", int(dim))
+        head += struct.pack("<IQ", dt, off)
+        offsets.append(off)
+        off = (off + sz + 31) // 32 * 32
+    head += b"\0" * ((32 - len(head) % 32) % 32)
+    with open(path, "wb") as f:
+        f.write(head)
+        pos = 0
+        for (name, shape, dt, data), sz, o in zip(tensors, sizes, offsets):
+            if pos < o:
+                f.write(b"\0" * (o - pos)); pos = o
+            buf = data() if callable(data) else data
+            buf = memoryview(np.ascontiguousarray(buf)).cast("B")
+            assert len(buf) == sz, (name, len(buf), sz)
+            f.write(buf); pos += sz
+
+
+def write_synthetic_gguf(path: str, dims: ModelDims, seed: int = 42, dense_override=None):
+    """Write a synthetic Q4_0 GGUF for ``dims``.  Deterministic in (dims, seed).
+    ``dense_override``: optional {name: float32 array} quantised with the reference quantiser
+    instead of the random generator."""
+    man = tensor_manifest(dims)
+
+    def gen(idx, name, shape, kind, sigma):
+        def make():
+            rng = np.random.default_rng([seed, idx])
+            ne = int(np.prod(shape))
+            if dense_override is not None and name in dense_override:
+                a = np.asarray(dense_override[name], dtype=np.float32).reshape(shape)
+                return quantize_q4_0(a) if kind == "q4" else a
+            if kind == "q4":
+                return synth_q4_blocks(rng, ne, sigma)
+            if kind == "norm":
+                return (1.0 + sigma * rng.standard_normal(ne)).astype(np.float32)
+            return (sigma * rng.standard_normal(ne)).astype(np.float32)
+        return make
+
+    tensors = [(name, shape, GGML_Q4_0 if kind == "q4" else GGML_F32, gen(i, name, shape, kind, sigma))
+               for i, (name, shape, kind, sigma) in enumerate(man)]
+    write_gguf(path, tensors)
+    return path
+
+
+def synth_audio(seconds: float = 16.0, seed: int = 1234, sample_rate: int = 16000) -> np.ndarray:
+    """SURVEY.md section 8(d) clip: 0.3 sin(2 pi 220 t) + 0.2 sin(2 pi (440+30t) t) + 0.05 N(0,1),
+    0.5 s fade in/out, float32 in [-1, 1]."""
+    n = int(round(seconds * sample_rate))
+    t = np.arange(n, dtype=np.float64) / sample_rate
+    rng = np.random.default_rng(seed)
+    x = 0.3 * np.sin(2 * np.pi * 220.0 * t) + 0.2 * np.sin(2 * np.pi * (440.0 + 30.0 * t) * t) + 0.05 * rng.standard_normal(n)
+    fade = min(int(0.5 * sample_rate), n // 2)
+    if fade > 0:
+        ramp = np.linspace(0.0, 1.0, fade)
+        x[:fade] *= ramp
+        x[-fade:] *= ramp[::-1]
+    return x.astype(np.float32)
