@@ -1,0 +1,51 @@
+"""Shared helpers for model-level tests: deterministic synthetic GGUFs (cached in the temp dir)."""
+import os
+import tempfile
+
+import numpy as np
+
+from __graft_entry__ import load_package
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_python_golden.npz")
+
+
+def cache_dir():
+    d = os.path.join(tempfile.gettempdir(), "vox_test_models")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def synth_gguf(dims, seed, tag):
+    S = load_package().synth
+    p = os.path.join(cache_dir(), f"{tag}_{seed}.gguf")
+    if not os.path.exists(p):
+        tmp = p + f".tmp{os.getpid()}"
+        S.write_synthetic_gguf(tmp, dims, seed=seed)
+        os.replace(tmp, p)
+    return p
+
+
+def golden():
+    return np.load(GOLDEN)
+
+
+def golden_gguf():
+    S = load_package().synth; g = golden()
+    dims = S.ModelDims(**{str(k): int(v) for k, v in zip(g["dims_keys"], g["dims"])})
+    return synth_gguf(dims, int(g["seed"]), "golden"), dims
+
+
+def tiny_gguf(seed=7, **kw):
+    S = load_package().synth
+    tag = "tiny" + "".join(f"_{k}{v}" for k, v in sorted(kw.items()))
+    return synth_gguf(S.tiny_dims(**kw), seed, tag), S.tiny_dims(**kw)
+
+
+def fake_mel(T, seed=0, n_mels=128):
+    rng = np.random.default_rng(seed)
+    return (0.6 * rng.standard_normal((n_mels, T)) + 0.3).astype(np.float32)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))

@@ -1,0 +1,351 @@
+"""Host-side mirror of the reference's `src/gguf` module over the C ABI: GgufReader (reader.rs),
+Q4Tensor (tensor.rs), q4_matmul (op.rs), Q4Linear (linear.rs), Q4ModelLoader (loader.rs),
+Q4VoxtralModel / Q4LanguageModel surface (model.rs).  All tensors cross as numpy float32 / int32."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, VoxError
+
+F32, F16, Q4_0 = 0, 1, 2
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP device + stream (the reference's implicit WgpuDevice::default())."""
+
+    def __init__(self, device: int = 0):
+        self.h = C.c_void_p()
+        check(lib().vox_ctx_create(device, C.byref(self.h)))
+        self.device = device
+
+    def synchronize(self):
+        check(lib().vox_ctx_synchronize(self.h))
+
+    def stream(self):
+        s = C.c_void_p(); check(lib().vox_ctx_stream(self.h, C.byref(s)))
+        return s.value
+
+    def alloc(self, nbytes):
+        p = C.c_void_p(); check(lib().vox_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, p):
+        check(lib().vox_dev_free(self.h, C.c_void_p(p)))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr); p = self.alloc(arr.nbytes)
+        check(lib().vox_dev_upload(self.h, C.c_void_p(p), _ptr(arr), arr.nbytes))
+        return p
+
+    def download(self, p, shape, dtype=np.float32):
+        out = np.empty(shape, dtype=dtype)
+        check(lib().vox_dev_download(self.h, _ptr(out), C.c_void_p(p), out.nbytes))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().vox_ctx_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_count():
+    n = C.c_int32(); check(lib().vox_device_count(C.byref(n)))
+    return n.value
+
+
+class GgufTensorInfo:
+    def __init__(self, name, dims, dtype, nbytes):
+        self.name, self._dims, self._dtype, self._nbytes = name, dims, dtype, nbytes
+
+    def shape(self):
+        return list(self._dims)
+
+    def dtype(self):
+        return self._dtype
+
+    def num_elements(self):
+        return int(np.prod(self._dims)) if self._dims else 1
+
+    def byte_size(self):
+        return self._nbytes
+
+
+class GgufReader:
+    """gguf/reader.rs:98-223 (v2/v3; dtypes F32/F16/Q4_0)"""
+
+    def __init__(self, path):
+        self.h = C.c_void_p()
+        check(lib().vox_gguf_open(str(path).encode(), C.byref(self.h)))
+
+    @classmethod
+    def open(cls, path):
+        return cls(path)
+
+    def version(self):
+        v = C.c_uint32(); check(lib().vox_gguf_version(self.h, C.byref(v))); return v.value
+
+    def tensor_count(self):
+        v = C.c_uint64(); check(lib().vox_gguf_tensor_count(self.h, C.byref(v))); return v.value
+
+    def tensor_names(self):
+        out = []
+        for i in range(self.tensor_count()):
+            s = C.c_char_p(); check(lib().vox_gguf_tensor_name(self.h, i, C.byref(s))); out.append(s.value.decode())
+        return out
+
+    def tensor_info(self, name):
+        dims = (C.c_uint64 * 4)(); nd = C.c_uint32(); dt = C.c_uint32(); nb = C.c_uint64()
+        r = lib().vox_gguf_tensor_info(self.h, name.encode(), C.byref(dims), C.byref(nd), C.byref(dt), C.byref(nb))
+        if r == 4:
+            return None                      # Option::None, reader.rs:200-202
+        check(r)
+        return GgufTensorInfo(name, [int(dims[i]) for i in range(nd.value)], dt.value, nb.value)
+
+    def tensor_data(self, name):
+        info = self.tensor_info(name)
+        if info is None:
+            raise VoxError(4, f"Tensor '{name}' not found in GGUF")
+        out = np.empty(info.byte_size(), dtype=np.uint8)
+        check(lib().vox_gguf_tensor_data(self.h, name.encode(), _ptr(out), out.size))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().vox_gguf_close(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Q4Tensor:
+    """gguf/tensor.rs:21-113"""
+
+    def __init__(self, ctx, h, shape):
+        self.ctx, self.h, self._shape = ctx, h, shape
+
+    @classmethod
+    def from_q4_bytes(cls, raw_bytes, shape, ctx: Context):
+        raw = np.ascontiguousarray(np.frombuffer(raw_bytes, dtype=np.uint8) if not isinstance(raw_bytes, np.ndarray) else raw_bytes, dtype=np.uint8)
+        n, k = shape; h = C.c_void_p()
+        check(lib().vox_q4_tensor_from_bytes(ctx.h, _ptr(raw), raw.size, n, k, C.byref(h)))
+        return cls(ctx, h, [n, k])
+
+    def shape(self):
+        return list(self._shape)
+
+    def num_blocks(self):
+        v = C.c_int64(); check(lib().vox_q4_tensor_num_blocks(self.h, C.byref(v))); return v.value
+
+    def dequantize(self):
+        out = np.empty(self._shape, dtype=np.float32)
+        check(lib().vox_q4_tensor_dequantize(self.ctx.h, self.h, _ptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().vox_q4_tensor_free(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def q4_matmul(x, weights: Q4Tensor):
+    """gguf/op.rs:86-137: x [B, M, K] float32 -> [B, M, N]; raises on rank/shape mismatch (the reference panics)."""
+    x = _f32(x)
+    if x.ndim != 3:
+        raise VoxError(1, f"q4_matmul expects a 3-D input, got {x.ndim}-D")
+    b, m, k = x.shape
+    n, kw = weights.shape()
+    if k != kw:
+        raise VoxError(1, f"q4_matmul: input K={k} != weight K={kw}")
+    out = np.empty((b, m, n), dtype=np.float32)
+    check(lib().vox_q4_matmul(weights.ctx.h, weights.h, _ptr(x), b, m, _ptr(out), 0))
+    return out
+
+
+class Q4Linear:
+    """gguf/linear.rs:17-40"""
+
+    def __init__(self, weights: Q4Tensor, bias=None):
+        self.weights = weights
+        self.bias = None if bias is None else _f32(bias)
+
+    @classmethod
+    def new(cls, weights, bias=None):
+        return cls(weights, bias)
+
+    def forward(self, x):
+        x = _f32(x); b, m, k = x.shape; n = self.weights.shape()[0]
+        out = np.empty((b, m, n), dtype=np.float32)
+        check(lib().vox_q4_linear_forward(self.weights.ctx.h, self.weights.h, None if self.bias is None else _ptr(self.bias),
+                                          _ptr(x), b, m, _ptr(out), 0))
+        return out
+
+
+class LayerCaches:
+    """create_cache_preallocated, gguf/model.rs:711-723 / kv_cache.rs:221-258"""
+
+    def __init__(self, model, max_seq):
+        self.model = model; self.h = C.c_void_p()
+        check(lib().vox_decoder_cache_create(model.h, max_seq, C.byref(self.h)))
+
+    def seq_len(self):
+        v = C.c_int32(); check(lib().vox_cache_seq_len(self.h, C.byref(v))); return v.value
+
+    def reset(self):
+        check(lib().vox_cache_reset(self.h))
+
+    def close(self):
+        if self.h:
+            lib().vox_cache_free(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Q4LanguageModel:
+    """The decoder surface used by e2e-bench (gguf/model.rs:566-723)."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def n_layers(self):
+        return self._m.config.dec_layers
+
+    def d_model(self):
+        return self._m.config.dec_dim
+
+    def embed_tokens_from_ids(self, ids, batch=1, seq=None):
+        ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1)
+        out = np.empty((ids.size, self.d_model()), dtype=np.float32)
+        check(lib().vox_embed_tokens_from_ids(self._m.h, _ptr(ids), ids.size, _ptr(out)))
+        return out.reshape(batch, -1, self.d_model())
+
+    def create_cache_preallocated(self, max_seq):
+        return LayerCaches(self._m, max_seq)
+
+    def forward_hidden_with_cache(self, x, t_embed, caches: LayerCaches):
+        x = _f32(x); shp = x.shape; x2 = x.reshape(-1, self.d_model())
+        out = np.empty_like(x2)
+        check(lib().vox_forward_hidden_with_cache(self._m.h, _ptr(x2), x2.shape[0], _ptr(_f32(t_embed).reshape(-1)), caches.h, _ptr(out)))
+        return out.reshape(shp)
+
+    def lm_head(self, hidden):
+        h = _f32(hidden); shp = h.shape; h2 = h.reshape(-1, self.d_model())
+        out = np.empty((h2.shape[0], self._m.config.vocab), dtype=np.float32)
+        check(lib().vox_lm_head(self._m.h, _ptr(h2), h2.shape[0], _ptr(out)))
+        return out.reshape(shp[:-1] + (self._m.config.vocab,))
+
+
+class Q4VoxtralModel:
+    """gguf/model.rs:759-989"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+        self.config = _lib.ModelCfg(); check(lib().vox_model_config(h, C.byref(self.config)))
+
+    def decoder(self):
+        return Q4LanguageModel(self)
+
+    def create_decoder_cache_preallocated(self, max_seq):
+        return LayerCaches(self, max_seq)
+
+    def weight_bytes(self):
+        v = C.c_uint64(); check(lib().vox_model_weight_bytes(self.h, C.byref(v))); return v.value
+
+    def arena(self):
+        p = C.c_void_p(); n = C.c_uint64(); check(lib().vox_model_arena(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def encode_audio(self, mel):
+        """mel [1,128,T] or [128,T] -> [1,S,dec_dim] (gguf/model.rs:783-788)"""
+        mel = _f32(mel); mel = mel.reshape(mel.shape[-2], mel.shape[-1]); T = mel.shape[1]
+        cap = T // 16 + 2
+        out = np.empty((cap, self.config.dec_dim), dtype=np.float32); S = C.c_int32()
+        check(lib().vox_encode_audio(self.h, _ptr(mel), T, _ptr(out), cap, C.byref(S), 0))
+        return out[:S.value].reshape(1, S.value, self.config.dec_dim).copy()
+
+    def transcribe_streaming(self, mel, t_embed, return_logits=False):
+        """-> list[int] of length S-38 (gguf/model.rs:873-963)"""
+        mel = _f32(mel); mel = mel.reshape(mel.shape[-2], mel.shape[-1]); T = mel.shape[1]
+        cap = T // 16 + 2
+        ids = np.zeros(cap, dtype=np.int32); n = C.c_int32()
+        t = _f32(t_embed).reshape(-1)
+        lg = np.empty((cap, self.config.vocab), dtype=np.float32) if return_logits else None
+        check(lib().vox_transcribe_streaming(self.h, _ptr(mel), T, _ptr(t), _ptr(ids), cap, C.byref(n),
+                                             None if lg is None else _ptr(lg), 0))
+        if return_logits:
+            return ids[:n.value].copy(), lg[:n.value].copy()
+        return ids[:n.value].copy()
+
+    def transcribe_audio(self, samples, t_embed, device_ptr=None, n_samples=None):
+        """Whole path from 16 kHz samples (peak-normalise, pad, mel, encode, decode)."""
+        t = _f32(t_embed).reshape(-1)
+        if device_ptr is None:
+            x = _f32(samples); n_samples = x.size; ptr = _ptr(x); kind = 0
+        else:
+            ptr = C.c_void_p(device_ptr); kind = 1
+        cap = n_samples // 1280 + 128
+        ids = np.zeros(cap, dtype=np.int32); n = C.c_int32()
+        check(lib().vox_transcribe_audio(self.h, ptr, n_samples, _ptr(t), _ptr(ids), cap, C.byref(n), kind))
+        return ids[:n.value].copy()
+
+    def timings(self):
+        t = _lib.Timings(); check(lib().vox_get_stage_timings(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _lib.Timings._fields_}
+
+    def bench_decode_gemv(self, which, iters=200):
+        us = C.c_double(); by = C.c_double(); nm = C.c_char_p()
+        check(lib().vox_bench_decode_gemv(self.h, which, iters, C.byref(us), C.byref(by), C.byref(nm)))
+        return us.value, by.value, (nm.value or b"").decode()
+
+    def close(self):
+        if self.h:
+            lib().vox_model_free(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Q4ModelLoader:
+    """gguf/loader.rs:67-128"""
+
+    def __init__(self, path):
+        self.path = str(path)
+
+    @classmethod
+    def from_file(cls, path):
+        return cls(path)
+
+    def load(self, ctx: Context) -> Q4VoxtralModel:
+        h = C.c_void_p()
+        check(lib().vox_q4_model_load(ctx.h, self.path.encode(), C.byref(h)))
+        return Q4VoxtralModel(ctx, h)

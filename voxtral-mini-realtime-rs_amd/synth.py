@@ -127,14 +127,19 @@ def dequantize_q4_0(raw: np.ndarray, n_elems: int) -> np.ndarray:
     return out.reshape(-1)[:n_elems]
 
 
+_NIB_LUT = np.array([1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 14, 15], dtype=np.uint8)   # symmetric about 8 -> zero-mean weights
+_BYTE_LUT = (_NIB_LUT[np.arange(256) & 15] | (_NIB_LUT[np.arange(256) >> 4] << 4)).astype(np.uint8)
+
+
 def synth_q4_blocks(rng: np.random.Generator, n_elems: int, sigma: float) -> np.ndarray:
     """Random Q4_0 blocks generated directly in the quantised domain (fast enough for the 2.5 GB
-    full-size model): uniform nibbles, f16 scale d ~ sigma/4.61 * U(0.5, 1.5) so that the
-    dequantised weights have std ~ sigma."""
+    full-size model): nibbles in 1..15 with mean exactly 8 (zero-mean weights, the range the GGML
+    quantiser produces), f16 scale d ~ sigma/4.18 * U(0.5, 1.5) so the dequantised weights have
+    std ~ sigma."""
     nb = n_elems // 32
     out = np.empty((nb, 18), dtype=np.uint8)
-    out[:, 2:] = np.frombuffer(rng.bytes(nb * 16), dtype=np.uint8).reshape(nb, 16)
-    d = (np.float32(sigma / 4.61) * (np.float32(0.5) + rng.random(nb, dtype=np.float32))).astype(np.float16)
+    out[:, 2:] = _BYTE_LUT[np.frombuffer(rng.bytes(nb * 16), dtype=np.uint8)].reshape(nb, 16)
+    d = (np.float32(sigma / 4.18) * (np.float32(0.5) + rng.random(nb, dtype=np.float32))).astype(np.float16)
     out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
     return out.reshape(-1)
 
@@ -220,3 +225,47 @@ def synth_audio(seconds: float = 16.0, seed: int = 1234, sample_rate: int = 1600
         x[:fade] *= ramp
         x[-fade:] *= ramp[::-1]
     return x.astype(np.float32)
+
+
+def read_gguf_tensors(path: str):
+    """Minimal numpy GGUF parser for files written by `write_gguf` (tooling/tests only):
+    returns {name: (shape_pytorch_order, ggml_dtype, raw uint8 array)}."""
+    buf = np.memmap(path, dtype=np.uint8, mode="r")
+    pos = 0
+
+    def rd(fmt):
+        nonlocal pos
+        v = struct.unpack_from(fmt, buf, pos); pos += struct.calcsize(fmt); return v if len(v) > 1 else v[0]
+
+    def rstr():
+        nonlocal pos
+        n = rd("<Q"); s = bytes(buf[pos:pos + n]).decode(); pos += n; return s
+
+    magic, ver, nt, nkv = rd("<IIQQ")
+    assert magic == 0x46554747
+    for _ in range(nkv):
+        rstr(); ty = rd("<I"); assert ty == 8; rstr()
+    infos = []
+    for _ in range(nt):
+        name = rstr(); nd = rd("<I"); dims = [rd("<Q") for _ in range(nd)]; dt = rd("<I"); off = rd("<Q")
+        infos.append((name, tuple(reversed(dims)), dt, off))
+    data0 = (pos + 31) // 32 * 32
+    out = {}
+    for name, shape, dt, off in infos:
+        ne = int(np.prod(shape)); nb = ne * 4 if dt == 0 else ne * 2 if dt == 1 else ne // 32 * 18
+        out[name] = (shape, dt, buf[data0 + off:data0 + off + nb])
+    return out
+
+
+def gguf_dense_f32(path: str):
+    """{name: float32 array in PyTorch shape} with Q4_0 tensors dequantised (gguf/tensor.rs:88-113)."""
+    out = {}
+    for name, (shape, dt, raw) in read_gguf_tensors(path).items():
+        ne = int(np.prod(shape))
+        if dt == GGML_Q4_0:
+            out[name] = dequantize_q4_0(np.asarray(raw), ne).reshape(shape)
+        elif dt == GGML_F16:
+            out[name] = np.asarray(raw).view(np.float16).astype(np.float32).reshape(shape)
+        else:
+            out[name] = np.asarray(raw).view(np.float32).reshape(shape).copy()
+    return out
