@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Voxtral-Mini realtime hot path on MI355X.
+
+Metric (BASELINE.json): RTF + decode tok/s on 16 s / 16 kHz clips, Q4 path.
+A "step" = one whole pass of the hot path over one synthetic 16 s clip that is already resident in HBM:
+peak-normalise -> pad -> log-mel -> 32-layer encoder -> adapter -> 38-token prefill -> 107 greedy decode
+steps -> 108 token ids read back (the reference's un-chunked `e2e-bench` pipeline, bin/e2e_bench.rs:138-254;
+workload = BASELINE.json configs[2] "Single 16 s WAV, Q4_0 GGUF on 1xMI355X").  Weights are synthetic
+random Q4_0 in the real GGUF layout (no checkpoint is available offline); token count is a pure function
+of audio length (no EOS), so throughput does not depend on weight values.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU (torch.distributed.run), independent utterances per rank ("weak" scaling), rank 0
+parses the GGUF and the packed weight arena reaches the other ranks through one RCCL broadcast; there is no
+collective in the data path.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PREFIX_LEN = 38
+REF_TOK_S = 19.4   # reference Q4 native decode tok/s (DGX Spark GB10), README.md:14
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def full_gguf_path(pkg, seed, rank, barrier):
+    path = os.path.join(os.environ.get("VOX_BENCH_DIR", "/tmp"), f"vox_bench_full_q4_seed{seed}.gguf")
+    if rank == 0 and not os.path.exists(path):
+        t0 = time.time()
+        tmp = path + ".tmp"
+        pkg.synth.write_synthetic_gguf(tmp, pkg.synth.ModelDims(), seed=seed)
+        os.replace(tmp, path)
+        log(f"[bench] wrote synthetic full-size Q4_0 GGUF {path} ({os.path.getsize(path) / 1e9:.2f} GB) in {time.time() - t0:.1f}s")
+    barrier()
+    return path
+
+
+def cpu_baseline(pkg, gguf_path, seconds):
+    """CPU restatement of the reference path (oracle, kind 'port') on this box's host cores, on a bounded
+    sample: the full pipeline on a `seconds`-long clip (same pad/mel/encoder/decoder, fewer positions)."""
+    import oracle_lib as orc
+    orc.build()
+    m = orc.Model(gguf_path)
+    x = pkg.synth.synth_audio(seconds, seed=1234)
+    t0 = time.time()
+    xn = x.copy(); orc.lib().orc_peak_normalize(xn, xn.size, 0.95)
+    mel = np.ascontiguousarray(orc.mel_compute_log(orc.pad_audio(xn)).T)
+    pre = time.time() - t0
+    t_embed = orc.time_embedding(6.0, m.cfg.dec_dim)
+    ids = m.transcribe_streaming(mel, t_embed)
+    total = time.time() - t0
+    enc_ms, dec_ms = m.timings()
+    m.close()
+    n = int(len(ids))
+    return {"value": round(n / (dec_ms / 1e3), 3) if dec_ms > 0 else None, "unit": "tok/s", "cores": orc.lib().orc_num_threads(),
+            "kind": "port",
+            "sample": f"{seconds:g} s synthetic clip, full pipeline (mel {pre * 1e3:.0f} ms, encode {enc_ms:.0f} ms, "
+                      f"prefill+{max(n - 1, 0)} decode steps {dec_ms:.0f} ms, {n} ids); value = ids / decode_s as bin/e2e_bench.rs:236-240",
+            "rtf": round(total / seconds, 3), "total_s": round(total, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=16.0)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("VOX_CPU_BASELINE_S", "1.0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemv-iters", type=int, default=260)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    # torch first: it bundles its own libamdhip64; importing it before libvoxtral_hip.so keeps ONE HIP runtime in-process.
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    pkg.lib()   # fails loudly if the HIP library is missing
+    ctx = pkg.Context(local)
+    path = full_gguf_path(pkg, args.seed, rank, barrier)
+
+    t0 = time.time()
+    loader = pkg.Q4ModelLoader.from_file(path)
+    if world > 1:
+        # rank 0 parses + repacks; the packed device arena reaches the other ranks by ONE RCCL broadcast over xGMI
+        model = loader.load(ctx, layout_only=(rank != 0))
+        ptr, nbytes = model.arena()
+        stage = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local}")
+        if rank == 0:
+            ctx.copy(stage.data_ptr(), ptr, nbytes)
+        torch.cuda.synchronize(); tb = time.time()
+        dist.broadcast(stage, src=0)
+        torch.cuda.synchronize(); bcast_s = time.time() - tb
+        if rank != 0:
+            ctx.copy(ptr, stage.data_ptr(), nbytes)
+        del stage
+    else:
+        model = loader.load(ctx); bcast_s = 0.0
+    load_s = time.time() - t0
+    cfg = model.config
+    t_embed = pkg.TimeEmbedding(cfg.dec_dim).embed(6.0)
+
+    # inputs resident in HBM before the timed region (each rank its own utterance: independent units)
+    x = pkg.synth.synth_audio(args.seconds, seed=1234 + rank)
+    d_x = ctx.upload(x)
+    ids = None
+    for _ in range(max(args.warmup, 0)):
+        ids = model.transcribe_audio(None, t_embed, device_ptr=d_x, n_samples=x.size)
+    barrier(); torch.cuda.synchronize(); ctx.synchronize()
+    stage_ms = {"preprocess_ms": 0.0, "encode_ms": 0.0, "decode_ms": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids = model.transcribe_audio(None, t_embed, device_ptr=d_x, n_samples=x.size)
+        tm = model.timings()
+        for k in stage_ms:
+            stage_ms[k] += tm[k]
+    ctx.synchronize(); torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    n_ids = int(len(ids))
+    steps = max(args.steps, 1)
+    for k in stage_ms:
+        stage_ms[k] /= steps
+    ms_per_step = elapsed * 1e3 / steps
+    value = world * steps * n_ids / elapsed
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "decode_tok_per_s", "value": round(value, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(value / REF_TOK_S, 2), "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"single {args.seconds:g} s 16 kHz clip per GPU, Q4_0 GGUF (BASELINE configs[2]); un-chunked e2e-bench pipeline: "
+                                   f"mel -> 32-layer encoder -> adapter -> 38-token prefill + {n_ids - 1} decode steps",
+                       "weights": "synthetic Q4_0, real Voxtral-Mini-4B-Realtime shapes (711 tensors, 2.5 GB)",
+                       "clip_s": args.seconds, "ids_per_clip": n_ids, "batch": 1, "parallelism": f"replicas x{world}"},
+            "rtf": round(ms_per_step / 1e3 / args.seconds, 5),
+            "decode_tok_per_s_ref_def": round(n_ids / (stage_ms["decode_ms"] / 1e3), 2) if stage_ms["decode_ms"] > 0 else None,
+            "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "load_s": round(load_s, 2), "weight_broadcast_s": round(bcast_s, 3), "weight_bytes": model.weight_bytes(),
+            "note": "value = ids emitted by all ranks / max-over-ranks wall time of the whole pipeline; decode_tok_per_s_ref_def follows "
+                    "bin/e2e_bench.rs:236-240 (ids / decode-stage time); vs_baseline divides by the reference's 19.4 tok/s measured on a DGX Spark GB10",
+        }
+        # ---- roofline of the dominant kernel: the fused gate/up Q4 GEMV (w1|w3, 26 launches per token), HIP events on our stream
+        names = ["qkv", "wo", "w1w3", "w2", "lm_head"]; per = {}
+        per_step_us = 0.0; per_step_bytes = 0.0
+        for which, nm in enumerate(names):
+            us, nbytes, kname = model.bench_decode_gemv(which, args.gemv_iters if which != 4 else 40)
+            per[nm] = {"avg_us": round(us, 3), "bytes": int(nbytes), "GBps": round(nbytes / us / 1e3, 1), "kernel": kname}
+            mult = 1 if which == 4 else cfg.dec_layers
+            per_step_us += us * mult; per_step_bytes += nbytes * mult
+        dom = per["w1w3"]
+        out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                           "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["avg_us"],
+                           "all_decode_gemvs": per,
+                           "decode_step_gemv_GBps": round(per_step_bytes / per_step_us / 1e3, 1),
+                           "decode_step_algorithmic_bytes": int(per_step_bytes),
+                           "decode_step_measured_ms": round(stage_ms["decode_ms"] / max(n_ids, 1), 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(pkg, path, args.cpu_baseline_seconds)
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "tok/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    ctx.free(d_x)
+    model.close(); ctx.close()
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

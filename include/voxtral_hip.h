@@ -65,6 +65,7 @@ int32_t vox_dev_alloc(vox_ctx* ctx, size_t nbytes, void** out);
 int32_t vox_dev_free(vox_ctx* ctx, void* p);
 int32_t vox_dev_upload(vox_ctx* ctx, void* dst_dev, const void* src_host, size_t nbytes);
 int32_t vox_dev_download(vox_ctx* ctx, void* dst_host, const void* src_dev, size_t nbytes);
+int32_t vox_dev_copy(vox_ctx* ctx, void* dst_dev, const void* src_dev, size_t nbytes);   /* device -> device, synchronous */
 
 /* ---- audio front-end (src/audio) ------------------------------------------------------- */
 /* AudioBuffer::peak_normalize, audio/io.rs:59-68 (host, in place) */
@@ -139,6 +140,10 @@ typedef struct {
 
 /* Q4ModelLoader::from_file(..).load(), gguf/loader.rs:82-128 */
 int32_t vox_q4_model_load(vox_ctx* ctx, const char* gguf_path, vox_model** out);
+/* flags: VOX_LOAD_LAYOUT_ONLY parses the GGUF header and allocates the identical device arena layout but does
+ * not read or upload tensor data -- the caller fills the arena (vox_model_arena) e.g. from an RCCL broadcast. */
+#define VOX_LOAD_LAYOUT_ONLY 1u
+int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* gguf_path, uint32_t flags, vox_model** out);
 int32_t vox_model_free(vox_model* m);
 int32_t vox_model_config(const vox_model* m, vox_model_cfg* out);
 int32_t vox_model_weight_bytes(const vox_model* m, uint64_t* out);   /* device bytes of the weight arena */

@@ -1,0 +1,118 @@
+"""CPU-only checks of the product library: it loads, exports every symbol include/voxtral_hip.h
+declares, and its host-side helpers (no compute) agree with the oracle.  No GPU calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    hdr = open(os.path.join(ROOT, "include", "voxtral_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vox_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 50
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in voxtral_hip.h but not exported"
+    bound = set(pkg._lib.SIGNATURES)
+    assert declared == bound, (declared - bound, bound - declared)
+    assert L.vox_abi_version() == 1
+
+
+def test_no_oracle_in_product(pkg):
+    """The product path must not import/link the oracle (parity claims are void otherwise)."""
+    pdir = os.path.join(ROOT, "voxtral-mini-realtime-rs_amd")
+    for dp, _, fs in os.walk(pdir):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert "vox_oracle" not in src and "oracle_lib" not in src and "libvox_oracle" not in src, f
+    out = os.popen(f"ldd {pkg.build.LIB_PATH}").read()
+    assert "oracle" not in out and "libamdhip64" in out
+
+
+def test_compute_fails_loudly_without_gpu(pkg):
+    n = C.c_int32(); pkg._lib.check(pkg.lib().vox_device_count(C.byref(n)))
+    if n.value > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.VoxError, match="no HIP device"):
+        pkg.Context(0)
+
+
+def test_host_helpers_match_oracle(pkg, orc):
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(255168) * 0.1).astype(np.float32)
+    a = pkg.peak_normalize(x, 0.95); b = x.copy(); orc.lib().orc_peak_normalize(b, b.size, 0.95)
+    assert (a == b).all() and abs(np.abs(a).max() - 0.95) < 1e-6
+    assert (pkg.peak_normalize(np.zeros(8, np.float32)) == 0).all()
+    cfg = pkg.PadConfig.voxtral()
+    assert (cfg.n_left_pad_tokens, cfg.extra_right_pad_tokens, cfg.samples_per_token(), cfg.left_pad_samples()) == (76, 17, 1280, 97280)
+    p = pkg.pad_audio(x)
+    assert p.size == 375040 and (p == orc.pad_audio(x)).all()
+    assert pkg.audio.num_audio_tokens(p.size) == 293                       # pad.rs:178-218
+    for n in (0, 1, 1279, 1280, 12800, 12801, 256000):
+        assert cfg.padded_len(n) == orc.pad_audio(np.zeros(n, np.float32)).size
+    cc = pkg.ChunkConfig.voxtral()
+    assert not pkg.needs_chunking(240000, cc) and pkg.needs_chunking(240001, cc)
+    ch = pkg.chunk_audio(np.arange(500000, dtype=np.float32), cc)          # chunk.rs:185-265
+    assert [c.start_sample for c in ch] == [0, 240000, 480000] and ch[-1].is_last and ch[-1].samples.size == 20000
+    assert pkg.chunk_audio(np.zeros(500000, np.float32), cc.with_overlap(100))[1].start_sample == 224000
+    ch = pkg.chunk_audio(np.zeros(256000, np.float32), cc.with_max_frames(1200))   # CLI default, transcribe.rs:55-57
+    assert [(c.start_sample, c.end_sample) for c in ch] == [(0, 192000), (192000, 256000)]
+    with pytest.raises(pkg.VoxError):
+        pkg.chunk_audio(np.zeros(10, np.float32), pkg.ChunkConfig(100, 160, 16000, 100))
+    fb = pkg.MelSpectrogram.mel_filterbank(); fo = np.zeros((128, 201), np.float32); orc.lib().orc_mel_filterbank(fo)
+    assert (fb == fo).all()
+    w = pkg.MelSpectrogram.hann_window(400); wo = np.zeros(400, np.float32); orc.lib().orc_hann_window(400, wo)
+    assert (w == wo).all() and abs(w[1] - 6.1690807e-05) < 1e-8              # mel.rs:396-405
+    assert pkg.MelSpectrogram(None).num_frames(375040) == 2344 and 99 <= pkg.MelSpectrogram(None).num_frames(16000) <= 101
+    for dim, t in ((4, 1.0), (3072, 6.0), (256, 6.0)):
+        assert (pkg.TimeEmbedding(dim).embed(t) == orc.time_embedding(t, dim)).all()
+
+
+def test_gguf_reader_cpu(pkg, orc, tmp_path):
+    S = pkg.synth
+    w = np.sin(np.arange(32 * 64, dtype=np.float32) * np.float32(0.001) - 1.0).astype(np.float32)
+    q = S.quantize_q4_0(w)
+    p = str(tmp_path / "t.gguf")
+    S.write_gguf(p, [("test.weight", (64, 32), S.GGML_Q4_0, q), ("b", (8,), S.GGML_F32, np.arange(8, dtype=np.float32))])
+    r = pkg.GgufReader.open(p)                                             # gguf/tests.rs:280-325
+    assert r.version() == 3 and r.tensor_count() == 2 and sorted(r.tensor_names()) == ["b", "test.weight"]
+    info = r.tensor_info("test.weight")
+    assert info.shape() == [32, 64] and info.dtype() == pkg.gguf.Q4_0 and info.byte_size() == q.size and info.num_elements() == 2048
+    assert (r.tensor_data("test.weight") == q).all()
+    assert (r.tensor_data("b").view(np.float32) == np.arange(8)).all()
+    assert r.tensor_info("nonexistent") is None
+    with pytest.raises(pkg.VoxError, match="not found"):
+        r.tensor_data("nonexistent")
+    r.close()
+    bad = tmp_path / "bad.gguf"; bad.write_bytes(b"NOPE" + b"\0" * 64)
+    with pytest.raises(pkg.VoxError, match="magic"):
+        pkg.GgufReader.open(str(bad))
+    v9 = tmp_path / "v9.gguf"; v9.write_bytes(b"GGUF" + (9).to_bytes(4, "little") + b"\0" * 64)
+    with pytest.raises(pkg.VoxError, match="version"):
+        pkg.GgufReader.open(str(v9))
+    with pytest.raises(pkg.VoxError):
+        pkg.GgufReader.open(str(tmp_path / "missing.gguf"))
+    # v2 accepted (reader.rs:117-120)
+    S.write_gguf(str(tmp_path / "v2.gguf"), [("a", (32, 32), S.GGML_Q4_0, S.quantize_q4_0(np.ones(1024, np.float32)))], version=2)
+    assert pkg.GgufReader.open(str(tmp_path / "v2.gguf")).version() == 2
+
+
+def test_synthetic_gguf_is_readable_by_both(pkg, orc, tmp_path):
+    d = pkg.synth.tiny_dims(); p = str(tmp_path / "tiny.gguf"); pkg.synth.write_synthetic_gguf(p, d, seed=3)
+    r = pkg.GgufReader.open(p); names = r.tensor_names()
+    assert len(names) == len(pkg.synth.tensor_manifest(d))
+    g = orc.lib().orc_gguf_open(p.encode())
+    for nm in names[::7]:
+        info = r.tensor_info(nm); raw = r.tensor_data(nm)
+        ptr = orc.lib().orc_gguf_tensor_data(g, nm.encode())
+        assert bytes((C.c_uint8 * info.byte_size()).from_address(ptr)) == raw.tobytes()
+    orc.lib().orc_gguf_close(g)
+    dense = pkg.synth.gguf_dense_f32(p)
+    wq = dense[pkg.synth.ENC + ".transformer.layers.0.attention.wq.weight"]
+    assert wq.shape == (128, 128) and abs(float(wq.mean())) < 2e-3 and 0.02 < float(wq.std()) < 0.04

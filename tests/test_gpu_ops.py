@@ -1,0 +1,154 @@
+"""GPU parity of the operator boundary (Q4Tensor / q4_matmul / Q4Linear / log-mel) against the CPU oracle.
+Every call goes through the C ABI of libvoxtral_hip.so.  Inputs are the reference's own deterministic
+sin/cos generators where the reference has a test for the case (gguf/tests.rs, tests/gguf_integration.rs)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def _w(n, k, f=0.0007, a=0.05, fn=np.cos):
+    return (fn(np.arange(n * k, dtype=np.float32) * np.float32(f)) * np.float32(a)).astype(np.float32)
+
+
+def _act(n, f=0.001, a=0.1):
+    return (np.sin(np.arange(n, dtype=np.float32) * np.float32(f)) * np.float32(a)).astype(np.float32)
+
+
+def test_q4_tensor_dequantize_bit_exact(pkg, orc, ctx):
+    # gguf/tests.rs:331-365 (tol 1e-5 there; the repack is lossless so we demand bit-exact)
+    w = (np.sin(np.arange(256, dtype=np.float32) * np.float32(0.05) - np.float32(6.4)) * np.float32(0.3)).astype(np.float32)
+    q = orc.q4_quantize(w)
+    t = pkg.Q4Tensor.from_q4_bytes(q, [8, 32], ctx)       # K must be a whole number of blocks
+    assert t.shape() == [8, 32] and t.num_blocks() == 8
+    assert (t.dequantize().reshape(-1) == orc.q4_dequantize(q, 256)).all()
+    rng = np.random.default_rng(0)
+    for n, k in ((16, 32), (64, 96), (3, 3072), (130, 1280)):
+        raw = pkg.synth.synth_q4_blocks(rng, n * k, 0.02)
+        t = pkg.Q4Tensor.from_q4_bytes(raw, [n, k], ctx)
+        assert t.num_blocks() == n * k // 32
+        assert (t.dequantize().reshape(-1) == orc.q4_dequantize(raw, n * k)).all()
+
+
+def test_q4_tensor_validation(pkg, orc, ctx):
+    raw = orc.q4_quantize(np.ones(64, np.float32))
+    with pytest.raises(pkg.VoxError, match="byte count mismatch"):          # tensor.rs:43-48
+        pkg.Q4Tensor.from_q4_bytes(raw[:-1], [2, 32], ctx)
+    with pytest.raises(pkg.VoxError, match="divisible by 32"):              # tensor.rs:38-41
+        pkg.Q4Tensor.from_q4_bytes(raw, [3, 11], ctx)
+    t = pkg.Q4Tensor.from_q4_bytes(raw, [2, 32], ctx)
+    with pytest.raises(pkg.VoxError, match="K="):                           # op.rs:98-100 (panic -> error status)
+        pkg.q4_matmul(np.zeros((1, 1, 64), np.float32), t)
+    with pytest.raises(pkg.VoxError, match="3-D"):                          # op.rs:92
+        pkg.q4_matmul(np.zeros((1, 32), np.float32), t)
+
+
+def test_q4_matmul_small(pkg, orc, ctx):
+    # gguf/tests.rs:371-412, tol 1e-3
+    k = n = 32
+    w = (np.sin(np.arange(n * k, dtype=np.float32) * np.float32(0.1)) * np.float32(0.5)).astype(np.float32)
+    q = orc.q4_quantize(w); act = (np.arange(k, dtype=np.float32) * np.float32(0.1)).reshape(1, 1, k)
+    exp = orc.reference_matmul(act.reshape(1, k), orc.q4_dequantize(q, n * k).reshape(n, k))
+    out = pkg.q4_matmul(act, pkg.Q4Tensor.from_q4_bytes(q, [n, k], ctx))
+    assert out.shape == (1, 1, n) and np.abs(out.reshape(1, n) - exp).max() < 1e-3
+
+
+@pytest.mark.parametrize("b,s,k,n,tol", [(1, 1, 128, 64, 1e-2), (1, 10, 3072, 3072, 1e-2), (1, 1, 3072, 9216, 1e-2),   # tests.rs:414-478
+                                         (4, 10, 128, 64, 1e-3),                                                      # tests.rs:642-694
+                                         (1, 5, 64, 64, 1e-2), (1, 8, 128, 64, 1e-2),                                 # gguf_integration.rs:73-148
+                                         (1, 1, 3072, 3072, 1e-2), (1, 10, 3072, 9216, 1e-2), (1, 1, 9216, 3072, 1e-2)])  # :150-224
+def test_q4_matmul_reference_shapes(pkg, orc, ctx, b, s, k, n, tol):
+    act = _act(b * s * k).reshape(b, s, k); w = _w(n, k)
+    q = orc.q4_quantize(w)
+    exp = orc.q4_matmul(q, n, k, act)
+    out = pkg.q4_matmul(act, pkg.Q4Tensor.from_q4_bytes(q, [n, k], ctx))
+    assert out.shape == (b, s, n)
+    err = np.abs(out - exp).max()
+    assert err < tol, err
+    assert err < 2e-5 * max(1.0, np.abs(exp).max()), err     # our own, tighter bar: f32-class accuracy
+
+
+def test_q4_linear_bias(pkg, orc, ctx):
+    # gguf/tests.rs:484-562
+    i, o = 64, 32
+    w = (np.sin(np.arange(o * i, dtype=np.float32) * np.float32(0.001)) * np.float32(0.1)).astype(np.float32)
+    q = orc.q4_quantize(w); bias = np.arange(o, dtype=np.float32) * np.float32(0.01)
+    act = (np.arange(i, dtype=np.float32) * np.float32(0.1)).reshape(1, 1, i)
+    lin = pkg.Q4Linear.new(pkg.Q4Tensor.from_q4_bytes(q, [o, i], ctx), bias)
+    out = lin.forward(act)
+    assert out.shape == (1, 1, o) and np.abs(out - orc.q4_matmul(q, o, i, act, bias)).max() < 1e-3
+    z = pkg.Q4Linear.new(pkg.Q4Tensor.from_q4_bytes(orc.q4_quantize(_w(64, 128, 0.001, 0.1, np.sin)), [64, 128], ctx)).forward(np.zeros((2, 5, 128), np.float32))
+    assert z.shape == (2, 5, 64) and (z == 0).all()
+    out = lin.forward(np.tile(act, (1, 9, 1)))                # M > 4 -> MFMA path with bias
+    assert np.abs(out - orc.q4_matmul(q, o, i, np.tile(act, (1, 9, 1)), bias)).max() < 1e-3
+
+
+MODEL_SHAPES = [(3072, 6144), (4096, 3072), (3072, 18432), (9216, 3072), (3072, 32), (32, 3072),     # decoder GEMVs
+                (1280, 6144), (2048, 1280), (1280, 10240), (5120, 1280), (5120, 3072), (3072, 3072)]  # encoder / adapter
+
+
+@pytest.mark.parametrize("k,n", MODEL_SHAPES)
+@pytest.mark.parametrize("m", [1, 3, 38])
+def test_q4_matmul_model_shapes_random(pkg, orc, ctx, k, n, m):
+    """Random (not slowly-varying) activations at every (K, N) the model uses; GEMV (m<=4) and MFMA GEMM (m=38)."""
+    rng = np.random.default_rng(k * 7 + n + m)
+    nn = min(n, 2048)                                            # oracle time; row coverage still spans many workgroups
+    raw = pkg.synth.synth_q4_blocks(rng, nn * k, 0.02)
+    x = rng.standard_normal((1, m, k)).astype(np.float32)
+    exp = orc.q4_matmul(raw, nn, k, x)
+    out = pkg.q4_matmul(x, pkg.Q4Tensor.from_q4_bytes(raw, [nn, k], ctx))
+    err = np.abs(out - exp).max() / np.abs(exp).max()
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("m,k,n", [(5, 32, 16), (17, 64, 48), (64, 128, 64), (65, 96, 80), (146, 5120, 256), (586, 1280, 192)])
+def test_q4_gemm_ragged(pkg, orc, ctx, m, k, n):
+    """MFMA GEMM edge tiles: M, N not multiples of the 64x64 workgroup tile; transposition-detecting (asymmetric) data."""
+    rng = np.random.default_rng(m + k + n)
+    raw = pkg.synth.synth_q4_blocks(rng, n * k, 0.05)
+    x = (rng.standard_normal((1, m, k)) * (1 + np.arange(k) / k)).astype(np.float32)
+    exp = orc.q4_matmul(raw, n, k, x)
+    out = pkg.q4_matmul(x, pkg.Q4Tensor.from_q4_bytes(raw, [n, k], ctx))
+    assert np.abs(out - exp).max() / np.abs(exp).max() < 2e-5
+
+
+def test_q4_matmul_device_pointers(pkg, orc, ctx):
+    import ctypes as C
+    rng = np.random.default_rng(1); n, k, m = 256, 512, 2
+    raw = pkg.synth.synth_q4_blocks(rng, n * k, 0.02); x = rng.standard_normal((m, k)).astype(np.float32)
+    t = pkg.Q4Tensor.from_q4_bytes(raw, [n, k], ctx)
+    dx = ctx.upload(x); dy = ctx.alloc(m * n * 4)
+    pkg._lib.check(pkg.lib().vox_q4_matmul(ctx.h, t.h, C.c_void_p(dx), 1, m, C.c_void_p(dy), 1))
+    ctx.synchronize()
+    out = ctx.download(dy, (m, n))
+    assert np.abs(out - orc.q4_matmul(raw, n, k, x)).max() < 1e-4
+    ctx.free(dx); ctx.free(dy)
+
+
+def test_log_mel_vs_oracle(pkg, orc, ctx):
+    """audio/mel.rs:128-165 on the GPU vs the oracle (f64-accumulated DFT): max|d| <= 1e-4.
+    Cases: the reference's own KAT inputs (silence, 440 Hz sine; mel.rs:416-465), noise, a padded clip."""
+    mel = pkg.MelSpectrogram.voxtral(ctx)
+    t = np.arange(16000) / 16000.0
+    sil = mel.compute_log(np.zeros(16000, np.float32))
+    assert sil.shape == (100, 128) and np.allclose(sil, (1.5 - 8 + 4) / 4)
+    sine = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    lm = mel.compute_log(sine)
+    assert lm.shape == (100, 128) and lm.min() >= -2.0 and lm.max() <= 3.0
+    assert np.abs(lm - orc.mel_compute_log(sine)).max() < 1e-4
+    rng = np.random.default_rng(2)
+    for n in (400, 1280 * 3, 16000 * 2 + 37):
+        x = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        a = mel.compute_log(x); b = orc.mel_compute_log(x)
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-4, n
+    clip = pkg.pad_audio(pkg.peak_normalize(pkg.synth.synth_audio(2.0, seed=5)))
+    a = mel.compute_log(clip); b = orc.mel_compute_log(clip)
+    assert a.shape == (clip.size // 160, 128) and np.abs(a - b).max() < 1e-4
+    assert mel.compute_log(np.zeros(100, np.float32)).shape == (0, 128)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "vox_dev_free": (i32, [vp, vp]),
     "vox_dev_upload": (i32, [vp, vp, vp, sz]),
     "vox_dev_download": (i32, [vp, vp, vp, sz]),
+    "vox_dev_copy": (i32, [vp, vp, vp, sz]),
     "vox_peak_normalize": (i32, [vp, sz, f32]),
     "vox_pad_cfg_voxtral": (i32, [P(PadCfg)]),
     "vox_pad_len": (i32, [sz, P(PadCfg), P(sz)]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     "vox_q4_matmul": (i32, [vp, vp, vp, i32, i32, vp, i32]),
     "vox_q4_linear_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, i32]),
     "vox_q4_model_load": (i32, [vp, C.c_char_p, P(vp)]),
+    "vox_q4_model_load_ex": (i32, [vp, C.c_char_p, u32, P(vp)]),
     "vox_model_free": (i32, [vp]),
     "vox_model_config": (i32, [vp, P(ModelCfg)]),
     "vox_model_weight_bytes": (i32, [vp, P(u64)]),

@@ -98,6 +98,11 @@ extern "C" int32_t vox_dev_download(vox_ctx* c, void* dst, const void* src, size
     HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return VOX_OK;
 }
 
+extern "C" int32_t vox_dev_copy(vox_ctx* c, void* dst, const void* src, size_t n) {
+    ARGCHK(c && dst && src, "null argument"); VOXCHK(ctx_bind(c));
+    HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return VOX_OK;
+}
+
 // small RAII device buffer for host-pointer entry points
 struct DevBuf {
     void* p = nullptr;
@@ -619,8 +624,11 @@ static void model_release(vox_model* m) {
 }
 extern "C" int32_t vox_model_free(vox_model* m) { model_release(m); return VOX_OK; }
 
-extern "C" int32_t vox_q4_model_load(vox_ctx* ctx, const char* path, vox_model** out) {
+extern "C" int32_t vox_q4_model_load(vox_ctx* ctx, const char* path, vox_model** out) { return vox_q4_model_load_ex(ctx, path, 0, out); }
+
+extern "C" int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* path, uint32_t flags, vox_model** out) {
     ARGCHK(ctx && path && out, "null argument"); VOXCHK(ctx_bind(ctx));
+    const bool layout_only = (flags & VOX_LOAD_LAYOUT_ONLY) != 0;
     vox_gguf* g = nullptr; VOXCHK(vox_gguf_open(path, &g));
     vox_model* m = new vox_model(); m->ctx = ctx;
     Loader plan{m, g, Arena{}, false};
@@ -628,8 +636,8 @@ extern "C" int32_t vox_q4_model_load(vox_ctx* ctx, const char* path, vox_model**
     m->arena_bytes = plan.ar.off + 256;
     if (hipMalloc((void**)&m->arena, m->arena_bytes) != hipSuccess) { vox_gguf_close(g); model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of %.1f MB weight arena failed", m->arena_bytes / 1e6); }
     size_t max_q4 = 0; for (auto& t : g->tensors) if (t.dtype == 2) max_q4 = std::max<size_t>(max_q4, t.nbytes);
-    DevBuf staging; if (staging.alloc(max_q4) != hipSuccess) { vox_gguf_close(g); model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of staging buffer failed"); }
-    Loader fillr{m, g, Arena{m->arena, 0}, true, staging.p, max_q4};
+    DevBuf staging; if (staging.alloc(layout_only ? 16 : max_q4) != hipSuccess) { vox_gguf_close(g); model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of staging buffer failed"); }
+    Loader fillr{m, g, Arena{m->arena, 0}, !layout_only, staging.p, max_q4};
     if (!fillr.run()) { std::string e = fillr.err; vox_gguf_close(g); model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
     vox_gguf_close(g);
     const vox_model_cfg& c = m->cfg;

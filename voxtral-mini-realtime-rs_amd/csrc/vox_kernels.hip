@@ -373,30 +373,28 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float x) {   // round-to-neare
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 // 8 floats -> packed bf16 hi plane + bf16 lo plane (x ~= hi + lo, |err| <= 2^-17 |x|)
-__device__ __forceinline__ void split_bf16x8(const float* v, uint4& hi, uint4& lo) {
-    uint32_t h[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        h[i] = bf16_rne_bits(v[i]);
-        const float rem = v[i] - __uint_as_float(h[i] << 16);
-        l[i] = bf16_rne_bits(rem);
-    }
-    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const uint32_t ha = bf16_rne_bits(a), hb = bf16_rne_bits(b);
+    const uint32_t la = bf16_rne_bits(a - __uint_as_float(ha << 16)), lb = bf16_rne_bits(b - __uint_as_float(hb << 16));
+    hi = ha | (hb << 16); lo = la | (lb << 16);
+}
+__device__ __forceinline__ void split_bf16x8(const float4 a, const float4 b, uint4& hi, uint4& lo) {
+    split_pair(a.x, a.y, hi.x, lo.x); split_pair(a.z, a.w, hi.y, lo.y);
+    split_pair(b.x, b.y, hi.z, lo.z); split_pair(b.z, b.w, hi.w, lo.w);
 }
 // one dword of a Q4 chunk (bytes 4g..4g+3) -> 8 exact bf16 integers (q-8):
 // slots 0..3 = low nibbles (elements 4g..4g+3), slots 4..7 = high nibbles (elements 16+4g..16+4g+3)
+__device__ __forceinline__ uint32_t pack_bf16_exact(float a, float b) {   // a, b small integers: exact in bf16
+    return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);
+}
 __device__ __forceinline__ uint4 q4_dword_to_bf16x8(uint32_t w) {
     const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
-    float f[8];
-    f[0] = ub0(lo) - 8.0f; f[1] = ub1(lo) - 8.0f;
-    f[2] = ub2(lo) - 8.0f; f[3] = ub3(lo) - 8.0f;
-    f[4] = ub0(hi) - 8.0f; f[5] = ub1(hi) - 8.0f;
-    f[6] = ub2(hi) - 8.0f; f[7] = ub3(hi) - 8.0f;
-    uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) o[i] = (__float_as_uint(f[2 * i]) >> 16) | (__float_as_uint(f[2 * i + 1]) & 0xFFFF0000u);
-    return make_uint4(o[0], o[1], o[2], o[3]);
+    uint4 o;
+    o.x = pack_bf16_exact(ub0(lo) - 8.0f, ub1(lo) - 8.0f);
+    o.y = pack_bf16_exact(ub2(lo) - 8.0f, ub3(lo) - 8.0f);
+    o.z = pack_bf16_exact(ub0(hi) - 8.0f, ub1(hi) - 8.0f);
+    o.w = pack_bf16_exact(ub2(hi) - 8.0f, ub3(hi) - 8.0f);
+    return o;
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
     union { uint4 u; bf16x8 b; } c; c.u = v; return c.b;
@@ -428,26 +426,23 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define VOX_GLOAD(B_)                                                                              \
+    xa = srow_ok ? *reinterpret_cast<const float4*>(xrow + 32 * (B_) + 4 * sg) : zero4;          \
+    xb = srow_ok ? *reinterpret_cast<const float4*>(xrow + 32 * (B_) + 16 + 4 * sg) : zero4;     \
+    wd = wrow_ok ? wq[(size_t)(B_) * 4] : 0x88888888u;                                             \
+    wsc = wrow_ok ? ws[(B_)] : (uint16_t)0;
+#define VOX_STAGE(BUF_)                                                                            \
+    { uint4 hi_, lo_; split_bf16x8(xa, xb, hi_, lo_); lds[(BUF_)][0][slot] = hi_; lds[(BUF_)][1][slot] = lo_; }
     float4 xa, xb; uint32_t wd; uint16_t wsc;
-    auto gload = [&](int b) {
-        if (srow_ok) {
-            xa = *reinterpret_cast<const float4*>(xrow + 32 * b + 4 * sg);
-            xb = *reinterpret_cast<const float4*>(xrow + 32 * b + 16 + 4 * sg);
-        } else { xa = make_float4(0, 0, 0, 0); xb = xa; }
-        wd = wrow_ok ? wq[(size_t)b * 4] : 0x88888888u;
-        wsc = wrow_ok ? ws[b] : (uint16_t)0;
-    };
-    auto stage = [&](int buf) {
-        const float v[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-        uint4 hi, lo; split_bf16x8(v, hi, lo);
-        lds[buf][0][slot] = hi; lds[buf][1][slot] = lo;
-    };
-    gload(0); stage(0);
+    VOX_GLOAD(0)
+    VOX_STAGE(0)
     uint32_t cur_wd = wd; uint16_t cur_sc = wsc;
     __syncthreads();
     for (int b = 0; b < nb; b++) {
         const int buf = b & 1;
-        if (b + 1 < nb) gload(b + 1);
+        const bool more = b + 1 < nb;
+        if (more) { VOX_GLOAD(b + 1) }
         const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8(cur_wd));
         const float d = f16_bits_to_f32(cur_sc);
 #pragma unroll
@@ -459,9 +454,11 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
             acc[mt][0] = fmaf(d, t[0], acc[mt][0]); acc[mt][1] = fmaf(d, t[1], acc[mt][1]);
             acc[mt][2] = fmaf(d, t[2], acc[mt][2]); acc[mt][3] = fmaf(d, t[3], acc[mt][3]);
         }
-        if (b + 1 < nb) { stage(buf ^ 1); cur_wd = wd; cur_sc = wsc; }
+        if (more) { VOX_STAGE(buf ^ 1) cur_wd = wd; cur_sc = wsc; }
         __syncthreads();
     }
+#undef VOX_GLOAD
+#undef VOX_STAGE
     // epilogue: lane holds D[m = m0 + mt*16 + 4*(lane>>4) + r][n = wn]
     const float bias = (p.bias && wrow_ok) ? p.bias[wn] : 0.f;
 #pragma unroll

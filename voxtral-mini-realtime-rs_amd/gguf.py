@@ -53,6 +53,9 @@ class Context:
         check(lib().vox_dev_download(self.h, _ptr(out), C.c_void_p(p), out.nbytes))
         return out
 
+    def copy(self, dst, src, nbytes):
+        check(lib().vox_dev_copy(self.h, C.c_void_p(dst), C.c_void_p(src), nbytes))
+
     def close(self):
         if self.h:
             lib().vox_ctx_destroy(self.h); self.h = None
@@ -345,7 +348,9 @@ class Q4ModelLoader:
     def from_file(cls, path):
         return cls(path)
 
-    def load(self, ctx: Context) -> Q4VoxtralModel:
+    def load(self, ctx: Context, layout_only: bool = False) -> Q4VoxtralModel:
+        """`layout_only`: allocate the device arena without reading tensor data (multi-GPU ranks > 0
+        receive the arena bytes from rank 0 with one RCCL broadcast)."""
         h = C.c_void_p()
-        check(lib().vox_q4_model_load(ctx.h, self.path.encode(), C.byref(h)))
+        check(lib().vox_q4_model_load_ex(ctx.h, self.path.encode(), 1 if layout_only else 0, C.byref(h)))
         return Q4VoxtralModel(ctx, h)

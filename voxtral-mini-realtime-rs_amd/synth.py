@@ -138,7 +138,7 @@ def synth_q4_blocks(rng: np.random.Generator, n_elems: int, sigma: float) -> np.
     std ~ sigma."""
     nb = n_elems // 32
     out = np.empty((nb, 18), dtype=np.uint8)
-    out[:, 2:] = _BYTE_LUT[np.frombuffer(rng.bytes(nb * 16), dtype=np.uint8)].reshape(nb, 16)
+    out[:, 2:] = _BYTE_LUT[rng.bit_generator.random_raw(nb * 2).view(np.uint8)].reshape(nb, 16)   # raw PCG64 stream: ~2 GB/s
     d = (np.float32(sigma / 4.18) * (np.float32(0.5) + rng.random(nb, dtype=np.float32))).astype(np.float16)
     out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
     return out.reshape(-1)
