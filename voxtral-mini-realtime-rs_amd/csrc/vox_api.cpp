@@ -419,7 +419,7 @@ struct Lin { Q4W w{}; const float* bias = nullptr; };
 struct EncLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2; };
 struct DecLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2, ada0, ada2; float* ada_mul = nullptr; };
 
-struct vox_cache { vox_model* m; float *k = nullptr, *v = nullptr; int max_seq = 0, len = 0; };   // per layer: [n_kv][max_seq][hd]
+struct vox_cache { vox_model* m; vox_ctx* ctx = nullptr; float *k = nullptr, *v = nullptr; int max_seq = 0, len = 0; };   // per layer: [n_kv][max_seq][hd]
 
 struct vox_model {
     vox_ctx* ctx = nullptr; vox_model_cfg cfg{};
@@ -439,7 +439,7 @@ struct vox_model {
     vox_cache* cache = nullptr;                           // internal cache for transcribe_streaming
     int *d_tokens = nullptr, *d_pos = nullptr; int tokens_cap = 0;
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
-    int n_parts = 0;
+    int n_parts = 0, argmax_R = 8;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; const vox_cache* graph_cache = nullptr;
     vox_timings timings{};
 };
@@ -643,7 +643,8 @@ extern "C" int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* path, uint32_t
     const vox_model_cfg& c = m->cfg;
     // decode-step buffers
     const int qdim = c.dec_heads * c.dec_head_dim;
-    m->n_parts = (c.vocab + 31) / 32;
+    m->argmax_R = q4_gemv_default_R(c.vocab, c.dec_dim, EPI_ARGMAX);
+    m->n_parts = (c.vocab + 4 * m->argmax_R - 1) / (4 * m->argmax_R);
     hipError_t e = hipSuccess;
     auto A = [&](void** p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n); };
     A((void**)&m->ada_mul, (size_t)c.dec_layers * c.dec_dim * 4); A((void**)&m->d_pos, 64); A((void**)&m->d_h, (size_t)c.dec_dim * 4 * 4);
@@ -723,7 +724,7 @@ static int32_t encode_dev(vox_model* m, const float* d_mel, int T, int* S4_out) 
 static int32_t cache_alloc(vox_model* m, int max_seq, vox_cache** out) {
     const vox_model_cfg& c = m->cfg;
     ARGCHK(max_seq > 0 && max_seq <= m->dec_rope_len, "max_seq %d out of range (1..%d)", max_seq, m->dec_rope_len);
-    vox_cache* k = new vox_cache(); k->m = m; k->max_seq = max_seq;
+    vox_cache* k = new vox_cache(); k->m = m; k->ctx = m->ctx; k->max_seq = max_seq;
     const size_t n = (size_t)c.dec_layers * c.dec_kv_heads * max_seq * c.dec_head_dim * 4;
     if (hipMalloc((void**)&k->k, n) != hipSuccess || hipMalloc((void**)&k->v, n) != hipSuccess) { if (k->k) (void)hipFree(k->k); delete k; return fail(VOX_ERR_HIP, "hipMalloc of KV cache failed"); }
     HIPCHK(hipMemsetAsync(k->k, 0, n, m->ctx->stream)); HIPCHK(hipMemsetAsync(k->v, 0, n, m->ctx->stream));
@@ -732,8 +733,7 @@ static int32_t cache_alloc(vox_model* m, int max_seq, vox_cache** out) {
 extern "C" int32_t vox_decoder_cache_create(vox_model* m, int32_t max_seq, vox_cache** out) { ARGCHK(m && out, "null argument"); VOXCHK(ctx_bind(m->ctx)); return cache_alloc(m, max_seq, out); }
 extern "C" int32_t vox_cache_free(vox_cache* k) {
     if (!k) return VOX_OK;
-    (void)hipSetDevice(k->m->ctx->device); (void)hipStreamSynchronize(k->m->ctx->stream);
-    if (k->m->graph_cache == k) k->m->graph_cache = nullptr;
+    (void)hipSetDevice(k->ctx->device); (void)hipStreamSynchronize(k->ctx->stream);   // never dereferences k->m: the model may be gone
     (void)hipFree(k->k); (void)hipFree(k->v); delete k; return VOX_OK;
 }
 extern "C" int32_t vox_cache_seq_len(const vox_cache* k, int32_t* out) { ARGCHK(k && out, "null argument"); *out = k->len; return VOX_OK; }
@@ -786,7 +786,7 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
         GemvParams o{}; o.w = L.wo.w; o.x = m->d_att; o.x_stride = QD; o.out = h; o.out_stride = D; o.resid = h; o.resid_stride = D;
         HIPCHK(launch_q4_gemv(o, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(o.w.N, o.w.K, EPI_RESID), s));
         GemvParams f{}; f.w = L.w13.w; f.x = h; f.x_stride = D; f.out = m->d_act; f.out_stride = F; f.gamma = L.ffn_norm; f.mul = L.ada_mul; f.eps = c.norm_eps;
-        HIPCHK(launch_q4_gemv(f, 1, PRO_RMS, EPI_SWIGLU, q4_gemv_default_R(f.w.N, f.w.K, EPI_SWIGLU), s));
+        HIPCHK(launch_q4_gemv(f, 1, PRO_RMS_MUL, EPI_SWIGLU, q4_gemv_default_R(f.w.N, f.w.K, EPI_SWIGLU), s));
         GemvParams d{}; d.w = L.w2.w; d.x = m->d_act; d.x_stride = F; d.out = h; d.out_stride = D; d.resid = h; d.resid_stride = D;
         HIPCHK(launch_q4_gemv(d, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(d.w.N, d.w.K, EPI_RESID), s));
     }
@@ -799,7 +799,7 @@ static int32_t lm_head_argmax_dev(vox_model* m, const float* h, float* logits_ou
     ARGCHK(c.dec_dim <= 4096, "lm_head GEMV is instantiated for dec_dim <= 4096 (got %d)", c.dec_dim);
     GemvParams p{}; p.w = m->tok.w; p.x = h; p.x_stride = c.dec_dim; p.out = logits_out; p.out_stride = c.vocab; p.gamma = m->dec_norm; p.eps = c.norm_eps;
     p.part_val = m->d_part_val; p.part_idx = m->d_part_idx;
-    HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ARGMAX, 8, m->ctx->stream));
+    HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ARGMAX, m->argmax_R, m->ctx->stream));
     return VOX_OK;
 }
 
@@ -825,8 +825,7 @@ static int32_t decode_step_enqueue(vox_model* m, float* logits_out) {
     HIPCHK(launch_embed(m->tok.w, m->d_tokens, 1, m->d_audio, c.dec_dim, m->d_pos, 0, 0, m->d_h, s));
     VOXCHK(decoder_step_dev(m, m->d_h, m->cache, m->d_pos, 0));
     VOXCHK(lm_head_argmax_dev(m, m->d_h, logits_out));
-    const int nwg = (c.vocab + 31) / 32;
-    HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, nwg, m->d_tokens, m->d_pos, 1, 1, s));
+    HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, m->n_parts, m->d_tokens, m->d_pos, 1, 1, s));
     return VOX_OK;
 }
 
@@ -859,7 +858,7 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     VOXCHK(lm_head_argmax_dev(m, px.as<float>() + (size_t)(PREFIX_LEN - 1) * c.dec_dim, d_logits_all));
     const int pos_init = PREFIX_LEN;
     HIPCHK(hipMemcpyAsync(m->d_pos, &pos_init, 4, hipMemcpyHostToDevice, s));
-    HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, (c.vocab + 31) / 32, m->d_tokens, m->d_pos, 0, 0, s));   // tokens[38]
+    HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, m->n_parts, m->d_tokens, m->d_pos, 0, 0, s));   // tokens[38]
     const int steps = S - PREFIX_LEN - 1;                                         // pos = 39 .. S-1 (model.rs:938)
     if (logits_host) {
         for (int i = 0; i < steps; i++) VOXCHK(decode_step_enqueue(m, d_logits_all + (size_t)(i + 1) * c.vocab));
@@ -1007,7 +1006,7 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
         case 1: p.w = L.wo.w; p.x = m->d_att; p.x_stride = QD; p.out = m->d_h; p.out_stride = D; p.resid = m->d_h; p.resid_stride = D;
                 HIPCHK(launch_q4_gemv(p, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(p.w.N, p.w.K, EPI_RESID), s)); break;
         case 2: p.w = L.w13.w; p.x = m->d_h; p.x_stride = D; p.out = m->d_act; p.out_stride = F; p.gamma = L.ffn_norm; p.mul = L.ada_mul; p.eps = c.norm_eps;
-                HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_SWIGLU, q4_gemv_default_R(p.w.N, p.w.K, EPI_SWIGLU), s)); break;
+                HIPCHK(launch_q4_gemv(p, 1, PRO_RMS_MUL, EPI_SWIGLU, q4_gemv_default_R(p.w.N, p.w.K, EPI_SWIGLU), s)); break;
         case 3: p.w = L.w2.w; p.x = m->d_act; p.x_stride = F; p.out = m->d_h; p.out_stride = D; p.resid = m->d_h; p.resid_stride = D;
                 HIPCHK(launch_q4_gemv(p, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(p.w.N, p.w.K, EPI_RESID), s)); break;
         default: VOXCHK(lm_head_argmax_dev(m, m->d_h, nullptr)); break;
@@ -1018,8 +1017,8 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
     *bytes_per_launch = (double)w->N * w->nb * 18.0;     // algorithmic bytes: the Q4_0 blocks of the weight (18 B / 32 elements)
     if (kernel_name) {
         const int epi = which == 0 ? EPI_ROPE_KV : which == 2 ? EPI_SWIGLU : which == 4 ? EPI_ARGMAX : EPI_RESID;
-        const int pro = (which == 0 || which == 2 || which == 4) ? PRO_RMS : PRO_NONE;
-        *kernel_name = q4_gemv_kernel_name(w->K, pro, epi, which == 4 ? 8 : q4_gemv_default_R(w->N, w->K, epi));
+        const int pro = which == 2 ? PRO_RMS_MUL : (which == 0 || which == 4) ? PRO_RMS : PRO_NONE;
+        *kernel_name = q4_gemv_kernel_name(w->K, pro, epi, which == 4 ? m->argmax_R : q4_gemv_default_R(w->N, w->K, epi));
     }
     for (int i = 0; i < std::min(iters, 8); i++) VOXCHK(launch(i));   // warm-up
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));

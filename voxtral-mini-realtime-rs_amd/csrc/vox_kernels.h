@@ -17,7 +17,7 @@ struct Q4W {
 };
 
 enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5 };
-enum Pro { PRO_NONE = 0, PRO_RMS = 1 };
+enum Pro { PRO_NONE = 0, PRO_RMS = 1, PRO_RMS_MUL = 2 };   // RMS_MUL: RMSNorm then * mul (the cached Ada scale)
 
 // ---- fused Q4 GEMV (decode, rows of x <= 4): out[y][n] = epi( sum_k pro(x[y])[k] * W[n][k] )
 struct GemvParams {

@@ -17,6 +17,9 @@
 
 #include <hip/hip_fp16.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace vox {
 
 // ------------------------------------------------------------------------------------------------
@@ -132,12 +135,16 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     const float* __restrict__ xg = p.x + (size_t)y * p.x_stride;
     const int npieces = K >> 2;
 
-    // (1) activation pieces first (they return first: VMEM returns in order) ...
-    float4 xp[2 * KT];
+    // Every global load below is UNCONDITIONAL (indices are clamped, never predicated): a "cond ? load : 0"
+    // makes hipcc branch around the load and drain vmcnt(0) per element, which serialises HBM round trips.
+    // (1) activation pieces (+ norm weights) first -- VMEM returns in order, so they land first ...
+    float4 xp[2 * KT], gp[PRO != PRO_NONE ? 2 * KT : 1], mp[PRO == PRO_RMS_MUL ? 2 * KT : 1];
 #pragma unroll
     for (int i = 0; i < 2 * KT; i++) {
-        const int pc = tid + 256 * i;
-        xp[i] = pc < npieces ? reinterpret_cast<const float4*>(xg)[pc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int pc = min(tid + 256 * i, npieces - 1);
+        xp[i] = reinterpret_cast<const float4*>(xg)[pc];
+        if (PRO != PRO_NONE) gp[i] = reinterpret_cast<const float4*>(p.gamma)[pc];
+        if (PRO == PRO_RMS_MUL) mp[i] = reinterpret_cast<const float4*>(p.mul)[pc];
     }
     // (2) ... then every weight byte this wave will ever need goes in flight at once.
     uint4 q[R][KT];
@@ -146,19 +153,18 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int t = 0; t < KT; t++) {
-            const int c = lane + 64 * t;
-            const bool ok = (c < nb) && (row0 + r < N);
-            const size_t idx = (size_t)(row0 + r) * nb + c;
-            q[r][t] = ok ? ld_nt_u4(p.w.qs + idx) : make_uint4(0, 0, 0, 0);
-            dh[r][t] = ok ? __builtin_nontemporal_load(p.w.sc + idx) : (uint16_t)0;
+            const size_t idx = (size_t)min(row0 + r, N - 1) * nb + min(lane + 64 * t, nb - 1);
+            q[r][t] = ld_nt_u4(p.w.qs + idx);
+            dh[r][t] = __builtin_nontemporal_load(p.w.sc + idx);
         }
 
     // (3) prologue on the activation vector (RMSNorm (+Ada multiplier) fused), staged to LDS.
     float rms = 1.0f;
-    if (PRO == PRO_RMS) {
+    if (PRO != PRO_NONE) {
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2 * KT; i++) ss += xp[i].x * xp[i].x + xp[i].y * xp[i].y + xp[i].z * xp[i].z + xp[i].w * xp[i].w;
+        for (int i = 0; i < 2 * KT; i++)
+            if (tid + 256 * i < npieces) ss += xp[i].x * xp[i].x + xp[i].y * xp[i].y + xp[i].z * xp[i].z + xp[i].w * xp[i].w;
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
@@ -170,11 +176,11 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
         const int pc = tid + 256 * i;
         if (pc < npieces) {
             float4 v = xp[i];
-            if (PRO == PRO_RMS) {
-                const float4 g = reinterpret_cast<const float4*>(p.gamma)[pc];
+            if (PRO != PRO_NONE) {
+                const float4 g = gp[i];
                 v.x = (v.x / rms) * g.x; v.y = (v.y / rms) * g.y; v.z = (v.z / rms) * g.z; v.w = (v.w / rms) * g.w;
-                if (p.mul) {
-                    const float4 m = reinterpret_cast<const float4*>(p.mul)[pc];
+                if (PRO == PRO_RMS_MUL) {
+                    const float4 m = mp[i];
                     v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
                 }
             }
@@ -294,10 +300,14 @@ static hipError_t ensure_dyn_lds(Kern kern, size_t lds, bool* done) {
 
 static inline int kt_for(int K) { return (K + 2047) / 2048; }
 
+static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+
+// rows per wave. Tuning knobs (measurement only): VOX_GEMV_R / VOX_GEMV_R_PAIR / VOX_GEMV_R_ARGMAX override the table.
 int q4_gemv_default_R(int N, int K, int epi) {
-    if (epi == EPI_ARGMAX) return 8;
     const int kt = kt_for(K);
-    if (epi == EPI_SWIGLU || epi == EPI_ROPE_KV) return kt <= 2 ? 4 : 2;
+    if (epi == EPI_ARGMAX) { const int e = env_int("VOX_GEMV_R_ARGMAX"); return e ? e : 8; }
+    if (epi == EPI_SWIGLU || epi == EPI_ROPE_KV) { const int e = env_int("VOX_GEMV_R_PAIR"); if (e) return e; return kt <= 2 ? 4 : 2; }
+    { const int e = env_int("VOX_GEMV_R"); if (e) return e; }
     // plain rows: keep >= ~3 workgroups per CU while every wave has >= 4 loads in flight
     if (kt >= 4) return 1;
     if ((long)N >= 16384) return 4;
@@ -322,9 +332,11 @@ static hipError_t gemv_dispatch_pe(const GemvParams& p, int ny, int pro, int epi
 #define VOX_CASE(P, E) if (pro == P && epi == E) return gemv_launch_t<KT, R, P, E>(p, ny, s)
     VOX_CASE(PRO_NONE, EPI_STORE); VOX_CASE(PRO_NONE, EPI_RESID); VOX_CASE(PRO_NONE, EPI_GELU);
     VOX_CASE(PRO_RMS, EPI_STORE); VOX_CASE(PRO_RMS, EPI_ARGMAX);
+    if (pro == PRO_RMS_MUL && p.mul == nullptr) return hipErrorInvalidValue;
     if (R >= 2) {
         constexpr int R2 = R >= 2 ? R : 2;
         if (pro == PRO_RMS && epi == EPI_SWIGLU) return gemv_launch_t<KT, R2, PRO_RMS, EPI_SWIGLU>(p, ny, s);
+        if (pro == PRO_RMS_MUL && epi == EPI_SWIGLU) return gemv_launch_t<KT, R2, PRO_RMS_MUL, EPI_SWIGLU>(p, ny, s);
         if (pro == PRO_NONE && epi == EPI_SWIGLU) return gemv_launch_t<KT, R2, PRO_NONE, EPI_SWIGLU>(p, ny, s);
         if (pro == PRO_RMS && epi == EPI_ROPE_KV) return gemv_launch_t<KT, R2, PRO_RMS, EPI_ROPE_KV>(p, ny, s);
     }
@@ -426,23 +438,24 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define VOX_GLOAD(B_)                                                                              \
-    xa = srow_ok ? *reinterpret_cast<const float4*>(xrow + 32 * (B_) + 4 * sg) : zero4;          \
-    xb = srow_ok ? *reinterpret_cast<const float4*>(xrow + 32 * (B_) + 16 + 4 * sg) : zero4;     \
-    wd = wrow_ok ? wq[(size_t)(B_) * 4] : 0x88888888u;                                             \
-    wsc = wrow_ok ? ws[(B_)] : (uint16_t)0;
+    xa = *reinterpret_cast<const float4*>(xrow + 32 * (B_) + 4 * sg);      /* unconditional loads (row clamped), */  \
+    xb = *reinterpret_cast<const float4*>(xrow + 32 * (B_) + 16 + 4 * sg); /* masked by select afterwards        */  \
+    wd = wq[(size_t)(B_) * 4]; wsc = ws[(B_)];   /* out-of-range rows/cols read row 0 and are never stored */
 #define VOX_STAGE(BUF_)                                                                            \
     { uint4 hi_, lo_; split_bf16x8(xa, xb, hi_, lo_); lds[(BUF_)][0][slot] = hi_; lds[(BUF_)][1][slot] = lo_; }
+    // two-deep register pipeline: loads for block b+2 are issued while block b is on the MFMAs and block b+1
+    // (loaded one iteration ago, so already landed) is converted and staged to the other LDS buffer.
     float4 xa, xb; uint32_t wd; uint16_t wsc;
     VOX_GLOAD(0)
     VOX_STAGE(0)
     uint32_t cur_wd = wd; uint16_t cur_sc = wsc;
+    { const int b1 = min(1, nb - 1); VOX_GLOAD(b1) }
     __syncthreads();
     for (int b = 0; b < nb; b++) {
         const int buf = b & 1;
-        const bool more = b + 1 < nb;
-        if (more) { VOX_GLOAD(b + 1) }
+        const float4 sxa = xa, sxb = xb; const uint32_t swd = wd; const uint16_t ssc = wsc;   // block b+1 (in flight since last iteration)
+        { const int b2 = min(b + 2, nb - 1); VOX_GLOAD(b2) }   // unconditional (clamped): a branch here forces phi copies + vmcnt waits
         const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8(cur_wd));
         const float d = f16_bits_to_f32(cur_sc);
 #pragma unroll
@@ -454,7 +467,10 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
             acc[mt][0] = fmaf(d, t[0], acc[mt][0]); acc[mt][1] = fmaf(d, t[1], acc[mt][1]);
             acc[mt][2] = fmaf(d, t[2], acc[mt][2]); acc[mt][3] = fmaf(d, t[3], acc[mt][3]);
         }
-        if (more) { VOX_STAGE(buf ^ 1) cur_wd = wd; cur_sc = wsc; }
+        if (b + 1 < nb) {
+            uint4 hi_, lo_; split_bf16x8(sxa, sxb, hi_, lo_); lds[buf ^ 1][0][slot] = hi_; lds[buf ^ 1][1][slot] = lo_;
+            cur_wd = swd; cur_sc = ssc;
+        }
         __syncthreads();
     }
 #undef VOX_GLOAD
@@ -604,11 +620,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnParams p) {
         __syncthreads();
         for (int i = tid; i < 64 * (HD / 4); i += 256) {
             const int jj = i / (HD / 4), d4 = i % (HD / 4), j = j0 + jj;
-            float4 kk = make_float4(0, 0, 0, 0), vv = kk;
-            if (j < p.kv_len) {
-                kk = *reinterpret_cast<const float4*>(kbase + (size_t)j * p.kv_row_stride + d4 * 4);
-                vv = *reinterpret_cast<const float4*>(vbase + (size_t)j * p.kv_row_stride + d4 * 4);
-            }
+            const int jc = min(j, p.kv_len - 1);     // unconditional (clamped) loads, masked afterwards
+            float4 kk = *reinterpret_cast<const float4*>(kbase + (size_t)jc * p.kv_row_stride + d4 * 4);
+            float4 vv = *reinterpret_cast<const float4*>(vbase + (size_t)jc * p.kv_row_stride + d4 * 4);
+            // keys >= kv_len are masked to -inf below (p = 0), and the clamped rows hold finite data: no zeroing needed
             reinterpret_cast<float4*>(Ks)[i] = kk;
             reinterpret_cast<float4*>(Vs)[i] = vv;
         }
@@ -772,11 +787,13 @@ __global__ __launch_bounds__(256) void conv1d_gelu_kernel(const float* __restric
         __syncthreads();
         for (int i = tid; i < CI * TW; i += 256) {
             const int ci = i / TW, x = i % TW, pos = 2 * t0 - 1 + x;
-            ins[ci][x] = (c0 + ci < Cin && pos >= 0 && pos < L) ? in[(size_t)(c0 + ci) * L + pos] : 0.f;
+            const float v = in[(size_t)min(c0 + ci, Cin - 1) * L + min(max(pos, 0), L - 1)];     // clamped, then masked
+            ins[ci][x] = (c0 + ci < Cin && pos >= 0 && pos < L) ? v : 0.f;
         }
         for (int i = tid; i < 64 * CI * 3; i += 256) {
             const int co = i / (CI * 3), rem = i % (CI * 3), ci = rem / 3, kk = rem % 3;
-            ws[ci][kk][co] = (co0 + co < Cout && c0 + ci < Cin) ? w[((size_t)(co0 + co) * Cin + c0 + ci) * 3 + kk] : 0.f;
+            const float v = w[((size_t)min(co0 + co, Cout - 1) * Cin + min(c0 + ci, Cin - 1)) * 3 + kk];
+            ws[ci][kk][co] = (co0 + co < Cout && c0 + ci < Cin) ? v : 0.f;
         }
         __syncthreads();
 #pragma unroll 4

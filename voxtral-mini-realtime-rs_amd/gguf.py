@@ -4,6 +4,7 @@ Q4VoxtralModel / Q4LanguageModel surface (model.rs).  All tensors cross as numpy
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -213,6 +214,7 @@ class LayerCaches:
     def __init__(self, model, max_seq):
         self.model = model; self.h = C.c_void_p()
         check(lib().vox_decoder_cache_create(model.h, max_seq, C.byref(self.h)))
+        model._caches.add(self)
 
     def seq_len(self):
         v = C.c_int32(); check(lib().vox_cache_seq_len(self.h, C.byref(v))); return v.value
@@ -270,6 +272,7 @@ class Q4VoxtralModel:
 
     def __init__(self, ctx, h):
         self.ctx, self.h = ctx, h
+        self._caches = weakref.WeakSet()
         self.config = _lib.ModelCfg(); check(lib().vox_model_config(h, C.byref(self.config)))
 
     def decoder(self):
@@ -329,6 +332,8 @@ class Q4VoxtralModel:
 
     def close(self):
         if self.h:
+            for c in list(self._caches):
+                c.close()
             lib().vox_model_free(self.h); self.h = None
 
     def __del__(self):
