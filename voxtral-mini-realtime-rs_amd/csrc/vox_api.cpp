@@ -644,7 +644,7 @@ extern "C" int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* path, uint32_t
     // decode-step buffers
     const int qdim = c.dec_heads * c.dec_head_dim;
     m->argmax_R = q4_gemv_default_R(c.vocab, c.dec_dim, EPI_ARGMAX);
-    m->n_parts = (c.vocab + 4 * m->argmax_R - 1) / (4 * m->argmax_R);
+    m->n_parts = q4_gemv_grid(c.vocab, m->argmax_R);
     hipError_t e = hipSuccess;
     auto A = [&](void** p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n); };
     A((void**)&m->ada_mul, (size_t)c.dec_layers * c.dec_dim * 4); A((void**)&m->d_pos, 64); A((void**)&m->d_h, (size_t)c.dec_dim * 4 * 4);

@@ -37,6 +37,7 @@ struct GemvParams {
 hipError_t launch_q4_gemv(const GemvParams& p, int n_rows_x, int pro, int epi, int R, hipStream_t s);
 const char* q4_gemv_kernel_name(int K, int pro, int epi, int R);
 int q4_gemv_default_R(int N, int K, int epi);
+int q4_gemv_grid(int N, int R);   // workgroups launched for N rows at R rows per wave (== number of argmax partials)
 
 // ---- Q4 GEMM on MFMA (prefill / encoder, rows of x > 4): out[M][N'] = epi( x[M][K] * W^T )
 struct GemmParams {

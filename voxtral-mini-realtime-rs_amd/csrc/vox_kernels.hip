@@ -25,16 +25,33 @@ namespace vox {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+// DPP cross-lane (no LDS traffic, unlike __shfl_xor -> ds_bpermute). ctrl: 0xB1 quad_perm[1,0,3,2] (xor 1),
+// 0x4E quad_perm[2,3,0,1] (xor 2), 0x141 row_half_mirror, 0x140 row_mirror. All lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+// sum over the 16 lanes of each DPP row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
     return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+// full-wave reductions, result uniform (every lane). Must be called with all 64 lanes active.
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = row16_max(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
+// sum over aligned groups of 8 lanes (result in every lane of the group)
+__device__ __forceinline__ float group8_sum(float v) { v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); return v; }
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return __half2float(__ushort_as_half(h)); }
 __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
@@ -44,11 +61,12 @@ __device__ __forceinline__ uint4 ld_nt_u4(const uint4* p) {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
-// byte n of a dword -> f32 (the backend selects v_cvt_f32_ubyte{0..3} for these patterns)
-__device__ __forceinline__ float ub0(uint32_t w) { return (float)(w & 0xFFu); }
-__device__ __forceinline__ float ub1(uint32_t w) { return (float)((w >> 8) & 0xFFu); }
-__device__ __forceinline__ float ub2(uint32_t w) { return (float)((w >> 16) & 0xFFu); }
-__device__ __forceinline__ float ub3(uint32_t w) { return (float)(w >> 24); }
+// byte n of a dword -> f32.  Inline asm: written as (w >> 8n) & 0xFF the backend folds the nibble mask into a
+// v_bfe + v_cvt_f32_ubyte0 pair (1.5x the VALU work); v_cvt_f32_ubyteN reads byte N directly.
+__device__ __forceinline__ float ub0(uint32_t w) { float f; asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w)); return f; }
+__device__ __forceinline__ float ub1(uint32_t w) { float f; asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w)); return f; }
+__device__ __forceinline__ float ub2(uint32_t w) { float f; asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w)); return f; }
+__device__ __forceinline__ float ub3(uint32_t w) { float f; asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w)); return f; }
 
 // sum_k x[k] * nibble_k for one 16-byte Q4_0 chunk (32 elements). Element i <-> low nibble of byte i,
 // element 16+i <-> high nibble of byte i (gguf/tensor.rs:98-109). Offset -8 is applied by the caller
@@ -130,10 +148,13 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     float* sxs = smem + K;                         // nb chunk sums
     float* red = sxs + nb;                         // 16 floats scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = (blockIdx.x * 4 + wave) * R;
     const int y = blockIdx.y;
     const float* __restrict__ xg = p.x + (size_t)y * p.x_stride;
     const int npieces = K >> 2;
+    // persistent waves: wave w handles row groups g = w, w + n_waves, ... (R rows each) with the NEXT group's weight
+    // loads issued before the current group is consumed, so HBM stays busy while the VALU works.
+    const int n_groups = (N + R - 1) / R, n_waves = gridDim.x * 4;
+    int g = blockIdx.x * 4 + wave;
 
     // Every global load below is UNCONDITIONAL (indices are clamped, never predicated): a "cond ? load : 0"
     // makes hipcc branch around the load and drain vmcnt(0) per element, which serialises HBM round trips.
@@ -146,17 +167,17 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
         if (PRO != PRO_NONE) gp[i] = reinterpret_cast<const float4*>(p.gamma)[pc];
         if (PRO == PRO_RMS_MUL) mp[i] = reinterpret_cast<const float4*>(p.mul)[pc];
     }
-    // (2) ... then every weight byte this wave will ever need goes in flight at once.
-    uint4 q[R][KT];
-    uint16_t dh[R][KT];
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int t = 0; t < KT; t++) {
-            const size_t idx = (size_t)min(row0 + r, N - 1) * nb + min(lane + 64 * t, nb - 1);
-            q[r][t] = ld_nt_u4(p.w.qs + idx);
-            dh[r][t] = __builtin_nontemporal_load(p.w.sc + idx);
+    // (2) ... then the first row group's weights.
+    uint4 q[R][KT], qn[R][KT];
+    uint16_t dh[R][KT], dn[R][KT];
+#define VOX_WLOAD(Q_, D_, G_)                                                                           \
+    _Pragma("unroll") for (int r = 0; r < R; r++)                                                        \
+        _Pragma("unroll") for (int t = 0; t < KT; t++) {                                                 \
+            const size_t idx = (size_t)min((G_) * R + r, N - 1) * nb + min(lane + 64 * t, nb - 1);       \
+            Q_[r][t] = ld_nt_u4(p.w.qs + idx);                                                           \
+            D_[r][t] = __builtin_nontemporal_load(p.w.sc + idx);                                         \
         }
+    VOX_WLOAD(q, dh, min(g, n_groups - 1))
 
     // (3) prologue on the activation vector (RMSNorm (+Ada multiplier) fused), staged to LDS.
     float rms = 1.0f;
@@ -173,109 +194,120 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     }
 #pragma unroll
     for (int i = 0; i < 2 * KT; i++) {
-        const int pc = tid + 256 * i;
-        if (pc < npieces) {
-            float4 v = xp[i];
-            if (PRO != PRO_NONE) {
-                const float4 g = gp[i];
-                v.x = (v.x / rms) * g.x; v.y = (v.y / rms) * g.y; v.z = (v.z / rms) * g.z; v.w = (v.w / rms) * g.w;
-                if (PRO == PRO_RMS_MUL) {
-                    const float4 m = mp[i];
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                }
+        const int pc = tid + 256 * i;           // pieces come in whole groups of 8 lanes (K % 32 == 0)
+        float4 v = xp[i];
+        if (PRO != PRO_NONE) {
+            const float4 gm = gp[i];
+            v.x = (v.x / rms) * gm.x; v.y = (v.y / rms) * gm.y; v.z = (v.z / rms) * gm.z; v.w = (v.w / rms) * gm.w;
+            if (PRO == PRO_RMS_MUL) {
+                const float4 m = mp[i];
+                v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
             }
+        }
+        const float s8 = group8_sum((v.x + v.y) + (v.z + v.w));     // all lanes active (DPP)
+        if (pc < npieces) {
             const int c = pc >> 3, j = pc & 7;
-            float s4 = (v.x + v.y) + (v.z + v.w);
-            s4 += __shfl_xor(s4, 1, 64); s4 += __shfl_xor(s4, 2, 64); s4 += __shfl_xor(s4, 4, 64);
-            if (j == 0) sxs[c] = s4;
+            if (j == 0) sxs[c] = s8;
             xs[xs_piece(c, j)] = v;
         }
     }
     __syncthreads();
 
-    // (4) consume: per K tile read this lane's 32 activations once, reuse for the R rows.
-    float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < KT; t++) {
-        const int c = lane + 64 * t;
-        if (c < nb) {
-            float xv[32];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float4 v = xs[xs_piece(c, j)];
-                xv[4 * j + 0] = v.x; xv[4 * j + 1] = v.y; xv[4 * j + 2] = v.z; xv[4 * j + 3] = v.w;
-            }
-            const float sx8 = 8.0f * sxs[c];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const float d = f16_bits_to_f32(dh[r][t]);
-                acc[r] = fmaf(d, q4_chunk_dot(q[r][t], xv) - sx8, acc[r]);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+    float best = -INFINITY; int best_i = 0x7fffffff;   // EPI_ARGMAX running (max, first index) of this wave
+    const int pos = (EPI == EPI_ROPE_KV) ? (p.pos_ptr ? *p.pos_ptr : 0) + p.pos_off : 0;
 
-    // (5) epilogue
-    if (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_GELU) {
+    // (4) stream the row groups
+    for (; g < n_groups; g += n_waves) {
+        VOX_WLOAD(qn, dn, min(g + n_waves, n_groups - 1))     // prefetch the next group (clamped: harmless re-read at the tail)
+        const int row0 = g * R;
+        float acc[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int n = row0 + r;
-            if (lane == r && n < N) {
-                float v = acc[r];
-                if (p.bias) v += p.bias[n];
-                if (EPI == EPI_RESID) v = v + p.resid[(size_t)y * p.resid_stride + n];
-                if (EPI == EPI_GELU) v = gelu_f(v);
-                p.out[(size_t)y * p.out_stride + n] = v;
-            }
-        }
-    } else if (EPI == EPI_SWIGLU) {
-        // rows interleaved at load: 2i = w1 row i (gate), 2i+1 = w3 row i (up)  (gguf/model.rs:220-224)
+        for (int r = 0; r < R; r++) acc[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r + 1 < R; r += 2) {
-            const int n = row0 + r;
-            if (lane == (r >> 1) && n + 1 < N) p.out[(size_t)y * p.out_stride + (n >> 1)] = silu_f(acc[r]) * acc[r + 1];
-        }
-    } else if (EPI == EPI_ROPE_KV) {
-        // fused rows [wq | wk | wv]; interleaved-pair RoPE on q,k (rope.rs:99-141), k/v written into the
-        // pre-allocated cache slot (kv_cache.rs:116-136), q to p.out.
-        const int pos = (p.pos_ptr ? *p.pos_ptr : 0) + p.pos_off;
-        const int hd = p.hd, half = hd >> 1;
+        for (int t = 0; t < KT; t++) {
+            const int c = lane + 64 * t;
+            if (c < nb) {
+                float xv[32];
 #pragma unroll
-        for (int r = 0; r + 1 < R; r += 2) {
-            const int n = row0 + r;
-            if (lane == (r >> 1) && n + 1 < N) {
-                const float a = acc[r], b = acc[r + 1];
-                if (n < p.n_q + p.n_k) {
-                    const int dd = n % hd;
-                    const float c = p.rope_cos[(size_t)pos * half + (dd >> 1)], sn = p.rope_sin[(size_t)pos * half + (dd >> 1)];
-                    const float ra = a * c - b * sn, rb = a * sn + b * c;
-                    if (n < p.n_q) { p.out[n] = ra; p.out[n + 1] = rb; }
-                    else {
-                        const int kn = n - p.n_q, kh = kn / hd;
-                        float* dst = p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd;
-                        dst[0] = ra; dst[1] = rb;
-                    }
-                } else {
-                    const int vn = n - p.n_q - p.n_k, vh = vn / hd, dd = vn % hd;
-                    float* dst = p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd;
-                    dst[0] = a; dst[1] = b;
+                for (int j = 0; j < 8; j++) {
+                    const float4 v = xs[xs_piece(c, j)];
+                    xv[4 * j + 0] = v.x; xv[4 * j + 1] = v.y; xv[4 * j + 2] = v.z; xv[4 * j + 3] = v.w;
+                }
+                const float sx8 = 8.0f * sxs[c];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float d = f16_bits_to_f32(dh[r][t]);
+                    acc[r] = fmaf(d, q4_chunk_dot(q[r][t], xv) - sx8, acc[r]);
                 }
             }
         }
-    } else if (EPI == EPI_ARGMAX) {
-        float best = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int n = row0 + r;
-            if (n < N) {
-                if (p.out && lane == r) p.out[(size_t)y * p.out_stride + n] = acc[r];
-                if (acc[r] > best) { best = acc[r]; bi = n; }   // ascending n: first max wins
+        for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);     // uniform
+
+        // (5) epilogue for rows row0 .. row0+R-1
+        if (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int n = row0 + r;
+                if (lane == r && n < N) {
+                    float v = acc[r];
+                    if (p.bias) v += p.bias[n];
+                    if (EPI == EPI_RESID) v = v + p.resid[(size_t)y * p.resid_stride + n];
+                    if (EPI == EPI_GELU) v = gelu_f(v);
+                    p.out[(size_t)y * p.out_stride + n] = v;
+                }
+            }
+        } else if (EPI == EPI_SWIGLU) {
+            // rows interleaved at load: 2i = w1 row i (gate), 2i+1 = w3 row i (up)  (gguf/model.rs:220-224)
+#pragma unroll
+            for (int r = 0; r + 1 < R; r += 2) {
+                const int n = row0 + r;
+                if (lane == (r >> 1) && n + 1 < N) p.out[(size_t)y * p.out_stride + (n >> 1)] = silu_f(acc[r]) * acc[r + 1];
+            }
+        } else if (EPI == EPI_ROPE_KV) {
+            // fused rows [wq | wk | wv]; interleaved-pair RoPE on q,k (rope.rs:99-141), k/v written into the
+            // pre-allocated cache slot (kv_cache.rs:116-136), q to p.out.
+            const int hd = p.hd, half = hd >> 1;
+#pragma unroll
+            for (int r = 0; r + 1 < R; r += 2) {
+                const int n = row0 + r;
+                if (lane == (r >> 1) && n + 1 < N) {
+                    const float a = acc[r], b = acc[r + 1];
+                    if (n < p.n_q + p.n_k) {
+                        const int dd = n % hd;
+                        const float c = p.rope_cos[(size_t)pos * half + (dd >> 1)], sn = p.rope_sin[(size_t)pos * half + (dd >> 1)];
+                        const float ra = a * c - b * sn, rb = a * sn + b * c;
+                        if (n < p.n_q) { p.out[n] = ra; p.out[n + 1] = rb; }
+                        else {
+                            const int kn = n - p.n_q, kh = kn / hd;
+                            float* dst = p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd;
+                            dst[0] = ra; dst[1] = rb;
+                        }
+                    } else {
+                        const int vn = n - p.n_q - p.n_k, vh = vn / hd, dd = vn % hd;
+                        float* dst = p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd;
+                        dst[0] = a; dst[1] = b;
+                    }
+                }
+            }
+        } else if (EPI == EPI_ARGMAX) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int n = row0 + r;
+                if (n < N) {
+                    if (p.out && lane == r) p.out[(size_t)y * p.out_stride + n] = acc[r];
+                    if (acc[r] > best || (acc[r] == best && n < best_i)) { best = acc[r]; best_i = n; }
+                }
             }
         }
-        if (lane == 0) { red[4 + wave] = best; reinterpret_cast<int*>(red)[8 + wave] = bi; }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int t = 0; t < KT; t++) { q[r][t] = qn[r][t]; dh[r][t] = dn[r][t]; }
+    }
+#undef VOX_WLOAD
+    if (EPI == EPI_ARGMAX) {
+        if (lane == 0) { red[4 + wave] = best; reinterpret_cast<int*>(red)[8 + wave] = best_i; }
         __syncthreads();
         if (tid == 0) {
             float bv = red[4]; int bidx = reinterpret_cast<int*>(red)[8];
@@ -305,19 +337,29 @@ static int env_int(const char* name) { const char* v = getenv(name); return v ? 
 // rows per wave. Tuning knobs (measurement only): VOX_GEMV_R / VOX_GEMV_R_PAIR / VOX_GEMV_R_ARGMAX override the table.
 int q4_gemv_default_R(int N, int K, int epi) {
     const int kt = kt_for(K);
-    if (epi == EPI_ARGMAX) { const int e = env_int("VOX_GEMV_R_ARGMAX"); return e ? e : 8; }
-    if (epi == EPI_SWIGLU || epi == EPI_ROPE_KV) { const int e = env_int("VOX_GEMV_R_PAIR"); if (e) return e; return kt <= 2 ? 4 : 2; }
+    if (epi == EPI_ARGMAX) { const int e = env_int("VOX_GEMV_R_ARGMAX"); return e ? e : 2; }
+    if (epi == EPI_SWIGLU || epi == EPI_ROPE_KV) { const int e = env_int("VOX_GEMV_R_PAIR"); if (e) return e; return 2; }
     { const int e = env_int("VOX_GEMV_R"); if (e) return e; }
-    // plain rows: keep >= ~3 workgroups per CU while every wave has >= 4 loads in flight
     if (kt >= 4) return 1;
-    if ((long)N >= 16384) return 4;
-    return 2;
+    return (long)N >= 16384 ? 2 : 1;
+}
+
+// number of workgroups for a GEMV over N rows with R rows per wave: every wave gets an equal whole number of row
+// groups where possible, at most ~3 workgroups per CU stay resident and stream (persistent waves).
+int q4_gemv_grid(int N, int R) {
+    const int n_groups = (N + R - 1) / R;
+    int target = env_int("VOX_GEMV_WGS"); if (target <= 0) target = 768;
+    int wgs = (n_groups + 3) / 4;
+    if (wgs > target) {
+        const int iters = (n_groups + 4 * target - 1) / (4 * target);
+        wgs = (n_groups + 4 * iters - 1) / (4 * iters);
+    }
+    return wgs < 1 ? 1 : wgs;
 }
 
 template <int KT, int R, int PRO, int EPI>
 static hipError_t gemv_launch_t(const GemvParams& p, int ny, hipStream_t s) {
-    const int rows_per_wg = 4 * R;
-    dim3 grid((p.w.N + rows_per_wg - 1) / rows_per_wg, ny);
+    dim3 grid(q4_gemv_grid(p.w.N, R), ny);
     const size_t lds = (size_t)(p.w.K + p.w.nb + 16) * sizeof(float);
     auto kern = q4_gemv_kernel<KT, R, PRO, EPI>;
     static bool attr_done = false;
@@ -484,7 +526,7 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
             const int m = m0 + mt * 16 + 4 * (lane >> 4) + r;
             float v = acc[mt][r] + bias;
             if (EPI == EPI_SWIGLU) {
-                const float other = __shfl_xor(v, 1, 64);    // rows interleaved: even n = gate, odd n = up
+                const float other = dpp_mov<0xB1>(v);        // lane^1; rows interleaved: even n = gate, odd n = up
                 if (m < M && wrow_ok && !(wn & 1)) p.out[(size_t)m * p.out_stride + (wn >> 1)] = silu_f(v) * other;
             } else if (m < M && wrow_ok) {
                 if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + wn];
@@ -697,10 +739,15 @@ hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
+    // Latency-bound (a few hundred KB of K/V per layer): the structure maximises independent loads in flight.
+    // scores: 8 lanes per key (each lane HD/8 contiguous floats, float4 loads), 32 keys per pass, 2 passes unrolled;
+    // P.V   : 8 key groups x HD/4 float4 columns, 4 keys unrolled.  All loads are unconditional (clamped).
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sc = smem;                 // scores, up to max_seq
+    float* sc = smem;                 // scores / probabilities, up to max_seq
     __shared__ float red[8];
-    __shared__ float osum[256];
+    __shared__ float4 osum[256];
+    static_assert(HD == 128 || HD == 64, "head_dim");
+    constexpr int PER = HD / 8;       // floats per lane in the score phase
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, kvh = h / (p.n_heads / p.n_kv_heads);
     const int pos = (p.pos_ptr ? *p.pos_ptr : 0) + p.offset;
@@ -710,17 +757,33 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     const float scale = 1.0f / sqrtf((float)HD);
     const float* kb = p.k + (size_t)kvh * p.kv_head_stride;
     const float* vb = p.v + (size_t)kvh * p.kv_head_stride;
-    constexpr int PER = HD / 64;
+    const int ks = tid >> 3, part = tid & 7;
     float qv[PER];
 #pragma unroll
-    for (int e = 0; e < PER; e++) qv[e] = p.q[h * HD + lane * PER + e];
-    for (int j = j_lo + wave; j < len; j += 4) {
-        const float* kr = kb + (size_t)j * p.kv_row_stride + lane * PER;
-        float s = 0.f;
+    for (int e = 0; e < PER; e += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p.q + h * HD + part * PER + e);
+        qv[e] = v.x; qv[e + 1] = v.y; qv[e + 2] = v.z; qv[e + 3] = v.w;
+    }
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        float s2[2];
 #pragma unroll
-        for (int e = 0; e < PER; e++) s = fmaf(qv[e], kr[e], s);
-        s = wave_sum(s);
-        if (lane == 0) sc[j - j_lo] = s * scale;
+        for (int u = 0; u < 2; u++) {
+            const int i = i0 + 32 * u + ks, jc = j_lo + min(i, n - 1);
+            const float* kr = kb + (size_t)jc * p.kv_row_stride + part * PER;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < PER; e += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(kr + e);
+                s = fmaf(qv[e], kv.x, s); s = fmaf(qv[e + 1], kv.y, s); s = fmaf(qv[e + 2], kv.z, s); s = fmaf(qv[e + 3], kv.w, s);
+            }
+            s2[u] = s;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const float s = group8_sum(s2[u]);
+            const int i = i0 + 32 * u + ks;
+            if (part == 0 && i < n) sc[i] = s * scale;
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -735,18 +798,31 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     sum = (red[4] + red[5]) + (red[6] + red[7]);
-    // P.V : thread -> (key parity group, d)
-    constexpr int GROUPS = 256 / HD;
-    const int grp = tid / HD, d = tid % HD;
-    float o = 0.f;
-    for (int i = grp; i < n; i += GROUPS) o = fmaf(sc[i], vb[(size_t)(j_lo + i) * p.kv_row_stride + d], o);
+    // P.V : thread -> (key group, float4 column)
+    constexpr int COLS = HD / 4, GROUPS = 256 / COLS;
+    const int grp = tid / COLS, col = tid % COLS;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = grp; i0 < n; i0 += 4 * GROUPS) {
+        float4 vv[4]; float pr[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * GROUPS, ic = min(i, n - 1);
+            vv[u] = *reinterpret_cast<const float4*>(vb + (size_t)(j_lo + ic) * p.kv_row_stride + col * 4);
+            pr[u] = i < n ? sc[ic] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            o.x = fmaf(pr[u], vv[u].x, o.x); o.y = fmaf(pr[u], vv[u].y, o.y); o.z = fmaf(pr[u], vv[u].z, o.z); o.w = fmaf(pr[u], vv[u].w, o.w);
+        }
+    }
     osum[tid] = o;
     __syncthreads();
-    if (tid < HD) {
-        float t = 0.f;
+    if (tid < COLS) {
+        float4 t = osum[tid];
 #pragma unroll
-        for (int g = 0; g < GROUPS; g++) t += osum[g * HD + tid];
-        p.out[h * HD + tid] = t / sum;
+        for (int gq = 1; gq < GROUPS; gq++) { const float4 u = osum[gq * COLS + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float inv = 1.0f / sum;
+        *reinterpret_cast<float4*>(p.out + h * HD + tid * 4) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
     }
 }
 hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s) {
