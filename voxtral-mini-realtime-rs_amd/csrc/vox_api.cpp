@@ -440,7 +440,7 @@ struct vox_model {
     int *d_tokens = nullptr, *d_pos = nullptr; int tokens_cap = 0;
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
     int n_parts = 0, argmax_R = 8;
-    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; const vox_cache* graph_cache = nullptr;
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
     vox_timings timings{};
 };
 
@@ -819,13 +819,13 @@ static int32_t ensure_decode_state(vox_model* m, int S) {
     return VOX_OK;
 }
 
-// one full sync-free decode step: embed(token[cur] + audio[cur]) -> 26 layers -> lm_head -> token[cur+1], cur++
+// one full sync-free decode step. On entry d_h holds the step's input embedding (audio[cur] + embed(token[cur])):
+// 26 layers -> final norm + lm_head (argmax partials) -> fused tail: token[cur+1], cur++, next step's d_h.
 static int32_t decode_step_enqueue(vox_model* m, float* logits_out) {
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
-    HIPCHK(launch_embed(m->tok.w, m->d_tokens, 1, m->d_audio, c.dec_dim, m->d_pos, 0, 0, m->d_h, s));
     VOXCHK(decoder_step_dev(m, m->d_h, m->cache, m->d_pos, 0));
     VOXCHK(lm_head_argmax_dev(m, m->d_h, logits_out));
-    HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, m->n_parts, m->d_tokens, m->d_pos, 1, 1, s));
+    HIPCHK(launch_argmax_embed(m->d_part_val, m->d_part_idx, m->n_parts, m->d_tokens, m->d_pos, m->tok.w, m->d_audio, c.dec_dim, m->d_h, s));
     return VOX_OK;
 }
 
@@ -859,11 +859,12 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     const int pos_init = PREFIX_LEN;
     HIPCHK(hipMemcpyAsync(m->d_pos, &pos_init, 4, hipMemcpyHostToDevice, s));
     HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, m->n_parts, m->d_tokens, m->d_pos, 0, 0, s));   // tokens[38]
+    HIPCHK(launch_embed(m->tok.w, m->d_tokens, 1, m->d_audio, c.dec_dim, m->d_pos, 0, 0, m->d_h, s));        // input of the first decode step
     const int steps = S - PREFIX_LEN - 1;                                         // pos = 39 .. S-1 (model.rs:938)
     if (logits_host) {
         for (int i = 0; i < steps; i++) VOXCHK(decode_step_enqueue(m, d_logits_all + (size_t)(i + 1) * c.vocab));
     } else if (steps > 0) {
-        if (!m->graph_exec || m->graph_cache != m->cache) {
+        if (!m->graph_exec || m->graph_cache != m->cache || m->graph_audio != m->d_audio) {   // the graph bakes these pointers in
             if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
             VOXCHK(decode_step_enqueue(m, nullptr));                               // eager first step (also warms function attributes)
@@ -874,7 +875,7 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
             if (r != VOX_OK) return r;
             HIPCHK(ce);
             HIPCHK(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
-            m->graph_cache = m->cache;
+            m->graph_cache = m->cache; m->graph_audio = m->d_audio;
             for (int i = 1; i < steps; i++) HIPCHK(hipGraphLaunch(m->graph_exec, s));
             m->timings.graph_replays = steps - 1;
         } else {

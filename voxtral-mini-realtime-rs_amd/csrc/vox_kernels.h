@@ -89,6 +89,9 @@ hipError_t launch_embed(Q4W tok, const int* ids, int n, const float* audio, int 
 // final argmax over per-workgroup partials (lowest index wins ties); writes tokens[*pos_ptr+tok_off], then *pos_ptr += inc
 hipError_t launch_argmax_final(const float* part_val, const int* part_idx, int n_parts, int* tokens, int* pos_ptr,
                                int tok_off, int inc, hipStream_t s);
+// fused decode-step tail: tokens[*pos+1] = argmax(partials); *pos += 1; h = audio[*pos] + dequant(tok[tokens[*pos]])
+hipError_t launch_argmax_embed(const float* part_val, const int* part_idx, int n_parts, int* tokens, int* pos_ptr, Q4W tok,
+                               const float* audio, int D, float* h, hipStream_t s);
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
 hipError_t launch_gelu(float* x, long n, hipStream_t s);
 

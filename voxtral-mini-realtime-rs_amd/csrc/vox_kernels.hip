@@ -555,19 +555,37 @@ hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
 __global__ __launch_bounds__(256) void rms_norm_kernel(const float* __restrict__ x, int x_stride, int rows, int dim,
                                                        const float* __restrict__ gamma, const float* __restrict__ mul,
                                                        float eps, float* __restrict__ out, int out_stride) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* xr = x + (size_t)row * x_stride;
+    // one wave per row; dim % 4 == 0; the row is held in registers (up to 16 float4 per lane = dim <= 4096) so x is
+    // read once, with all loads of the row issued together.
+    const int row = min(blockIdx.x * 4 + (threadIdx.x >> 6), rows - 1), lane = threadIdx.x & 63;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
+    const int n4 = dim >> 2;
+    float4 v[16];
     float ss = 0.f;
-    for (int i = lane; i < dim; i += 64) ss += xr[i] * xr[i];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int c = lane + 64 * i;
+        v[i] = xr[min(c, n4 - 1)];
+        if (c < n4) ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    for (int c = lane + 1024; c < n4; c += 64) { const float4 t = xr[c]; ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w); }   // dim > 4096
     ss = wave_sum(ss);
     const float rms = sqrtf(ss / (float)dim + eps);
-    float* o = out + (size_t)row * out_stride;
-    for (int i = lane; i < dim; i += 64) {
-        float v = (xr[i] / rms) * gamma[i];
-        if (mul) v *= mul[i];
-        o[i] = v;
+    float4* o = reinterpret_cast<float4*>(out + (size_t)row * out_stride);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* m4 = reinterpret_cast<const float4*>(mul);
+#define VOX_RMS_OUT(T_, C_)                                                                                     \
+    { float4 t = (T_); const float4 gm = g4[C_];                                                                \
+      t.x = (t.x / rms) * gm.x; t.y = (t.y / rms) * gm.y; t.z = (t.z / rms) * gm.z; t.w = (t.w / rms) * gm.w;   \
+      if (mul) { const float4 mm = m4[C_]; t.x *= mm.x; t.y *= mm.y; t.z *= mm.z; t.w *= mm.w; }               \
+      o[C_] = t; }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int c = lane + 64 * i;
+        if (c < n4) VOX_RMS_OUT(v[i], c)
     }
+    for (int c = lane + 1024; c < n4; c += 64) VOX_RMS_OUT(xr[c], c)
+#undef VOX_RMS_OUT
 }
 hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul, float eps,
                            float* out, int out_stride, hipStream_t s) {
@@ -1036,6 +1054,55 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
 hipError_t launch_argmax_final(const float* pv, const int* pi, int n_parts, int* tokens, int* pos_ptr, int tok_off, int inc,
                                hipStream_t s) {
     argmax_final_kernel<<<dim3(1), dim3(256), 0, s>>>(pv, pi, n_parts, tokens, pos_ptr, tok_off, inc);
+    return hipGetLastError();
+}
+
+// decode-step tail: final argmax over the lm_head partials -> tokens[cur+1]; cur += 1; then the NEXT step's input
+// h = audio[cur] + dequant(tok_emb[tokens[cur]]) (gguf/model.rs:938-948) -- one launch instead of two.
+__global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int n_parts,
+                                                           int* __restrict__ tokens, int* __restrict__ pos_ptr, Q4W tok,
+                                                           const float* __restrict__ audio, int D, float* __restrict__ h) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    __shared__ int s_tok, s_cur;
+    float v = -INFINITY; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n_parts; i += 256) {
+        const float x = pv[i]; const int ii = pi[i];
+        if (x > v || (x == v && ii < idx)) { v = x; idx = ii; }
+    }
+    bv[threadIdx.x] = v; bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            const float x = bv[threadIdx.x + st]; const int ii = bi[threadIdx.x + st];
+            if (x > bv[threadIdx.x] || (x == bv[threadIdx.x] && ii < bi[threadIdx.x])) { bv[threadIdx.x] = x; bi[threadIdx.x] = ii; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int cur = *pos_ptr + 1;
+        tokens[cur] = bi[0]; *pos_ptr = cur; s_tok = bi[0]; s_cur = cur;
+    }
+    __syncthreads();
+    const int id = s_tok;
+    const float4* arow = reinterpret_cast<const float4*>(audio + (size_t)s_cur * D);
+    float4* o = reinterpret_cast<float4*>(h);
+    for (int c = threadIdx.x; c < tok.nb; c += 256) {
+        const uint4 q = tok.qs[(size_t)id * tok.nb + c];
+        const float d = f16_bits_to_f32(tok.sc[(size_t)id * tok.nb + c]);
+        const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t lo = ww[i] & 0x0F0F0F0Fu, hi = (ww[i] >> 4) & 0x0F0F0F0Fu;
+            const float4 a0 = arow[c * 8 + i], a1 = arow[c * 8 + 4 + i];
+            o[c * 8 + i] = make_float4(a0.x + (ub0(lo) - 8.0f) * d, a0.y + (ub1(lo) - 8.0f) * d, a0.z + (ub2(lo) - 8.0f) * d, a0.w + (ub3(lo) - 8.0f) * d);
+            o[c * 8 + 4 + i] = make_float4(a1.x + (ub0(hi) - 8.0f) * d, a1.y + (ub1(hi) - 8.0f) * d, a1.z + (ub2(hi) - 8.0f) * d, a1.w + (ub3(hi) - 8.0f) * d);
+        }
+    }
+}
+hipError_t launch_argmax_embed(const float* pv, const int* pi, int n_parts, int* tokens, int* pos_ptr, Q4W tok, const float* audio, int D,
+                               float* h, hipStream_t s) {
+    argmax_embed_kernel<<<dim3(1), dim3(256), 0, s>>>(pv, pi, n_parts, tokens, pos_ptr, tok, audio, D, h);
     return hipGetLastError();
 }
 
