@@ -52,6 +52,7 @@ def full_gguf_path(pkg, seed, rank, barrier):
 def cpu_baseline(pkg, gguf_path, seconds):
     """CPU restatement of the reference path (oracle, kind 'port') on this box's host cores, on a bounded
     sample: the full pipeline on a `seconds`-long clip (same pad/mel/encoder/decoder, fewer positions)."""
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 8, 64)))   # threads actually used are reported as `cores`
     import oracle_lib as orc
     orc.build()
     m = orc.Model(gguf_path)

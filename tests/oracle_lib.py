@@ -57,6 +57,8 @@ def lib():
         return _lib
     if not os.path.exists(SO):
         build()
+    # the oracle's OpenMP regions are tiny for the small parity models; a 256-thread team makes them slower, not faster
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 8, 32)))
     L = C.CDLL(SO)
     vp = C.c_void_p
     sig = {

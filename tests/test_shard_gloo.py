@@ -1,0 +1,69 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the utterance-sharding layer used for N > 1 GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def test_lpt_partition(pkg):
+    shard = __import__("importlib").import_module(pkg.__name__ + ".shard")
+    rng = np.random.default_rng(7)
+    dur = np.clip(rng.lognormal(np.log(10.0), 0.5, 647), 3, 30)      # FLEURS-like durations
+    parts = shard.lpt_partition(dur, 8)
+    assert sorted(i for p in parts for i in p) == list(range(647))
+    assert shard.imbalance(dur, parts) < 0.02                         # < 2 % LPT imbalance over 8 ranks
+    assert shard.lpt_partition([], 4) == [[], [], [], []]
+    assert shard.lpt_partition([5.0], 2) == [[0], []]
+    assert shard.lpt_partition(dur, 8) == parts                       # deterministic
+    out = shard.run_sharded(list(range(5)), [1] * 5, lambda x: x * x, 0, 1)
+    assert out == [0, 1, 4, 9, 16]
+
+
+def _worker(rank, world, port, pkg_dir, q):
+    import importlib.util, sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("shard", os.path.join(pkg_dir, "shard.py"))
+    shard = importlib.util.module_from_spec(spec); spec.loader.exec_module(shard)
+    items = [f"utt{i}" for i in range(11)]
+    costs = [3.0 + (i * 7) % 11 for i in range(11)]
+    seen = []
+
+    def work(name):
+        seen.append(name)
+        return f"{name}:rank{rank}"
+
+    out = shard.run_sharded(items, costs, work, rank, world)
+    # bench.py-style timing reduction: barrier, max over ranks
+    import torch
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.barrier(); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, out, seen, float(t.item())))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_run_sharded_world2_gloo(pkg):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn"); q = ctx.Queue()
+    pkg_dir = os.path.dirname(pkg.__file__)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, pkg_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out, seen, tmax = q.get(timeout=180)
+        res[rank] = (out, seen, tmax)
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    out0, seen0, t0 = res[0]; out1, seen1, t1 = res[1]
+    assert out1 is None and len(out0) == 11
+    assert [o.split(":")[0] for o in out0] == [f"utt{i}" for i in range(11)]        # input order preserved
+    assert sorted(seen0 + seen1) == sorted(f"utt{i}" for i in range(11)) and not set(seen0) & set(seen1)
+    assert t0 == t1 == 2.0                                                            # max over ranks
+    for o in out0:
+        name, rk = o.split(":rank")
+        assert name in (seen0 if rk == "0" else seen1)

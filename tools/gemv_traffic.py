@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""PMC target: only the dominant decode GEMV (w1|w3) and lm_head, so FETCH_SIZE / WRITE_SIZE per launch can be read off."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench
+from __graft_entry__ import load_package
+pkg = load_package(); ctx = pkg.Context(0)
+path = bench.full_gguf_path(pkg, 42, 0, lambda: None)
+model = pkg.Q4ModelLoader.from_file(path).load(ctx)
+for which, iters in ((2, 104), (4, 16)):
+    us, nbytes, kn = model.bench_decode_gemv(which, iters)
+    print(which, kn, round(us, 2), "us", int(nbytes), "B", flush=True)
+model.close()

@@ -1,0 +1,51 @@
+"""Multi-GPU sharding of independent utterances: replicas only, one process per GPU,
+no collective inside encode/decode.  Units of work = utterances (or CLI chunks, which are independent too,
+bin/transcribe.rs:231-265).  Longest-processing-time-first assignment by audio duration (decode cost is
+proportional to S-38 ~ 6.25 * seconds because the reference has no early stop), results gathered by input
+index so the stdout order of `voxtral-transcribe` (one line per input, transcribe.rs:112-126) is preserved.
+
+torch.distributed is imported lazily so the single-GPU path never needs it."""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+
+def lpt_partition(costs: Sequence[float], world: int) -> list[list[int]]:
+    """Greedy LPT: sort by cost descending, give each item to the least-loaded rank. Deterministic."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    loads = [0.0] * world
+    parts: list[list[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        parts[r].append(i); loads[r] += float(costs[i])
+    for p in parts:
+        p.sort()
+    return parts
+
+
+def imbalance(costs: Sequence[float], parts: list[list[int]]) -> float:
+    loads = [sum(float(costs[i]) for i in p) for p in parts]
+    mean = sum(loads) / max(len(loads), 1)
+    return (max(loads) / mean - 1.0) if mean > 0 else 0.0
+
+
+def run_sharded(items: Sequence, costs: Sequence[float], work: Callable, rank: int, world: int, group=None):
+    """Every rank calls this with the same `items`/`costs`; rank r runs `work(item)` on its LPT share.
+    Returns the full, index-ordered result list on rank 0 (None elsewhere)."""
+    parts = lpt_partition(costs, world)
+    mine = [(i, work(items[i])) for i in parts[rank]]
+    if world == 1:
+        out = [None] * len(items)
+        for i, r in mine:
+            out[i] = r
+        return out
+    import torch.distributed as dist
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = [None] * len(items)
+    for part in gathered:
+        for i, r in part:
+            out[i] = r
+    return out
