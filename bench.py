@@ -179,8 +179,19 @@ def main():
             mult = 1 if which == 4 else cfg.dec_layers
             per_step_us += us * mult; per_step_bytes += nbytes * mult
         dom = per["w1w3"]
+        # HBM traffic per launch from the PMC counters: collected offline with rocprofv3 (separate --pmc passes, gfx950 FETCH_SIZE x2
+        # correction) and committed under profiles/; a live run cannot read PMCs, so this is the committed measurement or null.
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = dom["kernel"].replace("KT=", "").replace("R=", " ").replace("PRO=", " ").replace("EPI=", " ").replace(",", ",")
+            for k, v in pm["hbm_bytes_per_launch"].items():
+                if k.replace(" ", "") == key.replace(" ", ""):
+                    traffic, traffic_src = int(v), pm["source"]
+        except Exception:
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["avg_us"],
                            "all_decode_gemvs": per,
                            "decode_step_gemv_GBps": round(per_step_bytes / per_step_us / 1e3, 1),
