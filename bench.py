@@ -184,7 +184,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = dom["kernel"].replace("KT=", "").replace("R=", " ").replace("PRO=", " ").replace("EPI=", " ").replace(",", ",")
+            key = dom["kernel"].replace("P=", "").replace("R=", " ").replace("PRO=", " ").replace("EPI=", " ").replace(",", ",")
             for k, v in pm["hbm_bytes_per_launch"].items():
                 if k.replace(" ", "") == key.replace(" ", ""):
                     traffic, traffic_src = int(v), pm["source"]

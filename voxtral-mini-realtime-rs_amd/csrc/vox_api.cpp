@@ -988,6 +988,8 @@ extern "C" int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out) {
 
 // ---- measurement hook: average launch duration of one decode-step GEMV class, HIP events on the ctx stream
 extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t iters, double* avg_us, double* bytes_per_launch, const char** kernel_name) {
+    const bool warm = (which & 0x100) != 0;   // measurement variant: same layer every launch (weights stay in L2 / Infinity Cache)
+    which &= 0xff;
     ARGCHK(m && avg_us && bytes_per_launch && iters > 0 && which >= 0 && which <= 4, "bad argument"); VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
     VOXCHK(ensure_decode_state(m, 64));
@@ -998,6 +1000,7 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
     const int D = c.dec_dim, QD = c.dec_heads * c.dec_head_dim, KD = c.dec_kv_heads * c.dec_head_dim, F = c.dec_ffn, hd = c.dec_head_dim;
     const size_t lf = cache_layer_floats(m, m->cache);
     auto launch = [&](int l) -> int32_t {
+        if (warm) l = 0;
         const DecLayer& L = m->dec[l % c.dec_layers]; GemvParams p{};
         switch (which) {
         case 0: p.w = L.wqkv.w; p.x = m->d_h; p.x_stride = D; p.out = m->d_q; p.out_stride = QD; p.gamma = L.attn_norm; p.eps = c.norm_eps; p.pos_ptr = m->d_pos;

@@ -140,8 +140,12 @@ hipError_t launch_q4_dequant(Q4W w, float* out, hipStream_t s) {
 // lanes of one ds_read_b128 service group then hit 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int xs_piece(int c, int j) { return c * 8 + (j ^ ((c >> 1) & 7)); }
 
-template <int KT, int R, int PRO, int EPI>
+// P = passes per row group: the R rows of a group are one contiguous run of R*nb 16-byte chunks, walked 64 chunks
+// (one dwordx4 per lane) at a time, so every lane is busy in every pass even when K is not a multiple of 2048
+// (K = 3072: R = 2 -> exactly 3 passes).  Requires N % R == 0 and R*nb <= 64*P.
+template <int P, int R, int PRO, int EPI>
 __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
+    constexpr int NX = (2 * P + R - 1) / R;        // float4 activation pieces per thread (K <= 1024 * NX)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = p.w.K, nb = p.w.nb, N = p.w.N;
     float4* xs = reinterpret_cast<float4*>(smem);  // K floats, swizzled
@@ -151,54 +155,61 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     const int y = blockIdx.y;
     const float* __restrict__ xg = p.x + (size_t)y * p.x_stride;
     const int npieces = K >> 2;
-    // persistent waves: wave w handles row groups g = w, w + n_waves, ... (R rows each) with the NEXT group's weight
-    // loads issued before the current group is consumed, so HBM stays busy while the VALU works.
-    const int n_groups = (N + R - 1) / R, n_waves = gridDim.x * 4;
+    // persistent waves: wave w handles row groups g = w, w + n_waves, ... with the NEXT group's weight loads issued
+    // before the current group is consumed, so HBM stays busy while the VALU works.
+    const int rnb = R * nb, n_groups = N / R, n_waves = gridDim.x * 4;
     int g = blockIdx.x * 4 + wave;
 
     // Every global load below is UNCONDITIONAL (indices are clamped, never predicated): a "cond ? load : 0"
     // makes hipcc branch around the load and drain vmcnt(0) per element, which serialises HBM round trips.
     // (1) activation pieces (+ norm weights) first -- VMEM returns in order, so they land first ...
-    float4 xp[2 * KT], gp[PRO != PRO_NONE ? 2 * KT : 1], mp[PRO == PRO_RMS_MUL ? 2 * KT : 1];
+    float4 xp[NX], gp[PRO != PRO_NONE ? NX : 1], mp[PRO == PRO_RMS_MUL ? NX : 1];
 #pragma unroll
-    for (int i = 0; i < 2 * KT; i++) {
+    for (int i = 0; i < NX; i++) {
         const int pc = min(tid + 256 * i, npieces - 1);
         xp[i] = reinterpret_cast<const float4*>(xg)[pc];
         if (PRO != PRO_NONE) gp[i] = reinterpret_cast<const float4*>(p.gamma)[pc];
         if (PRO == PRO_RMS_MUL) mp[i] = reinterpret_cast<const float4*>(p.mul)[pc];
     }
+    // per-pass lane constants: chunk-in-group -> (row in group, chunk in row)
+    int vcl[P], cp[P], rp[P]; bool okp[P];
+#pragma unroll
+    for (int q_ = 0; q_ < P; q_++) {
+        const int v = lane + 64 * q_;
+        okp[q_] = v < rnb; vcl[q_] = min(v, rnb - 1);
+        rp[q_] = R == 1 ? 0 : vcl[q_] / nb; cp[q_] = vcl[q_] - rp[q_] * nb;
+    }
     // (2) ... then the first row group's weights.
-    uint4 q[R][KT], qn[R][KT];
-    uint16_t dh[R][KT], dn[R][KT];
+    uint4 qa[P], qb[P];
+    uint16_t da[P], db[P];
 #define VOX_WLOAD(Q_, D_, G_)                                                                           \
-    _Pragma("unroll") for (int r = 0; r < R; r++)                                                        \
-        _Pragma("unroll") for (int t = 0; t < KT; t++) {                                                 \
-            const size_t idx = (size_t)min((G_) * R + r, N - 1) * nb + min(lane + 64 * t, nb - 1);       \
-            Q_[r][t] = ld_nt_u4(p.w.qs + idx);                                                           \
-            D_[r][t] = __builtin_nontemporal_load(p.w.sc + idx);                                         \
-        }
-    VOX_WLOAD(q, dh, min(g, n_groups - 1))
+    _Pragma("unroll") for (int q_ = 0; q_ < P; q_++) {                                                   \
+        const size_t idx = (size_t)(G_) * rnb + vcl[q_];                                                 \
+        Q_[q_] = ld_nt_u4(p.w.qs + idx);                                                                 \
+        D_[q_] = __builtin_nontemporal_load(p.w.sc + idx);                                               \
+    }
+    VOX_WLOAD(qa, da, min(g, n_groups - 1))
 
     // (3) prologue on the activation vector (RMSNorm (+Ada multiplier) fused), staged to LDS.
     float rms = 1.0f;
     if (PRO != PRO_NONE) {
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2 * KT; i++)
+        for (int i = 0; i < NX; i++)
             if (tid + 256 * i < npieces) ss += xp[i].x * xp[i].x + xp[i].y * xp[i].y + xp[i].z * xp[i].z + xp[i].w * xp[i].w;
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
         ss = red[0] + red[1] + red[2] + red[3];
-        rms = sqrtf(ss / (float)K + p.eps);   // burn RmsNorm: sqrt(mean(x^2) + eps)
+        rms = 1.0f / sqrtf(ss / (float)K + p.eps);   // burn RmsNorm divides by sqrt(mean(x^2) + eps); we multiply by the reciprocal
     }
 #pragma unroll
-    for (int i = 0; i < 2 * KT; i++) {
+    for (int i = 0; i < NX; i++) {
         const int pc = tid + 256 * i;           // pieces come in whole groups of 8 lanes (K % 32 == 0)
         float4 v = xp[i];
         if (PRO != PRO_NONE) {
             const float4 gm = gp[i];
-            v.x = (v.x / rms) * gm.x; v.y = (v.y / rms) * gm.y; v.z = (v.z / rms) * gm.z; v.w = (v.w / rms) * gm.w;
+            v.x = (v.x * rms) * gm.x; v.y = (v.y * rms) * gm.y; v.z = (v.z * rms) * gm.z; v.w = (v.w * rms) * gm.w;
             if (PRO == PRO_RMS_MUL) {
                 const float4 m = mp[i];
                 v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
@@ -216,96 +227,96 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     float best = -INFINITY; int best_i = 0x7fffffff;   // EPI_ARGMAX running (max, first index) of this wave
     const int pos = (EPI == EPI_ROPE_KV) ? (p.pos_ptr ? *p.pos_ptr : 0) + p.pos_off : 0;
 
-    // (4) stream the row groups
-    for (; g < n_groups; g += n_waves) {
-        VOX_WLOAD(qn, dn, min(g + n_waves, n_groups - 1))     // prefetch the next group (clamped: harmless re-read at the tail)
-        const int row0 = g * R;
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < KT; t++) {
-            const int c = lane + 64 * t;
-            if (c < nb) {
-                float xv[32];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float4 v = xs[xs_piece(c, j)];
-                    xv[4 * j + 0] = v.x; xv[4 * j + 1] = v.y; xv[4 * j + 2] = v.z; xv[4 * j + 3] = v.w;
-                }
-                const float sx8 = 8.0f * sxs[c];
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const float d = f16_bits_to_f32(dh[r][t]);
-                    acc[r] = fmaf(d, q4_chunk_dot(q[r][t], xv) - sx8, acc[r]);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);     // uniform
+    // (4)+(5) consume one row group from registers (Q_, D_) and run its epilogue
+#define VOX_GROUP(Q_, D_, G_)                                                                                          \
+    {                                                                                                                  \
+        const int row0 = (G_) * R;                                                                                     \
+        float acc[R];                                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < R; r++) acc[r] = 0.f;                                                    \
+        _Pragma("unroll") for (int q_ = 0; q_ < P; q_++) {                                                             \
+            if (okp[q_]) {                                                                                             \
+                float xv[32];                                                                                          \
+                _Pragma("unroll") for (int j = 0; j < 8; j++) {                                                        \
+                    const float4 v = xs[xs_piece(cp[q_], j)];                                                          \
+                    xv[4 * j + 0] = v.x; xv[4 * j + 1] = v.y; xv[4 * j + 2] = v.z; xv[4 * j + 3] = v.w;                \
+                }                                                                                                      \
+                const float val = f16_bits_to_f32(D_[q_]) * (VOX_DOT(Q_[q_], xv) - 8.0f * sxs[cp[q_]]);                \
+                _Pragma("unroll") for (int r = 0; r < R; r++) acc[r] += (R == 1 || rp[q_] == r) ? val : 0.f;           \
+            }                                                                                                          \
+        }                                                                                                              \
+        VOX_REDUCE                                                                                                     \
+        if (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_GELU) {                                                 \
+            _Pragma("unroll") for (int r = 0; r < R; r++) {                                                            \
+                const int n = row0 + r;                                                                                \
+                if (lane == r) {                                                                                       \
+                    float v = acc[r];                                                                                  \
+                    if (p.bias) v += p.bias[n];                                                                        \
+                    if (EPI == EPI_RESID) v = v + p.resid[(size_t)y * p.resid_stride + n];                             \
+                    if (EPI == EPI_GELU) v = gelu_f(v);                                                                \
+                    p.out[(size_t)y * p.out_stride + n] = v;                                                           \
+                }                                                                                                      \
+            }                                                                                                          \
+        } else if (EPI == EPI_SWIGLU) { /* rows interleaved at load: 2i = w1 row i (gate), 2i+1 = w3 row i (up) */    \
+            _Pragma("unroll") for (int r = 0; r + 1 < R; r += 2) {                                                     \
+                const int n = row0 + r;                                                                                \
+                if (lane == (r >> 1)) p.out[(size_t)y * p.out_stride + (n >> 1)] = silu_f(acc[r]) * acc[r + 1];        \
+            }                                                                                                          \
+        } else if (EPI == EPI_ROPE_KV) { /* [wq|wk|wv]: RoPE pairs (rope.rs:99-141), k/v into the cache slot */        \
+            const int hd = p.hd, half = hd >> 1;                                                                       \
+            _Pragma("unroll") for (int r = 0; r + 1 < R; r += 2) {                                                     \
+                const int n = row0 + r;                                                                                \
+                if (lane == (r >> 1)) {                                                                                \
+                    const float a = acc[r], b = acc[r + 1];                                                            \
+                    if (n < p.n_q + p.n_k) {                                                                           \
+                        const int dd = n % hd;                                                                         \
+                        const float c = p.rope_cos[(size_t)pos * half + (dd >> 1)], sn = p.rope_sin[(size_t)pos * half + (dd >> 1)]; \
+                        const float ra = a * c - b * sn, rb = a * sn + b * c;                                          \
+                        if (n < p.n_q) { p.out[n] = ra; p.out[n + 1] = rb; }                                           \
+                        else {                                                                                         \
+                            const int kn = n - p.n_q, kh = kn / hd;                                                    \
+                            float* dst = p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd;          \
+                            dst[0] = ra; dst[1] = rb;                                                                  \
+                        }                                                                                              \
+                    } else {                                                                                           \
+                        const int vn = n - p.n_q - p.n_k, vh = vn / hd, dd = vn % hd;                                  \
+                        float* dst = p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd;              \
+                        dst[0] = a; dst[1] = b;                                                                        \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }                                                                                                          \
+        } else if (EPI == EPI_ARGMAX) {                                                                                \
+            _Pragma("unroll") for (int r = 0; r < R; r++) {                                                            \
+                const int n = row0 + r;                                                                                \
+                if (p.out && lane == r) p.out[(size_t)y * p.out_stride + n] = acc[r];                                  \
+                if (acc[r] > best || (acc[r] == best && n < best_i)) { best = acc[r]; best_i = n; }                    \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+#ifdef VOX_ABL_NOCONSUME
+#define VOX_DOT(Q_, X_) (__uint_as_float(((Q_).x ^ (Q_).y ^ (Q_).z ^ (Q_).w) & 0x3fffffffu) + (X_)[0])
+#else
+#define VOX_DOT(Q_, X_) q4_chunk_dot(Q_, X_)
+#endif
+#ifdef VOX_ABL_NOREDUCE
+#define VOX_REDUCE _Pragma("unroll") for (int r = 0; r < R; r++) acc[r] = readlane_f(acc[r], 0);
+#else
+#define VOX_REDUCE _Pragma("unroll") for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+#endif
 
-        // (5) epilogue for rows row0 .. row0+R-1
-        if (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_GELU) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int n = row0 + r;
-                if (lane == r && n < N) {
-                    float v = acc[r];
-                    if (p.bias) v += p.bias[n];
-                    if (EPI == EPI_RESID) v = v + p.resid[(size_t)y * p.resid_stride + n];
-                    if (EPI == EPI_GELU) v = gelu_f(v);
-                    p.out[(size_t)y * p.out_stride + n] = v;
-                }
-            }
-        } else if (EPI == EPI_SWIGLU) {
-            // rows interleaved at load: 2i = w1 row i (gate), 2i+1 = w3 row i (up)  (gguf/model.rs:220-224)
-#pragma unroll
-            for (int r = 0; r + 1 < R; r += 2) {
-                const int n = row0 + r;
-                if (lane == (r >> 1) && n + 1 < N) p.out[(size_t)y * p.out_stride + (n >> 1)] = silu_f(acc[r]) * acc[r + 1];
-            }
-        } else if (EPI == EPI_ROPE_KV) {
-            // fused rows [wq | wk | wv]; interleaved-pair RoPE on q,k (rope.rs:99-141), k/v written into the
-            // pre-allocated cache slot (kv_cache.rs:116-136), q to p.out.
-            const int hd = p.hd, half = hd >> 1;
-#pragma unroll
-            for (int r = 0; r + 1 < R; r += 2) {
-                const int n = row0 + r;
-                if (lane == (r >> 1) && n + 1 < N) {
-                    const float a = acc[r], b = acc[r + 1];
-                    if (n < p.n_q + p.n_k) {
-                        const int dd = n % hd;
-                        const float c = p.rope_cos[(size_t)pos * half + (dd >> 1)], sn = p.rope_sin[(size_t)pos * half + (dd >> 1)];
-                        const float ra = a * c - b * sn, rb = a * sn + b * c;
-                        if (n < p.n_q) { p.out[n] = ra; p.out[n + 1] = rb; }
-                        else {
-                            const int kn = n - p.n_q, kh = kn / hd;
-                            float* dst = p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd;
-                            dst[0] = ra; dst[1] = rb;
-                        }
-                    } else {
-                        const int vn = n - p.n_q - p.n_k, vh = vn / hd, dd = vn % hd;
-                        float* dst = p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd;
-                        dst[0] = a; dst[1] = b;
-                    }
-                }
-            }
-        } else if (EPI == EPI_ARGMAX) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int n = row0 + r;
-                if (n < N) {
-                    if (p.out && lane == r) p.out[(size_t)y * p.out_stride + n] = acc[r];
-                    if (acc[r] > best || (acc[r] == best && n < best_i)) { best = acc[r]; best_i = n; }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int t = 0; t < KT; t++) { q[r][t] = qn[r][t]; dh[r][t] = dn[r][t]; }
+    // software-pipelined, unrolled by two so the double buffer needs no register copies
+    while (g < n_groups) {
+        VOX_WLOAD(qb, db, min(g + n_waves, n_groups - 1))     // prefetch (clamped: harmless re-read at the tail)
+        VOX_GROUP(qa, da, g)
+        g += n_waves;
+        if (g >= n_groups) break;
+        VOX_WLOAD(qa, da, min(g + n_waves, n_groups - 1))
+        VOX_GROUP(qb, db, g)
+        g += n_waves;
     }
 #undef VOX_WLOAD
+#undef VOX_GROUP
+#undef VOX_DOT
+#undef VOX_REDUCE
     if (EPI == EPI_ARGMAX) {
         if (lane == 0) { red[4 + wave] = best; reinterpret_cast<int*>(red)[8 + wave] = best_i; }
         __syncthreads();
@@ -330,24 +341,37 @@ static hipError_t ensure_dyn_lds(Kern kern, size_t lds, bool* done) {
     return e;
 }
 
-static inline int kt_for(int K) { return (K + 2047) / 2048; }
-
 static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
 
-// rows per wave. Tuning knobs (measurement only): VOX_GEMV_R / VOX_GEMV_R_PAIR / VOX_GEMV_R_ARGMAX override the table.
+// instantiated (R, P) pairs; P = ceil(R * nb / 64)
+static bool gemv_has(int R, int P) {
+    switch (R) {
+    case 1: return P == 1 || P == 2 || P == 3 || P == 5;
+    case 2: return P == 1 || P == 2 || P == 3 || P == 4 || P == 5 || P == 9;
+    case 4: return P == 1 || P == 2 || P == 6;
+    default: return false;
+    }
+}
+static inline int passes_for(int K, int R) { return (R * (K / 32) + 63) / 64; }
+
+// rows per wave. Prefers the R that fills every pass exactly (R*nb % 64 == 0). Tuning knobs (measurement only):
+// VOX_GEMV_R / VOX_GEMV_R_PAIR / VOX_GEMV_R_ARGMAX override the choice when the (R, P) pair is instantiated.
 int q4_gemv_default_R(int N, int K, int epi) {
-    const int kt = kt_for(K);
-    if (epi == EPI_ARGMAX) { const int e = env_int("VOX_GEMV_R_ARGMAX"); return e ? e : 2; }
-    if (epi == EPI_SWIGLU || epi == EPI_ROPE_KV) { const int e = env_int("VOX_GEMV_R_PAIR"); if (e) return e; return 2; }
-    { const int e = env_int("VOX_GEMV_R"); if (e) return e; }
-    if (kt >= 4) return 1;
-    return (long)N >= 16384 ? 2 : 1;
+    const bool pair = (epi == EPI_SWIGLU || epi == EPI_ROPE_KV);
+    const int e = env_int(epi == EPI_ARGMAX ? "VOX_GEMV_R_ARGMAX" : pair ? "VOX_GEMV_R_PAIR" : "VOX_GEMV_R");
+    if (e && N % e == 0 && gemv_has(e, passes_for(K, e)) && (!pair || e % 2 == 0)) return e;
+    const int nb = K / 32;
+    const int order_exact[3] = {pair ? 2 : 1, pair ? 4 : 2, 4};
+    for (int i = 0; i < 3; i++) { const int R = order_exact[i]; if (N % R == 0 && (R * nb) % 64 == 0 && gemv_has(R, passes_for(K, R))) return R; }
+    const int order_any[3] = {2, pair ? 4 : 1, 4};
+    for (int i = 0; i < 3; i++) { const int R = order_any[i]; if ((!pair || R % 2 == 0) && N % R == 0 && gemv_has(R, passes_for(K, R))) return R; }
+    return 0;   // no instantiation covers this K
 }
 
 // number of workgroups for a GEMV over N rows with R rows per wave: every wave gets an equal whole number of row
 // groups where possible, at most ~3 workgroups per CU stay resident and stream (persistent waves).
 int q4_gemv_grid(int N, int R) {
-    const int n_groups = (N + R - 1) / R;
+    const int n_groups = N / R;
     int target = env_int("VOX_GEMV_WGS"); if (target <= 0) target = 768;
     int wgs = (n_groups + 3) / 4;
     if (wgs > target) {
@@ -357,11 +381,11 @@ int q4_gemv_grid(int N, int R) {
     return wgs < 1 ? 1 : wgs;
 }
 
-template <int KT, int R, int PRO, int EPI>
+template <int P, int R, int PRO, int EPI>
 static hipError_t gemv_launch_t(const GemvParams& p, int ny, hipStream_t s) {
     dim3 grid(q4_gemv_grid(p.w.N, R), ny);
     const size_t lds = (size_t)(p.w.K + p.w.nb + 16) * sizeof(float);
-    auto kern = q4_gemv_kernel<KT, R, PRO, EPI>;
+    auto kern = q4_gemv_kernel<P, R, PRO, EPI>;
     static bool attr_done = false;
     hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
     if (e != hipSuccess) return e;
@@ -369,50 +393,37 @@ static hipError_t gemv_launch_t(const GemvParams& p, int ny, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int KT, int R>
+template <int P, int R>
 static hipError_t gemv_dispatch_pe(const GemvParams& p, int ny, int pro, int epi, hipStream_t s) {
-#define VOX_CASE(P, E) if (pro == P && epi == E) return gemv_launch_t<KT, R, P, E>(p, ny, s)
+#define VOX_CASE(P_, E_) if (pro == P_ && epi == E_) return gemv_launch_t<P, R, P_, E_>(p, ny, s)
     VOX_CASE(PRO_NONE, EPI_STORE); VOX_CASE(PRO_NONE, EPI_RESID); VOX_CASE(PRO_NONE, EPI_GELU);
     VOX_CASE(PRO_RMS, EPI_STORE); VOX_CASE(PRO_RMS, EPI_ARGMAX);
     if (pro == PRO_RMS_MUL && p.mul == nullptr) return hipErrorInvalidValue;
     if (R >= 2) {
         constexpr int R2 = R >= 2 ? R : 2;
-        if (pro == PRO_RMS && epi == EPI_SWIGLU) return gemv_launch_t<KT, R2, PRO_RMS, EPI_SWIGLU>(p, ny, s);
-        if (pro == PRO_RMS_MUL && epi == EPI_SWIGLU) return gemv_launch_t<KT, R2, PRO_RMS_MUL, EPI_SWIGLU>(p, ny, s);
-        if (pro == PRO_NONE && epi == EPI_SWIGLU) return gemv_launch_t<KT, R2, PRO_NONE, EPI_SWIGLU>(p, ny, s);
-        if (pro == PRO_RMS && epi == EPI_ROPE_KV) return gemv_launch_t<KT, R2, PRO_RMS, EPI_ROPE_KV>(p, ny, s);
+        if (pro == PRO_RMS && epi == EPI_SWIGLU) return gemv_launch_t<P, R2, PRO_RMS, EPI_SWIGLU>(p, ny, s);
+        if (pro == PRO_RMS_MUL && epi == EPI_SWIGLU) return gemv_launch_t<P, R2, PRO_RMS_MUL, EPI_SWIGLU>(p, ny, s);
+        if (pro == PRO_NONE && epi == EPI_SWIGLU) return gemv_launch_t<P, R2, PRO_NONE, EPI_SWIGLU>(p, ny, s);
+        if (pro == PRO_RMS && epi == EPI_ROPE_KV) return gemv_launch_t<P, R2, PRO_RMS, EPI_ROPE_KV>(p, ny, s);
     }
 #undef VOX_CASE
     return hipErrorInvalidValue;
 }
 
-template <int KT>
-static hipError_t gemv_dispatch_r(const GemvParams& p, int ny, int pro, int epi, int R, hipStream_t s) {
-    switch (R) {
-    case 1: return gemv_dispatch_pe<KT, 1>(p, ny, pro, epi, s);
-    case 2: return gemv_dispatch_pe<KT, 2>(p, ny, pro, epi, s);
-    case 4: return gemv_dispatch_pe<KT, 4>(p, ny, pro, epi, s);
-    case 8: if (KT <= 2) return gemv_dispatch_pe<(KT <= 2 ? KT : 1), 8>(p, ny, pro, epi, s); return gemv_dispatch_pe<KT, 4>(p, ny, pro, epi, s);
-    default: return hipErrorInvalidValue;
-    }
-}
-
 hipError_t launch_q4_gemv(const GemvParams& p, int ny, int pro, int epi, int R, hipStream_t s) {
-    if (p.w.K % 32 || p.w.K <= 0 || p.w.N <= 0) return hipErrorInvalidValue;
-    const int kt = kt_for(p.w.K);
-    switch (kt) {
-    case 1: return gemv_dispatch_r<1>(p, ny, pro, epi, R, s);
-    case 2: return gemv_dispatch_r<2>(p, ny, pro, epi, R, s);
-    case 3: return gemv_dispatch_r<3>(p, ny, pro, epi, R > 4 ? 4 : R, s);
-    case 4: return gemv_dispatch_r<4>(p, ny, pro, epi, R > 2 ? 2 : R, s);
-    case 5: return gemv_dispatch_r<5>(p, ny, pro, epi, R > 2 ? 2 : R, s);
-    default: return hipErrorInvalidValue;   // K > 10240 is not a shape of this model family
-    }
+    if (p.w.K % 32 || p.w.K <= 0 || p.w.N <= 0 || R <= 0 || p.w.N % R) return hipErrorInvalidValue;
+    const int P = passes_for(p.w.K, R);
+#define VOX_RP(R_, P_) if (R == R_ && P == P_) return gemv_dispatch_pe<P_, R_>(p, ny, pro, epi, s)
+    VOX_RP(1, 1); VOX_RP(1, 2); VOX_RP(1, 3); VOX_RP(1, 5);
+    VOX_RP(2, 1); VOX_RP(2, 2); VOX_RP(2, 3); VOX_RP(2, 4); VOX_RP(2, 5); VOX_RP(2, 9);
+    VOX_RP(4, 1); VOX_RP(4, 2); VOX_RP(4, 6);
+#undef VOX_RP
+    return hipErrorInvalidValue;   // K beyond the instantiated range (this model family: K <= 9216)
 }
 
 const char* q4_gemv_kernel_name(int K, int pro, int epi, int R) {
     static thread_local char buf[96];
-    snprintf(buf, sizeof buf, "q4_gemv_kernel<KT=%d,R=%d,PRO=%d,EPI=%d>", kt_for(K), R, pro, epi);
+    snprintf(buf, sizeof buf, "q4_gemv_kernel<P=%d,R=%d,PRO=%d,EPI=%d>", passes_for(K, R), R, pro, epi);
     return buf;
 }
 
