@@ -144,6 +144,10 @@ int32_t vox_q4_model_load(vox_ctx* ctx, const char* gguf_path, vox_model** out);
  * not read or upload tensor data -- the caller fills the arena (vox_model_arena) e.g. from an RCCL broadcast. */
 #define VOX_LOAD_LAYOUT_ONLY 1u
 int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* gguf_path, uint32_t flags, vox_model** out);
+/* VoxtralModelLoader::from_file(..).load(), models/loader.rs:35-78: the f32 SafeTensors path (F32 / F16 / BF16 tensors,
+ * models/weights.rs:16-66).  Same vox_model handle and the same forward entry points as the Q4 model.  Linear weights are
+ * stored as bf16 on device: exact for the published BF16 checkpoint; F32/F16 inputs must hold bf16-representable values. */
+int32_t vox_f32_model_load(vox_ctx* ctx, const char* safetensors_path, vox_model** out);
 int32_t vox_model_free(vox_model* m);
 int32_t vox_model_config(const vox_model* m, vox_model_cfg* out);
 int32_t vox_model_weight_bytes(const vox_model* m, uint64_t* out);   /* device bytes of the weight arena */

@@ -49,3 +49,14 @@ def fake_mel(T, seed=0, n_mels=128):
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def tiny_f32_pair(seed=9):
+    """(safetensors path for the HIP f32 path, all-F32 GGUF with the same values for the oracle)."""
+    S = load_package().synth; d = S.tiny_dims()
+    st = os.path.join(cache_dir(), f"tiny_f32_{seed}.safetensors"); gg = os.path.join(cache_dir(), f"tiny_f32_{seed}.gguf")
+    if not os.path.exists(st):
+        S.write_synthetic_safetensors(st + ".tmp", d, seed); os.replace(st + ".tmp", st)
+    if not os.path.exists(gg):
+        S.write_synthetic_dense_gguf(gg + ".tmp", d, seed); os.replace(gg + ".tmp", gg)
+    return st, gg, d

@@ -1,0 +1,77 @@
+"""GPU parity of the f32 (SafeTensors) path -- SURVEY.md section 8 row a32 / BASELINE configs[0-1]: VoxtralModelLoader ->
+encode_audio / transcribe (transcribe_f32_with_model, bin/transcribe.rs:362-438) / decoder pieces, against the CPU oracle
+running the same dense weights.  Weights are BF16 on disk like the published checkpoint (exact on both sides);
+tolerance: max|d| <= 2e-4 * max|ref| on hidden states and logits, greedy ids identical up to the first near-tie."""
+import numpy as np
+import pytest
+
+from model_fixtures import fake_mel, rel_err, tiny_f32_pair
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def pair(pkg, orc):
+    ctx = pkg.Context(0)
+    st, gg, dims = tiny_f32_pair()
+    m = pkg.VoxtralModelLoader.from_file(st).load(ctx)
+    o = orc.Model(gg)
+    yield m, o, ctx
+    m.close(); o.close(); ctx.close()
+
+
+def test_f32_loader_and_embed(pkg, pair, tmp_path):
+    m, o, ctx = pair
+    c = m.config
+    assert (c.enc_layers, c.enc_dim, c.enc_heads, c.dec_layers, c.dec_dim, c.dec_heads, c.dec_kv_heads, c.vocab) == (2, 128, 2, 2, 256, 4, 2, 512)
+    ids = np.array([1, 32, 0, 511, 77], dtype=np.int32)
+    assert (m.decoder().embed_tokens_from_ids(ids, 1, 5)[0] == o.embed_tokens(ids)).all()          # exact: bf16 -> f32 row copy
+    S = pkg.synth
+    bad = str(tmp_path / "bad.safetensors")
+    w = np.full((64, 32), 0.1234567, np.float32)                                                     # not bf16-representable
+    tens = [(n, s, "BF16", b) for n, s, b in S.synth_dense_tensors(S.tiny_dims(), 1)]
+    tens = [(n, s, "F32", np.full(s, 0.1234567, np.float32)) if n.endswith("layers.0.attention.wo.weight") and n.startswith("layers.") else (n, s, d, b) for n, s, d, b in tens]
+    S.write_safetensors(bad, tens)
+    with pytest.raises(pkg.VoxError, match="bf16-representable"):
+        pkg.VoxtralModelLoader.from_file(bad).load(ctx)
+    with pytest.raises(pkg.VoxError):
+        pkg.VoxtralModelLoader.from_file(str(tmp_path / "missing.safetensors")).load(ctx)
+    junk = tmp_path / "junk.safetensors"; junk.write_bytes(b"\x10\0\0\0\0\0\0\0not json at all!!")
+    with pytest.raises(pkg.VoxError):
+        pkg.VoxtralModelLoader.from_file(str(junk)).load(ctx)
+
+
+@pytest.mark.parametrize("T", [64, 1144])
+def test_f32_encode_audio(pair, T):
+    m, o, _ = pair
+    mel = fake_mel(T, seed=3 + T)
+    ref = o.encode_audio(mel); out = m.encode_audio(mel[None])
+    assert out.shape == (1,) + ref.shape and rel_err(out[0], ref) < TOL, rel_err(out[0], ref)
+
+
+def test_f32_decoder_pieces(pkg, pair):
+    m, o, _ = pair
+    rng = np.random.default_rng(5); x = (0.5 * rng.standard_normal((12, 256))).astype(np.float32)
+    t = pkg.TimeEmbedding(256).embed(6.0)
+    oc = o.cache(16); ref = np.concatenate([o.forward_hidden_with_cache(x[:8], t, oc)] + [o.forward_hidden_with_cache(x[i:i + 1], t, oc) for i in range(8, 12)])
+    dec = m.decoder(); c = dec.create_cache_preallocated(16)
+    out = np.concatenate([dec.forward_hidden_with_cache(x[None, :8], t, c)[0]] + [dec.forward_hidden_with_cache(x[None, i:i + 1], t, c)[0] for i in range(8, 12)])
+    assert rel_err(out, ref) < TOL, rel_err(out, ref)
+    assert rel_err(dec.lm_head(out[None])[0], o.lm_head(ref)) < TOL
+    o.cache_free(oc)
+
+
+def test_f32_transcribe(pkg, pair):
+    m, o, _ = pair
+    mel = fake_mel(1144, seed=17); t = pkg.TimeEmbedding(256).embed(6.0)
+    rids, rlg = o.transcribe_streaming(mel, t, want_logits=True)
+    ids, lg = m.transcribe_streaming(mel[None], t, return_logits=True)
+    assert len(ids) == len(rids) == 33
+    scale = max(1.0, np.abs(rlg).max())
+    assert np.abs(lg - rlg).max() <= TOL * scale
+    srt = np.sort(rlg, axis=1); safe = (srt[:, -1] - srt[:, -2]) > 10 * TOL * scale
+    stop = len(safe) if safe.all() else int(np.argmin(safe))
+    assert stop > 0 and (ids[:stop] == rids[:stop]).all()                  # greedy ids identical to the CPU reference
+    ids_g = m.transcribe_streaming(mel[None], t)                            # graph-replayed decode
+    assert (ids_g == ids).all() and (m.transcribe_streaming(mel[None], t) == ids).all()

@@ -12,6 +12,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -460,78 +461,199 @@ struct Arena {
 #define TOK_NAME EMB_PFX ".tok_embeddings.weight"                               /* models/weights.rs:225 */
 #define ADP_PFX EMB_PFX ".audio_language_projection"                            /* models/weights.rs:227 */
 
+// ---- tensor sources: GGUF (Q4 path) and SafeTensors (f32 path) behind one lookup ----------------------------
+enum { DT_F32 = 0, DT_F16 = 1, DT_Q4_0 = 2, DT_BF16 = 3 };
+struct TensorView { std::vector<uint64_t> shape; int dtype = 0; const uint8_t* data = nullptr; uint64_t nbytes = 0; };   // shape in PyTorch order
+struct TensorSource {
+    virtual ~TensorSource() {}
+    virtual bool find(const std::string& name, TensorView* out) const = 0;
+    virtual uint64_t max_q4_bytes() const { return 0; }
+};
+struct GgufSource : TensorSource {
+    vox_gguf* g = nullptr;
+    ~GgufSource() override { if (g) vox_gguf_close(g); }
+    bool find(const std::string& name, TensorView* out) const override {
+        const GTensor* t = g->find(name); if (!t) return false;
+        out->shape.assign(t->dims, t->dims + t->ndims); std::reverse(out->shape.begin(), out->shape.end());   // gguf/loader.rs:497-499
+        out->dtype = (int)t->dtype; out->data = g->data(t); out->nbytes = t->nbytes; return true;
+    }
+    uint64_t max_q4_bytes() const override { uint64_t m = 0; for (auto& t : g->tensors) if (t.dtype == 2) m = std::max<uint64_t>(m, t.nbytes); return m; }
+};
+// SafeTensors: u64 header length, JSON header {"name": {"dtype": "BF16", "shape": [..], "data_offsets": [a, b]}, ...}, raw data
+// (models/weights.rs:16-66 load_tensor accepts F32 / F16 / BF16).
+struct SafeTensorsSource : TensorSource {
+    uint8_t* map = nullptr; size_t size = 0; std::map<std::string, TensorView> tensors;
+    ~SafeTensorsSource() override { if (map) munmap(map, size); }
+    bool find(const std::string& name, TensorView* out) const override { auto it = tensors.find(name); if (it == tensors.end()) return false; *out = it->second; return true; }
+    static void skip_ws(const char*& p, const char* e) { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    static bool parse_string(const char*& p, const char* e, std::string* out) {
+        skip_ws(p, e); if (p >= e || *p != '"') return false; p++; out->clear();
+        while (p < e && *p != '"') { if (*p == '\\' && p + 1 < e) { p++; } out->push_back(*p++); }
+        if (p >= e) return false; p++; return true;
+    }
+    static bool skip_value(const char*& p, const char* e) {   // any JSON value (used for __metadata__)
+        skip_ws(p, e); if (p >= e) return false;
+        if (*p == '"') { std::string s; return parse_string(p, e, &s); }
+        if (*p == '{' || *p == '[') {
+            const char open = *p, close = open == '{' ? '}' : ']'; int depth = 0;
+            while (p < e) {
+                if (*p == '"') { std::string s; if (!parse_string(p, e, &s)) return false; continue; }
+                if (*p == open) depth++; else if (*p == close) { depth--; if (depth == 0) { p++; return true; } }
+                p++;
+            }
+            return false;
+        }
+        while (p < e && *p != ',' && *p != '}' && *p != ']') p++;
+        return true;
+    }
+    int32_t open(const char* path) {
+        int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return fail(VOX_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+        struct stat st; fstat(fd, &st);
+        void* mp = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0); close(fd);
+        if (mp == MAP_FAILED) return fail(VOX_ERR_IO, "mmap of %s failed", path);
+        map = (uint8_t*)mp; size = st.st_size;
+        if (size < 8) return fail(VOX_ERR_IO, "SafeTensors file too small");
+        uint64_t hlen; std::memcpy(&hlen, map, 8);
+        if (hlen > size - 8) return fail(VOX_ERR_IO, "SafeTensors header length out of range");
+        const char* p = (const char*)map + 8; const char* e = p + hlen; const uint8_t* data0 = map + 8 + hlen; const uint64_t dsize = size - 8 - hlen;
+        skip_ws(p, e); if (p >= e || *p != '{') return fail(VOX_ERR_IO, "SafeTensors header is not a JSON object"); p++;
+        for (;;) {
+            skip_ws(p, e); if (p < e && *p == '}') break;
+            std::string name; if (!parse_string(p, e, &name)) return fail(VOX_ERR_IO, "bad SafeTensors header (key)");
+            skip_ws(p, e); if (p >= e || *p != ':') return fail(VOX_ERR_IO, "bad SafeTensors header (colon)"); p++;
+            if (name == "__metadata__") { if (!skip_value(p, e)) return fail(VOX_ERR_IO, "bad SafeTensors metadata"); }
+            else {
+                skip_ws(p, e); if (p >= e || *p != '{') return fail(VOX_ERR_IO, "bad SafeTensors entry for '%s'", name.c_str()); p++;
+                TensorView tv; std::string dt; uint64_t off[2] = {0, 0}; bool have_dt = false, have_off = false, have_shape = false;
+                for (;;) {
+                    skip_ws(p, e); if (p < e && *p == '}') { p++; break; }
+                    std::string key; if (!parse_string(p, e, &key)) return fail(VOX_ERR_IO, "bad SafeTensors entry key");
+                    skip_ws(p, e); if (p >= e || *p != ':') return fail(VOX_ERR_IO, "bad SafeTensors entry"); p++;
+                    if (key == "dtype") { if (!parse_string(p, e, &dt)) return fail(VOX_ERR_IO, "bad dtype"); have_dt = true; }
+                    else if (key == "shape" || key == "data_offsets") {
+                        skip_ws(p, e); if (p >= e || *p != '[') return fail(VOX_ERR_IO, "bad array"); p++;
+                        std::vector<uint64_t> v;
+                        for (;;) { skip_ws(p, e); if (p < e && *p == ']') { p++; break; } char* q; v.push_back(strtoull(p, &q, 10)); if (q == p) return fail(VOX_ERR_IO, "bad number"); p = q; skip_ws(p, e); if (p < e && *p == ',') p++; }
+                        if (key == "shape") { tv.shape = v; have_shape = true; } else { if (v.size() != 2) return fail(VOX_ERR_IO, "bad data_offsets"); off[0] = v[0]; off[1] = v[1]; have_off = true; }
+                    } else if (!skip_value(p, e)) return fail(VOX_ERR_IO, "bad SafeTensors value");
+                    skip_ws(p, e); if (p < e && *p == ',') p++;
+                }
+                if (!have_dt || !have_off || !have_shape) return fail(VOX_ERR_IO, "incomplete SafeTensors entry '%s'", name.c_str());
+                if (dt == "F32") tv.dtype = DT_F32; else if (dt == "F16") tv.dtype = DT_F16; else if (dt == "BF16") tv.dtype = DT_BF16;
+                else return fail(VOX_ERR_UNSUPPORTED, "Unsupported dtype %s for tensor '%s'", dt.c_str(), name.c_str());   // weights.rs:60-64
+                if (off[1] < off[0] || off[1] > dsize) return fail(VOX_ERR_IO, "tensor '%s' exceeds file size", name.c_str());
+                uint64_t ne = 1; for (auto d : tv.shape) ne *= d;
+                if (off[1] - off[0] != ne * (tv.dtype == DT_F32 ? 4 : 2)) return fail(VOX_ERR_IO, "tensor '%s' byte size does not match its shape", name.c_str());
+                tv.data = data0 + off[0]; tv.nbytes = off[1] - off[0]; tensors[name] = tv;
+            }
+            skip_ws(p, e); if (p < e && *p == ',') p++;
+        }
+        return VOX_OK;
+    }
+};
+
+static float half_bits_to_f32(uint16_t x) {
+    const uint32_t sign = (uint32_t)(x & 0x8000u) << 16; uint32_t e = (x >> 10) & 0x1f, man = x & 0x3ffu, bits;
+    if (e == 0) { if (!man) bits = sign; else { int k = -1; do { man <<= 1; k++; } while (!(man & 0x400u)); bits = sign | ((uint32_t)(112 - k) << 23) | ((man & 0x3ffu) << 13); } }
+    else if (e == 31) bits = sign | 0x7f800000u | (man << 13); else bits = sign | ((e + 112) << 23) | (man << 13);
+    float f; std::memcpy(&f, &bits, 4); return f;
+}
+static void to_f32(const TensorView& t, uint64_t ne, float* out) {     // weights.rs:16-66 / gguf/loader.rs:443-474
+    if (t.dtype == DT_F32) std::memcpy(out, t.data, ne * 4);
+    else if (t.dtype == DT_F16) { const uint16_t* h = (const uint16_t*)t.data; for (uint64_t i = 0; i < ne; i++) out[i] = half_bits_to_f32(h[i]); }
+    else { const uint16_t* h = (const uint16_t*)t.data; for (uint64_t i = 0; i < ne; i++) { const uint32_t b = (uint32_t)h[i] << 16; std::memcpy(&out[i], &b, 4); } }
+}
+
 namespace {
 struct Loader {
-    vox_model* m; const vox_gguf* g; Arena ar; bool fill; void* staging = nullptr; size_t staging_cap = 0;
+    vox_model* m; const TensorSource* src; Arena ar; bool fill; void* staging = nullptr; size_t staging_cap = 0;
     std::string err;
 
     bool setfail(const std::string& e) { if (err.empty()) err = e; return false; }
-    const GTensor* need(const std::string& name) { const GTensor* t = g->find(name); if (!t) setfail("Tensor '" + name + "' not found"); return t; }
+    bool need(const std::string& name, TensorView* t) { if (!src->find(name, t)) return setfail("Tensor '" + name + "' not found"); return true; }
+    static uint64_t numel(const TensorView& t) { uint64_t n = 1; for (auto d : t.shape) n *= d; return n; }
 
-    // gguf/loader.rs:443-474: F32/F16 -> f32 device array
     const float* f32(const std::string& name, bool required = true) {
-        const GTensor* t = g->find(name);
-        if (!t) { if (required) setfail("Tensor '" + name + "' not found"); return nullptr; }
-        if (t->dtype == 2) { setfail("Cannot load Q4_0 tensor '" + name + "' as f32"); return nullptr; }
-        uint64_t ne = 1; for (uint32_t d = 0; d < t->ndims; d++) ne *= t->dims[d];
+        TensorView t;
+        if (!src->find(name, &t)) { if (required) setfail("Tensor '" + name + "' not found"); return nullptr; }
+        if (t.dtype == DT_Q4_0) { setfail("Cannot load Q4_0 tensor '" + name + "' as f32"); return nullptr; }
+        const uint64_t ne = numel(t);
         float* dst = ar.take<float>(ne);
         if (fill) {
-            std::vector<float> tmp;
-            const void* src = g->data(t);
-            if (t->dtype == 1) {
-                tmp.resize(ne); const uint16_t* h = (const uint16_t*)src;
-                for (uint64_t i = 0; i < ne; i++) {
-                    const uint16_t x = h[i]; const uint32_t sign = (uint32_t)(x & 0x8000u) << 16; uint32_t e = (x >> 10) & 0x1f, man = x & 0x3ffu, bits;
-                    if (e == 0) { if (!man) bits = sign; else { int k = -1; do { man <<= 1; k++; } while (!(man & 0x400u)); bits = sign | ((uint32_t)(112 - k) << 23) | ((man & 0x3ffu) << 13); } }
-                    else if (e == 31) bits = sign | 0x7f800000u | (man << 13); else bits = sign | ((e + 112) << 23) | (man << 13);
-                    std::memcpy(&tmp[i], &bits, 4);
-                }
-                src = tmp.data();
-            }
-            if (hipMemcpy(dst, src, ne * 4, hipMemcpyHostToDevice) != hipSuccess) setfail("hipMemcpy failed for '" + name + "'");
+            std::vector<float> tmp(ne); to_f32(t, ne, tmp.data());
+            if (hipMemcpy(dst, tmp.data(), ne * 4, hipMemcpyHostToDevice) != hipSuccess) setfail("hipMemcpy failed for '" + name + "'");
         }
         return dst;
     }
-    // Q4 linear made of `parts` source tensors; rows concatenated (interleave=false) or interleaved pairwise (true)
-    bool q4(const std::vector<std::string>& parts, bool interleave, Lin* L) {
-        int64_t K = -1, Ntot = 0; std::vector<const GTensor*> ts;
+    // linear made of `parts` source tensors [N_i][K]; rows concatenated (interleave=false) or interleaved (true).
+    // Q4_0 sources -> re-packed Q4 planes; dense sources (BF16, or F16/F32 holding bf16-representable values) -> bf16 plane.
+    bool lin(const std::vector<std::string>& parts, bool interleave, Lin* L, bool require_q4) {
+        int64_t K = -1, Ntot = 0; std::vector<TensorView> ts; int kind = -1;
         for (auto& n : parts) {
-            const GTensor* t = need(n); if (!t) return false;
-            if (t->dtype != 2) return setfail("Expected Q4_0 for '" + n + "'");                    // gguf/loader.rs:393-395
-            if (t->ndims != 2) return setfail("Tensor '" + n + "' is not 2-D");
-            const int64_t k = (int64_t)t->dims[0], nn = (int64_t)t->dims[1];                      // reversed dims (:497-499)
-            if (k % 32) return setfail("Q4_0 tensor '" + n + "' has K not divisible by 32");
-            if (K < 0) K = k; else if (K != k) return setfail("fused Q4 tensors disagree on K");
-            if (interleave && !ts.empty() && nn != (int64_t)ts[0]->dims[1]) return setfail("interleaved Q4 tensors disagree on N");
+            TensorView t; if (!need(n, &t)) return false;
+            if (require_q4 && t.dtype != DT_Q4_0) return setfail("Expected Q4_0 for '" + n + "'");                  // gguf/loader.rs:393-395
+            if (t.shape.size() != 2) return setfail("Tensor '" + n + "' is not 2-D");
+            const int64_t nn = (int64_t)t.shape[0], k = (int64_t)t.shape[1];
+            if (k % 32) return setfail("tensor '" + n + "' has an inner dimension not divisible by 32");
+            if (K < 0) K = k; else if (K != k) return setfail("fused tensors disagree on K");
+            if (interleave && !ts.empty() && nn != (int64_t)ts[0].shape[0]) return setfail("interleaved tensors disagree on N");
+            const int kd = t.dtype == DT_Q4_0 ? 0 : 1;
+            if (kind < 0) kind = kd; else if (kind != kd) return setfail("fused tensors mix Q4_0 and dense dtypes");
             Ntot += nn; ts.push_back(t);
         }
         const int nb = (int)(K / 32);
-        uint4* qs = ar.take<uint4>((size_t)Ntot * nb); uint16_t* sc = ar.take<uint16_t>((size_t)Ntot * nb);
-        L->w = Q4W{qs, sc, (int)Ntot, (int)K, nb};
+        if (kind == 0) {
+            uint4* qs = ar.take<uint4>((size_t)Ntot * nb); uint16_t* sc = ar.take<uint16_t>((size_t)Ntot * nb);
+            L->w = Q4W{qs, sc, (int)Ntot, (int)K, nb, WFMT_Q4_0};
+            if (fill) {
+                int64_t row0 = 0;
+                for (size_t i = 0; i < ts.size(); i++) {
+                    const int64_t nn = (int64_t)ts[i].shape[0];
+                    const int mul = interleave ? (int)ts.size() : 1, add = interleave ? (int)i : (int)row0;
+                    if (upload_repack(m->ctx, ts[i].data, nn * nb, nb, qs, sc, mul, add, staging, staging_cap) != VOX_OK) return setfail(g_err);
+                    row0 += nn;
+                }
+            }
+            return true;
+        }
+        uint16_t* w = ar.take<uint16_t>((size_t)Ntot * K);
+        L->w = Q4W{(const uint4*)w, nullptr, (int)Ntot, (int)K, nb, WFMT_BF16};
         if (fill) {
+            std::vector<uint16_t> host((size_t)Ntot * K);
             int64_t row0 = 0;
             for (size_t i = 0; i < ts.size(); i++) {
-                const int64_t nn = (int64_t)ts[i]->dims[1];
-                const int mul = interleave ? (int)ts.size() : 1, add = interleave ? (int)i : (int)row0;
-                if (upload_repack(m->ctx, g->data(ts[i]), nn * nb, nb, qs, sc, mul, add, staging, staging_cap) != VOX_OK) return setfail(g_err);
+                const int64_t nn = (int64_t)ts[i].shape[0];
+                for (int64_t r = 0; r < nn; r++) {
+                    uint16_t* dst = host.data() + (size_t)(interleave ? r * (int64_t)ts.size() + (int64_t)i : row0 + r) * K;
+                    if (ts[i].dtype == DT_BF16) std::memcpy(dst, (const uint16_t*)ts[i].data + (size_t)r * K, (size_t)K * 2);
+                    else {
+                        for (int64_t k = 0; k < K; k++) {
+                            float f = ts[i].dtype == DT_F32 ? ((const float*)ts[i].data)[(size_t)r * K + k] : half_bits_to_f32(((const uint16_t*)ts[i].data)[(size_t)r * K + k]);
+                            uint32_t b; std::memcpy(&b, &f, 4);
+                            if (b & 0xFFFFu) return setfail("dense weight '" + parts[i] + "' is not bf16-representable: the dense path stores weights as bf16 (the published checkpoint is BF16)");
+                            dst[k] = (uint16_t)(b >> 16);
+                        }
+                    }
+                }
                 row0 += nn;
             }
+            if (hipMemcpy(w, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return setfail("hipMemcpy failed for dense weight");
         }
         return true;
     }
     // concatenated f32 bias (missing parts -> zeros); returns nullptr if none of the parts exist
     const float* bias_cat(const std::vector<std::pair<std::string, int64_t>>& parts) {
-        bool any = false; int64_t tot = 0;
-        for (auto& p : parts) { if (!p.first.empty() && g->find(p.first)) any = true; tot += p.second; }
+        bool any = false; int64_t tot = 0; TensorView t;
+        for (auto& p : parts) { if (!p.first.empty() && src->find(p.first, &t)) any = true; tot += p.second; }
         if (!any) return nullptr;
         float* dst = ar.take<float>(tot);
         if (fill) {
             std::vector<float> host(tot, 0.0f); int64_t o = 0;
             for (auto& p : parts) {
-                const GTensor* t = p.first.empty() ? nullptr : g->find(p.first);
-                if (t) {
-                    if (t->dtype == 0) std::memcpy(host.data() + o, g->data(t), (size_t)p.second * 4);
-                    else if (t->dtype == 1) { setfail("f16 bias not supported for fused projections"); }
+                if (!p.first.empty() && src->find(p.first, &t)) {
+                    if (t.dtype == DT_Q4_0 || (int64_t)numel(t) != p.second) setfail("bias '" + p.first + "' has the wrong dtype or size");
+                    else to_f32(t, (uint64_t)p.second, host.data() + o);
                 }
                 o += p.second;
             }
@@ -553,55 +675,57 @@ struct Loader {
         return dst;
     }
 
-    bool run() {
-        vox_model_cfg& c = m->cfg; char a[320];
+    // q4 == true: the GGUF path (gguf/loader.rs:109-491, linears must be Q4_0); false: the SafeTensors f32 path (models/loader.rs:49-300)
+    bool run(bool q4) {
+        vox_model_cfg& c = m->cfg; char a[320]; TensorView tv;
         // defaults not derivable from shapes: models/config.rs:441-493
         c.enc_head_dim = 64; c.dec_head_dim = 128; c.enc_window = 750; c.dec_window = 8192; c.rope_theta = 1e6f; c.norm_eps = 1e-5f; c.reshape_factor = 4;
         int ne = 0, nd = 0;
-        for (;; ne++) { snprintf(a, sizeof a, ENC_PFX ".transformer.layers.%d.attention.wq.weight", ne); if (!g->find(a)) break; }
-        for (;; nd++) { snprintf(a, sizeof a, "layers.%d.attention.wq.weight", nd); if (!g->find(a)) break; }
-        if (ne == 0 || nd == 0) return setfail("GGUF has no encoder/decoder layers");
+        for (;; ne++) { snprintf(a, sizeof a, ENC_PFX ".transformer.layers.%d.attention.wq.weight", ne); if (!src->find(a, &tv)) break; }
+        for (;; nd++) { snprintf(a, sizeof a, "layers.%d.attention.wq.weight", nd); if (!src->find(a, &tv)) break; }
+        if (ne == 0 || nd == 0) return setfail("model file has no encoder/decoder layers");
         c.enc_layers = ne; c.dec_layers = nd; m->enc.resize(ne); m->dec.resize(nd);
-        const GTensor* cw = need(ENC_PFX ".conv_layers.0.conv.weight"); if (!cw) return false;
-        if (cw->ndims != 3 || cw->dims[0] != 3) return setfail("conv weight must be [out][in][3]");
-        c.n_mels = (int)cw->dims[1]; c.enc_dim = (int)cw->dims[2];
+        TensorView cw; if (!need(ENC_PFX ".conv_layers.0.conv.weight", &cw)) return false;
+        if (cw.shape.size() != 3 || cw.shape[2] != 3) return setfail("conv weight must be [out][in][3]");
+        c.n_mels = (int)cw.shape[1]; c.enc_dim = (int)cw.shape[0];
         m->conv1_w = f32(ENC_PFX ".conv_layers.0.conv.weight"); m->conv1_b = f32(ENC_PFX ".conv_layers.0.conv.bias");
         m->conv2_w = f32(ENC_PFX ".conv_layers.1.conv.weight"); m->conv2_b = f32(ENC_PFX ".conv_layers.1.conv.bias");
-        for (int i = 0; i < ne; i++) {                                                      // gguf/loader.rs:215-260
+        for (int i = 0; i < ne; i++) {                                                      // gguf/loader.rs:215-260, models/loader.rs:84-196
             EncLayer& L = m->enc[i]; std::string p = std::string(ENC_PFX ".transformer.layers.") + std::to_string(i);
             L.attn_norm = f32(p + ".attention_norm.weight"); L.ffn_norm = f32(p + ".ffn_norm.weight");
-            if (!q4({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight"}, false, &L.wqkv)) return false;
+            if (!lin({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight"}, false, &L.wqkv, q4)) return false;
             const int64_t hq = L.wqkv.w.N / 3;
             L.wqkv.bias = bias_cat({{p + ".attention.wq.bias", hq}, {"", hq}, {p + ".attention.wv.bias", hq}});   // wk has no bias (:228)
-            if (!q4({p + ".attention.wo.weight"}, false, &L.wo)) return false;
+            if (!lin({p + ".attention.wo.weight"}, false, &L.wo, q4)) return false;
             L.wo.bias = bias_cat({{p + ".attention.wo.bias", L.wo.w.N}});
-            if (!q4({p + ".feed_forward.w1.weight", p + ".feed_forward.w3.weight"}, true, &L.w13)) return false;
-            if (!q4({p + ".feed_forward.w2.weight"}, false, &L.w2)) return false;
+            if (!lin({p + ".feed_forward.w1.weight", p + ".feed_forward.w3.weight"}, true, &L.w13, q4)) return false;
+            if (!lin({p + ".feed_forward.w2.weight"}, false, &L.w2, q4)) return false;
             L.w2.bias = bias_cat({{p + ".feed_forward.w2.bias", L.w2.w.N}});
         }
         m->enc_norm = f32(ENC_PFX ".transformer.norm.weight");
-        if (!q4({ADP_PFX ".0.weight"}, false, &m->ad0) || !q4({ADP_PFX ".2.weight"}, false, &m->ad2)) return false;    // :378-383
-        if (!q4({TOK_NAME}, false, &m->tok)) return false;   // kept Q4 on device (the reference's WASM branch, gguf/model.rs:689)
+        if (!lin({ADP_PFX ".0.weight"}, false, &m->ad0, q4) || !lin({ADP_PFX ".2.weight"}, false, &m->ad2, q4)) return false;    // :378-383
+        // tok_embeddings: Q4 (kept Q4 on device, the reference's WASM branch gguf/model.rs:689), or dense (F32/F16 accepted, loader.rs:305-326)
+        if (!lin({TOK_NAME}, false, &m->tok, false)) return false;
         for (int i = 0; i < nd; i++) {                                                      // gguf/loader.rs:329-375
             DecLayer& L = m->dec[i]; std::string p = "layers." + std::to_string(i);
-            if (!q4({p + ".ada_rms_norm_t_cond.0.weight"}, false, &L.ada0) || !q4({p + ".ada_rms_norm_t_cond.2.weight"}, false, &L.ada2)) return false;
+            if (!lin({p + ".ada_rms_norm_t_cond.0.weight"}, false, &L.ada0, q4) || !lin({p + ".ada_rms_norm_t_cond.2.weight"}, false, &L.ada2, q4)) return false;
             L.attn_norm = f32(p + ".attention_norm.weight"); L.ffn_norm = f32(p + ".ffn_norm.weight");
-            if (!q4({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight"}, false, &L.wqkv)) return false;
-            if (!q4({p + ".attention.wo.weight"}, false, &L.wo)) return false;
-            if (!q4({p + ".feed_forward.w1.weight", p + ".feed_forward.w3.weight"}, true, &L.w13)) return false;
-            if (!q4({p + ".feed_forward.w2.weight"}, false, &L.w2)) return false;
+            if (!lin({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight"}, false, &L.wqkv, q4)) return false;
+            if (!lin({p + ".attention.wo.weight"}, false, &L.wo, q4)) return false;
+            if (!lin({p + ".feed_forward.w1.weight", p + ".feed_forward.w3.weight"}, true, &L.w13, q4)) return false;
+            if (!lin({p + ".feed_forward.w2.weight"}, false, &L.w2, q4)) return false;
         }
         m->dec_norm = f32("norm.weight");
         if (!err.empty()) return false;
-        // derived dims
-        const GTensor* ewq = g->find(std::string(ENC_PFX ".transformer.layers.0.attention.wq.weight"));
-        const GTensor* dwq = g->find("layers.0.attention.wq.weight"); const GTensor* dwk = g->find("layers.0.attention.wk.weight");
-        c.enc_heads = (int)(ewq->dims[1] / c.enc_head_dim); c.enc_ffn = m->enc[0].w13.w.N / 2;
-        c.dec_dim = (int)dwq->dims[0]; c.dec_heads = (int)(dwq->dims[1] / c.dec_head_dim); c.dec_kv_heads = (int)(dwk->dims[1] / c.dec_head_dim);
+        // derived dims (PyTorch order [out, in])
+        TensorView ewq, dwq, dwk;
+        need(std::string(ENC_PFX ".transformer.layers.0.attention.wq.weight"), &ewq); need("layers.0.attention.wq.weight", &dwq); need("layers.0.attention.wk.weight", &dwk);
+        c.enc_heads = (int)(ewq.shape[0] / c.enc_head_dim); c.enc_ffn = m->enc[0].w13.w.N / 2;
+        c.dec_dim = (int)dwq.shape[1]; c.dec_heads = (int)(dwq.shape[0] / c.dec_head_dim); c.dec_kv_heads = (int)(dwk.shape[0] / c.dec_head_dim);
         c.dec_ffn = m->dec[0].w13.w.N / 2; c.vocab = m->tok.w.N; c.t_cond_dim = m->dec[0].ada0.w.N;
-        if (ewq->dims[1] % c.enc_head_dim || dwq->dims[1] % c.dec_head_dim || dwk->dims[1] % c.dec_head_dim || c.dec_kv_heads == 0 || c.dec_heads % c.dec_kv_heads)
+        if (ewq.shape[0] % c.enc_head_dim || dwq.shape[0] % c.dec_head_dim || dwk.shape[0] % c.dec_head_dim || c.dec_kv_heads == 0 || c.dec_heads % c.dec_kv_heads)
             return setfail("attention projection shapes are not multiples of head_dim");
-        if ((int)ewq->dims[0] != c.enc_dim || m->ad0.w.K != c.enc_dim * c.reshape_factor || m->ad2.w.N != c.dec_dim || m->ad0.w.N != m->ad2.w.K || m->tok.w.K != c.dec_dim)
+        if ((int)ewq.shape[1] != c.enc_dim || m->ad0.w.K != c.enc_dim * c.reshape_factor || m->ad2.w.N != c.dec_dim || m->ad0.w.N != m->ad2.w.K || m->tok.w.K != c.dec_dim)
             return setfail("inconsistent encoder / adapter / embedding shapes");
         if (c.enc_dim % 32 || c.dec_dim % 32) return setfail("model dims must be multiples of 32");
         m->enc_cos = rope(c.enc_head_dim, m->enc_rope_len, c.rope_theta, false); m->enc_sin = rope(c.enc_head_dim, m->enc_rope_len, c.rope_theta, true);
@@ -624,27 +748,21 @@ static void model_release(vox_model* m) {
 }
 extern "C" int32_t vox_model_free(vox_model* m) { model_release(m); return VOX_OK; }
 
-extern "C" int32_t vox_q4_model_load(vox_ctx* ctx, const char* path, vox_model** out) { return vox_q4_model_load_ex(ctx, path, 0, out); }
-
-extern "C" int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* path, uint32_t flags, vox_model** out) {
-    ARGCHK(ctx && path && out, "null argument"); VOXCHK(ctx_bind(ctx));
-    const bool layout_only = (flags & VOX_LOAD_LAYOUT_ONLY) != 0;
-    vox_gguf* g = nullptr; VOXCHK(vox_gguf_open(path, &g));
+// shared tail of both loaders: plan the arena, fill it, allocate the decode-step buffers
+static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool layout_only, vox_model** out) {
     vox_model* m = new vox_model(); m->ctx = ctx;
-    Loader plan{m, g, Arena{}, false};
-    if (!plan.run()) { std::string e = plan.err; vox_gguf_close(g); model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
+    Loader plan{m, src, Arena{}, false};
+    if (!plan.run(q4)) { std::string e = plan.err; model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
     m->arena_bytes = plan.ar.off + 256;
-    if (hipMalloc((void**)&m->arena, m->arena_bytes) != hipSuccess) { vox_gguf_close(g); model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of %.1f MB weight arena failed", m->arena_bytes / 1e6); }
-    size_t max_q4 = 0; for (auto& t : g->tensors) if (t.dtype == 2) max_q4 = std::max<size_t>(max_q4, t.nbytes);
-    DevBuf staging; if (staging.alloc(layout_only ? 16 : max_q4) != hipSuccess) { vox_gguf_close(g); model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of staging buffer failed"); }
-    Loader fillr{m, g, Arena{m->arena, 0}, !layout_only, staging.p, max_q4};
-    if (!fillr.run()) { std::string e = fillr.err; vox_gguf_close(g); model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
-    vox_gguf_close(g);
+    if (hipMalloc((void**)&m->arena, m->arena_bytes) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of %.1f MB weight arena failed", m->arena_bytes / 1e6); }
+    const size_t max_q4 = layout_only ? 16 : std::max<uint64_t>(src->max_q4_bytes(), 16);
+    DevBuf staging; if (staging.alloc(max_q4) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of staging buffer failed"); }
+    Loader fillr{m, src, Arena{m->arena, 0}, !layout_only, staging.p, max_q4};
+    if (!fillr.run(q4)) { std::string e = fillr.err; model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
     const vox_model_cfg& c = m->cfg;
-    // decode-step buffers
     const int qdim = c.dec_heads * c.dec_head_dim;
-    m->argmax_R = q4_gemv_default_R(c.vocab, c.dec_dim, EPI_ARGMAX);
-    m->n_parts = q4_gemv_grid(c.vocab, m->argmax_R);
+    if (m->tok.w.fmt == WFMT_BF16) { m->argmax_R = 2; m->n_parts = dense_gemv_grid(c.vocab); }
+    else { m->argmax_R = q4_gemv_default_R(c.vocab, c.dec_dim, EPI_ARGMAX); m->n_parts = m->argmax_R > 0 ? q4_gemv_grid(c.vocab, m->argmax_R) : 1; }
     hipError_t e = hipSuccess;
     auto A = [&](void** p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n); };
     A((void**)&m->ada_mul, (size_t)c.dec_layers * c.dec_dim * 4); A((void**)&m->d_pos, 64); A((void**)&m->d_h, (size_t)c.dec_dim * 4 * 4);
@@ -654,6 +772,23 @@ extern "C" int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* path, uint32_t
     for (int i = 0; i < c.dec_layers; i++) m->dec[i].ada_mul = m->ada_mul + (size_t)i * c.dec_dim;
     *out = m; return VOX_OK;
 }
+
+extern "C" int32_t vox_q4_model_load(vox_ctx* ctx, const char* path, vox_model** out) { return vox_q4_model_load_ex(ctx, path, 0, out); }
+
+extern "C" int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* path, uint32_t flags, vox_model** out) {
+    ARGCHK(ctx && path && out, "null argument"); VOXCHK(ctx_bind(ctx));
+    GgufSource src; VOXCHK(vox_gguf_open(path, &src.g));
+    return model_build(ctx, &src, true, (flags & VOX_LOAD_LAYOUT_ONLY) != 0, out);
+}
+
+// VoxtralModelLoader::from_file(consolidated.safetensors).load(), models/loader.rs:35-78: the f32 path.  Linear weights are kept
+// as bf16 on device (exact for the published BF16 checkpoint; F32/F16 inputs must hold bf16-representable values).
+extern "C" int32_t vox_f32_model_load(vox_ctx* ctx, const char* path, vox_model** out) {
+    ARGCHK(ctx && path && out, "null argument"); VOXCHK(ctx_bind(ctx));
+    SafeTensorsSource src; VOXCHK(src.open(path));
+    return model_build(ctx, &src, false, false, out);
+}
+
 extern "C" int32_t vox_model_config(const vox_model* m, vox_model_cfg* out) { ARGCHK(m && out, "null argument"); *out = m->cfg; return VOX_OK; }
 extern "C" int32_t vox_model_weight_bytes(const vox_model* m, uint64_t* out) { ARGCHK(m && out, "null argument"); *out = m->arena_bytes; return VOX_OK; }
 extern "C" int32_t vox_model_arena(const vox_model* m, void** p, uint64_t* n) { ARGCHK(m && p && n, "null argument"); *p = m->arena; *n = m->arena_bytes; return VOX_OK; }
@@ -1018,7 +1153,7 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
         return VOX_OK;
     };
     const Q4W* w = which == 0 ? &m->dec[0].wqkv.w : which == 1 ? &m->dec[0].wo.w : which == 2 ? &m->dec[0].w13.w : which == 3 ? &m->dec[0].w2.w : &m->tok.w;
-    *bytes_per_launch = (double)w->N * w->nb * 18.0;     // algorithmic bytes: the Q4_0 blocks of the weight (18 B / 32 elements)
+    *bytes_per_launch = w->fmt == WFMT_BF16 ? (double)w->N * w->K * 2.0 : (double)w->N * w->nb * 18.0;   // algorithmic bytes: Q4_0 blocks (18 B / 32 weights) or bf16
     if (kernel_name) {
         const int epi = which == 0 ? EPI_ROPE_KV : which == 2 ? EPI_SWIGLU : which == 4 ? EPI_ARGMAX : EPI_RESID;
         const int pro = which == 2 ? PRO_RMS_MUL : (which == 0 || which == 4) ? PRO_RMS : PRO_NONE;

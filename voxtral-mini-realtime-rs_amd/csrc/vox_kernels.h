@@ -11,10 +11,12 @@ namespace vox {
 // global_load_dwordx4:  qs[n][b] = the block's 16 nibble bytes (element i <-> low nibble of
 // byte i, element i+16 <-> high nibble), sc[n][b] = the block's f16 scale.
 struct Q4W {
-    const uint4* qs;
-    const uint16_t* sc;  // IEEE f16 bits
+    const uint4* qs;     // fmt 0: nibble chunks [N][nb]; fmt 1: dense bf16 weights [N][K] viewed as uint4 (8 bf16 each)
+    const uint16_t* sc;  // fmt 0: IEEE f16 scale bits [N][nb]; fmt 1: unused (nullptr)
     int N, K, nb;        // nb = K / 32
+    int fmt;             // WFMT_Q4_0 or WFMT_BF16 (the f32 SafeTensors path: the checkpoint is BF16 on disk, exact in bf16)
 };
+enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1 };
 
 enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5 };
 enum Pro { PRO_NONE = 0, PRO_RMS = 1, PRO_RMS_MUL = 2 };   // RMS_MUL: RMSNorm then * mul (the cached Ada scale)
@@ -37,7 +39,8 @@ struct GemvParams {
 hipError_t launch_q4_gemv(const GemvParams& p, int n_rows_x, int pro, int epi, int R, hipStream_t s);
 const char* q4_gemv_kernel_name(int K, int pro, int epi, int R);
 int q4_gemv_default_R(int N, int K, int epi);
-int q4_gemv_grid(int N, int R);   // workgroups launched for N rows at R rows per wave (== number of argmax partials)
+int q4_gemv_grid(int N, int R);
+int dense_gemv_grid(int N);        // same, for WFMT_BF16 weights   // workgroups launched for N rows at R rows per wave (== number of argmax partials)
 
 // ---- Q4 GEMM on MFMA (prefill / encoder, rows of x > 4): out[M][N'] = epi( x[M][K] * W^T )
 struct GemmParams {

@@ -341,6 +341,7 @@ static hipError_t ensure_dyn_lds(Kern kern, size_t lds, bool* done) {
     return e;
 }
 
+static hipError_t launch_dense_gemv(const GemvParams& p, int ny, int pro, int epi, hipStream_t s);
 static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
 
 // instantiated (R, P) pairs; P = ceil(R * nb / 64)
@@ -362,7 +363,11 @@ int q4_gemv_default_R(int N, int K, int epi) {
     if (e && N % e == 0 && gemv_has(e, passes_for(K, e)) && (!pair || e % 2 == 0)) return e;
     const int nb = K / 32;
     const int order_exact[3] = {pair ? 2 : 1, pair ? 4 : 2, 4};
-    for (int i = 0; i < 3; i++) { const int R = order_exact[i]; if (N % R == 0 && (R * nb) % 64 == 0 && gemv_has(R, passes_for(K, R))) return R; }
+    for (int i = 0; i < 3; i++) {   // exact fit, unless it needs so many passes that the register file halves occupancy
+        const int R = order_exact[i];
+        if (N % R == 0 && (R * nb) % 64 == 0 && passes_for(K, R) <= 6 && gemv_has(R, passes_for(K, R))) return R;
+    }
+    if (!pair && gemv_has(1, passes_for(K, 1))) return 1;
     const int order_any[3] = {2, pair ? 4 : 1, 4};
     for (int i = 0; i < 3; i++) { const int R = order_any[i]; if ((!pair || R % 2 == 0) && N % R == 0 && gemv_has(R, passes_for(K, R))) return R; }
     return 0;   // no instantiation covers this K
@@ -370,6 +375,7 @@ int q4_gemv_default_R(int N, int K, int epi) {
 
 // number of workgroups for a GEMV over N rows with R rows per wave: every wave gets an equal whole number of row
 // groups where possible, at most ~3 workgroups per CU stay resident and stream (persistent waves).
+int dense_gemv_grid(int N);
 int q4_gemv_grid(int N, int R) {
     const int n_groups = N / R;
     int target = env_int("VOX_GEMV_WGS"); if (target <= 0) target = 768;
@@ -411,6 +417,7 @@ static hipError_t gemv_dispatch_pe(const GemvParams& p, int ny, int pro, int epi
 }
 
 hipError_t launch_q4_gemv(const GemvParams& p, int ny, int pro, int epi, int R, hipStream_t s) {
+    if (p.w.fmt == WFMT_BF16) return launch_dense_gemv(p, ny, pro, epi, s);
     if (p.w.K % 32 || p.w.K <= 0 || p.w.N <= 0 || R <= 0 || p.w.N % R) return hipErrorInvalidValue;
     const int P = passes_for(p.w.K, R);
 #define VOX_RP(R_, P_) if (R == R_ && P == P_) return gemv_dispatch_pe<P_, R_>(p, ny, pro, epi, s)
@@ -425,6 +432,156 @@ const char* q4_gemv_kernel_name(int K, int pro, int epi, int R) {
     static thread_local char buf[96];
     snprintf(buf, sizeof buf, "q4_gemv_kernel<P=%d,R=%d,PRO=%d,EPI=%d>", passes_for(K, R), R, pro, epi);
     return buf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense bf16 GEMV (the f32 SafeTensors path, models/layers/*.rs with burn::nn::Linear; decode rows <= 4).
+// Weights are the checkpoint's BF16 values (exact), activations and accumulation f32.  HBM-bound like the Q4 GEMV
+// (6.9 GB per token); low register use -> 8 waves/SIMD hide the latency, no explicit pipelining needed.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot8_bf16(const uint4 w, const float4 xa, const float4 xb) {
+    float s0 = __uint_as_float(w.x << 16) * xa.x, s1 = __uint_as_float(w.x & 0xFFFF0000u) * xa.y;
+    s0 = fmaf(__uint_as_float(w.y << 16), xa.z, s0); s1 = fmaf(__uint_as_float(w.y & 0xFFFF0000u), xa.w, s1);
+    s0 = fmaf(__uint_as_float(w.z << 16), xb.x, s0); s1 = fmaf(__uint_as_float(w.z & 0xFFFF0000u), xb.y, s1);
+    s0 = fmaf(__uint_as_float(w.w << 16), xb.z, s0); s1 = fmaf(__uint_as_float(w.w & 0xFFFF0000u), xb.w, s1);
+    return s0 + s1;
+}
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void dense_gemv_kernel(const GemvParams p) {
+    constexpr int NX = 10, R = 2;                  // K <= 10240; one wave = one row pair
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = p.w.K, N = p.w.N, nc = K >> 3;   // 16-byte chunks (8 bf16) per row
+    float4* xe = reinterpret_cast<float4*>(smem);  // x[8c .. 8c+3]
+    float4* xo = xe + nc;                          // x[8c+4 .. 8c+7]   (split so lane-consecutive reads are conflict-free)
+    float* red = smem + K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, y = blockIdx.y;
+    const float* __restrict__ xg = p.x + (size_t)y * p.x_stride;
+    const int npieces = K >> 2;
+    float4 xp[NX];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+        const int pc = tid + 256 * i;
+        xp[i] = reinterpret_cast<const float4*>(xg)[min(pc, npieces - 1)];
+        if (PRO != PRO_NONE && pc < npieces) ss += (xp[i].x * xp[i].x + xp[i].y * xp[i].y) + (xp[i].z * xp[i].z + xp[i].w * xp[i].w);
+    }
+    float rms = 1.0f;
+    if (PRO != PRO_NONE) {
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        rms = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + p.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+        const int pc = tid + 256 * i;
+        if (pc < npieces) {
+            float4 v = xp[i];
+            if (PRO != PRO_NONE) {
+                const float4 gm = reinterpret_cast<const float4*>(p.gamma)[pc];
+                v.x = (v.x * rms) * gm.x; v.y = (v.y * rms) * gm.y; v.z = (v.z * rms) * gm.z; v.w = (v.w * rms) * gm.w;
+                if (PRO == PRO_RMS_MUL) {
+                    const float4 m = reinterpret_cast<const float4*>(p.mul)[pc];
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
+            if (pc & 1) xo[pc >> 1] = v; else xe[pc >> 1] = v;
+        }
+    }
+    __syncthreads();
+    float best = -INFINITY; int best_i = 0x7fffffff;
+    const int pos = (EPI == EPI_ROPE_KV) ? (p.pos_ptr ? *p.pos_ptr : 0) + p.pos_off : 0;
+    const int n_groups = N / R, n_waves = gridDim.x * 4;
+    for (int g = blockIdx.x * 4 + wave; g < n_groups; g += n_waves) {
+        const int row0 = g * R;
+        const uint4* w0 = p.w.qs + (size_t)row0 * nc;
+        const uint4* w1 = w0 + nc;
+        float acc[R] = {0.f, 0.f};
+        for (int c0 = 0; c0 < nc; c0 += 128) {
+            const int ca = c0 + lane, cb = ca + 64, cca = min(ca, nc - 1), ccb = min(cb, nc - 1);
+            const uint4 a0 = ld_nt_u4(w0 + cca), a1 = ld_nt_u4(w0 + ccb), b0 = ld_nt_u4(w1 + cca), b1 = ld_nt_u4(w1 + ccb);
+            const float4 xea = xe[cca], xoa = xo[cca], xeb = xe[ccb], xob = xo[ccb];
+            const float ma = ca < nc ? 1.0f : 0.0f, mb = cb < nc ? 1.0f : 0.0f;
+            acc[0] += ma * dot8_bf16(a0, xea, xoa) + mb * dot8_bf16(a1, xeb, xob);
+            acc[1] += ma * dot8_bf16(b0, xea, xoa) + mb * dot8_bf16(b1, xeb, xob);
+        }
+        acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]);
+        if (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int n = row0 + r;
+                if (lane == r) {
+                    float v = acc[r];
+                    if (p.bias) v += p.bias[n];
+                    if (EPI == EPI_RESID) v = v + p.resid[(size_t)y * p.resid_stride + n];
+                    if (EPI == EPI_GELU) v = gelu_f(v);
+                    p.out[(size_t)y * p.out_stride + n] = v;
+                }
+            }
+        } else if (EPI == EPI_SWIGLU) {
+            if (lane == 0) p.out[(size_t)y * p.out_stride + (row0 >> 1)] = silu_f(acc[0]) * acc[1];
+        } else if (EPI == EPI_ROPE_KV) {
+            const int hd = p.hd, half = hd >> 1, n = row0;
+            if (lane == 0) {
+                const float a = acc[0], b = acc[1];
+                if (n < p.n_q + p.n_k) {
+                    const int dd = n % hd;
+                    const float c = p.rope_cos[(size_t)pos * half + (dd >> 1)], sn = p.rope_sin[(size_t)pos * half + (dd >> 1)];
+                    const float ra = a * c - b * sn, rb = a * sn + b * c;
+                    if (n < p.n_q) { p.out[n] = ra; p.out[n + 1] = rb; }
+                    else {
+                        const int kn = n - p.n_q, kh = kn / hd;
+                        float* dst = p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd;
+                        dst[0] = ra; dst[1] = rb;
+                    }
+                } else {
+                    const int vn = n - p.n_q - p.n_k, vh = vn / hd, dd = vn % hd;
+                    float* dst = p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd;
+                    dst[0] = a; dst[1] = b;
+                }
+            }
+        } else if (EPI == EPI_ARGMAX) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int n = row0 + r;
+                if (p.out && lane == r) p.out[(size_t)y * p.out_stride + n] = acc[r];
+                if (acc[r] > best || (acc[r] == best && n < best_i)) { best = acc[r]; best_i = n; }
+            }
+        }
+    }
+    if (EPI == EPI_ARGMAX) {
+        if (lane == 0) { red[4 + wave] = best; reinterpret_cast<int*>(red)[8 + wave] = best_i; }
+        __syncthreads();
+        if (tid == 0) {
+            float bv = red[4]; int bidx = reinterpret_cast<int*>(red)[8];
+            for (int wv = 1; wv < 4; wv++) {
+                const float v = red[4 + wv]; const int ii = reinterpret_cast<int*>(red)[8 + wv];
+                if (v > bv || (v == bv && ii < bidx)) { bv = v; bidx = ii; }
+            }
+            p.part_val[(size_t)y * gridDim.x + blockIdx.x] = bv;
+            p.part_idx[(size_t)y * gridDim.x + blockIdx.x] = bidx;
+        }
+    }
+}
+
+int dense_gemv_grid(int N) { const int wgs = (N / 2 + 3) / 4; return wgs > 2048 ? 2048 : (wgs < 1 ? 1 : wgs); }
+
+template <int PRO, int EPI>
+static hipError_t dense_launch_t(const GemvParams& p, int ny, hipStream_t s) {
+    const size_t lds = (size_t)(p.w.K + 16) * sizeof(float);
+    dense_gemv_kernel<PRO, EPI><<<dim3(dense_gemv_grid(p.w.N), ny), dim3(256), lds, s>>>(p);
+    return hipGetLastError();
+}
+static hipError_t launch_dense_gemv(const GemvParams& p, int ny, int pro, int epi, hipStream_t s) {
+    if (p.w.K % 32 || p.w.K > 10240 || p.w.N % 2) return hipErrorInvalidValue;
+    if (pro == PRO_RMS_MUL && p.mul == nullptr) return hipErrorInvalidValue;
+#define VOX_CASE(P_, E_) if (pro == P_ && epi == E_) return dense_launch_t<P_, E_>(p, ny, s)
+    VOX_CASE(PRO_NONE, EPI_STORE); VOX_CASE(PRO_NONE, EPI_RESID); VOX_CASE(PRO_NONE, EPI_GELU); VOX_CASE(PRO_NONE, EPI_SWIGLU);
+    VOX_CASE(PRO_RMS, EPI_STORE); VOX_CASE(PRO_RMS, EPI_ARGMAX); VOX_CASE(PRO_RMS, EPI_SWIGLU); VOX_CASE(PRO_RMS_MUL, EPI_SWIGLU);
+    VOX_CASE(PRO_RMS, EPI_ROPE_KV);
+#undef VOX_CASE
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,7 +626,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
 // A operand = activations (rows m, k = 8*(lane>>4)..+7), B operand = integer weights (cols n = lane&15),
 // D[m][n]: lane holds n = lane&15, m = 4*(lane>>4) + reg.  The K order inside one MFMA follows the Q4 chunk:
 // lane group g = lane>>4 contributes elements {4g..4g+3, 16+4g..16+4g+3} of the block.
-template <int EPI>
+template <int EPI, int FMT>
 __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) uint4 lds[2][2][256];   // [buffer][hi/lo][mt*64 + lane]
     const int K = p.w.K, nb = p.w.nb, N = p.w.N, M = p.M;
@@ -484,33 +641,38 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
     // MFMA role: weight row for this lane
     const int wn = n0 + wave * 16 + (lane & 15), wg = lane >> 4;
     const bool wrow_ok = wn < N;
+    // FMT Q4_0: one dword of nibbles per lane per block (+ f16 scale). FMT BF16: 8 bf16 weights (16 B) per lane per 32-k step,
+    // natural k order (k = 32b + 8g .. +7), no scale.
     const uint32_t* wq = reinterpret_cast<const uint32_t*>(p.w.qs) + (size_t)(wrow_ok ? wn : 0) * nb * 4 + wg;
-    const uint16_t* ws = p.w.sc + (size_t)(wrow_ok ? wn : 0) * nb;
+    const uint16_t* ws = FMT == WFMT_Q4_0 ? p.w.sc + (size_t)(wrow_ok ? wn : 0) * nb : nullptr;
+    const uint4* wd16 = p.w.qs + (size_t)(wrow_ok ? wn : 0) * nb * 4 + wg;
+    const int xoff_a = FMT == WFMT_Q4_0 ? 4 * sg : 8 * sg, xoff_b = FMT == WFMT_Q4_0 ? 16 + 4 * sg : 8 * sg + 4;
 
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #define VOX_GLOAD(B_)                                                                              \
-    xa = *reinterpret_cast<const float4*>(xrow + 32 * (B_) + 4 * sg);      /* unconditional loads (row clamped), */  \
-    xb = *reinterpret_cast<const float4*>(xrow + 32 * (B_) + 16 + 4 * sg); /* masked by select afterwards        */  \
-    wd = wq[(size_t)(B_) * 4]; wsc = ws[(B_)];   /* out-of-range rows/cols read row 0 and are never stored */
+    xa = *reinterpret_cast<const float4*>(xrow + 32 * (B_) + xoff_a);      /* unconditional loads (row clamped)  */  \
+    xb = *reinterpret_cast<const float4*>(xrow + 32 * (B_) + xoff_b);                                               \
+    if (FMT == WFMT_Q4_0) { wd = wq[(size_t)(B_) * 4]; wsc = ws[(B_)]; }   /* out-of-range rows/cols read row 0, never stored */ \
+    else { wdv = wd16[(size_t)(B_) * 4]; }
 #define VOX_STAGE(BUF_)                                                                            \
     { uint4 hi_, lo_; split_bf16x8(xa, xb, hi_, lo_); lds[(BUF_)][0][slot] = hi_; lds[(BUF_)][1][slot] = lo_; }
     // two-deep register pipeline: loads for block b+2 are issued while block b is on the MFMAs and block b+1
     // (loaded one iteration ago, so already landed) is converted and staged to the other LDS buffer.
-    float4 xa, xb; uint32_t wd; uint16_t wsc;
+    float4 xa, xb; uint32_t wd = 0; uint16_t wsc = 0; uint4 wdv = make_uint4(0, 0, 0, 0);
     VOX_GLOAD(0)
     VOX_STAGE(0)
-    uint32_t cur_wd = wd; uint16_t cur_sc = wsc;
+    uint32_t cur_wd = wd; uint16_t cur_sc = wsc; uint4 cur_wdv = wdv;
     { const int b1 = min(1, nb - 1); VOX_GLOAD(b1) }
     __syncthreads();
     for (int b = 0; b < nb; b++) {
         const int buf = b & 1;
-        const float4 sxa = xa, sxb = xb; const uint32_t swd = wd; const uint16_t ssc = wsc;   // block b+1 (in flight since last iteration)
+        const float4 sxa = xa, sxb = xb; const uint32_t swd = wd; const uint16_t ssc = wsc; const uint4 swdv = wdv;   // block b+1 (in flight since last iteration)
         { const int b2 = min(b + 2, nb - 1); VOX_GLOAD(b2) }   // unconditional (clamped): a branch here forces phi copies + vmcnt waits
-        const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8(cur_wd));
-        const float d = f16_bits_to_f32(cur_sc);
+        const bf16x8 bw = as_bf16x8(FMT == WFMT_Q4_0 ? q4_dword_to_bf16x8(cur_wd) : cur_wdv);
+        const float d = FMT == WFMT_Q4_0 ? f16_bits_to_f32(cur_sc) : 1.0f;
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
             const bf16x8 ah = as_bf16x8(lds[buf][0][mt * 64 + lane]);
@@ -522,7 +684,7 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
         }
         if (b + 1 < nb) {
             uint4 hi_, lo_; split_bf16x8(sxa, sxb, hi_, lo_); lds[buf ^ 1][0][slot] = hi_; lds[buf ^ 1][1][slot] = lo_;
-            cur_wd = swd; cur_sc = ssc;
+            cur_wd = swd; cur_sc = ssc; cur_wdv = swdv;
         }
         __syncthreads();
     }
@@ -547,17 +709,21 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
         }
 }
 
-hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
-    if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
-    dim3 grid((p.w.N + 63) / 64, (p.M + 63) / 64);
+template <int FMT>
+static hipError_t gemm_launch_f(const GemmParams& p, int epi, dim3 grid, hipStream_t s) {
     switch (epi) {
-    case EPI_STORE: q4_gemm_kernel<EPI_STORE><<<grid, dim3(256), 0, s>>>(p); break;
-    case EPI_RESID: q4_gemm_kernel<EPI_RESID><<<grid, dim3(256), 0, s>>>(p); break;
-    case EPI_GELU: q4_gemm_kernel<EPI_GELU><<<grid, dim3(256), 0, s>>>(p); break;
-    case EPI_SWIGLU: q4_gemm_kernel<EPI_SWIGLU><<<grid, dim3(256), 0, s>>>(p); break;
+    case EPI_STORE: q4_gemm_kernel<EPI_STORE, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+    case EPI_RESID: q4_gemm_kernel<EPI_RESID, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+    case EPI_GELU: q4_gemm_kernel<EPI_GELU, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+    case EPI_SWIGLU: q4_gemm_kernel<EPI_SWIGLU, FMT><<<grid, dim3(256), 0, s>>>(p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
+    if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
+    dim3 grid((p.w.N + 63) / 64, (p.M + 63) / 64);
+    return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, grid, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, grid, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1011,25 +1177,47 @@ hipError_t launch_absmax(const float* x, long n, float target, float* scale_out,
 // ------------------------------------------------------------------------------------------------
 // token embedding row dequant (+ audio embedding add) (gguf/model.rs:584-618, :898-902, :942-948)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embed_kernel(Q4W tok, const int* __restrict__ ids, const float* __restrict__ audio, int D,
-                                                    const int* __restrict__ pos_ptr, int id_off, int a_off, float* __restrict__ out) {
-    const int i = blockIdx.x;
-    const int base = pos_ptr ? *pos_ptr : 0;
-    const int id = ids[base + id_off + i];
-    const float* arow = audio ? audio + (size_t)(base + a_off + i) * D : nullptr;
-    float* o = out + (size_t)i * D;
+// one token-embedding row (Q4_0 row dequant, gguf/model.rs:584-618, or dense bf16 row, models/decoder.rs:250-262)
+// plus the audio embedding of the same position (gguf/model.rs:898-902, :942-948); 256 threads cooperate.
+__device__ __forceinline__ void embed_row(const Q4W& tok, int id, const float* __restrict__ arow, float* __restrict__ o, int D) {
+    if (tok.fmt == WFMT_BF16) {
+        const uint4* w = tok.qs + (size_t)id * (D >> 3);
+        for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+            const uint4 q = w[c];
+            float4 a = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xFFFF0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xFFFF0000u));
+            float4 b = make_float4(__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xFFFF0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xFFFF0000u));
+            if (arow) {
+                const float4 u = reinterpret_cast<const float4*>(arow)[2 * c], v = reinterpret_cast<const float4*>(arow)[2 * c + 1];
+                a.x = u.x + a.x; a.y = u.y + a.y; a.z = u.z + a.z; a.w = u.w + a.w; b.x = v.x + b.x; b.y = v.y + b.y; b.z = v.z + b.z; b.w = v.w + b.w;
+            }
+            reinterpret_cast<float4*>(o)[2 * c] = a; reinterpret_cast<float4*>(o)[2 * c + 1] = b;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < tok.nb; c += 256) {
         const uint4 q = tok.qs[(size_t)id * tok.nb + c];
         const float d = f16_bits_to_f32(tok.sc[(size_t)id * tok.nb + c]);
         const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t by = (ww[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            const float lo = ((float)(by & 0xF) - 8.0f) * d, hi = ((float)(by >> 4) - 8.0f) * d;
-            o[c * 32 + k] = arow ? arow[c * 32 + k] + lo : lo;
-            o[c * 32 + 16 + k] = arow ? arow[c * 32 + 16 + k] + hi : hi;
+        for (int i = 0; i < 4; i++) {
+            const uint32_t lo = ww[i] & 0x0F0F0F0Fu, hi = (ww[i] >> 4) & 0x0F0F0F0Fu;
+            float4 a = make_float4((ub0(lo) - 8.0f) * d, (ub1(lo) - 8.0f) * d, (ub2(lo) - 8.0f) * d, (ub3(lo) - 8.0f) * d);
+            float4 b = make_float4((ub0(hi) - 8.0f) * d, (ub1(hi) - 8.0f) * d, (ub2(hi) - 8.0f) * d, (ub3(hi) - 8.0f) * d);
+            if (arow) {
+                const float4 u = reinterpret_cast<const float4*>(arow)[c * 8 + i], v = reinterpret_cast<const float4*>(arow)[c * 8 + 4 + i];
+                a.x = u.x + a.x; a.y = u.y + a.y; a.z = u.z + a.z; a.w = u.w + a.w; b.x = v.x + b.x; b.y = v.y + b.y; b.z = v.z + b.z; b.w = v.w + b.w;
+            }
+            reinterpret_cast<float4*>(o)[c * 8 + i] = a; reinterpret_cast<float4*>(o)[c * 8 + 4 + i] = b;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(Q4W tok, const int* __restrict__ ids, const float* __restrict__ audio, int D,
+                                                    const int* __restrict__ pos_ptr, int id_off, int a_off, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    const int base = pos_ptr ? *pos_ptr : 0;
+    const int id = ids[base + id_off + i];
+    embed_row(tok, id, audio ? audio + (size_t)(base + a_off + i) * D : nullptr, out + (size_t)i * D, D);
 }
 hipError_t launch_embed(Q4W tok, const int* ids, int n, const float* audio, int D, const int* pos_ptr, int id_off, int a_off,
                         float* out, hipStream_t s) {
@@ -1095,21 +1283,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
         tokens[cur] = bi[0]; *pos_ptr = cur; s_tok = bi[0]; s_cur = cur;
     }
     __syncthreads();
-    const int id = s_tok;
-    const float4* arow = reinterpret_cast<const float4*>(audio + (size_t)s_cur * D);
-    float4* o = reinterpret_cast<float4*>(h);
-    for (int c = threadIdx.x; c < tok.nb; c += 256) {
-        const uint4 q = tok.qs[(size_t)id * tok.nb + c];
-        const float d = f16_bits_to_f32(tok.sc[(size_t)id * tok.nb + c]);
-        const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t lo = ww[i] & 0x0F0F0F0Fu, hi = (ww[i] >> 4) & 0x0F0F0F0Fu;
-            const float4 a0 = arow[c * 8 + i], a1 = arow[c * 8 + 4 + i];
-            o[c * 8 + i] = make_float4(a0.x + (ub0(lo) - 8.0f) * d, a0.y + (ub1(lo) - 8.0f) * d, a0.z + (ub2(lo) - 8.0f) * d, a0.w + (ub3(lo) - 8.0f) * d);
-            o[c * 8 + 4 + i] = make_float4(a1.x + (ub0(hi) - 8.0f) * d, a1.y + (ub1(hi) - 8.0f) * d, a1.z + (ub2(hi) - 8.0f) * d, a1.w + (ub3(hi) - 8.0f) * d);
-        }
-    }
+    embed_row(tok, s_tok, audio + (size_t)s_cur * D, h, D);
 }
 hipError_t launch_argmax_embed(const float* pv, const int* pi, int n_parts, int* tokens, int* pos_ptr, Q4W tok, const float* audio, int D,
                                float* h, hipStream_t s) {

@@ -269,3 +269,58 @@ def gguf_dense_f32(path: str):
         else:
             out[name] = np.asarray(raw).view(np.float32).reshape(shape).copy()
     return out
+
+
+# --------------------------------------------------------------------------- f32 / SafeTensors path (BF16 on disk)
+
+def f32_to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even f32 -> bf16 bit patterns (uint16)."""
+    b = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    return ((b + np.uint32(0x7FFF) + ((b >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def bf16_bits_to_f32(bits: np.ndarray) -> np.ndarray:
+    return (bits.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def synth_dense_tensors(dims: ModelDims, seed: int = 42):
+    """Yield (name, shape, bf16 bit pattern array) for the dense (f32-path) model: the same tensor names and
+    shapes as the published ``consolidated.safetensors`` (BF16 on disk, ``src/models/weights.rs:219-397``)."""
+    for idx, (name, shape, kind, sigma) in enumerate(tensor_manifest(dims)):
+        rng = np.random.default_rng([seed, idx, 77])
+        ne = int(np.prod(shape))
+        if kind == "norm":
+            v = (1.0 + sigma * rng.standard_normal(ne)).astype(np.float32)
+        else:
+            v = (sigma * rng.standard_normal(ne)).astype(np.float32)
+        yield name, shape, f32_to_bf16_bits(v)
+
+
+def write_safetensors(path: str, tensors):
+    """tensors: iterable of (name, shape, dtype_str, bytes-like). Minimal SafeTensors writer (u64 header length,
+    JSON header, raw little-endian data) -- the layout ``safetensors`` / ``src/models/weights.rs:170-205`` read."""
+    import json
+    tensors = list(tensors)
+    hdr = {}; off = 0
+    for name, shape, dt, data in tensors:
+        n = memoryview(np.ascontiguousarray(data)).nbytes
+        hdr[name] = {"dtype": dt, "shape": [int(s) for s in shape], "data_offsets": [off, off + n]}
+        off += n
+    hdr["__metadata__"] = {"format": "pt"}
+    hb = json.dumps(hdr, separators=(",", ":")).encode()
+    hb += b" " * ((8 - len(hb) % 8) % 8)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(hb))); f.write(hb)
+        for _, _, _, data in tensors:
+            f.write(memoryview(np.ascontiguousarray(data)).cast("B"))
+
+
+def write_synthetic_safetensors(path: str, dims: ModelDims, seed: int = 42):
+    write_safetensors(path, ((n, s, "BF16", bits) for n, s, bits in synth_dense_tensors(dims, seed)))
+    return path
+
+
+def write_synthetic_dense_gguf(path: str, dims: ModelDims, seed: int = 42):
+    """The same values as ``write_synthetic_safetensors`` as an all-F32 GGUF (what the CPU oracle loads for the f32 path)."""
+    write_gguf(path, ((n, s, GGML_F32, bf16_bits_to_f32(bits)) for n, s, bits in synth_dense_tensors(dims, seed)))
+    return path
