@@ -60,3 +60,17 @@ def tiny_f32_pair(seed=9):
     if not os.path.exists(gg):
         S.write_synthetic_dense_gguf(gg + ".tmp", d, seed); os.replace(gg + ".tmp", gg)
     return st, gg, d
+
+
+def check_greedy_ids(ids, rids, rlg, tol):
+    """Greedy ids must equal the oracle's; the only admissible first disagreement is at a step whose oracle top-2
+    logit margin is below 10x the logit tolerance (a near-tie; after it the autoregressive sequences may diverge)."""
+    ids = np.asarray(ids); rids = np.asarray(rids)
+    assert ids.shape == rids.shape
+    agree = ids == rids
+    if agree.all():
+        return len(ids)
+    first = int(np.argmin(agree))
+    srt = np.sort(rlg[first]); margin = srt[-1] - srt[-2]
+    assert margin <= 10 * tol * max(1.0, float(np.abs(rlg).max())), f"ids differ at step {first} with a clear margin {margin}"
+    return first

@@ -5,7 +5,7 @@ tolerance: max|d| <= 2e-4 * max|ref| on hidden states and logits, greedy ids ide
 import numpy as np
 import pytest
 
-from model_fixtures import fake_mel, rel_err, tiny_f32_pair
+from model_fixtures import check_greedy_ids, fake_mel, rel_err, tiny_f32_pair
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -70,8 +70,6 @@ def test_f32_transcribe(pkg, pair):
     assert len(ids) == len(rids) == 33
     scale = max(1.0, np.abs(rlg).max())
     assert np.abs(lg - rlg).max() <= TOL * scale
-    srt = np.sort(rlg, axis=1); safe = (srt[:, -1] - srt[:, -2]) > 10 * TOL * scale
-    stop = len(safe) if safe.all() else int(np.argmin(safe))
-    assert stop > 0 and (ids[:stop] == rids[:stop]).all()                  # greedy ids identical to the CPU reference
+    check_greedy_ids(ids, rids, rlg, TOL)                                  # greedy ids identical to the CPU reference
     ids_g = m.transcribe_streaming(mel[None], t)                            # graph-replayed decode
     assert (ids_g == ids).all() and (m.transcribe_streaming(mel[None], t) == ids).all()

@@ -10,7 +10,7 @@ Tolerances (stated here, used below):
 import numpy as np
 import pytest
 
-from model_fixtures import fake_mel, golden, golden_gguf, rel_err, tiny_gguf
+from model_fixtures import check_greedy_ids, fake_mel, golden, golden_gguf, rel_err, tiny_gguf
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -96,10 +96,7 @@ def _check_ids(ids, lg, rids, rlg):
     assert ids.shape == rids.shape and lg.shape == rlg.shape
     e = np.abs(lg - rlg).max(); scale = max(1.0, np.abs(rlg).max())
     assert e <= TOL * scale, e
-    srt = np.sort(rlg, axis=1); margin = srt[:, -1] - srt[:, -2]
-    safe = margin > 10 * TOL * scale
-    agree = ids == rids
-    assert agree[: np.argmin(safe) if not safe.all() else len(safe)].all()   # identical up to the first near-tie
+    check_greedy_ids(ids, rids, rlg, TOL)                                     # identical up to the first near-tie
     assert (lg.argmax(1) == ids).all()                                        # ids are the argmax of the returned logits
 
 
@@ -134,9 +131,7 @@ def test_transcribe_audio_full_path(pkg, orc, tiny, ctx):
     rids, rlg = o.transcribe_streaming(mel, t, want_logits=True)
     ids = m.transcribe_audio(x, t)
     assert len(ids) == len(rids) == o.enc_seq_len(mel.shape[1]) // 4 - 38
-    srt = np.sort(rlg, axis=1); safe = (srt[:, -1] - srt[:, -2]) > 10 * TOL * max(1.0, np.abs(rlg).max())
-    stop = len(safe) if safe.all() else int(np.argmin(safe))
-    assert (ids[:stop] == rids[:stop]).all()
+    check_greedy_ids(ids, rids, rlg, TOL)
     d = ctx.upload(x)                                                        # device-resident samples (bench path)
     ids_d = m.transcribe_audio(None, t, device_ptr=d, n_samples=x.size)
     assert (ids_d == ids).all()
