@@ -1,0 +1,69 @@
+"""Tekken decode (tokenizer/mod.rs:170-194) and the voxtral-transcribe-compatible driver (bin/transcribe.rs)."""
+import base64
+import json
+import os
+import subprocess
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tekken(n=1200):
+    vocab = [{"rank": i, "token_bytes": base64.b64encode(f" w{i}".encode()).decode(), "token_str": f" w{i}"} for i in range(n)]
+    vocab[3] = {"rank": 3, "token_bytes": None, "token_str": "plain"}
+    vocab[4] = {"rank": 4, "token_bytes": base64.b64encode(b"\xff\xfe").decode(), "token_str": None}      # invalid UTF-8 -> lossy
+    vocab[5] = {"rank": 5, "token_str": "<ctl>", "is_control": True}
+    return {"config": {"pattern": "", "num_vocab_tokens": n, "default_vocab_size": 131072, "default_num_special_tokens": 1000, "version": "v7"}, "vocab": vocab}
+
+
+def test_tokenizer_decode(pkg):
+    t = pkg.VoxtralTokenizer.from_json(json.dumps(_tekken()))
+    assert t.vocab_size() == 131072
+    assert t.decode([1, 32, 33, 999]) == ""                                   # control / streaming ids < 1000 are dropped
+    assert t.decode([1000, 1001, 32, 1002]) == " w0 w1 w2"                    # id - 1000 = vocab index
+    assert t.decode([1003]) == "plain" and t.decode([1004]) == "��"  # token_str fallback; lossy UTF-8
+    assert t.decode([1005]) == "" and t.decode([1000 + 5000]) == ""           # control entry / out of range skipped
+    assert t.decode_token(1001) == " w1" and t.decode_token(5) == "<ctl>" and t.decode_token(7) is None
+
+
+def _write_wav(path, x, sr=16000, ch=1):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(ch); w.setsampwidth(2); w.setframerate(sr)
+        d = np.clip(x, -1, 1); d = (d * 32767).astype("<i2")
+        if ch > 1:
+            d = np.repeat(d[:, None], ch, axis=1).reshape(-1)
+        w.writeframes(d.tobytes())
+
+
+def test_wav_loader(pkg, tmp_path):
+    cli = __import__("importlib").import_module(pkg.__name__ + ".cli")
+    x = pkg.synth.synth_audio(0.5, seed=1)
+    _write_wav(str(tmp_path / "m.wav"), x); _write_wav(str(tmp_path / "s.wav"), x, ch=2); _write_wav(str(tmp_path / "r.wav"), x[::2], sr=8000)
+    a, sr = cli.load_wav(str(tmp_path / "m.wav")); assert sr == 16000 and a.size == x.size and np.abs(a - x).max() < 1e-4 + 1 / 32767
+    b, _ = cli.load_wav(str(tmp_path / "s.wav")); assert np.abs(b - a).max() < 1e-6                 # stereo averaged to mono
+    r, sr = cli.load_wav(str(tmp_path / "r.wav")); assert sr == 8000
+    assert abs(cli.resample_to_16k(r, 8000).size - x.size) <= 2
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(pkg, tmp_path):
+    """One line per input on stdout, logs on stderr (transcribe.rs:61-64,125); chunked long input; missing file -> empty line."""
+    S = pkg.synth
+    gguf = str(tmp_path / "m.gguf"); S.write_synthetic_gguf(gguf, S.tiny_dims(vocab=2048), seed=5)
+    tok = str(tmp_path / "tekken.json"); json.dump(_tekken(1200), open(tok, "w"))
+    _write_wav(str(tmp_path / "a.wav"), S.synth_audio(3.0, seed=2)); _write_wav(str(tmp_path / "b.wav"), S.synth_audio(9.0, seed=3))
+    lst = tmp_path / "list.txt"; lst.write_text(f"{tmp_path / 'a.wav'}\n\n{tmp_path / 'b.wav'}\n{tmp_path / 'missing.wav'}\n")
+    cmd = [sys.executable, os.path.join(ROOT, "voxtral-mini-realtime-rs_amd", "cli.py"), "--gguf", gguf, "--tokenizer", tok,
+           "--audio-list", str(lst), "--max-mel-frames", "600"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    lines = r.stdout.split("\n")
+    assert lines[-1] == "" and len(lines) == 4, r.stdout + r.stderr            # exactly one line per input
+    assert r.returncode == 1 and "missing.wav" in r.stderr and lines[2] == ""
+    assert "chunk 2/2" in r.stderr                                              # 9 s > 600 frames = 6 s -> two chunks
+    assert all(w.startswith("w") for w in lines[0].split()) and all(w.startswith("w") for w in lines[1].split())
+    r2 = subprocess.run(cmd[:-4] + ["--audio", str(tmp_path / "a.wav")], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and r2.stdout.split("\n")[0] == lines[0]           # deterministic, same text

@@ -1,0 +1,126 @@
+"""`voxtral-transcribe`-compatible driver (reference: src/bin/transcribe.rs:27-318): same flags, one line of text per
+input on stdout, logs on stderr.  WAV ingest / resampling / chunking / token decode stay on the CPU (caller side in the
+reference too); pad -> log-mel -> encoder -> decoder run on the GPU through the C ABI.
+
+    python -m ... cli --gguf model.gguf --tokenizer tekken.json --audio a.wav [--audio b.wav] [--delay 6] [--max-mel-frames 1200]
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+import wave
+
+import numpy as np
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def load_wav(path):
+    """audio/io.rs:90-131: PCM int (8/16/24/32 bit) or float32, mixed to mono by averaging channels."""
+    with wave.open(path, "rb") as w:
+        ch, sw, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if sw == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / np.float32(1 << 15)
+    elif sw == 4:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / np.float32(1 << 31)
+    elif sw == 3:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16); v = np.where(v & 0x800000, v - (1 << 24), v)
+        x = v.astype(np.float32) / np.float32(1 << 23)
+    elif sw == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError(f"unsupported WAV sample width {sw}")
+    if ch > 1:
+        x = x.reshape(-1, ch).mean(axis=1).astype(np.float32)
+    return x, sr
+
+
+def resample_to_16k(x, sr):
+    """audio/resample.rs:16-52 uses rubato's FFT resampler; here a polyphase FIR (caller-side, off the accelerated path)."""
+    from math import gcd
+    from scipy.signal import resample_poly
+    g = gcd(16000, int(sr))
+    return resample_poly(x.astype(np.float64), 16000 // g, int(sr) // g).astype(np.float32)
+
+
+def transcribe_one(pkg, path, model, tokenizer, mel, pad_cfg, chunk_cfg, t_embed):
+    """bin/transcribe.rs:187-276"""
+    x, sr = load_wav(path)
+    if sr != 16000:
+        log(f"  resampling {sr} Hz -> 16 kHz"); x = resample_to_16k(x, sr)
+    x = pkg.peak_normalize(x, 0.95)                                              # :207
+    chunks = pkg.chunk_audio(x, chunk_cfg) if pkg.needs_chunking(x.size, chunk_cfg) else [None]
+    texts = []
+    for i, ch in enumerate(chunks):
+        samples = x if ch is None else ch.samples
+        if len(chunks) > 1:
+            log(f"  chunk {i + 1}/{len(chunks)}: {ch.start_sample / 16000:.2f}-{ch.end_sample / 16000:.2f} s")
+        m = mel.compute_log(pkg.pad_audio(samples, pad_cfg))                     # :279-306
+        if m.shape[0] == 0:
+            raise RuntimeError("Audio too short to produce mel frames")
+        ids = model.transcribe_streaming(np.ascontiguousarray(m.T)[None], t_embed)
+        text = tokenizer.decode([t for t in ids if t >= 1000]).strip()           # :309-318
+        if text:
+            texts.append(text)
+    return " ".join(texts)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="voxtral-transcribe", description="Transcribe audio using Voxtral Mini 4B Realtime (MI355X HIP path)")
+    ap.add_argument("-a", "--audio", action="append", default=[])
+    ap.add_argument("--audio-list")
+    ap.add_argument("-m", "--model", default="models/voxtral")
+    ap.add_argument("--gguf")
+    ap.add_argument("--tokenizer")
+    ap.add_argument("-d", "--delay", type=int, default=6)
+    ap.add_argument("--max-mel-frames", type=int, default=1200)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.audio_list and a.audio:
+        ap.error("--audio-list conflicts with --audio")
+    if a.gguf and not a.tokenizer:
+        ap.error("--gguf requires --tokenizer")
+    paths = a.audio
+    if a.audio_list:
+        paths = [l.strip() for l in open(a.audio_list) if l.strip()]
+    if not paths:
+        ap.error("No audio files specified")
+    if a.max_mel_frames <= 0:
+        ap.error("--max-mel-frames must be greater than 0")
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    tok_path = a.tokenizer or os.path.join(a.model, "tekken.json")
+    if not os.path.exists(tok_path):
+        log(f"Error: Tokenizer not found at {tok_path}"); return 1
+    tokenizer = pkg.VoxtralTokenizer.from_file(tok_path)
+    ctx = pkg.Context(a.device)
+    t0 = time.time()
+    if a.gguf:
+        log(f"Loading Q4 GGUF model from {a.gguf}"); model = pkg.Q4ModelLoader.from_file(a.gguf).load(ctx)
+    else:
+        st = os.path.join(a.model, "consolidated.safetensors")
+        log(f"Loading f32 model from {st}"); model = pkg.VoxtralModelLoader.from_file(st).load(ctx)
+    log(f"Model loaded in {time.time() - t0:.2f}s")
+    t_embed = pkg.TimeEmbedding(model.config.dec_dim).embed(float(a.delay))
+    mel = pkg.MelSpectrogram.voxtral(ctx); pad_cfg = pkg.PadConfig.voxtral()
+    chunk_cfg = pkg.ChunkConfig.voxtral().with_max_frames(a.max_mel_frames)
+    rc = 0
+    for p in paths:
+        try:
+            t1 = time.time(); text = transcribe_one(pkg, p, model, tokenizer, mel, pad_cfg, chunk_cfg, t_embed)
+            log(f"{p}: {time.time() - t1:.3f}s")
+        except Exception as e:      # per-utterance failure isolates to that line (empty), eval_wer.py:211-223 tolerates it
+            log(f"Error transcribing {p}: {e}"); text = ""; rc = 1
+        print(text, flush=True)
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())
