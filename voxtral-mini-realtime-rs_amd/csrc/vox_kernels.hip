@@ -627,7 +627,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
 // D[m][n]: lane holds n = lane&15, m = 4*(lane>>4) + reg.  The K order inside one MFMA follows the Q4 chunk:
 // lane group g = lane>>4 contributes elements {4g..4g+3, 16+4g..16+4g+3} of the block.
 template <int EPI, int FMT>
-__global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void q4_gemm_k32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) uint4 lds[2][2][256];   // [buffer][hi/lo][mt*64 + lane]
     const int K = p.w.K, nb = p.w.nb, N = p.w.N, M = p.M;
     (void)K;
@@ -709,21 +709,181 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
         }
 }
 
-template <int FMT>
-static hipError_t gemm_launch_f(const GemmParams& p, int epi, dim3 grid, hipStream_t s) {
-    switch (epi) {
-    case EPI_STORE: q4_gemm_kernel<EPI_STORE, FMT><<<grid, dim3(256), 0, s>>>(p); break;
-    case EPI_RESID: q4_gemm_kernel<EPI_RESID, FMT><<<grid, dim3(256), 0, s>>>(p); break;
-    case EPI_GELU: q4_gemm_kernel<EPI_GELU, FMT><<<grid, dim3(256), 0, s>>>(p); break;
-    case EPI_SWIGLU: q4_gemm_kernel<EPI_SWIGLU, FMT><<<grid, dim3(256), 0, s>>>(p); break;
-    default: return hipErrorInvalidValue;
+// ---- main MFMA GEMM: K step of 128 (four Q4_0 blocks / four 32-k dense steps per barrier), workgroup tile
+// (16*MT rows) x (64*NT cols); wave w owns n-tiles [w*NT, w*NT+NT) x all MT m-tiles.  Per barrier a wave issues
+// 4*NT*MT*2 MFMAs against 8*MT ds_read_b128 -- 4x the work per barrier of the K-32 kernel above (kept as the
+// fallback for K % 128 != 0).  Same operand conventions: A = activations (hi+lo bf16 through LDS in fragment order),
+// B = integer Q4 weights straight from global (one dword per lane per block) or dense bf16 (16 B per lane per step).
+template <int MT, int NT, int EPI, int FMT>
+__global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 glds[];      // [buf 2][hi/lo 2][j 4][MT][64]
+    constexpr int PLANE = 4 * MT * 64, BUF = 2 * PLANE;
+    const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * (16 * MT), n0 = blockIdx.x * (64 * NT);
+    // staging role: fragment f = tid + 256*i -> (row sm = f>>4, block j = (f>>2)&3, group g = f&3)
+    const float* xrow[MT]; int slot[MT], xo_a[MT], xo_b[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const int f = tid + 256 * i, sm = f >> 4, j = (f >> 2) & 3, g = f & 3;
+        xrow[i] = p.x + (size_t)min(m0 + sm, M - 1) * p.x_stride;
+        slot[i] = (j * MT + (sm >> 4)) * 64 + g * 16 + (sm & 15);
+        xo_a[i] = 32 * j + (FMT == WFMT_Q4_0 ? 4 * g : 8 * g); xo_b[i] = 32 * j + (FMT == WFMT_Q4_0 ? 16 + 4 * g : 8 * g + 4);
     }
+    // MFMA role
+    const int wg = lane >> 4;
+    const uint32_t* wq[NT]; const uint16_t* ws[NT]; const uint4* wd16[NT]; int wn[NT]; bool wok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        wn[t] = n0 + (wave * NT + t) * 16 + (lane & 15); wok[t] = wn[t] < N;
+        const size_t row = (size_t)min(wn[t], N - 1);
+        wq[t] = reinterpret_cast<const uint32_t*>(p.w.qs) + row * nb * 4 + wg;
+        ws[t] = FMT == WFMT_Q4_0 ? p.w.sc + row * nb : nullptr;
+        wd16[t] = p.w.qs + row * nb * 4 + wg;
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < MT; i++) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 xa[MT], xb[MT];
+    uint32_t wd[NT][4]; uint2 wsc[NT]; uint4 wdv[NT][4];
+#define VOX_GLOAD(Q_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                           \
+        xa[i] = *reinterpret_cast<const float4*>(xrow[i] + 128 * (Q_) + xo_a[i]);                              \
+        xb[i] = *reinterpret_cast<const float4*>(xrow[i] + 128 * (Q_) + xo_b[i]);                              \
+    }                                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                           \
+        if (FMT == WFMT_Q4_0) {                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) wd[t][j] = wq[t][(size_t)(4 * (Q_) + j) * 4];        \
+            wsc[t] = *reinterpret_cast<const uint2*>(ws[t] + 4 * (Q_));                                        \
+        } else {                                                                                               \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) wdv[t][j] = wd16[t][(size_t)(4 * (Q_) + j) * 4];     \
+        }                                                                                                      \
+    }
+#define VOX_STAGE(BUF_)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                           \
+        uint4 hi_, lo_; split_bf16x8(sxa[i], sxb[i], hi_, lo_);                                                \
+        glds[(BUF_) * BUF + slot[i]] = hi_; glds[(BUF_) * BUF + PLANE + slot[i]] = lo_;                        \
+    }
+    VOX_GLOAD(0)
+    float4 sxa[MT], sxb[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) { sxa[i] = xa[i]; sxb[i] = xb[i]; }
+    VOX_STAGE(0)
+    uint32_t cwd[NT][4]; uint2 csc[NT]; uint4 cwdv[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; t++) { csc[t] = wsc[t];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cwd[t][j] = wd[t][j]; cwdv[t][j] = wdv[t][j]; } }
+    { const int q1 = min(1, nq - 1); VOX_GLOAD(q1) }
+    __syncthreads();
+    for (int q = 0; q < nq; q++) {
+        const int buf = q & 1;
+#pragma unroll
+        for (int i = 0; i < MT; i++) { sxa[i] = xa[i]; sxb[i] = xb[i]; }          // k-step q+1 (in flight since last iteration)
+        uint32_t nwd[NT][4]; uint2 nsc[NT]; uint4 nwdv[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; t++) { nsc[t] = wsc[t];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { nwd[t][j] = wd[t][j]; nwdv[t][j] = wdv[t][j]; } }
+        { const int q2 = min(q + 2, nq - 1); VOX_GLOAD(q2) }                      // unconditional (clamped) prefetch
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const bf16x8 bw = as_bf16x8(FMT == WFMT_Q4_0 ? q4_dword_to_bf16x8(cwd[t][j]) : cwdv[t][j]);
+                float d = 1.0f;
+                if (FMT == WFMT_Q4_0) {
+                    const uint32_t pr = (j & 2) ? csc[t].y : csc[t].x;
+                    d = f16_bits_to_f32((uint16_t)((j & 1) ? (pr >> 16) : (pr & 0xFFFFu)));
+                }
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+                    const bf16x8 ah = as_bf16x8(glds[buf * BUF + (j * MT + i) * 64 + lane]);
+                    const bf16x8 al = as_bf16x8(glds[buf * BUF + PLANE + (j * MT + i) * 64 + lane]);
+                    f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bw, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw, tt, 0, 0, 0);
+                    acc[t][i][0] = fmaf(d, tt[0], acc[t][i][0]); acc[t][i][1] = fmaf(d, tt[1], acc[t][i][1]);
+                    acc[t][i][2] = fmaf(d, tt[2], acc[t][i][2]); acc[t][i][3] = fmaf(d, tt[3], acc[t][i][3]);
+                }
+            }
+        }
+        if (q + 1 < nq) {
+            VOX_STAGE(buf ^ 1)
+#pragma unroll
+            for (int t = 0; t < NT; t++) { csc[t] = nsc[t];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { cwd[t][j] = nwd[t][j]; cwdv[t][j] = nwdv[t][j]; } }
+        }
+        __syncthreads();
+    }
+#undef VOX_GLOAD
+#undef VOX_STAGE
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float bias = (p.bias && wok[t]) ? p.bias[wn[t]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + i * 16 + 4 * (lane >> 4) + r;
+                float v = acc[t][i][r] + bias;
+                if (EPI == EPI_SWIGLU) {
+                    const float other = dpp_mov<0xB1>(v);        // lane^1; rows interleaved: even n = gate, odd n = up
+                    if (m < M && wok[t] && !(wn[t] & 1)) p.out[(size_t)m * p.out_stride + (wn[t] >> 1)] = silu_f(v) * other;
+                } else if (m < M && wok[t]) {
+                    if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + wn[t]];
+                    if (EPI == EPI_GELU) v = gelu_f(v);
+                    p.out[(size_t)m * p.out_stride + wn[t]] = v;
+                }
+            }
+    }
+}
+
+template <int MT, int NT, int FMT>
+static hipError_t gemm_launch_mn(const GemmParams& p, int epi, hipStream_t s) {
+    dim3 grid((p.w.N + 64 * NT - 1) / (64 * NT), (p.M + 16 * MT - 1) / (16 * MT));
+    const size_t lds = (size_t)2 * 2 * 4 * MT * 64 * sizeof(uint4);     // MT * 16 KB
+#define VOX_E(E_) case E_: { auto kern = q4_gemm_kernel<MT, NT, E_, FMT>; static bool done = false;          \
+        hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;                       \
+        kern<<<grid, dim3(256), lds, s>>>(p); break; }
+    switch (epi) { VOX_E(EPI_STORE) VOX_E(EPI_RESID) VOX_E(EPI_GELU) VOX_E(EPI_SWIGLU) default: return hipErrorInvalidValue; }
+#undef VOX_E
     return hipGetLastError();
+}
+template <int FMT>
+static hipError_t gemm_launch_f(const GemmParams& p, int epi, hipStream_t s) {
+    if (p.w.nb % 4) {   // K % 128 != 0: K-32 kernel
+        dim3 grid((p.w.N + 63) / 64, (p.M + 63) / 64);
+        switch (epi) {
+        case EPI_STORE: q4_gemm_k32_kernel<EPI_STORE, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+        case EPI_RESID: q4_gemm_k32_kernel<EPI_RESID, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+        case EPI_GELU: q4_gemm_k32_kernel<EPI_GELU, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+        case EPI_SWIGLU: q4_gemm_k32_kernel<EPI_SWIGLU, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    // tile choice: big tiles when there is enough work to fill 256 CUs, smaller ones otherwise
+    int mt = p.M <= 16 ? 1 : p.M <= 32 ? 2 : 4;
+    int nt = p.w.N >= 4096 ? 2 : 1;
+    { const int e = env_int("VOX_GEMM_MT"); if (e == 1 || e == 2 || e == 4) mt = e; }
+    { const int e = env_int("VOX_GEMM_NT"); if (e == 1 || e == 2) nt = e; }
+    auto wgs = [&](int mt_, int nt_) { return (long)((p.w.N + 64 * nt_ - 1) / (64 * nt_)) * ((p.M + 16 * mt_ - 1) / (16 * mt_)); };
+    if (!env_int("VOX_GEMM_MT") && !env_int("VOX_GEMM_NT")) {
+        if (nt == 2 && wgs(mt, 2) < 256) nt = 1;
+        if (mt == 4 && p.M > 32 && wgs(4, nt) < 256) mt = 2;
+    }
+#define VOX_MN(M_, N_) if (mt == M_ && nt == N_) return gemm_launch_mn<M_, N_, FMT>(p, epi, s)
+    VOX_MN(1, 1); VOX_MN(1, 2); VOX_MN(2, 1); VOX_MN(2, 2); VOX_MN(4, 1); VOX_MN(4, 2);
+#undef VOX_MN
+    return hipErrorInvalidValue;
 }
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
-    dim3 grid((p.w.N + 63) / 64, (p.M + 63) / 64);
-    return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, grid, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, grid, s);
+    return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, s);
 }
 
 // ------------------------------------------------------------------------------------------------
