@@ -866,18 +866,28 @@ static hipError_t gemm_launch_f(const GemmParams& p, int epi, hipStream_t s) {
         }
         return hipGetLastError();
     }
-    // tile choice: big tiles when there is enough work to fill 256 CUs, smaller ones otherwise
-    int mt = p.M <= 16 ? 1 : p.M <= 32 ? 2 : 4;
-    int nt = p.w.N >= 4096 ? 2 : 1;
-    { const int e = env_int("VOX_GEMM_MT"); if (e == 1 || e == 2 || e == 4) mt = e; }
-    { const int e = env_int("VOX_GEMM_NT"); if (e == 1 || e == 2) nt = e; }
+    // tile choice from the round-1 sweep (profiles/r01_gemm_sweep.txt): 16-row tiles up to M = 48, 32-row tiles above;
+    // two n-tiles per wave only when that still leaves >= 256 workgroups.  VOX_GEMM_MT / VOX_GEMM_NT / VOX_GEMM_K32 are
+    // measurement knobs.
+    int mt = p.M <= 48 ? 1 : 2;
+    int nt = 2;
     auto wgs = [&](int mt_, int nt_) { return (long)((p.w.N + 64 * nt_ - 1) / (64 * nt_)) * ((p.M + 16 * mt_ - 1) / (16 * mt_)); };
-    if (!env_int("VOX_GEMM_MT") && !env_int("VOX_GEMM_NT")) {
-        if (nt == 2 && wgs(mt, 2) < 256) nt = 1;
-        if (mt == 4 && p.M > 32 && wgs(4, nt) < 256) mt = 2;
+    if (wgs(mt, 2) < 256) nt = 1;
+    { const int e = env_int("VOX_GEMM_MT"); if (e == 1 || e == 2) mt = e; }
+    { const int e = env_int("VOX_GEMM_NT"); if (e == 1 || e == 2) nt = e; }
+    if (env_int("VOX_GEMM_K32") || (!env_int("VOX_GEMM_MT") && p.M > 48 && env_int("VOX_GEMM_K32_BIG"))) {
+        dim3 grid((p.w.N + 63) / 64, (p.M + 63) / 64);
+        switch (epi) {
+        case EPI_STORE: q4_gemm_k32_kernel<EPI_STORE, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+        case EPI_RESID: q4_gemm_k32_kernel<EPI_RESID, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+        case EPI_GELU: q4_gemm_k32_kernel<EPI_GELU, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+        case EPI_SWIGLU: q4_gemm_k32_kernel<EPI_SWIGLU, FMT><<<grid, dim3(256), 0, s>>>(p); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
     }
 #define VOX_MN(M_, N_) if (mt == M_ && nt == N_) return gemm_launch_mn<M_, N_, FMT>(p, epi, s)
-    VOX_MN(1, 1); VOX_MN(1, 2); VOX_MN(2, 1); VOX_MN(2, 2); VOX_MN(4, 1); VOX_MN(4, 2);
+    VOX_MN(1, 1); VOX_MN(1, 2); VOX_MN(2, 1); VOX_MN(2, 2);
 #undef VOX_MN
     return hipErrorInvalidValue;
 }
