@@ -173,6 +173,13 @@ int32_t vox_transcribe_streaming(vox_model* m, const float* mel_128xT, int32_t T
 int32_t vox_transcribe_audio(vox_model* m, const float* samples, size_t n, const float* t_embed,
                              int32_t* out_ids, int32_t cap, int32_t* n_ids, int32_t mem_kind);
 
+/* Batched transcription (BASELINE.json config "Batch=16 x 16 s utterances"; extension -- the reference's callers loop over files,
+ * bin/transcribe.rs:112-126).  n <= 64 independent utterances, each through the whole path of vox_transcribe_audio; the decode
+ * loop advances all sequences per step so the weights are streamed once per step for the whole batch.  samples[i] / out_ids[i]
+ * are per-utterance buffers (samples host or device per mem_kind, ids always host); n_ids[i] receives S_i - 38 (or 0). */
+int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
+                             int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind);
+
 /* Q4LanguageModel pieces used directly by e2e-bench / WASM (gguf/model.rs:566,665,680,711) */
 int32_t vox_decoder_cache_create(vox_model* m, int32_t max_seq, vox_cache** out);   /* create_cache_preallocated */
 int32_t vox_cache_free(vox_cache* c);

@@ -161,3 +161,26 @@ def test_golden_reference_python(pkg, ctx):
     hs = [dec.forward_hidden_with_cache(g["in_dec_x"][None, i:i + 1], t, c) for i in range(8, 12)]      # decode-step kernels
     assert rel_err(np.concatenate([h1[0]] + [h[0] for h in hs]), g["out_decoder_hidden"]) < 3e-4
     m.close()
+
+
+def test_transcribe_batch(pkg, orc, tiny):
+    """Batched decode (vox_transcribe_batch): ragged batch of independent utterances == per-utterance oracle / single-stream path."""
+    m, o, _ = tiny
+    t = pkg.TimeEmbedding(256).embed(6.0)
+    clips = [pkg.synth.synth_audio(sec, seed=30 + i) for i, sec in enumerate((2.0, 3.3, 0.4, 2.0))]
+    outs = m.transcribe_batch(clips, t)
+    assert len(outs) == 4
+    tm = m.timings()
+    assert tm["decode_tokens"] == sum(len(x) for x in outs) and tm["graph_replays"] > 0
+    for x, ids in zip(clips, outs):
+        xn = x.copy(); orc.lib().orc_peak_normalize(xn, xn.size, 0.95)
+        mel = np.ascontiguousarray(orc.mel_compute_log(orc.pad_audio(xn)).T)
+        rids, rlg = o.transcribe_streaming(mel, t, want_logits=True)
+        assert len(ids) == len(rids) == o.enc_seq_len(mel.shape[1]) // 4 - 38
+        check_greedy_ids(ids, rids, rlg, TOL)
+    single = [m.transcribe_audio(x, t) for x in clips]
+    outs2 = m.transcribe_batch(clips, t)
+    for a, b, c in zip(outs, outs2, single):
+        assert (a == b).all()                               # deterministic
+        assert len(a) == len(c)
+    assert len(m.transcribe_batch(clips[:1], t)[0]) == len(single[0])

@@ -420,7 +420,7 @@ struct Lin { Q4W w{}; const float* bias = nullptr; };
 struct EncLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2; };
 struct DecLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2, ada0, ada2; float* ada_mul = nullptr; };
 
-struct vox_cache { vox_model* m; vox_ctx* ctx = nullptr; float *k = nullptr, *v = nullptr; int max_seq = 0, len = 0; };   // per layer: [n_kv][max_seq][hd]
+struct vox_cache { vox_model* m; vox_ctx* ctx = nullptr; float *k = nullptr, *v = nullptr; int max_seq = 0, len = 0; size_t layer_stride = 0; };   // layer_stride in floats   // per layer: [n_kv][max_seq][hd]
 
 struct vox_model {
     vox_ctx* ctx = nullptr; vox_model_cfg cfg{};
@@ -863,6 +863,7 @@ static int32_t cache_alloc(vox_model* m, int max_seq, vox_cache** out) {
     const size_t n = (size_t)c.dec_layers * c.dec_kv_heads * max_seq * c.dec_head_dim * 4;
     if (hipMalloc((void**)&k->k, n) != hipSuccess || hipMalloc((void**)&k->v, n) != hipSuccess) { if (k->k) (void)hipFree(k->k); delete k; return fail(VOX_ERR_HIP, "hipMalloc of KV cache failed"); }
     HIPCHK(hipMemsetAsync(k->k, 0, n, m->ctx->stream)); HIPCHK(hipMemsetAsync(k->v, 0, n, m->ctx->stream));
+    k->layer_stride = (size_t)c.dec_kv_heads * max_seq * c.dec_head_dim;
     *out = k; return VOX_OK;
 }
 extern "C" int32_t vox_decoder_cache_create(vox_model* m, int32_t max_seq, vox_cache** out) { ARGCHK(m && out, "null argument"); VOXCHK(ctx_bind(m->ctx)); return cache_alloc(m, max_seq, out); }
@@ -874,7 +875,7 @@ extern "C" int32_t vox_cache_free(vox_cache* k) {
 extern "C" int32_t vox_cache_seq_len(const vox_cache* k, int32_t* out) { ARGCHK(k && out, "null argument"); *out = k->len; return VOX_OK; }
 extern "C" int32_t vox_cache_reset(vox_cache* k) { ARGCHK(k, "null cache"); k->len = 0; return VOX_OK; }
 
-static size_t cache_layer_floats(const vox_model* m, const vox_cache* k) { return (size_t)m->cfg.dec_kv_heads * k->max_seq * m->cfg.dec_head_dim; }
+static size_t cache_layer_floats(const vox_model* m, const vox_cache* k) { (void)m; return k->layer_stride; }
 
 // ---- multi-row decoder forward (prefill): x [M][D] device, in place; positions off..off+M-1  (gguf/model.rs:370-387)
 static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc, int off) {
@@ -1080,6 +1081,132 @@ extern "C" int32_t vox_transcribe_audio(vox_model* m, const float* samples, size
     m->timings.preprocess_ms = now_ms() - t0;
     VOXCHK(transcribe_dev(m, m->d_mel, (int)T, t_embed, out_ids, cap, n_ids, nullptr));
     m->timings.total_ms = m->timings.preprocess_ms + m->timings.encode_ms + m->timings.decode_ms;
+    return VOX_OK;
+}
+
+// ---- batched transcription (BASELINE config "Batch=16 x 16 s"; the reference has no batch API: its callers loop) -------------
+// Every utterance runs the whole hot path; encode + 38-token prefill are per utterance, the decode loop is batched: one step
+// advances all sequences (rows of one skinny MFMA GEMM per linear, so the Q4 weights are streamed once per step for the
+// whole batch), per-sequence positions / KV-cache slices / audio rows live on the device, the step is hipGraph-replayed.
+extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
+                                        int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind) {
+    ARGCHK(m && samples && n_samples && t_embed && out_ids && caps && n_ids, "null argument"); ARGCHK(n > 0 && n <= 64, "batch size %d out of range (1..64)", n);
+    VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
+    ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
+    const int PREFIX_LEN = 38, BOS = 1, STREAMING_PAD = 32;
+    const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, W = QD + 2 * KD, F = c.dec_ffn, V = c.vocab;
+    VOXCHK(vox_model_set_t_embed(m, t_embed));
+    m->timings = vox_timings{};
+    vox_pad_cfg pc; vox_pad_cfg_voxtral(&pc);
+    MelTables mt; VOXCHK(ctx_mel_tables(cx, &mt));
+    // sequence lengths (pure function of the sample count: pad.rs + mel.rs:175-182 + conv.rs:47-48 + adapter.rs:114)
+    std::vector<int> S(n), T(n); int Smax = 0;
+    for (int i = 0; i < n; i++) {
+        ARGCHK(samples[i] && n_samples[i] > 0, "empty audio in batch slot %d", i);
+        const size_t left = pad_left(&pc), total = left + n_samples[i] + pad_right(&pc, n_samples[i] + left);
+        T[i] = (int)(total / 160); S[i] = conv_len(conv_len(T[i])) / c.reshape_factor; Smax = std::max(Smax, S[i]);
+        ARGCHK(caps[i] >= std::max(S[i] - PREFIX_LEN, 0), "out_ids[%d] capacity %d < %d", i, caps[i], S[i] - PREFIX_LEN);
+    }
+    ARGCHK(Smax <= m->dec_rope_len, "sequence too long for the decoder RoPE table");
+    const int max_seq = std::max((Smax + 63) / 64 * 64, 64), tstride = Smax + 2;
+    const size_t seq_stride = (size_t)KV * max_seq * hd, layer_stride = (size_t)n * seq_stride;
+    DevBuf b_audio, b_k, b_v, b_tok, b_pos, b_len, b_h, b_xn, b_qkv, b_att, b_act, b_logits, b_px;
+    HIPCHK(b_audio.alloc((size_t)n * Smax * D * 4)); HIPCHK(b_k.alloc(layer_stride * c.dec_layers * 4)); HIPCHK(b_v.alloc(layer_stride * c.dec_layers * 4));
+    HIPCHK(b_tok.alloc((size_t)n * tstride * 4)); HIPCHK(b_pos.alloc((size_t)n * 4)); HIPCHK(b_len.alloc((size_t)n * 4));
+    HIPCHK(b_h.alloc((size_t)n * D * 4)); HIPCHK(b_xn.alloc((size_t)n * D * 4)); HIPCHK(b_qkv.alloc((size_t)n * W * 4)); HIPCHK(b_att.alloc((size_t)n * QD * 4));
+    HIPCHK(b_act.alloc((size_t)n * F * 4)); HIPCHK(b_logits.alloc((size_t)n * V * 4)); HIPCHK(b_px.alloc((size_t)PREFIX_LEN * D * 4));
+    HIPCHK(hipMemsetAsync(b_tok.p, 0, (size_t)n * tstride * 4, s)); HIPCHK(hipMemsetAsync(b_h.p, 0, (size_t)n * D * 4, s));
+    float* d_audio = b_audio.as<float>(); int* d_tok = b_tok.as<int>(); int* d_pos = b_pos.as<int>();
+    const double t0 = now_ms();
+    // (1) per utterance: peak-normalise -> pad -> log-mel -> encoder -> adapter; (2) 38-token prefill into its KV-cache slice
+    std::vector<int32_t> prefix(PREFIX_LEN, STREAMING_PAD); prefix[0] = BOS;
+    std::vector<int> pos0(n), len(n);
+    double enc_ms = 0, pre_ms = 0;
+    for (int i = 0; i < n; i++) {
+        const double ta = now_ms();
+        const float* d_s = samples[i];
+        if (mem_kind == VOX_MEM_HOST) {
+            VOXCHK(ensure(&m->d_samples, &m->samples_cap, n_samples[i]));
+            HIPCHK(hipMemcpyAsync(m->d_samples, samples[i], n_samples[i] * 4, hipMemcpyHostToDevice, s)); d_s = m->d_samples;
+        }
+        const size_t left = pad_left(&pc), right = pad_right(&pc, n_samples[i] + left);
+        VOXCHK(ensure(&m->d_mel, &m->mel_cap, (size_t)128 * T[i]));
+        HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, cx->d_scale, s));
+        HIPCHK(launch_mel(d_s, (long)n_samples[i], (long)left, (long)right, cx->d_scale, mt, m->d_mel, T[i], 1, s));
+        HIPCHK(hipStreamSynchronize(s)); const double tb = now_ms(); pre_ms += tb - ta;
+        int S4 = 0; VOXCHK(encode_dev(m, m->d_mel, T[i], &S4));
+        ARGCHK(S4 == S[i], "internal: sequence length mismatch (%d vs %d)", S4, S[i]);
+        if (S4 > 0) HIPCHK(hipMemcpyAsync(d_audio + (size_t)i * Smax * D, m->d_audio, (size_t)S4 * D * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s)); enc_ms += now_ms() - tb;
+        pos0[i] = PREFIX_LEN; len[i] = S[i];
+        if (S[i] < PREFIX_LEN) { pos0[i] = 0; len[i] = 1; continue; }          // gguf/model.rs:887-889: empty result
+        HIPCHK(hipMemcpyAsync(d_tok + (size_t)i * tstride, prefix.data(), PREFIX_LEN * 4, hipMemcpyHostToDevice, s));
+    }
+    const double t1 = now_ms();
+    HIPCHK(hipMemcpyAsync(d_pos, pos0.data(), (size_t)n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    for (int i = 0; i < n; i++) {
+        if (S[i] < PREFIX_LEN) continue;
+        vox_cache view; view.m = m; view.ctx = cx; view.k = b_k.as<float>() + (size_t)i * seq_stride; view.v = b_v.as<float>() + (size_t)i * seq_stride;
+        view.max_seq = max_seq; view.len = 0; view.layer_stride = layer_stride;
+        const float* au = d_audio + (size_t)i * Smax * D;
+        HIPCHK(launch_embed(m->tok.w, d_tok + (size_t)i * tstride, PREFIX_LEN, au, D, nullptr, 0, 0, b_px.as<float>(), s));
+        VOXCHK(decoder_prefill_dev(m, b_px.as<float>(), PREFIX_LEN, &view, 0));
+        VOXCHK(lm_head_argmax_dev(m, b_px.as<float>() + (size_t)(PREFIX_LEN - 1) * D, nullptr));
+        HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, m->n_parts, d_tok + (size_t)i * tstride, d_pos + i, 0, 0, s));          // tokens[i][38]
+        HIPCHK(launch_embed(m->tok.w, d_tok + (size_t)i * tstride, 1, au, D, d_pos + i, 0, 0, b_h.as<float>() + (size_t)i * D, s));     // first step input
+    }
+    // (3) batched decode steps
+    int steps = 0; for (int i = 0; i < n; i++) steps = std::max(steps, S[i] - PREFIX_LEN - 1);
+    auto step = [&]() -> int32_t {
+        float* h = b_h.as<float>(); float* xn = b_xn.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>(); float* act = b_act.as<float>();
+        for (int l = 0; l < c.dec_layers; l++) {
+            const DecLayer& L = m->dec[l]; float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;
+            HIPCHK(launch_rms_norm(h, D, n, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
+            { GemmParams g{}; g.w = L.wqkv.w; g.x = xn; g.x_stride = D; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+            HIPCHK(launch_rope_kv_batch(qkv, n, W, QD, KV, hd, d_pos, m->dec_cos, m->dec_sin, kl, vl, (long)seq_stride, max_seq * hd, s));
+            AttnParams ap{}; ap.q = qkv; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
+            ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
+            HIPCHK(launch_attn_decode(ap, hd, max_seq, s, n));
+            { GemmParams g{}; g.w = L.wo.w; g.x = att; g.x_stride = QD; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+            HIPCHK(launch_rms_norm(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));
+            { GemmParams g{}; g.w = L.w13.w; g.x = xn; g.x_stride = D; g.M = n; g.out = act; g.out_stride = F; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU, s)); }
+            { GemmParams g{}; g.w = L.w2.w; g.x = act; g.x_stride = F; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+        }
+        HIPCHK(launch_rms_norm(h, D, n, D, m->dec_norm, nullptr, c.norm_eps, xn, D, s));
+        { GemmParams g{}; g.w = m->tok.w; g.x = xn; g.x_stride = D; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+        HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)Smax * D, D, h, s));
+        return VOX_OK;
+    };
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int replays = 0;
+    if (steps > 0) {
+        VOXCHK(step());                                          // eager first step
+        if (steps > 1) {
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int32_t r = step();
+            const hipError_t ce = hipStreamEndCapture(s, &graph);
+            if (r != VOX_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
+            HIPCHK(ce);
+            hipError_t ie = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+            if (ie != hipSuccess) { (void)hipGraphDestroy(graph); return fail(VOX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+            for (int i = 1; i < steps; i++) { if (hipGraphLaunch(gexec, s) != hipSuccess) { (void)hipGraphExecDestroy(gexec); (void)hipGraphDestroy(graph); return fail(VOX_ERR_HIP, "hipGraphLaunch failed"); } }
+            replays = steps - 1;
+        }
+    }
+    std::vector<int32_t> host_tok((size_t)n * tstride);
+    HIPCHK(hipMemcpyAsync(host_tok.data(), d_tok, host_tok.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
+    int total = 0;
+    for (int i = 0; i < n; i++) {
+        const int cnt = std::max(S[i] - PREFIX_LEN, 0);
+        if (cnt > 0) std::memcpy(out_ids[i], host_tok.data() + (size_t)i * tstride + PREFIX_LEN, (size_t)cnt * 4);
+        n_ids[i] = cnt; total += cnt;
+    }
+    m->timings.preprocess_ms = pre_ms; m->timings.encode_ms = enc_ms; m->timings.decode_ms = now_ms() - t1; m->timings.total_ms = now_ms() - t0;
+    m->timings.decode_tokens = total; m->timings.graph_replays = replays;
     return VOX_OK;
 }
 

@@ -71,9 +71,11 @@ struct AttnParams {
     float* out; int out_stride;              // out[m][h*hd + d]
     int M, kv_len, n_heads, n_kv_heads, offset, window;   // query m at position offset+m; window<0: none
     const int* pos_ptr;                      // decode: position = *pos_ptr + offset, kv_len = position+1
+    // batched decode (gridDim.y = sequences): sequence s reads pos_ptr[s] and its own q / out rows and KV-cache slice
+    int pos_per_seq; int q_seq_stride, out_seq_stride; long kv_seq_stride;
 };
 hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s);     // M > 1, causal (+window)
-hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s);  // M == 1
+hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq = 1);  // M == 1 per sequence
 
 // gelu(conv1d k3 s2 p1): in [Cin][L] -> out; out_token_major: out[t][co] else out[co][t]
 hipError_t launch_conv1d_gelu(const float* in, int Cin, int L, const float* w, const float* b, int Cout, float* out,
@@ -95,6 +97,11 @@ hipError_t launch_argmax_final(const float* part_val, const int* part_idx, int n
 // fused decode-step tail: tokens[*pos+1] = argmax(partials); *pos += 1; h = audio[*pos] + dequant(tok[tokens[*pos]])
 hipError_t launch_argmax_embed(const float* part_val, const int* part_idx, int n_parts, int* tokens, int* pos_ptr, Q4W tok,
                                const float* audio, int D, float* h, hipStream_t s);
+// batched decode step helpers (n sequences, per-sequence positions pos[s], caches [seq][kv_head][max_seq][hd] per layer)
+hipError_t launch_rope_kv_batch(float* qkv, int n, int stride, int n_q, int n_kv, int hd, const int* pos, const float* cos_t, const float* sin_t,
+                                float* kcache, float* vcache, long seq_stride, int head_stride, hipStream_t s);
+hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int* tokens, int tok_stride, int* pos, const int* seq_len, Q4W tok,
+                                     const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s);
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
 hipError_t launch_gelu(float* x, long n, hipStream_t s);
 

@@ -1114,19 +1114,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     static_assert(HD == 128 || HD == 64, "head_dim");
     constexpr int PER = HD / 8;       // floats per lane in the score phase
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, kvh = h / (p.n_heads / p.n_kv_heads);
-    const int pos = (p.pos_ptr ? *p.pos_ptr : 0) + p.offset;
+    const int h = blockIdx.x, kvh = h / (p.n_heads / p.n_kv_heads), seq = blockIdx.y;
+    const int pos = (p.pos_ptr ? p.pos_ptr[p.pos_per_seq ? seq : 0] : 0) + p.offset;
     const int len = pos + 1;
     const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0;
     const int n = len - j_lo;
     const float scale = 1.0f / sqrtf((float)HD);
-    const float* kb = p.k + (size_t)kvh * p.kv_head_stride;
-    const float* vb = p.v + (size_t)kvh * p.kv_head_stride;
+    const float* kb = p.k + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const float* vb = p.v + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const float* qrow = p.q + (size_t)seq * p.q_seq_stride;
+    float* orow = p.out + (size_t)seq * p.out_seq_stride;
     const int ks = tid >> 3, part = tid & 7;
     float qv[PER];
 #pragma unroll
     for (int e = 0; e < PER; e += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(p.q + h * HD + part * PER + e);
+        const float4 v = *reinterpret_cast<const float4*>(qrow + h * HD + part * PER + e);
         qv[e] = v.x; qv[e + 1] = v.y; qv[e + 2] = v.z; qv[e + 3] = v.w;
     }
     for (int i0 = 0; i0 < n; i0 += 64) {
@@ -1187,20 +1189,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
 #pragma unroll
         for (int gq = 1; gq < GROUPS; gq++) { const float4 u = osum[gq * COLS + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
         const float inv = 1.0f / sum;
-        *reinterpret_cast<float4*>(p.out + h * HD + tid * 4) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+        *reinterpret_cast<float4*>(orow + h * HD + tid * 4) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
     }
 }
-hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s) {
+hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq) {
     const size_t lds = (size_t)max_seq * sizeof(float);
     if (hd == 128) {
         auto kern = attn_decode_kernel<128>;
         static bool attr_done = false;
         hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
         if (e != hipSuccess) return e;
-        kern<<<dim3(p.n_heads), dim3(256), lds, s>>>(p);
+        kern<<<dim3(p.n_heads, n_seq), dim3(256), lds, s>>>(p);
     } else if (hd == 64) {
         auto kern = attn_decode_kernel<64>;
-        kern<<<dim3(p.n_heads), dim3(256), lds, s>>>(p);
+        kern<<<dim3(p.n_heads, n_seq), dim3(256), lds, s>>>(p);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1458,6 +1460,77 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
 hipError_t launch_argmax_embed(const float* pv, const int* pi, int n_parts, int* tokens, int* pos_ptr, Q4W tok, const float* audio, int D,
                                float* h, hipStream_t s) {
     argmax_embed_kernel<<<dim3(1), dim3(256), 0, s>>>(pv, pi, n_parts, tokens, pos_ptr, tok, audio, D, h);
+    return hipGetLastError();
+}
+
+// ---- batched decode step helpers -------------------------------------------------------------------------------
+// RoPE on q,k of every sequence's fused [q|k|v] row at that sequence's own position, k/v scattered into its cache slice.
+__global__ void rope_kv_batch_kernel(float* __restrict__ qkv, int n, int stride, int n_q, int n_kv, int hd, const int* __restrict__ pos,
+                                     const float* __restrict__ cos_t, const float* __restrict__ sin_t, float* __restrict__ kc,
+                                     float* __restrict__ vc, long seq_stride, int head_stride) {
+    const int kd = n_kv * hd, pairs = (n_q + 2 * kd) >> 1, half = hd >> 1;
+    const long total = (long)n * pairs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / pairs), col = (int)(i % pairs) * 2, ps = pos[r];
+        float* row = qkv + (size_t)r * stride;
+        const float a = row[col], b = row[col + 1];
+        if (col < n_q + kd) {
+            const int dd = col % hd;
+            const float c = cos_t[(size_t)ps * half + (dd >> 1)], sn = sin_t[(size_t)ps * half + (dd >> 1)];
+            const float ra = a * c - b * sn, rb = a * sn + b * c;
+            if (col < n_q) { row[col] = ra; row[col + 1] = rb; }
+            else {
+                const int kn = col - n_q;
+                float* dst = kc + (size_t)r * seq_stride + (size_t)(kn / hd) * head_stride + (size_t)ps * hd + dd;
+                dst[0] = ra; dst[1] = rb;
+            }
+        } else {
+            const int vn = col - n_q - kd;
+            float* dst = vc + (size_t)r * seq_stride + (size_t)(vn / hd) * head_stride + (size_t)ps * hd + (vn % hd);
+            dst[0] = a; dst[1] = b;
+        }
+    }
+}
+hipError_t launch_rope_kv_batch(float* qkv, int n, int stride, int n_q, int n_kv, int hd, const int* pos, const float* cos_t, const float* sin_t,
+                                float* kc, float* vc, long seq_stride, int head_stride, hipStream_t s) {
+    const long total = (long)n * ((n_q + 2 * n_kv * hd) / 2);
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    rope_kv_batch_kernel<<<dim3(blocks), dim3(256), 0, s>>>(qkv, n, stride, n_q, n_kv, hd, pos, cos_t, sin_t, kc, vc, seq_stride, head_stride);
+    return hipGetLastError();
+}
+
+// one workgroup per sequence: argmax of its logits row (lowest index wins ties) -> tokens[s][pos+1], pos[s]++ (until the
+// sequence's last position), then the next step's input h[s] = audio[s][pos] + embed(tokens[s][pos]).
+__global__ __launch_bounds__(256) void argmax_embed_batch_kernel(const float* __restrict__ logits, int vocab, int* __restrict__ tokens,
+                                                                 int tok_stride, int* __restrict__ pos, const int* __restrict__ seq_len, Q4W tok,
+                                                                 const float* __restrict__ audio, long audio_seq_stride, int D, float* __restrict__ h) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    __shared__ int s_tok, s_cur;
+    const int sq = blockIdx.x;
+    const float* lg = logits + (size_t)sq * vocab;
+    float v = -INFINITY; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < vocab; i += 256) { const float x = lg[i]; if (x > v) { v = x; idx = i; } }   // ascending i: first max wins
+    bv[threadIdx.x] = v; bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            const float x = bv[threadIdx.x + st]; const int ii = bi[threadIdx.x + st];
+            if (x > bv[threadIdx.x] || (x == bv[threadIdx.x] && ii < bi[threadIdx.x])) { bv[threadIdx.x] = x; bi[threadIdx.x] = ii; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int cur = pos[sq];
+        if (cur + 1 < seq_len[sq]) { cur += 1; tokens[(size_t)sq * tok_stride + cur] = bi[0]; pos[sq] = cur; }   // finished sequences idle in place
+        s_cur = cur; s_tok = tokens[(size_t)sq * tok_stride + cur];
+    }
+    __syncthreads();
+    embed_row(tok, s_tok, audio + (size_t)sq * audio_seq_stride + (size_t)s_cur * D, h + (size_t)sq * D, D);
+}
+hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int* tokens, int tok_stride, int* pos, const int* seq_len, Q4W tok,
+                                     const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s) {
+    argmax_embed_batch_kernel<<<dim3(n), dim3(256), 0, s>>>(logits, vocab, tokens, tok_stride, pos, seq_len, tok, audio, audio_seq_stride, D, h);
     return hipGetLastError();
 }
 

@@ -321,6 +321,21 @@ class Q4VoxtralModel:
         check(lib().vox_transcribe_audio(self.h, ptr, n_samples, _ptr(t), _ptr(ids), cap, C.byref(n), kind))
         return ids[:n.value].copy()
 
+    def transcribe_batch(self, samples_list, t_embed, device_ptrs=None, n_samples=None):
+        """Batched whole-path transcription of independent utterances (<= 64): list of float32 sample arrays (or device
+        pointers + lengths) -> list of id arrays.  Decode steps are batched so weights stream once per step."""
+        t = _f32(t_embed).reshape(-1)
+        if device_ptrs is None:
+            arrs = [_f32(x) for x in samples_list]; n = len(arrs)
+            ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs]); lens = (C.c_size_t * n)(*[a.size for a in arrs]); kind = 0
+        else:
+            n = len(device_ptrs); ptrs = (C.c_void_p * n)(*device_ptrs); lens = (C.c_size_t * n)(*n_samples); kind = 1
+        caps = [int(lens[i]) // 1280 + 128 for i in range(n)]
+        outs = [np.zeros(cp, dtype=np.int32) for cp in caps]
+        optrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs]); ccaps = (C.c_int32 * n)(*caps); nids = (C.c_int32 * n)()
+        check(lib().vox_transcribe_batch(self.h, n, ptrs, lens, _ptr(t), optrs, ccaps, nids, kind))
+        return [outs[i][:nids[i]].copy() for i in range(n)]
+
     def timings(self):
         t = _lib.Timings(); check(lib().vox_get_stage_timings(self.h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.Timings._fields_}
