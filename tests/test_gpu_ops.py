@@ -152,3 +152,19 @@ def test_log_mel_vs_oracle(pkg, orc, ctx):
     a = mel.compute_log(clip); b = orc.mel_compute_log(clip)
     assert a.shape == (clip.size // 160, 128) and np.abs(a - b).max() < 1e-4
     assert mel.compute_log(np.zeros(100, np.float32)).shape == (0, 128)
+
+
+@pytest.mark.parametrize("m,k,n", [(16, 128, 16), (16, 3072, 512), (9, 9216, 96), (16, 4096, 40), (5, 256, 1000), (13, 1280, 2048), (16, 5120, 272)])
+def test_q4_skinny_batched_decode_gemm(pkg, orc, ctx, m, k, n):
+    """5..16 rows (one per sequence of a decode batch) x K % 128 == 0: the skinny MFMA kernel (split-K across waves,
+    in-register 4x4 dword transpose of the weight fragments); ragged N, asymmetric data."""
+    rng = np.random.default_rng(m * 3 + k + n)
+    raw = pkg.synth.synth_q4_blocks(rng, n * k, 0.05)
+    x = (rng.standard_normal((1, m, k)) * (1 + np.arange(k) / k)).astype(np.float32)
+    x[0, :, ::7] *= 3.0
+    exp = orc.q4_matmul(raw, n, k, x)
+    out = pkg.q4_matmul(x, pkg.Q4Tensor.from_q4_bytes(raw, [n, k], ctx))
+    assert np.abs(out - exp).max() / np.abs(exp).max() < 2e-5
+    bias = rng.standard_normal(n).astype(np.float32)
+    outb = pkg.Q4Linear.new(pkg.Q4Tensor.from_q4_bytes(raw, [n, k], ctx), bias).forward(x)
+    assert np.abs(outb - (exp + bias)).max() / np.abs(exp).max() < 2e-5

@@ -842,6 +842,128 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
     }
 }
 
+// ---- skinny MFMA GEMM for M <= 16 rows (batched decode: one row per sequence).  HBM-bound: the weights are streamed once
+// for the whole batch.  No LDS on the operand path, no barriers until the final reduction:
+//  * a wave owns NTW n-tiles (16 weight rows each) and every KS-th 128-wide K step (split-K across the KS waves of the
+//    workgroup, combined through LDS in a fixed order -> deterministic);
+//  * weights: one global_load_dwordx4 per lane per n-tile per K step -- lane (n = l&15, g = l>>4) fetches the whole 16-byte
+//    block 4q+g of row n (1 KB contiguous per wave-load from the row-major plane), then a 4x4 dword transpose across the four
+//    16-lane rows (2x v_permlane16_swap + 2x v_permlane32_swap) leaves it with dword g of blocks 4q..4q+3 = its MFMA B fragments;
+//  * activations: f32 rows read straight from global/L2 in fragment order and split hi+lo bf16 in registers, reused by the NTW tiles.
+template <int NTW, int EPI>
+__global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS][NTW][64][4]
+    const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, KS = blockDim.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int nbase = blockIdx.x * (16 * NTW);
+    const float* xrow = p.x + (size_t)min(li, M - 1) * p.x_stride;
+    const uint4* wq[NTW]; const uint16_t* ws[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const size_t row = (size_t)min(nbase + t * 16 + li, N - 1);
+        wq[t] = p.w.qs + row * nb + g; ws[t] = p.w.sc + row * nb;
+    }
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 wv[NTW], wvn[NTW]; uint2 sv[NTW], svn[NTW]; float4 xa[4], xb[4], xan[4], xbn[4];
+#define VOX_SLOAD(WV_, SV_, XA_, XB_, Q_)                                                                  \
+    _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                      \
+        WV_[t] = ld_nt_u4(wq[t] + 4 * (Q_)); SV_[t] = *reinterpret_cast<const uint2*>(ws[t] + 4 * (Q_)); } \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                        \
+        XA_[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 4 * g);                     \
+        XB_[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 16 + 4 * g); }
+#define VOX_SSTEP(WV_, SV_, XA_, XB_)                                                                      \
+    {                                                                                                      \
+        uint4 ah[4], al[4];                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) split_bf16x8(XA_[j], XB_[j], ah[j], al[j]);          \
+        _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                  \
+            /* 4x4 dword transpose across the four 16-lane rows: row g ends up with dword g of blocks 4q..4q+3 */ \
+            auto s01 = __builtin_amdgcn_permlane16_swap(WV_[t].x, WV_[t].y, false, false);                 \
+            auto s23 = __builtin_amdgcn_permlane16_swap(WV_[t].z, WV_[t].w, false, false);                 \
+            auto u02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);                     \
+            auto u13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);                     \
+            const uint32_t dw[4] = {u02[0], u13[0], u02[1], u13[1]};                                       \
+            const uint32_t sc2[2] = {SV_[t].x, SV_[t].y};                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                \
+                const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8(dw[j]));                                    \
+                const float d = f16_bits_to_f32((uint16_t)((j & 1) ? (sc2[j >> 1] >> 16) : (sc2[j >> 1] & 0xFFFFu))); \
+                f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), bw, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+                tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[j]), bw, tt, 0, 0, 0);            \
+                acc[t][0] = fmaf(d, tt[0], acc[t][0]); acc[t][1] = fmaf(d, tt[1], acc[t][1]);              \
+                acc[t][2] = fmaf(d, tt[2], acc[t][2]); acc[t][3] = fmaf(d, tt[3], acc[t][3]);              \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+    int q = wave;
+    if (q < nq) {
+        VOX_SLOAD(wv, sv, xa, xb, q)
+        for (;;) {
+            { const int qn = min(q + KS, nq - 1); VOX_SLOAD(wvn, svn, xan, xbn, qn) }     // unconditional prefetch (clamped)
+            VOX_SSTEP(wv, sv, xa, xb)
+            q += KS; if (q >= nq) break;
+            { const int qn = min(q + KS, nq - 1); VOX_SLOAD(wv, sv, xa, xb, qn) }
+            VOX_SSTEP(wvn, svn, xan, xbn)
+            q += KS; if (q >= nq) break;
+        }
+    }
+#undef VOX_SLOAD
+#undef VOX_SSTEP
+    // split-K combine (fixed order) + epilogue: wave t (< NTW) finishes tile t
+#pragma unroll
+    for (int t = 0; t < NTW; t++)
+        *reinterpret_cast<float4*>(sred + ((size_t)(wave * NTW + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
+    if (wave < NTW) {
+        const int t = wave;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < KS; w++) {
+            const float4 v = *reinterpret_cast<const float4*>(sred + ((size_t)(w * NTW + t) * 64 + lane) * 4);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        const int n = nbase + t * 16 + li; const bool nok = n < N;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+        const float vals[4] = {sum.x + bias, sum.y + bias, sum.z + bias, sum.w + bias};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = 4 * g + r;
+            float v = vals[r];
+            if (EPI == EPI_SWIGLU) {
+                const float other = dpp_mov<0xB1>(v);
+                if (m < M && nok && !(n & 1)) p.out[(size_t)m * p.out_stride + (n >> 1)] = silu_f(v) * other;
+            } else if (m < M && nok) {
+                if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + n];
+                if (EPI == EPI_GELU) v = gelu_f(v);
+                p.out[(size_t)m * p.out_stride + n] = v;
+            }
+        }
+    }
+}
+
+template <int NTW>
+static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStream_t s) {
+    dim3 grid((p.w.N + 16 * NTW - 1) / (16 * NTW));
+    const size_t lds = (size_t)ks * NTW * 64 * 4 * sizeof(float);
+    switch (epi) {
+    case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_GELU: q4_skinny_kernel<NTW, EPI_GELU><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_SWIGLU: q4_skinny_kernel<NTW, EPI_SWIGLU><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) {
+    const int nq = p.w.nb / 4, tiles = (p.w.N + 15) / 16;
+    int ntw = (tiles / 4) * 8 >= 1024 ? 4 : 2;
+    int ks = nq >= 8 ? 8 : 4;
+    if ((long)((tiles + ntw - 1) / ntw) * 4 >= 2048) ks = 4;
+    { const int e = env_int("VOX_SKINNY_NTW"); if (e == 2 || e == 4) ntw = e; }
+    { const int e = env_int("VOX_SKINNY_KS"); if (e == 2 || e == 4 || e == 8) ks = e; }
+    return ntw == 4 ? skinny_launch_n<4>(p, epi, ks, s) : skinny_launch_n<2>(p, epi, ks, s);
+}
+
 template <int MT, int NT, int FMT>
 static hipError_t gemm_launch_mn(const GemmParams& p, int epi, hipStream_t s) {
     dim3 grid((p.w.N + 64 * NT - 1) / (64 * NT), (p.M + 16 * MT - 1) / (16 * MT));
@@ -893,6 +1015,7 @@ static hipError_t gemm_launch_f(const GemmParams& p, int epi, hipStream_t s) {
 }
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
+    if (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && !env_int("VOX_NO_SKINNY")) return launch_q4_skinny(p, epi, s);
     return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, s);
 }
 
