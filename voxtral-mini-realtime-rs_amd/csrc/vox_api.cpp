@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -416,7 +417,7 @@ extern "C" int32_t vox_q4_matmul(vox_ctx* c, const vox_q4* w, const float* x, in
 // ------------------------------------------------------------------------------------------------
 // model
 // ------------------------------------------------------------------------------------------------
-struct Lin { Q4W w{}; const float* bias = nullptr; };
+struct Lin { Q4W w{}; const float* bias = nullptr; const uint4* qt = nullptr; const uint16_t* st = nullptr; };   // qt/st: tile-layout copy (batched decode)
 struct EncLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2; };
 struct DecLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2, ada0, ada2; float* ada_mul = nullptr; };
 
@@ -588,7 +589,7 @@ struct Loader {
     }
     // linear made of `parts` source tensors [N_i][K]; rows concatenated (interleave=false) or interleaved (true).
     // Q4_0 sources -> re-packed Q4 planes; dense sources (BF16, or F16/F32 holding bf16-representable values) -> bf16 plane.
-    bool lin(const std::vector<std::string>& parts, bool interleave, Lin* L, bool require_q4) {
+    bool lin(const std::vector<std::string>& parts, bool interleave, Lin* L, bool require_q4, bool tile = false) {
         int64_t K = -1, Ntot = 0; std::vector<TensorView> ts; int kind = -1;
         for (auto& n : parts) {
             TensorView t; if (!need(n, &t)) return false;
@@ -613,6 +614,15 @@ struct Loader {
                     const int mul = interleave ? (int)ts.size() : 1, add = interleave ? (int)i : (int)row0;
                     if (upload_repack(m->ctx, ts[i].data, nn * nb, nb, qs, sc, mul, add, staging, staging_cap) != VOX_OK) return setfail(g_err);
                     row0 += nn;
+                }
+            }
+            if (tile && nb % 4 == 0) {   // second copy in MFMA tile order for the batched-decode (M <= 16) kernel
+                const size_t n_tiles = (size_t)(Ntot + 15) / 16, nq = (size_t)nb / 4;
+                uint4* qt = ar.take<uint4>(n_tiles * nq * 64); uint16_t* st = ar.take<uint16_t>(n_tiles * nq * 64);
+                L->qt = qt; L->st = st;
+                if (fill) {
+                    if (launch_q4_tile_build(L->w, qt, st, m->ctx->stream) != hipSuccess || hipStreamSynchronize(m->ctx->stream) != hipSuccess)
+                        return setfail("q4_tile_build failed");
                 }
             }
             return true;
@@ -705,15 +715,15 @@ struct Loader {
         m->enc_norm = f32(ENC_PFX ".transformer.norm.weight");
         if (!lin({ADP_PFX ".0.weight"}, false, &m->ad0, q4) || !lin({ADP_PFX ".2.weight"}, false, &m->ad2, q4)) return false;    // :378-383
         // tok_embeddings: Q4 (kept Q4 on device, the reference's WASM branch gguf/model.rs:689), or dense (F32/F16 accepted, loader.rs:305-326)
-        if (!lin({TOK_NAME}, false, &m->tok, false)) return false;
+        if (!lin({TOK_NAME}, false, &m->tok, false, true)) return false;
         for (int i = 0; i < nd; i++) {                                                      // gguf/loader.rs:329-375
             DecLayer& L = m->dec[i]; std::string p = "layers." + std::to_string(i);
             if (!lin({p + ".ada_rms_norm_t_cond.0.weight"}, false, &L.ada0, q4) || !lin({p + ".ada_rms_norm_t_cond.2.weight"}, false, &L.ada2, q4)) return false;
             L.attn_norm = f32(p + ".attention_norm.weight"); L.ffn_norm = f32(p + ".ffn_norm.weight");
-            if (!lin({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight"}, false, &L.wqkv, q4)) return false;
-            if (!lin({p + ".attention.wo.weight"}, false, &L.wo, q4)) return false;
-            if (!lin({p + ".feed_forward.w1.weight", p + ".feed_forward.w3.weight"}, true, &L.w13, q4)) return false;
-            if (!lin({p + ".feed_forward.w2.weight"}, false, &L.w2, q4)) return false;
+            if (!lin({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight"}, false, &L.wqkv, q4, true)) return false;
+            if (!lin({p + ".attention.wo.weight"}, false, &L.wo, q4, true)) return false;
+            if (!lin({p + ".feed_forward.w1.weight", p + ".feed_forward.w3.weight"}, true, &L.w13, q4, true)) return false;
+            if (!lin({p + ".feed_forward.w2.weight"}, false, &L.w2, q4, true)) return false;
         }
         m->dec_norm = f32("norm.weight");
         if (!err.empty()) return false;
@@ -1163,25 +1173,26 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         for (int l = 0; l < c.dec_layers; l++) {
             const DecLayer& L = m->dec[l]; float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;
             HIPCHK(launch_rms_norm(h, D, n, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
-            { GemmParams g{}; g.w = L.wqkv.w; g.x = xn; g.x_stride = D; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+            { GemmParams g{}; g.w = L.wqkv.w; g.qt = L.wqkv.qt; g.st = L.wqkv.st; g.x = xn; g.x_stride = D; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
             HIPCHK(launch_rope_kv_batch(qkv, n, W, QD, KV, hd, d_pos, m->dec_cos, m->dec_sin, kl, vl, (long)seq_stride, max_seq * hd, s));
             AttnParams ap{}; ap.q = qkv; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
             ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
             HIPCHK(launch_attn_decode(ap, hd, max_seq, s, n));
-            { GemmParams g{}; g.w = L.wo.w; g.x = att; g.x_stride = QD; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+            { GemmParams g{}; g.w = L.wo.w; g.qt = L.wo.qt; g.st = L.wo.st; g.x = att; g.x_stride = QD; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
             HIPCHK(launch_rms_norm(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));
-            { GemmParams g{}; g.w = L.w13.w; g.x = xn; g.x_stride = D; g.M = n; g.out = act; g.out_stride = F; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU, s)); }
-            { GemmParams g{}; g.w = L.w2.w; g.x = act; g.x_stride = F; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+            { GemmParams g{}; g.w = L.w13.w; g.qt = L.w13.qt; g.st = L.w13.st; g.x = xn; g.x_stride = D; g.M = n; g.out = act; g.out_stride = F; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU, s)); }
+            { GemmParams g{}; g.w = L.w2.w; g.qt = L.w2.qt; g.st = L.w2.st; g.x = act; g.x_stride = F; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
         }
         HIPCHK(launch_rms_norm(h, D, n, D, m->dec_norm, nullptr, c.norm_eps, xn, D, s));
-        { GemmParams g{}; g.w = m->tok.w; g.x = xn; g.x_stride = D; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+        { GemmParams g{}; g.w = m->tok.w; g.qt = m->tok.qt; g.st = m->tok.st; g.x = xn; g.x_stride = D; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
         HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)Smax * D, D, h, s));
         return VOX_OK;
     };
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int replays = 0;
     if (steps > 0) {
         VOXCHK(step());                                          // eager first step
-        if (steps > 1) {
+        if (steps > 1 && getenv("VOX_BATCH_NO_GRAPH")) { for (int i = 1; i < steps; i++) VOXCHK(step()); }   // measurement knob (profilers)
+        else if (steps > 1) {
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             const int32_t r = step();

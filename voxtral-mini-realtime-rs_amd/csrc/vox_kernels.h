@@ -49,7 +49,9 @@ struct GemmParams {
     float* out; int out_stride;
     const float* bias;
     const float* resid; int resid_stride;
+    const uint4* qt; const uint16_t* st;   // optional tile-layout copy of w (see q4_tile_build_kernel); used when M <= 16
 };
+hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);
 
 // ---- small fused ops

@@ -850,7 +850,37 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
 //    block 4q+g of row n (1 KB contiguous per wave-load from the row-major plane), then a 4x4 dword transpose across the four
 //    16-lane rows (2x v_permlane16_swap + 2x v_permlane32_swap) leaves it with dword g of blocks 4q..4q+3 = its MFMA B fragments;
 //  * activations: f32 rows read straight from global/L2 in fragment order and split hi+lo bf16 in registers, reused by the NTW tiles.
-template <int NTW, int EPI>
+// Tile layout (second copy of a Q4 weight, built at load for the batched-decode linears): for n-tile T (16 rows) and K step q
+// (4 blocks) qt[(T*nq + q)*64 + lane] is exactly the uint4 the lane needs -- dword g = lane>>4 of blocks 4q..4q+3 of row
+// 16T + (lane&15) -- so a wave-load is 1 KB contiguous and consecutive K steps are contiguous (pure streaming, no transpose);
+// st[((T*nq + q)*16 + n)*4 + j] is the f16 scale of block 4q+j of row 16T+n.
+__global__ void q4_tile_build_kernel(Q4W w, uint4* __restrict__ qt, uint16_t* __restrict__ st, int n_tiles) {
+    const int nq = w.nb >> 2;
+    const long total = (long)n_tiles * nq * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63); const long tq = i >> 6; const int q = (int)(tq % nq), T = (int)(tq / nq);
+        const int g = lane >> 4, n = T * 16 + (lane & 15);
+        uint32_t d[4] = {0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
+        if (n < w.N) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(w.qs) + ((size_t)n * w.nb + 4 * q) * 4 + g;
+#pragma unroll
+            for (int j = 0; j < 4; j++) d[j] = src[j * 4];
+        }
+        qt[i] = make_uint4(d[0], d[1], d[2], d[3]);
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) st[(tq * 16 + (lane & 15)) * 4 + j] = n < w.N ? w.sc[(size_t)n * w.nb + 4 * q + j] : (uint16_t)0;
+        }
+    }
+}
+hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s) {
+    if (w.nb % 4) return hipErrorInvalidValue;
+    const int n_tiles = (w.N + 15) / 16;
+    q4_tile_build_kernel<<<dim3(2048), dim3(256), 0, s>>>(w, qt, st, n_tiles);
+    return hipGetLastError();
+}
+
+template <int NTW, int EPI, int TILED>
 __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS][NTW][64][4]
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
@@ -859,10 +889,16 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     const int nbase = blockIdx.x * (16 * NTW);
     const float* xrow = p.x + (size_t)min(li, M - 1) * p.x_stride;
     const uint4* wq[NTW]; const uint16_t* ws[NTW];
+    const int n_tiles = (N + 15) >> 4;
 #pragma unroll
     for (int t = 0; t < NTW; t++) {
-        const size_t row = (size_t)min(nbase + t * 16 + li, N - 1);
-        wq[t] = p.w.qs + row * nb + g; ws[t] = p.w.sc + row * nb;
+        if (TILED) {
+            const size_t T = (size_t)min(blockIdx.x * NTW + t, n_tiles - 1);
+            wq[t] = p.qt + T * nq * 64 + lane; ws[t] = p.st + (T * nq * 16 + li) * 4;
+        } else {
+            const size_t row = (size_t)min(nbase + t * 16 + li, N - 1);
+            wq[t] = p.w.qs + row * nb + g; ws[t] = p.w.sc + row * nb;
+        }
     }
     f32x4 acc[NTW];
 #pragma unroll
@@ -870,7 +906,7 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     uint4 wv[NTW], wvn[NTW]; uint2 sv[NTW], svn[NTW]; float4 xa[4], xb[4], xan[4], xbn[4];
 #define VOX_SLOAD(WV_, SV_, XA_, XB_, Q_)                                                                  \
     _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                      \
-        WV_[t] = ld_nt_u4(wq[t] + 4 * (Q_)); SV_[t] = *reinterpret_cast<const uint2*>(ws[t] + 4 * (Q_)); } \
+        WV_[t] = ld_nt_u4(wq[t] + (TILED ? 64 : 4) * (Q_)); SV_[t] = *reinterpret_cast<const uint2*>(ws[t] + (TILED ? 64 : 4) * (Q_)); } \
     _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                        \
         XA_[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 4 * g);                     \
         XB_[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 16 + 4 * g); }
@@ -880,11 +916,14 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
         _Pragma("unroll") for (int j = 0; j < 4; j++) split_bf16x8(XA_[j], XB_[j], ah[j], al[j]);          \
         _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                  \
             /* 4x4 dword transpose across the four 16-lane rows: row g ends up with dword g of blocks 4q..4q+3 */ \
-            auto s01 = __builtin_amdgcn_permlane16_swap(WV_[t].x, WV_[t].y, false, false);                 \
-            auto s23 = __builtin_amdgcn_permlane16_swap(WV_[t].z, WV_[t].w, false, false);                 \
-            auto u02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);                     \
-            auto u13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);                     \
-            const uint32_t dw[4] = {u02[0], u13[0], u02[1], u13[1]};                                       \
+            uint32_t dw[4] = {WV_[t].x, WV_[t].y, WV_[t].z, WV_[t].w};                                     \
+            if (!TILED) {                                                                                  \
+                auto s01 = __builtin_amdgcn_permlane16_swap(WV_[t].x, WV_[t].y, false, false);             \
+                auto s23 = __builtin_amdgcn_permlane16_swap(WV_[t].z, WV_[t].w, false, false);             \
+                auto u02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);                 \
+                auto u13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);                 \
+                dw[0] = u02[0]; dw[1] = u13[0]; dw[2] = u02[1]; dw[3] = u13[1];                            \
+            }                                                                                              \
             const uint32_t sc2[2] = {SV_[t].x, SV_[t].y};                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                \
                 const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8(dw[j]));                                    \
@@ -896,16 +935,19 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             }                                                                                              \
         }                                                                                                  \
     }
-    int q = wave;
-    if (q < nq) {
+    // wave's K steps: [q, qend) step qs -- a contiguous range when tiled (pure streaming), interleaved otherwise
+    const int per = (nq + KS - 1) / KS;
+    int q = TILED ? wave * per : wave;
+    const int qend = TILED ? min(q + per, nq) : nq, qs = TILED ? 1 : KS;
+    if (q < qend) {
         VOX_SLOAD(wv, sv, xa, xb, q)
         for (;;) {
-            { const int qn = min(q + KS, nq - 1); VOX_SLOAD(wvn, svn, xan, xbn, qn) }     // unconditional prefetch (clamped)
+            { const int qn = min(q + qs, qend - 1); VOX_SLOAD(wvn, svn, xan, xbn, qn) }     // unconditional prefetch (clamped)
             VOX_SSTEP(wv, sv, xa, xb)
-            q += KS; if (q >= nq) break;
-            { const int qn = min(q + KS, nq - 1); VOX_SLOAD(wv, sv, xa, xb, qn) }
+            q += qs; if (q >= qend) break;
+            { const int qn = min(q + qs, qend - 1); VOX_SLOAD(wv, sv, xa, xb, qn) }
             VOX_SSTEP(wvn, svn, xan, xbn)
-            q += KS; if (q >= nq) break;
+            q += qs; if (q >= qend) break;
         }
     }
 #undef VOX_SLOAD
@@ -941,15 +983,15 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     }
 }
 
-template <int NTW>
+template <int NTW, int TILED>
 static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStream_t s) {
     dim3 grid((p.w.N + 16 * NTW - 1) / (16 * NTW));
     const size_t lds = (size_t)ks * NTW * 64 * 4 * sizeof(float);
     switch (epi) {
-    case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-    case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-    case EPI_GELU: q4_skinny_kernel<NTW, EPI_GELU><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-    case EPI_SWIGLU: q4_skinny_kernel<NTW, EPI_SWIGLU><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE, TILED><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID, TILED><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_GELU: q4_skinny_kernel<NTW, EPI_GELU, TILED><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_SWIGLU: q4_skinny_kernel<NTW, EPI_SWIGLU, TILED><<<grid, dim3(64 * ks), lds, s>>>(p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -961,7 +1003,9 @@ static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) 
     if ((long)((tiles + ntw - 1) / ntw) * 4 >= 2048) ks = 4;
     { const int e = env_int("VOX_SKINNY_NTW"); if (e == 2 || e == 4) ntw = e; }
     { const int e = env_int("VOX_SKINNY_KS"); if (e == 2 || e == 4 || e == 8) ks = e; }
-    return ntw == 4 ? skinny_launch_n<4>(p, epi, ks, s) : skinny_launch_n<2>(p, epi, ks, s);
+    if (p.qt && p.st && !env_int("VOX_SKINNY_NO_TILE"))
+        return ntw == 4 ? skinny_launch_n<4, 1>(p, epi, ks, s) : skinny_launch_n<2, 1>(p, epi, ks, s);
+    return ntw == 4 ? skinny_launch_n<4, 0>(p, epi, ks, s) : skinny_launch_n<2, 0>(p, epi, ks, s);
 }
 
 template <int MT, int NT, int FMT>
@@ -1057,9 +1101,43 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(const float* __restrict__
     for (int c = lane + 1024; c < n4; c += 64) VOX_RMS_OUT(xr[c], c)
 #undef VOX_RMS_OUT
 }
+// few rows (batched decode: one row per sequence): one 256-thread workgroup per row, every load issued at once
+__global__ __launch_bounds__(256) void rms_norm_row_kernel(const float* __restrict__ x, int x_stride, int dim, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mul, float eps, float* __restrict__ out, int out_stride) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, n4 = dim >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
+    float4 v[10]; float ss = 0.f;                       // dim <= 10240
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const int c = tid + 256 * i;
+        v[i] = xr[min(c, n4 - 1)];
+        if (c < n4) ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float rms = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)dim + eps);
+    float4* o = reinterpret_cast<float4*>(out + (size_t)row * out_stride);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* m4 = reinterpret_cast<const float4*>(mul);
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const int c = tid + 256 * i;
+        if (c < n4) {
+            float4 t = v[i]; const float4 gm = g4[c];
+            t.x = (t.x / rms) * gm.x; t.y = (t.y / rms) * gm.y; t.z = (t.z / rms) * gm.z; t.w = (t.w / rms) * gm.w;
+            if (mul) { const float4 mm = m4[c]; t.x *= mm.x; t.y *= mm.y; t.z *= mm.z; t.w *= mm.w; }
+            o[c] = t;
+        }
+    }
+}
 hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul, float eps,
                            float* out, int out_stride, hipStream_t s) {
-    rms_norm_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(x, x_stride, rows, dim, gamma, mul, eps, out, out_stride);
+    if (rows <= 64 && dim <= 10240 && dim >= 1024)
+        rms_norm_row_kernel<<<dim3(rows), dim3(256), 0, s>>>(x, x_stride, dim, gamma, mul, eps, out, out_stride);
+    else
+        rms_norm_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(x, x_stride, rows, dim, gamma, mul, eps, out, out_stride);
     return hipGetLastError();
 }
 
@@ -1477,7 +1555,7 @@ hipError_t launch_absmax(const float* x, long n, float target, float* scale_out,
 __device__ __forceinline__ void embed_row(const Q4W& tok, int id, const float* __restrict__ arow, float* __restrict__ o, int D) {
     if (tok.fmt == WFMT_BF16) {
         const uint4* w = tok.qs + (size_t)id * (D >> 3);
-        for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+        for (int c = threadIdx.x; c < (D >> 3); c += blockDim.x) {
             const uint4 q = w[c];
             float4 a = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xFFFF0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xFFFF0000u));
             float4 b = make_float4(__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xFFFF0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xFFFF0000u));
@@ -1489,7 +1567,7 @@ __device__ __forceinline__ void embed_row(const Q4W& tok, int id, const float* _
         }
         return;
     }
-    for (int c = threadIdx.x; c < tok.nb; c += 256) {
+    for (int c = threadIdx.x; c < tok.nb; c += blockDim.x) {
         const uint4 q = tok.qs[(size_t)id * tok.nb + c];
         const float d = f16_bits_to_f32(tok.sc[(size_t)id * tok.nb + c]);
         const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
@@ -1624,19 +1702,25 @@ hipError_t launch_rope_kv_batch(float* qkv, int n, int stride, int n_q, int n_kv
 
 // one workgroup per sequence: argmax of its logits row (lowest index wins ties) -> tokens[s][pos+1], pos[s]++ (until the
 // sequence's last position), then the next step's input h[s] = audio[s][pos] + embed(tokens[s][pos]).
-__global__ __launch_bounds__(256) void argmax_embed_batch_kernel(const float* __restrict__ logits, int vocab, int* __restrict__ tokens,
+__global__ __launch_bounds__(1024) void argmax_embed_batch_kernel(const float* __restrict__ logits, int vocab, int* __restrict__ tokens,
                                                                  int tok_stride, int* __restrict__ pos, const int* __restrict__ seq_len, Q4W tok,
                                                                  const float* __restrict__ audio, long audio_seq_stride, int D, float* __restrict__ h) {
-    __shared__ float bv[256];
-    __shared__ int bi[256];
+    __shared__ float bv[1024];
+    __shared__ int bi[1024];
     __shared__ int s_tok, s_cur;
-    const int sq = blockIdx.x;
+    const int sq = blockIdx.x, nt = blockDim.x;
     const float* lg = logits + (size_t)sq * vocab;
     float v = -INFINITY; int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < vocab; i += 256) { const float x = lg[i]; if (x > v) { v = x; idx = i; } }   // ascending i: first max wins
+    const int v4 = vocab >> 2;
+    for (int i = threadIdx.x; i < v4; i += nt) {            // ascending i per thread: first max wins
+        const float4 x = reinterpret_cast<const float4*>(lg)[i];
+        if (x.x > v) { v = x.x; idx = 4 * i; } if (x.y > v) { v = x.y; idx = 4 * i + 1; }
+        if (x.z > v) { v = x.z; idx = 4 * i + 2; } if (x.w > v) { v = x.w; idx = 4 * i + 3; }
+    }
+    for (int i = 4 * v4 + threadIdx.x; i < vocab; i += nt) { const float x = lg[i]; if (x > v) { v = x; idx = i; } }
     bv[threadIdx.x] = v; bi[threadIdx.x] = idx;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = nt >> 1; st > 0; st >>= 1) {
         if (threadIdx.x < st) {
             const float x = bv[threadIdx.x + st]; const int ii = bi[threadIdx.x + st];
             if (x > bv[threadIdx.x] || (x == bv[threadIdx.x] && ii < bi[threadIdx.x])) { bv[threadIdx.x] = x; bi[threadIdx.x] = ii; }
@@ -1653,7 +1737,7 @@ __global__ __launch_bounds__(256) void argmax_embed_batch_kernel(const float* __
 }
 hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int* tokens, int tok_stride, int* pos, const int* seq_len, Q4W tok,
                                      const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s) {
-    argmax_embed_batch_kernel<<<dim3(n), dim3(256), 0, s>>>(logits, vocab, tokens, tok_stride, pos, seq_len, tok, audio, audio_seq_stride, D, h);
+    argmax_embed_batch_kernel<<<dim3(n), dim3(1024), 0, s>>>(logits, vocab, tokens, tok_stride, pos, seq_len, tok, audio, audio_seq_stride, D, h);
     return hipGetLastError();
 }
 
