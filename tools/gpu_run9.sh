@@ -12,7 +12,7 @@ pkg = load_package(); ctx = pkg.Context(0)
 path = bench.full_gguf_path(pkg, 42, 0, lambda: None)
 model = pkg.Q4ModelLoader.from_file(path).load(ctx)
 t = pkg.TimeEmbedding(3072).embed(6.0)
-for B in (4, 16, 32):
+for B in (1, 16, 32):
     clips = [pkg.synth.synth_audio(16.0, seed=1234 + i) for i in range(B)]
     ptrs = [ctx.upload(c) for c in clips]; lens = [c.size for c in clips]
     model.transcribe_batch(None, t, device_ptrs=ptrs, n_samples=lens)

@@ -881,7 +881,7 @@ hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s) {
 }
 
 template <int NTW, int EPI, int TILED>
-__global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void q4_skinny_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS][NTW][64][4]
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, KS = blockDim.x >> 6;
@@ -903,13 +903,14 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     f32x4 acc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint4 wv[NTW], wvn[NTW]; uint2 sv[NTW], svn[NTW]; float4 xa[4], xb[4], xan[4], xbn[4];
-#define VOX_SLOAD(WV_, SV_, XA_, XB_, Q_)                                                                  \
+    uint4 wv[NTW], wvn[NTW]; uint2 sv[NTW], svn[NTW]; float4 xa[4], xb[4];
+#define VOX_WLOAD(WV_, SV_, Q_)                                                                            \
     _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                      \
-        WV_[t] = ld_nt_u4(wq[t] + (TILED ? 64 : 4) * (Q_)); SV_[t] = *reinterpret_cast<const uint2*>(ws[t] + (TILED ? 64 : 4) * (Q_)); } \
+        WV_[t] = ld_nt_u4(wq[t] + (TILED ? 64 : 4) * (Q_)); SV_[t] = *reinterpret_cast<const uint2*>(ws[t] + (TILED ? 64 : 4) * (Q_)); }
+#define VOX_XLOAD(Q_)                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                        \
-        XA_[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 4 * g);                     \
-        XB_[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 16 + 4 * g); }
+        xa[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 4 * g);                      \
+        xb[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 16 + 4 * g); }
 #define VOX_SSTEP(WV_, SV_, XA_, XB_)                                                                      \
     {                                                                                                      \
         uint4 ah[4], al[4];                                                                                \
@@ -940,17 +941,24 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     int q = TILED ? wave * per : wave;
     const int qend = TILED ? min(q + per, nq) : nq, qs = TILED ? 1 : KS;
     if (q < qend) {
-        VOX_SLOAD(wv, sv, xa, xb, q)
+        VOX_WLOAD(wv, sv, q)
         for (;;) {
-            { const int qn = min(q + qs, qend - 1); VOX_SLOAD(wvn, svn, xan, xbn, qn) }     // unconditional prefetch (clamped)
+            // the weight prefetch for the NEXT step is issued (and pinned) before anything of this step: hipcc otherwise sinks
+            // it next to its consumers to save registers and exposes the HBM latency on every step
+            { const int qn = min(q + qs, qend - 1); VOX_WLOAD(wvn, svn, qn) }
+            VOX_XLOAD(q)
+            __builtin_amdgcn_sched_barrier(0);
             VOX_SSTEP(wv, sv, xa, xb)
             q += qs; if (q >= qend) break;
-            { const int qn = min(q + qs, qend - 1); VOX_SLOAD(wv, sv, xa, xb, qn) }
-            VOX_SSTEP(wvn, svn, xan, xbn)
+            { const int qn = min(q + qs, qend - 1); VOX_WLOAD(wv, sv, qn) }
+            VOX_XLOAD(q)
+            __builtin_amdgcn_sched_barrier(0);
+            VOX_SSTEP(wvn, svn, xa, xb)
             q += qs; if (q >= qend) break;
         }
     }
-#undef VOX_SLOAD
+#undef VOX_WLOAD
+#undef VOX_XLOAD
 #undef VOX_SSTEP
     // split-K combine (fixed order) + epilogue: wave t (< NTW) finishes tile t
 #pragma unroll
@@ -998,11 +1006,10 @@ static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStrea
 }
 static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) {
     const int nq = p.w.nb / 4, tiles = (p.w.N + 15) / 16;
-    int ntw = (tiles / 4) * 8 >= 1024 ? 4 : 2;
-    int ks = nq >= 8 ? 8 : 4;
-    if ((long)((tiles + ntw - 1) / ntw) * 4 >= 2048) ks = 4;
+    int ntw = (tiles / 4) * 4 >= 1024 ? 4 : 2;          // four n-tiles per wave only when that still yields >= 1024 waves
+    int ks = nq >= 4 ? 4 : (nq >= 2 ? 2 : 1);
     { const int e = env_int("VOX_SKINNY_NTW"); if (e == 2 || e == 4) ntw = e; }
-    { const int e = env_int("VOX_SKINNY_KS"); if (e == 2 || e == 4 || e == 8) ks = e; }
+    { const int e = env_int("VOX_SKINNY_KS"); if (e == 1 || e == 2 || e == 4) ks = e; }
     if (p.qt && p.st && !env_int("VOX_SKINNY_NO_TILE"))
         return ntw == 4 ? skinny_launch_n<4, 1>(p, epi, ks, s) : skinny_launch_n<2, 1>(p, epi, ks, s);
     return ntw == 4 ? skinny_launch_n<4, 0>(p, epi, ks, s) : skinny_launch_n<2, 0>(p, epi, ks, s);
