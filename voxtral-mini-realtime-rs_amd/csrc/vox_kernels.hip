@@ -911,14 +911,24 @@ __global__ __launch_bounds__(256) void q4_skinny_kernel(const GemmParams p) {
     _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                        \
         xa[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 4 * g);                      \
         xb[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 16 + 4 * g); }
+// B fragments by bit tricks: bf16 bits 0x4300 | q are exactly 128 + q, so one dword of 8 nibbles becomes 8 bf16 operands
+// in 7 VALU ops (v_and_or_b32 on nibble pairs 16 bits apart).  sum_k x_k (q_k - 8) = sum_k x_k (128 + q_k) - 136 sum_k x_k, and
+// sum_k x_k per (row, block) comes from one extra MFMA pair against an all-ones B, shared by the wave's NTW tiles and already
+// in the accumulator layout.  K-slot order of a lane group g: {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3}.
 #define VOX_SSTEP(WV_, SV_, XA_, XB_)                                                                      \
     {                                                                                                      \
-        uint4 ah[4], al[4];                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) split_bf16x8(XA_[j], XB_[j], ah[j], al[j]);          \
+        uint4 ah[4], al[4]; f32x4 cs[4];                                                                   \
+        const bf16x8 ones = as_bf16x8(make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));     \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                    \
+            split_pair(XA_[j].x, XA_[j].z, ah[j].x, al[j].x); split_pair(XB_[j].x, XB_[j].z, ah[j].y, al[j].y); \
+            split_pair(XA_[j].y, XA_[j].w, ah[j].z, al[j].z); split_pair(XB_[j].y, XB_[j].w, ah[j].w, al[j].w); \
+            f32x4 sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), ones, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+            sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[j]), ones, sx, 0, 0, 0);             \
+            cs[j] = sx * -136.0f;                                                                          \
+        }                                                                                                  \
         _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                  \
-            /* 4x4 dword transpose across the four 16-lane rows: row g ends up with dword g of blocks 4q..4q+3 */ \
             uint32_t dw[4] = {WV_[t].x, WV_[t].y, WV_[t].z, WV_[t].w};                                     \
-            if (!TILED) {                                                                                  \
+            if (!TILED) { /* 4x4 dword transpose across the four 16-lane rows */                           \
                 auto s01 = __builtin_amdgcn_permlane16_swap(WV_[t].x, WV_[t].y, false, false);             \
                 auto s23 = __builtin_amdgcn_permlane16_swap(WV_[t].z, WV_[t].w, false, false);             \
                 auto u02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);                 \
@@ -927,9 +937,11 @@ __global__ __launch_bounds__(256) void q4_skinny_kernel(const GemmParams p) {
             }                                                                                              \
             const uint32_t sc2[2] = {SV_[t].x, SV_[t].y};                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                \
-                const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8(dw[j]));                                    \
+                const uint32_t w_ = dw[j];                                                                 \
+                const bf16x8 bw = as_bf16x8(make_uint4((w_ & 0x000F000Fu) | 0x43004300u, ((w_ >> 4) & 0x000F000Fu) | 0x43004300u, \
+                                                       ((w_ >> 8) & 0x000F000Fu) | 0x43004300u, ((w_ >> 12) & 0x000F000Fu) | 0x43004300u)); \
                 const float d = f16_bits_to_f32((uint16_t)((j & 1) ? (sc2[j >> 1] >> 16) : (sc2[j >> 1] & 0xFFFFu))); \
-                f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), bw, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+                f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), bw, cs[j], 0, 0, 0);   \
                 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[j]), bw, tt, 0, 0, 0);            \
                 acc[t][0] = fmaf(d, tt[0], acc[t][0]); acc[t][1] = fmaf(d, tt[1], acc[t][1]);              \
                 acc[t][2] = fmaf(d, tt[2], acc[t][2]); acc[t][3] = fmaf(d, tt[3], acc[t][3]);              \
