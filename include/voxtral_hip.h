@@ -138,6 +138,13 @@ typedef struct {
     float rope_theta, norm_eps;
 } vox_model_cfg;
 
+/* Attention core of both stacks: softmax(q k^T * head_dim^-0.5 + causal/sliding-window mask) v with grouped-query heads
+ * (gguf/model.rs:100-120 encoder MHA, :125-198 decoder GQA without materialising the x4 KV expansion; masking.rs:9-107:
+ * query at position offset+m sees keys j <= offset+m and, when window >= 0, offset+m-j <= window).
+ * q [M][n_heads*head_dim], k / v [kv_len][n_kv_heads*head_dim], out [M][n_heads*head_dim]; head_dim 64 or 128. */
+int32_t vox_attention(vox_ctx* ctx, const float* q, const float* k, const float* v, int32_t M, int32_t kv_len, int32_t n_heads,
+                      int32_t n_kv_heads, int32_t head_dim, int32_t offset, int32_t window, float* out, int32_t mem_kind);
+
 /* Q4ModelLoader::from_file(..).load(), gguf/loader.rs:82-128 */
 int32_t vox_q4_model_load(vox_ctx* ctx, const char* gguf_path, vox_model** out);
 /* flags: VOX_LOAD_LAYOUT_ONLY parses the GGUF header and allocates the identical device arena layout but does

@@ -154,7 +154,7 @@ def test_log_mel_vs_oracle(pkg, orc, ctx):
     assert mel.compute_log(np.zeros(100, np.float32)).shape == (0, 128)
 
 
-@pytest.mark.parametrize("m,k,n", [(16, 128, 16), (16, 3072, 512), (9, 9216, 96), (16, 4096, 40), (5, 256, 1000), (13, 1280, 2048), (16, 5120, 272)])
+@pytest.mark.parametrize("m,k,n", [(16, 128, 16), (16, 128, 384), (7, 256, 130), (16, 3072, 512), (9, 9216, 96), (16, 4096, 40), (5, 256, 1000), (13, 1280, 2048), (16, 5120, 272)])
 def test_q4_skinny_batched_decode_gemm(pkg, orc, ctx, m, k, n):
     """5..16 rows (one per sequence of a decode batch) x K % 128 == 0: the skinny MFMA kernel (split-K across waves,
     in-register 4x4 dword transpose of the weight fragments); ragged N, asymmetric data."""
@@ -168,3 +168,29 @@ def test_q4_skinny_batched_decode_gemm(pkg, orc, ctx, m, k, n):
     bias = rng.standard_normal(n).astype(np.float32)
     outb = pkg.Q4Linear.new(pkg.Q4Tensor.from_q4_bytes(raw, [n, k], ctx), bias).forward(x)
     assert np.abs(outb - (exp + bias)).max() / np.abs(exp).max() < 2e-5
+
+
+@pytest.mark.parametrize("M,kv,H,KV,hd,off,win", [
+    (16, 16, 2, 2, 64, 0, -1),          # one partial tile (tiny-model encoder shape)
+    (1, 1, 2, 1, 128, 0, -1),           # single query / key
+    (70, 70, 4, 4, 64, 0, 750),         # two query blocks, ragged tail
+    (200, 200, 3, 3, 64, 0, 20),        # sliding window much smaller than the sequence (masking.rs:26-44)
+    (38, 38, 8, 2, 128, 0, 8192),       # decoder prefill shape: GQA 4:1 (gguf/model.rs:177-197)
+    (5, 133, 4, 2, 128, 128, -1),       # continuation: 5 new queries against a 133-long cache (offset > 0)
+    (130, 190, 2, 1, 64, 60, 64),       # offset + window + GQA + several key tiles
+])
+def test_attention_vs_oracle(pkg, orc, ctx, M, kv, H, KV, hd, off, win):
+    """MFMA flash attention (hi/lo bf16 split) against the oracle's f32 score path; tolerance: |d| <= 2e-5 * max|ref| (f32-class)."""
+    from importlib import import_module
+    attention = import_module(pkg.__name__ + ".gguf").attention
+    rng = np.random.default_rng(M * 1000 + kv)
+    q = (rng.standard_normal((M, H * hd)) * 1.5).astype(np.float32)
+    k = (rng.standard_normal((kv, KV * hd)) * 1.5).astype(np.float32)
+    v = rng.standard_normal((kv, KV * hd)).astype(np.float32)
+    ref = np.zeros((M, H * hd), np.float32)
+    orc.lib().orc_attention(q, k, v, M, kv, H, KV, hd, off, 1, win, ref)
+    out = attention(ctx, q, k, v, H, KV, offset=off, window=win)
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err < 2e-5, err
+    with pytest.raises(pkg.VoxError):
+        attention(ctx, q, k, v, H, KV, offset=kv, window=win)       # queries outside the key range

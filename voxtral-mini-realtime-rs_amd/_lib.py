@@ -83,6 +83,7 @@ SIGNATURES = {
     "vox_q4_tensor_free": (i32, [vp]),
     "vox_q4_matmul": (i32, [vp, vp, vp, i32, i32, vp, i32]),
     "vox_q4_linear_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, i32]),
+    "vox_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32]),
     "vox_q4_model_load": (i32, [vp, C.c_char_p, P(vp)]),
     "vox_q4_model_load_ex": (i32, [vp, C.c_char_p, u32, P(vp)]),
     "vox_f32_model_load": (i32, [vp, C.c_char_p, P(vp)]),

@@ -414,6 +414,33 @@ extern "C" int32_t vox_q4_matmul(vox_ctx* c, const vox_q4* w, const float* x, in
     return vox_q4_linear_forward(c, w, nullptr, x, B, M, out, mem_kind);
 }
 
+// causal (+ sliding-window) multi-head / grouped-query attention core on host or device buffers
+// (gguf/model.rs:100-120,125-198; masking.rs:9-107).  q [M][n_heads*hd], k/v [kv_len][n_kv*hd] (token-major), query m at
+// position offset+m sees keys j <= offset+m with offset+m-j <= window (window < 0: no window).  out [M][n_heads*hd].
+extern "C" int32_t vox_attention(vox_ctx* c, const float* q, const float* k, const float* v, int32_t M, int32_t kv_len, int32_t n_heads,
+                                 int32_t n_kv_heads, int32_t head_dim, int32_t offset, int32_t window, float* out, int32_t mem_kind) {
+    ARGCHK(c && q && k && v && out, "null argument");
+    ARGCHK(M > 0 && kv_len > 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "bad attention shape");
+    ARGCHK(head_dim == 64 || head_dim == 128, "head_dim must be 64 (encoder) or 128 (decoder)");
+    ARGCHK(offset >= 0 && offset + M <= kv_len, "queries must lie inside the key range (offset + M <= kv_len)");
+    VOXCHK(ctx_bind(c));
+    const size_t qn = (size_t)M * n_heads * head_dim, kn = (size_t)kv_len * n_kv_heads * head_dim;
+    DevBuf dq, dk, dv, dout;
+    const float *pq = q, *pk = k, *pv = v; float* po = out;
+    if (mem_kind != VOX_MEM_DEVICE) {
+        HIPCHK(dq.alloc(qn * 4)); HIPCHK(dk.alloc(kn * 4)); HIPCHK(dv.alloc(kn * 4)); HIPCHK(dout.alloc(qn * 4));
+        HIPCHK(hipMemcpyAsync(dq.p, q, qn * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dk.p, k, kn * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dv.p, v, kn * 4, hipMemcpyHostToDevice, c->stream));
+        pq = dq.as<float>(); pk = dk.as<float>(); pv = dv.as<float>(); po = dout.as<float>();
+    }
+    AttnParams ap{}; ap.q = pq; ap.q_stride = n_heads * head_dim; ap.k = pk; ap.v = pv; ap.kv_row_stride = n_kv_heads * head_dim; ap.kv_head_stride = head_dim;
+    ap.out = po; ap.out_stride = n_heads * head_dim; ap.M = M; ap.kv_len = kv_len; ap.n_heads = n_heads; ap.n_kv_heads = n_kv_heads; ap.offset = offset; ap.window = window;
+    HIPCHK(launch_attn_prefill(ap, head_dim, c->stream));
+    if (mem_kind != VOX_MEM_DEVICE) { HIPCHK(hipMemcpyAsync(out, po, qn * 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
+    return VOX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // model
 // ------------------------------------------------------------------------------------------------

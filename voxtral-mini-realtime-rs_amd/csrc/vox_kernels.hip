@@ -972,13 +972,12 @@ __global__ __launch_bounds__(256) void q4_skinny_kernel(const GemmParams p) {
 #undef VOX_WLOAD
 #undef VOX_XLOAD
 #undef VOX_SSTEP
-    // split-K combine (fixed order) + epilogue: wave t (< NTW) finishes tile t
+    // split-K combine (fixed order) + epilogue: wave t finishes tile t
 #pragma unroll
     for (int t = 0; t < NTW; t++)
         *reinterpret_cast<float4*>(sred + ((size_t)(wave * NTW + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
     __syncthreads();
-    if (wave < NTW) {
-        const int t = wave;
+    for (int t = wave; t < NTW; t += KS) {      // (KS may be smaller than NTW for short K: a wave then finishes several tiles)
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int w = 0; w < KS; w++) {
             const float4 v = *reinterpret_cast<const float4*>(sred + ((size_t)(w * NTW + t) * 64 + lane) * 4);
@@ -1303,7 +1302,169 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnParams p) {
             *reinterpret_cast<float4*>(op + e) = make_float4(o[e] * inv, o[e + 1] * inv, o[e + 2] * inv, o[e + 3] * inv);
     }
 }
+// ------------------------------------------------------------------------------------------------
+// The same attention on the matrix cores.  Workgroup = 64 queries x one head, wave = 16 queries, K/V tiles of 64 keys staged
+// through LDS as bf16 hi+lo planes (x ~= hi + lo keeps f32-class accuracy: 3 MFMAs per product, hi*hi + hi*lo + lo*hi).
+// Both products are computed TRANSPOSED so that the softmax statistics stay lane-local and P never leaves registers:
+//   S^T[key][query] = K . Q^T   (A = K rows from LDS, B = Q fragment held in registers for the whole kernel)
+//   O^T[d][query]   = V^T . P^T (A = V^T rows from LDS -- V is transposed while it is staged --, B = P^T = the S^T
+//                                accumulator registers themselves: C-layout row 4g+r of key sub-tile t is B-layout k-slot
+//                                (g, r) of that sub-tile, so two sub-tiles form one 32-key MFMA step with no shuffle)
+// In every fragment the lane's column index is the query (lane & 15): running max, running sum and the rescale factor of
+// the online softmax are per-lane scalars; only the tile max needs a cross-lane step (xor 16, 32).
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams p) {
+    constexpr int KS = HD / 32, DT = HD / 16, KROW = HD + 8, VROW = 72;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smh[];
+    uint16_t* Kh = smh;                  // [64 keys][KROW]   bf16 hi
+    uint16_t* Kl = Kh + 64 * KROW;       //                   bf16 lo
+    uint16_t* Vh = Kl + 64 * KROW;       // [HD][VROW keys]   transposed, bf16 hi
+    uint16_t* Vl = Vh + HD * VROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, kvh = h / (p.n_heads / p.n_kv_heads);
+    const int m0 = blockIdx.x * 64;
+    const int m = m0 + wave * 16 + c;
+    const int mq = min(m, p.M - 1);
+    const int pos = p.offset + mq;
+    const int wave_pos_hi = p.offset + min(m0 + wave * 16 + 15, p.M - 1);   // last position any query of this wave has
+    const float scale = 1.0f / sqrtf((float)HD);      // head_dim^-0.5 (gguf/model.rs:65)
+
+    bf16x8 qh[KS], ql[KS];
+    {
+        const float* qp = p.q + (size_t)mq * p.q_stride + h * HD + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + ks * 32), b = *reinterpret_cast<const float4*>(qp + ks * 32 + 4);
+            uint4 hi, lo; split_bf16x8(a, b, hi, lo); qh[ks] = as_bf16x8(hi); ql[ks] = as_bf16x8(lo);
+        }
+    }
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mx = -INFINITY, lsum = 0.f;
+
+    const int last_m = min(m0 + 63, p.M - 1);
+    int j_lo = 0;
+    if (p.window >= 0) j_lo = max(0, p.offset + m0 - p.window);
+    const int j_hi = min(p.kv_len - 1, p.offset + last_m);   // inclusive
+    const float* kbase = p.k + (size_t)kvh * p.kv_head_stride;
+    const float* vbase = p.v + (size_t)kvh * p.kv_head_stride;
+
+    for (int j0 = (j_lo / 64) * 64; j0 <= j_hi; j0 += 64) {
+        __syncthreads();
+        // ---- stage K (row-major) and V (transposed) as bf16 hi/lo; unconditional clamped loads, masked keys get p = 0 below
+#pragma unroll
+        for (int i = tid; i < 64 * (HD / 4); i += 256) {
+            const int key = i / (HD / 4), d4 = i % (HD / 4);
+            const int jc = min(j0 + key, p.kv_len - 1);
+            const float4 kk = *reinterpret_cast<const float4*>(kbase + (size_t)jc * p.kv_row_stride + d4 * 4);
+            uint2 hi, lo; split_pair(kk.x, kk.y, hi.x, lo.x); split_pair(kk.z, kk.w, hi.y, lo.y);
+            *reinterpret_cast<uint2*>(Kh + key * KROW + d4 * 4) = hi;
+            *reinterpret_cast<uint2*>(Kl + key * KROW + d4 * 4) = lo;
+        }
+#pragma unroll
+        for (int i = tid; i < 32 * (HD / 4); i += 256) {
+            const int kp = i / (HD / 4), d4 = i % (HD / 4);
+            const int ja = min(j0 + 2 * kp, p.kv_len - 1), jb = min(j0 + 2 * kp + 1, p.kv_len - 1);
+            const float4 va = *reinterpret_cast<const float4*>(vbase + (size_t)ja * p.kv_row_stride + d4 * 4);
+            const float4 vb = *reinterpret_cast<const float4*>(vbase + (size_t)jb * p.kv_row_stride + d4 * 4);
+            uint32_t hi, lo;
+            split_pair(va.x, vb.x, hi, lo); *reinterpret_cast<uint32_t*>(Vh + (d4 * 4 + 0) * VROW + 2 * kp) = hi; *reinterpret_cast<uint32_t*>(Vl + (d4 * 4 + 0) * VROW + 2 * kp) = lo;
+            split_pair(va.y, vb.y, hi, lo); *reinterpret_cast<uint32_t*>(Vh + (d4 * 4 + 1) * VROW + 2 * kp) = hi; *reinterpret_cast<uint32_t*>(Vl + (d4 * 4 + 1) * VROW + 2 * kp) = lo;
+            split_pair(va.z, vb.z, hi, lo); *reinterpret_cast<uint32_t*>(Vh + (d4 * 4 + 2) * VROW + 2 * kp) = hi; *reinterpret_cast<uint32_t*>(Vl + (d4 * 4 + 2) * VROW + 2 * kp) = lo;
+            split_pair(va.w, vb.w, hi, lo); *reinterpret_cast<uint32_t*>(Vh + (d4 * 4 + 3) * VROW + 2 * kp) = hi; *reinterpret_cast<uint32_t*>(Vl + (d4 * 4 + 3) * VROW + 2 * kp) = lo;
+        }
+        __syncthreads();
+        if (j0 > wave_pos_hi) continue;                       // wave-uniform: every key of this tile is in the future of all 16 queries
+
+        // ---- S^T = K . Q^T for the four 16-key sub-tiles
+        f32x4 sc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++) {
+            sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (j0 + kt * 16 <= wave_pos_hi) {                // wave-uniform
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 ah = as_bf16x8(*reinterpret_cast<const uint4*>(Kh + (kt * 16 + c) * KROW + ks * 32 + 8 * g));
+                    const bf16x8 al = as_bf16x8(*reinterpret_cast<const uint4*>(Kl + (kt * 16 + c) * KROW + ks * 32 + 8 * g));
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, qh[ks], sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ql[ks], sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, qh[ks], sc[kt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- mask + online softmax (lane: query c, keys j0 + 16 kt + 4 g + r)
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = j0 + kt * 16 + 4 * g + r;
+                bool vis = (j < p.kv_len) && (j <= pos);
+                if (p.window >= 0) vis = vis && (pos - j <= p.window);
+                const float v = vis ? sc[kt][r] * scale : -INFINITY;
+                sc[kt][r] = v; mt = fmaxf(mt, v);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64)); mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mnew = fmaxf(mx, mt);
+        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = __expf(mx - msafe);               // mx = -inf -> 0
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const float e = __expf(sc[kt][r] - msafe); sc[kt][r] = e; ps += e; }
+        lsum = lsum * alpha + ps; mx = mnew;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) { o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha; }
+        // ---- O^T += V^T . P^T, 32 keys per MFMA step
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            if (j0 + kk * 32 <= wave_pos_hi) {                // wave-uniform
+                uint4 ph, pl;
+                split_pair(sc[2 * kk][0], sc[2 * kk][1], ph.x, pl.x); split_pair(sc[2 * kk][2], sc[2 * kk][3], ph.y, pl.y);
+                split_pair(sc[2 * kk + 1][0], sc[2 * kk + 1][1], ph.z, pl.z); split_pair(sc[2 * kk + 1][2], sc[2 * kk + 1][3], ph.w, pl.w);
+                const bf16x8 bh = as_bf16x8(ph), bl = as_bf16x8(pl);
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++) {
+                    const uint16_t* vh = Vh + (dt * 16 + c) * VROW + kk * 32 + 4 * g;
+                    const uint16_t* vl = Vl + (dt * 16 + c) * VROW + kk * 32 + 4 * g;
+                    const uint2 h0 = *reinterpret_cast<const uint2*>(vh), h1 = *reinterpret_cast<const uint2*>(vh + 16);
+                    const uint2 l0 = *reinterpret_cast<const uint2*>(vl), l1 = *reinterpret_cast<const uint2*>(vl + 16);
+                    const bf16x8 ah = as_bf16x8(make_uint4(h0.x, h0.y, h1.x, h1.y)), al = as_bf16x8(make_uint4(l0.x, l0.y, l1.x, l1.y));
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, o[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
+    if (m < p.M) {
+        const float inv = 1.0f / lsum;
+        float* op = p.out + (size_t)m * p.out_stride + h * HD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++)
+            *reinterpret_cast<float4*>(op + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+}
+template <int HD>
+static hipError_t attn_prefill_mfma_launch(const AttnParams& p, hipStream_t s) {
+    constexpr size_t lds = ((size_t)2 * 64 * (HD + 8) + (size_t)2 * HD * 72) * sizeof(uint16_t);
+    auto kern = attn_prefill_mfma_kernel<HD>;
+    static bool attr_done = false;
+    hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
+    if (e != hipSuccess) return e;
+    kern<<<dim3((p.M + 63) / 64, p.n_heads), dim3(256), lds, s>>>(p);
+    return hipGetLastError();
+}
 hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s) {
+    static const int f32_only = env_int("VOX_ATTN_F32");        // ablation / cross-check knob: the f32 VALU kernel
+    if (!f32_only && (p.q_stride % 4) == 0 && (p.kv_row_stride % 4) == 0) {
+        if (hd == 64) return attn_prefill_mfma_launch<64>(p, s);
+        if (hd == 128) return attn_prefill_mfma_launch<128>(p, s);
+    }
     dim3 grid((p.M + 63) / 64, p.n_heads);
     const size_t lds = (size_t)2 * 64 * hd * sizeof(float);
     if (hd == 64) {

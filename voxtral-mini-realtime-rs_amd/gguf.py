@@ -189,6 +189,20 @@ def q4_matmul(x, weights: Q4Tensor):
     return out
 
 
+def attention(ctx, q, k, v, n_heads, n_kv_heads, offset=0, window=-1):
+    """Attention core (gguf/model.rs:100-120,125-198 + masking.rs:9-107): q [M, n_heads*hd], k/v [kv_len, n_kv_heads*hd]
+    -> [M, n_heads*hd]; query m sits at position offset+m, causal, optional sliding window."""
+    q, k, v = _f32(q), _f32(k), _f32(v)
+    if q.ndim != 2 or k.ndim != 2 or k.shape != v.shape or q.shape[1] % n_heads:
+        raise VoxError(1, "attention: bad shapes")
+    hd = q.shape[1] // n_heads
+    if k.shape[1] != n_kv_heads * hd:
+        raise VoxError(1, "attention: k/v width != n_kv_heads*head_dim")
+    out = np.empty_like(q)
+    check(lib().vox_attention(ctx.h, _ptr(q), _ptr(k), _ptr(v), q.shape[0], k.shape[0], n_heads, n_kv_heads, hd, offset, window, _ptr(out), 0))
+    return out
+
+
 class Q4Linear:
     """gguf/linear.rs:17-40"""
 
