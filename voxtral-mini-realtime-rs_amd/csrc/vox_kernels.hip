@@ -594,11 +594,17 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float x) {   // round-to-neare
     const uint32_t u = __float_as_uint(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-// 8 floats -> packed bf16 hi plane + bf16 lo plane (x ~= hi + lo, |err| <= 2^-17 |x|)
+// 8 floats -> packed bf16 hi plane + bf16 lo plane (x ~= hi + lo, |err| <= 2^-17 |x|).  gfx950 has a hardware
+// round-to-nearest-even pack (v_cvt_pk_bf16_f32): a pair costs 2 cvt + 2 unpack + 2 sub instead of ~14 integer ops.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    union { bf16x2_t b; uint32_t u; } c; c.b = __builtin_convertvector(v, bf16x2_t); return c.u;
+}
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const uint32_t ha = bf16_rne_bits(a), hb = bf16_rne_bits(b);
-    const uint32_t la = bf16_rne_bits(a - __uint_as_float(ha << 16)), lb = bf16_rne_bits(b - __uint_as_float(hb << 16));
-    hi = ha | (hb << 16); lo = la | (lb << 16);
+    hi = cvt_pk_bf16(a, b);
+    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
 }
 __device__ __forceinline__ void split_bf16x8(const float4 a, const float4 b, uint4& hi, uint4& lo) {
     split_pair(a.x, a.y, hi.x, lo.x); split_pair(a.z, a.w, hi.y, lo.y);
@@ -1323,7 +1329,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams
     uint16_t* Vl = Vh + HD * VROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const int h = blockIdx.y, kvh = h / (p.n_heads / p.n_kv_heads);
-    const int m0 = blockIdx.x * 64;
+    const int m0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 64;    // causal: late query blocks have the most keys -- dispatch them first
     const int m = m0 + wave * 16 + c;
     const int mq = min(m, p.M - 1);
     const int pos = p.offset + mq;
@@ -1351,24 +1357,37 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams
     const float* kbase = p.k + (size_t)kvh * p.kv_head_stride;
     const float* vbase = p.v + (size_t)kvh * p.kv_head_stride;
 
-    for (int j0 = (j_lo / 64) * 64; j0 <= j_hi; j0 += 64) {
+    // register-staged software pipeline: the global loads of tile t+1 are in flight while tile t is being multiplied
+    constexpr int NK = (64 * (HD / 4)) / 256, NV = (32 * (HD / 4)) / 256;
+    float4 kreg[NK], vra[NV], vrb[NV];
+#define VOX_ATT_LOAD(J0_)                                                                                           \
+    _Pragma("unroll") for (int u = 0; u < NK; u++) {                                                                \
+        const int i = tid + 256 * u, key = i / (HD / 4), d4 = i % (HD / 4);                                         \
+        const int jc = min((J0_) + key, p.kv_len - 1);   /* unconditional clamped loads; masked keys get p = 0 */   \
+        kreg[u] = *reinterpret_cast<const float4*>(kbase + (size_t)jc * p.kv_row_stride + d4 * 4);                  \
+    }                                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < NV; u++) {                                                                \
+        const int i = tid + 256 * u, kp = i / (HD / 4), d4 = i % (HD / 4);                                          \
+        const int ja = min((J0_) + 2 * kp, p.kv_len - 1), jb = min((J0_) + 2 * kp + 1, p.kv_len - 1);               \
+        vra[u] = *reinterpret_cast<const float4*>(vbase + (size_t)ja * p.kv_row_stride + d4 * 4);                   \
+        vrb[u] = *reinterpret_cast<const float4*>(vbase + (size_t)jb * p.kv_row_stride + d4 * 4);                   \
+    }
+    const int j_first = (j_lo / 64) * 64, j_last = (j_hi / 64) * 64;
+    VOX_ATT_LOAD(j_first)
+    for (int j0 = j_first; j0 <= j_hi; j0 += 64) {
         __syncthreads();
-        // ---- stage K (row-major) and V (transposed) as bf16 hi/lo; unconditional clamped loads, masked keys get p = 0 below
+        // ---- stage K (row-major) and V (transposed) as bf16 hi/lo planes
 #pragma unroll
-        for (int i = tid; i < 64 * (HD / 4); i += 256) {
-            const int key = i / (HD / 4), d4 = i % (HD / 4);
-            const int jc = min(j0 + key, p.kv_len - 1);
-            const float4 kk = *reinterpret_cast<const float4*>(kbase + (size_t)jc * p.kv_row_stride + d4 * 4);
-            uint2 hi, lo; split_pair(kk.x, kk.y, hi.x, lo.x); split_pair(kk.z, kk.w, hi.y, lo.y);
+        for (int u = 0; u < NK; u++) {
+            const int i = tid + 256 * u, key = i / (HD / 4), d4 = i % (HD / 4);
+            uint2 hi, lo; split_pair(kreg[u].x, kreg[u].y, hi.x, lo.x); split_pair(kreg[u].z, kreg[u].w, hi.y, lo.y);
             *reinterpret_cast<uint2*>(Kh + key * KROW + d4 * 4) = hi;
             *reinterpret_cast<uint2*>(Kl + key * KROW + d4 * 4) = lo;
         }
 #pragma unroll
-        for (int i = tid; i < 32 * (HD / 4); i += 256) {
-            const int kp = i / (HD / 4), d4 = i % (HD / 4);
-            const int ja = min(j0 + 2 * kp, p.kv_len - 1), jb = min(j0 + 2 * kp + 1, p.kv_len - 1);
-            const float4 va = *reinterpret_cast<const float4*>(vbase + (size_t)ja * p.kv_row_stride + d4 * 4);
-            const float4 vb = *reinterpret_cast<const float4*>(vbase + (size_t)jb * p.kv_row_stride + d4 * 4);
+        for (int u = 0; u < NV; u++) {
+            const int i = tid + 256 * u, kp = i / (HD / 4), d4 = i % (HD / 4);
+            const float4 va = vra[u], vb = vrb[u];
             uint32_t hi, lo;
             split_pair(va.x, vb.x, hi, lo); *reinterpret_cast<uint32_t*>(Vh + (d4 * 4 + 0) * VROW + 2 * kp) = hi; *reinterpret_cast<uint32_t*>(Vl + (d4 * 4 + 0) * VROW + 2 * kp) = lo;
             split_pair(va.y, vb.y, hi, lo); *reinterpret_cast<uint32_t*>(Vh + (d4 * 4 + 1) * VROW + 2 * kp) = hi; *reinterpret_cast<uint32_t*>(Vl + (d4 * 4 + 1) * VROW + 2 * kp) = lo;
@@ -1376,6 +1395,8 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams
             split_pair(va.w, vb.w, hi, lo); *reinterpret_cast<uint32_t*>(Vh + (d4 * 4 + 3) * VROW + 2 * kp) = hi; *reinterpret_cast<uint32_t*>(Vl + (d4 * 4 + 3) * VROW + 2 * kp) = lo;
         }
         __syncthreads();
+        { const int jn = min(j0 + 64, j_last); VOX_ATT_LOAD(jn) }        // next tile (the last one re-loads itself: unconditional)
+        __builtin_amdgcn_sched_barrier(0);
         if (j0 > wave_pos_hi) continue;                       // wave-uniform: every key of this tile is in the future of all 16 queries
 
         // ---- S^T = K . Q^T for the four 16-key sub-tiles
@@ -1440,6 +1461,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams
             }
         }
     }
+#undef VOX_ATT_LOAD
     lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
     if (m < p.M) {
         const float inv = 1.0f / lsum;
