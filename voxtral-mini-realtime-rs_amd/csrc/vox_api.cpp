@@ -338,7 +338,7 @@ extern "C" int32_t vox_gguf_tensor_data(const vox_gguf* g, const char* name, voi
 // ------------------------------------------------------------------------------------------------
 // Q4 tensor + operator (gguf/tensor.rs, op.rs, linear.rs)
 // ------------------------------------------------------------------------------------------------
-struct vox_q4 { vox_ctx* ctx; Q4W w; void* qs_mem; void* sc_mem; };
+struct vox_q4 { vox_ctx* ctx; Q4W w; void* qs_mem; void* sc_mem; void* qt_mem = nullptr; void* st_mem = nullptr; };
 
 // upload raw 18-byte blocks and re-pack into (qs, sc) planes at [dst_row0 ..) of the destination planes
 static int32_t upload_repack(vox_ctx* c, const uint8_t* raw, int64_t n_blocks, int nb, uint4* qs, uint16_t* sc, int row_mul, int row_add,
@@ -366,6 +366,13 @@ extern "C" int32_t vox_q4_tensor_from_bytes(vox_ctx* c, const uint8_t* raw, size
     q->w = Q4W{(const uint4*)q->qs_mem, (const uint16_t*)q->sc_mem, (int)N, (int)K, (int)(K / 32)};
     int32_t r = upload_repack(c, raw, nblk, (int)(K / 32), (uint4*)q->qs_mem, (uint16_t*)q->sc_mem, 1, 0, nullptr, 0);
     if (r != VOX_OK) { (void)hipFree(q->qs_mem); (void)hipFree(q->sc_mem); delete q; return r; }
+    if ((K / 32) % 4 == 0) {     // MFMA tile-order copy (skinny / large-M kernels); same bits, different order
+        const size_t n_tiles = (size_t)(N + 15) / 16, nq = (size_t)(K / 128);
+        if (hipMalloc(&q->qt_mem, n_tiles * nq * 64 * 16) == hipSuccess && hipMalloc(&q->st_mem, n_tiles * nq * 64 * 2) == hipSuccess &&
+            launch_q4_tile_build(q->w, (uint4*)q->qt_mem, (uint16_t*)q->st_mem, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) {
+            q->w.qt = (const uint4*)q->qt_mem; q->w.st = (const uint16_t*)q->st_mem;
+        } else { (void)hipFree(q->qt_mem); (void)hipFree(q->st_mem); (void)hipFree(q->qs_mem); (void)hipFree(q->sc_mem); delete q; return fail(VOX_ERR_HIP, "tile copy of Q4 tensor failed"); }
+    }
     *out = q; return VOX_OK;
 }
 extern "C" int32_t vox_q4_tensor_shape(const vox_q4* q, int64_t* N, int64_t* K) { ARGCHK(q && N && K, "null argument"); *N = q->w.N; *K = q->w.K; return VOX_OK; }
@@ -373,7 +380,7 @@ extern "C" int32_t vox_q4_tensor_num_blocks(const vox_q4* q, int64_t* out) { ARG
 extern "C" int32_t vox_q4_tensor_free(vox_q4* q) {
     if (!q) return VOX_OK;
     (void)hipSetDevice(q->ctx->device); (void)hipStreamSynchronize(q->ctx->stream);
-    (void)hipFree(q->qs_mem); (void)hipFree(q->sc_mem); delete q; return VOX_OK;
+    (void)hipFree(q->qs_mem); (void)hipFree(q->sc_mem); (void)hipFree(q->qt_mem); (void)hipFree(q->st_mem); delete q; return VOX_OK;
 }
 extern "C" int32_t vox_q4_tensor_dequantize(vox_ctx* c, const vox_q4* q, float* out) {
     ARGCHK(c && q && out, "null argument"); VOXCHK(ctx_bind(c));
@@ -444,7 +451,7 @@ extern "C" int32_t vox_attention(vox_ctx* c, const float* q, const float* k, con
 // ------------------------------------------------------------------------------------------------
 // model
 // ------------------------------------------------------------------------------------------------
-struct Lin { Q4W w{}; const float* bias = nullptr; const uint4* qt = nullptr; const uint16_t* st = nullptr; };   // qt/st: tile-layout copy (batched decode)
+struct Lin { Q4W w{}; const float* bias = nullptr; };
 struct EncLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2; };
 struct DecLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2, ada0, ada2; float* ada_mul = nullptr; };
 
@@ -467,6 +474,7 @@ struct vox_model {
     // decode state
     vox_cache* cache = nullptr;                           // internal cache for transcribe_streaming
     int *d_tokens = nullptr, *d_pos = nullptr; int tokens_cap = 0;
+    int* d_seq_len = nullptr; std::vector<int> h_seq_len;  // per-utterance encoder rows of a stacked batch
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
     int n_parts = 0, argmax_R = 8;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
@@ -616,7 +624,7 @@ struct Loader {
     }
     // linear made of `parts` source tensors [N_i][K]; rows concatenated (interleave=false) or interleaved (true).
     // Q4_0 sources -> re-packed Q4 planes; dense sources (BF16, or F16/F32 holding bf16-representable values) -> bf16 plane.
-    bool lin(const std::vector<std::string>& parts, bool interleave, Lin* L, bool require_q4, bool tile = false) {
+    bool lin(const std::vector<std::string>& parts, bool interleave, Lin* L, bool require_q4, bool tile = true) {
         int64_t K = -1, Ntot = 0; std::vector<TensorView> ts; int kind = -1;
         for (auto& n : parts) {
             TensorView t; if (!need(n, &t)) return false;
@@ -646,7 +654,7 @@ struct Loader {
             if (tile && nb % 4 == 0) {   // second copy in MFMA tile order for the batched-decode (M <= 16) kernel
                 const size_t n_tiles = (size_t)(Ntot + 15) / 16, nq = (size_t)nb / 4;
                 uint4* qt = ar.take<uint4>(n_tiles * nq * 64); uint16_t* st = ar.take<uint16_t>(n_tiles * nq * 64);
-                L->qt = qt; L->st = st;
+                L->w.qt = qt; L->w.st = st;
                 if (fill) {
                     if (launch_q4_tile_build(L->w, qt, st, m->ctx->stream) != hipSuccess || hipStreamSynchronize(m->ctx->stream) != hipSuccess)
                         return setfail("q4_tile_build failed");
@@ -779,7 +787,7 @@ static void model_release(vox_model* m) {
     if (m->graph) (void)hipGraphDestroy(m->graph);
     if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx})
+                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -857,39 +865,73 @@ static int32_t ensure(float** p, size_t* cap, size_t need) {
     HIPCHK(hipMalloc((void**)p, need * sizeof(float))); *cap = need; return VOX_OK;
 }
 
-// ---- encoder + adapter (gguf/model.rs:425-434, 783-788) on device. mel [n_mels][T] device -> m->d_audio [S4][dec_dim]
-static int32_t encode_dev(vox_model* m, const float* d_mel, int T, int* S4_out) {
+// ---- encoder + adapter (gguf/model.rs:425-434, 783-788) on device for n stacked utterances.
+// Every utterance owns a budget of S_pad rows (S_pad = the longest S_enc rounded up to a multiple of the reshape factor, so the
+// adapter's [S/4][4D] view of the stack stays uniformly strided); utterance i uses its first S_enc_i rows, the rest are
+// scratch rows that flow through the row-independent operators and are never read by attention.  All GEMMs run once over
+// the n*S_pad rows (the weights are streamed once per batch); convs are per utterance; attention is per utterance (grid.z).
+// d_mels[i]: [n_mels][T[i]] device.  audio_out: [n][audio_rows][dec_dim] with audio_rows >= S_pad/4; S4_out[i] = S_enc_i / 4.
+static int enc_rows(int T) { return conv_len(conv_len(T)); }
+static int enc_row_budget(const vox_model* m, const int* T, int n) {
+    int mx = 0; for (int i = 0; i < n; i++) mx = std::max(mx, enc_rows(T[i]));
+    const int r = m->cfg.reshape_factor; return n == 1 ? mx : (mx + r - 1) / r * r;
+}
+static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels, const int* T, float* audio_out, int audio_rows, int* S4_out) {
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
-    const int T1 = conv_len(T), S = conv_len(T1), D = c.enc_dim, H = c.enc_heads, hd = c.enc_head_dim, QD = H * hd, F = c.enc_ffn;
-    const int S4 = S / c.reshape_factor;
-    *S4_out = S4;
-    if (S <= 0 || S4 <= 0) return VOX_OK;
-    ARGCHK(S <= m->enc_rope_len, "audio too long for the encoder RoPE table (%d > %d positions); chunk it (--max-mel-frames)", S, m->enc_rope_len);
-    const size_t need = (size_t)D * T1 + (size_t)S * D * 2 + (size_t)S * QD * 4 + (size_t)S * F + (size_t)S4 * m->ad0.w.N + 1024;
+    const int D = c.enc_dim, H = c.enc_heads, hd = c.enc_head_dim, QD = H * hd, F = c.enc_ffn, R = c.reshape_factor;
+    const int S_pad = enc_row_budget(m, T, n);
+    int T1max = 0; bool any = false;
+    std::vector<int> S(n);
+    for (int i = 0; i < n; i++) { S[i] = enc_rows(T[i]); S4_out[i] = S[i] / R; T1max = std::max(T1max, conv_len(T[i])); any = any || S4_out[i] > 0; }
+    if (!any || S_pad <= 0) return VOX_OK;
+    ARGCHK(S_pad <= m->enc_rope_len, "audio too long for the encoder RoPE table (%d > %d positions); chunk it (--max-mel-frames)", S_pad, m->enc_rope_len);
+    const int Mtot = n * S_pad, M4 = n == 1 ? S4_out[0] : Mtot / R;          // adapter rows
+    ARGCHK(n == 1 || audio_rows >= S_pad / R, "internal: audio row budget %d < %d", audio_rows, S_pad / R);
+    const size_t need = (size_t)D * T1max + (size_t)Mtot * D * 2 + (size_t)Mtot * QD * 4 + (size_t)Mtot * F + (size_t)(M4 + 1) * m->ad0.w.N + 1024;
     VOXCHK(ensure(&m->ws, &m->ws_floats, need));
-    float* c1 = m->ws; float* x = c1 + (size_t)D * T1; float* xn = x + (size_t)S * D; float* qkv = xn + (size_t)S * D;
-    float* att = qkv + (size_t)S * QD * 3; float* ffn = att + (size_t)S * QD; float* ah = ffn + (size_t)S * F;
-    { size_t cap = (size_t)m->audio_cap * c.dec_dim; VOXCHK(ensure(&m->d_audio, &cap, (size_t)S4 * c.dec_dim)); m->audio_cap = (int)(cap / c.dec_dim); }
-    HIPCHK(launch_conv1d_gelu(d_mel, c.n_mels, T, m->conv1_w, m->conv1_b, D, c1, 0, s));
-    HIPCHK(launch_conv1d_gelu(c1, D, T1, m->conv2_w, m->conv2_b, D, x, 1, s));      // token-major [S][D] (swap_dims, model.rs:427)
+    float* c1 = m->ws; float* x = c1 + (size_t)D * T1max; float* xn = x + (size_t)Mtot * D; float* qkv = xn + (size_t)Mtot * D;
+    float* att = qkv + (size_t)Mtot * QD * 3; float* ffn = att + (size_t)Mtot * QD; float* ah = ffn + (size_t)Mtot * F;
+    const int* d_len = nullptr;
+    if (n > 1) {
+        HIPCHK(hipMemsetAsync(x, 0, (size_t)Mtot * D * 4, s));               // scratch rows: finite values
+        if (!m->d_seq_len) HIPCHK(hipMalloc((void**)&m->d_seq_len, 64 * sizeof(int)));
+        m->h_seq_len.assign(S.begin(), S.end());
+        HIPCHK(hipMemcpyAsync(m->d_seq_len, m->h_seq_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        d_len = m->d_seq_len;
+    }
+    for (int i = 0; i < n; i++) {
+        if (S[i] <= 0) continue;
+        const int T1 = conv_len(T[i]);
+        HIPCHK(launch_conv1d_gelu(d_mels[i], c.n_mels, T[i], m->conv1_w, m->conv1_b, D, c1, 0, s));
+        HIPCHK(launch_conv1d_gelu(c1, D, T1, m->conv2_w, m->conv2_b, D, x + (size_t)i * S_pad * D, 1, s));      // token-major [S][D] (swap_dims, model.rs:427)
+    }
+    const int seq_rows = n > 1 ? S_pad : 0;
     for (int l = 0; l < c.enc_layers; l++) {
         const EncLayer& L = m->enc[l];
-        HIPCHK(launch_rms_norm(x, D, S, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
-        VOXCHK(q4_linear_dev(cx, L.wqkv.w, L.wqkv.bias, xn, D, S, qkv, 3 * QD));
-        HIPCHK(launch_rope(qkv, S, 3 * QD, 2 * QD, hd, 0, m->enc_cos, m->enc_sin, s));
+        HIPCHK(launch_rms_norm(x, D, Mtot, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
+        VOXCHK(q4_linear_dev(cx, L.wqkv.w, L.wqkv.bias, xn, D, Mtot, qkv, 3 * QD));
+        HIPCHK(launch_rope(qkv, Mtot, 3 * QD, 2 * QD, hd, 0, m->enc_cos, m->enc_sin, s, seq_rows));
         AttnParams ap{}; ap.q = qkv; ap.q_stride = 3 * QD; ap.k = qkv + QD; ap.v = qkv + 2 * QD; ap.kv_row_stride = 3 * QD; ap.kv_head_stride = hd;
-        ap.out = att; ap.out_stride = QD; ap.M = S; ap.kv_len = S; ap.n_heads = H; ap.n_kv_heads = H; ap.offset = 0; ap.window = c.enc_window;
-        HIPCHK(launch_attn_prefill(ap, hd, s));
-        VOXCHK(q4_linear_dev(cx, L.wo.w, L.wo.bias, att, QD, S, x, D, EPI_RESID, x, D));
-        HIPCHK(launch_rms_norm(x, D, S, D, L.ffn_norm, nullptr, c.norm_eps, xn, D, s));
-        VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, S, ffn, F, EPI_SWIGLU));
-        VOXCHK(q4_linear_dev(cx, L.w2.w, L.w2.bias, ffn, F, S, x, D, EPI_RESID, x, D));
+        ap.out = att; ap.out_stride = QD; ap.M = S_pad; ap.kv_len = S_pad; ap.n_heads = H; ap.n_kv_heads = H; ap.offset = 0; ap.window = c.enc_window;
+        ap.seq_len = d_len; ap.q_seq_stride = S_pad * 3 * QD; ap.out_seq_stride = S_pad * QD; ap.kv_seq_stride = (long)S_pad * 3 * QD;
+        HIPCHK(launch_attn_prefill(ap, hd, s, n));
+        VOXCHK(q4_linear_dev(cx, L.wo.w, L.wo.bias, att, QD, Mtot, x, D, EPI_RESID, x, D));
+        HIPCHK(launch_rms_norm(x, D, Mtot, D, L.ffn_norm, nullptr, c.norm_eps, xn, D, s));
+        VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, Mtot, ffn, F, EPI_SWIGLU));
+        VOXCHK(q4_linear_dev(cx, L.w2.w, L.w2.bias, ffn, F, Mtot, x, D, EPI_RESID, x, D));
     }
-    HIPCHK(launch_rms_norm(x, D, S, D, m->enc_norm, nullptr, c.norm_eps, xn, D, s));
-    // reshape_encoder_output (models/adapter.rs:108-122): rows [0, 4*S4) viewed as [S4][4D]; adapter (model.rs:745-749)
-    VOXCHK(q4_linear_dev(cx, m->ad0.w, nullptr, xn, D * c.reshape_factor, S4, ah, m->ad0.w.N, EPI_GELU));
-    VOXCHK(q4_linear_dev(cx, m->ad2.w, nullptr, ah, m->ad0.w.N, S4, m->d_audio, c.dec_dim));
+    HIPCHK(launch_rms_norm(x, D, Mtot, D, m->enc_norm, nullptr, c.norm_eps, xn, D, s));
+    // reshape_encoder_output (models/adapter.rs:108-122): rows [0, 4*S4) of each utterance viewed as [S4][4D]; adapter (model.rs:745-749)
+    VOXCHK(q4_linear_dev(cx, m->ad0.w, nullptr, xn, D * R, M4, ah, m->ad0.w.N, EPI_GELU));
+    if (n == 1 || audio_rows * R == S_pad) VOXCHK(q4_linear_dev(cx, m->ad2.w, nullptr, ah, m->ad0.w.N, M4, audio_out, c.dec_dim));
+    else for (int i = 0; i < n; i++)      // wider per-utterance stride on the output side
+        VOXCHK(q4_linear_dev(cx, m->ad2.w, nullptr, ah + (size_t)i * (S_pad / R) * m->ad0.w.N, m->ad0.w.N, S_pad / R, audio_out + (size_t)i * audio_rows * c.dec_dim, c.dec_dim));
     return VOX_OK;
+}
+static int32_t encode_dev(vox_model* m, const float* d_mel, int T, int* S4_out) {
+    const int S4 = enc_rows(T) / m->cfg.reshape_factor;
+    if (S4 > 0) { size_t cap = (size_t)m->audio_cap * m->cfg.dec_dim; VOXCHK(ensure(&m->d_audio, &cap, (size_t)S4 * m->cfg.dec_dim)); m->audio_cap = (int)(cap / m->cfg.dec_dim); }
+    return encode_batch_dev(m, 1, &d_mel, &T, m->d_audio, S4, S4_out);
 }
 
 // ---- KV cache (models/layers/kv_cache.rs:52-65,221-234)
@@ -914,10 +956,13 @@ extern "C" int32_t vox_cache_reset(vox_cache* k) { ARGCHK(k, "null cache"); k->l
 
 static size_t cache_layer_floats(const vox_model* m, const vox_cache* k) { (void)m; return k->layer_stride; }
 
-// ---- multi-row decoder forward (prefill): x [M][D] device, in place; positions off..off+M-1  (gguf/model.rs:370-387)
-static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc, int off) {
+// ---- multi-row decoder forward (prefill): x [M][D] device, in place; positions off..off+M-1  (gguf/model.rs:370-387).
+// n_seq > 1: x holds n_seq stacked sequences of seq_rows = M / n_seq rows, each with its own cache slice kv_seq_stride floats apart
+// (positions restart at off per sequence); the GEMMs run once over all M rows.
+static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc, int off, int n_seq = 1, long kv_seq_stride = 0) {
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, W = QD + 2 * KD, F = c.dec_ffn;
+    const int seq_rows = n_seq > 1 ? M / n_seq : 0, Mq = n_seq > 1 ? seq_rows : M;
     // workspace after the encoder region is reused: [xn | qkv | att | ffn]
     const size_t need = (size_t)M * D + (size_t)M * W + (size_t)M * QD + (size_t)M * F + 1024;
     VOXCHK(ensure(&m->ws, &m->ws_floats, need));
@@ -927,11 +972,12 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
         const DecLayer& L = m->dec[l]; float* kl = kc->k + (size_t)l * lf; float* vl = kc->v + (size_t)l * lf;
         HIPCHK(launch_rms_norm(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
         VOXCHK(q4_linear_dev(cx, L.wqkv.w, nullptr, xn, D, M, qkv, W));
-        HIPCHK(launch_rope(qkv, M, W, QD + KD, hd, off, m->dec_cos, m->dec_sin, s));
-        HIPCHK(launch_kv_store(qkv, M, W, QD, KV, hd, off, kl, vl, kc->max_seq * hd, s));
+        HIPCHK(launch_rope(qkv, M, W, QD + KD, hd, off, m->dec_cos, m->dec_sin, s, seq_rows));
+        HIPCHK(launch_kv_store(qkv, M, W, QD, KV, hd, off, kl, vl, kc->max_seq * hd, s, seq_rows, kv_seq_stride));
         AttnParams ap{}; ap.q = qkv; ap.q_stride = W; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd;
-        ap.out = att; ap.out_stride = QD; ap.M = M; ap.kv_len = off + M; ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = off; ap.window = c.dec_window;
-        HIPCHK(launch_attn_prefill(ap, hd, s));
+        ap.out = att; ap.out_stride = QD; ap.M = Mq; ap.kv_len = off + Mq; ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = off; ap.window = c.dec_window;
+        ap.q_seq_stride = seq_rows * W; ap.out_seq_stride = seq_rows * QD; ap.kv_seq_stride = kv_seq_stride;
+        HIPCHK(launch_attn_prefill(ap, hd, s, n_seq));
         VOXCHK(q4_linear_dev(cx, L.wo.w, nullptr, att, QD, M, x, D, EPI_RESID, x, D));
         HIPCHK(launch_rms_norm(x, D, M, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));    // norm then Ada x*(1+s) (model.rs:382-385)
         VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, M, ffn, F, EPI_SWIGLU));
@@ -1146,73 +1192,86 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         ARGCHK(caps[i] >= std::max(S[i] - PREFIX_LEN, 0), "out_ids[%d] capacity %d < %d", i, caps[i], S[i] - PREFIX_LEN);
     }
     ARGCHK(Smax <= m->dec_rope_len, "sequence too long for the decoder RoPE table");
-    const int max_seq = std::max((Smax + 63) / 64 * 64, 64), tstride = Smax + 2;
+    const int max_seq = std::max((Smax + 63) / 64 * 64, 64), tstride = std::max(Smax, PREFIX_LEN) + 2;
+    const int audio_rows = std::max(enc_row_budget(m, T.data(), n) / c.reshape_factor, PREFIX_LEN + 1);   // per-utterance row budget of the stacked audio embeddings
     const size_t seq_stride = (size_t)KV * max_seq * hd, layer_stride = (size_t)n * seq_stride;
-    DevBuf b_audio, b_k, b_v, b_tok, b_pos, b_len, b_h, b_xn, b_qkv, b_att, b_act, b_logits, b_px;
-    HIPCHK(b_audio.alloc((size_t)n * Smax * D * 4)); HIPCHK(b_k.alloc(layer_stride * c.dec_layers * 4)); HIPCHK(b_v.alloc(layer_stride * c.dec_layers * 4));
+    size_t mel_floats = 0; for (int i = 0; i < n; i++) mel_floats += (size_t)128 * T[i];
+    DevBuf b_audio, b_k, b_v, b_tok, b_pos, b_len, b_h, b_xn, b_qkv, b_att, b_act, b_logits, b_px, b_mel, b_scale, b_smp;
+    HIPCHK(b_audio.alloc((size_t)n * audio_rows * D * 4)); HIPCHK(b_k.alloc(layer_stride * c.dec_layers * 4)); HIPCHK(b_v.alloc(layer_stride * c.dec_layers * 4));
     HIPCHK(b_tok.alloc((size_t)n * tstride * 4)); HIPCHK(b_pos.alloc((size_t)n * 4)); HIPCHK(b_len.alloc((size_t)n * 4));
     HIPCHK(b_h.alloc((size_t)n * D * 4)); HIPCHK(b_xn.alloc((size_t)n * D * 4)); HIPCHK(b_qkv.alloc((size_t)n * W * 4)); HIPCHK(b_att.alloc((size_t)n * QD * 4));
-    HIPCHK(b_act.alloc((size_t)n * F * 4)); HIPCHK(b_logits.alloc((size_t)n * V * 4)); HIPCHK(b_px.alloc((size_t)PREFIX_LEN * D * 4));
+    HIPCHK(b_act.alloc((size_t)n * F * 4)); HIPCHK(b_logits.alloc((size_t)n * V * 4)); HIPCHK(b_px.alloc((size_t)n * PREFIX_LEN * D * 4));
+    HIPCHK(b_mel.alloc(std::max<size_t>(mel_floats, 1) * 4)); HIPCHK(b_scale.alloc((size_t)n * 4));
     HIPCHK(hipMemsetAsync(b_tok.p, 0, (size_t)n * tstride * 4, s)); HIPCHK(hipMemsetAsync(b_h.p, 0, (size_t)n * D * 4, s));
+    HIPCHK(hipMemsetAsync(b_audio.p, 0, (size_t)n * audio_rows * D * 4, s));
     float* d_audio = b_audio.as<float>(); int* d_tok = b_tok.as<int>(); int* d_pos = b_pos.as<int>();
     const double t0 = now_ms();
-    // (1) per utterance: peak-normalise -> pad -> log-mel -> encoder -> adapter; (2) 38-token prefill into its KV-cache slice
-    std::vector<int32_t> prefix(PREFIX_LEN, STREAMING_PAD); prefix[0] = BOS;
-    std::vector<int> pos0(n), len(n);
-    double enc_ms = 0, pre_ms = 0;
-    for (int i = 0; i < n; i++) {
-        const double ta = now_ms();
-        const float* d_s = samples[i];
-        if (mem_kind == VOX_MEM_HOST) {
-            VOXCHK(ensure(&m->d_samples, &m->samples_cap, n_samples[i]));
-            HIPCHK(hipMemcpyAsync(m->d_samples, samples[i], n_samples[i] * 4, hipMemcpyHostToDevice, s)); d_s = m->d_samples;
+    // (1) front-end per utterance, no host synchronisation in between: peak-normalise -> (virtual) pad -> log-mel
+    std::vector<const float*> d_mels(n);
+    {
+        size_t smp_total = 0; if (mem_kind == VOX_MEM_HOST) { for (int i = 0; i < n; i++) smp_total += n_samples[i]; HIPCHK(b_smp.alloc(smp_total * 4)); }
+        size_t mo = 0, so = 0;
+        for (int i = 0; i < n; i++) {
+            const float* d_s = samples[i];
+            if (mem_kind == VOX_MEM_HOST) {
+                float* dst = b_smp.as<float>() + so; so += n_samples[i];
+                HIPCHK(hipMemcpyAsync(dst, samples[i], n_samples[i] * 4, hipMemcpyHostToDevice, s)); d_s = dst;
+            }
+            const size_t left = pad_left(&pc), right = pad_right(&pc, n_samples[i] + left);
+            float* mel_i = b_mel.as<float>() + mo; mo += (size_t)128 * T[i]; d_mels[i] = mel_i;
+            float* scale_i = b_scale.as<float>() + i;
+            HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, scale_i, s));
+            HIPCHK(launch_mel(d_s, (long)n_samples[i], (long)left, (long)right, scale_i, mt, mel_i, T[i], 1, s));
         }
-        const size_t left = pad_left(&pc), right = pad_right(&pc, n_samples[i] + left);
-        VOXCHK(ensure(&m->d_mel, &m->mel_cap, (size_t)128 * T[i]));
-        HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, cx->d_scale, s));
-        HIPCHK(launch_mel(d_s, (long)n_samples[i], (long)left, (long)right, cx->d_scale, mt, m->d_mel, T[i], 1, s));
-        HIPCHK(hipStreamSynchronize(s)); const double tb = now_ms(); pre_ms += tb - ta;
-        int S4 = 0; VOXCHK(encode_dev(m, m->d_mel, T[i], &S4));
-        ARGCHK(S4 == S[i], "internal: sequence length mismatch (%d vs %d)", S4, S[i]);
-        if (S4 > 0) HIPCHK(hipMemcpyAsync(d_audio + (size_t)i * Smax * D, m->d_audio, (size_t)S4 * D * 4, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipStreamSynchronize(s)); enc_ms += now_ms() - tb;
-        pos0[i] = PREFIX_LEN; len[i] = S[i];
-        if (S[i] < PREFIX_LEN) { pos0[i] = 0; len[i] = 1; continue; }          // gguf/model.rs:887-889: empty result
-        HIPCHK(hipMemcpyAsync(d_tok + (size_t)i * tstride, prefix.data(), PREFIX_LEN * 4, hipMemcpyHostToDevice, s));
     }
-    const double t1 = now_ms();
-    HIPCHK(hipMemcpyAsync(d_pos, pos0.data(), (size_t)n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s)); const double t_pre = now_ms();
+    // (2) stacked encoder + adapter: every GEMM once over all utterances' frames
+    std::vector<int> S4(n);
+    VOXCHK(encode_batch_dev(m, n, d_mels.data(), T.data(), d_audio, audio_rows, S4.data()));
+    for (int i = 0; i < n; i++) ARGCHK(S4[i] == S[i], "internal: sequence length mismatch (%d vs %d)", S4[i], S[i]);
+    HIPCHK(hipStreamSynchronize(s)); const double t1 = now_ms();
+    const double pre_ms = t_pre - t0, enc_ms = t1 - t_pre;
+    // (3) stacked 38-token prefill (gguf/model.rs:887-919): x0[i][r] = audio[i][r] + embed(prefix[r]); utterances shorter than the
+    // prefix emit nothing (model.rs:887-889) -- they ride along as idle rows
+    std::vector<int32_t> prefix((size_t)n * tstride, 0);
+    std::vector<int> pos0(n), len(n);
     for (int i = 0; i < n; i++) {
-        if (S[i] < PREFIX_LEN) continue;
-        vox_cache view; view.m = m; view.ctx = cx; view.k = b_k.as<float>() + (size_t)i * seq_stride; view.v = b_v.as<float>() + (size_t)i * seq_stride;
-        view.max_seq = max_seq; view.len = 0; view.layer_stride = layer_stride;
-        const float* au = d_audio + (size_t)i * Smax * D;
-        HIPCHK(launch_embed(m->tok.w, d_tok + (size_t)i * tstride, PREFIX_LEN, au, D, nullptr, 0, 0, b_px.as<float>(), s));
-        VOXCHK(decoder_prefill_dev(m, b_px.as<float>(), PREFIX_LEN, &view, 0));
-        VOXCHK(lm_head_argmax_dev(m, b_px.as<float>() + (size_t)(PREFIX_LEN - 1) * D, nullptr));
-        HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, m->n_parts, d_tok + (size_t)i * tstride, d_pos + i, 0, 0, s));          // tokens[i][38]
-        HIPCHK(launch_embed(m->tok.w, d_tok + (size_t)i * tstride, 1, au, D, d_pos + i, 0, 0, b_h.as<float>() + (size_t)i * D, s));     // first step input
+        prefix[(size_t)i * tstride] = BOS; for (int r = 1; r < PREFIX_LEN; r++) prefix[(size_t)i * tstride + r] = STREAMING_PAD;
+        pos0[i] = PREFIX_LEN - 1; len[i] = S[i] >= PREFIX_LEN ? S[i] : 0;          // pos = index of the last token written so far
     }
-    // (3) batched decode steps
+    HIPCHK(hipMemcpyAsync(d_tok, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_pos, pos0.data(), (size_t)n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    {
+        float* px = b_px.as<float>();
+        for (int i = 0; i < n; i++)
+            HIPCHK(launch_embed(m->tok.w, d_tok + (size_t)i * tstride, PREFIX_LEN, d_audio + (size_t)i * audio_rows * D, D, nullptr, 0, 0, px + (size_t)i * PREFIX_LEN * D, s));
+        vox_cache view; view.m = m; view.ctx = cx; view.k = b_k.as<float>(); view.v = b_v.as<float>(); view.max_seq = max_seq; view.len = 0; view.layer_stride = layer_stride;
+        VOXCHK(decoder_prefill_dev(m, px, n * PREFIX_LEN, &view, 0, n, (long)seq_stride));
+        // logits of every utterance's last prefix row -> first generated token + first step input (same tail as a decode step)
+        HIPCHK(launch_rms_norm(px + (size_t)(PREFIX_LEN - 1) * D, PREFIX_LEN * D, n, D, m->dec_norm, nullptr, c.norm_eps, b_xn.as<float>(), D, s));
+        { GemmParams g{}; g.w = m->tok.w; g.x = b_xn.as<float>(); g.x_stride = D; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+        HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, b_h.as<float>(), s));
+    }
+    // (4) batched decode steps
     int steps = 0; for (int i = 0; i < n; i++) steps = std::max(steps, S[i] - PREFIX_LEN - 1);
     auto step = [&]() -> int32_t {
         float* h = b_h.as<float>(); float* xn = b_xn.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>(); float* act = b_act.as<float>();
         for (int l = 0; l < c.dec_layers; l++) {
             const DecLayer& L = m->dec[l]; float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;
             HIPCHK(launch_rms_norm(h, D, n, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
-            { GemmParams g{}; g.w = L.wqkv.w; g.qt = L.wqkv.qt; g.st = L.wqkv.st; g.x = xn; g.x_stride = D; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+            { GemmParams g{}; g.w = L.wqkv.w; g.x = xn; g.x_stride = D; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
             HIPCHK(launch_rope_kv_batch(qkv, n, W, QD, KV, hd, d_pos, m->dec_cos, m->dec_sin, kl, vl, (long)seq_stride, max_seq * hd, s));
             AttnParams ap{}; ap.q = qkv; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
             ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
             HIPCHK(launch_attn_decode(ap, hd, max_seq, s, n));
-            { GemmParams g{}; g.w = L.wo.w; g.qt = L.wo.qt; g.st = L.wo.st; g.x = att; g.x_stride = QD; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+            { GemmParams g{}; g.w = L.wo.w; g.x = att; g.x_stride = QD; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
             HIPCHK(launch_rms_norm(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));
-            { GemmParams g{}; g.w = L.w13.w; g.qt = L.w13.qt; g.st = L.w13.st; g.x = xn; g.x_stride = D; g.M = n; g.out = act; g.out_stride = F; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU, s)); }
-            { GemmParams g{}; g.w = L.w2.w; g.qt = L.w2.qt; g.st = L.w2.st; g.x = act; g.x_stride = F; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+            { GemmParams g{}; g.w = L.w13.w; g.x = xn; g.x_stride = D; g.M = n; g.out = act; g.out_stride = F; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU, s)); }
+            { GemmParams g{}; g.w = L.w2.w; g.x = act; g.x_stride = F; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
         }
         HIPCHK(launch_rms_norm(h, D, n, D, m->dec_norm, nullptr, c.norm_eps, xn, D, s));
-        { GemmParams g{}; g.w = m->tok.w; g.qt = m->tok.qt; g.st = m->tok.st; g.x = xn; g.x_stride = D; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
-        HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)Smax * D, D, h, s));
+        { GemmParams g{}; g.w = m->tok.w; g.x = xn; g.x_stride = D; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+        HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s));
         return VOX_OK;
     };
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int replays = 0;

@@ -15,6 +15,9 @@ struct Q4W {
     const uint16_t* sc;  // fmt 0: IEEE f16 scale bits [N][nb]; fmt 1: unused (nullptr)
     int N, K, nb;        // nb = K / 32
     int fmt;             // WFMT_Q4_0 or WFMT_BF16 (the f32 SafeTensors path: the checkpoint is BF16 on disk, exact in bf16)
+    // optional second copy in MFMA tile order (q4_tile_build_kernel): [N/16 tiles][nb/4][64 lanes] uint4 + scales; used by the
+    // skinny (M <= 16) and the large-M MFMA kernels, whose B fragments then are single coalesced dwordx4 loads
+    const uint4* qt = nullptr; const uint16_t* st = nullptr;
 };
 enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1 };
 
@@ -49,7 +52,6 @@ struct GemmParams {
     float* out; int out_stride;
     const float* bias;
     const float* resid; int resid_stride;
-    const uint4* qt; const uint16_t* st;   // optional tile-layout copy of w (see q4_tile_build_kernel); used when M <= 16
 };
 hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);
@@ -60,11 +62,12 @@ hipError_t launch_q4_dequant(Q4W w, float* out, hipStream_t s);                 
 hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul,
                            float eps, float* out, int out_stride, hipStream_t s);
 // interleaved-pair RoPE in place on columns [0, n_rot) of buf[M][stride]; row m has position pos_off + m
+// (seq_rows > 0: stacked sequences of seq_rows rows each, positions restart per sequence)
 hipError_t launch_rope(float* buf, int M, int stride, int n_rot, int hd, int pos_off, const float* cos_t,
-                       const float* sin_t, hipStream_t s);
+                       const float* sin_t, hipStream_t s, int seq_rows = 0);
 // copy k (columns [k_col, k_col+n_kv*hd)) and v (next n_kv*hd columns) of buf rows into the cache at pos_off+m
 hipError_t launch_kv_store(const float* buf, int M, int stride, int k_col, int n_kv, int hd, int pos_off,
-                           float* kcache, float* vcache, int cache_head_stride, hipStream_t s);
+                           float* kcache, float* vcache, int cache_head_stride, hipStream_t s, int seq_rows = 0, long kv_seq_stride = 0);
 
 struct AttnParams {
     const float* q; int q_stride;            // q[m][h*hd + d]
@@ -75,8 +78,11 @@ struct AttnParams {
     const int* pos_ptr;                      // decode: position = *pos_ptr + offset, kv_len = position+1
     // batched decode (gridDim.y = sequences): sequence s reads pos_ptr[s] and its own q / out rows and KV-cache slice
     int pos_per_seq; int q_seq_stride, out_seq_stride; long kv_seq_stride;
+    // stacked prefill (gridDim.z = sequences): sequence z has seq_len[z] query rows (kv_len = offset + seq_len[z]); p.M = the maximum;
+    // q / out / k / v of sequence z start q_seq_stride / out_seq_stride / kv_seq_stride floats after those of z-1
+    const int* seq_len;
 };
-hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s);     // M > 1, causal (+window)
+hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n_seq = 1);     // M > 1, causal (+window)
 hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq = 1);  // M == 1 per sequence
 
 // gelu(conv1d k3 s2 p1): in [Cin][L] -> out; out_token_major: out[t][co] else out[co][t]

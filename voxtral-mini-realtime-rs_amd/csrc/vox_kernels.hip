@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256) void q4_skinny_kernel(const GemmParams p) {
     for (int t = 0; t < NTW; t++) {
         if (TILED) {
             const size_t T = (size_t)min(blockIdx.x * NTW + t, n_tiles - 1);
-            wq[t] = p.qt + T * nq * 64 + lane; ws[t] = p.st + (T * nq * 16 + li) * 4;
+            wq[t] = p.w.qt + T * nq * 64 + lane; ws[t] = p.w.st + (T * nq * 16 + li) * 4;
         } else {
             const size_t row = (size_t)min(nbase + t * 16 + li, N - 1);
             wq[t] = p.w.qs + row * nb + g; ws[t] = p.w.sc + row * nb;
@@ -1008,6 +1008,133 @@ __global__ __launch_bounds__(256) void q4_skinny_kernel(const GemmParams p) {
     }
 }
 
+// ---- large-M MFMA GEMM (batched encoder / long prefill): workgroup tile (64*WGM) x (64*WGN), four waves in a WGM x WGN grid,
+// every wave owns a 64 x 64 output block = 4 m-tiles x 4 n-tiles (16 accumulators), K step 128 (four Q4 blocks).
+//  * A (activations): f32 rows -> bf16 hi+lo planes in LDS, MFMA-fragment order, written 1 KB-contiguous per wave
+//    (conflict-free ds_write_b128 / ds_read_b128); the next K step's rows are already in flight in registers.
+//  * B (weights): the tile-ordered copy -- one coalesced dwordx4 per lane per n-tile per K step IS the lane's four B
+//    fragments; nibbles -> bf16 by the bit trick 0x4300|q = 128+q, and the -136*sum(x) correction enters as the initial
+//    accumulator through one ones-MFMA pair per (m-tile, block), shared by the four n-tiles (uses the same hi+lo values,
+//    so the split error cancels exactly).
+//  * per (m-tile, n-tile, block): 2 MFMAs + 2 packed FMAs for the f16 block scale.
+// ------------------------------------------------------------------------------------------------
+template <int WGM, int WGN, int EPI>
+__global__ __launch_bounds__(256) void q4_gemm_big_kernel(const GemmParams p) {
+    constexpr int BM = 64 * WGM, MTB = BM / 16;                     // rows / m-tiles per workgroup
+    constexpr int PAIRS = 4 * MTB, NU = PAIRS / 4;                  // (block j, m-tile i) fragments groups; per-wave share
+    extern __shared__ __attribute__((aligned(16))) uint4 blds[];    // [hi/lo][j 4][MTB][64]
+    constexpr int PLANE = 4 * MTB * 64;
+    const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * (64 * WGN);
+    const int n_tiles = (N + 15) >> 4;
+    // staging role: wave handles pairs {wave + 4u}; lane (g, li) stages row 16*i + li, K slots of group g
+    const float* xrow[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int pair = wave + 4 * u, j = pair / MTB, i = pair % MTB;
+        xrow[u] = p.x + (size_t)min(m0 + 16 * i + li, M - 1) * p.x_stride + 32 * j + 4 * g;
+    }
+    // MFMA role
+    const uint4* wq[4]; const uint16_t* ws[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const size_t T = (size_t)min((n0 >> 4) + wn * 4 + t, n_tiles - 1);
+        wq[t] = p.w.qt + T * nq * 64 + lane; ws[t] = p.w.st + (T * nq * 16 + li) * 4;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 xa[NU], xb[NU]; uint4 bw[4], bwn[4]; uint2 bs[4], bsn[4];
+#define VOX_ALOAD(Q_)                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < NU; u++) {                                                           \
+        xa[u] = *reinterpret_cast<const float4*>(xrow[u] + 128 * (Q_));                                        \
+        xb[u] = *reinterpret_cast<const float4*>(xrow[u] + 128 * (Q_) + 16); }
+#define VOX_BLOAD(W_, S_, Q_)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                            \
+        W_[t] = wq[t][(size_t)64 * (Q_)]; S_[t] = *reinterpret_cast<const uint2*>(ws[t] + 64 * (Q_)); }
+    VOX_ALOAD(0)
+    VOX_BLOAD(bw, bs, 0)
+    const bf16x8 ones = as_bf16x8(make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    for (int q = 0; q < nq; q++) {
+        __syncthreads();                                          // every wave is done reading the previous K step
+#pragma unroll
+        for (int u = 0; u < NU; u++) {                            // K-slot order of the bit-trick B fragment: {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3}
+            uint4 hi, lo;
+            split_pair(xa[u].x, xa[u].z, hi.x, lo.x); split_pair(xb[u].x, xb[u].z, hi.y, lo.y);
+            split_pair(xa[u].y, xa[u].w, hi.z, lo.z); split_pair(xb[u].y, xb[u].w, hi.w, lo.w);
+            blds[(wave + 4 * u) * 64 + lane] = hi; blds[PLANE + (wave + 4 * u) * 64 + lane] = lo;
+        }
+        __syncthreads();
+        { const int q1 = min(q + 1, nq - 1); VOX_ALOAD(q1) VOX_BLOAD(bwn, bsn, q1) }      // unconditional (clamped) prefetch
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bf16x8 bf[4]; float d[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t w_ = j == 0 ? bw[t].x : j == 1 ? bw[t].y : j == 2 ? bw[t].z : bw[t].w;
+                bf[t] = as_bf16x8(make_uint4((w_ & 0x000F000Fu) | 0x43004300u, ((w_ >> 4) & 0x000F000Fu) | 0x43004300u,
+                                             ((w_ >> 8) & 0x000F000Fu) | 0x43004300u, ((w_ >> 12) & 0x000F000Fu) | 0x43004300u));
+                const uint32_t pr = (j & 2) ? bs[t].y : bs[t].x;
+                d[t] = f16_bits_to_f32((uint16_t)((j & 1) ? (pr >> 16) : (pr & 0xFFFFu)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bf16x8 ah = as_bf16x8(blds[(j * MTB + wm * 4 + i) * 64 + lane]);
+                const bf16x8 al = as_bf16x8(blds[PLANE + (j * MTB + wm * 4 + i) * 64 + lane]);
+                f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, cs, 0, 0, 0);
+                cs = cs * -136.0f;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bf[t], cs, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bf[t], tt, 0, 0, 0);
+                    acc[t][i] = __builtin_elementwise_fma((f32x4){d[t], d[t], d[t], d[t]}, tt, acc[t][i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) { bw[t] = bwn[t]; bs[t] = bsn[t]; }
+    }
+#undef VOX_ALOAD
+#undef VOX_BLOAD
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int n = n0 + (wn * 4 + t) * 16 + li; const bool nok = n < N;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + (wm * 4 + i) * 16 + 4 * g + r;
+                float v = acc[t][i][r] + bias;
+                if (EPI == EPI_SWIGLU) {
+                    const float other = dpp_mov<0xB1>(v);        // lane^1; rows interleaved: even n = gate, odd n = up
+                    if (m < M && nok && !(n & 1)) p.out[(size_t)m * p.out_stride + (n >> 1)] = silu_f(v) * other;
+                } else if (m < M && nok) {
+                    if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + n];
+                    if (EPI == EPI_GELU) v = gelu_f(v);
+                    p.out[(size_t)m * p.out_stride + n] = v;
+                }
+            }
+    }
+}
+template <int WGM, int WGN>
+static hipError_t gemm_big_launch(const GemmParams& p, int epi, hipStream_t s) {
+    dim3 grid((p.w.N + 64 * WGN - 1) / (64 * WGN), (p.M + 64 * WGM - 1) / (64 * WGM));
+    const size_t lds = (size_t)2 * 4 * (4 * WGM) * 64 * sizeof(uint4);      // WGM * 32 KB
+#define VOX_E(E_) case E_: { auto kern = q4_gemm_big_kernel<WGM, WGN, E_>; static bool done = false;          \
+        hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;                       \
+        kern<<<grid, dim3(256), lds, s>>>(p); break; }
+    switch (epi) { VOX_E(EPI_STORE) VOX_E(EPI_RESID) VOX_E(EPI_GELU) VOX_E(EPI_SWIGLU) default: return hipErrorInvalidValue; }
+#undef VOX_E
+    return hipGetLastError();
+}
+
 template <int NTW, int TILED>
 static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStream_t s) {
     dim3 grid((p.w.N + 16 * NTW - 1) / (16 * NTW));
@@ -1027,7 +1154,7 @@ static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) 
     int ks = nq >= 4 ? 4 : (nq >= 2 ? 2 : 1);
     { const int e = env_int("VOX_SKINNY_NTW"); if (e == 2 || e == 4) ntw = e; }
     { const int e = env_int("VOX_SKINNY_KS"); if (e == 1 || e == 2 || e == 4) ks = e; }
-    if (p.qt && p.st && !env_int("VOX_SKINNY_NO_TILE"))
+    if (p.w.qt && p.w.st && !env_int("VOX_SKINNY_NO_TILE"))
         return ntw == 4 ? skinny_launch_n<4, 1>(p, epi, ks, s) : skinny_launch_n<2, 1>(p, epi, ks, s);
     return ntw == 4 ? skinny_launch_n<4, 0>(p, epi, ks, s) : skinny_launch_n<2, 0>(p, epi, ks, s);
 }
@@ -1084,6 +1211,13 @@ static hipError_t gemm_launch_f(const GemmParams& p, int epi, hipStream_t s) {
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
     if (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && !env_int("VOX_NO_SKINNY")) return launch_q4_skinny(p, epi, s);
+    if (p.w.fmt == WFMT_Q4_0 && p.w.qt && p.w.st && p.w.nb % 4 == 0 && (p.x_stride % 4) == 0) {
+        // large M: 64 x 256 workgroup tiles (64 x 64 per wave) once they fill the chip -- 1.2-1.55x the 32 x 128 kernel
+        // (profiles/r01_gemm_sweep.txt).  VOX_GEMM_BIG: 0 auto, 1 force, -1 off (measurement knob)
+        const int big = env_int("VOX_GEMM_BIG");
+        const long wg14 = (long)((p.w.N + 255) / 256) * ((p.M + 63) / 64);
+        if (big == 1 || (big == 0 && wg14 >= 200)) return gemm_big_launch<1, 4>(p, epi, s);
+    }
     return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, s);
 }
 
@@ -1169,13 +1303,13 @@ hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, cons
 // RoPE (interleaved pairs) + KV store for the multi-row paths
 // ------------------------------------------------------------------------------------------------
 __global__ void rope_kernel(float* __restrict__ buf, int M, int stride, int n_rot, int hd, int pos_off,
-                            const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
+                            const float* __restrict__ cos_t, const float* __restrict__ sin_t, int seq_rows) {
     const int half_cols = n_rot >> 1;
     const long total = (long)M * half_cols;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / half_cols), pc = (int)(i % half_cols);
         const int col = pc * 2, j = (col % hd) >> 1;
-        const size_t ti = (size_t)(pos_off + m) * (hd >> 1) + j;
+        const size_t ti = (size_t)(pos_off + (seq_rows > 0 ? m % seq_rows : m)) * (hd >> 1) + j;   // stacked sequences restart at 0
         const float c = cos_t[ti], sn = sin_t[ti];
         float* p = buf + (size_t)m * stride + col;
         const float xr = p[0], xi = p[1];
@@ -1183,29 +1317,30 @@ __global__ void rope_kernel(float* __restrict__ buf, int M, int stride, int n_ro
     }
 }
 hipError_t launch_rope(float* buf, int M, int stride, int n_rot, int hd, int pos_off, const float* cos_t, const float* sin_t,
-                       hipStream_t s) {
+                       hipStream_t s, int seq_rows) {
     const long total = (long)M * (n_rot / 2);
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-    rope_kernel<<<dim3(blocks), dim3(256), 0, s>>>(buf, M, stride, n_rot, hd, pos_off, cos_t, sin_t);
+    rope_kernel<<<dim3(blocks), dim3(256), 0, s>>>(buf, M, stride, n_rot, hd, pos_off, cos_t, sin_t, seq_rows);
     return hipGetLastError();
 }
 
 __global__ void kv_store_kernel(const float* __restrict__ buf, int M, int stride, int k_col, int n_kv, int hd, int pos_off,
-                                float* __restrict__ kc, float* __restrict__ vc, int head_stride) {
+                                float* __restrict__ kc, float* __restrict__ vc, int head_stride, int seq_rows, long kv_seq_stride) {
     const int w = n_kv * hd;
     const long total = (long)M * w;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / w), c = (int)(i % w), h = c / hd, d = c % hd;
-        const size_t dst = (size_t)h * head_stride + (size_t)(pos_off + m) * hd + d;
+        const int sq = seq_rows > 0 ? m / seq_rows : 0, mm = seq_rows > 0 ? m % seq_rows : m;     // stacked sequences: own cache slice each
+        const size_t dst = (size_t)sq * kv_seq_stride + (size_t)h * head_stride + (size_t)(pos_off + mm) * hd + d;
         kc[dst] = buf[(size_t)m * stride + k_col + c];
         vc[dst] = buf[(size_t)m * stride + k_col + w + c];
     }
 }
 hipError_t launch_kv_store(const float* buf, int M, int stride, int k_col, int n_kv, int hd, int pos_off, float* kc, float* vc,
-                           int head_stride, hipStream_t s) {
+                           int head_stride, hipStream_t s, int seq_rows, long kv_seq_stride) {
     const long total = (long)M * n_kv * hd;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-    kv_store_kernel<<<dim3(blocks), dim3(256), 0, s>>>(buf, M, stride, k_col, n_kv, hd, pos_off, kc, vc, head_stride);
+    kv_store_kernel<<<dim3(blocks), dim3(256), 0, s>>>(buf, M, stride, k_col, n_kv, hd, pos_off, kc, vc, head_stride, seq_rows, kv_seq_stride);
     return hipGetLastError();
 }
 
@@ -1329,16 +1464,20 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams
     uint16_t* Vl = Vh + HD * VROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const int h = blockIdx.y, kvh = h / (p.n_heads / p.n_kv_heads);
+    // stacked sequences (gridDim.z): sequence z owns rows [z*seq stride ..) of q / out / k / v and has seq_len[z] rows
+    const int sq = blockIdx.z;
+    const int M = p.seq_len ? p.seq_len[sq] : p.M, kv_len = p.seq_len ? p.offset + M : p.kv_len;
     const int m0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 64;    // causal: late query blocks have the most keys -- dispatch them first
+    if (m0 >= M) return;                                           // whole workgroup (ragged batch)
     const int m = m0 + wave * 16 + c;
-    const int mq = min(m, p.M - 1);
+    const int mq = min(m, M - 1);
     const int pos = p.offset + mq;
-    const int wave_pos_hi = p.offset + min(m0 + wave * 16 + 15, p.M - 1);   // last position any query of this wave has
+    const int wave_pos_hi = p.offset + min(m0 + wave * 16 + 15, M - 1);   // last position any query of this wave has
     const float scale = 1.0f / sqrtf((float)HD);      // head_dim^-0.5 (gguf/model.rs:65)
 
     bf16x8 qh[KS], ql[KS];
     {
-        const float* qp = p.q + (size_t)mq * p.q_stride + h * HD + 8 * g;
+        const float* qp = p.q + (size_t)sq * p.q_seq_stride + (size_t)mq * p.q_stride + h * HD + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const float4 a = *reinterpret_cast<const float4*>(qp + ks * 32), b = *reinterpret_cast<const float4*>(qp + ks * 32 + 4);
@@ -1350,12 +1489,12 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams
     for (int dt = 0; dt < DT; dt++) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float mx = -INFINITY, lsum = 0.f;
 
-    const int last_m = min(m0 + 63, p.M - 1);
+    const int last_m = min(m0 + 63, M - 1);
     int j_lo = 0;
     if (p.window >= 0) j_lo = max(0, p.offset + m0 - p.window);
-    const int j_hi = min(p.kv_len - 1, p.offset + last_m);   // inclusive
-    const float* kbase = p.k + (size_t)kvh * p.kv_head_stride;
-    const float* vbase = p.v + (size_t)kvh * p.kv_head_stride;
+    const int j_hi = min(kv_len - 1, p.offset + last_m);   // inclusive
+    const float* kbase = p.k + (size_t)sq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const float* vbase = p.v + (size_t)sq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
 
     // register-staged software pipeline: the global loads of tile t+1 are in flight while tile t is being multiplied
     constexpr int NK = (64 * (HD / 4)) / 256, NV = (32 * (HD / 4)) / 256;
@@ -1363,12 +1502,12 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams
 #define VOX_ATT_LOAD(J0_)                                                                                           \
     _Pragma("unroll") for (int u = 0; u < NK; u++) {                                                                \
         const int i = tid + 256 * u, key = i / (HD / 4), d4 = i % (HD / 4);                                         \
-        const int jc = min((J0_) + key, p.kv_len - 1);   /* unconditional clamped loads; masked keys get p = 0 */   \
+        const int jc = min((J0_) + key, kv_len - 1);   /* unconditional clamped loads; masked keys get p = 0 */   \
         kreg[u] = *reinterpret_cast<const float4*>(kbase + (size_t)jc * p.kv_row_stride + d4 * 4);                  \
     }                                                                                                               \
     _Pragma("unroll") for (int u = 0; u < NV; u++) {                                                                \
         const int i = tid + 256 * u, kp = i / (HD / 4), d4 = i % (HD / 4);                                          \
-        const int ja = min((J0_) + 2 * kp, p.kv_len - 1), jb = min((J0_) + 2 * kp + 1, p.kv_len - 1);               \
+        const int ja = min((J0_) + 2 * kp, kv_len - 1), jb = min((J0_) + 2 * kp + 1, kv_len - 1);               \
         vra[u] = *reinterpret_cast<const float4*>(vbase + (size_t)ja * p.kv_row_stride + d4 * 4);                   \
         vrb[u] = *reinterpret_cast<const float4*>(vbase + (size_t)jb * p.kv_row_stride + d4 * 4);                   \
     }
@@ -1422,7 +1561,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int j = j0 + kt * 16 + 4 * g + r;
-                bool vis = (j < p.kv_len) && (j <= pos);
+                bool vis = (j < kv_len) && (j <= pos);
                 if (p.window >= 0) vis = vis && (pos - j <= p.window);
                 const float v = vis ? sc[kt][r] * scale : -INFINITY;
                 sc[kt][r] = v; mt = fmaxf(mt, v);
@@ -1463,30 +1602,31 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams
     }
 #undef VOX_ATT_LOAD
     lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
-    if (m < p.M) {
+    if (m < M) {
         const float inv = 1.0f / lsum;
-        float* op = p.out + (size_t)m * p.out_stride + h * HD + 4 * g;
+        float* op = p.out + (size_t)sq * p.out_seq_stride + (size_t)m * p.out_stride + h * HD + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < DT; dt++)
             *reinterpret_cast<float4*>(op + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
     }
 }
 template <int HD>
-static hipError_t attn_prefill_mfma_launch(const AttnParams& p, hipStream_t s) {
+static hipError_t attn_prefill_mfma_launch(const AttnParams& p, hipStream_t s, int n_seq) {
     constexpr size_t lds = ((size_t)2 * 64 * (HD + 8) + (size_t)2 * HD * 72) * sizeof(uint16_t);
     auto kern = attn_prefill_mfma_kernel<HD>;
     static bool attr_done = false;
     hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
     if (e != hipSuccess) return e;
-    kern<<<dim3((p.M + 63) / 64, p.n_heads), dim3(256), lds, s>>>(p);
+    kern<<<dim3((p.M + 63) / 64, p.n_heads, n_seq), dim3(256), lds, s>>>(p);
     return hipGetLastError();
 }
-hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s) {
+hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n_seq) {
     static const int f32_only = env_int("VOX_ATTN_F32");        // ablation / cross-check knob: the f32 VALU kernel
     if (!f32_only && (p.q_stride % 4) == 0 && (p.kv_row_stride % 4) == 0) {
-        if (hd == 64) return attn_prefill_mfma_launch<64>(p, s);
-        if (hd == 128) return attn_prefill_mfma_launch<128>(p, s);
+        if (hd == 64) return attn_prefill_mfma_launch<64>(p, s, n_seq);
+        if (hd == 128) return attn_prefill_mfma_launch<128>(p, s, n_seq);
     }
+    if (n_seq != 1 || p.seq_len) return hipErrorInvalidValue;      // stacked sequences: MFMA kernel only
     dim3 grid((p.M + 63) / 64, p.n_heads);
     const size_t lds = (size_t)2 * 64 * hd * sizeof(float);
     if (hd == 64) {
