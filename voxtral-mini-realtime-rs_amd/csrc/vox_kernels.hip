@@ -887,7 +887,7 @@ hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s) {
 }
 
 template <int NTW, int EPI, int TILED>
-__global__ __launch_bounds__(256) void q4_skinny_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS][NTW][64][4]
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, KS = blockDim.x >> 6;
@@ -1150,13 +1150,17 @@ static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStrea
 }
 static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) {
     const int nq = p.w.nb / 4, tiles = (p.w.N + 15) / 16;
-    int ntw = (tiles / 4) * 4 >= 1024 ? 4 : 2;          // four n-tiles per wave only when that still yields >= 1024 waves
+    // n-tiles per wave: as many as still leave >= 192 workgroups (N = 3072 has only 192 tiles); split-K over 4 waves, 8 when
+    // the grid is small and K is long enough.  VOX_SKINNY_NTW / VOX_SKINNY_KS are measurement knobs.
+    int ntw = tiles >= 4 * 192 ? 4 : (tiles >= 2 * 192 ? 2 : 1);      // the x fragments are converted once per wave: more tiles per wave = less VALU
     int ks = nq >= 4 ? 4 : (nq >= 2 ? 2 : 1);
-    { const int e = env_int("VOX_SKINNY_NTW"); if (e == 2 || e == 4) ntw = e; }
-    { const int e = env_int("VOX_SKINNY_KS"); if (e == 1 || e == 2 || e == 4) ks = e; }
-    if (p.w.qt && p.w.st && !env_int("VOX_SKINNY_NO_TILE"))
-        return ntw == 4 ? skinny_launch_n<4, 1>(p, epi, ks, s) : skinny_launch_n<2, 1>(p, epi, ks, s);
-    return ntw == 4 ? skinny_launch_n<4, 0>(p, epi, ks, s) : skinny_launch_n<2, 0>(p, epi, ks, s);
+    if (tiles / ntw < 256 && nq >= 16) ks = 8;                        // profiles/r01_skinny_sweep.txt
+    { const int e = env_int("VOX_SKINNY_NTW"); if (e == 1 || e == 2 || e == 4) ntw = e; }
+    { const int e = env_int("VOX_SKINNY_KS"); if (e == 1 || e == 2 || e == 4 || e == 8) ks = e; }
+    const bool tiled = p.w.qt && p.w.st && !env_int("VOX_SKINNY_NO_TILE");
+    if (ntw == 4) return tiled ? skinny_launch_n<4, 1>(p, epi, ks, s) : skinny_launch_n<4, 0>(p, epi, ks, s);
+    if (ntw == 2) return tiled ? skinny_launch_n<2, 1>(p, epi, ks, s) : skinny_launch_n<2, 0>(p, epi, ks, s);
+    return tiled ? skinny_launch_n<1, 1>(p, epi, ks, s) : skinny_launch_n<1, 0>(p, epi, ks, s);
 }
 
 template <int MT, int NT, int FMT>
