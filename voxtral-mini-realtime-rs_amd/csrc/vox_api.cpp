@@ -1254,23 +1254,38 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     }
     // (4) batched decode steps
     int steps = 0; for (int i = 0; i < n; i++) steps = std::max(steps, S[i] - PREFIX_LEN - 1);
+    // <= 16 sequences: the step's GEMM inputs live as XF fragment planes (bf16 hi+lo in MFMA A-operand order, written once by the
+    // producing kernel), so the skinny kernels spend no VALU on conversion and RMSNorm output never exists as f32
+    const bool use_xf = n <= 16 && m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !getenv("VOX_BATCH_NO_XF");
+    auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
+    DevBuf b_xf1, b_xf2, b_xf3;
+    if (use_xf) {
+        HIPCHK(b_xf1.alloc(xf_bytes(D))); HIPCHK(b_xf2.alloc(xf_bytes(QD))); HIPCHK(b_xf3.alloc(xf_bytes(F)));
+        HIPCHK(hipMemsetAsync(b_xf1.p, 0, xf_bytes(D), s)); HIPCHK(hipMemsetAsync(b_xf2.p, 0, xf_bytes(QD), s)); HIPCHK(hipMemsetAsync(b_xf3.p, 0, xf_bytes(F), s));
+    }
     auto step = [&]() -> int32_t {
         float* h = b_h.as<float>(); float* xn = b_xn.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>(); float* act = b_act.as<float>();
+        uint16_t* xf1 = b_xf1.as<uint16_t>(); uint16_t* xf2 = b_xf2.as<uint16_t>(); uint16_t* xf3 = b_xf3.as<uint16_t>();
         for (int l = 0; l < c.dec_layers; l++) {
             const DecLayer& L = m->dec[l]; float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;
-            HIPCHK(launch_rms_norm(h, D, n, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
-            { GemmParams g{}; g.w = L.wqkv.w; g.x = xn; g.x_stride = D; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+            if (use_xf) HIPCHK(launch_rms_norm_xf(h, D, n, D, L.attn_norm, nullptr, c.norm_eps, xf1, s));
+            else HIPCHK(launch_rms_norm(h, D, n, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
+            { GemmParams g{}; g.w = L.wqkv.w; g.x = xn; g.x_stride = D; g.xf = use_xf ? (const uint4*)xf1 : nullptr; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
             HIPCHK(launch_rope_kv_batch(qkv, n, W, QD, KV, hd, d_pos, m->dec_cos, m->dec_sin, kl, vl, (long)seq_stride, max_seq * hd, s));
             AttnParams ap{}; ap.q = qkv; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
             ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
+            ap.out_xf = use_xf ? xf2 : nullptr;
             HIPCHK(launch_attn_decode(ap, hd, max_seq, s, n));
-            { GemmParams g{}; g.w = L.wo.w; g.x = att; g.x_stride = QD; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
-            HIPCHK(launch_rms_norm(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));
-            { GemmParams g{}; g.w = L.w13.w; g.x = xn; g.x_stride = D; g.M = n; g.out = act; g.out_stride = F; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU, s)); }
-            { GemmParams g{}; g.w = L.w2.w; g.x = act; g.x_stride = F; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+            { GemmParams g{}; g.w = L.wo.w; g.x = att; g.x_stride = QD; g.xf = use_xf ? (const uint4*)xf2 : nullptr; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+            if (use_xf) HIPCHK(launch_rms_norm_xf(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xf1, s));
+            else HIPCHK(launch_rms_norm(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));
+            { GemmParams g{}; g.w = L.w13.w; g.x = xn; g.x_stride = D; g.xf = use_xf ? (const uint4*)xf1 : nullptr; g.M = n; g.out = use_xf ? (float*)xf3 : act; g.out_stride = F;
+              HIPCHK(launch_q4_gemm(g, use_xf ? EPI_SWIGLU_XF : EPI_SWIGLU, s)); }
+            { GemmParams g{}; g.w = L.w2.w; g.x = act; g.x_stride = F; g.xf = use_xf ? (const uint4*)xf3 : nullptr; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
         }
-        HIPCHK(launch_rms_norm(h, D, n, D, m->dec_norm, nullptr, c.norm_eps, xn, D, s));
-        { GemmParams g{}; g.w = m->tok.w; g.x = xn; g.x_stride = D; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+        if (use_xf) HIPCHK(launch_rms_norm_xf(h, D, n, D, m->dec_norm, nullptr, c.norm_eps, xf1, s));
+        else HIPCHK(launch_rms_norm(h, D, n, D, m->dec_norm, nullptr, c.norm_eps, xn, D, s));
+        { GemmParams g{}; g.w = m->tok.w; g.x = xn; g.x_stride = D; g.xf = use_xf ? (const uint4*)xf1 : nullptr; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
         HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s));
         return VOX_OK;
     };

@@ -21,7 +21,7 @@ struct Q4W {
 };
 enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1 };
 
-enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5 };
+enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6 };   // _XF: SwiGLU written as XF planes (M <= 16)
 enum Pro { PRO_NONE = 0, PRO_RMS = 1, PRO_RMS_MUL = 2 };   // RMS_MUL: RMSNorm then * mul (the cached Ada scale)
 
 // ---- fused Q4 GEMV (decode, rows of x <= 4): out[y][n] = epi( sum_k pro(x[y])[k] * W[n][k] )
@@ -52,6 +52,7 @@ struct GemmParams {
     float* out; int out_stride;
     const float* bias;
     const float* resid; int resid_stride;
+    const uint4* xf;      // optional (M <= 16): the input as XF fragment planes (see xf_store4) instead of f32 rows x
 };
 hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);
@@ -61,6 +62,8 @@ hipError_t launch_q4_repack(const uint8_t* raw, uint4* qs, uint16_t* sc, int64_t
 hipError_t launch_q4_dequant(Q4W w, float* out, hipStream_t s);                 // diagnostics (tensor.rs:88-113)
 hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul,
                            float eps, float* out, int out_stride, hipStream_t s);
+hipError_t launch_rms_norm_xf(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul,
+                              float eps, uint16_t* xf, hipStream_t s);   // rows <= 16 -> XF fragment planes
 // interleaved-pair RoPE in place on columns [0, n_rot) of buf[M][stride]; row m has position pos_off + m
 // (seq_rows > 0: stacked sequences of seq_rows rows each, positions restart per sequence)
 hipError_t launch_rope(float* buf, int M, int stride, int n_rot, int hd, int pos_off, const float* cos_t,
@@ -81,6 +84,7 @@ struct AttnParams {
     // stacked prefill (gridDim.z = sequences): sequence z has seq_len[z] query rows (kv_len = offset + seq_len[z]); p.M = the maximum;
     // q / out / k / v of sequence z start q_seq_stride / out_seq_stride / kv_seq_stride floats after those of z-1
     const int* seq_len;
+    uint16_t* out_xf;     // batched decode: write the output rows (row = sequence) as XF fragment planes instead of out
 };
 hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n_seq = 1);     // M > 1, causal (+window)
 hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq = 1);  // M == 1 per sequence

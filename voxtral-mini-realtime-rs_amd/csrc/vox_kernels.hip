@@ -628,6 +628,20 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
     union { uint4 u; bf16x8 b; } c; c.u = v; return c.b;
 }
 
+// ---- XF: activations of a <= 16-row batch stored ONCE as MFMA A-fragments (bf16 hi + lo planes), so the batched-decode
+// GEMMs load their operands with plain coalesced dwordx4 and spend no VALU on conversion (the conversion used to be redone
+// by every wave of every workgroup).  Plane layout: uint4 [K/128 (q)][4 (j)][64 lanes]; lane = 16*g + row holds block
+// 4q+j elements in the K-slot order of the bit-trick B fragment {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3};
+// the lo plane follows the hi plane (K/128 * 256 uint4 later).  Producers call xf_store4 with k % 4 == 0.
+__device__ __forceinline__ void xf_store4(uint16_t* __restrict__ xf, int K, int row, int k, float4 v) {
+    const int q = k >> 7, j = (k >> 5) & 3, e = k & 31, half = e >> 4, g = (e & 15) >> 2;
+    const size_t base = ((size_t)((q * 4 + j) * 64 + g * 16 + row)) * 8 + 2 * half;
+    const size_t plane = (size_t)(K >> 7) * 256 * 8;
+    uint32_t hi, lo;
+    split_pair(v.x, v.z, hi, lo); *reinterpret_cast<uint32_t*>(xf + base) = hi; *reinterpret_cast<uint32_t*>(xf + plane + base) = lo;
+    split_pair(v.y, v.w, hi, lo); *reinterpret_cast<uint32_t*>(xf + base + 4) = hi; *reinterpret_cast<uint32_t*>(xf + plane + base + 4) = lo;
+}
+
 // Workgroup tile: 64 rows of x (4 MFMA m-tiles) x 64 weight rows (wave w owns n-tile w).
 // A operand = activations (rows m, k = 8*(lane>>4)..+7), B operand = integer weights (cols n = lane&15),
 // D[m][n]: lane holds n = lane&15, m = 4*(lane>>4) + reg.  The K order inside one MFMA follows the Q4 chunk:
@@ -886,7 +900,7 @@ hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int NTW, int EPI, int TILED>
+template <int NTW, int EPI, int TILED, int XIN>
 __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS][NTW][64][4]
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
@@ -909,14 +923,19 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     f32x4 acc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint4 wv[NTW], wvn[NTW]; uint2 sv[NTW], svn[NTW]; float4 xa[4], xb[4];
+    uint4 wv[NTW], wvn[NTW]; uint2 sv[NTW], svn[NTW]; float4 xa[4], xb[4];      // XIN: xa = hi fragments, xb = lo fragments (bit patterns)
+    const uint4* xfh = p.xf + lane; const uint4* xfl = p.xf + (size_t)nq * 256 + lane;
 #define VOX_WLOAD(WV_, SV_, Q_)                                                                            \
     _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                      \
         WV_[t] = ld_nt_u4(wq[t] + (TILED ? 64 : 4) * (Q_)); SV_[t] = *reinterpret_cast<const uint2*>(ws[t] + (TILED ? 64 : 4) * (Q_)); }
 #define VOX_XLOAD(Q_)                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                        \
-        xa[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 4 * g);                      \
-        xb[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 16 + 4 * g); }
+        if (XIN) {                                                                                         \
+            xa[j] = *reinterpret_cast<const float4*>(xfh + ((Q_) * 4 + j) * 64);                           \
+            xb[j] = *reinterpret_cast<const float4*>(xfl + ((Q_) * 4 + j) * 64);                           \
+        } else {                                                                                           \
+            xa[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 4 * g);                  \
+            xb[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 16 + 4 * g); } }
 // B fragments by bit tricks: bf16 bits 0x4300 | q are exactly 128 + q, so one dword of 8 nibbles becomes 8 bf16 operands
 // in 7 VALU ops (v_and_or_b32 on nibble pairs 16 bits apart).  sum_k x_k (q_k - 8) = sum_k x_k (128 + q_k) - 136 sum_k x_k, and
 // sum_k x_k per (row, block) comes from one extra MFMA pair against an all-ones B, shared by the wave's NTW tiles and already
@@ -926,8 +945,13 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
         uint4 ah[4], al[4]; f32x4 cs[4];                                                                   \
         const bf16x8 ones = as_bf16x8(make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));     \
         _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                    \
-            split_pair(XA_[j].x, XA_[j].z, ah[j].x, al[j].x); split_pair(XB_[j].x, XB_[j].z, ah[j].y, al[j].y); \
-            split_pair(XA_[j].y, XA_[j].w, ah[j].z, al[j].z); split_pair(XB_[j].y, XB_[j].w, ah[j].w, al[j].w); \
+            if (XIN) {                                                                                     \
+                ah[j] = make_uint4(__float_as_uint(XA_[j].x), __float_as_uint(XA_[j].y), __float_as_uint(XA_[j].z), __float_as_uint(XA_[j].w)); \
+                al[j] = make_uint4(__float_as_uint(XB_[j].x), __float_as_uint(XB_[j].y), __float_as_uint(XB_[j].z), __float_as_uint(XB_[j].w)); \
+            } else {                                                                                       \
+                split_pair(XA_[j].x, XA_[j].z, ah[j].x, al[j].x); split_pair(XB_[j].x, XB_[j].z, ah[j].y, al[j].y); \
+                split_pair(XA_[j].y, XA_[j].w, ah[j].z, al[j].z); split_pair(XB_[j].y, XB_[j].w, ah[j].w, al[j].w); \
+            }                                                                                              \
             f32x4 sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), ones, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
             sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[j]), ones, sx, 0, 0, 0);             \
             cs[j] = sx * -136.0f;                                                                          \
@@ -999,6 +1023,19 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             if (EPI == EPI_SWIGLU) {
                 const float other = dpp_mov<0xB1>(v);
                 if (m < M && nok && !(n & 1)) p.out[(size_t)m * p.out_stride + (n >> 1)] = silu_f(v) * other;
+            } else if (EPI == EPI_SWIGLU_XF) {
+                // activation k = n/2 of row m straight into the XF planes of the next GEMM (K' = N/2): lanes li = 0,2,..,14 hold
+                // k = k0..k0+7; a K-slot pair is (k, k+2), i.e. lanes li and li+4
+                const float a = silu_f(v) * dpp_mov<0xB1>(v);
+                const float b = __shfl(a, lane + 4, 64);
+                const int k = n >> 1;
+                if (m < M && nok && !(n & 1) && !(k & 2)) {
+                    uint32_t hi, lo; split_pair(a, b, hi, lo);
+                    const int K2 = N >> 1, qq = k >> 7, jj = (k >> 5) & 3, e = k & 31, half = e >> 4, gg = (e & 15) >> 2, t = e & 3;
+                    const size_t base = ((size_t)((qq * 4 + jj) * 64 + gg * 16 + m)) * 8 + 2 * half + 4 * (t & 1);
+                    uint16_t* xo = reinterpret_cast<uint16_t*>(p.out);
+                    *reinterpret_cast<uint32_t*>(xo + base) = hi; *reinterpret_cast<uint32_t*>(xo + (size_t)(K2 >> 7) * 256 * 8 + base) = lo;
+                }
             } else if (m < M && nok) {
                 if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + n];
                 if (EPI == EPI_GELU) v = gelu_f(v);
@@ -1139,11 +1176,21 @@ template <int NTW, int TILED>
 static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStream_t s) {
     dim3 grid((p.w.N + 16 * NTW - 1) / (16 * NTW));
     const size_t lds = (size_t)ks * NTW * 64 * 4 * sizeof(float);
+    if (p.xf) {      // fragment-ordered bf16 hi/lo input (batched decode step); tile-ordered weights only
+        if (!TILED) return hipErrorInvalidValue;
+        switch (epi) {
+        case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE, 1, 1><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+        case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID, 1, 1><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+        case EPI_SWIGLU_XF: q4_skinny_kernel<NTW, EPI_SWIGLU_XF, 1, 1><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (epi) {
-    case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE, TILED><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-    case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID, TILED><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-    case EPI_GELU: q4_skinny_kernel<NTW, EPI_GELU, TILED><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-    case EPI_SWIGLU: q4_skinny_kernel<NTW, EPI_SWIGLU, TILED><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE, TILED, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID, TILED, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_GELU: q4_skinny_kernel<NTW, EPI_GELU, TILED, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_SWIGLU: q4_skinny_kernel<NTW, EPI_SWIGLU, TILED, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1214,6 +1261,7 @@ static hipError_t gemm_launch_f(const GemmParams& p, int epi, hipStream_t s) {
 }
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
+    if (p.xf) return (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && p.w.qt) ? launch_q4_skinny(p, epi, s) : hipErrorInvalidValue;
     if (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && !env_int("VOX_NO_SKINNY")) return launch_q4_skinny(p, epi, s);
     if (p.w.fmt == WFMT_Q4_0 && p.w.qt && p.w.st && p.w.nb % 4 == 0 && (p.x_stride % 4) == 0) {
         // large M: 64 x 256 workgroup tiles (64 x 64 per wave) once they fill the chip -- 1.2-1.55x the 32 x 128 kernel
@@ -1265,7 +1313,8 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(const float* __restrict__
 }
 // few rows (batched decode: one row per sequence): one 256-thread workgroup per row, every load issued at once
 __global__ __launch_bounds__(256) void rms_norm_row_kernel(const float* __restrict__ x, int x_stride, int dim, const float* __restrict__ gamma,
-                                                           const float* __restrict__ mul, float eps, float* __restrict__ out, int out_stride) {
+                                                           const float* __restrict__ mul, float eps, float* __restrict__ out, int out_stride,
+                                                           uint16_t* __restrict__ xf) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x, n4 = dim >> 2;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
@@ -1290,14 +1339,21 @@ __global__ __launch_bounds__(256) void rms_norm_row_kernel(const float* __restri
             float4 t = v[i]; const float4 gm = g4[c];
             t.x = (t.x / rms) * gm.x; t.y = (t.y / rms) * gm.y; t.z = (t.z / rms) * gm.z; t.w = (t.w / rms) * gm.w;
             if (mul) { const float4 mm = m4[c]; t.x *= mm.x; t.y *= mm.y; t.z *= mm.z; t.w *= mm.w; }
-            o[c] = t;
+            if (xf) xf_store4(xf, dim, row, 4 * c, t); else o[c] = t;
         }
     }
+}
+// same, but the normalised rows (<= 16) go straight into the XF fragment planes of the following batched-decode GEMM
+hipError_t launch_rms_norm_xf(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul, float eps,
+                              uint16_t* xf, hipStream_t s) {
+    if (rows > 16 || dim > 10240 || dim % 128) return hipErrorInvalidValue;
+    rms_norm_row_kernel<<<dim3(rows), dim3(256), 0, s>>>(x, x_stride, dim, gamma, mul, eps, nullptr, 0, xf);
+    return hipGetLastError();
 }
 hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul, float eps,
                            float* out, int out_stride, hipStream_t s) {
     if (rows <= 64 && dim <= 10240 && dim >= 1024)
-        rms_norm_row_kernel<<<dim3(rows), dim3(256), 0, s>>>(x, x_stride, dim, gamma, mul, eps, out, out_stride);
+        rms_norm_row_kernel<<<dim3(rows), dim3(256), 0, s>>>(x, x_stride, dim, gamma, mul, eps, out, out_stride, nullptr);
     else
         rms_norm_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(x, x_stride, rows, dim, gamma, mul, eps, out, out_stride);
     return hipGetLastError();
@@ -1736,7 +1792,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
 #pragma unroll
         for (int gq = 1; gq < GROUPS; gq++) { const float4 u = osum[gq * COLS + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
         const float inv = 1.0f / sum;
-        *reinterpret_cast<float4*>(orow + h * HD + tid * 4) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+        const float4 r4 = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+        if (p.out_xf) xf_store4(p.out_xf, p.n_heads * HD, seq, h * HD + tid * 4, r4);       // batched decode: A-fragments of the wo GEMM
+        else *reinterpret_cast<float4*>(orow + h * HD + tid * 4) = r4;
     }
 }
 hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq) {
