@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("VOX_CPU_BASELINE_S", "1.0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=16, help="also report BASELINE configs[3] (B utterances through vox_transcribe_batch) at N=1; 0 = skip")
     ap.add_argument("--gemv-iters", type=int, default=260)
     args = ap.parse_args()
 
@@ -197,6 +198,23 @@ def main():
                            "decode_step_gemv_GBps": round(per_step_bytes / per_step_us / 1e3, 1),
                            "decode_step_algorithmic_bytes": int(per_step_bytes),
                            "decode_step_measured_ms": round(stage_ms["decode_ms"] / max(n_ids, 1), 4)}
+        if world == 1 and args.batch > 1:
+            # BASELINE configs[3]: B x 16 s utterances on one GPU -- stacked encoder (every GEMM once over all frames), stacked prefill,
+            # one batched decode step per position (weights streamed once per step for the whole batch).  An extra, not `value`.
+            clips = [pkg.synth.synth_audio(args.seconds, seed=4321 + i) for i in range(args.batch)]
+            ptrs = [ctx.upload(c) for c in clips]; lens = [c.size for c in clips]
+            model.transcribe_batch(None, t_embed, device_ptrs=ptrs, n_samples=lens)                       # warm-up
+            reps = 3; ctx.synchronize(); tb = time.perf_counter()
+            for _ in range(reps):
+                outs = model.transcribe_batch(None, t_embed, device_ptrs=ptrs, n_samples=lens)
+            ctx.synchronize(); bdt = (time.perf_counter() - tb) / reps
+            tmb = model.timings(); ntok = sum(len(o) for o in outs)
+            out["batch"] = {"workload": f"{args.batch} x {args.seconds:g} s clips, Q4_0 (BASELINE configs[3])", "batch": args.batch,
+                            "tok_per_s": round(ntok / bdt, 1), "ms_per_batch": round(bdt * 1e3, 2), "rtf": round(bdt / (args.seconds * args.batch), 5),
+                            "stage_ms": {k: round(tmb[k], 2) for k in ("preprocess_ms", "encode_ms", "decode_ms")},
+                            "decode_step_weight_GBps": round(per_step_bytes / 1e9 / (tmb["decode_ms"] / 1e3 / max(ntok // args.batch, 1)), 1)}
+            for pp in ptrs:
+                ctx.free(pp)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(pkg, path, args.cpu_baseline_seconds)

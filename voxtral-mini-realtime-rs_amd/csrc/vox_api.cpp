@@ -1241,6 +1241,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     }
     HIPCHK(hipMemcpyAsync(d_tok, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_pos, pos0.data(), (size_t)n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    bool tail_logits_ready = false;
     {
         float* px = b_px.as<float>();
         for (int i = 0; i < n; i++)
@@ -1250,7 +1251,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         // logits of every utterance's last prefix row -> first generated token + first step input (same tail as a decode step)
         HIPCHK(launch_rms_norm(px + (size_t)(PREFIX_LEN - 1) * D, PREFIX_LEN * D, n, D, m->dec_norm, nullptr, c.norm_eps, b_xn.as<float>(), D, s));
         { GemmParams g{}; g.w = m->tok.w; g.x = b_xn.as<float>(); g.x_stride = D; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
-        HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, b_h.as<float>(), s));
+        tail_logits_ready = true;
     }
     // (4) batched decode steps
     int steps = 0; for (int i = 0; i < n; i++) steps = std::max(steps, S[i] - PREFIX_LEN - 1);
@@ -1263,29 +1264,56 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         HIPCHK(b_xf1.alloc(xf_bytes(D))); HIPCHK(b_xf2.alloc(xf_bytes(QD))); HIPCHK(b_xf3.alloc(xf_bytes(F)));
         HIPCHK(hipMemsetAsync(b_xf1.p, 0, xf_bytes(D), s)); HIPCHK(hipMemsetAsync(b_xf2.p, 0, xf_bytes(QD), s)); HIPCHK(hipMemsetAsync(b_xf3.p, 0, xf_bytes(F), s));
     }
+    // XF step: 4 launches per layer.  RMSNorm never runs as a kernel: its producer (residual epilogue / token embedding) writes x*gamma as
+    // XF planes plus partial sums of squares, its consumer scales the accumulators by rstd (a per-row scalar commutes with the GEMM);
+    // RoPE + KV-cache write are the q|k|v GEMM's epilogue.
+    DevBuf b_ssq; const int parts_D = q4_skinny_resid_xf_parts(D);
+    if (use_xf) { HIPCHK(b_ssq.alloc((size_t)parts_D * 16 * 4)); HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4, s)); }
+    if (tail_logits_ready)      // first generated token of every utterance + the first step's input (and, XF step, its folded first RMSNorm)
+        HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, b_h.as<float>(), s,
+                                         use_xf ? b_xf1.as<uint16_t>() : nullptr, use_xf ? m->dec[0].attn_norm : nullptr, use_xf ? b_ssq.as<float>() : nullptr));
     auto step = [&]() -> int32_t {
         float* h = b_h.as<float>(); float* xn = b_xn.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>(); float* act = b_act.as<float>();
-        uint16_t* xf1 = b_xf1.as<uint16_t>(); uint16_t* xf2 = b_xf2.as<uint16_t>(); uint16_t* xf3 = b_xf3.as<uint16_t>();
+        if (use_xf) {
+            uint16_t* xf1 = b_xf1.as<uint16_t>(); uint16_t* xf2 = b_xf2.as<uint16_t>(); uint16_t* xf3 = b_xf3.as<uint16_t>(); float* ssq = b_ssq.as<float>();
+            for (int l = 0; l < c.dec_layers; l++) {
+                const DecLayer& L = m->dec[l]; float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;
+                { GemmParams g{}; g.w = L.wqkv.w; g.xf = (const uint4*)xf1; g.M = n; g.out = qkv; g.out_stride = W;
+                  g.ssq_part = ssq; g.n_part = l == 0 ? 1 : parts_D; g.norm_eps = c.norm_eps;
+                  g.pos = d_pos; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd;
+                  HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, s)); }
+                AttnParams ap{}; ap.q = qkv; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
+                ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
+                ap.out_xf = xf2;
+                HIPCHK(launch_attn_decode(ap, hd, max_seq, s, n));
+                { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D;
+                  g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, s)); }
+                { GemmParams g{}; g.w = L.w13.w; g.xf = (const uint4*)xf1; g.M = n; g.out = (float*)xf3; g.out_stride = F;
+                  g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU_XF, s)); }
+                { GemmParams g{}; g.w = L.w2.w; g.xf = (const uint4*)xf3; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D;
+                  g.xf_out = xf1; g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, s)); }
+            }
+            { GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)xf1; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V;
+              g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+            HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s,
+                                             xf1, m->dec[0].attn_norm, ssq));
+            return VOX_OK;
+        }
         for (int l = 0; l < c.dec_layers; l++) {
             const DecLayer& L = m->dec[l]; float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;
-            if (use_xf) HIPCHK(launch_rms_norm_xf(h, D, n, D, L.attn_norm, nullptr, c.norm_eps, xf1, s));
-            else HIPCHK(launch_rms_norm(h, D, n, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
-            { GemmParams g{}; g.w = L.wqkv.w; g.x = xn; g.x_stride = D; g.xf = use_xf ? (const uint4*)xf1 : nullptr; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+            HIPCHK(launch_rms_norm(h, D, n, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
+            { GemmParams g{}; g.w = L.wqkv.w; g.x = xn; g.x_stride = D; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
             HIPCHK(launch_rope_kv_batch(qkv, n, W, QD, KV, hd, d_pos, m->dec_cos, m->dec_sin, kl, vl, (long)seq_stride, max_seq * hd, s));
             AttnParams ap{}; ap.q = qkv; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
             ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
-            ap.out_xf = use_xf ? xf2 : nullptr;
             HIPCHK(launch_attn_decode(ap, hd, max_seq, s, n));
-            { GemmParams g{}; g.w = L.wo.w; g.x = att; g.x_stride = QD; g.xf = use_xf ? (const uint4*)xf2 : nullptr; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
-            if (use_xf) HIPCHK(launch_rms_norm_xf(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xf1, s));
-            else HIPCHK(launch_rms_norm(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));
-            { GemmParams g{}; g.w = L.w13.w; g.x = xn; g.x_stride = D; g.xf = use_xf ? (const uint4*)xf1 : nullptr; g.M = n; g.out = use_xf ? (float*)xf3 : act; g.out_stride = F;
-              HIPCHK(launch_q4_gemm(g, use_xf ? EPI_SWIGLU_XF : EPI_SWIGLU, s)); }
-            { GemmParams g{}; g.w = L.w2.w; g.x = act; g.x_stride = F; g.xf = use_xf ? (const uint4*)xf3 : nullptr; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+            { GemmParams g{}; g.w = L.wo.w; g.x = att; g.x_stride = QD; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
+            HIPCHK(launch_rms_norm(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));
+            { GemmParams g{}; g.w = L.w13.w; g.x = xn; g.x_stride = D; g.M = n; g.out = act; g.out_stride = F; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU, s)); }
+            { GemmParams g{}; g.w = L.w2.w; g.x = act; g.x_stride = F; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
         }
-        if (use_xf) HIPCHK(launch_rms_norm_xf(h, D, n, D, m->dec_norm, nullptr, c.norm_eps, xf1, s));
-        else HIPCHK(launch_rms_norm(h, D, n, D, m->dec_norm, nullptr, c.norm_eps, xn, D, s));
-        { GemmParams g{}; g.w = m->tok.w; g.x = xn; g.x_stride = D; g.xf = use_xf ? (const uint4*)xf1 : nullptr; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+        HIPCHK(launch_rms_norm(h, D, n, D, m->dec_norm, nullptr, c.norm_eps, xn, D, s));
+        { GemmParams g{}; g.w = m->tok.w; g.x = xn; g.x_stride = D; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
         HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s));
         return VOX_OK;
     };

@@ -21,7 +21,9 @@ struct Q4W {
 };
 enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1 };
 
-enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6 };   // _XF: SwiGLU written as XF planes (M <= 16)
+enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6, EPI_RESID_XF = 7 };
+// (M <= 16 only) _SWIGLU_XF: SwiGLU written as XF planes; _RESID_XF: out = acc + resid as f32 AND as XF planes of out * xf_w (* xf_w2) plus
+// per-workgroup partial sums of squares -- the next RMSNorm is folded into its producer and its consumer (GemmParams::ssq_part)
 enum Pro { PRO_NONE = 0, PRO_RMS = 1, PRO_RMS_MUL = 2 };   // RMS_MUL: RMSNorm then * mul (the cached Ada scale)
 
 // ---- fused Q4 GEMV (decode, rows of x <= 4): out[y][n] = epi( sum_k pro(x[y])[k] * W[n][k] )
@@ -53,9 +55,18 @@ struct GemmParams {
     const float* bias;
     const float* resid; int resid_stride;
     const uint4* xf;      // optional (M <= 16): the input as XF fragment planes (see xf_store4) instead of f32 rows x
+    // fused RMSNorm, consumer side: the XF input holds x * gamma UNnormalised; row m's accumulators are scaled by
+    // rstd[m] = 1/sqrt(sum_i ssq_part[i][m] / K + norm_eps) (a per-row scalar commutes with the GEMM); n_part partials of 16 rows
+    const float* ssq_part; int n_part; float norm_eps;
+    // EPI_RESID_XF, producer side
+    uint16_t* xf_out; const float* xf_w; const float* xf_w2; float* ssq_out;
+    // EPI_ROPE_KV (M <= 16, one row per sequence): columns [0, n_q) -> RoPE -> out; [n_q, n_q + n_kv*hd) -> RoPE -> K cache; rest -> V cache,
+    // all at position pos[m] of sequence m's cache slice
+    const int* pos; const float* rope_cos; const float* rope_sin; int hd, n_q, n_kv; float* kc; float* vc; long kv_seq_stride; int kv_head_stride;
 };
 hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);
+int q4_skinny_resid_xf_parts(int N);   // number of [16]-row partial sums of squares an EPI_RESID_XF launch writes to ssq_out
 
 // ---- small fused ops
 hipError_t launch_q4_repack(const uint8_t* raw, uint4* qs, uint16_t* sc, int64_t n_blocks, int nb, int row_mul, int row_add, hipStream_t s);
@@ -113,7 +124,8 @@ hipError_t launch_argmax_embed(const float* part_val, const int* part_idx, int n
 hipError_t launch_rope_kv_batch(float* qkv, int n, int stride, int n_q, int n_kv, int hd, const int* pos, const float* cos_t, const float* sin_t,
                                 float* kcache, float* vcache, long seq_stride, int head_stride, hipStream_t s);
 hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int* tokens, int tok_stride, int* pos, const int* seq_len, Q4W tok,
-                                     const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s);
+                                     const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s,
+                                     uint16_t* xf = nullptr, const float* xf_w = nullptr, float* ssq_out = nullptr);   // xf: also h * xf_w as XF planes + sum of squares
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
 hipError_t launch_gelu(float* x, long n, hipStream_t s);
 

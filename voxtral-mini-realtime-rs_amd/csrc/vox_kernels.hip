@@ -900,9 +900,10 @@ hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int NTW, int EPI, int TILED, int XIN>
+template <int NTW, int EPI, int TILED, int XIN, int PRO>
 __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS][NTW][64][4]
+    __shared__ float s_rstd[16]; __shared__ float s_pp[32 * 16];
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, KS = blockDim.x >> 6;
     const int g = lane >> 4, li = lane & 15;
@@ -978,6 +979,17 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             }                                                                                              \
         }                                                                                                  \
     }
+    // fused RMSNorm: the producers' partial sums of squares are fetched now (all loads in flight during the K loop) and reduced
+    // in a fixed order just before the epilogue.  thread -> (row = tid & 15, chunk = tid >> 4); up to 12 partials per thread.
+    float pv[12]; const int prow = tid & 15, pch = tid >> 4, nch = blockDim.x >> 4;
+    if (PRO) {
+#pragma unroll
+        for (int u = 0; u < 12; u++) {
+            const int pi = pch + u * nch;
+            const float v = p.ssq_part[(size_t)min(pi, p.n_part - 1) * 16 + prow];
+            pv[u] = pi < p.n_part ? v : 0.f;
+        }
+    }
     // wave's K steps: [q, qend) step qs -- a contiguous range when tiled (pure streaming), interleaved otherwise
     const int per = (nq + KS - 1) / KS;
     int q = TILED ? wave * per : wave;
@@ -1006,16 +1018,24 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
 #pragma unroll
     for (int t = 0; t < NTW; t++)
         *reinterpret_cast<float4*>(sred + ((size_t)(wave * NTW + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    if (PRO) s_pp[pch * 16 + prow] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7])) + ((pv[8] + pv[9]) + (pv[10] + pv[11]));
     __syncthreads();
+    if (PRO) {
+        if (tid < 16) { float a = 0.f; for (int cch = 0; cch < nch; cch++) a += s_pp[cch * 16 + tid]; s_rstd[tid] = 1.0f / sqrtf(a / (float)p.w.K + p.norm_eps); }
+        __syncthreads();
+    }
     for (int t = wave; t < NTW; t += KS) {      // (KS may be smaller than NTW for short K: a wave then finishes several tiles)
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int w = 0; w < KS; w++) {
             const float4 v = *reinterpret_cast<const float4*>(sred + ((size_t)(w * NTW + t) * 64 + lane) * 4);
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
+        if (PRO) { const float4 rs = *reinterpret_cast<const float4*>(s_rstd + 4 * g); sum.x *= rs.x; sum.y *= rs.y; sum.z *= rs.z; sum.w *= rs.w; }
         const int n = nbase + t * 16 + li; const bool nok = n < N;
         const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
         const float vals[4] = {sum.x + bias, sum.y + bias, sum.z + bias, sum.w + bias};
+        float xw = 0.f;
+        if (EPI == EPI_RESID_XF && nok) { xw = p.xf_w[n]; if (p.xf_w2) xw *= p.xf_w2[n]; }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int m = 4 * g + r;
@@ -1031,10 +1051,40 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
                 const int k = n >> 1;
                 if (m < M && nok && !(n & 1) && !(k & 2)) {
                     uint32_t hi, lo; split_pair(a, b, hi, lo);
-                    const int K2 = N >> 1, qq = k >> 7, jj = (k >> 5) & 3, e = k & 31, half = e >> 4, gg = (e & 15) >> 2, t = e & 3;
-                    const size_t base = ((size_t)((qq * 4 + jj) * 64 + gg * 16 + m)) * 8 + 2 * half + 4 * (t & 1);
+                    const int K2 = N >> 1, qq = k >> 7, jj = (k >> 5) & 3, e = k & 31, half = e >> 4, gg = (e & 15) >> 2, tt = e & 3;
+                    const size_t base = ((size_t)((qq * 4 + jj) * 64 + gg * 16 + m)) * 8 + 2 * half + 4 * (tt & 1);
                     uint16_t* xo = reinterpret_cast<uint16_t*>(p.out);
                     *reinterpret_cast<uint32_t*>(xo + base) = hi; *reinterpret_cast<uint32_t*>(xo + (size_t)(K2 >> 7) * 256 * 8 + base) = lo;
+                }
+            } else if (EPI == EPI_RESID_XF) {
+                // residual stream as f32 + the next RMSNorm folded in: XF planes of v * gamma (K-slot pair (k, k+2) = lanes li, li+2)
+                // and this workgroup's partial sum of squares per row
+                const bool ok = m < M && nok;
+                if (ok) { v = v + p.resid[(size_t)m * p.resid_stride + n]; p.out[(size_t)m * p.out_stride + n] = v; } else v = 0.f;
+                const float ss = row16_sum(v * v);
+                if (li == 0) p.ssq_out[(size_t)blockIdx.x * 16 + m] = ss;
+                const float a = v * xw, b = dpp_mov<0x4E>(a);
+                if (ok && !(li & 2)) {
+                    uint32_t hi, lo; split_pair(a, b, hi, lo);
+                    const int qq = n >> 7, jj = (n >> 5) & 3, e = n & 31, half = e >> 4, gg = (e & 15) >> 2, tt = e & 3;
+                    const size_t base = ((size_t)((qq * 4 + jj) * 64 + gg * 16 + m)) * 8 + 2 * half + 4 * (tt & 1);
+                    *reinterpret_cast<uint32_t*>(p.xf_out + base) = hi; *reinterpret_cast<uint32_t*>(p.xf_out + (size_t)(N >> 7) * 256 * 8 + base) = lo;
+                }
+            } else if (EPI == EPI_ROPE_KV) {
+                const float other = dpp_mov<0xB1>(v);          // the pair partner (interleaved RoPE pairs, rope.rs:77-141)
+                if (m < M && nok) {
+                    const int ps = p.pos[m], kd = p.n_kv * p.hd;
+                    if (n < p.n_q + kd) {
+                        const int dd = n % p.hd;
+                        const size_t ti = (size_t)ps * (p.hd >> 1) + (dd >> 1);
+                        const float c = p.rope_cos[ti], sn = p.rope_sin[ti];
+                        const float o = (n & 1) ? other * sn + v * c : v * c - other * sn;
+                        if (n < p.n_q) p.out[(size_t)m * p.out_stride + n] = o;
+                        else p.kc[(size_t)m * p.kv_seq_stride + (size_t)((n - p.n_q) / p.hd) * p.kv_head_stride + (size_t)ps * p.hd + dd] = o;
+                    } else {
+                        const int vn = n - p.n_q - kd;
+                        p.vc[(size_t)m * p.kv_seq_stride + (size_t)(vn / p.hd) * p.kv_head_stride + (size_t)ps * p.hd + (vn % p.hd)] = v;
+                    }
                 }
             } else if (m < M && nok) {
                 if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + n];
@@ -1178,23 +1228,38 @@ static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStrea
     const size_t lds = (size_t)ks * NTW * 64 * 4 * sizeof(float);
     if (p.xf) {      // fragment-ordered bf16 hi/lo input (batched decode step); tile-ordered weights only
         if (!TILED) return hipErrorInvalidValue;
-        switch (epi) {
-        case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE, 1, 1><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-        case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID, 1, 1><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-        case EPI_SWIGLU_XF: q4_skinny_kernel<NTW, EPI_SWIGLU_XF, 1, 1><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-        default: return hipErrorInvalidValue;
+        const bool pro = p.ssq_part != nullptr;
+        if (pro && (p.n_part < 1 || p.n_part > 12 * (64 * ks / 16))) return hipErrorInvalidValue;     // partials per thread (q4_skinny_kernel PRO)
+        if (epi == EPI_RESID_XF) {
+            if (NTW != 1 || pro || !p.xf_out || !p.xf_w || !p.ssq_out) return hipErrorInvalidValue;
+            q4_skinny_kernel<1, EPI_RESID_XF, 1, 1, 0><<<grid, dim3(64 * ks), lds, s>>>(p);
+        } else if (pro) {
+            switch (epi) {
+            case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE, 1, 1, 1><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+            case EPI_ROPE_KV: q4_skinny_kernel<NTW, EPI_ROPE_KV, 1, 1, 1><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+            case EPI_SWIGLU_XF: q4_skinny_kernel<NTW, EPI_SWIGLU_XF, 1, 1, 1><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+            default: return hipErrorInvalidValue;
+            }
+        } else {
+            switch (epi) {
+            case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE, 1, 1, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+            case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID, 1, 1, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+            case EPI_SWIGLU_XF: q4_skinny_kernel<NTW, EPI_SWIGLU_XF, 1, 1, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+            default: return hipErrorInvalidValue;
+            }
         }
         return hipGetLastError();
     }
     switch (epi) {
-    case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE, TILED, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-    case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID, TILED, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-    case EPI_GELU: q4_skinny_kernel<NTW, EPI_GELU, TILED, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
-    case EPI_SWIGLU: q4_skinny_kernel<NTW, EPI_SWIGLU, TILED, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_STORE: q4_skinny_kernel<NTW, EPI_STORE, TILED, 0, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_RESID: q4_skinny_kernel<NTW, EPI_RESID, TILED, 0, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_GELU: q4_skinny_kernel<NTW, EPI_GELU, TILED, 0, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
+    case EPI_SWIGLU: q4_skinny_kernel<NTW, EPI_SWIGLU, TILED, 0, 0><<<grid, dim3(64 * ks), lds, s>>>(p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
+int q4_skinny_resid_xf_parts(int N) { return (N + 15) / 16; }     // partial sums of squares written by an EPI_RESID_XF launch
 static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) {
     const int nq = p.w.nb / 4, tiles = (p.w.N + 15) / 16;
     // n-tiles per wave: as many as still leave >= 192 workgroups (N = 3072 has only 192 tiles); split-K over 4 waves, 8 when
@@ -1203,6 +1268,7 @@ static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) 
     int ks = nq >= 4 ? 4 : (nq >= 2 ? 2 : 1);
     if (tiles / ntw < 256 && nq >= 16) ks = 8;                        // profiles/r01_skinny_sweep.txt
     { const int e = env_int("VOX_SKINNY_NTW"); if (e == 1 || e == 2 || e == 4) ntw = e; }
+    if (epi == EPI_RESID_XF) ntw = 1;       // its partial sums of squares are per workgroup = per 16-column tile
     { const int e = env_int("VOX_SKINNY_KS"); if (e == 1 || e == 2 || e == 4 || e == 8) ks = e; }
     const bool tiled = p.w.qt && p.w.st && !env_int("VOX_SKINNY_NO_TILE");
     if (ntw == 4) return tiled ? skinny_launch_n<4, 1>(p, epi, ks, s) : skinny_launch_n<4, 0>(p, epi, ks, s);
@@ -2108,7 +2174,8 @@ hipError_t launch_rope_kv_batch(float* qkv, int n, int stride, int n_q, int n_kv
 // sequence's last position), then the next step's input h[s] = audio[s][pos] + embed(tokens[s][pos]).
 __global__ __launch_bounds__(1024) void argmax_embed_batch_kernel(const float* __restrict__ logits, int vocab, int* __restrict__ tokens,
                                                                  int tok_stride, int* __restrict__ pos, const int* __restrict__ seq_len, Q4W tok,
-                                                                 const float* __restrict__ audio, long audio_seq_stride, int D, float* __restrict__ h) {
+                                                                 const float* __restrict__ audio, long audio_seq_stride, int D, float* __restrict__ h,
+                                                                 uint16_t* __restrict__ xf, const float* __restrict__ xf_w, float* __restrict__ ssq_out) {
     __shared__ float bv[1024];
     __shared__ int bi[1024];
     __shared__ int s_tok, s_cur;
@@ -2138,10 +2205,26 @@ __global__ __launch_bounds__(1024) void argmax_embed_batch_kernel(const float* _
     }
     __syncthreads();
     embed_row(tok, s_tok, audio + (size_t)sq * audio_seq_stride + (size_t)s_cur * D, h + (size_t)sq * D, D);
+    if (xf) {     // the first layer's RMSNorm folded in: XF planes of h * gamma and the row's sum of squares (one partial)
+        __syncthreads();
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < (D >> 2); c += nt) {
+            float4 v = reinterpret_cast<const float4*>(h + (size_t)sq * D)[c]; const float4 gm = reinterpret_cast<const float4*>(xf_w)[c];
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
+            xf_store4(xf, D, sq, 4 * c, v);
+        }
+        ss = wave_sum(ss);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) bv[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) { float a = 0.f; for (int w = 0; w < (nt >> 6); w++) a += bv[w]; ssq_out[sq] = a; }
+    }
 }
 hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int* tokens, int tok_stride, int* pos, const int* seq_len, Q4W tok,
-                                     const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s) {
-    argmax_embed_batch_kernel<<<dim3(n), dim3(1024), 0, s>>>(logits, vocab, tokens, tok_stride, pos, seq_len, tok, audio, audio_seq_stride, D, h);
+                                     const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s,
+                                     uint16_t* xf, const float* xf_w, float* ssq_out) {
+    argmax_embed_batch_kernel<<<dim3(n), dim3(1024), 0, s>>>(logits, vocab, tokens, tok_stride, pos, seq_len, tok, audio, audio_seq_stride, D, h, xf, xf_w, ssq_out);
     return hipGetLastError();
 }
 
