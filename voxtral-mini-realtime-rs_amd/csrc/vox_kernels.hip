@@ -647,7 +647,7 @@ __device__ __forceinline__ void xf_store4(uint16_t* __restrict__ xf, int K, int 
 // D[m][n]: lane holds n = lane&15, m = 4*(lane>>4) + reg.  The K order inside one MFMA follows the Q4 chunk:
 // lane group g = lane>>4 contributes elements {4g..4g+3, 16+4g..16+4g+3} of the block.
 template <int EPI, int FMT>
-__global__ __launch_bounds__(256) void q4_gemm_k32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q4_gemm_k32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) uint4 lds[2][2][256];   // [buffer][hi/lo][mt*64 + lane]
     const int K = p.w.K, nb = p.w.nb, N = p.w.N, M = p.M;
     (void)K;
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void q4_gemm_k32_kernel(const GemmParams p) {
 // fallback for K % 128 != 0).  Same operand conventions: A = activations (hi+lo bf16 through LDS in fragment order),
 // B = integer Q4 weights straight from global (one dword per lane per block) or dense bf16 (16 B per lane per step).
 template <int MT, int NT, int EPI, int FMT>
-__global__ __launch_bounds__(256) void q4_gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q4_gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint4 glds[];      // [buf 2][hi/lo 2][j 4][MT][64]
     constexpr int PLANE = 4 * MT * 64, BUF = 2 * PLANE;
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
 //  * per (m-tile, n-tile, block): 2 MFMAs + 2 packed FMAs for the f16 block scale.
 // ------------------------------------------------------------------------------------------------
 template <int WGM, int WGN, int EPI>
-__global__ __launch_bounds__(256) void q4_gemm_big_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q4_gemm_big_kernel(const GemmParams p) {
     constexpr int BM = 64 * WGM, MTB = BM / 16;                     // rows / m-tiles per workgroup
     constexpr int PAIRS = 4 * MTB, NU = PAIRS / 4;                  // (block j, m-tile i) fragments groups; per-wave share
     extern __shared__ __attribute__((aligned(16))) uint4 blds[];    // [hi/lo][j 4][MTB][64]
@@ -1581,7 +1581,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnParams p) {
 // the online softmax are per-lane scalars; only the tile max needs a cross-lane step (xor 16, 32).
 // ------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_prefill_mfma_kernel(const AttnParams p) {
     constexpr int KS = HD / 32, DT = HD / 16, KROW = HD + 8, VROW = 72;
     extern __shared__ __attribute__((aligned(16))) uint16_t smh[];
     uint16_t* Kh = smh;                  // [64 keys][KROW]   bf16 hi
