@@ -628,6 +628,15 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
     union { uint4 u; bf16x8 b; } c; c.u = v; return c.b;
 }
 
+// one dword of a Q4 chunk (8 nibbles) -> 8 bf16 operands 128+q (bits 0x4300|q) in the K-slot order
+// {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3}: 2 v_and + 1 shift + 4 v_perm_b32 (no inline asm: an asm VALU
+// result feeding an MFMA is invisible to the hazard recognizer)
+__device__ __forceinline__ uint4 q4_dword_to_bf16x8_biased(uint32_t w) {
+    const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu, c = 0x43434343u;
+    return make_uint4(__builtin_amdgcn_perm(lo, c, 0x00060004u), __builtin_amdgcn_perm(hi, c, 0x00060004u),
+                      __builtin_amdgcn_perm(lo, c, 0x00070005u), __builtin_amdgcn_perm(hi, c, 0x00070005u));
+}
+
 // ---- XF: activations of a <= 16-row batch stored ONCE as MFMA A-fragments (bf16 hi + lo planes), so the batched-decode
 // GEMMs load their operands with plain coalesced dwordx4 and spend no VALU on conversion (the conversion used to be redone
 // by every wave of every workgroup).  Plane layout: uint4 [K/128 (q)][4 (j)][64 lanes]; lane = 16*g + row holds block
@@ -939,12 +948,12 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             xb[j] = *reinterpret_cast<const float4*>(xrow + 128 * (Q_) + 32 * j + 16 + 4 * g); } }
 // B fragments by bit tricks: bf16 bits 0x4300 | q are exactly 128 + q, so one dword of 8 nibbles becomes 8 bf16 operands
 // in 7 VALU ops (v_and_or_b32 on nibble pairs 16 bits apart).  sum_k x_k (q_k - 8) = sum_k x_k (128 + q_k) - 136 sum_k x_k, and
-// sum_k x_k per (row, block) comes from one extra MFMA pair against an all-ones B, shared by the wave's NTW tiles and already
-// in the accumulator layout.  K-slot order of a lane group g: {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3}.
+// -136 sum_k x_k per (row, block) comes from one extra MFMA pair against a B of bf16(-136), shared by the wave's NTW tiles and
+// already in the accumulator layout.  K-slot order of a lane group g: {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3}.
 #define VOX_SSTEP(WV_, SV_, XA_, XB_)                                                                      \
     {                                                                                                      \
         uint4 ah[4], al[4]; f32x4 cs[4];                                                                   \
-        const bf16x8 ones = as_bf16x8(make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));     \
+        const bf16x8 m136 = as_bf16x8(make_uint4(0xC308C308u, 0xC308C308u, 0xC308C308u, 0xC308C308u));     \
         _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                    \
             if (XIN) {                                                                                     \
                 ah[j] = make_uint4(__float_as_uint(XA_[j].x), __float_as_uint(XA_[j].y), __float_as_uint(XA_[j].z), __float_as_uint(XA_[j].w)); \
@@ -953,9 +962,8 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
                 split_pair(XA_[j].x, XA_[j].z, ah[j].x, al[j].x); split_pair(XB_[j].x, XB_[j].z, ah[j].y, al[j].y); \
                 split_pair(XA_[j].y, XA_[j].w, ah[j].z, al[j].z); split_pair(XB_[j].y, XB_[j].w, ah[j].w, al[j].w); \
             }                                                                                              \
-            f32x4 sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), ones, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
-            sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[j]), ones, sx, 0, 0, 0);             \
-            cs[j] = sx * -136.0f;                                                                          \
+            f32x4 sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+            cs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[j]), m136, sx, 0, 0, 0);          \
         }                                                                                                  \
         _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                  \
             uint32_t dw[4] = {WV_[t].x, WV_[t].y, WV_[t].z, WV_[t].w};                                     \
@@ -969,13 +977,11 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             const uint32_t sc2[2] = {SV_[t].x, SV_[t].y};                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                \
                 const uint32_t w_ = dw[j];                                                                 \
-                const bf16x8 bw = as_bf16x8(make_uint4((w_ & 0x000F000Fu) | 0x43004300u, ((w_ >> 4) & 0x000F000Fu) | 0x43004300u, \
-                                                       ((w_ >> 8) & 0x000F000Fu) | 0x43004300u, ((w_ >> 12) & 0x000F000Fu) | 0x43004300u)); \
+                const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8_biased(w_));                                \
                 const float d = f16_bits_to_f32((uint16_t)((j & 1) ? (sc2[j >> 1] >> 16) : (sc2[j >> 1] & 0xFFFFu))); \
                 f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), bw, cs[j], 0, 0, 0);   \
                 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[j]), bw, tt, 0, 0, 0);            \
-                acc[t][0] = fmaf(d, tt[0], acc[t][0]); acc[t][1] = fmaf(d, tt[1], acc[t][1]);              \
-                acc[t][2] = fmaf(d, tt[2], acc[t][2]); acc[t][3] = fmaf(d, tt[3], acc[t][3]);              \
+                acc[t] = __builtin_elementwise_fma((f32x4){d, d, d, d}, tt, acc[t]);                        \
             }                                                                                              \
         }                                                                                                  \
     }
@@ -1145,7 +1151,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
         W_[t] = wq[t][(size_t)64 * (Q_)]; S_[t] = *reinterpret_cast<const uint2*>(ws[t] + 64 * (Q_)); }
     VOX_ALOAD(0)
     VOX_BLOAD(bw, bs, 0)
-    const bf16x8 ones = as_bf16x8(make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    // B operand of the correction MFMA: bf16(-136) in every slot (0xC308, exact), so  sum_k x~_k * (-136)  comes out of the matrix core directly
+    const bf16x8 m136 = as_bf16x8(make_uint4(0xC308C308u, 0xC308C308u, 0xC308C308u, 0xC308C308u));
     for (int q = 0; q < nq; q++) {
         __syncthreads();                                          // every wave is done reading the previous K step
 #pragma unroll
@@ -1164,8 +1171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const uint32_t w_ = j == 0 ? bw[t].x : j == 1 ? bw[t].y : j == 2 ? bw[t].z : bw[t].w;
-                bf[t] = as_bf16x8(make_uint4((w_ & 0x000F000Fu) | 0x43004300u, ((w_ >> 4) & 0x000F000Fu) | 0x43004300u,
-                                             ((w_ >> 8) & 0x000F000Fu) | 0x43004300u, ((w_ >> 12) & 0x000F000Fu) | 0x43004300u));
+                bf[t] = as_bf16x8(q4_dword_to_bf16x8_biased(w_));
                 const uint32_t pr = (j & 2) ? bs[t].y : bs[t].x;
                 d[t] = f16_bits_to_f32((uint16_t)((j & 1) ? (pr >> 16) : (pr & 0xFFFFu)));
             }
@@ -1173,9 +1179,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
             for (int i = 0; i < 4; i++) {
                 const bf16x8 ah = as_bf16x8(blds[(j * MTB + wm * 4 + i) * 64 + lane]);
                 const bf16x8 al = as_bf16x8(blds[PLANE + (j * MTB + wm * 4 + i) * 64 + lane]);
-                f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, cs, 0, 0, 0);
-                cs = cs * -136.0f;
+                f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, m136, cs, 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bf[t], cs, 0, 0, 0);
