@@ -63,6 +63,10 @@ struct vox_ctx {
     int *d_fb_lo = nullptr, *d_fb_hi = nullptr;
     float* d_scale = nullptr;   // peak-normalise scale scratch
     bool mel_ready = false;
+    // grow-only pool of per-call device workspaces (batched transcription): hipMalloc/hipFree of a few hundred MB per call cost
+    // tens of ms and serialise the device; buffers are handed back after the call's final stream synchronisation
+    struct PoolEntry { void* p; size_t cap; bool used; };
+    std::vector<PoolEntry> pool;
 };
 
 static int32_t ctx_bind(const vox_ctx* c) { HIPCHK(hipSetDevice(c->device)); return VOX_OK; }
@@ -84,6 +88,7 @@ extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (void* p : {(void*)c->d_window, (void*)c->d_cos, (void*)c->d_sin, (void*)c->d_fb, (void*)c->d_fb_lo, (void*)c->d_fb_hi, (void*)c->d_scale})
         if (p) (void)hipFree(p);
+    for (auto& e : c->pool) (void)hipFree(e.p);
     (void)hipStreamDestroy(c->stream);
     delete c; return VOX_OK;
 }
@@ -107,9 +112,30 @@ extern "C" int32_t vox_dev_copy(vox_ctx* c, void* dst, const void* src, size_t n
 
 // small RAII device buffer for host-pointer entry points
 struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    void* p = nullptr; vox_ctx* pool_ctx = nullptr;
+    ~DevBuf() {
+        if (!p) return;
+        if (pool_ctx) { for (auto& e : pool_ctx->pool) if (e.p == p) { e.used = false; return; } }
+        (void)hipFree(p);
+    }
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    // from the context's workspace pool (best fit, at most 2x oversize); the caller must have synchronised the stream before the
+    // buffer goes out of scope
+    hipError_t alloc_pooled(vox_ctx* c, size_t n) {
+        n = n ? n : 1;
+        int best = -1;
+        for (size_t i = 0; i < c->pool.size(); i++) {
+            const auto& e = c->pool[i];
+            if (!e.used && e.cap >= n && e.cap <= 2 * n + (1u << 20) && (best < 0 || e.cap < c->pool[best].cap)) best = (int)i;
+        }
+        if (best >= 0) { c->pool[best].used = true; p = c->pool[best].p; pool_ctx = c; return hipSuccess; }
+        if (c->pool.size() >= 96) {          // bound the pool: drop idle entries
+            for (size_t i = 0; i < c->pool.size();) { if (!c->pool[i].used) { (void)hipFree(c->pool[i].p); c->pool.erase(c->pool.begin() + i); } else i++; }
+        }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) { c->pool.push_back({p, n, true}); pool_ctx = c; }
+        return e;
+    }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
@@ -1197,11 +1223,11 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     const size_t seq_stride = (size_t)KV * max_seq * hd, layer_stride = (size_t)n * seq_stride;
     size_t mel_floats = 0; for (int i = 0; i < n; i++) mel_floats += (size_t)128 * T[i];
     DevBuf b_audio, b_k, b_v, b_tok, b_pos, b_len, b_h, b_xn, b_qkv, b_att, b_act, b_logits, b_px, b_mel, b_scale, b_smp;
-    HIPCHK(b_audio.alloc((size_t)n * audio_rows * D * 4)); HIPCHK(b_k.alloc(layer_stride * c.dec_layers * 4)); HIPCHK(b_v.alloc(layer_stride * c.dec_layers * 4));
-    HIPCHK(b_tok.alloc((size_t)n * tstride * 4)); HIPCHK(b_pos.alloc((size_t)n * 4)); HIPCHK(b_len.alloc((size_t)n * 4));
-    HIPCHK(b_h.alloc((size_t)n * D * 4)); HIPCHK(b_xn.alloc((size_t)n * D * 4)); HIPCHK(b_qkv.alloc((size_t)n * W * 4)); HIPCHK(b_att.alloc((size_t)n * QD * 4));
-    HIPCHK(b_act.alloc((size_t)n * F * 4)); HIPCHK(b_logits.alloc((size_t)n * V * 4)); HIPCHK(b_px.alloc((size_t)n * PREFIX_LEN * D * 4));
-    HIPCHK(b_mel.alloc(std::max<size_t>(mel_floats, 1) * 4)); HIPCHK(b_scale.alloc((size_t)n * 4));
+    HIPCHK(b_audio.alloc_pooled(cx, (size_t)n * audio_rows * D * 4)); HIPCHK(b_k.alloc_pooled(cx, layer_stride * c.dec_layers * 4)); HIPCHK(b_v.alloc_pooled(cx, layer_stride * c.dec_layers * 4));
+    HIPCHK(b_tok.alloc_pooled(cx, (size_t)n * tstride * 4)); HIPCHK(b_pos.alloc_pooled(cx, (size_t)n * 4)); HIPCHK(b_len.alloc_pooled(cx, (size_t)n * 4));
+    HIPCHK(b_h.alloc_pooled(cx, (size_t)n * D * 4)); HIPCHK(b_xn.alloc_pooled(cx, (size_t)n * D * 4)); HIPCHK(b_qkv.alloc_pooled(cx, (size_t)n * W * 4)); HIPCHK(b_att.alloc_pooled(cx, (size_t)n * QD * 4));
+    HIPCHK(b_act.alloc_pooled(cx, (size_t)n * F * 4)); HIPCHK(b_logits.alloc_pooled(cx, (size_t)n * V * 4)); HIPCHK(b_px.alloc_pooled(cx, (size_t)n * PREFIX_LEN * D * 4));
+    HIPCHK(b_mel.alloc_pooled(cx, std::max<size_t>(mel_floats, 1) * 4)); HIPCHK(b_scale.alloc_pooled(cx, (size_t)n * 4));
     HIPCHK(hipMemsetAsync(b_tok.p, 0, (size_t)n * tstride * 4, s)); HIPCHK(hipMemsetAsync(b_h.p, 0, (size_t)n * D * 4, s));
     HIPCHK(hipMemsetAsync(b_audio.p, 0, (size_t)n * audio_rows * D * 4, s));
     float* d_audio = b_audio.as<float>(); int* d_tok = b_tok.as<int>(); int* d_pos = b_pos.as<int>();
@@ -1209,7 +1235,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     // (1) front-end per utterance, no host synchronisation in between: peak-normalise -> (virtual) pad -> log-mel
     std::vector<const float*> d_mels(n);
     {
-        size_t smp_total = 0; if (mem_kind == VOX_MEM_HOST) { for (int i = 0; i < n; i++) smp_total += n_samples[i]; HIPCHK(b_smp.alloc(smp_total * 4)); }
+        size_t smp_total = 0; if (mem_kind == VOX_MEM_HOST) { for (int i = 0; i < n; i++) smp_total += n_samples[i]; HIPCHK(b_smp.alloc_pooled(cx, smp_total * 4)); }
         size_t mo = 0, so = 0;
         for (int i = 0; i < n; i++) {
             const float* d_s = samples[i];
@@ -1261,14 +1287,14 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
     DevBuf b_xf1, b_xf2, b_xf3;
     if (use_xf) {
-        HIPCHK(b_xf1.alloc(xf_bytes(D))); HIPCHK(b_xf2.alloc(xf_bytes(QD))); HIPCHK(b_xf3.alloc(xf_bytes(F)));
+        HIPCHK(b_xf1.alloc_pooled(cx, xf_bytes(D))); HIPCHK(b_xf2.alloc_pooled(cx, xf_bytes(QD))); HIPCHK(b_xf3.alloc_pooled(cx, xf_bytes(F)));
         HIPCHK(hipMemsetAsync(b_xf1.p, 0, xf_bytes(D), s)); HIPCHK(hipMemsetAsync(b_xf2.p, 0, xf_bytes(QD), s)); HIPCHK(hipMemsetAsync(b_xf3.p, 0, xf_bytes(F), s));
     }
     // XF step: 4 launches per layer.  RMSNorm never runs as a kernel: its producer (residual epilogue / token embedding) writes x*gamma as
     // XF planes plus partial sums of squares, its consumer scales the accumulators by rstd (a per-row scalar commutes with the GEMM);
     // RoPE + KV-cache write are the q|k|v GEMM's epilogue.
     DevBuf b_ssq; const int parts_D = q4_skinny_resid_xf_parts(D);
-    if (use_xf) { HIPCHK(b_ssq.alloc((size_t)parts_D * 16 * 4)); HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4, s)); }
+    if (use_xf) { HIPCHK(b_ssq.alloc_pooled(cx, (size_t)parts_D * 16 * 4)); HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4, s)); }
     if (tail_logits_ready)      // first generated token of every utterance + the first step's input (and, XF step, its folded first RMSNorm)
         HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, b_h.as<float>(), s,
                                          use_xf ? b_xf1.as<uint16_t>() : nullptr, use_xf ? m->dec[0].attn_norm : nullptr, use_xf ? b_ssq.as<float>() : nullptr));
