@@ -1450,7 +1450,8 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
     if (kernel_name) {
         const int epi = which == 0 ? EPI_ROPE_KV : which == 2 ? EPI_SWIGLU : which == 4 ? EPI_ARGMAX : EPI_RESID;
         const int pro = which == 2 ? PRO_RMS_MUL : (which == 0 || which == 4) ? PRO_RMS : PRO_NONE;
-        *kernel_name = q4_gemv_kernel_name(w->K, pro, epi, which == 4 ? m->argmax_R : q4_gemv_default_R(w->N, w->K, epi));
+        if (w->fmt == WFMT_BF16) { static thread_local char nb_[64]; snprintf(nb_, sizeof nb_, "dense_gemv_kernel<PRO=%d,EPI=%d>", pro, epi); *kernel_name = nb_; }
+        else *kernel_name = q4_gemv_kernel_name(w->K, pro, epi, which == 4 ? m->argmax_R : q4_gemv_default_R(w->N, w->K, epi));
     }
     for (int i = 0; i < std::min(iters, 8); i++) VOXCHK(launch(i));   // warm-up
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
