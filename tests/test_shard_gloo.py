@@ -18,6 +18,13 @@ def test_lpt_partition(pkg):
     assert shard.lpt_partition(dur, 8) == parts                       # deterministic
     out = shard.run_sharded(list(range(5)), [1] * 5, lambda x: x * x, 0, 1)
     assert out == [0, 1, 4, 9, 16]
+    # length-bucketed batches (vox_transcribe_batch groups): every index once, batches <= 16, neighbours in length together
+    b = shard.length_buckets(parts[0], dur, 16)
+    assert sorted(i for g in b for i in g) == parts[0] and max(len(g) for g in b) <= 16
+    assert all(min(dur[i] for i in b[k]) >= max(dur[i] for i in b[k + 1]) for k in range(len(b) - 1))
+    calls = []
+    out = shard.run_sharded(list(range(7)), [3, 1, 2, 9, 5, 4, 8], None, 0, 1, batch=3, batch_work=lambda xs: (calls.append(list(xs)), [x * 10 for x in xs])[1])
+    assert out == [0, 10, 20, 30, 40, 50, 60] and calls == [[3, 6, 4], [5, 0, 2], [1]]
 
 
 def _worker(rank, world, port, pkg_dir, q):
@@ -36,6 +43,8 @@ def _worker(rank, world, port, pkg_dir, q):
         return f"{name}:rank{rank}"
 
     out = shard.run_sharded(items, costs, work, rank, world)
+    outb = shard.run_sharded(items, costs, None, rank, world, batch=4, batch_work=lambda names: [f"{n}:rank{rank}" for n in names])
+    assert (outb is None) == (out is None) and (out is None or [o.split(":")[0] for o in outb] == items)
     # bench.py-style timing reduction: barrier, max over ranks
     import torch
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)

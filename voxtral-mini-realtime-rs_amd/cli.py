@@ -80,6 +80,8 @@ def main(argv=None):
     ap.add_argument("-d", "--delay", type=int, default=6)
     ap.add_argument("--max-mel-frames", type=int, default=1200)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=1, help="extension: transcribe up to N un-chunked files per vox_transcribe_batch call "
+                    "(same ids as one by one; output order unchanged)")
     a = ap.parse_args(argv)
     if a.audio_list and a.audio:
         ap.error("--audio-list conflicts with --audio")
@@ -112,7 +114,33 @@ def main(argv=None):
     mel = pkg.MelSpectrogram.voxtral(ctx); pad_cfg = pkg.PadConfig.voxtral()
     chunk_cfg = pkg.ChunkConfig.voxtral().with_max_frames(a.max_mel_frames)
     rc = 0
-    for p in paths:
+    texts = {}
+    if a.batch > 1:
+        # files that fit one chunk go through the batched path in groups of similar length; chunked / failing files fall back below
+        units = []
+        for i, p in enumerate(paths):
+            try:
+                x, sr = load_wav(p)
+                if sr != 16000:
+                    x = resample_to_16k(x, sr)
+                x = pkg.peak_normalize(x, 0.95)
+                if not pkg.needs_chunking(x.size, chunk_cfg) and x.size > 0:
+                    units.append((i, x))
+            except Exception:
+                pass
+        units.sort(key=lambda u: -u[1].size)
+        for k in range(0, len(units), a.batch):
+            grp = units[k:k + a.batch]
+            try:
+                t1 = time.time(); outs = model.transcribe_batch([x for _, x in grp], t_embed)
+                log(f"batch of {len(grp)}: {time.time() - t1:.3f}s")
+                for (i, _), ids in zip(grp, outs):
+                    texts[i] = tokenizer.decode([t for t in ids if t >= 1000]).strip()
+            except Exception as e:
+                log(f"batched path failed ({e}); falling back to one by one")
+    for i, p in enumerate(paths):
+        if i in texts:
+            print(texts[i], flush=True); continue
         try:
             t1 = time.time(); text = transcribe_one(pkg, p, model, tokenizer, mel, pad_cfg, chunk_cfg, t_embed)
             log(f"{p}: {time.time() - t1:.3f}s")

@@ -29,11 +29,28 @@ def imbalance(costs: Sequence[float], parts: list[list[int]]) -> float:
     return (max(loads) / mean - 1.0) if mean > 0 else 0.0
 
 
-def run_sharded(items: Sequence, costs: Sequence[float], work: Callable, rank: int, world: int, group=None):
-    """Every rank calls this with the same `items`/`costs`; rank r runs `work(item)` on its LPT share.
+def length_buckets(idx: Sequence[int], costs: Sequence[float], batch: int) -> list[list[int]]:
+    """Group a rank's share into batches of <= `batch` utterances of similar length (sorted by cost): the stacked encoder and
+    the batched decode loop of vox_transcribe_batch pay for the longest member of a batch, so neighbours in length go together."""
+    order = sorted(idx, key=lambda i: (-float(costs[i]), i))
+    return [order[k:k + batch] for k in range(0, len(order), max(batch, 1))]
+
+
+def run_sharded(items: Sequence, costs: Sequence[float], work: Callable, rank: int, world: int, group=None,
+                batch: int = 1, batch_work: Callable | None = None):
+    """Every rank calls this with the same `items`/`costs`; rank r runs `work(item)` on its LPT share -- or, with `batch > 1`,
+    `batch_work(list_of_items) -> list_of_results` on length-bucketed groups of its share (one vox_transcribe_batch call each).
     Returns the full, index-ordered result list on rank 0 (None elsewhere)."""
     parts = lpt_partition(costs, world)
-    mine = [(i, work(items[i])) for i in parts[rank]]
+    if batch > 1 and batch_work is not None:
+        mine = []
+        for grp in length_buckets(parts[rank], costs, batch):
+            res = batch_work([items[i] for i in grp])
+            if len(res) != len(grp):
+                raise ValueError("batch_work must return one result per item")
+            mine.extend(zip(grp, res))
+    else:
+        mine = [(i, work(items[i])) for i in parts[rank]]
     if world == 1:
         out = [None] * len(items)
         for i, r in mine:
