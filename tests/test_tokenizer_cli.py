@@ -67,3 +67,6 @@ def test_cli_end_to_end(pkg, tmp_path):
     assert all(w.startswith("w") for w in lines[0].split()) and all(w.startswith("w") for w in lines[1].split())
     r2 = subprocess.run(cmd[:-4] + ["--audio", str(tmp_path / "a.wav")], capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0 and r2.stdout.split("\n")[0] == lines[0]           # deterministic, same text
+    # --batch (extension): un-chunked files go through vox_transcribe_batch, chunked ones one by one; same lines in the same order
+    r3 = subprocess.run(cmd + ["--batch", "4"], capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 1 and r3.stdout == r.stdout and "batch of 1" in r3.stderr
