@@ -487,6 +487,7 @@ struct vox_model {
     vox_ctx* ctx = nullptr; vox_model_cfg cfg{};
     uint8_t* arena = nullptr; uint64_t arena_bytes = 0;
     const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_norm = nullptr, *dec_norm = nullptr;
+    Q4W conv1_g{}, conv2_g{};                               // conv weights as im2col GEMM operands (two bf16 planes), optional
     const float *enc_cos = nullptr, *enc_sin = nullptr, *dec_cos = nullptr, *dec_sin = nullptr;
     int enc_rope_len = 4096, dec_rope_len = 16384;                         // gguf/loader.rs:196-198,284-286
     std::vector<EncLayer> enc; std::vector<DecLayer> dec; Lin ad0, ad2, tok;
@@ -648,6 +649,32 @@ struct Loader {
         }
         return dst;
     }
+    // conv weight [Cout][Cin][3] (f32 in the checkpoint) as the im2col GEMM operand W'[co][kk*Cin + ci] = w[co][ci][kk], held as two
+    // dense bf16 planes hi + lo (w ~= hi + lo to 2^-17 relative): the conv stem then runs on the matrix cores (dense2_gemm_kernel)
+    bool conv_planes(const std::string& name, Q4W* out) {
+        TensorView t; if (!need(name, &t)) return false;
+        if (t.dtype == DT_Q4_0 || t.shape.size() != 3 || t.shape[2] != 3) return setfail("conv weight '" + name + "' must be a dense [out][in][3] tensor");
+        const int64_t Co = (int64_t)t.shape[0], Ci = (int64_t)t.shape[1], K = 3 * Ci;
+        if (K % 128) return setfail("conv weight '" + name + "': 3*Cin must be a multiple of 128");
+        uint16_t* hi = ar.take<uint16_t>((size_t)Co * K); uint16_t* lo = ar.take<uint16_t>((size_t)Co * K);
+        *out = Q4W{(const uint4*)hi, lo, (int)Co, (int)K, (int)(K / 32), WFMT_BF16X2};
+        if (fill) {
+            const uint64_t ne = numel(t); std::vector<float> w(ne); to_f32(t, ne, w.data());
+            std::vector<uint16_t> h((size_t)Co * K), l((size_t)Co * K);
+            auto rne = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+            for (int64_t co = 0; co < Co; co++)
+                for (int64_t ci = 0; ci < Ci; ci++)
+                    for (int kk = 0; kk < 3; kk++) {
+                        const float v = w[(size_t)(co * Ci + ci) * 3 + kk];
+                        const uint16_t hb = rne(v); const uint32_t hu = (uint32_t)hb << 16; float hf; std::memcpy(&hf, &hu, 4);
+                        const size_t d = (size_t)co * K + (size_t)kk * Ci + ci;
+                        h[d] = hb; l[d] = rne(v - hf);
+                    }
+            if (hipMemcpy(hi, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(lo, l.data(), l.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                return setfail("hipMemcpy failed for conv planes");
+        }
+        return true;
+    }
     // linear made of `parts` source tensors [N_i][K]; rows concatenated (interleave=false) or interleaved (true).
     // Q4_0 sources -> re-packed Q4 planes; dense sources (BF16, or F16/F32 holding bf16-representable values) -> bf16 plane.
     bool lin(const std::vector<std::string>& parts, bool interleave, Lin* L, bool require_q4, bool tile = true) {
@@ -761,6 +788,9 @@ struct Loader {
         c.n_mels = (int)cw.shape[1]; c.enc_dim = (int)cw.shape[0];
         m->conv1_w = f32(ENC_PFX ".conv_layers.0.conv.weight"); m->conv1_b = f32(ENC_PFX ".conv_layers.0.conv.bias");
         m->conv2_w = f32(ENC_PFX ".conv_layers.1.conv.weight"); m->conv2_b = f32(ENC_PFX ".conv_layers.1.conv.bias");
+        if ((3 * c.n_mels) % 128 == 0 && (3 * c.enc_dim) % 128 == 0) {      // MFMA conv stem (else the VALU conv kernel)
+            if (!conv_planes(ENC_PFX ".conv_layers.0.conv.weight", &m->conv1_g) || !conv_planes(ENC_PFX ".conv_layers.1.conv.weight", &m->conv2_g)) return false;
+        }
         for (int i = 0; i < ne; i++) {                                                      // gguf/loader.rs:215-260, models/loader.rs:84-196
             EncLayer& L = m->enc[i]; std::string p = std::string(ENC_PFX ".transformer.layers.") + std::to_string(i);
             L.attn_norm = f32(p + ".attention_norm.weight"); L.ffn_norm = f32(p + ".ffn_norm.weight");
@@ -913,9 +943,11 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     ARGCHK(S_pad <= m->enc_rope_len, "audio too long for the encoder RoPE table (%d > %d positions); chunk it (--max-mel-frames)", S_pad, m->enc_rope_len);
     const int Mtot = n * S_pad, M4 = n == 1 ? S4_out[0] : Mtot / R;          // adapter rows
     ARGCHK(n == 1 || audio_rows >= S_pad / R, "internal: audio row budget %d < %d", audio_rows, S_pad / R);
-    const size_t need = (size_t)D * T1max + (size_t)Mtot * D * 2 + (size_t)Mtot * QD * 4 + (size_t)Mtot * F + (size_t)(M4 + 1) * m->ad0.w.N + 1024;
+    int Tmax = 0; for (int i = 0; i < n; i++) Tmax = std::max(Tmax, T[i]);
+    const size_t c1_floats = std::max((size_t)D * T1max, (size_t)(Tmax + 2) * c.n_mels + (size_t)(T1max + 2) * D) + 64;   // VALU conv: [D][T1]; MFMA conv: padded token-major mel + conv1 output
+    const size_t need = c1_floats + (size_t)Mtot * D * 2 + (size_t)Mtot * QD * 4 + (size_t)Mtot * F + (size_t)(M4 + 1) * m->ad0.w.N + 1024;
     VOXCHK(ensure(&m->ws, &m->ws_floats, need));
-    float* c1 = m->ws; float* x = c1 + (size_t)D * T1max; float* xn = x + (size_t)Mtot * D; float* qkv = xn + (size_t)Mtot * D;
+    float* c1 = m->ws; float* x = c1 + c1_floats / 64 * 64; float* xn = x + (size_t)Mtot * D; float* qkv = xn + (size_t)Mtot * D;
     float* att = qkv + (size_t)Mtot * QD * 3; float* ffn = att + (size_t)Mtot * QD; float* ah = ffn + (size_t)Mtot * F;
     const int* d_len = nullptr;
     if (n > 1) {
@@ -925,11 +957,24 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
         HIPCHK(hipMemcpyAsync(m->d_seq_len, m->h_seq_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         d_len = m->d_seq_len;
     }
+    const bool conv_mfma = m->conv1_g.qs && m->conv2_g.qs && !getenv("VOX_CONV_VALU");
     for (int i = 0; i < n; i++) {
         if (S[i] <= 0) continue;
         const int T1 = conv_len(T[i]);
-        HIPCHK(launch_conv1d_gelu(d_mels[i], c.n_mels, T[i], m->conv1_w, m->conv1_b, D, c1, 0, s));
-        HIPCHK(launch_conv1d_gelu(c1, D, T1, m->conv2_w, m->conv2_b, D, x + (size_t)i * S_pad * D, 1, s));      // token-major [S][D] (swap_dims, model.rs:427)
+        if (conv_mfma) {
+            // gelu(conv1d k3 s2 p1) as an im2col GEMM: with the input token-major and one zero row either side, output row t reads the
+            // CONTIGUOUS window rows [2t, 2t+2] of the padded buffer (= frames 2t-1..2t+1): A = that buffer with row stride 2*Cin, K = 3*Cin
+            const int Cm = c.n_mels;
+            float* melT = c1; float* c1T = melT + (size_t)(T[i] + 2) * Cm;                       // [(T+2)][Cm], [(T1+2)][D]
+            HIPCHK(hipMemsetAsync(melT, 0, (size_t)Cm * 4, s)); HIPCHK(hipMemsetAsync(melT + (size_t)(T[i] + 1) * Cm, 0, (size_t)Cm * 4, s));
+            HIPCHK(hipMemsetAsync(c1T, 0, (size_t)D * 4, s)); HIPCHK(hipMemsetAsync(c1T + (size_t)(T1 + 1) * D, 0, (size_t)D * 4, s));
+            HIPCHK(launch_transpose(d_mels[i], Cm, T[i], melT + Cm, s));                          // [Cm][T] -> [T][Cm]
+            { GemmParams g{}; g.w = m->conv1_g; g.x = melT; g.x_stride = 2 * Cm; g.M = T1; g.out = c1T + D; g.out_stride = D; g.bias = m->conv1_b; HIPCHK(launch_dense2_gemm(g, EPI_GELU, s)); }
+            { GemmParams g{}; g.w = m->conv2_g; g.x = c1T; g.x_stride = 2 * D; g.M = S[i]; g.out = x + (size_t)i * S_pad * D; g.out_stride = D; g.bias = m->conv2_b; HIPCHK(launch_dense2_gemm(g, EPI_GELU, s)); }
+        } else {
+            HIPCHK(launch_conv1d_gelu(d_mels[i], c.n_mels, T[i], m->conv1_w, m->conv1_b, D, c1, 0, s));
+            HIPCHK(launch_conv1d_gelu(c1, D, T1, m->conv2_w, m->conv2_b, D, x + (size_t)i * S_pad * D, 1, s));      // token-major [S][D] (swap_dims, model.rs:427)
+        }
     }
     const int seq_rows = n > 1 ? S_pad : 0;
     for (int l = 0; l < c.enc_layers; l++) {

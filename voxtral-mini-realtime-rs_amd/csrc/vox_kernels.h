@@ -19,7 +19,7 @@ struct Q4W {
     // skinny (M <= 16) and the large-M MFMA kernels, whose B fragments then are single coalesced dwordx4 loads
     const uint4* qt = nullptr; const uint16_t* st = nullptr;
 };
-enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1 };
+enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1, WFMT_BF16X2 = 2 };   // BF16X2: f32 weights as two dense bf16 planes, qs = hi [N][K], sc = lo [N][K] (conv stem)
 
 enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6, EPI_RESID_XF = 7 };
 // (M <= 16 only) _SWIGLU_XF: SwiGLU written as XF planes; _RESID_XF: out = acc + resid as f32 AND as XF planes of out * xf_w (* xf_w2) plus
@@ -66,6 +66,9 @@ struct GemmParams {
 };
 hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);
+// dense f32-class GEMM on two bf16 weight planes (w.fmt == WFMT_BF16X2; the conv stem as an im2col GEMM); epi: EPI_STORE / EPI_GELU
+hipError_t launch_dense2_gemm(const GemmParams& p, int epi, hipStream_t s);
+hipError_t launch_transpose(const float* in, int R, int C, float* out, hipStream_t s);   // [R][C] -> [C][R]
 int q4_skinny_resid_xf_parts(int N);   // number of [16]-row partial sums of squares an EPI_RESID_XF launch writes to ssq_out
 
 // ---- small fused ops

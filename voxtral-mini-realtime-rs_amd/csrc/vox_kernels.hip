@@ -1227,6 +1227,116 @@ static hipError_t gemm_big_launch(const GemmParams& p, int epi, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- dense f32-class GEMM for the convolution stem (models/layers/conv.rs:78-83 as an im2col GEMM): weights are f32 in the
+// checkpoint, held as two bf16 planes hi + lo ([N][K] row-major, w ~= hi + lo to 2^-17), activations split hi + lo on the way into LDS;
+// three MFMAs per product (ah*bh + al*bh + ah*bl) and the accumulation over all of K stays inside the matrix core (no scales, so no
+// per-block VALU at all).  Workgroup = 64 rows x (64*NTW) columns, wave = 64 x (16*NTW); K step 128; A rows may overlap (x_stride <
+// K: row t of a stride-2 kernel-3 convolution is the contiguous window [2t-1, 2t+1] of the token-major, zero-padded input).
+template <int NTW, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dense2_gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 dlds[];    // [hi/lo][j 4][4 m-tiles][64]
+    constexpr int PLANE = 4 * 4 * 64;
+    const int N = p.w.N, K = p.w.K, M = p.M, nq = K >> 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * (64 * NTW);
+    const float* xrow[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int pair = wave + 4 * u, j = pair >> 2, i = pair & 3;
+        xrow[u] = p.x + (size_t)min(m0 + 16 * i + li, M - 1) * p.x_stride + 32 * j + 8 * g;
+    }
+    const uint4* wh[NTW]; const uint4* wl[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const size_t row = (size_t)min(n0 + (wave * NTW + t) * 16 + li, N - 1);
+        wh[t] = p.w.qs + row * (K >> 3) + g; wl[t] = reinterpret_cast<const uint4*>(p.w.sc) + row * (K >> 3) + g;
+    }
+    f32x4 acc[NTW][4];
+#pragma unroll
+    for (int t = 0; t < NTW; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 xa[4], xb[4]; uint4 bh[NTW][4], bl[NTW][4], bhn[NTW][4], bln[NTW][4];
+#define VOX_ALOAD(Q_)                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                            \
+        xa[u] = *reinterpret_cast<const float4*>(xrow[u] + 128 * (Q_));                                        \
+        xb[u] = *reinterpret_cast<const float4*>(xrow[u] + 128 * (Q_) + 4); }
+#define VOX_BLOAD(H_, L_, Q_)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < NTW; t++)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) { H_[t][j] = wh[t][(Q_) * 16 + j * 4]; L_[t][j] = wl[t][(Q_) * 16 + j * 4]; }
+    VOX_ALOAD(0)
+    VOX_BLOAD(bh, bl, 0)
+    for (int q = 0; q < nq; q++) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint4 hi, lo; split_bf16x8(xa[u], xb[u], hi, lo);
+            dlds[(wave + 4 * u) * 64 + lane] = hi; dlds[PLANE + (wave + 4 * u) * 64 + lane] = lo;
+        }
+        __syncthreads();
+        { const int q1 = min(q + 1, nq - 1); VOX_ALOAD(q1) VOX_BLOAD(bhn, bln, q1) }      // unconditional (clamped) prefetch
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bf16x8 ah = as_bf16x8(dlds[(j * 4 + i) * 64 + lane]);
+                const bf16x8 al = as_bf16x8(dlds[PLANE + (j * 4 + i) * 64 + lane]);
+#pragma unroll
+                for (int t = 0; t < NTW; t++) {
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(bh[t][j]), acc[t][i], 0, 0, 0);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(bh[t][j]), acc[t][i], 0, 0, 0);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(bl[t][j]), acc[t][i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { bh[t][j] = bhn[t][j]; bl[t][j] = bln[t][j]; }
+    }
+#undef VOX_ALOAD
+#undef VOX_BLOAD
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const int n = n0 + (wave * NTW + t) * 16 + li; const bool nok = n < N;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + i * 16 + 4 * g + r;
+                float v = acc[t][i][r] + bias;
+                if (EPI == EPI_GELU) v = gelu_f(v);
+                if (m < M && nok) p.out[(size_t)m * p.out_stride + n] = v;
+            }
+    }
+}
+hipError_t launch_dense2_gemm(const GemmParams& p, int epi, hipStream_t s) {
+    if (p.w.fmt != WFMT_BF16X2 || p.w.K % 128 || (p.x_stride % 4) || p.M <= 0 || (epi != EPI_GELU && epi != EPI_STORE)) return hipErrorInvalidValue;
+    const long wg4 = (long)((p.w.N + 255) / 256) * ((p.M + 63) / 64);
+    const size_t lds = (size_t)2 * 4 * 4 * 64 * sizeof(uint4);      // 32 KB
+    if (wg4 >= 200) {
+        dim3 grid((p.w.N + 255) / 256, (p.M + 63) / 64);
+        if (epi == EPI_GELU) dense2_gemm_kernel<4, EPI_GELU><<<grid, dim3(256), lds, s>>>(p); else dense2_gemm_kernel<4, EPI_STORE><<<grid, dim3(256), lds, s>>>(p);
+    } else {
+        dim3 grid((p.w.N + 63) / 64, (p.M + 63) / 64);
+        if (epi == EPI_GELU) dense2_gemm_kernel<1, EPI_GELU><<<grid, dim3(256), lds, s>>>(p); else dense2_gemm_kernel<1, EPI_STORE><<<grid, dim3(256), lds, s>>>(p);
+    }
+    return hipGetLastError();
+}
+// [R][C] -> [C][R] (mel handed over as [128][T] by the reference's callers -> token-major rows for the im2col view)
+__global__ void transpose_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 32 x 8
+    for (int k = ty; k < 32; k += 8) { const int r = r0 + k, c = c0 + tx; tile[k][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f; }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) { const int c = c0 + k, r = r0 + tx; if (c < C && r < R) out[(size_t)c * R + r] = tile[tx][k]; }
+}
+hipError_t launch_transpose(const float* in, int R, int C, float* out, hipStream_t s) {
+    transpose_kernel<<<dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s>>>(in, R, C, out);
+    return hipGetLastError();
+}
+
 template <int NTW, int TILED>
 static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStream_t s) {
     dim3 grid((p.w.N + 16 * NTW - 1) / (16 * NTW));
