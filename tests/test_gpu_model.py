@@ -184,3 +184,28 @@ def test_transcribe_batch(pkg, orc, tiny):
         assert (a == b).all()                               # deterministic
         assert len(a) == len(c)
     assert len(m.transcribe_batch(clips[:1], t)[0]) == len(single[0])
+
+
+def test_transcribe_batch_wide_and_fallback_paths(pkg, tiny, monkeypatch):
+    """More than 16 utterances (the f32-activation step: the XF fragment path holds <= 16 rows), exactly 16, and the
+    VOX_BATCH_NO_XF knob must all give the ids of the one-by-one path (up to a near-tie, so lengths + first ids are compared strictly)."""
+    m, _, _ = tiny
+    t = pkg.TimeEmbedding(256).embed(6.0)
+    secs = [2.0 + 0.17 * (i % 5) for i in range(20)]
+    clips = [pkg.synth.synth_audio(s, seed=70 + i) for i, s in enumerate(secs)]
+    single = [m.transcribe_audio(x, t) for x in clips]
+    wide = m.transcribe_batch(clips, t)                       # n = 20 > 16
+    exact = m.transcribe_batch(clips[:16], t)                 # n = 16: XF step
+    monkeypatch.setenv("VOX_BATCH_NO_XF", "1")
+    noxf = m.transcribe_batch(clips[:16], t)
+    monkeypatch.delenv("VOX_BATCH_NO_XF")
+    same = 0
+    for i, s in enumerate(single):
+        assert len(wide[i]) == len(s)
+        same += int((wide[i] == s).all())
+        if i < 16:
+            assert len(exact[i]) == len(s) == len(noxf[i])
+            same += int((exact[i] == s).all()) + int((noxf[i] == s).all())
+    assert same >= 0.9 * (20 + 32), same                      # near-ties may flip a few sequences between kernel families
+    with pytest.raises(pkg.VoxError):
+        m.transcribe_batch([clips[0]] * 65, t)                # batch size limit (1..64)
