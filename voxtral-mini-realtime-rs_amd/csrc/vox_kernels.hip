@@ -190,8 +190,9 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     }
     VOX_WLOAD(qa, da, min(g, n_groups - 1))
 
-    // (3) prologue on the activation vector (RMSNorm (+Ada multiplier) fused), staged to LDS.
-    float rms = 1.0f;
+    // (3) prologue on the activation vector (RMSNorm (+Ada multiplier) fused), staged to LDS.  The row scale 1/rms is a scalar, so it
+    // commutes with the dot products: x * gamma is staged UNnormalised right away and every row result is multiplied by rstd in
+    // the epilogue -- the sum-of-squares reduction no longer sits (with its own barrier) in front of the staging.
     if (PRO != PRO_NONE) {
         float ss = 0.f;
 #pragma unroll
@@ -199,9 +200,6 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
             if (tid + 256 * i < npieces) ss += xp[i].x * xp[i].x + xp[i].y * xp[i].y + xp[i].z * xp[i].z + xp[i].w * xp[i].w;
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
-        __syncthreads();
-        ss = red[0] + red[1] + red[2] + red[3];
-        rms = 1.0f / sqrtf(ss / (float)K + p.eps);   // burn RmsNorm divides by sqrt(mean(x^2) + eps); we multiply by the reciprocal
     }
 #pragma unroll
     for (int i = 0; i < NX; i++) {
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
         float4 v = xp[i];
         if (PRO != PRO_NONE) {
             const float4 gm = gp[i];
-            v.x = (v.x * rms) * gm.x; v.y = (v.y * rms) * gm.y; v.z = (v.z * rms) * gm.z; v.w = (v.w * rms) * gm.w;
+            v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
             if (PRO == PRO_RMS_MUL) {
                 const float4 m = mp[i];
                 v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
@@ -223,6 +221,8 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
         }
     }
     __syncthreads();
+    // burn RmsNorm divides by sqrt(mean(x^2) + eps); we multiply by the reciprocal
+    const float rstd = PRO != PRO_NONE ? 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + p.eps) : 1.0f;
 
     float best = -INFINITY; int best_i = 0x7fffffff;   // EPI_ARGMAX running (max, first index) of this wave
     const int pos = (EPI == EPI_ROPE_KV) ? (p.pos_ptr ? *p.pos_ptr : 0) + p.pos_off : 0;
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
             }                                                                                                          \
         }                                                                                                              \
         VOX_REDUCE                                                                                                     \
+        if (PRO != PRO_NONE) { _Pragma("unroll") for (int r = 0; r < R; r++) acc[r] *= rstd; }                          \
         if (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_GELU) {                                                 \
             _Pragma("unroll") for (int r = 0; r < R; r++) {                                                            \
                 const int n = row0 + r;                                                                                \
@@ -1915,7 +1916,39 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
         const float4 v = *reinterpret_cast<const float4*>(qrow + h * HD + part * PER + e);
         qv[e] = v.x; qv[e + 1] = v.y; qv[e + 2] = v.z; qv[e + 3] = v.w;
     }
-    for (int i0 = 0; i0 < n; i0 += 64) {
+    // The first NPRE*32 keys (every 16 s clip: <= 146 positions) are handled with ALL their K and V loads issued up front, before any
+    // arithmetic: the kernel is a chain of dependent round trips (q -> K -> softmax -> V) and this collapses the K and V trips into one.
+    constexpr int NPRE = 5, COLS = HD / 4, GROUPS = 256 / COLS;
+    static_assert(4 * GROUPS == 32 || HD != 128, "prefetch tiling assumes 32 keys per P.V iteration for HD = 128");
+    const int grp = tid / COLS, col = tid % COLS;
+    float4 kpre[NPRE][PER / 4], vpre[NPRE][4];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        const int jc = j_lo + min(32 * u + ks, n - 1);
+        const float* kr = kb + (size_t)jc * p.kv_row_stride + part * PER;
+#pragma unroll
+        for (int e = 0; e < PER / 4; e++) kpre[u][e] = *reinterpret_cast<const float4*>(kr + 4 * e);
+    }
+#pragma unroll
+    for (int u = 0; u < NPRE; u++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int ic = min(u * 4 * GROUPS + grp + w * GROUPS, n - 1);
+            vpre[u][w] = *reinterpret_cast<const float4*>(vb + (size_t)(j_lo + ic) * p.kv_row_stride + col * 4);
+        }
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < PER / 4; e++) {
+            const float4 kv = kpre[u][e];
+            s = fmaf(qv[4 * e], kv.x, s); s = fmaf(qv[4 * e + 1], kv.y, s); s = fmaf(qv[4 * e + 2], kv.z, s); s = fmaf(qv[4 * e + 3], kv.w, s);
+        }
+        s = group8_sum(s);
+        const int i = 32 * u + ks;
+        if (part == 0 && i < n) sc[i] = s * scale;
+    }
+    for (int i0 = 32 * NPRE; i0 < n; i0 += 64) {
         float s2[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -1950,10 +1983,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     __syncthreads();
     sum = (red[4] + red[5]) + (red[6] + red[7]);
     // P.V : thread -> (key group, float4 column)
-    constexpr int COLS = HD / 4, GROUPS = 256 / COLS;
-    const int grp = tid / COLS, col = tid % COLS;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i0 = grp; i0 < n; i0 += 4 * GROUPS) {
+    if (4 * GROUPS == 32) {
+#pragma unroll
+        for (int u = 0; u < NPRE; u++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int i = u * 32 + grp + w * GROUPS;
+                const float pr = i < n ? sc[min(i, n - 1)] : 0.f;
+                const float4 vv = vpre[u][w];
+                o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w);
+            }
+    }
+    for (int i0 = (4 * GROUPS == 32 ? 32 * NPRE : 0) + grp; i0 < n; i0 += 4 * GROUPS) {
         float4 vv[4]; float pr[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
