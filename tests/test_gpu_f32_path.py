@@ -73,3 +73,15 @@ def test_f32_transcribe(pkg, pair):
     check_greedy_ids(ids, rids, rlg, TOL)                                  # greedy ids identical to the CPU reference
     ids_g = m.transcribe_streaming(mel[None], t)                            # graph-replayed decode
     assert (ids_g == ids).all() and (m.transcribe_streaming(mel[None], t) == ids).all()
+
+
+def test_f32_transcribe_batch(pkg, pair):
+    """The batch API on the dense path (no tile-ordered weights -> the f32-activation step): rows == one-by-one transcription."""
+    m, _, _ = pair
+    t = pkg.TimeEmbedding(256).embed(6.0)
+    clips = [pkg.synth.synth_audio(sec, seed=90 + i) for i, sec in enumerate((2.0, 2.6, 2.0))]
+    single = [m.transcribe_audio(x, t) for x in clips]
+    outs = m.transcribe_batch(clips, t)
+    assert [len(o) for o in outs] == [len(s) for s in single]
+    assert sum(int((a == b).all()) for a, b in zip(outs, single)) >= 2          # a near-tie may flip one sequence
+    assert all((a == b).all() for a, b in zip(outs, m.transcribe_batch(clips, t)))
