@@ -107,6 +107,10 @@ int32_t vox_time_embedding(float t, int32_t dim, float* out);
 
 /* ---- GGUF reader (src/gguf/reader.rs:98-223) -------------------------------------------- */
 int32_t vox_gguf_open(const char* path, vox_gguf** out);                         /* GgufReader::open */
+/* GgufReader::from_bytes (gguf/reader.rs:98-103): parse an image already in host memory (BORROWED until vox_gguf_close) */
+int32_t vox_gguf_open_memory(const void* data, size_t size, vox_gguf** out);
+/* Q4ModelLoader::from_shards (gguf/loader.rs:101-107, the WASM <= 512 MB pieces): consecutive pieces of one GGUF image (copied) */
+int32_t vox_gguf_open_shards(const void* const* shards, const size_t* sizes, int32_t n, vox_gguf** out);
 int32_t vox_gguf_close(vox_gguf* g);
 int32_t vox_gguf_version(const vox_gguf* g, uint32_t* out);
 int32_t vox_gguf_tensor_count(const vox_gguf* g, uint64_t* out);
@@ -151,6 +155,9 @@ int32_t vox_q4_model_load(vox_ctx* ctx, const char* gguf_path, vox_model** out);
  * not read or upload tensor data -- the caller fills the arena (vox_model_arena) e.g. from an RCCL broadcast. */
 #define VOX_LOAD_LAYOUT_ONLY 1u
 int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* gguf_path, uint32_t flags, vox_model** out);
+/* Q4ModelLoader::from_bytes / from_shards -> load (gguf/loader.rs:92-128): from an open reader (file, memory image or shards);
+ * the reader is only read during the call and stays owned by the caller. */
+int32_t vox_q4_model_load_gguf(vox_ctx* ctx, vox_gguf* g, uint32_t flags, vox_model** out);
 /* VoxtralModelLoader::from_file(..).load(), models/loader.rs:35-78: the f32 SafeTensors path (F32 / F16 / BF16 tensors,
  * models/weights.rs:16-66).  Same vox_model handle and the same forward entry points as the Q4 model.  Linear weights are
  * stored as bf16 on device: exact for the published BF16 checkpoint; F32/F16 inputs must hold bf16-representable values. */

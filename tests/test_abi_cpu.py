@@ -101,6 +101,17 @@ def test_gguf_reader_cpu(pkg, orc, tmp_path):
     # v2 accepted (reader.rs:117-120)
     S.write_gguf(str(tmp_path / "v2.gguf"), [("a", (32, 32), S.GGML_Q4_0, S.quantize_q4_0(np.ones(1024, np.float32)))], version=2)
     assert pkg.GgufReader.open(str(tmp_path / "v2.gguf")).version() == 2
+    # from_bytes (reader.rs:98-103) and from_shards (loader.rs:101-107): same view of the same image
+    img = open(p, "rb").read()
+    rb = pkg.GgufReader.from_bytes(img)
+    assert rb.tensor_count() == 2 and (rb.tensor_data("test.weight") == q).all() and rb.tensor_info("b").shape() == [8]
+    cut = [0, 5, 100, len(img) // 2, len(img)]
+    rs = pkg.GgufReader.from_shards([img[a:b] for a, b in zip(cut[:-1], cut[1:])])
+    assert rs.tensor_count() == 2 and (rs.tensor_data("test.weight") == q).all() and (rs.tensor_data("b").view(np.float32) == np.arange(8)).all()
+    with pytest.raises(pkg.VoxError, match="magic|small"):
+        pkg.GgufReader.from_bytes(b"NOPE" + b"\0" * 64)
+    with pytest.raises(pkg.VoxError, match="exceeds|parse|read"):
+        pkg.GgufReader.from_bytes(img[: len(img) - 40])                      # truncated tensor data
 
 
 def test_synthetic_gguf_is_readable_by_both(pkg, orc, tmp_path):

@@ -209,3 +209,17 @@ def test_transcribe_batch_wide_and_fallback_paths(pkg, tiny, monkeypatch):
     assert same >= 0.9 * (20 + 32), same                      # near-ties may flip a few sequences between kernel families
     with pytest.raises(pkg.VoxError):
         m.transcribe_batch([clips[0]] * 65, t)                # batch size limit (1..64)
+
+
+def test_load_from_bytes_and_shards(pkg, ctx, tiny):
+    """Q4ModelLoader::from_bytes / from_shards (gguf/loader.rs:92-107): the same model as from_file -> identical ids."""
+    m, _, _ = tiny
+    img = open(tiny_gguf()[0], "rb").read()
+    t = pkg.TimeEmbedding(256).embed(6.0); x = pkg.synth.synth_audio(2.5, seed=4)
+    ref = m.transcribe_audio(x, t)
+    mb = pkg.Q4ModelLoader.from_bytes(img).load(ctx)
+    third = len(img) // 3
+    ms = pkg.Q4ModelLoader.from_shards([img[:third], img[third:2 * third], img[2 * third:]]).load(ctx)
+    assert (mb.transcribe_audio(x, t) == ref).all() and (ms.transcribe_audio(x, t) == ref).all()
+    assert mb.weight_bytes() == m.weight_bytes() == ms.weight_bytes()
+    mb.close(); ms.close()

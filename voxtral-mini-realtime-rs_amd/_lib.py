@@ -70,6 +70,9 @@ SIGNATURES = {
     "vox_mel_compute_log": (i32, [vp, vp, sz, vp, i32]),
     "vox_time_embedding": (i32, [f32, i32, vp]),
     "vox_gguf_open": (i32, [C.c_char_p, P(vp)]),
+    "vox_gguf_open_memory": (i32, [vp, C.c_size_t, P(vp)]),
+    "vox_gguf_open_shards": (i32, [vp, vp, i32, P(vp)]),
+    "vox_q4_model_load_gguf": (i32, [vp, vp, C.c_uint32, P(vp)]),
     "vox_gguf_close": (i32, [vp]),
     "vox_gguf_version": (i32, [vp, P(u32)]),
     "vox_gguf_tensor_count": (i32, [vp, P(u64)]),

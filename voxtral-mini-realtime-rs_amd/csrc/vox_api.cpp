@@ -279,6 +279,7 @@ extern "C" int32_t vox_time_embedding(float t, int32_t dim, float* out) {   // m
 struct GTensor { std::string name; uint32_t ndims = 0; uint64_t dims[4] = {0, 0, 0, 0}; uint32_t dtype = 0; uint64_t offset = 0, nbytes = 0; };
 struct vox_gguf {
     uint8_t* map = nullptr; size_t size = 0; uint32_t version = 0;
+    int own = 1;                    // 1: mmap'ed file (munmap), 0: borrowed caller memory (from_bytes), 2: heap copy of shards (free)
     std::vector<GTensor> tensors; std::map<std::string, size_t> index; uint64_t data_off = 0;
     const GTensor* find(const std::string& n) const { auto it = index.find(n); return it == index.end() ? nullptr : &tensors[it->second]; }
     const uint8_t* data(const GTensor* t) const { return map + data_off + t->offset; }
@@ -304,15 +305,12 @@ struct Cur {
 };
 }  // namespace
 
-extern "C" int32_t vox_gguf_close(vox_gguf* g) { if (g) { if (g->map) munmap(g->map, g->size); delete g; } return VOX_OK; }
-extern "C" int32_t vox_gguf_open(const char* path, vox_gguf** out) {
-    ARGCHK(path && out, "null argument");
-    int fd = open(path, O_RDONLY);
-    if (fd < 0) return fail(VOX_ERR_IO, "cannot open %s: %s", path, strerror(errno));
-    struct stat st; fstat(fd, &st);
-    void* mp = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0); close(fd);
-    if (mp == MAP_FAILED) return fail(VOX_ERR_IO, "mmap of %s failed", path);
-    vox_gguf* g = new vox_gguf(); g->map = (uint8_t*)mp; g->size = st.st_size;
+extern "C" int32_t vox_gguf_close(vox_gguf* g) {
+    if (g) { if (g->map && g->own == 1) munmap(g->map, g->size); else if (g->map && g->own == 2) std::free(g->map); delete g; }
+    return VOX_OK;
+}
+// parse the header of g->map / g->size (takes ownership of g: closes it on error)
+static int32_t gguf_parse(vox_gguf* g, vox_gguf** out) {
     Cur c{g->map, 0, g->size};
     const uint32_t magic = c.rd<uint32_t>();
     if (c.bad || magic != 0x46554747u) { vox_gguf_close(g); return fail(VOX_ERR_IO, "Invalid GGUF magic: 0x%08X (expected 0x46554747)", magic); }
@@ -340,6 +338,34 @@ extern "C" int32_t vox_gguf_open(const char* path, vox_gguf** out) {
     for (auto& t : g->tensors)
         if (g->data_off + t.offset + t.nbytes > g->size) { std::string n = t.name; vox_gguf_close(g); return fail(VOX_ERR_IO, "tensor '%s' exceeds file size", n.c_str()); }
     *out = g; return VOX_OK;
+}
+extern "C" int32_t vox_gguf_open(const char* path, vox_gguf** out) {
+    ARGCHK(path && out, "null argument");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(VOX_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+    struct stat st; fstat(fd, &st);
+    void* mp = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0); close(fd);
+    if (mp == MAP_FAILED) return fail(VOX_ERR_IO, "mmap of %s failed", path);
+    vox_gguf* g = new vox_gguf(); g->map = (uint8_t*)mp; g->size = st.st_size; g->own = 1;
+    return gguf_parse(g, out);
+}
+// GgufReader::from_bytes (gguf/reader.rs:98-103): parse a GGUF image that is already in host memory.  The memory is BORROWED: it
+// must stay valid and unchanged until vox_gguf_close.
+extern "C" int32_t vox_gguf_open_memory(const void* data, size_t size, vox_gguf** out) {
+    ARGCHK(data && out, "null argument"); ARGCHK(size >= 24, "GGUF image too small (%zu bytes)", size);
+    vox_gguf* g = new vox_gguf(); g->map = (uint8_t*)const_cast<void*>(data); g->size = size; g->own = 0;
+    return gguf_parse(g, out);
+}
+// Q4ModelLoader::from_shards (gguf/loader.rs:101-107; the reference's ShardedCursor reads <= 512 MB pieces as one stream): the shards
+// are the consecutive pieces of ONE GGUF image; they are concatenated into a private host copy.
+extern "C" int32_t vox_gguf_open_shards(const void* const* shards, const size_t* sizes, int32_t n, vox_gguf** out) {
+    ARGCHK(shards && sizes && out && n > 0, "bad shard list");
+    size_t total = 0; for (int i = 0; i < n; i++) { ARGCHK(shards[i] || sizes[i] == 0, "null shard %d", i); total += sizes[i]; }
+    ARGCHK(total >= 24, "GGUF image too small (%zu bytes)", total);
+    uint8_t* buf = (uint8_t*)std::malloc(total); if (!buf) return fail(VOX_ERR_IO, "out of host memory for %zu bytes of shards", total);
+    size_t o = 0; for (int i = 0; i < n; i++) { std::memcpy(buf + o, shards[i], sizes[i]); o += sizes[i]; }
+    vox_gguf* g = new vox_gguf(); g->map = buf; g->size = total; g->own = 2;
+    return gguf_parse(g, out);
 }
 extern "C" int32_t vox_gguf_version(const vox_gguf* g, uint32_t* out) { ARGCHK(g && out, "null argument"); *out = g->version; return VOX_OK; }
 extern "C" int32_t vox_gguf_tensor_count(const vox_gguf* g, uint64_t* out) { ARGCHK(g && out, "null argument"); *out = g->tensors.size(); return VOX_OK; }
@@ -876,6 +902,15 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
 
 extern "C" int32_t vox_q4_model_load(vox_ctx* ctx, const char* path, vox_model** out) { return vox_q4_model_load_ex(ctx, path, 0, out); }
 
+// Q4ModelLoader::from_bytes / from_shards + load (gguf/loader.rs:92-128): build the model from an already-open GGUF reader (file,
+// memory image or shards).  The reader is only read during the call; the caller closes it afterwards.
+extern "C" int32_t vox_q4_model_load_gguf(vox_ctx* ctx, vox_gguf* g, uint32_t flags, vox_model** out) {
+    ARGCHK(ctx && g && out, "null argument"); VOXCHK(ctx_bind(ctx));
+    GgufSource src; src.g = g;
+    const int32_t r = model_build(ctx, &src, true, (flags & VOX_LOAD_LAYOUT_ONLY) != 0, out);
+    src.g = nullptr;      // borrowed
+    return r;
+}
 extern "C" int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* path, uint32_t flags, vox_model** out) {
     ARGCHK(ctx && path && out, "null argument"); VOXCHK(ctx_bind(ctx));
     GgufSource src; VOXCHK(vox_gguf_open(path, &src.g));

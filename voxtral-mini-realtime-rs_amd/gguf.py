@@ -93,13 +93,29 @@ class GgufTensorInfo:
 class GgufReader:
     """gguf/reader.rs:98-223 (v2/v3; dtypes F32/F16/Q4_0)"""
 
-    def __init__(self, path):
-        self.h = C.c_void_p()
-        check(lib().vox_gguf_open(str(path).encode(), C.byref(self.h)))
+    def __init__(self, path=None):
+        self.h = C.c_void_p(); self._keep = None
+        if path is not None:
+            check(lib().vox_gguf_open(str(path).encode(), C.byref(self.h)))
 
     @classmethod
     def open(cls, path):
         return cls(path)
+
+    @classmethod
+    def from_bytes(cls, data):
+        """gguf/reader.rs:98-103: parse a GGUF image held in memory (kept alive by this object, not copied)."""
+        r = cls(); r._keep = np.frombuffer(data, dtype=np.uint8)
+        check(lib().vox_gguf_open_memory(r._keep.ctypes.data, r._keep.size, C.byref(r.h)))
+        return r
+
+    @classmethod
+    def from_shards(cls, shards):
+        """gguf/loader.rs:101-107: consecutive pieces (<= 512 MB each in the reference's WASM loader) of one GGUF image."""
+        arrs = [np.frombuffer(s, dtype=np.uint8) for s in shards]; n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs]); sizes = (C.c_size_t * n)(*[a.size for a in arrs])
+        r = cls(); check(lib().vox_gguf_open_shards(ptrs, sizes, n, C.byref(r.h)))
+        return r
 
     def version(self):
         v = C.c_uint32(); check(lib().vox_gguf_version(self.h, C.byref(v))); return v.value
@@ -375,16 +391,29 @@ class Q4VoxtralModel:
 class Q4ModelLoader:
     """gguf/loader.rs:67-128"""
 
-    def __init__(self, path):
-        self.path = str(path)
+    def __init__(self, path=None, reader=None):
+        self.path = None if path is None else str(path); self.reader = reader
 
     @classmethod
     def from_file(cls, path):
         return cls(path)
 
+    @classmethod
+    def from_bytes(cls, data):
+        """gguf/loader.rs:92-99"""
+        return cls(reader=GgufReader.from_bytes(data))
+
+    @classmethod
+    def from_shards(cls, shards):
+        """gguf/loader.rs:101-107"""
+        return cls(reader=GgufReader.from_shards(shards))
+
     def load(self, ctx: Context, layout_only: bool = False) -> Q4VoxtralModel:
         """`layout_only`: allocate the device arena without reading tensor data (multi-GPU ranks > 0
         receive the arena bytes from rank 0 with one RCCL broadcast)."""
         h = C.c_void_p()
-        check(lib().vox_q4_model_load_ex(ctx.h, self.path.encode(), 1 if layout_only else 0, C.byref(h)))
+        if self.reader is not None:
+            check(lib().vox_q4_model_load_gguf(ctx.h, self.reader.h, 1 if layout_only else 0, C.byref(h)))
+        else:
+            check(lib().vox_q4_model_load_ex(ctx.h, self.path.encode(), 1 if layout_only else 0, C.byref(h)))
         return Q4VoxtralModel(ctx, h)
