@@ -54,7 +54,7 @@ def test_embed_tokens(tiny):
     assert (m.decoder().embed_tokens_from_ids(ids, 1, 5)[0] == o.embed_tokens(ids)).all()     # exact: pure dequant
 
 
-@pytest.mark.parametrize("T", [64, 250, 1144])
+@pytest.mark.parametrize("T", [64, 250, 1144, 3400])      # 3400 frames -> 850 encoder positions > the 750 sliding window (masking.rs:26-44)
 def test_encode_audio(tiny, T):
     m, o, _ = tiny
     mel = fake_mel(T, seed=T)
