@@ -1361,48 +1361,60 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     }
     // (4) batched decode steps
     int steps = 0; for (int i = 0; i < n; i++) steps = std::max(steps, S[i] - PREFIX_LEN - 1);
-    // <= 16 sequences: the step's GEMM inputs live as XF fragment planes (bf16 hi+lo in MFMA A-operand order, written once by the
-    // producing kernel), so the skinny kernels spend no VALU on conversion and RMSNorm output never exists as f32
-    const bool use_xf = n <= 16 && m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !getenv("VOX_BATCH_NO_XF");
+    // The step's GEMM inputs live as XF fragment planes (bf16 hi+lo in MFMA A-operand order, written once by the producing kernel), so
+    // the skinny kernels spend no VALU on conversion and RMSNorm output never exists as f32.  Sequences are processed in groups of
+    // 16 rows (one MFMA m-tile); the groups of a layer run back to back so the second group finds the layer's weights in L2 / MALL.
+    const bool use_xf = m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !getenv("VOX_BATCH_NO_XF");
+    const int n_grp = (n + 15) / 16;
     auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
     DevBuf b_xf1, b_xf2, b_xf3;
     if (use_xf) {
-        HIPCHK(b_xf1.alloc_pooled(cx, xf_bytes(D))); HIPCHK(b_xf2.alloc_pooled(cx, xf_bytes(QD))); HIPCHK(b_xf3.alloc_pooled(cx, xf_bytes(F)));
-        HIPCHK(hipMemsetAsync(b_xf1.p, 0, xf_bytes(D), s)); HIPCHK(hipMemsetAsync(b_xf2.p, 0, xf_bytes(QD), s)); HIPCHK(hipMemsetAsync(b_xf3.p, 0, xf_bytes(F), s));
+        HIPCHK(b_xf1.alloc_pooled(cx, xf_bytes(D) * n_grp)); HIPCHK(b_xf2.alloc_pooled(cx, xf_bytes(QD) * n_grp)); HIPCHK(b_xf3.alloc_pooled(cx, xf_bytes(F) * n_grp));
+        HIPCHK(hipMemsetAsync(b_xf1.p, 0, xf_bytes(D) * n_grp, s)); HIPCHK(hipMemsetAsync(b_xf2.p, 0, xf_bytes(QD) * n_grp, s)); HIPCHK(hipMemsetAsync(b_xf3.p, 0, xf_bytes(F) * n_grp, s));
     }
-    // XF step: 4 launches per layer.  RMSNorm never runs as a kernel: its producer (residual epilogue / token embedding) writes x*gamma as
-    // XF planes plus partial sums of squares, its consumer scales the accumulators by rstd (a per-row scalar commutes with the GEMM);
-    // RoPE + KV-cache write are the q|k|v GEMM's epilogue.
+    // XF step: 4 launches per layer and group.  RMSNorm never runs as a kernel: its producer (residual epilogue / token embedding) writes
+    // x*gamma as XF planes plus partial sums of squares, its consumer scales the accumulators by rstd (a per-row scalar commutes with the
+    // GEMM); RoPE + KV-cache write are the q|k|v GEMM's epilogue.
     DevBuf b_ssq; const int parts_D = q4_skinny_resid_xf_parts(D);
-    if (use_xf) { HIPCHK(b_ssq.alloc_pooled(cx, (size_t)parts_D * 16 * 4)); HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4, s)); }
+    if (use_xf) { HIPCHK(b_ssq.alloc_pooled(cx, (size_t)parts_D * 16 * 4 * n_grp)); HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4 * n_grp, s)); }
     if (tail_logits_ready)      // first generated token of every utterance + the first step's input (and, XF step, its folded first RMSNorm)
         HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, b_h.as<float>(), s,
-                                         use_xf ? b_xf1.as<uint16_t>() : nullptr, use_xf ? m->dec[0].attn_norm : nullptr, use_xf ? b_ssq.as<float>() : nullptr));
+                                         use_xf ? b_xf1.as<uint16_t>() : nullptr, use_xf ? m->dec[0].attn_norm : nullptr, use_xf ? b_ssq.as<float>() : nullptr,
+                                         (long)(xf_bytes(D) / 2), parts_D * 16));
     auto step = [&]() -> int32_t {
         float* h = b_h.as<float>(); float* xn = b_xn.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>(); float* act = b_act.as<float>();
         if (use_xf) {
-            uint16_t* xf1 = b_xf1.as<uint16_t>(); uint16_t* xf2 = b_xf2.as<uint16_t>(); uint16_t* xf3 = b_xf3.as<uint16_t>(); float* ssq = b_ssq.as<float>();
             for (int l = 0; l < c.dec_layers; l++) {
-                const DecLayer& L = m->dec[l]; float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;
-                { GemmParams g{}; g.w = L.wqkv.w; g.xf = (const uint4*)xf1; g.M = n; g.out = qkv; g.out_stride = W;
-                  g.ssq_part = ssq; g.n_part = l == 0 ? 1 : parts_D; g.norm_eps = c.norm_eps;
-                  g.pos = d_pos; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd;
-                  HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, s)); }
-                AttnParams ap{}; ap.q = qkv; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
-                ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
-                ap.out_xf = xf2;
-                HIPCHK(launch_attn_decode(ap, hd, max_seq, s, n));
-                { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D;
-                  g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, s)); }
-                { GemmParams g{}; g.w = L.w13.w; g.xf = (const uint4*)xf1; g.M = n; g.out = (float*)xf3; g.out_stride = F;
-                  g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU_XF, s)); }
-                { GemmParams g{}; g.w = L.w2.w; g.xf = (const uint4*)xf3; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D;
-                  g.xf_out = xf1; g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, s)); }
+                const DecLayer& L = m->dec[l];
+                for (int gi = 0; gi < n_grp; gi++) {
+                    const int r0 = gi * 16, ng = std::min(16, n - r0);
+                    uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)gi * (xf_bytes(QD) / 2);
+                    uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)gi * (xf_bytes(F) / 2); float* ssq = b_ssq.as<float>() + (size_t)gi * parts_D * 16;
+                    float* hg = h + (size_t)r0 * D; float* qg = qkv + (size_t)r0 * W; const int* pg = d_pos + r0;
+                    float* kl = b_k.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride;
+                    { GemmParams g{}; g.w = L.wqkv.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = qg; g.out_stride = W;
+                      g.ssq_part = ssq; g.n_part = l == 0 ? 1 : parts_D; g.norm_eps = c.norm_eps;
+                      g.pos = pg; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd;
+                      HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, s)); }
+                    AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
+                    ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = pg; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
+                    ap.out_xf = xf2;
+                    HIPCHK(launch_attn_decode(ap, hd, max_seq, s, ng));
+                    { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
+                      g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, s)); }
+                    { GemmParams g{}; g.w = L.w13.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = (float*)xf3; g.out_stride = F;
+                      g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU_XF, s)); }
+                    { GemmParams g{}; g.w = L.w2.w; g.xf = (const uint4*)xf3; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
+                      g.xf_out = xf1; g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, s)); }
+                }
             }
-            { GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)xf1; g.M = n; g.out = b_logits.as<float>(); g.out_stride = V;
-              g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+            for (int gi = 0; gi < n_grp; gi++) {
+                const int r0 = gi * 16, ng = std::min(16, n - r0);
+                GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)(b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2)); g.M = ng; g.out = b_logits.as<float>() + (size_t)r0 * V; g.out_stride = V;
+                g.ssq_part = b_ssq.as<float>() + (size_t)gi * parts_D * 16; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, s));
+            }
             HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s,
-                                             xf1, m->dec[0].attn_norm, ssq));
+                                             b_xf1.as<uint16_t>(), m->dec[0].attn_norm, b_ssq.as<float>(), (long)(xf_bytes(D) / 2), parts_D * 16));
             return VOX_OK;
         }
         for (int l = 0; l < c.dec_layers; l++) {

@@ -128,7 +128,8 @@ hipError_t launch_rope_kv_batch(float* qkv, int n, int stride, int n_q, int n_kv
                                 float* kcache, float* vcache, long seq_stride, int head_stride, hipStream_t s);
 hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int* tokens, int tok_stride, int* pos, const int* seq_len, Q4W tok,
                                      const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s,
-                                     uint16_t* xf = nullptr, const float* xf_w = nullptr, float* ssq_out = nullptr);   // xf: also h * xf_w as XF planes + sum of squares
+                                     uint16_t* xf = nullptr, const float* xf_w = nullptr, float* ssq_out = nullptr,     // xf: also h * xf_w as XF planes + sum of squares,
+                                     long xf_group_stride = 0, int ssq_group_stride = 0);                                 // per group of 16 sequences (strides in elements)
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
 hipError_t launch_gelu(float* x, long n, hipStream_t s);
 

@@ -2332,7 +2332,8 @@ hipError_t launch_rope_kv_batch(float* qkv, int n, int stride, int n_q, int n_kv
 __global__ __launch_bounds__(1024) void argmax_embed_batch_kernel(const float* __restrict__ logits, int vocab, int* __restrict__ tokens,
                                                                  int tok_stride, int* __restrict__ pos, const int* __restrict__ seq_len, Q4W tok,
                                                                  const float* __restrict__ audio, long audio_seq_stride, int D, float* __restrict__ h,
-                                                                 uint16_t* __restrict__ xf, const float* __restrict__ xf_w, float* __restrict__ ssq_out) {
+                                                                 uint16_t* __restrict__ xf, const float* __restrict__ xf_w, float* __restrict__ ssq_out,
+                                                                 long xf_group_stride, int ssq_group_stride) {
     __shared__ float bv[1024];
     __shared__ int bi[1024];
     __shared__ int s_tok, s_cur;
@@ -2362,26 +2363,30 @@ __global__ __launch_bounds__(1024) void argmax_embed_batch_kernel(const float* _
     }
     __syncthreads();
     embed_row(tok, s_tok, audio + (size_t)sq * audio_seq_stride + (size_t)s_cur * D, h + (size_t)sq * D, D);
-    if (xf) {     // the first layer's RMSNorm folded in: XF planes of h * gamma and the row's sum of squares (one partial)
+    if (xf) {     // the first layer's RMSNorm folded in: XF planes of h * gamma and the row's sum of squares (one partial);
+        // sequences are processed in groups of 16 rows, each group with its own XF planes / partial-sum block
+        xf += (size_t)(sq >> 4) * xf_group_stride; ssq_out += (size_t)(sq >> 4) * ssq_group_stride;
+        const int row = sq & 15;
         __syncthreads();
         float ss = 0.f;
         for (int c = threadIdx.x; c < (D >> 2); c += nt) {
             float4 v = reinterpret_cast<const float4*>(h + (size_t)sq * D)[c]; const float4 gm = reinterpret_cast<const float4*>(xf_w)[c];
             ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
-            xf_store4(xf, D, sq, 4 * c, v);
+            xf_store4(xf, D, row, 4 * c, v);
         }
         ss = wave_sum(ss);
         __syncthreads();
         if ((threadIdx.x & 63) == 0) bv[threadIdx.x >> 6] = ss;
         __syncthreads();
-        if (threadIdx.x == 0) { float a = 0.f; for (int w = 0; w < (nt >> 6); w++) a += bv[w]; ssq_out[sq] = a; }
+        if (threadIdx.x == 0) { float a = 0.f; for (int w = 0; w < (nt >> 6); w++) a += bv[w]; ssq_out[row] = a; }
     }
 }
 hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int* tokens, int tok_stride, int* pos, const int* seq_len, Q4W tok,
                                      const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s,
-                                     uint16_t* xf, const float* xf_w, float* ssq_out) {
-    argmax_embed_batch_kernel<<<dim3(n), dim3(1024), 0, s>>>(logits, vocab, tokens, tok_stride, pos, seq_len, tok, audio, audio_seq_stride, D, h, xf, xf_w, ssq_out);
+                                     uint16_t* xf, const float* xf_w, float* ssq_out, long xf_group_stride, int ssq_group_stride) {
+    argmax_embed_batch_kernel<<<dim3(n), dim3(1024), 0, s>>>(logits, vocab, tokens, tok_stride, pos, seq_len, tok, audio, audio_seq_stride, D, h, xf, xf_w, ssq_out,
+                                                             xf_group_stride, ssq_group_stride);
     return hipGetLastError();
 }
 
