@@ -67,6 +67,8 @@ struct vox_ctx {
     // tens of ms and serialise the device; buffers are handed back after the call's final stream synchronisation
     struct PoolEntry { void* p; size_t cap; bool used; };
     std::vector<PoolEntry> pool;
+    // side streams + fork/join events: independent 16-row groups of a wide batched decode step run concurrently
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 };
 
 static int32_t ctx_bind(const vox_ctx* c) { HIPCHK(hipSetDevice(c->device)); return VOX_OK; }
@@ -89,6 +91,8 @@ extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
     for (void* p : {(void*)c->d_window, (void*)c->d_cos, (void*)c->d_sin, (void*)c->d_fb, (void*)c->d_fb_lo, (void*)c->d_fb_hi, (void*)c->d_scale})
         if (p) (void)hipFree(p);
     for (auto& e : c->pool) (void)hipFree(e.p);
+    for (int i = 0; i < 3; i++) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     (void)hipStreamDestroy(c->stream);
     delete c; return VOX_OK;
 }
@@ -1384,34 +1388,45 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     auto step = [&]() -> int32_t {
         float* h = b_h.as<float>(); float* xn = b_xn.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>(); float* act = b_act.as<float>();
         if (use_xf) {
-            for (int l = 0; l < c.dec_layers; l++) {
-                const DecLayer& L = m->dec[l];
-                for (int gi = 0; gi < n_grp; gi++) {
-                    const int r0 = gi * 16, ng = std::min(16, n - r0);
-                    uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)gi * (xf_bytes(QD) / 2);
-                    uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)gi * (xf_bytes(F) / 2); float* ssq = b_ssq.as<float>() + (size_t)gi * parts_D * 16;
-                    float* hg = h + (size_t)r0 * D; float* qg = qkv + (size_t)r0 * W; const int* pg = d_pos + r0;
+            // groups are independent sequences: group gi > 0 runs its whole layer chain on a side stream (fork / join with events, which
+            // a stream capture records as parallel graph branches), so the latency-bound skinny kernels of different groups overlap
+            const bool fork = n_grp > 1 && !getenv("VOX_BATCH_SERIAL_GROUPS");
+            if (fork) {
+                if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+                for (int i = 0; i < n_grp - 1 && i < 3; i++) {
+                    if (!cx->aux[i]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking));
+                    if (!cx->ev_join[i]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[i], hipEventDisableTiming));
+                }
+                HIPCHK(hipEventRecord(cx->ev_fork, s));
+                for (int i = 0; i < n_grp - 1 && i < 3; i++) HIPCHK(hipStreamWaitEvent(cx->aux[i], cx->ev_fork, 0));
+            }
+            for (int gi = 0; gi < n_grp; gi++) {
+                hipStream_t sg = (fork && gi > 0) ? cx->aux[gi - 1] : s;
+                const int r0 = gi * 16, ng = std::min(16, n - r0);
+                uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)gi * (xf_bytes(QD) / 2);
+                uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)gi * (xf_bytes(F) / 2); float* ssq = b_ssq.as<float>() + (size_t)gi * parts_D * 16;
+                float* hg = h + (size_t)r0 * D; float* qg = qkv + (size_t)r0 * W; const int* pg = d_pos + r0;
+                for (int l = 0; l < c.dec_layers; l++) {
+                    const DecLayer& L = m->dec[l];
                     float* kl = b_k.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride;
                     { GemmParams g{}; g.w = L.wqkv.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = qg; g.out_stride = W;
                       g.ssq_part = ssq; g.n_part = l == 0 ? 1 : parts_D; g.norm_eps = c.norm_eps;
                       g.pos = pg; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd;
-                      HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, s)); }
+                      HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, sg)); }
                     AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
                     ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = pg; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
                     ap.out_xf = xf2;
-                    HIPCHK(launch_attn_decode(ap, hd, max_seq, s, ng));
+                    HIPCHK(launch_attn_decode(ap, hd, max_seq, sg, ng));
                     { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
-                      g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, s)); }
+                      g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
                     { GemmParams g{}; g.w = L.w13.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = (float*)xf3; g.out_stride = F;
-                      g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU_XF, s)); }
+                      g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU_XF, sg)); }
                     { GemmParams g{}; g.w = L.w2.w; g.xf = (const uint4*)xf3; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
-                      g.xf_out = xf1; g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, s)); }
+                      g.xf_out = xf1; g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
                 }
-            }
-            for (int gi = 0; gi < n_grp; gi++) {
-                const int r0 = gi * 16, ng = std::min(16, n - r0);
-                GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)(b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2)); g.M = ng; g.out = b_logits.as<float>() + (size_t)r0 * V; g.out_stride = V;
-                g.ssq_part = b_ssq.as<float>() + (size_t)gi * parts_D * 16; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, s));
+                { GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = b_logits.as<float>() + (size_t)r0 * V; g.out_stride = V;
+                  g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, sg)); }
+                if (fork && gi > 0) { HIPCHK(hipEventRecord(cx->ev_join[gi - 1], sg)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[gi - 1], 0)); }
             }
             HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s,
                                              b_xf1.as<uint16_t>(), m->dec[0].attn_norm, b_ssq.as<float>(), (long)(xf_bytes(D) / 2), parts_D * 16));
