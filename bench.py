@@ -12,7 +12,9 @@ of audio length (no EOS), so throughput does not depend on weight values.
     python bench.py --gpus N --steps K --warmup W
 N > 1: one rank per GPU (torch.distributed.run), independent utterances per rank ("weak" scaling), rank 0
 parses the GGUF and the packed weight arena reaches the other ranks through one RCCL broadcast; there is no
-collective in the data path.  Rank 0 prints ONE JSON line.
+collective in the data path.  Rank 0 prints ONE JSON line.  At N = 1 the line also carries `batch` (BASELINE configs[3]: 16 clips
+through vox_transcribe_batch; an extra, never `value`), `roofline` (dominant decode kernel, HIP events + committed PMC traffic) and
+`cpu_baseline` (the CPU oracle on a bounded sample).
 """
 from __future__ import annotations
 
