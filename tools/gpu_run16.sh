@@ -35,5 +35,8 @@ json.dump({"source": "profiles/r01_pmc_gemv_traffic.txt (rocprofv3 --pmc FETCH_S
            "hbm_bytes_per_launch": out}, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_batch -o b16 -- env VOX_BATCH_NO_GRAPH=1 python $REPO/tools/batch_prof.py 16 > $REPO/gpurun_out/prof_batch.log 2>&1
+cd $REPO
 timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
 tail -2 gpurun_out/bench_n1.err; cat gpurun_out/bench_n1.json
