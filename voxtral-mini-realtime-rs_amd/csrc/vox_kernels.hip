@@ -2020,8 +2020,141 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
         else *reinterpret_cast<float4*>(orow + h * HD + tid * 4) = r4;
     }
 }
+// Batched decode (many sequences): one workgroup per (KV head, sequence) serves all G = n_heads / n_kv_heads query heads of the
+// group, so every K / V row is fetched from L2 once instead of G times (512 -> 128 workgroups at 16 sequences, a quarter of the
+// traffic).  Measured: neutral for one group of 16 sequences, +3 % at 64 sequences (four concurrent groups) -- used for wide batches only.  Same structure: all K loads of the
+// first 160 keys up front, softmax through LDS, V loads issued before the softmax, P.V reduced across 8 key groups.
+template <int G>
+__global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const AttnParams p) {
+    constexpr int HD = 128, PER = HD / 8, NPRE = 5, COLS = HD / 4, GROUPS = 256 / COLS;   // GROUPS = 8
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // scores [G][max_seq]
+    __shared__ float red[2 * G * 4];
+    __shared__ float4 osum[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kvh = blockIdx.x, seq = blockIdx.y, max_seq = p.kv_head_stride / HD;
+    const int pos = (p.pos_ptr ? p.pos_ptr[p.pos_per_seq ? seq : 0] : 0) + p.offset;
+    const int len = pos + 1;
+    const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0;
+    const int n = len - j_lo;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const float* kb = p.k + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const float* vb = p.v + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const float* qrow = p.q + (size_t)seq * p.q_seq_stride + (size_t)kvh * G * HD;
+    const int ks = tid >> 3, part = tid & 7;
+    const int grp = tid / COLS, col = tid % COLS;
+    float4 kpre[NPRE][PER / 4];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        const int jc = j_lo + min(32 * u + ks, n - 1);
+        const float* kr = kb + (size_t)jc * p.kv_row_stride + part * PER;
+#pragma unroll
+        for (int e = 0; e < PER / 4; e++) kpre[u][e] = *reinterpret_cast<const float4*>(kr + 4 * e);
+    }
+    float4 qv[G][PER / 4];
+#pragma unroll
+    for (int hh = 0; hh < G; hh++)
+#pragma unroll
+        for (int e = 0; e < PER / 4; e++) qv[hh][e] = *reinterpret_cast<const float4*>(qrow + hh * HD + part * PER + 4 * e);
+#define VOX_SCORE(KR_, I_)                                                                                      \
+    _Pragma("unroll") for (int hh = 0; hh < G; hh++) {                                                          \
+        float s_ = 0.f;                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < PER / 4; e++) {                                                   \
+            const float4 kv = KR_[e], qq = qv[hh][e];                                                           \
+            s_ = fmaf(qq.x, kv.x, s_); s_ = fmaf(qq.y, kv.y, s_); s_ = fmaf(qq.z, kv.z, s_); s_ = fmaf(qq.w, kv.w, s_); \
+        }                                                                                                       \
+        s_ = group8_sum(s_);                                                                                    \
+        if (part == 0 && (I_) < n) smem[hh * max_seq + (I_)] = s_ * scale;                                      \
+    }
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) { const int i = 32 * u + ks; VOX_SCORE(kpre[u], i) }
+    for (int i0 = 32 * NPRE; i0 < n; i0 += 32) {
+        const int i = i0 + ks, jc = j_lo + min(i, n - 1);
+        float4 kr[PER / 4];
+#pragma unroll
+        for (int e = 0; e < PER / 4; e++) kr[e] = *reinterpret_cast<const float4*>(kb + (size_t)jc * p.kv_row_stride + part * PER + 4 * e);
+        VOX_SCORE(kr, i)
+    }
+#undef VOX_SCORE
+    // V rows of the first NPRE*32 keys: in flight while the softmax runs
+    float4 vpre[NPRE][4];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int ic = min(u * 32 + grp + w * GROUPS, n - 1);
+            vpre[u][w] = *reinterpret_cast<const float4*>(vb + (size_t)(j_lo + ic) * p.kv_row_stride + col * 4);
+        }
+    __syncthreads();
+    float mx[G], sum[G];
+#pragma unroll
+    for (int hh = 0; hh < G; hh++) {
+        float m_ = -INFINITY;
+        for (int i = tid; i < n; i += 256) m_ = fmaxf(m_, smem[hh * max_seq + i]);
+        m_ = wave_max(m_);
+        if (lane == 0) red[hh * 4 + wave] = m_;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < G; hh++) {
+        mx[hh] = fmaxf(fmaxf(red[hh * 4], red[hh * 4 + 1]), fmaxf(red[hh * 4 + 2], red[hh * 4 + 3]));
+        float s_ = 0.f;
+        for (int i = tid; i < n; i += 256) { const float e = expf(smem[hh * max_seq + i] - mx[hh]); smem[hh * max_seq + i] = e; s_ += e; }
+        s_ = wave_sum(s_);
+        if (lane == 0) red[G * 4 + hh * 4 + wave] = s_;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < G; hh++) sum[hh] = (red[G * 4 + hh * 4] + red[G * 4 + hh * 4 + 1]) + (red[G * 4 + hh * 4 + 2] + red[G * 4 + hh * 4 + 3]);
+    float4 o[G];
+#pragma unroll
+    for (int hh = 0; hh < G; hh++) o[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NPRE; u++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int i = u * 32 + grp + w * GROUPS, ic = min(i, n - 1);
+            const float4 vv = vpre[u][w];
+#pragma unroll
+            for (int hh = 0; hh < G; hh++) {
+                const float pr = i < n ? smem[hh * max_seq + ic] : 0.f;
+                o[hh].x = fmaf(pr, vv.x, o[hh].x); o[hh].y = fmaf(pr, vv.y, o[hh].y); o[hh].z = fmaf(pr, vv.z, o[hh].z); o[hh].w = fmaf(pr, vv.w, o[hh].w);
+            }
+        }
+    for (int i0 = 32 * NPRE + grp; i0 < n; i0 += GROUPS) {
+        const float4 vv = *reinterpret_cast<const float4*>(vb + (size_t)(j_lo + i0) * p.kv_row_stride + col * 4);
+#pragma unroll
+        for (int hh = 0; hh < G; hh++) {
+            const float pr = smem[hh * max_seq + i0];
+            o[hh].x = fmaf(pr, vv.x, o[hh].x); o[hh].y = fmaf(pr, vv.y, o[hh].y); o[hh].z = fmaf(pr, vv.z, o[hh].z); o[hh].w = fmaf(pr, vv.w, o[hh].w);
+        }
+    }
+#pragma unroll
+    for (int hh = 0; hh < G; hh++) {
+        __syncthreads();
+        osum[tid] = o[hh];
+        __syncthreads();
+        if (tid < COLS) {
+            float4 t = osum[tid];
+#pragma unroll
+            for (int gq = 1; gq < GROUPS; gq++) { const float4 u = osum[gq * COLS + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            const float inv = 1.0f / sum[hh];
+            const float4 r4 = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+            const int h = kvh * G + hh;
+            if (p.out_xf) xf_store4(p.out_xf, p.n_heads * HD, seq, h * HD + tid * 4, r4);
+            else *reinterpret_cast<float4*>(p.out + (size_t)seq * p.out_seq_stride + h * HD + tid * 4) = r4;
+        }
+    }
+}
 hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq) {
     const size_t lds = (size_t)max_seq * sizeof(float);
+    if (hd == 128 && p.prefer_gqa && p.n_heads == 4 * p.n_kv_heads && p.kv_head_stride == max_seq * 128 && !env_int("VOX_ATTN_NO_GQA")) {
+        auto kern = attn_decode_gqa_kernel<4>;      // many sequences: one workgroup per (KV head, sequence), K/V fetched once for its 4 query heads
+        static bool attr_done = false;
+        hipError_t e = ensure_dyn_lds(kern, 4 * lds, &attr_done);
+        if (e != hipSuccess) return e;
+        kern<<<dim3(p.n_kv_heads, n_seq), dim3(256), 4 * lds, s>>>(p);
+        return hipGetLastError();
+    }
     if (hd == 128) {
         auto kern = attn_decode_kernel<128>;
         static bool attr_done = false;
