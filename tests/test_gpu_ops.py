@@ -194,3 +194,21 @@ def test_attention_vs_oracle(pkg, orc, ctx, M, kv, H, KV, hd, off, win):
     assert err < 2e-5, err
     with pytest.raises(pkg.VoxError):
         attention(ctx, q, k, v, H, KV, offset=kv, window=win)       # queries outside the key range
+
+
+@pytest.mark.parametrize("m,k,n", [(1001, 1280, 6144), (2344, 2048, 1280 + 48), (700, 5120, 10240)])
+def test_q4_gemm_big_kernel_matches_tile_kernel(pkg, orc, ctx, monkeypatch, m, k, n):
+    """Large-M MFMA GEMM (64x256 tiles, tile-ordered weights, bit-trick B fragments + -136 correction MFMA) against the 32x128 kernel on
+    ragged M / N edges, and a row sample against the oracle's sequential-k f32 sums."""
+    rng = np.random.default_rng(m + n)
+    q = pkg.synth.synth_q4_blocks(rng, n * k, 0.02); w = pkg.Q4Tensor.from_q4_bytes(q, [n, k], ctx)
+    x = rng.standard_normal((1, m, k)).astype(np.float32)
+    monkeypatch.setenv("VOX_GEMM_BIG", "1"); big = pkg.q4_matmul(x, w)
+    monkeypatch.setenv("VOX_GEMM_BIG", "-1"); old = pkg.q4_matmul(x, w)
+    monkeypatch.delenv("VOX_GEMM_BIG")
+    scale = np.abs(old).max()
+    assert np.abs(big - old).max() < 2e-5 * scale
+    rows = [0, 63, 64, m - 1]
+    ref = orc.q4_matmul(q, n, k, x[:, rows])
+    assert np.abs(big[:, rows] - ref).max() < 2e-5 * scale
+    w.close()
