@@ -1384,6 +1384,8 @@ static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) 
     int ks = nq >= 4 ? 4 : (nq >= 2 ? 2 : 1);
     if (tiles / ntw < 256 && nq >= 16) ks = 8;                        // profiles/r01_skinny_sweep.txt
     { const int e = env_int("VOX_SKINNY_NTW"); if (e == 1 || e == 2 || e == 4) ntw = e; }
+    { const char* f = getenv("VOX_SKINNY_FORCE");      // measurement knob "N:ntw:ks": override for one weight shape only
+      if (f) { int fn = 0, fw = 0, fk = 0; if (sscanf(f, "%d:%d:%d", &fn, &fw, &fk) == 3 && fn == p.w.N && (fw == 1 || fw == 2 || fw == 4) && (fk == 1 || fk == 2 || fk == 4 || fk == 8)) { ntw = fw; ks = fk; } } }
     if (epi == EPI_RESID_XF) ntw = 1;       // its partial sums of squares are per workgroup = per 16-column tile
     { const int e = env_int("VOX_SKINNY_KS"); if (e == 1 || e == 2 || e == 4 || e == 8) ks = e; }
     const bool tiled = p.w.qt && p.w.st && !env_int("VOX_SKINNY_NO_TILE");
