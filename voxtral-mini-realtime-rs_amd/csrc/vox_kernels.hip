@@ -1180,13 +1180,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
             for (int i = 0; i < 4; i++) {
                 const bf16x8 ah = as_bf16x8(blds[(j * MTB + wm * 4 + i) * 64 + lane]);
                 const bf16x8 al = as_bf16x8(blds[PLANE + (j * MTB + wm * 4 + i) * 64 + lane]);
+#ifdef VOX_ABL_BIG_NOCS      /* measurement build: results wrong, shows what the correction MFMAs cost */
+                f32x4 cs = (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
                 f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, m136, cs, 0, 0, 0);
+#endif
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
+#ifdef VOX_ABL_BIG_NOFMA
+                    f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bf[t], acc[t][i], 0, 0, 0);
+#else
                     f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bf[t], cs, 0, 0, 0);
+#endif
                     tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bf[t], tt, 0, 0, 0);
+#ifdef VOX_ABL_BIG_NOFMA     /* measurement build: accumulate in the matrix core, no block scale */
+                    acc[t][i] = tt;
+#else
                     acc[t][i] = __builtin_elementwise_fma((f32x4){d[t], d[t], d[t], d[t]}, tt, acc[t][i]);
+#endif
                 }
             }
         }
