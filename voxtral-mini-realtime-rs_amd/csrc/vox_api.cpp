@@ -1415,7 +1415,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
                       HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, sg)); }
                     AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
                     ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = pg; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
-                    ap.out_xf = xf2; ap.prefer_gqa = n_grp > 1 || getenv("VOX_ATTN_GQA") != nullptr;
+                    ap.out_xf = xf2; ap.prefer_gqa = n_grp > 1 || getenv("VOX_ATTN_GQA") != nullptr; ap.no_xcd_remap = getenv("VOX_ATTN_NO_XCD") != nullptr;
                     HIPCHK(launch_attn_decode(ap, hd, max_seq, sg, ng));
                     { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
                       g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }

@@ -1913,7 +1913,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     static_assert(HD == 128 || HD == 64, "head_dim");
     constexpr int PER = HD / 8;       // floats per lane in the score phase
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, kvh = h / (p.n_heads / p.n_kv_heads), seq = blockIdx.y;
+    // Many sequences: hardware deals workgroups round-robin to the 8 XCDs (each with its own L2) by linear id, which would scatter the
+    // G query heads that share one KV head over G different L2s.  Re-map so that they occupy consecutive slots of ONE XCD: the K / V rows
+    // are then fetched from HBM / MALL once and hit in L2 for the other G-1 heads.
+    int h = blockIdx.x, seq = blockIdx.y;
+    {
+        const int G_ = p.n_heads / p.n_kv_heads, total = gridDim.x * gridDim.y;
+        if (gridDim.y > 1 && G_ > 1 && total % (8 * G_) == 0 && !p.no_xcd_remap) {
+            const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+            const int pair = xcd * (total / (8 * G_)) + slot / G_;                 // (kv head, sequence) pair index
+            h = (pair % p.n_kv_heads) * G_ + slot % G_; seq = pair / p.n_kv_heads;
+        }
+    }
+    const int kvh = h / (p.n_heads / p.n_kv_heads);
     const int pos = (p.pos_ptr ? p.pos_ptr[p.pos_per_seq ? seq : 0] : 0) + p.offset;
     const int len = pos + 1;
     const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0;
