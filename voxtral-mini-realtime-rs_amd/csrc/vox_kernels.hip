@@ -1919,7 +1919,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     int h = blockIdx.x, seq = blockIdx.y;
     {
         const int G_ = p.n_heads / p.n_kv_heads, total = gridDim.x * gridDim.y;
-        if (gridDim.y > 1 && G_ > 1 && total % (8 * G_) == 0 && !p.no_xcd_remap) {
+        if (G_ > 1 && total % (8 * G_) == 0 && !p.no_xcd_remap) {
             const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
             const int pair = xcd * (total / (8 * G_)) + slot / G_;                 // (kv head, sequence) pair index
             h = (pair % p.n_kv_heads) * G_ + slot % G_; seq = pair / p.n_kv_heads;
