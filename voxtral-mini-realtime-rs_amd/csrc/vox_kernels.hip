@@ -1719,11 +1719,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     uint16_t* Vh = Kl + 64 * KROW;       // [HD][VROW keys]   transposed, bf16 hi
     uint16_t* Vl = Vh + HD * VROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, kvh = h / (p.n_heads / p.n_kv_heads);
-    // stacked sequences (gridDim.z): sequence z owns rows [z*seq stride ..) of q / out / k / v and has seq_len[z] rows
-    const int sq = blockIdx.z;
+    // XCD-aware order: all query blocks of one (head, sequence) read the same K / V; the hardware deals workgroups round-robin to the
+    // 8 XCDs by linear id, so (head, sequence) pairs are dealt to XCDs and a pair's query blocks take consecutive slots of its XCD.
+    int bx = blockIdx.x, h = blockIdx.y, sq = blockIdx.z;       // stacked sequences (gridDim.z): sequence z owns rows [z*seq stride ..)
+    {
+        const int nblk = gridDim.x, pairs = gridDim.y * gridDim.z;
+        if (nblk > 1 && pairs % 8 == 0) {
+            const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * nblk + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+            const int pair = xcd * (pairs >> 3) + slot / nblk;
+            bx = slot % nblk; h = pair % (int)gridDim.y; sq = pair / (int)gridDim.y;
+        }
+    }
+    const int kvh = h / (p.n_heads / p.n_kv_heads);
     const int M = p.seq_len ? p.seq_len[sq] : p.M, kv_len = p.seq_len ? p.offset + M : p.kv_len;
-    const int m0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 64;    // causal: late query blocks have the most keys -- dispatch them first
+    const int m0 = ((int)gridDim.x - 1 - bx) * 64;                 // causal: late query blocks have the most keys -- dispatch them first
     if (m0 >= M) return;                                           // whole workgroup (ragged batch)
     const int m = m0 + wave * 16 + c;
     const int mq = min(m, M - 1);
