@@ -793,7 +793,7 @@ int orc_transcribe_streaming(const orc_model* m, const float* mel, int T, const 
         if (logits_out) memcpy(logits_out + (size_t)n * V, lg, sizeof(float) * V);
         n++;
     }
-    int n_ids = S - PREFIX_LEN;
+    int n_ids = n;   /* = max(S - 38, 1): at S == 38 the reference still returns the first predicted token (model.rs:922-926, loop :938 empty) */
     for (int i = 0; i < n_ids && i < cap; i++) out_ids[i] = gen[PREFIX_LEN + i];
     g_dec_ms = now_ms() - t0;
     orc_cache_free(kc); free(audio); free(gen); free(x); free(h); free(lg);

@@ -31,6 +31,7 @@ GOLDEN_SEED = 20260924
 
 
 def import_reference():
+    from transformers.audio_utils import mel_filter_bank as hf_bank      # before the stubs below (transformers probes for mistral_common)
     for name in ["mistral_common", "mistral_common.tokens", "mistral_common.tokens.tokenizers",
                  "mistral_common.tokens.tokenizers.mistral", "mistral_common.protocol",
                  "mistral_common.protocol.transcription", "mistral_common.protocol.transcription.request",
@@ -41,6 +42,12 @@ def import_reference():
     sys.modules["mistral_common.protocol.transcription.request"].StreamingMode = object
     sys.modules["mistral_common.protocol.instruct.chunk"].RawAudio = object
     sys.modules["mistral_common.audio"].Audio = object
+    # compute_mel (:62-98) imports mistral_common.audio.mel_filter_bank inside the function: the Slaney-scale, Slaney-normalised bank.
+    # mistral-common is not installed; transformers.audio_utils.mel_filter_bank (installed) is the implementation mistral-common's was
+    # taken from -- same formula, selected by norm="slaney", mel_scale="slaney"; the reference's own Rust bank follows it (mel.rs:260-339)
+    sys.modules["mistral_common.audio"].mel_filter_bank = lambda num_frequency_bins, num_mel_bins, min_frequency, max_frequency, sampling_rate: \
+        hf_bank(num_frequency_bins=num_frequency_bins, num_mel_filters=num_mel_bins, min_frequency=min_frequency, max_frequency=max_frequency,
+                sampling_rate=sampling_rate, norm="slaney", mel_scale="slaney")
     spec = importlib.util.spec_from_file_location("ref_proper_inference", REF)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
@@ -63,7 +70,13 @@ def golden_inputs():
     dec_x = (0.5 * rng.standard_normal((12, 256))).astype(np.float32)           # decoder inputs (audio+text embeds), 12 positions
     norm_x = rng.standard_normal((5, 96)).astype(np.float32); norm_w = (1 + 0.1 * rng.standard_normal(96)).astype(np.float32)
     rope_x = rng.standard_normal((1, 7, 3, 64)).astype(np.float32)
-    return dict(mel=mel, dec_x=dec_x, norm_x=norm_x, norm_w=norm_w, rope_x=rope_x)
+    # audio for the log-mel fixture: 1.3 s of the SURVEY 8(d) synthetic clip recipe (two tones + noise, fades), peak 0.95, already padded
+    # the way the pipeline pads (32 left-pad tokens of silence here: the python script uses mistral-common's 32, not the Rust 76)
+    n = 20800; tt = np.arange(n) / 16000.0
+    a = 0.3 * np.sin(2 * np.pi * 220.0 * tt) + 0.2 * np.sin(2 * np.pi * (440.0 + 30.0 * tt) * tt) + 0.05 * rng.standard_normal(n)
+    a[:800] *= np.linspace(0, 1, 800); a[-800:] *= np.linspace(1, 0, 800); a *= 0.95 / np.abs(a).max()
+    mel_audio = np.concatenate([np.zeros(32 * 1280), a, np.zeros(1280 - n % 1280 + 17 * 1280)]).astype(np.float32)
+    return dict(mel=mel, dec_x=dec_x, norm_x=norm_x, norm_w=norm_w, rope_x=rope_x, mel_audio=mel_audio)
 
 
 def main():
@@ -81,6 +94,7 @@ def main():
         out["rope"] = ref.apply_rope(torch.from_numpy(inp["rope_x"]), cos, sin).numpy()
         out["time_embedding_6"] = ref.time_embedding(torch.tensor([6.0]), dim=256).numpy()[0]
         out["time_embedding_full"] = ref.time_embedding(torch.tensor([6.0]), dim=3072).numpy()[0]
+        out["log_mel"] = ref.compute_mel(inp["mel_audio"]).numpy()                                     # [128, T] (:62-98)
         out["encoder_out"] = ref.run_encoder(torch.from_numpy(inp["mel"]), f).numpy()[0]              # [10, 256]
         x = torch.from_numpy(inp["dec_x"]).unsqueeze(0)
         t_embed = ref.time_embedding(torch.tensor([6.0]), dim=256)                                     # [1, 256]

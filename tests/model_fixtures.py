@@ -74,3 +74,22 @@ def check_greedy_ids(ids, rids, rlg, tol):
     srt = np.sort(rlg[first]); margin = srt[-1] - srt[-2]
     assert margin <= 10 * tol * max(1.0, float(np.abs(rlg).max())), f"ids differ at step {first} with a clear margin {margin}"
     return first
+
+
+def single_stream_reference(pkg, ctx, model, x, t_embed):
+    """(ids, logits) of the single-stream EAGER path (logits tap) for 16 kHz samples x: the per-sequence reference the batched paths are
+    held to -- same device log-mel kernel as the batch path, then vox_transcribe_streaming with return_logits."""
+    mel = pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x)))
+    return model.transcribe_streaming(np.ascontiguousarray(mel.T)[None], t_embed, return_logits=True)
+
+
+def check_batch_rows(pkg, ctx, model, clips, t_embed, outs, tol):
+    """Every sequence of a batched transcription must equal the single-stream ids up to the first near-tie of ITS OWN single-stream logits
+    (top-2 margin < 10 x tol x max|logit|); returns how many sequences are identical end to end."""
+    assert len(outs) == len(clips)
+    identical = 0
+    for x, ids in zip(clips, outs):
+        rids, rlg = single_stream_reference(pkg, ctx, model, x, t_embed)
+        first = check_greedy_ids(ids, rids, rlg, tol)
+        identical += int(first == len(rids))
+    return identical

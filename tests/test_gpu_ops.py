@@ -154,6 +154,17 @@ def test_log_mel_vs_oracle(pkg, orc, ctx):
     assert mel.compute_log(np.zeros(100, np.float32)).shape == (0, 128)
 
 
+def test_log_mel_vs_reference_python_golden(pkg, ctx):
+    """The HIP mel kernel against the reference's own PyTorch front-end (scripts/test_proper_inference.py:62-98 compute_mel), fixture from
+    tests/golden/make_golden.py; tolerance 5e-4 absolute on the log-mel (<0.1 % of the values above 1e-4: torch's f32 FFT rounds at low-power bins) (the reference's own fixture tolerance is 1e-2, mel.rs:608-613)."""
+    from model_fixtures import golden
+    g = golden()
+    out = pkg.MelSpectrogram.voxtral(ctx).compute_log(g["in_mel_audio"])
+    assert out.shape == g["out_log_mel"].T.shape
+    d = np.abs(out - g["out_log_mel"].T)
+    assert d.max() < 5e-4 and (d > 1e-4).mean() < 1e-3, d.max()
+
+
 @pytest.mark.parametrize("m,k,n", [(16, 128, 16), (16, 128, 384), (7, 256, 130), (16, 3072, 512), (9, 9216, 96), (16, 4096, 40), (5, 256, 1000), (13, 1280, 2048), (16, 5120, 272)])
 def test_q4_skinny_batched_decode_gemm(pkg, orc, ctx, m, k, n):
     """5..16 rows (one per sequence of a decode batch) x K % 128 == 0: the skinny MFMA kernel (split-K across waves,

@@ -48,3 +48,17 @@ def test_decoder_matches_reference_python(orc):
     assert orc.lib().orc_cache_len(c) == 12
     assert np.abs(np.concatenate([h1] + hs) - hid).max() < 1e-5
     m.cache_free(c); m.close()
+
+
+def test_log_mel_matches_reference_python(orc):
+    """Pins the oracle's log-mel VALUES to the reference's own PyTorch front-end (scripts/test_proper_inference.py:62-98 compute_mel:
+    torch.stft with the periodic Hann window, power spectrum without the last frame, Slaney bank, log10 / max(-6.5) / (x+4)/4), run on
+    an already-padded clip by tests/golden/make_golden.py.  The reference's Rust test pins its mel to the same kind of fixture at 1e-2
+    (mel.rs:608-613); f32 STFT vs the oracle's f64-accumulated DFT agree far tighter."""
+    g = golden()
+    ref = g["out_log_mel"]                                  # [128][T]
+    out = orc.mel_compute_log(g["in_mel_audio"])            # [T][128]
+    assert out.shape == ref.T.shape == (g["in_mel_audio"].size // 160, 128)
+    d = np.abs(out - ref.T)
+    assert d.max() < 5e-4 and (d > 1e-4).mean() < 1e-3, d.max()     # worst points: low-power bins next to the tones, where torch's f32 FFT rounds (2.3e-4)
+    assert (ref > -0.6).mean() > 0.2                        # the fixture is not all floor values

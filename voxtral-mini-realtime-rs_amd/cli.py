@@ -123,7 +123,8 @@ def main(argv=None):
                 x, sr = load_wav(p)
                 if sr != 16000:
                     x = resample_to_16k(x, sr)
-                x = pkg.peak_normalize(x, 0.95)
+                # NOT peak-normalised here: vox_transcribe_batch normalises on the device (absmax reduction + scale inside the mel
+                # kernel) exactly once, like the one-by-one path does on the host (transcribe.rs:207)
                 if not pkg.needs_chunking(x.size, chunk_cfg) and x.size > 0:
                     units.append((i, x))
             except Exception:

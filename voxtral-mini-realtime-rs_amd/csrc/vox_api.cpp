@@ -7,6 +7,7 @@
 #include "../../include/voxtral_hip.h"
 #include "vox_kernels.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -47,6 +48,29 @@ extern "C" int32_t vox_device_count(int32_t* n) {
     if (e != hipSuccess) { *n = 0; (void)hipGetLastError(); return VOX_OK; }
     *n = c; return VOX_OK;
 }
+
+// ---- roctx ranges with the reference's tracing span names (gguf/model.rs:784 "encode_audio", :878 "transcribe_streaming", :909 "prefill",
+// :936-937 "decode"): librocprofiler-sdk-roctx is resolved lazily so the library has no hard dependency on the profiler; without it the
+// calls are no-ops.  Under `rocprofv3 --marker-trace` the ranges attribute the kernel trace to the pipeline stages.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        if (getenv("VOX_NO_ROCTX")) return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA")); pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+}  // namespace
+static Roctx& roctx() { static Roctx r; return r; }
+static void roctx_push(const char* name) { Roctx& r = roctx(); if (r.push) (void)r.push(name); }
+static void roctx_pop() { Roctx& r = roctx(); if (r.pop) (void)r.pop(); }
+struct RoctxScope { explicit RoctxScope(const char* n) { roctx_push(n); } ~RoctxScope() { roctx_pop(); } };
+// consecutive stages of one function: begin() closes the previous stage; every exit path (error returns included) closes the open one
+struct RoctxStage { bool open = false; void begin(const char* n) { end(); roctx_push(n); open = true; } void end() { if (open) { roctx_pop(); open = false; } } ~RoctxStage() { end(); } };
 
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -331,23 +355,30 @@ static int32_t gguf_parse(vox_gguf* g, vox_gguf** out) {
         GTensor& t = g->tensors[i];
         t.name = c.str(); t.ndims = c.rd<uint32_t>();
         if (c.bad || t.ndims > 4) { vox_gguf_close(g); return fail(VOX_ERR_IO, "Failed to read tensor %llu", (unsigned long long)i); }
-        uint64_t ne = 1; for (uint32_t d = 0; d < t.ndims; d++) { t.dims[d] = c.rd<uint64_t>(); ne *= t.dims[d]; }
+        uint64_t ne = 1; bool ovf = false;
+        for (uint32_t d = 0; d < t.ndims; d++) { t.dims[d] = c.rd<uint64_t>(); if (__builtin_mul_overflow(ne, t.dims[d], &ne)) ovf = true; }
         t.dtype = c.rd<uint32_t>(); t.offset = c.rd<uint64_t>();
         if (c.bad) { vox_gguf_close(g); return fail(VOX_ERR_IO, "Failed to read tensor %llu", (unsigned long long)i); }
+        if (ovf || ne > (1ull << 60)) { std::string n = t.name; vox_gguf_close(g); return fail(VOX_ERR_IO, "tensor '%s' has an element count that overflows", n.c_str()); }
         if (t.dtype > 2) { uint32_t d = t.dtype; vox_gguf_close(g); return fail(VOX_ERR_IO, "Unsupported GGML dtype code: %u", d); }
         t.nbytes = t.dtype == 0 ? ne * 4 : t.dtype == 1 ? ne * 2 : (ne / 32) * 18;     // reader.rs:37-48
         g->index[t.name] = i;
     }
     g->data_off = (c.pos + 31) / 32 * 32;                                                // reader.rs:177-179
-    for (auto& t : g->tensors)
-        if (g->data_off + t.offset + t.nbytes > g->size) { std::string n = t.name; vox_gguf_close(g); return fail(VOX_ERR_IO, "tensor '%s' exceeds file size", n.c_str()); }
+    for (auto& t : g->tensors) {    // checked: a crafted offset / size must not wrap around the bounds test
+        uint64_t end = 0;
+        if (g->data_off > g->size || __builtin_add_overflow(g->data_off, t.offset, &end) || __builtin_add_overflow(end, t.nbytes, &end) || end > g->size) {
+            std::string n = t.name; vox_gguf_close(g); return fail(VOX_ERR_IO, "tensor '%s' exceeds file size", n.c_str());
+        }
+    }
     *out = g; return VOX_OK;
 }
 extern "C" int32_t vox_gguf_open(const char* path, vox_gguf** out) {
     ARGCHK(path && out, "null argument");
     int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(VOX_ERR_IO, "cannot open %s: %s", path, strerror(errno));
-    struct stat st; fstat(fd, &st);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 24) { close(fd); return fail(VOX_ERR_IO, "%s is not a GGUF file (stat failed or shorter than a header)", path); }
     void* mp = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0); close(fd);
     if (mp == MAP_FAILED) return fail(VOX_ERR_IO, "mmap of %s failed", path);
     vox_gguf* g = new vox_gguf(); g->map = (uint8_t*)mp; g->size = st.st_size; g->own = 1;
@@ -531,6 +562,7 @@ struct vox_model {
     // decode state
     vox_cache* cache = nullptr;                           // internal cache for transcribe_streaming
     int *d_tokens = nullptr, *d_pos = nullptr; int tokens_cap = 0;
+    float* d_prefix = nullptr;                            // [38][dec_dim] prefill inputs (transcribe_dev)
     int* d_seq_len = nullptr; std::vector<int> h_seq_len;  // per-utterance encoder rows of a stacked batch
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
     int n_parts = 0, argmax_R = 8;
@@ -602,7 +634,8 @@ struct SafeTensorsSource : TensorSource {
     int32_t open(const char* path) {
         int fd = ::open(path, O_RDONLY);
         if (fd < 0) return fail(VOX_ERR_IO, "cannot open %s: %s", path, strerror(errno));
-        struct stat st; fstat(fd, &st);
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 8) { close(fd); return fail(VOX_ERR_IO, "SafeTensors file too small"); }
         void* mp = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0); close(fd);
         if (mp == MAP_FAILED) return fail(VOX_ERR_IO, "mmap of %s failed", path);
         map = (uint8_t*)mp; size = st.st_size;
@@ -873,7 +906,7 @@ static void model_release(vox_model* m) {
     if (m->graph) (void)hipGraphDestroy(m->graph);
     if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len})
+                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -991,6 +1024,7 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     const int* d_len = nullptr;
     if (n > 1) {
         HIPCHK(hipMemsetAsync(x, 0, (size_t)Mtot * D * 4, s));               // scratch rows: finite values
+        HIPCHK(hipMemsetAsync(att, 0, (size_t)Mtot * QD * 4, s));            // rows >= seq_len[i] are never written by attention
         if (!m->d_seq_len) HIPCHK(hipMalloc((void**)&m->d_seq_len, 64 * sizeof(int)));
         m->h_seq_len.assign(S.begin(), S.end());
         HIPCHK(hipMemcpyAsync(m->d_seq_len, m->h_seq_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
@@ -1141,10 +1175,10 @@ static int32_t ensure_decode_state(vox_model* m, int S) {
         if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
         VOXCHK(cache_alloc(m, cap, &m->cache));
     }
-    if (m->tokens_cap < S + 2) {
-        if (m->d_tokens) HIPCHK(hipFree(m->d_tokens));
-        m->tokens_cap = std::max(S + 2, 1024); HIPCHK(hipMalloc((void**)&m->d_tokens, (size_t)m->tokens_cap * 4));
-    }
+    // token buffer: allocated ONCE for the longest admissible sequence (S <= dec_rope_len) -- the captured decode graph bakes this
+    // pointer into argmax_embed_kernel, so it must never move while a graph is alive
+    if (!m->d_tokens) { m->tokens_cap = m->dec_rope_len + 2; HIPCHK(hipMalloc((void**)&m->d_tokens, (size_t)m->tokens_cap * 4)); }
+    ARGCHK(S + 2 <= m->tokens_cap, "sequence of %d decoder positions exceeds the token buffer", S);
     return VOX_OK;
 }
 
@@ -1165,31 +1199,37 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     const int PREFIX_LEN = 38, BOS = 1, STREAMING_PAD = 32;
     VOXCHK(vox_model_set_t_embed(m, t_embed));
     double t0 = now_ms();
+    RoctxScope whole("transcribe_streaming"); RoctxStage stage;
+    stage.begin("encode_audio");
     int S = 0; VOXCHK(encode_dev(m, d_mel, T, &S));
     HIPCHK(hipStreamSynchronize(s));                       // e2e_bench.rs:161-167 forces a sync here too
+    stage.end();
     m->timings.encode_ms = now_ms() - t0; t0 = now_ms();
     *n_ids = 0; m->timings.decode_tokens = 0; m->timings.graph_replays = 0;
     if (S < PREFIX_LEN) { m->timings.decode_ms = 0; return VOX_OK; }               // model.rs:887-889
-    ARGCHK(cap >= S - PREFIX_LEN, "out_ids capacity %d < %d", cap, S - PREFIX_LEN);
+    const int n = std::max(S - PREFIX_LEN, 1);                                      // S == 38: prefill + first token only (model.rs:922-926,938)
+    ARGCHK(cap >= n, "out_ids capacity %d < %d", cap, n);
     VOXCHK(ensure_decode_state(m, S));
     std::vector<int32_t> prefix(PREFIX_LEN, STREAMING_PAD); prefix[0] = BOS;      // model.rs:891-892
     HIPCHK(hipMemcpyAsync(m->d_tokens, prefix.data(), PREFIX_LEN * 4, hipMemcpyHostToDevice, s));
     m->cache->len = 0;
     // prefix inputs = audio[:38] + embed(prefix)  (model.rs:896-902)
-    const size_t need = (size_t)PREFIX_LEN * c.dec_dim;
-    DevBuf px; HIPCHK(px.alloc(need * 4));
-    HIPCHK(launch_embed(m->tok.w, m->d_tokens, PREFIX_LEN, m->d_audio, c.dec_dim, nullptr, 0, 0, px.as<float>(), s));
-    VOXCHK(decoder_prefill_dev(m, px.as<float>(), PREFIX_LEN, m->cache, 0));
+    if (!m->d_prefix) HIPCHK(hipMalloc((void**)&m->d_prefix, (size_t)PREFIX_LEN * c.dec_dim * 4));   // model-owned: no hipMalloc/hipFree in the timed path
+    float* px = m->d_prefix;
+    stage.begin("prefill");
+    HIPCHK(launch_embed(m->tok.w, m->d_tokens, PREFIX_LEN, m->d_audio, c.dec_dim, nullptr, 0, 0, px, s));
+    VOXCHK(decoder_prefill_dev(m, px, PREFIX_LEN, m->cache, 0));
     m->cache->len = PREFIX_LEN;
     // lm_head on the last prefix row only (the reference computes all 38 and keeps the last, model.rs:916-923)
     DevBuf dlog; float* d_logits_all = nullptr;
-    if (logits_host) { HIPCHK(dlog.alloc((size_t)(S - PREFIX_LEN) * c.vocab * 4)); d_logits_all = dlog.as<float>(); }
-    VOXCHK(lm_head_argmax_dev(m, px.as<float>() + (size_t)(PREFIX_LEN - 1) * c.dec_dim, d_logits_all));
+    if (logits_host) { HIPCHK(dlog.alloc((size_t)n * c.vocab * 4)); d_logits_all = dlog.as<float>(); }
+    VOXCHK(lm_head_argmax_dev(m, px + (size_t)(PREFIX_LEN - 1) * c.dec_dim, d_logits_all));
     const int pos_init = PREFIX_LEN;
     HIPCHK(hipMemcpyAsync(m->d_pos, &pos_init, 4, hipMemcpyHostToDevice, s));
     HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, m->n_parts, m->d_tokens, m->d_pos, 0, 0, s));   // tokens[38]
-    HIPCHK(launch_embed(m->tok.w, m->d_tokens, 1, m->d_audio, c.dec_dim, m->d_pos, 0, 0, m->d_h, s));        // input of the first decode step
-    const int steps = S - PREFIX_LEN - 1;                                         // pos = 39 .. S-1 (model.rs:938)
+    const int steps = std::max(S - PREFIX_LEN - 1, 0);                            // pos = 39 .. S-1 (model.rs:938)
+    stage.begin("decode");
+    if (steps > 0) HIPCHK(launch_embed(m->tok.w, m->d_tokens, 1, m->d_audio, c.dec_dim, m->d_pos, 0, 0, m->d_h, s));   // input of the first decode step (audio[38] exists iff S >= 39)
     if (logits_host) {
         for (int i = 0; i < steps; i++) VOXCHK(decode_step_enqueue(m, d_logits_all + (size_t)(i + 1) * c.vocab));
     } else if (steps > 0) {
@@ -1212,11 +1252,11 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
             m->timings.graph_replays = steps;
         }
     }
-    const int n = S - PREFIX_LEN;
     HIPCHK(hipMemcpyAsync(out_ids, m->d_tokens + PREFIX_LEN, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     if (logits_host) HIPCHK(hipMemcpyAsync(logits_host, d_logits_all, (size_t)n * c.vocab * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    m->cache->len = S - 1;
+    stage.end();
+    m->cache->len = PREFIX_LEN + steps;
     *n_ids = n; m->timings.decode_tokens = n;
     m->timings.decode_ms = now_ms() - t0;
     return VOX_OK;
@@ -1299,14 +1339,18 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         ARGCHK(samples[i] && n_samples[i] > 0, "empty audio in batch slot %d", i);
         const size_t left = pad_left(&pc), total = left + n_samples[i] + pad_right(&pc, n_samples[i] + left);
         T[i] = (int)(total / 160); S[i] = conv_len(conv_len(T[i])) / c.reshape_factor; Smax = std::max(Smax, S[i]);
-        ARGCHK(caps[i] >= std::max(S[i] - PREFIX_LEN, 0), "out_ids[%d] capacity %d < %d", i, caps[i], S[i] - PREFIX_LEN);
+        const int cnt_i = S[i] >= PREFIX_LEN ? std::max(S[i] - PREFIX_LEN, 1) : 0;     // S == 38 still emits its first token (model.rs:922-926)
+        ARGCHK(caps[i] >= cnt_i, "out_ids[%d] capacity %d < %d", i, caps[i], cnt_i);
     }
     ARGCHK(Smax <= m->dec_rope_len, "sequence too long for the decoder RoPE table");
     const int max_seq = std::max((Smax + 63) / 64 * 64, 64), tstride = std::max(Smax, PREFIX_LEN) + 2;
     const int audio_rows = std::max(enc_row_budget(m, T.data(), n) / c.reshape_factor, PREFIX_LEN + 1);   // per-utterance row budget of the stacked audio embeddings
     const size_t seq_stride = (size_t)KV * max_seq * hd, layer_stride = (size_t)n * seq_stride;
     size_t mel_floats = 0; for (int i = 0; i < n; i++) mel_floats += (size_t)128 * T[i];
-    DevBuf b_audio, b_k, b_v, b_tok, b_pos, b_len, b_h, b_xn, b_qkv, b_att, b_act, b_logits, b_px, b_mel, b_scale, b_smp;
+    DevBuf b_audio, b_k, b_v, b_tok, b_pos, b_len, b_h, b_xn, b_qkv, b_att, b_act, b_logits, b_px, b_mel, b_scale, b_smp, b_xf1, b_xf2, b_xf3, b_ssq;
+    // pooled buffers go back to the pool in the DevBuf destructors: on EVERY exit path (early error returns included) the main and side
+    // streams are drained first (this guard is declared after the buffers, so it is destroyed before them)
+    struct Drain { vox_ctx* c; ~Drain() { (void)hipStreamSynchronize(c->stream); for (auto a : c->aux) if (a) (void)hipStreamSynchronize(a); } } drain{cx};
     HIPCHK(b_audio.alloc_pooled(cx, (size_t)n * audio_rows * D * 4)); HIPCHK(b_k.alloc_pooled(cx, layer_stride * c.dec_layers * 4)); HIPCHK(b_v.alloc_pooled(cx, layer_stride * c.dec_layers * 4));
     HIPCHK(b_tok.alloc_pooled(cx, (size_t)n * tstride * 4)); HIPCHK(b_pos.alloc_pooled(cx, (size_t)n * 4)); HIPCHK(b_len.alloc_pooled(cx, (size_t)n * 4));
     HIPCHK(b_h.alloc_pooled(cx, (size_t)n * D * 4)); HIPCHK(b_xn.alloc_pooled(cx, (size_t)n * D * 4)); HIPCHK(b_qkv.alloc_pooled(cx, (size_t)n * W * 4)); HIPCHK(b_att.alloc_pooled(cx, (size_t)n * QD * 4));
@@ -1347,7 +1391,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     std::vector<int> pos0(n), len(n);
     for (int i = 0; i < n; i++) {
         prefix[(size_t)i * tstride] = BOS; for (int r = 1; r < PREFIX_LEN; r++) prefix[(size_t)i * tstride + r] = STREAMING_PAD;
-        pos0[i] = PREFIX_LEN - 1; len[i] = S[i] >= PREFIX_LEN ? S[i] : 0;          // pos = index of the last token written so far
+        pos0[i] = PREFIX_LEN - 1; len[i] = S[i] >= PREFIX_LEN ? std::max(S[i], PREFIX_LEN + 1) : 0;   // pos = index of the last token written so far; S == 38 writes tokens[38]
     }
     HIPCHK(hipMemcpyAsync(d_tok, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_pos, pos0.data(), (size_t)n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
@@ -1371,7 +1415,6 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     const bool use_xf = m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !getenv("VOX_BATCH_NO_XF");
     const int n_grp = (n + 15) / 16;
     auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
-    DevBuf b_xf1, b_xf2, b_xf3;
     if (use_xf) {
         HIPCHK(b_xf1.alloc_pooled(cx, xf_bytes(D) * n_grp)); HIPCHK(b_xf2.alloc_pooled(cx, xf_bytes(QD) * n_grp)); HIPCHK(b_xf3.alloc_pooled(cx, xf_bytes(F) * n_grp));
         HIPCHK(hipMemsetAsync(b_xf1.p, 0, xf_bytes(D) * n_grp, s)); HIPCHK(hipMemsetAsync(b_xf2.p, 0, xf_bytes(QD) * n_grp, s)); HIPCHK(hipMemsetAsync(b_xf3.p, 0, xf_bytes(F) * n_grp, s));
@@ -1379,7 +1422,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     // XF step: 4 launches per layer and group.  RMSNorm never runs as a kernel: its producer (residual epilogue / token embedding) writes
     // x*gamma as XF planes plus partial sums of squares, its consumer scales the accumulators by rstd (a per-row scalar commutes with the
     // GEMM); RoPE + KV-cache write are the q|k|v GEMM's epilogue.
-    DevBuf b_ssq; const int parts_D = q4_skinny_resid_xf_parts(D);
+    const int parts_D = q4_skinny_resid_xf_parts(D);
     if (use_xf) { HIPCHK(b_ssq.alloc_pooled(cx, (size_t)parts_D * 16 * 4 * n_grp)); HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4 * n_grp, s)); }
     if (tail_logits_ready)      // first generated token of every utterance + the first step's input (and, XF step, its folded first RMSNorm)
         HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, b_h.as<float>(), s,
@@ -1474,7 +1517,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     if (graph) (void)hipGraphDestroy(graph);
     int total = 0;
     for (int i = 0; i < n; i++) {
-        const int cnt = std::max(S[i] - PREFIX_LEN, 0);
+        const int cnt = S[i] >= PREFIX_LEN ? std::max(S[i] - PREFIX_LEN, 1) : 0;
         if (cnt > 0) std::memcpy(out_ids[i], host_tok.data() + (size_t)i * tstride + PREFIX_LEN, (size_t)cnt * 4);
         n_ids[i] = cnt; total += cnt;
     }

@@ -327,7 +327,7 @@ class Q4VoxtralModel:
         return out[:S.value].reshape(1, S.value, self.config.dec_dim).copy()
 
     def transcribe_streaming(self, mel, t_embed, return_logits=False):
-        """-> list[int] of length S-38 (gguf/model.rs:873-963)"""
+        """-> ids of length max(S-38, 1) for S >= 38 decoder positions, empty below (gguf/model.rs:873-963)"""
         mel = _f32(mel); mel = mel.reshape(mel.shape[-2], mel.shape[-1]); T = mel.shape[1]
         cap = T // 16 + 2
         ids = np.zeros(cap, dtype=np.int32); n = C.c_int32()
