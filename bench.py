@@ -10,11 +10,16 @@ random Q4_0 in the real GGUF layout (no checkpoint is available offline); token 
 of audio length (no EOS), so throughput does not depend on weight values.
 
     python bench.py --gpus N --steps K --warmup W
-N > 1: one rank per GPU (torch.distributed.run), independent utterances per rank ("weak" scaling), rank 0
-parses the GGUF and the packed weight arena reaches the other ranks through one RCCL broadcast; there is no
-collective in the data path.  Rank 0 prints ONE JSON line.  At N = 1 the line also carries `batch` (BASELINE configs[3]: 16 clips
-through vox_transcribe_batch; an extra, never `value`), `roofline` (dominant decode kernel, HIP events + committed PMC traffic) and
-`cpu_baseline` (the CPU oracle on a bounded sample).
+N > 1: one rank per GPU.  Launched by the driver through torch.distributed.run (RANK / WORLD_SIZE in the environment), or -- when
+WORLD_SIZE is not set -- bench.py re-executes ITSELF through the same launcher (shard.spawn_ranks) after checking that the box has N
+GPUs; it fails loudly otherwise.  Independent utterances per rank ("weak" scaling: every rank transcribes its own clip each step),
+rank 0 parses the GGUF and the packed weight arena reaches the other ranks through ONE RCCL broadcast; no collective in the data path.
+Rank 0 prints ONE JSON line.  Extras in the same line (never `value`):
+  `batch`       BASELINE configs[3]: 16 clips through vox_transcribe_batch (N = 1)
+  `f32`         BASELINE configs[1]: the same clip through the f32 SafeTensors path (dense bf16 weights, N = 1)
+  `fleurs_like` BASELINE configs[4] stand-in: 647 clips with FLEURS-like durations sharded LPT over the ranks, 16-clip batches per rank
+                (replaces bin/transcribe.rs:112-126's serial loop); aggregate RTF, tok/s, LPT imbalance (every N)
+  `roofline`    dominant decode kernel, HIP events on the library stream + committed PMC traffic;  `cpu_baseline`  CPU oracle, bounded sample
 """
 from __future__ import annotations
 
@@ -76,6 +81,63 @@ def cpu_baseline(pkg, gguf_path, seconds):
             "rtf": round(total / seconds, 3), "total_s": round(total, 2)}
 
 
+def f32_extra(pkg, ctx, t_embed, seconds, reps=3):
+    """BASELINE configs[1]: the bench clip through the f32 SafeTensors path (VoxtralModelLoader; bf16 checkpoint exact on device,
+    f32 activations and accumulation).  Parity of this exact model + clip: tests/test_gpu_fullsize.py::test_full_16s_clip_f32_vs_oracle_golden."""
+    from model_fixtures import full_dense_safetensors
+    t0 = time.time(); st = full_dense_safetensors(7); t_gen = time.time() - t0
+    t0 = time.time(); m = pkg.VoxtralModelLoader.from_file(st).load(ctx); t_load = time.time() - t0
+    x = pkg.synth.synth_audio(seconds, seed=1234); dx = ctx.upload(x)
+    ids = m.transcribe_audio(None, t_embed, device_ptr=dx, n_samples=x.size)      # warm-up (graph capture)
+    ctx.synchronize(); tb = time.perf_counter(); st_ms = {"preprocess_ms": 0.0, "encode_ms": 0.0, "decode_ms": 0.0}
+    for _ in range(reps):
+        ids = m.transcribe_audio(None, t_embed, device_ptr=dx, n_samples=x.size)
+        tm = m.timings()
+        for k in st_ms:
+            st_ms[k] += tm[k] / reps
+    ctx.synchronize(); dt = (time.perf_counter() - tb) / reps
+    wb = m.weight_bytes(); ctx.free(dx); m.close()
+    n = len(ids)
+    return {"workload": f"single {seconds:g} s clip, f32 SafeTensors path (BASELINE configs[1]): synthetic BF16 checkpoint, dense bf16 weights on device, f32 arithmetic",
+            "tok_per_s": round(n / dt, 1), "ms_per_clip": round(dt * 1e3, 2), "rtf": round(dt / seconds, 5), "ids_per_clip": n,
+            "decode_tok_per_s_ref_def": round(n / (st_ms["decode_ms"] / 1e3), 1), "stage_ms": {k: round(v, 3) for k, v in st_ms.items()},
+            "weight_bytes": wb, "decode_step_weight_GBps": round(wb / 1e9 / (st_ms["decode_ms"] / 1e3 / max(n, 1)), 1) if st_ms["decode_ms"] > 0 else None,
+            "checkpoint_write_s": round(t_gen, 1), "load_s": round(t_load, 1)}
+
+
+def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch):
+    """BASELINE configs[4] stand-in (no FLEURS offline): `n_clips` synthetic clips with FLEURS-like durations, LPT-sharded over the ranks
+    (shard.run_sharded), each rank running 16-clip length-bucketed batches through vox_transcribe_batch; results gathered in input order.
+    Wall time = barrier .. barrier, max over ranks.  Replaces the reference's serial per-file loop (bin/transcribe.rs:112-126)."""
+    import importlib
+    shard = importlib.import_module(pkg.__name__ + ".shard")
+    durs = shard.fleurs_like_durations(n_clips, seed=7)
+    parts = shard.lpt_partition(durs, world)
+    clips = {i: pkg.synth.synth_audio(durs[i], seed=9000 + i) for i in parts[rank]}      # every rank synthesises only its share (host, untimed)
+
+    def batch_work(idx_list):
+        outs = model.transcribe_batch([clips[i] for i in idx_list], t_embed)
+        return [len(o) for o in outs]
+
+    model.transcribe_batch([clips[i] for i in parts[rank][:min(batch, len(parts[rank]))]], t_embed)      # warm-up: workspaces + kernels
+    if world > 1:
+        dist.barrier()
+    ctx.synchronize(); t0 = time.perf_counter()
+    res = shard.run_sharded(list(range(n_clips)), durs, None, rank, world, batch=batch, batch_work=batch_work)
+    ctx.synchronize(); dt = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    if rank != 0:
+        return None
+    total_s = float(sum(durs)); ntok = int(sum(res))
+    return {"workload": f"{n_clips} synthetic clips, FLEURS-like log-normal durations (median 10 s, 3..30 s, rng 7), host samples -> ids; LPT shards over {world} rank(s), "
+                        f"{batch}-clip length-bucketed batches (BASELINE configs[4] stand-in; no FLEURS / WER offline)",
+            "clips": n_clips, "audio_s": round(total_s, 1), "wall_s": round(dt, 3), "rtf": round(dt / total_s, 6), "tok_per_s": round(ntok / dt, 1),
+            "ids": ntok, "lpt_imbalance": round(shard.imbalance(durs, parts), 4), "batch": batch}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,10 +148,26 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("VOX_CPU_BASELINE_S", "1.0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=16, help="also report BASELINE configs[3] (B utterances through vox_transcribe_batch) at N=1; 0 = skip")
+    ap.add_argument("--no-f32", action="store_true", help="skip the f32 SafeTensors extra (BASELINE configs[1], N = 1)")
+    ap.add_argument("--fleurs-clips", type=int, default=647, help="clips of the FLEURS-like sharded extra (BASELINE configs[4] stand-in); 0 = skip")
     ap.add_argument("--gemv-iters", type=int, default=260)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by hand: spawn the N ranks ourselves, exactly the way the driver does
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            log(f"[bench] --gpus {args.gpus} requested but this box has {have} GPU(s): refusing to run (no silent single-rank fallback)")
+            sys.exit(2)
+        from __graft_entry__ import load_package
+        import importlib
+        shard = importlib.import_module(load_package().__name__ + ".shard")
+        sys.exit(shard.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} does not match --gpus {args.gpus}: refusing to run"); sys.exit(2)
     # torch first: it bundles its own libamdhip64; importing it before libvoxtral_hip.so keeps ONE HIP runtime in-process.
     import torch
     import torch.distributed as dist
@@ -111,7 +189,7 @@ def main():
     t0 = time.time()
     loader = pkg.Q4ModelLoader.from_file(path)
     if world > 1:
-        # rank 0 parses + repacks; the packed device arena reaches the other ranks by ONE RCCL broadcast over xGMI
+        # rank 0 parses + repacks; the packed device arena (row planes + tile-ordered copies) reaches the other ranks by ONE RCCL broadcast over xGMI
         model = loader.load(ctx, layout_only=(rank != 0))
         ptr, nbytes = model.arena()
         stage = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local}")
@@ -144,17 +222,28 @@ def main():
         for k in stage_ms:
             stage_ms[k] += tm[k]
     ctx.synchronize(); torch.cuda.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank_ms = [elapsed_local * 1e3 / max(args.steps, 1)]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank_ms = [float(v.item()) * 1e3 / max(args.steps, 1) for v in allt]
+        elapsed = max(float(v.item()) for v in allt)
     n_ids = int(len(ids))
     steps = max(args.steps, 1)
     for k in stage_ms:
         stage_ms[k] /= steps
     ms_per_step = elapsed * 1e3 / steps
     value = world * steps * n_ids / elapsed
+
+    fleurs = None
+    if args.fleurs_clips > 0:
+        try:
+            fleurs = fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, args.fleurs_clips, 16)
+        except Exception as e:     # an extra never costs the headline line
+            fleurs = {"error": str(e)} if rank == 0 else None
 
     out = None
     if rank == 0:
@@ -169,10 +258,13 @@ def main():
             "rtf": round(ms_per_step / 1e3 / args.seconds, 5),
             "decode_tok_per_s_ref_def": round(n_ids / (stage_ms["decode_ms"] / 1e3), 2) if stage_ms["decode_ms"] > 0 else None,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
             "load_s": round(load_s, 2), "weight_broadcast_s": round(bcast_s, 3), "weight_bytes": model.weight_bytes(),
             "note": "value = ids emitted by all ranks / max-over-ranks wall time of the whole pipeline; decode_tok_per_s_ref_def follows "
                     "bin/e2e_bench.rs:236-240 (ids / decode-stage time); vs_baseline divides by the reference's 19.4 tok/s measured on a DGX Spark GB10",
         }
+        if fleurs is not None:
+            out["fleurs_like"] = fleurs
         # ---- roofline of the dominant kernel: the fused gate/up Q4 GEMV (w1|w3, 26 launches per token), HIP events on our stream
         names = ["qkv", "wo", "w1w3", "w2", "lm_head"]; per = {}
         per_step_us = 0.0; per_step_bytes = 0.0
@@ -199,7 +291,8 @@ def main():
                            "all_decode_gemvs": per,
                            "decode_step_gemv_GBps": round(per_step_bytes / per_step_us / 1e3, 1),
                            "decode_step_algorithmic_bytes": int(per_step_bytes),
-                           "decode_step_measured_ms": round(stage_ms["decode_ms"] / max(n_ids, 1), 4)}
+                           "decode_step_measured_ms": round(stage_ms["decode_ms"] / max(n_ids, 1), 4),
+                           "decode_step_frac_of_hbm_peak": round(per_step_bytes / (stage_ms["decode_ms"] / 1e3 / max(n_ids, 1)) / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and args.batch > 1:
             # BASELINE configs[3]: B x 16 s utterances on one GPU -- stacked encoder (every GEMM once over all frames), stacked prefill,
             # one batched decode step per position (weights streamed once per step for the whole batch).  An extra, not `value`.
@@ -211,12 +304,20 @@ def main():
                 outs = model.transcribe_batch(None, t_embed, device_ptrs=ptrs, n_samples=lens)
             ctx.synchronize(); bdt = (time.perf_counter() - tb) / reps
             tmb = model.timings(); ntok = sum(len(o) for o in outs)
+            step_ms = tmb["decode_ms"] / max(ntok // args.batch, 1)
             out["batch"] = {"workload": f"{args.batch} x {args.seconds:g} s clips, Q4_0 (BASELINE configs[3])", "batch": args.batch,
                             "tok_per_s": round(ntok / bdt, 1), "ms_per_batch": round(bdt * 1e3, 2), "rtf": round(bdt / (args.seconds * args.batch), 5),
                             "stage_ms": {k: round(tmb[k], 2) for k in ("preprocess_ms", "encode_ms", "decode_ms")},
-                            "decode_step_weight_GBps": round(per_step_bytes / 1e9 / (tmb["decode_ms"] / 1e3 / max(ntok // args.batch, 1)), 1)}
+                            "decode_step_ms": round(step_ms, 4),
+                            "decode_step_weight_GBps": round(per_step_bytes / 1e9 / (step_ms / 1e3), 1),
+                            "decode_step_frac_of_hbm_peak": round(per_step_bytes / 1e9 / (step_ms / 1e3) / HBM_PEAK_GBS, 4)}
             for pp in ptrs:
                 ctx.free(pp)
+        if world == 1 and not args.no_f32:
+            try:
+                out["f32"] = f32_extra(pkg, ctx, t_embed, args.seconds)
+            except Exception as e:
+                out["f32"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(pkg, path, args.cpu_baseline_seconds)

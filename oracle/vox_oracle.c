@@ -557,7 +557,10 @@ static float* load_f32(orc_model* m, const char* name, int required) {
     uint64_t ne = 1; for (uint32_t d = 0; d < t->ndims; d++) ne *= t->dims[d];
     float* out = (float*)malloc(ne * sizeof(float)); const uint8_t* src = m->g->map + m->g->data_off + t->offset;
     if (t->dtype == 0) memcpy(out, src, ne * 4);
-    else for (uint64_t i = 0; i < ne; i++) { uint16_t h; memcpy(&h, src + 2 * i, 2); out[i] = f16_to_f32(h); }
+    else {
+        _Pragma("omp parallel for schedule(static)")
+        for (int64_t i = 0; i < (int64_t)ne; i++) { uint16_t h; memcpy(&h, src + 2 * i, 2); out[i] = f16_to_f32(h); }
+    }
     return own(m, out);
 }
 /* gguf/loader.rs:385-441 load_q4_linear(_with_optional_bias); dims reversed (:497-499) */

@@ -93,3 +93,19 @@ def check_batch_rows(pkg, ctx, model, clips, t_embed, outs, tol):
         first = check_greedy_ids(ids, rids, rlg, tol)
         identical += int(first == len(rids))
     return identical
+
+
+def dense_head_sha(path, nbytes=64 << 20):
+    """sha256 of the first 64 MB of a (8.9 GB) synthetic dense checkpoint: cheap identity check of the deterministic generator's output."""
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read(nbytes)).digest()
+
+
+def full_dense_safetensors(seed=7):
+    """The full-size synthetic BF16 SafeTensors checkpoint of the f32 path (8.9 GB, written in a few seconds, cached in the temp dir)."""
+    S = load_package().synth
+    st = os.path.join(cache_dir(), f"full_dense_seed{seed}.safetensors")
+    if not os.path.exists(st):
+        S.write_fast_dense_checkpoint(st + ".tmp", None, S.ModelDims(), seed=seed); os.replace(st + ".tmp", st)
+    return st

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from model_fixtures import cache_dir, check_batch_rows, check_greedy_ids, rel_err
+from model_fixtures import cache_dir, check_batch_rows, check_greedy_ids, dense_head_sha, full_dense_safetensors, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -174,3 +174,41 @@ def test_full_batch16_vs_oracle_golden(pkg, full):
         assert (o == outs[0]).all(), f"row {r} differs from row 0"
     tm = m.timings(); assert tm["decode_tokens"] == 16 * 108
     print(f"batch-16 golden: all 16 rows agree with the oracle for {stop}/108 steps ({int((outs[0] == rids).sum())} ids equal)")
+
+
+def test_full_16s_clip_f32_vs_oracle_golden(pkg):
+    """BASELINE configs[0-1] at FULL size: the f32 SafeTensors path (VoxtralModelLoader -> transcribe_f32_with_model, bin/transcribe.rs:362-438;
+    dense bf16 weights exact on device, f32 activations / accumulation) on the 16 s bench clip against the CPU oracle's golden
+    (tests/golden/make_fullsize_f32_golden.py, run once on the GPU box's host).  north_star: "greedy token IDs bit-exact on the f32 path" --
+    the count of identical ids is printed; a disagreement is only admissible at a near-tie of the oracle (top-2 margin < 10 x tolerance)."""
+    import hashlib
+    gp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_16s_f32_oracle.npz")
+    if not os.path.exists(gp):
+        pytest.skip("full-size f32 golden not generated yet (tests/golden/make_fullsize_f32_golden.py)")
+    g = np.load(gp)
+    st = full_dense_safetensors(int(g["seed"]))
+    assert os.path.getsize(st) == int(g["st_size"]) and dense_head_sha(st) == g["st_head_sha256"].tobytes()      # same weights
+    x = pkg.synth.synth_audio(16.0, seed=1234)
+    assert hashlib.sha256(x.tobytes()).digest() == g["audio_sha256"].tobytes()                                    # same clip
+    ctx = pkg.Context(0)
+    m = pkg.VoxtralModelLoader.from_file(st).load(ctx)
+    c = m.config
+    assert (c.enc_layers, c.enc_dim, c.dec_layers, c.dec_dim, c.dec_heads, c.dec_kv_heads, c.dec_ffn, c.vocab) == (32, 1280, 26, 3072, 32, 8, 9216, 131072)
+    t = pkg.TimeEmbedding(3072).embed(6.0)
+    mel = pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x)))
+    assert mel.shape[0] == int(g["mel_frames"])
+    ids, lg = m.transcribe_streaming(np.ascontiguousarray(mel.T)[None], t, return_logits=True)
+    rids, top1, top2, amax = g["ids"], g["top1"], g["top2"], float(g["logit_absmax"])
+    assert len(ids) == len(rids) == 108
+    agree = ids == rids
+    stop = len(ids) if agree.all() else int(np.argmin(agree))
+    if stop < len(ids):
+        assert top1[stop] - top2[stop] <= 10 * TOL * max(1.0, amax), f"f32 ids differ at step {stop} with a clear margin {top1[stop] - top2[stop]}"
+    assert stop >= 1
+    assert np.abs(lg[:stop].max(axis=1) - top1[:stop]).max() <= TOL * max(1.0, amax)
+    assert np.abs(lg[0, :4096] - g["logits_step0"]).max() <= TOL * max(1.0, amax)
+    ids_a = m.transcribe_audio(x, t)                                          # product path: device mel + graph replay
+    assert (ids_a[:stop] == rids[:stop]).all() and (m.transcribe_audio(x, t) == ids_a).all()
+    print(f"full-size f32 golden: {int(agree.sum())}/108 ids identical to the CPU oracle (first difference: {'none' if stop == 108 else stop}; "
+          f"min oracle top-2 margin {float((top1 - top2).min()):.4g})")
+    m.close(); ctx.close()

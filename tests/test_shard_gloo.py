@@ -76,3 +76,34 @@ def test_run_sharded_world2_gloo(pkg):
     for o in out0:
         name, rk = o.split(":rank")
         assert name in (seen0 if rk == "0" else seen1)
+
+
+def test_spawn_ranks_world2_gloo(pkg, tmp_path):
+    """The rank launcher behind `bench.py --gpus N` (shard.spawn_ranks -> torch.distributed.run, rendezvous on 127.0.0.1), world 2 on CPU."""
+    pytest.importorskip("torch")
+    import json, sys
+    shard = __import__("importlib").import_module(pkg.__name__ + ".shard")
+    out = tmp_path / "r0.json"
+    here = os.path.dirname(os.path.abspath(__file__))
+    rc = shard.spawn_ranks(2, os.path.join(here, "rank_worker.py"), [str(out), os.path.dirname(pkg.__file__)])
+    assert rc == 0
+    r = json.loads(out.read_text())
+    assert r["world"] == 2 and r["n"] == 37 and r["order_ok"] and r["ranks_used"] == [0, 1] and r["imbalance"] < 0.1
+    assert r["t_max"] >= 1.0                                   # max over ranks (rank 1 adds 1 s to its time)
+    d = shard.fleurs_like_durations()
+    assert len(d) == 647 and min(d) >= 3.0 and max(d) <= 30.0 and 9.0 < sorted(d)[323] < 11.0 and d == shard.fleurs_like_durations()
+
+
+def test_bench_gpus_flag_fails_loudly_without_enough_gpus():
+    """`python bench.py --gpus 2` on a box with fewer than 2 GPUs must refuse (exit code 2, message), not run one rank silently."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("2+ GPUs present")
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 2 and "refusing to run" in p.stderr and p.stdout.strip() == ""
+    env["WORLD_SIZE"] = "1"; env["RANK"] = "0"; env["LOCAL_RANK"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 2 and "does not match --gpus" in p.stderr

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of ONE graph-replayed decode step (measurement build: `python voxtral-mini-realtime-rs_amd/build.py timeline`,
+run with VOX_LIB=.../libvoxtral_hip_timeline.so, which this script selects itself).  Every q4_gemv / attn_decode launch of the step
+stamps s_memrealtime (100 MHz, chip-global) per wave at: 0 kernel entry, 1 activation vector staged (GEMV) / scores done (attention),
+2 first row group consumed (GEMV) / softmax done, 3 wave done.  Printed per kernel class, averaged over the 26 layers:
+gap = first wave entry - last wave exit of the previous kernel; skew = last entry - first entry; x = median(stamp1 - own entry);
+g1 = median(stamp2 - own entry); span = last exit - first entry (the kernel's in-flight time); all in microseconds."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("VOX_LIB", os.path.join(ROOT, "voxtral-mini-realtime-rs_amd", "libvoxtral_hip_timeline.so"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from __graft_entry__ import load_package
+pkg = load_package(); L = pkg.lib(); S = pkg.synth
+path = os.path.join(os.environ.get("VOX_BENCH_DIR", "/tmp"), "vox_bench_full_q4_seed42.gguf")
+if not os.path.exists(path):
+    S.write_synthetic_gguf(path + ".tmp", S.ModelDims(), seed=42); os.replace(path + ".tmp", path)
+ctx = pkg.Context(0); model = pkg.Q4ModelLoader.from_file(path).load(ctx)
+t = pkg.TimeEmbedding(3072).embed(6.0)
+x = S.synth_audio(float(os.environ.get("VOX_TL_SECONDS", "16")), seed=1234); dx = ctx.upload(x)
+NS, NW = 300, 3072
+pkg._lib.check(L.vox_debug_timeline_start(ctx.h, NS, NW))
+for _ in range(3):
+    ids = model.transcribe_audio(None, t, device_ptr=dx, n_samples=x.size)
+buf = np.zeros((NS, NW, 4), dtype=np.uint64); used = C.c_int32()
+pkg._lib.check(L.vox_debug_timeline_fetch(ctx.h, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(used)))
+tm = model.timings()
+print(f"ids {len(ids)}, decode {tm['decode_ms']:.2f} ms -> {tm['decode_ms'] / max(len(ids), 1) * 1e3:.1f} us per step (instrumented build); slots used {used.value}")
+per_step = 26 * 5 + 1
+first = used.value - per_step               # the captured step's slots are the last `per_step` taken
+assert first >= 0, used.value
+names = ["qkv", "attn", "wo", "w13", "w2"]
+TICK = 0.01   # us per s_memrealtime tick (100 MHz)
+rows = {n: [] for n in names + ["lm_head"]}
+prev_end = None; t_first = None
+for k in range(per_step):
+    b = buf[first + k].astype(np.int64); live = b[:, 0] > 0
+    if not live.any():
+        continue
+    s0, s1, s2, s3 = (b[live, i] for i in range(4))
+    t0 = s0.min(); t_first = t0 if t_first is None else t_first
+    name = "lm_head" if k == per_step - 1 else names[k % 5]
+    rows[name].append(dict(gap=(t0 - prev_end) * TICK if prev_end is not None else np.nan, skew=(s0.max() - t0) * TICK,
+                           x=float(np.median(s1 - s0)) * TICK, xmax=float((s1 - t0).max()) * TICK, g1=float(np.median(s2[s2 > 0] - s0[s2 > 0])) * TICK if (s2 > 0).any() else np.nan,
+                           span=(s3.max() - t0) * TICK, waves=int(live.sum()), med_wave=float(np.median(s3 - s0)) * TICK))
+    prev_end = s3.max()
+print(f"captured step: first entry -> last exit {(prev_end - t_first) * TICK:.1f} us")
+print(f"{'kernel':8s} {'n':>3s} {'waves':>6s} {'gap':>6s} {'skew':>6s} {'x_med':>6s} {'x_last':>7s} {'g1_med':>7s} {'wave':>6s} {'span':>6s}")
+tot = 0.0
+for n in names + ["lm_head"]:
+    r = rows[n]
+    if not r:
+        continue
+    m = {k: float(np.nanmean([e[k] for e in r])) for k in r[0]}
+    tot += (m["gap"] + m["span"]) * len(r)
+    print(f"{n:8s} {len(r):3d} {int(m['waves']):6d} {m['gap']:6.2f} {m['skew']:6.2f} {m['x']:6.2f} {m['xmax']:7.2f} {m['g1']:7.2f} {m['med_wave']:6.2f} {m['span']:6.2f}")
+print(f"sum of (gap + span) over the step: {tot:.1f} us")
+ctx.free(dx); model.close(); ctx.close()

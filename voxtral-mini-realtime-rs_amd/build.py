@@ -21,16 +21,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_all(verbose: bool = False, force: bool = False) -> str:
-    os.makedirs(os.path.join(PKG_DIR, "build"), exist_ok=True)
+def variant_lib_path(tag: str) -> str:
+    return os.path.join(PKG_DIR, f"libvoxtral_hip_{tag}.so")
+
+
+def build_all(verbose: bool = False, force: bool = False, tag: str | None = None, extra_flags=()) -> str:
+    """Product build (tag None): build/*.o -> libvoxtral_hip.so.  Measurement variants (`tag`, e.g. "timeline" with
+    extra_flags=["-DVOX_TIMELINE"]): build/<tag>/*.o -> libvoxtral_hip_<tag>.so, selected at run time with VOX_LIB=<that path>."""
+    bdir = os.path.join(PKG_DIR, "build", tag) if tag else os.path.join(PKG_DIR, "build")
+    lib_path = variant_lib_path(tag) if tag else LIB_PATH
+    os.makedirs(bdir, exist_ok=True)
     deps = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(PKG_DIR, "build", src.rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(bdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + deps):
-            jobs.append([HIPCC, *FLAGS, "-x", "hip", "-c", sp, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *extra_flags, "-x", "hip", "-c", sp, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -39,10 +47,16 @@ def build_all(verbose: bool = False, force: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB_PATH, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs])
-    return LIB_PATH
+    if jobs or force or _stale(lib_path, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs])
+    return lib_path
 
+
+VARIANTS = {"timeline": ["-DVOX_TIMELINE"]}      # measurement builds (tools/timeline.py)
 
 if __name__ == "__main__":
-    print(build_all(verbose=True))
+    import sys
+    if len(sys.argv) > 1:
+        print(build_all(verbose=True, tag=sys.argv[1], extra_flags=VARIANTS.get(sys.argv[1], sys.argv[2:])))
+    else:
+        print(build_all(verbose=True))

@@ -1613,3 +1613,25 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
     *avg_us = (double)ms * 1000.0 / iters;
     return VOX_OK;
 }
+
+// ---- measurement hook (timeline builds, -DVOX_TIMELINE): per-wave s_memrealtime stamps of every decode-step GEMV / attention launch
+static unsigned long long* g_tl_dev = nullptr; static int g_tl_nslots = 0, g_tl_nwaves = 0;
+extern "C" int32_t vox_debug_timeline_start(vox_ctx* c, int32_t n_slots, int32_t n_waves) {
+    ARGCHK(c && n_slots > 0 && n_waves > 0, "bad argument"); VOXCHK(ctx_bind(c));
+    if (g_tl_dev) { (void)tl_configure(nullptr, 0, 0); (void)hipFree(g_tl_dev); g_tl_dev = nullptr; }
+    const size_t bytes = (size_t)n_slots * n_waves * 4 * sizeof(unsigned long long);
+    HIPCHK(hipMalloc((void**)&g_tl_dev, bytes)); HIPCHK(hipMemset(g_tl_dev, 0, bytes));
+    if (tl_configure(g_tl_dev, n_slots, n_waves) != hipSuccess) { (void)hipFree(g_tl_dev); g_tl_dev = nullptr; return fail(VOX_ERR_UNSUPPORTED, "library built without -DVOX_TIMELINE"); }
+    g_tl_nslots = n_slots; g_tl_nwaves = n_waves; return VOX_OK;
+}
+extern "C" int32_t vox_debug_timeline_fetch(vox_ctx* c, uint64_t* out, size_t cap_words, int32_t* slots_used) {
+    ARGCHK(c && out && slots_used, "null argument"); VOXCHK(ctx_bind(c));
+    ARGCHK(g_tl_dev, "timeline not started");
+    const size_t words = (size_t)g_tl_nslots * g_tl_nwaves * 4;
+    ARGCHK(cap_words >= words, "timeline output buffer too small (%zu < %zu words)", cap_words, words);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, g_tl_dev, words * 8, hipMemcpyDeviceToHost));
+    *slots_used = tl_slots_used();
+    (void)tl_configure(nullptr, 0, 0); (void)hipFree(g_tl_dev); g_tl_dev = nullptr;
+    return VOX_OK;
+}

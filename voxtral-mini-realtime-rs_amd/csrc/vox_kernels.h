@@ -39,6 +39,7 @@ struct GemvParams {
     int n_q, n_k;                        // EPI_ROPE_KV: rows [0,n_q) q, [n_q,n_q+n_k) k, then v
     float* kcache; float* vcache; int cache_head_stride;    // [kv_head][max_seq][hd]
     float* part_val; int* part_idx;      // EPI_ARGMAX: per-workgroup (max, argmax)
+    int tl_slot;                         // timeline slot (measurement builds, -DVOX_TIMELINE; assigned by the launcher, -1 = off)
 };
 // rows_per_wave R in {1,2,4,8}; K tiles of 2048 chosen from K. Returns hipError_t.
 hipError_t launch_q4_gemv(const GemvParams& p, int n_rows_x, int pro, int epi, int R, hipStream_t s);
@@ -101,6 +102,7 @@ struct AttnParams {
     uint16_t* out_xf;     // batched decode: write the output rows (row = sequence) as XF fragment planes instead of out
     int prefer_gqa;       // batched decode: one workgroup per (KV head, sequence) serving its 4 query heads (wide batches)
     int no_xcd_remap;     // measurement knob: keep the linear (head, sequence) workgroup order in attn_decode_kernel
+    int tl_slot;          // timeline slot (measurement builds, -DVOX_TIMELINE)
 };
 hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n_seq = 1);     // M > 1, causal (+window)
 hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq = 1);  // M == 1 per sequence
@@ -134,5 +136,11 @@ hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int*
                                      long xf_group_stride = 0, int ssq_group_stride = 0);                                 // per group of 16 sequences (strides in elements)
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
 hipError_t launch_gelu(float* x, long n, hipStream_t s);
+
+// ---- timeline instrumentation (measurement builds only, -DVOX_TIMELINE): every q4_gemv / attn_decode launch gets the next slot and its
+// waves stamp s_memrealtime (100 MHz) at 4 points into buf[slot][wave][4]; under graph replay the captured slot is rewritten per replay.
+// Returns hipErrorNotSupported in product builds.
+hipError_t tl_configure(unsigned long long* buf, int n_slots, int n_waves);   // buf == nullptr: off
+int tl_slots_used();
 
 }  // namespace vox

@@ -22,6 +22,29 @@
 
 namespace vox {
 
+// ---- timeline instrumentation (measurement builds only) ------------------------------------------
+static int g_tl_next = -1, g_tl_slots = 0;
+#ifdef VOX_TIMELINE
+__device__ unsigned long long* g_tl_buf = nullptr;
+__device__ int g_tl_waves = 0;
+__device__ __forceinline__ void tl_stamp(int slot, int wave_global, int k) {
+    if (slot >= 0 && (threadIdx.x & 63) == 0 && g_tl_buf && wave_global < g_tl_waves)
+        g_tl_buf[((size_t)slot * g_tl_waves + wave_global) * 4 + k] = wall_clock64();
+}
+#define VOX_TL(slot, wave, k) tl_stamp(slot, wave, k)
+hipError_t tl_configure(unsigned long long* buf, int n_slots, int n_waves) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_tl_buf), &buf, sizeof buf); if (e != hipSuccess) return e;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_tl_waves), &n_waves, sizeof n_waves); if (e != hipSuccess) return e;
+    g_tl_next = buf ? 0 : -1; g_tl_slots = buf ? n_slots : 0;
+    return hipSuccess;
+}
+#else
+#define VOX_TL(slot, wave, k) ((void)0)
+hipError_t tl_configure(unsigned long long*, int, int) { return hipErrorNotSupported; }
+#endif
+int tl_slots_used() { return g_tl_next < 0 ? 0 : g_tl_next; }
+static int tl_take_slot() { if (g_tl_next < 0) return -1; if (g_tl_next >= g_tl_slots) return -1; return g_tl_next++; }
+
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
@@ -159,6 +182,7 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     // before the current group is consumed, so HBM stays busy while the VALU works.
     const int rnb = R * nb, n_groups = N / R, n_waves = gridDim.x * 4;
     int g = blockIdx.x * 4 + wave;
+    VOX_TL(p.tl_slot, blockIdx.x * 4 + wave, 0);
 
     // Every global load below is UNCONDITIONAL (indices are clamped, never predicated): a "cond ? load : 0"
     // makes hipcc branch around the load and drain vmcnt(0) per element, which serialises HBM round trips.
@@ -221,6 +245,7 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
         }
     }
     __syncthreads();
+    VOX_TL(p.tl_slot, blockIdx.x * 4 + wave, 1);
     // burn RmsNorm divides by sqrt(mean(x^2) + eps); we multiply by the reciprocal
     const float rstd = PRO != PRO_NONE ? 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + p.eps) : 1.0f;
 
@@ -308,6 +333,7 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     while (g < n_groups) {
         VOX_WLOAD(qb, db, min(g + n_waves, n_groups - 1))     // prefetch (clamped: harmless re-read at the tail)
         VOX_GROUP(qa, da, g)
+        VOX_TL(p.tl_slot, blockIdx.x * 4 + wave, 2);      // (rewritten every other group: the last odd group's completion)
         g += n_waves;
         if (g >= n_groups) break;
         VOX_WLOAD(qa, da, min(g + n_waves, n_groups - 1))
@@ -318,6 +344,7 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
 #undef VOX_GROUP
 #undef VOX_DOT
 #undef VOX_REDUCE
+    VOX_TL(p.tl_slot, blockIdx.x * 4 + wave, 3);
     if (EPI == EPI_ARGMAX) {
         if (lane == 0) { red[4 + wave] = best; reinterpret_cast<int*>(red)[8 + wave] = best_i; }
         __syncthreads();
@@ -417,7 +444,8 @@ static hipError_t gemv_dispatch_pe(const GemvParams& p, int ny, int pro, int epi
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_q4_gemv(const GemvParams& p, int ny, int pro, int epi, int R, hipStream_t s) {
+hipError_t launch_q4_gemv(const GemvParams& p_in, int ny, int pro, int epi, int R, hipStream_t s) {
+    GemvParams p = p_in; p.tl_slot = tl_take_slot();
     if (p.w.fmt == WFMT_BF16) return launch_dense_gemv(p, ny, pro, epi, s);
     if (p.w.K % 32 || p.w.K <= 0 || p.w.N <= 0 || R <= 0 || p.w.N % R) return hipErrorInvalidValue;
     const int P = passes_for(p.w.K, R);
@@ -1945,6 +1973,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     const float* qrow = p.q + (size_t)seq * p.q_seq_stride;
     float* orow = p.out + (size_t)seq * p.out_seq_stride;
     const int ks = tid >> 3, part = tid & 7;
+    const int tlw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave; (void)tlw;
+    VOX_TL(p.tl_slot, tlw, 0);
     float qv[PER];
 #pragma unroll
     for (int e = 0; e < PER; e += 4) {
@@ -2005,6 +2035,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
         }
     }
     __syncthreads();
+    VOX_TL(p.tl_slot, tlw, 1);
     float mx = -INFINITY;
     for (int i = tid; i < n; i += 256) mx = fmaxf(mx, sc[i]);
     mx = wave_max(mx);
@@ -2016,6 +2047,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     sum = wave_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
+    VOX_TL(p.tl_slot, tlw, 2);
     sum = (red[4] + red[5]) + (red[6] + red[7]);
     // P.V : thread -> (key group, float4 column)
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2054,6 +2086,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
         if (p.out_xf) xf_store4(p.out_xf, p.n_heads * HD, seq, h * HD + tid * 4, r4);       // batched decode: A-fragments of the wo GEMM
         else *reinterpret_cast<float4*>(orow + h * HD + tid * 4) = r4;
     }
+    VOX_TL(p.tl_slot, tlw, 3);
 }
 // Batched decode (many sequences): one workgroup per (KV head, sequence) serves all G = n_heads / n_kv_heads query heads of the
 // group, so every K / V row is fetched from L2 once instead of G times (512 -> 128 workgroups at 16 sequences, a quarter of the
@@ -2180,7 +2213,8 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const AttnParams p
         }
     }
 }
-hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq) {
+hipError_t launch_attn_decode(const AttnParams& p_in, int hd, int max_seq, hipStream_t s, int n_seq) {
+    AttnParams p = p_in; p.tl_slot = tl_take_slot();
     const size_t lds = (size_t)max_seq * sizeof(float);
     if (hd == 128 && p.prefer_gqa && p.n_heads == 4 * p.n_kv_heads && p.kv_head_stride == max_seq * 128 && !env_int("VOX_ATTN_NO_GQA")) {
         auto kern = attn_decode_gqa_kernel<4>;      // many sequences: one workgroup per (KV head, sequence), K/V fetched once for its 4 query heads

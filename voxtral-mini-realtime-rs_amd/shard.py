@@ -66,3 +66,28 @@ def run_sharded(items: Sequence, costs: Sequence[float], work: Callable, rank: i
         for i, r in part:
             out[i] = r
     return out
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def spawn_ranks(n: int, script: str, argv: Sequence[str], env: dict | None = None, port: int | None = None) -> int:
+    """Run `script argv` as `n` ranks of ONE node through torch.distributed.run (rendezvous on 127.0.0.1: the container hostname may
+    not resolve) -- the launch the driver uses for `bench.py --gpus N`.  Returns the launcher's exit code.  The script reads
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port or free_port()), script, *argv]
+    return subprocess.call(cmd, env=env)
+
+
+def fleurs_like_durations(n: int = 647, seed: int = 7):
+    """SURVEY.md section 8(d) config 5 stand-in for FLEURS-en test (647 utterances): log-normal durations, median 10 s, clipped to
+    3..30 s, numpy default_rng(seed).  Returns a list of seconds (rounded to 10 ms so sample counts are exact)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    return [round(float(d), 2) for d in np.clip(rng.lognormal(np.log(10.0), 0.5, n), 3.0, 30.0)]

@@ -324,3 +324,67 @@ def write_synthetic_dense_gguf(path: str, dims: ModelDims, seed: int = 42):
     """The same values as ``write_synthetic_safetensors`` as an all-F32 GGUF (what the CPU oracle loads for the f32 path)."""
     write_gguf(path, ((n, s, GGML_F32, bf16_bits_to_f32(bits)) for n, s, bits in synth_dense_tensors(dims, seed)))
     return path
+
+
+# --------------------------------------------------------------------------- full-size dense checkpoints (fast generator)
+
+def _fast_bf16_bits(rng: np.random.Generator, ne: int, sigma: float) -> np.ndarray:
+    """bf16 bit patterns sign | exponent | 7 random mantissa bits: +-[2^-6, 2^-5) (rms 0.023) for linear weights, +-[2^-8, 2^-7) for
+    tensors with a small sigma (biases).  One raw PCG64 draw per four values: fast enough for the 4.4 G-parameter model (seconds)."""
+    r = rng.bit_generator.random_raw((ne + 3) // 4).view(np.uint16)[:ne]
+    return (r & np.uint16(0x807F)) | np.uint16(0x3C80 if sigma >= 0.015 else 0x3B80)
+
+
+def _bf16_bits_to_f16_bits(b: np.ndarray) -> np.ndarray:
+    """Exact for the patterns of `_fast_bf16_bits` (exponents 2^-6 / 2^-8, 7 mantissa bits: all inside f16's normal range)."""
+    e = ((b >> np.uint16(7)) & np.uint16(0xFF)).astype(np.int32) - 127 + 15
+    assert e.min() >= 1 and e.max() <= 30
+    return (b & np.uint16(0x8000)) | (e.astype(np.uint16) << np.uint16(10)) | ((b & np.uint16(0x7F)) << np.uint16(3))
+
+
+def dense_checkpoint_tensors(dims: ModelDims, seed: int = 7):
+    """Yield (name, shape, kind, bf16 bit patterns) of the synthetic dense (f32-path) checkpoint with the published tensor names and
+    shapes; linear / conv / bias values come from the fast bit-level generator, norm weights are 1 + N(0, sigma^2) rounded to bf16."""
+    for idx, (name, shape, kind, sigma) in enumerate(tensor_manifest(dims)):
+        rng = np.random.default_rng([seed, idx, 99])
+        ne = int(np.prod(shape))
+        if kind == "norm":
+            bits = f32_to_bf16_bits((1.0 + sigma * rng.standard_normal(ne)).astype(np.float32))
+        else:
+            bits = _fast_bf16_bits(rng, ne, sigma)
+        yield name, shape, kind, bits
+
+
+def write_fast_dense_checkpoint(st_path: str | None, gguf_path: str | None, dims: ModelDims, seed: int = 7):
+    """The SAME synthetic dense model twice: `st_path` = BF16 SafeTensors (what VoxtralModelLoader reads, like the published
+    consolidated.safetensors), `gguf_path` = a dense GGUF for the CPU oracle (2-D linears as F16 -- exact, see _bf16_bits_to_f16_bits --
+    everything else as F32).  Either path may be None.  Full size: 8.9 GB each, a few seconds per file."""
+    import json
+    man = tensor_manifest(dims)
+    if st_path:
+        hdr = {}; off = 0
+        for name, shape, kind, sigma in man:
+            n = int(np.prod(shape)) * 2
+            hdr[name] = {"dtype": "BF16", "shape": [int(x) for x in shape], "data_offsets": [off, off + n]}; off += n
+        hdr["__metadata__"] = {"format": "pt"}
+        hb = json.dumps(hdr, separators=(",", ":")).encode(); hb += b" " * ((8 - len(hb) % 8) % 8)
+        with open(st_path, "wb") as f:
+            f.write(struct.pack("<Q", len(hb))); f.write(hb)
+            for name, shape, kind, bits in dense_checkpoint_tensors(dims, seed):
+                f.write(np.ascontiguousarray(bits).tobytes())
+    if gguf_path:
+        def gen(name, shape, kind, bits):
+            if kind == "q4" and len(shape) == 2:
+                return GGML_F16, _bf16_bits_to_f16_bits(bits)
+            return GGML_F32, bf16_bits_to_f32(bits)
+        # write_gguf wants the dtype up front: linears (kind q4 in the manifest) are the F16 ones
+        it = dense_checkpoint_tensors(dims, seed)
+        def lazy(entry):
+            name, shape, kind, sigma = entry
+            def make():
+                n2, s2, k2, bits = next(it)
+                assert n2 == name
+                return gen(n2, s2, k2, bits)[1]
+            return make
+        write_gguf(gguf_path, [(name, shape, GGML_F16 if (kind == "q4" and len(shape) == 2) else GGML_F32, lazy((name, shape, kind, sigma)))
+                               for name, shape, kind, sigma in man])
