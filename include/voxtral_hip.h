@@ -219,7 +219,7 @@ int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t iters, double
  * attention launch after _start takes the next of `n_slots` slots and each of its first `n_waves` waves stamps the 100 MHz
  * s_memrealtime counter at 4 points; _fetch copies out[n_slots][n_waves][4] back and switches the instrumentation off. */
 int32_t vox_debug_timeline_start(vox_ctx* ctx, int32_t n_slots, int32_t n_waves);
-int32_t vox_debug_timeline_fetch(vox_ctx* ctx, uint64_t* out, size_t cap_words, int32_t* slots_used);
+int32_t vox_debug_timeline_fetch(vox_ctx* ctx, uint64_t* out, size_t cap_words, int32_t* slots_used, int32_t* meta /* [n_slots][4] {0 gemv / 1 attention, epilogue, N, K}, may be NULL */);
 
 #ifdef __cplusplus
 }

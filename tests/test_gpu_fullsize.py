@@ -212,3 +212,17 @@ def test_full_16s_clip_f32_vs_oracle_golden(pkg):
     print(f"full-size f32 golden: {int(agree.sum())}/108 ids identical to the CPU oracle (first difference: {'none' if stop == 108 else stop}; "
           f"min oracle top-2 margin {float((top1 - top2).min()):.4g})")
     m.close(); ctx.close()
+
+
+def test_full_fused_attention_equals_separate_launches(pkg, full, monkeypatch):
+    """Full size, 16 s clip, eager logits path: the fused q|k|v + attention launch (opt-in, VOX_FUSED_ATTN=1) against the default two-launch path -- bit-identical logits for all 108
+    steps (26 layers x 32 heads x 107 steps of cross-workgroup hand-offs under real streaming load; a stale read would show here)."""
+    m, _, ctx = full
+    x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
+    mel = np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
+    ids_s, lg_s = m.transcribe_streaming(mel, t, return_logits=True)
+    monkeypatch.setenv("VOX_FUSED_ATTN", "1")
+    ids_f, lg_f = m.transcribe_streaming(mel, t, return_logits=True)
+    monkeypatch.delenv("VOX_FUSED_ATTN")
+    assert np.array_equal(ids_f, ids_s) and np.array_equal(lg_f, lg_s)
+    assert np.array_equal(m.transcribe_streaming(mel, t), ids_s)          # graph replay

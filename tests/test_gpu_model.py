@@ -222,24 +222,15 @@ def test_transcribe_exactly_prefix_len(pkg, orc, tiny):
             assert (m.transcribe_streaming(mel[None], t) == ids).all()     # graph / no-logits path
 
 
-def test_transcribe_batch_exactly_prefix_len(pkg, tiny):
-    """The batch path at S == 38 (rides along with longer rows) returns that row's single first token."""
+def test_audio_entry_points_never_reach_prefix_len_edge(pkg, ctx, tiny):
+    """Through the audio entry points (vox_transcribe_audio / _batch) the S == 38 edge cannot occur: the 76 + 17 pad tokens alone give
+    T >= 744 frames -> S >= 46 (pad.rs:32-46), so even a 10 ms clip emits S - 38 >= 8 ids, the same on both paths."""
     m, _, _ = tiny
     t = pkg.TimeEmbedding(256).embed(6.0)
-    # samples -> S: pad to 1280-sample tokens, 76 left + 17 right pad tokens, T = 8 frames per token; S = conv(conv(T)) / 4
-    def S_of(n):
-        total = 76 * 1280 + n + ((-(76 * 1280 + n)) % 1280) + 17 * 1280; T = total // 160
-        c = lambda L: (L - 1) // 2 + 1
-        return c(c(T)) // 4
-    short = next(n for n in range(1600, 64000, 160) if S_of(n) == 38)
-    clips = [pkg.synth.synth_audio(2.0, seed=5), pkg.synth.synth_audio(short / 16000.0, seed=6)[:short], pkg.synth.synth_audio(0.2, seed=7)]
-    assert [S_of(c.size) for c in clips][1] == 38 and S_of(clips[2].size) < 38
-    outs = m.transcribe_batch(clips, t)
-    single = [m.transcribe_audio(c, t) for c in clips]
-    assert [len(o) for o in outs] == [len(s) for s in single] and len(outs[1]) == 1 and len(outs[2]) == 0
-    assert outs[1][0] == single[1][0]
-    alone = m.transcribe_batch([clips[1]], t)                 # every row at S == 38: no decode step at all
-    assert len(alone[0]) == 1 and alone[0][0] == single[1][0]
+    clips = [pkg.synth.synth_audio(0.01, seed=3), pkg.synth.synth_audio(1.0, seed=4)]      # 160 samples -> T = 752 -> S = 47
+    a = m.transcribe_audio(clips[0], t); b = m.transcribe_batch(clips, t)
+    assert len(a) == len(b[0]) == 47 - 38
+    check_batch_rows(pkg, ctx, m, clips, t, b, TOL)
 
 
 def test_token_buffer_survives_longer_sequence(pkg, ctx, tiny):
@@ -271,3 +262,28 @@ def test_load_from_bytes_and_shards(pkg, ctx, tiny):
     assert (mb.transcribe_audio(x, t) == ref).all() and (ms.transcribe_audio(x, t) == ref).all()
     assert mb.weight_bytes() == m.weight_bytes() == ms.weight_bytes()
     mb.close(); ms.close()
+
+
+def test_fused_attention_equals_separate_launches(pkg, tiny, monkeypatch):
+    """The fused q|k|v GEMV + attention launch (EPI_ROPE_KV_ATTN: write-through q / k / v stores, per-head arrival counters, the last-arriving
+    workgroup runs the head) must give bit-identical hidden states and ids to the two-launch path (the default; the fused launch is opt-in, VOX_FUSED_ATTN=1, because it measured slower): same arithmetic, only
+    the hand-off differs.  Eager paths (no cached graph) so the knob takes effect per call."""
+    m, _, _ = tiny
+    t = pkg.TimeEmbedding(256).embed(6.0)
+    rng = np.random.default_rng(12); x = (0.5 * rng.standard_normal((30, 256))).astype(np.float32)
+    dec = m.decoder()
+
+    def run():
+        c = dec.create_cache_preallocated(64)
+        out = [dec.forward_hidden_with_cache(x[None, :6], t, c)[0]] + [dec.forward_hidden_with_cache(x[None, i:i + 1], t, c)[0] for i in range(6, 30)]
+        c.close()
+        mel = fake_mel(1144, seed=3)
+        ids, lg = m.transcribe_streaming(mel[None], t, return_logits=True)
+        return np.concatenate(out), ids, lg
+
+    b = run()                                             # default: two launches
+    monkeypatch.setenv("VOX_FUSED_ATTN", "1")
+    for _ in range(3):                                    # repeat: a stale hand-off would be intermittent
+        a = run()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    monkeypatch.delenv("VOX_FUSED_ATTN")

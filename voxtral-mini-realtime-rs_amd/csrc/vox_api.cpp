@@ -563,10 +563,13 @@ struct vox_model {
     vox_cache* cache = nullptr;                           // internal cache for transcribe_streaming
     int *d_tokens = nullptr, *d_pos = nullptr; int tokens_cap = 0;
     float* d_prefix = nullptr;                            // [38][dec_dim] prefill inputs (transcribe_dev)
+    unsigned* d_attn_cnt = nullptr; int attn_cnt_stride = 1024;   // [dec_layers][dec_heads][stride] arrival counters, 4 KB apart (VOX_ATTN_CNT_STRIDE, in uints) of the fused q|k|v + attention launch
     int* d_seq_len = nullptr; std::vector<int> h_seq_len;  // per-utterance encoder rows of a stacked batch
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
     int n_parts = 0, argmax_R = 8;
-    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
+    // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
+    hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0;
+    const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
     vox_timings timings{};
 };
 
@@ -899,14 +902,19 @@ struct Loader {
 };
 }  // namespace
 
+static void graphs_destroy(vox_model* m) {
+    for (int i = 0; i < 2; i++) {
+        if (m->graph_exec[i]) { (void)hipGraphExecDestroy(m->graph_exec[i]); m->graph_exec[i] = nullptr; }
+        if (m->graph[i]) { (void)hipGraphDestroy(m->graph[i]); m->graph[i] = nullptr; }
+    }
+}
 static void model_release(vox_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream);
-    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) (void)hipGraphDestroy(m->graph);
+    graphs_destroy(m);
     if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix})
+                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -932,7 +940,11 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
     A((void**)&m->ada_mul, (size_t)c.dec_layers * c.dec_dim * 4); A((void**)&m->d_pos, 64); A((void**)&m->d_h, (size_t)c.dec_dim * 4 * 4);
     A((void**)&m->d_q, (size_t)qdim * 4 * 4); A((void**)&m->d_att, (size_t)qdim * 4 * 4); A((void**)&m->d_act, (size_t)c.dec_ffn * 4 * 4);
     A((void**)&m->d_logits, (size_t)c.vocab * 4); A((void**)&m->d_part_val, (size_t)m->n_parts * 4 * 4); A((void**)&m->d_part_idx, (size_t)m->n_parts * 4 * 4);
+    { const char* e_ = getenv("VOX_ATTN_CNT_STRIDE"); if (e_ && atoi(e_) >= 1 && atoi(e_) <= (1 << 16)) m->attn_cnt_stride = atoi(e_); }
+    const size_t cnt_bytes = (size_t)c.dec_layers * c.dec_heads * m->attn_cnt_stride * 4;
+    A((void**)&m->d_attn_cnt, cnt_bytes);
     if (e != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of decode buffers failed: %s", hipGetErrorString(e)); }
+    if (hipMemset(m->d_attn_cnt, 0, cnt_bytes) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMemset failed"); }
     for (int i = 0; i < c.dec_layers; i++) m->dec[i].ada_mul = m->ada_mul + (size_t)i * c.dec_dim;
     *out = m; return VOX_OK;
 }
@@ -1142,10 +1154,16 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
         p.w = L.wqkv.w; p.x = h; p.x_stride = D; p.out = m->d_q; p.out_stride = QD; p.gamma = L.attn_norm; p.eps = c.norm_eps;
         p.pos_ptr = pos_ptr; p.pos_off = pos_off; p.rope_cos = m->dec_cos; p.rope_sin = m->dec_sin; p.hd = hd; p.n_q = QD; p.n_k = KD;
         p.kcache = kl; p.vcache = vl; p.cache_head_stride = kc->max_seq * hd;
-        HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV, q4_gemv_default_R(p.w.N, p.w.K, EPI_ROPE_KV), s));
-        AttnParams ap{}; ap.q = m->d_q; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd; ap.out = m->d_att;
-        ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = pos_off; ap.window = c.dec_window; ap.pos_ptr = pos_ptr; ap.M = 1;
-        HIPCHK(launch_attn_decode(ap, hd, kc->max_seq, s));
+        if (p.w.fmt == WFMT_Q4_0 && q4_gemv_attn_fusable(p.w.N, p.w.K, hd, QD, KD, kc->max_seq)) {
+            // one launch: q|k|v GEMV + RoPE + cache write, and the last workgroup to complete a query head's inputs runs that head's attention
+            p.attn_cnt = m->d_attn_cnt + (size_t)l * H * m->attn_cnt_stride; p.attn_cnt_stride = m->attn_cnt_stride; p.attn_out = m->d_att; p.attn_window = c.dec_window; p.attn_max_seq = kc->max_seq;
+            HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV_ATTN, 2, s));
+        } else {
+            HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV, q4_gemv_default_R(p.w.N, p.w.K, EPI_ROPE_KV), s));
+            AttnParams ap{}; ap.q = m->d_q; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd; ap.out = m->d_att;
+            ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = pos_off; ap.window = c.dec_window; ap.pos_ptr = pos_ptr; ap.M = 1;
+            HIPCHK(launch_attn_decode(ap, hd, kc->max_seq, s));
+        }
         GemvParams o{}; o.w = L.wo.w; o.x = m->d_att; o.x_stride = QD; o.out = h; o.out_stride = D; o.resid = h; o.resid_stride = D;
         HIPCHK(launch_q4_gemv(o, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(o.w.N, o.w.K, EPI_RESID), s));
         GemvParams f{}; f.w = L.w13.w; f.x = h; f.x_stride = D; f.out = m->d_act; f.out_stride = F; f.gamma = L.ffn_norm; f.mul = L.ada_mul; f.eps = c.norm_eps;
@@ -1162,6 +1180,7 @@ static int32_t lm_head_argmax_dev(vox_model* m, const float* h, float* logits_ou
     ARGCHK(c.dec_dim <= 4096, "lm_head GEMV is instantiated for dec_dim <= 4096 (got %d)", c.dec_dim);
     GemvParams p{}; p.w = m->tok.w; p.x = h; p.x_stride = c.dec_dim; p.out = logits_out; p.out_stride = c.vocab; p.gamma = m->dec_norm; p.eps = c.norm_eps;
     p.part_val = m->d_part_val; p.part_idx = m->d_part_idx;
+    if (m->tok.w.fmt != WFMT_BF16) m->n_parts = q4_gemv_grid_k(c.vocab, c.dec_dim, m->argmax_R, EPI_ARGMAX);   // partials = workgroups of THIS launch (<= the allocated count)
     HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ARGMAX, m->argmax_R, m->ctx->stream));
     return VOX_OK;
 }
@@ -1171,8 +1190,7 @@ static int32_t ensure_decode_state(vox_model* m, int S) {
         int cap = std::max(S, 256); cap = std::min((cap + 255) / 256 * 256, m->dec_rope_len);
         ARGCHK(S <= cap, "sequence of %d decoder positions exceeds the RoPE table (%d)", S, m->dec_rope_len);
         if (m->cache) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; m->cache = nullptr; }
-        if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-        if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+        graphs_destroy(m);
         VOXCHK(cache_alloc(m, cap, &m->cache));
     }
     // token buffer: allocated ONCE for the longest admissible sequence (S <= dec_rope_len) -- the captured decode graph bakes this
@@ -1213,6 +1231,7 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     std::vector<int32_t> prefix(PREFIX_LEN, STREAMING_PAD); prefix[0] = BOS;      // model.rs:891-892
     HIPCHK(hipMemcpyAsync(m->d_tokens, prefix.data(), PREFIX_LEN * 4, hipMemcpyHostToDevice, s));
     m->cache->len = 0;
+    HIPCHK(hipMemsetAsync(m->d_attn_cnt, 0, (size_t)c.dec_layers * c.dec_heads * m->attn_cnt_stride * 4, s));   // arrival counters: every fused launch adds a whole period; re-zeroed per utterance anyway
     // prefix inputs = audio[:38] + embed(prefix)  (model.rs:896-902)
     if (!m->d_prefix) HIPCHK(hipMalloc((void**)&m->d_prefix, (size_t)PREFIX_LEN * c.dec_dim * 4));   // model-owned: no hipMalloc/hipFree in the timed path
     float* px = m->d_prefix;
@@ -1233,24 +1252,30 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     if (logits_host) {
         for (int i = 0; i < steps; i++) VOXCHK(decode_step_enqueue(m, d_logits_all + (size_t)(i + 1) * c.vocab));
     } else if (steps > 0) {
-        if (!m->graph_exec || m->graph_cache != m->cache || m->graph_audio != m->d_audio) {   // the graph bakes these pointers in
-            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
-            VOXCHK(decode_step_enqueue(m, nullptr));                               // eager first step (also warms function attributes)
-            HIPCHK(hipStreamSynchronize(s));
+        // Replayed graphs: one step per graph by default.  VOX_DECODE_UNROLL=U (measurement knob) also builds a U-step graph for the bulk of
+        // the steps; measured in round 2 (profiles/r02_decode_knobs.txt): no gain -- graph boundaries are not where the time goes.
+        int U = 1; { const char* e = getenv("VOX_DECODE_UNROLL"); if (e && atoi(e) >= 1 && atoi(e) <= 32) U = atoi(e); }
+        if (m->graph_cache != m->cache || m->graph_audio != m->d_audio || m->graph_unroll != U) { graphs_destroy(m); m->graph_cache = m->cache; m->graph_audio = m->d_audio; m->graph_unroll = U; }
+        auto capture = [&](int which, int n_steps) -> int32_t {
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            int32_t r = decode_step_enqueue(m, nullptr);
-            hipError_t ce = hipStreamEndCapture(s, &m->graph);
+            int32_t r = VOX_OK;
+            for (int i = 0; i < n_steps && r == VOX_OK; i++) r = decode_step_enqueue(m, nullptr);
+            hipError_t ce = hipStreamEndCapture(s, &m->graph[which]);
             if (r != VOX_OK) return r;
             HIPCHK(ce);
-            HIPCHK(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
-            m->graph_cache = m->cache; m->graph_audio = m->d_audio;
-            for (int i = 1; i < steps; i++) HIPCHK(hipGraphLaunch(m->graph_exec, s));
-            m->timings.graph_replays = steps - 1;
-        } else {
-            for (int i = 0; i < steps; i++) HIPCHK(hipGraphLaunch(m->graph_exec, s));
-            m->timings.graph_replays = steps;
+            HIPCHK(hipGraphInstantiate(&m->graph_exec[which], m->graph[which], nullptr, nullptr, 0));
+            return VOX_OK;
+        };
+        int done = 0;
+        if (!m->graph_exec[0]) {
+            VOXCHK(decode_step_enqueue(m, nullptr));                               // eager first step (also warms function attributes)
+            HIPCHK(hipStreamSynchronize(s));
+            VOXCHK(capture(0, 1));
+            done = 1;
         }
+        if (U > 1 && !m->graph_exec[1] && steps - done >= 2 * U) VOXCHK(capture(1, U));      // only worth building for long enough utterances
+        while (U > 1 && m->graph_exec[1] && steps - done >= U) { HIPCHK(hipGraphLaunch(m->graph_exec[1], s)); done += U; m->timings.graph_replays += U; }
+        while (done < steps) { HIPCHK(hipGraphLaunch(m->graph_exec[0], s)); done++; m->timings.graph_replays++; }
     }
     HIPCHK(hipMemcpyAsync(out_ids, m->d_tokens + PREFIX_LEN, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     if (logits_host) HIPCHK(hipMemcpyAsync(logits_host, d_logits_all, (size_t)n * c.vocab * 4, hipMemcpyDeviceToHost, s));
@@ -1624,8 +1649,9 @@ extern "C" int32_t vox_debug_timeline_start(vox_ctx* c, int32_t n_slots, int32_t
     if (tl_configure(g_tl_dev, n_slots, n_waves) != hipSuccess) { (void)hipFree(g_tl_dev); g_tl_dev = nullptr; return fail(VOX_ERR_UNSUPPORTED, "library built without -DVOX_TIMELINE"); }
     g_tl_nslots = n_slots; g_tl_nwaves = n_waves; return VOX_OK;
 }
-extern "C" int32_t vox_debug_timeline_fetch(vox_ctx* c, uint64_t* out, size_t cap_words, int32_t* slots_used) {
+extern "C" int32_t vox_debug_timeline_fetch(vox_ctx* c, uint64_t* out, size_t cap_words, int32_t* slots_used, int32_t* meta) {
     ARGCHK(c && out && slots_used, "null argument"); VOXCHK(ctx_bind(c));
+    if (meta) for (int i = 0; i < g_tl_nslots; i++) tl_slot_meta(i, meta + 4 * i);
     ARGCHK(g_tl_dev, "timeline not started");
     const size_t words = (size_t)g_tl_nslots * g_tl_nwaves * 4;
     ARGCHK(cap_words >= words, "timeline output buffer too small (%zu < %zu words)", cap_words, words);

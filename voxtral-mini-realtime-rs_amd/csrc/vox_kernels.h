@@ -21,7 +21,9 @@ struct Q4W {
 };
 enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1, WFMT_BF16X2 = 2 };   // BF16X2: f32 weights as two dense bf16 planes, qs = hi [N][K], sc = lo [N][K] (conv stem)
 
-enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6, EPI_RESID_XF = 7 };
+enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6, EPI_RESID_XF = 7, EPI_ROPE_KV_ATTN = 8 };
+// _ROPE_KV_ATTN (GEMV, one row): _ROPE_KV with write-through stores, then the workgroup that arrives LAST on a query head's counter (its q rows +
+// its KV head's k and v rows are complete) runs that head's single-query attention in the same launch -- one launch less per decoder layer
 // (M <= 16 only) _SWIGLU_XF: SwiGLU written as XF planes; _RESID_XF: out = acc + resid as f32 AND as XF planes of out * xf_w (* xf_w2) plus
 // per-workgroup partial sums of squares -- the next RMSNorm is folded into its producer and its consumer (GemmParams::ssq_part)
 enum Pro { PRO_NONE = 0, PRO_RMS = 1, PRO_RMS_MUL = 2 };   // RMS_MUL: RMSNorm then * mul (the cached Ada scale)
@@ -39,6 +41,9 @@ struct GemvParams {
     int n_q, n_k;                        // EPI_ROPE_KV: rows [0,n_q) q, [n_q,n_q+n_k) k, then v
     float* kcache; float* vcache; int cache_head_stride;    // [kv_head][max_seq][hd]
     float* part_val; int* part_idx;      // EPI_ARGMAX: per-workgroup (max, argmax)
+    // EPI_ROPE_KV_ATTN: per-query-head arrival counters attn_cnt[attn_cnt_stride * h] (far apart: device-scope atomics on neighbouring addresses
+    // serialise in one memory channel; monotonic: every launch adds 3*hd/8 per head), attention output [n_q], window, cache rows
+    unsigned* attn_cnt; int attn_cnt_stride; float* attn_out; int attn_window, attn_max_seq;
     int tl_slot;                         // timeline slot (measurement builds, -DVOX_TIMELINE; assigned by the launcher, -1 = off)
 };
 // rows_per_wave R in {1,2,4,8}; K tiles of 2048 chosen from K. Returns hipError_t.
@@ -46,6 +51,9 @@ hipError_t launch_q4_gemv(const GemvParams& p, int n_rows_x, int pro, int epi, i
 const char* q4_gemv_kernel_name(int K, int pro, int epi, int R);
 int q4_gemv_default_R(int N, int K, int epi);
 int q4_gemv_grid(int N, int R);
+int q4_gemv_nwv(int K, int epi);        // waves per workgroup the launcher will use for this shape (4 / 6 / 12)
+int q4_gemv_grid_k(int N, int K, int R, int epi);
+bool q4_gemv_attn_fusable(int N, int K, int hd, int n_q, int n_k, int max_seq);   // may launch_q4_gemv(.., PRO_RMS, EPI_ROPE_KV_ATTN, R = 2, ..) be used?   // workgroups launched for an [N][K] GEMV at R rows per wave (== number of argmax partials)
 int dense_gemv_grid(int N);        // same, for WFMT_BF16 weights   // workgroups launched for N rows at R rows per wave (== number of argmax partials)
 
 // ---- Q4 GEMM on MFMA (prefill / encoder, rows of x > 4): out[M][N'] = epi( x[M][K] * W^T )
@@ -142,5 +150,6 @@ hipError_t launch_gelu(float* x, long n, hipStream_t s);
 // Returns hipErrorNotSupported in product builds.
 hipError_t tl_configure(unsigned long long* buf, int n_slots, int n_waves);   // buf == nullptr: off
 int tl_slots_used();
+void tl_slot_meta(int slot, int out[4]);    // {0 gemv / 1 attention, epi, N, K} of the launch that took `slot`
 
 }  // namespace vox

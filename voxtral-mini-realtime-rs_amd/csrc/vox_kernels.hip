@@ -28,7 +28,7 @@ static int g_tl_next = -1, g_tl_slots = 0;
 __device__ unsigned long long* g_tl_buf = nullptr;
 __device__ int g_tl_waves = 0;
 __device__ __forceinline__ void tl_stamp(int slot, int wave_global, int k) {
-    if (slot >= 0 && (threadIdx.x & 63) == 0 && g_tl_buf && wave_global < g_tl_waves)
+    if (slot >= 0 && (wave_global & 3) == 0 && (threadIdx.x & 63) == 0 && g_tl_buf && wave_global < g_tl_waves)   // wave 0 of every workgroup only (keeps the overhead low)
         g_tl_buf[((size_t)slot * g_tl_waves + wave_global) * 4 + k] = wall_clock64();
 }
 #define VOX_TL(slot, wave, k) tl_stamp(slot, wave, k)
@@ -43,7 +43,13 @@ hipError_t tl_configure(unsigned long long* buf, int n_slots, int n_waves) {
 hipError_t tl_configure(unsigned long long*, int, int) { return hipErrorNotSupported; }
 #endif
 int tl_slots_used() { return g_tl_next < 0 ? 0 : g_tl_next; }
-static int tl_take_slot() { if (g_tl_next < 0) return -1; if (g_tl_next >= g_tl_slots) return -1; return g_tl_next++; }
+static int g_tl_meta[4096][4];     // per slot: {0 gemv / 1 attention, epi, N, K}
+static int tl_take_slot(int type, int epi, int N, int K) {
+    if (g_tl_next < 0 || g_tl_next >= g_tl_slots || g_tl_next >= 4096) return -1;
+    g_tl_meta[g_tl_next][0] = type; g_tl_meta[g_tl_next][1] = epi; g_tl_meta[g_tl_next][2] = N; g_tl_meta[g_tl_next][3] = K;
+    return g_tl_next++;
+}
+void tl_slot_meta(int slot, int out[4]) { for (int i = 0; i < 4; i++) out[i] = (slot >= 0 && slot < 4096) ? g_tl_meta[slot][i] : 0; }
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -159,6 +165,18 @@ hipError_t launch_q4_dequant(Q4W w, float* out, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // fused Q4 GEMV
 // ------------------------------------------------------------------------------------------------
+template <int HD, bool NT, bool LATE_V>
+__device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh, const float* __restrict__ kb, const float* __restrict__ vb, int kv_row_stride,
+                                                   int pos, int window, float* __restrict__ sc, float* __restrict__ red, float4* __restrict__ osum, int tl_slot, int tlw);
+
+// two adjacent floats: plain stores, or ONE 8-byte write-through (sc1) store -- visible to other workgroups of the same launch once the
+// storing wave has drained it (s_waitcnt vmcnt(0)) and published a flag / counter (MI355X_MICROARCH.md, inter-workgroup visibility, form R1)
+template <bool WT>
+__device__ __forceinline__ void st_pair(float* dst, float a, float b) {
+    if (WT) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else { dst[0] = a; dst[1] = b; }
+}
+
 // LDS image of x: chunk c (32 floats) holds its eight 16-byte pieces at piece index j ^ ((c>>1)&7):
 // lanes of one ds_read_b128 service group then hit 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int xs_piece(int c, int j) { return c * 8 + (j ^ ((c >> 1) & 7)); }
@@ -166,23 +184,30 @@ __device__ __forceinline__ int xs_piece(int c, int j) { return c * 8 + (j ^ ((c 
 // P = passes per row group: the R rows of a group are one contiguous run of R*nb 16-byte chunks, walked 64 chunks
 // (one dwordx4 per lane) at a time, so every lane is busy in every pass even when K is not a multiple of 2048
 // (K = 3072: R = 2 -> exactly 3 passes).  Requires N % R == 0 and R*nb <= 64*P.
-template <int P, int R, int PRO, int EPI>
-__global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
-    constexpr int NX = (2 * P + R - 1) / R;        // float4 activation pieces per thread (K <= 1024 * NX)
+// NWV = waves per workgroup (4, 6 or 12): the total number of waves (and so the row-group -> wave mapping) is the same for every NWV,
+// a bigger workgroup only shares one staged copy of the activation vector between more waves (768 / 512 / 256 workgroups re-read it).
+template <int P, int R, int PRO, int EPI, int NWV>
+__global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_gemv_kernel(const GemvParams p) {   // fused attention: 3 workgroups per CU must stay resident
+    constexpr int NT = 64 * NWV;                                      // threads per workgroup
+    constexpr int NX = (8 * P + R * NWV - 1) / (R * NWV);             // float4 activation pieces per thread (K/4 <= 512 P / R pieces)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = p.w.K, nb = p.w.nb, N = p.w.N;
     float4* xs = reinterpret_cast<float4*>(smem);  // K floats, swizzled
     float* sxs = smem + K;                         // nb chunk sums
-    float* red = sxs + nb;                         // 16 floats scratch
+    float* red = sxs + nb;                         // 4 * NWV floats scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int y = blockIdx.y;
     const float* __restrict__ xg = p.x + (size_t)y * p.x_stride;
     const int npieces = K >> 2;
     // persistent waves: wave w handles row groups g = w, w + n_waves, ... with the NEXT group's weight loads issued
     // before the current group is consumed, so HBM stays busy while the VALU works.
-    const int rnb = R * nb, n_groups = N / R, n_waves = gridDim.x * 4;
-    int g = blockIdx.x * 4 + wave;
-    VOX_TL(p.tl_slot, blockIdx.x * 4 + wave, 0);
+    const int rnb = R * nb, n_groups = N / R, n_waves = gridDim.x * NWV;
+    // fused attention: workgroups are dispatched in blockIdx order, so the k / v row blocks go FIRST and the q blocks last -- the last arriver
+    // of a head is then (almost always) one of its own 16 q workgroups: 32 heads finish on 32 different workgroups, in parallel.  (A k / v
+    // workgroup arriving last would have to run all G heads of its KV head one after the other.)
+    const int bx = EPI == EPI_ROPE_KV_ATTN ? (int)((blockIdx.x + (unsigned)(p.n_q / (NWV * R))) % gridDim.x) : (int)blockIdx.x;
+    int g = bx * NWV + wave;
+    VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 0);
 
     // Every global load below is UNCONDITIONAL (indices are clamped, never predicated): a "cond ? load : 0"
     // makes hipcc branch around the load and drain vmcnt(0) per element, which serialises HBM round trips.
@@ -190,7 +215,7 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     float4 xp[NX], gp[PRO != PRO_NONE ? NX : 1], mp[PRO == PRO_RMS_MUL ? NX : 1];
 #pragma unroll
     for (int i = 0; i < NX; i++) {
-        const int pc = min(tid + 256 * i, npieces - 1);
+        const int pc = min(tid + NT * i, npieces - 1);
         xp[i] = reinterpret_cast<const float4*>(xg)[pc];
         if (PRO != PRO_NONE) gp[i] = reinterpret_cast<const float4*>(p.gamma)[pc];
         if (PRO == PRO_RMS_MUL) mp[i] = reinterpret_cast<const float4*>(p.mul)[pc];
@@ -221,13 +246,13 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NX; i++)
-            if (tid + 256 * i < npieces) ss += xp[i].x * xp[i].x + xp[i].y * xp[i].y + xp[i].z * xp[i].z + xp[i].w * xp[i].w;
+            if (tid + NT * i < npieces) ss += xp[i].x * xp[i].x + xp[i].y * xp[i].y + xp[i].z * xp[i].z + xp[i].w * xp[i].w;
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
     }
 #pragma unroll
     for (int i = 0; i < NX; i++) {
-        const int pc = tid + 256 * i;           // pieces come in whole groups of 8 lanes (K % 32 == 0)
+        const int pc = tid + NT * i;            // pieces come in whole groups of 8 lanes (K % 32 == 0)
         float4 v = xp[i];
         if (PRO != PRO_NONE) {
             const float4 gm = gp[i];
@@ -245,12 +270,18 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
         }
     }
     __syncthreads();
-    VOX_TL(p.tl_slot, blockIdx.x * 4 + wave, 1);
+    VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 1);
     // burn RmsNorm divides by sqrt(mean(x^2) + eps); we multiply by the reciprocal
-    const float rstd = PRO != PRO_NONE ? 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + p.eps) : 1.0f;
+    float ssq = 0.f;
+    if (PRO != PRO_NONE) {      // fixed order: deterministic
+#pragma unroll
+        for (int w = 0; w < NWV; w += 4) ssq += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+    }
+    const float rstd = PRO != PRO_NONE ? 1.0f / sqrtf(ssq / (float)K + p.eps) : 1.0f;
 
     float best = -INFINITY; int best_i = 0x7fffffff;   // EPI_ARGMAX running (max, first index) of this wave
-    const int pos = (EPI == EPI_ROPE_KV) ? (p.pos_ptr ? *p.pos_ptr : 0) + p.pos_off : 0;
+    constexpr bool ROPE = EPI == EPI_ROPE_KV || EPI == EPI_ROPE_KV_ATTN, WT = EPI == EPI_ROPE_KV_ATTN;
+    const int pos = ROPE ? (p.pos_ptr ? *p.pos_ptr : 0) + p.pos_off : 0;
 
     // (4)+(5) consume one row group from registers (Q_, D_) and run its epilogue
 #define VOX_GROUP(Q_, D_, G_)                                                                                          \
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
                 const int n = row0 + r;                                                                                \
                 if (lane == (r >> 1)) p.out[(size_t)y * p.out_stride + (n >> 1)] = silu_f(acc[r]) * acc[r + 1];        \
             }                                                                                                          \
-        } else if (EPI == EPI_ROPE_KV) { /* [wq|wk|wv]: RoPE pairs (rope.rs:99-141), k/v into the cache slot */        \
+        } else if (ROPE) { /* [wq|wk|wv]: RoPE pairs (rope.rs:99-141), k/v into the cache slot */                      \
             const int hd = p.hd, half = hd >> 1;                                                                       \
             _Pragma("unroll") for (int r = 0; r + 1 < R; r += 2) {                                                     \
                 const int n = row0 + r;                                                                                \
@@ -297,16 +328,14 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
                         const int dd = n % hd;                                                                         \
                         const float c = p.rope_cos[(size_t)pos * half + (dd >> 1)], sn = p.rope_sin[(size_t)pos * half + (dd >> 1)]; \
                         const float ra = a * c - b * sn, rb = a * sn + b * c;                                          \
-                        if (n < p.n_q) { p.out[n] = ra; p.out[n + 1] = rb; }                                           \
+                        if (n < p.n_q) st_pair<WT>(p.out + n, ra, rb);                                                 \
                         else {                                                                                         \
                             const int kn = n - p.n_q, kh = kn / hd;                                                    \
-                            float* dst = p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd;          \
-                            dst[0] = ra; dst[1] = rb;                                                                  \
+                            st_pair<WT>(p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd, ra, rb);  \
                         }                                                                                              \
                     } else {                                                                                           \
                         const int vn = n - p.n_q - p.n_k, vh = vn / hd, dd = vn % hd;                                  \
-                        float* dst = p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd;              \
-                        dst[0] = a; dst[1] = b;                                                                        \
+                        st_pair<WT>(p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd, a, b);        \
                     }                                                                                                  \
                 }                                                                                                      \
             }                                                                                                          \
@@ -333,7 +362,7 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
     while (g < n_groups) {
         VOX_WLOAD(qb, db, min(g + n_waves, n_groups - 1))     // prefetch (clamped: harmless re-read at the tail)
         VOX_GROUP(qa, da, g)
-        VOX_TL(p.tl_slot, blockIdx.x * 4 + wave, 2);      // (rewritten every other group: the last odd group's completion)
+        VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 2);      // (rewritten every other group: the last odd group's completion)
         g += n_waves;
         if (g >= n_groups) break;
         VOX_WLOAD(qa, da, min(g + n_waves, n_groups - 1))
@@ -344,14 +373,49 @@ __global__ __launch_bounds__(256) void q4_gemv_kernel(const GemvParams p) {
 #undef VOX_GROUP
 #undef VOX_DOT
 #undef VOX_REDUCE
-    VOX_TL(p.tl_slot, blockIdx.x * 4 + wave, 3);
+    VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 3);
+    if (EPI == EPI_ROPE_KV_ATTN) {
+        // ---- fused single-query attention: no workgroup ever waits.  (a) every wave drains its write-through q / k / v stores, then the
+        // workgroup arrives on the counter of each query head its 8 rows feed (a q block: its own head; a k or v block: the G heads of its
+        // KV head).  A head's counter receives 3*hd/8 arrivals per launch; whoever brings it to a multiple of that runs the head.
+        static_assert(EPI != EPI_ROPE_KV_ATTN || (NWV == 4 && R == 2), "fused attention: 256-thread workgroups of 8 rows");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // also: the x staging area is dead from here on, the attention reuses it
+        const int hd = p.hd, G = p.n_q / p.n_k;            // G = query heads per KV head
+        float* sc = smem;                                  // [attn_max_seq] scores
+        float4* osum = reinterpret_cast<float4*>(smem + ((p.attn_max_seq + 3) & ~3));
+        float* red2 = reinterpret_cast<float*>(osum + 256);
+        int* s_my = reinterpret_cast<int*>(red2 + 8);      // [0] = number of heads this workgroup completed, then the heads
+        if (tid == 0) {
+            const int rows_wg = NWV * R, per_head = 3 * hd / rows_wg, row0 = bx * rows_wg;
+            int h0, nh;
+            if (row0 < p.n_q) { h0 = row0 / hd; nh = 1; }
+            else { h0 = (((row0 - p.n_q) % p.n_k) / hd) * G; nh = G; }
+            int cnt = 0;
+            for (int i = 0; i < nh; i++) {
+                const unsigned old = __hip_atomic_fetch_add(p.attn_cnt + (size_t)(h0 + i) * p.attn_cnt_stride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((old + 1) % (unsigned)per_head == 0) s_my[1 + cnt++] = h0 + i;
+            }
+            s_my[0] = cnt;
+        }
+        __syncthreads();
+        const int n_mine = s_my[0];
+        for (int i = 0; i < n_mine; i++) {                 // (b) uniform per workgroup; zero iterations for all but the last arrivers
+            const int h = s_my[1 + i], kvh = h / G;
+            const float4 r4 = attn_decode_core<128, true, true>(p.out + (size_t)h * hd, p.kcache + (size_t)kvh * p.cache_head_stride, p.vcache + (size_t)kvh * p.cache_head_stride,
+                                                          hd, pos, p.attn_window, sc, red2, osum, -1, 0);
+            if (tid < 32) *reinterpret_cast<float4*>(p.attn_out + (size_t)h * hd + tid * 4) = r4;
+            __syncthreads();
+        }
+        VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 3);     // (timeline builds: wave exit including the attention tail)
+    }
     if (EPI == EPI_ARGMAX) {
-        if (lane == 0) { red[4 + wave] = best; reinterpret_cast<int*>(red)[8 + wave] = best_i; }
+        if (lane == 0) { red[NWV + wave] = best; reinterpret_cast<int*>(red)[2 * NWV + wave] = best_i; }
         __syncthreads();
         if (tid == 0) {
-            float bv = red[4]; int bidx = reinterpret_cast<int*>(red)[8];
-            for (int wv = 1; wv < 4; wv++) {
-                const float v = red[4 + wv]; const int ii = reinterpret_cast<int*>(red)[8 + wv];
+            float bv = red[NWV]; int bidx = reinterpret_cast<int*>(red)[2 * NWV];
+            for (int wv = 1; wv < NWV; wv++) {
+                const float v = red[NWV + wv]; const int ii = reinterpret_cast<int*>(red)[2 * NWV + wv];
                 if (v > bv || (v == bv && ii < bidx)) { bv = v; bidx = ii; }
             }
             p.part_val[(size_t)y * gridDim.x + blockIdx.x] = bv;
@@ -386,6 +450,7 @@ static inline int passes_for(int K, int R) { return (R * (K / 32) + 63) / 64; }
 // rows per wave. Prefers the R that fills every pass exactly (R*nb % 64 == 0). Tuning knobs (measurement only):
 // VOX_GEMV_R / VOX_GEMV_R_PAIR / VOX_GEMV_R_ARGMAX override the choice when the (R, P) pair is instantiated.
 int q4_gemv_default_R(int N, int K, int epi) {
+    if (epi == EPI_ROPE_KV_ATTN) return 2;
     const bool pair = (epi == EPI_SWIGLU || epi == EPI_ROPE_KV);
     const int e = env_int(epi == EPI_ARGMAX ? "VOX_GEMV_R_ARGMAX" : pair ? "VOX_GEMV_R_PAIR" : "VOX_GEMV_R");
     if (e && N % e == 0 && gemv_has(e, passes_for(K, e)) && (!pair || e % 2 == 0)) return e;
@@ -404,27 +469,70 @@ int q4_gemv_default_R(int N, int K, int epi) {
 // number of workgroups for a GEMV over N rows with R rows per wave: every wave gets an equal whole number of row
 // groups where possible, at most ~3 workgroups per CU stay resident and stream (persistent waves).
 int dense_gemv_grid(int N);
-int q4_gemv_grid(int N, int R) {
+// waves per workgroup of the decode GEMV: 4 (768 workgroups), 6 (512) or 12 (256, one per CU) -- same total waves, fewer copies of the
+// staged activation vector.  VOX_GEMV_NWV overrides (measurement knob).
+// Round-2 measurements (profiles/r02_decode_knobs.txt): 12-wave workgroups (one copy of x per CU instead of three) win where the staged
+// vector is long or the kernel is long enough to amortise the bigger barrier -- wo (K = 4096) 4.93 -> 4.68 us, w2 (K = 9216) 8.31 -> 7.89 us,
+// w1|w3 9.58 -> 9.25 us -- and lose on q|k|v (RoPE / cache epilogue; 6.08 -> 6.16) and lm_head (38.9 -> 41.1).
+int q4_gemv_nwv(int K, int epi) {
+    const int e = env_int("VOX_GEMV_NWV");
+    if (e == 4 || e == 6 || e == 12) return e;
+    if (epi == EPI_ARGMAX || epi == EPI_ROPE_KV || epi == EPI_ROPE_KV_ATTN) return 4;
+    return (K >= 4096 || epi == EPI_SWIGLU) ? 12 : 4;
+}
+static int q4_gemv_grid_w(int N, int R, int nwv) {
     const int n_groups = N / R;
     int target = env_int("VOX_GEMV_WGS"); if (target <= 0) target = 768;
-    int wgs = (n_groups + 3) / 4;
+    target = target * 4 / nwv;                      // the same number of waves for every workgroup size
+    int wgs = (n_groups + nwv - 1) / nwv;
     if (wgs > target) {
-        const int iters = (n_groups + 4 * target - 1) / (4 * target);
-        wgs = (n_groups + 4 * iters - 1) / (4 * iters);
+        const int iters = (n_groups + nwv * target - 1) / (nwv * target);
+        wgs = (n_groups + nwv * iters - 1) / (nwv * iters);
     }
     return wgs < 1 ? 1 : wgs;
 }
+int q4_gemv_grid(int N, int R) { return q4_gemv_grid_w(N, R, 4); }
 
-template <int P, int R, int PRO, int EPI>
-static hipError_t gemv_launch_t(const GemvParams& p, int ny, hipStream_t s) {
-    dim3 grid(q4_gemv_grid(p.w.N, R), ny);
-    const size_t lds = (size_t)(p.w.K + p.w.nb + 16) * sizeof(float);
-    auto kern = q4_gemv_kernel<P, R, PRO, EPI>;
+static bool gemv_fat_shape(int K, int R) { const int P = passes_for(K, R); return (R == 2 && P == 3) || (R == 1 && (P == 2 || P == 5)); }
+int q4_gemv_grid_k(int N, int K, int R, int epi) { return q4_gemv_grid_w(N, R, gemv_fat_shape(K, R) ? q4_gemv_nwv(K, epi) : 4); }
+
+static size_t gemv_attn_lds(int max_seq) { return ((size_t)((max_seq + 3) & ~3) + 256 * 4 + 8 + 16) * sizeof(float); }
+bool q4_gemv_attn_fusable(int N, int K, int hd, int n_q, int n_k, int max_seq) {
+    // OPT-IN (VOX_FUSED_ATTN=1).  Correct (bit-identical to two launches, tests/test_gpu_model.py::test_fused_attention_equals_separate_launches) but
+    // SLOWER on MI355X: the hand-off costs what it saves -- draining the write-through q / k / v stores + one returning device-scope atomic
+    // (~1.6 us) replace a ~1.9 us kernel boundary, and the last arriver then runs the head's dependent chain (q, K -> scores -> V) alone
+    // while the chip idles: 22.5 us per layer against 6.8 + 1.9 + 4.6 for two launches (profiles/r02_fused_attention_timeline.txt).
+    if (!env_int("VOX_FUSED_ATTN")) return false;
+    if (hd != 128 || n_k <= 0 || n_q % n_k || n_q / n_k > 8 || N != n_q + 2 * n_k || N % 8 || n_q % 8 || n_k % 8 || K % 32) return false;
+    if (max_seq > 4096) return false;                                        // LDS for the score row
+    if (!gemv_has(2, passes_for(K, 2))) return false;
+    return q4_gemv_grid_w(N, 2, 4) * 8 == N;                                 // one row group per wave: workgroup b <-> rows 8b .. 8b+7
+}
+template <int P, int R, int PRO, int EPI, int NWV>
+static hipError_t gemv_launch_w(const GemvParams& p, int ny, hipStream_t s) {
+    dim3 grid(q4_gemv_grid_w(p.w.N, R, NWV), ny);
+    size_t lds = (size_t)(p.w.K + p.w.nb + 4 * NWV) * sizeof(float);
+    if (EPI == EPI_ROPE_KV_ATTN) {
+        if (ny != 1 || !p.attn_cnt || !p.attn_out || !q4_gemv_attn_fusable(p.w.N, p.w.K, p.hd, p.n_q, p.n_k, p.attn_max_seq)) return hipErrorInvalidValue;
+        lds = lds > gemv_attn_lds(p.attn_max_seq) ? lds : gemv_attn_lds(p.attn_max_seq);
+    }
+    auto kern = q4_gemv_kernel<P, R, PRO, EPI, NWV>;
     static bool attr_done = false;
     hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
     if (e != hipSuccess) return e;
-    kern<<<grid, dim3(256), lds, s>>>(p);
+    kern<<<grid, dim3(64 * NWV), lds, s>>>(p);
     return hipGetLastError();
+}
+// fat workgroups are instantiated for the decode-step shapes only (R*nb % 64 == 0 passes: (R, P) = (2,3) (1,2) (1,5) (1,3) (2,2))
+template <int P, int R, int PRO, int EPI>
+static hipError_t gemv_launch_t(const GemvParams& p, int ny, hipStream_t s) {
+    constexpr bool fat = (R == 2 && P == 3) || (R == 1 && (P == 2 || P == 5));      // == gemv_fat_shape(K, R)
+    if (fat) {
+        const int nwv = q4_gemv_nwv(p.w.K, EPI);
+        if (nwv == 12) return gemv_launch_w<P, R, PRO, EPI, fat ? 12 : 4>(p, ny, s);
+        if (nwv == 6) return gemv_launch_w<P, R, PRO, EPI, fat ? 6 : 4>(p, ny, s);
+    }
+    return gemv_launch_w<P, R, PRO, EPI, 4>(p, ny, s);
 }
 
 template <int P, int R>
@@ -439,13 +547,14 @@ static hipError_t gemv_dispatch_pe(const GemvParams& p, int ny, int pro, int epi
         if (pro == PRO_RMS_MUL && epi == EPI_SWIGLU) return gemv_launch_t<P, R2, PRO_RMS_MUL, EPI_SWIGLU>(p, ny, s);
         if (pro == PRO_NONE && epi == EPI_SWIGLU) return gemv_launch_t<P, R2, PRO_NONE, EPI_SWIGLU>(p, ny, s);
         if (pro == PRO_RMS && epi == EPI_ROPE_KV) return gemv_launch_t<P, R2, PRO_RMS, EPI_ROPE_KV>(p, ny, s);
+        if (pro == PRO_RMS && epi == EPI_ROPE_KV_ATTN && R == 2) return gemv_launch_w<P, 2, PRO_RMS, EPI_ROPE_KV_ATTN, 4>(p, ny, s);
     }
 #undef VOX_CASE
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_q4_gemv(const GemvParams& p_in, int ny, int pro, int epi, int R, hipStream_t s) {
-    GemvParams p = p_in; p.tl_slot = tl_take_slot();
+    GemvParams p = p_in; p.tl_slot = tl_take_slot(0, epi, p.w.N, p.w.K);
     if (p.w.fmt == WFMT_BF16) return launch_dense_gemv(p, ny, pro, epi, s);
     if (p.w.K % 32 || p.w.K <= 0 || p.w.N <= 0 || R <= 0 || p.w.N % R) return hipErrorInvalidValue;
     const int P = passes_for(p.w.K, R);
@@ -1938,69 +2047,58 @@ hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n
 // single-query GQA attention against the cache (gguf/model.rs:125-174 with q_len == 1): one workgroup per
 // q-head, KV heads are NOT expanded (model.rs:177-197 materialises x4; here q-head h reads kv-head h/group).
 // ------------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
+// One query head against its KV head's cache rows [j_lo, pos], 256 threads; shared by attn_decode_kernel and by the fused
+// q|k|v GEMV + attention kernel (q4_gemv_kernel<.., EPI_ROPE_KV_ATTN>).  NT: every q / K / V load is non-temporal (bypasses this CU's L1,
+// served by L2 / memory): required when the rows were written by OTHER workgroups of the SAME launch (write-through stores).
+// Returns the normalised output float4 for threads tid < HD/4 (column tid); sc: n floats, red: 8 floats, osum: 256 float4 of LDS.
+template <bool NT>
+__device__ __forceinline__ float4 ldf4(const float* p) {
+    if (NT) { const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+    return *reinterpret_cast<const float4*>(p);
+}
+// LATE_V: the V rows of the first NPRE*32 keys are requested only after their K rows have been consumed (the K registers are reused:
+// ~half the VGPRs, one more round trip that overlaps the softmax) -- the fused GEMV + attention kernel needs 3 waves per SIMD.
+template <int HD, bool NT, bool LATE_V>
+__device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh, const float* __restrict__ kb, const float* __restrict__ vb, int kv_row_stride,
+                                                   int pos, int window, float* __restrict__ sc, float* __restrict__ red, float4* __restrict__ osum, int tl_slot, int tlw) {
     // Latency-bound (a few hundred KB of K/V per layer): the structure maximises independent loads in flight.
     // scores: 8 lanes per key (each lane HD/8 contiguous floats, float4 loads), 32 keys per pass, 2 passes unrolled;
     // P.V   : 8 key groups x HD/4 float4 columns, 4 keys unrolled.  All loads are unconditional (clamped).
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sc = smem;                 // scores / probabilities, up to max_seq
-    __shared__ float red[8];
-    __shared__ float4 osum[256];
     static_assert(HD == 128 || HD == 64, "head_dim");
     constexpr int PER = HD / 8;       // floats per lane in the score phase
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Many sequences: hardware deals workgroups round-robin to the 8 XCDs (each with its own L2) by linear id, which would scatter the
-    // G query heads that share one KV head over G different L2s.  Re-map so that they occupy consecutive slots of ONE XCD: the K / V rows
-    // are then fetched from HBM / MALL once and hit in L2 for the other G-1 heads.
-    int h = blockIdx.x, seq = blockIdx.y;
-    {
-        const int G_ = p.n_heads / p.n_kv_heads, total = gridDim.x * gridDim.y;
-        if (G_ > 1 && total % (8 * G_) == 0 && !p.no_xcd_remap) {
-            const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-            const int pair = xcd * (total / (8 * G_)) + slot / G_;                 // (kv head, sequence) pair index
-            h = (pair % p.n_kv_heads) * G_ + slot % G_; seq = pair / p.n_kv_heads;
-        }
-    }
-    const int kvh = h / (p.n_heads / p.n_kv_heads);
-    const int pos = (p.pos_ptr ? p.pos_ptr[p.pos_per_seq ? seq : 0] : 0) + p.offset;
     const int len = pos + 1;
-    const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0;
+    const int j_lo = window >= 0 ? max(0, pos - window) : 0;
     const int n = len - j_lo;
     const float scale = 1.0f / sqrtf((float)HD);
-    const float* kb = p.k + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
-    const float* vb = p.v + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
-    const float* qrow = p.q + (size_t)seq * p.q_seq_stride;
-    float* orow = p.out + (size_t)seq * p.out_seq_stride;
     const int ks = tid >> 3, part = tid & 7;
-    const int tlw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave; (void)tlw;
-    VOX_TL(p.tl_slot, tlw, 0);
+    (void)tl_slot; (void)tlw;
     float qv[PER];
 #pragma unroll
     for (int e = 0; e < PER; e += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(qrow + h * HD + part * PER + e);
+        const float4 v = ldf4<NT>(qh + part * PER + e);
         qv[e] = v.x; qv[e + 1] = v.y; qv[e + 2] = v.z; qv[e + 3] = v.w;
     }
     // The first NPRE*32 keys (every 16 s clip: <= 146 positions) are handled with ALL their K and V loads issued up front, before any
     // arithmetic: the kernel is a chain of dependent round trips (q -> K -> softmax -> V) and this collapses the K and V trips into one.
-    constexpr int NPRE = 5, COLS = HD / 4, GROUPS = 256 / COLS;
+    constexpr int NPRE = LATE_V ? 4 : 5, COLS = HD / 4, GROUPS = 256 / COLS;      // LATE_V (fused kernel): 128 keys up front, the register budget is 168
     static_assert(4 * GROUPS == 32 || HD != 128, "prefetch tiling assumes 32 keys per P.V iteration for HD = 128");
     const int grp = tid / COLS, col = tid % COLS;
     float4 kpre[NPRE][PER / 4], vpre[NPRE][4];
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {
         const int jc = j_lo + min(32 * u + ks, n - 1);
-        const float* kr = kb + (size_t)jc * p.kv_row_stride + part * PER;
+        const float* kr = kb + (size_t)jc * kv_row_stride + part * PER;
 #pragma unroll
-        for (int e = 0; e < PER / 4; e++) kpre[u][e] = *reinterpret_cast<const float4*>(kr + 4 * e);
+        for (int e = 0; e < PER / 4; e++) kpre[u][e] = ldf4<NT>(kr + 4 * e);
     }
-#pragma unroll
-    for (int u = 0; u < NPRE; u++)
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const int ic = min(u * 4 * GROUPS + grp + w * GROUPS, n - 1);
-            vpre[u][w] = *reinterpret_cast<const float4*>(vb + (size_t)(j_lo + ic) * p.kv_row_stride + col * 4);
+#define VOX_VPRE                                                                                              \
+    _Pragma("unroll") for (int u = 0; u < NPRE; u++)                                                          \
+        _Pragma("unroll") for (int w = 0; w < 4; w++) {                                                       \
+            const int ic = min(u * 4 * GROUPS + grp + w * GROUPS, n - 1);                                     \
+            vpre[u][w] = ldf4<NT>(vb + (size_t)(j_lo + ic) * kv_row_stride + col * 4);                        \
         }
+    if (!LATE_V) { VOX_VPRE }
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {
         float s = 0.f;
@@ -2013,16 +2111,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
         const int i = 32 * u + ks;
         if (part == 0 && i < n) sc[i] = s * scale;
     }
+    if (LATE_V) { VOX_VPRE }
+#undef VOX_VPRE
     for (int i0 = 32 * NPRE; i0 < n; i0 += 64) {
         float s2[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int i = i0 + 32 * u + ks, jc = j_lo + min(i, n - 1);
-            const float* kr = kb + (size_t)jc * p.kv_row_stride + part * PER;
+            const float* kr = kb + (size_t)jc * kv_row_stride + part * PER;
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < PER; e += 4) {
-                const float4 kv = *reinterpret_cast<const float4*>(kr + e);
+                const float4 kv = ldf4<NT>(kr + e);
                 s = fmaf(qv[e], kv.x, s); s = fmaf(qv[e + 1], kv.y, s); s = fmaf(qv[e + 2], kv.z, s); s = fmaf(qv[e + 3], kv.w, s);
             }
             s2[u] = s;
@@ -2035,7 +2135,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
         }
     }
     __syncthreads();
-    VOX_TL(p.tl_slot, tlw, 1);
+    VOX_TL(tl_slot, tlw, 1);
     float mx = -INFINITY;
     for (int i = tid; i < n; i += 256) mx = fmaxf(mx, sc[i]);
     mx = wave_max(mx);
@@ -2047,7 +2147,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     sum = wave_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
-    VOX_TL(p.tl_slot, tlw, 2);
+    VOX_TL(tl_slot, tlw, 2);
     sum = (red[4] + red[5]) + (red[6] + red[7]);
     // P.V : thread -> (key group, float4 column)
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2067,7 +2167,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = i0 + u * GROUPS, ic = min(i, n - 1);
-            vv[u] = *reinterpret_cast<const float4*>(vb + (size_t)(j_lo + ic) * p.kv_row_stride + col * 4);
+            vv[u] = ldf4<NT>(vb + (size_t)(j_lo + ic) * kv_row_stride + col * 4);
             pr[u] = i < n ? sc[ic] : 0.f;
         }
 #pragma unroll
@@ -2077,12 +2177,46 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     }
     osum[tid] = o;
     __syncthreads();
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < COLS) {
         float4 t = osum[tid];
 #pragma unroll
         for (int gq = 1; gq < GROUPS; gq++) { const float4 u = osum[gq * COLS + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
         const float inv = 1.0f / sum;
-        const float4 r4 = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+        r4 = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
+    return r4;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sc = smem;                 // scores / probabilities, up to max_seq
+    __shared__ float red[8];
+    __shared__ float4 osum[256];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    // Many sequences: hardware deals workgroups round-robin to the 8 XCDs (each with its own L2) by linear id, which would scatter the
+    // G query heads that share one KV head over G different L2s.  Re-map so that they occupy consecutive slots of ONE XCD: the K / V rows
+    // are then fetched from HBM / MALL once and hit in L2 for the other G-1 heads.
+    int h = blockIdx.x, seq = blockIdx.y;
+    {
+        const int G_ = p.n_heads / p.n_kv_heads, total = gridDim.x * gridDim.y;
+        if (G_ > 1 && total % (8 * G_) == 0 && !p.no_xcd_remap) {
+            const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+            const int pair = xcd * (total / (8 * G_)) + slot / G_;                 // (kv head, sequence) pair index
+            h = (pair % p.n_kv_heads) * G_ + slot % G_; seq = pair / p.n_kv_heads;
+        }
+    }
+    const int kvh = h / (p.n_heads / p.n_kv_heads);
+    const int pos = (p.pos_ptr ? p.pos_ptr[p.pos_per_seq ? seq : 0] : 0) + p.offset;
+    const float* kb = p.k + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const float* vb = p.v + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const float* qrow = p.q + (size_t)seq * p.q_seq_stride;
+    float* orow = p.out + (size_t)seq * p.out_seq_stride;
+    const int tlw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave; (void)tlw;
+    VOX_TL(p.tl_slot, tlw, 0);
+    const float4 r4 = attn_decode_core<HD, false, false>(qrow + h * HD, kb, vb, p.kv_row_stride, pos, p.window, sc, red, osum, p.tl_slot, tlw);
+    if (tid < HD / 4) {
         if (p.out_xf) xf_store4(p.out_xf, p.n_heads * HD, seq, h * HD + tid * 4, r4);       // batched decode: A-fragments of the wo GEMM
         else *reinterpret_cast<float4*>(orow + h * HD + tid * 4) = r4;
     }
@@ -2214,7 +2348,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const AttnParams p
     }
 }
 hipError_t launch_attn_decode(const AttnParams& p_in, int hd, int max_seq, hipStream_t s, int n_seq) {
-    AttnParams p = p_in; p.tl_slot = tl_take_slot();
+    AttnParams p = p_in; p.tl_slot = tl_take_slot(1, 0, p.n_heads, hd);
     const size_t lds = (size_t)max_seq * sizeof(float);
     if (hd == 128 && p.prefer_gqa && p.n_heads == 4 * p.n_kv_heads && p.kv_head_stride == max_seq * 128 && !env_int("VOX_ATTN_NO_GQA")) {
         auto kern = attn_decode_gqa_kernel<4>;      // many sequences: one workgroup per (KV head, sequence), K/V fetched once for its 4 query heads
