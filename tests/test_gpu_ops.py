@@ -108,6 +108,24 @@ def test_q4_matmul_model_shapes_random(pkg, orc, ctx, k, n, m):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("m,k,n", [(17, 128, 16), (32, 3072, 528), (38, 4096, 3072), (48, 9216, 200), (33, 1280, 2050), (47, 3072, 18432 // 8)])
+def test_q4_skinny_mt_prefill_rows(pkg, orc, ctx, m, k, n, monkeypatch):
+    """17..48 rows (the 38-token decoder prefill): q4_skinny_mt_kernel -- 2 or 3 m-tiles sharing one weight fetch, split-K over 4 waves;
+    ragged N and M, with bias (Q4Linear), against the oracle and against the 32 x 128 MFMA kernel it replaces (VOX_NO_SKINNY_MT=1)."""
+    rng = np.random.default_rng(m * 5 + k + n)
+    raw = pkg.synth.synth_q4_blocks(rng, n * k, 0.04)
+    x = (rng.standard_normal((1, m, k)) * (1 + np.arange(k) / k)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    w = pkg.Q4Tensor.from_q4_bytes(raw, [n, k], ctx)
+    exp = orc.q4_matmul(raw, n, k, x, bias=bias)
+    out = pkg.Q4Linear(w, bias).forward(x)
+    assert np.abs(out - exp).max() / np.abs(exp).max() < 2e-5
+    monkeypatch.setenv("VOX_NO_SKINNY_MT", "1")
+    old = pkg.Q4Linear(w, bias).forward(x)
+    assert np.abs(out - old).max() / np.abs(exp).max() < 2e-5
+    w.close()
+
+
 @pytest.mark.parametrize("m,k,n", [(5, 32, 16), (17, 64, 48), (64, 128, 64), (65, 96, 80), (146, 5120, 256), (586, 1280, 192)])
 def test_q4_gemm_ragged(pkg, orc, ctx, m, k, n):
     """MFMA GEMM edge tiles: M, N not multiples of the 64x64 workgroup tile; transposition-detecting (asymmetric) data."""

@@ -70,3 +70,30 @@ def test_cli_end_to_end(pkg, tmp_path):
     # --batch (extension): un-chunked files go through vox_transcribe_batch, chunked ones one by one; same lines in the same order
     r3 = subprocess.run(cmd + ["--batch", "4"], capture_output=True, text=True, timeout=300)
     assert r3.returncode == 1 and r3.stdout == r.stdout and "batch of 1" in r3.stderr
+
+
+@pytest.mark.gpu
+def test_wer_harness_end_to_end(pkg, tmp_path, capsys):
+    """wer.main (scripts/eval_wer.py flow: manifest -> one in-process `voxtral-transcribe` run -> normalise -> WER / CER -> JSON report)."""
+    S = pkg.synth
+    cli = __import__("importlib").import_module(pkg.__name__ + ".cli")
+    gguf = str(tmp_path / "m.gguf"); S.write_synthetic_gguf(gguf, S.tiny_dims(vocab=2048), seed=5)
+    tok = str(tmp_path / "tekken.json"); json.dump(_tekken(1200), open(tok, "w"))
+    wavs = []
+    for i, sec in enumerate((3.0, 2.0, 4.0)):
+        p = str(tmp_path / f"u{i}.wav"); _write_wav(p, S.synth_audio(sec, seed=20 + i)); wavs.append(p)
+    import contextlib, io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert cli.main(["--gguf", gguf, "--tokenizer", tok] + sum((["--audio", w] for w in wavs), [])) == 0
+    texts = buf.getvalue().split("\n")[:3]
+    assert all(t for t in texts)
+    words = texts[1].split()
+    refs = [texts[0].upper() + "!", " ".join(words[:-1] + ["zzz"]), texts[2]]              # punctuation / case only; one substituted word; exact
+    man = tmp_path / "corpus.tsv"; man.write_text("".join(f"{w}\t{r}\n" for w, r in zip(wavs, refs)))
+    out = tmp_path / "wer.json"
+    assert pkg.wer.main(["--manifest", str(man), "--gguf", gguf, "--tokenizer", tok, "--output", str(out), "--dataset", "toy", "--batch", "2"]) == 0
+    rep = json.loads(out.read_text())
+    n_words = sum(len(pkg.wer.normalize_text(r).split()) for r in refs)
+    assert rep["total_utterances"] == 3 and rep["aggregate_wer"] == pytest.approx(1 / n_words) and rep["utterances"][0]["wer"] == 0.0 and rep["utterances"][2]["wer"] == 0.0
+    assert rep["total_audio_secs"] == pytest.approx(9.0, abs=0.01) and rep["rtf"] > 0 and "WER Evaluation Report: toy" in capsys.readouterr().out

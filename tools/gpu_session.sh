@@ -21,5 +21,6 @@ step_prof()      { cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --outpu
                    f=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_kernel_stats.csv && head -24 $f | cut -c1-160; }
 step_profbatch() { cd /tmp; VOX_BATCH_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_profb -o p -- python $REPO/tools/batch_prof.py 16 > $OUT/${TAG}_profb.log 2>&1; echo "profbatch rc=$?"; cd $REPO
                    f=$(find $OUT/${TAG}_profb -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_batch16_kernel_stats.csv && head -16 $f | cut -c1-160; }
+step_prefill()   { timeout 300 python tools/prefill_bench.py 2>&1 | tee $OUT/${TAG}_prefill.txt | tail -6; }
 step_batch()     { timeout 300 python tools/batch_prof.py ${VOX_BENCH_BATCH:-16} 2>&1 | tail -4; }
 for s in "$@"; do echo "=== $s"; t0=$(date +%s); step_$s; echo "--- $s took $(( $(date +%s) - t0 )) s"; done

@@ -10,5 +10,6 @@ from ._lib import lib, VoxError  # noqa: F401
 from .audio import (PadConfig, ChunkConfig, MelSpectrogram, pad_audio, chunk_audio, needs_chunking,  # noqa: F401
                     peak_normalize, TimeEmbedding)
 from .tokenizer import VoxtralTokenizer  # noqa: F401
+from . import wer  # noqa: F401  (WER / CER harness, scripts/eval_wer.py)
 from .models import VoxtralModel, VoxtralModelLoader  # noqa: F401
 from .gguf import (Context, GgufReader, Q4Tensor, Q4Linear, q4_matmul, Q4ModelLoader, Q4VoxtralModel)  # noqa: F401

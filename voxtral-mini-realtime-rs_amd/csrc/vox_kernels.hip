@@ -881,7 +881,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 // 4*NT*MT*2 MFMAs against 8*MT ds_read_b128 -- 4x the work per barrier of the K-32 kernel above (kept as the
 // fallback for K % 128 != 0).  Same operand conventions: A = activations (hi+lo bf16 through LDS in fragment order),
 // B = integer Q4 weights straight from global (one dword per lane per block) or dense bf16 (16 B per lane per step).
-template <int MT, int NT, int EPI, int FMT>
+// TB: Q4 weights come from the tile-ordered copy (one coalesced dwordx4 per lane per n-tile per K step = the lane's dword of the four blocks)
+// instead of four strided dword loads from the row planes -- used for the 33..48-row prefill tile (MT = 3), where the weight stream is the bound.
+template <int MT, int NT, int EPI, int FMT, int TB = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q4_gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint4 glds[];      // [buf 2][hi/lo 2][j 4][MT][64]
     constexpr int PLANE = 4 * MT * 64, BUF = 2 * PLANE;
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     }
     // MFMA role
     const int wg = lane >> 4;
-    const uint32_t* wq[NT]; const uint16_t* ws[NT]; const uint4* wd16[NT]; int wn[NT]; bool wok[NT];
+    const uint32_t* wq[NT]; const uint16_t* ws[NT]; const uint4* wd16[NT]; const uint4* wqt[NT]; int wn[NT]; bool wok[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         wn[t] = n0 + (wave * NT + t) * 16 + (lane & 15); wok[t] = wn[t] < N;
@@ -907,6 +909,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
         wq[t] = reinterpret_cast<const uint32_t*>(p.w.qs) + row * nb * 4 + wg;
         ws[t] = FMT == WFMT_Q4_0 ? p.w.sc + row * nb : nullptr;
         wd16[t] = p.w.qs + row * nb * 4 + wg;
+        const size_t T = (size_t)min((n0 >> 4) + wave * NT + t, ((N + 15) >> 4) - 1);
+        wqt[t] = TB ? p.w.qt + T * nq * 64 + lane : nullptr;
     }
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -923,7 +927,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     }                                                                                                          \
     _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                           \
         if (FMT == WFMT_Q4_0) {                                                                                \
-            _Pragma("unroll") for (int j = 0; j < 4; j++) wd[t][j] = wq[t][(size_t)(4 * (Q_) + j) * 4];        \
+            if (TB) { const uint4 w4 = ld_nt_u4(wqt[t] + (size_t)64 * (Q_)); wd[t][0] = w4.x; wd[t][1] = w4.y; wd[t][2] = w4.z; wd[t][3] = w4.w; } \
+            else { _Pragma("unroll") for (int j = 0; j < 4; j++) wd[t][j] = wq[t][(size_t)(4 * (Q_) + j) * 4]; } \
             wsc[t] = *reinterpret_cast<const uint2*>(ws[t] + 4 * (Q_));                                        \
         } else {                                                                                               \
             _Pragma("unroll") for (int j = 0; j < 4; j++) wdv[t][j] = wd16[t][(size_t)(4 * (Q_) + j) * 4];     \
@@ -1047,8 +1052,14 @@ hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef VOX_SKINNY_RING
+#define VOX_RING_ON 1
+#else
+#define VOX_RING_ON 0
+#endif
 template <int NTW, int EPI, int TILED, int XIN, int PRO>
 __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
+    constexpr bool RING = VOX_RING_ON != 0;
     extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS][NTW][64][4]
     __shared__ float s_rstd[16]; __shared__ float s_pp[32 * 16];
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
@@ -1138,7 +1149,37 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     const int per = (nq + KS - 1) / KS;
     int q = TILED ? wave * per : wave;
     const int qend = TILED ? min(q + per, nq) : nq, qs = TILED ? 1 : KS;
-    if (q < qend) {
+    if (RING && TILED && XIN && q < qend) {
+        // MEASUREMENT VARIANT (-DVOX_SKINNY_RING; not in the product build).  Batched decode step: a register RING of D K-steps of weights -- the
+        // first D steps are requested before anything else (D >= the wave's whole range for q|k|v and wo), a slot is refilled with step s + D as
+        // soon as step s has been multiplied.  Round 2 measured it 6..8 % SLOWER than one step of look-ahead on every decode shape
+        // (profiles/r02_batch16_ring_prefetch.txt): these kernels are not bound by the weight bytes each wave has in flight.
+        constexpr int D = NTW >= 4 ? 3 : 4, XB = NTW >= 4 ? 1 : 2;     // 4 tiles per wave: 3 slots and single-buffered activations keep it under 256 VGPRs
+        uint4 wr[D][NTW]; uint2 sr[D][NTW];
+#pragma unroll
+        for (int u = 0; u < D; u++) { const int qq = min(q + u, qend - 1); VOX_WLOAD(wr[u], sr[u], qq) }
+        float4 xr[XB][2][4];                                  // activation fragments: (XB = 2) step s + 1 requested before step s is multiplied
+#define VOX_XLOAD2(B_, Q_)                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                    \
+            xr[B_][0][j] = *reinterpret_cast<const float4*>(xfh + ((Q_) * 4 + j) * 64);                    \
+            xr[B_][1][j] = *reinterpret_cast<const float4*>(xfl + ((Q_) * 4 + j) * 64); }
+        VOX_XLOAD2(0, q)
+        __builtin_amdgcn_sched_barrier(0);
+        for (int base = 0; q + base < qend; base += 2 * D) {  // unrolled by 2 D: ring slot and activation buffer indices are compile-time
+#pragma unroll
+            for (int u = 0; u < 2 * D; u++) {
+                const int st = q + base + u;
+                if (st < qend) {                              // wave-uniform
+                    if (XB == 2) { const int qx = min(st + 1, qend - 1); VOX_XLOAD2((u + 1) & (XB - 1), qx) }
+                    else if (u > 0 || base > 0) { VOX_XLOAD2(0, st) }
+                    VOX_SSTEP(wr[u % D], sr[u % D], xr[u & (XB - 1)][0], xr[u & (XB - 1)][1])
+                    { const int qn = min(st + D, qend - 1); VOX_WLOAD(wr[u % D], sr[u % D], qn) }       // refill (clamped: harmless re-read at the tail)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#undef VOX_XLOAD2
+    } else if (q < qend) {
         VOX_WLOAD(wv, sv, q)
         for (;;) {
             // the weight prefetch for the NEXT step is issued (and pinned) before anything of this step: hipcc otherwise sinks
@@ -1237,6 +1278,141 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             }
         }
     }
+}
+
+// ---- skinny MFMA GEMM for 17..48 rows (the 38-token decoder prefill, gguf/model.rs:908-923): MT m-tiles of 16 rows share ONE weight fetch.
+// The 32 x 128 MFMA kernel walks the weights once per 16-row m-tile (three times for M = 38: 0.5 TB/s, profiles/r01_bench_kernel_stats.csv);
+// here a wave owns NTW n-tiles and a contiguous range of 128-wide K steps (split-K over the 4 waves of the workgroup, combined through LDS in
+// a fixed order), converts its tile-ordered weight dwords to bf16 B fragments ONCE per K step and reuses them for the MT activation tiles
+// (f32 rows read from L2, split hi + lo bf16 in registers).  Same arithmetic as q4_skinny_kernel: exact integer weights through the matrix
+// core, f16 block scale applied to the f32 result, -136 * sum(x) through a constant-B MFMA pair.
+template <int MT, int NTW, int EPI>
+__global__ __launch_bounds__(256) void q4_skinny_mt_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS 4][MT][NTW][64][4]
+    const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int KS = 4;
+    const int g = lane >> 4, li = lane & 15;
+    const int nbase = blockIdx.x * (16 * NTW), n_tiles = (N + 15) >> 4;
+    const float* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) xrow[mt] = p.x + (size_t)min(mt * 16 + li, M - 1) * p.x_stride;
+    const uint4* wq[NTW]; const uint16_t* ws[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const size_t T = (size_t)min(blockIdx.x * NTW + t, n_tiles - 1);
+        wq[t] = p.w.qt + T * nq * 64 + lane; ws[t] = p.w.st + (T * nq * 16 + li) * 4;
+    }
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int per = (nq + KS - 1) / KS, q0 = wave * per, q1 = min(q0 + per, nq);
+    const bf16x8 m136 = as_bf16x8(make_uint4(0xC308C308u, 0xC308C308u, 0xC308C308u, 0xC308C308u));
+    uint4 wv[NTW]; uint2 sv[NTW];
+    if (q0 < q1) {
+#pragma unroll
+        for (int t = 0; t < NTW; t++) { wv[t] = ld_nt_u4(wq[t] + 64 * q0); sv[t] = *reinterpret_cast<const uint2*>(ws[t] + 64 * q0); }
+    }
+    for (int q = q0; q < q1; q++) {
+        uint4 wn[NTW]; uint2 sn[NTW];
+        const int qn = min(q + 1, q1 - 1);
+#pragma unroll
+        for (int t = 0; t < NTW; t++) { wn[t] = ld_nt_u4(wq[t] + 64 * qn); sn[t] = *reinterpret_cast<const uint2*>(ws[t] + 64 * qn); }   // next step's weights in flight first
+        // B fragments + block scales of this K step, once for all m-tiles
+        bf16x8 bw[NTW][4]; float dsc[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            const uint32_t dw[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w}; const uint32_t sc2[2] = {sv[t].x, sv[t].y};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bw[t][j] = as_bf16x8(q4_dword_to_bf16x8_biased(dw[j]));
+                dsc[t][j] = f16_bits_to_f32((uint16_t)((j & 1) ? (sc2[j >> 1] >> 16) : (sc2[j >> 1] & 0xFFFFu)));
+            }
+        }
+        // (requesting tile mt + 1's rows before tile mt is multiplied -- a register ping-pong -- measured SLOWER: 7.1 vs 4.8 ms per prefill)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            float4 xa[4], xb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                xa[j] = *reinterpret_cast<const float4*>(xrow[mt] + 128 * q + 32 * j + 4 * g);
+                xb[j] = *reinterpret_cast<const float4*>(xrow[mt] + 128 * q + 32 * j + 16 + 4 * g);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint4 ah, al;
+                split_pair(xa[j].x, xa[j].z, ah.x, al.x); split_pair(xb[j].x, xb[j].z, ah.y, al.y);
+                split_pair(xa[j].y, xa[j].w, ah.z, al.z); split_pair(xb[j].y, xb[j].w, ah.w, al.w);
+                f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), m136, cs, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTW; t++) {
+                    f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), bw[t][j], cs, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), bw[t][j], tt, 0, 0, 0);
+                    const float d = dsc[t][j];
+                    acc[mt][t] = __builtin_elementwise_fma((f32x4){d, d, d, d}, tt, acc[mt][t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; t++) { wv[t] = wn[t]; sv[t] = sn[t]; }
+    }
+    // split-K combine (fixed order) + epilogue: wave w finishes (m-tile, n-tile) pairs w, w + 4, ...
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+            *reinterpret_cast<float4*>(sred + ((size_t)((wave * MT + mt) * NTW + t) * 64 + lane) * 4) = make_float4(acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]);
+    __syncthreads();
+    for (int pr = wave; pr < MT * NTW; pr += KS) {
+        const int mt = pr / NTW, t = pr % NTW;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < KS; w++) {
+            const float4 v = *reinterpret_cast<const float4*>(sred + ((size_t)((w * MT + mt) * NTW + t) * 64 + lane) * 4);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        const int n = nbase + t * 16 + li; const bool nok = n < N;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+        const float vals[4] = {sum.x + bias, sum.y + bias, sum.z + bias, sum.w + bias};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = mt * 16 + 4 * g + r;
+            float v = vals[r];
+            if (EPI == EPI_SWIGLU) {
+                const float other = dpp_mov<0xB1>(v);        // lane^1; rows interleaved: even n = gate, odd n = up
+                if (m < M && nok && !(n & 1)) p.out[(size_t)m * p.out_stride + (n >> 1)] = silu_f(v) * other;
+            } else if (m < M && nok) {
+                if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + n];
+                if (EPI == EPI_GELU) v = gelu_f(v);
+                p.out[(size_t)m * p.out_stride + n] = v;
+            }
+        }
+    }
+}
+template <int MT, int NTW>
+static hipError_t skinny_mt_launch(const GemmParams& p, int epi, hipStream_t s) {
+    dim3 grid((p.w.N + 16 * NTW - 1) / (16 * NTW));
+    const size_t lds = (size_t)4 * MT * NTW * 64 * 4 * sizeof(float);
+    switch (epi) {
+    case EPI_STORE: q4_skinny_mt_kernel<MT, NTW, EPI_STORE><<<grid, dim3(256), lds, s>>>(p); break;
+    case EPI_RESID: q4_skinny_mt_kernel<MT, NTW, EPI_RESID><<<grid, dim3(256), lds, s>>>(p); break;
+    case EPI_GELU: q4_skinny_mt_kernel<MT, NTW, EPI_GELU><<<grid, dim3(256), lds, s>>>(p); break;
+    case EPI_SWIGLU: q4_skinny_mt_kernel<MT, NTW, EPI_SWIGLU><<<grid, dim3(256), lds, s>>>(p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+// 17..48 rows, tile-ordered Q4 weights, K % 128 == 0, 16-byte aligned f32 rows
+static hipError_t launch_q4_skinny_mt(const GemmParams& p, int epi, hipStream_t s) {
+    const int mt = (p.M + 15) / 16, tiles = (p.w.N + 15) / 16;
+    int ntw = tiles >= 512 ? 2 : 1;                           // two n-tiles per wave only while >= 256 workgroups remain
+    { const int e = env_int("VOX_SKINNY_MT_NTW"); if (e == 1 || e == 2) ntw = e; }
+#define VOX_MTN(M_, N_) if (mt == M_ && ntw == N_) return skinny_mt_launch<M_, N_>(p, epi, s)
+    VOX_MTN(2, 1); VOX_MTN(2, 2); VOX_MTN(3, 1); VOX_MTN(3, 2);
+#undef VOX_MTN
+    return hipErrorInvalidValue;
 }
 
 // ---- large-M MFMA GEMM (batched encoder / long prefill): workgroup tile (64*WGM) x (64*WGN), four waves in a WGM x WGN grid,
@@ -1543,11 +1719,11 @@ static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) 
     return tiled ? skinny_launch_n<1, 1>(p, epi, ks, s) : skinny_launch_n<1, 0>(p, epi, ks, s);
 }
 
-template <int MT, int NT, int FMT>
+template <int MT, int NT, int FMT, int TB = 0>
 static hipError_t gemm_launch_mn(const GemmParams& p, int epi, hipStream_t s) {
     dim3 grid((p.w.N + 64 * NT - 1) / (64 * NT), (p.M + 16 * MT - 1) / (16 * MT));
     const size_t lds = (size_t)2 * 2 * 4 * MT * 64 * sizeof(uint4);     // MT * 16 KB
-#define VOX_E(E_) case E_: { auto kern = q4_gemm_kernel<MT, NT, E_, FMT>; static bool done = false;          \
+#define VOX_E(E_) case E_: { auto kern = q4_gemm_kernel<MT, NT, E_, FMT, TB>; static bool done = false;      \
         hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;                       \
         kern<<<grid, dim3(256), lds, s>>>(p); break; }
     switch (epi) { VOX_E(EPI_STORE) VOX_E(EPI_RESID) VOX_E(EPI_GELU) VOX_E(EPI_SWIGLU) default: return hipErrorInvalidValue; }
@@ -1596,6 +1772,16 @@ hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
     if (p.xf) return (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && p.w.qt) ? launch_q4_skinny(p, epi, s) : hipErrorInvalidValue;
     if (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && !env_int("VOX_NO_SKINNY")) return launch_q4_skinny(p, epi, s);
+    if (p.M > 16 && p.M <= 48 && p.w.fmt == WFMT_Q4_0 && p.w.qt && p.w.st && p.w.nb % 4 == 0 && (p.x_stride % 4) == 0 && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_GELU || epi == EPI_SWIGLU) &&
+        !env_int("VOX_NO_SKINNY_MT")) {
+        // the 38-row decoder prefill: the weights are streamed ONCE for all m-tiles.  VOX_PREFILL_KERNEL: 0 auto, 1 = q4_skinny_mt_kernel (activation rows
+        // from L2 per wave), 2 = q4_gemm_kernel<3, NT, ., ., tile-ordered B> (48 x 64NT workgroup tile, activations staged + converted once per workgroup)
+        const int pk = env_int("VOX_PREFILL_KERNEL");
+        if (pk != 2) return launch_q4_skinny_mt(p, epi, s);      // measured (profiles/r02_prefill_kernels.txt): 5.69 ms (round 1) / 4.84 / 7.06 ms (the 48-row tile leaves 48..288 workgroups)
+        const long wg1 = (p.w.N + 63) / 64;
+        int nt = wg1 >= 512 ? 2 : 1; { const int e = env_int("VOX_GEMM_NT"); if (e == 1 || e == 2) nt = e; }
+        return nt == 2 ? gemm_launch_mn<3, 2, WFMT_Q4_0, 1>(p, epi, s) : gemm_launch_mn<3, 1, WFMT_Q4_0, 1>(p, epi, s);
+    }
     if (p.w.fmt == WFMT_Q4_0 && p.w.qt && p.w.st && p.w.nb % 4 == 0 && (p.x_stride % 4) == 0) {
         // large M: 64 x 256 workgroup tiles (64 x 64 per wave) once they fill the chip -- 1.2-1.55x the 32 x 128 kernel
         // (profiles/r01_gemm_sweep.txt).  VOX_GEMM_BIG: 0 auto, 1 force, -1 off (measurement knob)
