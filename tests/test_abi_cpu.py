@@ -127,3 +127,15 @@ def test_synthetic_gguf_is_readable_by_both(pkg, orc, tmp_path):
     dense = pkg.synth.gguf_dense_f32(p)
     wq = dense[pkg.synth.ENC + ".transformer.layers.0.attention.wq.weight"]
     assert wq.shape == (128, 128) and abs(float(wq.mean())) < 2e-3 and 0.02 < float(wq.std()) < 0.04
+
+
+def test_integration_md_sys_block_is_complete_and_current(pkg):
+    """INTEGRATION.md section 2 is generated from the header: every declared symbol has its Rust declaration and the block is not stale."""
+    import subprocess, sys
+    hdr = open(os.path.join(ROOT, "include", "voxtral_hip.h")).read()
+    declared = set(re.findall(r"\b(vox_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("BEGIN GENERATED -sys"):doc.index("END GENERATED -sys")]
+    for name in sorted(declared):
+        assert f"pub fn {name}(" in block, name
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_sys_block.py"), "--check"]).returncode == 0
