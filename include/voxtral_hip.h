@@ -199,6 +199,15 @@ int32_t vox_decoder_cache_create(vox_model* m, int32_t max_seq, vox_cache** out)
 int32_t vox_cache_free(vox_cache* c);
 int32_t vox_cache_seq_len(const vox_cache* c, int32_t* out);                         /* KVCache::seq_len */
 int32_t vox_cache_reset(vox_cache* c);
+/* Streaming encoder: Q4AudioEncoder::create_cache + Q4VoxtralModel::encode_audio_with_cache (gguf/model.rs:437-459,791-799; per layer
+ * :299-317,125-174), eviction KVCache::apply_sliding_window (kv_cache.rs:176-203).  The chunk's conv output rows are run through the 32 layers
+ * against the cached K / V (RoPE at the absolute stream position; the cache evicts rows older than the 750-row window by itself when a chunk
+ * does not fit), then reshaped / adapted like encode_audio: floor(S_chunk / 4) rows of [dec_dim].  capacity_rows 0 = 2 * window + 512. */
+int32_t vox_encoder_cache_create(vox_model* m, int32_t capacity_rows, vox_cache** out);
+int32_t vox_encoder_cache_apply_sliding_window(vox_cache* enc_cache, int32_t window);
+int32_t vox_cache_abs_pos(const vox_cache* c, int32_t* out);      /* encoder cache: stream positions seen so far; decoder cache: == seq_len */
+int32_t vox_encode_audio_with_cache(vox_model* m, const float* mel_128xT, int32_t T, vox_cache* enc_cache, float* out, int32_t cap_rows,
+                                    int32_t* S, int32_t mem_kind);
 int32_t vox_embed_tokens_from_ids(vox_model* m, const int32_t* ids, int32_t n, float* out_nxD);      /* host out */
 int32_t vox_forward_hidden_with_cache(vox_model* m, const float* x_MxD, int32_t M, const float* t_embed,
                                       vox_cache* cache, float* out_MxD);                              /* host in/out */

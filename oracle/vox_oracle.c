@@ -703,6 +703,71 @@ int orc_encode_audio(const orc_model* m, const float* mel, int T, float* out) {
     free(x); return S4;
 }
 
+/* ---- streaming encoder: Q4AudioEncoder::forward_with_cache (gguf/model.rs:437-452), Q4EncoderLayer::forward_with_cache (:299-317),
+ * Q4Attention::forward_with_cache (:125-174: offset = cache length, k/v appended, causal + sliding-window masks with offset),
+ * Q4VoxtralModel::encode_audio_with_cache (:791-799).  The cache is the reference's DYNAMIC (cat-based) mode, the only one
+ * KVCache::apply_sliding_window (kv_cache.rs:176-203) supports: evict = keep the last `window` rows.  `abs` = positions seen so far
+ * = RoPE offset of the next chunk (the reference uses cache.seq_len() for both; after an eviction its seq_len() restarts from the window
+ * size, which would rotate new keys with the wrong phase -- nothing in the reference calls apply_sliding_window, so the streaming path here
+ * keeps the ABSOLUTE position for RoPE: chunked == whole-utterance for any stream length, which is the property the tests pin). */
+struct orc_enc_cache { int layers, heads, hd, cap, len, abs; float* k; float* v; };   /* [layer][cap][heads][hd] */
+orc_enc_cache* orc_enc_cache_create(const orc_model* m, int cap) {
+    orc_enc_cache* c = (orc_enc_cache*)calloc(1, sizeof *c);
+    c->layers = m->cfg.enc_layers; c->heads = m->cfg.enc_heads; c->hd = m->cfg.enc_head_dim; c->cap = cap;
+    size_t n = (size_t)c->layers * cap * c->heads * c->hd;
+    c->k = (float*)calloc(n ? n : 1, sizeof(float)); c->v = (float*)calloc(n ? n : 1, sizeof(float)); return c;
+}
+void orc_enc_cache_free(orc_enc_cache* c) { if (c) { free(c->k); free(c->v); free(c); } }
+int orc_enc_cache_len(const orc_enc_cache* c) { return c->len; }
+int orc_enc_cache_abs(const orc_enc_cache* c) { return c->abs; }
+/* kv_cache.rs:176-203 for every layer */
+void orc_enc_cache_apply_sliding_window(orc_enc_cache* c, int window) {
+    if (c->len <= window) return;
+    const size_t row = (size_t)c->heads * c->hd; const int start = c->len - window;
+    for (int l = 0; l < c->layers; l++) {
+        float* kl = c->k + (size_t)l * c->cap * row; float* vl = c->v + (size_t)l * c->cap * row;
+        memmove(kl, kl + (size_t)start * row, sizeof(float) * (size_t)window * row);
+        memmove(vl, vl + (size_t)start * row, sizeof(float) * (size_t)window * row);
+    }
+    c->len = window;
+}
+/* returns the number of adapter rows written to out ([S4][dec_dim]); -1 if the chunk does not fit the cache */
+int orc_encode_audio_with_cache(const orc_model* m, const float* mel, int T, orc_enc_cache* kc, float* out) {
+    const orc_model_cfg* c = &m->cfg; int S = orc_enc_seq_len(m, T), D = c->enc_dim, H = c->enc_heads, hd = c->enc_head_dim;
+    if (S <= 0) return 0;
+    if (kc->len + S > kc->cap) return -1;
+    const int off = kc->len; const size_t row = (size_t)H * hd, sd = (size_t)S * D, sh = (size_t)S * row;
+    float* x = (float*)malloc(sizeof(float) * sd);
+    orc_encoder_conv(m, mel, T, x);
+    float *xn = (float*)malloc(sizeof(float) * sd), *q = (float*)malloc(sizeof(float) * sh), *at = (float*)malloc(sizeof(float) * sh), *o = (float*)malloc(sizeof(float) * sd);
+    for (int l = 0; l < c->enc_layers; l++) {
+        const enc_layer_t* L = &m->enc[l];
+        float* kl = kc->k + (size_t)l * kc->cap * row; float* vl = kc->v + (size_t)l * kc->cap * row;
+        orc_rms_norm(x, S, D, L->attn_norm, c->norm_eps, xn);
+        linear_fwd(&L->wq, xn, S, q);
+        linear_fwd(&L->wk, xn, S, kl + (size_t)off * row);
+        linear_fwd(&L->wv, xn, S, vl + (size_t)off * row);
+        orc_rope(q, S, H, hd, kc->abs, c->rope_theta); orc_rope(kl + (size_t)off * row, S, H, hd, kc->abs, c->rope_theta);
+        orc_attention(q, kl, vl, S, off + S, H, H, hd, off, 1, c->enc_window, at);
+        linear_fwd(&L->wo, at, S, o);
+        for (size_t i = 0; i < sd; i++) x[i] = o[i] + x[i];
+        orc_rms_norm(x, S, D, L->ffn_norm, c->norm_eps, xn);
+        swiglu(&L->w1, &L->w2, &L->w3, xn, S, o);
+        for (size_t i = 0; i < sd; i++) x[i] = o[i] + x[i];
+    }
+    kc->len = off + S; kc->abs += S;
+    orc_encoder_final_norm(m, x, S);
+    int S4 = S / c->reshape_factor;
+    if (S4 > 0) {
+        float* h = (float*)malloc(sizeof(float) * (size_t)S4 * m->ad0.N);
+        linear_fwd(&m->ad0, x, S4, h);
+        for (size_t i = 0; i < (size_t)S4 * m->ad0.N; i++) h[i] = orc_gelu(h[i]);
+        linear_fwd(&m->ad2, h, S4, out); free(h);
+    }
+    free(x); free(xn); free(q); free(at); free(o);
+    return S4;
+}
+
 /* gguf/model.rs:584-618 (row dequant) == select on the dequantised table (:568-576) */
 void orc_embed_tokens(const orc_model* m, const int32_t* ids, int n, float* out) {
     int64_t D = m->tok.K;

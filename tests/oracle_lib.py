@@ -107,6 +107,12 @@ def lib():
         "orc_encoder_layer": (None, [vp, C.c_int, f32p, C.c_int]),
         "orc_encoder_final_norm": (None, [vp, f32p, C.c_int]),
         "orc_encode_audio": (C.c_int, [vp, f32p, C.c_int, f32p]),
+        "orc_enc_cache_create": (vp, [vp, C.c_int]),
+        "orc_enc_cache_free": (None, [vp]),
+        "orc_enc_cache_len": (C.c_int, [vp]),
+        "orc_enc_cache_abs": (C.c_int, [vp]),
+        "orc_enc_cache_apply_sliding_window": (None, [vp, C.c_int]),
+        "orc_encode_audio_with_cache": (C.c_int, [vp, f32p, C.c_int, vp, f32p]),
         "orc_embed_tokens": (None, [vp, i32p, C.c_int, f32p]),
         "orc_cache_create": (vp, [vp, C.c_int]),
         "orc_cache_free": (None, [vp]),
@@ -236,6 +242,18 @@ class Model:
         S4 = self.enc_seq_len(T) // self.cfg.reshape_factor
         out = np.zeros((max(S4, 1), self.cfg.dec_dim), dtype=np.float32)
         n = lib().orc_encode_audio(self.h, mel, T, out)
+        return out[:n]
+
+    def enc_cache(self, cap):
+        return lib().orc_enc_cache_create(self.h, cap)
+
+    def encode_audio_with_cache(self, mel, cache):
+        mel = f32(mel); T = mel.shape[1]
+        S4 = self.enc_seq_len(T) // self.cfg.reshape_factor
+        out = np.zeros((max(S4, 1), self.cfg.dec_dim), dtype=np.float32)
+        n = lib().orc_encode_audio_with_cache(self.h, mel, T, cache, out)
+        if n < 0:
+            raise RuntimeError("oracle: chunk does not fit the encoder cache")
         return out[:n]
 
     def embed_tokens(self, ids):

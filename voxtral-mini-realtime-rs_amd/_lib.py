@@ -103,6 +103,10 @@ SIGNATURES = {
     "vox_cache_free": (i32, [vp]),
     "vox_cache_seq_len": (i32, [vp, P(i32)]),
     "vox_cache_reset": (i32, [vp]),
+    "vox_encoder_cache_create": (i32, [vp, i32, P(vp)]),
+    "vox_encoder_cache_apply_sliding_window": (i32, [vp, i32]),
+    "vox_cache_abs_pos": (i32, [vp, P(i32)]),
+    "vox_encode_audio_with_cache": (i32, [vp, vp, i32, vp, vp, i32, P(i32), i32]),
     "vox_embed_tokens_from_ids": (i32, [vp, vp, i32, vp]),
     "vox_forward_hidden_with_cache": (i32, [vp, vp, i32, vp, vp, vp]),
     "vox_lm_head": (i32, [vp, vp, i32, vp]),

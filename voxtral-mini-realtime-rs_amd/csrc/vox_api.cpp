@@ -542,7 +542,8 @@ struct Lin { Q4W w{}; const float* bias = nullptr; };
 struct EncLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2; };
 struct DecLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2, ada0, ada2; float* ada_mul = nullptr; };
 
-struct vox_cache { vox_model* m; vox_ctx* ctx = nullptr; float *k = nullptr, *v = nullptr; int max_seq = 0, len = 0; size_t layer_stride = 0; };   // layer_stride in floats   // per layer: [n_kv][max_seq][hd]
+struct vox_cache { vox_model* m; vox_ctx* ctx = nullptr; float *k = nullptr, *v = nullptr; int max_seq = 0, len = 0; size_t layer_stride = 0;
+                   int kind = 0, abs_pos = 0; };   // kind 0: decoder cache, 1: encoder (streaming) cache; abs_pos: positions seen so far (RoPE offset of the next chunk)   // layer_stride in floats   // per layer: [n_kv][max_seq][hd]
 
 struct vox_model {
     vox_ctx* ctx = nullptr; vox_model_cfg cfg{};
@@ -563,6 +564,7 @@ struct vox_model {
     vox_cache* cache = nullptr;                           // internal cache for transcribe_streaming
     int *d_tokens = nullptr, *d_pos = nullptr; int tokens_cap = 0;
     float* d_prefix = nullptr;                            // [38][dec_dim] prefill inputs (transcribe_dev)
+    float *enc_cos_s = nullptr, *enc_sin_s = nullptr; int enc_rope_s_len = 0;   // RoPE tables for the streaming encoder (positions beyond the 4096-row load-time table)
     unsigned* d_attn_cnt = nullptr; int attn_cnt_stride = 1024;   // [dec_layers][dec_heads][stride] arrival counters, 4 KB apart (VOX_ATTN_CNT_STRIDE, in uints) of the fused q|k|v + attention launch
     int* d_seq_len = nullptr; std::vector<int> h_seq_len;  // per-utterance encoder rows of a stacked batch
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
@@ -914,7 +916,7 @@ static void model_release(vox_model* m) {
     graphs_destroy(m);
     if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt})
+                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -1016,6 +1018,30 @@ static int enc_row_budget(const vox_model* m, const int* T, int n) {
     int mx = 0; for (int i = 0; i < n; i++) mx = std::max(mx, enc_rows(T[i]));
     const int r = m->cfg.reshape_factor; return n == 1 ? mx : (mx + r - 1) / r * r;
 }
+// conv stem (models/layers/conv.rs:78-83, gguf/model.rs:426-427): d_mel [n_mels][T] -> x [S][enc_dim] token-major; c1 = scratch of c1_floats(T) floats
+static size_t conv_scratch_floats(const vox_model* m, int T) {
+    const int D = m->cfg.enc_dim, T1 = conv_len(T);
+    return std::max((size_t)D * T1, (size_t)(T + 2) * m->cfg.n_mels + (size_t)(T1 + 2) * D) + 64;   // VALU conv: [D][T1]; MFMA conv: padded token-major mel + conv1 output
+}
+static int32_t conv_stem_dev(vox_model* m, const float* d_mel, int T, float* c1, float* x) {
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream; const int D = c.enc_dim, T1 = conv_len(T), S = conv_len(T1);
+    const bool conv_mfma = m->conv1_g.qs && m->conv2_g.qs && !getenv("VOX_CONV_VALU");
+    if (conv_mfma) {
+        // gelu(conv1d k3 s2 p1) as an im2col GEMM: with the input token-major and one zero row either side, output row t reads the
+        // CONTIGUOUS window rows [2t, 2t+2] of the padded buffer (= frames 2t-1..2t+1): A = that buffer with row stride 2*Cin, K = 3*Cin
+        const int Cm = c.n_mels;
+        float* melT = c1; float* c1T = melT + (size_t)(T + 2) * Cm;                       // [(T+2)][Cm], [(T1+2)][D]
+        HIPCHK(hipMemsetAsync(melT, 0, (size_t)Cm * 4, s)); HIPCHK(hipMemsetAsync(melT + (size_t)(T + 1) * Cm, 0, (size_t)Cm * 4, s));
+        HIPCHK(hipMemsetAsync(c1T, 0, (size_t)D * 4, s)); HIPCHK(hipMemsetAsync(c1T + (size_t)(T1 + 1) * D, 0, (size_t)D * 4, s));
+        HIPCHK(launch_transpose(d_mel, Cm, T, melT + Cm, s));                          // [Cm][T] -> [T][Cm]
+        { GemmParams g{}; g.w = m->conv1_g; g.x = melT; g.x_stride = 2 * Cm; g.M = T1; g.out = c1T + D; g.out_stride = D; g.bias = m->conv1_b; HIPCHK(launch_dense2_gemm(g, EPI_GELU, s)); }
+        { GemmParams g{}; g.w = m->conv2_g; g.x = c1T; g.x_stride = 2 * D; g.M = S; g.out = x; g.out_stride = D; g.bias = m->conv2_b; HIPCHK(launch_dense2_gemm(g, EPI_GELU, s)); }
+    } else {
+        HIPCHK(launch_conv1d_gelu(d_mel, c.n_mels, T, m->conv1_w, m->conv1_b, D, c1, 0, s));
+        HIPCHK(launch_conv1d_gelu(c1, D, T1, m->conv2_w, m->conv2_b, D, x, 1, s));      // token-major [S][D] (swap_dims, model.rs:427)
+    }
+    return VOX_OK;
+}
 static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels, const int* T, float* audio_out, int audio_rows, int* S4_out) {
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     const int D = c.enc_dim, H = c.enc_heads, hd = c.enc_head_dim, QD = H * hd, F = c.enc_ffn, R = c.reshape_factor;
@@ -1028,7 +1054,8 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     const int Mtot = n * S_pad, M4 = n == 1 ? S4_out[0] : Mtot / R;          // adapter rows
     ARGCHK(n == 1 || audio_rows >= S_pad / R, "internal: audio row budget %d < %d", audio_rows, S_pad / R);
     int Tmax = 0; for (int i = 0; i < n; i++) Tmax = std::max(Tmax, T[i]);
-    const size_t c1_floats = std::max((size_t)D * T1max, (size_t)(Tmax + 2) * c.n_mels + (size_t)(T1max + 2) * D) + 64;   // VALU conv: [D][T1]; MFMA conv: padded token-major mel + conv1 output
+    (void)T1max;
+    const size_t c1_floats = conv_scratch_floats(m, Tmax);
     const size_t need = c1_floats + (size_t)Mtot * D * 2 + (size_t)Mtot * QD * 4 + (size_t)Mtot * F + (size_t)(M4 + 1) * m->ad0.w.N + 1024;
     VOXCHK(ensure(&m->ws, &m->ws_floats, need));
     float* c1 = m->ws; float* x = c1 + c1_floats / 64 * 64; float* xn = x + (size_t)Mtot * D; float* qkv = xn + (size_t)Mtot * D;
@@ -1042,24 +1069,9 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
         HIPCHK(hipMemcpyAsync(m->d_seq_len, m->h_seq_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         d_len = m->d_seq_len;
     }
-    const bool conv_mfma = m->conv1_g.qs && m->conv2_g.qs && !getenv("VOX_CONV_VALU");
     for (int i = 0; i < n; i++) {
         if (S[i] <= 0) continue;
-        const int T1 = conv_len(T[i]);
-        if (conv_mfma) {
-            // gelu(conv1d k3 s2 p1) as an im2col GEMM: with the input token-major and one zero row either side, output row t reads the
-            // CONTIGUOUS window rows [2t, 2t+2] of the padded buffer (= frames 2t-1..2t+1): A = that buffer with row stride 2*Cin, K = 3*Cin
-            const int Cm = c.n_mels;
-            float* melT = c1; float* c1T = melT + (size_t)(T[i] + 2) * Cm;                       // [(T+2)][Cm], [(T1+2)][D]
-            HIPCHK(hipMemsetAsync(melT, 0, (size_t)Cm * 4, s)); HIPCHK(hipMemsetAsync(melT + (size_t)(T[i] + 1) * Cm, 0, (size_t)Cm * 4, s));
-            HIPCHK(hipMemsetAsync(c1T, 0, (size_t)D * 4, s)); HIPCHK(hipMemsetAsync(c1T + (size_t)(T1 + 1) * D, 0, (size_t)D * 4, s));
-            HIPCHK(launch_transpose(d_mels[i], Cm, T[i], melT + Cm, s));                          // [Cm][T] -> [T][Cm]
-            { GemmParams g{}; g.w = m->conv1_g; g.x = melT; g.x_stride = 2 * Cm; g.M = T1; g.out = c1T + D; g.out_stride = D; g.bias = m->conv1_b; HIPCHK(launch_dense2_gemm(g, EPI_GELU, s)); }
-            { GemmParams g{}; g.w = m->conv2_g; g.x = c1T; g.x_stride = 2 * D; g.M = S[i]; g.out = x + (size_t)i * S_pad * D; g.out_stride = D; g.bias = m->conv2_b; HIPCHK(launch_dense2_gemm(g, EPI_GELU, s)); }
-        } else {
-            HIPCHK(launch_conv1d_gelu(d_mels[i], c.n_mels, T[i], m->conv1_w, m->conv1_b, D, c1, 0, s));
-            HIPCHK(launch_conv1d_gelu(c1, D, T1, m->conv2_w, m->conv2_b, D, x + (size_t)i * S_pad * D, 1, s));      // token-major [S][D] (swap_dims, model.rs:427)
-        }
+        VOXCHK(conv_stem_dev(m, d_mels[i], T[i], c1, x + (size_t)i * S_pad * D));
     }
     const int seq_rows = n > 1 ? S_pad : 0;
     for (int l = 0; l < c.enc_layers; l++) {
@@ -1108,9 +1120,115 @@ extern "C" int32_t vox_cache_free(vox_cache* k) {
     (void)hipFree(k->k); (void)hipFree(k->v); delete k; return VOX_OK;
 }
 extern "C" int32_t vox_cache_seq_len(const vox_cache* k, int32_t* out) { ARGCHK(k && out, "null argument"); *out = k->len; return VOX_OK; }
-extern "C" int32_t vox_cache_reset(vox_cache* k) { ARGCHK(k, "null cache"); k->len = 0; return VOX_OK; }
+extern "C" int32_t vox_cache_reset(vox_cache* k) { ARGCHK(k, "null cache"); k->len = 0; k->abs_pos = 0; return VOX_OK; }
 
 static size_t cache_layer_floats(const vox_model* m, const vox_cache* k) { (void)m; return k->layer_stride; }
+
+// ---- streaming encoder: Q4AudioEncoder::create_cache / forward_with_cache (gguf/model.rs:437-459), Q4EncoderLayer::forward_with_cache
+// (:299-317), Q4Attention::forward_with_cache (:125-174), Q4VoxtralModel::encode_audio_with_cache (:791-799), eviction KVCache::apply_sliding_window
+// (kv_cache.rs:176-203).  One cache = K / V rows [enc_layers][enc_heads][capacity][64] f32.  A chunk's K / V are appended at row `len`; when the chunk
+// does not fit, the cache is compacted to its last `enc_window` rows first (keys older than the window can never be attended again: exact).  RoPE uses
+// the ABSOLUTE stream position (abs_pos), so chunked == whole-utterance for the transformer stack at any stream length.
+extern "C" int32_t vox_encoder_cache_create(vox_model* m, int32_t capacity_rows, vox_cache** out) {
+    ARGCHK(m && out, "null argument"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg;
+    if (capacity_rows <= 0) capacity_rows = 2 * c.enc_window + 512;
+    ARGCHK(capacity_rows > c.enc_window, "encoder cache capacity %d must exceed the sliding window (%d)", capacity_rows, c.enc_window);
+    vox_cache* k = new vox_cache(); k->m = m; k->ctx = m->ctx; k->max_seq = capacity_rows; k->kind = 1;
+    const size_t n = (size_t)c.enc_layers * c.enc_heads * capacity_rows * c.enc_head_dim * 4;
+    if (hipMalloc((void**)&k->k, n) != hipSuccess || hipMalloc((void**)&k->v, n) != hipSuccess) { if (k->k) (void)hipFree(k->k); delete k; return fail(VOX_ERR_HIP, "hipMalloc of encoder KV cache failed"); }
+    HIPCHK(hipMemsetAsync(k->k, 0, n, m->ctx->stream)); HIPCHK(hipMemsetAsync(k->v, 0, n, m->ctx->stream));
+    k->layer_stride = (size_t)c.enc_heads * capacity_rows * c.enc_head_dim;
+    *out = k; return VOX_OK;
+}
+extern "C" int32_t vox_cache_abs_pos(const vox_cache* k, int32_t* out) { ARGCHK(k && out, "null argument"); *out = k->kind == 1 ? k->abs_pos : k->len; return VOX_OK; }
+
+// keep the last `keep` rows of every (layer, head) plane: rows [len - keep, len) -> [0, keep).  Two strided 2-D copies through the workspace
+// (source and destination ranges may overlap).  One pitch covers all planes: layer_stride == heads * capacity * hd.
+static int32_t enc_cache_evict(vox_model* m, vox_cache* kc, int keep) {
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    if (keep >= kc->len) return VOX_OK;
+    const size_t planes = (size_t)c.enc_layers * c.enc_heads, pitch = (size_t)kc->max_seq * c.enc_head_dim * 4, width = (size_t)keep * c.enc_head_dim * 4;
+    VOXCHK(ensure(&m->ws, &m->ws_floats, planes * width / 4 + 64));
+    for (float* base : {kc->k, kc->v}) {
+        const char* src = reinterpret_cast<const char*>(base) + (size_t)(kc->len - keep) * c.enc_head_dim * 4;
+        HIPCHK(hipMemcpy2DAsync(m->ws, width, src, pitch, width, planes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpy2DAsync(base, pitch, m->ws, width, width, planes, hipMemcpyDeviceToDevice, s));
+    }
+    kc->len = keep;
+    return VOX_OK;
+}
+extern "C" int32_t vox_encoder_cache_apply_sliding_window(vox_cache* kc, int32_t window) {      // kv_cache.rs:176-203, all layers
+    ARGCHK(kc && kc->kind == 1 && window > 0, "bad argument"); VOXCHK(ctx_bind(kc->ctx));
+    VOXCHK(enc_cache_evict(kc->m, kc, window)); HIPCHK(hipStreamSynchronize(kc->ctx->stream)); return VOX_OK;
+}
+
+static int32_t encode_with_cache_dev(vox_model* m, const float* d_mel, int T, vox_cache* kc, int* S4_out) {
+    const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
+    const int D = c.enc_dim, H = c.enc_heads, hd = c.enc_head_dim, QD = H * hd, F = c.enc_ffn, R = c.reshape_factor;
+    const int S = enc_rows(T), S4 = S / R; *S4_out = S4;
+    if (S <= 0) return VOX_OK;
+    ARGCHK(S <= kc->max_seq - std::min(c.enc_window, kc->max_seq - 1), "chunk of %d encoder rows does not fit a cache of %d rows next to the %d-row window", S, kc->max_seq, c.enc_window);
+    if (kc->len + S > kc->max_seq) VOXCHK(enc_cache_evict(m, kc, std::min(kc->len, c.enc_window)));
+    // RoPE table for absolute stream positions (the load-time table covers 4096 rows, gguf/loader.rs:196-198)
+    const float *cos_t = m->enc_cos, *sin_t = m->enc_sin;
+    if (kc->abs_pos + S > m->enc_rope_len) {
+        if (!m->enc_cos_s) {
+            const int len = 1 << 16, half = hd / 2; std::vector<float> ct((size_t)len * half), st((size_t)len * half);
+            for (int i = 0; i < len; i++) for (int j = 0; j < half; j++) { const float inv = 1.0f / std::pow(c.rope_theta, (float)(2 * j) / (float)hd), fr = (float)i * inv; ct[(size_t)i * half + j] = std::cos(fr); st[(size_t)i * half + j] = std::sin(fr); }
+            HIPCHK(hipMalloc((void**)&m->enc_cos_s, ct.size() * 4)); HIPCHK(hipMalloc((void**)&m->enc_sin_s, st.size() * 4));
+            HIPCHK(hipMemcpy(m->enc_cos_s, ct.data(), ct.size() * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(m->enc_sin_s, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+            m->enc_rope_s_len = len;
+        }
+        ARGCHK(kc->abs_pos + S <= m->enc_rope_s_len, "stream of %d encoder positions exceeds the streaming RoPE table (%d)", kc->abs_pos + S, m->enc_rope_s_len);
+        cos_t = m->enc_cos_s; sin_t = m->enc_sin_s;
+    }
+    if (S4 > 0) { size_t cap = (size_t)m->audio_cap * c.dec_dim; VOXCHK(ensure(&m->d_audio, &cap, (size_t)S4 * c.dec_dim)); m->audio_cap = (int)(cap / c.dec_dim); }
+    const size_t c1f = conv_scratch_floats(m, T);
+    const size_t need = c1f + (size_t)S * D * 2 + (size_t)S * QD * 4 + (size_t)S * F + (size_t)(S4 + 1) * m->ad0.w.N + 1024;
+    VOXCHK(ensure(&m->ws, &m->ws_floats, need));
+    float* c1 = m->ws; float* x = c1 + c1f / 64 * 64; float* xn = x + (size_t)S * D; float* qkv = xn + (size_t)S * D;
+    float* att = qkv + (size_t)S * QD * 3; float* ffn = att + (size_t)S * QD; float* ah = ffn + (size_t)S * F;
+    VOXCHK(conv_stem_dev(m, d_mel, T, c1, x));
+    const int off = kc->len; const size_t lf = kc->layer_stride;
+    for (int l = 0; l < c.enc_layers; l++) {
+        const EncLayer& L = m->enc[l]; float* kl = kc->k + (size_t)l * lf; float* vl = kc->v + (size_t)l * lf;
+        HIPCHK(launch_rms_norm(x, D, S, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
+        VOXCHK(q4_linear_dev(cx, L.wqkv.w, L.wqkv.bias, xn, D, S, qkv, 3 * QD));
+        HIPCHK(launch_rope(qkv, S, 3 * QD, 2 * QD, hd, kc->abs_pos, cos_t, sin_t, s, 0));                     // q and k at the absolute positions
+        HIPCHK(launch_kv_store(qkv, S, 3 * QD, QD, H, hd, off, kl, vl, kc->max_seq * hd, s));                   // append at rows [len, len + S)
+        AttnParams ap{}; ap.q = qkv; ap.q_stride = 3 * QD; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd;
+        ap.out = att; ap.out_stride = QD; ap.M = S; ap.kv_len = off + S; ap.n_heads = H; ap.n_kv_heads = H; ap.offset = off; ap.window = c.enc_window;
+        HIPCHK(launch_attn_prefill(ap, hd, s, 1));
+        VOXCHK(q4_linear_dev(cx, L.wo.w, L.wo.bias, att, QD, S, x, D, EPI_RESID, x, D));
+        HIPCHK(launch_rms_norm(x, D, S, D, L.ffn_norm, nullptr, c.norm_eps, xn, D, s));
+        VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, S, ffn, F, EPI_SWIGLU));
+        VOXCHK(q4_linear_dev(cx, L.w2.w, L.w2.bias, ffn, F, S, x, D, EPI_RESID, x, D));
+    }
+    kc->len = off + S; kc->abs_pos += S;
+    if (S4 > 0) {
+        HIPCHK(launch_rms_norm(x, D, S4 * R, D, m->enc_norm, nullptr, c.norm_eps, xn, D, s));
+        VOXCHK(q4_linear_dev(cx, m->ad0.w, nullptr, xn, D * R, S4, ah, m->ad0.w.N, EPI_GELU));
+        VOXCHK(q4_linear_dev(cx, m->ad2.w, nullptr, ah, m->ad0.w.N, S4, m->d_audio, c.dec_dim));
+    }
+    return VOX_OK;
+}
+extern "C" int32_t vox_encode_audio_with_cache(vox_model* m, const float* mel, int32_t T, vox_cache* enc_cache, float* out, int32_t cap_rows, int32_t* S,
+                                               int32_t mem_kind) {
+    ARGCHK(m && mel && enc_cache && out && S, "null argument"); ARGCHK(T > 0, "empty mel");
+    ARGCHK(enc_cache->kind == 1 && enc_cache->m == m, "not an encoder cache of this model (vox_encoder_cache_create)"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    const float* d_mel = mel;
+    if (mem_kind == VOX_MEM_HOST) {
+        VOXCHK(ensure(&m->d_mel, &m->mel_cap, (size_t)c.n_mels * T));
+        HIPCHK(hipMemcpyAsync(m->d_mel, mel, (size_t)c.n_mels * T * 4, hipMemcpyHostToDevice, s)); d_mel = m->d_mel;
+    }
+    int S4 = 0; VOXCHK(encode_with_cache_dev(m, d_mel, T, enc_cache, &S4));
+    ARGCHK(cap_rows >= S4, "output capacity %d rows < %d", cap_rows, S4);
+    if (S4 > 0) HIPCHK(hipMemcpyAsync(out, m->d_audio, (size_t)S4 * c.dec_dim * 4, mem_kind == VOX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *S = S4; return VOX_OK;
+}
 
 // ---- multi-row decoder forward (prefill): x [M][D] device, in place; positions off..off+M-1  (gguf/model.rs:370-387).
 // n_seq > 1: x holds n_seq stacked sequences of seq_rows = M / n_seq rows, each with its own cache slice kv_seq_stride floats apart
@@ -1563,7 +1681,7 @@ extern "C" int32_t vox_embed_tokens_from_ids(vox_model* m, const int32_t* ids, i
 }
 
 extern "C" int32_t vox_forward_hidden_with_cache(vox_model* m, const float* x, int32_t M, const float* t_embed, vox_cache* kc, float* out) {
-    ARGCHK(m && x && t_embed && kc && out && M > 0, "bad argument"); ARGCHK(kc->m == m, "cache belongs to another model"); VOXCHK(ctx_bind(m->ctx));
+    ARGCHK(m && x && t_embed && kc && out && M > 0, "bad argument"); ARGCHK(kc->m == m && kc->kind == 0, "cache belongs to another model or is an encoder cache"); VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
     ARGCHK(kc->len + M <= kc->max_seq, "KV cache overflow: %d + %d > %d", kc->len, M, kc->max_seq);
     VOXCHK(vox_model_set_t_embed(m, t_embed));

@@ -263,6 +263,22 @@ class LayerCaches:
             pass
 
 
+class EncoderCaches(LayerCaches):
+    """Q4AudioEncoder::create_cache (gguf/model.rs:454-459): K / V of the streaming encoder; evicts rows older than the sliding window by itself."""
+
+    def __init__(self, model, capacity_rows=0):
+        self.model = model; self.h = C.c_void_p()
+        check(lib().vox_encoder_cache_create(model.h, capacity_rows, C.byref(self.h)))
+        model._caches.add(self)
+
+    def abs_pos(self):
+        v = C.c_int32(); check(lib().vox_cache_abs_pos(self.h, C.byref(v))); return v.value
+
+    def apply_sliding_window(self, window):
+        """kv_cache.rs:176-203 (every layer)"""
+        check(lib().vox_encoder_cache_apply_sliding_window(self.h, window))
+
+
 class Q4LanguageModel:
     """The decoder surface used by e2e-bench (gguf/model.rs:566-723)."""
 
@@ -324,6 +340,17 @@ class Q4VoxtralModel:
         cap = T // 16 + 2
         out = np.empty((cap, self.config.dec_dim), dtype=np.float32); S = C.c_int32()
         check(lib().vox_encode_audio(self.h, _ptr(mel), T, _ptr(out), cap, C.byref(S), 0))
+        return out[:S.value].reshape(1, S.value, self.config.dec_dim).copy()
+
+    def create_encoder_cache(self, capacity_rows=0):
+        return EncoderCaches(self, capacity_rows)
+
+    def encode_audio_with_cache(self, mel, encoder_cache):
+        """mel chunk [1,128,T] or [128,T] -> [1, floor(S_chunk/4), dec_dim] (gguf/model.rs:791-799); K / V appended to `encoder_cache`"""
+        mel = _f32(mel); mel = mel.reshape(mel.shape[-2], mel.shape[-1]); T = mel.shape[1]
+        cap = T // 16 + 2
+        out = np.empty((cap, self.config.dec_dim), dtype=np.float32); S = C.c_int32()
+        check(lib().vox_encode_audio_with_cache(self.h, _ptr(mel), T, encoder_cache.h, _ptr(out), cap, C.byref(S), 0))
         return out[:S.value].reshape(1, S.value, self.config.dec_dim).copy()
 
     def transcribe_streaming(self, mel, t_embed, return_logits=False):
