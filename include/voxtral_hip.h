@@ -68,6 +68,14 @@ int32_t vox_dev_download(vox_ctx* ctx, void* dst_host, const void* src_dev, size
 int32_t vox_dev_copy(vox_ctx* ctx, void* dst_dev, const void* src_dev, size_t nbytes);   /* device -> device, synchronous */
 
 /* ---- audio front-end (src/audio) ------------------------------------------------------- */
+/* resample / resample_to_16k, audio/resample.rs:10-52.  The reference delegates to rubato 1.0 (`Fft`, chunk 1024, 2 sub-chunks), a crate that
+ * is not in its tree and whose output cannot be pinned; this is band-limited polyphase interpolation on the GPU (Kaiser-windowed sinc, 32 zero
+ * crossings, cutoff 0.95 x the lower Nyquist, unit DC gain) with the reference's contract: same rate -> copy; n_out = ceil(n * out / in)
+ * (inside the +-100 samples its tests allow, resample.rs:66-83).  in / out host or device buffers (mem_kind). */
+int32_t vox_resample_len(size_t n_in, uint32_t sr_in, uint32_t sr_out, size_t* n_out);
+int32_t vox_resample(vox_ctx* ctx, const float* in, size_t n_in, uint32_t sr_in, uint32_t sr_out, float* out, size_t cap, size_t* n_out,
+                     int32_t mem_kind);
+int32_t vox_resample_filter(uint32_t sr_in, uint32_t sr_out, int32_t* P, int32_t* Q, int32_t* W, float* h_or_null, size_t cap);   /* table [Q][2W+1] */
 /* AudioBuffer::peak_normalize, audio/io.rs:59-68 (host, in place) */
 int32_t vox_peak_normalize(float* samples, size_t n, float target_peak);
 

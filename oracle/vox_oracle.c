@@ -703,6 +703,41 @@ int orc_encode_audio(const orc_model* m, const float* mel, int T, float* out) {
     free(x); return S4;
 }
 
+/* ---- sample-rate conversion (audio/resample.rs:16-52).  The reference calls rubato 1.0 (`Fft` synchronous resampler), a third-party crate absent from
+ * /root/reference whose output is not pinned by any reference test beyond the length (resample.rs:66-83: within 100 samples of n * out / in).
+ * PARITY UNPINNED versus rubato.  What is restated here is the SPECIFICATION of the replacement (band-limited interpolation, Kaiser-windowed
+ * sinc, 32 zero crossings, beta 12, cutoff 0.95 x the lower Nyquist, unit DC gain per phase; n_out = ceil(n * out / in); same rate = copy),
+ * in double precision, so the GPU kernel has an independent checker. */
+static double orc_i0(double x) { double s = 1.0, t = 1.0; for (int k = 1; k < 60; k++) { t *= (x / (2.0 * k)) * (x / (2.0 * k)); s += t; if (t < 1e-18 * s) break; } return s; }
+size_t orc_resample_len(size_t n_in, uint32_t sr_in, uint32_t sr_out) { return sr_in == sr_out ? n_in : (size_t)(((unsigned long long)n_in * sr_out + sr_in - 1) / sr_in); }
+void orc_resample(const float* in, size_t n_in, uint32_t sr_in, uint32_t sr_out, float* out) {
+    if (sr_in == sr_out) { memcpy(out, in, n_in * sizeof(float)); return; }
+    long a = sr_in, b = sr_out; while (b) { long t = a % b; a = b; b = t; }
+    const long P = sr_in / a, Q = sr_out / a;
+    const double scale = (double)Q / (double)P < 1.0 ? (double)Q / (double)P : 1.0, cutoff = 0.95 * scale, beta = 12.0;
+    const long W = (long)ceil(32.0 / scale), taps = 2 * W + 1;
+    const size_t n_out = orc_resample_len(n_in, sr_in, sr_out);
+    const double i0b = orc_i0(beta);
+    #pragma omp parallel
+    {
+        double* row = (double*)malloc(sizeof(double) * (size_t)taps);
+        #pragma omp for schedule(static)
+        for (long m = 0; m < (long)n_out; m++) {
+            const long num = m * P, n0 = num / Q, ph = num % Q; const double frac = (double)ph / (double)Q; double sum = 0.0;
+            for (long k = 0; k < taps; k++) {
+                const double tau = (double)(k - W) - frac, u = tau / (double)(W + 1);
+                const double w = fabs(u) < 1.0 ? orc_i0(beta * sqrt(1.0 - u * u)) / i0b : 0.0;
+                const double x = M_PI * cutoff * tau, sinc = fabs(x) < 1e-12 ? 1.0 : sin(x) / x;
+                row[k] = cutoff * sinc * w; sum += row[k];
+            }
+            double acc = 0.0;
+            for (long k = 0; k < taps; k++) { const long i = n0 - W + k; if (i >= 0 && i < (long)n_in) acc += (double)in[i] * (row[k] / sum); }
+            out[m] = (float)acc;
+        }
+        free(row);
+    }
+}
+
 /* ---- streaming encoder: Q4AudioEncoder::forward_with_cache (gguf/model.rs:437-452), Q4EncoderLayer::forward_with_cache (:299-317),
  * Q4Attention::forward_with_cache (:125-174: offset = cache length, k/v appended, causal + sliding-window masks with offset),
  * Q4VoxtralModel::encode_audio_with_cache (:791-799).  The cache is the reference's DYNAMIC (cat-based) mode, the only one

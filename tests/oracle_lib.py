@@ -107,6 +107,8 @@ def lib():
         "orc_encoder_layer": (None, [vp, C.c_int, f32p, C.c_int]),
         "orc_encoder_final_norm": (None, [vp, f32p, C.c_int]),
         "orc_encode_audio": (C.c_int, [vp, f32p, C.c_int, f32p]),
+        "orc_resample_len": (C.c_size_t, [C.c_size_t, C.c_uint32, C.c_uint32]),
+        "orc_resample": (None, [f32p, C.c_size_t, C.c_uint32, C.c_uint32, f32p]),
         "orc_enc_cache_create": (vp, [vp, C.c_int]),
         "orc_enc_cache_free": (None, [vp]),
         "orc_enc_cache_len": (C.c_int, [vp]),
@@ -167,6 +169,13 @@ def mel_compute(x):
     T = L.orc_mel_num_frames(x.size)
     out = np.zeros((T, 128), dtype=np.float32)
     L.orc_mel_compute(x, x.size, out)
+    return out
+
+
+def resample(x, sr_in, sr_out=16000):
+    L = lib(); x = f32(x)
+    out = np.zeros(L.orc_resample_len(x.size, sr_in, sr_out), dtype=np.float32)
+    L.orc_resample(x, x.size, sr_in, sr_out, out)
     return out
 
 

@@ -112,6 +112,29 @@ def chunk_audio(samples, config: ChunkConfig):
                        arr[i].index, bool(arr[i].is_last)) for i in range(n.value)]
 
 
+def resample(ctx, samples, sample_rate, target_rate=16000):
+    """audio/resample.rs:16-52 `resample` (GPU polyphase band-limited interpolation; same rate -> copy)"""
+    x = _f32(samples); n = C.c_size_t()
+    check(lib().vox_resample_len(x.size, int(sample_rate), int(target_rate), C.byref(n)))
+    out = np.empty(x.size if sample_rate == target_rate else n.value, dtype=np.float32)
+    check(lib().vox_resample(ctx.h, _ptr(x), x.size, int(sample_rate), int(target_rate), _ptr(out), out.size, C.byref(n), 0))
+    return out[:n.value]
+
+
+def resample_to_16k(ctx, samples, sample_rate):
+    """audio/resample.rs:10-13"""
+    return resample(ctx, samples, sample_rate, 16000)
+
+
+def resample_filter(sample_rate, target_rate=16000):
+    """(P, Q, W, h[Q][2W+1]) of the polyphase design (host)"""
+    P_, Q_, W_ = C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().vox_resample_filter(int(sample_rate), int(target_rate), C.byref(P_), C.byref(Q_), C.byref(W_), None, 0))
+    h = np.empty((Q_.value, 2 * W_.value + 1), dtype=np.float32)
+    check(lib().vox_resample_filter(int(sample_rate), int(target_rate), C.byref(P_), C.byref(Q_), C.byref(W_), _ptr(h), h.size))
+    return P_.value, Q_.value, W_.value, h
+
+
 def peak_normalize(samples, target_peak=0.95):
     """AudioBuffer::peak_normalize, audio/io.rs:59-68 (returns a new array)"""
     x = _f32(samples).copy()

@@ -19,29 +19,32 @@ def log(*a):
 
 
 def load_wav(path):
-    """audio/io.rs:90-131: PCM int (8/16/24/32 bit) or float32, mixed to mono by averaging channels."""
+    """audio/io.rs:90-131: PCM int (8/16/24/32 bit, hound's i32 samples) mixed to mono as (sum of the channels as f32 / channels) / 2^(bits-1);
+    IEEE float: mean of the channels."""
     with wave.open(path, "rb") as w:
         ch, sw, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
         raw = w.readframes(n)
     if sw == 2:
-        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / np.float32(1 << 15)
+        v = np.frombuffer(raw, dtype="<i2").astype(np.int64)
     elif sw == 4:
-        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / np.float32(1 << 31)
+        v = np.frombuffer(raw, dtype="<i4").astype(np.int64)
     elif sw == 3:
-        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int64)
         v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16); v = np.where(v & 0x800000, v - (1 << 24), v)
-        x = v.astype(np.float32) / np.float32(1 << 23)
     elif sw == 1:
-        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        v = np.frombuffer(raw, dtype=np.uint8).astype(np.int64) - 128            # hound: 8-bit WAV is unsigned, read as signed
     else:
         raise ValueError(f"unsupported WAV sample width {sw}")
-    if ch > 1:
-        x = x.reshape(-1, ch).mean(axis=1).astype(np.float32)
-    return x, sr
+    s = v.reshape(-1, ch).sum(axis=1) if ch > 1 else v                            # i32 sum of the frame's channels (io.rs:110-113)
+    x = (s.astype(np.float32) / np.float32(ch)) / np.float32(1 << (8 * sw - 1))
+    return x.astype(np.float32), sr
 
 
-def resample_to_16k(x, sr):
-    """audio/resample.rs:16-52 uses rubato's FFT resampler; here a polyphase FIR (caller-side, off the accelerated path)."""
+def resample_to_16k(x, sr, ctx=None, pkg=None):
+    """audio/resample.rs:10-52.  On the GPU when a context is given (vox_resample: polyphase band-limited interpolation); the scipy polyphase
+    filter remains as the host-only fallback of this CLI helper (tests without a GPU)."""
+    if ctx is not None and pkg is not None:
+        return pkg.resample_to_16k(ctx, x, sr)
     from math import gcd
     from scipy.signal import resample_poly
     g = gcd(16000, int(sr))
@@ -52,7 +55,7 @@ def transcribe_one(pkg, path, model, tokenizer, mel, pad_cfg, chunk_cfg, t_embed
     """bin/transcribe.rs:187-276"""
     x, sr = load_wav(path)
     if sr != 16000:
-        log(f"  resampling {sr} Hz -> 16 kHz"); x = resample_to_16k(x, sr)
+        log(f"  resampling {sr} Hz -> 16 kHz"); x = resample_to_16k(x, sr, mel.ctx, pkg)
     x = pkg.peak_normalize(x, 0.95)                                              # :207
     chunks = pkg.chunk_audio(x, chunk_cfg) if pkg.needs_chunking(x.size, chunk_cfg) else [None]
     texts = []
@@ -122,7 +125,7 @@ def main(argv=None):
             try:
                 x, sr = load_wav(p)
                 if sr != 16000:
-                    x = resample_to_16k(x, sr)
+                    x = resample_to_16k(x, sr, ctx, pkg)
                 # NOT peak-normalised here: vox_transcribe_batch normalises on the device (absmax reduction + scale inside the mel
                 # kernel) exactly once, like the one-by-one path does on the host (transcribe.rs:207)
                 if not pkg.needs_chunking(x.size, chunk_cfg) and x.size > 0:

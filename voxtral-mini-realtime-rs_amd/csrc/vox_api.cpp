@@ -291,6 +291,62 @@ extern "C" int32_t vox_mel_compute_log(vox_ctx* c, const float* samples, size_t 
     return VOX_OK;
 }
 
+// ---- sample-rate conversion (audio/resample.rs:16-52).  Filter design (host, double precision): Kaiser-windowed sinc, Z = 32 zero crossings of
+// the narrower band each side, beta = 12 (stop band < -110 dB), cutoff = 0.95 x the lower Nyquist; every phase normalised to unit DC gain.
+static double bessel_i0(double x) { double s = 1.0, t = 1.0; for (int k = 1; k < 60; k++) { t *= (x / (2.0 * k)) * (x / (2.0 * k)); s += t; if (t < 1e-18 * s) break; } return s; }
+static long gcd_l(long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; }
+extern "C" int32_t vox_resample_len(size_t n_in, uint32_t sr_in, uint32_t sr_out, size_t* n_out) {
+    ARGCHK(n_out && sr_in > 0 && sr_out > 0, "bad argument");
+    *n_out = (size_t)(((unsigned long long)n_in * sr_out + sr_in - 1) / sr_in); return VOX_OK;      // ceil(n * out / in)
+}
+static void resample_design(uint32_t sr_in, uint32_t sr_out, int* P, int* Q, int* W, std::vector<float>* h) {
+    const long g = gcd_l(sr_in, sr_out); *P = (int)(sr_in / g); *Q = (int)(sr_out / g);
+    const double scale = std::min(1.0, (double)*Q / (double)*P), cutoff = 0.95 * scale, beta = 12.0; const int Z = 32;
+    *W = (int)std::ceil(Z / scale); const int taps = 2 * *W + 1;
+    h->assign((size_t)*Q * taps, 0.f);
+    const double i0b = bessel_i0(beta);
+    for (int ph = 0; ph < *Q; ph++) {
+        const double frac = (double)ph / (double)*Q; std::vector<double> row(taps); double sum = 0.0;
+        for (int k = 0; k < taps; k++) {
+            const double tau = (double)(k - *W) - frac;                      // input-sample offset of tap k from the output instant
+            const double u = tau / (double)(*W + 1);
+            double w = 0.0; if (std::fabs(u) < 1.0) w = bessel_i0(beta * std::sqrt(1.0 - u * u)) / i0b;
+            const double a = M_PI * cutoff * tau; const double sinc = std::fabs(a) < 1e-12 ? 1.0 : std::sin(a) / a;
+            row[k] = cutoff * sinc * w; sum += row[k];
+        }
+        for (int k = 0; k < taps; k++) (*h)[(size_t)ph * taps + k] = (float)(row[k] / sum);
+    }
+}
+extern "C" int32_t vox_resample(vox_ctx* c, const float* in, size_t n_in, uint32_t sr_in, uint32_t sr_out, float* out, size_t cap, size_t* n_out, int32_t mem_kind) {
+    ARGCHK(c && out && n_out && (in || n_in == 0), "null argument"); ARGCHK(sr_in > 0 && sr_out > 0, "bad sample rate"); VOXCHK(ctx_bind(c));
+    size_t no; VOXCHK(vox_resample_len(n_in, sr_in, sr_out, &no)); if (sr_in == sr_out) no = n_in;
+    ARGCHK(cap >= no, "output capacity %zu < %zu samples", cap, no);
+    *n_out = no; if (no == 0) return VOX_OK;
+    hipStream_t s = c->stream;
+    if (sr_in == sr_out) {                                                     // resample.rs:17-19: same rate -> clone
+        HIPCHK(hipMemcpyAsync(out, in, n_in * 4, mem_kind == VOX_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToHost, s)); HIPCHK(hipStreamSynchronize(s)); return VOX_OK;
+    }
+    int P, Q, W; std::vector<float> h; resample_design(sr_in, sr_out, &P, &Q, &W, &h);
+    DevBuf dh, din, dout; HIPCHK(dh.alloc(h.size() * 4)); HIPCHK(hipMemcpyAsync(dh.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, s));
+    const float* d_in = in; float* d_out = out;
+    if (mem_kind != VOX_MEM_DEVICE) {
+        HIPCHK(din.alloc(n_in * 4)); HIPCHK(dout.alloc(no * 4));
+        HIPCHK(hipMemcpyAsync(din.p, in, n_in * 4, hipMemcpyHostToDevice, s)); d_in = din.as<float>(); d_out = dout.as<float>();
+    }
+    HIPCHK(launch_resample(d_in, (long)n_in, dh.as<float>(), P, Q, W, d_out, (long)no, s));
+    if (mem_kind != VOX_MEM_DEVICE) HIPCHK(hipMemcpyAsync(out, d_out, no * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return VOX_OK;
+}
+// the filter table itself (host; [Q][2 W + 1]) -- lets the parity tests check the design independently of the kernel
+extern "C" int32_t vox_resample_filter(uint32_t sr_in, uint32_t sr_out, int32_t* P, int32_t* Q, int32_t* W, float* h, size_t cap) {
+    ARGCHK(P && Q && W && sr_in > 0 && sr_out > 0, "bad argument");
+    int p_, q_, w_; std::vector<float> t; resample_design(sr_in, sr_out, &p_, &q_, &w_, &t);
+    *P = p_; *Q = q_; *W = w_;
+    if (h) { ARGCHK(cap >= t.size(), "filter buffer too small (%zu < %zu floats)", cap, t.size()); std::memcpy(h, t.data(), t.size() * 4); }
+    return VOX_OK;
+}
+
 extern "C" int32_t vox_time_embedding(float t, int32_t dim, float* out) {   // models/time_embedding.rs:41-71
     ARGCHK(out && dim > 0 && dim % 2 == 0, "bad argument");
     const int half = dim / 2; const float log_theta = std::log(10000.0f);

@@ -2912,6 +2912,33 @@ hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int*
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sample-rate conversion (audio/resample.rs:16-52 `resample`; the reference calls rubato's synchronous FFT resampler, a third-party crate
+// that cannot be restated bit for bit -- see DESIGN.md).  Band-limited interpolation as a polyphase FIR: output sample m sits at input time
+// m * P / Q (P/Q = sr_in/sr_out in lowest terms); its phase (m * P) mod Q selects one row of a host-built Kaiser-windowed-sinc table
+// h[Q][taps]; out[m] = sum_k x[n0 - W + k] * h[phase][k], zeros beyond the ends.  HBM-trivial (a 30 s clip is 5.8 MB): one thread per output.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, long n_in, const float* __restrict__ h, int P, int Q, int W,
+                                                       float* __restrict__ out, long n_out) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_out) return;
+    const long num = m * (long)P; const long n0 = num / Q; const int phase = (int)(num % Q);
+    const int taps = 2 * W + 1;
+    const float* hp = h + (size_t)phase * taps;
+    float acc = 0.f;
+    for (int k = 0; k < taps; k++) {
+        const long i = n0 - W + k;
+        const float v = (i >= 0 && i < n_in) ? x[i] : 0.f;
+        acc = fmaf(v, hp[k], acc);
+    }
+    out[m] = acc;
+}
+hipError_t launch_resample(const float* x, long n_in, const float* h, int P, int Q, int W, float* out, long n_out, hipStream_t s) {
+    if (n_out <= 0) return hipSuccess;
+    resample_kernel<<<dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s>>>(x, n_in, h, P, Q, W, out, n_out);
+    return hipGetLastError();
+}
+
 __global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }
