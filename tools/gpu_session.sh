@@ -22,5 +22,10 @@ step_prof()      { cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --outpu
 step_profbatch() { cd /tmp; VOX_BATCH_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_profb -o p -- python $REPO/tools/batch_prof.py 16 > $OUT/${TAG}_profb.log 2>&1; echo "profbatch rc=$?"; cd $REPO
                    f=$(find $OUT/${TAG}_profb -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_batch16_kernel_stats.csv && head -16 $f | cut -c1-160; }
 step_prefill()   { timeout 300 python tools/prefill_bench.py 2>&1 | tee $OUT/${TAG}_prefill.txt | tail -6; }
+step_pmc()       { # per-kernel PMC averages of the batched decode step (separate --pmc passes, kernel trace only: no other trace domains)
+                   cd /tmp; i=0
+                   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"; do
+                     i=$((i+1)); VOX_BATCH_NO_GRAPH=1 timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/${TAG}_pmc$i -o p -- python $REPO/${VOX_PMC_CMD:-tools/batch_prof.py 16} > $OUT/${TAG}_pmc$i.log 2>&1; echo "pmc pass $i rc=$?"
+                   done; cd $REPO; python tools/pmc_summary.py $OUT/${TAG}_pmc* > $OUT/${TAG}_pmc_summary.txt 2>&1; cat $OUT/${TAG}_pmc_summary.txt | head -60; }
 step_batch()     { timeout 300 python tools/batch_prof.py ${VOX_BENCH_BATCH:-16} 2>&1 | tail -4; }
 for s in "$@"; do echo "=== $s"; t0=$(date +%s); step_$s; echo "--- $s took $(( $(date +%s) - t0 )) s"; done
