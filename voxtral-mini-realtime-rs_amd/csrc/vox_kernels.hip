@@ -1145,6 +1145,22 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             pv[u] = pi < p.n_part ? v : 0.f;
         }
     }
+    // Epilogue operands of the tile this wave will finish (t = wave): requested NOW, so the residual / norm-weight / position reads are not a
+    // dependent round trip behind the split-K barrier (PMC: the batched-decode kernels sit parked in s_waitcnt for > 50 % of their cycles).
+    // Unconditional clamped loads (a branch around a load makes hipcc drain vmcnt); used only when t == wave below.
+    float pre_res[4] = {0.f, 0.f, 0.f, 0.f}; float pre_xw = 0.f; int pre_pos[4] = {0, 0, 0, 0};
+    {
+        const int n0_ = min(nbase + min(wave, NTW - 1) * 16 + li, N - 1);
+        if (EPI == EPI_RESID_XF || EPI == EPI_RESID) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) pre_res[r] = p.resid[(size_t)min(4 * g + r, M - 1) * p.resid_stride + n0_];
+        }
+        if (EPI == EPI_RESID_XF) { pre_xw = p.xf_w[n0_]; if (p.xf_w2) pre_xw *= p.xf_w2[n0_]; }
+        if (EPI == EPI_ROPE_KV) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) pre_pos[r] = p.pos[min(4 * g + r, M - 1)];
+        }
+    }
     // wave's K steps: [q, qend) step qs -- a contiguous range when tiled (pure streaming), interleaved otherwise
     const int per = (nq + KS - 1) / KS;
     int q = TILED ? wave * per : wave;
@@ -1220,7 +1236,8 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
         const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
         const float vals[4] = {sum.x + bias, sum.y + bias, sum.z + bias, sum.w + bias};
         float xw = 0.f;
-        if (EPI == EPI_RESID_XF && nok) { xw = p.xf_w[n]; if (p.xf_w2) xw *= p.xf_w2[n]; }
+        const bool pre = t == wave;                         // operands prefetched at kernel start
+        if (EPI == EPI_RESID_XF && nok) { if (pre) xw = pre_xw; else { xw = p.xf_w[n]; if (p.xf_w2) xw *= p.xf_w2[n]; } }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int m = 4 * g + r;
@@ -1245,7 +1262,7 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
                 // residual stream as f32 + the next RMSNorm folded in: XF planes of v * gamma (K-slot pair (k, k+2) = lanes li, li+2)
                 // and this workgroup's partial sum of squares per row
                 const bool ok = m < M && nok;
-                if (ok) { v = v + p.resid[(size_t)m * p.resid_stride + n]; p.out[(size_t)m * p.out_stride + n] = v; } else v = 0.f;
+                if (ok) { v = v + (pre ? pre_res[r] : p.resid[(size_t)m * p.resid_stride + n]); p.out[(size_t)m * p.out_stride + n] = v; } else v = 0.f;
                 const float ss = row16_sum(v * v);
                 if (li == 0) p.ssq_out[(size_t)blockIdx.x * 16 + m] = ss;
                 const float a = v * xw, b = dpp_mov<0x4E>(a);
@@ -1258,7 +1275,7 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             } else if (EPI == EPI_ROPE_KV) {
                 const float other = dpp_mov<0xB1>(v);          // the pair partner (interleaved RoPE pairs, rope.rs:77-141)
                 if (m < M && nok) {
-                    const int ps = p.pos[m], kd = p.n_kv * p.hd;
+                    const int ps = pre ? pre_pos[r] : p.pos[m], kd = p.n_kv * p.hd;
                     if (n < p.n_q + kd) {
                         const int dd = n % p.hd;
                         const size_t ti = (size_t)ps * (p.hd >> 1) + (dd >> 1);
@@ -1272,7 +1289,7 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
                     }
                 }
             } else if (m < M && nok) {
-                if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + n];
+                if (EPI == EPI_RESID) v = v + (pre ? pre_res[r] : p.resid[(size_t)m * p.resid_stride + n]);
                 if (EPI == EPI_GELU) v = gelu_f(v);
                 p.out[(size_t)m * p.out_stride + n] = v;
             }
