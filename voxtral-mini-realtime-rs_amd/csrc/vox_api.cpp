@@ -755,6 +755,7 @@ static void to_f32(const TensorView& t, uint64_t ne, float* out) {     // weight
 namespace {
 struct Loader {
     vox_model* m; const TensorSource* src; Arena ar; bool fill; void* staging = nullptr; size_t staging_cap = 0;
+    std::map<std::string, bool>* fmt_cache = nullptr;       // first tensor name of a dense linear -> all values bf16-representable (shared by both passes)
     std::string err;
 
     bool setfail(const std::string& e) { if (err.empty()) err = e; return false; }
@@ -839,6 +840,42 @@ struct Loader {
             }
             return true;
         }
+        // F32 / F16 sources whose values are not all bf16-representable keep their exact f32 values (WFMT_F32: f32 plane + bf16 hi / lo planes;
+        // models/weights.rs:16-66 accepts any F32 / F16 / BF16 checkpoint).  The decision is made once per tensor set (both loader passes agree).
+        bool exact_bf16 = true;
+        {
+            auto it = fmt_cache->find(parts[0]);
+            if (it != fmt_cache->end()) exact_bf16 = it->second;
+            else {
+                for (size_t i = 0; i < ts.size() && exact_bf16; i++) {
+                    if (ts[i].dtype == DT_BF16) continue;
+                    const uint64_t ne = numel(ts[i]);
+                    if (ts[i].dtype == DT_F32) { const uint32_t* b = (const uint32_t*)ts[i].data; for (uint64_t e = 0; e < ne; e++) if (b[e] & 0xFFFFu) { exact_bf16 = false; break; } }
+                    else { const uint16_t* h = (const uint16_t*)ts[i].data; for (uint64_t e = 0; e < ne; e++) { const float f = half_bits_to_f32(h[e]); uint32_t b; std::memcpy(&b, &f, 4); if (b & 0xFFFFu) { exact_bf16 = false; break; } } }
+                }
+                (*fmt_cache)[parts[0]] = exact_bf16;
+            }
+        }
+        if (!exact_bf16) {
+            float* wf = ar.take<float>((size_t)Ntot * K); uint16_t* hi = ar.take<uint16_t>((size_t)Ntot * K); uint16_t* lo = ar.take<uint16_t>((size_t)Ntot * K);
+            L->w = Q4W{(const uint4*)hi, lo, (int)Ntot, (int)K, nb, WFMT_F32}; L->w.qt = (const uint4*)wf;
+            if (fill) {
+                std::vector<float> host((size_t)Ntot * K); std::vector<uint16_t> h2((size_t)Ntot * K), l2((size_t)Ntot * K);
+                auto rne = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+                int64_t row0 = 0;
+                for (size_t i = 0; i < ts.size(); i++) {
+                    const int64_t nn = (int64_t)ts[i].shape[0];
+                    std::vector<float> src((size_t)nn * K); to_f32(ts[i], (uint64_t)nn * K, src.data());
+                    for (int64_t r = 0; r < nn; r++)
+                        std::memcpy(host.data() + (size_t)(interleave ? r * (int64_t)ts.size() + (int64_t)i : row0 + r) * K, src.data() + (size_t)r * K, (size_t)K * 4);
+                    row0 += nn;
+                }
+                for (size_t e = 0; e < host.size(); e++) { const uint16_t hb = rne(host[e]); const uint32_t hu = (uint32_t)hb << 16; float hf; std::memcpy(&hf, &hu, 4); h2[e] = hb; l2[e] = rne(host[e] - hf); }
+                if (hipMemcpy(wf, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(hi, h2.data(), h2.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(lo, l2.data(), l2.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return setfail("hipMemcpy failed for dense f32 weight");
+            }
+            return true;
+        }
         uint16_t* w = ar.take<uint16_t>((size_t)Ntot * K);
         L->w = Q4W{(const uint4*)w, nullptr, (int)Ntot, (int)K, nb, WFMT_BF16};
         if (fill) {
@@ -853,7 +890,7 @@ struct Loader {
                         for (int64_t k = 0; k < K; k++) {
                             float f = ts[i].dtype == DT_F32 ? ((const float*)ts[i].data)[(size_t)r * K + k] : half_bits_to_f32(((const uint16_t*)ts[i].data)[(size_t)r * K + k]);
                             uint32_t b; std::memcpy(&b, &f, 4);
-                            if (b & 0xFFFFu) return setfail("dense weight '" + parts[i] + "' is not bf16-representable: the dense path stores weights as bf16 (the published checkpoint is BF16)");
+                            if (b & 0xFFFFu) return setfail("internal: dense weight '" + parts[i] + "' was classified bf16-exact but is not");
                             dst[k] = (uint16_t)(b >> 16);
                         }
                     }
@@ -981,17 +1018,18 @@ extern "C" int32_t vox_model_free(vox_model* m) { model_release(m); return VOX_O
 // shared tail of both loaders: plan the arena, fill it, allocate the decode-step buffers
 static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool layout_only, vox_model** out) {
     vox_model* m = new vox_model(); m->ctx = ctx;
-    Loader plan{m, src, Arena{}, false};
+    std::map<std::string, bool> fmt_cache;
+    Loader plan{m, src, Arena{}, false}; plan.fmt_cache = &fmt_cache;
     if (!plan.run(q4)) { std::string e = plan.err; model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
     m->arena_bytes = plan.ar.off + 256;
     if (hipMalloc((void**)&m->arena, m->arena_bytes) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of %.1f MB weight arena failed", m->arena_bytes / 1e6); }
     const size_t max_q4 = layout_only ? 16 : std::max<uint64_t>(src->max_q4_bytes(), 16);
     DevBuf staging; if (staging.alloc(max_q4) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of staging buffer failed"); }
-    Loader fillr{m, src, Arena{m->arena, 0}, !layout_only, staging.p, max_q4};
+    Loader fillr{m, src, Arena{m->arena, 0}, !layout_only, staging.p, max_q4}; fillr.fmt_cache = &fmt_cache;
     if (!fillr.run(q4)) { std::string e = fillr.err; model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
     const vox_model_cfg& c = m->cfg;
     const int qdim = c.dec_heads * c.dec_head_dim;
-    if (m->tok.w.fmt == WFMT_BF16) { m->argmax_R = 2; m->n_parts = dense_gemv_grid(c.vocab); }
+    if (m->tok.w.fmt == WFMT_BF16 || m->tok.w.fmt == WFMT_F32) { m->argmax_R = 2; m->n_parts = dense_gemv_grid(c.vocab); }
     else { m->argmax_R = q4_gemv_default_R(c.vocab, c.dec_dim, EPI_ARGMAX); m->n_parts = m->argmax_R > 0 ? q4_gemv_grid(c.vocab, m->argmax_R) : 1; }
     hipError_t e = hipSuccess;
     auto A = [&](void** p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n); };
@@ -1354,7 +1392,7 @@ static int32_t lm_head_argmax_dev(vox_model* m, const float* h, float* logits_ou
     ARGCHK(c.dec_dim <= 4096, "lm_head GEMV is instantiated for dec_dim <= 4096 (got %d)", c.dec_dim);
     GemvParams p{}; p.w = m->tok.w; p.x = h; p.x_stride = c.dec_dim; p.out = logits_out; p.out_stride = c.vocab; p.gamma = m->dec_norm; p.eps = c.norm_eps;
     p.part_val = m->d_part_val; p.part_idx = m->d_part_idx;
-    if (m->tok.w.fmt != WFMT_BF16) m->n_parts = q4_gemv_grid_k(c.vocab, c.dec_dim, m->argmax_R, EPI_ARGMAX);   // partials = workgroups of THIS launch (<= the allocated count)
+    if (m->tok.w.fmt == WFMT_Q4_0) m->n_parts = q4_gemv_grid_k(c.vocab, c.dec_dim, m->argmax_R, EPI_ARGMAX);   // partials = workgroups of THIS launch (<= the allocated count)
     HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ARGMAX, m->argmax_R, m->ctx->stream));
     return VOX_OK;
 }
@@ -1611,7 +1649,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     // The step's GEMM inputs live as XF fragment planes (bf16 hi+lo in MFMA A-operand order, written once by the producing kernel), so
     // the skinny kernels spend no VALU on conversion and RMSNorm output never exists as f32.  Sequences are processed in groups of
     // 16 rows (one MFMA m-tile); the groups of a layer run back to back so the second group finds the layer's weights in L2 / MALL.
-    const bool use_xf = m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !getenv("VOX_BATCH_NO_XF");
+    const bool use_xf = m->tok.w.fmt == WFMT_Q4_0 && m->dec[0].wqkv.w.fmt == WFMT_Q4_0 && m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !getenv("VOX_BATCH_NO_XF");
     const int n_grp = (n + 15) / 16;
     auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
     if (use_xf) {
@@ -1795,11 +1833,11 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
         return VOX_OK;
     };
     const Q4W* w = which == 0 ? &m->dec[0].wqkv.w : which == 1 ? &m->dec[0].wo.w : which == 2 ? &m->dec[0].w13.w : which == 3 ? &m->dec[0].w2.w : &m->tok.w;
-    *bytes_per_launch = w->fmt == WFMT_BF16 ? (double)w->N * w->K * 2.0 : (double)w->N * w->nb * 18.0;   // algorithmic bytes: Q4_0 blocks (18 B / 32 weights) or bf16
+    *bytes_per_launch = w->fmt == WFMT_BF16 ? (double)w->N * w->K * 2.0 : w->fmt == WFMT_F32 ? (double)w->N * w->K * 4.0 : (double)w->N * w->nb * 18.0;   // algorithmic bytes: Q4_0 blocks (18 B / 32 weights) or bf16
     if (kernel_name) {
         const int epi = which == 0 ? EPI_ROPE_KV : which == 2 ? EPI_SWIGLU : which == 4 ? EPI_ARGMAX : EPI_RESID;
         const int pro = which == 2 ? PRO_RMS_MUL : (which == 0 || which == 4) ? PRO_RMS : PRO_NONE;
-        if (w->fmt == WFMT_BF16) { static thread_local char nb_[64]; snprintf(nb_, sizeof nb_, "dense_gemv_kernel<PRO=%d,EPI=%d>", pro, epi); *kernel_name = nb_; }
+        if (w->fmt == WFMT_BF16 || w->fmt == WFMT_F32) { static thread_local char nb_[64]; snprintf(nb_, sizeof nb_, "dense_gemv_kernel<PRO=%d,EPI=%d>", pro, epi); *kernel_name = nb_; }
         else *kernel_name = q4_gemv_kernel_name(w->K, pro, epi, which == 4 ? m->argmax_R : q4_gemv_default_R(w->N, w->K, epi));
     }
     for (int i = 0; i < std::min(iters, 8); i++) VOXCHK(launch(i));   // warm-up

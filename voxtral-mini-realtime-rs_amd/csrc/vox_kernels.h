@@ -19,7 +19,9 @@ struct Q4W {
     // skinny (M <= 16) and the large-M MFMA kernels, whose B fragments then are single coalesced dwordx4 loads
     const uint4* qt = nullptr; const uint16_t* st = nullptr;
 };
-enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1, WFMT_BF16X2 = 2 };   // BF16X2: f32 weights as two dense bf16 planes, qs = hi [N][K], sc = lo [N][K] (conv stem)
+enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1, WFMT_BF16X2 = 2, WFMT_F32 = 3 };
+// WFMT_F32: a dense F32 / F16 checkpoint tensor whose values are NOT bf16-representable (models/weights.rs:16-66 accepts any): qt = the exact f32
+// plane [N][K] (decode GEMV, embedding lookup), qs / sc = bf16 hi / lo planes (w ~= hi + lo to 2^-17; the MFMA GEMMs for > 4 rows).   // BF16X2: f32 weights as two dense bf16 planes, qs = hi [N][K], sc = lo [N][K] (conv stem)
 
 enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6, EPI_RESID_XF = 7, EPI_ROPE_KV_ATTN = 8 };
 // _ROPE_KV_ATTN (GEMV, one row): _ROPE_KV with write-through stores, then the workgroup that arrives LAST on a query head's counter (its q rows +

@@ -555,7 +555,7 @@ static hipError_t gemv_dispatch_pe(const GemvParams& p, int ny, int pro, int epi
 
 hipError_t launch_q4_gemv(const GemvParams& p_in, int ny, int pro, int epi, int R, hipStream_t s) {
     GemvParams p = p_in; p.tl_slot = tl_take_slot(0, epi, p.w.N, p.w.K);
-    if (p.w.fmt == WFMT_BF16) return launch_dense_gemv(p, ny, pro, epi, s);
+    if (p.w.fmt == WFMT_BF16 || p.w.fmt == WFMT_F32) return launch_dense_gemv(p, ny, pro, epi, s);
     if (p.w.K % 32 || p.w.K <= 0 || p.w.N <= 0 || R <= 0 || p.w.N % R) return hipErrorInvalidValue;
     const int P = passes_for(p.w.K, R);
 #define VOX_RP(R_, P_) if (R == R_ && P == P_) return gemv_dispatch_pe<P_, R_>(p, ny, pro, epi, s)
@@ -585,7 +585,15 @@ __device__ __forceinline__ float dot8_bf16(const uint4 w, const float4 xa, const
     return s0 + s1;
 }
 
-template <int PRO, int EPI>
+__device__ __forceinline__ float dot8_f32(const uint4 we, const uint4 wo, const float4 xa, const float4 xb) {   // 8 consecutive f32 weights . x
+    float s0 = __uint_as_float(we.x) * xa.x, s1 = __uint_as_float(we.y) * xa.y;
+    s0 = fmaf(__uint_as_float(we.z), xa.z, s0); s1 = fmaf(__uint_as_float(we.w), xa.w, s1);
+    s0 = fmaf(__uint_as_float(wo.x), xb.x, s0); s1 = fmaf(__uint_as_float(wo.y), xb.y, s1);
+    s0 = fmaf(__uint_as_float(wo.z), xb.z, s0); s1 = fmaf(__uint_as_float(wo.w), xb.w, s1);
+    return s0 + s1;
+}
+// F32W: the weights are the exact f32 plane (WFMT_F32: 32 bytes per 8 weights instead of 16)
+template <int PRO, int EPI, int F32W = 0>
 __global__ __launch_bounds__(256) void dense_gemv_kernel(const GemvParams p) {
     constexpr int NX = 10, R = 2;                  // K <= 10240; one wave = one row pair
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -633,16 +641,23 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const GemvParams p) {
     const int n_groups = N / R, n_waves = gridDim.x * 4;
     for (int g = blockIdx.x * 4 + wave; g < n_groups; g += n_waves) {
         const int row0 = g * R;
-        const uint4* w0 = p.w.qs + (size_t)row0 * nc;
-        const uint4* w1 = w0 + nc;
+        const uint4* w0 = (F32W ? p.w.qt : p.w.qs) + (size_t)row0 * nc * (F32W ? 2 : 1);
+        const uint4* w1 = w0 + nc * (F32W ? 2 : 1);
         float acc[R] = {0.f, 0.f};
         for (int c0 = 0; c0 < nc; c0 += 128) {
             const int ca = c0 + lane, cb = ca + 64, cca = min(ca, nc - 1), ccb = min(cb, nc - 1);
-            const uint4 a0 = ld_nt_u4(w0 + cca), a1 = ld_nt_u4(w0 + ccb), b0 = ld_nt_u4(w1 + cca), b1 = ld_nt_u4(w1 + ccb);
             const float4 xea = xe[cca], xoa = xo[cca], xeb = xe[ccb], xob = xo[ccb];
             const float ma = ca < nc ? 1.0f : 0.0f, mb = cb < nc ? 1.0f : 0.0f;
-            acc[0] += ma * dot8_bf16(a0, xea, xoa) + mb * dot8_bf16(a1, xeb, xob);
-            acc[1] += ma * dot8_bf16(b0, xea, xoa) + mb * dot8_bf16(b1, xeb, xob);
+            if (F32W) {
+                const uint4 a0e = ld_nt_u4(w0 + 2 * cca), a0o = ld_nt_u4(w0 + 2 * cca + 1), a1e = ld_nt_u4(w0 + 2 * ccb), a1o = ld_nt_u4(w0 + 2 * ccb + 1);
+                const uint4 b0e = ld_nt_u4(w1 + 2 * cca), b0o = ld_nt_u4(w1 + 2 * cca + 1), b1e = ld_nt_u4(w1 + 2 * ccb), b1o = ld_nt_u4(w1 + 2 * ccb + 1);
+                acc[0] += ma * dot8_f32(a0e, a0o, xea, xoa) + mb * dot8_f32(a1e, a1o, xeb, xob);
+                acc[1] += ma * dot8_f32(b0e, b0o, xea, xoa) + mb * dot8_f32(b1e, b1o, xeb, xob);
+            } else {
+                const uint4 a0 = ld_nt_u4(w0 + cca), a1 = ld_nt_u4(w0 + ccb), b0 = ld_nt_u4(w1 + cca), b1 = ld_nt_u4(w1 + ccb);
+                acc[0] += ma * dot8_bf16(a0, xea, xoa) + mb * dot8_bf16(a1, xeb, xob);
+                acc[1] += ma * dot8_bf16(b0, xea, xoa) + mb * dot8_bf16(b1, xeb, xob);
+            }
         }
         acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]);
         if (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_GELU) {
@@ -708,7 +723,8 @@ int dense_gemv_grid(int N) { const int wgs = (N / 2 + 3) / 4; return wgs > 2048 
 template <int PRO, int EPI>
 static hipError_t dense_launch_t(const GemvParams& p, int ny, hipStream_t s) {
     const size_t lds = (size_t)(p.w.K + 16) * sizeof(float);
-    dense_gemv_kernel<PRO, EPI><<<dim3(dense_gemv_grid(p.w.N), ny), dim3(256), lds, s>>>(p);
+    if (p.w.fmt == WFMT_F32) dense_gemv_kernel<PRO, EPI, 1><<<dim3(dense_gemv_grid(p.w.N), ny), dim3(256), lds, s>>>(p);
+    else dense_gemv_kernel<PRO, EPI, 0><<<dim3(dense_gemv_grid(p.w.N), ny), dim3(256), lds, s>>>(p);
     return hipGetLastError();
 }
 static hipError_t launch_dense_gemv(const GemvParams& p, int ny, int pro, int epi, hipStream_t s) {
@@ -1649,22 +1665,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             for (int r = 0; r < 4; r++) {
                 const int m = m0 + i * 16 + 4 * g + r;
                 float v = acc[t][i][r] + bias;
-                if (EPI == EPI_GELU) v = gelu_f(v);
-                if (m < M && nok) p.out[(size_t)m * p.out_stride + n] = v;
+                if (EPI == EPI_SWIGLU) {
+                    const float other = dpp_mov<0xB1>(v);        // lane^1 = column n^1; rows interleaved: even n = gate, odd n = up
+                    if (m < M && nok && !(n & 1)) p.out[(size_t)m * p.out_stride + (n >> 1)] = silu_f(v) * other;
+                } else {
+                    if (EPI == EPI_GELU) v = gelu_f(v);
+                    if (EPI == EPI_RESID && m < M && nok) v = v + p.resid[(size_t)m * p.resid_stride + n];
+                    if (m < M && nok) p.out[(size_t)m * p.out_stride + n] = v;
+                }
             }
     }
 }
 hipError_t launch_dense2_gemm(const GemmParams& p, int epi, hipStream_t s) {
-    if (p.w.fmt != WFMT_BF16X2 || p.w.K % 128 || (p.x_stride % 4) || p.M <= 0 || (epi != EPI_GELU && epi != EPI_STORE)) return hipErrorInvalidValue;
+    if (p.w.fmt != WFMT_BF16X2 || p.w.K % 128 || (p.x_stride % 4) || p.M <= 0) return hipErrorInvalidValue;
     const long wg4 = (long)((p.w.N + 255) / 256) * ((p.M + 63) / 64);
     const size_t lds = (size_t)2 * 4 * 4 * 64 * sizeof(uint4);      // 32 KB
-    if (wg4 >= 200) {
-        dim3 grid((p.w.N + 255) / 256, (p.M + 63) / 64);
-        if (epi == EPI_GELU) dense2_gemm_kernel<4, EPI_GELU><<<grid, dim3(256), lds, s>>>(p); else dense2_gemm_kernel<4, EPI_STORE><<<grid, dim3(256), lds, s>>>(p);
-    } else {
-        dim3 grid((p.w.N + 63) / 64, (p.M + 63) / 64);
-        if (epi == EPI_GELU) dense2_gemm_kernel<1, EPI_GELU><<<grid, dim3(256), lds, s>>>(p); else dense2_gemm_kernel<1, EPI_STORE><<<grid, dim3(256), lds, s>>>(p);
-    }
+    const bool wide = wg4 >= 200;
+    dim3 grid(wide ? (p.w.N + 255) / 256 : (p.w.N + 63) / 64, (p.M + 63) / 64);
+#define VOX_D2(E_) case E_: if (wide) dense2_gemm_kernel<4, E_><<<grid, dim3(256), lds, s>>>(p); else dense2_gemm_kernel<1, E_><<<grid, dim3(256), lds, s>>>(p); break;
+    switch (epi) { VOX_D2(EPI_STORE) VOX_D2(EPI_GELU) VOX_D2(EPI_RESID) VOX_D2(EPI_SWIGLU) default: return hipErrorInvalidValue; }
+#undef VOX_D2
     return hipGetLastError();
 }
 // [R][C] -> [C][R] (mel handed over as [128][T] by the reference's callers -> token-major rows for the im2col view)
@@ -1787,6 +1807,11 @@ static hipError_t gemm_launch_f(const GemmParams& p, int epi, hipStream_t s) {
 }
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
+    if (p.w.fmt == WFMT_F32) {      // true-f32 dense weights: bf16 hi + lo planes on the matrix cores (3 MFMAs per product, f32-class like the conv stem)
+        if (p.xf) return hipErrorInvalidValue;
+        GemmParams v = p; v.w.fmt = WFMT_BF16X2; v.w.qt = nullptr; v.w.st = nullptr;
+        return launch_dense2_gemm(v, epi, s);
+    }
     if (p.xf) return (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && p.w.qt) ? launch_q4_skinny(p, epi, s) : hipErrorInvalidValue;
     if (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && !env_int("VOX_NO_SKINNY")) return launch_q4_skinny(p, epi, s);
     if (p.M > 16 && p.M <= 48 && p.w.fmt == WFMT_Q4_0 && p.w.qt && p.w.st && p.w.nb % 4 == 0 && (p.x_stride % 4) == 0 && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_GELU || epi == EPI_SWIGLU) &&
@@ -2719,6 +2744,15 @@ hipError_t launch_absmax(const float* x, long n, float target, float* scale_out,
 // one token-embedding row (Q4_0 row dequant, gguf/model.rs:584-618, or dense bf16 row, models/decoder.rs:250-262)
 // plus the audio embedding of the same position (gguf/model.rs:898-902, :942-948); 256 threads cooperate.
 __device__ __forceinline__ void embed_row(const Q4W& tok, int id, const float* __restrict__ arow, float* __restrict__ o, int D) {
+    if (tok.fmt == WFMT_F32) {
+        const float4* w = reinterpret_cast<const float4*>(tok.qt) + (size_t)id * (D >> 2);
+        for (int c = threadIdx.x; c < (D >> 2); c += blockDim.x) {
+            float4 a = w[c];
+            if (arow) { const float4 u = reinterpret_cast<const float4*>(arow)[c]; a.x = u.x + a.x; a.y = u.y + a.y; a.z = u.z + a.z; a.w = u.w + a.w; }
+            reinterpret_cast<float4*>(o)[c] = a;
+        }
+        return;
+    }
     if (tok.fmt == WFMT_BF16) {
         const uint4* w = tok.qs + (size_t)id * (D >> 3);
         for (int c = threadIdx.x; c < (D >> 3); c += blockDim.x) {
