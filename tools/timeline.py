@@ -19,19 +19,26 @@ if not os.path.exists(path):
 ctx = pkg.Context(0); model = pkg.Q4ModelLoader.from_file(path).load(ctx)
 t = pkg.TimeEmbedding(3072).embed(6.0)
 x = S.synth_audio(float(os.environ.get("VOX_TL_SECONDS", "16")), seed=1234); dx = ctx.upload(x)
-NS, NW = 400, 3072
+NS, NW = 400, 8192
+BATCH = int(os.environ.get("VOX_TL_BATCH", "0"))      # > 0: the batched decode step (vox_transcribe_batch of BATCH clips) instead of single-stream
 # warm-up on a SHORT clip first (Ada scales, workspaces, a graph without slots); the 16 s clip then needs a larger audio buffer, so its
 # first call re-captures the decode graph -- with timeline slots: slot 0 = prefill lm_head, 1..131 the eager step, 132..262 the CAPTURED step
 xs = S.synth_audio(4.0, seed=99); dxs = ctx.upload(xs); model.transcribe_audio(None, t, device_ptr=dxs, n_samples=xs.size); ctx.free(dxs)
+if BATCH:
+    clips = [S.synth_audio(16.0, seed=1234 + i) for i in range(BATCH)]; ptrs = [ctx.upload(c) for c in clips]; lens = [c.size for c in clips]
+    model.transcribe_batch(None, t, device_ptrs=ptrs, n_samples=lens)                      # warm-up (workspaces)
 pkg._lib.check(L.vox_debug_timeline_start(ctx.h, NS, NW))
-for _ in range(3):
-    ids = model.transcribe_audio(None, t, device_ptr=dx, n_samples=x.size)
+if BATCH:
+    outs = model.transcribe_batch(None, t, device_ptrs=ptrs, n_samples=lens); ids = outs[0]      # slots: first lm_head, the eager step, then the CAPTURED step (rewritten by every replay)
+else:
+    for _ in range(3):
+        ids = model.transcribe_audio(None, t, device_ptr=dx, n_samples=x.size)
 buf = np.zeros((NS, NW, 4), dtype=np.uint64); used = C.c_int32(); meta = np.zeros((NS, 4), dtype=np.int32)
 pkg._lib.check(L.vox_debug_timeline_fetch(ctx.h, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(used), meta.ctypes.data_as(C.c_void_p)))
 tm = model.timings()
 print(f"ids {len(ids)}, decode {tm['decode_ms']:.2f} ms -> {tm['decode_ms'] / max(len(ids), 1) * 1e3:.1f} us per step (instrumented build); slots used {used.value}")
 TICK = 0.01   # us per s_memrealtime tick (100 MHz)
-EPI = {0: "store", 1: "resid", 2: "swiglu", 3: "rope_kv", 4: "argmax", 5: "gelu", 8: "rope_kv+attn"}
+EPI = {0: "store", 1: "resid", 2: "swiglu", 3: "rope_kv", 4: "argmax", 5: "gelu", 6: "swiglu_xf", 7: "resid_xf", 8: "rope_kv+attn"}
 # the captured 1-step graph = the slots stamped LAST (the final replay): order the live slots by first entry and keep the trailing run
 # that fits in one step period
 live = []
@@ -47,7 +54,7 @@ for k in step:
     b = buf[k].astype(np.int64); ok = b[:, 0] > 0
     s0, s1, s2, s3 = (b[ok, i] for i in range(4))
     t0 = s0.min(); t_first = t0 if t_first is None else t_first
-    name = ("attn" if meta[k][0] == 1 else f"gemv {meta[k][2]}x{meta[k][3]} {EPI.get(int(meta[k][1]), meta[k][1])}")
+    name = ("attn" if meta[k][0] == 1 else f"{'skinny' if meta[k][0] == 2 else 'gemv'} {meta[k][2]}x{meta[k][3]} {EPI.get(int(meta[k][1]), meta[k][1])}")
     if name not in rows:
         rows[name] = []; order.append(name)
     rows[name].append(dict(gap=(t0 - prev_end) * TICK if prev_end is not None else np.nan, skew=(s0.max() - t0) * TICK,

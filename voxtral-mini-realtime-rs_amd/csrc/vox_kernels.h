@@ -74,6 +74,7 @@ struct GemmParams {
     // EPI_ROPE_KV (M <= 16, one row per sequence): columns [0, n_q) -> RoPE -> out; [n_q, n_q + n_kv*hd) -> RoPE -> K cache; rest -> V cache,
     // all at position pos[m] of sequence m's cache slice
     const int* pos; const float* rope_cos; const float* rope_sin; int hd, n_q, n_kv; float* kc; float* vc; long kv_seq_stride; int kv_head_stride;
+    int tl_slot;          // timeline slot (measurement builds, -DVOX_TIMELINE)
 };
 hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);

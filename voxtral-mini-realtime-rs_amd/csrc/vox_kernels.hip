@@ -1068,20 +1068,18 @@ hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s) {
     return hipGetLastError();
 }
 
-#ifdef VOX_SKINNY_RING
-#define VOX_RING_ON 1
-#else
-#define VOX_RING_ON 0
-#endif
-template <int NTW, int EPI, int TILED, int XIN, int PRO>
+// STEPS > 0 (batched decode step, tile-ordered weights + XF activations): every wave owns exactly STEPS K-steps and runs them as straight-line
+// code with the loads issued IN CONSUMPTION ORDER, D steps ahead (see the main loop).
+template <int NTW, int EPI, int TILED, int XIN, int PRO, int STEPS = 0>
 __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
-    constexpr bool RING = VOX_RING_ON != 0;
     extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS][NTW][64][4]
     __shared__ float s_rstd[16]; __shared__ float s_pp[32 * 16];
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, KS = blockDim.x >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int nbase = blockIdx.x * (16 * NTW);
+    const int tlw = wave == 0 ? (int)blockIdx.x * 4 : 1; (void)tlw;      // timeline builds: wave 0 of every workgroup stamps (tl_stamp keeps indices % 4 == 0)
+    VOX_TL(p.tl_slot, tlw, 0);
     const float* xrow = p.x + (size_t)min(li, M - 1) * p.x_stride;
     const uint4* wq[NTW]; const uint16_t* ws[NTW];
     const int n_tiles = (N + 15) >> 4;
@@ -1181,36 +1179,30 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
     const int per = (nq + KS - 1) / KS;
     int q = TILED ? wave * per : wave;
     const int qend = TILED ? min(q + per, nq) : nq, qs = TILED ? 1 : KS;
-    if (RING && TILED && XIN && q < qend) {
-        // MEASUREMENT VARIANT (-DVOX_SKINNY_RING; not in the product build).  Batched decode step: a register RING of D K-steps of weights -- the
-        // first D steps are requested before anything else (D >= the wave's whole range for q|k|v and wo), a slot is refilled with step s + D as
-        // soon as step s has been multiplied.  Round 2 measured it 6..8 % SLOWER than one step of look-ahead on every decode shape
-        // (profiles/r02_batch16_ring_prefetch.txt): these kernels are not bound by the weight bytes each wave has in flight.
-        constexpr int D = NTW >= 4 ? 3 : 4, XB = NTW >= 4 ? 1 : 2;     // 4 tiles per wave: 3 slots and single-buffered activations keep it under 256 VGPRs
-        uint4 wr[D][NTW]; uint2 sr[D][NTW];
+    if (STEPS > 0 && TILED && XIN) {
+        // vmcnt retires loads IN ORDER: waiting for a young L2-hit load (an activation fragment) also waits for every older HBM load.  The legacy
+        // loop issued the NEXT step's weights before the CURRENT step's fragments, so every step paid a full HBM round trip (timeline:
+        // ~2 us per K step, waves parked > 50 %); a ring that refilled weights out of consumption order was slower still (round-2 experiments,
+        // profiles/r02_batch16_ring_prefetch.txt).  Here: w(s), x(s) of steps 0..D-1 first, then after step s is multiplied, w(s+D), x(s+D) -- the
+        // issue order IS the consumption order, D steps of latency cover; fully unrolled (STEPS is exact: the launcher only picks this
+        // instantiation when every wave of the workgroup owns STEPS steps), so there is no control flow around any load.
+        constexpr int D = NTW >= 4 ? 2 : 3, DB = STEPS <= 0 ? 1 : (D < STEPS ? D : STEPS);      // (DB = 1 keeps the dead STEPS = 0 instantiation legal)
+        uint4 wr[DB][NTW]; uint2 sr[DB][NTW]; float4 xr[DB][2][4];
+#define VOX_ISSUE(B_, Q_)                                                                                  \
+        { VOX_WLOAD(wr[B_], sr[B_], (Q_))                                                                  \
+          _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                  \
+              xr[B_][0][j] = *reinterpret_cast<const float4*>(xfh + ((Q_) * 4 + j) * 64);                  \
+              xr[B_][1][j] = *reinterpret_cast<const float4*>(xfl + ((Q_) * 4 + j) * 64); } }
 #pragma unroll
-        for (int u = 0; u < D; u++) { const int qq = min(q + u, qend - 1); VOX_WLOAD(wr[u], sr[u], qq) }
-        float4 xr[XB][2][4];                                  // activation fragments: (XB = 2) step s + 1 requested before step s is multiplied
-#define VOX_XLOAD2(B_, Q_)                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                    \
-            xr[B_][0][j] = *reinterpret_cast<const float4*>(xfh + ((Q_) * 4 + j) * 64);                    \
-            xr[B_][1][j] = *reinterpret_cast<const float4*>(xfl + ((Q_) * 4 + j) * 64); }
-        VOX_XLOAD2(0, q)
-        __builtin_amdgcn_sched_barrier(0);
-        for (int base = 0; q + base < qend; base += 2 * D) {  // unrolled by 2 D: ring slot and activation buffer indices are compile-time
+        for (int u = 0; u < DB; u++) VOX_ISSUE(u, q + u)
 #pragma unroll
-            for (int u = 0; u < 2 * D; u++) {
-                const int st = q + base + u;
-                if (st < qend) {                              // wave-uniform
-                    if (XB == 2) { const int qx = min(st + 1, qend - 1); VOX_XLOAD2((u + 1) & (XB - 1), qx) }
-                    else if (u > 0 || base > 0) { VOX_XLOAD2(0, st) }
-                    VOX_SSTEP(wr[u % D], sr[u % D], xr[u & (XB - 1)][0], xr[u & (XB - 1)][1])
-                    { const int qn = min(st + D, qend - 1); VOX_WLOAD(wr[u % D], sr[u % D], qn) }       // refill (clamped: harmless re-read at the tail)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+        for (int st = 0; st < STEPS; st++) {
+            __builtin_amdgcn_sched_barrier(0);
+            VOX_SSTEP(wr[st % DB], sr[st % DB], xr[st % DB][0], xr[st % DB][1])
+            if (st + DB < STEPS) VOX_ISSUE(st % DB, q + st + DB)          // compile-time condition
+            VOX_TL(p.tl_slot, tlw, 1);
         }
-#undef VOX_XLOAD2
+#undef VOX_ISSUE
     } else if (q < qend) {
         VOX_WLOAD(wv, sv, q)
         for (;;) {
@@ -1220,6 +1212,7 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             VOX_XLOAD(q)
             __builtin_amdgcn_sched_barrier(0);
             VOX_SSTEP(wv, sv, xa, xb)
+            VOX_TL(p.tl_slot, tlw, 1);                     // (rewritten every other step: completion of the last even step)
             q += qs; if (q >= qend) break;
             { const int qn = min(q + qs, qend - 1); VOX_WLOAD(wv, sv, qn) }
             VOX_XLOAD(q)
@@ -1231,6 +1224,7 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
 #undef VOX_WLOAD
 #undef VOX_XLOAD
 #undef VOX_SSTEP
+    VOX_TL(p.tl_slot, tlw, 2);                             // K loop done
     // split-K combine (fixed order) + epilogue: wave t finishes tile t
 #pragma unroll
     for (int t = 0; t < NTW; t++)
@@ -1311,6 +1305,7 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
             }
         }
     }
+    VOX_TL(p.tl_slot, tlw, 3);
 }
 
 // ---- skinny MFMA GEMM for 17..48 rows (the 38-token decoder prefill, gguf/model.rs:908-923): MT m-tiles of 16 rows share ONE weight fetch.
@@ -1708,6 +1703,16 @@ static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStrea
         if (!TILED) return hipErrorInvalidValue;
         const bool pro = p.ssq_part != nullptr;
         if (pro && (p.n_part < 1 || p.n_part > 12 * (64 * ks / 16))) return hipErrorInvalidValue;     // partials per thread (q4_skinny_kernel PRO)
+        // straight-line in-order pipeline when every wave owns exactly STEPS K-steps (the decode-step shapes of the real model); VOX_SKINNY_NO_STEPS=1:
+        // the legacy loop (measurement knob)
+        const int nq = p.w.nb / 4, per = nq % ks == 0 ? nq / ks : 0;
+        if (per && !env_int("VOX_SKINNY_NO_STEPS")) {
+#define VOX_ST(N_, E_, P_, S_) if (NTW == N_ && epi == E_ && (int)pro == P_ && per == S_) { \
+            if (E_ == EPI_RESID_XF && (!p.xf_out || !p.xf_w || !p.ssq_out)) return hipErrorInvalidValue; \
+            q4_skinny_kernel<N_, E_, 1, 1, P_, S_><<<grid, dim3(64 * ks), lds, s>>>(p); return hipGetLastError(); }
+            VOX_ST(2, EPI_ROPE_KV, 1, 3) VOX_ST(1, EPI_RESID_XF, 0, 4) VOX_ST(4, EPI_SWIGLU_XF, 1, 6) VOX_ST(1, EPI_RESID_XF, 0, 9) VOX_ST(4, EPI_STORE, 1, 6)
+#undef VOX_ST
+        }
         if (epi == EPI_RESID_XF) {
             if (NTW != 1 || pro || !p.xf_out || !p.xf_w || !p.ssq_out) return hipErrorInvalidValue;
             q4_skinny_kernel<1, EPI_RESID_XF, 1, 1, 0><<<grid, dim3(64 * ks), lds, s>>>(p);
@@ -1738,7 +1743,8 @@ static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStrea
     return hipGetLastError();
 }
 int q4_skinny_resid_xf_parts(int N) { return (N + 15) / 16; }     // partial sums of squares written by an EPI_RESID_XF launch
-static hipError_t launch_q4_skinny(const GemmParams& p, int epi, hipStream_t s) {
+static hipError_t launch_q4_skinny(const GemmParams& p_in, int epi, hipStream_t s) {
+    GemmParams p = p_in; p.tl_slot = tl_take_slot(2, epi, p.w.N, p.w.K);
     const int nq = p.w.nb / 4, tiles = (p.w.N + 15) / 16;
     // n-tiles per wave: as many as still leave >= 192 workgroups (N = 3072 has only 192 tiles); split-K over 4 waves, 8 when
     // the grid is small and K is long enough.  VOX_SKINNY_NTW / VOX_SKINNY_KS are measurement knobs.
