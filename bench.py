@@ -279,9 +279,10 @@ def main():
         traffic, traffic_src = None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = dom["kernel"].replace("P=", "").replace("R=", " ").replace("PRO=", " ").replace("EPI=", " ").replace(",", ",")
+            import re
+            key = re.sub(r"[A-Z]+=", "", dom["kernel"]).replace(" ", "")       # "q4_gemv_kernel<P=3,R=2,...>" -> the demangled template name
             for k, v in pm["hbm_bytes_per_launch"].items():
-                if k.replace(" ", "") == key.replace(" ", ""):
+                if k.replace(" ", "") == key:
                     traffic, traffic_src = int(v), pm["source"]
         except Exception:
             pass

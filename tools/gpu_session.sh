@@ -27,5 +27,10 @@ step_pmc()       { # per-kernel PMC averages of the batched decode step (separat
                    for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"; do
                      i=$((i+1)); VOX_BATCH_NO_GRAPH=1 timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/${TAG}_pmc$i -o p -- python $REPO/${VOX_PMC_CMD:-tools/batch_prof.py 16} > $OUT/${TAG}_pmc$i.log 2>&1; echo "pmc pass $i rc=$?"
                    done; cd $REPO; python tools/pmc_summary.py $OUT/${TAG}_pmc* > $OUT/${TAG}_pmc_summary.txt 2>&1; cat $OUT/${TAG}_pmc_summary.txt | head -60; }
+step_traffic()   { # HBM bytes per launch of the dominant decode GEMV: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes over a short target
+                   cd /tmp
+                   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python $REPO/tools/gemv_traffic.py > $OUT/${TAG}_pmc_fetch.log 2>&1; echo "fetch rc=$?"
+                   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o p -- python $REPO/tools/gemv_traffic.py > $OUT/${TAG}_pmc_write.log 2>&1; echo "write rc=$?"
+                   cd $REPO; python tools/traffic_summary.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write | tee $OUT/${TAG}_pmc_gemv_traffic.txt; }
 step_batch()     { timeout 300 python tools/batch_prof.py ${VOX_BENCH_BATCH:-16} 2>&1 | tail -4; }
 for s in "$@"; do echo "=== $s"; t0=$(date +%s); step_$s; echo "--- $s took $(( $(date +%s) - t0 )) s"; done

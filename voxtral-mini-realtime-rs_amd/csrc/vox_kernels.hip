@@ -568,7 +568,7 @@ hipError_t launch_q4_gemv(const GemvParams& p_in, int ny, int pro, int epi, int 
 
 const char* q4_gemv_kernel_name(int K, int pro, int epi, int R) {
     static thread_local char buf[96];
-    snprintf(buf, sizeof buf, "q4_gemv_kernel<P=%d,R=%d,PRO=%d,EPI=%d>", passes_for(K, R), R, pro, epi);
+    snprintf(buf, sizeof buf, "q4_gemv_kernel<P=%d,R=%d,PRO=%d,EPI=%d,NWV=%d>", passes_for(K, R), R, pro, epi, gemv_fat_shape(K, R) ? q4_gemv_nwv(K, epi) : 4);
     return buf;
 }
 
