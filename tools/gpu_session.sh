@@ -32,5 +32,8 @@ step_traffic()   { # HBM bytes per launch of the dominant decode GEMV: FETCH_SIZ
                    timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python $REPO/tools/gemv_traffic.py > $OUT/${TAG}_pmc_fetch.log 2>&1; echo "fetch rc=$?"
                    timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o p -- python $REPO/tools/gemv_traffic.py > $OUT/${TAG}_pmc_write.log 2>&1; echo "write rc=$?"
                    cd $REPO; python tools/traffic_summary.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write | tee $OUT/${TAG}_pmc_gemv_traffic.txt; }
+step_ablate()    { # what each part of q4_gemv_kernel costs: product build, then every abl_* measurement build present
+                   python tools/gemv_ablate.py 2>/dev/null | tail -1 | tee $OUT/${TAG}_gemv_ablate.txt
+                   for l in voxtral-mini-realtime-rs_amd/libvoxtral_hip_abl_*.so; do VOX_LIB=$REPO/$l timeout 120 python tools/gemv_ablate.py 2>/dev/null | tail -1 | tee -a $OUT/${TAG}_gemv_ablate.txt; done; }
 step_batch()     { timeout 300 python tools/batch_prof.py ${VOX_BENCH_BATCH:-16} 2>&1 | tail -4; }
 for s in "$@"; do echo "=== $s"; t0=$(date +%s); step_$s; echo "--- $s took $(( $(date +%s) - t0 )) s"; done

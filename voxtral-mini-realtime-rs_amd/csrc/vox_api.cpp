@@ -1373,7 +1373,7 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
         } else {
             HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV, q4_gemv_default_R(p.w.N, p.w.K, EPI_ROPE_KV), s));
             AttnParams ap{}; ap.q = m->d_q; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd; ap.out = m->d_att;
-            ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = pos_off; ap.window = c.dec_window; ap.pos_ptr = pos_ptr; ap.M = 1;
+            ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = pos_off; ap.window = c.dec_window; ap.pos_ptr = pos_ptr; ap.M = 1; ap.spec_rows = kc->max_seq;
             HIPCHK(launch_attn_decode(ap, hd, kc->max_seq, s));
         }
         GemvParams o{}; o.w = L.wo.w; o.x = m->d_att; o.x_stride = QD; o.out = h; o.out_stride = D; o.resid = h; o.resid_stride = D;
@@ -1695,7 +1695,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
                       HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, sg)); }
                     AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
                     ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = pg; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
-                    ap.out_xf = xf2; ap.prefer_gqa = n_grp > 1 || getenv("VOX_ATTN_GQA") != nullptr; ap.no_xcd_remap = getenv("VOX_ATTN_NO_XCD") != nullptr;
+                    ap.out_xf = xf2; ap.prefer_gqa = n_grp > 1 || getenv("VOX_ATTN_GQA") != nullptr; ap.no_xcd_remap = getenv("VOX_ATTN_NO_XCD") != nullptr; ap.spec_rows = max_seq;
                     HIPCHK(launch_attn_decode(ap, hd, max_seq, sg, ng));
                     { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
                       g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
@@ -1718,7 +1718,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
             { GemmParams g{}; g.w = L.wqkv.w; g.x = xn; g.x_stride = D; g.M = n; g.out = qkv; g.out_stride = W; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
             HIPCHK(launch_rope_kv_batch(qkv, n, W, QD, KV, hd, d_pos, m->dec_cos, m->dec_sin, kl, vl, (long)seq_stride, max_seq * hd, s));
             AttnParams ap{}; ap.q = qkv; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
-            ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
+            ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride; ap.spec_rows = max_seq;
             HIPCHK(launch_attn_decode(ap, hd, max_seq, s, n));
             { GemmParams g{}; g.w = L.wo.w; g.x = att; g.x_stride = QD; g.M = n; g.out = h; g.out_stride = D; g.resid = h; g.resid_stride = D; HIPCHK(launch_q4_gemm(g, EPI_RESID, s)); }
             HIPCHK(launch_rms_norm(h, D, n, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));

@@ -114,6 +114,9 @@ struct AttnParams {
     int prefer_gqa;       // batched decode: one workgroup per (KV head, sequence) serving its 4 query heads (wide batches)
     int no_xcd_remap;     // measurement knob: keep the linear (head, sequence) workgroup order in attn_decode_kernel
     int tl_slot;          // timeline slot (measurement builds, -DVOX_TIMELINE)
+    int spec_zero;        // always 0 (see attn_decode_kernel: keeps the position load a vector load)
+    int spec_rows;        // decode (head-major cache, kv_row_stride == hd): rows per KV head in the cache; > 0 lets the kernel request the first
+                          // 160 rows before the position word has arrived (attn_decode_core SPEC).  0: indices derived from the position.
 };
 hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n_seq = 1);     // M > 1, causal (+window)
 hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq = 1);  // M == 1 per sequence

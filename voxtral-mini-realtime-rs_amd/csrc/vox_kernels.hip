@@ -165,9 +165,10 @@ hipError_t launch_q4_dequant(Q4W w, float* out, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // fused Q4 GEMV
 // ------------------------------------------------------------------------------------------------
-template <int HD, bool NT, bool LATE_V>
+template <int HD, bool NT, bool LATE_V, bool SPEC = false>
 __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh, const float* __restrict__ kb, const float* __restrict__ vb, int kv_row_stride,
-                                                   int pos, int window, float* __restrict__ sc, float* __restrict__ red, float4* __restrict__ osum, int tl_slot, int tlw);
+                                                   int pos, int window, float* __restrict__ sc, float* __restrict__ red, float4* __restrict__ osum, int tl_slot, int tlw,
+                                                   int spec_rows = 0);
 
 // two adjacent floats: plain stores, or ONE 8-byte write-through (sc1) store -- visible to other workgroups of the same launch once the
 // storing wave has drained it (s_waitcnt vmcnt(0)) and published a flag / counter (MI355X_MICROARCH.md, inter-workgroup visibility, form R1)
@@ -213,13 +214,19 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
     // makes hipcc branch around the load and drain vmcnt(0) per element, which serialises HBM round trips.
     // (1) activation pieces (+ norm weights) first -- VMEM returns in order, so they land first ...
     float4 xp[NX], gp[PRO != PRO_NONE ? NX : 1], mp[PRO == PRO_RMS_MUL ? NX : 1];
-#pragma unroll
-    for (int i = 0; i < NX; i++) {
-        const int pc = min(tid + NT * i, npieces - 1);
-        xp[i] = reinterpret_cast<const float4*>(xg)[pc];
-        if (PRO != PRO_NONE) gp[i] = reinterpret_cast<const float4*>(p.gamma)[pc];
-        if (PRO == PRO_RMS_MUL) mp[i] = reinterpret_cast<const float4*>(p.mul)[pc];
+#define VOX_XLOAD                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NX; i++) {                                                     \
+        const int pc = min(tid + NT * i, npieces - 1);                                                   \
+        xp[i] = reinterpret_cast<const float4*>(xg)[pc];                                                 \
+        if (PRO != PRO_NONE) gp[i] = reinterpret_cast<const float4*>(p.gamma)[pc];                       \
+        if (PRO == PRO_RMS_MUL) mp[i] = reinterpret_cast<const float4*>(p.mul)[pc];                      \
     }
+#if defined(VOX_ABL_NOX)          /* measurement build: no activation loads at all (results wrong) */
+#pragma unroll
+    for (int i = 0; i < NX; i++) { xp[i] = make_float4(1.f, 2.f, 3.f, 4.f); gp[PRO != PRO_NONE ? i : 0] = xp[i]; mp[PRO == PRO_RMS_MUL ? i : 0] = xp[i]; }
+#elif !defined(VOX_ABL_WFIRST)
+    VOX_XLOAD
+#endif
     // per-pass lane constants: chunk-in-group -> (row in group, chunk in row)
     int vcl[P], cp[P], rp[P]; bool okp[P];
 #pragma unroll
@@ -235,9 +242,18 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
     _Pragma("unroll") for (int q_ = 0; q_ < P; q_++) {                                                   \
         const size_t idx = (size_t)(G_) * rnb + vcl[q_];                                                 \
         Q_[q_] = ld_nt_u4(p.w.qs + idx);                                                                 \
-        D_[q_] = __builtin_nontemporal_load(p.w.sc + idx);                                               \
+        D_[q_] = VOX_SCLOAD(idx);                                                                        \
     }
+#ifdef VOX_ABL_NOSCALE            /* measurement build: no block-scale loads (results wrong) */
+#define VOX_SCLOAD(I_) ((uint16_t)0x3c00)
+#else
+#define VOX_SCLOAD(I_) __builtin_nontemporal_load(p.w.sc + (I_))
+#endif
     VOX_WLOAD(qa, da, min(g, n_groups - 1))
+#if defined(VOX_ABL_WFIRST) && !defined(VOX_ABL_NOX)       /* measurement build: weights issued BEFORE the activation loads */
+    VOX_XLOAD
+#endif
+#undef VOX_XLOAD
 
     // (3) prologue on the activation vector (RMSNorm (+Ada multiplier) fused), staged to LDS.  The row scale 1/rms is a scalar, so it
     // commutes with the dot products: x * gamma is staged UNnormalised right away and every row result is multiplied by rstd in
@@ -370,6 +386,7 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
         g += n_waves;
     }
 #undef VOX_WLOAD
+#undef VOX_SCLOAD
 #undef VOX_GROUP
 #undef VOX_DOT
 #undef VOX_REDUCE
@@ -1070,8 +1087,10 @@ hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s) {
 
 // STEPS > 0 (batched decode step, tile-ordered weights + XF activations): every wave owns exactly STEPS K-steps and runs them as straight-line
 // code with the loads issued IN CONSUMPTION ORDER, D steps ahead (see the main loop).
+// NTW == 3 (w1|w3 of the real model: 2304 n-tiles = 768 workgroups of 4 waves = exactly 3 per CU): 256-thread workgroups, <= 168 VGPRs so that the
+// three workgroups of a CU are resident together (with NTW = 4 the 576 workgroups needed 256 VGPRs -> 512 slots -> a second round of 64).
 template <int NTW, int EPI, int TILED, int XIN, int PRO, int STEPS = 0>
-__global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NTW == 3 ? 256 : 512, NTW == 3 ? 3 : 1) void q4_skinny_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS][NTW][64][4]
     __shared__ float s_rstd[16]; __shared__ float s_pp[32 * 16];
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
@@ -1115,92 +1134,99 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
 // already in the accumulator layout.  K-slot order of a lane group g: {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3}.
 #define VOX_SSTEP(WV_, SV_, XA_, XB_)                                                                      \
     {                                                                                                      \
-        uint4 ah[4], al[4]; f32x4 cs[4];                                                                   \
         const bf16x8 m136 = as_bf16x8(make_uint4(0xC308C308u, 0xC308C308u, 0xC308C308u, 0xC308C308u));     \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                    \
-            if (XIN) {                                                                                     \
-                ah[j] = make_uint4(__float_as_uint(XA_[j].x), __float_as_uint(XA_[j].y), __float_as_uint(XA_[j].z), __float_as_uint(XA_[j].w)); \
-                al[j] = make_uint4(__float_as_uint(XB_[j].x), __float_as_uint(XB_[j].y), __float_as_uint(XB_[j].z), __float_as_uint(XB_[j].w)); \
-            } else {                                                                                       \
-                split_pair(XA_[j].x, XA_[j].z, ah[j].x, al[j].x); split_pair(XB_[j].x, XB_[j].z, ah[j].y, al[j].y); \
-                split_pair(XA_[j].y, XA_[j].w, ah[j].z, al[j].z); split_pair(XB_[j].y, XB_[j].w, ah[j].w, al[j].w); \
-            }                                                                                              \
-            f32x4 sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
-            cs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[j]), m136, sx, 0, 0, 0);          \
-        }                                                                                                  \
+        uint32_t dw[NTW][4];                                                                               \
         _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                  \
-            uint32_t dw[4] = {WV_[t].x, WV_[t].y, WV_[t].z, WV_[t].w};                                     \
+            dw[t][0] = WV_[t].x; dw[t][1] = WV_[t].y; dw[t][2] = WV_[t].z; dw[t][3] = WV_[t].w;            \
             if (!TILED) { /* 4x4 dword transpose across the four 16-lane rows */                           \
                 auto s01 = __builtin_amdgcn_permlane16_swap(WV_[t].x, WV_[t].y, false, false);             \
                 auto s23 = __builtin_amdgcn_permlane16_swap(WV_[t].z, WV_[t].w, false, false);             \
                 auto u02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);                 \
                 auto u13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);                 \
-                dw[0] = u02[0]; dw[1] = u13[0]; dw[2] = u02[1]; dw[3] = u13[1];                            \
+                dw[t][0] = u02[0]; dw[t][1] = u13[0]; dw[t][2] = u02[1]; dw[t][3] = u13[1];                \
             }                                                                                              \
-            const uint32_t sc2[2] = {SV_[t].x, SV_[t].y};                                                  \
-            _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                \
-                const uint32_t w_ = dw[j];                                                                 \
-                const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8_biased(w_));                                \
-                const float d = f16_bits_to_f32((uint16_t)((j & 1) ? (sc2[j >> 1] >> 16) : (sc2[j >> 1] & 0xFFFFu))); \
-                f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[j]), bw, cs[j], 0, 0, 0);   \
-                tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[j]), bw, tt, 0, 0, 0);            \
+        }                                                                                                  \
+        /* block j outermost: one correction accumulator (4 registers) is live at a time, not four */       \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                    \
+            uint4 ah, al;                                                                                  \
+            if (XIN) {                                                                                     \
+                ah = make_uint4(__float_as_uint(XA_[j].x), __float_as_uint(XA_[j].y), __float_as_uint(XA_[j].z), __float_as_uint(XA_[j].w)); \
+                al = make_uint4(__float_as_uint(XB_[j].x), __float_as_uint(XB_[j].y), __float_as_uint(XB_[j].z), __float_as_uint(XB_[j].w)); \
+            } else {                                                                                       \
+                split_pair(XA_[j].x, XA_[j].z, ah.x, al.x); split_pair(XB_[j].x, XB_[j].z, ah.y, al.y);    \
+                split_pair(XA_[j].y, XA_[j].w, ah.z, al.z); split_pair(XB_[j].y, XB_[j].w, ah.w, al.w);    \
+            }                                                                                              \
+            const f32x4 sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+            const f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), m136, sx, 0, 0, 0);    \
+            _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                              \
+                const bf16x8 bw = as_bf16x8(q4_dword_to_bf16x8_biased(dw[t][j]));                          \
+                const uint32_t sc2 = (j >> 1) ? SV_[t].y : SV_[t].x;                                       \
+                const float d = f16_bits_to_f32((uint16_t)((j & 1) ? (sc2 >> 16) : (sc2 & 0xFFFFu)));      \
+                f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), bw, cs, 0, 0, 0);        \
+                tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), bw, tt, 0, 0, 0);              \
                 acc[t] = __builtin_elementwise_fma((f32x4){d, d, d, d}, tt, acc[t]);                        \
             }                                                                                              \
         }                                                                                                  \
     }
-    // fused RMSNorm: the producers' partial sums of squares are fetched now (all loads in flight during the K loop) and reduced
-    // in a fixed order just before the epilogue.  thread -> (row = tid & 15, chunk = tid >> 4); up to 12 partials per thread.
+    // fused RMSNorm: the producers' partial sums of squares (thread -> (row = tid & 15, chunk = tid >> 4); up to 12 partials per thread), and the
+    // epilogue operands of the tile this wave will finish (t = wave: residual / norm weight / position -- not a dependent round trip behind the
+    // split-K barrier; PMC: the batched-decode kernels sat parked in s_waitcnt for > 50 % of their cycles).  Unconditional clamped loads (a
+    // branch around a load makes hipcc drain vmcnt).  vmcnt retires IN ORDER and these words were written by the previous launches on other XCDs
+    // (memory round trips): the straight-line path requests them BEHIND its first K step's operands, so that step does not wait for them.
     float pv[12]; const int prow = tid & 15, pch = tid >> 4, nch = blockDim.x >> 4;
-    if (PRO) {
-#pragma unroll
-        for (int u = 0; u < 12; u++) {
-            const int pi = pch + u * nch;
-            const float v = p.ssq_part[(size_t)min(pi, p.n_part - 1) * 16 + prow];
-            pv[u] = pi < p.n_part ? v : 0.f;
-        }
-    }
-    // Epilogue operands of the tile this wave will finish (t = wave): requested NOW, so the residual / norm-weight / position reads are not a
-    // dependent round trip behind the split-K barrier (PMC: the batched-decode kernels sit parked in s_waitcnt for > 50 % of their cycles).
-    // Unconditional clamped loads (a branch around a load makes hipcc drain vmcnt); used only when t == wave below.
     float pre_res[4] = {0.f, 0.f, 0.f, 0.f}; float pre_xw = 0.f; int pre_pos[4] = {0, 0, 0, 0};
-    {
-        const int n0_ = min(nbase + min(wave, NTW - 1) * 16 + li, N - 1);
-        if (EPI == EPI_RESID_XF || EPI == EPI_RESID) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) pre_res[r] = p.resid[(size_t)min(4 * g + r, M - 1) * p.resid_stride + n0_];
-        }
-        if (EPI == EPI_RESID_XF) { pre_xw = p.xf_w[n0_]; if (p.xf_w2) pre_xw *= p.xf_w2[n0_]; }
-        if (EPI == EPI_ROPE_KV) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) pre_pos[r] = p.pos[min(4 * g + r, M - 1)];
-        }
+#define VOX_PRELOADS                                                                                       \
+    {                                                                                                      \
+        if (PRO) {                                                                                         \
+            _Pragma("unroll") for (int u = 0; u < 12; u++) {                                               \
+                const int pi = pch + u * nch;                                                              \
+                const float v = p.ssq_part[(size_t)min(pi, p.n_part - 1) * 16 + prow];                     \
+                pv[u] = pi < p.n_part ? v : 0.f;                                                           \
+            }                                                                                              \
+        }                                                                                                  \
+        const int n0_ = min(nbase + min(wave, NTW - 1) * 16 + li, N - 1);                                  \
+        if (EPI == EPI_RESID_XF || EPI == EPI_RESID) {                                                     \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) pre_res[r] = p.resid[(size_t)min(4 * g + r, M - 1) * p.resid_stride + n0_]; \
+        }                                                                                                  \
+        if (EPI == EPI_RESID_XF) { pre_xw = p.xf_w[n0_]; if (p.xf_w2) pre_xw *= p.xf_w2[n0_]; }            \
+        if (EPI == EPI_ROPE_KV) {                                                                          \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) pre_pos[r] = p.pos[min(4 * g + r, M - 1)];       \
+        }                                                                                                  \
     }
+    constexpr bool STRAIGHT = STEPS > 0 && TILED && XIN;
+    if (!STRAIGHT) VOX_PRELOADS
     // wave's K steps: [q, qend) step qs -- a contiguous range when tiled (pure streaming), interleaved otherwise
     const int per = (nq + KS - 1) / KS;
     int q = TILED ? wave * per : wave;
     const int qend = TILED ? min(q + per, nq) : nq, qs = TILED ? 1 : KS;
-    if (STEPS > 0 && TILED && XIN) {
+    if (STRAIGHT) {
         // vmcnt retires loads IN ORDER: waiting for a young L2-hit load (an activation fragment) also waits for every older HBM load.  The legacy
         // loop issued the NEXT step's weights before the CURRENT step's fragments, so every step paid a full HBM round trip (timeline:
         // ~2 us per K step, waves parked > 50 %); a ring that refilled weights out of consumption order was slower still (round-2 experiments,
         // profiles/r02_batch16_ring_prefetch.txt).  Here: w(s), x(s) of steps 0..D-1 first, then after step s is multiplied, w(s+D), x(s+D) -- the
         // issue order IS the consumption order, D steps of latency cover; fully unrolled (STEPS is exact: the launcher only picks this
         // instantiation when every wave of the workgroup owns STEPS steps), so there is no control flow around any load.
-        constexpr int D = NTW >= 4 ? 2 : 3, DB = STEPS <= 0 ? 1 : (D < STEPS ? D : STEPS);      // (DB = 1 keeps the dead STEPS = 0 instantiation legal)
+        constexpr int D = NTW >= 3 ? 2 : 3, DB = STEPS <= 0 ? 1 : (D < STEPS ? D : STEPS);      // (DB = 1 keeps the dead STEPS = 0 instantiation legal)
         uint4 wr[DB][NTW]; uint2 sr[DB][NTW]; float4 xr[DB][2][4];
 #define VOX_ISSUE(B_, Q_)                                                                                  \
         { VOX_WLOAD(wr[B_], sr[B_], (Q_))                                                                  \
           _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                  \
               xr[B_][0][j] = *reinterpret_cast<const float4*>(xfh + ((Q_) * 4 + j) * 64);                  \
               xr[B_][1][j] = *reinterpret_cast<const float4*>(xfl + ((Q_) * 4 + j) * 64); } }
+        VOX_ISSUE(0, q)
+        __builtin_amdgcn_sched_barrier(0);
+        VOX_PRELOADS
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < DB; u++) VOX_ISSUE(u, q + u)
+        for (int u = 1; u < DB; u++) VOX_ISSUE(u, q + u)
 #pragma unroll
         for (int st = 0; st < STEPS; st++) {
             __builtin_amdgcn_sched_barrier(0);
             VOX_SSTEP(wr[st % DB], sr[st % DB], xr[st % DB][0], xr[st % DB][1])
+            // the norm partials are older than every load still in flight: fold them now (12 registers less in the rest of the loop)
+            if (st == 0 && PRO) s_pp[pch * 16 + prow] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7])) + ((pv[8] + pv[9]) + (pv[10] + pv[11]));
             if (st + DB < STEPS) VOX_ISSUE(st % DB, q + st + DB)          // compile-time condition
-            VOX_TL(p.tl_slot, tlw, 1);
+            if (st == 0) { VOX_TL(p.tl_slot, tlw, 1); }                   // first K step multiplied
         }
 #undef VOX_ISSUE
     } else if (q < qend) {
@@ -1224,12 +1250,13 @@ __global__ __launch_bounds__(512) void q4_skinny_kernel(const GemmParams p) {
 #undef VOX_WLOAD
 #undef VOX_XLOAD
 #undef VOX_SSTEP
+#undef VOX_PRELOADS
     VOX_TL(p.tl_slot, tlw, 2);                             // K loop done
     // split-K combine (fixed order) + epilogue: wave t finishes tile t
 #pragma unroll
     for (int t = 0; t < NTW; t++)
         *reinterpret_cast<float4*>(sred + ((size_t)(wave * NTW + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-    if (PRO) s_pp[pch * 16 + prow] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7])) + ((pv[8] + pv[9]) + (pv[10] + pv[11]));
+    if (PRO && !STRAIGHT) s_pp[pch * 16 + prow] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7])) + ((pv[8] + pv[9]) + (pv[10] + pv[11]));
     __syncthreads();
     if (PRO) {
         if (tid < 16) { float a = 0.f; for (int cch = 0; cch < nch; cch++) a += s_pp[cch * 16 + tid]; s_rstd[tid] = 1.0f / sqrtf(a / (float)p.w.K + p.norm_eps); }
@@ -1710,7 +1737,7 @@ static hipError_t skinny_launch_n(const GemmParams& p, int epi, int ks, hipStrea
 #define VOX_ST(N_, E_, P_, S_) if (NTW == N_ && epi == E_ && (int)pro == P_ && per == S_) { \
             if (E_ == EPI_RESID_XF && (!p.xf_out || !p.xf_w || !p.ssq_out)) return hipErrorInvalidValue; \
             q4_skinny_kernel<N_, E_, 1, 1, P_, S_><<<grid, dim3(64 * ks), lds, s>>>(p); return hipGetLastError(); }
-            VOX_ST(2, EPI_ROPE_KV, 1, 3) VOX_ST(1, EPI_RESID_XF, 0, 4) VOX_ST(4, EPI_SWIGLU_XF, 1, 6) VOX_ST(1, EPI_RESID_XF, 0, 9) VOX_ST(4, EPI_STORE, 1, 6)
+            VOX_ST(2, EPI_ROPE_KV, 1, 3) VOX_ST(2, EPI_SWIGLU_XF, 1, 6) VOX_ST(1, EPI_SWIGLU_XF, 1, 6) VOX_ST(1, EPI_RESID_XF, 0, 4) VOX_ST(4, EPI_SWIGLU_XF, 1, 6) VOX_ST(1, EPI_RESID_XF, 0, 9) VOX_ST(4, EPI_STORE, 1, 6)
 #undef VOX_ST
         }
         if (epi == EPI_RESID_XF) {
@@ -1757,6 +1784,13 @@ static hipError_t launch_q4_skinny(const GemmParams& p_in, int epi, hipStream_t 
     if (epi == EPI_RESID_XF) ntw = 1;       // its partial sums of squares are per workgroup = per 16-column tile
     { const int e = env_int("VOX_SKINNY_KS"); if (e == 1 || e == 2 || e == 4 || e == 8) ks = e; }
     const bool tiled = p.w.qt && p.w.st && !env_int("VOX_SKINNY_NO_TILE");
+    // three n-tiles per wave when that makes the grid a whole number of workgroups per CU and four does not (w1|w3: 2304 tiles -> 768 = 3 x 256
+    // instead of 576): only the straight-line decode-step instantiation exists for it.  VOX_SKINNY_NO_NTW3=1: measurement knob.
+    if (ntw == 4 && ks == 4 && tiled && p.xf && p.ssq_part && epi == EPI_SWIGLU_XF && nq == 24 && tiles % 3 == 0 && env_int("VOX_SKINNY_NTW3") &&
+        p.n_part >= 1 && p.n_part <= 12 * 16 && !env_int("VOX_SKINNY_NO_STEPS")) {
+        q4_skinny_kernel<3, EPI_SWIGLU_XF, 1, 1, 1, 6><<<dim3(tiles / 3), dim3(256), (size_t)4 * 3 * 64 * 4 * sizeof(float), s>>>(p);
+        return hipGetLastError();
+    }
     if (ntw == 4) return tiled ? skinny_launch_n<4, 1>(p, epi, ks, s) : skinny_launch_n<4, 0>(p, epi, ks, s);
     if (ntw == 2) return tiled ? skinny_launch_n<2, 1>(p, epi, ks, s) : skinny_launch_n<2, 0>(p, epi, ks, s);
     return tiled ? skinny_launch_n<1, 1>(p, epi, ks, s) : skinny_launch_n<1, 0>(p, epi, ks, s);
@@ -2292,18 +2326,21 @@ __device__ __forceinline__ float4 ldf4(const float* p) {
 }
 // LATE_V: the V rows of the first NPRE*32 keys are requested only after their K rows have been consumed (the K registers are reused:
 // ~half the VGPRs, one more round trip that overlaps the softmax) -- the fused GEMV + attention kernel needs 3 waves per SIMD.
-template <int HD, bool NT, bool LATE_V>
+// SPEC: the K / V rows of the first NPRE*32 keys are requested at rows 0 .. NPRE*32-1 of the cache (clamped to its spec_rows rows) WITHOUT
+// knowing pos -- the position word was written by the previous step's argmax kernel (another XCD: a memory round trip), and with the row
+// indices depending on it the kernel was pos -> K -> softmax -> V; now pos, q, K and V are four independent requests in flight together.
+// Rows past pos hold stale or uninitialised data: their scores are never stored and their V values are replaced by 0.  A sliding window
+// that has started to move (j_lo > 0) re-requests the rows (uniform branch).
+template <int HD, bool NT, bool LATE_V, bool SPEC>
 __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh, const float* __restrict__ kb, const float* __restrict__ vb, int kv_row_stride,
-                                                   int pos, int window, float* __restrict__ sc, float* __restrict__ red, float4* __restrict__ osum, int tl_slot, int tlw) {
+                                                   int pos_in, int window, float* __restrict__ sc, float* __restrict__ red, float4* __restrict__ osum, int tl_slot, int tlw,
+                                                   int spec_rows) {
     // Latency-bound (a few hundred KB of K/V per layer): the structure maximises independent loads in flight.
     // scores: 8 lanes per key (each lane HD/8 contiguous floats, float4 loads), 32 keys per pass, 2 passes unrolled;
     // P.V   : 8 key groups x HD/4 float4 columns, 4 keys unrolled.  All loads are unconditional (clamped).
     static_assert(HD == 128 || HD == 64, "head_dim");
     constexpr int PER = HD / 8;       // floats per lane in the score phase
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int len = pos + 1;
-    const int j_lo = window >= 0 ? max(0, pos - window) : 0;
-    const int n = len - j_lo;
     const float scale = 1.0f / sqrtf((float)HD);
     const int ks = tid >> 3, part = tid & 7;
     (void)tl_slot; (void)tlw;
@@ -2319,20 +2356,39 @@ __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh,
     static_assert(4 * GROUPS == 32 || HD != 128, "prefetch tiling assumes 32 keys per P.V iteration for HD = 128");
     const int grp = tid / COLS, col = tid % COLS;
     float4 kpre[NPRE][PER / 4], vpre[NPRE][4];
-#pragma unroll
-    for (int u = 0; u < NPRE; u++) {
-        const int jc = j_lo + min(32 * u + ks, n - 1);
-        const float* kr = kb + (size_t)jc * kv_row_stride + part * PER;
-#pragma unroll
-        for (int e = 0; e < PER / 4; e++) kpre[u][e] = ldf4<NT>(kr + 4 * e);
+#define VOX_KPRE(ROW_)                                                                                        \
+    _Pragma("unroll") for (int u = 0; u < NPRE; u++) {                                                        \
+        const int jc = (ROW_);                                                                                \
+        const float* kr = kb + (size_t)jc * kv_row_stride + part * PER;                                       \
+        _Pragma("unroll") for (int e = 0; e < PER / 4; e++) kpre[u][e] = ldf4<NT>(kr + 4 * e);                \
     }
-#define VOX_VPRE                                                                                              \
+#define VOX_VPRE_AT(ROW_)                                                                                     \
     _Pragma("unroll") for (int u = 0; u < NPRE; u++)                                                          \
         _Pragma("unroll") for (int w = 0; w < 4; w++) {                                                       \
-            const int ic = min(u * 4 * GROUPS + grp + w * GROUPS, n - 1);                                     \
-            vpre[u][w] = ldf4<NT>(vb + (size_t)(j_lo + ic) * kv_row_stride + col * 4);                        \
+            const int iv = u * 4 * GROUPS + grp + w * GROUPS;                                                 \
+            vpre[u][w] = ldf4<NT>(vb + (size_t)(ROW_) * kv_row_stride + col * 4);                             \
         }
-    if (!LATE_V) { VOX_VPRE }
+#define VOX_VPRE VOX_VPRE_AT(j_lo + min(iv, n - 1))
+    static_assert(!SPEC || !LATE_V, "speculative rows: K and V are both requested up front");
+    if (SPEC) {                              // pos_in is still in flight (a per-lane vector load issued by the caller): nothing here may use it
+        VOX_KPRE(min(32 * u + ks, spec_rows - 1))
+        VOX_VPRE_AT(min(iv, spec_rows - 1))
+        __builtin_amdgcn_sched_barrier(0);   // keep the wait for the position word BELOW the requests
+    }
+    const int pos = SPEC ? __builtin_amdgcn_readfirstlane(pos_in) : pos_in;      // SPEC: the first wait on the position word, all requests are out
+    const int len = pos + 1;
+    const int j_lo = window >= 0 ? max(0, pos - window) : 0;
+    const int n = len - j_lo;
+    if (SPEC) {
+        if (j_lo != 0) {                     // the window moved: rows 0.. are not the window's rows (rare; uniform)
+            VOX_KPRE(j_lo + min(32 * u + ks, n - 1))
+            VOX_VPRE
+        }
+    } else {
+        VOX_KPRE(j_lo + min(32 * u + ks, n - 1))
+        if (!LATE_V) { VOX_VPRE }
+    }
+#undef VOX_KPRE
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {
         float s = 0.f;
@@ -2347,6 +2403,7 @@ __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh,
     }
     if (LATE_V) { VOX_VPRE }
 #undef VOX_VPRE
+#undef VOX_VPRE_AT
     for (int i0 = 32 * NPRE; i0 < n; i0 += 64) {
         float s2[2];
 #pragma unroll
@@ -2392,7 +2449,8 @@ __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh,
             for (int w = 0; w < 4; w++) {
                 const int i = u * 32 + grp + w * GROUPS;
                 const float pr = i < n ? sc[min(i, n - 1)] : 0.f;
-                const float4 vv = vpre[u][w];
+                float4 vv = vpre[u][w];
+                if (SPEC && i >= n) vv = make_float4(0.f, 0.f, 0.f, 0.f);      // a row past pos: 0 * (stale bits, possibly NaN) must stay 0
                 o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w);
             }
     }
@@ -2422,7 +2480,7 @@ __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh,
     return r4;
 }
 
-template <int HD>
+template <int HD, bool SPEC>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sc = smem;                 // scores / probabilities, up to max_seq
@@ -2442,14 +2500,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
         }
     }
     const int kvh = h / (p.n_heads / p.n_kv_heads);
-    const int pos = (p.pos_ptr ? p.pos_ptr[p.pos_per_seq ? seq : 0] : 0) + p.offset;
+    // SPEC: the position word is fetched with a per-lane VECTOR load (the address carries a term the compiler cannot fold: p.spec_zero == 0):
+    // a scalar load would be waited for with lgkmcnt(0) before the first K request; a vector load is simply the oldest entry of the in-order
+    // vmcnt queue and the core waits for it only after q, K and V have been requested.
+    int pos;
+    if (SPEC) pos = (p.pos_ptr ? __builtin_nontemporal_load(p.pos_ptr + (p.pos_per_seq ? seq : 0) + (tid & p.spec_zero)) : 0) + p.offset;
+    else pos = (p.pos_ptr ? p.pos_ptr[p.pos_per_seq ? seq : 0] : 0) + p.offset;
     const float* kb = p.k + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
     const float* vb = p.v + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
     const float* qrow = p.q + (size_t)seq * p.q_seq_stride;
     float* orow = p.out + (size_t)seq * p.out_seq_stride;
     const int tlw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave; (void)tlw;
     VOX_TL(p.tl_slot, tlw, 0);
-    const float4 r4 = attn_decode_core<HD, false, false>(qrow + h * HD, kb, vb, p.kv_row_stride, pos, p.window, sc, red, osum, p.tl_slot, tlw);
+    const float4 r4 = attn_decode_core<HD, false, false, SPEC>(qrow + h * HD, kb, vb, p.kv_row_stride, pos, p.window, sc, red, osum, p.tl_slot, tlw, p.spec_rows);
     if (tid < HD / 4) {
         if (p.out_xf) xf_store4(p.out_xf, p.n_heads * HD, seq, h * HD + tid * 4, r4);       // batched decode: A-fragments of the wo GEMM
         else *reinterpret_cast<float4*>(orow + h * HD + tid * 4) = r4;
@@ -2592,14 +2655,24 @@ hipError_t launch_attn_decode(const AttnParams& p_in, int hd, int max_seq, hipSt
         kern<<<dim3(p.n_kv_heads, n_seq), dim3(256), 4 * lds, s>>>(p);
         return hipGetLastError();
     }
-    if (hd == 128) {
-        auto kern = attn_decode_kernel<128>;
+    // Speculative K / V rows (attn_decode_core SPEC) are opt-in (VOX_ATTN_SPEC=1): measured neutral for one sequence (the position word is not the
+    // long pole: the K rows themselves take ~2.5 us to arrive) and 14 % slower at 16 sequences (every workgroup then requests 160 rows whatever
+    // its length) -- profiles/r02_decode_knobs.txt.
+    if (!env_int("VOX_ATTN_SPEC")) p.spec_rows = 0;
+    if (hd == 128 && p.spec_rows > 0) {
+        auto kern = attn_decode_kernel<128, true>;
+        static bool attr_done = false;
+        hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
+        if (e != hipSuccess) return e;
+        kern<<<dim3(p.n_heads, n_seq), dim3(256), lds, s>>>(p);
+    } else if (hd == 128) {
+        auto kern = attn_decode_kernel<128, false>;
         static bool attr_done = false;
         hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
         if (e != hipSuccess) return e;
         kern<<<dim3(p.n_heads, n_seq), dim3(256), lds, s>>>(p);
     } else if (hd == 64) {
-        auto kern = attn_decode_kernel<64>;
+        auto kern = attn_decode_kernel<64, false>;
         kern<<<dim3(p.n_heads, n_seq), dim3(256), lds, s>>>(p);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
