@@ -33,18 +33,26 @@ __global__ __launch_bounds__(NT) void op_kernel(const uint4* __restrict__ w, con
     __shared__ float red[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint4 wr[NL > 0 ? NL : 1];
+    if (blockIdx.x >= NWG) {
+        // L2 prefetch workgroup p = blockIdx - NWG (same blockIdx % 8 -> same XCD as compute workgroup p of the NEXT operator): plain loads of exactly
+        // the slice that workgroup will read, PFL of its NL loads per thread; nothing is kept
+        if (!next_w) return;
+        const int pb = blockIdx.x - NWG;
+        const uint4* np = next_w + (size_t)pb * NT * NL + tid;
+        unsigned acc_ = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) if (i < pf_pages) acc_ ^= np[(size_t)i * NT].x;
+        if (acc_ == 0x12345u) xout[0] = 1.f;       // (weights are 0x35 bytes: never true)
+        return;
+    }
     const uint4* wp = w + (size_t)blockIdx.x * NT * NL + tid;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(wp + (size_t)i * NT));
-        wr[i] = make_uint4(t.x, t.y, t.z, t.w);
+        if (pf_stride16 < 0) wr[i] = wp[(size_t)i * NT];       // consumer with plain loads
+        else { const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(wp + (size_t)i * NT)); wr[i] = make_uint4(t.x, t.y, t.z, t.w); }
     }
-    unsigned pf_sink = 0;
-    if (next_w && blockIdx.x < 8 && wave == 0) {
-        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        for (int pg = lane; pg < pf_pages; pg += 64) pf_sink ^= __builtin_nontemporal_load(reinterpret_cast<const v4u*>(next_w + (size_t)pg * pf_stride16)).x;
-    }
+    const unsigned pf_sink = 0;
     float4 v;
     if (FLAG) {
         if (cnt_prev) {
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(NT) void op_kernel(const uint4* __restrict__ w, con
     }
 }
 
-struct Cfg { int mode, ops, reps; bool graph; int n_w; long pf_stride; };
+struct Cfg { int mode, ops, reps; bool graph; int n_w; int pf_loads; bool plain; };
 
 template <int NL>
 static float run(const Cfg& c, const uint4* w, size_t w_stride, int n_w, float* xa, float* xb, unsigned* cnt, unsigned* fail, const std::vector<float>& x0, std::vector<float>* result) {
@@ -100,11 +108,11 @@ static float run(const Cfg& c, const uint4* w, size_t w_stride, int n_w, float* 
             hipStream_t s = (c.mode == 1 && (i & 1)) ? s2 : s1;
             const int nw = c.n_w ? c.n_w : n_w;
             const uint4* wi = w + (size_t)(i % nw) * w_stride;
-            const uint4* wn = c.pf_stride ? w + (size_t)((i + 1) % nw) * w_stride : nullptr;
-            const int pf_pages = c.pf_stride ? (int)(((size_t)NWG * NT * NL * 16 + c.pf_stride - 1) / c.pf_stride) : 0;
+            const uint4* wn = c.pf_loads ? w + (size_t)((i + 1) % nw) * w_stride : nullptr;
+            const int grid = c.pf_loads ? 2 * NWG : NWG;
             const float* in = i & 1 ? xb : xa; float* out = i & 1 ? xa : xb;
-            if (c.mode == 0) op_kernel<NL, false><<<NWG, NT, 0, s>>>(wi, in, out, nullptr, nullptr, fail, wn, pf_pages, c.pf_stride / 16);
-            else op_kernel<NL, true><<<NWG, NT, 0, s>>>(wi, in, out, i ? cnt + (size_t)(i - 1) * 32 : nullptr, cnt + (size_t)i * 32, fail, wn, pf_pages, c.pf_stride / 16);
+            if (c.mode == 0) op_kernel<NL, false><<<grid, NT, 0, s>>>(wi, in, out, nullptr, nullptr, fail, wn, c.pf_loads, c.plain ? -1 : 0);
+            else op_kernel<NL, true><<<grid, NT, 0, s>>>(wi, in, out, i ? cnt + (size_t)(i - 1) * 32 : nullptr, cnt + (size_t)i * 32, fail, wn, c.pf_loads, c.plain ? -1 : 0);
         }
         if (c.mode == 1) { CHK(hipEventRecord(join, s2)); CHK(hipStreamWaitEvent(s1, join, 0)); }
     };
@@ -131,16 +139,17 @@ template <int NL>
 static void sweep(const uint4* w, size_t w_stride, int n_w, float* xa, float* xb, unsigned* cnt, unsigned* fail, const std::vector<float>& x0) {
     const int ops = 130, reps = 20;
     std::vector<float> r0, r1, r2, r3;
-    const float t0 = run<NL>({0, ops, reps, true, 0, 0}, w, w_stride, n_w, xa, xb, cnt, fail, x0, &r0);
-    const float t2 = run<NL>({2, ops, reps, true, 0, 0}, w, w_stride, n_w, xa, xb, cnt, fail, x0, &r2);
-    const bool same = !memcmp(r0.data(), r2.data(), XN * 4);
-    const float th = run<NL>({0, ops, reps, true, 1, 0}, w, w_stride, n_w, xa, xb, cnt, fail, x0, nullptr);
-    const float tp2 = run<NL>({0, ops, reps, true, 0, 2l << 20}, w, w_stride, n_w, xa, xb, cnt, fail, x0, nullptr);
-    const float tp64 = run<NL>({0, ops, reps, true, 0, 64l << 10}, w, w_stride, n_w, xa, xb, cnt, fail, x0, nullptr);
-    const float tp4 = run<NL>({0, ops, reps, true, 0, 4l << 10}, w, w_stride, n_w, xa, xb, cnt, fail, x0, nullptr);
+    const float t0 = run<NL>({0, ops, reps, true, 0, 0, false}, w, w_stride, n_w, xa, xb, cnt, fail, x0, &r0);
+    const float tpl = run<NL>({0, ops, reps, true, 0, 0, true}, w, w_stride, n_w, xa, xb, cnt, fail, x0, &r1);
+    const float th = run<NL>({0, ops, reps, true, 1, 0, false}, w, w_stride, n_w, xa, xb, cnt, fail, x0, nullptr);
+    const float thp = run<NL>({0, ops, reps, true, 1, 0, true}, w, w_stride, n_w, xa, xb, cnt, fail, x0, nullptr);
+    const float tf = run<NL>({0, ops, reps, true, 0, NL, false}, w, w_stride, n_w, xa, xb, cnt, fail, x0, &r2);
+    const float tfp = run<NL>({0, ops, reps, true, 0, NL, true}, w, w_stride, n_w, xa, xb, cnt, fail, x0, &r3);
+    const float thalf = run<NL>({0, ops, reps, true, 0, (NL + 1) / 2, true}, w, w_stride, n_w, xa, xb, cnt, fail, x0, nullptr);
+    const bool same = !memcmp(r0.data(), r1.data(), XN * 4) && !memcmp(r0.data(), r2.data(), XN * 4) && !memcmp(r0.data(), r3.data(), XN * 4);
     const double mb = (double)NWG * NT * NL * 16 / 1e6;
-    printf("weights %5.1f MB per op [%.2f us at 5.5 TB/s]: kernel-boundary chain, 26 matrices cycled %.2f us/op | ONE matrix (MALL / TLB warm) %.2f | cycled + next matrix touched every 2 MB %.2f, "
-           "every 64 KB %.2f, every 4 KB %.2f | flag protocol, one stream %.2f (identical: %s)\n", mb, mb / 5.5, t0, th, tp2, tp64, tp4, t2, same ? "yes" : "NO");
+    printf("weights %5.1f MB per op [%.2f us at 5.5 TB/s]: 26 matrices cycled: nt loads %.2f us/op, plain loads %.2f | ONE matrix: nt %.2f, plain %.2f | cycled + NEXT matrix prefetched into L2 "
+           "by 256 extra workgroups: consumer nt %.2f, consumer plain %.2f, first half only (plain) %.2f   (identical: %s)\n", mb, mb / 5.5, t0, tpl, th, thp, tf, tfp, thalf, same ? "yes" : "NO");
     fflush(stdout);
 }
 
