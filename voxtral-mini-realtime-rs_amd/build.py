@@ -54,7 +54,7 @@ def build_all(verbose: bool = False, force: bool = False, tag: str | None = None
 
 VARIANTS = {"timeline": ["-DVOX_TIMELINE"],      # measurement builds (tools/timeline.py)
             # GEMV ablations (tools/gemv_ablate.py; results are wrong by construction, only the timing is read)
-            "abl_noscale": ["-DVOX_ABL_NOSCALE"], "abl_nox": ["-DVOX_ABL_NOX"], "abl_wfirst": ["-DVOX_ABL_WFIRST"],
+            "abl_noscale": ["-DVOX_ABL_NOSCALE"], "abl_nox": ["-DVOX_ABL_NOX"], "abl_wfirst": ["-DVOX_ABL_WFIRST"], "abl_xfirst": ["-DVOX_ABL_XFIRST"],
             "abl_noconsume": ["-DVOX_ABL_NOCONSUME"], "abl_noreduce": ["-DVOX_ABL_NOREDUCE"],
             "abl_all": ["-DVOX_ABL_NOSCALE", "-DVOX_ABL_NOX", "-DVOX_ABL_NOCONSUME", "-DVOX_ABL_NOREDUCE"]}
 

@@ -249,7 +249,14 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
 #else
 #define VOX_SCLOAD(I_) __builtin_nontemporal_load(p.w.sc + (I_))
 #endif
-    VOX_WLOAD(qa, da, min(g, n_groups - 1))
+    // wo / w2 (no prologue, residual epilogue): no weight request before the activation vector is staged -- the vector is a cross-XCD read that
+    // otherwise queues behind the weight bursts of the workgroups that started first (w2 7.9 -> 7.6 us, wo 4.75 -> 4.65; q|k|v and w1|w3: neutral)
+#ifdef VOX_ABL_XFIRST
+    constexpr bool XFIRST = true;
+#else
+    constexpr bool XFIRST = PRO == PRO_NONE && EPI == EPI_RESID;
+#endif
+    if (!XFIRST) { VOX_WLOAD(qa, da, min(g, n_groups - 1)) }
 #if defined(VOX_ABL_WFIRST) && !defined(VOX_ABL_NOX)       /* measurement build: weights issued BEFORE the activation loads */
     VOX_XLOAD
 #endif
@@ -286,6 +293,7 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
         }
     }
     __syncthreads();
+    if (XFIRST) { VOX_WLOAD(qa, da, min(g, n_groups - 1)) }
     VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 1);
     // burn RmsNorm divides by sqrt(mean(x^2) + eps); we multiply by the reciprocal
     float ssq = 0.f;
