@@ -220,9 +220,29 @@ def test_full_fused_attention_equals_separate_launches(pkg, full, monkeypatch):
     m, _, ctx = full
     x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
     mel = np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
+    monkeypatch.setenv("VOX_NO_ATTN_WO", "1")          # both sides on the five-launch layer (attention and wo as separate launches)
     ids_s, lg_s = m.transcribe_streaming(mel, t, return_logits=True)
     monkeypatch.setenv("VOX_FUSED_ATTN", "1")
     ids_f, lg_f = m.transcribe_streaming(mel, t, return_logits=True)
     monkeypatch.delenv("VOX_FUSED_ATTN")
     assert np.array_equal(ids_f, ids_s) and np.array_equal(lg_f, lg_s)
-    assert np.array_equal(m.transcribe_streaming(mel, t), ids_s)          # graph replay
+
+
+def test_full_attention_wo_launch(pkg, full, monkeypatch):
+    """Full size, 16 s clip: the default decode layer runs attention + wo as ONE launch whose 32-way K split is combined with int64 fixed-point
+    atomics (attn_wo_kernel).  (a) order independence: two eager runs give bit-identical logits for all 108 steps although the 256 workgroups'
+    atomics interleave differently; (b) against the separate attention and wo launches (VOX_NO_ATTN_WO=1): the same ids, logits equal to
+    summation-order noise (the stated bound: 2e-4 of the largest |logit|); (c) the replayed graph emits the same ids."""
+    m, _, ctx = full
+    x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
+    mel = np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
+    ids_a, lg_a = m.transcribe_streaming(mel, t, return_logits=True)
+    ids_b, lg_b = m.transcribe_streaming(mel, t, return_logits=True)
+    assert np.array_equal(ids_a, ids_b) and np.array_equal(lg_a, lg_b)
+    monkeypatch.setenv("VOX_NO_ATTN_WO", "1")
+    ids_s, lg_s = m.transcribe_streaming(mel, t, return_logits=True)
+    monkeypatch.delenv("VOX_NO_ATTN_WO")
+    err = float(np.max(np.abs(lg_a - lg_s))); top = float(np.max(np.abs(lg_s)))
+    print(f"attention+wo launch vs separate launches: max |dlogit| {err:.3e} (largest |logit| {top:.2f}), ids equal: {np.array_equal(ids_a, ids_s)}")
+    assert np.array_equal(ids_a, ids_s) and err <= 2e-4 * top
+    assert np.array_equal(m.transcribe_streaming(mel, t), ids_a)          # graph replay

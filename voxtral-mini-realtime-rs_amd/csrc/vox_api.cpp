@@ -624,6 +624,7 @@ struct vox_model {
     unsigned* d_attn_cnt = nullptr; int attn_cnt_stride = 1024;   // [dec_layers][dec_heads][stride] arrival counters, 4 KB apart (VOX_ATTN_CNT_STRIDE, in uints) of the fused q|k|v + attention launch
     int* d_seq_len = nullptr; std::vector<int> h_seq_len;  // per-utterance encoder rows of a stacked batch
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
+    float* d_h2 = nullptr; long long* d_wo_acc = nullptr;      // fused attention + wo decode launch: residual stream after wo; per-layer fixed-point accumulators [dec_layers][dec_dim]
     int n_parts = 0, argmax_R = 8;
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0;
@@ -1009,7 +1010,7 @@ static void model_release(vox_model* m) {
     graphs_destroy(m);
     if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s})
+                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -1035,6 +1036,7 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
     auto A = [&](void** p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n); };
     A((void**)&m->ada_mul, (size_t)c.dec_layers * c.dec_dim * 4); A((void**)&m->d_pos, 64); A((void**)&m->d_h, (size_t)c.dec_dim * 4 * 4);
     A((void**)&m->d_q, (size_t)qdim * 4 * 4); A((void**)&m->d_att, (size_t)qdim * 4 * 4); A((void**)&m->d_act, (size_t)c.dec_ffn * 4 * 4);
+    A((void**)&m->d_h2, (size_t)c.dec_dim * 4); A((void**)&m->d_wo_acc, (size_t)c.dec_layers * c.dec_dim * 8);
     A((void**)&m->d_logits, (size_t)c.vocab * 4); A((void**)&m->d_part_val, (size_t)m->n_parts * 4 * 4); A((void**)&m->d_part_idx, (size_t)m->n_parts * 4 * 4);
     { const char* e_ = getenv("VOX_ATTN_CNT_STRIDE"); if (e_ && atoi(e_) >= 1 && atoi(e_) <= (1 << 16)) m->attn_cnt_stride = atoi(e_); }
     const size_t cnt_bytes = (size_t)c.dec_layers * c.dec_heads * m->attn_cnt_stride * 4;
@@ -1360,6 +1362,7 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
     const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, F = c.dec_ffn;
     const size_t lf = cache_layer_floats(m, kc);
+    bool acc_zeroed = false;
     for (int l = 0; l < c.dec_layers; l++) {
         const DecLayer& L = m->dec[l]; float* kl = kc->k + (size_t)l * lf; float* vl = kc->v + (size_t)l * lf;
         GemvParams p{};
@@ -1374,6 +1377,20 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
             HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV, q4_gemv_default_R(p.w.N, p.w.K, EPI_ROPE_KV), s));
             AttnParams ap{}; ap.q = m->d_q; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd; ap.out = m->d_att;
             ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = pos_off; ap.window = c.dec_window; ap.pos_ptr = pos_ptr; ap.M = 1; ap.spec_rows = kc->max_seq;
+            // four launches per layer: attention + wo in one (K split over the 8 KV groups), the 8 partial products are summed by w1|w3's prologue,
+            // which also writes the residual stream after wo (d_h2) for w2's epilogue
+            const int R13 = q4_gemv_default_R(L.w13.w.N, L.w13.w.K, EPI_SWIGLU);
+            if (attn_wo_supported(ap, L.wo.w, hd, kc->max_seq) && L.w13.w.fmt == WFMT_Q4_0 && L.wo.w.N == D && D % 4 == 0 && L.w13.w.K == 3072 && R13 == 2 && h != m->d_h2) {
+                if (!acc_zeroed) { HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * D * 8, s)); acc_zeroed = true; }     // one fill per step
+                long long* acc = m->d_wo_acc + (size_t)l * D;
+                HIPCHK(launch_attn_wo(ap, L.wo.w, acc, kc->max_seq, s));
+                GemvParams f{}; f.w = L.w13.w; f.x = h; f.x_stride = D; f.out = m->d_act; f.out_stride = F; f.gamma = L.ffn_norm; f.mul = L.ada_mul; f.eps = c.norm_eps;
+                f.xacc = acc; f.x_out = m->d_h2;
+                HIPCHK(launch_q4_gemv(f, 1, PRO_RMS_MUL_SUM, EPI_SWIGLU, R13, s));
+                GemvParams d{}; d.w = L.w2.w; d.x = m->d_act; d.x_stride = F; d.out = h; d.out_stride = D; d.resid = m->d_h2; d.resid_stride = D;
+                HIPCHK(launch_q4_gemv(d, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(d.w.N, d.w.K, EPI_RESID), s));
+                continue;
+            }
             HIPCHK(launch_attn_decode(ap, hd, kc->max_seq, s));
         }
         GemvParams o{}; o.w = L.wo.w; o.x = m->d_att; o.x_stride = QD; o.out = h; o.out_stride = D; o.resid = h; o.resid_stride = D;

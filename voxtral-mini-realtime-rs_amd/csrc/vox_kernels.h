@@ -28,7 +28,8 @@ enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_AR
 // its KV head's k and v rows are complete) runs that head's single-query attention in the same launch -- one launch less per decoder layer
 // (M <= 16 only) _SWIGLU_XF: SwiGLU written as XF planes; _RESID_XF: out = acc + resid as f32 AND as XF planes of out * xf_w (* xf_w2) plus
 // per-workgroup partial sums of squares -- the next RMSNorm is folded into its producer and its consumer (GemmParams::ssq_part)
-enum Pro { PRO_NONE = 0, PRO_RMS = 1, PRO_RMS_MUL = 2 };   // RMS_MUL: RMSNorm then * mul (the cached Ada scale)
+enum Pro { PRO_NONE = 0, PRO_RMS = 1, PRO_RMS_MUL = 2,      // RMS_MUL: RMSNorm then * mul (the cached Ada scale)
+           PRO_RMS_MUL_SUM = 3 };   // RMS_MUL on x + xacc * 2^-32 (the fixed-point wo product accumulated by attn_wo_kernel); the sum is also written to x_out
 
 // ---- fused Q4 GEMV (decode, rows of x <= 4): out[y][n] = epi( sum_k pro(x[y])[k] * W[n][k] )
 struct GemvParams {
@@ -38,6 +39,7 @@ struct GemvParams {
     const float* bias;                   // [N] or null
     const float* resid; int resid_stride;// EPI_RESID: out = resid + acc (+ bias)
     const float* gamma; const float* mul; float eps;   // PRO_RMS: x <- (x / rms(x)) * gamma (* mul)
+    const long long* xacc; float* x_out;   // PRO_RMS_MUL_SUM: int64 fixed-point (2^-32) accumulators xacc[k]; x_out[k] = x[k] + xacc[k] * 2^-32 (one workgroup per piece writes it)
     const int* pos_ptr; int pos_off;     // position = (pos_ptr ? *pos_ptr : 0) + pos_off
     const float* rope_cos; const float* rope_sin; int hd;   // tables [max_pos][hd/2]
     int n_q, n_k;                        // EPI_ROPE_KV: rows [0,n_q) q, [n_q,n_q+n_k) k, then v
@@ -120,6 +122,9 @@ struct AttnParams {
 };
 hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n_seq = 1);     // M > 1, causal (+window)
 hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq = 1);  // M == 1 per sequence
+// single sequence: attention + the wo linear in one launch; acc[wo.N] (int64, zero on entry) receives the product in 2^-32 fixed point (consumer: PRO_RMS_MUL_SUM)
+bool attn_wo_supported(const AttnParams& p, const Q4W& wo, int hd, int max_seq);
+hipError_t launch_attn_wo(const AttnParams& p, const Q4W& wo, long long* acc, int max_seq, hipStream_t s);
 
 // gelu(conv1d k3 s2 p1): in [Cin][L] -> out; out_token_major: out[t][co] else out[co][t]
 hipError_t launch_conv1d_gelu(const float* in, int Cin, int L, const float* w, const float* b, int Cout, float* out,

@@ -165,10 +165,11 @@ hipError_t launch_q4_dequant(Q4W w, float* out, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // fused Q4 GEMV
 // ------------------------------------------------------------------------------------------------
-template <int HD, bool NT, bool LATE_V, bool SPEC = false>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int HD, bool NT, bool LATE_V, bool SPEC = false, class Hook = NoHook>
 __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh, const float* __restrict__ kb, const float* __restrict__ vb, int kv_row_stride,
                                                    int pos, int window, float* __restrict__ sc, float* __restrict__ red, float4* __restrict__ osum, int tl_slot, int tlw,
-                                                   int spec_rows = 0);
+                                                   int spec_rows = 0, Hook after_issue = Hook());
 
 // two adjacent floats: plain stores, or ONE 8-byte write-through (sc1) store -- visible to other workgroups of the same launch once the
 // storing wave has drained it (s_waitcnt vmcnt(0)) and published a flag / counter (MI355X_MICROARCH.md, inter-workgroup visibility, form R1)
@@ -213,17 +214,20 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
     // Every global load below is UNCONDITIONAL (indices are clamped, never predicated): a "cond ? load : 0"
     // makes hipcc branch around the load and drain vmcnt(0) per element, which serialises HBM round trips.
     // (1) activation pieces (+ norm weights) first -- VMEM returns in order, so they land first ...
-    float4 xp[NX], gp[PRO != PRO_NONE ? NX : 1], mp[PRO == PRO_RMS_MUL ? NX : 1];
+    constexpr bool HAS_MUL = PRO == PRO_RMS_MUL || PRO == PRO_RMS_MUL_SUM, SUMP = PRO == PRO_RMS_MUL_SUM;
+    constexpr int NPART = 2;                                          // PRO_RMS_MUL_SUM: the 4 int64 accumulators of a piece = two 16-byte loads
+    float4 xp[NX], gp[PRO != PRO_NONE ? NX : 1], mp[HAS_MUL ? NX : 1], pp[SUMP ? NX : 1][SUMP ? NPART : 1];
 #define VOX_XLOAD                                                                                        \
     _Pragma("unroll") for (int i = 0; i < NX; i++) {                                                     \
         const int pc = min(tid + NT * i, npieces - 1);                                                   \
         xp[i] = reinterpret_cast<const float4*>(xg)[pc];                                                 \
+        if (SUMP) { pp[i][0] = reinterpret_cast<const float4*>(p.xacc)[2 * pc]; pp[i][1] = reinterpret_cast<const float4*>(p.xacc)[2 * pc + 1]; } \
         if (PRO != PRO_NONE) gp[i] = reinterpret_cast<const float4*>(p.gamma)[pc];                       \
-        if (PRO == PRO_RMS_MUL) mp[i] = reinterpret_cast<const float4*>(p.mul)[pc];                      \
+        if (HAS_MUL) mp[i] = reinterpret_cast<const float4*>(p.mul)[pc];                                 \
     }
 #if defined(VOX_ABL_NOX)          /* measurement build: no activation loads at all (results wrong) */
 #pragma unroll
-    for (int i = 0; i < NX; i++) { xp[i] = make_float4(1.f, 2.f, 3.f, 4.f); gp[PRO != PRO_NONE ? i : 0] = xp[i]; mp[PRO == PRO_RMS_MUL ? i : 0] = xp[i]; }
+    for (int i = 0; i < NX; i++) { xp[i] = make_float4(1.f, 2.f, 3.f, 4.f); gp[PRO != PRO_NONE ? i : 0] = xp[i]; mp[HAS_MUL ? i : 0] = xp[i]; if (SUMP) for (int u = 0; u < NPART; u++) pp[i][u] = make_float4(0.f, 0.f, 0.f, 0.f); }
 #elif !defined(VOX_ABL_WFIRST)
     VOX_XLOAD
 #endif
@@ -265,6 +269,18 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
     // (3) prologue on the activation vector (RMSNorm (+Ada multiplier) fused), staged to LDS.  The row scale 1/rms is a scalar, so it
     // commutes with the dot products: x * gamma is staged UNnormalised right away and every row result is multiplied by rstd in
     // the epilogue -- the sum-of-squares reduction no longer sits (with its own barrier) in front of the staging.
+    if (SUMP) {      // x = resid + acc * 2^-32 (attn_wo_kernel's fixed-point sums); piece pc of the result is written back by workgroup pc % gridDim.x
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            float4 a = xp[i];
+            const float4 lo = pp[i][0], hi = pp[i][1];
+            const auto fx = [](float l, float h_) { const long long v = (long long)(((unsigned long long)__float_as_uint(h_) << 32) | __float_as_uint(l)); return (float)((double)v * (1.0 / 4294967296.0)); };
+            a.x += fx(lo.x, lo.y); a.y += fx(lo.z, lo.w); a.z += fx(hi.x, hi.y); a.w += fx(hi.z, hi.w);
+            xp[i] = a;
+            const int pc = tid + NT * i;
+            if (pc < npieces && pc % (int)gridDim.x == (int)blockIdx.x) reinterpret_cast<float4*>(p.x_out)[pc] = a;
+        }
+    }
     if (PRO != PRO_NONE) {
         float ss = 0.f;
 #pragma unroll
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
         if (PRO != PRO_NONE) {
             const float4 gm = gp[i];
             v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
-            if (PRO == PRO_RMS_MUL) {
+            if (HAS_MUL) {
                 const float4 m = mp[i];
                 v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
             }
@@ -565,11 +581,13 @@ static hipError_t gemv_dispatch_pe(const GemvParams& p, int ny, int pro, int epi
 #define VOX_CASE(P_, E_) if (pro == P_ && epi == E_) return gemv_launch_t<P, R, P_, E_>(p, ny, s)
     VOX_CASE(PRO_NONE, EPI_STORE); VOX_CASE(PRO_NONE, EPI_RESID); VOX_CASE(PRO_NONE, EPI_GELU);
     VOX_CASE(PRO_RMS, EPI_STORE); VOX_CASE(PRO_RMS, EPI_ARGMAX);
-    if (pro == PRO_RMS_MUL && p.mul == nullptr) return hipErrorInvalidValue;
+    if ((pro == PRO_RMS_MUL || pro == PRO_RMS_MUL_SUM) && p.mul == nullptr) return hipErrorInvalidValue;
+    if (pro == PRO_RMS_MUL_SUM && (!p.xacc || !p.x_out || ny != 1)) return hipErrorInvalidValue;
     if (R >= 2) {
         constexpr int R2 = R >= 2 ? R : 2;
         if (pro == PRO_RMS && epi == EPI_SWIGLU) return gemv_launch_t<P, R2, PRO_RMS, EPI_SWIGLU>(p, ny, s);
         if (pro == PRO_RMS_MUL && epi == EPI_SWIGLU) return gemv_launch_t<P, R2, PRO_RMS_MUL, EPI_SWIGLU>(p, ny, s);
+        if (pro == PRO_RMS_MUL_SUM && epi == EPI_SWIGLU && P == 3 && R == 2) return gemv_launch_t<3, 2, PRO_RMS_MUL_SUM, EPI_SWIGLU>(p, ny, s);
         if (pro == PRO_NONE && epi == EPI_SWIGLU) return gemv_launch_t<P, R2, PRO_NONE, EPI_SWIGLU>(p, ny, s);
         if (pro == PRO_RMS && epi == EPI_ROPE_KV) return gemv_launch_t<P, R2, PRO_RMS, EPI_ROPE_KV>(p, ny, s);
         if (pro == PRO_RMS && epi == EPI_ROPE_KV_ATTN && R == 2) return gemv_launch_w<P, 2, PRO_RMS, EPI_ROPE_KV_ATTN, 4>(p, ny, s);
@@ -754,7 +772,8 @@ static hipError_t dense_launch_t(const GemvParams& p, int ny, hipStream_t s) {
 }
 static hipError_t launch_dense_gemv(const GemvParams& p, int ny, int pro, int epi, hipStream_t s) {
     if (p.w.K % 32 || p.w.K > 10240 || p.w.N % 2) return hipErrorInvalidValue;
-    if (pro == PRO_RMS_MUL && p.mul == nullptr) return hipErrorInvalidValue;
+    if ((pro == PRO_RMS_MUL || pro == PRO_RMS_MUL_SUM) && p.mul == nullptr) return hipErrorInvalidValue;
+    if (pro == PRO_RMS_MUL_SUM) return hipErrorInvalidValue;      // Q4 decode step only
 #define VOX_CASE(P_, E_) if (pro == P_ && epi == E_) return dense_launch_t<P_, E_>(p, ny, s)
     VOX_CASE(PRO_NONE, EPI_STORE); VOX_CASE(PRO_NONE, EPI_RESID); VOX_CASE(PRO_NONE, EPI_GELU); VOX_CASE(PRO_NONE, EPI_SWIGLU);
     VOX_CASE(PRO_RMS, EPI_STORE); VOX_CASE(PRO_RMS, EPI_ARGMAX); VOX_CASE(PRO_RMS, EPI_SWIGLU); VOX_CASE(PRO_RMS_MUL, EPI_SWIGLU);
@@ -2339,10 +2358,12 @@ __device__ __forceinline__ float4 ldf4(const float* p) {
 // indices depending on it the kernel was pos -> K -> softmax -> V; now pos, q, K and V are four independent requests in flight together.
 // Rows past pos hold stale or uninitialised data: their scores are never stored and their V values are replaced by 0.  A sliding window
 // that has started to move (j_lo > 0) re-requests the rows (uniform branch).
-template <int HD, bool NT, bool LATE_V, bool SPEC>
+// after_issue(): called once the q / K (/ V) requests of the first NPRE*32 keys are out -- a caller's own loads placed there are YOUNGER in the
+// in-order vmcnt queue, so the waits for K and V do not wait for them (attn_wo_kernel: its block of wo).
+template <int HD, bool NT, bool LATE_V, bool SPEC, class Hook>
 __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh, const float* __restrict__ kb, const float* __restrict__ vb, int kv_row_stride,
                                                    int pos_in, int window, float* __restrict__ sc, float* __restrict__ red, float4* __restrict__ osum, int tl_slot, int tlw,
-                                                   int spec_rows) {
+                                                   int spec_rows, Hook after_issue) {
     // Latency-bound (a few hundred KB of K/V per layer): the structure maximises independent loads in flight.
     // scores: 8 lanes per key (each lane HD/8 contiguous floats, float4 loads), 32 keys per pass, 2 passes unrolled;
     // P.V   : 8 key groups x HD/4 float4 columns, 4 keys unrolled.  All loads are unconditional (clamped).
@@ -2396,6 +2417,9 @@ __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh,
         VOX_KPRE(j_lo + min(32 * u + ks, n - 1))
         if (!LATE_V) { VOX_VPRE }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    after_issue();
+    __builtin_amdgcn_sched_barrier(0);
 #undef VOX_KPRE
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {
@@ -2652,6 +2676,79 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const AttnParams p
         }
     }
 }
+// ---- single-stream decode: attention + wo in ONE launch (gguf/model.rs:125-174 + the wo linear of model.rs:230-238), no cross-workgroup wait.
+// Workgroup (h, slice): runs the attention of query head h (redundantly in each of the 8 slices: K / V rows are L2 hits after the first; the
+// 4 heads of a KV group and their slices share blockIdx % 8, i.e. one XCD) and multiplies the head's 128 outputs with ITS 384 x 128 block of
+// wo -- requested at entry, so the weights stream from HBM while the attention's dependent chain (q, K -> softmax -> V) runs.  The 32-way K
+// split of wo is combined with ORDER-INDEPENDENT fixed-point atomics: every partial product is rounded to a multiple of 2^-32 and added as an
+// int64 (agent scope) into acc[row] -- integer addition commutes, so the result is bit-identical however the 32 workgroups interleave
+// (tools/micro/atomic_reduce.hip: +1.1 us for the 98 k atomics of a launch).  The consumer (q4_gemv_kernel PRO_RMS_MUL_SUM) converts back,
+// adds the residual and writes the new residual stream.  Replaces two launches (attention: 32 workgroups with HBM idle; wo GEMV: bound by the
+// cross-XCD read of the attention output) -- profiles/r02_attn_wo.txt.
+template <int NI>      // NI passes of 64 rows per workgroup (6: 8 row slices per head, 256 workgroups)
+__global__ __launch_bounds__(256) void attn_wo_kernel(const AttnParams p, const Q4W wo, long long* __restrict__ acc) {
+    constexpr int HD = 128, CH = HD / 32, RPI = 256 / CH;             // 4 chunks per head; 64 rows per pass
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // scores [max_seq]
+    __shared__ float red[8];
+    __shared__ float4 osum[256];
+    __shared__ __attribute__((aligned(16))) float4 a_s[HD / 4];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int G = p.n_heads / p.n_kv_heads, n_slices = gridDim.x / p.n_heads;
+    const int kvh = blockIdx.x % p.n_kv_heads, j_ = blockIdx.x / p.n_kv_heads, h = kvh * G + j_ / n_slices, slice = j_ % n_slices;
+    const int tlw = blockIdx.x * 4 + wave; (void)tlw;
+    VOX_TL(p.tl_slot, tlw, 0);
+    // (1) this workgroup's block of wo: thread -> chunk c of rows r0 + 64 i
+    const int c = tid & (CH - 1), r0 = slice * (RPI * NI) + (tid >> 2);
+    uint4 wq[NI]; uint16_t wd[NI];
+    auto load_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const size_t idx = (size_t)(r0 + RPI * i) * wo.nb + h * CH + c;
+            wq[i] = ld_nt_u4(wo.qs + idx); wd[i] = __builtin_nontemporal_load(wo.sc + idx);
+        }
+    };
+    // (2) attention of head h; the weight requests go out right behind its q / K / V requests
+    const int pos = (p.pos_ptr ? p.pos_ptr[0] : 0) + p.offset;
+    const float4 r4 = attn_decode_core<HD, false, false, false>(p.q + h * HD, p.k + (size_t)kvh * p.kv_head_stride, p.v + (size_t)kvh * p.kv_head_stride,
+                                                                 p.kv_row_stride, pos, p.window, smem, red, osum, p.tl_slot, tlw, 0, load_w);
+    if (tid < HD / 4) a_s[tid] = r4;
+    __syncthreads();
+    VOX_TL(p.tl_slot, tlw, 2);
+    // (3) GEMV block: the lane's chunk column is the same for its NI rows
+    float xv[32]; float sx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float4 v = a_s[c * 8 + j];
+        xv[4 * j] = v.x; xv[4 * j + 1] = v.y; xv[4 * j + 2] = v.z; xv[4 * j + 3] = v.w;
+        sx += (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        float val = f16_bits_to_f32(wd[i]) * (q4_chunk_dot(wq[i], xv) - 8.0f * sx);
+        val += __shfl_xor(val, 1, 64); val += __shfl_xor(val, 2, 64);
+        if (c == 0) __hip_atomic_fetch_add(acc + r0 + RPI * i, __double2ll_rn((double)val * 4294967296.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    VOX_TL(p.tl_slot, tlw, 3);
+}
+bool attn_wo_supported(const AttnParams& p, const Q4W& wo, int hd, int max_seq) {
+    const int G = p.n_kv_heads > 0 ? p.n_heads / p.n_kv_heads : 0;
+    if (wo.fmt != WFMT_Q4_0 || hd != 128 || G < 1 || p.n_heads != G * p.n_kv_heads || wo.K != p.n_heads * hd || p.kv_row_stride != hd || p.kv_head_stride != max_seq * hd) return false;
+    if (256 % p.n_heads) return false;
+    const int n_slices = 256 / p.n_heads;                     // 256 workgroups: one per CU
+    return wo.N % (n_slices * 64) == 0 && wo.N / (n_slices * 64) == 6 && !env_int("VOX_NO_ATTN_WO");
+}
+hipError_t launch_attn_wo(const AttnParams& p_in, const Q4W& wo, long long* acc, int max_seq, hipStream_t s) {
+    if (!attn_wo_supported(p_in, wo, 128, max_seq) || !acc) return hipErrorInvalidValue;
+    AttnParams p = p_in; p.tl_slot = tl_take_slot(1, 0, p.n_heads, 128);
+    const size_t lds = (size_t)max_seq * sizeof(float);
+    static bool attr_done = false;
+    auto kern = attn_wo_kernel<6>;       // 8 row slices per head = 256 workgroups (4 slices: 1.05 ms per step, 16: 0.975, 8: 0.94 -- profiles/r02_attn_wo.txt)
+    hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
+    if (e != hipSuccess) return e;
+    kern<<<dim3(256), dim3(256), lds, s>>>(p, wo, acc);
+    return hipGetLastError();
+}
+
 hipError_t launch_attn_decode(const AttnParams& p_in, int hd, int max_seq, hipStream_t s, int n_seq) {
     AttnParams p = p_in; p.tl_slot = tl_take_slot(1, 0, p.n_heads, hd);
     const size_t lds = (size_t)max_seq * sizeof(float);
