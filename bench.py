@@ -290,6 +290,8 @@ def main():
                            "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["avg_us"],
                            "all_decode_gemvs": per,
+                           "all_decode_gemvs_note": "stand-alone launches, 26 layers cycled; in the decode step wo's bytes are streamed by attn_wo_kernel "
+                                                    "(attention + wo in one launch), the other four run exactly as timed here",
                            "decode_step_gemv_GBps": round(per_step_bytes / per_step_us / 1e3, 1),
                            "decode_step_algorithmic_bytes": int(per_step_bytes),
                            "decode_step_measured_ms": round(stage_ms["decode_ms"] / max(n_ids, 1), 4),

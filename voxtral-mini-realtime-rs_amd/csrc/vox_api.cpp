@@ -1358,6 +1358,13 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
 
 // ---- one decode step on device (Appendix B of SURVEY.md): 5 fused launches per layer.
 // h [D] in place. position = (pos_ptr ? *pos_ptr : 0) + pos_off.
+// single-stream decode layer as four launches (attention + wo in one: attn_wo_kernel; the sum lands in w1|w3's prologue)?
+static bool decode_layer_fuses_attn_wo(const vox_model* m, const DecLayer& L, const AttnParams& ap, const vox_cache* kc) {
+    const vox_model_cfg& c = m->cfg; const int D = c.dec_dim;
+    return attn_wo_supported(ap, L.wo.w, c.dec_head_dim, kc->max_seq) && L.w13.w.fmt == WFMT_Q4_0 && L.wo.w.N == D && D % 4 == 0 && L.w13.w.K == 3072 &&
+           q4_gemv_default_R(L.w13.w.N, L.w13.w.K, EPI_SWIGLU) == 2;
+}
+
 static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int* pos_ptr, int pos_off) {
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
     const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, F = c.dec_ffn;
@@ -1380,7 +1387,7 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
             // four launches per layer: attention + wo in one (K split over the 8 KV groups), the 8 partial products are summed by w1|w3's prologue,
             // which also writes the residual stream after wo (d_h2) for w2's epilogue
             const int R13 = q4_gemv_default_R(L.w13.w.N, L.w13.w.K, EPI_SWIGLU);
-            if (attn_wo_supported(ap, L.wo.w, hd, kc->max_seq) && L.w13.w.fmt == WFMT_Q4_0 && L.wo.w.N == D && D % 4 == 0 && L.w13.w.K == 3072 && R13 == 2 && h != m->d_h2) {
+            if (decode_layer_fuses_attn_wo(m, L, ap, kc) && h != m->d_h2) {
                 if (!acc_zeroed) { HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * D * 8, s)); acc_zeroed = true; }     // one fill per step
                 long long* acc = m->d_wo_acc + (size_t)l * D;
                 HIPCHK(launch_attn_wo(ap, L.wo.w, acc, kc->max_seq, s));
@@ -1831,6 +1838,9 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
     if (!m->t_embed_set) { std::vector<float> te(c.dec_dim); vox_time_embedding(6.0f, c.dec_dim, te.data()); VOXCHK(vox_model_set_t_embed(m, te.data())); }
     const int D = c.dec_dim, QD = c.dec_heads * c.dec_head_dim, KD = c.dec_kv_heads * c.dec_head_dim, F = c.dec_ffn, hd = c.dec_head_dim;
     const size_t lf = cache_layer_floats(m, m->cache);
+    bool fused = false;
+    { AttnParams ap{}; ap.n_heads = c.dec_heads; ap.n_kv_heads = c.dec_kv_heads; ap.kv_row_stride = hd; ap.kv_head_stride = m->cache->max_seq * hd;
+      fused = decode_layer_fuses_attn_wo(m, m->dec[0], ap, m->cache); if (fused) HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * D * 8, s)); }
     auto launch = [&](int l) -> int32_t {
         if (warm) l = 0;
         const DecLayer& L = m->dec[l % c.dec_layers]; GemvParams p{};
@@ -1842,7 +1852,8 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
         case 1: p.w = L.wo.w; p.x = m->d_att; p.x_stride = QD; p.out = m->d_h; p.out_stride = D; p.resid = m->d_h; p.resid_stride = D;
                 HIPCHK(launch_q4_gemv(p, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(p.w.N, p.w.K, EPI_RESID), s)); break;
         case 2: p.w = L.w13.w; p.x = m->d_h; p.x_stride = D; p.out = m->d_act; p.out_stride = F; p.gamma = L.ffn_norm; p.mul = L.ada_mul; p.eps = c.norm_eps;
-                HIPCHK(launch_q4_gemv(p, 1, PRO_RMS_MUL, EPI_SWIGLU, q4_gemv_default_R(p.w.N, p.w.K, EPI_SWIGLU), s)); break;
+                if (fused) { p.xacc = m->d_wo_acc + (size_t)(l % c.dec_layers) * D; p.x_out = m->d_h2; }      // as launched by the decode step (accumulators: zeros)
+                HIPCHK(launch_q4_gemv(p, 1, fused ? PRO_RMS_MUL_SUM : PRO_RMS_MUL, EPI_SWIGLU, q4_gemv_default_R(p.w.N, p.w.K, EPI_SWIGLU), s)); break;
         case 3: p.w = L.w2.w; p.x = m->d_act; p.x_stride = F; p.out = m->d_h; p.out_stride = D; p.resid = m->d_h; p.resid_stride = D;
                 HIPCHK(launch_q4_gemv(p, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(p.w.N, p.w.K, EPI_RESID), s)); break;
         default: VOXCHK(lm_head_argmax_dev(m, m->d_h, nullptr)); break;
@@ -1853,7 +1864,7 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
     *bytes_per_launch = w->fmt == WFMT_BF16 ? (double)w->N * w->K * 2.0 : w->fmt == WFMT_F32 ? (double)w->N * w->K * 4.0 : (double)w->N * w->nb * 18.0;   // algorithmic bytes: Q4_0 blocks (18 B / 32 weights) or bf16
     if (kernel_name) {
         const int epi = which == 0 ? EPI_ROPE_KV : which == 2 ? EPI_SWIGLU : which == 4 ? EPI_ARGMAX : EPI_RESID;
-        const int pro = which == 2 ? PRO_RMS_MUL : (which == 0 || which == 4) ? PRO_RMS : PRO_NONE;
+        const int pro = which == 2 ? (fused ? PRO_RMS_MUL_SUM : PRO_RMS_MUL) : (which == 0 || which == 4) ? PRO_RMS : PRO_NONE;
         if (w->fmt == WFMT_BF16 || w->fmt == WFMT_F32) { static thread_local char nb_[64]; snprintf(nb_, sizeof nb_, "dense_gemv_kernel<PRO=%d,EPI=%d>", pro, epi); *kernel_name = nb_; }
         else *kernel_name = q4_gemv_kernel_name(w->K, pro, epi, which == 4 ? m->argmax_R : q4_gemv_default_R(w->N, w->K, epi));
     }

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
         for (int i = 0; i < NX; i++) {
             float4 a = xp[i];
             const float4 lo = pp[i][0], hi = pp[i][1];
-            const auto fx = [](float l, float h_) { const long long v = (long long)(((unsigned long long)__float_as_uint(h_) << 32) | __float_as_uint(l)); return (float)((double)v * (1.0 / 4294967296.0)); };
+            // int64 with 32 fractional bits -> f32: signed integer part (exact) + unsigned fraction * 2^-32 (one f32 rounding each, like any f32 add)
+            const auto fx = [](float l, float h_) { return (float)(int)__float_as_uint(h_) + (float)__float_as_uint(l) * (1.0f / 4294967296.0f); };
             a.x += fx(lo.x, lo.y); a.y += fx(lo.z, lo.w); a.z += fx(hi.x, hi.y); a.w += fx(hi.z, hi.w);
             xp[i] = a;
             const int pc = tid + NT * i;
