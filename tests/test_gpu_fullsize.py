@@ -246,3 +246,21 @@ def test_full_attention_wo_launch(pkg, full, monkeypatch):
     print(f"attention+wo launch vs separate launches: max |dlogit| {err:.3e} (largest |logit| {top:.2f}), ids equal: {np.array_equal(ids_a, ids_s)}")
     assert np.array_equal(ids_a, ids_s) and err <= 2e-4 * top
     assert np.array_equal(m.transcribe_streaming(mel, t), ids_a)          # graph replay
+
+
+def test_full_attention_wo_launch_long_context(pkg, full, monkeypatch):
+    """30 s clip (234 decoder positions): the attention + wo launch beyond the 160 keys it requests up front (the looped K / V passes of
+    attn_decode_core) against the separate launches -- same ids, logits equal to summation-order noise."""
+    m, _, ctx = full
+    x = pkg.synth.synth_audio(30.0, seed=4321); t = pkg.TimeEmbedding(3072).embed(6.0)
+    mel = np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
+    ids_a, lg_a = m.transcribe_streaming(mel, t, return_logits=True)
+    monkeypatch.setenv("VOX_NO_ATTN_WO", "1")
+    ids_s, lg_s = m.transcribe_streaming(mel, t, return_logits=True)
+    monkeypatch.delenv("VOX_NO_ATTN_WO")
+    assert len(ids_a) > 180                     # 38 + 196 positions > the 160 keys requested up front
+    err = float(np.max(np.abs(lg_a - lg_s))); top = float(np.max(np.abs(lg_s)))
+    srt = np.sort(lg_s, axis=1); safe = (srt[:, -1] - srt[:, -2]) > 10 * TOL * max(1.0, top)
+    stop = len(safe) if safe.all() else int(np.argmin(safe))
+    print(f"30 s clip, {len(ids_a)} ids: attention+wo launch vs separate launches max |dlogit| {err:.3e} (largest |logit| {top:.2f}); ids equal up to step {stop}")
+    assert (ids_a[:stop] == ids_s[:stop]).all() and (stop < len(ids_a) or err <= 2e-4 * top)
