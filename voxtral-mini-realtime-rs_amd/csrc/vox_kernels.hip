@@ -1868,6 +1868,12 @@ static hipError_t gemm_launch_f(const GemmParams& p, int epi, hipStream_t s) {
         }
         return hipGetLastError();
     }
+    // 32-row tiles on the tile-ordered copy (no cross-lane transpose of the weight words): the single-clip encoder's wo / w2 (N = 1280, 800 rows)
+    // 8.79 -> 8.33 ms per clip with two n-tiles per wave at 250 workgroups (48-row tiles: 9.2-9.4 ms).  VOX_GEMM_NO_TB=1: the row-plane form.
+    if (FMT == WFMT_Q4_0 && p.w.qt && p.w.st && mt == 2 && !env_int("VOX_GEMM_NO_TB")) {
+        if (!env_int("VOX_GEMM_NT") && wgs(2, 2) >= 128) nt = 2;      // (threshold 64 / 128 / 200: 8.32 / 8.30 / 8.49 ms)
+        return nt == 2 ? gemm_launch_mn<2, 2, WFMT_Q4_0, 1>(p, epi, s) : gemm_launch_mn<2, 1, WFMT_Q4_0, 1>(p, epi, s);
+    }
 #define VOX_MN(M_, N_) if (mt == M_ && nt == N_) return gemm_launch_mn<M_, N_, FMT>(p, epi, s)
     VOX_MN(1, 1); VOX_MN(1, 2); VOX_MN(2, 1); VOX_MN(2, 2);
 #undef VOX_MN
