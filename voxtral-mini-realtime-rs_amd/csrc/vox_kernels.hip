@@ -12,7 +12,12 @@
 //      MFMA-bound.  v_mfma_f32_16x16x32_bf16: one MFMA K-step == one Q4_0 block, so the integer
 //      weights (q-8, exact in bf16) go through the matrix core and the f16 block scale is applied
 //      to the 16x16 result in f32; activations are split hi+lo bf16 (2 MFMAs) for f32-class accuracy.
-//  * attention, conv, mel, norm, rope: wave64 shuffle / LDS kernels, f32.
+//  * q4_skinny_kernel / q4_skinny_mt_kernel / q4_gemm_big_kernel : <= 16 rows (batched decode step, XF fragment planes in, straight-line
+//      in-order load pipeline), 17..48 rows (the 38-token prefill), large M (stacked encoder) -- all on the tile-ordered weight copy.
+//  * attn_wo_kernel  : single-stream decode, attention + wo in one launch; the per-head partial products are combined with int64
+//      fixed-point atomics (order-independent => deterministic) and summed into the residual by the next GEMV's prologue.
+//  * attention, conv, mel, norm, rope, resampler: wave64 shuffle / LDS kernels, f32.
+// vmcnt retires loads IN ORDER: every pipeline here requests its operands in consumption order.
 #include "vox_kernels.h"
 
 #include <hip/hip_fp16.h>
