@@ -17,7 +17,7 @@ rank 0 parses the GGUF and the packed weight arena reaches the other ranks throu
 Rank 0 prints ONE JSON line.  Extras in the same line (never `value`):
   `batch`       BASELINE configs[3]: 16 clips through vox_transcribe_batch (N = 1)
   `f32`         BASELINE configs[1]: the same clip through the f32 SafeTensors path (dense bf16 weights, N = 1)
-  `fleurs_like` BASELINE configs[4] stand-in: 647 clips with FLEURS-like durations sharded LPT over the ranks, 16-clip batches per rank
+  `fleurs_like` BASELINE configs[4] stand-in: 647 clips with FLEURS-like durations sharded LPT over the ranks, 64-clip length-bucketed batches per rank (--fleurs-batch)
                 (replaces bin/transcribe.rs:112-126's serial loop); aggregate RTF, tok/s, LPT imbalance (every N)
   `roofline`    dominant decode kernel, HIP events on the library stream + committed PMC traffic;  `cpu_baseline`  CPU oracle, bounded sample
 """
@@ -107,7 +107,7 @@ def f32_extra(pkg, ctx, t_embed, seconds, reps=3):
 
 def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch):
     """BASELINE configs[4] stand-in (no FLEURS offline): `n_clips` synthetic clips with FLEURS-like durations, LPT-sharded over the ranks
-    (shard.run_sharded), each rank running 16-clip length-bucketed batches through vox_transcribe_batch; results gathered in input order.
+    (shard.run_sharded), each rank running `batch`-clip length-bucketed batches (64: four concurrent 16-row groups) through vox_transcribe_batch; results gathered in input order.
     Wall time = barrier .. barrier, max over ranks.  Replaces the reference's serial per-file loop (bin/transcribe.rs:112-126)."""
     import importlib
     shard = importlib.import_module(pkg.__name__ + ".shard")
@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="also report BASELINE configs[3] (B utterances through vox_transcribe_batch) at N=1; 0 = skip")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 SafeTensors extra (BASELINE configs[1], N = 1)")
     ap.add_argument("--fleurs-clips", type=int, default=647, help="clips of the FLEURS-like sharded extra (BASELINE configs[4] stand-in); 0 = skip")
+    ap.add_argument("--fleurs-batch", type=int, default=64, help="clips per vox_transcribe_batch call of the FLEURS-like extra (<= 64)")
     ap.add_argument("--gemv-iters", type=int, default=260)
     args = ap.parse_args()
 
@@ -241,7 +242,7 @@ def main():
     fleurs = None
     if args.fleurs_clips > 0:
         try:
-            fleurs = fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, args.fleurs_clips, 16)
+            fleurs = fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, args.fleurs_clips, max(1, min(64, args.fleurs_batch)))
         except Exception as e:     # an extra never costs the headline line
             fleurs = {"error": str(e)} if rank == 0 else None
 
