@@ -1042,7 +1042,7 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
     const size_t cnt_bytes = (size_t)c.dec_layers * c.dec_heads * m->attn_cnt_stride * 4;
     A((void**)&m->d_attn_cnt, cnt_bytes);
     if (e != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of decode buffers failed: %s", hipGetErrorString(e)); }
-    if (hipMemset(m->d_attn_cnt, 0, cnt_bytes) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMemset failed"); }
+    if (hipMemset(m->d_attn_cnt, 0, cnt_bytes) != hipSuccess || hipMemset(m->d_wo_acc, 0, (size_t)c.dec_layers * c.dec_dim * 8) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMemset failed"); }
     for (int i = 0; i < c.dec_layers; i++) m->dec[i].ada_mul = m->ada_mul + (size_t)i * c.dec_dim;
     *out = m; return VOX_OK;
 }
@@ -1369,7 +1369,6 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
     const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, F = c.dec_ffn;
     const size_t lf = cache_layer_floats(m, kc);
-    bool acc_zeroed = false;
     for (int l = 0; l < c.dec_layers; l++) {
         const DecLayer& L = m->dec[l]; float* kl = kc->k + (size_t)l * lf; float* vl = kc->v + (size_t)l * lf;
         GemvParams p{};
@@ -1388,13 +1387,13 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
             // which also writes the residual stream after wo (d_h2) for w2's epilogue
             const int R13 = q4_gemv_default_R(L.w13.w.N, L.w13.w.K, EPI_SWIGLU);
             if (decode_layer_fuses_attn_wo(m, L, ap, kc) && h != m->d_h2) {
-                if (!acc_zeroed) { HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * D * 8, s)); acc_zeroed = true; }     // one fill per step
-                long long* acc = m->d_wo_acc + (size_t)l * D;
+                long long* acc = m->d_wo_acc + (size_t)l * D;      // zero on entry: cleared at allocation, and by w2 below after every use
                 HIPCHK(launch_attn_wo(ap, L.wo.w, acc, kc->max_seq, s));
                 GemvParams f{}; f.w = L.w13.w; f.x = h; f.x_stride = D; f.out = m->d_act; f.out_stride = F; f.gamma = L.ffn_norm; f.mul = L.ada_mul; f.eps = c.norm_eps;
                 f.xacc = acc; f.x_out = m->d_h2;
                 HIPCHK(launch_q4_gemv(f, 1, PRO_RMS_MUL_SUM, EPI_SWIGLU, R13, s));
                 GemvParams d{}; d.w = L.w2.w; d.x = m->d_act; d.x_stride = F; d.out = h; d.out_stride = D; d.resid = m->d_h2; d.resid_stride = D;
+                d.zero_acc = acc; d.zero_n = D;                  // w1|w3 has consumed the accumulators: clear them for the next step (no fill node in the graph)
                 HIPCHK(launch_q4_gemv(d, 1, PRO_NONE, EPI_RESID, q4_gemv_default_R(d.w.N, d.w.K, EPI_RESID), s));
                 continue;
             }
@@ -1484,6 +1483,9 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, m->n_parts, m->d_tokens, m->d_pos, 0, 0, s));   // tokens[38]
     const int steps = std::max(S - PREFIX_LEN - 1, 0);                            // pos = 39 .. S-1 (model.rs:938)
     stage.begin("decode");
+    // attn_wo accumulators: every step leaves them cleared (w2 does it); once per utterance they are cleared outright, so a call that failed
+    // half-way through a layer cannot leak into the next one
+    if (steps > 0 && m->d_wo_acc) HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * c.dec_dim * 8, s));
     if (steps > 0) HIPCHK(launch_embed(m->tok.w, m->d_tokens, 1, m->d_audio, c.dec_dim, m->d_pos, 0, 0, m->d_h, s));   // input of the first decode step (audio[38] exists iff S >= 39)
     if (logits_host) {
         for (int i = 0; i < steps; i++) VOXCHK(decode_step_enqueue(m, d_logits_all + (size_t)(i + 1) * c.vocab));
@@ -1805,7 +1807,7 @@ extern "C" int32_t vox_forward_hidden_with_cache(vox_model* m, const float* x, i
     VOXCHK(vox_model_set_t_embed(m, t_embed));
     DevBuf dx, dy; HIPCHK(dx.alloc((size_t)M * c.dec_dim * 4)); HIPCHK(dy.alloc((size_t)M * c.dec_dim * 4));
     HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)M * c.dec_dim * 4, hipMemcpyHostToDevice, s));
-    if (M == 1) VOXCHK(decoder_step_dev(m, dx.as<float>(), kc, nullptr, kc->len));
+    if (M == 1) { if (m->d_wo_acc) HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * c.dec_dim * 8, s)); VOXCHK(decoder_step_dev(m, dx.as<float>(), kc, nullptr, kc->len)); }
     else VOXCHK(decoder_prefill_dev(m, dx.as<float>(), M, kc, kc->len));
     kc->len += M;
     HIPCHK(launch_rms_norm(dx.as<float>(), c.dec_dim, M, c.dec_dim, m->dec_norm, nullptr, c.norm_eps, dy.as<float>(), c.dec_dim, s));   // model.rs:676

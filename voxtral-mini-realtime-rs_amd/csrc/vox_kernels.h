@@ -39,6 +39,7 @@ struct GemvParams {
     const float* bias;                   // [N] or null
     const float* resid; int resid_stride;// EPI_RESID: out = resid + acc (+ bias)
     const float* gamma; const float* mul; float eps;   // PRO_RMS: x <- (x / rms(x)) * gamma (* mul)
+    long long* zero_acc; int zero_n;     // any launch: workgroup b clears its share of zero_acc[0, zero_n) (the layer's attn_wo accumulators, already consumed by w1|w3)
     const long long* xacc; float* x_out;   // PRO_RMS_MUL_SUM: int64 fixed-point (2^-32) accumulators xacc[k]; x_out[k] = x[k] + xacc[k] * 2^-32 (one workgroup per piece writes it)
     const int* pos_ptr; int pos_off;     // position = (pos_ptr ? *pos_ptr : 0) + pos_off
     const float* rope_cos; const float* rope_sin; int hd;   // tables [max_pos][hd/2]

@@ -215,6 +215,10 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
     const int bx = EPI == EPI_ROPE_KV_ATTN ? (int)((blockIdx.x + (unsigned)(p.n_q / (NWV * R))) % gridDim.x) : (int)blockIdx.x;
     int g = bx * NWV + wave;
     VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 0);
+    if (p.zero_acc) {      // uniform; a handful of stores per workgroup
+        const int per = (p.zero_n + (int)gridDim.x - 1) / (int)gridDim.x, i = blockIdx.x * per + tid;
+        if (tid < per && i < p.zero_n) p.zero_acc[i] = 0;
+    }
 
     // Every global load below is UNCONDITIONAL (indices are clamped, never predicated): a "cond ? load : 0"
     // makes hipcc branch around the load and drain vmcnt(0) per element, which serialises HBM round trips.
