@@ -93,6 +93,8 @@ struct vox_ctx {
     std::vector<PoolEntry> pool;
     // side streams + fork/join events: independent 16-row groups of a wide batched decode step run concurrently
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    // XF tiles of a 17..48-row GEMM input (the 38-token prefill): 3 tiles x K columns x 64 B; sized once for K <= 16384, reused by every such GEMM of the stream
+    uint16_t* xf_scratch = nullptr; size_t xf_scratch_bytes = 0;
 };
 
 static int32_t ctx_bind(const vox_ctx* c) { HIPCHK(hipSetDevice(c->device)); return VOX_OK; }
@@ -115,6 +117,7 @@ extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
     for (void* p : {(void*)c->d_window, (void*)c->d_cos, (void*)c->d_sin, (void*)c->d_fb, (void*)c->d_fb_lo, (void*)c->d_fb_hi, (void*)c->d_scale})
         if (p) (void)hipFree(p);
     for (auto& e : c->pool) (void)hipFree(e.p);
+    if (c->xf_scratch) (void)hipFree(c->xf_scratch);
     for (int i = 0; i < 3; i++) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     (void)hipStreamDestroy(c->stream);
@@ -544,6 +547,10 @@ static int32_t q4_linear_dev(vox_ctx* c, const Q4W& w, const float* bias, const 
     } else {
         GemmParams p{}; p.w = w; p.x = x; p.x_stride = x_stride; p.M = rows; p.out = out; p.out_stride = out_stride; p.bias = bias;
         p.resid = resid; p.resid_stride = resid_stride;
+        if (rows > 16 && rows <= 48 && w.fmt == WFMT_Q4_0 && w.K <= 16384) {      // the prefill GEMMs: rows -> XF tiles once (launch_q4_skinny_mt)
+            if (!c->xf_scratch) { c->xf_scratch_bytes = (size_t)3 * 16384 * 64; if (hipMalloc((void**)&c->xf_scratch, c->xf_scratch_bytes) != hipSuccess) { (void)hipGetLastError(); c->xf_scratch = nullptr; c->xf_scratch_bytes = 0; } }
+            p.xf_scratch = c->xf_scratch; p.xf_scratch_bytes = c->xf_scratch_bytes;
+        }
         HIPCHK(launch_q4_gemm(p, epi, c->stream));
     }
     return VOX_OK;
@@ -1338,10 +1345,27 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
     VOXCHK(ensure(&m->ws, &m->ws_floats, need));
     float* xn = m->ws; float* qkv = xn + (size_t)M * D; float* att = qkv + (size_t)M * W; float* ffn = att + (size_t)M * QD;
     const size_t lf = cache_layer_floats(m, kc);
+    // 17..48 rows in one sequence (the 38-token prefill): both RMSNorms write their output straight as XF tiles (the MFMA A-fragments the
+    // q4_skinny_mt_kernel consumes) into the context's XF scratch -- no f32 xn, no conversion launch for q|k|v and w1|w3
+    auto xf_ok = [&](const Q4W& w) { return w.fmt == WFMT_Q4_0 && w.qt && w.st && w.nb % 4 == 0 && w.K == D && D % 128 == 0 && D <= 10240; };
+    bool norm_xf = n_seq == 1 && M > 16 && M <= 48 && getenv("VOX_PREFILL_NO_NORM_XF") == nullptr;
+    if (norm_xf) {
+        if (!cx->xf_scratch) { cx->xf_scratch_bytes = (size_t)3 * 16384 * 64; if (hipMalloc((void**)&cx->xf_scratch, cx->xf_scratch_bytes) != hipSuccess) { (void)hipGetLastError(); cx->xf_scratch = nullptr; cx->xf_scratch_bytes = 0; } }
+        norm_xf = cx->xf_scratch != nullptr;
+    }
+    auto linear_xf = [&](const Q4W& w, float* out, int out_stride, int epi) -> int32_t {
+        GemmParams p{}; p.w = w; p.xf = reinterpret_cast<const uint4*>(cx->xf_scratch); p.M = M; p.out = out; p.out_stride = out_stride;
+        HIPCHK(launch_q4_gemm(p, epi, s)); return VOX_OK;
+    };
     for (int l = 0; l < c.dec_layers; l++) {
         const DecLayer& L = m->dec[l]; float* kl = kc->k + (size_t)l * lf; float* vl = kc->v + (size_t)l * lf;
-        HIPCHK(launch_rms_norm(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
-        VOXCHK(q4_linear_dev(cx, L.wqkv.w, nullptr, xn, D, M, qkv, W));
+        if (norm_xf && xf_ok(L.wqkv.w)) {
+            HIPCHK(launch_rms_norm_xf(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, cx->xf_scratch, s));
+            VOXCHK(linear_xf(L.wqkv.w, qkv, W, EPI_STORE));
+        } else {
+            HIPCHK(launch_rms_norm(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
+            VOXCHK(q4_linear_dev(cx, L.wqkv.w, nullptr, xn, D, M, qkv, W));
+        }
         HIPCHK(launch_rope(qkv, M, W, QD + KD, hd, off, m->dec_cos, m->dec_sin, s, seq_rows));
         HIPCHK(launch_kv_store(qkv, M, W, QD, KV, hd, off, kl, vl, kc->max_seq * hd, s, seq_rows, kv_seq_stride));
         AttnParams ap{}; ap.q = qkv; ap.q_stride = W; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd;
@@ -1349,8 +1373,13 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
         ap.q_seq_stride = seq_rows * W; ap.out_seq_stride = seq_rows * QD; ap.kv_seq_stride = kv_seq_stride;
         HIPCHK(launch_attn_prefill(ap, hd, s, n_seq));
         VOXCHK(q4_linear_dev(cx, L.wo.w, nullptr, att, QD, M, x, D, EPI_RESID, x, D));
-        HIPCHK(launch_rms_norm(x, D, M, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));    // norm then Ada x*(1+s) (model.rs:382-385)
-        VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, M, ffn, F, EPI_SWIGLU));
+        if (norm_xf && xf_ok(L.w13.w)) {
+            HIPCHK(launch_rms_norm_xf(x, D, M, D, L.ffn_norm, L.ada_mul, c.norm_eps, cx->xf_scratch, s));    // norm then Ada x*(1+s) (model.rs:382-385)
+            VOXCHK(linear_xf(L.w13.w, ffn, F, EPI_SWIGLU));
+        } else {
+            HIPCHK(launch_rms_norm(x, D, M, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));    // norm then Ada x*(1+s) (model.rs:382-385)
+            VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, M, ffn, F, EPI_SWIGLU));
+        }
         VOXCHK(q4_linear_dev(cx, L.w2.w, nullptr, ffn, F, M, x, D, EPI_RESID, x, D));
     }
     return VOX_OK;

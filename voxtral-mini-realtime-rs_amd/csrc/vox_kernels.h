@@ -69,6 +69,8 @@ struct GemmParams {
     const float* bias;
     const float* resid; int resid_stride;
     const uint4* xf;      // optional (M <= 16): the input as XF fragment planes (see xf_store4) instead of f32 rows x
+    uint16_t* xf_scratch; size_t xf_scratch_bytes;   // 17..48 rows (the 38-token prefill): room for ceil(M/16) XF tiles of K columns (64 B per column and tile);
+                          // the launcher converts the f32 rows ONCE (xf_rows_kernel) instead of every wave of every workgroup splitting them again
     // fused RMSNorm, consumer side: the XF input holds x * gamma UNnormalised; row m's accumulators are scaled by
     // rstd[m] = 1/sqrt(sum_i ssq_part[i][m] / K + norm_eps) (a per-row scalar commutes with the GEMM); n_part partials of 16 rows
     const float* ssq_part; int n_part; float norm_eps;

@@ -22,6 +22,7 @@
 
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1378,7 +1379,19 @@ __global__ __launch_bounds__(NTW == 3 ? 256 : 512, NTW == 3 ? 3 : 1) void q4_ski
 // a fixed order), converts its tile-ordered weight dwords to bf16 B fragments ONCE per K step and reuses them for the MT activation tiles
 // (f32 rows read from L2, split hi + lo bf16 in registers).  Same arithmetic as q4_skinny_kernel: exact integer weights through the matrix
 // core, f16 block scale applied to the f32 result, -136 * sum(x) through a constant-B MFMA pair.
-template <int MT, int NTW, int EPI>
+// XIN: the rows arrive as MT XF tiles (bf16 hi + lo MFMA A-fragments, converted once by xf_rows_kernel): no conversion VALU here.  The f32 form
+// spent 680 of its ~750 VALU instructions per K step splitting the same 48 x 128 block in every wave of every workgroup (PMC: VALU-bound,
+// profiles/r02_pmc_prefill.txt).
+__global__ __launch_bounds__(256) void xf_rows_kernel(const float* __restrict__ x, int x_stride, int M, int K, uint16_t* __restrict__ xf, int n_tiles) {
+    const int k4 = K >> 2;
+    const long total = (long)n_tiles * 16 * k4, tile_stride = (long)2 * (K >> 7) * 256 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / k4), k = (int)(i % k4) * 4;
+        const float4 v = row < M ? *reinterpret_cast<const float4*>(x + (size_t)row * x_stride + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xf_store4(xf + (size_t)(row >> 4) * tile_stride, K, row & 15, k, v);
+    }
+}
+template <int MT, int NTW, int EPI, bool XIN = false>
 __global__ __launch_bounds__(256) void q4_skinny_mt_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float sred[];      // [KS 4][MT][NTW][64][4]
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
@@ -1429,14 +1442,25 @@ __global__ __launch_bounds__(256) void q4_skinny_mt_kernel(const GemmParams p) {
             float4 xa[4], xb[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                xa[j] = *reinterpret_cast<const float4*>(xrow[mt] + 128 * q + 32 * j + 4 * g);
-                xb[j] = *reinterpret_cast<const float4*>(xrow[mt] + 128 * q + 32 * j + 16 + 4 * g);
+                if (XIN) {
+                    const uint4* xt = p.xf + (size_t)mt * 2 * nq * 256 + lane;
+                    xa[j] = *reinterpret_cast<const float4*>(xt + (q * 4 + j) * 64);                       // hi fragments (bit patterns)
+                    xb[j] = *reinterpret_cast<const float4*>(xt + (size_t)nq * 256 + (q * 4 + j) * 64);    // lo fragments
+                } else {
+                    xa[j] = *reinterpret_cast<const float4*>(xrow[mt] + 128 * q + 32 * j + 4 * g);
+                    xb[j] = *reinterpret_cast<const float4*>(xrow[mt] + 128 * q + 32 * j + 16 + 4 * g);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 uint4 ah, al;
-                split_pair(xa[j].x, xa[j].z, ah.x, al.x); split_pair(xb[j].x, xb[j].z, ah.y, al.y);
-                split_pair(xa[j].y, xa[j].w, ah.z, al.z); split_pair(xb[j].y, xb[j].w, ah.w, al.w);
+                if (XIN) {
+                    ah = make_uint4(__float_as_uint(xa[j].x), __float_as_uint(xa[j].y), __float_as_uint(xa[j].z), __float_as_uint(xa[j].w));
+                    al = make_uint4(__float_as_uint(xb[j].x), __float_as_uint(xb[j].y), __float_as_uint(xb[j].z), __float_as_uint(xb[j].w));
+                } else {
+                    split_pair(xa[j].x, xa[j].z, ah.x, al.x); split_pair(xb[j].x, xb[j].z, ah.y, al.y);
+                    split_pair(xa[j].y, xa[j].w, ah.z, al.z); split_pair(xb[j].y, xb[j].w, ah.w, al.w);
+                }
                 f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), m136, cs, 0, 0, 0);
 #pragma unroll
@@ -1487,6 +1511,16 @@ template <int MT, int NTW>
 static hipError_t skinny_mt_launch(const GemmParams& p, int epi, hipStream_t s) {
     dim3 grid((p.w.N + 16 * NTW - 1) / (16 * NTW));
     const size_t lds = (size_t)4 * MT * NTW * 64 * 4 * sizeof(float);
+    if (p.xf) {
+        switch (epi) {
+        case EPI_STORE: q4_skinny_mt_kernel<MT, NTW, EPI_STORE, true><<<grid, dim3(256), lds, s>>>(p); break;
+        case EPI_RESID: q4_skinny_mt_kernel<MT, NTW, EPI_RESID, true><<<grid, dim3(256), lds, s>>>(p); break;
+        case EPI_GELU: q4_skinny_mt_kernel<MT, NTW, EPI_GELU, true><<<grid, dim3(256), lds, s>>>(p); break;
+        case EPI_SWIGLU: q4_skinny_mt_kernel<MT, NTW, EPI_SWIGLU, true><<<grid, dim3(256), lds, s>>>(p); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (epi) {
     case EPI_STORE: q4_skinny_mt_kernel<MT, NTW, EPI_STORE><<<grid, dim3(256), lds, s>>>(p); break;
     case EPI_RESID: q4_skinny_mt_kernel<MT, NTW, EPI_RESID><<<grid, dim3(256), lds, s>>>(p); break;
@@ -1497,8 +1531,15 @@ static hipError_t skinny_mt_launch(const GemmParams& p, int epi, hipStream_t s) 
     return hipGetLastError();
 }
 // 17..48 rows, tile-ordered Q4 weights, K % 128 == 0, 16-byte aligned f32 rows
-static hipError_t launch_q4_skinny_mt(const GemmParams& p, int epi, hipStream_t s) {
+static hipError_t launch_q4_skinny_mt(const GemmParams& p_in, int epi, hipStream_t s) {
+    GemmParams p = p_in;
     const int mt = (p.M + 15) / 16, tiles = (p.w.N + 15) / 16;
+    if (!p.xf && p.xf_scratch && p.xf_scratch_bytes >= (size_t)mt * p.w.K * 64 && p.w.K % 128 == 0 && !env_int("VOX_SKINNY_MT_NO_XF")) {
+        // rows -> XF tiles once per GEMM (a ~3 us launch), then the conversion-free kernel
+        const long total = (long)mt * 16 * (p.w.K >> 2);
+        xf_rows_kernel<<<dim3((unsigned)std::min<long>((total + 255) / 256, 1024)), dim3(256), 0, s>>>(p.x, p.x_stride, p.M, p.w.K, p.xf_scratch, mt);
+        p.xf = reinterpret_cast<const uint4*>(p.xf_scratch);
+    }
     int ntw = tiles >= 512 ? 2 : 1;                           // two n-tiles per wave only while >= 256 workgroups remain
     { const int e = env_int("VOX_SKINNY_MT_NTW"); if (e == 1 || e == 2) ntw = e; }
 #define VOX_MTN(M_, N_) if (mt == M_ && ntw == N_) return skinny_mt_launch<M_, N_>(p, epi, s)
@@ -1895,6 +1936,8 @@ hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
         GemmParams v = p; v.w.fmt = WFMT_BF16X2; v.w.qt = nullptr; v.w.st = nullptr;
         return launch_dense2_gemm(v, epi, s);
     }
+    if (p.xf && p.M > 16) return (p.M <= 48 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && p.w.qt && p.w.st && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_GELU || epi == EPI_SWIGLU))
+                                     ? launch_q4_skinny_mt(p, epi, s) : hipErrorInvalidValue;      // ceil(M/16) XF tiles (launch_rms_norm_xf / xf_rows_kernel)
     if (p.xf) return (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && p.w.qt) ? launch_q4_skinny(p, epi, s) : hipErrorInvalidValue;
     if (p.M <= 16 && p.w.fmt == WFMT_Q4_0 && p.w.nb % 4 == 0 && !env_int("VOX_NO_SKINNY")) return launch_q4_skinny(p, epi, s);
     if (p.M > 16 && p.M <= 48 && p.w.fmt == WFMT_Q4_0 && p.w.qt && p.w.st && p.w.nb % 4 == 0 && (p.x_stride % 4) == 0 && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_GELU || epi == EPI_SWIGLU) &&
@@ -1983,14 +2026,14 @@ __global__ __launch_bounds__(256) void rms_norm_row_kernel(const float* __restri
             float4 t = v[i]; const float4 gm = g4[c];
             t.x = (t.x / rms) * gm.x; t.y = (t.y / rms) * gm.y; t.z = (t.z / rms) * gm.z; t.w = (t.w / rms) * gm.w;
             if (mul) { const float4 mm = m4[c]; t.x *= mm.x; t.y *= mm.y; t.z *= mm.z; t.w *= mm.w; }
-            if (xf) xf_store4(xf, dim, row, 4 * c, t); else o[c] = t;
+            if (xf) xf_store4(xf + (size_t)(row >> 4) * ((size_t)2 * (dim >> 7) * 256 * 8), dim, row & 15, 4 * c, t); else o[c] = t;      // XF tile row / 16
         }
     }
 }
 // same, but the normalised rows (<= 16) go straight into the XF fragment planes of the following batched-decode GEMM
 hipError_t launch_rms_norm_xf(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul, float eps,
                               uint16_t* xf, hipStream_t s) {
-    if (rows > 16 || dim > 10240 || dim % 128) return hipErrorInvalidValue;
+    if (rows > 48 || dim > 10240 || dim % 128) return hipErrorInvalidValue;      // up to three XF tiles (the 38-token prefill); rows of the last tile past `rows` keep their old contents
     rms_norm_row_kernel<<<dim3(rows), dim3(256), 0, s>>>(x, x_stride, dim, gamma, mul, eps, nullptr, 0, xf);
     return hipGetLastError();
 }
