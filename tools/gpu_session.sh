@@ -7,7 +7,9 @@ step_tests()     { timeout 900 python -m pytest tests -m gpu -x -q ${VOX_PYTEST_
 step_tests_all() { timeout 900 python -m pytest tests -m gpu -q -rA ${VOX_PYTEST_ARGS:-} > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|FAILED|full-size|batch" $OUT/${TAG}_pytest_gpu.log | tail -30; }
 step_smoke()     { timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/${TAG}_smoke.log; }
 step_f32golden() { timeout 900 python tests/golden/make_fullsize_f32_golden.py > $OUT/${TAG}_f32golden.log 2>&1; echo "f32golden rc=$?"; tail -4 $OUT/${TAG}_f32golden.log; }
-step_micro()     { timeout 300 tools/micro/chain_floor > $OUT/${TAG}_chain_floor.txt 2>&1; echo "micro rc=$?"; cat $OUT/${TAG}_chain_floor.txt; }
+step_micro()     { # tools/micro/build.sh first (cross-compiles here, the binaries travel with the snapshot)
+                   timeout 300 tools/micro/chain_floor > $OUT/${TAG}_chain_floor.txt 2>&1; echo "micro rc=$?"; cat $OUT/${TAG}_chain_floor.txt
+                   for b in overlap_chain atomic_reduce; do [ -x tools/micro/$b ] && timeout 120 tools/micro/$b | tee $OUT/${TAG}_$b.txt; done; }
 step_timeline()  { timeout 300 python tools/timeline.py > $OUT/${TAG}_timeline.txt 2>&1; echo "timeline rc=$?"; cat $OUT/${TAG}_timeline.txt; }
 step_bench()     { timeout 900 python bench.py --steps ${VOX_BENCH_STEPS:-10} --warmup 3 ${VOX_BENCH_ARGS:-} > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err; }
 step_benchq()    { timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --batch ${VOX_BENCH_BATCH:-16} ${VOX_BENCH_ARGS:---no-f32 --fleurs-clips 0} > $OUT/${TAG}_benchq.json 2> $OUT/${TAG}_benchq.err; echo "benchq rc=$?"; python - <<PY
