@@ -263,12 +263,13 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
 #else
 #define VOX_SCLOAD(I_) __builtin_nontemporal_load(p.w.sc + (I_))
 #endif
-    // wo / w2 (no prologue, residual epilogue): no weight request before the activation vector is staged -- the vector is a cross-XCD read that
-    // otherwise queues behind the weight bursts of the workgroups that started first (w2 7.9 -> 7.6 us, wo 4.75 -> 4.65; q|k|v and w1|w3: neutral)
-#ifdef VOX_ABL_XFIRST
-    constexpr bool XFIRST = true;
-#else
+    // No weight request before the activation vector is staged: the vector is a cross-XCD read that otherwise queues behind the weight bursts of
+    // the workgroups that started first (3 x 3 back-to-back pairs, tools/gemv_ablate.py: q|k|v 6.75 -> 6.20 us, w2 7.9 -> 7.6, wo 4.75 -> 4.65;
+    // w1|w3 and lm_head neutral).  The opt-in fused-attention epilogue keeps the old order (its measurements were taken with it).
+#ifdef VOX_ABL_XFIRST_RESID_ONLY      /* measurement build: the earlier setting (only wo / w2 wait for the vector) */
     constexpr bool XFIRST = PRO == PRO_NONE && EPI == EPI_RESID;
+#else
+    constexpr bool XFIRST = EPI != EPI_ROPE_KV_ATTN;
 #endif
     if (!XFIRST) { VOX_WLOAD(qa, da, min(g, n_groups - 1)) }
 #if defined(VOX_ABL_WFIRST) && !defined(VOX_ABL_NOX)       /* measurement build: weights issued BEFORE the activation loads */
