@@ -55,7 +55,7 @@ def build_all(verbose: bool = False, force: bool = False, tag: str | None = None
 VARIANTS = {"timeline": ["-DVOX_TIMELINE"],      # measurement builds (tools/timeline.py)
             # GEMV ablations (tools/gemv_ablate.py; results are wrong by construction, only the timing is read)
             "abl_noscale": ["-DVOX_ABL_NOSCALE"], "abl_nox": ["-DVOX_ABL_NOX"], "abl_wfirst": ["-DVOX_ABL_WFIRST"],      # (abl_wfirst predates the x-first default and is a no-op now)
-            "abl_noconsume": ["-DVOX_ABL_NOCONSUME"], "abl_xfirst_resid": ["-DVOX_ABL_XFIRST_RESID_ONLY"], "abl_noreduce": ["-DVOX_ABL_NOREDUCE"],
+            "abl_noconsume": ["-DVOX_ABL_NOCONSUME"], "abl_xfirst_resid": ["-DVOX_ABL_XFIRST_RESID_ONLY"], "abl_xfirst_noswiglu": ["-DVOX_ABL_XFIRST_NO_SWIGLU"], "abl_noreduce": ["-DVOX_ABL_NOREDUCE"],
             "abl_all": ["-DVOX_ABL_NOSCALE", "-DVOX_ABL_NOX", "-DVOX_ABL_NOCONSUME", "-DVOX_ABL_NOREDUCE"]}
 
 if __name__ == "__main__":

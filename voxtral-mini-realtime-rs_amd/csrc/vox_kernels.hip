@@ -268,6 +268,8 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
     // w1|w3 and lm_head neutral).  The opt-in fused-attention epilogue keeps the old order (its measurements were taken with it).
 #ifdef VOX_ABL_XFIRST_RESID_ONLY      /* measurement build: the earlier setting (only wo / w2 wait for the vector) */
     constexpr bool XFIRST = PRO == PRO_NONE && EPI == EPI_RESID;
+#elif defined(VOX_ABL_XFIRST_NO_SWIGLU)  /* measurement build: w1|w3 keeps the weights-with-vector order */
+    constexpr bool XFIRST = EPI != EPI_ROPE_KV_ATTN && EPI != EPI_SWIGLU;
 #else
     constexpr bool XFIRST = EPI != EPI_ROPE_KV_ATTN;
 #endif
