@@ -1385,9 +1385,10 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
     return VOX_OK;
 }
 
-// ---- one decode step on device (Appendix B of SURVEY.md): 5 fused launches per layer.
-// h [D] in place. position = (pos_ptr ? *pos_ptr : 0) + pos_off.
-// single-stream decode layer as four launches (attention + wo in one: attn_wo_kernel; the sum lands in w1|w3's prologue)?
+// ---- one decode step on device (Appendix B of SURVEY.md): 4 fused launches per layer -- q|k|v (+ RMSNorm, RoPE, cache write), attention + wo
+// (attn_wo_kernel), w1|w3 (+ sum of the wo partials, residual, RMSNorm * Ada, SwiGLU), w2 (+ residual) -- or 5 (separate attention and wo
+// launches) for dense checkpoints / other head geometries.  h [D] in place.  position = (pos_ptr ? *pos_ptr : 0) + pos_off.
+// May this layer run as four launches?
 static bool decode_layer_fuses_attn_wo(const vox_model* m, const DecLayer& L, const AttnParams& ap, const vox_cache* kc) {
     const vox_model_cfg& c = m->cfg; const int D = c.dec_dim;
     return attn_wo_supported(ap, L.wo.w, c.dec_head_dim, kc->max_seq) && L.w13.w.fmt == WFMT_Q4_0 && L.wo.w.N == D && D % 4 == 0 && L.w13.w.K == 3072 &&
@@ -1412,8 +1413,8 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
             HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV, q4_gemv_default_R(p.w.N, p.w.K, EPI_ROPE_KV), s));
             AttnParams ap{}; ap.q = m->d_q; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd; ap.out = m->d_att;
             ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = pos_off; ap.window = c.dec_window; ap.pos_ptr = pos_ptr; ap.M = 1; ap.spec_rows = kc->max_seq;
-            // four launches per layer: attention + wo in one (K split over the 8 KV groups), the 8 partial products are summed by w1|w3's prologue,
-            // which also writes the residual stream after wo (d_h2) for w2's epilogue
+            // four launches per layer: attention + wo in one (32-way K split, one partial product per head, combined with int64 fixed-point atomics);
+            // w1|w3's prologue adds the sum to the residual and writes the new residual stream (d_h2) for w2's epilogue
             const int R13 = q4_gemv_default_R(L.w13.w.N, L.w13.w.K, EPI_SWIGLU);
             if (decode_layer_fuses_attn_wo(m, L, ap, kc) && h != m->d_h2) {
                 long long* acc = m->d_wo_acc + (size_t)l * D;      // zero on entry: cleared at allocation, and by w2 below after every use
