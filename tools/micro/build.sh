@@ -4,3 +4,7 @@ cd "$(dirname "$0")"
 for f in chain_floor gridbar_bench overlap_chain atomic_reduce; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $f $f.hip 2>&1 | grep -v "argument unused" ; echo "built $f"
 done
+# engine_bench links the product's kernel objects (python voxtral-mini-realtime-rs_amd/build.py first)
+B=../../voxtral-mini-realtime-rs_amd/build
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -c -o engine_bench.o engine_bench.hip 2>&1 | grep -v "argument unused"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -o engine_bench engine_bench.o $B/vox_kernels.o $B/vox_engine.o 2>&1 | grep -v "argument unused"; echo "built engine_bench"

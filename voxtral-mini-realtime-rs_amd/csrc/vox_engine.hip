@@ -1,0 +1,759 @@
+// vox_engine.hip -- persistent decode-step engine for gfx950 (MI355X): one launch per decoded token.
+//
+// What it replaces: the 26 x 4 + 1 dependent launches of one single-stream decode step (reference: gguf/model.rs:938-960 -> forward_hidden_with_cache
+// + lm_head, model.rs:566-691).  Why: a decode layer streams 65.5 MB of Q4 weights -- 10 us at HBM speed -- but every launch pays a kernel
+// boundary, a ramp, and the round trip of its activation vector before the first weight byte is consumed.  Here the
+// weight stream never stops: it does not depend on anything, so a loader wave per CU runs AHEAD of every dependency edge, and the edges
+// themselves are 8-byte {value, tag} write-through granules swept by one wave per CU (MI355X_MICROARCH.md "Persistent kernels" price list).
+//
+// Geometry (fixed: the real Voxtral decoder -- D 3072, 32 query heads / 8 KV heads x 128, FFN 9216; other shapes keep the per-operator path):
+//   grid = 256 workgroups (one per CU, all resident) x 512 threads = 8 waves:
+//     wave 0      LOADER   global_load_lds_dwordx4 ... nt: this CU's slice of q|k|v, wo, w1|w3, w2 of every layer, then lm_head, as 21 KiB packets
+//                          into a ring of LDS slots; 2-3 packets in flight; waits only for free slots.
+//     wave 1      COMM     sweeps granules written by other CUs into LDS staging (activation vectors, partial sums), applies RMSNorm weights,
+//                          reduces partial sums in a FIXED order (deterministic), publishes this CU's 12 rows of the residual stream.
+//     waves 2..7  CONSUMERS  one "pass" (3456 B: 192 Q4 blocks) per wave per packet: v_cvt_pk_f32_fp8 turns two nibble bytes into two floats
+//                          (an e4m3 byte 0x0q is exactly q * 2^-9), v_pk_fma_f32 against the activation slice held in REGISTERS; attention.
+//   CU b = (g = b % 8: KV head / XCD, j = b / 8): query head h = 4 g + j / 8, slice s = j % 8.  Per layer:
+//     q|k|v   CU computes q rows [128 h + 16 s, +16), k rows [4 j, +4) and v rows [4 j, +4) of KV head g (K = 3072, RMSNorm folded)   -> granules G
+//     attn    CU (h, s) gathers q_h, k_g, v_g (new row) and runs head h's single-query attention over the cache (redundantly per slice)
+//     wo      CU (h, s): rows [384 s, +384) x columns of head h (K = 128)  -> 32 partial planes PW; owner of rows [12 b, +12) sums them + residual -> H1
+//     w1|w3   CU (g, j): SwiGLU outputs [1152 g + 36 j, +36) (K = 3072)     -> granules A (read inside the XCD group only)
+//     w2      CU (g, j): rows [96 j, +96) x K slice [1152 g, +1152), split in 3 sub-slices over the consumer waves -> 24 partial planes P2;
+//             owner sums + residual -> H0 (next layer's input)
+//   Every all-to-all edge (H0, H1) is one 24 KB granule sweep per CU; the other edges are <= 1152 granules.
+// Tags = launch serial * 64 + layer + 1: unique per (launch, layer), so no buffer is ever re-initialised and a stale granule can never match.
+// Every spin is bounded (20 ms): on timeout the workgroup sets *err, marks itself dead and runs to completion without waiting.
+#include "vox_kernels.h"
+
+#include <hip/hip_fp16.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace vox {
+namespace {
+
+typedef unsigned long long u64;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ED = 3072, ENH = 32, ENKV = 8, EHD = 128, EQD = ENH * EHD, EKD = ENKV * EHD, EF = 9216;
+constexpr int NCU = 256, NCONS = 6, NWAVES = NCONS + 2, NTHR = 64 * NWAVES;
+constexpr int PASS_A = 3456, PASS_WO = 2304;          // bytes per pass: 3 (2) planes of 64 x 16 B nibbles + 64 x 2 B scales
+constexpr int LINES_A = 21, LINES_WO = 14;            // 1 KiB LDS-DMA lines per packet (6 passes)
+constexpr int SLOT_BYTES = LINES_A * 1024, NSLOT = 5;
+constexpr int QKV_PK = 2, WO_PK = 2, W13_PK = 6, W2_PK = 3;
+constexpr int LAYER_LINES = (QKV_PK + W13_PK + W2_PK) * LINES_A + WO_PK * LINES_WO;   // 259 KiB per CU per layer
+constexpr int OFF_QKV = 0, OFF_WO = QKV_PK * LINES_A, OFF_W13 = OFF_WO + WO_PK * LINES_WO, OFF_W2 = OFF_W13 + W13_PK * LINES_A;   // in lines
+constexpr int SC_MAX = 1024;                          // attention scores in LDS: cache rows per KV head (max_seq) <= 1024
+constexpr int OWN = ED / NCU;                         // 12 rows of the residual stream per CU
+constexpr int NPW = ENH, NP2 = 24;                    // partial planes of wo / w2
+constexpr u64 TIMEOUT_TICKS = 2000000;                // s_memrealtime ticks (100 MHz): 20 ms
+
+enum { EOP_QKV = 0, EOP_WO = 1, EOP_W13 = 2, EOP_W2 = 3, EOP_LM = 4 };
+enum { ERR_RING = 1, ERR_STAGE = 2, ERR_SWEEP = 3, ERR_CBAR = 4, ERR_SLOT = 5 };
+
+__host__ __device__ inline int lm_rows_per_cu(int vocab) { return vocab / NCU; }
+__host__ __device__ inline int lm_passes(int vocab) { return lm_rows_per_cu(vocab) / 2; }
+__host__ __device__ inline int lm_packets(int vocab) { return (lm_passes(vocab) + NCONS - 1) / NCONS; }
+__host__ __device__ inline size_t cu_stream_bytes(int n_layers, int vocab) { return ((size_t)n_layers * LAYER_LINES + (size_t)lm_packets(vocab) * LINES_A) * 1024; }
+
+// (row, block) of weight matrix `op` that lands in 16-byte chunk [plane p][lane] of pass q on CU b.  Lanes that split one row hold whole Q4 blocks.
+__host__ __device__ inline void eng_src(int op, int b, int q, int p, int lane, int vocab, int* row, int* blk) {
+    const int g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
+    if (op == EOP_QKV || op == EOP_W13 || op == EOP_LM) {              // 2 rows per pass, 32 lanes x 3 blocks per row
+        const int hr = lane >> 5, li = lane & 31;
+        *blk = li + 32 * p;
+        if (op == EOP_W13) *row = 2 * (1152 * g + 36 * j + q) + hr;
+        else if (op == EOP_LM) *row = lm_rows_per_cu(vocab) * b + 2 * q + hr;
+        else if (q < 8) *row = 128 * h + 16 * s + 2 * q + hr;
+        else if (q < 10) *row = EQD + 128 * g + 4 * j + 2 * (q - 8) + hr;
+        else *row = EQD + EKD + 128 * g + 4 * j + 2 * (q - 10) + hr;
+    } else if (op == EOP_WO) {                                         // 32 rows per pass, 2 lanes x 2 blocks per row (K = the head's 128 columns)
+        *row = 384 * s + 32 * q + (lane >> 1);
+        *blk = 4 * h + (lane & 1) + 2 * p;
+    } else {                                                           // w2: 16 rows per pass, 4 lanes x 3 blocks; wave w = q % 6: sub-slice w % 3, row half w / 3
+        const int t3 = q / NCONS, w = q % NCONS, ts = w % 3, rh = w / 3;
+        *row = 96 * j + 48 * rh + 16 * t3 + (lane >> 2);
+        *blk = 36 * g + 12 * ts + (lane & 3) + 4 * p;
+    }
+}
+
+__global__ __launch_bounds__(192) void eng_pack_kernel(Q4W w, int op, unsigned char* __restrict__ stream, size_t cu_stride, size_t op_off, int vocab) {
+    const int q = blockIdx.x, b = blockIdx.y, t = threadIdx.x, NB = op == EOP_WO ? 2 : 3;
+    if (t >= NB * 64) return;
+    const int p = t >> 6, lane = t & 63;
+    int row, blk; eng_src(op, b, q, p, lane, vocab, &row, &blk);
+    const size_t pk_bytes = (size_t)(op == EOP_WO ? LINES_WO : LINES_A) * 1024, pass_bytes = op == EOP_WO ? PASS_WO : PASS_A;
+    unsigned char* dst = stream + (size_t)b * cu_stride + op_off + (size_t)(q / NCONS) * pk_bytes + (size_t)(q % NCONS) * pass_bytes;
+    const size_t src = (size_t)row * w.nb + blk;
+    reinterpret_cast<uint4*>(dst)[p * 64 + lane] = w.qs[src];
+    reinterpret_cast<uint16_t*>(dst + NB * 1024)[p * 64 + lane] = w.sc[src];
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS map
+// ------------------------------------------------------------------------------------------------
+struct EngCtl {
+    unsigned ring_ready[8], ring_done[8];         // monotonic per slot: fills landed / passes consumed
+    unsigned xs0_flag, xs1_flag, xa_flag, qkv_flag;   // layer + 1 of the staged content (monotonic)
+    unsigned cbar, dead, gathering, pad0;
+    float rstd0, rstd1, pad1, pad2;
+    float best_val[8]; int best_idx[8];
+    float h_own[16], h1_own[16];
+};
+constexpr int L_RING = 0;
+constexpr int L_XS0 = L_RING + NSLOT * SLOT_BYTES;      // [3072] f32, swizzled chunks: q|k|v (and lm_head) input
+constexpr int L_XS1 = L_XS0 + ED * 4;                   // w1|w3 input
+constexpr int L_XA = L_XS1 + ED * 4;                    // [1152] the XCD group's SwiGLU outputs (w2 input)
+constexpr int L_XO = L_XA + 1152 * 4;                   // [128] attention output of head h (wo input)
+constexpr int L_QKVN = L_XO + 128 * 4;                  // q_h[128] k_g[128] v_g[128] of this step (plain order)
+constexpr int L_SC = L_QKVN + 384 * 4;                  // [SC_MAX] scores
+constexpr int L_PO = L_SC + SC_MAX * 4;                 // [12][128] partial attention outputs
+constexpr int L_PL = L_PO + 12 * 128 * 4;               // [16] partial softmax sums
+constexpr int L_TMP = L_PL + 64;                        // [384] partial sums swept by the comm wave
+constexpr int L_CTL = L_TMP + 384 * 4;
+constexpr int L_TOTAL = L_CTL + (int)sizeof(EngCtl);
+static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
+static_assert(L_XS0 % 16 == 0 && L_XA % 16 == 0 && L_XO % 16 == 0 && L_QKVN % 16 == 0 && L_PO % 16 == 0 && L_CTL % 16 == 0, "16-byte aligned carve");
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+#define ENG_CFENCE() asm volatile("" ::: "memory")
+typedef const __attribute__((address_space(1))) float* gcf_p;      // pointers that come out of the device-resident layer table: the compiler cannot infer
+typedef __attribute__((address_space(1))) float* gf_p;             // their address space, and a FLAT load also counts on lgkmcnt (an LDS wait would wait for it)
+typedef float fv4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gcf_p as_g(const float* p) { return (gcf_p)(uintptr_t)p; }
+__device__ __forceinline__ gf_p as_g(float* p) { return (gf_p)(uintptr_t)p; }
+__device__ __forceinline__ float4 ldg4(gcf_p p) { const fv4 v = *(const __attribute__((address_space(1))) fv4*)p; return make_float4(v.x, v.y, v.z, v.w); }
+#define RLX __ATOMIC_RELAXED
+#define WG __HIP_MEMORY_SCOPE_WORKGROUP
+#define AG __HIP_MEMORY_SCOPE_AGENT
+// control words are wave-uniform: readfirstlane keeps every branch on them a scalar branch (all 64 lanes stay active for the DPP reductions)
+__device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, RLX, WG)); }
+__device__ __forceinline__ void lds_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, RLX, WG); }
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+__device__ __forceinline__ float rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ float row16_sum_e(float v) { v += dppf<0xB1>(v); v += dppf<0x4E>(v); v += dppf<0x141>(v); v += dppf<0x140>(v); return v; }
+__device__ __forceinline__ float row16_max_e(float v) { v = fmaxf(v, dppf<0xB1>(v)); v = fmaxf(v, dppf<0x4E>(v)); v = fmaxf(v, dppf<0x141>(v)); v = fmaxf(v, dppf<0x140>(v)); return v; }
+__device__ __forceinline__ float wave_sum_e(float v) { v = row16_sum_e(v); return (rlf(v, 0) + rlf(v, 16)) + (rlf(v, 32) + rlf(v, 48)); }
+__device__ __forceinline__ float wave_max_e(float v) { v = row16_max_e(v); return fmaxf(fmaxf(rlf(v, 0), rlf(v, 16)), fmaxf(rlf(v, 32), rlf(v, 48))); }
+__device__ __forceinline__ float group8_sum_e(float v) { v += dppf<0xB1>(v); v += dppf<0x4E>(v); v += dppf<0x141>(v); return v; }
+__device__ __forceinline__ float silu_e(float x) { return x / (1.0f + expf(-x)); }
+
+// staged activation vectors: chunk c (32 floats) keeps its eight 16-byte pieces at piece index j ^ ((c >> 1) & 7), so the ds_read_b128 of lanes that
+// hold consecutive chunks is bank-conflict free (the same swizzle as q4_gemv_kernel's)
+__device__ __forceinline__ int sw_piece(int c, int j) { return c * 8 + (j ^ ((c >> 1) & 7)); }
+__device__ __forceinline__ int sw_dword(int k) { const int c = k >> 5, e = k & 31; return sw_piece(c, e >> 2) * 4 + (e & 3); }
+
+struct Tl {      // timeline stamps (measurement runs: p.tl != nullptr), lane 0 of the stamping wave
+    u64* buf; bool on;
+    __device__ __forceinline__ void operator()(int evt) const { if (on) buf[evt] = wall_clock64(); }
+};
+
+// wait until *word >= target (LDS word, monotonic).  Bounded; a dead workgroup never waits.
+__device__ __forceinline__ bool wait_ge(unsigned* word, unsigned target, EngCtl* c, unsigned* err, unsigned code) {
+    if (lds_ld(word) >= target) { ENG_CFENCE(); return true; }
+    if (lds_ld(&c->dead)) return false;
+    const u64 t0 = wall_clock64();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (lds_ld(word) >= target) break;
+        if (lds_ld(&c->dead)) return false;
+        if (wall_clock64() - t0 > TIMEOUT_TICKS) {
+            lds_st(&c->dead, 1u);
+            __hip_atomic_store(err, code | ((unsigned)blockIdx.x << 8), RLX, AG);
+            return false;
+        }
+    }
+    ENG_CFENCE();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LOADER wave
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma_line(unsigned voff, unsigned lds_dst_, u64 gsrc_) {
+    unsigned keep;
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_);      // wave-uniform by construction; make the compiler see it
+    const u64 gsrc = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(gsrc_ >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gsrc_);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(gsrc) : "memory");
+}
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n = DMA lines allowed to stay in flight (younger packets)
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+struct Loader {
+    EngCtl* c; unsigned* err; unsigned ring_lds; unsigned voff;
+    int nfl = 0, s0 = 0, l0 = 0, s1 = 0, l1 = 0;    // packets issued, not yet published: (s0, l0) oldest, (s1, l1) newer -- plain scalars (an indexed array would live in scratch = VMEM)
+    unsigned P = 0;                                   // next packet index
+    bool thin;
+    __device__ __forceinline__ void publish_slot(int slot) { lds_st(&c->ring_ready[slot], lds_ld(&c->ring_ready[slot]) + 1u); }   // only this wave writes ring_ready
+    __device__ __forceinline__ void flush() {
+        if (nfl == 2) { wait_vmcnt(l1); publish_slot(s0); s0 = s1; l0 = l1; nfl = 1; }
+        if (nfl == 1) { wait_vmcnt(0); publish_slot(s0); nfl = 0; }
+    }
+    __device__ __forceinline__ void issue(u64 gsrc, int lines) {
+        const int slot = (int)(P % NSLOT); const unsigned k = P / NSLOT;
+        if (k > 0 && lds_ld(&c->ring_done[slot]) < NCONS * k) {
+            flush();                                   // publish what has landed before blocking: the consumers may be waiting for exactly that
+            wait_ge(&c->ring_done[slot], NCONS * k, c, err, ERR_SLOT);
+        }
+        if (thin && lds_ld(&c->gathering)) flush();    // one fill outstanding while this CU's comm wave sweeps (MI355X_MICROARCH.md gather-pass)
+        const unsigned dst = ring_lds + (unsigned)slot * SLOT_BYTES;
+#pragma unroll 1
+        for (int i = 0; i < lines; i++) dma_line(voff, dst + (unsigned)i * 1024u, gsrc + (u64)i * 1024u);
+        P++;
+        if (nfl == 2) { wait_vmcnt(l1 + lines); publish_slot(s0); s0 = s1; l0 = l1; s1 = slot; l1 = lines; }      // three in flight: retire the oldest
+        else if (nfl == 1) { s1 = slot; l1 = lines; nfl = 2; }
+        else { s0 = slot; l0 = lines; nfl = 1; }
+    }
+};
+
+__device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsigned ring_lds, int lane, const Tl& tl) {
+    Loader ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = (p.flags & 1) != 0;
+    const u64 base = (u64)(p.stream + (size_t)blockIdx.x * p.cu_stride);
+    for (int l = 0; l < p.n_layers; l++) {
+        const u64 lb = base + (u64)l * LAYER_LINES * 1024;
+        if (l == p.tl_layer) tl(16);
+        for (int k = 0; k < QKV_PK; k++) ld.issue(lb + (u64)(OFF_QKV + k * LINES_A) * 1024, LINES_A);
+        for (int k = 0; k < WO_PK; k++) ld.issue(lb + (u64)(OFF_WO + k * LINES_WO) * 1024, LINES_WO);
+        for (int k = 0; k < W13_PK; k++) ld.issue(lb + (u64)(OFF_W13 + k * LINES_A) * 1024, LINES_A);
+        for (int k = 0; k < W2_PK; k++) ld.issue(lb + (u64)(OFF_W2 + k * LINES_A) * 1024, LINES_A);
+        if (l == p.tl_layer) tl(17);
+    }
+    const u64 lmb = base + (u64)p.n_layers * LAYER_LINES * 1024;
+    const int npk = lm_packets(p.vocab);
+    for (int k = 0; k < npk; k++) ld.issue(lmb + (u64)k * LINES_A * 1024, LINES_A);
+    ld.flush();
+    tl(18);
+}
+
+// ------------------------------------------------------------------------------------------------
+// COMM wave
+// ------------------------------------------------------------------------------------------------
+// Sweep N granules per lane until every tag matches (values in v).  Bounded.  While the producers are still working the wave polls ONE granule per
+// lane (`probe(lane)`: one granule of every producer, or of every n-th) instead of the whole chunk: 256 CUs polling 8 KB each would put TB/s of
+// coherent reads next to the weight stream (MI355X_MICROARCH.md polling-cost).
+__device__ __forceinline__ bool sweep_bail(u64& t0, unsigned tag, EngCtl* c, unsigned* err) {
+    if (lds_ld(&c->dead)) return true;
+    if (t0 == 0) t0 = wall_clock64();
+    else if (wall_clock64() - t0 > TIMEOUT_TICKS) {
+        lds_st(&c->dead, 1u);
+        __hip_atomic_store(err, (unsigned)ERR_SWEEP | ((unsigned)blockIdx.x << 8) | (tag << 16), RLX, AG);
+        return true;
+    }
+    __builtin_amdgcn_s_sleep(2);
+    return false;
+}
+template <int N, class IdxF, class ProbeF>
+__device__ __forceinline__ bool sweep(const u64* __restrict__ base, unsigned tag, IdxF idx, ProbeF probe, bool do_probe, float (&v)[N], EngCtl* c, unsigned* err) {
+    u64 t0 = 0;
+    if (do_probe) {
+        const u64* pp = base + probe();
+        for (;;) {
+            const u64 gq = __hip_atomic_load(pp, RLX, AG);
+            if (__all((unsigned)(gq >> 32) == tag)) break;
+            if (sweep_bail(t0, tag, c, err)) return false;
+        }
+    }
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            const u64 gq = __hip_atomic_load(base + idx(u), RLX, AG);
+            v[u] = __uint_as_float((unsigned)gq);
+            ok &= (unsigned)(gq >> 32) == tag;
+        }
+        if (__all(ok)) return true;
+        if (sweep_bail(t0, tag, c, err)) return false;
+    }
+}
+__device__ __forceinline__ void publish(u64* g, unsigned tag, float v) { __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), RLX, AG); }
+
+// gather the full residual stream (plain h_in for layer 0, granules otherwise), stage x = h * gamma (* mul) * 512 swizzled, rstd, this CU's own rows.
+// 48 values per lane in 3 chunks of 16: the first chunk is polled until its producers are done, the others are then (almost always) complete.
+__device__ __forceinline__ void comm_stage_h(const EngParams& p, EngCtl* c, int lane, const u64* src, unsigned tag, const float* plain,
+                                             const float* gamma_, const float* mul_, float* xs, float* rstd_out, float* own) {
+    const gcf_p gamma = as_g(gamma_), mul = as_g(mul_), plain_g = as_g(plain);
+    float ss = 0.f;
+    const int b12 = (int)blockIdx.x * OWN;
+#pragma unroll 1
+    for (int ch = 0; ch < 3; ch++) {
+        const int k0 = lane + 1024 * ch;
+        float gm[16], hv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int k = k0 + 64 * u; gm[u] = gamma[k] * (mul ? mul[k] : 1.0f); }
+        if (plain) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) hv[u] = plain_g[k0 + 64 * u];
+        } else {
+            sweep<16>(src, tag, [&](int u) { return k0 + 64 * u; }, [&]() { return 48 * lane; }, ch == 0, hv, c, p.err);      // probe: a row of every 4th producer
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int k = k0 + 64 * u;
+            ss = fmaf(hv[u], hv[u], ss);
+            xs[sw_dword(k)] = hv[u] * gm[u] * 512.0f;
+            if ((unsigned)(k - b12) < (unsigned)OWN) own[k - b12] = hv[u];
+        }
+    }
+    ss = wave_sum_e(ss);
+    if (lane == 0) *rstd_out = 1.0f / sqrtf(ss / (float)ED + p.eps);
+}
+
+__device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned char* lds, int lane, const Tl& tl) {
+    const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3);
+    float* xs0 = reinterpret_cast<float*>(lds + L_XS0); float* xs1 = reinterpret_cast<float*>(lds + L_XS1);
+    float* xa = reinterpret_cast<float*>(lds + L_XA); float* qkvn = reinterpret_cast<float*>(lds + L_QKVN);
+    float* tmp = reinterpret_cast<float*>(lds + L_TMP);
+    const unsigned tag_base = *p.serial * 64u;
+    for (int l = 0; l <= p.n_layers; l++) {
+        const bool T = l == p.tl_layer;
+        const unsigned tag = tag_base + (unsigned)l + 1u;           // written during layer l
+        // (a) the layer's input (the previous layer's output: tag - 1)
+        lds_st(&c->gathering, 1u);
+        const bool last = l == p.n_layers;
+        const EngLayerTab* L = p.layers + (last ? 0 : l);
+        comm_stage_h(p, c, lane, p.H0, tag - 1u, l == 0 ? p.h_in : nullptr, last ? p.final_norm : L->attn_norm, nullptr, xs0, &c->rstd0, c->h_own);
+        ENG_CFENCE(); lds_st(&c->xs0_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
+        if (T) tl(8);
+        if (last) break;
+        // (b) this step's q_h, k_g, v_g rows
+        {
+            float v[6];
+            lds_st(&c->gathering, 1u);
+            sweep<6>(p.G, tag, [&](int u) { const int i = lane + 64 * u, seg = i >> 7, e = i & 127; return seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e; },
+                     [&]() { return lane < 32 ? EQD + 128 * g + 4 * lane : EQD + EKD + 128 * g + 4 * (lane - 32); }, true, v, c, p.err);      // probe: a k / v row of each of the group's 32 CUs
+#pragma unroll
+            for (int u = 0; u < 6; u++) qkvn[lane + 64 * u] = v[u];
+            ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
+        }
+        if (T) tl(9);
+        // (c) wo: 32 partial planes of this CU's 12 rows -> residual stream after attention
+        {
+            float v[6];
+            lds_st(&c->gathering, 1u);
+            sweep<6>(p.PW, tag, [&](int u) { const int i = lane + 64 * u, hh = i / OWN, r = i - hh * OWN; return hh * ED + OWN * b + r; }, [&]() { return (lane & 31) * ED + OWN * b; }, true, v, c, p.err);
+#pragma unroll
+            for (int u = 0; u < 6; u++) tmp[lane + 64 * u] = v[u];
+            ENG_CFENCE();
+            if (lane < OWN) {
+                float a = 0.f;
+                for (int hh = 0; hh < NPW; hh++) a += tmp[hh * OWN + lane];      // fixed order
+                const float h1 = c->h_own[lane] + a;
+                c->h1_own[lane] = h1;
+                publish(p.H1 + OWN * b + lane, tag, h1);
+            }
+            lds_st(&c->gathering, 0u);
+        }
+        if (T) tl(10);
+        // (d) all-gather of the post-attention residual stream -> w1|w3 input (RMSNorm weight and Ada scale folded)
+        lds_st(&c->gathering, 1u);
+        comm_stage_h(p, c, lane, p.H1, tag, nullptr, L->ffn_norm, L->ada_mul, xs1, &c->rstd1, c->h1_own);
+        ENG_CFENCE(); lds_st(&c->xs1_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
+        if (T) tl(11);
+        // (e) the XCD group's 1152 SwiGLU outputs -> w2 input
+        {
+            float v[18];
+            lds_st(&c->gathering, 1u);
+            sweep<18>(p.A, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, true, v, c, p.err);      // probe: the last output of each CU of the group
+#pragma unroll
+            for (int u = 0; u < 18; u++) xa[sw_dword(lane + 64 * u)] = v[u] * 512.0f;
+            ENG_CFENCE(); lds_st(&c->xa_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
+        }
+        if (T) tl(12);
+        // (f) w2: 24 partial planes of this CU's 12 rows -> the layer's output
+        {
+            float v[5];
+            lds_st(&c->gathering, 1u);
+            sweep<5>(p.P2, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, true, v, c, p.err);
+#pragma unroll
+            for (int u = 0; u < 5; u++) if (lane + 64 * u < NP2 * OWN) tmp[lane + 64 * u] = v[u];
+            ENG_CFENCE();
+            if (lane < OWN) {
+                float a = 0.f;
+                for (int pp = 0; pp < NP2; pp++) a += tmp[pp * OWN + lane];      // fixed order
+                publish(p.H0 + OWN * b + lane, tag, c->h1_own[lane] + a);
+            }
+            lds_st(&c->gathering, 0u);
+        }
+        if (T) tl(13);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CONSUMER waves
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f2 cvt2(unsigned w, bool hi) { return hi ? __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false); }
+// sum_k x'[k] * (q_k / 512) over one Q4_0 block (x' = 512 x: the staged vector is pre-scaled, so this is sum x q exactly as in f32); `init` = -8 sum x
+__device__ __forceinline__ float block_dot(const uint4 q, const f2* __restrict__ x, float init) {
+    f2 a0 = {init, 0.f}, a1 = {0.f, 0.f};
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const unsigned lo = w[d] & 0x0F0F0F0Fu, hi = (w[d] >> 4) & 0x0F0F0F0Fu;
+        a0 = __builtin_elementwise_fma(cvt2(lo, false), x[2 * d], a0);
+        a1 = __builtin_elementwise_fma(cvt2(lo, true), x[2 * d + 1], a1);
+        a0 = __builtin_elementwise_fma(cvt2(hi, false), x[8 + 2 * d], a0);
+        a1 = __builtin_elementwise_fma(cvt2(hi, true), x[8 + 2 * d + 1], a1);
+    }
+    return (a0.x + a0.y) + (a1.x + a1.y);
+}
+
+template <int NB>
+struct XRegs {
+    f2 x[NB][16]; float m8[NB];
+    // chunk(p) = first + step * p of the staged vector xs
+    __device__ __forceinline__ void load(const float* xs, int first, int step) {
+        asm volatile("" : "+v"(first));      // opaque per call: keeps the 8 swizzled piece addresses out of the layer loop's invariants (they cost ~100 VGPRs hoisted)
+        const float4* x4 = reinterpret_cast<const float4*>(xs);
+#pragma unroll
+        for (int p = 0; p < NB; p++) {
+            const int cidx = first + step * p;
+            float s = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const float4 v = x4[sw_piece(cidx, jj)];
+                x[p][2 * jj] = f2{v.x, v.y}; x[p][2 * jj + 1] = f2{v.z, v.w};
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+            m8[p] = s * (-1.0f / 64.0f);        // -8 * sum x = -(8 / 512) * sum x'
+        }
+    }
+};
+
+struct Cons {
+    const EngParams& p; EngCtl* c; unsigned char* lds; int cw, lane; unsigned P; unsigned cbar_n;
+    __device__ __forceinline__ Cons(const EngParams& p_, EngCtl* c_, unsigned char* lds_, int cw_, int lane_) : p(p_), c(c_), lds(lds_), cw(cw_), lane(lane_), P(0), cbar_n(0) {}
+    __device__ __forceinline__ void cbarrier() {
+        cbar_n += NCONS;
+        ENG_CFENCE();
+        if (lane == 0) __hip_atomic_fetch_add(&c->cbar, 1u, RLX, WG);
+        wait_ge(&c->cbar, cbar_n, c, p.err, ERR_CBAR);
+    }
+    // fetch this wave's pass of packet P (+ dp) into registers and release the slot; `real` false: only release (a packet with fewer passes)
+    template <int NB>
+    __device__ __forceinline__ void fetch(unsigned pk, uint4 (&Q)[NB], float (&S)[NB], bool real) {
+        const int slot = (int)(pk % NSLOT); const unsigned k = pk / NSLOT;
+        wait_ge(&c->ring_ready[slot], k + 1u, c, p.err, ERR_RING);
+        if (real) {
+            const unsigned char* base = lds + L_RING + slot * SLOT_BYTES + cw * (NB == 2 ? PASS_WO : PASS_A);
+#pragma unroll
+            for (int i = 0; i < NB; i++) Q[i] = reinterpret_cast<const uint4*>(base)[i * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < NB; i++) S[i] = __half2float(__ushort_as_half(reinterpret_cast<const unsigned short*>(base + NB * 1024)[i * 64 + lane]));
+        }
+        ENG_CFENCE();      // the LDS pipeline executes a wave's instructions in order: the reads above have been served when this add is
+        if (lane == 0) __hip_atomic_fetch_add(&c->ring_done[slot], 1u, RLX, WG);
+    }
+    template <int NB>
+    __device__ __forceinline__ float pass_dot(const uint4 (&Q)[NB], const float (&S)[NB], const XRegs<NB>& xr) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; i++) acc = fmaf(S[i], block_dot(Q[i], xr.x[i], xr.m8[i]), acc);
+        return acc;
+    }
+};
+
+__device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsigned char* lds, int cw, int lane, const Tl& tl) {
+    Cons cs(p, c, lds, cw, lane);
+    const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
+    const float* xs0 = reinterpret_cast<const float*>(lds + L_XS0); const float* xs1 = reinterpret_cast<const float*>(lds + L_XS1);
+    const float* xa = reinterpret_cast<const float*>(lds + L_XA); float* xo = reinterpret_cast<float*>(lds + L_XO);
+    const float* qkvn = reinterpret_cast<const float*>(lds + L_QKVN);
+    float* sc = reinterpret_cast<float*>(lds + L_SC); float4* po = reinterpret_cast<float4*>(lds + L_PO); float* pl = reinterpret_cast<float*>(lds + L_PL);
+    const unsigned tag_base = *p.serial * 64u;
+    const int pos = *p.pos_ptr + p.pos_off;
+    const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0, n_old = pos - j_lo, last_old = max(n_old - 1, 0);
+    const int tid6 = cw * 64 + lane;
+    // RoPE factors of this wave's two q|k|v passes (the same rows in every layer): pass cw is a q pair; pass 6 + cw is q (cw < 2), k (cw 2, 3) or v
+    const int half = EHD / 2;
+    const int pr0 = 8 * s + cw, pr1 = cw < 2 ? 8 * s + 6 + cw : 2 * j + (cw - 2);
+    const float rc0 = p.rope_cos[(size_t)pos * half + pr0], rs0 = p.rope_sin[(size_t)pos * half + pr0];
+    const float rc1 = cw < 4 ? p.rope_cos[(size_t)pos * half + pr1] : 1.0f, rs1 = cw < 4 ? p.rope_sin[(size_t)pos * half + pr1] : 0.0f;
+    const float scale = 1.0f / sqrtf((float)EHD);
+
+    for (int l = 0; l < p.n_layers; l++) {
+        const bool T = l == p.tl_layer && cw == 0;
+        const unsigned tag = tag_base + (unsigned)l + 1u;
+        const EngLayerTab* L = p.layers + l;
+        const gf_p kc = as_g(L->kc) + (size_t)g * p.max_seq * EHD, vc = as_g(L->vc) + (size_t)g * p.max_seq * EHD;
+        // ---------------- q|k|v ----------------
+        {
+            wait_ge(&c->xs0_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+            if (T) tl(0);
+            XRegs<3> xr; xr.load(xs0, lane & 31, 32);
+            const float rstd = c->rstd0;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                uint4 Q[3]; float S[3];
+                cs.fetch<3>(cs.P + t, Q, S, true);
+                float acc = row16_sum_e(cs.pass_dot<3>(Q, S, xr));
+                const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, bq = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
+                const int q = cw + 6 * t;
+                int n; float c_, s_;
+                if (t == 0) { n = 128 * h + 16 * s + 2 * q; c_ = rc0; s_ = rs0; }
+                else if (cw < 2) { n = 128 * h + 16 * s + 2 * q; c_ = rc1; s_ = rs1; }
+                else if (cw < 4) { n = EQD + 128 * g + 4 * j + 2 * (q - 8); c_ = rc1; s_ = rs1; }
+                else { n = EQD + EKD + 128 * g + 4 * j + 2 * (q - 10); c_ = 1.0f; s_ = 0.0f; }
+                const float ra = a * c_ - bq * s_, rb = a * s_ + bq * c_;        // interleaved-pair RoPE (rope.rs:99-141); identity for v
+                if (lane < 2) {
+                    const float v = lane ? rb : ra;
+                    publish(p.G + n + lane, tag, v);
+                    if (t == 1 && cw >= 2) {                                      // k / v rows also go to the cache (read by later steps)
+                        const gf_p dst = (cw < 4 ? kc : vc) + (size_t)pos * EHD + (n & 127) + lane;
+                        *dst = v;
+                    }
+                }
+            }
+            cs.P += QKV_PK;
+            if (T) tl(1);
+        }
+        // ---------------- attention of head h (the old K / V rows do not depend on this step: requested before the q|k|v edge resolves) ----------------
+        {
+            int t6 = tid6; asm volatile("" : "+v"(t6));         // opaque per layer: the 20 row offsets below are recomputed, not carried around the layer loop
+            const int part = t6 & 7, ks = t6 >> 3;              // scores: 8 lanes per key, 48 keys per pass
+            const int kg = t6 >> 5, col = t6 & 31;              // P.V: 12 key groups x 32 float4 columns
+            float4 kpre[4][4], vpre[16];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned ko = (unsigned)(j_lo + min(ks + 48 * u, last_old)) * EHD + part * 16;      // 32-bit lane offset + uniform base: one VGPR per address
+#pragma unroll
+                for (int e = 0; e < 4; e++) kpre[u][e] = ldg4(kc + (ko + 4 * e));
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
+            wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+            if (T) tl(2);
+            float qv[16];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float4 v = *reinterpret_cast<const float4*>(qkvn + part * 16 + 4 * e); qv[4 * e] = v.x; qv[4 * e + 1] = v.y; qv[4 * e + 2] = v.z; qv[4 * e + 3] = v.w; }
+            auto dot16 = [&](const float4 (&kk)[4]) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { sacc = fmaf(qv[4 * e], kk[e].x, sacc); sacc = fmaf(qv[4 * e + 1], kk[e].y, sacc); sacc = fmaf(qv[4 * e + 2], kk[e].z, sacc); sacc = fmaf(qv[4 * e + 3], kk[e].w, sacc); }
+                return group8_sum_e(sacc);
+            };
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float sv = dot16(kpre[u]);
+                const int i = ks + 48 * u;
+                if (part == 0 && i < n_old) sc[i] = sv * scale;
+            }
+            for (int i0 = 192; i0 < n_old; i0 += 48) {           // long contexts
+                const int i = i0 + ks;
+                float4 kk[4];
+                const unsigned ko = (unsigned)(j_lo + min(i, last_old)) * EHD + part * 16;
+#pragma unroll
+                for (int e = 0; e < 4; e++) kk[e] = ldg4(kc + (ko + 4 * e));
+                const float sv = dot16(kk);
+                if (part == 0 && i < n_old) sc[i] = sv * scale;
+            }
+            if (cw == 0) {                                       // the new key (this step's k row)
+                float4 kk[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) kk[e] = *reinterpret_cast<const float4*>(qkvn + 128 + part * 16 + 4 * e);
+                const float sv = dot16(kk);
+                if (tid6 == 0) sc[n_old] = sv * scale;
+            }
+            cs.cbarrier();
+            const int n = n_old + 1;
+            float mx = -INFINITY;
+            for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[i]);
+            mx = wave_max_e(mx);
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f); float lsum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int i = kg + 12 * u;
+                if (i < n_old) {
+                    const float pr = expf(sc[i] - mx); const float4 vv = vpre[u];
+                    o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
+                }
+            }
+            for (int i = 192 + kg; i < n_old; i += 12) {
+                const float pr = expf(sc[i] - mx); const float4 vv = ldg4(vc + ((unsigned)(j_lo + i) * EHD + col * 4));
+                o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
+            }
+            if (kg == 0) {
+                const float pr = expf(sc[n_old] - mx); const float4 vv = *reinterpret_cast<const float4*>(qkvn + 256 + col * 4);
+                o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
+            }
+            po[kg * 32 + col] = o;
+            if (col == 0) pl[kg] = lsum;
+            cs.cbarrier();
+            if (tid6 < EHD) {
+                const float* pof = reinterpret_cast<const float*>(po);
+                float so = 0.f, sl = 0.f;
+#pragma unroll
+                for (int q = 0; q < 12; q++) { so += pof[q * 128 + tid6]; sl += pl[q]; }      // fixed order
+                xo[sw_dword(tid6)] = so * (1.0f / sl) * 512.0f;
+            }
+            cs.cbarrier();
+            if (T) tl(3);
+        }
+        // ---------------- wo: rows [384 s, +384) x head h's 128 columns ----------------
+        {
+            XRegs<2> xr; xr.load(xo, lane & 1, 2);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                uint4 Q[2]; float S[2];
+                cs.fetch<2>(cs.P + t, Q, S, true);
+                float acc = cs.pass_dot<2>(Q, S, xr);
+                acc += dppf<0xB1>(acc);
+                if ((lane & 1) == 0) publish(p.PW + (size_t)h * ED + 384 * s + 32 * (cw + 6 * t) + (lane >> 1), tag, acc);
+            }
+            cs.P += WO_PK;
+            if (T) tl(4);
+        }
+        // ---------------- w1|w3 + SwiGLU ----------------
+        {
+            wait_ge(&c->xs1_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+            if (T) tl(5);
+            XRegs<3> xr; xr.load(xs1, lane & 31, 32);
+            const float rstd = c->rstd1;
+#pragma unroll 2
+            for (int t = 0; t < W13_PK; t++) {
+                uint4 Q[3]; float S[3];
+                cs.fetch<3>(cs.P + t, Q, S, true);
+                float acc = row16_sum_e(cs.pass_dot<3>(Q, S, xr));
+                const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, up = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
+                if (lane == 0) publish(p.A + 1152 * g + 36 * j + cw + 6 * t, tag, silu_e(a) * up);
+            }
+            cs.P += W13_PK;
+            if (T) tl(6);
+        }
+        // ---------------- w2: rows [96 j, +96) x K sub-slice (cw % 3) of the group's 1152 ----------------
+        {
+            wait_ge(&c->xa_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+            if (T) tl(7);
+            const int ts = cw % 3, rh = cw / 3;
+            XRegs<3> xr; xr.load(xa, 12 * ts + (lane & 3), 4);
+#pragma unroll
+            for (int t = 0; t < W2_PK; t++) {
+                uint4 Q[3]; float S[3];
+                cs.fetch<3>(cs.P + t, Q, S, true);
+                float acc = cs.pass_dot<3>(Q, S, xr);
+                acc += dppf<0xB1>(acc); acc += dppf<0x4E>(acc);
+                if ((lane & 3) == 0) publish(p.P2 + (size_t)(3 * g + ts) * ED + 96 * j + 48 * rh + 16 * t + (lane >> 2), tag, acc);
+            }
+            cs.P += W2_PK;
+            if (T) tl(14);
+        }
+    }
+    // ---------------- final norm + tied lm_head + argmax partial ----------------
+    {
+        wait_ge(&c->xs0_flag, (unsigned)p.n_layers + 1u, c, p.err, ERR_STAGE);
+        XRegs<3> xr; xr.load(xs0, lane & 31, 32);
+        const float rstd = c->rstd0;
+        const int npk = lm_packets(p.vocab), npass = lm_passes(p.vocab), row0 = lm_rows_per_cu(p.vocab) * b;
+        float best = -INFINITY; int best_i = 0x7fffffff;
+#pragma unroll 2
+        for (int t = 0; t < npk; t++) {
+            const int q = cw + 6 * t;
+            uint4 Q[3]; float S[3];
+            cs.fetch<3>(cs.P + t, Q, S, q < npass);
+            if (q < npass) {
+                float acc = row16_sum_e(cs.pass_dot<3>(Q, S, xr));
+                const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, b2 = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
+                const int n = row0 + 2 * q;
+                if (p.logits_out && lane < 2) p.logits_out[n + lane] = lane ? b2 : a;
+                if (a > best || (a == best && n < best_i)) { best = a; best_i = n; }
+                if (b2 > best || (b2 == best && n + 1 < best_i)) { best = b2; best_i = n + 1; }
+            }
+        }
+        cs.P += npk;
+        if (lane == 0) { c->best_val[cw] = best; c->best_idx[cw] = best_i; }
+        cs.cbarrier();
+        if (tid6 == 0) {
+            float bv = c->best_val[0]; int bi = c->best_idx[0];
+            for (int w = 1; w < NCONS; w++) { const float v = c->best_val[w]; const int ii = c->best_idx[w]; if (v > bv || (v == bv && ii < bi)) { bv = v; bi = ii; } }
+            p.part_val[b] = bv; p.part_idx[b] = bi;
+        }
+        if (cw == 0) tl(15);
+    }
+}
+
+__global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    EngCtl* c = reinterpret_cast<EngCtl*>(lds + L_CTL);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < (int)(sizeof(EngCtl) / 4)) reinterpret_cast<unsigned*>(c)[tid] = 0u;
+    __syncthreads();
+    Tl tl; tl.on = p.tl != nullptr && lane == 0; tl.buf = p.tl ? p.tl + (size_t)blockIdx.x * 32 : nullptr;
+#ifndef ENG_ROLES
+#define ENG_ROLES 7
+#endif
+    if (wave == 0) {
+        tl(19);
+        if (ENG_ROLES & 1) eng_loader(p, c, (unsigned)(uintptr_t)(lds + L_RING), lane, tl);
+    } else if (wave == 1) {
+        if (ENG_ROLES & 2) eng_comm(p, c, lds, lane, tl);
+        // the last workgroup-independent act of the launch: bump the serial (every workgroup has read it long before any lm_head input existed)
+        if (blockIdx.x == 0 && lane == 0) { const unsigned sv = *p.serial; asm volatile("" ::: "memory"); *p.serial = sv + 1u; }
+    } else {
+        if (ENG_ROLES & 4) eng_consumer(p, c, lds, wave - 2, lane, tl);
+    }
+}
+
+}  // namespace
+
+bool eng_geometry_ok(int D, int n_heads, int n_kv, int hd, int ffn, int vocab, int max_seq) {
+    return D == ED && n_heads == ENH && n_kv == ENKV && hd == EHD && ffn == EF && vocab > 0 && vocab % (2 * NCU) == 0 && max_seq > 0 && max_seq <= SC_MAX;
+}
+size_t eng_stream_bytes(int n_layers, int vocab) { return cu_stream_bytes(n_layers, vocab) * NCU; }
+int eng_lds_bytes() { return L_TOTAL; }
+
+// state block layout (bytes): H0, H1 [3072] | G [6144] | PW [32][3072] | A [9216] | P2 [24][3072] granules, then serial, err
+static constexpr size_t ST_H0 = 0, ST_H1 = ST_H0 + (size_t)ED * 8, ST_G = ST_H1 + (size_t)ED * 8, ST_PW = ST_G + (size_t)(EQD + 2 * EKD) * 8,
+                        ST_A = ST_PW + (size_t)NPW * ED * 8, ST_P2 = ST_A + (size_t)EF * 8, ST_SERIAL = ST_P2 + (size_t)NP2 * ED * 8, ST_ERR = ST_SERIAL + 256, ST_TOTAL = ST_ERR + 256;
+size_t eng_state_bytes() { return ST_TOTAL; }
+void eng_state_carve(unsigned char* st, EngParams* p) {
+    p->H0 = reinterpret_cast<unsigned long long*>(st + ST_H0); p->H1 = reinterpret_cast<unsigned long long*>(st + ST_H1);
+    p->G = reinterpret_cast<unsigned long long*>(st + ST_G); p->PW = reinterpret_cast<unsigned long long*>(st + ST_PW);
+    p->A = reinterpret_cast<unsigned long long*>(st + ST_A); p->P2 = reinterpret_cast<unsigned long long*>(st + ST_P2);
+    p->serial = reinterpret_cast<unsigned*>(st + ST_SERIAL); p->err = reinterpret_cast<unsigned*>(st + ST_ERR);
+}
+
+hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsigned char* stream, int vocab, hipStream_t s) {
+    if (w.fmt != WFMT_Q4_0 || !w.qs || !w.sc) return hipErrorInvalidValue;
+    int passes, off_lines, N, K;
+    switch (op) {
+    case EOP_QKV: passes = QKV_PK * NCONS; off_lines = OFF_QKV; N = EQD + 2 * EKD; K = ED; break;
+    case EOP_WO: passes = WO_PK * NCONS; off_lines = OFF_WO; N = ED; K = EQD; break;
+    case EOP_W13: passes = W13_PK * NCONS; off_lines = OFF_W13; N = 2 * EF; K = ED; break;
+    case EOP_W2: passes = W2_PK * NCONS; off_lines = OFF_W2; N = ED; K = EF; break;
+    case EOP_LM: passes = lm_passes(vocab); off_lines = 0; N = vocab; K = ED; break;
+    default: return hipErrorInvalidValue;
+    }
+    if (w.N != N || w.K != K) return hipErrorInvalidValue;
+    const size_t op_off = op == EOP_LM ? (size_t)n_layers * LAYER_LINES * 1024 : ((size_t)layer * LAYER_LINES + off_lines) * 1024;
+    eng_pack_kernel<<<dim3(passes, NCU), dim3(192), 0, s>>>(w, op, stream, cu_stream_bytes(n_layers, vocab), op_off, vocab);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_engine(const EngParams& p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    decode_engine_kernel<<<dim3(NCU), dim3(NTHR), L_TOTAL, s>>>(p);
+    return hipGetLastError();
+}
+
+}  // namespace vox

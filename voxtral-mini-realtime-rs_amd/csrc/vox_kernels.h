@@ -161,6 +161,37 @@ hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int*
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
 hipError_t launch_gelu(float* x, long n, hipStream_t s);
 
+// ---- persistent decode-step engine (vox_engine.hip): the whole single-stream decode step -- 26 layers + final norm + tied lm_head + argmax
+// partials -- as ONE launch of 256 workgroups (one per CU) x 8 waves: wave 0 streams this CU's slice of every Q4 operator, in consumption order,
+// from a per-CU contiguous copy of the weights into an LDS ring with LDS-DMA (global_load_lds ... nt) and runs ahead of every dependency edge;
+// wave 1 moves activations between CUs as 8-byte {value, tag} write-through granules; waves 2..7 consume the ring (VALU dot products, x in registers).
+// Replaces gguf/model.rs:938-960 (one decode step) for the real Voxtral decoder geometry; everything else keeps the per-operator launches.
+struct EngLayerTab { const float* attn_norm; const float* ffn_norm; const float* ada_mul; float* kc; float* vc; };   // per decoder layer; kc / vc: [n_kv][max_seq][hd]
+struct EngParams {
+    const unsigned char* stream; size_t cu_stride;   // per-CU weight stream (eng_stream_bytes / 256 bytes each)
+    const EngLayerTab* layers; int n_layers;          // device array
+    const float* h_in;                                // [D] the step's input embedding
+    const float* final_norm;                          // [D]
+    const int* pos_ptr; int pos_off;                  // position = *pos_ptr + pos_off
+    const float* rope_cos; const float* rope_sin;     // [max_pos][hd/2]
+    int max_seq, window; float eps;
+    unsigned long long *H0, *H1, *G, *PW, *A, *P2;    // granule buffers: [3072] [3072] [6144] [32][3072] [9216] [24][3072]
+    unsigned* serial; unsigned* err;                  // launch serial (tags never repeat), first failure code (0 = ok)
+    float* part_val; int* part_idx;                   // [256] per-CU argmax partials
+    float* logits_out;                                // optional [vocab]
+    int vocab;
+    unsigned long long* tl; int tl_layer;             // timeline stamps [256][32] of layer tl_layer (null: off)
+    int flags;                                        // bit 0: thin the loader to one fill in flight while this CU's comm wave sweeps
+};
+bool eng_geometry_ok(int D, int n_heads, int n_kv, int hd, int ffn, int vocab, int max_seq);
+size_t eng_stream_bytes(int n_layers, int vocab);     // total bytes of the engine weight copy (all 256 CU streams)
+size_t eng_state_bytes();                             // granule buffers + serial + err
+// op: 0 q|k|v (fused [6144][3072]), 1 wo, 2 w1|w3 (row-interleaved), 3 w2, 4 tied lm_head; layer ignored for op 4
+hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsigned char* stream, int vocab, hipStream_t s);
+void eng_state_carve(unsigned char* state, EngParams* p);      // point p's granule buffers / serial / err into a zero-initialised state block
+hipError_t launch_decode_engine(const EngParams& p, hipStream_t s);
+int eng_lds_bytes();
+
 // ---- timeline instrumentation (measurement builds only, -DVOX_TIMELINE): every q4_gemv / attn_decode launch gets the next slot and its
 // waves stamp s_memrealtime (100 MHz) at 4 points into buf[slot][wave][4]; under graph replay the captured slot is rewritten per replay.
 // Returns hipErrorNotSupported in product builds.
