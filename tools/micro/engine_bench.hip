@@ -1,6 +1,6 @@
 // engine_bench -- stand-alone check + timing of the persistent decode-step engine (csrc/vox_engine.hip) against the per-operator kernels
 // (csrc/vox_kernels.hip: the path the product used before, and keeps for other geometries).  Not product code; links the two object files.
-//   engine_bench [n_layers=26] [pos=100] [reps=40] [tl_layer=-1] [flags=0]
+//   engine_bench [n_layers=26] [pos=100] [reps=40] [tl_layer=-1] [flags=0] [pace_ticks=0]
 // Synthetic Q4 weights (random nibbles, f16 scales ~ N(0, 0.02) weights), random residual stream / KV cache.  Checks, in one run:
 //   * LDS-DMA reaches LDS addresses >= 64 KiB (the ring needs it);
 //   * v_cvt_pk_f32_fp8 of bytes 0..15 is q * 2^-9 (the consumer's nibble conversion);
@@ -86,10 +86,10 @@ static void report(const char* what, const std::vector<float>& ref, const std::v
 }
 
 int main(int argc, char** argv) {
-    const int n_layers = argc > 1 ? atoi(argv[1]) : 26, pos = argc > 2 ? atoi(argv[2]) : 100, reps = argc > 3 ? atoi(argv[3]) : 40, tl_layer = argc > 4 ? atoi(argv[4]) : -1, flags = argc > 5 ? atoi(argv[5]) : 0;
+    const int n_layers = argc > 1 ? atoi(argv[1]) : 26, pos = argc > 2 ? atoi(argv[2]) : 100, reps = argc > 3 ? atoi(argv[3]) : 40, tl_layer = argc > 4 ? atoi(argv[4]) : -1, flags = argc > 5 ? atoi(argv[5]) : 0, pace = argc > 6 ? atoi(argv[6]) : 0;
     const int max_seq = 256, window = 8192;
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
-    printf("device %s, %d CUs; n_layers %d pos %d reps %d; engine LDS %d bytes, stream %.1f MB\n", prop.name, prop.multiProcessorCount, n_layers, pos, reps, eng_lds_bytes(),
+    printf("flags %d pace %d; ", flags, pace); printf("device %s, %d CUs; n_layers %d pos %d reps %d; engine LDS %d bytes, stream %.1f MB\n", prop.name, prop.multiProcessorCount, n_layers, pos, reps, eng_lds_bytes(),
            eng_stream_bytes(n_layers, V) / 1e6);
     hipStream_t s; CHK(hipStreamCreate(&s));
 
@@ -183,7 +183,7 @@ int main(int argc, char** argv) {
     unsigned long long* tlbuf = dalloc<unsigned long long>(256 * 32); CHK(hipMemset(tlbuf, 0, 256 * 32 * 8));
     EngParams ep{}; ep.stream = stream; ep.cu_stride = sbytes / 256; ep.layers = d_tab; ep.n_layers = n_layers; ep.h_in = h_in; ep.final_norm = final_norm; ep.pos_ptr = d_pos; ep.pos_off = 0;
     ep.rope_cos = rope_c; ep.rope_sin = rope_s; ep.max_seq = max_seq; ep.window = window; ep.eps = eps; eng_state_carve(state, &ep);
-    ep.part_val = pv2; ep.part_idx = pi2; ep.logits_out = logits_eng; ep.vocab = V; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = flags;
+    ep.part_val = pv2; ep.part_idx = pi2; ep.logits_out = logits_eng; ep.vocab = V; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = flags; ep.pace_ticks = pace;
     CHK(hipStreamSynchronize(s));
     auto check_err = [&](const char* when) { unsigned e; CHK(hipMemcpy(&e, ep.err, 4, hipMemcpyDeviceToHost)); if (e) printf("ENGINE ERROR after %s: code %u, workgroup %u, tag bits %u\n", when, e & 0xff, (e >> 8) & 0xff, e >> 16); return e; };
     CHK(launch_decode_engine(ep, s));

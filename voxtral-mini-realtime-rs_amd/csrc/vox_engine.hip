@@ -129,9 +129,17 @@ __device__ __forceinline__ gcf_p as_g(const float* p) { return (gcf_p)(uintptr_t
 __device__ __forceinline__ gf_p as_g(float* p) { return (gf_p)(uintptr_t)p; }
 __device__ __forceinline__ float4 ldg4(gcf_p p) { const fv4 v = *(const __attribute__((address_space(1))) fv4*)p; return make_float4(v.x, v.y, v.z, v.w); }
 #define RLX __ATOMIC_RELAXED
+// granule / table loads are addressed as (wave-uniform base in SGPRs) + (32-bit byte offset in ONE VGPR): with 64-bit per-lane pointers a 48-load
+// sweep carries 80 address VGPRs around its retry loop
 #define WG __HIP_MEMORY_SCOPE_WORKGROUP
 #define AG __HIP_MEMORY_SCOPE_AGENT
 // control words are wave-uniform: readfirstlane keeps every branch on them a scalar branch (all 64 lanes stay active for the DPP reductions)
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000); }
+// granule load: buffer_load_dwordx2 ... offen sc1 (aux 16 = sc1: served by L2 / memory, never by this CU's L1)
+__device__ __forceinline__ u64 ld_gran(srd_t srd, unsigned idx) { const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(srd, (int)(idx * 8u), 0, 16); return ((u64)v.y << 32) | (u64)v.x; }
+__device__ __forceinline__ float ld_gf(srd_t srd, unsigned idx) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, (int)(idx * 4u), 0, 0)); }
 __device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, RLX, WG)); }
 __device__ __forceinline__ void lds_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, RLX, WG); }
 
@@ -200,7 +208,7 @@ struct Loader {
     EngCtl* c; unsigned* err; unsigned ring_lds; unsigned voff;
     int nfl = 0, s0 = 0, l0 = 0, s1 = 0, l1 = 0;    // packets issued, not yet published: (s0, l0) oldest, (s1, l1) newer -- plain scalars (an indexed array would live in scratch = VMEM)
     unsigned P = 0;                                   // next packet index
-    bool thin;
+    bool thin; u64 pace = 0, t_last = 0;              // pace: minimum s_memrealtime ticks between two packet issues (0: none)
     __device__ __forceinline__ void publish_slot(int slot) { lds_st(&c->ring_ready[slot], lds_ld(&c->ring_ready[slot]) + 1u); }   // only this wave writes ring_ready
     __device__ __forceinline__ void flush() {
         if (nfl == 2) { wait_vmcnt(l1); publish_slot(s0); s0 = s1; l0 = l1; nfl = 1; }
@@ -213,6 +221,7 @@ struct Loader {
             wait_ge(&c->ring_done[slot], NCONS * k, c, err, ERR_SLOT);
         }
         if (thin && lds_ld(&c->gathering)) flush();    // one fill outstanding while this CU's comm wave sweeps (MI355X_MICROARCH.md gather-pass)
+        if (pace) { while (wall_clock64() - t_last < pace) __builtin_amdgcn_s_sleep(1); t_last = wall_clock64(); }
         const unsigned dst = ring_lds + (unsigned)slot * SLOT_BYTES;
 #pragma unroll 1
         for (int i = 0; i < lines; i++) dma_line(voff, dst + (unsigned)i * 1024u, gsrc + (u64)i * 1024u);
@@ -224,20 +233,22 @@ struct Loader {
 };
 
 __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsigned ring_lds, int lane, const Tl& tl) {
-    Loader ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = (p.flags & 1) != 0;
+    Loader ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = (p.flags & 1) != 0; ld.pace = (u64)p.pace_ticks;
+    const bool fake = (p.flags & 2) != 0;      // diagnostic: every packet re-reads the CU's first 21 KiB (L2 hits, no HBM traffic; results wrong)
     const u64 base = (u64)(p.stream + (size_t)blockIdx.x * p.cu_stride);
     for (int l = 0; l < p.n_layers; l++) {
         const u64 lb = base + (u64)l * LAYER_LINES * 1024;
         if (l == p.tl_layer) tl(16);
-        for (int k = 0; k < QKV_PK; k++) ld.issue(lb + (u64)(OFF_QKV + k * LINES_A) * 1024, LINES_A);
-        for (int k = 0; k < WO_PK; k++) ld.issue(lb + (u64)(OFF_WO + k * LINES_WO) * 1024, LINES_WO);
-        for (int k = 0; k < W13_PK; k++) ld.issue(lb + (u64)(OFF_W13 + k * LINES_A) * 1024, LINES_A);
-        for (int k = 0; k < W2_PK; k++) ld.issue(lb + (u64)(OFF_W2 + k * LINES_A) * 1024, LINES_A);
+        for (int k = 0; k < QKV_PK; k++) ld.issue(fake ? base : lb + (u64)(OFF_QKV + k * LINES_A) * 1024, LINES_A);
+        for (int k = 0; k < WO_PK; k++) ld.issue(fake ? base : lb + (u64)(OFF_WO + k * LINES_WO) * 1024, LINES_WO);
+        for (int k = 0; k < W13_PK; k++) ld.issue(fake ? base : lb + (u64)(OFF_W13 + k * LINES_A) * 1024, LINES_A);
+        for (int k = 0; k < W2_PK; k++) ld.issue(fake ? base : lb + (u64)(OFF_W2 + k * LINES_A) * 1024, LINES_A);
         if (l == p.tl_layer) tl(17);
     }
     const u64 lmb = base + (u64)p.n_layers * LAYER_LINES * 1024;
     const int npk = lm_packets(p.vocab);
-    for (int k = 0; k < npk; k++) ld.issue(lmb + (u64)k * LINES_A * 1024, LINES_A);
+    ld.pace = 0;                                   // no edge left to protect: the lm_head streams at full depth
+    for (int k = 0; k < npk; k++) ld.issue(fake ? base : lmb + (u64)k * LINES_A * 1024, LINES_A);
     ld.flush();
     tl(18);
 }
@@ -260,12 +271,13 @@ __device__ __forceinline__ bool sweep_bail(u64& t0, unsigned tag, EngCtl* c, uns
     return false;
 }
 template <int N, class IdxF, class ProbeF>
-__device__ __forceinline__ bool sweep(const u64* __restrict__ base, unsigned tag, IdxF idx, ProbeF probe, bool do_probe, float (&v)[N], EngCtl* c, unsigned* err) {
+__device__ __forceinline__ bool sweep(const u64* base_, unsigned bytes, unsigned tag, IdxF idx, ProbeF probe, bool do_probe, float (&v)[N], EngCtl* c, unsigned* err) {
+    const srd_t base = make_srd(base_, bytes);
     u64 t0 = 0;
     if (do_probe) {
-        const u64* pp = base + probe();
+        const unsigned pi = (unsigned)probe();
         for (;;) {
-            const u64 gq = __hip_atomic_load(pp, RLX, AG);
+            const u64 gq = ld_gran(base, pi);
             if (__all((unsigned)(gq >> 32) == tag)) break;
             if (sweep_bail(t0, tag, c, err)) return false;
         }
@@ -274,7 +286,7 @@ __device__ __forceinline__ bool sweep(const u64* __restrict__ base, unsigned tag
         bool ok = true;
 #pragma unroll
         for (int u = 0; u < N; u++) {
-            const u64 gq = __hip_atomic_load(base + idx(u), RLX, AG);
+            const u64 gq = ld_gran(base, (unsigned)idx(u));
             v[u] = __uint_as_float((unsigned)gq);
             ok &= (unsigned)(gq >> 32) == tag;
         }
@@ -285,50 +297,72 @@ __device__ __forceinline__ bool sweep(const u64* __restrict__ base, unsigned tag
 __device__ __forceinline__ void publish(u64* g, unsigned tag, float v) { __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), RLX, AG); }
 
 // gather the full residual stream (plain h_in for layer 0, granules otherwise), stage x = h * gamma (* mul) * 512 swizzled, rstd, this CU's own rows.
-// 48 values per lane in 3 chunks of 16: the first chunk is polled until its producers are done, the others are then (almost always) complete.
+// 48 granules per lane, all requested in ONE round trip (three dependent 16-load round trips cost 2 us more per all-gather); while the producers
+// are still working only the probe granule is polled.  The norm weights are requested first: they do not depend on the edge.  Values are staged as
+// they arrive (a failed pass stages garbage that the next pass overwrites; the flag is raised by the caller after success).
+template <bool PLAIN>
 __device__ __forceinline__ void comm_stage_h(const EngParams& p, EngCtl* c, int lane, const u64* src, unsigned tag, const float* plain,
                                              const float* gamma_, const float* mul_, float* xs, float* rstd_out, float* own) {
-    const gcf_p gamma = as_g(gamma_), mul = as_g(mul_), plain_g = as_g(plain);
-    float ss = 0.f;
+    constexpr int NU = ED / 64;
+    asm volatile("" : "+v"(lane));      // opaque per call: the 48 swizzled staging addresses are computed where they are used, not carried across the layer loop
+    const srd_t gamma = make_srd(gamma_, ED * 4u), mul = make_srd(mul_ ? mul_ : gamma_, ED * 4u), plain_g = make_srd(PLAIN ? (const void*)plain : (const void*)gamma_, ED * 4u), srcd = make_srd(src, ED * 8u);
+    const bool has_mul = mul_ != nullptr;
+    float gm[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) { const unsigned k = (unsigned)lane + 64u * u; gm[u] = ld_gf(gamma, k) * (has_mul ? ld_gf(mul, k) : 1.0f) * 512.0f; }
     const int b12 = (int)blockIdx.x * OWN;
-#pragma unroll 1
-    for (int ch = 0; ch < 3; ch++) {
-        const int k0 = lane + 1024 * ch;
-        float gm[16], hv[16];
+    float ss = 0.f;
+    u64 t0 = 0;
+    if (!PLAIN) {      // probe: a row of every 4th producer
+        for (;;) {
+            const u64 gq = ld_gran(srcd, 48u * (unsigned)lane);
+            if (__all((unsigned)(gq >> 32) == tag)) break;
+            if (sweep_bail(t0, tag, c, p.err)) break;
+        }
+    }
+    u64 raw[NU];
+    for (;;) {
+        bool ok = true;
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int k = k0 + 64 * u; gm[u] = gamma[k] * (mul ? mul[k] : 1.0f); }
-        if (plain) {
-#pragma unroll
-            for (int u = 0; u < 16; u++) hv[u] = plain_g[k0 + 64 * u];
-        } else {
-            sweep<16>(src, tag, [&](int u) { return k0 + 64 * u; }, [&]() { return 48 * lane; }, ch == 0, hv, c, p.err);      // probe: a row of every 4th producer
+        for (int u = 0; u < NU; u++) {
+            if (PLAIN) raw[u] = (u64)__float_as_uint(ld_gf(plain_g, (unsigned)lane + 64u * u)) | ((u64)tag << 32);
+            else raw[u] = ld_gran(srcd, (unsigned)lane + 64u * u);
         }
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const int k = k0 + 64 * u;
-            ss = fmaf(hv[u], hv[u], ss);
-            xs[sw_dword(k)] = hv[u] * gm[u] * 512.0f;
-            if ((unsigned)(k - b12) < (unsigned)OWN) own[k - b12] = hv[u];
-        }
+        for (int u = 0; u < NU; u++) ok &= (unsigned)(raw[u] >> 32) == tag;
+        if (PLAIN || __all(ok)) break;
+        if (sweep_bail(t0, tag, c, p.err)) break;
+    }
+    // staging happens after the retry loop, so its 48 swizzled LDS addresses are computed one by one instead of living around the loop
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int k = lane + 64 * u;
+        const float hv = __uint_as_float((unsigned)raw[u]);
+        ss = fmaf(hv, hv, ss);
+        xs[sw_dword(k)] = hv * gm[u];
+        if ((unsigned)(k - b12) < (unsigned)OWN) own[k - b12] = hv;
     }
     ss = wave_sum_e(ss);
     if (lane == 0) *rstd_out = 1.0f / sqrtf(ss / (float)ED + p.eps);
 }
 
-__device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned char* lds, int lane, const Tl& tl) {
+__device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned char* lds, const int lane0, const Tl& tl) {
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3);
     float* xs0 = reinterpret_cast<float*>(lds + L_XS0); float* xs1 = reinterpret_cast<float*>(lds + L_XS1);
     float* xa = reinterpret_cast<float*>(lds + L_XA); float* qkvn = reinterpret_cast<float*>(lds + L_QKVN);
     float* tmp = reinterpret_cast<float*>(lds + L_TMP);
     const unsigned tag_base = *p.serial * 64u;
+    const bool PROBE_SMALL = (p.flags & 4) != 0;      // small edges (<= 18 granules per lane) are polled with the sweep itself: one round trip less per edge
     for (int l = 0; l <= p.n_layers; l++) {
+        int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per layer: lane-derived addresses are recomputed, not carried around the loop in VGPRs
         const bool T = l == p.tl_layer;
         const unsigned tag = tag_base + (unsigned)l + 1u;           // written during layer l
         // (a) the layer's input (the previous layer's output: tag - 1)
         lds_st(&c->gathering, 1u);
         const bool last = l == p.n_layers;
         const EngLayerTab* L = p.layers + (last ? 0 : l);
-        comm_stage_h(p, c, lane, p.H0, tag - 1u, l == 0 ? p.h_in : nullptr, last ? p.final_norm : L->attn_norm, nullptr, xs0, &c->rstd0, c->h_own);
+        if (l == 0) comm_stage_h<true>(p, c, lane, p.H0, tag - 1u, p.h_in, L->attn_norm, nullptr, xs0, &c->rstd0, c->h_own);
+        else comm_stage_h<false>(p, c, lane, p.H0, tag - 1u, nullptr, last ? p.final_norm : L->attn_norm, nullptr, xs0, &c->rstd0, c->h_own);
         ENG_CFENCE(); lds_st(&c->xs0_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
         if (T) tl(8);
         if (last) break;
@@ -336,8 +370,8 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
         {
             float v[6];
             lds_st(&c->gathering, 1u);
-            sweep<6>(p.G, tag, [&](int u) { const int i = lane + 64 * u, seg = i >> 7, e = i & 127; return seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e; },
-                     [&]() { return lane < 32 ? EQD + 128 * g + 4 * lane : EQD + EKD + 128 * g + 4 * (lane - 32); }, true, v, c, p.err);      // probe: a k / v row of each of the group's 32 CUs
+            sweep<6>(p.G, (EQD + 2 * EKD) * 8u, tag, [&](int u) { const int i = lane + 64 * u, seg = i >> 7, e = i & 127; return seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e; },
+                     [&]() { return lane < 32 ? EQD + 128 * g + 4 * lane : EQD + EKD + 128 * g + 4 * (lane - 32); }, PROBE_SMALL, v, c, p.err);      // probe: a k / v row of each of the group's 32 CUs
 #pragma unroll
             for (int u = 0; u < 6; u++) qkvn[lane + 64 * u] = v[u];
             ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
@@ -347,7 +381,7 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
         {
             float v[6];
             lds_st(&c->gathering, 1u);
-            sweep<6>(p.PW, tag, [&](int u) { const int i = lane + 64 * u, hh = i / OWN, r = i - hh * OWN; return hh * ED + OWN * b + r; }, [&]() { return (lane & 31) * ED + OWN * b; }, true, v, c, p.err);
+            sweep<6>(p.PW, NPW * ED * 8u, tag, [&](int u) { const int i = lane + 64 * u, hh = i / OWN, r = i - hh * OWN; return hh * ED + OWN * b + r; }, [&]() { return (lane & 31) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
 #pragma unroll
             for (int u = 0; u < 6; u++) tmp[lane + 64 * u] = v[u];
             ENG_CFENCE();
@@ -363,14 +397,14 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
         if (T) tl(10);
         // (d) all-gather of the post-attention residual stream -> w1|w3 input (RMSNorm weight and Ada scale folded)
         lds_st(&c->gathering, 1u);
-        comm_stage_h(p, c, lane, p.H1, tag, nullptr, L->ffn_norm, L->ada_mul, xs1, &c->rstd1, c->h1_own);
+        comm_stage_h<false>(p, c, lane, p.H1, tag, nullptr, L->ffn_norm, L->ada_mul, xs1, &c->rstd1, c->h1_own);
         ENG_CFENCE(); lds_st(&c->xs1_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
         if (T) tl(11);
         // (e) the XCD group's 1152 SwiGLU outputs -> w2 input
         {
             float v[18];
             lds_st(&c->gathering, 1u);
-            sweep<18>(p.A, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, true, v, c, p.err);      // probe: the last output of each CU of the group
+            sweep<18>(p.A, EF * 8u, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, PROBE_SMALL, v, c, p.err);      // probe: the last output of each CU of the group
 #pragma unroll
             for (int u = 0; u < 18; u++) xa[sw_dword(lane + 64 * u)] = v[u] * 512.0f;
             ENG_CFENCE(); lds_st(&c->xa_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
@@ -380,7 +414,7 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
         {
             float v[5];
             lds_st(&c->gathering, 1u);
-            sweep<5>(p.P2, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, true, v, c, p.err);
+            sweep<5>(p.P2, NP2 * ED * 8u, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
 #pragma unroll
             for (int u = 0; u < 5; u++) if (lane + 64 * u < NP2 * OWN) tmp[lane + 64 * u] = v[u];
             ENG_CFENCE();
@@ -469,6 +503,20 @@ struct Cons {
     }
 };
 
+// N passes of one operator, software-pipelined: the next pass's weights are requested from the ring (LDS) before the current pass is multiplied,
+// so the LDS round trip (and the ring flag poll) overlaps the ~150 VALU instructions of a pass.  epi(t, acc): acc = this lane's partial row sum of pass t.
+template <int NB, int N, class Epi>
+__device__ __forceinline__ void run_passes(Cons& cs, const XRegs<NB>& xr, Epi epi) {
+    uint4 Q[2][NB]; float S[2][NB];
+    cs.fetch<NB>(cs.P, Q[0], S[0], true);
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        if (t + 1 < N) cs.fetch<NB>(cs.P + t + 1, Q[(t + 1) & 1], S[(t + 1) & 1], true);
+        epi(t, cs.pass_dot<NB>(Q[t & 1], S[t & 1], xr));
+    }
+    cs.P += N;
+}
+
 __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsigned char* lds, int cw, int lane, const Tl& tl) {
     Cons cs(p, c, lds, cw, lane);
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
@@ -498,11 +546,8 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             if (T) tl(0);
             XRegs<3> xr; xr.load(xs0, lane & 31, 32);
             const float rstd = c->rstd0;
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                uint4 Q[3]; float S[3];
-                cs.fetch<3>(cs.P + t, Q, S, true);
-                float acc = row16_sum_e(cs.pass_dot<3>(Q, S, xr));
+            run_passes<3, QKV_PK>(cs, xr, [&](int t, float acc0) {
+                const float acc = row16_sum_e(acc0);
                 const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, bq = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
                 const int q = cw + 6 * t;
                 int n; float c_, s_;
@@ -519,8 +564,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                         *dst = v;
                     }
                 }
-            }
-            cs.P += QKV_PK;
+            });
             if (T) tl(1);
         }
         // ---------------- attention of head h (the old K / V rows do not depend on this step: requested before the q|k|v edge resolves) ----------------
@@ -608,15 +652,10 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         // ---------------- wo: rows [384 s, +384) x head h's 128 columns ----------------
         {
             XRegs<2> xr; xr.load(xo, lane & 1, 2);
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                uint4 Q[2]; float S[2];
-                cs.fetch<2>(cs.P + t, Q, S, true);
-                float acc = cs.pass_dot<2>(Q, S, xr);
+            run_passes<2, WO_PK>(cs, xr, [&](int t, float acc) {
                 acc += dppf<0xB1>(acc);
                 if ((lane & 1) == 0) publish(p.PW + (size_t)h * ED + 384 * s + 32 * (cw + 6 * t) + (lane >> 1), tag, acc);
-            }
-            cs.P += WO_PK;
+            });
             if (T) tl(4);
         }
         // ---------------- w1|w3 + SwiGLU ----------------
@@ -625,15 +664,11 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             if (T) tl(5);
             XRegs<3> xr; xr.load(xs1, lane & 31, 32);
             const float rstd = c->rstd1;
-#pragma unroll 2
-            for (int t = 0; t < W13_PK; t++) {
-                uint4 Q[3]; float S[3];
-                cs.fetch<3>(cs.P + t, Q, S, true);
-                float acc = row16_sum_e(cs.pass_dot<3>(Q, S, xr));
+            run_passes<3, W13_PK>(cs, xr, [&](int t, float acc0) {
+                const float acc = row16_sum_e(acc0);
                 const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, up = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
                 if (lane == 0) publish(p.A + 1152 * g + 36 * j + cw + 6 * t, tag, silu_e(a) * up);
-            }
-            cs.P += W13_PK;
+            });
             if (T) tl(6);
         }
         // ---------------- w2: rows [96 j, +96) x K sub-slice (cw % 3) of the group's 1152 ----------------
@@ -642,15 +677,10 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             if (T) tl(7);
             const int ts = cw % 3, rh = cw / 3;
             XRegs<3> xr; xr.load(xa, 12 * ts + (lane & 3), 4);
-#pragma unroll
-            for (int t = 0; t < W2_PK; t++) {
-                uint4 Q[3]; float S[3];
-                cs.fetch<3>(cs.P + t, Q, S, true);
-                float acc = cs.pass_dot<3>(Q, S, xr);
+            run_passes<3, W2_PK>(cs, xr, [&](int t, float acc) {
                 acc += dppf<0xB1>(acc); acc += dppf<0x4E>(acc);
                 if ((lane & 3) == 0) publish(p.P2 + (size_t)(3 * g + ts) * ED + 96 * j + 48 * rh + 16 * t + (lane >> 2), tag, acc);
-            }
-            cs.P += W2_PK;
+            });
             if (T) tl(14);
         }
     }
@@ -661,19 +691,22 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         const float rstd = c->rstd0;
         const int npk = lm_packets(p.vocab), npass = lm_passes(p.vocab), row0 = lm_rows_per_cu(p.vocab) * b;
         float best = -INFINITY; int best_i = 0x7fffffff;
-#pragma unroll 2
-        for (int t = 0; t < npk; t++) {
-            const int q = cw + 6 * t;
-            uint4 Q[3]; float S[3];
-            cs.fetch<3>(cs.P + t, Q, S, q < npass);
-            if (q < npass) {
-                float acc = row16_sum_e(cs.pass_dot<3>(Q, S, xr));
-                const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, b2 = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
-                const int n = row0 + 2 * q;
-                if (p.logits_out && lane < 2) p.logits_out[n + lane] = lane ? b2 : a;
-                if (a > best || (a == best && n < best_i)) { best = a; best_i = n; }
-                if (b2 > best || (b2 == best && n + 1 < best_i)) { best = b2; best_i = n + 1; }
-            }
+        auto lm_epi = [&](int q, float acc0) {
+            const float acc = row16_sum_e(acc0);
+            const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, b2 = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
+            const int n = row0 + 2 * q;
+            if (p.logits_out && lane < 2) p.logits_out[n + lane] = lane ? b2 : a;
+            if (a > best || (a == best && n < best_i)) { best = a; best_i = n; }
+            if (b2 > best || (b2 == best && n + 1 < best_i)) { best = b2; best_i = n + 1; }
+        };
+        uint4 Q0[3], Q1[3]; float S0[3], S1[3];      // two register sets: the next pass is requested from the ring before the current one is multiplied
+        cs.fetch<3>(cs.P, Q0, S0, cw < npass);
+        for (int t = 0; t < npk; t += 2) {
+            const int q0 = cw + 6 * t, q1 = q0 + 6;
+            if (t + 1 < npk) cs.fetch<3>(cs.P + t + 1, Q1, S1, q1 < npass);
+            if (q0 < npass) lm_epi(q0, cs.pass_dot<3>(Q0, S0, xr));
+            if (t + 2 < npk) cs.fetch<3>(cs.P + t + 2, Q0, S0, q1 + 6 < npass);
+            if (t + 1 < npk && q1 < npass) lm_epi(q1, cs.pass_dot<3>(Q1, S1, xr));
         }
         cs.P += npk;
         if (lane == 0) { c->best_val[cw] = best; c->best_idx[cw] = best_i; }
