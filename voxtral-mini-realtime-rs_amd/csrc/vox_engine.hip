@@ -232,23 +232,27 @@ struct Loader {
     }
 };
 
+// ONE rolled loop over the step's packets (the kernel's code must stay small: the instruction cache is shared by two CUs and every layer walks
+// through all three roles' code -- a 100 KB kernel ran 13 % slower than a 68 KB one with the same structure)
 __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsigned ring_lds, int lane, const Tl& tl) {
     Loader ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = (p.flags & 1) != 0; ld.pace = (u64)p.pace_ticks;
     const bool fake = (p.flags & 2) != 0;      // diagnostic: every packet re-reads the CU's first 21 KiB (L2 hits, no HBM traffic; results wrong)
     const u64 base = (u64)(p.stream + (size_t)blockIdx.x * p.cu_stride);
-    for (int l = 0; l < p.n_layers; l++) {
-        const u64 lb = base + (u64)l * LAYER_LINES * 1024;
-        if (l == p.tl_layer) tl(16);
-        for (int k = 0; k < QKV_PK; k++) ld.issue(fake ? base : lb + (u64)(OFF_QKV + k * LINES_A) * 1024, LINES_A);
-        for (int k = 0; k < WO_PK; k++) ld.issue(fake ? base : lb + (u64)(OFF_WO + k * LINES_WO) * 1024, LINES_WO);
-        for (int k = 0; k < W13_PK; k++) ld.issue(fake ? base : lb + (u64)(OFF_W13 + k * LINES_A) * 1024, LINES_A);
-        for (int k = 0; k < W2_PK; k++) ld.issue(fake ? base : lb + (u64)(OFF_W2 + k * LINES_A) * 1024, LINES_A);
-        if (l == p.tl_layer) tl(17);
+    constexpr int PK_LAYER = QKV_PK + WO_PK + W13_PK + W2_PK;
+    const unsigned n_layer_pk = (unsigned)p.n_layers * PK_LAYER, n_pk = n_layer_pk + (unsigned)lm_packets(p.vocab);
+    unsigned l = 0, r = 0;                       // layer, packet within the layer
+    u64 off = 0;                                 // byte offset of the next packet in this CU's stream (packets are stored in consumption order)
+#pragma unroll 1
+    for (unsigned pk = 0; pk < n_pk; pk++) {
+        int lines = LINES_A;
+        if (pk < n_layer_pk) {
+            if (r >= QKV_PK && r < QKV_PK + WO_PK) lines = LINES_WO;
+            if (r == 0 && (int)l == p.tl_layer) tl(16);
+        } else ld.pace = 0;                      // no edge left to protect: the lm_head streams at full depth
+        ld.issue(fake ? base : base + off, lines);
+        off += (u64)lines * 1024u;
+        if (++r == PK_LAYER) { if ((int)l == p.tl_layer) tl(17); r = 0; l++; }
     }
-    const u64 lmb = base + (u64)p.n_layers * LAYER_LINES * 1024;
-    const int npk = lm_packets(p.vocab);
-    ld.pace = 0;                                   // no edge left to protect: the lm_head streams at full depth
-    for (int k = 0; k < npk; k++) ld.issue(fake ? base : lmb + (u64)k * LINES_A * 1024, LINES_A);
     ld.flush();
     tl(18);
 }
@@ -256,9 +260,6 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
 // ------------------------------------------------------------------------------------------------
 // COMM wave
 // ------------------------------------------------------------------------------------------------
-// Sweep N granules per lane until every tag matches (values in v).  Bounded.  While the producers are still working the wave polls ONE granule per
-// lane (`probe(lane)`: one granule of every producer, or of every n-th) instead of the whole chunk: 256 CUs polling 8 KB each would put TB/s of
-// coherent reads next to the weight stream (MI355X_MICROARCH.md polling-cost).
 __device__ __forceinline__ bool sweep_bail(u64& t0, unsigned tag, EngCtl* c, unsigned* err) {
     if (lds_ld(&c->dead)) return true;
     if (t0 == 0) t0 = wall_clock64();
@@ -270,6 +271,9 @@ __device__ __forceinline__ bool sweep_bail(u64& t0, unsigned tag, EngCtl* c, uns
     __builtin_amdgcn_s_sleep(2);
     return false;
 }
+// Sweep N granules per lane until every tag matches (values in v).  Bounded.  With `do_probe` the wave first polls ONE granule per lane (`probe()`:
+// one granule of every producer, or of every n-th) instead of the whole set: 256 CUs polling 8 KB each would put TB/s of coherent reads next to the
+// weight stream (MI355X_MICROARCH.md polling-cost).
 template <int N, class IdxF, class ProbeF>
 __device__ __forceinline__ bool sweep(const u64* base_, unsigned bytes, unsigned tag, IdxF idx, ProbeF probe, bool do_probe, float (&v)[N], EngCtl* c, unsigned* err) {
     const srd_t base = make_srd(base_, bytes);
@@ -296,136 +300,113 @@ __device__ __forceinline__ bool sweep(const u64* base_, unsigned bytes, unsigned
 }
 __device__ __forceinline__ void publish(u64* g, unsigned tag, float v) { __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), RLX, AG); }
 
-// gather the full residual stream (plain h_in for layer 0, granules otherwise), stage x = h * gamma (* mul) * 512 swizzled, rstd, this CU's own rows.
-// 48 granules per lane, all requested in ONE round trip (three dependent 16-load round trips cost 2 us more per all-gather); while the producers
-// are still working only the probe granule is polled.  The norm weights are requested first: they do not depend on the edge.  Values are staged as
-// they arrive (a failed pass stages garbage that the next pass overwrites; the flag is raised by the caller after success).
-template <bool PLAIN>
-__device__ __forceinline__ void comm_stage_h(const EngParams& p, EngCtl* c, int lane, const u64* src, unsigned tag, const float* plain,
-                                             const float* gamma_, const float* mul_, float* xs, float* rstd_out, float* own) {
-    constexpr int NU = ED / 64;
-    asm volatile("" : "+v"(lane));      // opaque per call: the 48 swizzled staging addresses are computed where they are used, not carried across the layer loop
-    const srd_t gamma = make_srd(gamma_, ED * 4u), mul = make_srd(mul_ ? mul_ : gamma_, ED * 4u), plain_g = make_srd(PLAIN ? (const void*)plain : (const void*)gamma_, ED * 4u), srcd = make_srd(src, ED * 8u);
+// All-gather of a residual stream (3072 granules): stage x = h * gamma (* mul) * 512 swizzled, rstd, this CU's own rows.  48 granules per lane in
+// AG_CH chunks (rolled loop: one copy of the code); the first chunk starts with a probe of one row of every 4th producer.  The norm weights of a chunk
+// are requested before its granules: they do not depend on the edge.
+constexpr int AG_CH = 3, AG_N = ED / 64 / AG_CH;
+__device__ __forceinline__ void comm_stage_h(const EngParams& p, EngCtl* c, int lane, const u64* src, unsigned tag, const float* gamma_, const float* mul_,
+                                             float* xs, float* rstd_out, float* own) {
+    asm volatile("" : "+v"(lane));      // opaque per call: swizzled staging addresses are computed where they are used, not carried in VGPRs
+    const srd_t gamma = make_srd(gamma_, ED * 4u), mul = make_srd(mul_ ? mul_ : gamma_, ED * 4u);
     const bool has_mul = mul_ != nullptr;
-    float gm[NU];
-#pragma unroll
-    for (int u = 0; u < NU; u++) { const unsigned k = (unsigned)lane + 64u * u; gm[u] = ld_gf(gamma, k) * (has_mul ? ld_gf(mul, k) : 1.0f) * 512.0f; }
     const int b12 = (int)blockIdx.x * OWN;
     float ss = 0.f;
-    u64 t0 = 0;
-    if (!PLAIN) {      // probe: a row of every 4th producer
-        for (;;) {
-            const u64 gq = ld_gran(srcd, 48u * (unsigned)lane);
-            if (__all((unsigned)(gq >> 32) == tag)) break;
-            if (sweep_bail(t0, tag, c, p.err)) break;
+#pragma unroll 1
+    for (int ch = 0; ch < AG_CH; ch++) {
+        const int k0 = lane + 64 * AG_N * ch;
+        float gm[AG_N], hv[AG_N];
+#pragma unroll
+        for (int u = 0; u < AG_N; u++) gm[u] = ld_gf(gamma, (unsigned)(k0 + 64 * u)) * 512.0f;
+        if (has_mul) {
+#pragma unroll
+            for (int u = 0; u < AG_N; u++) gm[u] *= ld_gf(mul, (unsigned)(k0 + 64 * u));
         }
-    }
-    u64 raw[NU];
-    for (;;) {
-        bool ok = true;
+        sweep<AG_N>(src, ED * 8u, tag, [&](int u) { return k0 + 64 * u; }, [&]() { return 48 * lane; }, ch == 0, hv, c, p.err);
 #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            if (PLAIN) raw[u] = (u64)__float_as_uint(ld_gf(plain_g, (unsigned)lane + 64u * u)) | ((u64)tag << 32);
-            else raw[u] = ld_gran(srcd, (unsigned)lane + 64u * u);
+        for (int u = 0; u < AG_N; u++) {
+            const int k = k0 + 64 * u;
+            ss = fmaf(hv[u], hv[u], ss);
+            xs[sw_dword(k)] = hv[u] * gm[u];
+            if ((unsigned)(k - b12) < (unsigned)OWN) own[k - b12] = hv[u];
         }
-#pragma unroll
-        for (int u = 0; u < NU; u++) ok &= (unsigned)(raw[u] >> 32) == tag;
-        if (PLAIN || __all(ok)) break;
-        if (sweep_bail(t0, tag, c, p.err)) break;
-    }
-    // staging happens after the retry loop, so its 48 swizzled LDS addresses are computed one by one instead of living around the loop
-#pragma unroll
-    for (int u = 0; u < NU; u++) {
-        const int k = lane + 64 * u;
-        const float hv = __uint_as_float((unsigned)raw[u]);
-        ss = fmaf(hv, hv, ss);
-        xs[sw_dword(k)] = hv * gm[u];
-        if ((unsigned)(k - b12) < (unsigned)OWN) own[k - b12] = hv;
     }
     ss = wave_sum_e(ss);
     if (lane == 0) *rstd_out = 1.0f / sqrtf(ss / (float)ED + p.eps);
 }
 
+// ONE rolled loop over the 2 L + 1 all-gathers of the step: stage 2 l = layer l's input (-> q|k|v), stage 2 l + 1 = its post-attention stream (-> w1|w3),
+// stage 2 L = the final norm's input (-> lm_head); the small edges that follow each all-gather hang off the loop body.
 __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned char* lds, const int lane0, const Tl& tl) {
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3);
     float* xs0 = reinterpret_cast<float*>(lds + L_XS0); float* xs1 = reinterpret_cast<float*>(lds + L_XS1);
     float* xa = reinterpret_cast<float*>(lds + L_XA); float* qkvn = reinterpret_cast<float*>(lds + L_QKVN);
     float* tmp = reinterpret_cast<float*>(lds + L_TMP);
-    const unsigned tag_base = *p.serial * 64u;
-    const bool PROBE_SMALL = (p.flags & 4) != 0;      // small edges (<= 18 granules per lane) are polled with the sweep itself: one round trip less per edge
-    for (int l = 0; l <= p.n_layers; l++) {
-        int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per layer: lane-derived addresses are recomputed, not carried around the loop in VGPRs
-        const bool T = l == p.tl_layer;
-        const unsigned tag = tag_base + (unsigned)l + 1u;           // written during layer l
-        // (a) the layer's input (the previous layer's output: tag - 1)
-        lds_st(&c->gathering, 1u);
-        const bool last = l == p.n_layers;
+    const unsigned tag_base = (*p.serial + 1u) * 64u;     // tags of this launch: tag_base (the step's input) .. tag_base + n_layers; never 0, never reused
+    const bool PROBE_SMALL = (p.flags & 4) != 0;          // small edges (<= 18 granules per lane) are polled with the sweep itself unless this is set
+    // the step's input joins the granule protocol: every CU publishes its 12 rows of h_in, so layer 0 takes the same all-gather as every other layer
+    if (lane0 < OWN) publish(p.H0 + OWN * b + lane0, tag_base, as_g(p.h_in)[OWN * b + lane0]);
+#pragma unroll 1
+    for (int st = 0; st <= 2 * p.n_layers; st++) {
+        int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per stage: lane-derived addresses are recomputed, not carried around the loop in VGPRs
+        const int l = st >> 1; const bool odd = st & 1, last = st == 2 * p.n_layers, T = l == p.tl_layer;
+        const unsigned tag = tag_base + (unsigned)l + 1u;       // written during layer l
         const EngLayerTab* L = p.layers + (last ? 0 : l);
-        if (l == 0) comm_stage_h<true>(p, c, lane, p.H0, tag - 1u, p.h_in, L->attn_norm, nullptr, xs0, &c->rstd0, c->h_own);
-        else comm_stage_h<false>(p, c, lane, p.H0, tag - 1u, nullptr, last ? p.final_norm : L->attn_norm, nullptr, xs0, &c->rstd0, c->h_own);
-        ENG_CFENCE(); lds_st(&c->xs0_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
-        if (T) tl(8);
-        if (last) break;
-        // (b) this step's q_h, k_g, v_g rows
-        {
-            float v[6];
-            lds_st(&c->gathering, 1u);
-            sweep<6>(p.G, (EQD + 2 * EKD) * 8u, tag, [&](int u) { const int i = lane + 64 * u, seg = i >> 7, e = i & 127; return seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e; },
-                     [&]() { return lane < 32 ? EQD + 128 * g + 4 * lane : EQD + EKD + 128 * g + 4 * (lane - 32); }, PROBE_SMALL, v, c, p.err);      // probe: a k / v row of each of the group's 32 CUs
-#pragma unroll
-            for (int u = 0; u < 6; u++) qkvn[lane + 64 * u] = v[u];
-            ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
-        }
-        if (T) tl(9);
-        // (c) wo: 32 partial planes of this CU's 12 rows -> residual stream after attention
-        {
-            float v[6];
-            lds_st(&c->gathering, 1u);
-            sweep<6>(p.PW, NPW * ED * 8u, tag, [&](int u) { const int i = lane + 64 * u, hh = i / OWN, r = i - hh * OWN; return hh * ED + OWN * b + r; }, [&]() { return (lane & 31) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
-#pragma unroll
-            for (int u = 0; u < 6; u++) tmp[lane + 64 * u] = v[u];
-            ENG_CFENCE();
-            if (lane < OWN) {
-                float a = 0.f;
-                for (int hh = 0; hh < NPW; hh++) a += tmp[hh * OWN + lane];      // fixed order
-                const float h1 = c->h_own[lane] + a;
-                c->h1_own[lane] = h1;
-                publish(p.H1 + OWN * b + lane, tag, h1);
-            }
-            lds_st(&c->gathering, 0u);
-        }
-        if (T) tl(10);
-        // (d) all-gather of the post-attention residual stream -> w1|w3 input (RMSNorm weight and Ada scale folded)
         lds_st(&c->gathering, 1u);
-        comm_stage_h<false>(p, c, lane, p.H1, tag, nullptr, L->ffn_norm, L->ada_mul, xs1, &c->rstd1, c->h1_own);
-        ENG_CFENCE(); lds_st(&c->xs1_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
-        if (T) tl(11);
-        // (e) the XCD group's 1152 SwiGLU outputs -> w2 input
-        {
-            float v[18];
-            lds_st(&c->gathering, 1u);
-            sweep<18>(p.A, EF * 8u, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, PROBE_SMALL, v, c, p.err);      // probe: the last output of each CU of the group
+        if (odd) comm_stage_h(p, c, lane, p.H1, tag, L->ffn_norm, L->ada_mul, xs1, &c->rstd1, c->h1_own);
+        else comm_stage_h(p, c, lane, p.H0, tag - 1u, last ? p.final_norm : L->attn_norm, nullptr, xs0, &c->rstd0, c->h_own);
+        ENG_CFENCE(); lds_st(odd ? &c->xs1_flag : &c->xs0_flag, (unsigned)l + 1u);
+        if (T) tl(odd ? 11 : 8);
+        if (last) { lds_st(&c->gathering, 0u); break; }
+        if (!odd) {
+            {   // this step's q_h, k_g, v_g rows
+                float v[6];
+                sweep<6>(p.G, (EQD + 2 * EKD) * 8u, tag, [&](int u) { const int i = lane + 64 * u, seg = i >> 7, e = i & 127; return seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e; },
+                         [&]() { return lane < 32 ? EQD + 128 * g + 4 * lane : EQD + EKD + 128 * g + 4 * (lane - 32); }, PROBE_SMALL, v, c, p.err);      // probe: a k / v row of each of the group's 32 CUs
 #pragma unroll
-            for (int u = 0; u < 18; u++) xa[sw_dword(lane + 64 * u)] = v[u] * 512.0f;
-            ENG_CFENCE(); lds_st(&c->xa_flag, (unsigned)l + 1u); lds_st(&c->gathering, 0u);
-        }
-        if (T) tl(12);
-        // (f) w2: 24 partial planes of this CU's 12 rows -> the layer's output
-        {
-            float v[5];
-            lds_st(&c->gathering, 1u);
-            sweep<5>(p.P2, NP2 * ED * 8u, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
-#pragma unroll
-            for (int u = 0; u < 5; u++) if (lane + 64 * u < NP2 * OWN) tmp[lane + 64 * u] = v[u];
-            ENG_CFENCE();
-            if (lane < OWN) {
-                float a = 0.f;
-                for (int pp = 0; pp < NP2; pp++) a += tmp[pp * OWN + lane];      // fixed order
-                publish(p.H0 + OWN * b + lane, tag, c->h1_own[lane] + a);
+                for (int u = 0; u < 6; u++) qkvn[lane + 64 * u] = v[u];
+                ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u);
             }
-            lds_st(&c->gathering, 0u);
+            if (T) tl(9);
+            {   // wo: 32 partial planes of this CU's 12 rows -> residual stream after attention
+                float v[6];
+                sweep<6>(p.PW, NPW * ED * 8u, tag, [&](int u) { const int i = lane + 64 * u, hh = i / OWN, r = i - hh * OWN; return hh * ED + OWN * b + r; }, [&]() { return (lane & 31) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
+#pragma unroll
+                for (int u = 0; u < 6; u++) tmp[lane + 64 * u] = v[u];
+                ENG_CFENCE();
+                if (lane < OWN) {
+                    float a = 0.f;
+#pragma unroll 4
+                    for (int hh = 0; hh < NPW; hh++) a += tmp[hh * OWN + lane];      // fixed order
+                    const float h1 = c->h_own[lane] + a;
+                    publish(p.H1 + OWN * b + lane, tag, h1);
+                }
+            }
+            if (T) tl(10);
+        } else {
+            {   // the XCD group's 1152 SwiGLU outputs -> w2 input
+                float v[18];
+                sweep<18>(p.A, EF * 8u, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, PROBE_SMALL, v, c, p.err);      // probe: the last output of each CU of the group
+#pragma unroll
+                for (int u = 0; u < 18; u++) xa[sw_dword(lane + 64 * u)] = v[u] * 512.0f;
+                ENG_CFENCE(); lds_st(&c->xa_flag, (unsigned)l + 1u);
+            }
+            if (T) tl(12);
+            {   // w2: 24 partial planes of this CU's 12 rows -> the layer's output
+                float v[5];
+                sweep<5>(p.P2, NP2 * ED * 8u, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
+#pragma unroll
+                for (int u = 0; u < 5; u++) if (lane + 64 * u < NP2 * OWN) tmp[lane + 64 * u] = v[u];
+                ENG_CFENCE();
+                if (lane < OWN) {
+                    float a = 0.f;
+#pragma unroll 4
+                    for (int pp = 0; pp < NP2; pp++) a += tmp[pp * OWN + lane];      // fixed order
+                    publish(p.H0 + OWN * b + lane, tag, c->h1_own[lane] + a);
+                }
+            }
+            if (T) tl(13);
         }
-        if (T) tl(13);
+        lds_st(&c->gathering, 0u);
     }
 }
 
@@ -453,7 +434,7 @@ struct XRegs {
     f2 x[NB][16]; float m8[NB];
     // chunk(p) = first + step * p of the staged vector xs
     __device__ __forceinline__ void load(const float* xs, int first, int step) {
-        asm volatile("" : "+v"(first));      // opaque per call: keeps the 8 swizzled piece addresses out of the layer loop's invariants (they cost ~100 VGPRs hoisted)
+        asm volatile("" : "+v"(first));      // opaque per call: keeps the 8 swizzled piece addresses out of the loop invariants (they cost ~100 VGPRs hoisted)
         const float4* x4 = reinterpret_cast<const float4*>(xs);
 #pragma unroll
         for (int p = 0; p < NB; p++) {
@@ -479,7 +460,7 @@ struct Cons {
         if (lane == 0) __hip_atomic_fetch_add(&c->cbar, 1u, RLX, WG);
         wait_ge(&c->cbar, cbar_n, c, p.err, ERR_CBAR);
     }
-    // fetch this wave's pass of packet P (+ dp) into registers and release the slot; `real` false: only release (a packet with fewer passes)
+    // fetch this wave's pass of packet pk into registers and release the slot; `real` false: only release (a packet with fewer passes)
     template <int NB>
     __device__ __forceinline__ void fetch(unsigned pk, uint4 (&Q)[NB], float (&S)[NB], bool real) {
         const int slot = (int)(pk % NSLOT); const unsigned k = pk / NSLOT;
@@ -503,221 +484,203 @@ struct Cons {
     }
 };
 
-// N passes of one operator, software-pipelined: the next pass's weights are requested from the ring (LDS) before the current pass is multiplied,
-// so the LDS round trip (and the ring flag poll) overlaps the ~150 VALU instructions of a pass.  epi(t, acc): acc = this lane's partial row sum of pass t.
-template <int NB, int N, class Epi>
-__device__ __forceinline__ void run_passes(Cons& cs, const XRegs<NB>& xr, Epi epi) {
-    uint4 Q[2][NB]; float S[2][NB];
-    cs.fetch<NB>(cs.P, Q[0], S[0], true);
-#pragma unroll
-    for (int t = 0; t < N; t++) {
-        if (t + 1 < N) cs.fetch<NB>(cs.P + t + 1, Q[(t + 1) & 1], S[(t + 1) & 1], true);
-        epi(t, cs.pass_dot<NB>(Q[t & 1], S[t & 1], xr));
-    }
-    cs.P += N;
-}
-
-__device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsigned char* lds, int cw, int lane, const Tl& tl) {
-    Cons cs(p, c, lds, cw, lane);
+// ONE rolled loop over the step's 4 L + 1 operators (one copy of the pass body in the instruction cache): item 4 l + op, op in EOP_* order
+// (q|k|v, attention + wo, w1|w3, w2), then the lm_head.  Passes are software-pipelined: the next pass's weights are requested from the ring (LDS)
+// before the current pass is multiplied.
+__device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsigned char* lds, int cw, const int lane0, const Tl& tl) {
+    Cons cs(p, c, lds, cw, lane0);
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
     const float* xs0 = reinterpret_cast<const float*>(lds + L_XS0); const float* xs1 = reinterpret_cast<const float*>(lds + L_XS1);
     const float* xa = reinterpret_cast<const float*>(lds + L_XA); float* xo = reinterpret_cast<float*>(lds + L_XO);
     const float* qkvn = reinterpret_cast<const float*>(lds + L_QKVN);
     float* sc = reinterpret_cast<float*>(lds + L_SC); float4* po = reinterpret_cast<float4*>(lds + L_PO); float* pl = reinterpret_cast<float*>(lds + L_PL);
-    const unsigned tag_base = *p.serial * 64u;
+    const unsigned tag_base = (*p.serial + 1u) * 64u;
     const int pos = *p.pos_ptr + p.pos_off;
     const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0, n_old = pos - j_lo, last_old = max(n_old - 1, 0);
-    const int tid6 = cw * 64 + lane;
     // RoPE factors of this wave's two q|k|v passes (the same rows in every layer): pass cw is a q pair; pass 6 + cw is q (cw < 2), k (cw 2, 3) or v
     const int half = EHD / 2;
     const int pr0 = 8 * s + cw, pr1 = cw < 2 ? 8 * s + 6 + cw : 2 * j + (cw - 2);
     const float rc0 = p.rope_cos[(size_t)pos * half + pr0], rs0 = p.rope_sin[(size_t)pos * half + pr0];
     const float rc1 = cw < 4 ? p.rope_cos[(size_t)pos * half + pr1] : 1.0f, rs1 = cw < 4 ? p.rope_sin[(size_t)pos * half + pr1] : 0.0f;
     const float scale = 1.0f / sqrtf((float)EHD);
+    const int n_items = 4 * p.n_layers, npass_lm = lm_passes(p.vocab), row0_lm = lm_rows_per_cu(p.vocab) * b;
+    float best = -INFINITY; int best_i = 0x7fffffff;
 
-    for (int l = 0; l < p.n_layers; l++) {
-        const bool T = l == p.tl_layer && cw == 0;
+#pragma unroll 1
+    for (int it = 0; it <= n_items; it++) {
+        int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per item: lane-derived addresses are recomputed, not carried around the loop in VGPRs
+        const int l = it >> 2, op = it == n_items ? (int)EOP_LM : (it & 3);
+        const bool T = l == p.tl_layer && cw == 0 && op != EOP_LM;
         const unsigned tag = tag_base + (unsigned)l + 1u;
-        const EngLayerTab* L = p.layers + l;
-        const gf_p kc = as_g(L->kc) + (size_t)g * p.max_seq * EHD, vc = as_g(L->vc) + (size_t)g * p.max_seq * EHD;
-        // ---------------- q|k|v ----------------
-        {
-            wait_ge(&c->xs0_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
-            if (T) tl(0);
-            XRegs<3> xr; xr.load(xs0, lane & 31, 32);
-            const float rstd = c->rstd0;
-            run_passes<3, QKV_PK>(cs, xr, [&](int t, float acc0) {
-                const float acc = row16_sum_e(acc0);
-                const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, bq = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
-                const int q = cw + 6 * t;
-                int n; float c_, s_;
-                if (t == 0) { n = 128 * h + 16 * s + 2 * q; c_ = rc0; s_ = rs0; }
-                else if (cw < 2) { n = 128 * h + 16 * s + 2 * q; c_ = rc1; s_ = rs1; }
-                else if (cw < 4) { n = EQD + 128 * g + 4 * j + 2 * (q - 8); c_ = rc1; s_ = rs1; }
-                else { n = EQD + EKD + 128 * g + 4 * j + 2 * (q - 10); c_ = 1.0f; s_ = 0.0f; }
-                const float ra = a * c_ - bq * s_, rb = a * s_ + bq * c_;        // interleaved-pair RoPE (rope.rs:99-141); identity for v
-                if (lane < 2) {
-                    const float v = lane ? rb : ra;
-                    publish(p.G + n + lane, tag, v);
-                    if (t == 1 && cw >= 2) {                                      // k / v rows also go to the cache (read by later steps)
-                        const gf_p dst = (cw < 4 ? kc : vc) + (size_t)pos * EHD + (n & 127) + lane;
-                        *dst = v;
+        if (op == EOP_WO) {
+            const EngLayerTab* L = p.layers + l;
+            const gf_p kc = as_g(L->kc) + (size_t)g * p.max_seq * EHD, vc = as_g(L->vc) + (size_t)g * p.max_seq * EHD;
+            // ---------------- attention of head h (the old K / V rows do not depend on this step: requested before the q|k|v edge resolves) ----------------
+            {
+                const int t6 = cw * 64 + lane;
+                const int part = t6 & 7, ks = t6 >> 3;              // scores: 8 lanes per key, 48 keys per pass
+                const int kg = t6 >> 5, col = t6 & 31;              // P.V: 12 key groups x 32 float4 columns
+                float4 kpre[4][4], vpre[16];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned ko = (unsigned)(j_lo + min(ks + 48 * u, last_old)) * EHD + part * 16;      // 32-bit lane offset + uniform base: one VGPR per address
+#pragma unroll
+                    for (int e = 0; e < 4; e++) kpre[u][e] = ldg4(kc + (ko + 4 * e));
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
+                wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+                if (T) tl(2);
+                float qv[16];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float4 v = *reinterpret_cast<const float4*>(qkvn + part * 16 + 4 * e); qv[4 * e] = v.x; qv[4 * e + 1] = v.y; qv[4 * e + 2] = v.z; qv[4 * e + 3] = v.w; }
+                auto dot16 = [&](const float4 (&kk)[4]) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { sacc = fmaf(qv[4 * e], kk[e].x, sacc); sacc = fmaf(qv[4 * e + 1], kk[e].y, sacc); sacc = fmaf(qv[4 * e + 2], kk[e].z, sacc); sacc = fmaf(qv[4 * e + 3], kk[e].w, sacc); }
+                    return group8_sum_e(sacc);
+                };
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float sv = dot16(kpre[u]);
+                    const int i = ks + 48 * u;
+                    if (part == 0 && i < n_old) sc[i] = sv * scale;
+                }
+                for (int i0 = 192; i0 < n_old; i0 += 48) {           // long contexts
+                    const int i = i0 + ks;
+                    float4 kk[4];
+                    const unsigned ko = (unsigned)(j_lo + min(i, last_old)) * EHD + part * 16;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) kk[e] = ldg4(kc + (ko + 4 * e));
+                    const float sv = dot16(kk);
+                    if (part == 0 && i < n_old) sc[i] = sv * scale;
+                }
+                if (cw == 0) {                                       // the new key (this step's k row)
+                    float4 kk[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) kk[e] = *reinterpret_cast<const float4*>(qkvn + 128 + part * 16 + 4 * e);
+                    const float sv = dot16(kk);
+                    if (t6 == 0) sc[n_old] = sv * scale;
+                }
+                cs.cbarrier();
+                const int n = n_old + 1;
+                float mx = -INFINITY;
+                for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[i]);
+                mx = wave_max_e(mx);
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f); float lsum = 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int i = kg + 12 * u;
+                    if (i < n_old) {
+                        const float pr = expf(sc[i] - mx); const float4 vv = vpre[u];
+                        o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
                     }
                 }
-            });
-            if (T) tl(1);
-        }
-        // ---------------- attention of head h (the old K / V rows do not depend on this step: requested before the q|k|v edge resolves) ----------------
-        {
-            int t6 = tid6; asm volatile("" : "+v"(t6));         // opaque per layer: the 20 row offsets below are recomputed, not carried around the layer loop
-            const int part = t6 & 7, ks = t6 >> 3;              // scores: 8 lanes per key, 48 keys per pass
-            const int kg = t6 >> 5, col = t6 & 31;              // P.V: 12 key groups x 32 float4 columns
-            float4 kpre[4][4], vpre[16];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const unsigned ko = (unsigned)(j_lo + min(ks + 48 * u, last_old)) * EHD + part * 16;      // 32-bit lane offset + uniform base: one VGPR per address
-#pragma unroll
-                for (int e = 0; e < 4; e++) kpre[u][e] = ldg4(kc + (ko + 4 * e));
-            }
-#pragma unroll
-            for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
-            wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
-            if (T) tl(2);
-            float qv[16];
-#pragma unroll
-            for (int e = 0; e < 4; e++) { const float4 v = *reinterpret_cast<const float4*>(qkvn + part * 16 + 4 * e); qv[4 * e] = v.x; qv[4 * e + 1] = v.y; qv[4 * e + 2] = v.z; qv[4 * e + 3] = v.w; }
-            auto dot16 = [&](const float4 (&kk)[4]) {
-                float sacc = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; e++) { sacc = fmaf(qv[4 * e], kk[e].x, sacc); sacc = fmaf(qv[4 * e + 1], kk[e].y, sacc); sacc = fmaf(qv[4 * e + 2], kk[e].z, sacc); sacc = fmaf(qv[4 * e + 3], kk[e].w, sacc); }
-                return group8_sum_e(sacc);
-            };
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float sv = dot16(kpre[u]);
-                const int i = ks + 48 * u;
-                if (part == 0 && i < n_old) sc[i] = sv * scale;
-            }
-            for (int i0 = 192; i0 < n_old; i0 += 48) {           // long contexts
-                const int i = i0 + ks;
-                float4 kk[4];
-                const unsigned ko = (unsigned)(j_lo + min(i, last_old)) * EHD + part * 16;
-#pragma unroll
-                for (int e = 0; e < 4; e++) kk[e] = ldg4(kc + (ko + 4 * e));
-                const float sv = dot16(kk);
-                if (part == 0 && i < n_old) sc[i] = sv * scale;
-            }
-            if (cw == 0) {                                       // the new key (this step's k row)
-                float4 kk[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) kk[e] = *reinterpret_cast<const float4*>(qkvn + 128 + part * 16 + 4 * e);
-                const float sv = dot16(kk);
-                if (tid6 == 0) sc[n_old] = sv * scale;
-            }
-            cs.cbarrier();
-            const int n = n_old + 1;
-            float mx = -INFINITY;
-            for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[i]);
-            mx = wave_max_e(mx);
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f); float lsum = 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int i = kg + 12 * u;
-                if (i < n_old) {
-                    const float pr = expf(sc[i] - mx); const float4 vv = vpre[u];
+                for (int i = 192 + kg; i < n_old; i += 12) {
+                    const float pr = expf(sc[i] - mx); const float4 vv = ldg4(vc + ((unsigned)(j_lo + i) * EHD + col * 4));
                     o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
                 }
-            }
-            for (int i = 192 + kg; i < n_old; i += 12) {
-                const float pr = expf(sc[i] - mx); const float4 vv = ldg4(vc + ((unsigned)(j_lo + i) * EHD + col * 4));
-                o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
-            }
-            if (kg == 0) {
-                const float pr = expf(sc[n_old] - mx); const float4 vv = *reinterpret_cast<const float4*>(qkvn + 256 + col * 4);
-                o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
-            }
-            po[kg * 32 + col] = o;
-            if (col == 0) pl[kg] = lsum;
-            cs.cbarrier();
-            if (tid6 < EHD) {
-                const float* pof = reinterpret_cast<const float*>(po);
-                float so = 0.f, sl = 0.f;
+                if (kg == 0) {
+                    const float pr = expf(sc[n_old] - mx); const float4 vv = *reinterpret_cast<const float4*>(qkvn + 256 + col * 4);
+                    o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
+                }
+                po[kg * 32 + col] = o;
+                if (col == 0) pl[kg] = lsum;
+                cs.cbarrier();
+                if (t6 < EHD) {
+                    const float* pof = reinterpret_cast<const float*>(po);
+                    float so = 0.f, sl = 0.f;
 #pragma unroll
-                for (int q = 0; q < 12; q++) { so += pof[q * 128 + tid6]; sl += pl[q]; }      // fixed order
-                xo[sw_dword(tid6)] = so * (1.0f / sl) * 512.0f;
+                    for (int q = 0; q < 12; q++) { so += pof[q * 128 + t6]; sl += pl[q]; }      // fixed order
+                    xo[sw_dword(t6)] = so * (1.0f / sl) * 512.0f;
+                }
+                cs.cbarrier();
+                if (T) tl(3);
             }
-            cs.cbarrier();
-            if (T) tl(3);
+            // ---------------- wo: rows [384 s, +384) x head h's 128 columns ----------------
+            {
+                XRegs<2> xr; xr.load(xo, lane & 1, 2);
+                uint4 Qa[2], Qb[2]; float Sa[2], Sb[2];
+                cs.fetch<2>(cs.P, Qa, Sa, true);
+#pragma unroll 1
+                for (int t = 0; t < WO_PK; t++) {
+                    if (t + 1 < WO_PK) cs.fetch<2>(cs.P + t + 1, Qb, Sb, true);
+                    float acc = cs.pass_dot<2>(Qa, Sa, xr);
+                    acc += dppf<0xB1>(acc);
+                    if ((lane & 1) == 0) publish(p.PW + (size_t)h * ED + 384 * s + 32 * (cw + 6 * t) + (lane >> 1), tag, acc);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) { Qa[i] = Qb[i]; Sa[i] = Sb[i]; }
+                }
+                cs.P += WO_PK;
+                if (T) tl(4);
+            }
+            continue;
         }
-        // ---------------- wo: rows [384 s, +384) x head h's 128 columns ----------------
-        {
-            XRegs<2> xr; xr.load(xo, lane & 1, 2);
-            run_passes<2, WO_PK>(cs, xr, [&](int t, float acc) {
-                acc += dppf<0xB1>(acc);
-                if ((lane & 1) == 0) publish(p.PW + (size_t)h * ED + 384 * s + 32 * (cw + 6 * t) + (lane >> 1), tag, acc);
-            });
-            if (T) tl(4);
+        // ---------------- the 3-plane operators: q|k|v, w1|w3, w2, lm_head ----------------
+        unsigned* flag; unsigned target; const float* xs; int first, step, n_pass; float rstd;
+        if (op == EOP_QKV) { flag = &c->xs0_flag; target = (unsigned)l + 1u; xs = xs0; first = lane & 31; step = 32; n_pass = QKV_PK; }
+        else if (op == EOP_W13) { flag = &c->xs1_flag; target = (unsigned)l + 1u; xs = xs1; first = lane & 31; step = 32; n_pass = W13_PK; }
+        else if (op == EOP_W2) { flag = &c->xa_flag; target = (unsigned)l + 1u; xs = xa; first = 12 * (cw % 3) + (lane & 3); step = 4; n_pass = W2_PK; }
+        else { flag = &c->xs0_flag; target = (unsigned)p.n_layers + 1u; xs = xs0; first = lane & 31; step = 32; n_pass = lm_packets(p.vocab); }
+        wait_ge(flag, target, c, p.err, ERR_STAGE);
+        if (T) tl(op == EOP_QKV ? 0 : op == EOP_W13 ? 5 : 7);
+        rstd = op == EOP_W13 ? c->rstd1 : op == EOP_W2 ? 1.0f : c->rstd0;
+        XRegs<3> xr; xr.load(xs, first, step);
+        const EngLayerTab* L = p.layers + (op == EOP_LM ? 0 : l);
+        uint4 Qa[3], Qb[3]; float Sa[3], Sb[3];
+        cs.fetch<3>(cs.P, Qa, Sa, op != EOP_LM || cw < npass_lm);
+#pragma unroll 1
+        for (int t = 0; t < n_pass; t++) {
+            const int q = cw + 6 * t;                                  // this wave's pass of packet t
+            if (t + 1 < n_pass) cs.fetch<3>(cs.P + t + 1, Qb, Sb, op != EOP_LM || q + 6 < npass_lm);
+            if (op != EOP_LM || q < npass_lm) {
+                float acc = cs.pass_dot<3>(Qa, Sa, xr);
+                if (op == EOP_W2) {
+                    acc += dppf<0xB1>(acc); acc += dppf<0x4E>(acc);
+                    if ((lane & 3) == 0) publish(p.P2 + (size_t)(3 * g + cw % 3) * ED + 96 * j + 48 * (cw / 3) + 16 * t + (lane >> 2), tag, acc);
+                } else {
+                    acc = row16_sum_e(acc);
+                    const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, bq = (rlf(acc, 32) + rlf(acc, 48)) * rstd;      // the pass's two rows
+                    if (op == EOP_QKV) {
+                        int n; float c_, s_;
+                        if (t == 0) { n = 128 * h + 16 * s + 2 * q; c_ = rc0; s_ = rs0; }
+                        else if (cw < 2) { n = 128 * h + 16 * s + 2 * q; c_ = rc1; s_ = rs1; }
+                        else if (cw < 4) { n = EQD + 128 * g + 4 * j + 2 * (q - 8); c_ = rc1; s_ = rs1; }
+                        else { n = EQD + EKD + 128 * g + 4 * j + 2 * (q - 10); c_ = 1.0f; s_ = 0.0f; }
+                        const float ra = a * c_ - bq * s_, rb = a * s_ + bq * c_;        // interleaved-pair RoPE (rope.rs:99-141); identity for v
+                        if (lane < 2) {
+                            const float v = lane ? rb : ra;
+                            publish(p.G + n + lane, tag, v);
+                            if (t == 1 && cw >= 2) {                                      // k / v rows also go to the cache (read by later steps)
+                                const gf_p dst = as_g(cw < 4 ? L->kc : L->vc) + (size_t)g * p.max_seq * EHD + (size_t)pos * EHD + (n & 127) + lane;
+                                *dst = v;
+                            }
+                        }
+                    } else if (op == EOP_W13) {
+                        if (lane == 0) publish(p.A + 1152 * g + 36 * j + q, tag, silu_e(a) * bq);
+                    } else {
+                        const int n = row0_lm + 2 * q;
+                        if (p.logits_out && lane < 2) p.logits_out[n + lane] = lane ? bq : a;
+                        if (a > best || (a == best && n < best_i)) { best = a; best_i = n; }
+                        if (bq > best || (bq == best && n + 1 < best_i)) { best = bq; best_i = n + 1; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) { Qa[i] = Qb[i]; Sa[i] = Sb[i]; }
         }
-        // ---------------- w1|w3 + SwiGLU ----------------
-        {
-            wait_ge(&c->xs1_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
-            if (T) tl(5);
-            XRegs<3> xr; xr.load(xs1, lane & 31, 32);
-            const float rstd = c->rstd1;
-            run_passes<3, W13_PK>(cs, xr, [&](int t, float acc0) {
-                const float acc = row16_sum_e(acc0);
-                const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, up = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
-                if (lane == 0) publish(p.A + 1152 * g + 36 * j + cw + 6 * t, tag, silu_e(a) * up);
-            });
-            if (T) tl(6);
-        }
-        // ---------------- w2: rows [96 j, +96) x K sub-slice (cw % 3) of the group's 1152 ----------------
-        {
-            wait_ge(&c->xa_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
-            if (T) tl(7);
-            const int ts = cw % 3, rh = cw / 3;
-            XRegs<3> xr; xr.load(xa, 12 * ts + (lane & 3), 4);
-            run_passes<3, W2_PK>(cs, xr, [&](int t, float acc) {
-                acc += dppf<0xB1>(acc); acc += dppf<0x4E>(acc);
-                if ((lane & 3) == 0) publish(p.P2 + (size_t)(3 * g + ts) * ED + 96 * j + 48 * rh + 16 * t + (lane >> 2), tag, acc);
-            });
-            if (T) tl(14);
-        }
+        cs.P += (unsigned)n_pass;
+        if (T) tl(op == EOP_QKV ? 1 : op == EOP_W13 ? 6 : 14);
     }
-    // ---------------- final norm + tied lm_head + argmax partial ----------------
-    {
-        wait_ge(&c->xs0_flag, (unsigned)p.n_layers + 1u, c, p.err, ERR_STAGE);
-        XRegs<3> xr; xr.load(xs0, lane & 31, 32);
-        const float rstd = c->rstd0;
-        const int npk = lm_packets(p.vocab), npass = lm_passes(p.vocab), row0 = lm_rows_per_cu(p.vocab) * b;
-        float best = -INFINITY; int best_i = 0x7fffffff;
-        auto lm_epi = [&](int q, float acc0) {
-            const float acc = row16_sum_e(acc0);
-            const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, b2 = (rlf(acc, 32) + rlf(acc, 48)) * rstd;
-            const int n = row0 + 2 * q;
-            if (p.logits_out && lane < 2) p.logits_out[n + lane] = lane ? b2 : a;
-            if (a > best || (a == best && n < best_i)) { best = a; best_i = n; }
-            if (b2 > best || (b2 == best && n + 1 < best_i)) { best = b2; best_i = n + 1; }
-        };
-        uint4 Q0[3], Q1[3]; float S0[3], S1[3];      // two register sets: the next pass is requested from the ring before the current one is multiplied
-        cs.fetch<3>(cs.P, Q0, S0, cw < npass);
-        for (int t = 0; t < npk; t += 2) {
-            const int q0 = cw + 6 * t, q1 = q0 + 6;
-            if (t + 1 < npk) cs.fetch<3>(cs.P + t + 1, Q1, S1, q1 < npass);
-            if (q0 < npass) lm_epi(q0, cs.pass_dot<3>(Q0, S0, xr));
-            if (t + 2 < npk) cs.fetch<3>(cs.P + t + 2, Q0, S0, q1 + 6 < npass);
-            if (t + 1 < npk && q1 < npass) lm_epi(q1, cs.pass_dot<3>(Q1, S1, xr));
-        }
-        cs.P += npk;
-        if (lane == 0) { c->best_val[cw] = best; c->best_idx[cw] = best_i; }
-        cs.cbarrier();
-        if (tid6 == 0) {
-            float bv = c->best_val[0]; int bi = c->best_idx[0];
-            for (int w = 1; w < NCONS; w++) { const float v = c->best_val[w]; const int ii = c->best_idx[w]; if (v > bv || (v == bv && ii < bi)) { bv = v; bi = ii; } }
-            p.part_val[b] = bv; p.part_idx[b] = bi;
-        }
-        if (cw == 0) tl(15);
+    // ---------------- argmax partial of this CU ----------------
+    if (lane0 == 0) { c->best_val[cw] = best; c->best_idx[cw] = best_i; }
+    cs.cbarrier();
+    if (cw == 0 && lane0 == 0) {
+        float bv = c->best_val[0]; int bi = c->best_idx[0];
+        for (int w = 1; w < NCONS; w++) { const float v = c->best_val[w]; const int ii = c->best_idx[w]; if (v > bv || (v == bv && ii < bi)) { bv = v; bi = ii; } }
+        p.part_val[b] = bv; p.part_idx[b] = bi;
     }
+    if (cw == 0) tl(15);
 }
 
 __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams p) {
