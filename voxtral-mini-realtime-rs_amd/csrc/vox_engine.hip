@@ -304,22 +304,38 @@ __device__ __forceinline__ void publish(u64* g, unsigned tag, float v) { __hip_a
 // AG_CH chunks (rolled loop: one copy of the code); the first chunk starts with a probe of one row of every 4th producer.  The norm weights of a chunk
 // are requested before its granules: they do not depend on the edge.
 constexpr int AG_CH = 3, AG_N = ED / 64 / AG_CH;
+template <bool PRE>      // PRE: all 48 norm weights are requested before the probe (48 VGPRs), otherwise 16 per chunk right before the chunk's granules
 __device__ __forceinline__ void comm_stage_h(const EngParams& p, EngCtl* c, int lane, const u64* src, unsigned tag, const float* gamma_, const float* mul_,
-                                             float* xs, float* rstd_out, float* own) {
+                                             float* xs, float* rstd_out, float* own, const Tl& tl, bool T) {
     asm volatile("" : "+v"(lane));      // opaque per call: swizzled staging addresses are computed where they are used, not carried in VGPRs
     const srd_t gamma = make_srd(gamma_, ED * 4u), mul = make_srd(mul_ ? mul_ : gamma_, ED * 4u);
     const bool has_mul = mul_ != nullptr;
     const int b12 = (int)blockIdx.x * OWN;
     float ss = 0.f;
-#pragma unroll 1
+    float gma[PRE ? AG_CH * AG_N : 1];
+    if (PRE) {
+#pragma unroll
+        for (int u = 0; u < AG_CH * AG_N; u++) gma[u] = ld_gf(gamma, (unsigned)(lane + 64 * u)) * 512.0f;
+        if (has_mul) {
+#pragma unroll
+            for (int u = 0; u < AG_CH * AG_N; u++) gma[u] *= ld_gf(mul, (unsigned)(lane + 64 * u));
+        }
+    }
+    if (T) tl(20);
+#pragma unroll
     for (int ch = 0; ch < AG_CH; ch++) {
         const int k0 = lane + 64 * AG_N * ch;
         float gm[AG_N], hv[AG_N];
+        if (!PRE) {
 #pragma unroll
-        for (int u = 0; u < AG_N; u++) gm[u] = ld_gf(gamma, (unsigned)(k0 + 64 * u)) * 512.0f;
-        if (has_mul) {
+            for (int u = 0; u < AG_N; u++) gm[u] = ld_gf(gamma, (unsigned)(k0 + 64 * u)) * 512.0f;
+            if (has_mul) {
 #pragma unroll
-            for (int u = 0; u < AG_N; u++) gm[u] *= ld_gf(mul, (unsigned)(k0 + 64 * u));
+                for (int u = 0; u < AG_N; u++) gm[u] *= ld_gf(mul, (unsigned)(k0 + 64 * u));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < AG_N; u++) gm[u] = gma[AG_N * ch + u];
         }
         sweep<AG_N>(src, ED * 8u, tag, [&](int u) { return k0 + 64 * u; }, [&]() { return 48 * lane; }, ch == 0, hv, c, p.err);
 #pragma unroll
@@ -329,6 +345,7 @@ __device__ __forceinline__ void comm_stage_h(const EngParams& p, EngCtl* c, int 
             xs[sw_dword(k)] = hv[u] * gm[u];
             if ((unsigned)(k - b12) < (unsigned)OWN) own[k - b12] = hv[u];
         }
+        if (T) tl(21 + ch);
     }
     ss = wave_sum_e(ss);
     if (lane == 0) *rstd_out = 1.0f / sqrtf(ss / (float)ED + p.eps);
@@ -352,8 +369,13 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
         const unsigned tag = tag_base + (unsigned)l + 1u;       // written during layer l
         const EngLayerTab* L = p.layers + (last ? 0 : l);
         lds_st(&c->gathering, 1u);
-        if (odd) comm_stage_h(p, c, lane, p.H1, tag, L->ffn_norm, L->ada_mul, xs1, &c->rstd1, c->h1_own);
-        else comm_stage_h(p, c, lane, p.H0, tag - 1u, last ? p.final_norm : L->attn_norm, nullptr, xs0, &c->rstd0, c->h_own);
+        {
+            const u64* src = odd ? p.H1 : p.H0; const unsigned tg = odd ? tag : tag - 1u;
+            const float* gam = odd ? L->ffn_norm : (last ? p.final_norm : L->attn_norm); const float* mul = odd ? L->ada_mul : nullptr;
+            float* xs = odd ? xs1 : xs0; float* rs = odd ? &c->rstd1 : &c->rstd0; float* own = odd ? c->h1_own : c->h_own;
+            if (p.flags & 16) comm_stage_h<true>(p, c, lane, src, tg, gam, mul, xs, rs, own, tl, T && odd);
+            else comm_stage_h<false>(p, c, lane, src, tg, gam, mul, xs, rs, own, tl, T && odd);
+        }
         ENG_CFENCE(); lds_st(odd ? &c->xs1_flag : &c->xs0_flag, (unsigned)l + 1u);
         if (T) tl(odd ? 11 : 8);
         if (last) { lds_st(&c->gathering, 0u); break; }
@@ -478,6 +500,26 @@ struct Cons {
     template <int NB>
     __device__ __forceinline__ float pass_dot(const uint4 (&Q)[NB], const float (&S)[NB], const XRegs<NB>& xr) {
         float acc = 0.f;
+        if (p.flags & 8) {      // interleaved: dword d of every block before dword d + 1 -- 2 NB independent accumulator chains instead of 2
+            f2 a0[NB], a1[NB];
+#pragma unroll
+            for (int i = 0; i < NB; i++) { a0[i] = f2{xr.m8[i], 0.f}; a1[i] = f2{0.f, 0.f}; }
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    const unsigned w = d == 0 ? Q[i].x : d == 1 ? Q[i].y : d == 2 ? Q[i].z : Q[i].w;
+                    const unsigned lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
+                    a0[i] = __builtin_elementwise_fma(cvt2(lo, false), xr.x[i][2 * d], a0[i]);
+                    a1[i] = __builtin_elementwise_fma(cvt2(lo, true), xr.x[i][2 * d + 1], a1[i]);
+                    a0[i] = __builtin_elementwise_fma(cvt2(hi, false), xr.x[i][8 + 2 * d], a0[i]);
+                    a1[i] = __builtin_elementwise_fma(cvt2(hi, true), xr.x[i][8 + 2 * d + 1], a1[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; i++) acc = fmaf(S[i], (a0[i].x + a0[i].y) + (a1[i].x + a1[i].y), acc);
+            return acc;
+        }
 #pragma unroll
         for (int i = 0; i < NB; i++) acc = fmaf(S[i], block_dot(Q[i], xr.x[i], xr.m8[i]), acc);
         return acc;
@@ -624,11 +666,14 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         else { flag = &c->xs0_flag; target = (unsigned)p.n_layers + 1u; xs = xs0; first = lane & 31; step = 32; n_pass = lm_packets(p.vocab); }
         wait_ge(flag, target, c, p.err, ERR_STAGE);
         if (T) tl(op == EOP_QKV ? 0 : op == EOP_W13 ? 5 : 7);
+        const bool TP = T && op == EOP_W13;
         rstd = op == EOP_W13 ? c->rstd1 : op == EOP_W2 ? 1.0f : c->rstd0;
         XRegs<3> xr; xr.load(xs, first, step);
         const EngLayerTab* L = p.layers + (op == EOP_LM ? 0 : l);
         uint4 Qa[3], Qb[3]; float Sa[3], Sb[3];
+        if (TP) tl(24);
         cs.fetch<3>(cs.P, Qa, Sa, op != EOP_LM || cw < npass_lm);
+        if (TP) tl(25);
 #pragma unroll 1
         for (int t = 0; t < n_pass; t++) {
             const int q = cw + 6 * t;                                  // this wave's pass of packet t
@@ -668,6 +713,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             }
 #pragma unroll
             for (int i = 0; i < 3; i++) { Qa[i] = Qb[i]; Sa[i] = Sb[i]; }
+            if (TP) tl(26 + t);
         }
         cs.P += (unsigned)n_pass;
         if (T) tl(op == EOP_QKV ? 1 : op == EOP_W13 ? 6 : 14);
