@@ -98,7 +98,7 @@ __global__ __launch_bounds__(192) void eng_pack_kernel(Q4W w, int op, unsigned c
 struct EngCtl {
     unsigned ring_ready[8], ring_done[8];         // monotonic per slot: fills landed / passes consumed
     unsigned xs0_flag, xs1_flag, xa_flag, qkv_flag;   // layer + 1 of the staged content (monotonic)
-    unsigned cbar, dead, gathering, pad0;
+    unsigned cbar, dead, gathering, gw_flag;
     float rstd0, rstd1, pad1, pad2;
     float best_val[8]; int best_idx[8];
     float h_own[16], h1_own[16];
@@ -113,9 +113,13 @@ constexpr int L_SC = L_QKVN + 384 * 4;                  // [SC_MAX] scores
 constexpr int L_PO = L_SC + SC_MAX * 4;                 // [12][128] partial attention outputs
 constexpr int L_PL = L_PO + 12 * 128 * 4;               // [16] partial softmax sums
 constexpr int L_TMP = L_PL + 64;                        // [384] partial sums swept by the comm wave
-constexpr int L_CTL = L_TMP + 384 * 4;
+constexpr int L_TAB = L_TMP + 384 * 4;                  // [MAX_LAYERS] copy of the layer table: pointer reads never touch VMEM (a vector load behind a publish waits for the store)
+constexpr int MAX_LAYERS = 32;
+constexpr int L_GW = L_TAB + MAX_LAYERS * (int)sizeof(EngLayerTab);      // [MAX_LAYERS + 1][2][16] norm weight * 512 of this CU's 12 rows: [l][0] attn_norm (l = L: final norm), [l][1] ffn_norm * Ada
+constexpr int L_CTL = L_GW + (MAX_LAYERS + 1) * 32 * 4;
 constexpr int L_TOTAL = L_CTL + (int)sizeof(EngCtl);
 static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
+static_assert(L_TAB % 16 == 0 && sizeof(EngLayerTab) == 40, "layer table");
 static_assert(L_XS0 % 16 == 0 && L_XA % 16 == 0 && L_XO % 16 == 0 && L_QKVN % 16 == 0 && L_PO % 16 == 0 && L_CTL % 16 == 0, "16-byte aligned carve");
 
 // ------------------------------------------------------------------------------------------------
@@ -300,55 +304,38 @@ __device__ __forceinline__ bool sweep(const u64* base_, unsigned bytes, unsigned
 }
 __device__ __forceinline__ void publish(u64* g, unsigned tag, float v) { __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), RLX, AG); }
 
-// All-gather of a residual stream (3072 granules): stage x = h * gamma (* mul) * 512 swizzled, rstd, this CU's own rows.  48 granules per lane in
-// AG_CH chunks (rolled loop: one copy of the code); the first chunk starts with a probe of one row of every 4th producer.  The norm weights of a chunk
-// are requested before its granules: they do not depend on the edge.
-constexpr int AG_CH = 3, AG_N = ED / 64 / AG_CH;
-template <bool PRE>      // PRE: all 48 norm weights are requested before the probe (48 VGPRs), otherwise 16 per chunk right before the chunk's granules
-__device__ __forceinline__ void comm_stage_h(const EngParams& p, EngCtl* c, int lane, const u64* src, unsigned tag, const float* gamma_, const float* mul_,
-                                             float* xs, float* rstd_out, float* own, const Tl& tl, bool T) {
+// All-gather of a staged activation vector: the owners publish their 12 rows ALREADY multiplied by the consumer's norm weight (* Ada scale) * 512,
+// plus one partial sum of squares per CU, so the sweep is granules -> LDS with no other memory operand (the per-layer norm vectors take microseconds to
+// arrive and would sit in front of the granule loads: VMEM returns in order).  48 + 4 granules per lane; the first chunk starts with a probe of one
+// row of every 4th producer.
+#ifndef ENG_AG_CH
+#define ENG_AG_CH 3
+#endif
+constexpr int AG_CH = ENG_AG_CH, AG_N = ED / 64 / AG_CH;
+__device__ __forceinline__ void comm_stage_x(const EngParams& p, EngCtl* c, int lane, const u64* src, const u64* ssq, unsigned tag, float* xs, float* rstd_out, const Tl& tl, bool T) {
     asm volatile("" : "+v"(lane));      // opaque per call: swizzled staging addresses are computed where they are used, not carried in VGPRs
-    const srd_t gamma = make_srd(gamma_, ED * 4u), mul = make_srd(mul_ ? mul_ : gamma_, ED * 4u);
-    const bool has_mul = mul_ != nullptr;
-    const int b12 = (int)blockIdx.x * OWN;
-    float ss = 0.f;
-    float gma[PRE ? AG_CH * AG_N : 1];
-    if (PRE) {
-#pragma unroll
-        for (int u = 0; u < AG_CH * AG_N; u++) gma[u] = ld_gf(gamma, (unsigned)(lane + 64 * u)) * 512.0f;
-        if (has_mul) {
-#pragma unroll
-            for (int u = 0; u < AG_CH * AG_N; u++) gma[u] *= ld_gf(mul, (unsigned)(lane + 64 * u));
-        }
-    }
     if (T) tl(20);
-#pragma unroll
+#pragma unroll 1
     for (int ch = 0; ch < AG_CH; ch++) {
         const int k0 = lane + 64 * AG_N * ch;
-        float gm[AG_N], hv[AG_N];
-        if (!PRE) {
-#pragma unroll
-            for (int u = 0; u < AG_N; u++) gm[u] = ld_gf(gamma, (unsigned)(k0 + 64 * u)) * 512.0f;
-            if (has_mul) {
-#pragma unroll
-                for (int u = 0; u < AG_N; u++) gm[u] *= ld_gf(mul, (unsigned)(k0 + 64 * u));
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < AG_N; u++) gm[u] = gma[AG_N * ch + u];
-        }
+        float hv[AG_N];
         sweep<AG_N>(src, ED * 8u, tag, [&](int u) { return k0 + 64 * u; }, [&]() { return 48 * lane; }, ch == 0, hv, c, p.err);
 #pragma unroll
-        for (int u = 0; u < AG_N; u++) {
-            const int k = k0 + 64 * u;
-            ss = fmaf(hv[u], hv[u], ss);
-            xs[sw_dword(k)] = hv[u] * gm[u];
-            if ((unsigned)(k - b12) < (unsigned)OWN) own[k - b12] = hv[u];
-        }
-        if (T) tl(21 + ch);
+        for (int u = 0; u < AG_N; u++) xs[sw_dword(k0 + 64 * u)] = hv[u];
+        if (T && ch < 3) tl(21 + ch);
     }
-    ss = wave_sum_e(ss);
+    float sq[4];
+    sweep<4>(ssq, NCU * 8u, tag, [&](int u) { return lane + 64 * u; }, [&]() { return 0; }, false, sq, c, p.err);
+    const float ss = wave_sum_e((sq[0] + sq[1]) + (sq[2] + sq[3]));      // fixed order: bit-identical on every CU
     if (lane == 0) *rstd_out = 1.0f / sqrtf(ss / (float)ED + p.eps);
+}
+// the owner's side: rows [12 b, +12) of a residual stream -> granules of row * (next norm weight) * 512, the CU's partial sum of squares, raw rows kept in LDS
+__device__ __forceinline__ void comm_publish_rows(const EngParams& p, int lane, float hraw, float gw, u64* dst, u64* ssq, unsigned tag, float* own) {
+    const int b = blockIdx.x;
+    float sq = lane < OWN ? hraw * hraw : 0.f;
+    sq = row16_sum_e(sq);                                   // lanes 0..11 live in the first DPP row
+    if (lane < OWN) { publish(dst + OWN * b + lane, tag, hraw * gw); own[lane] = hraw; }
+    if (lane == 0) publish(ssq + b, tag, sq);
 }
 
 // ONE rolled loop over the 2 L + 1 all-gathers of the step: stage 2 l = layer l's input (-> q|k|v), stage 2 l + 1 = its post-attention stream (-> w1|w3),
@@ -358,24 +345,25 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
     float* xs0 = reinterpret_cast<float*>(lds + L_XS0); float* xs1 = reinterpret_cast<float*>(lds + L_XS1);
     float* xa = reinterpret_cast<float*>(lds + L_XA); float* qkvn = reinterpret_cast<float*>(lds + L_QKVN);
     float* tmp = reinterpret_cast<float*>(lds + L_TMP);
+    const EngLayerTab* tab = reinterpret_cast<const EngLayerTab*>(lds + L_TAB);
     const unsigned tag_base = (*p.serial + 1u) * 64u;     // tags of this launch: tag_base (the step's input) .. tag_base + n_layers; never 0, never reused
     const bool PROBE_SMALL = (p.flags & 4) != 0;          // small edges (<= 18 granules per lane) are polled with the sweep itself unless this is set
+    const int own_r = min(lane0, OWN - 1);
+    const unsigned own_k = (unsigned)(OWN * b + own_r);
+    const float* gwt = reinterpret_cast<const float*>(lds + L_GW);      // filled by consumer wave 5 while everybody waits for the first all-gather
     // the step's input joins the granule protocol: every CU publishes its 12 rows of h_in, so layer 0 takes the same all-gather as every other layer
-    if (lane0 < OWN) publish(p.H0 + OWN * b + lane0, tag_base, as_g(p.h_in)[OWN * b + lane0]);
+    {
+        const float g0 = ld_gf(make_srd(p.n_layers > 0 ? tab[0].attn_norm : p.final_norm, ED * 4u), own_k) * 512.0f;
+        comm_publish_rows(p, lane0, ld_gf(make_srd(p.h_in, ED * 4u), own_k), g0, p.H0, p.SS0, tag_base, c->h_own);
+    }
 #pragma unroll 1
     for (int st = 0; st <= 2 * p.n_layers; st++) {
         int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per stage: lane-derived addresses are recomputed, not carried around the loop in VGPRs
         const int l = st >> 1; const bool odd = st & 1, last = st == 2 * p.n_layers, T = l == p.tl_layer;
         const unsigned tag = tag_base + (unsigned)l + 1u;       // written during layer l
-        const EngLayerTab* L = p.layers + (last ? 0 : l);
         lds_st(&c->gathering, 1u);
-        {
-            const u64* src = odd ? p.H1 : p.H0; const unsigned tg = odd ? tag : tag - 1u;
-            const float* gam = odd ? L->ffn_norm : (last ? p.final_norm : L->attn_norm); const float* mul = odd ? L->ada_mul : nullptr;
-            float* xs = odd ? xs1 : xs0; float* rs = odd ? &c->rstd1 : &c->rstd0; float* own = odd ? c->h1_own : c->h_own;
-            if (p.flags & 16) comm_stage_h<true>(p, c, lane, src, tg, gam, mul, xs, rs, own, tl, T && odd);
-            else comm_stage_h<false>(p, c, lane, src, tg, gam, mul, xs, rs, own, tl, T && odd);
-        }
+        if (odd) comm_stage_x(p, c, lane, p.H1, p.SS1, tag, xs1, &c->rstd1, tl, T);
+        else comm_stage_x(p, c, lane, p.H0, p.SS0, tag - 1u, xs0, &c->rstd0, tl, false);
         ENG_CFENCE(); lds_st(odd ? &c->xs1_flag : &c->xs0_flag, (unsigned)l + 1u);
         if (T) tl(odd ? 11 : 8);
         if (last) { lds_st(&c->gathering, 0u); break; }
@@ -389,19 +377,18 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
                 ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u);
             }
             if (T) tl(9);
-            {   // wo: 32 partial planes of this CU's 12 rows -> residual stream after attention
+            {   // wo: 32 partial planes of this CU's 12 rows -> residual stream after attention, published as the w1|w3 input (gw = ffn_norm * Ada * 512)
                 float v[6];
                 sweep<6>(p.PW, NPW * ED * 8u, tag, [&](int u) { const int i = lane + 64 * u, hh = i / OWN, r = i - hh * OWN; return hh * ED + OWN * b + r; }, [&]() { return (lane & 31) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
 #pragma unroll
                 for (int u = 0; u < 6; u++) tmp[lane + 64 * u] = v[u];
                 ENG_CFENCE();
-                if (lane < OWN) {
-                    float a = 0.f;
+                float a = 0.f;
+                const int r = min(lane, OWN - 1);
 #pragma unroll 4
-                    for (int hh = 0; hh < NPW; hh++) a += tmp[hh * OWN + lane];      // fixed order
-                    const float h1 = c->h_own[lane] + a;
-                    publish(p.H1 + OWN * b + lane, tag, h1);
-                }
+                for (int hh = 0; hh < NPW; hh++) a += tmp[hh * OWN + r];      // fixed order
+                wait_ge(&c->gw_flag, 1u, c, p.err, ERR_STAGE);
+                comm_publish_rows(p, lane, c->h_own[r] + a, gwt[(l * 2 + 1) * 16 + r], p.H1, p.SS1, tag, c->h1_own);
             }
             if (T) tl(10);
         } else {
@@ -413,18 +400,17 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
                 ENG_CFENCE(); lds_st(&c->xa_flag, (unsigned)l + 1u);
             }
             if (T) tl(12);
-            {   // w2: 24 partial planes of this CU's 12 rows -> the layer's output
+            {   // w2: 24 partial planes of this CU's 12 rows -> the layer's output, published as the next layer's q|k|v input (gw = next attn_norm * 512)
                 float v[5];
                 sweep<5>(p.P2, NP2 * ED * 8u, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
 #pragma unroll
                 for (int u = 0; u < 5; u++) if (lane + 64 * u < NP2 * OWN) tmp[lane + 64 * u] = v[u];
                 ENG_CFENCE();
-                if (lane < OWN) {
-                    float a = 0.f;
+                float a = 0.f;
+                const int r = min(lane, OWN - 1);
 #pragma unroll 4
-                    for (int pp = 0; pp < NP2; pp++) a += tmp[pp * OWN + lane];      // fixed order
-                    publish(p.H0 + OWN * b + lane, tag, c->h1_own[lane] + a);
-                }
+                for (int pp = 0; pp < NP2; pp++) a += tmp[pp * OWN + r];      // fixed order
+                comm_publish_rows(p, lane, c->h1_own[r] + a, gwt[((l + 1) * 2) * 16 + r], p.H0, p.SS0, tag, c->h_own);
             }
             if (T) tl(13);
         }
@@ -500,26 +486,6 @@ struct Cons {
     template <int NB>
     __device__ __forceinline__ float pass_dot(const uint4 (&Q)[NB], const float (&S)[NB], const XRegs<NB>& xr) {
         float acc = 0.f;
-        if (p.flags & 8) {      // interleaved: dword d of every block before dword d + 1 -- 2 NB independent accumulator chains instead of 2
-            f2 a0[NB], a1[NB];
-#pragma unroll
-            for (int i = 0; i < NB; i++) { a0[i] = f2{xr.m8[i], 0.f}; a1[i] = f2{0.f, 0.f}; }
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-#pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    const unsigned w = d == 0 ? Q[i].x : d == 1 ? Q[i].y : d == 2 ? Q[i].z : Q[i].w;
-                    const unsigned lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
-                    a0[i] = __builtin_elementwise_fma(cvt2(lo, false), xr.x[i][2 * d], a0[i]);
-                    a1[i] = __builtin_elementwise_fma(cvt2(lo, true), xr.x[i][2 * d + 1], a1[i]);
-                    a0[i] = __builtin_elementwise_fma(cvt2(hi, false), xr.x[i][8 + 2 * d], a0[i]);
-                    a1[i] = __builtin_elementwise_fma(cvt2(hi, true), xr.x[i][8 + 2 * d + 1], a1[i]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NB; i++) acc = fmaf(S[i], (a0[i].x + a0[i].y) + (a1[i].x + a1[i].y), acc);
-            return acc;
-        }
 #pragma unroll
         for (int i = 0; i < NB; i++) acc = fmaf(S[i], block_dot(Q[i], xr.x[i], xr.m8[i]), acc);
         return acc;
@@ -546,6 +512,18 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
     const float rc1 = cw < 4 ? p.rope_cos[(size_t)pos * half + pr1] : 1.0f, rs1 = cw < 4 ? p.rope_sin[(size_t)pos * half + pr1] : 0.0f;
     const float scale = 1.0f / sqrtf((float)EHD);
     const int n_items = 4 * p.n_layers, npass_lm = lm_passes(p.vocab), row0_lm = lm_rows_per_cu(p.vocab) * b;
+    if (cw == NCONS - 1) {      // norm weights (* Ada scale) * 512 of this CU's 12 rows for every layer -> LDS, once per launch, while everybody waits for the first all-gather
+        const EngLayerTab* tab = reinterpret_cast<const EngLayerTab*>(lds + L_TAB);
+        float* gwt = reinterpret_cast<float*>(lds + L_GW);
+        for (int i = lane0; i <= p.n_layers * OWN + OWN - 1; i += 64) {
+            const int l = i / OWN, r = i - l * OWN; const unsigned k = (unsigned)(OWN * b + r);
+            if (l < p.n_layers) {
+                gwt[(l * 2) * 16 + r] = as_g(tab[l].attn_norm)[k] * 512.0f;
+                gwt[(l * 2 + 1) * 16 + r] = as_g(tab[l].ffn_norm)[k] * as_g(tab[l].ada_mul)[k] * 512.0f;
+            } else gwt[(l * 2) * 16 + r] = as_g(p.final_norm)[k] * 512.0f;
+        }
+        ENG_CFENCE(); lds_st(&c->gw_flag, 1u);
+    }
     float best = -INFINITY; int best_i = 0x7fffffff;
 
 #pragma unroll 1
@@ -555,7 +533,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         const bool T = l == p.tl_layer && cw == 0 && op != EOP_LM;
         const unsigned tag = tag_base + (unsigned)l + 1u;
         if (op == EOP_WO) {
-            const EngLayerTab* L = p.layers + l;
+            const EngLayerTab* L = reinterpret_cast<const EngLayerTab*>(lds + L_TAB) + l;
             const gf_p kc = as_g(L->kc) + (size_t)g * p.max_seq * EHD, vc = as_g(L->vc) + (size_t)g * p.max_seq * EHD;
             // ---------------- attention of head h (the old K / V rows do not depend on this step: requested before the q|k|v edge resolves) ----------------
             {
@@ -669,7 +647,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         const bool TP = T && op == EOP_W13;
         rstd = op == EOP_W13 ? c->rstd1 : op == EOP_W2 ? 1.0f : c->rstd0;
         XRegs<3> xr; xr.load(xs, first, step);
-        const EngLayerTab* L = p.layers + (op == EOP_LM ? 0 : l);
+        const EngLayerTab* L = reinterpret_cast<const EngLayerTab*>(lds + L_TAB) + (op == EOP_LM ? 0 : l);
         uint4 Qa[3], Qb[3]; float Sa[3], Sb[3];
         if (TP) tl(24);
         cs.fetch<3>(cs.P, Qa, Sa, op != EOP_LM || cw < npass_lm);
@@ -734,6 +712,7 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams 
     EngCtl* c = reinterpret_cast<EngCtl*>(lds + L_CTL);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < (int)(sizeof(EngCtl) / 4)) reinterpret_cast<unsigned*>(c)[tid] = 0u;
+    for (int i = tid; i < p.n_layers * (int)(sizeof(EngLayerTab) / 8); i += NTHR) reinterpret_cast<u64*>(lds + L_TAB)[i] = reinterpret_cast<const u64*>(p.layers)[i];
     __syncthreads();
     Tl tl; tl.on = p.tl != nullptr && lane == 0; tl.buf = p.tl ? p.tl + (size_t)blockIdx.x * 32 : nullptr;
 #ifndef ENG_ROLES
@@ -761,10 +740,11 @@ int eng_lds_bytes() { return L_TOTAL; }
 
 // state block layout (bytes): H0, H1 [3072] | G [6144] | PW [32][3072] | A [9216] | P2 [24][3072] granules, then serial, err
 static constexpr size_t ST_H0 = 0, ST_H1 = ST_H0 + (size_t)ED * 8, ST_G = ST_H1 + (size_t)ED * 8, ST_PW = ST_G + (size_t)(EQD + 2 * EKD) * 8,
-                        ST_A = ST_PW + (size_t)NPW * ED * 8, ST_P2 = ST_A + (size_t)EF * 8, ST_SERIAL = ST_P2 + (size_t)NP2 * ED * 8, ST_ERR = ST_SERIAL + 256, ST_TOTAL = ST_ERR + 256;
+                        ST_A = ST_PW + (size_t)NPW * ED * 8, ST_P2 = ST_A + (size_t)EF * 8, ST_SS0 = ST_P2 + (size_t)NP2 * ED * 8, ST_SS1 = ST_SS0 + (size_t)NCU * 8, ST_SERIAL = ST_SS1 + (size_t)NCU * 8, ST_ERR = ST_SERIAL + 256, ST_TOTAL = ST_ERR + 256;
 size_t eng_state_bytes() { return ST_TOTAL; }
 void eng_state_carve(unsigned char* st, EngParams* p) {
     p->H0 = reinterpret_cast<unsigned long long*>(st + ST_H0); p->H1 = reinterpret_cast<unsigned long long*>(st + ST_H1);
+    p->SS0 = reinterpret_cast<unsigned long long*>(st + ST_SS0); p->SS1 = reinterpret_cast<unsigned long long*>(st + ST_SS1);
     p->G = reinterpret_cast<unsigned long long*>(st + ST_G); p->PW = reinterpret_cast<unsigned long long*>(st + ST_PW);
     p->A = reinterpret_cast<unsigned long long*>(st + ST_A); p->P2 = reinterpret_cast<unsigned long long*>(st + ST_P2);
     p->serial = reinterpret_cast<unsigned*>(st + ST_SERIAL); p->err = reinterpret_cast<unsigned*>(st + ST_ERR);
