@@ -69,6 +69,40 @@ __global__ void fp8_probe_kernel(float* out) {
     if (threadIdx.x < 16) { out[4 * q] = a.x; out[4 * q + 1] = a.y; out[4 * q + 2] = b.x; out[4 * q + 3] = b.y; }
 }
 
+// ---- VALU issue rates of the consumer's instruction mix (one workgroup per CU; 1 or 2 waves per SIMD): ns per wave-instruction
+template <int OP>
+__global__ void rate_kernel(float* out, int iters) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b0 = 1.5f, b1 = 2.5f; unsigned w = threadIdx.x * 0x01010101u;
+    typedef float f2r __attribute__((ext_vector_type(2)));
+    f2r p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a1, a2}, p3 = {a3, a0}, q0 = {b0, b1};
+    for (int i = 0; i < iters; i++) {
+        if (OP == 0) asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));
+        if (OP == 1) asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(q0));
+        if (OP == 2) asm volatile("v_cvt_pk_f32_fp8_e32 %0, %4\n v_cvt_pk_f32_fp8_e32 %1, %4\n v_cvt_pk_f32_fp8_e32 %2, %4\n v_cvt_pk_f32_fp8_e32 %3, %4\n v_cvt_pk_f32_fp8_e32 %0, %4\n v_cvt_pk_f32_fp8_e32 %1, %4\n v_cvt_pk_f32_fp8_e32 %2, %4\n v_cvt_pk_f32_fp8_e32 %3, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(w));
+        if (OP == 3) asm volatile("v_cvt_pk_f32_fp8_sdwa %0, %4 src0_sel:WORD_1\n v_cvt_pk_f32_fp8_sdwa %1, %4 src0_sel:WORD_1\n v_cvt_pk_f32_fp8_sdwa %2, %4 src0_sel:WORD_1\n v_cvt_pk_f32_fp8_sdwa %3, %4 src0_sel:WORD_1\n v_cvt_pk_f32_fp8_sdwa %0, %4 src0_sel:WORD_1\n v_cvt_pk_f32_fp8_sdwa %1, %4 src0_sel:WORD_1\n v_cvt_pk_f32_fp8_sdwa %2, %4 src0_sel:WORD_1\n v_cvt_pk_f32_fp8_sdwa %3, %4 src0_sel:WORD_1" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(w));
+        if (OP == 4) asm volatile("v_cvt_f32_ubyte0 %0, %4\n v_cvt_f32_ubyte1 %1, %4\n v_cvt_f32_ubyte2 %2, %4\n v_cvt_f32_ubyte3 %3, %4\n v_cvt_f32_ubyte0 %0, %4\n v_cvt_f32_ubyte1 %1, %4\n v_cvt_f32_ubyte2 %2, %4\n v_cvt_f32_ubyte3 %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(w));
+        if (OP == 5) asm volatile("v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_and_b32 %3, %3, %4\n v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_and_b32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(w));
+        if (OP == 6) asm volatile("v_pk_fma_f32 %0, %0, %2, %2\n v_pk_fma_f32 %1, %1, %2, %2\n v_pk_fma_f32 %0, %0, %2, %2\n v_pk_fma_f32 %1, %1, %2, %2\n v_pk_fma_f32 %0, %0, %2, %2\n v_pk_fma_f32 %1, %1, %2, %2\n v_pk_fma_f32 %0, %0, %2, %2\n v_pk_fma_f32 %1, %1, %2, %2" : "+v"(p0), "+v"(p1) : "v"(q0));   // two dependent chains (the consumer's block_dot)
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p1.x + p2.x + p3.x + p0.y + p1.y;
+}
+static void run_rates() {
+    float* out = dalloc<float>(256 * 1024);
+    const char* names[7] = {"v_fma_f32 (4 chains)", "v_pk_fma_f32 (4 chains)", "v_cvt_pk_f32_fp8 e32", "v_cvt_pk_f32_fp8 sdwa", "v_cvt_f32_ubyteN", "v_and_b32", "v_pk_fma_f32 (2 chains)"};
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const int iters = 20000;
+    for (int op = 0; op < 7; op++) for (int wv = 4; wv <= 8; wv += 4) {
+        auto launch = [&]() {
+            switch (op) { case 0: rate_kernel<0><<<256, 64 * wv>>>(out, iters); break; case 1: rate_kernel<1><<<256, 64 * wv>>>(out, iters); break; case 2: rate_kernel<2><<<256, 64 * wv>>>(out, iters); break;
+                          case 3: rate_kernel<3><<<256, 64 * wv>>>(out, iters); break; case 4: rate_kernel<4><<<256, 64 * wv>>>(out, iters); break; case 5: rate_kernel<5><<<256, 64 * wv>>>(out, iters); break; default: rate_kernel<6><<<256, 64 * wv>>>(out, iters); }
+        };
+        launch(); CHK(hipDeviceSynchronize());
+        CHK(hipEventRecord(e0)); launch(); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        printf("rate %-26s %d waves/SIMD: %.2f ns per wave-instruction (%.1f cycles at 2.4 GHz)\n", names[op], wv / 4, ms * 1e6 / (iters * 8.0), ms * 1e6 / (iters * 8.0) * 2.4);
+    }
+}
+
 struct Layer { Q4W wqkv, wo, w13, w2; float *attn_norm, *ffn_norm, *ada; };
 
 static double maxabs(const std::vector<float>& a) { double m = 0; for (float v : a) m = std::max(m, (double)std::fabs(v)); return m; }
@@ -108,6 +142,7 @@ int main(int argc, char** argv) {
         printf("fp8 (e4m3) nibble conversion q * 2^-9: %s (cvt(1) = %g)\n", bad ? "FAIL" : "ok", f[4]);
     }
 
+    if (argc > 7 && atoi(argv[7])) run_rates();
     // ---- synthetic model
     std::vector<Layer> L(n_layers);
     const float sb = 0.004f;

@@ -41,11 +41,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int ED = 3072, ENH = 32, ENKV = 8, EHD = 128, EQD = ENH * EHD, EKD = ENKV * EHD, EF = 9216;
 constexpr int NCU = 256, NCONS = 6, NWAVES = NCONS + 2, NTHR = 64 * NWAVES;
 constexpr int PASS_A = 3456, PASS_WO = 2304;          // bytes per pass: 3 (2) planes of 64 x 16 B nibbles + 64 x 2 B scales
-constexpr int LINES_A = 21, LINES_WO = 14;            // 1 KiB LDS-DMA lines per packet (6 passes)
-constexpr int SLOT_BYTES = LINES_A * 1024, NSLOT = 5;
+constexpr int PK_A = NCONS * PASS_A, PK_WO = NCONS * PASS_WO;   // packet = one pass per consumer wave: 20736 / 13824 bytes, stored back to back (no padding)
+constexpr int LINES_A = (PK_A + 1023) / 1024, LINES_WO = (PK_WO + 1023) / 1024;      // LDS-DMA instructions per packet (the last one partial: 16 / 32 lanes)
+constexpr int SLOT_BYTES = PK_A, NSLOT = 6;            // w1|w3's six packets fit: with five slots its last pass waited for a refill (4 us tail per layer)
 constexpr int QKV_PK = 2, WO_PK = 2, W13_PK = 6, W2_PK = 3;
-constexpr int LAYER_LINES = (QKV_PK + W13_PK + W2_PK) * LINES_A + WO_PK * LINES_WO;   // 259 KiB per CU per layer
-constexpr int OFF_QKV = 0, OFF_WO = QKV_PK * LINES_A, OFF_W13 = OFF_WO + WO_PK * LINES_WO, OFF_W2 = OFF_W13 + W13_PK * LINES_A;   // in lines
+constexpr int LAYER_BYTES = (QKV_PK + W13_PK + W2_PK) * PK_A + WO_PK * PK_WO;   // 255744 bytes per CU per layer = exactly the Q4 bytes
+constexpr int OFF_QKV = 0, OFF_WO = QKV_PK * PK_A, OFF_W13 = OFF_WO + WO_PK * PK_WO, OFF_W2 = OFF_W13 + W13_PK * PK_A;   // byte offsets inside a layer
 constexpr int SC_MAX = 1024;                          // attention scores in LDS: cache rows per KV head (max_seq) <= 1024
 constexpr int OWN = ED / NCU;                         // 12 rows of the residual stream per CU
 constexpr int NPW = ENH, NP2 = 24;                    // partial planes of wo / w2
@@ -57,7 +58,7 @@ enum { ERR_RING = 1, ERR_STAGE = 2, ERR_SWEEP = 3, ERR_CBAR = 4, ERR_SLOT = 5 };
 __host__ __device__ inline int lm_rows_per_cu(int vocab) { return vocab / NCU; }
 __host__ __device__ inline int lm_passes(int vocab) { return lm_rows_per_cu(vocab) / 2; }
 __host__ __device__ inline int lm_packets(int vocab) { return (lm_passes(vocab) + NCONS - 1) / NCONS; }
-__host__ __device__ inline size_t cu_stream_bytes(int n_layers, int vocab) { return ((size_t)n_layers * LAYER_LINES + (size_t)lm_packets(vocab) * LINES_A) * 1024; }
+__host__ __device__ inline size_t cu_stream_bytes(int n_layers, int vocab) { return (size_t)n_layers * LAYER_BYTES + (size_t)lm_packets(vocab) * PK_A + 1024; }      // + 1 KiB: the stream is read in whole 16-byte lanes only, the pad keeps the allocation comfortable
 
 // (row, block) of weight matrix `op` that lands in 16-byte chunk [plane p][lane] of pass q on CU b.  Lanes that split one row hold whole Q4 blocks.
 __host__ __device__ inline void eng_src(int op, int b, int q, int p, int lane, int vocab, int* row, int* blk) {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(192) void eng_pack_kernel(Q4W w, int op, unsigned c
     if (t >= NB * 64) return;
     const int p = t >> 6, lane = t & 63;
     int row, blk; eng_src(op, b, q, p, lane, vocab, &row, &blk);
-    const size_t pk_bytes = (size_t)(op == EOP_WO ? LINES_WO : LINES_A) * 1024, pass_bytes = op == EOP_WO ? PASS_WO : PASS_A;
+    const size_t pk_bytes = op == EOP_WO ? PK_WO : PK_A, pass_bytes = op == EOP_WO ? PASS_WO : PASS_A;
     unsigned char* dst = stream + (size_t)b * cu_stride + op_off + (size_t)(q / NCONS) * pk_bytes + (size_t)(q % NCONS) * pass_bytes;
     const size_t src = (size_t)row * w.nb + blk;
     reinterpret_cast<uint4*>(dst)[p * 64 + lane] = w.qs[src];
@@ -104,15 +105,16 @@ struct EngCtl {
     float h_own[16], h1_own[16];
 };
 constexpr int L_RING = 0;
-constexpr int L_XS0 = L_RING + NSLOT * SLOT_BYTES;      // [3072] f32, swizzled chunks: q|k|v (and lm_head) input
-constexpr int L_XS1 = L_XS0 + ED * 4;                   // w1|w3 input
-constexpr int L_XA = L_XS1 + ED * 4;                    // [1152] the XCD group's SwiGLU outputs (w2 input)
-constexpr int L_XO = L_XA + 1152 * 4;                   // [128] attention output of head h (wo input)
+constexpr int L_XS = L_RING + NSLOT * SLOT_BYTES;       // [3072] f32, swizzled chunks: the all-gathered input of q|k|v / w1|w3 / lm_head.  ONE buffer: it is re-staged only
+constexpr int L_XS0 = L_XS, L_XS1 = L_XS;               //   after every consumer wave has published results computed from the previous content (registers hold x during an operator)
+constexpr int L_U = L_XS + ED * 4;                      // time-shared: the XCD group's 1152 SwiGLU outputs (w2 input) | attention scratch of the NEXT layer
+constexpr int L_XA = L_U;                               //   [1152] staged after w1|w3, loaded to registers at the start of w2
+constexpr int L_SC = L_U;                               //   [SC_MAX] scores
+constexpr int L_PO = L_SC + SC_MAX * 4;                 //   [12][128] partial attention outputs
+constexpr int L_PL = L_PO + 12 * 128 * 4;               //   [16] partial softmax sums
+constexpr int L_XO = L_PL + 64;                         // [128] attention output of head h (wo input)
 constexpr int L_QKVN = L_XO + 128 * 4;                  // q_h[128] k_g[128] v_g[128] of this step (plain order)
-constexpr int L_SC = L_QKVN + 384 * 4;                  // [SC_MAX] scores
-constexpr int L_PO = L_SC + SC_MAX * 4;                 // [12][128] partial attention outputs
-constexpr int L_PL = L_PO + 12 * 128 * 4;               // [16] partial softmax sums
-constexpr int L_TMP = L_PL + 64;                        // [384] partial sums swept by the comm wave
+constexpr int L_TMP = L_QKVN + 384 * 4;                 // [384] partial sums swept by the comm wave
 constexpr int L_TAB = L_TMP + 384 * 4;                  // [MAX_LAYERS] copy of the layer table: pointer reads never touch VMEM (a vector load behind a publish waits for the store)
 constexpr int MAX_LAYERS = 32;
 constexpr int L_GW = L_TAB + MAX_LAYERS * (int)sizeof(EngLayerTab);      // [MAX_LAYERS + 1][2][16] norm weight * 512 of this CU's 12 rows: [l][0] attn_norm (l = L: final norm), [l][1] ffn_norm * Ada
@@ -120,7 +122,7 @@ constexpr int L_CTL = L_GW + (MAX_LAYERS + 1) * 32 * 4;
 constexpr int L_TOTAL = L_CTL + (int)sizeof(EngCtl);
 static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
 static_assert(L_TAB % 16 == 0 && sizeof(EngLayerTab) == 40, "layer table");
-static_assert(L_XS0 % 16 == 0 && L_XA % 16 == 0 && L_XO % 16 == 0 && L_QKVN % 16 == 0 && L_PO % 16 == 0 && L_CTL % 16 == 0, "16-byte aligned carve");
+static_assert(L_XS % 16 == 0 && L_XA % 16 == 0 && L_XO % 16 == 0 && L_QKVN % 16 == 0 && L_PO % 16 == 0 && L_CTL % 16 == 0 && 1152 * 4 <= SC_MAX * 4 + 12 * 128 * 4, "16-byte aligned carve");
 
 // ------------------------------------------------------------------------------------------------
 // helpers
@@ -218,7 +220,8 @@ struct Loader {
         if (nfl == 2) { wait_vmcnt(l1); publish_slot(s0); s0 = s1; l0 = l1; nfl = 1; }
         if (nfl == 1) { wait_vmcnt(0); publish_slot(s0); nfl = 0; }
     }
-    __device__ __forceinline__ void issue(u64 gsrc, int lines) {
+    __device__ __forceinline__ void issue(u64 gsrc, int bytes, int lane) {
+        const int full = bytes >> 10, tail = (bytes & 1023) >> 4, lines = full + (tail ? 1 : 0);      // tail: lanes of the last, partial LDS-DMA instruction
         const int slot = (int)(P % NSLOT); const unsigned k = P / NSLOT;
         if (k > 0 && lds_ld(&c->ring_done[slot]) < NCONS * k) {
             flush();                                   // publish what has landed before blocking: the consumers may be waiting for exactly that
@@ -228,7 +231,8 @@ struct Loader {
         if (pace) { while (wall_clock64() - t_last < pace) __builtin_amdgcn_s_sleep(1); t_last = wall_clock64(); }
         const unsigned dst = ring_lds + (unsigned)slot * SLOT_BYTES;
 #pragma unroll 1
-        for (int i = 0; i < lines; i++) dma_line(voff, dst + (unsigned)i * 1024u, gsrc + (u64)i * 1024u);
+        for (int i = 0; i < full; i++) dma_line(voff, dst + (unsigned)i * 1024u, gsrc + (u64)i * 1024u);
+        if (lane < tail) dma_line(voff, dst + (unsigned)full * 1024u, gsrc + (u64)full * 1024u);      // EXEC-masked: only `tail` lanes write
         P++;
         if (nfl == 2) { wait_vmcnt(l1 + lines); publish_slot(s0); s0 = s1; l0 = l1; s1 = slot; l1 = lines; }      // three in flight: retire the oldest
         else if (nfl == 1) { s1 = slot; l1 = lines; nfl = 2; }
@@ -248,13 +252,13 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
     u64 off = 0;                                 // byte offset of the next packet in this CU's stream (packets are stored in consumption order)
 #pragma unroll 1
     for (unsigned pk = 0; pk < n_pk; pk++) {
-        int lines = LINES_A;
+        int bytes = PK_A;
         if (pk < n_layer_pk) {
-            if (r >= QKV_PK && r < QKV_PK + WO_PK) lines = LINES_WO;
+            if (r >= QKV_PK && r < QKV_PK + WO_PK) bytes = PK_WO;
             if (r == 0 && (int)l == p.tl_layer) tl(16);
         } else ld.pace = 0;                      // no edge left to protect: the lm_head streams at full depth
-        ld.issue(fake ? base : base + off, lines);
-        off += (u64)lines * 1024u;
+        ld.issue(fake ? base : base + off, bytes, lane);
+        off += (u64)bytes;
         if (++r == PK_LAYER) { if ((int)l == p.tl_layer) tl(17); r = 0; l++; }
     }
     ld.flush();
@@ -752,17 +756,17 @@ void eng_state_carve(unsigned char* st, EngParams* p) {
 
 hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsigned char* stream, int vocab, hipStream_t s) {
     if (w.fmt != WFMT_Q4_0 || !w.qs || !w.sc) return hipErrorInvalidValue;
-    int passes, off_lines, N, K;
+    int passes, off_bytes, N, K;
     switch (op) {
-    case EOP_QKV: passes = QKV_PK * NCONS; off_lines = OFF_QKV; N = EQD + 2 * EKD; K = ED; break;
-    case EOP_WO: passes = WO_PK * NCONS; off_lines = OFF_WO; N = ED; K = EQD; break;
-    case EOP_W13: passes = W13_PK * NCONS; off_lines = OFF_W13; N = 2 * EF; K = ED; break;
-    case EOP_W2: passes = W2_PK * NCONS; off_lines = OFF_W2; N = ED; K = EF; break;
-    case EOP_LM: passes = lm_passes(vocab); off_lines = 0; N = vocab; K = ED; break;
+    case EOP_QKV: passes = QKV_PK * NCONS; off_bytes = OFF_QKV; N = EQD + 2 * EKD; K = ED; break;
+    case EOP_WO: passes = WO_PK * NCONS; off_bytes = OFF_WO; N = ED; K = EQD; break;
+    case EOP_W13: passes = W13_PK * NCONS; off_bytes = OFF_W13; N = 2 * EF; K = ED; break;
+    case EOP_W2: passes = W2_PK * NCONS; off_bytes = OFF_W2; N = ED; K = EF; break;
+    case EOP_LM: passes = lm_passes(vocab); off_bytes = 0; N = vocab; K = ED; break;
     default: return hipErrorInvalidValue;
     }
     if (w.N != N || w.K != K) return hipErrorInvalidValue;
-    const size_t op_off = op == EOP_LM ? (size_t)n_layers * LAYER_LINES * 1024 : ((size_t)layer * LAYER_LINES + off_lines) * 1024;
+    const size_t op_off = op == EOP_LM ? (size_t)n_layers * LAYER_BYTES : (size_t)layer * LAYER_BYTES + off_bytes;
     eng_pack_kernel<<<dim3(passes, NCU), dim3(192), 0, s>>>(w, op, stream, cu_stream_bytes(n_layers, vocab), op_off, vocab);
     return hipGetLastError();
 }
