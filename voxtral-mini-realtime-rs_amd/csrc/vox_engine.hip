@@ -312,26 +312,38 @@ __device__ __forceinline__ void publish(u64* g, unsigned tag, float v) { __hip_a
 // plus one partial sum of squares per CU, so the sweep is granules -> LDS with no other memory operand (the per-layer norm vectors take microseconds to
 // arrive and would sit in front of the granule loads: VMEM returns in order).  48 + 4 granules per lane; the first chunk starts with a probe of one
 // row of every 4th producer.
-#ifndef ENG_AG_CH
-#define ENG_AG_CH 3
-#endif
-constexpr int AG_CH = ENG_AG_CH, AG_N = ED / 64 / AG_CH;
 __device__ __forceinline__ void comm_stage_x(const EngParams& p, EngCtl* c, int lane, const u64* src, const u64* ssq, unsigned tag, float* xs, float* rstd_out, const Tl& tl, bool T) {
     asm volatile("" : "+v"(lane));      // opaque per call: swizzled staging addresses are computed where they are used, not carried in VGPRs
+    constexpr int NU = ED / 64;
+    const srd_t sd = make_srd(src, ED * 8u), qd = make_srd(ssq, NCU * 8u);
     if (T) tl(20);
-#pragma unroll 1
-    for (int ch = 0; ch < AG_CH; ch++) {
-        const int k0 = lane + 64 * AG_N * ch;
-        float hv[AG_N];
-        sweep<AG_N>(src, ED * 8u, tag, [&](int u) { return k0 + 64 * u; }, [&]() { return 48 * lane; }, ch == 0, hv, c, p.err);
-#pragma unroll
-        for (int u = 0; u < AG_N; u++) xs[sw_dword(k0 + 64 * u)] = hv[u];
-        if (T && ch < 3) tl(21 + ch);
+    u64 t0 = 0;
+    for (;;) {      // probe: one row of every 4th producer
+        const u64 gq = ld_gran(sd, 48u * (unsigned)lane);
+        if (__all((unsigned)(gq >> 32) == tag)) break;
+        if (sweep_bail(t0, tag, c, p.err)) break;
     }
-    float sq[4];
-    sweep<4>(ssq, NCU * 8u, tag, [&](int u) { return lane + 64 * u; }, [&]() { return 0; }, false, sq, c, p.err);
-    const float ss = wave_sum_e((sq[0] + sq[1]) + (sq[2] + sq[3]));      // fixed order: bit-identical on every CU
+    if (T) tl(21);
+    u64 raw[NU], rq[4];
+    for (;;) {      // all 48 + 4 granules of this lane in ONE round trip (three dependent 16-load round trips cost ~2 us more per all-gather)
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < NU; u++) raw[u] = ld_gran(sd, (unsigned)lane + 64u * u);
+#pragma unroll
+        for (int u = 0; u < 4; u++) rq[u] = ld_gran(qd, (unsigned)lane + 64u * u);
+#pragma unroll
+        for (int u = 0; u < NU; u++) ok &= (unsigned)(raw[u] >> 32) == tag;
+#pragma unroll
+        for (int u = 0; u < 4; u++) ok &= (unsigned)(rq[u] >> 32) == tag;
+        if (__all(ok)) break;
+        if (sweep_bail(t0, tag, c, p.err)) break;
+    }
+    if (T) tl(22);
+#pragma unroll
+    for (int u = 0; u < NU; u++) xs[sw_dword(lane + 64 * u)] = __uint_as_float((unsigned)raw[u]);
+    const float ss = wave_sum_e((__uint_as_float((unsigned)rq[0]) + __uint_as_float((unsigned)rq[1])) + (__uint_as_float((unsigned)rq[2]) + __uint_as_float((unsigned)rq[3])));      // fixed order: bit-identical on every CU
     if (lane == 0) *rstd_out = 1.0f / sqrtf(ss / (float)ED + p.eps);
+    if (T) tl(23);
 }
 // the owner's side: rows [12 b, +12) of a residual stream -> granules of row * (next norm weight) * 512, the CU's partial sum of squares, raw rows kept in LDS
 __device__ __forceinline__ void comm_publish_rows(const EngParams& p, int lane, float hraw, float gw, u64* dst, u64* ssq, unsigned tag, float* own) {
@@ -515,7 +527,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
     const float rc0 = p.rope_cos[(size_t)pos * half + pr0], rs0 = p.rope_sin[(size_t)pos * half + pr0];
     const float rc1 = cw < 4 ? p.rope_cos[(size_t)pos * half + pr1] : 1.0f, rs1 = cw < 4 ? p.rope_sin[(size_t)pos * half + pr1] : 0.0f;
     const float scale = 1.0f / sqrtf((float)EHD);
-    const int n_items = 4 * p.n_layers, npass_lm = lm_passes(p.vocab), row0_lm = lm_rows_per_cu(p.vocab) * b;
+    const int n_items = 3 * p.n_layers, npass_lm = lm_passes(p.vocab), row0_lm = lm_rows_per_cu(p.vocab) * b;
     if (cw == NCONS - 1) {      // norm weights (* Ada scale) * 512 of this CU's 12 rows for every layer -> LDS, once per launch, while everybody waits for the first all-gather
         const EngLayerTab* tab = reinterpret_cast<const EngLayerTab*>(lds + L_TAB);
         float* gwt = reinterpret_cast<float*>(lds + L_GW);
@@ -530,31 +542,62 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
     }
     float best = -INFINITY; int best_i = 0x7fffffff;
 
+    // one pass of a 3-plane operator on its two rows: (a, b) = the pass's two row sums (before the RMSNorm scale)
+    auto two_rows = [&](float acc, float& a, float& bq) { acc = row16_sum_e(acc); a = rlf(acc, 0) + rlf(acc, 16); bq = rlf(acc, 32) + rlf(acc, 48); };
 #pragma unroll 1
     for (int it = 0; it <= n_items; it++) {
         int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per item: lane-derived addresses are recomputed, not carried around the loop in VGPRs
-        const int l = it >> 2, op = it == n_items ? (int)EOP_LM : (it & 3);
+        const int l = it / 3, op = it == n_items ? (int)EOP_LM : (it - 3 * l == 0 ? (int)EOP_QKV : it - 3 * l == 1 ? (int)EOP_W13 : (int)EOP_W2);
         const bool T = l == p.tl_layer && cw == 0 && op != EOP_LM;
         const unsigned tag = tag_base + (unsigned)l + 1u;
-        if (op == EOP_WO) {
-            const EngLayerTab* L = reinterpret_cast<const EngLayerTab*>(lds + L_TAB) + l;
+        const EngLayerTab* L = reinterpret_cast<const EngLayerTab*>(lds + L_TAB) + (op == EOP_LM ? 0 : l);
+        if (op == EOP_QKV) {
+            // ================= q|k|v  ->  attention of head h  ->  wo =================
             const gf_p kc = as_g(L->kc) + (size_t)g * p.max_seq * EHD, vc = as_g(L->vc) + (size_t)g * p.max_seq * EHD;
-            // ---------------- attention of head h (the old K / V rows do not depend on this step: requested before the q|k|v edge resolves) ----------------
+            const int t6 = cw * 64 + lane;
+            const int part = t6 & 7, ks = t6 >> 3;              // scores: 8 lanes per key, 48 keys per pass
+            const int kg = t6 >> 5, col = t6 & 31;              // P.V: 12 key groups x 32 float4 columns
+            wait_ge(&c->xs0_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+            if (T) tl(0);
+            // the old K rows do not depend on this step: requested BEFORE the q|k|v passes, so they are home before the q|k|v edge is polled (a prefetch burst
+            // right behind the publish sat in front of this CU's own granule sweep: +3 us on the edge); the V rows are requested once the edge has resolved
+            float4 kpre[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned ko = (unsigned)(j_lo + min(ks + 48 * u, last_old)) * EHD + part * 16;      // 32-bit lane offset + uniform base: one VGPR per address
+#pragma unroll
+                for (int e = 0; e < 4; e++) kpre[u][e] = ldg4(kc + (ko + 4 * e));
+            }
             {
-                const int t6 = cw * 64 + lane;
-                const int part = t6 & 7, ks = t6 >> 3;              // scores: 8 lanes per key, 48 keys per pass
-                const int kg = t6 >> 5, col = t6 & 31;              // P.V: 12 key groups x 32 float4 columns
-                float4 kpre[4][4], vpre[16];
+                XRegs<3> xr; xr.load(xs0, lane & 31, 32);
+                const float rstd = c->rstd0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const unsigned ko = (unsigned)(j_lo + min(ks + 48 * u, last_old)) * EHD + part * 16;      // 32-bit lane offset + uniform base: one VGPR per address
-#pragma unroll
-                    for (int e = 0; e < 4; e++) kpre[u][e] = ldg4(kc + (ko + 4 * e));
+                for (int t = 0; t < QKV_PK; t++) {
+                    uint4 Qa[3]; float Sa[3];      // (no register double-buffering here: the 64 K-prefetch registers are live)
+                    cs.fetch<3>(cs.P + t, Qa, Sa, true);
+                    float a, bq; two_rows(cs.pass_dot<3>(Qa, Sa, xr), a, bq); a *= rstd; bq *= rstd;
+                    const int q = cw + 6 * t;
+                    int n; float c_, s_;
+                    if (t == 0) { n = 128 * h + 16 * s + 2 * q; c_ = rc0; s_ = rs0; }
+                    else if (cw < 2) { n = 128 * h + 16 * s + 2 * q; c_ = rc1; s_ = rs1; }
+                    else if (cw < 4) { n = EQD + 128 * g + 4 * j + 2 * (q - 8); c_ = rc1; s_ = rs1; }
+                    else { n = EQD + EKD + 128 * g + 4 * j + 2 * (q - 10); c_ = 1.0f; s_ = 0.0f; }
+                    const float ra = a * c_ - bq * s_, rb = a * s_ + bq * c_;        // interleaved-pair RoPE (rope.rs:99-141); identity for v
+                    if (lane < 2) {
+                        const float v = lane ? rb : ra;
+                        publish(p.G + n + lane, tag, v);
+                        if (t == 1 && cw >= 2) (cw < 4 ? kc : vc)[(size_t)pos * EHD + (n & 127) + lane] = v;      // k / v rows also go to the cache (read by later steps)
+                    }
                 }
+                cs.P += QKV_PK;
+            }
+            if (T) tl(1);
+            wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+            if (T) tl(2);
+            float4 vpre[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
-                wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
-                if (T) tl(2);
+            for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
+            {
                 float qv[16];
 #pragma unroll
                 for (int e = 0; e < 4; e++) { const float4 v = *reinterpret_cast<const float4*>(qkvn + part * 16 + 4 * e); qv[4 * e] = v.x; qv[4 * e + 1] = v.y; qv[4 * e + 2] = v.z; qv[4 * e + 3] = v.w; }
@@ -586,7 +629,9 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                     const float sv = dot16(kk);
                     if (t6 == 0) sc[n_old] = sv * scale;
                 }
-                cs.cbarrier();
+            }
+            cs.cbarrier();
+            {
                 const int n = n_old + 1;
                 float mx = -INFINITY;
                 for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[i]);
@@ -610,19 +655,18 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 }
                 po[kg * 32 + col] = o;
                 if (col == 0) pl[kg] = lsum;
-                cs.cbarrier();
-                if (t6 < EHD) {
-                    const float* pof = reinterpret_cast<const float*>(po);
-                    float so = 0.f, sl = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 12; q++) { so += pof[q * 128 + t6]; sl += pl[q]; }      // fixed order
-                    xo[sw_dword(t6)] = so * (1.0f / sl) * 512.0f;
-                }
-                cs.cbarrier();
-                if (T) tl(3);
             }
-            // ---------------- wo: rows [384 s, +384) x head h's 128 columns ----------------
-            {
+            cs.cbarrier();
+            if (t6 < EHD) {
+                const float* pof = reinterpret_cast<const float*>(po);
+                float so = 0.f, sl = 0.f;
+#pragma unroll
+                for (int q = 0; q < 12; q++) { so += pof[q * 128 + t6]; sl += pl[q]; }      // fixed order
+                xo[sw_dword(t6)] = so * (1.0f / sl) * 512.0f;
+            }
+            cs.cbarrier();
+            if (T) tl(3);
+            {   // ---------------- wo: rows [384 s, +384) x head h's 128 columns ----------------
                 XRegs<2> xr; xr.load(xo, lane & 1, 2);
                 uint4 Qa[2], Qb[2]; float Sa[2], Sb[2];
                 cs.fetch<2>(cs.P, Qa, Sa, true);
@@ -636,22 +680,20 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                     for (int i = 0; i < 2; i++) { Qa[i] = Qb[i]; Sa[i] = Sb[i]; }
                 }
                 cs.P += WO_PK;
-                if (T) tl(4);
             }
+            if (T) tl(4);
             continue;
         }
-        // ---------------- the 3-plane operators: q|k|v, w1|w3, w2, lm_head ----------------
+        // ================= the other 3-plane operators: w1|w3, w2, lm_head (one copy of the pass loop) =================
         unsigned* flag; unsigned target; const float* xs; int first, step, n_pass; float rstd;
-        if (op == EOP_QKV) { flag = &c->xs0_flag; target = (unsigned)l + 1u; xs = xs0; first = lane & 31; step = 32; n_pass = QKV_PK; }
-        else if (op == EOP_W13) { flag = &c->xs1_flag; target = (unsigned)l + 1u; xs = xs1; first = lane & 31; step = 32; n_pass = W13_PK; }
+        if (op == EOP_W13) { flag = &c->xs1_flag; target = (unsigned)l + 1u; xs = xs1; first = lane & 31; step = 32; n_pass = W13_PK; }
         else if (op == EOP_W2) { flag = &c->xa_flag; target = (unsigned)l + 1u; xs = xa; first = 12 * (cw % 3) + (lane & 3); step = 4; n_pass = W2_PK; }
         else { flag = &c->xs0_flag; target = (unsigned)p.n_layers + 1u; xs = xs0; first = lane & 31; step = 32; n_pass = lm_packets(p.vocab); }
         wait_ge(flag, target, c, p.err, ERR_STAGE);
-        if (T) tl(op == EOP_QKV ? 0 : op == EOP_W13 ? 5 : 7);
+        if (T) tl(op == EOP_W13 ? 5 : 7);
         const bool TP = T && op == EOP_W13;
         rstd = op == EOP_W13 ? c->rstd1 : op == EOP_W2 ? 1.0f : c->rstd0;
         XRegs<3> xr; xr.load(xs, first, step);
-        const EngLayerTab* L = reinterpret_cast<const EngLayerTab*>(lds + L_TAB) + (op == EOP_LM ? 0 : l);
         uint4 Qa[3], Qb[3]; float Sa[3], Sb[3];
         if (TP) tl(24);
         cs.fetch<3>(cs.P, Qa, Sa, op != EOP_LM || cw < npass_lm);
@@ -666,24 +708,8 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                     acc += dppf<0xB1>(acc); acc += dppf<0x4E>(acc);
                     if ((lane & 3) == 0) publish(p.P2 + (size_t)(3 * g + cw % 3) * ED + 96 * j + 48 * (cw / 3) + 16 * t + (lane >> 2), tag, acc);
                 } else {
-                    acc = row16_sum_e(acc);
-                    const float a = (rlf(acc, 0) + rlf(acc, 16)) * rstd, bq = (rlf(acc, 32) + rlf(acc, 48)) * rstd;      // the pass's two rows
-                    if (op == EOP_QKV) {
-                        int n; float c_, s_;
-                        if (t == 0) { n = 128 * h + 16 * s + 2 * q; c_ = rc0; s_ = rs0; }
-                        else if (cw < 2) { n = 128 * h + 16 * s + 2 * q; c_ = rc1; s_ = rs1; }
-                        else if (cw < 4) { n = EQD + 128 * g + 4 * j + 2 * (q - 8); c_ = rc1; s_ = rs1; }
-                        else { n = EQD + EKD + 128 * g + 4 * j + 2 * (q - 10); c_ = 1.0f; s_ = 0.0f; }
-                        const float ra = a * c_ - bq * s_, rb = a * s_ + bq * c_;        // interleaved-pair RoPE (rope.rs:99-141); identity for v
-                        if (lane < 2) {
-                            const float v = lane ? rb : ra;
-                            publish(p.G + n + lane, tag, v);
-                            if (t == 1 && cw >= 2) {                                      // k / v rows also go to the cache (read by later steps)
-                                const gf_p dst = as_g(cw < 4 ? L->kc : L->vc) + (size_t)g * p.max_seq * EHD + (size_t)pos * EHD + (n & 127) + lane;
-                                *dst = v;
-                            }
-                        }
-                    } else if (op == EOP_W13) {
+                    float a, bq; two_rows(acc, a, bq); a *= rstd; bq *= rstd;
+                    if (op == EOP_W13) {
                         if (lane == 0) publish(p.A + 1152 * g + 36 * j + q, tag, silu_e(a) * bq);
                     } else {
                         const int n = row0_lm + 2 * q;
@@ -698,7 +724,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             if (TP) tl(26 + t);
         }
         cs.P += (unsigned)n_pass;
-        if (T) tl(op == EOP_QKV ? 1 : op == EOP_W13 ? 6 : 14);
+        if (T) tl(op == EOP_W13 ? 6 : 14);
     }
     // ---------------- argmax partial of this CU ----------------
     if (lane0 == 0) { c->best_val[cw] = best; c->best_idx[cw] = best_i; }
