@@ -87,7 +87,10 @@ __global__ __launch_bounds__(192) void eng_pack_kernel(Q4W w, int op, unsigned c
     const int p = t >> 6, lane = t & 63;
     int row, blk; eng_src(op, b, q, p, lane, vocab, &row, &blk);
     const size_t pk_bytes = op == EOP_WO ? PK_WO : PK_A, pass_bytes = op == EOP_WO ? PASS_WO : PASS_A;
-    unsigned char* dst = stream + (size_t)b * cu_stride + op_off + (size_t)(q / NCONS) * pk_bytes + (size_t)(q % NCONS) * pass_bytes;
+    // packet-major: packet k of all 256 CUs is contiguous ([k][cu][bytes]) -- at any moment the 256 loaders read one contiguous ~5 MB window, spread over
+    // every HBM channel (CU-major streams 7.3 MB apart put all loaders on the same channels at the same time)
+    (void)cu_stride;
+    unsigned char* dst = stream + (size_t)NCU * (op_off + (size_t)(q / NCONS) * pk_bytes) + (size_t)b * pk_bytes + (size_t)(q % NCONS) * pass_bytes;
     const size_t src = (size_t)row * w.nb + blk;
     reinterpret_cast<uint4*>(dst)[p * 64 + lane] = w.qs[src];
     reinterpret_cast<uint16_t*>(dst + NB * 1024)[p * 64 + lane] = w.sc[src];
@@ -214,13 +217,13 @@ struct Loader {
     EngCtl* c; unsigned* err; unsigned ring_lds; unsigned voff;
     int nfl = 0, s0 = 0, l0 = 0, s1 = 0, l1 = 0;    // packets issued, not yet published: (s0, l0) oldest, (s1, l1) newer -- plain scalars (an indexed array would live in scratch = VMEM)
     unsigned P = 0;                                   // next packet index
-    bool thin; u64 pace = 0, t_last = 0;              // pace: minimum s_memrealtime ticks between two packet issues (0: none)
+    bool thin; u64 pace = 0, t_last = 0, pause_ticks = 0;              // pace: minimum s_memrealtime ticks between two packet issues (0: none)
     __device__ __forceinline__ void publish_slot(int slot) { lds_st(&c->ring_ready[slot], lds_ld(&c->ring_ready[slot]) + 1u); }   // only this wave writes ring_ready
     __device__ __forceinline__ void flush() {
         if (nfl == 2) { wait_vmcnt(l1); publish_slot(s0); s0 = s1; l0 = l1; nfl = 1; }
         if (nfl == 1) { wait_vmcnt(0); publish_slot(s0); nfl = 0; }
     }
-    __device__ __forceinline__ void issue(u64 gsrc, int bytes, int lane) {
+    __device__ __forceinline__ void issue(u64 gsrc, int bytes, int lane, bool nodma) {
         const int full = bytes >> 10, tail = (bytes & 1023) >> 4, lines = full + (tail ? 1 : 0);      // tail: lanes of the last, partial LDS-DMA instruction
         const int slot = (int)(P % NSLOT); const unsigned k = P / NSLOT;
         if (k > 0 && lds_ld(&c->ring_done[slot]) < NCONS * k) {
@@ -228,11 +231,18 @@ struct Loader {
             wait_ge(&c->ring_done[slot], NCONS * k, c, err, ERR_SLOT);
         }
         if (thin && lds_ld(&c->gathering)) flush();    // one fill outstanding while this CU's comm wave sweeps (MI355X_MICROARCH.md gather-pass)
+        if (pause_ticks && lds_ld(&c->gathering)) {    // nothing new in flight while this CU's comm wave waits on an edge (bounded: never a deadlock)
+            flush();
+            const u64 tp = wall_clock64();
+            while (lds_ld(&c->gathering) && wall_clock64() - tp < pause_ticks) __builtin_amdgcn_s_sleep(2);
+        }
         if (pace) { while (wall_clock64() - t_last < pace) __builtin_amdgcn_s_sleep(1); t_last = wall_clock64(); }
         const unsigned dst = ring_lds + (unsigned)slot * SLOT_BYTES;
+        if (!nodma) {
 #pragma unroll 1
-        for (int i = 0; i < full; i++) dma_line(voff, dst + (unsigned)i * 1024u, gsrc + (u64)i * 1024u);
-        if (lane < tail) dma_line(voff, dst + (unsigned)full * 1024u, gsrc + (u64)full * 1024u);      // EXEC-masked: only `tail` lanes write
+            for (int i = 0; i < full; i++) dma_line(voff, dst + (unsigned)i * 1024u, gsrc + (u64)i * 1024u);
+            if (lane < tail) dma_line(voff, dst + (unsigned)full * 1024u, gsrc + (u64)full * 1024u);      // EXEC-masked: only `tail` lanes write
+        }
         P++;
         if (nfl == 2) { wait_vmcnt(l1 + lines); publish_slot(s0); s0 = s1; l0 = l1; s1 = slot; l1 = lines; }      // three in flight: retire the oldest
         else if (nfl == 1) { s1 = slot; l1 = lines; nfl = 2; }
@@ -244,8 +254,10 @@ struct Loader {
 // through all three roles' code -- a 100 KB kernel ran 13 % slower than a 68 KB one with the same structure)
 __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsigned ring_lds, int lane, const Tl& tl) {
     Loader ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = (p.flags & 1) != 0; ld.pace = (u64)p.pace_ticks;
-    const bool fake = (p.flags & 2) != 0;      // diagnostic: every packet re-reads the CU's first 21 KiB (L2 hits, no HBM traffic; results wrong)
-    const u64 base = (u64)(p.stream + (size_t)blockIdx.x * p.cu_stride);
+    const bool fake = (p.flags & 2) != 0;      // diagnostic: every packet re-reads one packet (L2 hits, no HBM traffic; results wrong)
+    const bool nodma = (p.flags & 32) != 0;    // diagnostic: no LDS-DMA at all inside the layers (results wrong)
+    if (p.flags & 64) ld.pause_ticks = 300;
+    const u64 base = (u64)p.stream;
     constexpr int PK_LAYER = QKV_PK + WO_PK + W13_PK + W2_PK;
     const unsigned n_layer_pk = (unsigned)p.n_layers * PK_LAYER, n_pk = n_layer_pk + (unsigned)lm_packets(p.vocab);
     unsigned l = 0, r = 0;                       // layer, packet within the layer
@@ -256,8 +268,8 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
         if (pk < n_layer_pk) {
             if (r >= QKV_PK && r < QKV_PK + WO_PK) bytes = PK_WO;
             if (r == 0 && (int)l == p.tl_layer) tl(16);
-        } else ld.pace = 0;                      // no edge left to protect: the lm_head streams at full depth
-        ld.issue(fake ? base : base + off, bytes, lane);
+        } else { ld.pace = 0; ld.pause_ticks = 0; }      // no edge left to protect: the lm_head streams at full depth
+        ld.issue(fake ? base + (u64)blockIdx.x * PK_A : base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes, bytes, lane, nodma);
         off += (u64)bytes;
         if (++r == PK_LAYER) { if ((int)l == p.tl_layer) tl(17); r = 0; l++; }
     }
