@@ -276,6 +276,15 @@ int main(int argc, char** argv) {
             std::sort(v.begin(), v.end());
             printf("  %-36s %9.2f %9.2f %9.2f\n", names[e], v.front(), v[v.size() / 2], v.back());
         }
+        for (int e : {1, 6, 14}) {      // where do the tails come from?  slowest CUs and per-XCD medians of three compute-phase ends
+            std::vector<std::pair<double, int>> v; for (int b = 0; b < 256; b++) if (tb[b * 32 + e]) v.push_back({(double)(tb[b * 32 + e] - t0) / 100.0, b});
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            printf("  tail of '%s': slowest", names[e]); for (int i = 0; i < 8; i++) printf(" cu%d(x%d,j%d)=%.2f", v[v.size() - 1 - i].second, v[v.size() - 1 - i].second & 7, v[v.size() - 1 - i].second >> 3, v[v.size() - 1 - i].first);
+            printf("\n    per-XCD median:");
+            for (int x = 0; x < 8; x++) { std::vector<double> m; for (auto& pr : v) if ((pr.second & 7) == x) m.push_back(pr.first); printf(" %.2f", m[m.size() / 2]); }
+            printf("\n");
+        }
         check_err("timeline launch");
     }
     return 0;

@@ -103,6 +103,7 @@ struct EngCtl {
     unsigned ring_ready[8], ring_done[8];         // monotonic per slot: fills landed / passes consumed
     unsigned xs0_flag, xs1_flag, xa_flag, qkv_flag;   // layer + 1 of the staged content (monotonic)
     unsigned cbar, dead, gathering, gw_flag;
+    unsigned xcd_ok, pad3[3];
     float rstd0, rstd1, pad1, pad2;
     float best_val[8]; int best_idx[8];
     float h_own[16], h1_own[16];
@@ -319,6 +320,15 @@ __device__ __forceinline__ bool sweep(const u64* base_, unsigned bytes, unsigned
     }
 }
 __device__ __forceinline__ void publish(u64* g, unsigned tag, float v) { __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), RLX, AG); }
+// XCD-local edge (producer and every reader on the same XCD -- checked at kernel start, see xcd_local): a PLAIN 8-byte store stays in the XCD's L2, where the
+// readers' sc1 loads (which bypass only their own L1) find it at L2-hit latency; the write-through (sc1) form is served at the cross-XCD rate
+// consumer-side publishes: buffer stores (uniform base in SGPRs + one 32-bit VGPR index -- a 64-bit per-lane pointer costs two VGPRs the consumer does not have)
+__device__ __forceinline__ void publish_b(const u64* base, unsigned bytes, unsigned idx, unsigned tag, float v, bool local) {
+    const srd_t srd = make_srd(base, bytes);
+    v2u_t x; x.x = __float_as_uint(v); x.y = tag;
+    if (local) __builtin_amdgcn_raw_buffer_store_b64(x, srd, (int)(idx * 8u), 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(x, srd, (int)(idx * 8u), 0, 16);      // aux 16 = sc1: write-through
+}
 
 // All-gather of a staged activation vector: the owners publish their 12 rows ALREADY multiplied by the consumer's norm weight (* Ada scale) * 512,
 // plus one partial sum of squares per CU, so the sweep is granules -> LDS with no other memory operand (the per-layer norm vectors take microseconds to
@@ -536,8 +546,9 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
     // RoPE factors of this wave's two q|k|v passes (the same rows in every layer): pass cw is a q pair; pass 6 + cw is q (cw < 2), k (cw 2, 3) or v
     const int half = EHD / 2;
     const int pr0 = 8 * s + cw, pr1 = cw < 2 ? 8 * s + 6 + cw : 2 * j + (cw - 2);
-    const float rc0 = p.rope_cos[(size_t)pos * half + pr0], rs0 = p.rope_sin[(size_t)pos * half + pr0];
-    const float rc1 = cw < 4 ? p.rope_cos[(size_t)pos * half + pr1] : 1.0f, rs1 = cw < 4 ? p.rope_sin[(size_t)pos * half + pr1] : 0.0f;
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };      // wave-uniform values live in SGPRs (the VGPR file is full)
+    const float rc0 = uni(p.rope_cos[(size_t)pos * half + pr0]), rs0 = uni(p.rope_sin[(size_t)pos * half + pr0]);
+    const float rc1 = cw < 4 ? uni(p.rope_cos[(size_t)pos * half + pr1]) : 1.0f, rs1 = cw < 4 ? uni(p.rope_sin[(size_t)pos * half + pr1]) : 0.0f;
     const float scale = 1.0f / sqrtf((float)EHD);
     const int n_items = 3 * p.n_layers, npass_lm = lm_passes(p.vocab), row0_lm = lm_rows_per_cu(p.vocab) * b;
     if (cw == NCONS - 1) {      // norm weights (* Ada scale) * 512 of this CU's 12 rows for every layer -> LDS, once per launch, while everybody waits for the first all-gather
@@ -553,6 +564,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         ENG_CFENCE(); lds_st(&c->gw_flag, 1u);
     }
     float best = -INFINITY; int best_i = 0x7fffffff;
+    const bool xloc = (p.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0;      // this workgroup runs on XCD blockIdx % 8, like (by the same check) the group's other 31
 
     // one pass of a 3-plane operator on its two rows: (a, b) = the pass's two row sums (before the RMSNorm scale)
     auto two_rows = [&](float acc, float& a, float& bq) { acc = row16_sum_e(acc); a = rlf(acc, 0) + rlf(acc, 16); bq = rlf(acc, 32) + rlf(acc, 48); };
@@ -573,9 +585,10 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             if (T) tl(0);
             // the old K rows do not depend on this step: requested BEFORE the q|k|v passes, so they are home before the q|k|v edge is polled (a prefetch burst
             // right behind the publish sat in front of this CU's own granule sweep: +3 us on the edge); the V rows are requested once the edge has resolved
-            float4 kpre[4][4];
+            constexpr int NKP = 3;      // 144 keys up front (48 VGPRs); later keys take the loop below
+            float4 kpre[NKP][4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < NKP; u++) {
                 const unsigned ko = (unsigned)(j_lo + min(ks + 48 * u, last_old)) * EHD + part * 16;      // 32-bit lane offset + uniform base: one VGPR per address
 #pragma unroll
                 for (int e = 0; e < 4; e++) kpre[u][e] = ldg4(kc + (ko + 4 * e));
@@ -597,7 +610,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                     const float ra = a * c_ - bq * s_, rb = a * s_ + bq * c_;        // interleaved-pair RoPE (rope.rs:99-141); identity for v
                     if (lane < 2) {
                         const float v = lane ? rb : ra;
-                        publish(p.G + n + lane, tag, v);
+                        publish_b(p.G, (EQD + 2 * EKD) * 8u, (unsigned)(n + lane), tag, v, xloc);
                         if (t == 1 && cw >= 2) (cw < 4 ? kc : vc)[(size_t)pos * EHD + (n & 127) + lane] = v;      // k / v rows also go to the cache (read by later steps)
                     }
                 }
@@ -620,12 +633,12 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                     return group8_sum_e(sacc);
                 };
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < NKP; u++) {
                     const float sv = dot16(kpre[u]);
                     const int i = ks + 48 * u;
                     if (part == 0 && i < n_old) sc[i] = sv * scale;
                 }
-                for (int i0 = 192; i0 < n_old; i0 += 48) {           // long contexts
+                for (int i0 = 48 * NKP; i0 < n_old; i0 += 48) {      // later keys
                     const int i = i0 + ks;
                     float4 kk[4];
                     const unsigned ko = (unsigned)(j_lo + min(i, last_old)) * EHD + part * 16;
@@ -687,7 +700,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                     if (t + 1 < WO_PK) cs.fetch<2>(cs.P + t + 1, Qb, Sb, true);
                     float acc = cs.pass_dot<2>(Qa, Sa, xr);
                     acc += dppf<0xB1>(acc);
-                    if ((lane & 1) == 0) publish(p.PW + (size_t)h * ED + 384 * s + 32 * (cw + 6 * t) + (lane >> 1), tag, acc);
+                    if ((lane & 1) == 0) publish_b(p.PW, NPW * ED * 8u, (unsigned)(h * ED + 384 * s + 32 * (cw + 6 * t) + (lane >> 1)), tag, acc, false);
 #pragma unroll
                     for (int i = 0; i < 2; i++) { Qa[i] = Qb[i]; Sa[i] = Sb[i]; }
                 }
@@ -718,11 +731,11 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 float acc = cs.pass_dot<3>(Qa, Sa, xr);
                 if (op == EOP_W2) {
                     acc += dppf<0xB1>(acc); acc += dppf<0x4E>(acc);
-                    if ((lane & 3) == 0) publish(p.P2 + (size_t)(3 * g + cw % 3) * ED + 96 * j + 48 * (cw / 3) + 16 * t + (lane >> 2), tag, acc);
+                    if ((lane & 3) == 0) publish_b(p.P2, NP2 * ED * 8u, (unsigned)((3 * g + cw % 3) * ED + 96 * j + 48 * (cw / 3) + 16 * t + (lane >> 2)), tag, acc, false);
                 } else {
                     float a, bq; two_rows(acc, a, bq); a *= rstd; bq *= rstd;
                     if (op == EOP_W13) {
-                        if (lane == 0) publish(p.A + 1152 * g + 36 * j + q, tag, silu_e(a) * bq);
+                        if (lane == 0) publish_b(p.A, EF * 8u, (unsigned)(1152 * g + 36 * j + q), tag, silu_e(a) * bq, xloc);
                     } else {
                         const int n = row0_lm + 2 * q;
                         if (p.logits_out && lane < 2) p.logits_out[n + lane] = lane ? bq : a;
@@ -755,6 +768,14 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < (int)(sizeof(EngCtl) / 4)) reinterpret_cast<unsigned*>(c)[tid] = 0u;
     for (int i = tid; i < p.n_layers * (int)(sizeof(EngLayerTab) / 8); i += NTHR) reinterpret_cast<u64*>(lds + L_TAB)[i] = reinterpret_cast<const u64*>(p.layers)[i];
+    if (tid == 0) {
+        // HW_REG_XCC_ID (id 20): bits 3:0 = XCC id.  Workgroup b is observed on XCD b % 8; the XCD-local edges rely on it, so it is CHECKED: every workgroup
+        // that finds itself elsewhere reports it (err code 9) and the host switches the fast edges off.
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
+        const bool ok = xcc == (blockIdx.x & 7u);
+        c->xcd_ok = ok ? 1u : 0u;
+        if (!ok && (p.flags & 128)) __hip_atomic_store(p.err, 9u | ((unsigned)blockIdx.x << 8) | (xcc << 16), RLX, AG);
+    }
     __syncthreads();
     Tl tl; tl.on = p.tl != nullptr && lane == 0; tl.buf = p.tl ? p.tl + (size_t)blockIdx.x * 32 : nullptr;
 #ifndef ENG_ROLES
