@@ -285,6 +285,14 @@ int main(int argc, char** argv) {
             for (int x = 0; x < 8; x++) { std::vector<double> m; for (auto& pr : v) if ((pr.second & 7) == x) m.push_back(pr.first); printf(" %.2f", m[m.size() / 2]); }
             printf("\n");
         }
+        {   // duration of w1|w3 (x staged -> done) by slice index j: median over the 8 groups
+            printf("  w1|w3 duration by j (median over groups):");
+            for (int j = 0; j < 32; j++) { std::vector<double> m; for (int x = 0; x < 8; x++) { const int b = 8 * j + x; if (tb[b * 32 + 6] && tb[b * 32 + 5]) m.push_back((double)(tb[b * 32 + 6] - tb[b * 32 + 5]) / 100.0); } std::sort(m.begin(), m.end()); if (!m.empty()) printf(" %.1f", m[m.size() / 2]); }
+            printf("\n  q|k|v duration by j:");
+            for (int j = 0; j < 32; j++) { std::vector<double> m; for (int x = 0; x < 8; x++) { const int b = 8 * j + x; if (tb[b * 32 + 1] && tb[b * 32 + 0]) m.push_back((double)(tb[b * 32 + 1] - tb[b * 32 + 0]) / 100.0); } std::sort(m.begin(), m.end()); if (!m.empty()) printf(" %.1f", m[m.size() / 2]); }
+            printf("\n");
+            unsigned e1; CHK(hipMemcpy(&e1, ep.err + 1, 4, hipMemcpyDeviceToHost)); if (e1) printf("  note: XCD group check failed somewhere (workgroup %u on xcc %u): fast edges off\n", (e1 >> 8) & 0xff, e1 >> 16);
+        }
         check_err("timeline launch");
     }
     return 0;

@@ -103,7 +103,7 @@ struct EngCtl {
     unsigned ring_ready[8], ring_done[8];         // monotonic per slot: fills landed / passes consumed
     unsigned xs0_flag, xs1_flag, xa_flag, qkv_flag;   // layer + 1 of the staged content (monotonic)
     unsigned cbar, dead, gathering, gw_flag;
-    unsigned xcd_ok, pad3[3];
+    unsigned xcd_ok, xcc_id, pad3[2];
     float rstd0, rstd1, pad1, pad2;
     float best_val[8]; int best_idx[8];
     float h_own[16], h1_own[16];
@@ -561,8 +561,21 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 gwt[(l * 2 + 1) * 16 + r] = as_g(tab[l].ffn_norm)[k] * as_g(tab[l].ada_mul)[k] * 512.0f;
             } else gwt[(l * 2) * 16 + r] = as_g(p.final_norm)[k] * 512.0f;
         }
+        // XCD-local edges (q|k|v -> attention, SwiGLU -> w2) go through the shared L2 only if the 32 workgroups of group g really sit on ONE XCD: workgroup b is
+        // observed on XCD (b + rotation) % 8 (the dispatcher's round-robin carries over from the previous launch), so the ids are EXCHANGED and compared
+        unsigned ok = 0;
+        if (p.flags & 128) {
+            const unsigned my = c->xcc_id;
+            if (lane0 == 0) publish(p.XC + b, tag_base, __uint_as_float(my));
+            float v[1];
+            const bool got = sweep<1>(p.XC, NCU * 8u, tag_base, [&](int) { return 8 * (lane0 & 31) + g; }, [&]() { return 0; }, false, v, c, p.err);
+            ok = got && __all(__float_as_uint(v[0]) == my) ? 1u : 0u;
+            if (!ok && lane0 == 0) __hip_atomic_store(p.err + 1, 9u | ((unsigned)b << 8) | (my << 16), RLX, AG);      // informational (err[1]): the fast edges are off for this launch
+        }
+        lds_st(&c->xcd_ok, ok);
         ENG_CFENCE(); lds_st(&c->gw_flag, 1u);
     }
+    wait_ge(&c->gw_flag, 1u, c, p.err, ERR_STAGE);
     float best = -INFINITY; int best_i = 0x7fffffff;
     const bool xloc = (p.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0;      // this workgroup runs on XCD blockIdx % 8, like (by the same check) the group's other 31
 
@@ -768,14 +781,7 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < (int)(sizeof(EngCtl) / 4)) reinterpret_cast<unsigned*>(c)[tid] = 0u;
     for (int i = tid; i < p.n_layers * (int)(sizeof(EngLayerTab) / 8); i += NTHR) reinterpret_cast<u64*>(lds + L_TAB)[i] = reinterpret_cast<const u64*>(p.layers)[i];
-    if (tid == 0) {
-        // HW_REG_XCC_ID (id 20): bits 3:0 = XCC id.  Workgroup b is observed on XCD b % 8; the XCD-local edges rely on it, so it is CHECKED: every workgroup
-        // that finds itself elsewhere reports it (err code 9) and the host switches the fast edges off.
-        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
-        const bool ok = xcc == (blockIdx.x & 7u);
-        c->xcd_ok = ok ? 1u : 0u;
-        if (!ok && (p.flags & 128)) __hip_atomic_store(p.err, 9u | ((unsigned)blockIdx.x << 8) | (xcc << 16), RLX, AG);
-    }
+    if (tid == 0) c->xcc_id = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));      // HW_REG_XCC_ID (id 20), bits 3:0
     __syncthreads();
     Tl tl; tl.on = p.tl != nullptr && lane == 0; tl.buf = p.tl ? p.tl + (size_t)blockIdx.x * 32 : nullptr;
 #ifndef ENG_ROLES
@@ -803,10 +809,11 @@ int eng_lds_bytes() { return L_TOTAL; }
 
 // state block layout (bytes): H0, H1 [3072] | G [6144] | PW [32][3072] | A [9216] | P2 [24][3072] granules, then serial, err
 static constexpr size_t ST_H0 = 0, ST_H1 = ST_H0 + (size_t)ED * 8, ST_G = ST_H1 + (size_t)ED * 8, ST_PW = ST_G + (size_t)(EQD + 2 * EKD) * 8,
-                        ST_A = ST_PW + (size_t)NPW * ED * 8, ST_P2 = ST_A + (size_t)EF * 8, ST_SS0 = ST_P2 + (size_t)NP2 * ED * 8, ST_SS1 = ST_SS0 + (size_t)NCU * 8, ST_SERIAL = ST_SS1 + (size_t)NCU * 8, ST_ERR = ST_SERIAL + 256, ST_TOTAL = ST_ERR + 256;
+                        ST_A = ST_PW + (size_t)NPW * ED * 8, ST_P2 = ST_A + (size_t)EF * 8, ST_SS0 = ST_P2 + (size_t)NP2 * ED * 8, ST_SS1 = ST_SS0 + (size_t)NCU * 8, ST_XC = ST_SS1 + (size_t)NCU * 8, ST_SERIAL = ST_XC + (size_t)NCU * 8, ST_ERR = ST_SERIAL + 256, ST_TOTAL = ST_ERR + 256;
 size_t eng_state_bytes() { return ST_TOTAL; }
 void eng_state_carve(unsigned char* st, EngParams* p) {
     p->H0 = reinterpret_cast<unsigned long long*>(st + ST_H0); p->H1 = reinterpret_cast<unsigned long long*>(st + ST_H1);
+    p->XC = reinterpret_cast<unsigned long long*>(st + ST_XC);
     p->SS0 = reinterpret_cast<unsigned long long*>(st + ST_SS0); p->SS1 = reinterpret_cast<unsigned long long*>(st + ST_SS1);
     p->G = reinterpret_cast<unsigned long long*>(st + ST_G); p->PW = reinterpret_cast<unsigned long long*>(st + ST_PW);
     p->A = reinterpret_cast<unsigned long long*>(st + ST_A); p->P2 = reinterpret_cast<unsigned long long*>(st + ST_P2);

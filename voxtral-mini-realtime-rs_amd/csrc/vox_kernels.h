@@ -177,6 +177,7 @@ struct EngParams {
     int max_seq, window; float eps;
     unsigned long long *H0, *H1, *G, *PW, *A, *P2;    // granule buffers: [3072] [3072] [6144] [32][3072] [9216] [24][3072]
     unsigned long long *SS0, *SS1;                    // [256] per-CU partial sums of squares of H0 / H1's raw rows
+    unsigned long long* XC;                           // [256] XCC id of every workgroup (start-up exchange)
     unsigned* serial; unsigned* err;                  // launch serial (tags never repeat), first failure code (0 = ok)
     float* part_val; int* part_idx;                   // [256] per-CU argmax partials
     float* logits_out;                                // optional [vocab]
