@@ -181,6 +181,11 @@ int32_t vox_model_arena(const vox_model* m, void** dev_ptr, uint64_t* nbytes);
  * (bin/transcribe.rs:104-105).  Ada scales 1 + w2(gelu(w0 t_embed)) (gguf/model.rs:250-255) are
  * loop-invariant and cached per t_embed. */
 int32_t vox_model_set_t_embed(vox_model* m, const float* t_embed_host);
+/* Single-stream decode loop of transcribe_streaming (gguf/model.rs:938-960): by default every step is ONE launch of the persistent decode engine
+ * (all 26 layers + final norm + lm_head; real decoder geometry, Q4 weights, 256-CU device); on = 0 selects the per-operator launches (4 per layer),
+ * which other geometries / dense checkpoints always use.  *active_or_null reports whether the engine will be used.  Results of both paths agree to
+ * summation-order noise (same ids; tests/test_gpu_fullsize.py).  Environment VOX_ENGINE=0 sets the default to off at load time. */
+int32_t vox_model_set_decode_engine(vox_model* m, int32_t on, int32_t* active_or_null);
 
 /* Q4VoxtralModel::encode_audio, gguf/model.rs:783-788: mel [128][T] -> [S][dec_dim]; *S = floor(S_enc/4) */
 int32_t vox_encode_audio(vox_model* m, const float* mel_128xT, int32_t T, float* out, int32_t cap_rows,
@@ -226,7 +231,7 @@ typedef struct { double preprocess_ms, encode_ms, decode_ms, total_ms; int32_t d
 int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out);
 
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -------- */
-/* Launch the decode-step Q4 GEMV of decoder layer `layer` (`which`: 0 qkv, 1 wo, 2 w1w3, 3 w2, 4 lm_head)
+/* Launch the decode-step Q4 GEMV of decoder layer `layer` (`which`: 0 qkv, 1 wo, 2 w1w3, 3 w2, 4 lm_head; 5 = the whole step as one decode-engine launch)
  * `iters` times on the ctx stream, cycling layers so weights stay HBM-cold; returns the average
  * launch duration measured with hipEvents on that stream and the algorithmic bytes per launch. */
 int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t iters, double* avg_us, double* bytes_per_launch,

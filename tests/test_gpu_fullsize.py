@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-4
 
 
+@pytest.fixture(autouse=True)
+def _engine_default(request):
+    """Every test starts with the model's default decode path (the persistent engine where the device allows it)."""
+    yield
+    if "full" in request.fixturenames:
+        request.getfixturevalue("full")[0].set_decode_engine(True)
+
+
 @pytest.fixture(scope="module")
 def full(pkg, orc):
     S = pkg.synth
@@ -218,6 +226,7 @@ def test_full_fused_attention_equals_separate_launches(pkg, full, monkeypatch):
     """Full size, 16 s clip, eager logits path: the fused q|k|v + attention launch (opt-in, VOX_FUSED_ATTN=1) against the default two-launch path -- bit-identical logits for all 108
     steps (26 layers x 32 heads x 107 steps of cross-workgroup hand-offs under real streaming load; a stale read would show here)."""
     m, _, ctx = full
+    m.set_decode_engine(False)      # these tests compare variants of the per-operator decode path
     x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
     mel = np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
     monkeypatch.setenv("VOX_NO_ATTN_WO", "1")          # both sides on the five-launch layer (attention and wo as separate launches)
@@ -234,6 +243,7 @@ def test_full_attention_wo_launch(pkg, full, monkeypatch):
     atomics interleave differently; (b) against the separate attention and wo launches (VOX_NO_ATTN_WO=1): the same ids, logits equal to
     summation-order noise (the stated bound: 2e-4 of the largest |logit|); (c) the replayed graph emits the same ids."""
     m, _, ctx = full
+    m.set_decode_engine(False)      # these tests compare variants of the per-operator decode path
     x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
     mel = np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
     ids_a, lg_a = m.transcribe_streaming(mel, t, return_logits=True)
@@ -252,6 +262,7 @@ def test_full_attention_wo_launch_long_context(pkg, full, monkeypatch):
     """30 s clip (234 decoder positions): the attention + wo launch beyond the 160 keys it requests up front (the looped K / V passes of
     attn_decode_core) against the separate launches -- same ids, logits equal to summation-order noise."""
     m, _, ctx = full
+    m.set_decode_engine(False)      # these tests compare variants of the per-operator decode path
     x = pkg.synth.synth_audio(30.0, seed=4321); t = pkg.TimeEmbedding(3072).embed(6.0)
     mel = np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
     ids_a, lg_a = m.transcribe_streaming(mel, t, return_logits=True)
@@ -264,3 +275,31 @@ def test_full_attention_wo_launch_long_context(pkg, full, monkeypatch):
     stop = len(safe) if safe.all() else int(np.argmin(safe))
     print(f"30 s clip, {len(ids_a)} ids: attention+wo launch vs separate launches max |dlogit| {err:.3e} (largest |logit| {top:.2f}); ids equal up to step {stop}")
     assert (ids_a[:stop] == ids_s[:stop]).all() and (stop < len(ids_a) or err <= 2e-4 * top)
+
+
+def _mel_of(pkg, ctx, seconds, seed):
+    x = pkg.synth.synth_audio(seconds, seed=seed)
+    return np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
+
+
+@pytest.mark.parametrize("seconds,seed", [(16.0, 1234), (30.0, 4321)])
+def test_full_decode_engine_vs_per_operator_path(pkg, full, seconds, seed):
+    """The persistent decode-step engine (ONE launch per token: vox_engine.hip) against the per-operator launches it replaces, full size: same ids, logits equal to
+    summation-order noise (stated bound 2e-4 of the largest |logit|) on every step; the engine is run-to-run bit-identical (every cross-CU sum has a fixed order);
+    its graph-replayed ids equal its eager ids.  30 s clip: 234 decoder positions, past the 144 keys the engine's attention requests up front."""
+    m, _, ctx = full
+    if not m.set_decode_engine(True):
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    t = pkg.TimeEmbedding(3072).embed(6.0); mel = _mel_of(pkg, ctx, seconds, seed)
+    ids_e, lg_e = m.transcribe_streaming(mel, t, return_logits=True)
+    ids_e2, lg_e2 = m.transcribe_streaming(mel, t, return_logits=True)
+    assert np.array_equal(ids_e, ids_e2) and np.array_equal(lg_e, lg_e2)
+    ids_g = m.transcribe_streaming(mel, t)                                  # graph replay
+    assert not m.set_decode_engine(False)
+    ids_o, lg_o = m.transcribe_streaming(mel, t, return_logits=True)
+    ids_og = m.transcribe_streaming(mel, t)
+    err = float(np.max(np.abs(lg_e - lg_o))); top = float(np.max(np.abs(lg_o)))
+    print(f"decode engine vs per-operator path ({seconds:.0f} s, {len(ids_e)} ids): max |dlogit| {err:.3e} (largest |logit| {top:.2f}), ids equal: {np.array_equal(ids_e, ids_o)}")
+    assert len(ids_e) == len(ids_o) and (seconds < 20 or len(ids_e) > 180)
+    assert np.array_equal(ids_e, ids_o) and err <= 2e-4 * top
+    assert np.array_equal(ids_g, ids_e) and np.array_equal(ids_og, ids_o)

@@ -633,6 +633,9 @@ struct vox_model {
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
     float* d_h2 = nullptr; long long* d_wo_acc = nullptr;      // fused attention + wo decode launch: residual stream after wo; per-layer fixed-point accumulators [dec_layers][dec_dim]
     int n_parts = 0, argmax_R = 8;
+    // persistent decode-step engine (vox_engine.hip): one launch per token for the real decoder geometry; eng_ok = eligible, eng_ready = stream packed + state allocated
+    bool eng_ok = false, eng_on = true, eng_ready = false; unsigned char* eng_stream = nullptr; unsigned char* eng_state = nullptr; EngLayerTab* eng_tab = nullptr;
+    const vox_cache* eng_tab_cache = nullptr; std::vector<EngLayerTab> eng_tab_host; int eng_flags = 128, eng_pace = 0; unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0;
     const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
@@ -1017,7 +1020,7 @@ static void model_release(vox_model* m) {
     graphs_destroy(m);
     if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s})
+                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_state, (void*)m->eng_tab})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -1051,6 +1054,15 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
     if (e != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of decode buffers failed: %s", hipGetErrorString(e)); }
     if (hipMemset(m->d_attn_cnt, 0, cnt_bytes) != hipSuccess || hipMemset(m->d_wo_acc, 0, (size_t)c.dec_layers * c.dec_dim * 8) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMemset failed"); }
     for (int i = 0; i < c.dec_layers; i++) m->dec[i].ada_mul = m->ada_mul + (size_t)i * c.dec_dim;
+    // decode engine eligibility: the real Voxtral decoder geometry, every decoder linear Q4_0 without bias, a 256-CU device.  VOX_ENGINE=0 keeps the per-operator launches.
+    {
+        const char* ev = getenv("VOX_ENGINE"); bool ok = !(ev && ev[0] == '0') && c.dec_layers <= 32 && eng_geometry_ok(c.dec_dim, c.dec_heads, c.dec_kv_heads, c.dec_head_dim, c.dec_ffn, c.vocab, 256);
+        hipDeviceProp_t prop; if (ok && (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess || prop.multiProcessorCount != 256)) ok = false;
+        for (int i = 0; ok && i < c.dec_layers; i++) { const DecLayer& L = m->dec[i]; for (const Lin* w : {&L.wqkv, &L.wo, &L.w13, &L.w2}) if (w->w.fmt != WFMT_Q4_0 || !w->w.qs || !w->w.sc || w->bias) ok = false; }
+        if (ok && (m->tok.w.fmt != WFMT_Q4_0 || !m->tok.w.qs)) ok = false;
+        m->eng_ok = ok; m->eng_on = ok;
+        if (const char* f = getenv("VOX_ENGINE_FLAGS")) m->eng_flags = atoi(f);      // measurement knobs of tools/micro/engine_bench (thin / probe / XCD-local edges)
+    }
     *out = m; return VOX_OK;
 }
 
@@ -1439,6 +1451,50 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
     return VOX_OK;
 }
 
+// decode engine: per-CU weight stream (a second copy of the decoder's Q4 bytes in consumption order, built on the GPU from the row planes), granule state, layer table
+static int32_t engine_prepare(vox_model* m) {
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    if (!m->eng_ok || !m->eng_on || !m->cache || m->cache->max_seq > 1024) return VOX_OK;      // long caches keep the per-operator path (attention scores live in LDS)
+    if (!m->eng_ready) {
+        const size_t sb = eng_stream_bytes(c.dec_layers, c.vocab);
+        HIPCHK(hipMalloc((void**)&m->eng_stream, sb)); HIPCHK(hipMalloc((void**)&m->eng_state, eng_state_bytes())); HIPCHK(hipMalloc((void**)&m->eng_tab, sizeof(EngLayerTab) * 32));
+        HIPCHK(hipMemsetAsync(m->eng_stream, 0, sb, s)); HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), s));
+        for (int l = 0; l < c.dec_layers; l++) {
+            const DecLayer& L = m->dec[l];
+            HIPCHK(launch_eng_pack(L.wqkv.w, 0, l, c.dec_layers, m->eng_stream, c.vocab, s)); HIPCHK(launch_eng_pack(L.wo.w, 1, l, c.dec_layers, m->eng_stream, c.vocab, s));
+            HIPCHK(launch_eng_pack(L.w13.w, 2, l, c.dec_layers, m->eng_stream, c.vocab, s)); HIPCHK(launch_eng_pack(L.w2.w, 3, l, c.dec_layers, m->eng_stream, c.vocab, s));
+        }
+        HIPCHK(launch_eng_pack(m->tok.w, 4, 0, c.dec_layers, m->eng_stream, c.vocab, s));
+        m->eng_ready = true; m->eng_tab_cache = nullptr;
+    }
+    if (m->eng_tab_cache != m->cache) {
+        const size_t lf = cache_layer_floats(m, m->cache);
+        m->eng_tab_host.resize(c.dec_layers);
+        for (int l = 0; l < c.dec_layers; l++) m->eng_tab_host[l] = EngLayerTab{m->dec[l].attn_norm, m->dec[l].ffn_norm, m->dec[l].ada_mul, m->cache->k + (size_t)l * lf, m->cache->v + (size_t)l * lf};
+        HIPCHK(hipMemcpyAsync(m->eng_tab, m->eng_tab_host.data(), sizeof(EngLayerTab) * c.dec_layers, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        m->eng_tab_cache = m->cache;
+    }
+    return VOX_OK;
+}
+static bool engine_active(const vox_model* m) { return m->eng_on && m->eng_ready && m->eng_tab_cache == m->cache && m->cache && m->cache->max_seq <= 1024; }
+static EngParams engine_params(vox_model* m, float* logits_out) {
+    const vox_model_cfg& c = m->cfg;
+    EngParams ep{}; ep.stream = m->eng_stream; ep.cu_stride = eng_stream_bytes(c.dec_layers, c.vocab) / 256; ep.layers = m->eng_tab; ep.n_layers = c.dec_layers; ep.h_in = m->d_h; ep.final_norm = m->dec_norm;
+    ep.pos_ptr = m->d_pos; ep.pos_off = 0; ep.rope_cos = m->dec_cos; ep.rope_sin = m->dec_sin; ep.max_seq = m->cache->max_seq; ep.window = c.dec_window; ep.eps = c.norm_eps;
+    eng_state_carve(m->eng_state, &ep); ep.part_val = m->d_part_val; ep.part_idx = m->d_part_idx; ep.logits_out = logits_out; ep.vocab = c.vocab; ep.tl = nullptr; ep.tl_layer = -1;
+    ep.flags = m->eng_flags; ep.pace_ticks = m->eng_pace;
+    return ep;
+}
+
+extern "C" int32_t vox_model_set_decode_engine(vox_model* m, int32_t on, int32_t* active) {
+    ARGCHK(m, "null argument"); VOXCHK(ctx_bind(m->ctx));
+    const bool want = on != 0 && m->eng_ok;
+    if (want != m->eng_on) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); graphs_destroy(m); m->eng_on = want; }      // the captured decode graph holds the other path's launches
+    if (active) *active = m->eng_on ? 1 : 0;
+    return VOX_OK;
+}
+
 // final RMSNorm + tied lm_head (Q4) + argmax partials (gguf/model.rs:676,680-691,922-923); logits_out optional [vocab]
 static int32_t lm_head_argmax_dev(vox_model* m, const float* h, float* logits_out) {
     const vox_model_cfg& c = m->cfg;
@@ -1469,6 +1525,11 @@ static int32_t ensure_decode_state(vox_model* m, int S) {
 // 26 layers -> final norm + lm_head (argmax partials) -> fused tail: token[cur+1], cur++, next step's d_h.
 static int32_t decode_step_enqueue(vox_model* m, float* logits_out) {
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    if (engine_active(m)) {      // one launch: 26 layers + final norm + lm_head + per-CU argmax partials
+        HIPCHK(launch_decode_engine(engine_params(m, logits_out), s));
+        HIPCHK(launch_argmax_embed(m->d_part_val, m->d_part_idx, 256, m->d_tokens, m->d_pos, m->tok.w, m->d_audio, c.dec_dim, m->d_h, s));
+        return VOX_OK;
+    }
     VOXCHK(decoder_step_dev(m, m->d_h, m->cache, m->d_pos, 0));
     VOXCHK(lm_head_argmax_dev(m, m->d_h, logits_out));
     HIPCHK(launch_argmax_embed(m->d_part_val, m->d_part_idx, m->n_parts, m->d_tokens, m->d_pos, m->tok.w, m->d_audio, c.dec_dim, m->d_h, s));
@@ -1493,6 +1554,11 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     const int n = std::max(S - PREFIX_LEN, 1);                                      // S == 38: prefill + first token only (model.rs:922-926,938)
     ARGCHK(cap >= n, "out_ids capacity %d < %d", cap, n);
     VOXCHK(ensure_decode_state(m, S));
+    VOXCHK(engine_prepare(m));
+    if (engine_active(m)) {      // tags = (launch serial + 1) * 64 + layer + 1 are 32-bit: restart the serial long before they wrap (never inside a captured graph)
+        if (m->eng_launches + (unsigned long long)S + 8 > (1ull << 25)) { HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), s)); m->eng_launches = 0; }
+        m->eng_launches += (unsigned long long)S + 8;
+    }
     std::vector<int32_t> prefix(PREFIX_LEN, STREAMING_PAD); prefix[0] = BOS;      // model.rs:891-892
     HIPCHK(hipMemcpyAsync(m->d_tokens, prefix.data(), PREFIX_LEN * 4, hipMemcpyHostToDevice, s));
     m->cache->len = 0;
@@ -1547,8 +1613,15 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     }
     HIPCHK(hipMemcpyAsync(out_ids, m->d_tokens + PREFIX_LEN, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     if (logits_host) HIPCHK(hipMemcpyAsync(logits_host, d_logits_all, (size_t)n * c.vocab * 4, hipMemcpyDeviceToHost, s));
+    const bool eng_used = engine_active(m) && steps > 0;
+    if (eng_used) { EngParams ep = engine_params(m, nullptr); HIPCHK(hipMemcpyAsync(m->eng_err_host, ep.err, 8, hipMemcpyDeviceToHost, s)); }
     HIPCHK(hipStreamSynchronize(s));
     stage.end();
+    if (eng_used && m->eng_err_host[0]) {      // a bounded hand-off wait expired inside the engine: the ids of this call are not trustworthy.  Fail loudly, fall back for later calls.
+        const unsigned e = m->eng_err_host[0];
+        (void)hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), s); m->eng_launches = 0; m->eng_ok = false; m->eng_ready = false; graphs_destroy(m);
+        return fail(VOX_ERR_HIP, "decode engine: hand-off timeout (code %u, workgroup %u); the per-operator path is used from now on", e & 0xff, (e >> 8) & 0xff);
+    }
     m->cache->len = PREFIX_LEN + steps;
     *n_ids = n; m->timings.decode_tokens = n;
     m->timings.decode_ms = now_ms() - t0;
@@ -1861,9 +1934,32 @@ extern "C" int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out) {
 extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t iters, double* avg_us, double* bytes_per_launch, const char** kernel_name) {
     const bool warm = (which & 0x100) != 0;   // measurement variant: same layer every launch (weights stay in L2 / Infinity Cache)
     which &= 0xff;
-    ARGCHK(m && avg_us && bytes_per_launch && iters > 0 && which >= 0 && which <= 4, "bad argument"); VOXCHK(ctx_bind(m->ctx));
+    ARGCHK(m && avg_us && bytes_per_launch && iters > 0 && which >= 0 && which <= 5, "bad argument"); VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
     VOXCHK(ensure_decode_state(m, 64));
+    if (which == 5) {      // the whole decode step as ONE launch of the persistent engine (positions 64..: the engine reads the position word like the product does)
+        if (!m->t_embed_set) { std::vector<float> te(c.dec_dim); vox_time_embedding(6.0f, c.dec_dim, te.data()); VOXCHK(vox_model_set_t_embed(m, te.data())); }
+        VOXCHK(engine_prepare(m));
+        if (!engine_active(m)) return fail(VOX_ERR_UNSUPPORTED, "decode engine not active for this model / device");
+        const int p64 = 64; HIPCHK(hipMemcpyAsync(m->d_pos, &p64, 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemsetAsync(m->d_h, 0, (size_t)c.dec_dim * 4, s));
+        double bytes = 0; for (const Q4W* w : {&m->dec[0].wqkv.w, &m->dec[0].wo.w, &m->dec[0].w13.w, &m->dec[0].w2.w}) bytes += (double)w->N * w->nb * 18.0;
+        *bytes_per_launch = bytes * c.dec_layers + (double)m->tok.w.N * m->tok.w.nb * 18.0;
+        if (kernel_name) *kernel_name = "decode_engine_kernel";
+        const EngParams ep = engine_params(m, nullptr);
+        for (int i = 0; i < 3; i++) HIPCHK(launch_decode_engine(ep, s));
+        hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; i++) HIPCHK(launch_decode_engine(ep, s));
+        HIPCHK(hipEventRecord(e1, s)); HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        m->eng_launches += (unsigned long long)iters + 3;
+        *avg_us = (double)ms * 1000.0 / iters;
+        unsigned err2[2] = {0, 0}; HIPCHK(hipMemcpy(err2, ep.err, 8, hipMemcpyDeviceToHost));
+        if (err2[0]) return fail(VOX_ERR_HIP, "decode engine: hand-off timeout (code %u, workgroup %u)", err2[0] & 0xff, (err2[0] >> 8) & 0xff);
+        return VOX_OK;
+    }
     const int zero = 0; HIPCHK(hipMemcpyAsync(m->d_pos, &zero, 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(m->d_h, 0, (size_t)c.dec_dim * 4, s)); HIPCHK(hipMemsetAsync(m->d_att, 0, (size_t)c.dec_heads * c.dec_head_dim * 4, s));
     HIPCHK(hipMemsetAsync(m->d_act, 0, (size_t)c.dec_ffn * 4, s));

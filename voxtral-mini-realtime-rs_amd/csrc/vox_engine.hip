@@ -43,6 +43,7 @@ constexpr int NCU = 256, NCONS = 6, NWAVES = NCONS + 2, NTHR = 64 * NWAVES;
 constexpr int PASS_A = 3456, PASS_WO = 2304;          // bytes per pass: 3 (2) planes of 64 x 16 B nibbles + 64 x 2 B scales
 constexpr int PK_A = NCONS * PASS_A, PK_WO = NCONS * PASS_WO;   // packet = one pass per consumer wave: 20736 / 13824 bytes, stored back to back (no padding)
 constexpr int LINES_A = (PK_A + 1023) / 1024, LINES_WO = (PK_WO + 1023) / 1024;      // LDS-DMA instructions per packet (the last one partial: 16 / 32 lanes)
+static_assert(LINES_A == 21 && LINES_WO == 14, "wait_vmcnt() enumerates the in-flight line counts 14 / 21 / 28 / 35 / 42");
 constexpr int SLOT_BYTES = PK_A, NSLOT = 6;            // w1|w3's six packets fit: with five slots its last pass waited for a refill (4 us tail per layer)
 constexpr int QKV_PK = 2, WO_PK = 2, W13_PK = 6, W2_PK = 3;
 constexpr int LAYER_BYTES = (QKV_PK + W13_PK + W2_PK) * PK_A + WO_PK * PK_WO;   // 255744 bytes per CU per layer = exactly the Q4 bytes

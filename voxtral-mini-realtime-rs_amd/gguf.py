@@ -327,6 +327,10 @@ class Q4VoxtralModel:
     def create_decoder_cache_preallocated(self, max_seq):
         return LayerCaches(self, max_seq)
 
+    def set_decode_engine(self, on: bool) -> bool:
+        """Persistent decode-step engine (one launch per token) on / off; returns whether it is active (it needs the real decoder geometry on a 256-CU device)."""
+        a = C.c_int32(); check(lib().vox_model_set_decode_engine(self.h, 1 if on else 0, C.byref(a))); return bool(a.value)
+
     def weight_bytes(self):
         v = C.c_uint64(); check(lib().vox_model_weight_bytes(self.h, C.byref(v))); return v.value
 
