@@ -362,8 +362,17 @@ __device__ __forceinline__ void comm_stage_x(const EngParams& p, EngCtl* c, int 
         if (sweep_bail(t0, tag, c, p.err)) break;
     }
     if (T) tl(22);
+    // element k = lane + 64 u lives in chunk c = 2 u + (lane >> 5), piece (lane & 31) >> 2, and the chunk's swizzle is (c >> 1) & 7 = u & 7: eight lane-dependent
+    // byte offsets (one per value of u & 7) + 256 u cover all 48 stores -- ds_write_b32 with immediate offsets instead of 48 address computations
+    {
+        unsigned a8[8];
+        const unsigned jj = (unsigned)(lane & 31) >> 2, rr = (unsigned)lane & 3u, hi = (unsigned)lane >> 5;
 #pragma unroll
-    for (int u = 0; u < NU; u++) xs[sw_dword(lane + 64 * u)] = __uint_as_float((unsigned)raw[u]);
+        for (int m8 = 0; m8 < 8; m8++) a8[m8] = ((hi * 8u + (jj ^ (unsigned)m8)) * 4u + rr) * 4u;
+        unsigned char* xb = reinterpret_cast<unsigned char*>(xs);
+#pragma unroll
+        for (int u = 0; u < NU; u++) *reinterpret_cast<float*>(xb + a8[u & 7] + 256u * (unsigned)u) = __uint_as_float((unsigned)raw[u]);
+    }
     const float ss = wave_sum_e((__uint_as_float((unsigned)rq[0]) + __uint_as_float((unsigned)rq[1])) + (__uint_as_float((unsigned)rq[2]) + __uint_as_float((unsigned)rq[3])));      // fixed order: bit-identical on every CU
     if (lane == 0) *rstd_out = 1.0f / sqrtf(ss / (float)ED + p.eps);
     if (T) tl(23);
@@ -631,11 +640,18 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 cs.P += QKV_PK;
             }
             if (T) tl(1);
+            float4 vpre[16];
+            const bool v_early = (p.flags & 256) != 0;      // A/B: V rows requested before / after the q|k|v edge resolves
+            if (v_early) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
+            }
             wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
             if (T) tl(2);
-            float4 vpre[16];
+            if (!v_early) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
+                for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
+            }
             {
                 float qv[16];
 #pragma unroll
