@@ -640,18 +640,11 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 cs.P += QKV_PK;
             }
             if (T) tl(1);
-            float4 vpre[16];
-            const bool v_early = (p.flags & 256) != 0;      // A/B: V rows requested before / after the q|k|v edge resolves
-            if (v_early) {
-#pragma unroll
-                for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
-            }
             wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
             if (T) tl(2);
-            if (!v_early) {
+            float4 vpre[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
-            }
+            for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
             {
                 float qv[16];
 #pragma unroll
