@@ -218,7 +218,7 @@ int main(int argc, char** argv) {
     unsigned long long* tlbuf = dalloc<unsigned long long>(256 * 32); CHK(hipMemset(tlbuf, 0, 256 * 32 * 8));
     EngParams ep{}; ep.stream = stream; ep.cu_stride = sbytes / 256; ep.layers = d_tab; ep.n_layers = n_layers; ep.h_in = h_in; ep.final_norm = final_norm; ep.pos_ptr = d_pos; ep.pos_off = 0;
     ep.rope_cos = rope_c; ep.rope_sin = rope_s; ep.max_seq = max_seq; ep.window = window; ep.eps = eps; eng_state_carve(state, &ep);
-    ep.part_val = pv2; ep.part_idx = pi2; ep.logits_out = logits_eng; ep.vocab = V; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = flags; ep.pace_ticks = pace;
+    ep.part_val = pv2; ep.part_idx = pi2; ep.logits_out = logits_eng; ep.vocab = V; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = flags; ep.pace_ticks = (flags & 512) ? 0 : pace; ep.ag_delay_ticks = (flags & 512) ? pace : 0;
     CHK(hipStreamSynchronize(s));
     auto check_err = [&](const char* when) { unsigned e; CHK(hipMemcpy(&e, ep.err, 4, hipMemcpyDeviceToHost)); if (e) printf("ENGINE ERROR after %s: code %u, workgroup %u, tag bits %u\n", when, e & 0xff, (e >> 8) & 0xff, e >> 16); return e; };
     CHK(launch_decode_engine(ep, s));

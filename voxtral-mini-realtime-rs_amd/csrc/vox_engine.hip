@@ -308,32 +308,15 @@ __device__ __forceinline__ bool sweep(const u64* base_, unsigned bytes, unsigned
             if (sweep_bail(t0, tag, c, err)) return false;
         }
     }
-    // two polls in flight, half a round trip apart: the data is seen on average a quarter of a round trip after it lands instead of half
-    u64 ga[N], gb[N];
-#pragma unroll
-    for (int u = 0; u < N; u++) ga[u] = ld_gran(base, (unsigned)idx(u));
-    for (;;) {
+    for (;;) {      // (two polls in flight, half a round trip apart, were measured SLOWER on every edge: the extra coherent reads cost more than the earlier detection buys)
         bool ok = true;
 #pragma unroll
-        for (int u = 0; u < N; u++) gb[u] = ld_gran(base, (unsigned)idx(u));
-#pragma unroll
-        for (int u = 0; u < N; u++) ok &= (unsigned)(ga[u] >> 32) == tag;
-        if (__all(ok)) {
-#pragma unroll
-            for (int u = 0; u < N; u++) v[u] = __uint_as_float((unsigned)ga[u]);
-            return true;
+        for (int u = 0; u < N; u++) {
+            const u64 gq = ld_gran(base, (unsigned)idx(u));
+            v[u] = __uint_as_float((unsigned)gq);
+            ok &= (unsigned)(gq >> 32) == tag;
         }
-        if (sweep_bail(t0, tag, c, err)) return false;
-        ok = true;
-#pragma unroll
-        for (int u = 0; u < N; u++) ga[u] = ld_gran(base, (unsigned)idx(u));
-#pragma unroll
-        for (int u = 0; u < N; u++) ok &= (unsigned)(gb[u] >> 32) == tag;
-        if (__all(ok)) {
-#pragma unroll
-            for (int u = 0; u < N; u++) v[u] = __uint_as_float((unsigned)gb[u]);
-            return true;
-        }
+        if (__all(ok)) return true;
         if (sweep_bail(t0, tag, c, err)) return false;
     }
 }
@@ -358,6 +341,10 @@ __device__ __forceinline__ void comm_stage_x(const EngParams& p, EngCtl* c, int 
     const srd_t sd = make_srd(src, ED * 8u), qd = make_srd(ssq, NCU * 8u);
     if (T) tl(20);
     u64 t0 = 0;
+    if (p.flags & 512) {      // no probe: the owners publish within a fraction of a microsecond of each other, so wait out the store-to-visibility latency once
+        const u64 tw = wall_clock64();      // and go straight for the full sweep (a miss costs one more round trip)
+        while (wall_clock64() - tw < (u64)p.ag_delay_ticks) __builtin_amdgcn_s_sleep(1);
+    } else
     for (;;) {      // probe: one row of every 4th producer
         const u64 gq = ld_gran(sd, 48u * (unsigned)lane);
         if (__all((unsigned)(gq >> 32) == tag)) break;

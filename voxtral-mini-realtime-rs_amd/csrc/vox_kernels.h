@@ -185,6 +185,7 @@ struct EngParams {
     unsigned long long* tl; int tl_layer;             // timeline stamps [256][32] of layer tl_layer (null: off)
     int flags;                                        // bit 0: thin the loader to one fill in flight while this CU's comm wave sweeps; bit 1 (diagnostic): the loader
                                                       // re-reads one packet (no HBM traffic, wrong results); bit 2: probe granule before the small sweeps too
+    int ag_delay_ticks;                               // flags bit 9: all-gathers skip the probe and sweep after this many 10-ns ticks
     int pace_ticks;                                   // loader: minimum 10-ns ticks between two packet issues inside the layers (0: none)
 };
 bool eng_geometry_ok(int D, int n_heads, int n_kv, int hd, int ffn, int vocab, int max_seq);
