@@ -7,8 +7,8 @@ def load(d, counter):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter and "gemv" in r.get("Kernel_Name", ""):
-                k = r["Kernel_Name"].replace("void vox::", ""); k = k[:k.index("(")] if "(" in k else k
+            if r.get("Counter_Name") == counter and ("gemv" in r.get("Kernel_Name", "") or "decode_engine" in r.get("Kernel_Name", "")):
+                k = r["Kernel_Name"].replace("void vox::", "").replace("(anonymous namespace)::", ""); k = k[:k.index("(")] if "(" in k else k
                 a = acc[k]; a[0] += float(r["Counter_Value"]); a[1] += 1
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
