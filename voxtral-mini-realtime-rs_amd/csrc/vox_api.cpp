@@ -635,7 +635,7 @@ struct vox_model {
     int n_parts = 0, argmax_R = 8;
     // persistent decode-step engine (vox_engine.hip): one launch per token for the real decoder geometry; eng_ok = eligible, eng_ready = stream packed + state allocated
     bool eng_ok = false, eng_on = true, eng_ready = false; unsigned char* eng_stream = nullptr; unsigned char* eng_state = nullptr; EngLayerTab* eng_tab = nullptr;
-    const vox_cache* eng_tab_cache = nullptr; std::vector<EngLayerTab> eng_tab_host; int eng_flags = 128, eng_pace = 0; unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
+    const vox_cache* eng_tab_cache = nullptr; const float* eng_tab_k = nullptr; std::vector<EngLayerTab> eng_tab_host;      // (cache object, its K base) the device layer table was built for int eng_flags = 128, eng_pace = 0; unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0;
     const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
@@ -1467,17 +1467,17 @@ static int32_t engine_prepare(vox_model* m) {
         HIPCHK(launch_eng_pack(m->tok.w, 4, 0, c.dec_layers, m->eng_stream, c.vocab, s));
         m->eng_ready = true; m->eng_tab_cache = nullptr;
     }
-    if (m->eng_tab_cache != m->cache) {
+    if (m->eng_tab_cache != m->cache || m->eng_tab_k != m->cache->k) {      // (a re-allocated cache object can land on the old heap address: compare the device pointer too)
         const size_t lf = cache_layer_floats(m, m->cache);
         m->eng_tab_host.resize(c.dec_layers);
         for (int l = 0; l < c.dec_layers; l++) m->eng_tab_host[l] = EngLayerTab{m->dec[l].attn_norm, m->dec[l].ffn_norm, m->dec[l].ada_mul, m->cache->k + (size_t)l * lf, m->cache->v + (size_t)l * lf};
         HIPCHK(hipMemcpyAsync(m->eng_tab, m->eng_tab_host.data(), sizeof(EngLayerTab) * c.dec_layers, hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
-        m->eng_tab_cache = m->cache;
+        m->eng_tab_cache = m->cache; m->eng_tab_k = m->cache->k;
     }
     return VOX_OK;
 }
-static bool engine_active(const vox_model* m) { return m->eng_on && m->eng_ready && m->eng_tab_cache == m->cache && m->cache && m->cache->max_seq <= 1024; }
+static bool engine_active(const vox_model* m) { return m->eng_on && m->eng_ready && m->cache && m->eng_tab_cache == m->cache && m->eng_tab_k == m->cache->k && m->cache->max_seq <= 1024; }
 static EngParams engine_params(vox_model* m, float* logits_out) {
     const vox_model_cfg& c = m->cfg;
     EngParams ep{}; ep.stream = m->eng_stream; ep.cu_stride = eng_stream_bytes(c.dec_layers, c.vocab) / 256; ep.layers = m->eng_tab; ep.n_layers = c.dec_layers; ep.h_in = m->d_h; ep.final_norm = m->dec_norm;
@@ -1510,7 +1510,7 @@ static int32_t ensure_decode_state(vox_model* m, int S) {
     if (!m->cache || m->cache->max_seq < S) {
         int cap = std::max(S, 256); cap = std::min((cap + 255) / 256 * 256, m->dec_rope_len);
         ARGCHK(S <= cap, "sequence of %d decoder positions exceeds the RoPE table (%d)", S, m->dec_rope_len);
-        if (m->cache) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; m->cache = nullptr; }
+        if (m->cache) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; m->cache = nullptr; m->eng_tab_cache = nullptr; m->eng_tab_k = nullptr; }
         graphs_destroy(m);
         VOXCHK(cache_alloc(m, cap, &m->cache));
     }
