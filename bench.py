@@ -105,7 +105,7 @@ def f32_extra(pkg, ctx, t_embed, seconds, reps=3):
             "checkpoint_write_s": round(t_gen, 1), "load_s": round(t_load, 1)}
 
 
-def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch):
+def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch, simulate_world=0, bcast_bytes=0):
     """BASELINE configs[4] stand-in (no FLEURS offline): `n_clips` synthetic clips with FLEURS-like durations, LPT-sharded over the ranks
     (shard.run_sharded), each rank running `batch`-clip length-bucketed batches (64: four concurrent 16-row groups) through vox_transcribe_batch; results gathered in input order.
     Wall time = barrier .. barrier, max over ranks.  Replaces the reference's serial per-file loop (bin/transcribe.rs:112-126)."""
@@ -120,19 +120,60 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
         return [len(o) for o in outs]
 
     model.transcribe_batch([clips[i] for i in parts[rank][:min(batch, len(parts[rank]))]], t_embed)      # warm-up: workspaces + kernels
+    # a rank that throws inside the sharded section would leave the others in a collective until the NCCL timeout; so every rank runs its local
+    # work under try/except, the ranks agree on success (one all_reduce) BEFORE any gather, and a failure anywhere skips the extra on every rank
+    ok = 1; err = None; res = None; dt = 0.0
     if world > 1:
         dist.barrier()
     ctx.synchronize(); t0 = time.perf_counter()
-    res = shard.run_sharded(list(range(n_clips)), durs, None, rank, world, batch=batch, batch_work=batch_work)
+    try:
+        mine = []
+        for grp in shard.length_buckets(parts[rank], durs, batch):
+            mine.extend(zip(grp, batch_work(grp)))
+    except Exception as e:
+        ok = 0; err = str(e)
     ctx.synchronize(); dt = time.perf_counter() - t0
     if world > 1:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        tt = torch.tensor([dt, float(ok)], dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}")
+        mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); mn = tt.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        dt = float(mx[0].item())
+        if float(mn[1].item()) < 1.0:
+            return {"error": err or "a rank failed inside the sharded section"} if rank == 0 else None
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        if rank == 0:
+            res = [None] * n_clips
+            for part in gathered:
+                for i, r in part:
+                    res[i] = r
+    else:
+        if not ok:
+            return {"error": err}
+        res = [None] * n_clips
+        for i, r in mine:
+            res[i] = r
     if rank != 0:
         return None
     total_s = float(sum(durs)); ntok = int(sum(res))
-    return {"workload": f"{n_clips} synthetic clips, FLEURS-like log-normal durations (median 10 s, 3..30 s, rng 7), host samples -> ids; LPT shards over {world} rank(s), "
+    sim = None
+    if world == 1 and simulate_world > 1:
+        # Replicas share nothing in the data path, so the N-GPU wall time of this corpus = the slowest rank's share run alone.  On ONE GPU: run every rank's
+        # longest-first share serially, time each; predicted_scaling = T(all clips on one rank) / max_r T(share r).  The start-up broadcast (primary arena over
+        # xGMI) is reported beside it, not folded in: it is paid once per process, not per corpus.
+        sparts = shard.lpt_partition(durs, simulate_world); per = []
+        for r in range(simulate_world):
+            ctx.synchronize(); t1 = time.perf_counter()
+            for grp in shard.length_buckets(sparts[r], durs, batch):
+                batch_work(grp)
+            ctx.synchronize(); per.append(time.perf_counter() - t1)
+        sim = {"world": simulate_world, "per_rank_s": [round(v, 3) for v in per], "clips_per_rank": [len(q) for q in sparts],
+               "batches_per_rank": [[len(g) for g in shard.length_buckets(q, durs, batch)] for q in sparts][:2],
+               "predicted_wall_s": round(max(per), 3), "predicted_scaling": round(dt / max(per), 2), "predicted_efficiency": round(dt / max(per) / simulate_world, 3),
+               "lpt_imbalance": round(shard.imbalance(durs, sparts), 4), "weight_broadcast_bytes": int(bcast_bytes),
+               "weight_broadcast_s_estimate": round(bcast_bytes / 100e9, 3),
+               "note": "one-GPU bound on the N-GPU curve of this corpus (replicas only: no data-path collective); broadcast estimate at 100 GB/s per xGMI ring hop"}
+    return {"simulated_world": sim, "workload": f"{n_clips} synthetic clips, FLEURS-like log-normal durations (median 10 s, 3..30 s, rng 7), host samples -> ids; LPT shards over {world} rank(s), "
                         f"{batch}-clip length-bucketed batches (BASELINE configs[4] stand-in; no FLEURS / WER offline)",
             "clips": n_clips, "audio_s": round(total_s, 1), "wall_s": round(dt, 3), "rtf": round(dt / total_s, 6), "tok_per_s": round(ntok / dt, 1),
             "ids": ntok, "lpt_imbalance": round(shard.imbalance(durs, parts), 4), "batch": batch}
@@ -150,6 +191,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="also report BASELINE configs[3] (B utterances through vox_transcribe_batch) at N=1; 0 = skip")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 SafeTensors extra (BASELINE configs[1], N = 1)")
     ap.add_argument("--fleurs-clips", type=int, default=647, help="clips of the FLEURS-like sharded extra (BASELINE configs[4] stand-in); 0 = skip")
+    ap.add_argument("--simulate-world", type=int, default=8, help="N = 1 only: also run each of W ranks' share of the FLEURS-like corpus serially on this GPU and report the predicted 1 -> W scaling (0 = skip)")
     ap.add_argument("--fleurs-batch", type=int, default=64, help="clips per vox_transcribe_batch call of the FLEURS-like extra (<= 64)")
     ap.add_argument("--gemv-iters", type=int, default=260)
     args = ap.parse_args()
@@ -190,9 +232,10 @@ def main():
     t0 = time.time()
     loader = pkg.Q4ModelLoader.from_file(path)
     if world > 1:
-        # rank 0 parses + repacks; the packed device arena (row planes + tile-ordered copies) reaches the other ranks by ONE RCCL broadcast over xGMI
+        # rank 0 parses + repacks; the PRIMARY part of the device arena (the Q4 row planes + f32 tensors: 2.5 GB) reaches the other ranks by ONE RCCL
+        # broadcast over xGMI; every rank derives the rest on its own GPU (tile-ordered copies: arena_finalize; the decode engine's stream: first decode step)
         model = loader.load(ctx, layout_only=(rank != 0))
-        ptr, nbytes = model.arena()
+        ptr, nbytes = model.arena(); bcast_bytes = int(nbytes)
         stage = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local}")
         if rank == 0:
             ctx.copy(stage.data_ptr(), ptr, nbytes)
@@ -201,9 +244,10 @@ def main():
         torch.cuda.synchronize(); bcast_s = time.time() - tb
         if rank != 0:
             ctx.copy(ptr, stage.data_ptr(), nbytes)
+            model.arena_finalize()
         del stage
     else:
-        model = loader.load(ctx); bcast_s = 0.0
+        model = loader.load(ctx); bcast_s = 0.0; bcast_bytes = 0
     load_s = time.time() - t0
     cfg = model.config
     t_embed = pkg.TimeEmbedding(cfg.dec_dim).embed(6.0)
@@ -242,7 +286,8 @@ def main():
     fleurs = None
     if args.fleurs_clips > 0:
         try:
-            fleurs = fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, args.fleurs_clips, max(1, min(64, args.fleurs_batch)))
+            fleurs = fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, args.fleurs_clips, max(1, min(64, args.fleurs_batch)),
+                                       simulate_world=args.simulate_world, bcast_bytes=model.arena()[1])
         except Exception as e:     # an extra never costs the headline line
             fleurs = {"error": str(e)} if rank == 0 else None
 
@@ -260,7 +305,7 @@ def main():
             "decode_tok_per_s_ref_def": round(n_ids / (stage_ms["decode_ms"] / 1e3), 2) if stage_ms["decode_ms"] > 0 else None,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
-            "load_s": round(load_s, 2), "weight_broadcast_s": round(bcast_s, 3), "weight_bytes": model.weight_bytes(),
+            "load_s": round(load_s, 2), "weight_broadcast_s": round(bcast_s, 3), "weight_broadcast_bytes": bcast_bytes, "weight_bytes": model.weight_bytes(),
             "note": "value = ids emitted by all ranks / max-over-ranks wall time of the whole pipeline; decode_tok_per_s_ref_def follows "
                     "bin/e2e_bench.rs:236-240 (ids / decode-stage time); vs_baseline divides by the reference's 19.4 tok/s measured on a DGX Spark GB10",
         }

@@ -176,6 +176,10 @@ int32_t vox_model_weight_bytes(const vox_model* m, uint64_t* out);   /* device b
 /* Multi-GPU: export / import the packed device weight arena so rank 0 can parse the GGUF once and
  * the other ranks receive it with one RCCL broadcast over xGMI (no data-path collective). */
 int32_t vox_model_arena(const vox_model* m, void** dev_ptr, uint64_t* nbytes);
+/* Receiver side: after the bytes of vox_model_arena (the PRIMARY part of the arena: every tensor as parsed from the file, 2.5 GB for the
+ * Q4 model) have been written into a VOX_LOAD_LAYOUT_ONLY model, rebuild what is derived from them on this GPU (the tile-ordered copies
+ * of the Q4 linears; the decode engine's weight stream is packed lazily at the first decode step on every rank). */
+int32_t vox_model_arena_finalize(vox_model* m);
 
 /* the delay conditioning used by every decoder call: t_embed = TimeEmbedding(dec_dim).embed(delay)
  * (bin/transcribe.rs:104-105).  Ada scales 1 + w2(gelu(w0 t_embed)) (gguf/model.rs:250-255) are

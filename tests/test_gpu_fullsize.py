@@ -303,3 +303,24 @@ def test_full_decode_engine_vs_per_operator_path(pkg, full, seconds, seed):
     assert len(ids_e) == len(ids_o) and (seconds < 20 or len(ids_e) > 180)
     assert np.array_equal(ids_e, ids_o) and err <= 2e-4 * top
     assert np.array_equal(ids_g, ids_e) and np.array_equal(ids_og, ids_o)
+
+
+def test_full_layout_only_arena_copy_start_up(pkg, full):
+    """What ranks > 0 do at multi-GPU start-up, at full size on one GPU: VOX_LOAD_LAYOUT_ONLY model (no tensor data read) + the PRIMARY part of rank 0's arena
+    copied in (the RCCL broadcast's payload: 2.5 GB, the Q4 row planes -- not the 5 GB with the tile-ordered copies) + vox_model_arena_finalize => the same 108 ids as the
+    model that parsed the file, on the single-stream path (decode engine packed from the received planes) and on the batch path (tile-ordered copies rebuilt)."""
+    m, _, ctx = full
+    path = os.path.join(cache_dir(), "full_q4_seed42.gguf")
+    b = pkg.Q4ModelLoader.from_file(path).load(ctx, layout_only=True)
+    try:
+        pa, na = m.arena(); pb, nb = b.arena()
+        assert na == nb and 2.4e9 < na < 2.7e9, na                       # north_star: "RCCL broadcast of the 2.5 GB Q4 weights"
+        assert m.weight_bytes() > 4.5e9                                   # the whole arena still holds both copies
+        ctx.copy(pb, pa, na); b.arena_finalize()
+        x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
+        ids_a = m.transcribe_audio(x, t); ids_b = b.transcribe_audio(x, t)
+        assert len(ids_a) == 108 and np.array_equal(ids_a, ids_b)
+        bb = b.transcribe_batch([x, x], t)
+        assert np.array_equal(bb[0], m.transcribe_batch([x, x], t)[0]) and np.array_equal(bb[0], bb[1])
+    finally:
+        b.close()

@@ -24,7 +24,7 @@ def test_lpt_partition(pkg):
     assert all(min(dur[i] for i in b[k]) >= max(dur[i] for i in b[k + 1]) for k in range(len(b) - 1))
     calls = []
     out = shard.run_sharded(list(range(7)), [3, 1, 2, 9, 5, 4, 8], None, 0, 1, batch=3, batch_work=lambda xs: (calls.append(list(xs)), [x * 10 for x in xs])[1])
-    assert out == [0, 10, 20, 30, 40, 50, 60] and calls == [[3, 6, 4], [5, 0, 2], [1]]
+    assert out == [0, 10, 20, 30, 40, 50, 60] and calls == [[3, 6, 4], [5, 0], [2, 1]]           # balanced: 3 + 2 + 2, not 3 + 3 + 1
 
 
 def _worker(rank, world, port, pkg_dir, q):
@@ -107,3 +107,49 @@ def test_bench_gpus_flag_fails_loudly_without_enough_gpus():
     env["WORLD_SIZE"] = "1"; env["RANK"] = "0"; env["LOCAL_RANK"] = "0"
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 2 and "does not match --gpus" in p.stderr
+
+
+def _cli_worker(rank, world, port, pkg_dir, tmp, q):
+    import importlib.util, os, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(pkg_dir))
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    cli = importlib.import_module(pkg.__name__ + ".cli")
+    paths = [os.path.join(tmp, f"f{i}.bin") for i in range(11)]
+    done = []
+    def one(i):                                  # the fake model: the line names the file and the rank that "transcribed" it
+        done.append(i); return f"file{i}@rank{rank}"
+    lines = cli.sharded_lines(pkg, paths, one, rank, world)
+    q.put((rank, lines, done))
+
+
+def test_cli_sharded_lines_world2_gloo(pkg, tmp_path):
+    """`voxtral-transcribe --gpus N` data path on CPU (gloo, world 2, fake model): every file transcribed exactly once, by the rank the longest-first
+    partition of the file sizes names, and rank 0 gets one line per input IN INPUT ORDER (the reference's stdout contract, bin/transcribe.rs:112-126)."""
+    import multiprocessing as mp, os
+    shard = __import__("importlib").import_module(pkg.__name__ + ".shard")
+    sizes = [500, 100, 900, 300, 300, 800, 50, 700, 200, 600, 400]
+    for i, n in enumerate(sizes):
+        (tmp_path / f"f{i}.bin").write_bytes(b"x" * n)
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = shard.free_port()
+    ps = [ctx.Process(target=_cli_worker, args=(r, 2, port, os.path.dirname(os.path.abspath(pkg.__file__)), str(tmp_path), q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = {}
+    for _ in ps:
+        r, lines, done = q.get(timeout=120); res[r] = (lines, done)
+    [p.join(60) for p in ps]
+    parts = shard.lpt_partition([float(n) for n in sizes], 2)
+    assert res[1][0] is None and sorted(res[0][1]) == parts[0] and sorted(res[1][1]) == parts[1]
+    owner = {i: r for r in range(2) for i in parts[r]}
+    assert res[0][0] == [f"file{i}@rank{owner[i]}" for i in range(11)]
+
+
+def test_length_buckets_are_balanced(pkg):
+    shard = __import__("importlib").import_module(pkg.__name__ + ".shard")
+    costs = [float(i % 17) for i in range(81)]
+    b = shard.length_buckets(list(range(81)), costs, 64)
+    assert [len(x) for x in b] == [41, 40] and sorted(sum(b, [])) == list(range(81))          # not 64 + 17
+    assert all(costs[b[0][k]] >= costs[b[0][k + 1]] for k in range(40))                      # still sorted by length
+    assert shard.length_buckets([], costs, 64) == [] and [len(x) for x in shard.length_buckets(list(range(64)), costs, 64)] == [64]
+    assert [len(x) for x in shard.length_buckets(list(range(130)), [1.0] * 130, 64)] == [44, 43, 43]

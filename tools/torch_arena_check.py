@@ -17,6 +17,7 @@ stage = torch.empty(na, dtype=torch.uint8, device="cuda:0")
 ctx.copy(stage.data_ptr(), pa, na); torch.cuda.synchronize()
 chk = int(stage.to(torch.int64).sum().item())
 ctx.copy(pb, stage.data_ptr(), nb)
+b.arena_finalize()
 t = pkg.TimeEmbedding(256).embed(6.0); mel = fake_mel(900, seed=4)
 ia = a.transcribe_streaming(mel[None], t); ib = b.transcribe_streaming(mel[None], t)
 assert len(ia) > 0 and (ia == ib).all(), (ia, ib)

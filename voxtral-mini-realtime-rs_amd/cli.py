@@ -73,6 +73,26 @@ def transcribe_one(pkg, path, model, tokenizer, mel, pad_cfg, chunk_cfg, t_embed
     return " ".join(texts)
 
 
+def file_costs(paths):
+    """Decode cost of a file ~ its duration (the reference has no early stop): the file size is the proxy that needs no decode."""
+    import os
+    return [float(os.path.getsize(p)) if os.path.exists(p) else 0.0 for p in paths]
+
+
+def sharded_lines(pkg, paths, one, rank, world, group=None):
+    """N > 1 ranks: every rank transcribes its longest-first share of `paths` with `one(index) -> text`; rank 0 returns every line in input order
+    (None elsewhere).  The only collective is the final gather of the text lines (gloo: no GPU buffer involved)."""
+    import torch.distributed as dist
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("gloo")
+    try:
+        return pkg.shard.run_sharded(list(range(len(paths))), file_costs(paths), one, rank, world, group=group)
+    finally:
+        if own:
+            dist.barrier(); dist.destroy_process_group()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="voxtral-transcribe", description="Transcribe audio using Voxtral Mini 4B Realtime (MI355X HIP path)")
     ap.add_argument("-a", "--audio", action="append", default=[])
@@ -83,6 +103,8 @@ def main(argv=None):
     ap.add_argument("-d", "--delay", type=int, default=6)
     ap.add_argument("--max-mel-frames", type=int, default=1200)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1, help="extension: shard the input files over N GPUs of this node (one process per GPU, longest-first "
+                    "assignment, no collective in the data path; stdout keeps one line per input in input order)")
     ap.add_argument("--batch", type=int, default=1, help="extension: transcribe up to N un-chunked files per vox_transcribe_batch call "
                     "(same ids as one by one; output order unchanged)")
     a = ap.parse_args(argv)
@@ -101,6 +123,18 @@ def main(argv=None):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from __graft_entry__ import load_package
     pkg = load_package()
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        # the reference transcribes its files one after the other (bin/transcribe.rs:112-126); here they are independent units of work for N replicas:
+        # re-launch this command as N ranks (the driver's own launch for bench.py --gpus N); rank 0 prints every line, in input order
+        n_dev = pkg.device_count()
+        if n_dev < a.gpus:
+            log(f"Error: --gpus {a.gpus} requested but {n_dev} GPU(s) visible"); return 2
+        rc, out = pkg.shard.spawn_ranks(a.gpus, os.path.abspath(__file__), list(argv if argv is not None else sys.argv[1:]), capture=True)
+        sys.stdout.write(out); sys.stdout.flush()
+        return rc
+    if world > 1:
+        a.device = int(os.environ.get("LOCAL_RANK", rank))
     tok_path = a.tokenizer or os.path.join(a.model, "tekken.json")
     if not os.path.exists(tok_path):
         log(f"Error: Tokenizer not found at {tok_path}"); return 1
@@ -121,7 +155,10 @@ def main(argv=None):
     if a.batch > 1:
         # files that fit one chunk go through the batched path in groups of similar length; chunked / failing files fall back below
         units = []
+        mine = set(pkg.shard.lpt_partition(file_costs(paths), world)[rank]) if world > 1 else None
         for i, p in enumerate(paths):
+            if mine is not None and i not in mine:
+                continue
             try:
                 x, sr = load_wav(p)
                 if sr != 16000:
@@ -142,15 +179,25 @@ def main(argv=None):
                     texts[i] = tokenizer.decode([t for t in ids if t >= 1000]).strip()
             except Exception as e:
                 log(f"batched path failed ({e}); falling back to one by one")
-    for i, p in enumerate(paths):
+    def one(i):
+        nonlocal rc
         if i in texts:
-            print(texts[i], flush=True); continue
+            return texts[i]
+        p = paths[i]
         try:
             t1 = time.time(); text = transcribe_one(pkg, p, model, tokenizer, mel, pad_cfg, chunk_cfg, t_embed)
             log(f"{p}: {time.time() - t1:.3f}s")
         except Exception as e:      # per-utterance failure isolates to that line (empty), eval_wer.py:211-223 tolerates it
             log(f"Error transcribing {p}: {e}"); text = ""; rc = 1
-        print(text, flush=True)
+        return text
+    if world > 1:
+        lines = sharded_lines(pkg, paths, one, rank, world)
+        if rank == 0:
+            for text in lines:
+                print(text, flush=True)
+    else:
+        for i in range(len(paths)):
+            print(one(i), flush=True)
     return rc
 
 

@@ -610,7 +610,8 @@ struct vox_cache { vox_model* m; vox_ctx* ctx = nullptr; float *k = nullptr, *v 
 
 struct vox_model {
     vox_ctx* ctx = nullptr; vox_model_cfg cfg{};
-    uint8_t* arena = nullptr; uint64_t arena_bytes = 0;
+    uint8_t* arena = nullptr; uint64_t arena_bytes = 0, arena_primary_bytes = 0;      // [0, primary): everything parsed from the file; [primary, bytes): copies derived from it on the GPU
+    std::vector<Q4W*> tiled;                                 // Q4 linears that own a tile-ordered copy in the derived part
     const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_norm = nullptr, *dec_norm = nullptr;
     Q4W conv1_g{}, conv2_g{};                               // conv weights as im2col GEMM operands (two bf16 planes), optional
     const float *enc_cos = nullptr, *enc_sin = nullptr, *dec_cos = nullptr, *dec_sin = nullptr;
@@ -767,6 +768,7 @@ static void to_f32(const TensorView& t, uint64_t ne, float* out) {     // weight
 namespace {
 struct Loader {
     vox_model* m; const TensorSource* src; Arena ar; bool fill; void* staging = nullptr; size_t staging_cap = 0;
+    Arena ar2;      // DERIVED data (tile-ordered copies of the Q4 linears): laid out behind the primary planes so a multi-GPU start-up broadcasts only the primary part
     std::map<std::string, bool>* fmt_cache = nullptr;       // first tensor name of a dense linear -> all values bf16-representable (shared by both passes)
     std::string err;
 
@@ -843,8 +845,9 @@ struct Loader {
             }
             if (tile && nb % 4 == 0) {   // second copy in MFMA tile order for the batched-decode (M <= 16) kernel
                 const size_t n_tiles = (size_t)(Ntot + 15) / 16, nq = (size_t)nb / 4;
-                uint4* qt = ar.take<uint4>(n_tiles * nq * 64); uint16_t* st = ar.take<uint16_t>(n_tiles * nq * 64);
+                uint4* qt = ar2.take<uint4>(n_tiles * nq * 64); uint16_t* st = ar2.take<uint16_t>(n_tiles * nq * 64);
                 L->w.qt = qt; L->w.st = st;
+                if (ar2.base) m->tiled.push_back(&L->w);      // (second pass only; the Lin objects live in the model and never move)
                 if (fill) {
                     if (launch_q4_tile_build(L->w, qt, st, m->ctx->stream) != hipSuccess || hipStreamSynchronize(m->ctx->stream) != hipSuccess)
                         return setfail("q4_tile_build failed");
@@ -1033,11 +1036,12 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
     std::map<std::string, bool> fmt_cache;
     Loader plan{m, src, Arena{}, false}; plan.fmt_cache = &fmt_cache;
     if (!plan.run(q4)) { std::string e = plan.err; model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
-    m->arena_bytes = plan.ar.off + 256;
+    m->arena_primary_bytes = (plan.ar.off + 255) / 256 * 256 + 256;
+    m->arena_bytes = m->arena_primary_bytes + plan.ar2.off + 256;
     if (hipMalloc((void**)&m->arena, m->arena_bytes) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of %.1f MB weight arena failed", m->arena_bytes / 1e6); }
     const size_t max_q4 = layout_only ? 16 : std::max<uint64_t>(src->max_q4_bytes(), 16);
     DevBuf staging; if (staging.alloc(max_q4) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of staging buffer failed"); }
-    Loader fillr{m, src, Arena{m->arena, 0}, !layout_only, staging.p, max_q4}; fillr.fmt_cache = &fmt_cache;
+    Loader fillr{m, src, Arena{m->arena, 0}, !layout_only, staging.p, max_q4}; fillr.fmt_cache = &fmt_cache; fillr.ar2 = Arena{m->arena + m->arena_primary_bytes, 0};
     if (!fillr.run(q4)) { std::string e = fillr.err; model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
     const vox_model_cfg& c = m->cfg;
     const int qdim = c.dec_heads * c.dec_head_dim;
@@ -1094,7 +1098,17 @@ extern "C" int32_t vox_f32_model_load(vox_ctx* ctx, const char* path, vox_model*
 
 extern "C" int32_t vox_model_config(const vox_model* m, vox_model_cfg* out) { ARGCHK(m && out, "null argument"); *out = m->cfg; return VOX_OK; }
 extern "C" int32_t vox_model_weight_bytes(const vox_model* m, uint64_t* out) { ARGCHK(m && out, "null argument"); *out = m->arena_bytes; return VOX_OK; }
-extern "C" int32_t vox_model_arena(const vox_model* m, void** p, uint64_t* n) { ARGCHK(m && p && n, "null argument"); *p = m->arena; *n = m->arena_bytes; return VOX_OK; }
+extern "C" int32_t vox_model_arena(const vox_model* m, void** p, uint64_t* n) { ARGCHK(m && p && n, "null argument"); *p = m->arena; *n = m->arena_primary_bytes; return VOX_OK; }
+// receiver side of a multi-GPU start-up: the primary part of the arena has been filled (vox_model_arena + a broadcast); rebuild everything derived from it on
+// this GPU -- the tile-ordered copies of the Q4 linears (the decode engine's weight stream is built lazily at the first decode step either way)
+extern "C" int32_t vox_model_arena_finalize(vox_model* m) {
+    ARGCHK(m, "null argument"); VOXCHK(ctx_bind(m->ctx));
+    for (Q4W* w : m->tiled) HIPCHK(launch_q4_tile_build(*w, const_cast<uint4*>(w->qt), const_cast<uint16_t*>(w->st), m->ctx->stream));
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    m->eng_ready = false; m->eng_tab_cache = nullptr;      // a stream packed from an earlier arena content is stale
+    graphs_destroy(m);
+    return VOX_OK;
+}
 
 // Ada scales: 1 + w2(gelu(w0 t_embed)) (gguf/model.rs:250-255) -- loop-invariant for a fixed delay, computed once.
 extern "C" int32_t vox_model_set_t_embed(vox_model* m, const float* t_embed) {
@@ -1458,7 +1472,7 @@ static int32_t engine_prepare(vox_model* m) {
     if (!m->eng_ok || !m->eng_on || !m->cache || m->cache->max_seq > 1024) return VOX_OK;      // long caches keep the per-operator path (attention scores live in LDS)
     if (!m->eng_ready) {
         const size_t sb = eng_stream_bytes(c.dec_layers, c.vocab);
-        HIPCHK(hipMalloc((void**)&m->eng_stream, sb)); HIPCHK(hipMalloc((void**)&m->eng_state, eng_state_bytes())); HIPCHK(hipMalloc((void**)&m->eng_tab, sizeof(EngLayerTab) * 32));
+        if (!m->eng_stream) { HIPCHK(hipMalloc((void**)&m->eng_stream, sb)); HIPCHK(hipMalloc((void**)&m->eng_state, eng_state_bytes())); HIPCHK(hipMalloc((void**)&m->eng_tab, sizeof(EngLayerTab) * 32)); }
         HIPCHK(hipMemsetAsync(m->eng_stream, 0, sb, s)); HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), s));
         for (int l = 0; l < c.dec_layers; l++) {
             const DecLayer& L = m->dec[l];

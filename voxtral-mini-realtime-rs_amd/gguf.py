@@ -338,6 +338,10 @@ class Q4VoxtralModel:
         p = C.c_void_p(); n = C.c_uint64(); check(lib().vox_model_arena(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def arena_finalize(self):
+        """Receiver side of the multi-GPU start-up: the bytes of arena() have been written (e.g. by an RCCL broadcast); rebuild the derived copies on this GPU."""
+        check(lib().vox_model_arena_finalize(self.h))
+
     def encode_audio(self, mel):
         """mel [1,128,T] or [128,T] -> [1,S,dec_dim] (gguf/model.rs:783-788)"""
         mel = _f32(mel); mel = mel.reshape(mel.shape[-2], mel.shape[-1]); T = mel.shape[1]

@@ -33,7 +33,16 @@ def length_buckets(idx: Sequence[int], costs: Sequence[float], batch: int) -> li
     """Group a rank's share into batches of <= `batch` utterances of similar length (sorted by cost): the stacked encoder and
     the batched decode loop of vox_transcribe_batch pay for the longest member of a batch, so neighbours in length go together."""
     order = sorted(idx, key=lambda i: (-float(costs[i]), i))
-    return [order[k:k + batch] for k in range(0, len(order), max(batch, 1))]
+    n, b = len(order), max(int(batch), 1)
+    if n == 0:
+        return []
+    k = (n + b - 1) // b                       # number of batches; sizes differ by at most one (81 clips, batch 64 -> 41 + 40, not 64 + 17:
+    base, extra = divmod(n, k)                 # a 17-clip tail batch runs at a fraction of a 64-clip batch's throughput)
+    out, pos = [], 0
+    for j in range(k):
+        sz = base + (1 if j < extra else 0)
+        out.append(order[pos:pos + sz]); pos += sz
+    return out
 
 
 def run_sharded(items: Sequence, costs: Sequence[float], work: Callable, rank: int, world: int, group=None,
@@ -74,14 +83,17 @@ def free_port() -> int:
     return port
 
 
-def spawn_ranks(n: int, script: str, argv: Sequence[str], env: dict | None = None, port: int | None = None) -> int:
+def spawn_ranks(n: int, script: str, argv: Sequence[str], env: dict | None = None, port: int | None = None, capture: bool = False):
     """Run `script argv` as `n` ranks of ONE node through torch.distributed.run (rendezvous on 127.0.0.1: the container hostname may
-    not resolve) -- the launch the driver uses for `bench.py --gpus N`.  Returns the launcher's exit code.  The script reads
+    not resolve) -- the launch the driver uses for `bench.py --gpus N`.  Returns the launcher's exit code (with `capture`: (exit code, stdout)).  The script reads
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
     import subprocess
     import sys
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}", "--master-addr", "127.0.0.1",
            "--master-port", str(port or free_port()), script, *argv]
+    if capture:                                # (rc, stdout text): callers that re-emit rank 0's stdout through their own sys.stdout
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        return r.returncode, r.stdout
     return subprocess.call(cmd, env=env)
 
 

@@ -178,6 +178,7 @@ def main(argv=None):
     ap.add_argument("--gguf"); ap.add_argument("--model"); ap.add_argument("--tokenizer")
     ap.add_argument("--delay", type=int, default=6); ap.add_argument("--output"); ap.add_argument("--limit", type=int)
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1, help="shard the corpus over N GPUs (cli --gpus N: one process per GPU, transcriptions gathered in corpus order)")
     a = ap.parse_args(argv)
     if not a.gguf and not a.model:
         ap.error("Either --gguf or --model is required")
@@ -189,7 +190,7 @@ def main(argv=None):
         with wave.open(wav, "rb") as w:
             durations.append(w.getnframes() / float(w.getframerate()))
     from . import cli
-    args = ["--delay", str(a.delay), "--device", str(a.device), "--batch", str(a.batch)]
+    args = ["--delay", str(a.delay), "--device", str(a.device), "--batch", str(a.batch)] + (["--gpus", str(a.gpus)] if a.gpus > 1 else [])
     args += (["--gguf", a.gguf] if a.gguf else ["--model", a.model]) + (["--tokenizer", a.tokenizer] if a.tokenizer else [])
     for _, wav, _ in items:
         args += ["--audio", wav]
