@@ -324,3 +324,50 @@ def test_full_layout_only_arena_copy_start_up(pkg, full):
         assert np.array_equal(bb[0], m.transcribe_batch([x, x], t)[0]) and np.array_equal(bb[0], bb[1])
     finally:
         b.close()
+
+
+def test_full_30s_heavytail_vs_oracle_golden(pkg):
+    """Stress statistics at full size against the CPU oracle (tests/golden/make_fullsize_heavytail_golden.py): Student-t(4) block scales, six x50 outlier channels in
+    the decoder's residual stream, |logit| ~ 30, on a 30 s clip (234 decoder positions; the encoder's 750-frame window bites).  Exercises the hi/lo-bf16 splits of the MFMA
+    GEMMs, the engine's x * 512 pre-scale and every fixed-order cross-CU sum on data with real-checkpoint dynamics.  ids identical up to a near-tie of the oracle,
+    top logits within 2e-4 of the largest |logit|, on the decode engine, the per-operator path and the batch path."""
+    import hashlib
+    gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_30s_heavytail_oracle.npz")
+    if not os.path.exists(gpath):
+        pytest.skip("heavy-tail golden not generated yet")
+    g = np.load(gpath)
+    path = os.path.join(cache_dir(), "full_q4_heavytail_seed43.gguf")
+    if not os.path.exists(path):
+        pkg.synth.write_synthetic_gguf(path + ".tmp", pkg.synth.ModelDims(), seed=43, heavy_tail=True); os.replace(path + ".tmp", path)
+    hs = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            hs.update(chunk)
+    assert hs.digest() == g["gguf_sha256"].tobytes()
+    x = pkg.synth.synth_audio(30.0, seed=4321)
+    assert hashlib.sha256(x.tobytes()).digest() == g["audio_sha256"].tobytes()
+    ctx = pkg.Context(0); m = pkg.Q4ModelLoader.from_file(path).load(ctx)
+    try:
+        t = pkg.TimeEmbedding(3072).embed(6.0)
+        mel = pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x)))
+        assert mel.shape[0] == int(g["mel_frames"])
+        rids, top1, top2, amax = g["ids"], g["top1"], g["top2"], float(g["logit_absmax"])
+        assert amax > 15.0                                                         # the fixture really has large logits
+        for engine in (True, False):
+            if m.set_decode_engine(engine) != engine and engine:
+                continue
+            ids, lg = m.transcribe_streaming(np.ascontiguousarray(mel.T)[None], t, return_logits=True)
+            assert len(ids) == len(rids) > 180
+            agree = ids == rids
+            stop = len(ids) if agree.all() else int(np.argmin(agree))
+            if stop < len(ids):
+                assert top1[stop] - top2[stop] <= 10 * TOL * max(1.0, amax), f"engine={engine}: ids differ at step {stop} with a clear margin"
+            assert stop >= 1
+            err = float(np.abs(lg[:stop].max(axis=1) - top1[:stop]).max())
+            assert err <= TOL * max(1.0, amax), (engine, err, amax)
+            assert np.abs(lg[0, :4096] - g["logits_step0"]).max() <= TOL * max(1.0, amax)
+            print(f"heavy-tail golden (engine={engine}): ids agree for {stop}/{len(ids)} steps; max top-logit error {err:.3e} at |logit| max {amax:.1f}")
+            ids_b = m.transcribe_batch([x], t)[0]
+            assert (ids_b[:stop] == rids[:stop]).all()
+    finally:
+        m.close(); ctx.close()

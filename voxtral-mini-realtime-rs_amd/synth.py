@@ -186,10 +186,16 @@ def write_gguf(path: str, tensors, version: int = 3):
             f.write(buf); pos += sz
 
 
-def write_synthetic_gguf(path: str, dims: ModelDims, seed: int = 42, dense_override=None):
-    """Write a synthetic Q4_0 GGUF for ``dims``.  Deterministic in (dims, seed).
+HEAVY_OUTLIER_CHANNELS = (7, 301, 1024, 1777, 2048, 3000)      # residual-stream channels whose producers (decoder wo / w2 rows) are scaled x50
+
+
+def write_synthetic_gguf(path: str, dims: ModelDims, seed: int = 42, dense_override=None, heavy_tail: bool = False):
+    """Write a synthetic Q4_0 GGUF for ``dims``.  Deterministic in (dims, seed, heavy_tail).
     ``dense_override``: optional {name: float32 array} quantised with the reference quantiser
-    instead of the random generator."""
+    instead of the random generator.
+    ``heavy_tail``: realistic statistics instead of N(0, sigma^2) -- every Q4 block scale is multiplied by 0.3 + |Student-t(nu=4)| (clipped at 20: outlier
+    blocks), the decoder's wo / w2 rows that feed HEAVY_OUTLIER_CHANNELS of the residual stream are scaled x50 (outlier channels in h, as real
+    checkpoints have), and the final norm weight is centred on 5 instead of 1 (logits an order of magnitude larger)."""
     man = tensor_manifest(dims)
 
     def gen(idx, name, shape, kind, sigma):
@@ -200,9 +206,22 @@ def write_synthetic_gguf(path: str, dims: ModelDims, seed: int = 42, dense_overr
                 a = np.asarray(dense_override[name], dtype=np.float32).reshape(shape)
                 return quantize_q4_0(a) if kind == "q4" else a
             if kind == "q4":
-                return synth_q4_blocks(rng, ne, sigma)
+                blk = synth_q4_blocks(rng, ne, sigma)
+                if heavy_tail:
+                    b = blk.reshape(-1, 18)
+                    d = b[:, 0:2].copy().view(np.float16).astype(np.float32).reshape(-1)
+                    d *= np.minimum(0.3 + np.abs(rng.standard_t(4, d.size)), 20.0).astype(np.float32)
+                    if name.endswith("attention.wo.weight") or name.endswith("feed_forward.w2.weight"):
+                        if name.startswith("layers."):                     # decoder only: rows = residual-stream channels
+                            nbr = int(shape[1]) // 32
+                            for ch in HEAVY_OUTLIER_CHANNELS:
+                                if ch < int(shape[0]):
+                                    d[ch * nbr:(ch + 1) * nbr] *= 50.0
+                    b[:, 0:2] = np.minimum(d, 6.0e4).astype(np.float16).view(np.uint8).reshape(-1, 2)
+                return blk
             if kind == "norm":
-                return (1.0 + sigma * rng.standard_normal(ne)).astype(np.float32)
+                centre = 5.0 if (heavy_tail and name == "norm.weight") else 1.0
+                return (centre + sigma * rng.standard_normal(ne)).astype(np.float32)
             return (sigma * rng.standard_normal(ne)).astype(np.float32)
         return make
 
