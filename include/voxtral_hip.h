@@ -229,6 +229,9 @@ int32_t vox_embed_tokens_from_ids(vox_model* m, const int32_t* ids, int32_t n, f
 int32_t vox_forward_hidden_with_cache(vox_model* m, const float* x_MxD, int32_t M, const float* t_embed,
                                       vox_cache* cache, float* out_MxD);                              /* host in/out */
 int32_t vox_lm_head(vox_model* m, const float* hidden_MxD, int32_t M, float* logits_MxV);            /* host in/out */
+/* Q4VoxtralModel::generate_step_with_cache, gguf/model.rs:857-867 (text tokens only: embed -> decoder against the cache -> final norm -> lm_head) in one call;
+ * token_ids[n] host, logits[n][vocab] host; the cache advances by n. */
+int32_t vox_generate_step_with_cache(vox_model* m, const int32_t* token_ids, int32_t n, const float* t_embed, vox_cache* cache, float* logits_nxV);
 
 /* stage timers, BenchmarkResult parity (bin/e2e_bench.rs:62-74): ms of the last transcribe call */
 typedef struct { double preprocess_ms, encode_ms, decode_ms, total_ms; int32_t decode_tokens; int32_t graph_replays; } vox_timings;

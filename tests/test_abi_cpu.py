@@ -139,3 +139,26 @@ def test_integration_md_sys_block_is_complete_and_current(pkg):
     for name in sorted(declared):
         assert f"pub fn {name}(" in block, name
     assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_sys_block.py"), "--check"]).returncode == 0
+
+
+def _build_abi_smoke(tmp):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.join(root, "voxtral-mini-realtime-rs_amd")
+    exe = os.path.join(str(tmp), "abi_smoke")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "abi_smoke.c"), "-o", exe,
+           "-L" + pkg_dir, "-lvoxtral_hip", "-lm", "-Wl,-rpath," + pkg_dir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_valid_c11_and_links(pkg, tmp_path):
+    """include/voxtral_hip.h through a real C compiler: tests/abi_smoke.c (C11, -Wall -Wextra -Werror) includes the header, calls ~25 entry points with the declared
+    types and links against libvoxtral_hip.so -- ctypes only checks names, this catches header / implementation signature drift.  Without a GPU the program runs the
+    host-only entry points for real and checks that vox_ctx_create fails with VOX_ERR_HIP (no CPU fallback)."""
+    import subprocess
+    exe = _build_abi_smoke(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host helpers ok" in r.stdout

@@ -287,3 +287,65 @@ def test_fused_attention_equals_separate_launches(pkg, tiny, monkeypatch):
         a = run()
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     monkeypatch.delenv("VOX_FUSED_ATTN")
+
+
+def test_abi_smoke_c_program_on_device(pkg, tmp_path):
+    """tests/abi_smoke.c (C11 translation unit over include/voxtral_hip.h) with a GPU: context, GGUF reader, model load, vox_transcribe_audio, stage timings,
+    vox_generate_step_with_cache, cache accessors -- every call through the C header's own declarations."""
+    import subprocess
+    from test_abi_cpu import _build_abi_smoke
+    path, _ = tiny_gguf()
+    r = subprocess.run([_build_abi_smoke(tmp_path), path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "device path ok" in r.stdout, r.stdout
+
+
+def test_generate_step_with_cache_equals_composed_calls(pkg, tiny):
+    """Q4VoxtralModel::generate_step_with_cache (gguf/model.rs:857-867) as ONE C-ABI call against embed_tokens_from_ids -> forward_hidden_with_cache -> lm_head:
+    the same kernels in the same order, so the logits are bit-identical, for a multi-token prefix and for single-token steps; the cache advances alike."""
+    m = tiny[0]
+    t = pkg.TimeEmbedding(m.config.dec_dim).embed(6.0)
+    dec = m.decoder()
+    ids = np.array([1, 32, 32, 5, 7], dtype=np.int32)
+    ca = dec.create_cache_preallocated(32); cb = dec.create_cache_preallocated(32)
+    la = m.generate_step_with_cache(ids, t, ca)
+    hb = dec.forward_hidden_with_cache(dec.embed_tokens_from_ids(ids, 1, ids.size), t, cb)
+    lb = dec.lm_head(hb)[0]
+    assert la.shape == lb.shape == (5, m.config.vocab) and np.array_equal(la, lb)
+    for tok in (9, 11):
+        one = np.array([tok], dtype=np.int32)
+        la = m.generate_step_with_cache(one, t, ca)
+        lb = dec.lm_head(dec.forward_hidden_with_cache(dec.embed_tokens_from_ids(one, 1, 1), t, cb))[0]
+        assert np.array_equal(la, lb)
+    assert ca.seq_len() == cb.seq_len() == 7
+
+
+@pytest.mark.parametrize("scheme", ["reference", "ggml"])
+def test_exported_gguf_round_trip_on_device(pkg, orc, ctx, tmp_path, scheme):
+    """SURVEY 8(f4) on the GPU: a dense checkpoint (SafeTensors) exported by export.py (reference test quantiser gguf/tests.rs:24-57, and llama.cpp's quantize_row_q4_0_ref)
+    -> vox_q4_model_load -> whole hot path, against the CPU oracle loading THE SAME exported file: encoder output and decoder logits within the stated 2e-4, greedy ids
+    equal up to a near-tie; and the Q4 model stays close to the dense model it was exported from (quantisation error, not a format error)."""
+    S = pkg.synth; E = pkg.export
+    d = S.tiny_dims()
+    st = str(tmp_path / "dense.safetensors"); S.write_synthetic_safetensors(st, d, seed=5)
+    out = str(tmp_path / f"exported_{scheme}.gguf")
+    stats = E.export_q4_gguf(st, out, scheme=scheme)
+    assert stats["q4"] > 0
+    m = pkg.Q4ModelLoader.from_file(out).load(ctx); o = orc.Model(out)
+    try:
+        t = pkg.TimeEmbedding(d.dec_dim).embed(6.0); mel = fake_mel(900, seed=11)
+        a_ref = o.encode_audio(mel); a_hip = m.encode_audio(mel[None])[0]
+        assert rel_err(a_hip, a_ref) < 3e-4, rel_err(a_hip, a_ref)
+        ids, lg = m.transcribe_streaming(mel[None], t, return_logits=True)
+        rids, rlg = o.transcribe_streaming(mel, t, want_logits=True)
+        stop = check_greedy_ids(ids, rids, rlg, 2e-4)
+        assert stop >= 1 and rel_err(lg[:stop], rlg[:stop]) < 2e-4
+        # the dense model the file was exported from: same geometry, outputs within quantisation error (loose, structural check)
+        md = pkg.VoxtralModelLoader.from_file(st).load(ctx)
+        try:
+            a_dense = md.encode_audio(mel[None])[0]
+            assert a_dense.shape == a_hip.shape and rel_err(a_hip, a_dense) < 0.5
+        finally:
+            md.close()
+    finally:
+        m.close(); o.close()

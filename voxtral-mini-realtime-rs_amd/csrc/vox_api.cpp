@@ -1943,6 +1943,26 @@ extern "C" int32_t vox_lm_head(vox_model* m, const float* hidden, int32_t M, flo
     return VOX_OK;
 }
 
+// Q4VoxtralModel::generate_step_with_cache (gguf/model.rs:857-867): decoder.forward_with_cache(token_ids) = embed + layers against the cache + final norm, then lm_head --
+// one call, everything stays on the device between the three stages
+extern "C" int32_t vox_generate_step_with_cache(vox_model* m, const int32_t* token_ids, int32_t n, const float* t_embed, vox_cache* kc, float* logits) {
+    ARGCHK(m && token_ids && t_embed && kc && logits && n > 0, "bad argument"); ARGCHK(kc->m == m && kc->kind == 0, "cache belongs to another model or is an encoder cache"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    for (int i = 0; i < n; i++) ARGCHK(token_ids[i] >= 0 && token_ids[i] < c.vocab, "token id %d out of range", token_ids[i]);
+    ARGCHK(kc->len + n <= kc->max_seq, "KV cache overflow: %d + %d > %d", kc->len, n, kc->max_seq);
+    VOXCHK(vox_model_set_t_embed(m, t_embed));
+    DevBuf di, dx, dn, dy; HIPCHK(di.alloc((size_t)n * 4)); HIPCHK(dx.alloc((size_t)n * c.dec_dim * 4)); HIPCHK(dn.alloc((size_t)n * c.dec_dim * 4)); HIPCHK(dy.alloc((size_t)n * c.vocab * 4));
+    HIPCHK(hipMemcpyAsync(di.p, token_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(launch_embed(m->tok.w, di.as<int>(), n, nullptr, c.dec_dim, nullptr, 0, 0, dx.as<float>(), s));
+    if (n == 1) { if (m->d_wo_acc) HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * c.dec_dim * 8, s)); VOXCHK(decoder_step_dev(m, dx.as<float>(), kc, nullptr, kc->len)); }
+    else VOXCHK(decoder_prefill_dev(m, dx.as<float>(), n, kc, kc->len));
+    kc->len += n;
+    HIPCHK(launch_rms_norm(dx.as<float>(), c.dec_dim, n, c.dec_dim, m->dec_norm, nullptr, c.norm_eps, dn.as<float>(), c.dec_dim, s));
+    VOXCHK(q4_linear_dev(m->ctx, m->tok.w, nullptr, dn.as<float>(), c.dec_dim, n, dy.as<float>(), c.vocab));
+    HIPCHK(hipMemcpyAsync(logits, dy.p, (size_t)n * c.vocab * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    return VOX_OK;
+}
+
 extern "C" int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out) { ARGCHK(m && out, "null argument"); *out = m->timings; return VOX_OK; }
 
 // ---- measurement hook: average launch duration of one decode-step GEMV class, HIP events on the ctx stream

@@ -327,6 +327,13 @@ class Q4VoxtralModel:
     def create_decoder_cache_preallocated(self, max_seq):
         return LayerCaches(self, max_seq)
 
+    def generate_step_with_cache(self, token_ids, t_embed, caches):
+        """gguf/model.rs:857-867: logits [n][vocab] of the text tokens `token_ids` against the decoder cache (which advances by n)."""
+        ids = np.ascontiguousarray(token_ids, dtype=np.int32).reshape(-1)
+        out = np.empty((ids.size, self.config.vocab), dtype=np.float32)
+        check(lib().vox_generate_step_with_cache(self.h, _ptr(ids), ids.size, _ptr(_f32(t_embed).reshape(-1)), caches.h, _ptr(out)))
+        return out
+
     def set_decode_engine(self, on: bool) -> bool:
         """Persistent decode-step engine (one launch per token) on / off; returns whether it is active (it needs the real decoder geometry on a 256-CU device)."""
         a = C.c_int32(); check(lib().vox_model_set_decode_engine(self.h, 1 if on else 0, C.byref(a))); return bool(a.value)
