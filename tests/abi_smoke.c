@@ -32,6 +32,50 @@ int main(int argc, char** argv) {
     CHECK(fabsf(te[0] - cosf(6.0f)) < 1e-5f, "time embedding layout: cos first (time_embedding.rs:41-71)");
     printf("host helpers ok: pad %zu -> %zu samples\n", n, total);
 
+    /* ---- host-only: the GGUF reader (gguf/reader.rs:98-223) on an image built here -- a v3 file with one KV and one 2 x 4 F32 tensor -- then on EVERY truncation
+     * of it (each must fail cleanly: this is the reader's pointer arithmetic under -fsanitize=address in tests/test_abi_cpu.py) and as two shards */
+    {
+        unsigned char img[512]; size_t o = 0;
+#define PUT(ptr, len) do { memcpy(img + o, (ptr), (len)); o += (len); } while (0)
+#define PUT_U32(v) do { const uint32_t v_ = (v); PUT(&v_, 4); } while (0)
+#define PUT_U64(v) do { const uint64_t v_ = (v); PUT(&v_, 8); } while (0)
+#define PUT_STR(str) do { PUT_U64(strlen(str)); PUT((str), strlen(str)); } while (0)
+        PUT_U32(0x46554747u); PUT_U32(3u); PUT_U64(1); PUT_U64(1);
+        PUT_STR("general.architecture"); PUT_U32(8u); PUT_STR("voxtral");
+        PUT_STR("t.weight"); PUT_U32(2u); PUT_U64(4); PUT_U64(2); PUT_U32(0u); PUT_U64(0);
+        while (o % 32) img[o++] = 0;
+        float vals[8]; for (int i = 0; i < 8; i++) vals[i] = 1.5f * (float)i - 2.0f;
+        PUT(vals, sizeof vals);
+        const size_t size = o;
+        vox_gguf* g = NULL;
+        CHECK(vox_gguf_open_memory(img, size, &g) == VOX_OK, "vox_gguf_open_memory");
+        uint32_t ver = 0; uint64_t cnt = 0; const char* nm = NULL;
+        CHECK(vox_gguf_version(g, &ver) == VOX_OK && ver == 3, "version 3");
+        CHECK(vox_gguf_tensor_count(g, &cnt) == VOX_OK && cnt == 1, "one tensor");
+        CHECK(vox_gguf_tensor_name(g, 0, &nm) == VOX_OK && strcmp(nm, "t.weight") == 0, "tensor name");
+        uint64_t dims[4] = {0, 0, 0, 0}, nbytes = 0; uint32_t nd = 0, dt = 99;
+        CHECK(vox_gguf_tensor_info(g, "t.weight", dims, &nd, &dt, &nbytes) == VOX_OK && nd == 2 && dims[0] == 4 && dims[1] == 2 && dt == 0 && nbytes == 32, "tensor info");
+        float back[8]; CHECK(vox_gguf_tensor_data(g, "t.weight", back, sizeof back) == VOX_OK && memcmp(back, vals, sizeof vals) == 0, "tensor data");
+        CHECK(vox_gguf_tensor_data(g, "t.weight", back, 16) != VOX_OK, "short destination is refused");
+        CHECK(vox_gguf_tensor_info(g, "missing", dims, &nd, &dt, &nbytes) != VOX_OK, "unknown tensor is refused");
+        CHECK(vox_gguf_close(g) == VOX_OK, "close");
+        int refused = 0;
+        for (size_t cut = 0; cut < size; cut++) {                 /* heap copy of exactly `cut` bytes: a read past the end is an ASAN report */
+            unsigned char* part = (unsigned char*)malloc(cut ? cut : 1); memcpy(part, img, cut);
+            vox_gguf* gt = NULL;
+            if (vox_gguf_open_memory(part, cut, &gt) != VOX_OK) refused++;
+            else { float tmp[8]; if (vox_gguf_tensor_data(gt, "t.weight", tmp, sizeof tmp) != VOX_OK) refused++; (void)vox_gguf_close(gt); }
+            free(part);
+        }
+        CHECK(refused == (int)size, "every truncated image is refused (at open or at the tensor read)");
+        const void* shards[2] = {img, img + 50}; const size_t sizes[2] = {50, size - 50};
+        CHECK(vox_gguf_open_shards(shards, sizes, 2, &g) == VOX_OK, "vox_gguf_open_shards");
+        CHECK(vox_gguf_tensor_data(g, "t.weight", back, sizeof back) == VOX_OK && memcmp(back, vals, sizeof vals) == 0, "sharded image reads the same");
+        CHECK(vox_gguf_close(g) == VOX_OK, "close shards");
+        printf("gguf reader ok: %zu-byte image, %d truncations refused, shards ok\n", size, refused);
+    }
+    if (getenv("VOX_SMOKE_HOST_ONLY")) { free(x); free(xp); return 0; }
+
     /* ---- device: context, GGUF reader, model load, one transcription through the whole hot path */
     int32_t ndev = 0; CHECK(vox_device_count(&ndev) == VOX_OK, "vox_device_count");
     vox_ctx* ctx = NULL;

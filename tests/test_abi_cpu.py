@@ -162,3 +162,28 @@ def test_header_is_valid_c11_and_links(pkg, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host helpers ok" in r.stdout
+
+
+def test_host_code_under_address_sanitizer(pkg, tmp_path):
+    """vox_api.cpp's host side (GGUF reader, padding / chunk arithmetic, argument checks: ~2 000 lines of pointer arithmetic) rebuilt with -fsanitize=address and driven by
+    tests/abi_smoke.c's host section, including every truncation of a GGUF image.  Device objects are linked unchanged (ASAN does not instrument gfx950 code)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.join(root, "voxtral-mini-realtime-rs_amd"); bdir = os.path.join(pkg_dir, "build")
+    if not (os.path.exists(os.path.join(bdir, "vox_kernels.o")) and os.path.exists(os.path.join(bdir, "vox_engine.o"))):
+        pytest.skip("device objects not built")
+    hipcc = "/opt/rocm/bin/hipcc"; clang = "/opt/rocm/lib/llvm/bin/clang"
+    d = str(tmp_path)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=address", "-fno-omit-frame-pointer", "-x", "hip", "-c",
+                        os.path.join(pkg_dir, "csrc", "vox_api.cpp"), "-o", os.path.join(d, "vox_api.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-o", os.path.join(d, "libvoxtral_hip.so"),
+                        os.path.join(bdir, "vox_kernels.o"), os.path.join(bdir, "vox_engine.o"), os.path.join(d, "vox_api.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([clang, "-std=c11", "-g", "-fsanitize=address", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "abi_smoke.c"), "-o",
+                        os.path.join(d, "abi_smoke_asan"), "-L" + d, "-lvoxtral_hip", "-lm", "-Wl,-rpath," + d], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", VOX_SMOKE_HOST_ONLY="1")
+    r = subprocess.run([os.path.join(d, "abi_smoke_asan")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, r.stdout + r.stderr[-3000:]
+    assert "gguf reader ok" in r.stdout
