@@ -237,6 +237,10 @@ int32_t vox_generate_step_with_cache(vox_model* m, const int32_t* token_ids, int
 typedef struct { double preprocess_ms, encode_ms, decode_ms, total_ms; int32_t decode_tokens; int32_t graph_replays; } vox_timings;
 int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out);
 
+/* The VOX_* measurement knobs (kernel-selection overrides used by tools/ and by the A/B tests) are read from the environment ONCE, at vox_ctx_create;
+ * this re-reads them (tests that flip a knob between two calls).  Not part of the reference surface. */
+int32_t vox_debug_reload_knobs(void);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -------- */
 /* Launch the decode-step Q4 GEMV of decoder layer `layer` (`which`: 0 qkv, 1 wo, 2 w1w3, 3 w2, 4 lm_head; 5 = the whole step as one decode-engine launch)
  * `iters` times on the ctx stream, cycling layers so weights stay HBM-cold; returns the average

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vox_device_count": (i32, [P(i32)]),
     "vox_ctx_create": (i32, [i32, P(vp)]),
     "vox_ctx_destroy": (i32, [vp]),
+    "vox_debug_reload_knobs": (i32, []),
     "vox_ctx_synchronize": (i32, [vp]),
     "vox_ctx_stream": (i32, [vp, P(vp)]),
     "vox_dev_alloc": (i32, [vp, sz, P(vp)]),
@@ -123,12 +124,22 @@ SIGNATURES = {
 }
 
 _LIB = None
+_KNOBS = None
+
+
+def _knob_env():
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("VOX_")))
 
 
 def lib():
-    """dlopen libvoxtral_hip.so and bind every declared symbol.  Raises if the library is missing."""
-    global _LIB
+    """dlopen libvoxtral_hip.so and bind every declared symbol.  Raises if the library is missing.
+    The library snapshots its VOX_* measurement knobs at vox_ctx_create; this Python mirror (tests and tools flip knobs between two calls) asks it to
+    re-read them whenever the VOX_* part of os.environ has changed since the last call."""
+    global _LIB, _KNOBS
     if _LIB is not None:
+        k = _knob_env()
+        if k != _KNOBS:
+            _KNOBS = k; _LIB.vox_debug_reload_knobs()
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise VoxError(-1, f"{LIB_PATH} not built: run `python __graft_entry__.py build` (hipcc, gfx950). "
@@ -138,7 +149,7 @@ def lib():
         fn = getattr(L, name)   # AttributeError here == missing export == ABI drift; fail loudly
         fn.restype = res
         fn.argtypes = args
-    _LIB = L
+    _LIB = L; _KNOBS = _knob_env()
     return L
 
 

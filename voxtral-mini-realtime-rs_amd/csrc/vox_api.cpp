@@ -56,7 +56,7 @@ namespace {
 struct Roctx {
     int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
     Roctx() {
-        if (getenv("VOX_NO_ROCTX")) return;
+        if (knob_str("VOX_NO_ROCTX")) return;
         void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
         if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
         if (!h) return;
@@ -105,11 +105,13 @@ extern "C" int32_t vox_ctx_create(int32_t device, vox_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(VOX_ERR_HIP, "no HIP device available (libvoxtral_hip has no CPU fallback)"); }
     ARGCHK(device >= 0 && device < n, "device %d out of range (have %d)", device, n);
     HIPCHK(hipSetDevice(device));
+    knobs_reload();      // the VOX_* measurement knobs are read here, once: no launch path calls getenv
     vox_ctx* c = new vox_ctx(); c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(VOX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = c; return VOX_OK;
 }
+extern "C" int32_t vox_debug_reload_knobs(void) { knobs_reload(); return VOX_OK; }
 extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
     if (!c) return VOX_OK;
     (void)hipSetDevice(c->device);
@@ -1053,7 +1055,7 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
     A((void**)&m->d_q, (size_t)qdim * 4 * 4); A((void**)&m->d_att, (size_t)qdim * 4 * 4); A((void**)&m->d_act, (size_t)c.dec_ffn * 4 * 4);
     A((void**)&m->d_h2, (size_t)c.dec_dim * 4); A((void**)&m->d_wo_acc, (size_t)c.dec_layers * c.dec_dim * 8);
     A((void**)&m->d_logits, (size_t)c.vocab * 4); A((void**)&m->d_part_val, (size_t)m->n_parts * 4 * 4); A((void**)&m->d_part_idx, (size_t)m->n_parts * 4 * 4);
-    { const char* e_ = getenv("VOX_ATTN_CNT_STRIDE"); if (e_ && atoi(e_) >= 1 && atoi(e_) <= (1 << 16)) m->attn_cnt_stride = atoi(e_); }
+    { const char* e_ = knob_str("VOX_ATTN_CNT_STRIDE"); if (e_ && atoi(e_) >= 1 && atoi(e_) <= (1 << 16)) m->attn_cnt_stride = atoi(e_); }
     const size_t cnt_bytes = (size_t)c.dec_layers * c.dec_heads * m->attn_cnt_stride * 4;
     A((void**)&m->d_attn_cnt, cnt_bytes);
     if (e != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of decode buffers failed: %s", hipGetErrorString(e)); }
@@ -1061,12 +1063,12 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
     for (int i = 0; i < c.dec_layers; i++) m->dec[i].ada_mul = m->ada_mul + (size_t)i * c.dec_dim;
     // decode engine eligibility: the real Voxtral decoder geometry, every decoder linear Q4_0 without bias, a 256-CU device.  VOX_ENGINE=0 keeps the per-operator launches.
     {
-        const char* ev = getenv("VOX_ENGINE"); bool ok = !(ev && ev[0] == '0') && c.dec_layers <= 32 && eng_geometry_ok(c.dec_dim, c.dec_heads, c.dec_kv_heads, c.dec_head_dim, c.dec_ffn, c.vocab, 256);
+        const char* ev = knob_str("VOX_ENGINE"); bool ok = !(ev && ev[0] == '0') && c.dec_layers <= 32 && eng_geometry_ok(c.dec_dim, c.dec_heads, c.dec_kv_heads, c.dec_head_dim, c.dec_ffn, c.vocab, 256);
         hipDeviceProp_t prop; if (ok && (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess || prop.multiProcessorCount != 256)) ok = false;
         for (int i = 0; ok && i < c.dec_layers; i++) { const DecLayer& L = m->dec[i]; for (const Lin* w : {&L.wqkv, &L.wo, &L.w13, &L.w2}) if (w->w.fmt != WFMT_Q4_0 || !w->w.qs || !w->w.sc || w->bias) ok = false; }
         if (ok && (m->tok.w.fmt != WFMT_Q4_0 || !m->tok.w.qs)) ok = false;
         m->eng_ok = ok; m->eng_on = ok;
-        if (const char* f = getenv("VOX_ENGINE_FLAGS")) m->eng_flags = atoi(f);      // measurement knobs of tools/micro/engine_bench (thin / probe / XCD-local edges)
+        if (const char* f = knob_str("VOX_ENGINE_FLAGS")) m->eng_flags = atoi(f);      // measurement knobs of tools/micro/engine_bench (thin / probe / XCD-local edges)
     }
     *out = m; return VOX_OK;
 }
@@ -1155,7 +1157,7 @@ static size_t conv_scratch_floats(const vox_model* m, int T) {
 }
 static int32_t conv_stem_dev(vox_model* m, const float* d_mel, int T, float* c1, float* x) {
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream; const int D = c.enc_dim, T1 = conv_len(T), S = conv_len(T1);
-    const bool conv_mfma = m->conv1_g.qs && m->conv2_g.qs && !getenv("VOX_CONV_VALU");
+    const bool conv_mfma = m->conv1_g.qs && m->conv2_g.qs && !knob_str("VOX_CONV_VALU");
     if (conv_mfma) {
         // gelu(conv1d k3 s2 p1) as an im2col GEMM: with the input token-major and one zero row either side, output row t reads the
         // CONTIGUOUS window rows [2t, 2t+2] of the padded buffer (= frames 2t-1..2t+1): A = that buffer with row stride 2*Cin, K = 3*Cin
@@ -1375,7 +1377,7 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
     // 17..48 rows in one sequence (the 38-token prefill): both RMSNorms write their output straight as XF tiles (the MFMA A-fragments the
     // q4_skinny_mt_kernel consumes) into the context's XF scratch -- no f32 xn, no conversion launch for q|k|v and w1|w3
     auto xf_ok = [&](const Q4W& w) { return w.fmt == WFMT_Q4_0 && w.qt && w.st && w.nb % 4 == 0 && w.K == D && D % 128 == 0 && D <= 10240; };
-    bool norm_xf = n_seq == 1 && M > 16 && M <= 48 && getenv("VOX_PREFILL_NO_NORM_XF") == nullptr;
+    bool norm_xf = n_seq == 1 && M > 16 && M <= 48 && knob_str("VOX_PREFILL_NO_NORM_XF") == nullptr;
     if (norm_xf) {
         if (!cx->xf_scratch) { cx->xf_scratch_bytes = (size_t)3 * 16384 * 64; if (hipMalloc((void**)&cx->xf_scratch, cx->xf_scratch_bytes) != hipSuccess) { (void)hipGetLastError(); cx->xf_scratch = nullptr; cx->xf_scratch_bytes = 0; } }
         norm_xf = cx->xf_scratch != nullptr;
@@ -1603,7 +1605,7 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     } else if (steps > 0) {
         // Replayed graphs: one step per graph by default.  VOX_DECODE_UNROLL=U (measurement knob) also builds a U-step graph for the bulk of
         // the steps; measured in round 2 (profiles/r02_decode_knobs.txt): no gain -- graph boundaries are not where the time goes.
-        int U = 1; { const char* e = getenv("VOX_DECODE_UNROLL"); if (e && atoi(e) >= 1 && atoi(e) <= 32) U = atoi(e); }
+        int U = 1; { const char* e = knob_str("VOX_DECODE_UNROLL"); if (e && atoi(e) >= 1 && atoi(e) <= 32) U = atoi(e); }
         if (m->graph_cache != m->cache || m->graph_audio != m->d_audio || m->graph_unroll != U) { graphs_destroy(m); m->graph_cache = m->cache; m->graph_audio = m->d_audio; m->graph_unroll = U; }
         auto capture = [&](int which, int n_steps) -> int32_t {
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1793,7 +1795,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     // The step's GEMM inputs live as XF fragment planes (bf16 hi+lo in MFMA A-operand order, written once by the producing kernel), so
     // the skinny kernels spend no VALU on conversion and RMSNorm output never exists as f32.  Sequences are processed in groups of
     // 16 rows (one MFMA m-tile); the groups of a layer run back to back so the second group finds the layer's weights in L2 / MALL.
-    const bool use_xf = m->tok.w.fmt == WFMT_Q4_0 && m->dec[0].wqkv.w.fmt == WFMT_Q4_0 && m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !getenv("VOX_BATCH_NO_XF");
+    const bool use_xf = m->tok.w.fmt == WFMT_Q4_0 && m->dec[0].wqkv.w.fmt == WFMT_Q4_0 && m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !knob_str("VOX_BATCH_NO_XF");
     const int n_grp = (n + 15) / 16;
     auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
     if (use_xf) {
@@ -1814,7 +1816,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         if (use_xf) {
             // groups are independent sequences: group gi > 0 runs its whole layer chain on a side stream (fork / join with events, which
             // a stream capture records as parallel graph branches), so the latency-bound skinny kernels of different groups overlap
-            const bool fork = n_grp > 1 && !getenv("VOX_BATCH_SERIAL_GROUPS");
+            const bool fork = n_grp > 1 && !knob_str("VOX_BATCH_SERIAL_GROUPS");
             if (fork) {
                 if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
                 for (int i = 0; i < n_grp - 1 && i < 3; i++) {
@@ -1839,7 +1841,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
                       HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, sg)); }
                     AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
                     ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = pg; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
-                    ap.out_xf = xf2; ap.prefer_gqa = n_grp > 1 || getenv("VOX_ATTN_GQA") != nullptr; ap.no_xcd_remap = getenv("VOX_ATTN_NO_XCD") != nullptr; ap.spec_rows = max_seq;
+                    ap.out_xf = xf2; ap.prefer_gqa = n_grp > 1 || knob_str("VOX_ATTN_GQA") != nullptr; ap.no_xcd_remap = knob_str("VOX_ATTN_NO_XCD") != nullptr; ap.spec_rows = max_seq;
                     HIPCHK(launch_attn_decode(ap, hd, max_seq, sg, ng));
                     { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
                       g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
@@ -1877,7 +1879,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int replays = 0;
     if (steps > 0) {
         VOXCHK(step());                                          // eager first step
-        if (steps > 1 && getenv("VOX_BATCH_NO_GRAPH")) { for (int i = 1; i < steps; i++) VOXCHK(step()); }   // measurement knob (profilers)
+        if (steps > 1 && knob_str("VOX_BATCH_NO_GRAPH")) { for (int i = 1; i < steps; i++) VOXCHK(step()); }   // measurement knob (profilers)
         else if (steps > 1) {
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));

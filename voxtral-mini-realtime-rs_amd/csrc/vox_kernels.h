@@ -197,6 +197,10 @@ void eng_state_carve(unsigned char* state, EngParams* p);      // point p's gran
 hipError_t launch_decode_engine(const EngParams& p, hipStream_t s);
 int eng_lds_bytes();
 
+// ---- measurement knobs: VOX_* environment snapshot (taken at vox_ctx_create / vox_debug_reload_knobs); launch paths never call getenv
+void knobs_reload();
+const char* knob_str(const char* name);      // nullptr when unset
+
 // ---- timeline instrumentation (measurement builds only, -DVOX_TIMELINE): every q4_gemv / attn_decode launch gets the next slot and its
 // waves stamp s_memrealtime (100 MHz) at 4 points into buf[slot][wave][4]; under graph replay the captured slot is rewritten per replay.
 // Returns hipErrorNotSupported in product builds.

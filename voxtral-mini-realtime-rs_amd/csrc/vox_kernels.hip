@@ -22,9 +22,14 @@
 
 #include <hip/hip_fp16.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
 
 namespace vox {
 
@@ -489,7 +494,22 @@ static hipError_t ensure_dyn_lds(Kern kern, size_t lds, bool* done) {
 }
 
 static hipError_t launch_dense_gemv(const GemvParams& p, int ny, int pro, int epi, hipStream_t s);
-static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+// Measurement knobs (VOX_*): the environment is read ONCE -- at vox_ctx_create, or by vox_debug_reload_knobs() for the tests that flip a knob at run time -- into a
+// table; no launch path calls getenv.  Lookups are read-only between reloads (a reload while another thread launches is the caller's race, as with setenv itself).
+static std::unordered_map<std::string, std::string>& knob_table() { static std::unordered_map<std::string, std::string> t; return t; }
+static bool g_knobs_loaded = false;
+void knobs_reload() {
+    auto& t = knob_table(); t.clear();
+    for (char** e = environ; e && *e; ++e)
+        if (!strncmp(*e, "VOX_", 4)) { const char* eq = strchr(*e, '='); if (eq) t.emplace(std::string(*e, eq - *e), std::string(eq + 1)); }
+    g_knobs_loaded = true;
+}
+const char* knob_str(const char* name) {
+    if (!g_knobs_loaded) knobs_reload();
+    auto& t = knob_table(); auto it = t.find(name);
+    return it == t.end() ? nullptr : it->second.c_str();
+}
+static int env_int(const char* name) { const char* v = knob_str(name); return v ? atoi(v) : 0; }
 
 // instantiated (R, P) pairs; P = ceil(R * nb / 64)
 static bool gemv_has(int R, int P) {
@@ -1860,7 +1880,7 @@ static hipError_t launch_q4_skinny(const GemmParams& p_in, int epi, hipStream_t 
     int ks = nq >= 4 ? 4 : (nq >= 2 ? 2 : 1);
     if (tiles / ntw < 256 && nq >= 16) ks = 8;                        // profiles/r01_skinny_sweep.txt
     { const int e = env_int("VOX_SKINNY_NTW"); if (e == 1 || e == 2 || e == 4) ntw = e; }
-    { const char* f = getenv("VOX_SKINNY_FORCE");      // measurement knob "N:ntw:ks": override for one weight shape only
+    { const char* f = knob_str("VOX_SKINNY_FORCE");      // measurement knob "N:ntw:ks": override for one weight shape only
       if (f) { int fn = 0, fw = 0, fk = 0; if (sscanf(f, "%d:%d:%d", &fn, &fw, &fk) == 3 && fn == p.w.N && (fw == 1 || fw == 2 || fw == 4) && (fk == 1 || fk == 2 || fk == 4 || fk == 8)) { ntw = fw; ks = fk; } } }
     if (epi == EPI_RESID_XF) ntw = 1;       // its partial sums of squares are per workgroup = per 16-column tile
     { const int e = env_int("VOX_SKINNY_KS"); if (e == 1 || e == 2 || e == 4 || e == 8) ks = e; }
