@@ -39,8 +39,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ED = 3072, ENH = 32, ENKV = 8, EHD = 128, EQD = ENH * EHD, EKD = ENKV * EHD, EF = 9216;
-constexpr int NCU = 256, NCONS = 6, NWAVES = NCONS + 2, NTHR = 64 * NWAVES;
-constexpr int PASS_A = 3456, PASS_WO = 2304;          // bytes per pass: 3 (2) planes of 64 x 16 B nibbles + 64 x 2 B scales
+constexpr int NCU = 256, NCONS = 12, NWAVES = NCONS + 2, NTHR = 64 * NWAVES;      // 14 waves: 3-4 per SIMD (one wave per SIMD issues a VALU instruction only every ~8 cycles)
+// bytes per pass.  A-type (K = 3072 or a 384-column w2 sub-slice): ONE row (or 8 w2 row pieces) = 96 Q4 blocks over 64 lanes, 1.5 blocks per lane:
+//   [64] x 16 B nibbles of block `lane` | [64] x 8 B: half (lane & 1) of block 64 + lane / 2 | [64] x 2 B scales | [32] x 2 B scales of the split blocks.
+// wo-type (K = 128): 16 rows x 4 lanes x one block: [64] x 16 B | [64] x 2 B.
+constexpr int PASS_A = 1728, PASS_WO = 1152;
+constexpr int PA_Q1 = 1024, PA_S0 = 1536, PA_S1 = 1664, PW_S0 = 1024;
 constexpr int PK_A = NCONS * PASS_A, PK_WO = NCONS * PASS_WO;   // packet = one pass per consumer wave: 20736 / 13824 bytes, stored back to back (no padding)
 constexpr int LINES_A = (PK_A + 1023) / 1024, LINES_WO = (PK_WO + 1023) / 1024;      // LDS-DMA instructions per packet (the last one partial: 16 / 32 lanes)
 static_assert(LINES_A == 21 && LINES_WO == 14, "wait_vmcnt() enumerates the in-flight line counts 14 / 21 / 28 / 35 / 42");
@@ -57,44 +61,51 @@ enum { EOP_QKV = 0, EOP_WO = 1, EOP_W13 = 2, EOP_W2 = 3, EOP_LM = 4 };
 enum { ERR_RING = 1, ERR_STAGE = 2, ERR_SWEEP = 3, ERR_CBAR = 4, ERR_SLOT = 5 };
 
 __host__ __device__ inline int lm_rows_per_cu(int vocab) { return vocab / NCU; }
-__host__ __device__ inline int lm_passes(int vocab) { return lm_rows_per_cu(vocab) / 2; }
+__host__ __device__ inline int lm_passes(int vocab) { return lm_rows_per_cu(vocab); }      // one row per pass
 __host__ __device__ inline int lm_packets(int vocab) { return (lm_passes(vocab) + NCONS - 1) / NCONS; }
 __host__ __device__ inline size_t cu_stream_bytes(int n_layers, int vocab) { return (size_t)n_layers * LAYER_BYTES + (size_t)lm_packets(vocab) * PK_A + 1024; }      // + 1 KiB: the stream is read in whole 16-byte lanes only, the pad keeps the allocation comfortable
 
-// (row, block) of weight matrix `op` that lands in 16-byte chunk [plane p][lane] of pass q on CU b.  Lanes that split one row hold whole Q4 blocks.
-__host__ __device__ inline void eng_src(int op, int b, int q, int p, int lane, int vocab, int* row, int* blk) {
+// What pass q (= 12 * packet + consumer wave) of operator `op` on CU b holds for `lane`: the row, the lane's whole Q4 block and (A-type only) the block it
+// shares with its neighbour lane (half lane & 1 of it).
+__host__ __device__ inline void eng_src(int op, int b, int q, int lane, int vocab, int* row, int* blk, int* blk_half) {
     const int g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
-    if (op == EOP_QKV || op == EOP_W13 || op == EOP_LM) {              // 2 rows per pass, 32 lanes x 3 blocks per row
-        const int hr = lane >> 5, li = lane & 31;
-        *blk = li + 32 * p;
-        if (op == EOP_W13) *row = 2 * (1152 * g + 36 * j + q) + hr;
-        else if (op == EOP_LM) *row = lm_rows_per_cu(vocab) * b + 2 * q + hr;
-        else if (q < 8) *row = 128 * h + 16 * s + 2 * q + hr;
-        else if (q < 10) *row = EQD + 128 * g + 4 * j + 2 * (q - 8) + hr;
-        else *row = EQD + EKD + 128 * g + 4 * j + 2 * (q - 10) + hr;
-    } else if (op == EOP_WO) {                                         // 32 rows per pass, 2 lanes x 2 blocks per row (K = the head's 128 columns)
-        *row = 384 * s + 32 * q + (lane >> 1);
-        *blk = 4 * h + (lane & 1) + 2 * p;
-    } else {                                                           // w2: 16 rows per pass, 4 lanes x 3 blocks; wave w = q % 6: sub-slice w % 3, row half w / 3
-        const int t3 = q / NCONS, w = q % NCONS, ts = w % 3, rh = w / 3;
-        *row = 96 * j + 48 * rh + 16 * t3 + (lane >> 2);
-        *blk = 36 * g + 12 * ts + (lane & 3) + 4 * p;
+    const int t = q / NCONS, w = q % NCONS;
+    *blk = lane; *blk_half = 64 + (lane >> 1);
+    if (op == EOP_QKV) {                                               // wave w owns RoPE pair w of the CU's 12 (8 of q, 2 of k, 2 of v): element t of the pair in packet t
+        if (w < 8) *row = 128 * h + 16 * s + 2 * w + t;
+        else if (w < 10) *row = EQD + 128 * g + 4 * j + 2 * (w - 8) + t;
+        else *row = EQD + EKD + 128 * g + 4 * j + 2 * (w - 10) + t;
+    } else if (op == EOP_W13) {                                        // SwiGLU output w + 12 (t / 2) of the CU's 36: gate row in packet 2 k, up row in packet 2 k + 1
+        *row = 2 * (1152 * g + 36 * j + w + NCONS * (t >> 1)) + (t & 1);
+    } else if (op == EOP_LM) {
+        *row = lm_rows_per_cu(vocab) * b + q;
+    } else if (op == EOP_WO) {                                         // 16 rows per pass, 4 lanes x 1 block per row (K = the head's 128 columns)
+        *row = 384 * s + 16 * q + (lane >> 2);
+        *blk = 4 * h + (lane & 3); *blk_half = -1;
+    } else {                                                           // w2: 8 rows per pass, 8 lanes x 1.5 blocks; wave w: K sub-slice w % 3, row group w / 3
+        const int ts = w % 3, rg = w / 3, t8 = lane & 7;
+        *row = 96 * j + 32 * t + 8 * rg + (lane >> 3);
+        *blk = 36 * g + 12 * ts + t8; *blk_half = 36 * g + 12 * ts + 8 + (t8 >> 1);
     }
 }
 
-__global__ __launch_bounds__(192) void eng_pack_kernel(Q4W w, int op, unsigned char* __restrict__ stream, size_t cu_stride, size_t op_off, int vocab) {
-    const int q = blockIdx.x, b = blockIdx.y, t = threadIdx.x, NB = op == EOP_WO ? 2 : 3;
-    if (t >= NB * 64) return;
-    const int p = t >> 6, lane = t & 63;
-    int row, blk; eng_src(op, b, q, p, lane, vocab, &row, &blk);
+__global__ __launch_bounds__(64) void eng_pack_kernel(Q4W w, int op, unsigned char* __restrict__ stream, size_t cu_stride, size_t op_off, int vocab) {
+    const int q = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    int row, blk, blk_half; eng_src(op, b, q, lane, vocab, &row, &blk, &blk_half);
     const size_t pk_bytes = op == EOP_WO ? PK_WO : PK_A, pass_bytes = op == EOP_WO ? PASS_WO : PASS_A;
     // packet-major: packet k of all 256 CUs is contiguous ([k][cu][bytes]) -- at any moment the 256 loaders read one contiguous ~5 MB window, spread over
     // every HBM channel (CU-major streams 7.3 MB apart put all loaders on the same channels at the same time)
     (void)cu_stride;
     unsigned char* dst = stream + (size_t)NCU * (op_off + (size_t)(q / NCONS) * pk_bytes) + (size_t)b * pk_bytes + (size_t)(q % NCONS) * pass_bytes;
     const size_t src = (size_t)row * w.nb + blk;
-    reinterpret_cast<uint4*>(dst)[p * 64 + lane] = w.qs[src];
-    reinterpret_cast<uint16_t*>(dst + NB * 1024)[p * 64 + lane] = w.sc[src];
+    reinterpret_cast<uint4*>(dst)[lane] = w.qs[src];
+    reinterpret_cast<uint16_t*>(dst + (op == EOP_WO ? PW_S0 : PA_S0))[lane] = w.sc[src];
+    if (blk_half >= 0) {
+        const size_t sh = (size_t)row * w.nb + blk_half;
+        const uint4 qh = w.qs[sh];
+        reinterpret_cast<uint2*>(dst + PA_Q1)[lane] = (lane & 1) ? make_uint2(qh.z, qh.w) : make_uint2(qh.x, qh.y);      // bytes [8 half, +8): elements [8 half, +8) and 16 + the same
+        if ((lane & 1) == 0) reinterpret_cast<uint16_t*>(dst + PA_S1)[lane >> 1] = w.sc[sh];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -104,14 +115,14 @@ struct EngCtl {
     unsigned ring_ready[8], ring_done[8];         // monotonic per slot: fills landed / passes consumed
     unsigned xs0_flag, xs1_flag, xa_flag, qkv_flag;   // layer + 1 of the staged content (monotonic)
     unsigned cbar, dead, gathering, gw_flag;
-    unsigned xcd_ok, xcc_id, pad3[2];
+    unsigned xcd_ok, xcc_id, ag_flag, pub_cnt;    // pub_cnt: consumer waves that have issued an operator's publishes (12 per operator, 4 operators per layer)       // ag_flag: all-gather stages whose probe has resolved (the consumer waves then sweep the vector themselves)
     float rstd0, rstd1, pad1, pad2;
-    float best_val[8]; int best_idx[8];
+    float best_val[16]; int best_idx[16];
     float h_own[16], h1_own[16];
 };
 constexpr int L_RING = 0;
 constexpr int L_XS = L_RING + NSLOT * SLOT_BYTES;       // [3072] f32, swizzled chunks: the all-gathered input of q|k|v / w1|w3 / lm_head.  ONE buffer: it is re-staged only
-constexpr int L_XS0 = L_XS, L_XS1 = L_XS;               //   after every consumer wave has published results computed from the previous content (registers hold x during an operator)
+                                                        //   after every consumer wave has published results computed from the previous content (registers hold x during an operator)
 constexpr int L_U = L_XS + ED * 4;                      // time-shared: the XCD group's 1152 SwiGLU outputs (w2 input) | attention scratch of the NEXT layer
 constexpr int L_XA = L_U;                               //   [1152] staged after w1|w3, loaded to registers at the start of w2
 constexpr int L_SC = L_U;                               //   [SC_MAX] scores
@@ -120,7 +131,8 @@ constexpr int L_PL = L_PO + 12 * 128 * 4;               //   [16] partial softma
 constexpr int L_XO = L_PL + 64;                         // [128] attention output of head h (wo input)
 constexpr int L_QKVN = L_XO + 128 * 4;                  // q_h[128] k_g[128] v_g[128] of this step (plain order)
 constexpr int L_TMP = L_QKVN + 384 * 4;                 // [384] partial sums swept by the comm wave
-constexpr int L_TAB = L_TMP + 384 * 4;                  // [MAX_LAYERS] copy of the layer table: pointer reads never touch VMEM (a vector load behind a publish waits for the store)
+constexpr int L_SSQ = L_TMP + 384 * 4;                  // [256] per-CU partial sums of squares of the vector being all-gathered
+constexpr int L_TAB = L_SSQ + NCU * 4;                  // [MAX_LAYERS] copy of the layer table: pointer reads never touch VMEM (a vector load behind a publish waits for the store)
 constexpr int MAX_LAYERS = 32;
 constexpr int L_GW = L_TAB + MAX_LAYERS * (int)sizeof(EngLayerTab);      // [MAX_LAYERS + 1][2][16] norm weight * 512 of this CU's 12 rows: [l][0] attn_norm (l = L: final norm), [l][1] ffn_norm * Ada
 constexpr int L_CTL = L_GW + (MAX_LAYERS + 1) * 32 * 4;
@@ -136,6 +148,7 @@ static_assert(L_XS % 16 == 0 && L_XA % 16 == 0 && L_XO % 16 == 0 && L_QKVN % 16 
 typedef const __attribute__((address_space(1))) float* gcf_p;      // pointers that come out of the device-resident layer table: the compiler cannot infer
 typedef __attribute__((address_space(1))) float* gf_p;             // their address space, and a FLAT load also counts on lgkmcnt (an LDS wait would wait for it)
 typedef float fv4 __attribute__((ext_vector_type(4)));
+typedef float fv2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ gcf_p as_g(const float* p) { return (gcf_p)(uintptr_t)p; }
 __device__ __forceinline__ gf_p as_g(float* p) { return (gf_p)(uintptr_t)p; }
 __device__ __forceinline__ float4 ldg4(gcf_p p) { const fv4 v = *(const __attribute__((address_space(1))) fv4*)p; return make_float4(v.x, v.y, v.z, v.w); }
@@ -174,18 +187,24 @@ struct Tl {      // timeline stamps (measurement runs: p.tl != nullptr), lane 0 
     __device__ __forceinline__ void operator()(int evt) const { if (on) buf[evt] = wall_clock64(); }
 };
 
-// wait until *word >= target (LDS word, monotonic).  Bounded; a dead workgroup never waits.
+// wait until *word >= target (LDS word, monotonic).  Bounded; a dead workgroup never waits.  The clock (s_memrealtime: a round trip of its own, far
+// longer than the LDS poll) is read once per 256 polls only -- read on every poll it WAS the latency of every flag hand-off.
 __device__ __forceinline__ bool wait_ge(unsigned* word, unsigned target, EngCtl* c, unsigned* err, unsigned code) {
     if (lds_ld(word) >= target) { ENG_CFENCE(); return true; }
     if (lds_ld(&c->dead)) return false;
-    const u64 t0 = wall_clock64();
+    u64 t0 = 0; unsigned n = 0;
     for (;;) {
         __builtin_amdgcn_s_sleep(1);
         if (lds_ld(word) >= target) break;
+        if ((++n & 255u) != 0) continue;
         if (lds_ld(&c->dead)) return false;
-        if (wall_clock64() - t0 > TIMEOUT_TICKS) {
+        const u64 t = wall_clock64();
+        if (t0 == 0) t0 = t;
+        else if (t - t0 > TIMEOUT_TICKS) {
             lds_st(&c->dead, 1u);
-            __hip_atomic_store(err, code | ((unsigned)blockIdx.x << 8), RLX, AG);
+            unsigned ev = code | ((unsigned)blockIdx.x << 8);
+            asm volatile("" : "+s"(ev));      // built here, on the cold path: hoisted out of the item loop it costs a VGPR (or a scratch slot) everywhere
+            __hip_atomic_store(err, ev, RLX, AG);
             return false;
         }
     }
@@ -282,15 +301,19 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
 // ------------------------------------------------------------------------------------------------
 // COMM wave
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool sweep_bail(u64& t0, unsigned tag, EngCtl* c, unsigned* err) {
+__device__ __forceinline__ bool sweep_bail(u64& t0, unsigned tag, EngCtl* c, unsigned* err) {      // t0: low 8 bits = failed polls since the last clock read
+    __builtin_amdgcn_s_sleep(2);
+    if (((++t0) & 31u) != 0) return false;        // the clock is a long round trip: one read per 32 failed polls
     if (lds_ld(&c->dead)) return true;
-    if (t0 == 0) t0 = wall_clock64();
-    else if (wall_clock64() - t0 > TIMEOUT_TICKS) {
+    const u64 t = wall_clock64() << 8;
+    if (t0 < 256) t0 = t;
+    else if (t - (t0 & ~(u64)255) > (TIMEOUT_TICKS << 8)) {
         lds_st(&c->dead, 1u);
-        __hip_atomic_store(err, (unsigned)ERR_SWEEP | ((unsigned)blockIdx.x << 8) | (tag << 16), RLX, AG);
+        unsigned ev = (unsigned)ERR_SWEEP | ((unsigned)blockIdx.x << 8) | (tag << 16);
+        asm volatile("" : "+s"(ev));
+        __hip_atomic_store(err, ev, RLX, AG);
         return true;
     }
-    __builtin_amdgcn_s_sleep(2);
     return false;
 }
 // Sweep N granules per lane until every tag matches (values in v).  Bounded.  With `do_probe` the wave first polls ONE granule per lane (`probe()`:
@@ -333,53 +356,22 @@ __device__ __forceinline__ void publish_b(const u64* base, unsigned bytes, unsig
 
 // All-gather of a staged activation vector: the owners publish their 12 rows ALREADY multiplied by the consumer's norm weight (* Ada scale) * 512,
 // plus one partial sum of squares per CU, so the sweep is granules -> LDS with no other memory operand (the per-layer norm vectors take microseconds to
-// arrive and would sit in front of the granule loads: VMEM returns in order).  48 + 4 granules per lane; the first chunk starts with a probe of one
-// row of every 4th producer.
-__device__ __forceinline__ void comm_stage_x(const EngParams& p, EngCtl* c, int lane, const u64* src, const u64* ssq, unsigned tag, float* xs, float* rstd_out, const Tl& tl, bool T) {
-    asm volatile("" : "+v"(lane));      // opaque per call: swizzled staging addresses are computed where they are used, not carried in VGPRs
-    constexpr int NU = ED / 64;
-    const srd_t sd = make_srd(src, ED * 8u), qd = make_srd(ssq, NCU * 8u);
+// arrive and would sit in front of the granule loads: VMEM returns in order).  The COMM wave only probes (one row of every 4th producer, one granule per
+// lane); once the probe resolves, the 12 consumer waves sweep 4 (+ 1) granules per lane each -- one round trip, no 100-register sweep in one wave.
+__device__ __forceinline__ void comm_probe_x(const EngParams& p, EngCtl* c, int lane, const u64* src, unsigned tag, const Tl& tl, bool T) {
+    const srd_t sd = make_srd(src, ED * 8u);
     if (T) tl(20);
     u64 t0 = 0;
     if (p.flags & 512) {      // no probe: the owners publish within a fraction of a microsecond of each other, so wait out the store-to-visibility latency once
         const u64 tw = wall_clock64();      // and go straight for the full sweep (a miss costs one more round trip)
         while (wall_clock64() - tw < (u64)p.ag_delay_ticks) __builtin_amdgcn_s_sleep(1);
     } else
-    for (;;) {      // probe: one row of every 4th producer
+    for (;;) {
         const u64 gq = ld_gran(sd, 48u * (unsigned)lane);
         if (__all((unsigned)(gq >> 32) == tag)) break;
         if (sweep_bail(t0, tag, c, p.err)) break;
     }
     if (T) tl(21);
-    u64 raw[NU], rq[4];
-    for (;;) {      // all 48 + 4 granules of this lane in ONE round trip (three dependent 16-load round trips cost ~2 us more per all-gather)
-        bool ok = true;
-#pragma unroll
-        for (int u = 0; u < NU; u++) raw[u] = ld_gran(sd, (unsigned)lane + 64u * u);
-#pragma unroll
-        for (int u = 0; u < 4; u++) rq[u] = ld_gran(qd, (unsigned)lane + 64u * u);
-#pragma unroll
-        for (int u = 0; u < NU; u++) ok &= (unsigned)(raw[u] >> 32) == tag;
-#pragma unroll
-        for (int u = 0; u < 4; u++) ok &= (unsigned)(rq[u] >> 32) == tag;
-        if (__all(ok)) break;
-        if (sweep_bail(t0, tag, c, p.err)) break;
-    }
-    if (T) tl(22);
-    // element k = lane + 64 u lives in chunk c = 2 u + (lane >> 5), piece (lane & 31) >> 2, and the chunk's swizzle is (c >> 1) & 7 = u & 7: eight lane-dependent
-    // byte offsets (one per value of u & 7) + 256 u cover all 48 stores -- ds_write_b32 with immediate offsets instead of 48 address computations
-    {
-        unsigned a8[8];
-        const unsigned jj = (unsigned)(lane & 31) >> 2, rr = (unsigned)lane & 3u, hi = (unsigned)lane >> 5;
-#pragma unroll
-        for (int m8 = 0; m8 < 8; m8++) a8[m8] = ((hi * 8u + (jj ^ (unsigned)m8)) * 4u + rr) * 4u;
-        unsigned char* xb = reinterpret_cast<unsigned char*>(xs);
-#pragma unroll
-        for (int u = 0; u < NU; u++) *reinterpret_cast<float*>(xb + a8[u & 7] + 256u * (unsigned)u) = __uint_as_float((unsigned)raw[u]);
-    }
-    const float ss = wave_sum_e((__uint_as_float((unsigned)rq[0]) + __uint_as_float((unsigned)rq[1])) + (__uint_as_float((unsigned)rq[2]) + __uint_as_float((unsigned)rq[3])));      // fixed order: bit-identical on every CU
-    if (lane == 0) *rstd_out = 1.0f / sqrtf(ss / (float)ED + p.eps);
-    if (T) tl(23);
 }
 // the owner's side: rows [12 b, +12) of a residual stream -> granules of row * (next norm weight) * 512, the CU's partial sum of squares, raw rows kept in LDS
 __device__ __forceinline__ void comm_publish_rows(const EngParams& p, int lane, float hraw, float gw, u64* dst, u64* ssq, unsigned tag, float* own) {
@@ -394,7 +386,6 @@ __device__ __forceinline__ void comm_publish_rows(const EngParams& p, int lane, 
 // stage 2 L = the final norm's input (-> lm_head); the small edges that follow each all-gather hang off the loop body.
 __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned char* lds, const int lane0, const Tl& tl) {
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3);
-    float* xs0 = reinterpret_cast<float*>(lds + L_XS0); float* xs1 = reinterpret_cast<float*>(lds + L_XS1);
     float* xa = reinterpret_cast<float*>(lds + L_XA); float* qkvn = reinterpret_cast<float*>(lds + L_QKVN);
     float* tmp = reinterpret_cast<float*>(lds + L_TMP);
     const EngLayerTab* tab = reinterpret_cast<const EngLayerTab*>(lds + L_TAB);
@@ -414,13 +405,14 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
         const int l = st >> 1; const bool odd = st & 1, last = st == 2 * p.n_layers, T = l == p.tl_layer;
         const unsigned tag = tag_base + (unsigned)l + 1u;       // written during layer l
         lds_st(&c->gathering, 1u);
-        if (odd) comm_stage_x(p, c, lane, p.H1, p.SS1, tag, xs1, &c->rstd1, tl, T);
-        else comm_stage_x(p, c, lane, p.H0, p.SS0, tag - 1u, xs0, &c->rstd0, tl, false);
-        ENG_CFENCE(); lds_st(odd ? &c->xs1_flag : &c->xs0_flag, (unsigned)l + 1u);
+        if (odd) comm_probe_x(p, c, lane, p.H1, tag, tl, T);
+        else comm_probe_x(p, c, lane, p.H0, tag - 1u, tl, false);
+        lds_st(&c->ag_flag, (unsigned)st + 1u);
         if (T) tl(odd ? 11 : 8);
         if (last) { lds_st(&c->gathering, 0u); break; }
         if (!odd) {
             {   // this step's q_h, k_g, v_g rows
+                wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 1u), c, p.err, ERR_STAGE);
                 float v[6];
                 sweep<6>(p.G, (EQD + 2 * EKD) * 8u, tag, [&](int u) { const int i = lane + 64 * u, seg = i >> 7, e = i & 127; return seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e; },
                          [&]() { return lane < 32 ? EQD + 128 * g + 4 * lane : EQD + EKD + 128 * g + 4 * (lane - 32); }, PROBE_SMALL, v, c, p.err);      // probe: a k / v row of each of the group's 32 CUs
@@ -430,6 +422,7 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
             }
             if (T) tl(9);
             {   // wo: 32 partial planes of this CU's 12 rows -> residual stream after attention, published as the w1|w3 input (gw = ffn_norm * Ada * 512)
+                wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 2u), c, p.err, ERR_STAGE);
                 float v[6];
                 sweep<6>(p.PW, NPW * ED * 8u, tag, [&](int u) { const int i = lane + 64 * u, hh = i / OWN, r = i - hh * OWN; return hh * ED + OWN * b + r; }, [&]() { return (lane & 31) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
 #pragma unroll
@@ -445,6 +438,7 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
             if (T) tl(10);
         } else {
             {   // the XCD group's 1152 SwiGLU outputs -> w2 input
+                wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 3u), c, p.err, ERR_STAGE);
                 float v[18];
                 sweep<18>(p.A, EF * 8u, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, PROBE_SMALL, v, c, p.err);      // probe: the last output of each CU of the group
 #pragma unroll
@@ -453,6 +447,7 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
             }
             if (T) tl(12);
             {   // w2: 24 partial planes of this CU's 12 rows -> the layer's output, published as the next layer's q|k|v input (gw = next attn_norm * 512)
+                wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 4u), c, p.err, ERR_STAGE);
                 float v[5];
                 sweep<5>(p.P2, NP2 * ED * 8u, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
 #pragma unroll
@@ -489,27 +484,54 @@ __device__ __forceinline__ float block_dot(const uint4 q, const f2* __restrict__
     return (a0.x + a0.y) + (a1.x + a1.y);
 }
 
-template <int NB>
-struct XRegs {
-    f2 x[NB][16]; float m8[NB];
-    // chunk(p) = first + step * p of the staged vector xs
-    __device__ __forceinline__ void load(const float* xs, int first, int step) {
-        asm volatile("" : "+v"(first));      // opaque per call: keeps the 8 swizzled piece addresses out of the loop invariants (they cost ~100 VGPRs hoisted)
+// the 16 weights of half a block (bytes [8 hb, +8) of its nibbles: elements [8 hb, +8) and 16 + the same); x[4 d .. 4 d + 3] = the activations of dword d
+__device__ __forceinline__ float half_dot(const uint2 q, const f2* __restrict__ x, float init) {
+    f2 a0 = {init, 0.f}, a1 = {0.f, 0.f};
+    const unsigned w[2] = {q.x, q.y};
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const unsigned lo = w[d] & 0x0F0F0F0Fu, hi = (w[d] >> 4) & 0x0F0F0F0Fu;
+        a0 = __builtin_elementwise_fma(cvt2(lo, false), x[4 * d], a0);
+        a1 = __builtin_elementwise_fma(cvt2(lo, true), x[4 * d + 1], a1);
+        a0 = __builtin_elementwise_fma(cvt2(hi, false), x[4 * d + 2], a0);
+        a1 = __builtin_elementwise_fma(cvt2(hi, true), x[4 * d + 3], a1);
+    }
+    return (a0.x + a0.y) + (a1.x + a1.y);
+}
+
+// activation registers of one lane: a whole 32-element chunk and half of a second one (A-type passes: 96 blocks over 64 lanes), or one chunk (wo)
+struct XA {
+    f2 x[16], xh[8]; float m8, m8h;
+    __device__ __forceinline__ void load_chunk(const float* xs, int chunk) {
+        asm volatile("" : "+v"(chunk));      // opaque per call: keeps the swizzled piece addresses out of the loop invariants
         const float4* x4 = reinterpret_cast<const float4*>(xs);
+        float s = 0.f;
 #pragma unroll
-        for (int p = 0; p < NB; p++) {
-            const int cidx = first + step * p;
-            float s = 0.f;
+        for (int jj = 0; jj < 8; jj++) {
+            const float4 v = x4[sw_piece(chunk, jj)];
+            x[2 * jj] = f2{v.x, v.y}; x[2 * jj + 1] = f2{v.z, v.w};
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        m8 = s * (-1.0f / 64.0f);            // -8 * sum x = -(8 / 512) * sum x'
+    }
+    __device__ __forceinline__ void load(const float* xs, int chunk, int chunk_h, int hb) {
+        load_chunk(xs, chunk);
+        asm volatile("" : "+v"(chunk_h));
+        const float4* x4 = reinterpret_cast<const float4*>(xs);
+        float s = 0.f;
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                const float4 v = x4[sw_piece(cidx, jj)];
-                x[p][2 * jj] = f2{v.x, v.y}; x[p][2 * jj + 1] = f2{v.z, v.w};
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const float4 v = x4[sw_piece(chunk_h, 4 * hh + 2 * hb + d)];
+                xh[4 * d + 2 * hh] = f2{v.x, v.y}; xh[4 * d + 2 * hh + 1] = f2{v.z, v.w};
                 s += (v.x + v.y) + (v.z + v.w);
             }
-            m8[p] = s * (-1.0f / 64.0f);        // -8 * sum x = -(8 / 512) * sum x'
-        }
+        m8h = s * (-1.0f / 64.0f);
     }
 };
+struct PassA { uint4 q0; uint2 q1; float s0, s1; };
+struct PassW { uint4 q; float s; };
 
 struct Cons {
     const EngParams& p; EngCtl* c; unsigned char* lds; int cw, lane; unsigned P; unsigned cbar_n;
@@ -520,49 +542,87 @@ struct Cons {
         if (lane == 0) __hip_atomic_fetch_add(&c->cbar, 1u, RLX, WG);
         wait_ge(&c->cbar, cbar_n, c, p.err, ERR_CBAR);
     }
-    // fetch this wave's pass of packet pk into registers and release the slot; `real` false: only release (a packet with fewer passes)
-    template <int NB>
-    __device__ __forceinline__ void fetch(unsigned pk, uint4 (&Q)[NB], float (&S)[NB], bool real) {
-        const int slot = (int)(pk % NSLOT); const unsigned k = pk / NSLOT;
+    // this wave's publishes of the current operator are issued: the COMM wave polls memory for an edge only once the CU's own 12 waves are through (every CU
+    // runs the same schedule, so nothing can be complete much earlier; polling during the operator took VALU slots and fabric bandwidth from it)
+    __device__ __forceinline__ void published(const Tl& tl, int evt) {      // evt >= 0: timeline stamp by the LAST of the 12 waves
+        ENG_CFENCE();
+        if (lane == 0) { const unsigned old = __hip_atomic_fetch_add(&c->pub_cnt, 1u, RLX, WG); if (evt >= 0 && tl.buf && old % NCONS == NCONS - 1) tl.buf[evt] = wall_clock64(); }
+    }
+    __device__ __forceinline__ const unsigned char* slot_wait(unsigned pk, int pass_bytes, int& slot) {
+        slot = (int)(pk % NSLOT); const unsigned k = pk / NSLOT;
         wait_ge(&c->ring_ready[slot], k + 1u, c, p.err, ERR_RING);
-        if (real) {
-            const unsigned char* base = lds + L_RING + slot * SLOT_BYTES + cw * (NB == 2 ? PASS_WO : PASS_A);
-#pragma unroll
-            for (int i = 0; i < NB; i++) Q[i] = reinterpret_cast<const uint4*>(base)[i * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < NB; i++) S[i] = __half2float(__ushort_as_half(reinterpret_cast<const unsigned short*>(base + NB * 1024)[i * 64 + lane]));
-        }
+        return lds + L_RING + slot * SLOT_BYTES + cw * pass_bytes;
+    }
+    __device__ __forceinline__ void slot_release(int slot) {
         ENG_CFENCE();      // the LDS pipeline executes a wave's instructions in order: the reads above have been served when this add is
         if (lane == 0) __hip_atomic_fetch_add(&c->ring_done[slot], 1u, RLX, WG);
     }
-    template <int NB>
-    __device__ __forceinline__ float pass_dot(const uint4 (&Q)[NB], const float (&S)[NB], const XRegs<NB>& xr) {
-        float acc = 0.f;
+    // fetch this wave's pass of packet pk into registers and release the slot (the lm_head's last packet has fewer passes than waves: the surplus waves read
+    // whatever the slot holds and drop the result -- one straight-line body, no partially defined registers around the loop)
+    __device__ __forceinline__ void fetch(unsigned pk, PassA& P_) {
+        int slot; const unsigned char* base = slot_wait(pk, PASS_A, slot);
+        P_.q0 = reinterpret_cast<const uint4*>(base)[lane];
+        P_.q1 = reinterpret_cast<const uint2*>(base + PA_Q1)[lane];
+        P_.s0 = __half2float(__ushort_as_half(reinterpret_cast<const unsigned short*>(base + PA_S0)[lane]));
+        P_.s1 = __half2float(__ushort_as_half(reinterpret_cast<const unsigned short*>(base + PA_S1)[lane >> 1]));
+        slot_release(slot);
+    }
+    __device__ __forceinline__ void fetch(unsigned pk, PassW& P_) {
+        int slot; const unsigned char* base = slot_wait(pk, PASS_WO, slot);
+        P_.q = reinterpret_cast<const uint4*>(base)[lane];
+        P_.s = __half2float(__ushort_as_half(reinterpret_cast<const unsigned short*>(base + PW_S0)[lane]));
+        slot_release(slot);
+    }
+    // this lane's share of the pass's row(s); fixed evaluation order
+    static __device__ __forceinline__ float dot(const PassA& P_, const XA& xr) { return fmaf(P_.s1, half_dot(P_.q1, xr.xh, xr.m8h), P_.s0 * block_dot(P_.q0, xr.x, xr.m8)); }
+    static __device__ __forceinline__ float dot(const PassW& P_, const XA& xr) { return P_.s * block_dot(P_.q, xr.x, xr.m8); }
+
+    // This wave's share of an all-gather (after the COMM wave's probe has resolved): granules [256 cw, +256) of the vector -> swizzled LDS staging, waves 0..3 also the
+    // 256 per-CU partial sums of squares; then (every wave, same fixed order on every CU) the RMSNorm scale.
+    __device__ __forceinline__ float all_gather(const u64* src, const u64* ssq, unsigned tag, unsigned stage, float* xs, float* ssl, const Tl& tl, bool T) {
+        wait_ge(&c->ag_flag, stage + 1u, c, p.err, ERR_STAGE);
+        const srd_t sd = make_srd(src, ED * 8u), qd = make_srd(ssq, NCU * 8u);
+        int ln = lane; asm volatile("" : "+v"(ln));
+        const unsigned k0 = 256u * (((unsigned)cw + blockIdx.x) % NCONS) + (unsigned)ln;      // rotated by CU: the 256 CUs do not walk the 24 KB in the same order
+        u64 raw[4], rq = 0, t0 = 0;
+        for (;;) {
+            bool ok = true;
 #pragma unroll
-        for (int i = 0; i < NB; i++) acc = fmaf(S[i], block_dot(Q[i], xr.x[i], xr.m8[i]), acc);
-        return acc;
+            for (int u = 0; u < 4; u++) raw[u] = ld_gran(sd, k0 + 64u * u);
+            if (cw < 4) rq = ld_gran(qd, 64u * (unsigned)cw + (unsigned)ln);
+#pragma unroll
+            for (int u = 0; u < 4; u++) ok &= (unsigned)(raw[u] >> 32) == tag;
+            if (cw < 4) ok &= (unsigned)(rq >> 32) == tag;
+            if (__all(ok)) break;
+            if (sweep_bail(t0, tag, c, p.err)) break;
+        }
+        if (T) tl(22);
+#pragma unroll
+        for (int u = 0; u < 4; u++) xs[sw_dword((int)(k0 + 64u * u))] = __uint_as_float((unsigned)raw[u]);
+        if (cw < 4) ssl[64 * cw + ln] = __uint_as_float((unsigned)rq);
+        cbarrier();
+        const float ss = wave_sum_e((ssl[ln] + ssl[ln + 64]) + (ssl[ln + 128] + ssl[ln + 192]));      // fixed order: bit-identical on every wave of every CU
+        return 1.0f / sqrtf(ss / (float)ED + p.eps);
     }
 };
 
-// ONE rolled loop over the step's 4 L + 1 operators (one copy of the pass body in the instruction cache): item 4 l + op, op in EOP_* order
-// (q|k|v, attention + wo, w1|w3, w2), then the lm_head.  Passes are software-pipelined: the next pass's weights are requested from the ring (LDS)
-// before the current pass is multiplied.
+// ONE rolled loop over the step's 3 L + 1 items (one copy of the pass body in the instruction cache): per layer [q|k|v -> attention -> wo], w1|w3, w2; then the
+// lm_head.  Passes are software-pipelined: the next pass's weights are requested from the ring (LDS) before the current pass is multiplied.
 __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsigned char* lds, int cw, const int lane0, const Tl& tl) {
     Cons cs(p, c, lds, cw, lane0);
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
-    const float* xs0 = reinterpret_cast<const float*>(lds + L_XS0); const float* xs1 = reinterpret_cast<const float*>(lds + L_XS1);
+    float* xs = reinterpret_cast<float*>(lds + L_XS); float* ssl = reinterpret_cast<float*>(lds + L_SSQ);
     const float* xa = reinterpret_cast<const float*>(lds + L_XA); float* xo = reinterpret_cast<float*>(lds + L_XO);
     const float* qkvn = reinterpret_cast<const float*>(lds + L_QKVN);
-    float* sc = reinterpret_cast<float*>(lds + L_SC); float4* po = reinterpret_cast<float4*>(lds + L_PO); float* pl = reinterpret_cast<float*>(lds + L_PL);
+    float* sc = reinterpret_cast<float*>(lds + L_SC); float2* po = reinterpret_cast<float2*>(lds + L_PO); float* pl = reinterpret_cast<float*>(lds + L_PL);
     const unsigned tag_base = (*p.serial + 1u) * 64u;
     const int pos = *p.pos_ptr + p.pos_off;
     const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0, n_old = pos - j_lo, last_old = max(n_old - 1, 0);
-    // RoPE factors of this wave's two q|k|v passes (the same rows in every layer): pass cw is a q pair; pass 6 + cw is q (cw < 2), k (cw 2, 3) or v
+    // RoPE factor of this wave's q|k|v pair (the same rows in every layer): waves 0..7 a q pair, 8 / 9 a k pair, 10 / 11 a v pair (no rotation)
     const int half = EHD / 2;
-    const int pr0 = 8 * s + cw, pr1 = cw < 2 ? 8 * s + 6 + cw : 2 * j + (cw - 2);
-    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };      // wave-uniform values live in SGPRs (the VGPR file is full)
-    const float rc0 = uni(p.rope_cos[(size_t)pos * half + pr0]), rs0 = uni(p.rope_sin[(size_t)pos * half + pr0]);
-    const float rc1 = cw < 4 ? uni(p.rope_cos[(size_t)pos * half + pr1]) : 1.0f, rs1 = cw < 4 ? uni(p.rope_sin[(size_t)pos * half + pr1]) : 0.0f;
+    const int pr = cw < 8 ? 8 * s + cw : 2 * j + (cw - 8);
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };      // wave-uniform values live in SGPRs
+    const float rc = cw < 10 ? uni(p.rope_cos[(size_t)pos * half + pr]) : 1.0f, rs = cw < 10 ? uni(p.rope_sin[(size_t)pos * half + pr]) : 0.0f;
     const float scale = 1.0f / sqrtf((float)EHD);
     const int n_items = 3 * p.n_layers, npass_lm = lm_passes(p.vocab), row0_lm = lm_rows_per_cu(p.vocab) * b;
     if (cw == NCONS - 1) {      // norm weights (* Ada scale) * 512 of this CU's 12 rows for every layer -> LDS, once per launch, while everybody waits for the first all-gather
@@ -593,8 +653,6 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
     float best = -INFINITY; int best_i = 0x7fffffff;
     const bool xloc = (p.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0;      // this workgroup runs on XCD blockIdx % 8, like (by the same check) the group's other 31
 
-    // one pass of a 3-plane operator on its two rows: (a, b) = the pass's two row sums (before the RMSNorm scale)
-    auto two_rows = [&](float acc, float& a, float& bq) { acc = row16_sum_e(acc); a = rlf(acc, 0) + rlf(acc, 16); bq = rlf(acc, 32) + rlf(acc, 48); };
 #pragma unroll 1
     for (int it = 0; it <= n_items; it++) {
         int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per item: lane-derived addresses are recomputed, not carried around the loop in VGPRs
@@ -605,48 +663,52 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         if (op == EOP_QKV) {
             // ================= q|k|v  ->  attention of head h  ->  wo =================
             const gf_p kc = as_g(L->kc) + (size_t)g * p.max_seq * EHD, vc = as_g(L->vc) + (size_t)g * p.max_seq * EHD;
-            const int t6 = cw * 64 + lane;
-            const int part = t6 & 7, ks = t6 >> 3;              // scores: 8 lanes per key, 48 keys per pass
-            const int kg = t6 >> 5, col = t6 & 31;              // P.V: 12 key groups x 32 float4 columns
-            wait_ge(&c->xs0_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+            const int t12 = cw * 64 + lane;
+            const int part = t12 & 7, ks = t12 >> 3;            // scores: 8 lanes per key, 96 keys per pass
+            const float rstd = cs.all_gather(p.H0, p.SS0, tag - 1u, 2u * (unsigned)l, xs, ssl, tl, false);
             if (T) tl(0);
             // the old K rows do not depend on this step: requested BEFORE the q|k|v passes, so they are home before the q|k|v edge is polled (a prefetch burst
-            // right behind the publish sat in front of this CU's own granule sweep: +3 us on the edge); the V rows are requested once the edge has resolved
-            constexpr int NKP = 3;      // 144 keys up front (48 VGPRs); later keys take the loop below
+            // right behind the publish sat in front of this CU's own granule sweep: +3 us on the edge); the V rows are requested once the passes are done
+            constexpr int NKP = 2;      // 192 keys in registers (32 VGPRs): 96 requested here, 96 behind the passes (the activation registers are dead by then); later keys take the loop below
             float4 kpre[NKP][4];
+            auto kload = [&](int u) {      // only keys that exist: at position 100 the clamped form moved 150 KB per CU where 100 KB are rows -- in front of the COMM wave's polls
+                const unsigned ko = (unsigned)(j_lo + min(ks + 96 * u, last_old)) * EHD + part * 16;      // 32-bit lane offset + uniform base: one VGPR per address
 #pragma unroll
-            for (int u = 0; u < NKP; u++) {
-                const unsigned ko = (unsigned)(j_lo + min(ks + 48 * u, last_old)) * EHD + part * 16;      // 32-bit lane offset + uniform base: one VGPR per address
+                for (int e = 0; e < 4; e++) kpre[u][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ks + 96 * u < n_old) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) kpre[u][e] = ldg4(kc + (ko + 4 * e));
-            }
+                    for (int e = 0; e < 4; e++) kpre[u][e] = ldg4(kc + (ko + 4 * e));
+                }
+            };
+            kload(0);
             {
-                XRegs<3> xr; xr.load(xs0, lane & 31, 32);
-                const float rstd = c->rstd0;
-#pragma unroll
-                for (int t = 0; t < QKV_PK; t++) {
-                    uint4 Qa[3]; float Sa[3];      // (no register double-buffering here: the 64 K-prefetch registers are live)
-                    cs.fetch<3>(cs.P + t, Qa, Sa, true);
-                    float a, bq; two_rows(cs.pass_dot<3>(Qa, Sa, xr), a, bq); a *= rstd; bq *= rstd;
-                    const int q = cw + 6 * t;
-                    int n; float c_, s_;
-                    if (t == 0) { n = 128 * h + 16 * s + 2 * q; c_ = rc0; s_ = rs0; }
-                    else if (cw < 2) { n = 128 * h + 16 * s + 2 * q; c_ = rc1; s_ = rs1; }
-                    else if (cw < 4) { n = EQD + 128 * g + 4 * j + 2 * (q - 8); c_ = rc1; s_ = rs1; }
-                    else { n = EQD + EKD + 128 * g + 4 * j + 2 * (q - 10); c_ = 1.0f; s_ = 0.0f; }
-                    const float ra = a * c_ - bq * s_, rb = a * s_ + bq * c_;        // interleaved-pair RoPE (rope.rs:99-141); identity for v
-                    if (lane < 2) {
-                        const float v = lane ? rb : ra;
-                        publish_b(p.G, (EQD + 2 * EKD) * 8u, (unsigned)(n + lane), tag, v, xloc);
-                        if (t == 1 && cw >= 2) (cw < 4 ? kc : vc)[(size_t)pos * EHD + (n & 127) + lane] = v;      // k / v rows also go to the cache (read by later steps)
-                    }
+                XA xr; xr.load(xs, lane, 64 + (lane >> 1), lane & 1);
+                PassA Pa;
+                cs.fetch(cs.P, Pa);
+                const float a = wave_sum_e(Cons::dot(Pa, xr)) * rstd;      // the pair's two rows
+                cs.fetch(cs.P + 1, Pa);
+                const float bq = wave_sum_e(Cons::dot(Pa, xr)) * rstd;
+                const int n = cw < 8 ? 128 * h + 16 * s + 2 * cw : cw < 10 ? EQD + 128 * g + 4 * j + 2 * (cw - 8) : EQD + EKD + 128 * g + 4 * j + 2 * (cw - 10);
+                const float ra = a * rc - bq * rs, rb = a * rs + bq * rc;        // interleaved-pair RoPE (rope.rs:99-141); identity for v
+                if (lane < 2) {
+                    const float v = lane ? rb : ra;
+                    publish_b(p.G, (EQD + 2 * EKD) * 8u, (unsigned)(n + lane), tag, v, xloc);
+                    if (cw >= 8) (cw < 10 ? kc : vc)[(size_t)pos * EHD + (n & 127) + lane] = v;      // k / v rows also go to the cache (read by later steps)
                 }
                 cs.P += QKV_PK;
+                cs.published(tl, l == p.tl_layer ? 28 : -1);
             }
             if (T) tl(1);
-            float4 vpre[16];
+            kload(1);
+            float2 vpre[16];      // P.V: wave = key group (keys cw + 12 u), lane = float2 column
 #pragma unroll
-            for (int u = 0; u < 16; u++) vpre[u] = ldg4(vc + ((unsigned)(j_lo + min(kg + 12 * u, last_old)) * EHD + col * 4));
+            for (int u = 0; u < 16; u++) {
+                vpre[u] = make_float2(0.f, 0.f);
+                if (cw + 12 * u < n_old) {      // wave-uniform: rows that do not exist are not requested
+                    const fv2 v = *(const __attribute__((address_space(1))) fv2*)(vc + ((unsigned)(j_lo + cw + 12 * u) * EHD + lane * 2));
+                    vpre[u] = make_float2(v.x, v.y);
+                }
+            }
             wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
             if (T) tl(2);
             {
@@ -662,10 +724,10 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
 #pragma unroll
                 for (int u = 0; u < NKP; u++) {
                     const float sv = dot16(kpre[u]);
-                    const int i = ks + 48 * u;
+                    const int i = ks + 96 * u;
                     if (part == 0 && i < n_old) sc[i] = sv * scale;
                 }
-                for (int i0 = 48 * NKP; i0 < n_old; i0 += 48) {      // later keys
+                for (int i0 = 96 * NKP; i0 < n_old; i0 += 96) {      // later keys
                     const int i = i0 + ks;
                     float4 kk[4];
                     const unsigned ko = (unsigned)(j_lo + min(i, last_old)) * EHD + part * 16;
@@ -679,7 +741,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
 #pragma unroll
                     for (int e = 0; e < 4; e++) kk[e] = *reinterpret_cast<const float4*>(qkvn + 128 + part * 16 + 4 * e);
                     const float sv = dot16(kk);
-                    if (t6 == 0) sc[n_old] = sv * scale;
+                    if (t12 == 0) sc[n_old] = sv * scale;
                 }
             }
             cs.cbarrier();
@@ -688,94 +750,102 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 float mx = -INFINITY;
                 for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[i]);
                 mx = wave_max_e(mx);
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f); float lsum = 0.f;
+                float2 o = make_float2(0.f, 0.f); float lsum = 0.f;
 #pragma unroll
                 for (int u = 0; u < 16; u++) {
-                    const int i = kg + 12 * u;
+                    const int i = cw + 12 * u;
                     if (i < n_old) {
-                        const float pr = expf(sc[i] - mx); const float4 vv = vpre[u];
-                        o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
+                        const float pr_ = expf(sc[i] - mx); const float2 vv = vpre[u];
+                        o.x = fmaf(pr_, vv.x, o.x); o.y = fmaf(pr_, vv.y, o.y); lsum += pr_;
                     }
                 }
-                for (int i = 192 + kg; i < n_old; i += 12) {
-                    const float pr = expf(sc[i] - mx); const float4 vv = ldg4(vc + ((unsigned)(j_lo + i) * EHD + col * 4));
-                    o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
+                for (int i = 192 + cw; i < n_old; i += 12) {
+                    const fv2 v = *(const __attribute__((address_space(1))) fv2*)(vc + ((unsigned)(j_lo + i) * EHD + lane * 2));
+                    const float pr_ = expf(sc[i] - mx);
+                    o.x = fmaf(pr_, v.x, o.x); o.y = fmaf(pr_, v.y, o.y); lsum += pr_;
                 }
-                if (kg == 0) {
-                    const float pr = expf(sc[n_old] - mx); const float4 vv = *reinterpret_cast<const float4*>(qkvn + 256 + col * 4);
-                    o.x = fmaf(pr, vv.x, o.x); o.y = fmaf(pr, vv.y, o.y); o.z = fmaf(pr, vv.z, o.z); o.w = fmaf(pr, vv.w, o.w); lsum += pr;
+                if (cw == 0) {
+                    const float pr_ = expf(sc[n_old] - mx); const float2 vv = *reinterpret_cast<const float2*>(qkvn + 256 + lane * 2);
+                    o.x = fmaf(pr_, vv.x, o.x); o.y = fmaf(pr_, vv.y, o.y); lsum += pr_;
                 }
-                po[kg * 32 + col] = o;
-                if (col == 0) pl[kg] = lsum;
+                po[cw * 64 + lane] = o;
+                if (lane == 0) pl[cw] = lsum;
             }
             cs.cbarrier();
-            if (t6 < EHD) {
+            if (t12 < EHD) {
                 const float* pof = reinterpret_cast<const float*>(po);
                 float so = 0.f, sl = 0.f;
 #pragma unroll
-                for (int q = 0; q < 12; q++) { so += pof[q * 128 + t6]; sl += pl[q]; }      // fixed order
-                xo[sw_dword(t6)] = so * (1.0f / sl) * 512.0f;
+                for (int q = 0; q < 12; q++) { so += pof[q * 128 + t12]; sl += pl[q]; }      // fixed order
+                xo[sw_dword(t12)] = so * (1.0f / sl) * 512.0f;
             }
             cs.cbarrier();
             if (T) tl(3);
             {   // ---------------- wo: rows [384 s, +384) x head h's 128 columns ----------------
-                XRegs<2> xr; xr.load(xo, lane & 1, 2);
-                uint4 Qa[2], Qb[2]; float Sa[2], Sb[2];
-                cs.fetch<2>(cs.P, Qa, Sa, true);
+                XA xr; xr.load_chunk(xo, lane & 3);
+                PassW Qa, Qb;
+                cs.fetch(cs.P, Qa);
 #pragma unroll 1
                 for (int t = 0; t < WO_PK; t++) {
-                    if (t + 1 < WO_PK) cs.fetch<2>(cs.P + t + 1, Qb, Sb, true);
-                    float acc = cs.pass_dot<2>(Qa, Sa, xr);
-                    acc += dppf<0xB1>(acc);
-                    if ((lane & 1) == 0) publish_b(p.PW, NPW * ED * 8u, (unsigned)(h * ED + 384 * s + 32 * (cw + 6 * t) + (lane >> 1)), tag, acc, false);
-#pragma unroll
-                    for (int i = 0; i < 2; i++) { Qa[i] = Qb[i]; Sa[i] = Sb[i]; }
+                    if (t + 1 < WO_PK) cs.fetch(cs.P + t + 1, Qb);
+                    float acc = Cons::dot(Qa, xr);
+                    acc += dppf<0xB1>(acc); acc += dppf<0x4E>(acc);
+                    if ((lane & 3) == 0) publish_b(p.PW, NPW * ED * 8u, (unsigned)(h * ED + 384 * s + 16 * (cw + NCONS * t) + (lane >> 2)), tag, acc, false);
+                    Qa = Qb;
                 }
                 cs.P += WO_PK;
+                cs.published(tl, l == p.tl_layer ? 29 : -1);
             }
             if (T) tl(4);
             continue;
         }
-        // ================= the other 3-plane operators: w1|w3, w2, lm_head (one copy of the pass loop) =================
-        unsigned* flag; unsigned target; const float* xs; int first, step, n_pass; float rstd;
-        if (op == EOP_W13) { flag = &c->xs1_flag; target = (unsigned)l + 1u; xs = xs1; first = lane & 31; step = 32; n_pass = W13_PK; }
-        else if (op == EOP_W2) { flag = &c->xa_flag; target = (unsigned)l + 1u; xs = xa; first = 12 * (cw % 3) + (lane & 3); step = 4; n_pass = W2_PK; }
-        else { flag = &c->xs0_flag; target = (unsigned)p.n_layers + 1u; xs = xs0; first = lane & 31; step = 32; n_pass = lm_packets(p.vocab); }
-        wait_ge(flag, target, c, p.err, ERR_STAGE);
-        if (T) tl(op == EOP_W13 ? 5 : 7);
+        // ================= the other A-type operators: w1|w3, w2, lm_head (one copy of the pass loop) =================
+        int n_pass; float rstd;
+        XA xr;
+        const int ts = cw % 3, rg = cw / 3;
+        if (op == EOP_W2) {
+            wait_ge(&c->xa_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+            if (T) tl(7);
+            const int t8 = lane & 7;
+            xr.load(xa, 12 * ts + t8, 12 * ts + 8 + (t8 >> 1), t8 & 1);
+            n_pass = W2_PK; rstd = 1.0f;
+        } else {
+            if (op == EOP_W13) { rstd = cs.all_gather(p.H1, p.SS1, tag, 2u * (unsigned)l + 1u, xs, ssl, tl, T); n_pass = W13_PK; }
+            else { rstd = cs.all_gather(p.H0, p.SS0, tag_base + (unsigned)p.n_layers, 2u * (unsigned)p.n_layers, xs, ssl, tl, false); n_pass = lm_packets(p.vocab); }
+            if (T) tl(5);
+            xr.load(xs, lane, 64 + (lane >> 1), lane & 1);
+        }
         const bool TP = T && op == EOP_W13;
-        rstd = op == EOP_W13 ? c->rstd1 : op == EOP_W2 ? 1.0f : c->rstd0;
-        XRegs<3> xr; xr.load(xs, first, step);
-        uint4 Qa[3], Qb[3]; float Sa[3], Sb[3];
+        PassA Qa, Qb;
         if (TP) tl(24);
-        cs.fetch<3>(cs.P, Qa, Sa, op != EOP_LM || cw < npass_lm);
+        cs.fetch(cs.P, Qa);
         if (TP) tl(25);
+        float gate = 0.f;
 #pragma unroll 1
         for (int t = 0; t < n_pass; t++) {
-            const int q = cw + 6 * t;                                  // this wave's pass of packet t
-            if (t + 1 < n_pass) cs.fetch<3>(cs.P + t + 1, Qb, Sb, op != EOP_LM || q + 6 < npass_lm);
+            const int q = cw + NCONS * t;                              // this wave's pass of packet t
+            if (t + 1 < n_pass) cs.fetch(cs.P + t + 1, Qb);
             if (op != EOP_LM || q < npass_lm) {
-                float acc = cs.pass_dot<3>(Qa, Sa, xr);
+                float acc = Cons::dot(Qa, xr);
                 if (op == EOP_W2) {
-                    acc += dppf<0xB1>(acc); acc += dppf<0x4E>(acc);
-                    if ((lane & 3) == 0) publish_b(p.P2, NP2 * ED * 8u, (unsigned)((3 * g + cw % 3) * ED + 96 * j + 48 * (cw / 3) + 16 * t + (lane >> 2)), tag, acc, false);
+                    acc = group8_sum_e(acc);
+                    if ((lane & 7) == 0) publish_b(p.P2, NP2 * ED * 8u, (unsigned)((3 * g + ts) * ED + 96 * j + 32 * t + 8 * rg + (lane >> 3)), tag, acc, false);
                 } else {
-                    float a, bq; two_rows(acc, a, bq); a *= rstd; bq *= rstd;
+                    const float r = wave_sum_e(acc) * rstd;
                     if (op == EOP_W13) {
-                        if (lane == 0) publish_b(p.A, EF * 8u, (unsigned)(1152 * g + 36 * j + q), tag, silu_e(a) * bq, xloc);
+                        if ((t & 1) == 0) gate = r;
+                        else if (lane == 0) publish_b(p.A, EF * 8u, (unsigned)(1152 * g + 36 * j + cw + NCONS * (t >> 1)), tag, silu_e(gate) * r, xloc);
                     } else {
-                        const int n = row0_lm + 2 * q;
-                        if (p.logits_out && lane < 2) p.logits_out[n + lane] = lane ? bq : a;
-                        if (a > best || (a == best && n < best_i)) { best = a; best_i = n; }
-                        if (bq > best || (bq == best && n + 1 < best_i)) { best = bq; best_i = n + 1; }
+                        const int n = row0_lm + q;
+                        if (p.logits_out && lane == 0) p.logits_out[n] = r;
+                        if (r > best || (r == best && n < best_i)) { best = r; best_i = n; }
                     }
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 3; i++) { Qa[i] = Qb[i]; Sa[i] = Sb[i]; }
-            if (TP) tl(26 + t);
+            Qa = Qb;
         }
         cs.P += (unsigned)n_pass;
+        if (op != EOP_LM) cs.published(tl, l == p.tl_layer ? (op == EOP_W13 ? 30 : 31) : -1);
         if (T) tl(op == EOP_W13 ? 6 : 14);
     }
     // ---------------- argmax partial of this CU ----------------
@@ -816,7 +886,7 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams 
 }  // namespace
 
 bool eng_geometry_ok(int D, int n_heads, int n_kv, int hd, int ffn, int vocab, int max_seq) {
-    return D == ED && n_heads == ENH && n_kv == ENKV && hd == EHD && ffn == EF && vocab > 0 && vocab % (2 * NCU) == 0 && max_seq > 0 && max_seq <= SC_MAX;
+    return D == ED && n_heads == ENH && n_kv == ENKV && hd == EHD && ffn == EF && vocab > 0 && vocab % NCU == 0 && max_seq > 0 && max_seq <= SC_MAX;
 }
 size_t eng_stream_bytes(int n_layers, int vocab) { return cu_stream_bytes(n_layers, vocab) * NCU; }
 int eng_lds_bytes() { return L_TOTAL; }
@@ -847,7 +917,7 @@ hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsign
     }
     if (w.N != N || w.K != K) return hipErrorInvalidValue;
     const size_t op_off = op == EOP_LM ? (size_t)n_layers * LAYER_BYTES : (size_t)layer * LAYER_BYTES + off_bytes;
-    eng_pack_kernel<<<dim3(passes, NCU), dim3(192), 0, s>>>(w, op, stream, cu_stream_bytes(n_layers, vocab), op_off, vocab);
+    eng_pack_kernel<<<dim3(passes, NCU), dim3(64), 0, s>>>(w, op, stream, cu_stream_bytes(n_layers, vocab), op_off, vocab);
     return hipGetLastError();
 }
 
