@@ -40,21 +40,31 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ED = 3072, ENH = 32, ENKV = 8, EHD = 128, EQD = ENH * EHD, EKD = ENKV * EHD, EF = 9216;
 constexpr int NCU = 256, NCONS = 12, NWAVES = NCONS + 2, NTHR = 64 * NWAVES;      // 14 waves: 3-4 per SIMD (one wave per SIMD issues a VALU instruction only every ~8 cycles)
-// bytes per pass.  A-type (K = 3072 or a 384-column w2 sub-slice): ONE row (or 8 w2 row pieces) = 96 Q4 blocks over 64 lanes, 1.5 blocks per lane:
-//   [64] x 16 B nibbles of block `lane` | [64] x 8 B: half (lane & 1) of block 64 + lane / 2 | [64] x 2 B scales | [32] x 2 B scales of the split blocks.
-// wo-type (K = 128): 16 rows x 4 lanes x one block: [64] x 16 B | [64] x 2 B.
-constexpr int PASS_A = 1728, PASS_WO = 1152;
-constexpr int PA_Q1 = 1024, PA_S0 = 1536, PA_S1 = 1664, PW_S0 = 1024;
-constexpr int PK_A = NCONS * PASS_A, PK_WO = NCONS * PASS_WO;   // packet = one pass per consumer wave: 20736 / 13824 bytes, stored back to back (no padding)
-constexpr int LINES_A = (PK_A + 1023) / 1024, LINES_WO = (PK_WO + 1023) / 1024;      // LDS-DMA instructions per packet (the last one partial: 16 / 32 lanes)
-static_assert(LINES_A == 21 && LINES_WO == 14, "wait_vmcnt() enumerates the in-flight line counts 14 / 21 / 28 / 35 / 42");
-constexpr int SLOT_BYTES = PK_A, NSLOT = 6;            // w1|w3's six packets fit: with five slots its last pass waited for a refill (4 us tail per layer)
-constexpr int QKV_PK = 2, WO_PK = 2, W13_PK = 6, W2_PK = 3;
-constexpr int LAYER_BYTES = (QKV_PK + W13_PK + W2_PK) * PK_A + WO_PK * PK_WO;   // 255744 bytes per CU per layer = exactly the Q4 bytes
-constexpr int OFF_QKV = 0, OFF_WO = QKV_PK * PK_A, OFF_W13 = OFF_WO + WO_PK * PK_WO, OFF_W2 = OFF_W13 + W13_PK * PK_A;   // byte offsets inside a layer
+// ---- layer operators: 16-row x 64-column MFMA steps (v_mfma_i32_16x16x64_i8) ----
+// One STEP RECORD = what the 64 lanes of a wave feed one MFMA: lane (n = lane & 15, g = lane >> 4) holds 8 bytes of nibbles = half g & 1 of Q4 block
+// 2 T + (g >> 1) of tile row n (its elements 8 h .. 8 h + 7 and 16 + 8 h .. 16 + 8 h + 7), then the 2 x 16 f16 block scales [block parity][n]: 576 bytes.
+// A tile of 8 rows (the k|v rows of q|k|v, the last tile of w1|w3) stores lanes n < 8 only: 288 bytes.
+// A packet holds, for each of the 12 consumer waves, the records of ITS K-steps (the K range is split over the waves; the row tiles are shared):
+//   q|k|v (24 rows x 48 K-steps: wave w owns steps 4 w .. 4 w + 3)   packets 0, 1 = tile 0 steps {0, 1}, {2, 3}; packet 2 = the 8-row tile, 4 steps    3 x 13824 B
+//   wo    (384 rows x 2 steps: wave w owns tiles 2 w, 2 w + 1)       packet i = tile 2 w + i, both steps                                          2 x 13824 B
+//   w1|w3 (72 rows x 48 steps: wave w owns steps 4 w ..)             packets 2 i, 2 i + 1 = tile i < 4; packet 8 = the 8-row tile                9 x 13824 B
+//   w2    (96 rows x 18 steps: wave w owns steps 3 (w % 6) .. of tiles 3 (w / 6) ..)   packet i = tile 3 (w / 6) + i                        3 x 20736 B
+// lm_head: one ROW per wave per packet (VALU path): [64] x 16 B nibbles of block `lane` | [64] x 8 B: half (lane & 1) of block 64 + lane / 2 | [64] x 2 B
+// scales | [32] x 2 B scales of the split blocks = 1728 B per pass, 20736 B per packet.
+constexpr int REC = 576, REC_H = 288, REC_SC = 512, REC_H_SC = 256;
+constexpr int PASS_A = 1728;
+constexpr int PA_Q1 = 1024, PA_S0 = 1536, PA_S1 = 1664;
+constexpr int PK_A = NCONS * PASS_A, PK_M = NCONS * 2 * REC;    // 20736 / 13824 bytes, stored back to back (no padding)
+constexpr int LINES_A = (PK_A + 1023) / 1024, LINES_M = (PK_M + 1023) / 1024;      // LDS-DMA instructions per packet (the last one partial: 16 / 32 lanes)
+static_assert(LINES_A == 21 && LINES_M == 14, "wait_vmcnt() enumerates the in-flight line counts 14 / 21 / 28 / 35 / 42");
+constexpr int SLOT_BYTES = PK_A, NSLOT = 6;
+constexpr int QKV_PK = 3, WO_PK = 2, W13_PK = 9, W2_PK = 3, PK_LAYER = QKV_PK + WO_PK + W13_PK + W2_PK, PK_LAYER_M = QKV_PK + WO_PK + W13_PK;      // the first 14 packets of a layer are 13824 bytes
+constexpr int LAYER_BYTES = PK_LAYER_M * PK_M + W2_PK * PK_A;   // 255744 bytes per CU per layer = exactly the Q4 bytes
+constexpr int OFF_QKV = 0, OFF_WO = QKV_PK * PK_M, OFF_W13 = OFF_WO + WO_PK * PK_M, OFF_W2 = OFF_W13 + W13_PK * PK_M;   // byte offsets inside a layer
+static_assert(LAYER_BYTES == 255744, "layer bytes");
 constexpr int SC_MAX = 1024;                          // attention scores in LDS: cache rows per KV head (max_seq) <= 1024
 constexpr int OWN = ED / NCU;                         // 12 rows of the residual stream per CU
-constexpr int NPW = ENH, NP2 = 24;                    // partial planes of wo / w2
+constexpr int NPW = ENH, NP2 = ENKV;                  // partial planes of wo (one per head) / w2 (one per XCD group: the whole 1152-column slice in one CU)
 constexpr u64 TIMEOUT_TICKS = 2000000;                // s_memrealtime ticks (100 MHz): 20 ms
 
 enum { EOP_QKV = 0, EOP_WO = 1, EOP_W13 = 2, EOP_W2 = 3, EOP_LM = 4 };
@@ -65,47 +75,56 @@ __host__ __device__ inline int lm_passes(int vocab) { return lm_rows_per_cu(voca
 __host__ __device__ inline int lm_packets(int vocab) { return (lm_passes(vocab) + NCONS - 1) / NCONS; }
 __host__ __device__ inline size_t cu_stream_bytes(int n_layers, int vocab) { return (size_t)n_layers * LAYER_BYTES + (size_t)lm_packets(vocab) * PK_A + 1024; }      // + 1 KiB: the stream is read in whole 16-byte lanes only, the pad keeps the allocation comfortable
 
-// What pass q (= 12 * packet + consumer wave) of operator `op` on CU b holds for `lane`: the row, the lane's whole Q4 block and (A-type only) the block it
-// shares with its neighbour lane (half lane & 1 of it).
-__host__ __device__ inline void eng_src(int op, int b, int q, int lane, int vocab, int* row, int* blk, int* blk_half) {
+// ---- record addressing (shared by the pack kernel and -- implicitly, through the same formulas -- the consumer waves) ----
+__host__ __device__ inline int op_packets(int op) { return op == EOP_QKV ? QKV_PK : op == EOP_WO ? WO_PK : op == EOP_W13 ? W13_PK : W2_PK; }
+__host__ __device__ inline int op_pk_bytes(int op) { return op == EOP_W2 ? PK_A : PK_M; }
+__host__ __device__ inline bool pk_half_tile(int op, int pk) { return (op == EOP_QKV && pk == 2) || (op == EOP_W13 && pk == 8); }
+__host__ __device__ inline int pk_steps(int op, int pk) { return op == EOP_W2 ? 3 : pk_half_tile(op, pk) ? 4 : 2; }      // records per wave in the packet
+// record s of wave w in packet pk: the 16-row tile and the K-step (64 columns) of the operator's K range on this CU
+__host__ __device__ inline void rec_src(int op, int pk, int w, int s, int* tile, int* T) {
+    if (op == EOP_QKV) { if (pk < 2) { *tile = 0; *T = 4 * w + 2 * pk + s; } else { *tile = 1; *T = 4 * w + s; } }
+    else if (op == EOP_W13) { if (pk < 8) { *tile = pk >> 1; *T = 4 * w + 2 * (pk & 1) + s; } else { *tile = 4; *T = 4 * w + s; } }
+    else if (op == EOP_W2) { *tile = 3 * (w / 6) + pk; *T = 3 * (w % 6) + s; }
+    else { *tile = 2 * w + pk; *T = s; }
+}
+__host__ __device__ inline int tile_row(int op, int b, int tile, int n) {      // weight-matrix row of tile row n on CU b
     const int g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
-    const int t = q / NCONS, w = q % NCONS;
-    *blk = lane; *blk_half = 64 + (lane >> 1);
-    if (op == EOP_QKV) {                                               // wave w owns RoPE pair w of the CU's 12 (8 of q, 2 of k, 2 of v): element t of the pair in packet t
-        if (w < 8) *row = 128 * h + 16 * s + 2 * w + t;
-        else if (w < 10) *row = EQD + 128 * g + 4 * j + 2 * (w - 8) + t;
-        else *row = EQD + EKD + 128 * g + 4 * j + 2 * (w - 10) + t;
-    } else if (op == EOP_W13) {                                        // SwiGLU output w + 12 (t / 2) of the CU's 36: gate row in packet 2 k, up row in packet 2 k + 1
-        *row = 2 * (1152 * g + 36 * j + w + NCONS * (t >> 1)) + (t & 1);
-    } else if (op == EOP_LM) {
-        *row = lm_rows_per_cu(vocab) * b + q;
-    } else if (op == EOP_WO) {                                         // 16 rows per pass, 4 lanes x 1 block per row (K = the head's 128 columns)
-        *row = 384 * s + 16 * q + (lane >> 2);
-        *blk = 4 * h + (lane & 3); *blk_half = -1;
-    } else {                                                           // w2: 8 rows per pass, 8 lanes x 1.5 blocks; wave w: K sub-slice w % 3, row group w / 3
-        const int ts = w % 3, rg = w / 3, t8 = lane & 7;
-        *row = 96 * j + 32 * t + 8 * rg + (lane >> 3);
-        *blk = 36 * g + 12 * ts + t8; *blk_half = 36 * g + 12 * ts + 8 + (t8 >> 1);
-    }
+    if (op == EOP_QKV) return tile == 0 ? 128 * h + 16 * s + n : n < 4 ? EQD + 128 * g + 4 * j + n : EQD + EKD + 128 * g + 4 * j + (n - 4);
+    if (op == EOP_W13) return 2 * (1152 * g + 36 * j) + 16 * tile + n;      // interleaved gate / up rows: SwiGLU output i = rows 2 i, 2 i + 1
+    if (op == EOP_W2) return 96 * j + 16 * tile + n;
+    return 384 * s + 16 * tile + n;
+}
+__host__ __device__ inline int step_blk0(int op, int b, int T) {      // first Q4 block (of two) of K-step T
+    const int g = b & 7, j = b >> 3, h = 4 * g + (j >> 3);
+    return op == EOP_W2 ? 36 * g + 2 * T : op == EOP_WO ? 4 * h + 2 * T : 2 * T;
 }
 
-__global__ __launch_bounds__(64) void eng_pack_kernel(Q4W w, int op, unsigned char* __restrict__ stream, size_t cu_stride, size_t op_off, int vocab) {
+// lm_head pass q (= 12 * packet + consumer wave) on CU b: the row; lane holds block `lane` and half (lane & 1) of block 64 + lane / 2
+__global__ __launch_bounds__(64) void eng_pack_lm_kernel(Q4W w, unsigned char* __restrict__ stream, size_t op_off, int vocab) {
     const int q = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    int row, blk, blk_half; eng_src(op, b, q, lane, vocab, &row, &blk, &blk_half);
-    const size_t pk_bytes = op == EOP_WO ? PK_WO : PK_A, pass_bytes = op == EOP_WO ? PASS_WO : PASS_A;
-    // packet-major: packet k of all 256 CUs is contiguous ([k][cu][bytes]) -- at any moment the 256 loaders read one contiguous ~5 MB window, spread over
-    // every HBM channel (CU-major streams 7.3 MB apart put all loaders on the same channels at the same time)
-    (void)cu_stride;
-    unsigned char* dst = stream + (size_t)NCU * (op_off + (size_t)(q / NCONS) * pk_bytes) + (size_t)b * pk_bytes + (size_t)(q % NCONS) * pass_bytes;
-    const size_t src = (size_t)row * w.nb + blk;
+    const int row = lm_rows_per_cu(vocab) * b + q;
+    unsigned char* dst = stream + (size_t)NCU * (op_off + (size_t)(q / NCONS) * PK_A) + (size_t)b * PK_A + (size_t)(q % NCONS) * PASS_A;
+    const size_t src = (size_t)row * w.nb + lane;
     reinterpret_cast<uint4*>(dst)[lane] = w.qs[src];
-    reinterpret_cast<uint16_t*>(dst + (op == EOP_WO ? PW_S0 : PA_S0))[lane] = w.sc[src];
-    if (blk_half >= 0) {
-        const size_t sh = (size_t)row * w.nb + blk_half;
-        const uint4 qh = w.qs[sh];
-        reinterpret_cast<uint2*>(dst + PA_Q1)[lane] = (lane & 1) ? make_uint2(qh.z, qh.w) : make_uint2(qh.x, qh.y);      // bytes [8 half, +8): elements [8 half, +8) and 16 + the same
-        if ((lane & 1) == 0) reinterpret_cast<uint16_t*>(dst + PA_S1)[lane >> 1] = w.sc[sh];
-    }
+    reinterpret_cast<uint16_t*>(dst + PA_S0)[lane] = w.sc[src];
+    const size_t sh = (size_t)row * w.nb + 64 + (lane >> 1);
+    const uint4 qh = w.qs[sh];
+    reinterpret_cast<uint2*>(dst + PA_Q1)[lane] = (lane & 1) ? make_uint2(qh.z, qh.w) : make_uint2(qh.x, qh.y);      // bytes [8 half, +8): elements [8 half, +8) and 16 + the same
+    if ((lane & 1) == 0) reinterpret_cast<uint16_t*>(dst + PA_S1)[lane >> 1] = w.sc[sh];
+}
+// layer operators: one workgroup per (record, CU).  Packet-major stream: packet k of all 256 CUs is contiguous ([k][cu][bytes]) -- at any moment the 256
+// loaders read one contiguous ~5 MB window, spread over every HBM channel (CU-major streams 7.3 MB apart put all loaders on the same channels at the same time)
+__global__ __launch_bounds__(64) void eng_pack_kernel(Q4W w, int op, unsigned char* __restrict__ stream, size_t op_off) {
+    const int pk = blockIdx.x / (NCONS * 4), wv = (blockIdx.x / 4) % NCONS, s = blockIdx.x % 4, b = blockIdx.y, lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    const int steps = pk_steps(op, pk); const bool half = pk_half_tile(op, pk);
+    if (s >= steps || (half && n >= 8)) return;
+    int tile, T; rec_src(op, pk, wv, s, &tile, &T);
+    const int row = tile_row(op, b, tile, n), blk0 = step_blk0(op, b, T);
+    const size_t pk_bytes = (size_t)op_pk_bytes(op), rec_bytes = half ? REC_H : REC;
+    unsigned char* dst = stream + (size_t)NCU * (op_off + (size_t)pk * pk_bytes) + (size_t)b * pk_bytes + (size_t)wv * steps * rec_bytes + (size_t)s * rec_bytes;
+    const uint4 q = w.qs[(size_t)row * w.nb + blk0 + (g >> 1)];
+    reinterpret_cast<uint2*>(dst)[half ? g * 8 + n : lane] = (g & 1) ? make_uint2(q.z, q.w) : make_uint2(q.x, q.y);
+    if (g < 2) reinterpret_cast<uint16_t*>(dst + (half ? REC_H_SC : REC_SC))[(half ? 8 : 16) * g + n] = w.sc[(size_t)row * w.nb + blk0 + g];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -119,27 +138,31 @@ struct EngCtl {
     float rstd0, rstd1, pad1, pad2;
     float best_val[16]; int best_idx[16];
     float h_own[16], h1_own[16];
+    float rope_c[24], rope_s[24];                 // RoPE factors of the CU's 24 q|k|v rows (the same in every layer; wave 0 reads them back per layer instead of holding two VGPRs all step)
 };
 constexpr int L_RING = 0;
-constexpr int L_XS = L_RING + NSLOT * SLOT_BYTES;       // [3072] f32, swizzled chunks: the all-gathered input of q|k|v / w1|w3 / lm_head.  ONE buffer: it is re-staged only
-                                                        //   after every consumer wave has published results computed from the previous content (registers hold x during an operator)
-constexpr int L_U = L_XS + ED * 4;                      // time-shared: the XCD group's 1152 SwiGLU outputs (w2 input) | attention scratch of the NEXT layer
-constexpr int L_XA = L_U;                               //   [1152] staged after w1|w3, loaded to registers at the start of w2
-constexpr int L_SC = L_U;                               //   [SC_MAX] scores
+constexpr int L_XS = L_RING + NSLOT * SLOT_BYTES;       // 12 KB: the all-gathered (or XCD-gathered) input vector of the next operator, as FIXED-POINT DIGIT PLANES for the MFMA operators
+                                                        //   ([block][digit 0..3][half][16 B]: 128 bytes per 32-element block -- the same 4 bytes per element as f32), or as swizzled f32 chunks for
+                                                        //   the lm_head.  ONE buffer: it is re-staged only after every consumer wave has published results computed from the previous content
+constexpr int L_U = L_XS + ED * 4;                      // time-shared: cross-wave partial sums of the operator in flight | the XCD group's 1152 SwiGLU outputs (f32, before conversion) | attention scratch
+constexpr int L_XA = L_U;                               //   [1152] f32 staged by the COMM wave after w1|w3, converted to digit planes (in L_XS) by the consumer waves
+constexpr int L_PART = L_U;                             //   [rows][12 or 6] f32 partial sums (<= 72 x 12)
+constexpr int L_SC = L_U;                               //   [SC_MAX] scores; after the softmax: [128] attention output (f32) on its way to digits
 constexpr int L_PO = L_SC + SC_MAX * 4;                 //   [12][128] partial attention outputs
 constexpr int L_PL = L_PO + 12 * 128 * 4;               //   [16] partial softmax sums
-constexpr int L_XO = L_PL + 64;                         // [128] attention output of head h (wo input)
+constexpr int L_XO = L_PL + 64;                         // [4 blocks] digit planes of head h's attention output (wo input): 512 B
 constexpr int L_QKVN = L_XO + 128 * 4;                  // q_h[128] k_g[128] v_g[128] of this step (plain order)
 constexpr int L_TMP = L_QKVN + 384 * 4;                 // [384] partial sums swept by the comm wave
 constexpr int L_SSQ = L_TMP + 384 * 4;                  // [256] per-CU partial sums of squares of the vector being all-gathered
-constexpr int L_TAB = L_SSQ + NCU * 4;                  // [MAX_LAYERS] copy of the layer table: pointer reads never touch VMEM (a vector load behind a publish waits for the store)
+constexpr int L_BLK = L_SSQ + NCU * 4;                  // [96 + 4] per 32-element block of the staged vector: {-8 * sum of its fixed-point values, 2^-shift}; [96..99]: the wo input's 4 blocks
+constexpr int L_TAB = L_BLK + 100 * 8;                  // [MAX_LAYERS] copy of the layer table: pointer reads never touch VMEM (a vector load behind a publish waits for the store)
 constexpr int MAX_LAYERS = 32;
-constexpr int L_GW = L_TAB + MAX_LAYERS * (int)sizeof(EngLayerTab);      // [MAX_LAYERS + 1][2][16] norm weight * 512 of this CU's 12 rows: [l][0] attn_norm (l = L: final norm), [l][1] ffn_norm * Ada
+constexpr int L_GW = L_TAB + MAX_LAYERS * (int)sizeof(EngLayerTab);      // [MAX_LAYERS + 1][2][16] norm weight of this CU's 12 rows: [l][0] attn_norm (l = L: final norm * 512 -- the lm_head's fp8 trick), [l][1] ffn_norm * Ada
 constexpr int L_CTL = L_GW + (MAX_LAYERS + 1) * 32 * 4;
 constexpr int L_TOTAL = L_CTL + (int)sizeof(EngCtl);
 static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
 static_assert(L_TAB % 16 == 0 && sizeof(EngLayerTab) == 40, "layer table");
-static_assert(L_XS % 16 == 0 && L_XA % 16 == 0 && L_XO % 16 == 0 && L_QKVN % 16 == 0 && L_PO % 16 == 0 && L_CTL % 16 == 0 && 1152 * 4 <= SC_MAX * 4 + 12 * 128 * 4, "16-byte aligned carve");
+static_assert(L_XS % 16 == 0 && L_XA % 16 == 0 && L_XO % 16 == 0 && L_QKVN % 16 == 0 && L_PO % 16 == 0 && L_CTL % 16 == 0 && L_BLK % 8 == 0 && 72 * 12 * 4 <= SC_MAX * 4 && 1152 * 4 <= SC_MAX * 4 + 12 * 128 * 4, "aligned carve");
 
 // ------------------------------------------------------------------------------------------------
 // helpers
@@ -279,7 +302,6 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
     const bool nodma = (p.flags & 32) != 0;    // diagnostic: no LDS-DMA at all inside the layers (results wrong)
     if (p.flags & 64) ld.pause_ticks = 300;
     const u64 base = (u64)p.stream;
-    constexpr int PK_LAYER = QKV_PK + WO_PK + W13_PK + W2_PK;
     const unsigned n_layer_pk = (unsigned)p.n_layers * PK_LAYER, n_pk = n_layer_pk + (unsigned)lm_packets(p.vocab);
     unsigned l = 0, r = 0;                       // layer, packet within the layer
     u64 off = 0;                                 // byte offset of the next packet in this CU's stream (packets are stored in consumption order)
@@ -287,7 +309,7 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
     for (unsigned pk = 0; pk < n_pk; pk++) {
         int bytes = PK_A;
         if (pk < n_layer_pk) {
-            if (r >= QKV_PK && r < QKV_PK + WO_PK) bytes = PK_WO;
+            if (r < PK_LAYER_M) bytes = PK_M;
             if (r == 0 && (int)l == p.tl_layer) tl(16);
         } else { ld.pace = 0; ld.pause_ticks = 0; }      // no edge left to protect: the lm_head streams at full depth
         ld.issue(fake ? base + (u64)blockIdx.x * PK_A : base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes, bytes, lane, nodma);
@@ -396,7 +418,7 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
     const float* gwt = reinterpret_cast<const float*>(lds + L_GW);      // filled by consumer wave 5 while everybody waits for the first all-gather
     // the step's input joins the granule protocol: every CU publishes its 12 rows of h_in, so layer 0 takes the same all-gather as every other layer
     {
-        const float g0 = ld_gf(make_srd(p.n_layers > 0 ? tab[0].attn_norm : p.final_norm, ED * 4u), own_k) * 512.0f;
+        const float g0 = ld_gf(make_srd(p.n_layers > 0 ? tab[0].attn_norm : p.final_norm, ED * 4u), own_k) * (p.n_layers > 0 ? 1.0f : 512.0f);
         comm_publish_rows(p, lane0, ld_gf(make_srd(p.h_in, ED * 4u), own_k), g0, p.H0, p.SS0, tag_base, c->h_own);
     }
 #pragma unroll 1
@@ -442,20 +464,20 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
                 float v[18];
                 sweep<18>(p.A, EF * 8u, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, PROBE_SMALL, v, c, p.err);      // probe: the last output of each CU of the group
 #pragma unroll
-                for (int u = 0; u < 18; u++) xa[sw_dword(lane + 64 * u)] = v[u] * 512.0f;
+                for (int u = 0; u < 18; u++) xa[lane + 64 * u] = v[u];      // plain f32: the consumer waves turn it into digit planes
                 ENG_CFENCE(); lds_st(&c->xa_flag, (unsigned)l + 1u);
             }
             if (T) tl(12);
-            {   // w2: 24 partial planes of this CU's 12 rows -> the layer's output, published as the next layer's q|k|v input (gw = next attn_norm * 512)
+            {   // w2: 8 partial planes (one per XCD group) of this CU's 12 rows -> the layer's output, published as the next layer's q|k|v input (gw = next attn_norm)
                 wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 4u), c, p.err, ERR_STAGE);
-                float v[5];
-                sweep<5>(p.P2, NP2 * ED * 8u, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
+                float v[2];
+                sweep<2>(p.P2, NP2 * ED * 8u, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
 #pragma unroll
-                for (int u = 0; u < 5; u++) if (lane + 64 * u < NP2 * OWN) tmp[lane + 64 * u] = v[u];
+                for (int u = 0; u < 2; u++) if (lane + 64 * u < NP2 * OWN) tmp[lane + 64 * u] = v[u];
                 ENG_CFENCE();
                 float a = 0.f;
                 const int r = min(lane, OWN - 1);
-#pragma unroll 4
+#pragma unroll
                 for (int pp = 0; pp < NP2; pp++) a += tmp[pp * OWN + r];      // fixed order
                 comm_publish_rows(p, lane, c->h1_own[r] + a, gwt[((l + 1) * 2) * 16 + r], p.H0, p.SS0, tag, c->h_own);
             }
@@ -531,7 +553,62 @@ struct XA {
     }
 };
 struct PassA { uint4 q0; uint2 q1; float s0, s1; };
-struct PassW { uint4 q; float s; };
+
+// ---- MFMA side -----------------------------------------------------------------------------------------------------------------------------
+// The activation vector lives in LDS as fixed-point digit planes: per 32-element block a power-of-two scale 2^shift (block maximum < 2^26 after scaling),
+// x_int = rint(x * 2^shift) = d0 + 128 d1 + 128^2 d2 + 128^3 d3 (d0..d2 in 0..127, d3 signed), and per block {-8 * sum(x_int), 2^-shift}.
+// MFMA operand A, row m = 4 p + c: digit c of the step's block p, zero in the other block's columns -> D[4 p + c][n] = sum over block p of digit_c(x_k) * q[n][k]
+// EXACTLY (int32).  Lane group g < 2 then holds the four digit sums of block g for tile row n: Horner in f32, the -8 offset, the two scales.
+typedef int i4v __attribute__((ext_vector_type(4)));
+struct StepCtx { i4v A; float m8sx, sxinv; };
+__device__ __forceinline__ StepCtx load_ctx(const unsigned char* planes, const float2* binfo, int blk0, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+    StepCtx cx; cx.A = i4v{0, 0, 0, 0};
+    if (n < 8 && (g >> 1) == (n >> 2)) cx.A = *reinterpret_cast<const i4v*>(planes + (((blk0 + (n >> 2)) * 4 + (n & 3)) * 2 + (g & 1)) * 16);
+    const float2 bi = binfo[blk0 + (g & 1)];      // lane groups 0 / 1 finish blocks 0 / 1 (groups 2, 3 compute along on the same values; their results are dropped)
+    cx.m8sx = bi.x; cx.sxinv = bi.y;
+    return cx;
+}
+// one MFMA step of a 16-row (or 8-row) tile: acc += (block scale) * (x block scale) * sum_k x_int[k] * (q[k] - 8) for this lane's block of tile row n
+__device__ __forceinline__ float mstep(const unsigned char* rec, bool half, int lane, const StepCtx& cx, float acc) {
+    const int n = lane & 15, g = lane >> 4;
+    uint2 q = make_uint2(0u, 0u);
+    if (!half) q = reinterpret_cast<const uint2*>(rec)[lane];
+    else if (n < 8) q = reinterpret_cast<const uint2*>(rec)[g * 8 + n];
+    const unsigned short sb = reinterpret_cast<const unsigned short*>(rec + (half ? REC_H_SC : REC_SC))[(half ? 8 : 16) * (g & 1) + (half ? (n & 7) : n)];
+    i4v B; B[0] = (int)(q.x & 0x0F0F0F0Fu); B[1] = (int)(q.y & 0x0F0F0F0Fu); B[2] = (int)((q.x >> 4) & 0x0F0F0F0Fu); B[3] = (int)((q.y >> 4) & 0x0F0F0F0Fu);
+    const i4v D = __builtin_amdgcn_mfma_i32_16x16x64_i8(cx.A, B, i4v{0, 0, 0, 0}, 0, 0, 0);
+    float t = fmaf((float)D[3], 128.0f, (float)D[2]);
+    t = fmaf(t, 128.0f, (float)D[1]);
+    t = fmaf(t, 128.0f, (float)D[0]);
+    t += cx.m8sx;
+    return fmaf(t, __half2float(__ushort_as_half(sb)) * cx.sxinv, acc);
+}
+__device__ __forceinline__ float g01_sum(float v, int lane) { return v + __shfl(v, (lane + 16) & 63); }      // block 0 + block 1 partial of tile row n (valid in lanes 0..15)
+template <int CTRL>
+__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// Four consecutive elements of a 32-element block (8 consecutive lanes = one block, this lane: elements [4 (lane & 7), +4)) -> digit planes + block info
+__device__ __forceinline__ void to_digits(const float (&v)[4], int lane, unsigned char* plane_blk, float2* binfo_blk) {
+    float mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    mx = fmaxf(mx, dppf<0xB1>(mx)); mx = fmaxf(mx, dppf<0x4E>(mx)); mx = fmaxf(mx, dppf<0x141>(mx));      // over the block's 8 lanes
+    int e = __builtin_amdgcn_frexp_expf(mx);          // mx < 2^e (0 for mx == 0)
+    e = max(e, -100);
+    const float f = ldexpf(1.0f, 26 - e);
+    int xi[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) xi[i] = (int)rintf(v[i] * f);
+    int s = (xi[0] + xi[1]) + (xi[2] + xi[3]);
+    s += dppi<0xB1>(s); s += dppi<0x4E>(s); s += dppi<0x141>(s);      // exact: |x_int| <= 2^26, 32 of them
+    if ((lane & 7) == 0) *binfo_blk = make_float2(-8.0f * (float)s, ldexpf(1.0f, e - 26));
+    const int e0 = 4 * (lane & 7), h = (e0 >> 3) & 1, off = (e0 & 4) + 8 * (e0 >> 4);
+#pragma unroll
+    for (int cdig = 0; cdig < 4; cdig++) {
+        unsigned d = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int dv = cdig < 3 ? (xi[i] >> (7 * cdig)) & 127 : xi[i] >> 21; d |= (unsigned)(dv & 0xFF) << (8 * i); }
+        *reinterpret_cast<unsigned*>(plane_blk + (cdig * 2 + h) * 16 + off) = d;
+    }
+}
 
 struct Cons {
     const EngParams& p; EngCtl* c; unsigned char* lds; int cw, lane; unsigned P; unsigned cbar_n;
@@ -548,16 +625,17 @@ struct Cons {
         ENG_CFENCE();
         if (lane == 0) { const unsigned old = __hip_atomic_fetch_add(&c->pub_cnt, 1u, RLX, WG); if (evt >= 0 && tl.buf && old % NCONS == NCONS - 1) tl.buf[evt] = wall_clock64(); }
     }
-    __device__ __forceinline__ const unsigned char* slot_wait(unsigned pk, int pass_bytes, int& slot) {
+    // this wave's share (share_bytes per wave) of packet pk, once it has landed
+    __device__ __forceinline__ const unsigned char* slot_wait(unsigned pk, int share_bytes, int& slot) {
         slot = (int)(pk % NSLOT); const unsigned k = pk / NSLOT;
         wait_ge(&c->ring_ready[slot], k + 1u, c, p.err, ERR_RING);
-        return lds + L_RING + slot * SLOT_BYTES + cw * pass_bytes;
+        return lds + L_RING + slot * SLOT_BYTES + cw * share_bytes;
     }
     __device__ __forceinline__ void slot_release(int slot) {
         ENG_CFENCE();      // the LDS pipeline executes a wave's instructions in order: the reads above have been served when this add is
         if (lane == 0) __hip_atomic_fetch_add(&c->ring_done[slot], 1u, RLX, WG);
     }
-    // fetch this wave's pass of packet pk into registers and release the slot (the lm_head's last packet has fewer passes than waves: the surplus waves read
+    // lm_head: fetch this wave's pass of packet pk into registers and release the slot (the last packet has fewer passes than waves: the surplus waves read
     // whatever the slot holds and drop the result -- one straight-line body, no partially defined registers around the loop)
     __device__ __forceinline__ void fetch(unsigned pk, PassA& P_) {
         int slot; const unsigned char* base = slot_wait(pk, PASS_A, slot);
@@ -567,38 +645,34 @@ struct Cons {
         P_.s1 = __half2float(__ushort_as_half(reinterpret_cast<const unsigned short*>(base + PA_S1)[lane >> 1]));
         slot_release(slot);
     }
-    __device__ __forceinline__ void fetch(unsigned pk, PassW& P_) {
-        int slot; const unsigned char* base = slot_wait(pk, PASS_WO, slot);
-        P_.q = reinterpret_cast<const uint4*>(base)[lane];
-        P_.s = __half2float(__ushort_as_half(reinterpret_cast<const unsigned short*>(base + PW_S0)[lane]));
-        slot_release(slot);
-    }
-    // this lane's share of the pass's row(s); fixed evaluation order
     static __device__ __forceinline__ float dot(const PassA& P_, const XA& xr) { return fmaf(P_.s1, half_dot(P_.q1, xr.xh, xr.m8h), P_.s0 * block_dot(P_.q0, xr.x, xr.m8)); }
-    static __device__ __forceinline__ float dot(const PassW& P_, const XA& xr) { return P_.s * block_dot(P_.q, xr.x, xr.m8); }
 
-    // This wave's share of an all-gather (after the COMM wave's probe has resolved): granules [256 cw, +256) of the vector -> swizzled LDS staging, waves 0..3 also the
-    // 256 per-CU partial sums of squares; then (every wave, same fixed order on every CU) the RMSNorm scale.
-    __device__ __forceinline__ float all_gather(const u64* src, const u64* ssq, unsigned tag, unsigned stage, float* xs, float* ssl, const Tl& tl, bool T) {
+    // This wave's share of an all-gather (after the COMM wave's probe has resolved): 4 consecutive granules per lane (elements [4 q, +4), q = 64 * region + lane; the
+    // region is rotated by CU so that the 256 CUs do not walk the 24 KB in the same order), waves 0..3 also the 256 per-CU partial sums of squares.
+    // DIGITS: the vector goes to LDS as digit planes (MFMA operators); otherwise as swizzled f32 chunks (lm_head).  Returns the RMSNorm scale (same fixed order everywhere).
+    template <bool DIGITS>
+    __device__ __forceinline__ float all_gather(const u64* src, const u64* ssq, unsigned tag, unsigned stage, unsigned char* xs, float* ssl, float2* binfo, const Tl& tl, bool T) {
         wait_ge(&c->ag_flag, stage + 1u, c, p.err, ERR_STAGE);
         const srd_t sd = make_srd(src, ED * 8u), qd = make_srd(ssq, NCU * 8u);
         int ln = lane; asm volatile("" : "+v"(ln));
-        const unsigned k0 = 256u * (((unsigned)cw + blockIdx.x) % NCONS) + (unsigned)ln;      // rotated by CU: the 256 CUs do not walk the 24 KB in the same order
-        u64 raw[4], rq = 0, t0 = 0;
+        const unsigned q = 64u * (((unsigned)cw + blockIdx.x) % NCONS) + (unsigned)ln;
+        u32x4 ra, rb; u64 rq = 0, t0 = 0;
         for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (int u = 0; u < 4; u++) raw[u] = ld_gran(sd, k0 + 64u * u);
+            ra = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sd, (int)(q * 32u), 0, 16));
+            rb = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sd, (int)(q * 32u + 16u), 0, 16));
             if (cw < 4) rq = ld_gran(qd, 64u * (unsigned)cw + (unsigned)ln);
-#pragma unroll
-            for (int u = 0; u < 4; u++) ok &= (unsigned)(raw[u] >> 32) == tag;
+            bool ok = ra.y == tag && ra.w == tag && rb.y == tag && rb.w == tag;
             if (cw < 4) ok &= (unsigned)(rq >> 32) == tag;
             if (__all(ok)) break;
             if (sweep_bail(t0, tag, c, p.err)) break;
         }
         if (T) tl(22);
+        const float v[4] = {__uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rb.x), __uint_as_float(rb.z)};
+        if (DIGITS) to_digits(v, ln, xs + (q >> 3) * 128u, binfo + (q >> 3));
+        else {
 #pragma unroll
-        for (int u = 0; u < 4; u++) xs[sw_dword((int)(k0 + 64u * u))] = __uint_as_float((unsigned)raw[u]);
+            for (int i = 0; i < 4; i++) reinterpret_cast<float*>(xs)[sw_dword((int)(4u * q) + i)] = v[i];
+        }
         if (cw < 4) ssl[64 * cw + ln] = __uint_as_float((unsigned)rq);
         cbarrier();
         const float ss = wave_sum_e((ssl[ln] + ssl[ln + 64]) + (ssl[ln + 128] + ssl[ln + 192]));      // fixed order: bit-identical on every wave of every CU
@@ -606,34 +680,37 @@ struct Cons {
     }
 };
 
-// ONE rolled loop over the step's 3 L + 1 items (one copy of the pass body in the instruction cache): per layer [q|k|v -> attention -> wo], w1|w3, w2; then the
-// lm_head.  Passes are software-pipelined: the next pass's weights are requested from the ring (LDS) before the current pass is multiplied.
+// ONE rolled loop over the step's 3 L + 1 items: per layer [q|k|v -> attention -> wo], w1|w3, w2; then the lm_head.
 __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsigned char* lds, int cw, const int lane0, const Tl& tl) {
     Cons cs(p, c, lds, cw, lane0);
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
-    float* xs = reinterpret_cast<float*>(lds + L_XS); float* ssl = reinterpret_cast<float*>(lds + L_SSQ);
-    const float* xa = reinterpret_cast<const float*>(lds + L_XA); float* xo = reinterpret_cast<float*>(lds + L_XO);
+    unsigned char* xs = lds + L_XS; float* ssl = reinterpret_cast<float*>(lds + L_SSQ);
+    float2* binfo = reinterpret_cast<float2*>(lds + L_BLK);
+    const float* xa = reinterpret_cast<const float*>(lds + L_XA); unsigned char* xo = lds + L_XO;
+    float* part = reinterpret_cast<float*>(lds + L_PART);
     const float* qkvn = reinterpret_cast<const float*>(lds + L_QKVN);
     float* sc = reinterpret_cast<float*>(lds + L_SC); float2* po = reinterpret_cast<float2*>(lds + L_PO); float* pl = reinterpret_cast<float*>(lds + L_PL);
     const unsigned tag_base = (*p.serial + 1u) * 64u;
     const int pos = *p.pos_ptr + p.pos_off;
     const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0, n_old = pos - j_lo, last_old = max(n_old - 1, 0);
-    // RoPE factor of this wave's q|k|v pair (the same rows in every layer): waves 0..7 a q pair, 8 / 9 a k pair, 10 / 11 a v pair (no rotation)
+    // q|k|v epilogue (wave 0, lane r < 24 = the CU's row r: 16 of q, 4 of k, 4 of v): the RoPE factor of the row's pair -- the same in every layer
     const int half = EHD / 2;
-    const int pr = cw < 8 ? 8 * s + cw : 2 * j + (cw - 8);
-    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };      // wave-uniform values live in SGPRs
-    const float rc = cw < 10 ? uni(p.rope_cos[(size_t)pos * half + pr]) : 1.0f, rs = cw < 10 ? uni(p.rope_sin[(size_t)pos * half + pr]) : 0.0f;
+    if (cw == 0 && lane0 < 24) {
+        float rc = 1.0f, rs = 0.0f;
+        if (lane0 < 20) { const int pr = lane0 < 16 ? 8 * s + (lane0 >> 1) : 2 * j + ((lane0 - 16) >> 1); rc = p.rope_cos[(size_t)pos * half + pr]; rs = p.rope_sin[(size_t)pos * half + pr]; }
+        c->rope_c[lane0] = rc; c->rope_s[lane0] = rs;
+    }
     const float scale = 1.0f / sqrtf((float)EHD);
     const int n_items = 3 * p.n_layers, npass_lm = lm_passes(p.vocab), row0_lm = lm_rows_per_cu(p.vocab) * b;
-    if (cw == NCONS - 1) {      // norm weights (* Ada scale) * 512 of this CU's 12 rows for every layer -> LDS, once per launch, while everybody waits for the first all-gather
+    if (cw == NCONS - 1) {      // norm weights (* Ada scale) of this CU's 12 rows for every layer -> LDS, once per launch, while everybody waits for the first all-gather
         const EngLayerTab* tab = reinterpret_cast<const EngLayerTab*>(lds + L_TAB);
         float* gwt = reinterpret_cast<float*>(lds + L_GW);
         for (int i = lane0; i <= p.n_layers * OWN + OWN - 1; i += 64) {
             const int l = i / OWN, r = i - l * OWN; const unsigned k = (unsigned)(OWN * b + r);
             if (l < p.n_layers) {
-                gwt[(l * 2) * 16 + r] = as_g(tab[l].attn_norm)[k] * 512.0f;
-                gwt[(l * 2 + 1) * 16 + r] = as_g(tab[l].ffn_norm)[k] * as_g(tab[l].ada_mul)[k] * 512.0f;
-            } else gwt[(l * 2) * 16 + r] = as_g(p.final_norm)[k] * 512.0f;
+                gwt[(l * 2) * 16 + r] = as_g(tab[l].attn_norm)[k];
+                gwt[(l * 2 + 1) * 16 + r] = as_g(tab[l].ffn_norm)[k] * as_g(tab[l].ada_mul)[k];
+            } else gwt[(l * 2) * 16 + r] = as_g(p.final_norm)[k] * 512.0f;      // the lm_head's VALU path reads nibble bytes as e4m3 (q / 512)
         }
         // XCD-local edges (q|k|v -> attention, SwiGLU -> w2) go through the shared L2 only if the 32 workgroups of group g really sit on ONE XCD: workgroup b is
         // observed on XCD (b + rotation) % 8 (the dispatcher's round-robin carries over from the previous launch), so the ids are EXCHANGED and compared
@@ -658,21 +735,21 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per item: lane-derived addresses are recomputed, not carried around the loop in VGPRs
         const int l = it / 3, op = it == n_items ? (int)EOP_LM : (it - 3 * l == 0 ? (int)EOP_QKV : it - 3 * l == 1 ? (int)EOP_W13 : (int)EOP_W2);
         const bool T = l == p.tl_layer && cw == 0 && op != EOP_LM;
+        const int tlev = l == p.tl_layer ? 1 : 0;
         const unsigned tag = tag_base + (unsigned)l + 1u;
         const EngLayerTab* L = reinterpret_cast<const EngLayerTab*>(lds + L_TAB) + (op == EOP_LM ? 0 : l);
         if (op == EOP_QKV) {
             // ================= q|k|v  ->  attention of head h  ->  wo =================
             const gf_p kc = as_g(L->kc) + (size_t)g * p.max_seq * EHD, vc = as_g(L->vc) + (size_t)g * p.max_seq * EHD;
             const int t12 = cw * 64 + lane;
-            const int part = t12 & 7, ks = t12 >> 3;            // scores: 8 lanes per key, 96 keys per pass
-            const float rstd = cs.all_gather(p.H0, p.SS0, tag - 1u, 2u * (unsigned)l, xs, ssl, tl, false);
+            const int part_ = t12 & 7, ks = t12 >> 3;           // scores: 8 lanes per key, 96 keys per pass
+            const float rstd = cs.all_gather<true>(p.H0, p.SS0, tag - 1u, 2u * (unsigned)l, xs, ssl, binfo, tl, false);
             if (T) tl(0);
-            // the old K rows do not depend on this step: requested BEFORE the q|k|v passes, so they are home before the q|k|v edge is polled (a prefetch burst
-            // right behind the publish sat in front of this CU's own granule sweep: +3 us on the edge); the V rows are requested once the passes are done
-            constexpr int NKP = 2;      // 192 keys in registers (32 VGPRs): 96 requested here, 96 behind the passes (the activation registers are dead by then); later keys take the loop below
+            // the old K rows do not depend on this step: requested BEFORE the q|k|v steps, so they are home before the q|k|v edge is polled
+            constexpr int NKP = 2;      // 192 keys in registers (32 VGPRs): 96 requested here, 96 behind the q|k|v steps; later keys take the loop below
             float4 kpre[NKP][4];
-            auto kload = [&](int u) {      // only keys that exist: at position 100 the clamped form moved 150 KB per CU where 100 KB are rows -- in front of the COMM wave's polls
-                const unsigned ko = (unsigned)(j_lo + min(ks + 96 * u, last_old)) * EHD + part * 16;      // 32-bit lane offset + uniform base: one VGPR per address
+            auto kload = [&](int u) {      // only keys that exist
+                const unsigned ko = (unsigned)(j_lo + min(ks + 96 * u, last_old)) * EHD + part_ * 16;      // 32-bit lane offset + uniform base: one VGPR per address
 #pragma unroll
                 for (int e = 0; e < 4; e++) kpre[u][e] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ks + 96 * u < n_old) {
@@ -681,23 +758,43 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 }
             };
             kload(0);
-            {
-                XA xr; xr.load(xs, lane, 64 + (lane >> 1), lane & 1);
-                PassA Pa;
-                cs.fetch(cs.P, Pa);
-                const float a = wave_sum_e(Cons::dot(Pa, xr)) * rstd;      // the pair's two rows
-                cs.fetch(cs.P + 1, Pa);
-                const float bq = wave_sum_e(Cons::dot(Pa, xr)) * rstd;
-                const int n = cw < 8 ? 128 * h + 16 * s + 2 * cw : cw < 10 ? EQD + 128 * g + 4 * j + 2 * (cw - 8) : EQD + EKD + 128 * g + 4 * j + 2 * (cw - 10);
-                const float ra = a * rc - bq * rs, rb = a * rs + bq * rc;        // interleaved-pair RoPE (rope.rs:99-141); identity for v
-                if (lane < 2) {
-                    const float v = lane ? rb : ra;
-                    publish_b(p.G, (EQD + 2 * EKD) * 8u, (unsigned)(n + lane), tag, v, xloc);
-                    if (cw >= 8) (cw < 10 ? kc : vc)[(size_t)pos * EHD + (n & 127) + lane] = v;      // k / v rows also go to the cache (read by later steps)
-                }
+            {   // 24 rows x K 3072: this wave's K-steps 4 cw .. 4 cw + 3 of the 16-row q tile and the 8-row k|v tile
+                StepCtx cx[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) cx[i] = load_ctx(xs, binfo, 2 * (4 * cw + i), lane);
+                int s0, s1, s2;
+                const unsigned char* b0 = cs.slot_wait(cs.P, 2 * REC, s0);
+                const unsigned char* b1 = cs.slot_wait(cs.P + 1, 2 * REC, s1);
+                float a0 = mstep(b0, false, lane, cx[0], 0.f); a0 = mstep(b0 + REC, false, lane, cx[1], a0);
+                a0 = mstep(b1, false, lane, cx[2], a0); a0 = mstep(b1 + REC, false, lane, cx[3], a0);
+                cs.slot_release(s0); cs.slot_release(s1);
+                const unsigned char* b2 = cs.slot_wait(cs.P + 2, 4 * REC_H, s2);
+                float a1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) a1 = mstep(b2 + i * REC_H, true, lane, cx[i], a1);
+                cs.slot_release(s2);
                 cs.P += QKV_PK;
-                cs.published(tl, l == p.tl_layer ? 28 : -1);
+                a0 = g01_sum(a0, lane); a1 = g01_sum(a1, lane);
+                if (lane < 16) part[lane * NCONS + cw] = a0;
+                if (lane < 8) part[(16 + lane) * NCONS + cw] = a1;
             }
+            cs.cbarrier();
+            if (cw == 0) {      // rows 0..15: q, 16..19: k, 20..23: v -- sum the 12 K-slices (fixed order), RMSNorm scale, RoPE on (even, odd) row pairs, publish
+                const int r = min(lane, 23);
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < NCONS; w++) a += part[r * NCONS + w];
+                a *= rstd;
+                const float rc = c->rope_c[r], rs = c->rope_s[r];
+                const float o = dppf<0xB1>(a);                                   // the pair's other row
+                const float y = (lane & 1) ? fmaf(o, rs, a * rc) : fmaf(-o, rs, a * rc);      // interleaved-pair RoPE (rope.rs:99-141); identity (rc 1, rs 0) for v
+                if (lane < 24) {
+                    const int n = lane < 16 ? 128 * h + 16 * s + lane : lane < 20 ? EQD + 128 * g + 4 * j + (lane - 16) : EQD + EKD + 128 * g + 4 * j + (lane - 20);
+                    publish_b(p.G, (EQD + 2 * EKD) * 8u, (unsigned)n, tag, y, xloc);
+                    if (lane >= 16) (lane < 20 ? kc : vc)[(size_t)pos * EHD + (n & 127)] = y;      // k / v rows also go to the cache (read by later steps)
+                }
+            }
+            cs.published(tl, tlev ? 28 : -1);
             if (T) tl(1);
             kload(1);
             float2 vpre[16];      // P.V: wave = key group (keys cw + 12 u), lane = float2 column
@@ -714,7 +811,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             {
                 float qv[16];
 #pragma unroll
-                for (int e = 0; e < 4; e++) { const float4 v = *reinterpret_cast<const float4*>(qkvn + part * 16 + 4 * e); qv[4 * e] = v.x; qv[4 * e + 1] = v.y; qv[4 * e + 2] = v.z; qv[4 * e + 3] = v.w; }
+                for (int e = 0; e < 4; e++) { const float4 v = *reinterpret_cast<const float4*>(qkvn + part_ * 16 + 4 * e); qv[4 * e] = v.x; qv[4 * e + 1] = v.y; qv[4 * e + 2] = v.z; qv[4 * e + 3] = v.w; }
                 auto dot16 = [&](const float4 (&kk)[4]) {
                     float sacc = 0.f;
 #pragma unroll
@@ -725,21 +822,21 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 for (int u = 0; u < NKP; u++) {
                     const float sv = dot16(kpre[u]);
                     const int i = ks + 96 * u;
-                    if (part == 0 && i < n_old) sc[i] = sv * scale;
+                    if (part_ == 0 && i < n_old) sc[i] = sv * scale;
                 }
                 for (int i0 = 96 * NKP; i0 < n_old; i0 += 96) {      // later keys
                     const int i = i0 + ks;
                     float4 kk[4];
-                    const unsigned ko = (unsigned)(j_lo + min(i, last_old)) * EHD + part * 16;
+                    const unsigned ko = (unsigned)(j_lo + min(i, last_old)) * EHD + part_ * 16;
 #pragma unroll
                     for (int e = 0; e < 4; e++) kk[e] = ldg4(kc + (ko + 4 * e));
                     const float sv = dot16(kk);
-                    if (part == 0 && i < n_old) sc[i] = sv * scale;
+                    if (part_ == 0 && i < n_old) sc[i] = sv * scale;
                 }
                 if (cw == 0) {                                       // the new key (this step's k row)
                     float4 kk[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) kk[e] = *reinterpret_cast<const float4*>(qkvn + 128 + part * 16 + 4 * e);
+                    for (int e = 0; e < 4; e++) kk[e] = *reinterpret_cast<const float4*>(qkvn + 128 + part_ * 16 + 4 * e);
                     const float sv = dot16(kk);
                     if (t12 == 0) sc[n_old] = sv * scale;
                 }
@@ -772,81 +869,137 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 if (lane == 0) pl[cw] = lsum;
             }
             cs.cbarrier();
-            if (t12 < EHD) {
+            if (t12 < EHD) {      // head h's attention output (f32) -> the score area (dead since the barrier above)
                 const float* pof = reinterpret_cast<const float*>(po);
                 float so = 0.f, sl = 0.f;
 #pragma unroll
                 for (int q = 0; q < 12; q++) { so += pof[q * 128 + t12]; sl += pl[q]; }      // fixed order
-                xo[sw_dword(t12)] = so * (1.0f / sl) * 512.0f;
+                sc[t12] = so * (1.0f / sl);
+            }
+            cs.cbarrier();
+            if (cw == 0 && lane < 32) {      // -> digit planes (4 blocks)
+                const float4 v4 = *reinterpret_cast<const float4*>(sc + 4 * lane);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                to_digits(v, lane, xo + (lane >> 3) * 128, binfo + 96 + (lane >> 3));
             }
             cs.cbarrier();
             if (T) tl(3);
-            {   // ---------------- wo: rows [384 s, +384) x head h's 128 columns ----------------
-                XA xr; xr.load_chunk(xo, lane & 3);
-                PassW Qa, Qb;
-                cs.fetch(cs.P, Qa);
-#pragma unroll 1
-                for (int t = 0; t < WO_PK; t++) {
-                    if (t + 1 < WO_PK) cs.fetch(cs.P + t + 1, Qb);
-                    float acc = Cons::dot(Qa, xr);
-                    acc += dppf<0xB1>(acc); acc += dppf<0x4E>(acc);
-                    if ((lane & 3) == 0) publish_b(p.PW, NPW * ED * 8u, (unsigned)(h * ED + 384 * s + 16 * (cw + NCONS * t) + (lane >> 2)), tag, acc, false);
-                    Qa = Qb;
+            {   // ---------------- wo: rows [384 s, +384) x head h's 128 columns: this wave's tiles 2 cw, 2 cw + 1, two K-steps each ----------------
+                StepCtx cx[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) cx[i] = load_ctx(xo, binfo + 96, 2 * i, lane);
+#pragma unroll
+                for (int i = 0; i < WO_PK; i++) {
+                    int sl_; const unsigned char* bb = cs.slot_wait(cs.P + i, 2 * REC, sl_);
+                    float a = mstep(bb, false, lane, cx[0], 0.f); a = mstep(bb + REC, false, lane, cx[1], a);
+                    cs.slot_release(sl_);
+                    a = g01_sum(a, lane);
+                    if (lane < 16) publish_b(p.PW, NPW * ED * 8u, (unsigned)(h * ED + 384 * s + 16 * (2 * cw + i) + lane), tag, a, false);
                 }
                 cs.P += WO_PK;
-                cs.published(tl, l == p.tl_layer ? 29 : -1);
+                cs.published(tl, tlev ? 29 : -1);
             }
             if (T) tl(4);
             continue;
         }
-        // ================= the other A-type operators: w1|w3, w2, lm_head (one copy of the pass loop) =================
-        int n_pass; float rstd;
-        XA xr;
-        const int ts = cw % 3, rg = cw / 3;
+        if (op == EOP_W13) {
+            // ================= w1|w3: 72 rows (36 SwiGLU outputs) x K 3072: this wave's K-steps of 4 full tiles + the 8-row tile =================
+            const float rstd = cs.all_gather<true>(p.H1, p.SS1, tag, 2u * (unsigned)l + 1u, xs, ssl, binfo, tl, T);
+            if (T) tl(5);
+            StepCtx cx[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) cx[i] = load_ctx(xs, binfo, 2 * (4 * cw + i), lane);
+            if (T) tl(24);
+#pragma unroll 1
+            for (int ti = 0; ti < 4; ti++) {
+                int s0, s1;
+                const unsigned char* b0 = cs.slot_wait(cs.P + 2 * ti, 2 * REC, s0);
+                const unsigned char* b1 = cs.slot_wait(cs.P + 2 * ti + 1, 2 * REC, s1);
+                float a = mstep(b0, false, lane, cx[0], 0.f); a = mstep(b0 + REC, false, lane, cx[1], a);
+                a = mstep(b1, false, lane, cx[2], a); a = mstep(b1 + REC, false, lane, cx[3], a);
+                cs.slot_release(s0); cs.slot_release(s1);
+                a = g01_sum(a, lane);
+                if (lane < 16) part[(16 * ti + lane) * NCONS + cw] = a;
+            }
+            {
+                int s2; const unsigned char* b2 = cs.slot_wait(cs.P + 8, 4 * REC_H, s2);
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) a = mstep(b2 + i * REC_H, true, lane, cx[i], a);
+                cs.slot_release(s2);
+                a = g01_sum(a, lane);
+                if (lane < 8) part[(64 + lane) * NCONS + cw] = a;
+            }
+            cs.P += W13_PK;
+            cs.cbarrier();
+            if (cw < 2) {      // rows 2 i (gate), 2 i + 1 (up): sum the 12 K-slices (fixed order), RMSNorm scale, SwiGLU, publish to the XCD group
+                const int r = min(64 * cw + lane, 71);
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < NCONS; w++) a += part[r * NCONS + w];
+                a *= rstd;
+                const float up = dppf<0xB1>(a);
+                if ((lane & 1) == 0 && 64 * cw + lane < 72) publish_b(p.A, EF * 8u, (unsigned)(1152 * g + 36 * j + (r >> 1)), tag, silu_e(a) * up, xloc);
+            }
+            cs.published(tl, tlev ? 30 : -1);
+            if (T) tl(6);
+            continue;
+        }
         if (op == EOP_W2) {
+            // ================= w2: rows [96 j, +96) x the XCD group's 1152 columns: this wave's 3 K-steps (of 18) of 3 tiles (of 6) =================
             wait_ge(&c->xa_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
             if (T) tl(7);
-            const int t8 = lane & 7;
-            xr.load(xa, 12 * ts + t8, 12 * ts + 8 + (t8 >> 1), t8 & 1);
-            n_pass = W2_PK; rstd = 1.0f;
-        } else {
-            if (op == EOP_W13) { rstd = cs.all_gather(p.H1, p.SS1, tag, 2u * (unsigned)l + 1u, xs, ssl, tl, T); n_pass = W13_PK; }
-            else { rstd = cs.all_gather(p.H0, p.SS0, tag_base + (unsigned)p.n_layers, 2u * (unsigned)p.n_layers, xs, ssl, tl, false); n_pass = lm_packets(p.vocab); }
-            if (T) tl(5);
-            xr.load(xs, lane, 64 + (lane >> 1), lane & 1);
+            if (cw * 64 + lane < 288) {      // 36 blocks x 8 lanes: f32 -> digit planes
+                const int t = cw * 64 + lane;
+                const float4 v4 = *reinterpret_cast<const float4*>(xa + 4 * t);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                to_digits(v, lane, xs + (t >> 3) * 128, binfo + (t >> 3));
+            }
+            cs.cbarrier();
+            const int ksl = cw % 6, tg = cw / 6;
+            StepCtx cx[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) cx[i] = load_ctx(xs, binfo, 2 * (3 * ksl + i), lane);
+#pragma unroll 1
+            for (int i = 0; i < W2_PK; i++) {
+                int sl_; const unsigned char* bb = cs.slot_wait(cs.P + i, 3 * REC, sl_);
+                float a = mstep(bb, false, lane, cx[0], 0.f); a = mstep(bb + REC, false, lane, cx[1], a); a = mstep(bb + 2 * REC, false, lane, cx[2], a);
+                cs.slot_release(sl_);
+                a = g01_sum(a, lane);
+                if (lane < 16) part[(16 * (3 * tg + i) + lane) * 6 + ksl] = a;
+            }
+            cs.P += W2_PK;
+            cs.cbarrier();
+            if (cw < 2) {
+                const int r = min(64 * cw + lane, 95);
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 6; w++) a += part[r * 6 + w];      // fixed order
+                if (64 * cw + lane < 96) publish_b(p.P2, NP2 * ED * 8u, (unsigned)(g * ED + 96 * j + r), tag, a, false);
+            }
+            cs.published(tl, tlev ? 31 : -1);
+            if (T) tl(14);
+            continue;
         }
-        const bool TP = T && op == EOP_W13;
+        // ================= lm_head (VALU path: one row per wave per packet) =================
+        const float rstd = cs.all_gather<false>(p.H0, p.SS0, tag_base + (unsigned)p.n_layers, 2u * (unsigned)p.n_layers, xs, ssl, binfo, tl, false);
+        XA xr; xr.load(reinterpret_cast<const float*>(xs), lane, 64 + (lane >> 1), lane & 1);
+        const int n_pass = lm_packets(p.vocab);
         PassA Qa, Qb;
-        if (TP) tl(24);
         cs.fetch(cs.P, Qa);
-        if (TP) tl(25);
-        float gate = 0.f;
 #pragma unroll 1
         for (int t = 0; t < n_pass; t++) {
             const int q = cw + NCONS * t;                              // this wave's pass of packet t
             if (t + 1 < n_pass) cs.fetch(cs.P + t + 1, Qb);
-            if (op != EOP_LM || q < npass_lm) {
-                float acc = Cons::dot(Qa, xr);
-                if (op == EOP_W2) {
-                    acc = group8_sum_e(acc);
-                    if ((lane & 7) == 0) publish_b(p.P2, NP2 * ED * 8u, (unsigned)((3 * g + ts) * ED + 96 * j + 32 * t + 8 * rg + (lane >> 3)), tag, acc, false);
-                } else {
-                    const float r = wave_sum_e(acc) * rstd;
-                    if (op == EOP_W13) {
-                        if ((t & 1) == 0) gate = r;
-                        else if (lane == 0) publish_b(p.A, EF * 8u, (unsigned)(1152 * g + 36 * j + cw + NCONS * (t >> 1)), tag, silu_e(gate) * r, xloc);
-                    } else {
-                        const int n = row0_lm + q;
-                        if (p.logits_out && lane == 0) p.logits_out[n] = r;
-                        if (r > best || (r == best && n < best_i)) { best = r; best_i = n; }
-                    }
-                }
+            if (q < npass_lm) {
+                const float r = wave_sum_e(Cons::dot(Qa, xr)) * rstd;
+                const int n = row0_lm + q;
+                if (p.logits_out && lane == 0) p.logits_out[n] = r;
+                if (r > best || (r == best && n < best_i)) { best = r; best_i = n; }
             }
             Qa = Qb;
         }
         cs.P += (unsigned)n_pass;
-        if (op != EOP_LM) cs.published(tl, l == p.tl_layer ? (op == EOP_W13 ? 30 : 31) : -1);
-        if (T) tl(op == EOP_W13 ? 6 : 14);
     }
     // ---------------- argmax partial of this CU ----------------
     if (lane0 == 0) { c->best_val[cw] = best; c->best_idx[cw] = best_i; }
@@ -906,18 +1059,18 @@ void eng_state_carve(unsigned char* st, EngParams* p) {
 
 hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsigned char* stream, int vocab, hipStream_t s) {
     if (w.fmt != WFMT_Q4_0 || !w.qs || !w.sc) return hipErrorInvalidValue;
-    int passes, off_bytes, N, K;
+    int off_bytes, N, K;
     switch (op) {
-    case EOP_QKV: passes = QKV_PK * NCONS; off_bytes = OFF_QKV; N = EQD + 2 * EKD; K = ED; break;
-    case EOP_WO: passes = WO_PK * NCONS; off_bytes = OFF_WO; N = ED; K = EQD; break;
-    case EOP_W13: passes = W13_PK * NCONS; off_bytes = OFF_W13; N = 2 * EF; K = ED; break;
-    case EOP_W2: passes = W2_PK * NCONS; off_bytes = OFF_W2; N = ED; K = EF; break;
-    case EOP_LM: passes = lm_passes(vocab); off_bytes = 0; N = vocab; K = ED; break;
+    case EOP_QKV: off_bytes = OFF_QKV; N = EQD + 2 * EKD; K = ED; break;
+    case EOP_WO: off_bytes = OFF_WO; N = ED; K = EQD; break;
+    case EOP_W13: off_bytes = OFF_W13; N = 2 * EF; K = ED; break;
+    case EOP_W2: off_bytes = OFF_W2; N = ED; K = EF; break;
+    case EOP_LM: off_bytes = 0; N = vocab; K = ED; break;
     default: return hipErrorInvalidValue;
     }
     if (w.N != N || w.K != K) return hipErrorInvalidValue;
-    const size_t op_off = op == EOP_LM ? (size_t)n_layers * LAYER_BYTES : (size_t)layer * LAYER_BYTES + off_bytes;
-    eng_pack_kernel<<<dim3(passes, NCU), dim3(64), 0, s>>>(w, op, stream, cu_stream_bytes(n_layers, vocab), op_off, vocab);
+    if (op == EOP_LM) eng_pack_lm_kernel<<<dim3(lm_passes(vocab), NCU), dim3(64), 0, s>>>(w, stream, (size_t)n_layers * LAYER_BYTES, vocab);
+    else eng_pack_kernel<<<dim3(op_packets(op) * NCONS * 4, NCU), dim3(64), 0, s>>>(w, op, stream, (size_t)layer * LAYER_BYTES + off_bytes);
     return hipGetLastError();
 }
 
