@@ -639,7 +639,8 @@ struct vox_model {
     // persistent decode-step engine (vox_engine.hip): one launch per token for the real decoder geometry; eng_ok = eligible, eng_ready = stream packed + state allocated
     bool eng_ok = false, eng_on = true, eng_ready = false; unsigned char* eng_stream = nullptr; unsigned char* eng_state = nullptr; EngLayerTab* eng_tab = nullptr;
     const vox_cache* eng_tab_cache = nullptr; const float* eng_tab_k = nullptr; std::vector<EngLayerTab> eng_tab_host;      // (cache object, its K base) the device layer table was built for
-    int eng_flags = 128, eng_pace = 0; unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
+    int eng_flags = 128 | 512, eng_pace = 50;      // XCD-local edges; probe-less all-gather, swept 0.5 us after the CU's own rows went out
+    unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0;
     const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
@@ -1068,7 +1069,8 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
         for (int i = 0; ok && i < c.dec_layers; i++) { const DecLayer& L = m->dec[i]; for (const Lin* w : {&L.wqkv, &L.wo, &L.w13, &L.w2}) if (w->w.fmt != WFMT_Q4_0 || !w->w.qs || !w->w.sc || w->bias) ok = false; }
         if (ok && (m->tok.w.fmt != WFMT_Q4_0 || !m->tok.w.qs)) ok = false;
         m->eng_ok = ok; m->eng_on = ok;
-        if (const char* f = knob_str("VOX_ENGINE_FLAGS")) m->eng_flags = atoi(f);      // measurement knobs of tools/micro/engine_bench (thin / probe / XCD-local edges)
+        if (const char* f = knob_str("VOX_ENGINE_FLAGS")) m->eng_flags = atoi(f);      // measurement knobs of tools/micro/engine_bench (loader depth / probe / XCD-local edges)
+        if (const char* f = knob_str("VOX_ENGINE_PACE")) m->eng_pace = atoi(f);
     }
     *out = m; return VOX_OK;
 }
@@ -1500,7 +1502,7 @@ static EngParams engine_params(vox_model* m, float* logits_out) {
     EngParams ep{}; ep.stream = m->eng_stream; ep.cu_stride = eng_stream_bytes(c.dec_layers, c.vocab) / 256; ep.layers = m->eng_tab; ep.n_layers = c.dec_layers; ep.h_in = m->d_h; ep.final_norm = m->dec_norm;
     ep.pos_ptr = m->d_pos; ep.pos_off = 0; ep.rope_cos = m->dec_cos; ep.rope_sin = m->dec_sin; ep.max_seq = m->cache->max_seq; ep.window = c.dec_window; ep.eps = c.norm_eps;
     eng_state_carve(m->eng_state, &ep); ep.part_val = m->d_part_val; ep.part_idx = m->d_part_idx; ep.logits_out = logits_out; ep.vocab = c.vocab; ep.tl = nullptr; ep.tl_layer = -1;
-    ep.flags = m->eng_flags; ep.pace_ticks = m->eng_pace;
+    ep.flags = m->eng_flags; ep.pace_ticks = (m->eng_flags & 512) ? 0 : m->eng_pace; ep.ag_delay_ticks = (m->eng_flags & 512) ? m->eng_pace : 0;
     return ep;
 }
 

@@ -261,6 +261,7 @@ struct Loader {
     EngCtl* c; unsigned* err; unsigned ring_lds; unsigned voff;
     int nfl = 0, s0 = 0, l0 = 0, s1 = 0, l1 = 0;    // packets issued, not yet published: (s0, l0) oldest, (s1, l1) newer -- plain scalars (an indexed array would live in scratch = VMEM)
     unsigned P = 0;                                   // next packet index
+    int depth = 3;                                    // packets in flight (measurement knob: flags 1024 -> 2, 2048 -> 1)
     bool thin; u64 pace = 0, t_last = 0, pause_ticks = 0;              // pace: minimum s_memrealtime ticks between two packet issues (0: none)
     __device__ __forceinline__ void publish_slot(int slot) { lds_st(&c->ring_ready[slot], lds_ld(&c->ring_ready[slot]) + 1u); }   // only this wave writes ring_ready
     __device__ __forceinline__ void flush() {
@@ -289,8 +290,10 @@ struct Loader {
         }
         P++;
         if (nfl == 2) { wait_vmcnt(l1 + lines); publish_slot(s0); s0 = s1; l0 = l1; s1 = slot; l1 = lines; }      // three in flight: retire the oldest
-        else if (nfl == 1) { s1 = slot; l1 = lines; nfl = 2; }
-        else { s0 = slot; l0 = lines; nfl = 1; }
+        else if (nfl == 1) {
+            if (depth <= 2) { wait_vmcnt(lines); publish_slot(s0); s0 = slot; l0 = lines; }      // depth 2: retire the older one right away
+            else { s1 = slot; l1 = lines; nfl = 2; }
+        } else { s0 = slot; l0 = lines; nfl = 1; if (depth <= 1) { wait_vmcnt(0); publish_slot(s0); nfl = 0; } }
     }
 };
 
@@ -301,6 +304,8 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
     const bool fake = (p.flags & 2) != 0;      // diagnostic: every packet re-reads one packet (L2 hits, no HBM traffic; results wrong)
     const bool nodma = (p.flags & 32) != 0;    // diagnostic: no LDS-DMA at all inside the layers (results wrong)
     if (p.flags & 64) ld.pause_ticks = 300;
+    if (p.flags & 1024) ld.depth = 2;
+    if (p.flags & 2048) ld.depth = 1;
     const u64 base = (u64)p.stream;
     const unsigned n_layer_pk = (unsigned)p.n_layers * PK_LAYER, n_pk = n_layer_pk + (unsigned)lm_packets(p.vocab);
     unsigned l = 0, r = 0;                       // layer, packet within the layer
@@ -311,7 +316,7 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
         if (pk < n_layer_pk) {
             if (r < PK_LAYER_M) bytes = PK_M;
             if (r == 0 && (int)l == p.tl_layer) tl(16);
-        } else { ld.pace = 0; ld.pause_ticks = 0; }      // no edge left to protect: the lm_head streams at full depth
+        } else { ld.pace = 0; ld.pause_ticks = 0; ld.depth = 3; }      // no edge left to protect: the lm_head streams at full depth
         ld.issue(fake ? base + (u64)blockIdx.x * PK_A : base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes, bytes, lane, nodma);
         off += (u64)bytes;
         if (++r == PK_LAYER) { if ((int)l == p.tl_layer) tl(17); r = 0; l++; }
@@ -569,21 +574,28 @@ __device__ __forceinline__ StepCtx load_ctx(const unsigned char* planes, const f
     cx.m8sx = bi.x; cx.sxinv = bi.y;
     return cx;
 }
-// one MFMA step of a 16-row (or 8-row) tile: acc += (block scale) * (x block scale) * sum_k x_int[k] * (q[k] - 8) for this lane's block of tile row n
-__device__ __forceinline__ float mstep(const unsigned char* rec, bool half, int lane, const StepCtx& cx, float acc) {
+// one step record as this lane holds it: 8 bytes of nibbles + the f16 scale bits of its block.  Records do not depend on the step's activations, so a wave
+// moves them from the ring into REGISTERS while it waits for an edge (and frees the ring slots for the loader: the register file is the bigger buffer)
+struct RecR { uint2 q; unsigned sb; };
+__device__ __forceinline__ RecR rec_read(const unsigned char* rec, bool half, int lane) {
     const int n = lane & 15, g = lane >> 4;
-    uint2 q = make_uint2(0u, 0u);
-    if (!half) q = reinterpret_cast<const uint2*>(rec)[lane];
-    else if (n < 8) q = reinterpret_cast<const uint2*>(rec)[g * 8 + n];
-    const unsigned short sb = reinterpret_cast<const unsigned short*>(rec + (half ? REC_H_SC : REC_SC))[(half ? 8 : 16) * (g & 1) + (half ? (n & 7) : n)];
-    i4v B; B[0] = (int)(q.x & 0x0F0F0F0Fu); B[1] = (int)(q.y & 0x0F0F0F0Fu); B[2] = (int)((q.x >> 4) & 0x0F0F0F0Fu); B[3] = (int)((q.y >> 4) & 0x0F0F0F0Fu);
+    RecR r; r.q = make_uint2(0u, 0u);
+    if (!half) r.q = reinterpret_cast<const uint2*>(rec)[lane];
+    else if (n < 8) r.q = reinterpret_cast<const uint2*>(rec)[g * 8 + n];
+    r.sb = reinterpret_cast<const unsigned short*>(rec + (half ? REC_H_SC : REC_SC))[(half ? 8 : 16) * (g & 1) + (half ? (n & 7) : n)];
+    return r;
+}
+// one MFMA step of a 16-row (or 8-row) tile: acc += (block scale) * (x block scale) * sum_k x_int[k] * (q[k] - 8) for this lane's block of tile row n
+__device__ __forceinline__ float mstep(const RecR& r, const StepCtx& cx, float acc) {
+    i4v B; B[0] = (int)(r.q.x & 0x0F0F0F0Fu); B[1] = (int)(r.q.y & 0x0F0F0F0Fu); B[2] = (int)((r.q.x >> 4) & 0x0F0F0F0Fu); B[3] = (int)((r.q.y >> 4) & 0x0F0F0F0Fu);
     const i4v D = __builtin_amdgcn_mfma_i32_16x16x64_i8(cx.A, B, i4v{0, 0, 0, 0}, 0, 0, 0);
     float t = fmaf((float)D[3], 128.0f, (float)D[2]);
     t = fmaf(t, 128.0f, (float)D[1]);
     t = fmaf(t, 128.0f, (float)D[0]);
     t += cx.m8sx;
-    return fmaf(t, __half2float(__ushort_as_half(sb)) * cx.sxinv, acc);
+    return fmaf(t, __half2float(__ushort_as_half((unsigned short)r.sb)) * cx.sxinv, acc);
 }
+__device__ __forceinline__ float mstep(const unsigned char* rec, bool half, int lane, const StepCtx& cx, float acc) { return mstep(rec_read(rec, half, lane), cx, acc); }
 __device__ __forceinline__ float g01_sum(float v, int lane) { return v + __shfl(v, (lane + 16) & 63); }      // block 0 + block 1 partial of tile row n (valid in lanes 0..15)
 template <int CTRL>
 __device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
@@ -743,6 +755,22 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             const gf_p kc = as_g(L->kc) + (size_t)g * p.max_seq * EHD, vc = as_g(L->vc) + (size_t)g * p.max_seq * EHD;
             const int t12 = cw * 64 + lane;
             const int part_ = t12 & 7, ks = t12 >> 3;           // scores: 8 lanes per key, 96 keys per pass
+            // this wave's 8 step records (K-steps 4 cw .. 4 cw + 3 of the 16-row q tile and of the 8-row k|v tile) -> registers, BEFORE the input vector exists
+            RecR rq[8];
+            {
+                int s0, s1, s2;
+                const unsigned char* b0 = cs.slot_wait(cs.P, 2 * REC, s0);
+                rq[0] = rec_read(b0, false, lane); rq[1] = rec_read(b0 + REC, false, lane);
+                cs.slot_release(s0);
+                const unsigned char* b1 = cs.slot_wait(cs.P + 1, 2 * REC, s1);
+                rq[2] = rec_read(b1, false, lane); rq[3] = rec_read(b1 + REC, false, lane);
+                cs.slot_release(s1);
+                const unsigned char* b2 = cs.slot_wait(cs.P + 2, 4 * REC_H, s2);
+#pragma unroll
+                for (int i = 0; i < 4; i++) rq[4 + i] = rec_read(b2 + i * REC_H, true, lane);
+                cs.slot_release(s2);
+                cs.P += QKV_PK;
+            }
             const float rstd = cs.all_gather<true>(p.H0, p.SS0, tag - 1u, 2u * (unsigned)l, xs, ssl, binfo, tl, false);
             if (T) tl(0);
             // the old K rows do not depend on this step: requested BEFORE the q|k|v steps, so they are home before the q|k|v edge is polled
@@ -758,22 +786,13 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 }
             };
             kload(0);
-            {   // 24 rows x K 3072: this wave's K-steps 4 cw .. 4 cw + 3 of the 16-row q tile and the 8-row k|v tile
-                StepCtx cx[4];
+            {
+                float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; i++) cx[i] = load_ctx(xs, binfo, 2 * (4 * cw + i), lane);
-                int s0, s1, s2;
-                const unsigned char* b0 = cs.slot_wait(cs.P, 2 * REC, s0);
-                const unsigned char* b1 = cs.slot_wait(cs.P + 1, 2 * REC, s1);
-                float a0 = mstep(b0, false, lane, cx[0], 0.f); a0 = mstep(b0 + REC, false, lane, cx[1], a0);
-                a0 = mstep(b1, false, lane, cx[2], a0); a0 = mstep(b1 + REC, false, lane, cx[3], a0);
-                cs.slot_release(s0); cs.slot_release(s1);
-                const unsigned char* b2 = cs.slot_wait(cs.P + 2, 4 * REC_H, s2);
-                float a1 = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; i++) a1 = mstep(b2 + i * REC_H, true, lane, cx[i], a1);
-                cs.slot_release(s2);
-                cs.P += QKV_PK;
+                for (int i = 0; i < 4; i++) {
+                    const StepCtx cx = load_ctx(xs, binfo, 2 * (4 * cw + i), lane);
+                    a0 = mstep(rq[i], cx, a0); a1 = mstep(rq[4 + i], cx, a1);
+                }
                 a0 = g01_sum(a0, lane); a1 = g01_sum(a1, lane);
                 if (lane < 16) part[lane * NCONS + cw] = a0;
                 if (lane < 8) part[(16 + lane) * NCONS + cw] = a1;
@@ -904,14 +923,34 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         }
         if (op == EOP_W13) {
             // ================= w1|w3: 72 rows (36 SwiGLU outputs) x K 3072: this wave's K-steps of 4 full tiles + the 8-row tile =================
+            constexpr int NPRE = 3;      // tiles whose records wait in registers (36 VGPRs) while the post-attention stream is still on its way; their ring slots refill meanwhile
+            RecR rw[4 * NPRE];
+#pragma unroll
+            for (int ti = 0; ti < NPRE; ti++) {
+                int s0, s1;
+                const unsigned char* b0 = cs.slot_wait(cs.P + 2 * ti, 2 * REC, s0);
+                rw[4 * ti] = rec_read(b0, false, lane); rw[4 * ti + 1] = rec_read(b0 + REC, false, lane);
+                cs.slot_release(s0);
+                const unsigned char* b1 = cs.slot_wait(cs.P + 2 * ti + 1, 2 * REC, s1);
+                rw[4 * ti + 2] = rec_read(b1, false, lane); rw[4 * ti + 3] = rec_read(b1 + REC, false, lane);
+                cs.slot_release(s1);
+            }
             const float rstd = cs.all_gather<true>(p.H1, p.SS1, tag, 2u * (unsigned)l + 1u, xs, ssl, binfo, tl, T);
             if (T) tl(5);
             StepCtx cx[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) cx[i] = load_ctx(xs, binfo, 2 * (4 * cw + i), lane);
             if (T) tl(24);
+#pragma unroll
+            for (int ti = 0; ti < NPRE; ti++) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) a = mstep(rw[4 * ti + i], cx[i], a);
+                a = g01_sum(a, lane);
+                if (lane < 16) part[(16 * ti + lane) * NCONS + cw] = a;
+            }
 #pragma unroll 1
-            for (int ti = 0; ti < 4; ti++) {
+            for (int ti = NPRE; ti < 4; ti++) {
                 int s0, s1;
                 const unsigned char* b0 = cs.slot_wait(cs.P + 2 * ti, 2 * REC, s0);
                 const unsigned char* b1 = cs.slot_wait(cs.P + 2 * ti + 1, 2 * REC, s1);
@@ -947,6 +986,14 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
         }
         if (op == EOP_W2) {
             // ================= w2: rows [96 j, +96) x the XCD group's 1152 columns: this wave's 3 K-steps (of 18) of 3 tiles (of 6) =================
+            RecR r2[9];      // this wave's 3 K-steps of its 3 tiles -> registers while the SwiGLU outputs of the XCD group are still being exchanged
+#pragma unroll
+            for (int i = 0; i < W2_PK; i++) {
+                int sl_; const unsigned char* bb = cs.slot_wait(cs.P + i, 3 * REC, sl_);
+#pragma unroll
+                for (int k = 0; k < 3; k++) r2[3 * i + k] = rec_read(bb + k * REC, false, lane);
+                cs.slot_release(sl_);
+            }
             wait_ge(&c->xa_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
             if (T) tl(7);
             if (cw * 64 + lane < 288) {      // 36 blocks x 8 lanes: f32 -> digit planes
@@ -960,11 +1007,9 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             StepCtx cx[3];
 #pragma unroll
             for (int i = 0; i < 3; i++) cx[i] = load_ctx(xs, binfo, 2 * (3 * ksl + i), lane);
-#pragma unroll 1
+#pragma unroll
             for (int i = 0; i < W2_PK; i++) {
-                int sl_; const unsigned char* bb = cs.slot_wait(cs.P + i, 3 * REC, sl_);
-                float a = mstep(bb, false, lane, cx[0], 0.f); a = mstep(bb + REC, false, lane, cx[1], a); a = mstep(bb + 2 * REC, false, lane, cx[2], a);
-                cs.slot_release(sl_);
+                float a = mstep(r2[3 * i], cx[0], 0.f); a = mstep(r2[3 * i + 1], cx[1], a); a = mstep(r2[3 * i + 2], cx[2], a);
                 a = g01_sum(a, lane);
                 if (lane < 16) part[(16 * (3 * tg + i) + lane) * 6 + ksl] = a;
             }
