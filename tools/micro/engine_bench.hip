@@ -121,6 +121,7 @@ static void report(const char* what, const std::vector<float>& ref, const std::v
 
 int main(int argc, char** argv) {
     const int n_layers = argc > 1 ? atoi(argv[1]) : 26, pos = argc > 2 ? atoi(argv[2]) : 100, reps = argc > 3 ? atoi(argv[3]) : 40, tl_layer = argc > 4 ? atoi(argv[4]) : -1, flags = argc > 5 ? atoi(argv[5]) : 0, pace = argc > 6 ? atoi(argv[6]) : 0;
+    const int lpace = argc > 8 ? atoi(argv[8]) : -1;      // explicit loader pace (10-ns ticks between packet issues) next to an all-gather delay
     const int max_seq = 256, window = 8192;
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     printf("flags %d pace %d; ", flags, pace); printf("device %s, %d CUs; n_layers %d pos %d reps %d; engine LDS %d bytes, stream %.1f MB\n", prop.name, prop.multiProcessorCount, n_layers, pos, reps, eng_lds_bytes(),
@@ -218,7 +219,7 @@ int main(int argc, char** argv) {
     unsigned long long* tlbuf = dalloc<unsigned long long>(256 * 32); CHK(hipMemset(tlbuf, 0, 256 * 32 * 8));
     EngParams ep{}; ep.stream = stream; ep.cu_stride = sbytes / 256; ep.layers = d_tab; ep.n_layers = n_layers; ep.h_in = h_in; ep.final_norm = final_norm; ep.pos_ptr = d_pos; ep.pos_off = 0;
     ep.rope_cos = rope_c; ep.rope_sin = rope_s; ep.max_seq = max_seq; ep.window = window; ep.eps = eps; eng_state_carve(state, &ep);
-    ep.part_val = pv2; ep.part_idx = pi2; ep.logits_out = logits_eng; ep.vocab = V; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = flags; ep.pace_ticks = (flags & 512) ? 0 : pace; ep.ag_delay_ticks = (flags & 512) ? pace : 0;
+    ep.part_val = pv2; ep.part_idx = pi2; ep.logits_out = logits_eng; ep.vocab = V; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = flags; ep.pace_ticks = lpace >= 0 ? lpace : (flags & 512) ? 0 : pace; ep.ag_delay_ticks = (flags & 512) ? pace : 0;
     CHK(hipStreamSynchronize(s));
     auto check_err = [&](const char* when) { unsigned e; CHK(hipMemcpy(&e, ep.err, 4, hipMemcpyDeviceToHost)); if (e) printf("ENGINE ERROR after %s: code %u, workgroup %u, tag bits %u\n", when, e & 0xff, (e >> 8) & 0xff, e >> 16); return e; };
     CHK(launch_decode_engine(ep, s));

@@ -589,9 +589,9 @@ __device__ __forceinline__ RecR rec_read(const unsigned char* rec, bool half, in
 __device__ __forceinline__ float mstep(const RecR& r, const StepCtx& cx, float acc) {
     i4v B; B[0] = (int)(r.q.x & 0x0F0F0F0Fu); B[1] = (int)(r.q.y & 0x0F0F0F0Fu); B[2] = (int)((r.q.x >> 4) & 0x0F0F0F0Fu); B[3] = (int)((r.q.y >> 4) & 0x0F0F0F0Fu);
     const i4v D = __builtin_amdgcn_mfma_i32_16x16x64_i8(cx.A, B, i4v{0, 0, 0, 0}, 0, 0, 0);
-    float t = fmaf((float)D[3], 128.0f, (float)D[2]);
-    t = fmaf(t, 128.0f, (float)D[1]);
-    t = fmaf(t, 128.0f, (float)D[0]);
+    // digits -> value: (D0 + 128 D1) and (D2 + 128 D3) exactly in int32 (v_lshl_add_u32; |D| <= 32 * 15 * 128), then one f32 FMA (one rounding, as before)
+    const int lo = (int)((unsigned)D[0] + ((unsigned)D[1] << 7)), hi = (int)((unsigned)D[2] + ((unsigned)D[3] << 7));
+    float t = fmaf((float)hi, 16384.0f, (float)lo);
     t += cx.m8sx;
     return fmaf(t, __half2float(__ushort_as_half((unsigned short)r.sb)) * cx.sxinv, acc);
 }
@@ -667,6 +667,28 @@ struct Cons {
         wait_ge(&c->ag_flag, stage + 1u, c, p.err, ERR_STAGE);
         const srd_t sd = make_srd(src, ED * 8u), qd = make_srd(ssq, NCU * 8u);
         int ln = lane; asm volatile("" : "+v"(ln));
+        if (DIGITS) {
+            // MFMA operators split K over the waves: wave cw multiplies columns [256 cw, +256) only -- it gathers exactly those 256 rows (4 per lane), turns them into
+            // ITS 8 blocks of digit planes and goes on; no workgroup barrier, nobody waits for the slowest wave's granules.  Waves 0..3 also stage the 256 partial
+            // sums of squares: the RMSNorm scale is applied where the K-slices are summed, behind the operator's own barrier.
+            const unsigned q = 64u * (unsigned)cw + (unsigned)ln;
+            u32x4 ra, rb; u64 rq = 0, t0 = 0;
+            for (;;) {
+                ra = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sd, (int)(q * 32u), 0, 16));
+                rb = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sd, (int)(q * 32u + 16u), 0, 16));
+                if (cw < 4) rq = ld_gran(qd, 64u * (unsigned)cw + (unsigned)ln);
+                bool ok = ra.y == tag && ra.w == tag && rb.y == tag && rb.w == tag;
+                if (cw < 4) ok &= (unsigned)(rq >> 32) == tag;
+                if (__all(ok)) break;
+                if (sweep_bail(t0, tag, c, p.err)) break;
+            }
+            if (T) tl(22);
+            const float v[4] = {__uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rb.x), __uint_as_float(rb.z)};
+            to_digits(v, ln, xs + (q >> 3) * 128u, binfo + (q >> 3));
+            if (cw < 4) ssl[64 * cw + ln] = __uint_as_float((unsigned)rq);      // read back (rstd_staged) by the waves that finish the operator, behind its cross-wave barrier
+            return 0.f;
+        }
+        // lm_head (VALU path): every wave needs the whole vector -- 4 consecutive granules per lane of a region rotated by CU, waves 0..3 the partial sums of squares
         const unsigned q = 64u * (((unsigned)cw + blockIdx.x) % NCONS) + (unsigned)ln;
         u32x4 ra, rb; u64 rq = 0, t0 = 0;
         for (;;) {
@@ -678,16 +700,15 @@ struct Cons {
             if (__all(ok)) break;
             if (sweep_bail(t0, tag, c, p.err)) break;
         }
-        if (T) tl(22);
         const float v[4] = {__uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rb.x), __uint_as_float(rb.z)};
-        if (DIGITS) to_digits(v, ln, xs + (q >> 3) * 128u, binfo + (q >> 3));
-        else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) reinterpret_cast<float*>(xs)[sw_dword((int)(4u * q) + i)] = v[i];
-        }
+        for (int i = 0; i < 4; i++) reinterpret_cast<float*>(xs)[sw_dword((int)(4u * q) + i)] = v[i];
         if (cw < 4) ssl[64 * cw + ln] = __uint_as_float((unsigned)rq);
         cbarrier();
-        const float ss = wave_sum_e((ssl[ln] + ssl[ln + 64]) + (ssl[ln + 128] + ssl[ln + 192]));      // fixed order: bit-identical on every wave of every CU
+        return rstd_staged(ssl);
+    }
+    __device__ __forceinline__ float rstd_staged(const float* ssl) {
+        const float ss = wave_sum_e((ssl[lane] + ssl[lane + 64]) + (ssl[lane + 128] + ssl[lane + 192]));      // fixed order: bit-identical on every wave of every CU
         return 1.0f / sqrtf(ss / (float)ED + p.eps);
     }
 };
@@ -771,7 +792,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 cs.slot_release(s2);
                 cs.P += QKV_PK;
             }
-            const float rstd = cs.all_gather<true>(p.H0, p.SS0, tag - 1u, 2u * (unsigned)l, xs, ssl, binfo, tl, false);
+            cs.all_gather<true>(p.H0, p.SS0, tag - 1u, 2u * (unsigned)l, xs, ssl, binfo, tl, false);
             if (T) tl(0);
             // the old K rows do not depend on this step: requested BEFORE the q|k|v steps, so they are home before the q|k|v edge is polled
             constexpr int NKP = 2;      // 192 keys in registers (32 VGPRs): 96 requested here, 96 behind the q|k|v steps; later keys take the loop below
@@ -803,7 +824,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 float a = 0.f;
 #pragma unroll
                 for (int w = 0; w < NCONS; w++) a += part[r * NCONS + w];
-                a *= rstd;
+                a *= cs.rstd_staged(ssl);
                 const float rc = c->rope_c[r], rs = c->rope_s[r];
                 const float o = dppf<0xB1>(a);                                   // the pair's other row
                 const float y = (lane & 1) ? fmaf(o, rs, a * rc) : fmaf(-o, rs, a * rc);      // interleaved-pair RoPE (rope.rs:99-141); identity (rc 1, rs 0) for v
@@ -888,17 +909,13 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 if (lane == 0) pl[cw] = lsum;
             }
             cs.cbarrier();
-            if (t12 < EHD) {      // head h's attention output (f32) -> the score area (dead since the barrier above)
-                const float* pof = reinterpret_cast<const float*>(po);
-                float so = 0.f, sl = 0.f;
+            if (cw == 0 && lane < 32) {      // head h's attention output: lane = 4 consecutive columns, summed over the 12 key groups (fixed order) -> digit planes (4 blocks)
+                const float4* po4 = reinterpret_cast<const float4*>(po);
+                float4 so = make_float4(0.f, 0.f, 0.f, 0.f); float sl = 0.f;
 #pragma unroll
-                for (int q = 0; q < 12; q++) { so += pof[q * 128 + t12]; sl += pl[q]; }      // fixed order
-                sc[t12] = so * (1.0f / sl);
-            }
-            cs.cbarrier();
-            if (cw == 0 && lane < 32) {      // -> digit planes (4 blocks)
-                const float4 v4 = *reinterpret_cast<const float4*>(sc + 4 * lane);
-                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                for (int q = 0; q < 12; q++) { const float4 a = po4[q * 32 + lane]; so.x += a.x; so.y += a.y; so.z += a.z; so.w += a.w; sl += pl[q]; }
+                const float inv = 1.0f / sl;
+                const float v[4] = {so.x * inv, so.y * inv, so.z * inv, so.w * inv};
                 to_digits(v, lane, xo + (lane >> 3) * 128, binfo + 96 + (lane >> 3));
             }
             cs.cbarrier();
@@ -935,7 +952,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 rw[4 * ti + 2] = rec_read(b1, false, lane); rw[4 * ti + 3] = rec_read(b1 + REC, false, lane);
                 cs.slot_release(s1);
             }
-            const float rstd = cs.all_gather<true>(p.H1, p.SS1, tag, 2u * (unsigned)l + 1u, xs, ssl, binfo, tl, T);
+            cs.all_gather<true>(p.H1, p.SS1, tag, 2u * (unsigned)l + 1u, xs, ssl, binfo, tl, T);
             if (T) tl(5);
             StepCtx cx[4];
 #pragma unroll
@@ -976,7 +993,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 float a = 0.f;
 #pragma unroll
                 for (int w = 0; w < NCONS; w++) a += part[r * NCONS + w];
-                a *= rstd;
+                a *= cs.rstd_staged(ssl);
                 const float up = dppf<0xB1>(a);
                 if ((lane & 1) == 0 && 64 * cw + lane < 72) publish_b(p.A, EF * 8u, (unsigned)(1152 * g + 36 * j + (r >> 1)), tag, silu_e(a) * up, xloc);
             }
