@@ -266,9 +266,9 @@ int main(int argc, char** argv) {
         const char* names[32] = {"cons: x(q|k|v) staged", "cons: q|k|v done", "cons: q,k,v gathered", "cons: attention done", "cons: wo done", "cons: x(w13) staged", "cons: w1|w3 done", "cons: x(w2) staged",
                                  "comm: h gathered+staged", "comm: q|k|v gathered", "comm: wo partials summed, h1 out", "comm: h1 gathered+staged", "comm: act gathered", "comm: w2 partials summed, h2 out",
                                  "cons: w2 done", "cons: lm_head done", "load: layer's first packet issued", "load: layer's last packet issued", "load: stream done", "kernel start",
-                                 "comm(h1 gather): start", "comm(h1 gather): probe ok", "comm(h1 gather): 52 granules in", "comm(h1 gather): staged",
-                                 "cons(w13): x in registers", "cons(w13): first fetch done", "(unused)", "(unused)", "cons: LAST wave published q|k|v", "cons: LAST wave published wo", "cons: LAST wave published w1|w3", "cons: LAST wave published w2"};
-        const int order[32] = {19, 16, 8, 0, 1, 28, 9, 2, 3, 4, 29, 10, 20, 21, 22, 23, 11, 5, 24, 25, 26, 27, 6, 30, 12, 7, 14, 31, 13, 17, 18, 15};
+                                 "comm(h1 gather): start", "comm(h1 gather): probe ok", "comm(h1 gather): 52 granules in", "cons(attn): P.V partials written",
+                                 "cons(w13): x in registers", "cons(attn): barrier 2 passed", "cons(attn): scores written", "cons(attn): barrier 1 passed", "cons: LAST wave published q|k|v", "cons: LAST wave published wo", "cons: LAST wave published w1|w3", "cons: LAST wave published w2"};
+        const int order[32] = {19, 16, 8, 0, 1, 28, 9, 2, 26, 27, 23, 25, 3, 4, 29, 10, 20, 21, 22, 11, 5, 24, 6, 30, 12, 7, 14, 31, 13, 17, 18, 15};
         printf("timeline of layer %d (us since the first workgroup started; min / median / max over the 256 CUs):\n", tl_layer);
         for (int oi = 0; oi < 32; oi++) {
             const int e = order[oi]; std::vector<double> v;

@@ -881,20 +881,22 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                     if (t12 == 0) sc[n_old] = sv * scale;
                 }
             }
+            if (T) tl(26);
             cs.cbarrier();
+            if (T) tl(27);
             {
                 const int n = n_old + 1;
                 float mx = -INFINITY;
                 for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[i]);
                 mx = wave_max_e(mx);
                 float2 o = make_float2(0.f, 0.f); float lsum = 0.f;
+                // this wave's keys cw + 12 u: lane u computes the key's weight ONCE (the 64 lanes used to repeat every exponential), the P.V loop reads it back lane by lane
+                const int iu = cw + 12 * (lane & 15);
+                const float pv = iu < n_old ? expf(sc[iu] - mx) : 0.f;
 #pragma unroll
                 for (int u = 0; u < 16; u++) {
-                    const int i = cw + 12 * u;
-                    if (i < n_old) {
-                        const float pr_ = expf(sc[i] - mx); const float2 vv = vpre[u];
-                        o.x = fmaf(pr_, vv.x, o.x); o.y = fmaf(pr_, vv.y, o.y); lsum += pr_;
-                    }
+                    const float pr_ = rlf(pv, u); const float2 vv = vpre[u];      // rows that do not exist: weight 0, value 0
+                    o.x = fmaf(pr_, vv.x, o.x); o.y = fmaf(pr_, vv.y, o.y); lsum += pr_;
                 }
                 for (int i = 192 + cw; i < n_old; i += 12) {
                     const fv2 v = *(const __attribute__((address_space(1))) fv2*)(vc + ((unsigned)(j_lo + i) * EHD + lane * 2));
@@ -908,7 +910,9 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 po[cw * 64 + lane] = o;
                 if (lane == 0) pl[cw] = lsum;
             }
+            if (T) tl(23);
             cs.cbarrier();
+            if (T) tl(25);
             if (cw == 0 && lane < 32) {      // head h's attention output: lane = 4 consecutive columns, summed over the 12 key groups (fixed order) -> digit planes (4 blocks)
                 const float4* po4 = reinterpret_cast<const float4*>(po);
                 float4 so = make_float4(0.f, 0.f, 0.f, 0.f); float sl = 0.f;
