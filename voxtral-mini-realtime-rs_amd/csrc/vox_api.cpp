@@ -541,14 +541,14 @@ extern "C" int32_t vox_q4_tensor_dequantize(vox_ctx* c, const vox_q4* q, float* 
 
 // out[rows][N] = x[rows][K] * W^T (+bias), device pointers.  rows <= 4 -> fused GEMV, else MFMA GEMM (op.rs:144-150)
 static int32_t q4_linear_dev(vox_ctx* c, const Q4W& w, const float* bias, const float* x, int x_stride, int rows, float* out, int out_stride,
-                             int epi = EPI_STORE, const float* resid = nullptr, int resid_stride = 0) {
+                             int epi = EPI_STORE, const float* resid = nullptr, int resid_stride = 0, int ksplit = 0) {
     if (rows <= 4) {
         GemvParams p{}; p.w = w; p.x = x; p.x_stride = x_stride; p.out = out; p.out_stride = out_stride; p.bias = bias;
         p.resid = resid; p.resid_stride = resid_stride;
         HIPCHK(launch_q4_gemv(p, rows, PRO_NONE, epi, q4_gemv_default_R(w.N, w.K, epi), c->stream));
     } else {
         GemmParams p{}; p.w = w; p.x = x; p.x_stride = x_stride; p.M = rows; p.out = out; p.out_stride = out_stride; p.bias = bias;
-        p.resid = resid; p.resid_stride = resid_stride;
+        p.resid = resid; p.resid_stride = resid_stride; p.ksplit = ksplit;
         if (rows > 16 && rows <= 48 && w.fmt == WFMT_Q4_0 && w.K <= 16384) {      // the prefill GEMMs: rows -> XF tiles once (launch_q4_skinny_mt)
             if (!c->xf_scratch) { c->xf_scratch_bytes = (size_t)3 * 16384 * 64; if (hipMalloc((void**)&c->xf_scratch, c->xf_scratch_bytes) != hipSuccess) { (void)hipGetLastError(); c->xf_scratch = nullptr; c->xf_scratch_bytes = 0; } }
             p.xf_scratch = c->xf_scratch; p.xf_scratch_bytes = c->xf_scratch_bytes;
@@ -1190,10 +1190,20 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     int Tmax = 0; for (int i = 0; i < n; i++) Tmax = std::max(Tmax, T[i]);
     (void)T1max;
     const size_t c1_floats = conv_scratch_floats(m, Tmax);
-    const size_t need = c1_floats + (size_t)Mtot * D * 2 + (size_t)Mtot * QD * 4 + (size_t)Mtot * F + (size_t)(M4 + 1) * m->ad0.w.N + 1024;
+    // w2 (N = D columns only, K = F: 40 K-steps per workgroup at 250 workgroups for one clip) as a split-K GEMM: four K slices -> four partial planes, summed (fixed
+    // order) by the NEXT RMSNorm together with the residual add.  Only while the unsplit grid leaves the chip underfilled; VOX_ENC_SPLITK=0 switches it off.
+    int ksp = 0;
+    {
+        const Q4W& w2 = m->enc[0].w2.w;
+        const long wgs = (long)((w2.N + 127) / 128) * ((Mtot + 31) / 32);
+        if (w2.fmt == WFMT_Q4_0 && w2.qt && w2.st && w2.nb % 16 == 0 && Mtot > 48 && wgs < 1024 && D % 4 == 0 && D <= 4096) ksp = 4;
+        if (const char* e = knob_str("VOX_ENC_SPLITK")) ksp = atoi(e) > 1 ? atoi(e) : 0;
+        for (int l = 0; ksp && l < c.enc_layers; l++) if (m->enc[l].w2.w.fmt != WFMT_Q4_0 || !m->enc[l].w2.w.qt || m->enc[l].w2.w.nb / 4 < ksp) ksp = 0;
+    }
+    const size_t need = c1_floats + (size_t)Mtot * D * 2 + (size_t)Mtot * QD * 4 + (size_t)Mtot * F + (size_t)(M4 + 1) * m->ad0.w.N + (size_t)ksp * Mtot * D + 1024;
     VOXCHK(ensure(&m->ws, &m->ws_floats, need));
     float* c1 = m->ws; float* x = c1 + c1_floats / 64 * 64; float* xn = x + (size_t)Mtot * D; float* qkv = xn + (size_t)Mtot * D;
-    float* att = qkv + (size_t)Mtot * QD * 3; float* ffn = att + (size_t)Mtot * QD; float* ah = ffn + (size_t)Mtot * F;
+    float* att = qkv + (size_t)Mtot * QD * 3; float* ffn = att + (size_t)Mtot * QD; float* ah = ffn + (size_t)Mtot * F; float* w2p = ah + (size_t)(M4 + 1) * m->ad0.w.N;
     const int* d_len = nullptr;
     if (n > 1) {
         HIPCHK(hipMemsetAsync(x, 0, (size_t)Mtot * D * 4, s));               // scratch rows: finite values
@@ -1210,7 +1220,8 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     const int seq_rows = n > 1 ? S_pad : 0;
     for (int l = 0; l < c.enc_layers; l++) {
         const EncLayer& L = m->enc[l];
-        HIPCHK(launch_rms_norm(x, D, Mtot, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
+        if (ksp && l > 0) HIPCHK(launch_rms_norm_sumk(x, D, Mtot, D, w2p, (size_t)Mtot * D, ksp, L.attn_norm, c.norm_eps, xn, D, s));      // + the previous layer's w2
+        else HIPCHK(launch_rms_norm(x, D, Mtot, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
         VOXCHK(q4_linear_dev(cx, L.wqkv.w, L.wqkv.bias, xn, D, Mtot, qkv, 3 * QD));
         HIPCHK(launch_rope(qkv, Mtot, 3 * QD, 2 * QD, hd, 0, m->enc_cos, m->enc_sin, s, seq_rows));
         AttnParams ap{}; ap.q = qkv; ap.q_stride = 3 * QD; ap.k = qkv + QD; ap.v = qkv + 2 * QD; ap.kv_row_stride = 3 * QD; ap.kv_head_stride = hd;
@@ -1220,9 +1231,11 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
         VOXCHK(q4_linear_dev(cx, L.wo.w, L.wo.bias, att, QD, Mtot, x, D, EPI_RESID, x, D));
         HIPCHK(launch_rms_norm(x, D, Mtot, D, L.ffn_norm, nullptr, c.norm_eps, xn, D, s));
         VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, Mtot, ffn, F, EPI_SWIGLU));
-        VOXCHK(q4_linear_dev(cx, L.w2.w, L.w2.bias, ffn, F, Mtot, x, D, EPI_RESID, x, D));
+        if (ksp) VOXCHK(q4_linear_dev(cx, L.w2.w, L.w2.bias, ffn, F, Mtot, w2p, D, EPI_STORE, nullptr, 0, ksp));
+        else VOXCHK(q4_linear_dev(cx, L.w2.w, L.w2.bias, ffn, F, Mtot, x, D, EPI_RESID, x, D));
     }
-    HIPCHK(launch_rms_norm(x, D, Mtot, D, m->enc_norm, nullptr, c.norm_eps, xn, D, s));
+    if (ksp && c.enc_layers > 0) HIPCHK(launch_rms_norm_sumk(x, D, Mtot, D, w2p, (size_t)Mtot * D, ksp, m->enc_norm, c.norm_eps, xn, D, s));
+    else HIPCHK(launch_rms_norm(x, D, Mtot, D, m->enc_norm, nullptr, c.norm_eps, xn, D, s));
     // reshape_encoder_output (models/adapter.rs:108-122): rows [0, 4*S4) of each utterance viewed as [S4][4D]; adapter (model.rs:745-749)
     VOXCHK(q4_linear_dev(cx, m->ad0.w, nullptr, xn, D * R, M4, ah, m->ad0.w.N, EPI_GELU));
     if (n == 1 || audio_rows * R == S_pad) VOXCHK(q4_linear_dev(cx, m->ad2.w, nullptr, ah, m->ad0.w.N, M4, audio_out, c.dec_dim));

@@ -150,19 +150,18 @@ constexpr int L_PART = L_U;                             //   [rows][12 or 6] f32
 constexpr int L_SC = L_U;                               //   [SC_MAX] scores; after the softmax: [128] attention output (f32) on its way to digits
 constexpr int L_PO = L_SC + SC_MAX * 4;                 //   [12][128] partial attention outputs
 constexpr int L_PL = L_PO + 12 * 128 * 4;               //   [16] partial softmax sums
-constexpr int L_XO = L_PL + 64;                         // [4 blocks] digit planes of head h's attention output (wo input): 512 B
-constexpr int L_QKVN = L_XO + 128 * 4;                  // q_h[128] k_g[128] v_g[128] of this step (plain order)
+constexpr int L_QKVN = L_PL + 64;                  // q_h[128] k_g[128] v_g[128] of this step (plain order)
 constexpr int L_TMP = L_QKVN + 384 * 4;                 // [384] partial sums swept by the comm wave
 constexpr int L_SSQ = L_TMP + 384 * 4;                  // [256] per-CU partial sums of squares of the vector being all-gathered
-constexpr int L_BLK = L_SSQ + NCU * 4;                  // [96 + 4] per 32-element block of the staged vector: {-8 * sum of its fixed-point values, 2^-shift}; [96..99]: the wo input's 4 blocks
-constexpr int L_TAB = L_BLK + 100 * 8;                  // [MAX_LAYERS] copy of the layer table: pointer reads never touch VMEM (a vector load behind a publish waits for the store)
+constexpr int L_BLK = L_SSQ + NCU * 4;                  // [96] per 32-element block of the staged vector: {-8 * sum of its fixed-point values, 2^-shift}
+constexpr int L_TAB = L_BLK + 96 * 8;                  // [MAX_LAYERS] copy of the layer table: pointer reads never touch VMEM (a vector load behind a publish waits for the store)
 constexpr int MAX_LAYERS = 32;
 constexpr int L_GW = L_TAB + MAX_LAYERS * (int)sizeof(EngLayerTab);      // [MAX_LAYERS + 1][2][16] norm weight of this CU's 12 rows: [l][0] attn_norm (l = L: final norm * 512 -- the lm_head's fp8 trick), [l][1] ffn_norm * Ada
 constexpr int L_CTL = L_GW + (MAX_LAYERS + 1) * 32 * 4;
 constexpr int L_TOTAL = L_CTL + (int)sizeof(EngCtl);
 static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
 static_assert(L_TAB % 16 == 0 && sizeof(EngLayerTab) == 40, "layer table");
-static_assert(L_XS % 16 == 0 && L_XA % 16 == 0 && L_XO % 16 == 0 && L_QKVN % 16 == 0 && L_PO % 16 == 0 && L_CTL % 16 == 0 && L_BLK % 8 == 0 && 72 * 12 * 4 <= SC_MAX * 4 && 1152 * 4 <= SC_MAX * 4 + 12 * 128 * 4, "aligned carve");
+static_assert(L_XS % 16 == 0 && L_XA % 16 == 0 && L_QKVN % 16 == 0 && L_PO % 16 == 0 && L_CTL % 16 == 0 && L_BLK % 8 == 0 && 72 * 12 * 4 <= SC_MAX * 4 && 1152 * 4 + 96 * 6 * 4 <= SC_MAX * 4 + 12 * 128 * 4, "aligned carve");
 
 // ------------------------------------------------------------------------------------------------
 // helpers
@@ -719,8 +718,9 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
     unsigned char* xs = lds + L_XS; float* ssl = reinterpret_cast<float*>(lds + L_SSQ);
     float2* binfo = reinterpret_cast<float2*>(lds + L_BLK);
-    const float* xa = reinterpret_cast<const float*>(lds + L_XA); unsigned char* xo = lds + L_XO;
+    const float* xa = reinterpret_cast<const float*>(lds + L_XA);
     float* part = reinterpret_cast<float*>(lds + L_PART);
+    float* part2 = reinterpret_cast<float*>(lds + L_XA + 1152 * 4);      // w2's partial sums: behind the f32 SwiGLU outputs, which slower waves may still be converting
     const float* qkvn = reinterpret_cast<const float*>(lds + L_QKVN);
     float* sc = reinterpret_cast<float*>(lds + L_SC); float2* po = reinterpret_cast<float2*>(lds + L_PO); float* pl = reinterpret_cast<float*>(lds + L_PL);
     const unsigned tag_base = (*p.serial + 1u) * 64u;
@@ -913,21 +913,21 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             if (T) tl(23);
             cs.cbarrier();
             if (T) tl(25);
-            if (cw == 0 && lane < 32) {      // head h's attention output: lane = 4 consecutive columns, summed over the 12 key groups (fixed order) -> digit planes (4 blocks)
+            if (lane < 32) {      // head h's attention output: lane = 4 consecutive columns, summed over the 12 key groups (fixed order) -> digit planes (4 blocks).
+                // EVERY wave does this for itself, into its own (dead since the q|k|v steps) region of the plane buffer: no barrier before wo
                 const float4* po4 = reinterpret_cast<const float4*>(po);
                 float4 so = make_float4(0.f, 0.f, 0.f, 0.f); float sl = 0.f;
 #pragma unroll
                 for (int q = 0; q < 12; q++) { const float4 a = po4[q * 32 + lane]; so.x += a.x; so.y += a.y; so.z += a.z; so.w += a.w; sl += pl[q]; }
                 const float inv = 1.0f / sl;
                 const float v[4] = {so.x * inv, so.y * inv, so.z * inv, so.w * inv};
-                to_digits(v, lane, xo + (lane >> 3) * 128, binfo + 96 + (lane >> 3));
+                to_digits(v, lane, xs + (8 * cw + (lane >> 3)) * 128, binfo + 8 * cw + (lane >> 3));
             }
-            cs.cbarrier();
             if (T) tl(3);
             {   // ---------------- wo: rows [384 s, +384) x head h's 128 columns: this wave's tiles 2 cw, 2 cw + 1, two K-steps each ----------------
                 StepCtx cx[2];
 #pragma unroll
-                for (int i = 0; i < 2; i++) cx[i] = load_ctx(xo, binfo + 96, 2 * i, lane);
+                for (int i = 0; i < 2; i++) cx[i] = load_ctx(xs, binfo, 8 * cw + 2 * i, lane);
 #pragma unroll
                 for (int i = 0; i < WO_PK; i++) {
                     int sl_; const unsigned char* bb = cs.slot_wait(cs.P + i, 2 * REC, sl_);
@@ -1017,22 +1017,20 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
             }
             wait_ge(&c->xa_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
             if (T) tl(7);
-            if (cw * 64 + lane < 288) {      // 36 blocks x 8 lanes: f32 -> digit planes
-                const int t = cw * 64 + lane;
-                const float4 v4 = *reinterpret_cast<const float4*>(xa + 4 * t);
-                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-                to_digits(v, lane, xs + (t >> 3) * 128, binfo + (t >> 3));
-            }
-            cs.cbarrier();
             const int ksl = cw % 6, tg = cw / 6;
+            if (lane < 48) {      // this wave's 6 blocks (K-steps 3 ksl .. 3 ksl + 2) of the group's SwiGLU outputs: f32 -> digit planes in the wave's own region -- no barrier
+                const float4 v4 = *reinterpret_cast<const float4*>(xa + 32 * (6 * ksl + (lane >> 3)) + 4 * (lane & 7));
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                to_digits(v, lane, xs + (8 * cw + (lane >> 3)) * 128, binfo + 8 * cw + (lane >> 3));
+            }
             StepCtx cx[3];
 #pragma unroll
-            for (int i = 0; i < 3; i++) cx[i] = load_ctx(xs, binfo, 2 * (3 * ksl + i), lane);
+            for (int i = 0; i < 3; i++) cx[i] = load_ctx(xs, binfo, 8 * cw + 2 * i, lane);
 #pragma unroll
             for (int i = 0; i < W2_PK; i++) {
                 float a = mstep(r2[3 * i], cx[0], 0.f); a = mstep(r2[3 * i + 1], cx[1], a); a = mstep(r2[3 * i + 2], cx[2], a);
                 a = g01_sum(a, lane);
-                if (lane < 16) part[(16 * (3 * tg + i) + lane) * 6 + ksl] = a;
+                if (lane < 16) part2[(16 * (3 * tg + i) + lane) * 6 + ksl] = a;
             }
             cs.P += W2_PK;
             cs.cbarrier();
@@ -1040,7 +1038,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 const int r = min(64 * cw + lane, 95);
                 float a = 0.f;
 #pragma unroll
-                for (int w = 0; w < 6; w++) a += part[r * 6 + w];      // fixed order
+                for (int w = 0; w < 6; w++) a += part2[r * 6 + w];      // fixed order
                 if (64 * cw + lane < 96) publish_b(p.P2, NP2 * ED * 8u, (unsigned)(g * ED + 96 * j + r), tag, a, false);
             }
             cs.published(tl, tlev ? 31 : -1);

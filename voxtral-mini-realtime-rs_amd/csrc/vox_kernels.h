@@ -80,6 +80,9 @@ struct GemmParams {
     // all at position pos[m] of sequence m's cache slice
     const int* pos; const float* rope_cos; const float* rope_sin; int hd, n_q, n_kv; float* kc; float* vc; long kv_seq_stride; int kv_head_stride;
     int tl_slot;          // timeline slot (measurement builds, -DVOX_TIMELINE)
+    // split-K (q4_gemm_kernel only, EPI_STORE): blockIdx.z = K slice; slice z writes its partial product to out + z * M * out_stride (bias in slice 0).
+    // The consumer (launch_rms_norm_sumk) adds the slices in a fixed order -- for few-column GEMMs (the encoder's N = 1280 w2: 40 K-steps per workgroup)
+    int ksplit;
 };
 hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);
@@ -93,6 +96,8 @@ hipError_t launch_q4_repack(const uint8_t* raw, uint4* qs, uint16_t* sc, int64_t
 hipError_t launch_q4_dequant(Q4W w, float* out, hipStream_t s);                 // diagnostics (tensor.rs:88-113)
 hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul,
                            float eps, float* out, int out_stride, hipStream_t s);
+// x[row] += sum of ksplit partial planes (fixed order; plane stride = part_stride floats), written back, then RMSNorm -> out (dim <= 4096, dim % 4 == 0)
+hipError_t launch_rms_norm_sumk(float* x, int x_stride, int rows, int dim, const float* part, size_t part_stride, int ksplit, const float* gamma, float eps, float* out, int out_stride, hipStream_t s);
 hipError_t launch_rms_norm_xf(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul,
                               float eps, uint16_t* xf, hipStream_t s);   // rows <= 16 -> XF fragment planes
 // interleaved-pair RoPE in place on columns [0, n_rot) of buf[M][stride]; row m has position pos_off + m

@@ -984,6 +984,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * (16 * MT), n0 = blockIdx.x * (64 * NT);
+    const int KSP = p.ksplit > 1 ? p.ksplit : 1, kz = blockIdx.z;                               // split-K: this workgroup's K steps [qb, qe)
+    const int qb = (int)((long)nq * kz / KSP), qe = (int)((long)nq * (kz + 1) / KSP);
     // staging role: fragment f = tid + 256*i -> (row sm = f>>4, block j = (f>>2)&3, group g = f&3)
     const float* xrow[MT]; int slot[MT], xo_a[MT], xo_b[MT];
 #pragma unroll
@@ -1033,7 +1035,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
         uint4 hi_, lo_; split_bf16x8(sxa[i], sxb[i], hi_, lo_);                                                \
         glds[(BUF_) * BUF + slot[i]] = hi_; glds[(BUF_) * BUF + PLANE + slot[i]] = lo_;                        \
     }
-    VOX_GLOAD(0)
+    VOX_GLOAD(qb)
     float4 sxa[MT], sxb[MT];
 #pragma unroll
     for (int i = 0; i < MT; i++) { sxa[i] = xa[i]; sxb[i] = xb[i]; }
@@ -1043,10 +1045,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     for (int t = 0; t < NT; t++) { csc[t] = wsc[t];
 #pragma unroll
         for (int j = 0; j < 4; j++) { cwd[t][j] = wd[t][j]; cwdv[t][j] = wdv[t][j]; } }
-    { const int q1 = min(1, nq - 1); VOX_GLOAD(q1) }
+    { const int q1 = min(qb + 1, qe - 1); VOX_GLOAD(q1) }
     __syncthreads();
-    for (int q = 0; q < nq; q++) {
-        const int buf = q & 1;
+    for (int q = qb; q < qe; q++) {
+        const int buf = (q - qb) & 1;
 #pragma unroll
         for (int i = 0; i < MT; i++) { sxa[i] = xa[i]; sxb[i] = xb[i]; }          // k-step q+1 (in flight since last iteration)
         uint32_t nwd[NT][4]; uint2 nsc[NT]; uint4 nwdv[NT][4];
@@ -1054,7 +1056,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
         for (int t = 0; t < NT; t++) { nsc[t] = wsc[t];
 #pragma unroll
             for (int j = 0; j < 4; j++) { nwd[t][j] = wd[t][j]; nwdv[t][j] = wdv[t][j]; } }
-        { const int q2 = min(q + 2, nq - 1); VOX_GLOAD(q2) }                      // unconditional (clamped) prefetch
+        { const int q2 = min(q + 2, qe - 1); VOX_GLOAD(q2) }                      // unconditional (clamped) prefetch
 #pragma unroll
         for (int j = 0; j < 4; j++) {
 #pragma unroll
@@ -1076,7 +1078,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
                 }
             }
         }
-        if (q + 1 < nq) {
+        if (q + 1 < qe) {
             VOX_STAGE(buf ^ 1)
 #pragma unroll
             for (int t = 0; t < NT; t++) { csc[t] = nsc[t];
@@ -1089,7 +1091,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 #undef VOX_STAGE
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        const float bias = (p.bias && wok[t]) ? p.bias[wn[t]] : 0.f;
+        const float bias = (p.bias && wok[t] && kz == 0) ? p.bias[wn[t]] : 0.f;
 #pragma unroll
         for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
                 } else if (m < M && wok[t]) {
                     if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + wn[t]];
                     if (EPI == EPI_GELU) v = gelu_f(v);
-                    p.out[(size_t)m * p.out_stride + wn[t]] = v;
+                    (p.out + (size_t)kz * p.M * p.out_stride)[(size_t)m * p.out_stride + wn[t]] = v;
                 }
             }
     }
@@ -1899,7 +1901,8 @@ static hipError_t launch_q4_skinny(const GemmParams& p_in, int epi, hipStream_t 
 
 template <int MT, int NT, int FMT, int TB = 0>
 static hipError_t gemm_launch_mn(const GemmParams& p, int epi, hipStream_t s) {
-    dim3 grid((p.w.N + 64 * NT - 1) / (64 * NT), (p.M + 16 * MT - 1) / (16 * MT));
+    if (p.ksplit > 1 && (epi != EPI_STORE || p.ksplit > p.w.nb / 4)) return hipErrorInvalidValue;
+    dim3 grid((p.w.N + 64 * NT - 1) / (64 * NT), (p.M + 16 * MT - 1) / (16 * MT), p.ksplit > 1 ? p.ksplit : 1);
     const size_t lds = (size_t)2 * 2 * 4 * MT * 64 * sizeof(uint4);     // MT * 16 KB
 #define VOX_E(E_) case E_: { auto kern = q4_gemm_kernel<MT, NT, E_, FMT, TB>; static bool done = false;      \
         hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;                       \
@@ -1954,6 +1957,7 @@ static hipError_t gemm_launch_f(const GemmParams& p, int epi, hipStream_t s) {
 }
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
+    if (p.ksplit > 1 && (p.M <= 48 || p.xf || p.w.nb % 4 || env_int("VOX_GEMM_K32") || p.w.fmt == WFMT_F32)) return hipErrorInvalidValue;      // split-K exists in q4_gemm_kernel only
     if (p.w.fmt == WFMT_F32) {      // true-f32 dense weights: bf16 hi + lo planes on the matrix cores (3 MFMAs per product, f32-class like the conv stem)
         if (p.xf) return hipErrorInvalidValue;
         GemmParams v = p; v.w.fmt = WFMT_BF16X2; v.w.qt = nullptr; v.w.st = nullptr;
@@ -1978,7 +1982,7 @@ hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
         // (profiles/r01_gemm_sweep.txt).  VOX_GEMM_BIG: 0 auto, 1 force, -1 off (measurement knob)
         const int big = env_int("VOX_GEMM_BIG");
         const long wg14 = (long)((p.w.N + 255) / 256) * ((p.M + 63) / 64);
-        if (big == 1 || (big == 0 && wg14 >= 200)) return gemm_big_launch<1, 4>(p, epi, s);
+        if (p.ksplit <= 1 && (big == 1 || (big == 0 && wg14 >= 200))) return gemm_big_launch<1, 4>(p, epi, s);
     }
     return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, s);
 }
@@ -2053,7 +2057,41 @@ __global__ __launch_bounds__(256) void rms_norm_row_kernel(const float* __restri
         }
     }
 }
-// same, but the normalised rows (<= 16) go straight into the XF fragment planes of the following batched-decode GEMM
+// x += sum of KS split-K partial planes (fixed order), written back; RMSNorm of the new row -> out.  One wave per row, dim <= 4096.
+__global__ __launch_bounds__(256) void rms_norm_sumk_kernel(float* __restrict__ x, int x_stride, int rows, int dim, const float* __restrict__ part, size_t part_stride, int ks,
+                                                            const float* __restrict__ gamma, float eps, float* __restrict__ out, int out_stride) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float4* xr = reinterpret_cast<float4*>(x + (size_t)row * x_stride);
+    const int n4 = dim >> 2;
+    float4 v[16];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int c = lane + 64 * i;
+        if (c < n4) {
+            float4 a = xr[c];
+            for (int k = 0; k < ks; k++) { const float4 t = reinterpret_cast<const float4*>(part + (size_t)k * part_stride + (size_t)row * dim)[c]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+            v[i] = a; xr[c] = a;
+            ss += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+        } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    ss = wave_sum(ss);
+    const float rms = sqrtf(ss / (float)dim + eps);      // (x / rms) * gamma, like rms_norm_kernel
+    float4* o = reinterpret_cast<float4*>(out + (size_t)row * out_stride);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int c = lane + 64 * i;
+        if (c < n4) { const float4 g = g4[c]; o[c] = make_float4((v[i].x / rms) * g.x, (v[i].y / rms) * g.y, (v[i].z / rms) * g.z, (v[i].w / rms) * g.w); }
+    }
+}
+hipError_t launch_rms_norm_sumk(float* x, int x_stride, int rows, int dim, const float* part, size_t part_stride, int ksplit, const float* gamma, float eps, float* out, int out_stride, hipStream_t s) {
+    if (dim % 4 || dim > 4096 || rows <= 0 || ksplit < 1) return hipErrorInvalidValue;
+    rms_norm_sumk_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(x, x_stride, rows, dim, part, part_stride, ksplit, gamma, eps, out, out_stride);
+    return hipGetLastError();
+}
+// same as launch_rms_norm, but the normalised rows (<= 16) go straight into the XF fragment planes of the following batched-decode GEMM
 hipError_t launch_rms_norm_xf(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul, float eps,
                               uint16_t* xf, hipStream_t s) {
     if (rows > 48 || dim > 10240 || dim % 128) return hipErrorInvalidValue;      // up to three XF tiles (the 38-token prefill); rows of the last tile past `rows` keep their old contents
