@@ -219,7 +219,10 @@ int32_t vox_cache_reset(vox_cache* c);
 /* Streaming encoder: Q4AudioEncoder::create_cache + Q4VoxtralModel::encode_audio_with_cache (gguf/model.rs:437-459,791-799; per layer
  * :299-317,125-174), eviction KVCache::apply_sliding_window (kv_cache.rs:176-203).  The chunk's conv output rows are run through the 32 layers
  * against the cached K / V (RoPE at the absolute stream position; the cache evicts rows older than the 750-row window by itself when a chunk
- * does not fit), then reshaped / adapted like encode_audio: floor(S_chunk / 4) rows of [dec_dim].  capacity_rows 0 = 2 * window + 512. */
+ * does not fit), then reshaped / adapted like encode_audio: floor(S_chunk / 4) rows of [dec_dim].  capacity_rows 0 = 2 * window + 512.
+ * LIMIT: positions are ABSOLUTE stream positions (the reference offsets RoPE by cache.seq_len(), which restarts after an eviction); the position table
+ * holds 65 536 rows = 21.8 minutes of audio per cache -- later chunks are refused (VOX_ERR_ARG) until vox_cache_reset.  A too small `cap_rows` is refused
+ * BEFORE the chunk is appended (the stream cache is untouched and the call can be repeated with a larger buffer). */
 int32_t vox_encoder_cache_create(vox_model* m, int32_t capacity_rows, vox_cache** out);
 int32_t vox_encoder_cache_apply_sliding_window(vox_cache* enc_cache, int32_t window);
 int32_t vox_cache_abs_pos(const vox_cache* c, int32_t* out);      /* encoder cache: stream positions seen so far; decoder cache: == seq_len */

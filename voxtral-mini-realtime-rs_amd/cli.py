@@ -41,14 +41,12 @@ def load_wav(path):
 
 
 def resample_to_16k(x, sr, ctx=None, pkg=None):
-    """audio/resample.rs:10-52.  On the GPU when a context is given (vox_resample: polyphase band-limited interpolation); the scipy polyphase
-    filter remains as the host-only fallback of this CLI helper (tests without a GPU)."""
-    if ctx is not None and pkg is not None:
-        return pkg.resample_to_16k(ctx, x, sr)
-    from math import gcd
-    from scipy.signal import resample_poly
-    g = gcd(16000, int(sr))
-    return resample_poly(x.astype(np.float64), 16000 // g, int(sr) // g).astype(np.float32)
+    """audio/resample.rs:10-52.  vox_resample on the GPU (polyphase band-limited interpolation; tests/test_resample.py pins it against the CPU oracle -- the
+    reference's rubato FFT resampler is a third-party crate outside the tree, so bit parity with IT is unpinned and recorded as such in DESIGN.md).  There is no
+    host fallback: without the HIP library this CLI cannot resample."""
+    if ctx is None or pkg is None:
+        raise RuntimeError("resample_to_16k needs a GPU context (the product path has no CPU fallback)")
+    return pkg.resample_to_16k(ctx, x, sr)
 
 
 def transcribe_one(pkg, path, model, tokenizer, mel, pad_cfg, chunk_cfg, t_embed):

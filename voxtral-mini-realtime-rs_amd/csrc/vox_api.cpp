@@ -1365,13 +1365,13 @@ extern "C" int32_t vox_encode_audio_with_cache(vox_model* m, const float* mel, i
     ARGCHK(m && mel && enc_cache && out && S, "null argument"); ARGCHK(T > 0, "empty mel");
     ARGCHK(enc_cache->kind == 1 && enc_cache->m == m, "not an encoder cache of this model (vox_encoder_cache_create)"); VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    ARGCHK(cap_rows >= enc_rows(T) / c.reshape_factor, "output capacity %d rows < %d", cap_rows, enc_rows(T) / c.reshape_factor);      // BEFORE the chunk's K / V are appended: a refused call leaves the stream cache untouched
     const float* d_mel = mel;
     if (mem_kind == VOX_MEM_HOST) {
         VOXCHK(ensure(&m->d_mel, &m->mel_cap, (size_t)c.n_mels * T));
         HIPCHK(hipMemcpyAsync(m->d_mel, mel, (size_t)c.n_mels * T * 4, hipMemcpyHostToDevice, s)); d_mel = m->d_mel;
     }
     int S4 = 0; VOXCHK(encode_with_cache_dev(m, d_mel, T, enc_cache, &S4));
-    ARGCHK(cap_rows >= S4, "output capacity %d rows < %d", cap_rows, S4);
     if (S4 > 0) HIPCHK(hipMemcpyAsync(out, m->d_audio, (size_t)S4 * c.dec_dim * 4, mem_kind == VOX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     *S = S4; return VOX_OK;
@@ -1435,7 +1435,7 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
 // May this layer run as four launches?
 static bool decode_layer_fuses_attn_wo(const vox_model* m, const DecLayer& L, const AttnParams& ap, const vox_cache* kc) {
     const vox_model_cfg& c = m->cfg; const int D = c.dec_dim;
-    return attn_wo_supported(ap, L.wo.w, c.dec_head_dim, kc->max_seq) && L.w13.w.fmt == WFMT_Q4_0 && L.wo.w.N == D && D % 4 == 0 && L.w13.w.K == 3072 &&
+    return attn_wo_supported(ap, L.wo.w, c.dec_head_dim, kc->max_seq) && L.w13.w.fmt == WFMT_Q4_0 && L.w2.w.fmt == WFMT_Q4_0 /* w2's kernel clears the accumulators */ && L.wo.w.N == D && D % 4 == 0 && L.w13.w.K == 3072 &&
            q4_gemv_default_R(L.w13.w.N, L.w13.w.K, EPI_SWIGLU) == 2;
 }
 

@@ -185,6 +185,9 @@ typedef __amdgpu_buffer_rsrc_t srd_t;
 __device__ __forceinline__ srd_t make_srd(const void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000); }
 // granule load: buffer_load_dwordx2 ... offen sc1 (aux 16 = sc1: served by L2 / memory, never by this CU's L1)
 __device__ __forceinline__ u64 ld_gran(srd_t srd, unsigned idx) { const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(srd, (int)(idx * 8u), 0, 16); return ((u64)v.y << 32) | (u64)v.x; }
+// XCD-local form (producer and reader behind the same L2, verified at start-up): nt -- misses this CU's L1 but is served by the L2 at hit latency even while the
+// granule is still stale, where an sc1 poll of a clean line is a round trip to memory (tools/micro/edge_pingpong.hip: 0.31 us per hop with plain stores)
+__device__ __forceinline__ u64 ld_gran_l(srd_t srd, unsigned idx) { const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(srd, (int)(idx * 8u), 0, 2); return ((u64)v.y << 32) | (u64)v.x; }
 __device__ __forceinline__ float ld_gf(srd_t srd, unsigned idx) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, (int)(idx * 4u), 0, 0)); }
 __device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, RLX, WG)); }
 __device__ __forceinline__ void lds_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, RLX, WG); }
@@ -346,7 +349,7 @@ __device__ __forceinline__ bool sweep_bail(u64& t0, unsigned tag, EngCtl* c, uns
 // one granule of every producer, or of every n-th) instead of the whole set: 256 CUs polling 8 KB each would put TB/s of coherent reads next to the
 // weight stream (MI355X_MICROARCH.md polling-cost).
 template <int N, class IdxF, class ProbeF>
-__device__ __forceinline__ bool sweep(const u64* base_, unsigned bytes, unsigned tag, IdxF idx, ProbeF probe, bool do_probe, float (&v)[N], EngCtl* c, unsigned* err) {
+__device__ __forceinline__ bool sweep(const u64* base_, unsigned bytes, unsigned tag, IdxF idx, ProbeF probe, bool do_probe, float (&v)[N], EngCtl* c, unsigned* err, bool local = false) {
     const srd_t base = make_srd(base_, bytes);
     u64 t0 = 0;
     if (do_probe) {
@@ -361,7 +364,7 @@ __device__ __forceinline__ bool sweep(const u64* base_, unsigned bytes, unsigned
         bool ok = true;
 #pragma unroll
         for (int u = 0; u < N; u++) {
-            const u64 gq = ld_gran(base, (unsigned)idx(u));
+            const u64 gq = local ? ld_gran_l(base, (unsigned)idx(u)) : ld_gran(base, (unsigned)idx(u));
             v[u] = __uint_as_float((unsigned)gq);
             ok &= (unsigned)(gq >> 32) == tag;
         }
@@ -437,11 +440,13 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
         if (T) tl(odd ? 11 : 8);
         if (last) { lds_st(&c->gathering, 0u); break; }
         if (!odd) {
+            wait_ge(&c->gw_flag, 1u, c, p.err, ERR_STAGE);
+            const bool xloc_nt = (p.flags & 128) != 0 && (p.flags & 4096) != 0 && lds_ld(&c->xcd_ok) != 0;      // (measurement knob 4096: XCD-local edges polled with nt loads)
             {   // this step's q_h, k_g, v_g rows
                 wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 1u), c, p.err, ERR_STAGE);
                 float v[6];
                 sweep<6>(p.G, (EQD + 2 * EKD) * 8u, tag, [&](int u) { const int i = lane + 64 * u, seg = i >> 7, e = i & 127; return seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e; },
-                         [&]() { return lane < 32 ? EQD + 128 * g + 4 * lane : EQD + EKD + 128 * g + 4 * (lane - 32); }, PROBE_SMALL, v, c, p.err);      // probe: a k / v row of each of the group's 32 CUs
+                         [&]() { return lane < 32 ? EQD + 128 * g + 4 * lane : EQD + EKD + 128 * g + 4 * (lane - 32); }, PROBE_SMALL, v, c, p.err, xloc_nt);      // probe: a k / v row of each of the group's 32 CUs
 #pragma unroll
                 for (int u = 0; u < 6; u++) qkvn[lane + 64 * u] = v[u];
                 ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u);
@@ -463,10 +468,11 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
             }
             if (T) tl(10);
         } else {
+            const bool xloc_nt = (p.flags & 128) != 0 && (p.flags & 4096) != 0 && lds_ld(&c->xcd_ok) != 0;
             {   // the XCD group's 1152 SwiGLU outputs -> w2 input
                 wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 3u), c, p.err, ERR_STAGE);
                 float v[18];
-                sweep<18>(p.A, EF * 8u, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, PROBE_SMALL, v, c, p.err);      // probe: the last output of each CU of the group
+                sweep<18>(p.A, EF * 8u, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, PROBE_SMALL, v, c, p.err, xloc_nt);      // probe: the last output of each CU of the group
 #pragma unroll
                 for (int u = 0; u < 18; u++) xa[lane + 64 * u] = v[u];      // plain f32: the consumer waves turn it into digit planes
                 ENG_CFENCE(); lds_st(&c->xa_flag, (unsigned)l + 1u);

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
     int g = bx * NWV + wave;
     VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 0);
     if (p.zero_acc) {      // uniform; a handful of stores per workgroup
-        const int per = (p.zero_n + (int)gridDim.x - 1) / (int)gridDim.x, i = blockIdx.x * per + tid;
-        if (tid < per && i < p.zero_n) p.zero_acc[i] = 0;
+        const int per = (p.zero_n + (int)gridDim.x - 1) / (int)gridDim.x, i_end = min(((int)blockIdx.x + 1) * per, p.zero_n);
+        for (int i = blockIdx.x * per + tid; i < i_end; i += NT) p.zero_acc[i] = 0;      // (a loop: a small grid has more entries per workgroup than threads)
     }
 
     // Every global load below is UNCONDITIONAL (indices are clamped, never predicated): a "cond ? load : 0"
@@ -292,8 +292,9 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
         for (int i = 0; i < NX; i++) {
             float4 a = xp[i];
             const float4 lo = pp[i][0], hi = pp[i][1];
-            // int64 with 32 fractional bits -> f32: signed integer part (exact) + unsigned fraction * 2^-32 (one f32 rounding each, like any f32 add)
-            const auto fx = [](float l, float h_) { return (float)(int)__float_as_uint(h_) + (float)__float_as_uint(l) * (1.0f / 4294967296.0f); };
+            // int64 with 32 fractional bits -> f32 with ONE rounding (the integer and fraction halves converted separately cancel for small negative sums);
+            // the power-of-two scale afterwards is exact
+            const auto fx = [](float l, float h_) { return __ll2float_rn((long long)(((unsigned long long)__float_as_uint(h_) << 32) | (unsigned long long)__float_as_uint(l))) * (1.0f / 4294967296.0f); };
             a.x += fx(lo.x, lo.y); a.y += fx(lo.z, lo.w); a.z += fx(hi.x, hi.y); a.w += fx(hi.z, hi.w);
             xp[i] = a;
             const int pc = tid + NT * i;
