@@ -1200,6 +1200,9 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
         if (const char* e = knob_str("VOX_ENC_SPLITK")) ksp = atoi(e) > 1 ? atoi(e) : 0;
         for (int l = 0; ksp && l < c.enc_layers; l++) if (m->enc[l].w2.w.fmt != WFMT_Q4_0 || !m->enc[l].w2.w.qt || m->enc[l].w2.w.nb / 4 < ksp) ksp = 0;
     }
+    int ksp_wo = ksp ? 2 : 0;      // the same for wo (K = QD: 10 K-steps), two slices (7.85 -> 7.76 ms per clip; four: 7.93; profiles/r03_enc_splitk.txt); VOX_ENC_SPLITK_WO overrides
+    if (ksp) { if (const char* e = knob_str("VOX_ENC_SPLITK_WO")) ksp_wo = atoi(e) > 1 ? std::min(atoi(e), ksp) : 0; }
+    for (int l = 0; ksp_wo && l < c.enc_layers; l++) if (m->enc[l].wo.w.fmt != WFMT_Q4_0 || !m->enc[l].wo.w.qt || m->enc[l].wo.w.nb / 4 < ksp_wo || m->enc[l].wo.w.nb % 4) ksp_wo = 0;
     const size_t need = c1_floats + (size_t)Mtot * D * 2 + (size_t)Mtot * QD * 4 + (size_t)Mtot * F + (size_t)(M4 + 1) * m->ad0.w.N + (size_t)ksp * Mtot * D + 1024;
     VOXCHK(ensure(&m->ws, &m->ws_floats, need));
     float* c1 = m->ws; float* x = c1 + c1_floats / 64 * 64; float* xn = x + (size_t)Mtot * D; float* qkv = xn + (size_t)Mtot * D;
@@ -1228,8 +1231,13 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
         ap.out = att; ap.out_stride = QD; ap.M = S_pad; ap.kv_len = S_pad; ap.n_heads = H; ap.n_kv_heads = H; ap.offset = 0; ap.window = c.enc_window;
         ap.seq_len = d_len; ap.q_seq_stride = S_pad * 3 * QD; ap.out_seq_stride = S_pad * QD; ap.kv_seq_stride = (long)S_pad * 3 * QD;
         HIPCHK(launch_attn_prefill(ap, hd, s, n));
-        VOXCHK(q4_linear_dev(cx, L.wo.w, L.wo.bias, att, QD, Mtot, x, D, EPI_RESID, x, D));
-        HIPCHK(launch_rms_norm(x, D, Mtot, D, L.ffn_norm, nullptr, c.norm_eps, xn, D, s));
+        if (ksp_wo) {      // (w2p is free here: the previous layer's w2 planes were consumed by this layer's first norm)
+            VOXCHK(q4_linear_dev(cx, L.wo.w, L.wo.bias, att, QD, Mtot, w2p, D, EPI_STORE, nullptr, 0, ksp_wo));
+            HIPCHK(launch_rms_norm_sumk(x, D, Mtot, D, w2p, (size_t)Mtot * D, ksp_wo, L.ffn_norm, c.norm_eps, xn, D, s));
+        } else {
+            VOXCHK(q4_linear_dev(cx, L.wo.w, L.wo.bias, att, QD, Mtot, x, D, EPI_RESID, x, D));
+            HIPCHK(launch_rms_norm(x, D, Mtot, D, L.ffn_norm, nullptr, c.norm_eps, xn, D, s));
+        }
         VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, Mtot, ffn, F, EPI_SWIGLU));
         if (ksp) VOXCHK(q4_linear_dev(cx, L.w2.w, L.w2.bias, ffn, F, Mtot, w2p, D, EPI_STORE, nullptr, 0, ksp));
         else VOXCHK(q4_linear_dev(cx, L.w2.w, L.w2.bias, ffn, F, Mtot, x, D, EPI_RESID, x, D));
