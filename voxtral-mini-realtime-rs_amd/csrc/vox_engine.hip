@@ -581,24 +581,27 @@ __device__ __forceinline__ StepCtx load_ctx(const unsigned char* planes, const f
 }
 // one step record as this lane holds it: 8 bytes of nibbles + the f16 scale bits of its block.  Records do not depend on the step's activations, so a wave
 // moves them from the ring into REGISTERS while it waits for an edge (and frees the ring slots for the loader: the register file is the bigger buffer)
-struct RecR { uint2 q; unsigned sb; };
+struct RecR { i4v B; float sc; };      // the MFMA B operand (nibbles unpacked to int8 -- done while the wave waits, off the critical path) and the block scale as f32
 __device__ __forceinline__ RecR rec_read(const unsigned char* rec, bool half, int lane) {
     const int n = lane & 15, g = lane >> 4;
-    RecR r; r.q = make_uint2(0u, 0u);
-    if (!half) r.q = reinterpret_cast<const uint2*>(rec)[lane];
-    else if (n < 8) r.q = reinterpret_cast<const uint2*>(rec)[g * 8 + n];
-    r.sb = reinterpret_cast<const unsigned short*>(rec + (half ? REC_H_SC : REC_SC))[(half ? 8 : 16) * (g & 1) + (half ? (n & 7) : n)];
+    uint2 q = make_uint2(0u, 0u);
+    if (!half) q = reinterpret_cast<const uint2*>(rec)[lane];
+    else if (n < 8) q = reinterpret_cast<const uint2*>(rec)[g * 8 + n];
+    const unsigned short sb = reinterpret_cast<const unsigned short*>(rec + (half ? REC_H_SC : REC_SC))[(half ? 8 : 16) * (g & 1) + (half ? (n & 7) : n)];
+    RecR r;
+    r.B[0] = (int)(q.x & 0x0F0F0F0Fu); r.B[1] = (int)(q.y & 0x0F0F0F0Fu); r.B[2] = (int)((q.x >> 4) & 0x0F0F0F0Fu); r.B[3] = (int)((q.y >> 4) & 0x0F0F0F0Fu);
+    r.sc = __half2float(__ushort_as_half(sb));
+    asm volatile("" : "+v"(r.B[0]), "+v"(r.B[1]), "+v"(r.B[2]), "+v"(r.B[3]), "+v"(r.sc));      // pin the unpack HERE (hipcc sinks it to the MFMA otherwise: 7 VALU back on the critical path)
     return r;
 }
 // one MFMA step of a 16-row (or 8-row) tile: acc += (block scale) * (x block scale) * sum_k x_int[k] * (q[k] - 8) for this lane's block of tile row n
 __device__ __forceinline__ float mstep(const RecR& r, const StepCtx& cx, float acc) {
-    i4v B; B[0] = (int)(r.q.x & 0x0F0F0F0Fu); B[1] = (int)(r.q.y & 0x0F0F0F0Fu); B[2] = (int)((r.q.x >> 4) & 0x0F0F0F0Fu); B[3] = (int)((r.q.y >> 4) & 0x0F0F0F0Fu);
-    const i4v D = __builtin_amdgcn_mfma_i32_16x16x64_i8(cx.A, B, i4v{0, 0, 0, 0}, 0, 0, 0);
+    const i4v D = __builtin_amdgcn_mfma_i32_16x16x64_i8(cx.A, r.B, i4v{0, 0, 0, 0}, 0, 0, 0);
     // digits -> value: (D0 + 128 D1) and (D2 + 128 D3) exactly in int32 (v_lshl_add_u32; |D| <= 32 * 15 * 128), then one f32 FMA (one rounding, as before)
     const int lo = (int)((unsigned)D[0] + ((unsigned)D[1] << 7)), hi = (int)((unsigned)D[2] + ((unsigned)D[3] << 7));
     float t = fmaf((float)hi, 16384.0f, (float)lo);
     t += cx.m8sx;
-    return fmaf(t, __half2float(__ushort_as_half((unsigned short)r.sb)) * cx.sxinv, acc);
+    return fmaf(t, r.sc * cx.sxinv, acc);
 }
 __device__ __forceinline__ float mstep(const unsigned char* rec, bool half, int lane, const StepCtx& cx, float acc) { return mstep(rec_read(rec, half, lane), cx, acc); }
 __device__ __forceinline__ float g01_sum(float v, int lane) { return v + __shfl(v, (lane + 16) & 63); }      // block 0 + block 1 partial of tile row n (valid in lanes 0..15)
