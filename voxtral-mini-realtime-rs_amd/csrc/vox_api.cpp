@@ -639,7 +639,7 @@ struct vox_model {
     // persistent decode-step engine (vox_engine.hip): one launch per token for the real decoder geometry; eng_ok = eligible, eng_ready = stream packed + state allocated
     bool eng_ok = false, eng_on = true, eng_ready = false; unsigned char* eng_stream = nullptr; unsigned char* eng_state = nullptr; EngLayerTab* eng_tab = nullptr;
     const vox_cache* eng_tab_cache = nullptr; const float* eng_tab_k = nullptr; std::vector<EngLayerTab> eng_tab_host;      // (cache object, its K base) the device layer table was built for
-    int eng_flags = 128 | 512, eng_pace = 50;      // XCD-local edges; probe-less all-gather, swept 0.5 us after the CU's own rows went out
+    int eng_flags = 128 | 512 | 1, eng_pace = 50;      // XCD-local edges; probe-less all-gather, swept 0.5 us after the CU's own rows went out; one LDS-DMA packet in flight while the CU polls memory
     unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0;

@@ -138,6 +138,7 @@ struct EngCtl {
     float rstd0, rstd1, pad1, pad2;
     float best_val[16]; int best_idx[16];
     float h_own[16], h1_own[16];
+    unsigned ag_done, pad_q[3];                   // consumer waves through with their all-gather sweep (12 per stage)
     float rope_c[24], rope_s[24];                 // RoPE factors of the CU's 24 q|k|v rows (the same in every layer; wave 0 reads them back per layer instead of holding two VGPRs all step)
 };
 constexpr int L_RING = 0;
@@ -433,20 +434,24 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
         int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per stage: lane-derived addresses are recomputed, not carried around the loop in VGPRs
         const int l = st >> 1; const bool odd = st & 1, last = st == 2 * p.n_layers, T = l == p.tl_layer;
         const unsigned tag = tag_base + (unsigned)l + 1u;       // written during layer l
-        lds_st(&c->gathering, 1u);
         if (odd) comm_probe_x(p, c, lane, p.H1, tag, tl, T);
         else comm_probe_x(p, c, lane, p.H0, tag - 1u, tl, false);
+        lds_st(&c->gathering, 1u);      // "this CU is polling memory": the loader (flags 1 / 64) keeps its LDS-DMA traffic out of the CU's memory pipeline meanwhile
         lds_st(&c->ag_flag, (unsigned)st + 1u);
         if (T) tl(odd ? 11 : 8);
-        if (last) { lds_st(&c->gathering, 0u); break; }
+        if (p.flags & (1 | 64)) wait_ge(&c->ag_done, NCONS * ((unsigned)st + 1u), c, p.err, ERR_STAGE);
+        lds_st(&c->gathering, 0u);
+        if (last) break;
         if (!odd) {
             wait_ge(&c->gw_flag, 1u, c, p.err, ERR_STAGE);
             const bool xloc_nt = (p.flags & 128) != 0 && (p.flags & 4096) != 0 && lds_ld(&c->xcd_ok) != 0;      // (measurement knob 4096: XCD-local edges polled with nt loads)
             {   // this step's q_h, k_g, v_g rows
                 wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 1u), c, p.err, ERR_STAGE);
+                lds_st(&c->gathering, 1u);
                 float v[6];
                 sweep<6>(p.G, (EQD + 2 * EKD) * 8u, tag, [&](int u) { const int i = lane + 64 * u, seg = i >> 7, e = i & 127; return seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e; },
                          [&]() { return lane < 32 ? EQD + 128 * g + 4 * lane : EQD + EKD + 128 * g + 4 * (lane - 32); }, PROBE_SMALL, v, c, p.err, xloc_nt);      // probe: a k / v row of each of the group's 32 CUs
+                lds_st(&c->gathering, 0u);
 #pragma unroll
                 for (int u = 0; u < 6; u++) qkvn[lane + 64 * u] = v[u];
                 ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u);
@@ -454,10 +459,12 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
             if (T) tl(9);
             {   // wo: 32 partial planes of this CU's 12 rows -> residual stream after attention, published as the w1|w3 input (gw = ffn_norm * Ada * 512)
                 wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 2u), c, p.err, ERR_STAGE);
+                lds_st(&c->gathering, 1u);
                 float v[6];
                 sweep<6>(p.PW, NPW * ED * 8u, tag, [&](int u) { const int i = lane + 64 * u, hh = i / OWN, r = i - hh * OWN; return hh * ED + OWN * b + r; }, [&]() { return (lane & 31) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
 #pragma unroll
                 for (int u = 0; u < 6; u++) tmp[lane + 64 * u] = v[u];
+                lds_st(&c->gathering, 0u);
                 ENG_CFENCE();
                 float a = 0.f;
                 const int r = min(lane, OWN - 1);
@@ -471,19 +478,23 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
             const bool xloc_nt = (p.flags & 128) != 0 && (p.flags & 4096) != 0 && lds_ld(&c->xcd_ok) != 0;
             {   // the XCD group's 1152 SwiGLU outputs -> w2 input
                 wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 3u), c, p.err, ERR_STAGE);
+                lds_st(&c->gathering, 1u);
                 float v[18];
                 sweep<18>(p.A, EF * 8u, tag, [&](int u) { return 1152 * g + lane + 64 * u; }, [&]() { return 1152 * g + 36 * (lane & 31) + 35; }, PROBE_SMALL, v, c, p.err, xloc_nt);      // probe: the last output of each CU of the group
 #pragma unroll
                 for (int u = 0; u < 18; u++) xa[lane + 64 * u] = v[u];      // plain f32: the consumer waves turn it into digit planes
                 ENG_CFENCE(); lds_st(&c->xa_flag, (unsigned)l + 1u);
+                lds_st(&c->gathering, 0u);
             }
             if (T) tl(12);
             {   // w2: 8 partial planes (one per XCD group) of this CU's 12 rows -> the layer's output, published as the next layer's q|k|v input (gw = next attn_norm)
                 wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 4u), c, p.err, ERR_STAGE);
+                lds_st(&c->gathering, 1u);
                 float v[2];
                 sweep<2>(p.P2, NP2 * ED * 8u, tag, [&](int u) { const int i = min(lane + 64 * u, NP2 * OWN - 1), pp = i / OWN, r = i - pp * OWN; return pp * ED + OWN * b + r; }, [&]() { return min(lane, NP2 - 1) * ED + OWN * b; }, PROBE_SMALL, v, c, p.err);
 #pragma unroll
                 for (int u = 0; u < 2; u++) if (lane + 64 * u < NP2 * OWN) tmp[lane + 64 * u] = v[u];
+                lds_st(&c->gathering, 0u);
                 ENG_CFENCE();
                 float a = 0.f;
                 const int r = min(lane, OWN - 1);
@@ -493,7 +504,6 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
             }
             if (T) tl(13);
         }
-        lds_st(&c->gathering, 0u);
     }
 }
 
@@ -691,6 +701,7 @@ struct Cons {
                 if (sweep_bail(t0, tag, c, p.err)) break;
             }
             if (T) tl(22);
+            if (ln == 0) __hip_atomic_fetch_add(&c->ag_done, 1u, RLX, WG);
             const float v[4] = {__uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rb.x), __uint_as_float(rb.z)};
             to_digits(v, ln, xs + (q >> 3) * 128u, binfo + (q >> 3));
             if (cw < 4) ssl[64 * cw + ln] = __uint_as_float((unsigned)rq);      // read back (rstd_staged) by the waves that finish the operator, behind its cross-wave barrier
@@ -708,6 +719,7 @@ struct Cons {
             if (__all(ok)) break;
             if (sweep_bail(t0, tag, c, p.err)) break;
         }
+        if (ln == 0) __hip_atomic_fetch_add(&c->ag_done, 1u, RLX, WG);
         const float v[4] = {__uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rb.x), __uint_as_float(rb.z)};
 #pragma unroll
         for (int i = 0; i < 4; i++) reinterpret_cast<float*>(xs)[sw_dword((int)(4u * q) + i)] = v[i];
