@@ -63,6 +63,18 @@ def test_encode_audio(tiny, T):
     assert rel_err(out[0], ref) < TOL, rel_err(out[0], ref)
 
 
+def test_encode_audio_conv_valu_cross_check_path(tiny, monkeypatch):
+    """VOX_CONV_VALU=1 (the conv stem as plain VALU kernels instead of the im2col MFMA GEMM -- a cross-check switch that ships in the library) against the
+    default path and the oracle."""
+    m, o, _ = tiny
+    mel = fake_mel(250, seed=3)
+    ref = o.encode_audio(mel); a = m.encode_audio(mel[None])
+    monkeypatch.setenv("VOX_CONV_VALU", "1")
+    b = m.encode_audio(mel[None])
+    monkeypatch.delenv("VOX_CONV_VALU")
+    assert rel_err(b[0], ref) < TOL and rel_err(a[0], b[0]) < TOL, (rel_err(b[0], ref), rel_err(a[0], b[0]))
+
+
 def test_encode_audio_too_short(tiny):
     m, o, _ = tiny
     out = m.encode_audio(fake_mel(9))            # S_enc = 3 -> 0 tokens

@@ -225,6 +225,22 @@ def test_attention_vs_oracle(pkg, orc, ctx, M, kv, H, KV, hd, off, win):
         attention(ctx, q, k, v, H, KV, offset=kv, window=win)       # queries outside the key range
 
 
+def test_attention_f32_switch_vs_oracle(pkg, orc, ctx, monkeypatch):
+    """VOX_ATTN_F32=1 (the all-f32 VALU attention kept beside the MFMA kernel as a cross-check) on the decoder-prefill and a windowed encoder shape."""
+    from importlib import import_module
+    attention = import_module(pkg.__name__ + ".gguf").attention
+    monkeypatch.setenv("VOX_ATTN_F32", "1")
+    for (M, kv, H, KV, hd, off, win) in [(38, 38, 8, 2, 128, 0, 8192), (130, 190, 2, 1, 64, 60, 64)]:
+        rng = np.random.default_rng(M)
+        q = (rng.standard_normal((M, H * hd)) * 1.5).astype(np.float32); k = (rng.standard_normal((kv, KV * hd)) * 1.5).astype(np.float32)
+        v = rng.standard_normal((kv, KV * hd)).astype(np.float32)
+        ref = np.zeros((M, H * hd), np.float32)
+        orc.lib().orc_attention(q, k, v, M, kv, H, KV, hd, off, 1, win, ref)
+        out = attention(ctx, q, k, v, H, KV, offset=off, window=win)
+        assert np.abs(out - ref).max() / np.abs(ref).max() < 2e-5
+    monkeypatch.delenv("VOX_ATTN_F32")
+
+
 @pytest.mark.parametrize("m,k,n", [(1001, 1280, 6144), (2344, 2048, 1280 + 48), (700, 5120, 10240)])
 def test_q4_gemm_big_kernel_matches_tile_kernel(pkg, orc, ctx, monkeypatch, m, k, n):
     """Large-M MFMA GEMM (64x256 tiles, tile-ordered weights, bit-trick B fragments + -136 correction MFMA) against the 32x128 kernel on

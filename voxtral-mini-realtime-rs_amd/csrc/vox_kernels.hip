@@ -2439,7 +2439,7 @@ static hipError_t attn_prefill_mfma_launch(const AttnParams& p, hipStream_t s, i
     return hipGetLastError();
 }
 hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n_seq) {
-    static const int f32_only = env_int("VOX_ATTN_F32");        // ablation / cross-check knob: the f32 VALU kernel
+    const int f32_only = env_int("VOX_ATTN_F32");               // ablation / cross-check knob: the f32 VALU kernel (read from the knob table per launch: tests toggle it)
     if (!f32_only && (p.q_stride % 4) == 0 && (p.kv_row_stride % 4) == 0) {
         if (hd == 64) return attn_prefill_mfma_launch<64>(p, s, n_seq);
         if (hd == 128) return attn_prefill_mfma_launch<128>(p, s, n_seq);
