@@ -305,6 +305,30 @@ def test_full_decode_engine_vs_per_operator_path(pkg, full, seconds, seed):
     assert np.array_equal(ids_g, ids_e) and np.array_equal(ids_og, ids_o)
 
 
+def test_full_decode_engine_lost_publish_times_out_loudly_and_falls_back(pkg, full, monkeypatch):
+    """Every wait inside the engine is bounded (20 ms): with one workgroup's publish suppressed (fault-injection flag 16384) the launch must END, the call must fail
+    loudly (not return wrong ids), and the model must keep working on the per-operator path afterwards -- with the ids of the healthy engine."""
+    m0, _, ctx = full
+    if not m0.set_decode_engine(True):
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    x = pkg.synth.synth_audio(2.0, seed=5); t = pkg.TimeEmbedding(3072).embed(6.0)
+    good = m0.transcribe_audio(x, t)
+    monkeypatch.setenv("VOX_ENGINE_FLAGS", str(128 | 512 | 1 | 16384))
+    path = os.path.join(cache_dir(), "full_q4_seed42.gguf")
+    b = pkg.Q4ModelLoader.from_file(path).load(ctx)
+    monkeypatch.delenv("VOX_ENGINE_FLAGS")
+    try:
+        import time
+        t0 = time.time()
+        with pytest.raises(pkg.VoxError, match="hand-off timeout"):
+            b.transcribe_audio(x, t)
+        assert time.time() - t0 < 30.0                                   # bounded: a few 20 ms waits per launch, not a hang
+        assert not b.set_decode_engine(True)                             # the engine stays off for this model
+        assert np.array_equal(b.transcribe_audio(x, t), good)            # per-operator path
+    finally:
+        b.close()
+
+
 def test_full_layout_only_arena_copy_start_up(pkg, full):
     """What ranks > 0 do at multi-GPU start-up, at full size on one GPU: VOX_LOAD_LAYOUT_ONLY model (no tensor data read) + the PRIMARY part of rank 0's arena
     copied in (the RCCL broadcast's payload: 2.5 GB, the Q4 row planes -- not the 5 GB with the tile-ordered copies) + vox_model_arena_finalize => the same 108 ids as the

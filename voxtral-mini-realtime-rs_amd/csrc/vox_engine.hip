@@ -471,7 +471,8 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
 #pragma unroll 4
                 for (int hh = 0; hh < NPW; hh++) a += tmp[hh * OWN + r];      // fixed order
                 wait_ge(&c->gw_flag, 1u, c, p.err, ERR_STAGE);
-                comm_publish_rows(p, lane, c->h_own[r] + a, gwt[(l * 2 + 1) * 16 + r], p.H1, p.SS1, tag, c->h1_own);
+                if (!((p.flags & 16384) && blockIdx.x == 7 && l == 1))      // (flag 16384 = FAULT INJECTION for the test of the bounded waits: workgroup 7 loses a publish)
+                    comm_publish_rows(p, lane, c->h_own[r] + a, gwt[(l * 2 + 1) * 16 + r], p.H1, p.SS1, tag, c->h1_own);
             }
             if (T) tl(10);
         } else {
