@@ -95,6 +95,7 @@ struct vox_ctx {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // XF tiles of a 17..48-row GEMM input (the 38-token prefill): 3 tiles x K columns x 64 B; sized once for K <= 16384, reused by every such GEMM of the stream
     uint16_t* xf_scratch = nullptr; size_t xf_scratch_bytes = 0;
+    float* kz_scratch = nullptr; size_t kz_scratch_bytes = 0;      // K-slice planes of the 17..48-row GEMMs (q4_skinny_mt2_kernel): 8 x 48 x 18432 floats
 };
 
 static int32_t ctx_bind(const vox_ctx* c) { HIPCHK(hipSetDevice(c->device)); return VOX_OK; }
@@ -120,6 +121,7 @@ extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
         if (p) (void)hipFree(p);
     for (auto& e : c->pool) (void)hipFree(e.p);
     if (c->xf_scratch) (void)hipFree(c->xf_scratch);
+    if (c->kz_scratch) (void)hipFree(c->kz_scratch);
     for (int i = 0; i < 3; i++) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     (void)hipStreamDestroy(c->stream);
@@ -552,6 +554,8 @@ static int32_t q4_linear_dev(vox_ctx* c, const Q4W& w, const float* bias, const 
         if (rows > 16 && rows <= 48 && w.fmt == WFMT_Q4_0 && w.K <= 16384) {      // the prefill GEMMs: rows -> XF tiles once (launch_q4_skinny_mt)
             if (!c->xf_scratch) { c->xf_scratch_bytes = (size_t)3 * 16384 * 64; if (hipMalloc((void**)&c->xf_scratch, c->xf_scratch_bytes) != hipSuccess) { (void)hipGetLastError(); c->xf_scratch = nullptr; c->xf_scratch_bytes = 0; } }
             p.xf_scratch = c->xf_scratch; p.xf_scratch_bytes = c->xf_scratch_bytes;
+            if (!c->kz_scratch) { c->kz_scratch_bytes = (size_t)8 * 48 * 18432 * 4; if (hipMalloc((void**)&c->kz_scratch, c->kz_scratch_bytes) != hipSuccess) { (void)hipGetLastError(); c->kz_scratch = nullptr; c->kz_scratch_bytes = 0; } }
+            p.kz_scratch = c->kz_scratch; p.kz_scratch_bytes = c->kz_scratch_bytes;
         }
         HIPCHK(launch_q4_gemm(p, epi, c->stream));
     }
@@ -1407,6 +1411,8 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
     }
     auto linear_xf = [&](const Q4W& w, float* out, int out_stride, int epi) -> int32_t {
         GemmParams p{}; p.w = w; p.xf = reinterpret_cast<const uint4*>(cx->xf_scratch); p.M = M; p.out = out; p.out_stride = out_stride;
+        if (!cx->kz_scratch) { cx->kz_scratch_bytes = (size_t)8 * 48 * 18432 * 4; if (hipMalloc((void**)&cx->kz_scratch, cx->kz_scratch_bytes) != hipSuccess) { (void)hipGetLastError(); cx->kz_scratch = nullptr; cx->kz_scratch_bytes = 0; } }
+        p.kz_scratch = cx->kz_scratch; p.kz_scratch_bytes = cx->kz_scratch_bytes;
         HIPCHK(launch_q4_gemm(p, epi, s)); return VOX_OK;
     };
     for (int l = 0; l < c.dec_layers; l++) {

@@ -83,6 +83,7 @@ struct GemmParams {
     // split-K (q4_gemm_kernel only, EPI_STORE): blockIdx.z = K slice; slice z writes its partial product to out + z * M * out_stride (bias in slice 0).
     // The consumer (launch_rms_norm_sumk) adds the slices in a fixed order -- for few-column GEMMs (the encoder's N = 1280 w2: 40 K-steps per workgroup)
     int ksplit;
+    float* kz_scratch; size_t kz_scratch_bytes;      // 17..48 rows: room for the K-slice planes of q4_skinny_mt2_kernel ([ksplit][M][N] f32); null: the one-dimensional kernel
 };
 hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);

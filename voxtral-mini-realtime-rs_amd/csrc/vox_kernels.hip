@@ -1533,6 +1533,135 @@ __global__ __launch_bounds__(256) void q4_skinny_mt_kernel(const GemmParams p) {
         }
     }
 }
+// ---- 17..48 rows, TWO-DIMENSIONAL decomposition (round 3): the kernel above gives every workgroup one n-tile and ALL of K, so each of the 192..576 workgroups
+// re-reads the whole XF activation block from L2 (221 MB of L2 -> L1 for the 10.6 MB q|k|v, 354 MB for w1|w3: the launches are L2-bandwidth-bound at 12 TB/s,
+// profiles/r02_pmc_prefill.txt).  Here a workgroup = 4 * NTW n-tiles (one per wave) x ONE K slice (blockIdx.y of p.ksplit): its four waves walk the SAME K steps, so
+// the XF lines they request are the same lines (one L2 read per workgroup and step), and the activation traffic drops by the number of K slices.  Slice z writes its
+// partial sums to plane z; splitk_finish_kernel adds the planes in a fixed order and applies the epilogue.
+template <int MT, int NTW>
+__global__ __launch_bounds__(256) void q4_skinny_mt2_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 xlds[];      // [buf 2][fragment MT * 8][64 lanes]: the XF block of one K step, shared by the four waves
+    constexpr int NF = MT * 8, FPW = NF / 4;                          // fragments per step (m-tile, block j, hi / lo), per wave
+    const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int n_tiles = (N + 15) >> 4, tile0 = (blockIdx.x * 4 + wave) * NTW;
+    const int KZ = p.ksplit > 1 ? p.ksplit : 1, kz = blockIdx.y;
+    const int q0 = (int)((long)nq * kz / KZ), q1 = (int)((long)nq * (kz + 1) / KZ);
+    const uint4* wq[NTW]; const uint16_t* ws[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const size_t T = (size_t)min(tile0 + t, n_tiles - 1);
+        wq[t] = p.w.qt + T * nq * 64 + lane; ws[t] = p.w.st + (T * nq * 16 + li) * 4;
+    }
+    // this wave's share of a step's XF block: fragments f = wave + 4 i -> (m-tile f / 8, block (f % 8) / 2, hi / lo f % 2)
+    const uint4* xsrc[FPW];
+#pragma unroll
+    for (int i = 0; i < FPW; i++) { const int f = wave + 4 * i, mt = f >> 3, j = (f & 7) >> 1, hl = f & 1; xsrc[i] = p.xf + (size_t)mt * 2 * nq * 256 + (size_t)hl * nq * 256 + j * 64 + lane; }
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 m136 = as_bf16x8(make_uint4(0xC308C308u, 0xC308C308u, 0xC308C308u, 0xC308C308u));
+    uint4 wv[NTW]; uint2 sv[NTW]; uint4 xr[FPW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) { wv[t] = ld_nt_u4(wq[t] + 64 * q0); sv[t] = *reinterpret_cast<const uint2*>(ws[t] + 64 * q0); }
+#pragma unroll
+    for (int i = 0; i < FPW; i++) xr[i] = xsrc[i][(size_t)q0 * 256];
+#pragma unroll
+    for (int i = 0; i < FPW; i++) xlds[(wave + 4 * i) * 64 + lane] = xr[i];
+    __syncthreads();
+    for (int q = q0; q < q1; q++) {
+        const int buf = (q - q0) & 1;
+        uint4 wn[NTW]; uint2 sn[NTW];
+        const int qn = min(q + 1, q1 - 1);
+#pragma unroll
+        for (int t = 0; t < NTW; t++) { wn[t] = ld_nt_u4(wq[t] + 64 * qn); sn[t] = *reinterpret_cast<const uint2*>(ws[t] + 64 * qn); }   // next step's weights and activations in flight first
+#pragma unroll
+        for (int i = 0; i < FPW; i++) xr[i] = xsrc[i][(size_t)qn * 256];
+        bf16x8 bw[NTW][4]; float dsc[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            const uint32_t dw[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w}; const uint32_t sc2[2] = {sv[t].x, sv[t].y};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bw[t][j] = as_bf16x8(q4_dword_to_bf16x8_biased(dw[j]));
+                dsc[t][j] = f16_bits_to_f32((uint16_t)((j & 1) ? (sc2[j >> 1] >> 16) : (sc2[j >> 1] & 0xFFFFu)));
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bf16x8 ah = as_bf16x8(xlds[(buf * NF + mt * 8 + j * 2) * 64 + lane]), al = as_bf16x8(xlds[(buf * NF + mt * 8 + j * 2 + 1) * 64 + lane]);
+                f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, m136, cs, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTW; t++) {
+                    f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bw[t][j], cs, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw[t][j], tt, 0, 0, 0);
+                    const float d = dsc[t][j];
+                    acc[mt][t] = __builtin_elementwise_fma((f32x4){d, d, d, d}, tt, acc[mt][t]);
+                }
+            }
+        }
+        if (q + 1 < q1) {
+#pragma unroll
+            for (int i = 0; i < FPW; i++) xlds[((buf ^ 1) * NF + wave + 4 * i) * 64 + lane] = xr[i];
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; t++) { wv[t] = wn[t]; sv[t] = sn[t]; }
+        __syncthreads();
+    }
+    float* plane = p.out + (size_t)kz * M * N;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            const int n = (tile0 + t) * 16 + li;
+            if (tile0 + t < n_tiles && n < N) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const int m = mt * 16 + 4 * g + r; if (m < M) plane[(size_t)m * N + n] = acc[mt][t][r]; }
+            }
+        }
+}
+// sum of the K-slice planes (fixed order) + bias, then the GEMM's epilogue
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ planes, int KZ, int M, int N, const float* __restrict__ bias,
+                                                           const float* __restrict__ resid, int resid_stride, float* __restrict__ out, int out_stride) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float v = planes[i];
+        for (int k = 1; k < KZ; k++) v += planes[(size_t)k * total + i];
+        if (bias) v += bias[n];
+        if (EPI == EPI_SWIGLU) {
+            const float other = dpp_mov<0xB1>(v);        // lane ^ 1: rows interleaved, even n = gate, odd n = up (N is even, so a pair never straddles a row)
+            if (!(n & 1)) out[(size_t)m * out_stride + (n >> 1)] = silu_f(v) * other;
+        } else {
+            if (EPI == EPI_RESID) v = v + resid[(size_t)m * resid_stride + n];
+            if (EPI == EPI_GELU) v = gelu_f(v);
+            out[(size_t)m * out_stride + n] = v;
+        }
+    }
+}
+template <int MT, int NTW>
+static hipError_t skinny_mt2_launch(const GemmParams& p_in, int epi, int KZ, hipStream_t s) {
+    GemmParams p = p_in; p.ksplit = KZ; p.out = p_in.kz_scratch;
+    const int n_tiles = (p.w.N + 15) / 16;
+    q4_skinny_mt2_kernel<MT, NTW><<<dim3((n_tiles + 4 * NTW - 1) / (4 * NTW), KZ), dim3(256), (size_t)2 * MT * 8 * 64 * 16, s>>>(p);
+    hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
+    const long total = (long)p.M * p.w.N; const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+    switch (epi) {
+    case EPI_STORE: splitk_finish_kernel<EPI_STORE><<<blocks, 256, 0, s>>>(p_in.kz_scratch, KZ, p.M, p.w.N, p.bias, nullptr, 0, p_in.out, p_in.out_stride); break;
+    case EPI_RESID: splitk_finish_kernel<EPI_RESID><<<blocks, 256, 0, s>>>(p_in.kz_scratch, KZ, p.M, p.w.N, p.bias, p.resid, p.resid_stride, p_in.out, p_in.out_stride); break;
+    case EPI_GELU: splitk_finish_kernel<EPI_GELU><<<blocks, 256, 0, s>>>(p_in.kz_scratch, KZ, p.M, p.w.N, p.bias, nullptr, 0, p_in.out, p_in.out_stride); break;
+    case EPI_SWIGLU: splitk_finish_kernel<EPI_SWIGLU><<<blocks, 256, 0, s>>>(p_in.kz_scratch, KZ, p.M, p.w.N, p.bias, nullptr, 0, p_in.out, p_in.out_stride); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 template <int MT, int NTW>
 static hipError_t skinny_mt_launch(const GemmParams& p, int epi, hipStream_t s) {
     dim3 grid((p.w.N + 16 * NTW - 1) / (16 * NTW));
@@ -1568,6 +1697,17 @@ static hipError_t launch_q4_skinny_mt(const GemmParams& p_in, int epi, hipStream
     }
     int ntw = tiles >= 512 ? 2 : 1;                           // two n-tiles per wave only while >= 256 workgroups remain
     { const int e = env_int("VOX_SKINNY_MT_NTW"); if (e == 1 || e == 2) ntw = e; }
+    // two-dimensional form (q4_skinny_mt2_kernel): K slices so that >= 384 workgroups remain; needs the XF tiles and room for the planes.  VOX_SKINNY_MT2=-1: off
+    if (p.xf && p.kz_scratch && p.w.N % 2 == 0 && env_int("VOX_SKINNY_MT2") >= 0) {
+        const int nq = p.w.nb / 4, wg1 = (tiles + 4 * ntw - 1) / (4 * ntw);
+        int KZ = std::min(std::min(8, nq), std::max(1, (384 + wg1 - 1) / wg1));
+        { const int e = env_int("VOX_SKINNY_MT2"); if (e > 0) KZ = std::min(e, nq); }
+        if ((size_t)KZ * p.M * p.w.N * 4 <= p.kz_scratch_bytes) {
+#define VOX_MT2(M_, N_) if (mt == M_ && ntw == N_) return skinny_mt2_launch<M_, N_>(p, epi, KZ, s)
+            VOX_MT2(2, 1); VOX_MT2(2, 2); VOX_MT2(3, 1); VOX_MT2(3, 2);
+#undef VOX_MT2
+        }
+    }
 #define VOX_MTN(M_, N_) if (mt == M_ && ntw == N_) return skinny_mt_launch<M_, N_>(p, epi, s)
     VOX_MTN(2, 1); VOX_MTN(2, 2); VOX_MTN(3, 1); VOX_MTN(3, 2);
 #undef VOX_MTN
