@@ -1699,6 +1699,7 @@ static hipError_t launch_q4_skinny_mt(const GemmParams& p_in, int epi, hipStream
     { const int e = env_int("VOX_SKINNY_MT_NTW"); if (e == 1 || e == 2) ntw = e; }
     // two-dimensional form (q4_skinny_mt2_kernel): K slices so that >= 384 workgroups remain; needs the XF tiles and room for the planes.  VOX_SKINNY_MT2=-1: off
     if (p.xf && p.kz_scratch && p.w.N % 2 == 0 && env_int("VOX_SKINNY_MT2") >= 0) {
+        if (!env_int("VOX_SKINNY_MT_NTW")) ntw = 1;      // one n-tile per wave here (w1|w3 with two: 3.32 vs 3.23 ms per prefill, profiles/r03_prefill_2d_kernel.txt)
         const int nq = p.w.nb / 4, wg1 = (tiles + 4 * ntw - 1) / (4 * ntw);
         int KZ = std::min(std::min(8, nq), std::max(1, (384 + wg1 - 1) / wg1));
         { const int e = env_int("VOX_SKINNY_MT2"); if (e > 0) KZ = std::min(e, nq); }
