@@ -1404,7 +1404,8 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
     // 17..48 rows in one sequence (the 38-token prefill): both RMSNorms write their output straight as XF tiles (the MFMA A-fragments the
     // q4_skinny_mt_kernel consumes) into the context's XF scratch -- no f32 xn, no conversion launch for q|k|v and w1|w3
     auto xf_ok = [&](const Q4W& w) { return w.fmt == WFMT_Q4_0 && w.qt && w.st && w.nb % 4 == 0 && w.K == D && D % 128 == 0 && D <= 10240; };
-    bool norm_xf = n_seq == 1 && M > 16 && M <= 48 && knob_str("VOX_PREFILL_NO_NORM_XF") == nullptr;
+    bool norm_xf = n_seq == 1 && M > 16 && M <= 48 && knob_str("VOX_PREFILL_NO_NORM_XF") == nullptr &&
+                   knob_str("VOX_NO_SKINNY_MT") == nullptr && knob_str("VOX_PREFILL_KERNEL") == nullptr;      // (the kernel-selection knobs of tools/prefill_bench.py act on f32-row GEMMs)
     if (norm_xf) {
         if (!cx->xf_scratch) { cx->xf_scratch_bytes = (size_t)3 * 16384 * 64; if (hipMalloc((void**)&cx->xf_scratch, cx->xf_scratch_bytes) != hipSuccess) { (void)hipGetLastError(); cx->xf_scratch = nullptr; cx->xf_scratch_bytes = 0; } }
         norm_xf = cx->xf_scratch != nullptr;
@@ -1415,12 +1416,25 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
         p.kz_scratch = cx->kz_scratch; p.kz_scratch_bytes = cx->kz_scratch_bytes;
         HIPCHK(launch_q4_gemm(p, epi, s)); return VOX_OK;
     };
+    // wo / w2 (EPI_RESID) as two-dimensional GEMMs whose K-slice planes are summed by the RMSNorm that follows (one launch less per GEMM): `pend` = slices of the
+    // previous layer's w2 still waiting in the plane buffer.  VOX_PREFILL_NO_SUMK=1: finishing kernels instead.
+    const bool fuse_fin = norm_xf && knob_str("VOX_PREFILL_NO_SUMK") == nullptr;
+    auto planes_gemm = [&](const Q4W& w, const float* in, int K, int KZ) -> int32_t {      // in [M][K] f32 -> XF tiles -> planes
+        HIPCHK(launch_xf_rows(in, K, M, K, cx->xf_scratch, s));
+        GemmParams p{}; p.w = w; p.xf = reinterpret_cast<const uint4*>(cx->xf_scratch); p.M = M; p.kz_scratch = cx->kz_scratch; p.kz_scratch_bytes = cx->kz_scratch_bytes;
+        HIPCHK(launch_q4_skinny_mt2_planes(p, KZ, s)); return VOX_OK;
+    };
+    if (fuse_fin && !cx->kz_scratch) { cx->kz_scratch_bytes = (size_t)8 * 48 * 18432 * 4; if (hipMalloc((void**)&cx->kz_scratch, cx->kz_scratch_bytes) != hipSuccess) { (void)hipGetLastError(); cx->kz_scratch = nullptr; cx->kz_scratch_bytes = 0; } }
+    int pend = 0;
     for (int l = 0; l < c.dec_layers; l++) {
         const DecLayer& L = m->dec[l]; float* kl = kc->k + (size_t)l * lf; float* vl = kc->v + (size_t)l * lf;
         if (norm_xf && xf_ok(L.wqkv.w)) {
-            HIPCHK(launch_rms_norm_xf(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, cx->xf_scratch, s));
+            if (pend) HIPCHK(launch_rms_norm_xf_sumk(x, D, M, D, cx->kz_scratch, pend, L.attn_norm, nullptr, c.norm_eps, cx->xf_scratch, s));      // + the previous layer's w2
+            else HIPCHK(launch_rms_norm_xf(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, cx->xf_scratch, s));
+            pend = 0;
             VOXCHK(linear_xf(L.wqkv.w, qkv, W, EPI_STORE));
         } else {
+            if (pend) { HIPCHK(launch_splitk_finish_resid(cx->kz_scratch, pend, M, D, x, D, s)); pend = 0; }
             HIPCHK(launch_rms_norm(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
             VOXCHK(q4_linear_dev(cx, L.wqkv.w, nullptr, xn, D, M, qkv, W));
         }
@@ -1430,16 +1444,27 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
         ap.out = att; ap.out_stride = QD; ap.M = Mq; ap.kv_len = off + Mq; ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = off; ap.window = c.dec_window;
         ap.q_seq_stride = seq_rows * W; ap.out_seq_stride = seq_rows * QD; ap.kv_seq_stride = kv_seq_stride;
         HIPCHK(launch_attn_prefill(ap, hd, s, n_seq));
-        VOXCHK(q4_linear_dev(cx, L.wo.w, nullptr, att, QD, M, x, D, EPI_RESID, x, D));
-        if (norm_xf && xf_ok(L.w13.w)) {
-            HIPCHK(launch_rms_norm_xf(x, D, M, D, L.ffn_norm, L.ada_mul, c.norm_eps, cx->xf_scratch, s));    // norm then Ada x*(1+s) (model.rs:382-385)
+        const int kz_wo = fuse_fin && cx->kz_scratch && xf_ok(L.w13.w) && L.wo.w.N == D && QD % 128 == 0 ? q4_skinny_mt2_plan(L.wo.w, M) : 0;
+        if (kz_wo && (size_t)kz_wo * M * D * 4 <= cx->kz_scratch_bytes) {
+            VOXCHK(planes_gemm(L.wo.w, att, QD, kz_wo));
+            HIPCHK(launch_rms_norm_xf_sumk(x, D, M, D, cx->kz_scratch, kz_wo, L.ffn_norm, L.ada_mul, c.norm_eps, cx->xf_scratch, s));      // x += wo(att); norm then Ada x*(1+s) (model.rs:382-385)
             VOXCHK(linear_xf(L.w13.w, ffn, F, EPI_SWIGLU));
         } else {
-            HIPCHK(launch_rms_norm(x, D, M, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));    // norm then Ada x*(1+s) (model.rs:382-385)
-            VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, M, ffn, F, EPI_SWIGLU));
+            VOXCHK(q4_linear_dev(cx, L.wo.w, nullptr, att, QD, M, x, D, EPI_RESID, x, D));
+            if (norm_xf && xf_ok(L.w13.w)) {
+                HIPCHK(launch_rms_norm_xf(x, D, M, D, L.ffn_norm, L.ada_mul, c.norm_eps, cx->xf_scratch, s));    // norm then Ada x*(1+s) (model.rs:382-385)
+                VOXCHK(linear_xf(L.w13.w, ffn, F, EPI_SWIGLU));
+            } else {
+                HIPCHK(launch_rms_norm(x, D, M, D, L.ffn_norm, L.ada_mul, c.norm_eps, xn, D, s));    // norm then Ada x*(1+s) (model.rs:382-385)
+                VOXCHK(q4_linear_dev(cx, L.w13.w, nullptr, xn, D, M, ffn, F, EPI_SWIGLU));
+            }
         }
-        VOXCHK(q4_linear_dev(cx, L.w2.w, nullptr, ffn, F, M, x, D, EPI_RESID, x, D));
+        const int kz_w2 = fuse_fin && cx->kz_scratch && L.w2.w.N == D && F % 128 == 0 && F <= 16384 ? q4_skinny_mt2_plan(L.w2.w, M) : 0;
+        if (kz_w2 && (size_t)kz_w2 * M * D * 4 <= cx->kz_scratch_bytes && (l + 1 == c.dec_layers || xf_ok(m->dec[l + 1].wqkv.w))) {
+            VOXCHK(planes_gemm(L.w2.w, ffn, F, kz_w2)); pend = kz_w2;
+        } else VOXCHK(q4_linear_dev(cx, L.w2.w, nullptr, ffn, F, M, x, D, EPI_RESID, x, D));
     }
+    if (pend) HIPCHK(launch_splitk_finish_resid(cx->kz_scratch, pend, M, D, x, D, s));      // the last layer's w2
     return VOX_OK;
 }
 

@@ -99,6 +99,12 @@ hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, cons
                            float eps, float* out, int out_stride, hipStream_t s);
 // x[row] += sum of ksplit partial planes (fixed order; plane stride = part_stride floats), written back, then RMSNorm -> out (dim <= 4096, dim % 4 == 0)
 hipError_t launch_rms_norm_sumk(float* x, int x_stride, int rows, int dim, const float* part, size_t part_stride, int ksplit, const float* gamma, float eps, float* out, int out_stride, hipStream_t s);
+// pieces of the two-dimensional 17..48-row GEMM (q4_skinny_mt2_kernel) for callers that fold the finishing sum of the K-slice planes into their next kernel
+int q4_skinny_mt2_plan(const Q4W& w, int M);                                                                  // K slices, 0 = not applicable
+hipError_t launch_xf_rows(const float* x, int x_stride, int M, int K, uint16_t* xf, hipStream_t s);        // f32 rows -> XF tiles
+hipError_t launch_q4_skinny_mt2_planes(const GemmParams& p, int KZ, hipStream_t s);                         // p.xf in, planes [KZ][M][N] -> p.kz_scratch
+hipError_t launch_splitk_finish_resid(const float* planes, int KZ, int M, int N, float* x, int x_stride, hipStream_t s);
+hipError_t launch_rms_norm_xf_sumk(float* x, int x_stride, int rows, int dim, const float* planes, int kz, const float* gamma, const float* mul, float eps, uint16_t* xf, hipStream_t s);
 hipError_t launch_rms_norm_xf(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul,
                               float eps, uint16_t* xf, hipStream_t s);   // rows <= 16 -> XF fragment planes
 // interleaved-pair RoPE in place on columns [0, n_rot) of buf[M][stride]; row m has position pos_off + m

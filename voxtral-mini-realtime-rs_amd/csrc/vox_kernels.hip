@@ -1685,6 +1685,34 @@ static hipError_t skinny_mt_launch(const GemmParams& p, int epi, hipStream_t s) 
     }
     return hipGetLastError();
 }
+// The pieces of the two-dimensional 17..48-row GEMM for callers that fold the finishing sum into their next kernel (the decoder prefill):
+int q4_skinny_mt2_plan(const Q4W& w, int M) {      // K slices the 2-D kernel would use for this operator, 0 = not applicable
+    if (w.fmt != WFMT_Q4_0 || !w.qt || !w.st || w.nb % 4 || w.N % 2 || M <= 16 || M > 48 || env_int("VOX_SKINNY_MT2") < 0) return 0;
+    const int tiles = (w.N + 15) / 16, nq = w.nb / 4, wg1 = (tiles + 3) / 4;
+    int KZ = std::min(std::min(8, nq), std::max(1, (384 + wg1 - 1) / wg1));
+    { const int e = env_int("VOX_SKINNY_MT2"); if (e > 0) KZ = std::min(e, nq); }
+    return KZ;
+}
+hipError_t launch_xf_rows(const float* x, int x_stride, int M, int K, uint16_t* xf, hipStream_t s) {      // f32 rows -> ceil(M / 16) XF tiles
+    const int mt = (M + 15) / 16; const long total = (long)mt * 16 * (K >> 2);
+    if (K % 128) return hipErrorInvalidValue;
+    xf_rows_kernel<<<dim3((unsigned)std::min<long>((total + 255) / 256, 1024)), dim3(256), 0, s>>>(x, x_stride, M, K, xf, mt);
+    return hipGetLastError();
+}
+hipError_t launch_q4_skinny_mt2_planes(const GemmParams& p_in, int KZ, hipStream_t s) {      // p.xf = the input tiles; writes planes [KZ][M][N] to p.kz_scratch, no epilogue
+    GemmParams p = p_in; p.ksplit = KZ; p.out = p_in.kz_scratch;
+    const int mt = (p.M + 15) / 16, n_tiles = (p.w.N + 15) / 16;
+    if (!p.xf || !p.kz_scratch || (size_t)KZ * p.M * p.w.N * 4 > p.kz_scratch_bytes || KZ < 1) return hipErrorInvalidValue;
+    if (mt == 2) q4_skinny_mt2_kernel<2, 1><<<dim3((n_tiles + 3) / 4, KZ), dim3(256), (size_t)2 * 2 * 8 * 64 * 16, s>>>(p);
+    else if (mt == 3) q4_skinny_mt2_kernel<3, 1><<<dim3((n_tiles + 3) / 4, KZ), dim3(256), (size_t)2 * 3 * 8 * 64 * 16, s>>>(p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_splitk_finish_resid(const float* planes, int KZ, int M, int N, float* x, int x_stride, hipStream_t s) {      // x += sum of the planes
+    const long total = (long)M * N;
+    splitk_finish_kernel<EPI_RESID><<<(int)std::min<long>((total + 255) / 256, 2048), 256, 0, s>>>(planes, KZ, M, N, nullptr, x, x_stride, x, x_stride);
+    return hipGetLastError();
+}
 // 17..48 rows, tile-ordered Q4 weights, K % 128 == 0, 16-byte aligned f32 rows
 static hipError_t launch_q4_skinny_mt(const GemmParams& p_in, int epi, hipStream_t s) {
     GemmParams p = p_in;
@@ -2168,9 +2196,12 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(const float* __restrict__
 #undef VOX_RMS_OUT
 }
 // few rows (batched decode: one row per sequence): one 256-thread workgroup per row, every load issued at once
+// planes != nullptr: the row first takes the sum of `kz` split-K partial planes ([kz][rows][dim], fixed order) -- the finishing step of q4_skinny_mt2_kernel's
+// EPI_RESID GEMMs folded into the norm that follows them -- and is written back to x_rw.
 __global__ __launch_bounds__(256) void rms_norm_row_kernel(const float* __restrict__ x, int x_stride, int dim, const float* __restrict__ gamma,
                                                            const float* __restrict__ mul, float eps, float* __restrict__ out, int out_stride,
-                                                           uint16_t* __restrict__ xf) {
+                                                           uint16_t* __restrict__ xf, const float* __restrict__ planes = nullptr, size_t plane_stride = 0, int kz = 0,
+                                                           float* __restrict__ x_rw = nullptr) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x, n4 = dim >> 2;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
@@ -2179,6 +2210,10 @@ __global__ __launch_bounds__(256) void rms_norm_row_kernel(const float* __restri
     for (int i = 0; i < 10; i++) {
         const int c = tid + 256 * i;
         v[i] = xr[min(c, n4 - 1)];
+        if (planes && c < n4) {
+            for (int k = 0; k < kz; k++) { const float4 t = reinterpret_cast<const float4*>(planes + (size_t)k * plane_stride + (size_t)row * dim)[c]; v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w; }
+            reinterpret_cast<float4*>(x_rw + (size_t)row * x_stride)[c] = v[i];
+        }
         if (c < n4) ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
     ss = wave_sum(ss);
@@ -2234,6 +2269,12 @@ hipError_t launch_rms_norm_sumk(float* x, int x_stride, int rows, int dim, const
     return hipGetLastError();
 }
 // same as launch_rms_norm, but the normalised rows (<= 16) go straight into the XF fragment planes of the following batched-decode GEMM
+hipError_t launch_rms_norm_xf_sumk(float* x, int x_stride, int rows, int dim, const float* planes, int kz, const float* gamma, const float* mul, float eps,
+                                   uint16_t* xf, hipStream_t s) {
+    if (rows > 48 || dim > 10240 || dim % 128 || kz < 1 || !planes) return hipErrorInvalidValue;
+    rms_norm_row_kernel<<<dim3(rows), dim3(256), 0, s>>>(x, x_stride, dim, gamma, mul, eps, nullptr, 0, xf, planes, (size_t)rows * dim, kz, x);
+    return hipGetLastError();
+}
 hipError_t launch_rms_norm_xf(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul, float eps,
                               uint16_t* xf, hipStream_t s) {
     if (rows > 48 || dim > 10240 || dim % 128) return hipErrorInvalidValue;      // up to three XF tiles (the 38-token prefill); rows of the last tile past `rows` keep their old contents
