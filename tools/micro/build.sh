@@ -1,9 +1,10 @@
 #!/bin/bash
 # Cross-compiles the micro-benchmarks for gfx950 (no GPU needed); the binaries travel to the GPU box with the gpurun snapshot.
 cd "$(dirname "$0")"
-for f in chain_floor gridbar_bench overlap_chain atomic_reduce; do
+for f in chain_floor gridbar_bench overlap_chain atomic_reduce edge_pingpong edge_fanin; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $f $f.hip 2>&1 | grep -v "argument unused" ; echo "built $f"
 done
+for f in mfma_fp8_dot mfma_i8_dot; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o $f $f.hip 2>&1 | grep -v "argument unused"; echo "built $f"; done
 # engine_bench links the product's kernel objects (python voxtral-mini-realtime-rs_amd/build.py first)
 B=../../voxtral-mini-realtime-rs_amd/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -c -o engine_bench.o engine_bench.hip 2>&1 | grep -v "argument unused"
