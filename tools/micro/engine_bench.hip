@@ -122,7 +122,8 @@ static void report(const char* what, const std::vector<float>& ref, const std::v
 int main(int argc, char** argv) {
     const int n_layers = argc > 1 ? atoi(argv[1]) : 26, pos = argc > 2 ? atoi(argv[2]) : 100, reps = argc > 3 ? atoi(argv[3]) : 40, tl_layer = argc > 4 ? atoi(argv[4]) : -1, flags = argc > 5 ? atoi(argv[5]) : 0, pace = argc > 6 ? atoi(argv[6]) : 0;
     const int lpace = argc > 8 ? atoi(argv[8]) : -1;      // explicit loader pace (10-ns ticks between packet issues) next to an all-gather delay
-    const int max_seq = 256, window = 8192;
+    const int max_seq = pos < 248 ? 256 : ((pos + 8 + 63) / 64) * 64, window = 8192;
+    if (max_seq > 1024) { printf("pos %d: the engine holds at most 1024 cache rows\n", pos); return 1; }
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     printf("flags %d pace %d; ", flags, pace); printf("device %s, %d CUs; n_layers %d pos %d reps %d; engine LDS %d bytes, stream %.1f MB\n", prop.name, prop.multiProcessorCount, n_layers, pos, reps, eng_lds_bytes(),
            eng_stream_bytes(n_layers, V) / 1e6);

@@ -886,14 +886,24 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                     const int i = ks + 96 * u;
                     if (part_ == 0 && i < n_old) sc[i] = sv * scale;
                 }
-                for (int i0 = 96 * NKP; i0 < n_old; i0 += 96) {      // later keys
-                    const int i = i0 + ks;
-                    float4 kk[4];
-                    const unsigned ko = (unsigned)(j_lo + min(i, last_old)) * EHD + part_ * 16;
+                for (int i0 = 96 * NKP; i0 < n_old; i0 += 96 * NKP) {      // later keys, 192 per round: ALL loads of a round first (one exposed round trip per 192 keys, not per 96)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) kk[e] = ldg4(kc + (ko + 4 * e));
-                    const float sv = dot16(kk);
-                    if (part_ == 0 && i < n_old) sc[i] = sv * scale;
+                    for (int u = 0; u < NKP; u++) {
+                        const int i = i0 + ks + 96 * u;
+                        const unsigned ko = (unsigned)(j_lo + min(i, last_old)) * EHD + part_ * 16;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) kpre[u][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (i < n_old) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) kpre[u][e] = ldg4(kc + (ko + 4 * e));
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < NKP; u++) {
+                        const float sv = dot16(kpre[u]);
+                        const int i = i0 + ks + 96 * u;
+                        if (part_ == 0 && i < n_old) sc[i] = sv * scale;
+                    }
                 }
                 if (cw == 0) {                                       // the new key (this step's k row)
                     float4 kk[4];
@@ -920,10 +930,22 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                     const float pr_ = rlf(pv, u); const float2 vv = vpre[u];      // rows that do not exist: weight 0, value 0
                     o.x = fmaf(pr_, vv.x, o.x); o.y = fmaf(pr_, vv.y, o.y); lsum += pr_;
                 }
-                for (int i = 192 + cw; i < n_old; i += 12) {
-                    const fv2 v = *(const __attribute__((address_space(1))) fv2*)(vc + ((unsigned)(j_lo + i) * EHD + lane * 2));
-                    const float pr_ = expf(sc[i] - mx);
-                    o.x = fmaf(pr_, v.x, o.x); o.y = fmaf(pr_, v.y, o.y); lsum += pr_;
+                for (int b0 = 192; b0 < n_old; b0 += 192) {      // later keys, 16 per wave and round: all of a round's rows requested at once, one exponential per key (lane = key)
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        vpre[u] = make_float2(0.f, 0.f);
+                        if (b0 + cw + 12 * u < n_old) {
+                            const fv2 v = *(const __attribute__((address_space(1))) fv2*)(vc + ((unsigned)(j_lo + b0 + cw + 12 * u) * EHD + lane * 2));
+                            vpre[u] = make_float2(v.x, v.y);
+                        }
+                    }
+                    const int ib = b0 + cw + 12 * (lane & 15);
+                    const float pb = ib < n_old ? expf(sc[ib] - mx) : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const float pr_ = rlf(pb, u); const float2 vv = vpre[u];
+                        o.x = fmaf(pr_, vv.x, o.x); o.y = fmaf(pr_, vv.y, o.y); lsum += pr_;
+                    }
                 }
                 if (cw == 0) {
                     const float pr_ = expf(sc[n_old] - mx); const float2 vv = *reinterpret_cast<const float2*>(qkvn + 256 + lane * 2);
