@@ -7,23 +7,24 @@
 // themselves are 8-byte {value, tag} write-through granules swept by one wave per CU (MI355X_MICROARCH.md "Persistent kernels" price list).
 //
 // Geometry (fixed: the real Voxtral decoder -- D 3072, 32 query heads / 8 KV heads x 128, FFN 9216; other shapes keep the per-operator path):
-//   grid = 256 workgroups (one per CU, all resident) x 512 threads = 8 waves:
-//     wave 0      LOADER   global_load_lds_dwordx4 ... nt: this CU's slice of q|k|v, wo, w1|w3, w2 of every layer, then lm_head, as 21 KiB packets
-//                          into a ring of LDS slots; 2-3 packets in flight; waits only for free slots.
-//     wave 1      COMM     sweeps granules written by other CUs into LDS staging (activation vectors, partial sums), applies RMSNorm weights,
-//                          reduces partial sums in a FIXED order (deterministic), publishes this CU's 12 rows of the residual stream.
-//     waves 2..7  CONSUMERS  one "pass" (3456 B: 192 Q4 blocks) per wave per packet: v_cvt_pk_f32_fp8 turns two nibble bytes into two floats
-//                          (an e4m3 byte 0x0q is exactly q * 2^-9), v_pk_fma_f32 against the activation slice held in REGISTERS; attention.
+//   grid = 256 workgroups (one per CU, all resident) x 896 threads = 14 waves (<= 128 VGPRs):
+//     wave 0       LOADER   global_load_lds_dwordx4 ... nt: this CU's step records of q|k|v, wo, w1|w3, w2 of every layer, then the lm_head rows, as 13.5 / 20 KiB
+//                           packets into a ring of six LDS slots; 1-3 packets in flight; waits only for free slots.
+//     wave 1       COMM     sweeps granules written by other CUs into LDS (q|k|v of the head, the XCD group's SwiGLU outputs, partial planes of the CU's 12 residual
+//                           rows), reduces partial sums in a FIXED order (deterministic), publishes the CU's 12 rows (already multiplied by the next norm weight).
+//     waves 2..13  CONSUMERS  layer operators as EXACT integer dot products on v_mfma_i32_16x16x64_i8: B = Q4 nibbles as int8, A = the activation in per-block fixed
+//                           point split into four digits (rows 4 p + c = digit c of block p), K split over the 12 waves, cross-wave sums through LDS; step records
+//                           are moved into registers while a wave waits for an edge; attention; lm_head (fp8-trick VALU path, one row per wave per packet).
 //   CU b = (g = b % 8: KV head / XCD, j = b / 8): query head h = 4 g + j / 8, slice s = j % 8.  Per layer:
-//     q|k|v   CU computes q rows [128 h + 16 s, +16), k rows [4 j, +4) and v rows [4 j, +4) of KV head g (K = 3072, RMSNorm folded)   -> granules G
+//     q|k|v   CU computes q rows [128 h + 16 s, +16), k rows [4 j, +4) and v rows [4 j, +4) of KV head g (K = 3072, RMSNorm scale applied at the sum)  -> granules G
 //     attn    CU (h, s) gathers q_h, k_g, v_g (new row) and runs head h's single-query attention over the cache (redundantly per slice)
 //     wo      CU (h, s): rows [384 s, +384) x columns of head h (K = 128)  -> 32 partial planes PW; owner of rows [12 b, +12) sums them + residual -> H1
 //     w1|w3   CU (g, j): SwiGLU outputs [1152 g + 36 j, +36) (K = 3072)     -> granules A (read inside the XCD group only)
-//     w2      CU (g, j): rows [96 j, +96) x K slice [1152 g, +1152), split in 3 sub-slices over the consumer waves -> 24 partial planes P2;
-//             owner sums + residual -> H0 (next layer's input)
-//   Every all-to-all edge (H0, H1) is one 24 KB granule sweep per CU; the other edges are <= 1152 granules.
-// Tags = launch serial * 64 + layer + 1: unique per (launch, layer), so no buffer is ever re-initialised and a stale granule can never match.
+//     w2      CU (g, j): rows [96 j, +96) x the XCD group's K slice [1152 g, +1152) -> 8 partial planes P2; owner sums + residual -> H0 (next layer's input)
+//   An all-gather (H0, H1) is 4 granules per lane for each consumer wave (its own K slice); the other edges are <= 1152 granules.
+// Tags = (launch serial + 1) * 64 + layer + 1: unique per (launch, layer), so no buffer is ever re-initialised and a stale granule can never match.
 // Every spin is bounded (20 ms): on timeout the workgroup sets *err, marks itself dead and runs to completion without waiting.
+// History, measurements and everything that was tried: DESIGN.md section 3.0, profiles/r03_engine_experiments.md.
 #include "vox_kernels.h"
 
 #include <hip/hip_fp16.h>

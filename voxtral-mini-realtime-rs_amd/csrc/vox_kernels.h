@@ -195,9 +195,12 @@ struct EngParams {
     float* logits_out;                                // optional [vocab]
     int vocab;
     unsigned long long* tl; int tl_layer;             // timeline stamps [256][32] of layer tl_layer (null: off)
-    int flags;                                        // bit 0: thin the loader to one fill in flight while this CU's comm wave sweeps; bit 1 (diagnostic): the loader
-                                                      // re-reads one packet (no HBM traffic, wrong results); bit 2: probe granule before the small sweeps too
-    int ag_delay_ticks;                               // flags bit 9: all-gathers skip the probe and sweep after this many 10-ns ticks
+    int flags;                                        // product default 641 = 1 | 128 | 512.  1: one LDS-DMA packet in flight while the CU polls memory; 128: XCD-local
+                                                      // edges as plain stores through the shared L2 (placement verified per launch); 512: all-gathers swept ag_delay_ticks
+                                                      // after the CU's own publish instead of probe-then-sweep.  Measurement / diagnostic: 2 loader re-reads one packet,
+                                                      // 4 probe before small sweeps, 32 no LDS-DMA (wrong results), 64 loader pauses while polling, 1024 / 2048 loader depth
+                                                      // 2 / 1, 4096 nt polls on XCD-local edges, 16384 FAULT INJECTION (workgroup 7 loses a publish: the timeout test)
+    int ag_delay_ticks;                               // flags 512: 10-ns ticks between the CU's own publish and the all-gather sweep
     int pace_ticks;                                   // loader: minimum 10-ns ticks between two packet issues inside the layers (0: none)
 };
 bool eng_geometry_ok(int D, int n_heads, int n_kv, int hd, int ffn, int vocab, int max_seq);
