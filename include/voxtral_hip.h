@@ -68,14 +68,17 @@ int32_t vox_dev_download(vox_ctx* ctx, void* dst_host, const void* src_dev, size
 int32_t vox_dev_copy(vox_ctx* ctx, void* dst_dev, const void* src_dev, size_t nbytes);   /* device -> device, synchronous */
 
 /* ---- audio front-end (src/audio) ------------------------------------------------------- */
-/* resample / resample_to_16k, audio/resample.rs:10-52.  The reference delegates to rubato 1.0 (`Fft`, chunk 1024, 2 sub-chunks), a crate that
- * is not in its tree and whose output cannot be pinned; this is band-limited polyphase interpolation on the GPU (Kaiser-windowed sinc, 32 zero
- * crossings, cutoff 0.95 x the lower Nyquist, unit DC gain) with the reference's contract: same rate -> copy; n_out = ceil(n * out / in)
- * (inside the +-100 samples its tests allow, resample.rs:66-83).  in / out host or device buffers (mem_kind). */
+/* resample / resample_to_16k, audio/resample.rs:10-52.  The reference's resampler is rubato 1.0's synchronous FFT resampler
+ * (`Fft::<f32>::new(sr_in, sr_out, 1024, 2, 1, FixedSync::Input)` + `process_all_into_buffer`, resample.rs:22-45).  This is that crate's published algorithm on
+ * the GPU: blocks of fft_in samples through a Blackman-Harris^2 windowed-sinc filter in the frequency domain, the low bins re-synthesised at length 2 fft_out,
+ * overlap-added, the fft_out / 2 samples of delay dropped; n_out = ceil(n_in * (f64(sr_out) / f64(sr_in))); same rate -> copy (resample.rs:17-19).  rubato is not
+ * in the reference's tree, so parity against the crate itself is unpinned; the CPU oracle restates the same algorithm independently.
+ * Rate pairs whose blocks would not fit a 64 MB matrix (co-prime rates) are refused with VOX_ERR_UNSUPPORTED.  in / out host or device buffers (mem_kind). */
 int32_t vox_resample_len(size_t n_in, uint32_t sr_in, uint32_t sr_out, size_t* n_out);
 int32_t vox_resample(vox_ctx* ctx, const float* in, size_t n_in, uint32_t sr_in, uint32_t sr_out, float* out, size_t cap, size_t* n_out,
                      int32_t mem_kind);
-int32_t vox_resample_filter(uint32_t sr_in, uint32_t sr_out, int32_t* P, int32_t* Q, int32_t* W, float* h_or_null, size_t cap);   /* table [Q][2W+1] */
+/* the plan rubato derives from the two rates, and the filter taps (fft_in floats, already divided by 2 fft_in) when taps_or_null is given */
+int32_t vox_resample_plan(uint32_t sr_in, uint32_t sr_out, int32_t* fft_in, int32_t* fft_out, int32_t* delay, float* cutoff, float* taps_or_null, size_t cap);
 /* AudioBuffer::peak_normalize, audio/io.rs:59-68 (host, in place) */
 int32_t vox_peak_normalize(float* samples, size_t n, float target_peak);
 
@@ -221,7 +224,7 @@ int32_t vox_cache_reset(vox_cache* c);
  * against the cached K / V (RoPE at the absolute stream position; the cache evicts rows older than the 750-row window by itself when a chunk
  * does not fit), then reshaped / adapted like encode_audio: floor(S_chunk / 4) rows of [dec_dim].  capacity_rows 0 = 2 * window + 512.
  * LIMIT: positions are ABSOLUTE stream positions (the reference offsets RoPE by cache.seq_len(), which restarts after an eviction); the position table
- * holds 65 536 rows = 21.8 minutes of audio per cache -- later chunks are refused (VOX_ERR_ARG) until vox_cache_reset.  A too small `cap_rows` is refused
+ * holds 65 536 rows = 21.8 minutes of audio per cache -- later chunks are refused (VOX_ERR_INVALID) until vox_cache_reset.  A too small `cap_rows` is refused
  * BEFORE the chunk is appended (the stream cache is untouched and the call can be repeated with a larger buffer). */
 int32_t vox_encoder_cache_create(vox_model* m, int32_t capacity_rows, vox_cache** out);
 int32_t vox_encoder_cache_apply_sliding_window(vox_cache* enc_cache, int32_t window);

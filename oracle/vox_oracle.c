@@ -703,39 +703,85 @@ int orc_encode_audio(const orc_model* m, const float* mel, int T, float* out) {
     free(x); return S4;
 }
 
-/* ---- sample-rate conversion (audio/resample.rs:16-52).  The reference calls rubato 1.0 (`Fft` synchronous resampler), a third-party crate absent from
- * /root/reference whose output is not pinned by any reference test beyond the length (resample.rs:66-83: within 100 samples of n * out / in).
- * PARITY UNPINNED versus rubato.  What is restated here is the SPECIFICATION of the replacement (band-limited interpolation, Kaiser-windowed
- * sinc, 32 zero crossings, beta 12, cutoff 0.95 x the lower Nyquist, unit DC gain per phase; n_out = ceil(n * out / in); same rate = copy),
- * in double precision, so the GPU kernel has an independent checker. */
-static double orc_i0(double x) { double s = 1.0, t = 1.0; for (int k = 1; k < 60; k++) { t *= (x / (2.0 * k)) * (x / (2.0 * k)); s += t; if (t < 1e-18 * s) break; } return s; }
-size_t orc_resample_len(size_t n_in, uint32_t sr_in, uint32_t sr_out) { return sr_in == sr_out ? n_in : (size_t)(((unsigned long long)n_in * sr_out + sr_in - 1) / sr_in); }
+/* ---- sample-rate conversion (audio/resample.rs:16-52).  The reference calls rubato 1.0 (Cargo.toml:41 `rubato = "1.0"`; no Cargo.lock in the tree):
+ *   Fft::<f32>::new(sr_in, sr_out, 1024, 2, 1, FixedSync::Input)  +  process_all_into_buffer(.., n_in, None)        (resample.rs:22-45)
+ * rubato is a third-party crate that is NOT in /root/reference, so what follows is a restatement of its PUBLISHED algorithm (the crate's synchronous FFT
+ * resampler, src/synchro.rs + src/sinc.rs + src/windows.rs as released), not of code in the tree; PARITY UNPINNED -- no rubato output exists here to pin it
+ * with; the anchors are the reference's call site above and its contract tests (resample.rs:56-108: same rate = clone, length within 100 samples, duration).
+ *   plan      gcd = gcd(sr_in, sr_out); fft_chunks = ceil(f32(1024) / f32(2) / f32(sr_in / gcd)); fft_in = fft_chunks * sr_in / gcd, fft_out = fft_chunks * sr_out / gcd
+ *   filter    cutoff = 0.4f32 ^ (16 / fft_in) [* fft_out / fft_in when down-sampling]; taps h[x] = w[x] * sinc((x - fft_in / 2) * cutoff), x < fft_in, all in f32:
+ *             w = (periodic 4-term Blackman-Harris)^2, sinc(0) = 1, fft_in / 2 the INTEGER half; normalised to unit sum, then / (2 fft_in)
+ *   unit      one block of fft_in samples, zero-padded to 2 fft_in -> real FFT -> bins [0, new_len) times the filter's FFT, the rest dropped
+ *             (new_len = fft_out when down-sampling, fft_in + 1 otherwise) -> UNNORMALISED inverse real FFT of length 2 fft_out (the imaginary part of bin 0 is ignored)
+ *             -> first half + the previous block's second half is the block's fft_out output samples (overlap-add)
+ *   all       the stream of blocks over the zero-extended input, minus the first output_delay = fft_out / 2 samples, cut to ceil(n_in * (f64(sr_out) / f64(sr_in))).
+ * The transforms here are plain O(N * bins) DFT sums in double precision (rubato runs f32 FFTs: agreement to f32 rounding, not bits). */
+typedef struct { long fft_in, fft_out, new_len, delay; float cutoff; } orc_rs_plan;
+static orc_rs_plan orc_rs_make_plan(uint32_t sr_in, uint32_t sr_out) {
+    long a = sr_in, b = sr_out; while (b) { long t = a % b; a = b; b = t; }
+    orc_rs_plan p; const long min_in = sr_in / a, min_out = sr_out / a;
+    const long chunks = (long)ceilf(1024.0f / 2.0f / (float)min_in);
+    p.fft_in = chunks * min_in; p.fft_out = chunks * min_out;
+    p.cutoff = powf(0.4f, 16.0f / (float)p.fft_in); if (p.fft_in > p.fft_out) p.cutoff = p.cutoff * (float)p.fft_out / (float)p.fft_in;
+    p.new_len = p.fft_in < p.fft_out ? p.fft_in + 1 : p.fft_out; p.delay = p.fft_out / 2;
+    return p;
+}
+static void orc_rs_taps(const orc_rs_plan* p, float* h) {         /* sinc.rs make_sincs(fft_in, 1, cutoff, BlackmanHarris2)[0] / (2 fft_in), f32 throughout */
+    const long n = p->fft_in; const float np_f = (float)n, pi = 3.14159265358979323846f;
+    float sum = 0.f;
+    for (long x = 0; x < n; x++) {
+        const float xf = (float)x;
+        float w = 0.35875f - 0.48829f * cosf(2.0f * pi * xf / np_f) + 0.14128f * cosf(4.0f * pi * xf / np_f) - 0.01168f * cosf(6.0f * pi * xf / np_f);
+        w = w * w;
+        const float arg = (xf - (float)(n / 2)) * p->cutoff;
+        const float sc = arg == 0.f ? 1.0f : sinf(arg * pi) / (arg * pi);
+        h[x] = w * sc; sum += h[x];
+    }
+    for (long x = 0; x < n; x++) h[x] = h[x] / sum / (float)(2 * n);
+}
+size_t orc_resample_len(size_t n_in, uint32_t sr_in, uint32_t sr_out) { return sr_in == sr_out ? n_in : (size_t)ceil(((double)sr_out / (double)sr_in) * (double)n_in); }
+void orc_resample_plan(uint32_t sr_in, uint32_t sr_out, long* fft_in, long* fft_out, long* delay, float* cutoff, float* taps_or_null) {
+    const orc_rs_plan p = orc_rs_make_plan(sr_in, sr_out);
+    *fft_in = p.fft_in; *fft_out = p.fft_out; *delay = p.delay; *cutoff = p.cutoff; if (taps_or_null) orc_rs_taps(&p, taps_or_null);
+}
 void orc_resample(const float* in, size_t n_in, uint32_t sr_in, uint32_t sr_out, float* out) {
     if (sr_in == sr_out) { memcpy(out, in, n_in * sizeof(float)); return; }
-    long a = sr_in, b = sr_out; while (b) { long t = a % b; a = b; b = t; }
-    const long P = sr_in / a, Q = sr_out / a;
-    const double scale = (double)Q / (double)P < 1.0 ? (double)Q / (double)P : 1.0, cutoff = 0.95 * scale, beta = 12.0;
-    const long W = (long)ceil(32.0 / scale), taps = 2 * W + 1;
-    const size_t n_out = orc_resample_len(n_in, sr_in, sr_out);
-    const double i0b = orc_i0(beta);
+    const size_t n_out = orc_resample_len(n_in, sr_in, sr_out); if (!n_out) return;
+    const orc_rs_plan p = orc_rs_make_plan(sr_in, sr_out);
+    const long Ni = p.fft_in, No = p.fft_out, L = p.new_len, Pi = 2 * Ni, Po = 2 * No;
+    float* h = (float*)malloc(sizeof(float) * (size_t)Ni); orc_rs_taps(&p, h);
+    double *ci = (double*)malloc(sizeof(double) * Pi), *si = (double*)malloc(sizeof(double) * Pi), *co = (double*)malloc(sizeof(double) * Po), *so = (double*)malloc(sizeof(double) * Po);
+    for (long j = 0; j < Pi; j++) { ci[j] = cos(2.0 * M_PI * (double)j / (double)Pi); si[j] = sin(2.0 * M_PI * (double)j / (double)Pi); }
+    for (long j = 0; j < Po; j++) { co[j] = cos(2.0 * M_PI * (double)j / (double)Po); so[j] = sin(2.0 * M_PI * (double)j / (double)Po); }
+    double *Hr = (double*)calloc((size_t)L, sizeof(double)), *Hi = (double*)calloc((size_t)L, sizeof(double));
+    for (long k = 0; k < L; k++) for (long n = 0; n < Ni; n++) { const long j = (k * n) % Pi; Hr[k] += (double)h[n] * ci[j]; Hi[k] -= (double)h[n] * si[j]; }   /* filter_f = FFT(filter_t) */
+    const long n_blocks = ((long)n_out + p.delay + No - 1) / No;                 /* blocks whose first half reaches the last kept output sample */
+    double* stream = (double*)calloc((size_t)(n_blocks + 1) * (size_t)No, sizeof(double));
+    double* ob = (double*)malloc(sizeof(double) * (size_t)n_blocks * (size_t)Po);
     #pragma omp parallel
     {
-        double* row = (double*)malloc(sizeof(double) * (size_t)taps);
+        double *Yr = (double*)malloc(sizeof(double) * (size_t)L), *Yi = (double*)malloc(sizeof(double) * (size_t)L);
         #pragma omp for schedule(static)
-        for (long m = 0; m < (long)n_out; m++) {
-            const long num = m * P, n0 = num / Q, ph = num % Q; const double frac = (double)ph / (double)Q; double sum = 0.0;
-            for (long k = 0; k < taps; k++) {
-                const double tau = (double)(k - W) - frac, u = tau / (double)(W + 1);
-                const double w = fabs(u) < 1.0 ? orc_i0(beta * sqrt(1.0 - u * u)) / i0b : 0.0;
-                const double x = M_PI * cutoff * tau, sinc = fabs(x) < 1e-12 ? 1.0 : sin(x) / x;
-                row[k] = cutoff * sinc * w; sum += row[k];
+        for (long c = 0; c < n_blocks; c++) {
+            for (long k = 0; k < L; k++) {                                        /* forward transform of the zero-padded block, kept bins only, times the filter */
+                double xr = 0.0, xi = 0.0;
+                for (long n = 0; n < Ni; n++) {
+                    const size_t i = (size_t)c * (size_t)Ni + (size_t)n; if (i >= n_in) break;
+                    const long j = (k * n) % Pi; xr += (double)in[i] * ci[j]; xi -= (double)in[i] * si[j];
+                }
+                Yr[k] = xr * Hr[k] - xi * Hi[k]; Yi[k] = xr * Hi[k] + xi * Hr[k];
             }
-            double acc = 0.0;
-            for (long k = 0; k < taps; k++) { const long i = n0 - W + k; if (i >= 0 && i < (long)n_in) acc += (double)in[i] * (row[k] / sum); }
-            out[m] = (float)acc;
+            for (long m = 0; m < Po; m++) {                                       /* unnormalised c2r inverse of length 2 fft_out: bin 0 real part only, bins 1 .. L-1 twice (L - 1 < fft_out) */
+                double acc = Yr[0];
+                for (long k = 1; k < L; k++) { const long j = (k * m) % Po; acc += 2.0 * (Yr[k] * co[j] - Yi[k] * so[j]); }
+                ob[(size_t)c * (size_t)Po + (size_t)m] = acc;
+            }
         }
-        free(row);
+        free(Yr); free(Yi);
     }
+    for (long c = 0; c < n_blocks; c++) for (long m = 0; m < Po; m++) stream[(size_t)c * No + m] += ob[(size_t)c * Po + m];      /* wave_out = output_buf[..fft_out] + overlap */
+    for (size_t i = 0; i < n_out; i++) out[i] = (float)stream[(size_t)p.delay + i];
+    free(h); free(ci); free(si); free(co); free(so); free(Hr); free(Hi); free(stream); free(ob);
 }
 
 /* ---- streaming encoder: Q4AudioEncoder::forward_with_cache (gguf/model.rs:437-452), Q4EncoderLayer::forward_with_cache (:299-317),

@@ -109,6 +109,7 @@ def lib():
         "orc_encode_audio": (C.c_int, [vp, f32p, C.c_int, f32p]),
         "orc_resample_len": (C.c_size_t, [C.c_size_t, C.c_uint32, C.c_uint32]),
         "orc_resample": (None, [f32p, C.c_size_t, C.c_uint32, C.c_uint32, f32p]),
+        "orc_resample_plan": (None, [C.c_uint32, C.c_uint32, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_float), vp]),
         "orc_enc_cache_create": (vp, [vp, C.c_int]),
         "orc_enc_cache_free": (None, [vp]),
         "orc_enc_cache_len": (C.c_int, [vp]),
@@ -177,6 +178,15 @@ def resample(x, sr_in, sr_out=16000):
     out = np.zeros(L.orc_resample_len(x.size, sr_in, sr_out), dtype=np.float32)
     L.orc_resample(x, x.size, sr_in, sr_out, out)
     return out
+
+
+def resample_plan(sr_in, sr_out=16000):
+    """(fft_in, fft_out, output_delay, cutoff, taps[fft_in]) of the rubato `Fft` restatement"""
+    L = lib(); a, b, d, c = C.c_long(), C.c_long(), C.c_long(), C.c_float()
+    L.orc_resample_plan(sr_in, sr_out, C.byref(a), C.byref(b), C.byref(d), C.byref(c), None)
+    taps = np.zeros(a.value, dtype=np.float32)
+    L.orc_resample_plan(sr_in, sr_out, C.byref(a), C.byref(b), C.byref(d), C.byref(c), taps.ctypes.data_as(C.c_void_p))
+    return a.value, b.value, d.value, c.value, taps
 
 
 def time_embedding(t, dim=3072, theta=10000.0):

@@ -8,7 +8,7 @@ from . import synth  # noqa: F401  (numpy-only tooling: synthetic GGUF / audio)
 from . import build  # noqa: F401
 from ._lib import lib, VoxError  # noqa: F401
 from .audio import (PadConfig, ChunkConfig, MelSpectrogram, pad_audio, chunk_audio, needs_chunking,  # noqa: F401
-                    peak_normalize, resample, resample_to_16k, resample_filter, TimeEmbedding)
+                    peak_normalize, resample, resample_to_16k, resample_plan, TimeEmbedding)
 from .tokenizer import VoxtralTokenizer  # noqa: F401
 from . import wer  # noqa: F401  (WER / CER harness, scripts/eval_wer.py)
 from . import export  # noqa: F401  (SafeTensors -> Q4_0 GGUF)

@@ -109,7 +109,7 @@ SIGNATURES = {
     "vox_cache_reset": (i32, [vp]),
     "vox_resample_len": (i32, [sz, C.c_uint32, C.c_uint32, P(sz)]),
     "vox_resample": (i32, [vp, vp, sz, C.c_uint32, C.c_uint32, vp, sz, P(sz), i32]),
-    "vox_resample_filter": (i32, [C.c_uint32, C.c_uint32, P(i32), P(i32), P(i32), vp, sz]),
+    "vox_resample_plan": (i32, [C.c_uint32, C.c_uint32, P(i32), P(i32), P(i32), P(C.c_float), vp, sz]),
     "vox_encoder_cache_create": (i32, [vp, i32, P(vp)]),
     "vox_encoder_cache_apply_sliding_window": (i32, [vp, i32]),
     "vox_cache_abs_pos": (i32, [vp, P(i32)]),

@@ -113,7 +113,7 @@ def chunk_audio(samples, config: ChunkConfig):
 
 
 def resample(ctx, samples, sample_rate, target_rate=16000):
-    """audio/resample.rs:16-52 `resample` (GPU polyphase band-limited interpolation; same rate -> copy)"""
+    """audio/resample.rs:16-52 `resample` (rubato's synchronous FFT resampler as a block matrix product on the GPU; same rate -> copy)"""
     x = _f32(samples); n = C.c_size_t()
     check(lib().vox_resample_len(x.size, int(sample_rate), int(target_rate), C.byref(n)))
     out = np.empty(x.size if sample_rate == target_rate else n.value, dtype=np.float32)
@@ -126,13 +126,13 @@ def resample_to_16k(ctx, samples, sample_rate):
     return resample(ctx, samples, sample_rate, 16000)
 
 
-def resample_filter(sample_rate, target_rate=16000):
-    """(P, Q, W, h[Q][2W+1]) of the polyphase design (host)"""
-    P_, Q_, W_ = C.c_int32(), C.c_int32(), C.c_int32()
-    check(lib().vox_resample_filter(int(sample_rate), int(target_rate), C.byref(P_), C.byref(Q_), C.byref(W_), None, 0))
-    h = np.empty((Q_.value, 2 * W_.value + 1), dtype=np.float32)
-    check(lib().vox_resample_filter(int(sample_rate), int(target_rate), C.byref(P_), C.byref(Q_), C.byref(W_), _ptr(h), h.size))
-    return P_.value, Q_.value, W_.value, h
+def resample_plan(sample_rate, target_rate=16000):
+    """(fft_in, fft_out, output_delay, cutoff, taps[fft_in]) rubato's `Fft` resampler derives from the two rates (host)"""
+    a_, b_, d_, c_ = C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
+    check(lib().vox_resample_plan(int(sample_rate), int(target_rate), C.byref(a_), C.byref(b_), C.byref(d_), C.byref(c_), None, 0))
+    h = np.empty(a_.value, dtype=np.float32)
+    check(lib().vox_resample_plan(int(sample_rate), int(target_rate), C.byref(a_), C.byref(b_), C.byref(d_), C.byref(c_), _ptr(h), h.size))
+    return a_.value, b_.value, d_.value, c_.value, h
 
 
 def peak_normalize(samples, target_peak=0.95):

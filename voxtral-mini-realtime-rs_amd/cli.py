@@ -41,9 +41,9 @@ def load_wav(path):
 
 
 def resample_to_16k(x, sr, ctx=None, pkg=None):
-    """audio/resample.rs:10-52.  vox_resample on the GPU (polyphase band-limited interpolation; tests/test_resample.py pins it against the CPU oracle -- the
-    reference's rubato FFT resampler is a third-party crate outside the tree, so bit parity with IT is unpinned and recorded as such in DESIGN.md).  There is no
-    host fallback: without the HIP library this CLI cannot resample."""
+    """audio/resample.rs:10-52.  vox_resample on the GPU: the algorithm of rubato's synchronous FFT resampler, which is what the reference calls
+    (tests/test_resample.py pins it against the CPU oracle's independent restatement; the crate itself is outside the reference's tree, so parity with ITS
+    output is unpinned and recorded as such in DESIGN.md).  There is no host fallback: without the HIP library this CLI cannot resample."""
     if ctx is None or pkg is None:
         raise RuntimeError("resample_to_16k needs a GPU context (the product path has no CPU fallback)")
     return pkg.resample_to_16k(ctx, x, sr)

@@ -96,6 +96,7 @@ struct vox_ctx {
     // XF tiles of a 17..48-row GEMM input (the 38-token prefill): 3 tiles x K columns x 64 B; sized once for K <= 16384, reused by every such GEMM of the stream
     uint16_t* xf_scratch = nullptr; size_t xf_scratch_bytes = 0;
     float* kz_scratch = nullptr; size_t kz_scratch_bytes = 0;      // K-slice planes of the 17..48-row GEMMs (q4_skinny_mt2_kernel): 8 x 48 x 18432 floats
+    float* rs_matrix = nullptr; uint32_t rs_in = 0, rs_out = 0;    // block matrix of the last resampled rate pair (vox_resample)
 };
 
 static int32_t ctx_bind(const vox_ctx* c) { HIPCHK(hipSetDevice(c->device)); return VOX_OK; }
@@ -122,6 +123,7 @@ extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
     for (auto& e : c->pool) (void)hipFree(e.p);
     if (c->xf_scratch) (void)hipFree(c->xf_scratch);
     if (c->kz_scratch) (void)hipFree(c->kz_scratch);
+    if (c->rs_matrix) (void)hipFree(c->rs_matrix);
     for (int i = 0; i < 3; i++) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     (void)hipStreamDestroy(c->stream);
@@ -298,59 +300,97 @@ extern "C" int32_t vox_mel_compute_log(vox_ctx* c, const float* samples, size_t 
     return VOX_OK;
 }
 
-// ---- sample-rate conversion (audio/resample.rs:16-52).  Filter design (host, double precision): Kaiser-windowed sinc, Z = 32 zero crossings of
-// the narrower band each side, beta = 12 (stop band < -110 dB), cutoff = 0.95 x the lower Nyquist; every phase normalised to unit DC gain.
-static double bessel_i0(double x) { double s = 1.0, t = 1.0; for (int k = 1; k < 60; k++) { t *= (x / (2.0 * k)) * (x / (2.0 * k)); s += t; if (t < 1e-18 * s) break; } return s; }
+// ---- sample-rate conversion (audio/resample.rs:16-52).  The reference's whole resampler is two calls into rubato 1.0 (Cargo.toml:41), a third-party crate
+// that is not in the tree: Fft::<f32>::new(sr_in, sr_out, 1024, 2, 1, FixedSync::Input) and process_all_into_buffer.  What is implemented is that crate's
+// published algorithm (synchronous FFT resampler; restated a second time, independently, by the test-side CPU checker; PARITY UNPINNED against the crate itself):
+//   plan    gcd; fft_chunks = ceil(f32(1024) / f32(2) / f32(sr_in / gcd)); fft_in = fft_chunks * sr_in / gcd; fft_out = fft_chunks * sr_out / gcd
+//   filter  fft_in taps, f32 arithmetic: (periodic 4-term Blackman-Harris window)^2 * sinc((x - fft_in / 2) * cutoff), unit sum, / (2 fft_in);
+//           cutoff = 0.4^(16 / fft_in), times fft_out / fft_in when down-sampling
+//   blocks  zero-pad to 2 fft_in, FFT, keep new_len bins (fft_out down, fft_in + 1 up) times the filter spectrum, inverse FFT of length 2 fft_out, overlap-add
+//   output  drop output_delay = fft_out / 2 samples, keep ceil(n_in * (f64(sr_out) / f64(sr_in)))
+// On the device the block pipeline is one fixed matrix (vox_kernels.hip resample_*_kernel), built once per rate pair and kept in the context.
+struct ResamplePlan { long fft_in = 0, fft_out = 0, new_len = 0, delay = 0; float cutoff = 0.f; };
 static long gcd_l(long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; }
+static ResamplePlan resample_plan_make(uint32_t sr_in, uint32_t sr_out) {
+    ResamplePlan p; const long g = gcd_l(sr_in, sr_out), min_in = sr_in / g, min_out = sr_out / g;
+    const long chunks = (long)std::ceil(1024.0f / 2.0f / (float)min_in);
+    p.fft_in = chunks * min_in; p.fft_out = chunks * min_out;
+    const float base = std::pow(0.4f, 16.0f / (float)p.fft_in);
+    p.cutoff = p.fft_in > p.fft_out ? base * (float)p.fft_out / (float)p.fft_in : base;
+    p.new_len = p.fft_in < p.fft_out ? p.fft_in + 1 : p.fft_out; p.delay = p.fft_out / 2;
+    return p;
+}
+static std::vector<float> resample_taps(const ResamplePlan& p) {
+    const long n = p.fft_in; std::vector<float> h((size_t)n);
+    const float npf = (float)n, pi = (float)M_PI, pi2 = 2.0f * pi, pi4 = 4.0f * pi, pi6 = 6.0f * pi;
+    float sum = 0.f;
+    for (long x = 0; x < n; x++) {
+        const float xf = (float)x;
+        const float bh = 0.35875f - 0.48829f * std::cos(pi2 * xf / npf) + 0.14128f * std::cos(pi4 * xf / npf) - 0.01168f * std::cos(pi6 * xf / npf);
+        const float v = (xf - (float)(n / 2)) * p.cutoff;
+        const float sinc = v == 0.f ? 1.0f : std::sin(v * pi) / (v * pi);
+        h[(size_t)x] = bh * bh * sinc; sum += h[(size_t)x];
+    }
+    for (auto& v : h) v = v / sum / (float)(2 * n);
+    return h;
+}
+// largest block matrix kept on the device (2 fft_out x fft_in f32): every pair of standard audio rates needs <= 9 MB; co-prime rates would need FFTs of sr_in points
+static constexpr size_t RESAMPLE_MATRIX_MAX = (size_t)64 << 20;
 extern "C" int32_t vox_resample_len(size_t n_in, uint32_t sr_in, uint32_t sr_out, size_t* n_out) {
     ARGCHK(n_out && sr_in > 0 && sr_out > 0, "bad argument");
-    *n_out = (size_t)(((unsigned long long)n_in * sr_out + sr_in - 1) / sr_in); return VOX_OK;      // ceil(n * out / in)
+    *n_out = sr_in == sr_out ? n_in : (size_t)std::ceil(((double)sr_out / (double)sr_in) * (double)n_in); return VOX_OK;      // rubato: (resample_ratio() * len).ceil()
 }
-static void resample_design(uint32_t sr_in, uint32_t sr_out, int* P, int* Q, int* W, std::vector<float>* h) {
-    const long g = gcd_l(sr_in, sr_out); *P = (int)(sr_in / g); *Q = (int)(sr_out / g);
-    const double scale = std::min(1.0, (double)*Q / (double)*P), cutoff = 0.95 * scale, beta = 12.0; const int Z = 32;
-    *W = (int)std::ceil(Z / scale); const int taps = 2 * *W + 1;
-    h->assign((size_t)*Q * taps, 0.f);
-    const double i0b = bessel_i0(beta);
-    for (int ph = 0; ph < *Q; ph++) {
-        const double frac = (double)ph / (double)*Q; std::vector<double> row(taps); double sum = 0.0;
-        for (int k = 0; k < taps; k++) {
-            const double tau = (double)(k - *W) - frac;                      // input-sample offset of tap k from the output instant
-            const double u = tau / (double)(*W + 1);
-            double w = 0.0; if (std::fabs(u) < 1.0) w = bessel_i0(beta * std::sqrt(1.0 - u * u)) / i0b;
-            const double a = M_PI * cutoff * tau; const double sinc = std::fabs(a) < 1e-12 ? 1.0 : std::sin(a) / a;
-            row[k] = cutoff * sinc * w; sum += row[k];
-        }
-        for (int k = 0; k < taps; k++) (*h)[(size_t)ph * taps + k] = (float)(row[k] / sum);
+static int32_t resample_matrix_ensure(vox_ctx* c, uint32_t sr_in, uint32_t sr_out, const ResamplePlan& p) {
+    if (c->rs_matrix && c->rs_in == sr_in && c->rs_out == sr_out) return VOX_OK;
+    const size_t bytes = (size_t)p.fft_in * 2 * (size_t)p.fft_out * 4;
+    if (bytes > RESAMPLE_MATRIX_MAX) return fail(VOX_ERR_UNSUPPORTED, "resample %u -> %u Hz: FFT blocks of %ld -> %ld samples are not supported (rates must share a large common divisor)", sr_in, sr_out, p.fft_in, p.fft_out);
+    const std::vector<float> h = resample_taps(p);
+    const long Pi = 2 * p.fft_in; std::vector<double> ct((size_t)Pi), st((size_t)Pi), H((size_t)p.new_len * 2, 0.0);
+    for (long j = 0; j < Pi; j++) { ct[(size_t)j] = std::cos(2.0 * M_PI * (double)j / (double)Pi); st[(size_t)j] = std::sin(2.0 * M_PI * (double)j / (double)Pi); }
+    for (long k = 0; k < p.new_len; k++) {                                           // filter_f = FFT of the zero-padded taps (only the bins that are kept)
+        double re = 0.0, im = 0.0;
+        for (long n = 0; n < p.fft_in; n++) { const long j = (k * n) % Pi; re += (double)h[(size_t)n] * ct[(size_t)j]; im -= (double)h[(size_t)n] * st[(size_t)j]; }
+        H[(size_t)2 * k] = re; H[(size_t)2 * k + 1] = im;
     }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->rs_matrix) { (void)hipFree(c->rs_matrix); c->rs_matrix = nullptr; }
+    DevBuf dH; HIPCHK(dH.alloc(H.size() * 8)); HIPCHK(hipMalloc((void**)&c->rs_matrix, bytes));
+    HIPCHK(hipMemcpyAsync(dH.p, H.data(), H.size() * 8, hipMemcpyHostToDevice, c->stream));
+    hipError_t e = launch_resample_matrix(dH.as<double>(), (int)p.new_len, (int)p.fft_in, (int)p.fft_out, c->rs_matrix, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(c->rs_matrix); c->rs_matrix = nullptr; return fail(VOX_ERR_HIP, "resample matrix: %s", hipGetErrorString(e)); }
+    c->rs_in = sr_in; c->rs_out = sr_out;
+    return VOX_OK;
 }
 extern "C" int32_t vox_resample(vox_ctx* c, const float* in, size_t n_in, uint32_t sr_in, uint32_t sr_out, float* out, size_t cap, size_t* n_out, int32_t mem_kind) {
     ARGCHK(c && out && n_out && (in || n_in == 0), "null argument"); ARGCHK(sr_in > 0 && sr_out > 0, "bad sample rate"); VOXCHK(ctx_bind(c));
-    size_t no; VOXCHK(vox_resample_len(n_in, sr_in, sr_out, &no)); if (sr_in == sr_out) no = n_in;
+    size_t no; VOXCHK(vox_resample_len(n_in, sr_in, sr_out, &no));
     ARGCHK(cap >= no, "output capacity %zu < %zu samples", cap, no);
     *n_out = no; if (no == 0) return VOX_OK;
     hipStream_t s = c->stream;
     if (sr_in == sr_out) {                                                     // resample.rs:17-19: same rate -> clone
         HIPCHK(hipMemcpyAsync(out, in, n_in * 4, mem_kind == VOX_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToHost, s)); HIPCHK(hipStreamSynchronize(s)); return VOX_OK;
     }
-    int P, Q, W; std::vector<float> h; resample_design(sr_in, sr_out, &P, &Q, &W, &h);
-    DevBuf dh, din, dout; HIPCHK(dh.alloc(h.size() * 4)); HIPCHK(hipMemcpyAsync(dh.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, s));
+    const ResamplePlan p = resample_plan_make(sr_in, sr_out);
+    VOXCHK(resample_matrix_ensure(c, sr_in, sr_out, p));
+    DevBuf din, dout;
     const float* d_in = in; float* d_out = out;
     if (mem_kind != VOX_MEM_DEVICE) {
         HIPCHK(din.alloc(n_in * 4)); HIPCHK(dout.alloc(no * 4));
         HIPCHK(hipMemcpyAsync(din.p, in, n_in * 4, hipMemcpyHostToDevice, s)); d_in = din.as<float>(); d_out = dout.as<float>();
     }
-    HIPCHK(launch_resample(d_in, (long)n_in, dh.as<float>(), P, Q, W, d_out, (long)no, s));
+    HIPCHK(launch_resample(d_in, (long)n_in, c->rs_matrix, (int)p.fft_in, (int)p.fft_out, (int)p.delay, d_out, (long)no, s));
     if (mem_kind != VOX_MEM_DEVICE) HIPCHK(hipMemcpyAsync(out, d_out, no * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return VOX_OK;
 }
-// the filter table itself (host; [Q][2 W + 1]) -- lets the parity tests check the design independently of the kernel
-extern "C" int32_t vox_resample_filter(uint32_t sr_in, uint32_t sr_out, int32_t* P, int32_t* Q, int32_t* W, float* h, size_t cap) {
-    ARGCHK(P && Q && W && sr_in > 0 && sr_out > 0, "bad argument");
-    int p_, q_, w_; std::vector<float> t; resample_design(sr_in, sr_out, &p_, &q_, &w_, &t);
-    *P = p_; *Q = q_; *W = w_;
-    if (h) { ARGCHK(cap >= t.size(), "filter buffer too small (%zu < %zu floats)", cap, t.size()); std::memcpy(h, t.data(), t.size() * 4); }
+// the plan and the filter taps (host; fft_in floats) -- lets the parity tests check the design independently of the kernels
+extern "C" int32_t vox_resample_plan(uint32_t sr_in, uint32_t sr_out, int32_t* fft_in, int32_t* fft_out, int32_t* delay, float* cutoff, float* taps, size_t cap) {
+    ARGCHK(fft_in && fft_out && delay && cutoff && sr_in > 0 && sr_out > 0, "bad argument");
+    const ResamplePlan p = resample_plan_make(sr_in, sr_out);
+    ARGCHK(p.fft_in <= INT32_MAX && p.fft_out <= INT32_MAX, "rates too far from a common divisor");
+    *fft_in = (int32_t)p.fft_in; *fft_out = (int32_t)p.fft_out; *delay = (int32_t)p.delay; *cutoff = p.cutoff;
+    if (taps) { ARGCHK(cap >= (size_t)p.fft_in, "taps buffer too small (%zu < %ld floats)", cap, p.fft_in); const std::vector<float> h = resample_taps(p); std::memcpy(taps, h.data(), h.size() * 4); }
     return VOX_OK;
 }
 

@@ -150,8 +150,9 @@ hipError_t launch_conv1d_gelu(const float* in, int Cin, int L, const float* w, c
 struct MelTables { const float* window; const float* cos_t; const float* sin_t; const float* fb; const int* fb_lo; const int* fb_hi; };
 hipError_t launch_mel(const float* audio, long n, long left, long right, const float* scale_ptr, MelTables t,
                       float* out, int T, int transposed, hipStream_t s);
-// polyphase FIR sample-rate conversion: out[m] = sum_k x[floor(m P / Q) - W + k] * h[(m P) mod Q][k], h: [Q][2 W + 1]
-hipError_t launch_resample(const float* x, long n_in, const float* h, int P, int Q, int W, float* out, long n_out, hipStream_t s);
+// sample-rate conversion (rubato `Fft` algorithm as one block matrix, vox_kernels.hip): the matrix builder (once per rate pair) and the block product + overlap-add
+hipError_t launch_resample_matrix(const double* H, int new_len, int fft_in, int fft_out, float* At, hipStream_t s);      // H: new_len (re, im) pairs; At: [fft_in][2 fft_out]
+hipError_t launch_resample(const float* x, long n_in, const float* At, int fft_in, int fft_out, int delay, float* out, long n_out, hipStream_t s);
 hipError_t launch_absmax(const float* x, long n, float target_peak, float* scale_out, hipStream_t s);
 
 // h[i][:] = (audio ? audio[(a_base+i)][:] : 0) + dequant(tok[ids[id_base+i]]) ; bases add *pos_ptr if given

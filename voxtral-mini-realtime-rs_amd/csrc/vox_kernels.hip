@@ -3451,29 +3451,61 @@ hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int*
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sample-rate conversion (audio/resample.rs:16-52 `resample`; the reference calls rubato's synchronous FFT resampler, a third-party crate
-// that cannot be restated bit for bit -- see DESIGN.md).  Band-limited interpolation as a polyphase FIR: output sample m sits at input time
-// m * P / Q (P/Q = sr_in/sr_out in lowest terms); its phase (m * P) mod Q selects one row of a host-built Kaiser-windowed-sinc table
-// h[Q][taps]; out[m] = sum_k x[n0 - W + k] * h[phase][k], zeros beyond the ends.  HBM-trivial (a 30 s clip is 5.8 MB): one thread per output.
+// Sample-rate conversion (audio/resample.rs:16-52 `resample`).  The reference calls rubato 1.0's synchronous FFT resampler (`Fft`, FixedSync::Input,
+// chunk 1024, 2 sub-chunks): blocks of fft_in samples, zero-padded to 2 fft_in, real FFT, times the FFT of a Blackman-Harris^2 windowed sinc, the
+// low new_len bins re-synthesised by an unnormalised inverse real FFT of length 2 fft_out, overlap-added, minus fft_out / 2 samples of delay (plan
+// and filter taps: vox_api.cpp resample_plan_make).  Every step is linear and identical for every block, so one block is a fixed
+// (2 fft_out) x fft_in matrix applied to the block's samples:
+//     out_buf[m] = sum_n x[n] * A[m][n],   A[m][n] = sum_{k < new_len} w_k Re(H[k] e^{2 pi i k (m fft_in - n fft_out) / (2 fft_in fft_out)}),  w_0 = 1, w_k = 2
+// (H = the filter's spectrum; the inverse transform ignores the imaginary part of bin 0; new_len <= fft_out so the Nyquist bin never carries data).
+// resample_matrix_kernel builds A once per rate pair in f64 (rotation recurrence over k from one sincospi per element, error ~ k * 2^-53), stored
+// transposed At[n][m] in f32; resample_apply_kernel is the block matrix product + overlap-add + delay trim: one thread per output sample,
+//     out[i] = sum_n At[n][m] x[c fft_in + n]  +  sum_n At[n][fft_out + m] x[(c - 1) fft_in + n],   (c, m) = divmod(i + delay, fft_out),
+// the first sum being the block's own first half and the second the previous block's tail (rubato: output_buf[n] + overlap[n]); samples past the
+// end of the input are zeros.  At stays in L2 (<= a few MB for every common rate); a 30 s clip is ~1 GFLOP of f32 FMAs.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, long n_in, const float* __restrict__ h, int P, int Q, int W,
-                                                       float* __restrict__ out, long n_out) {
-    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_out) return;
-    const long num = m * (long)P; const long n0 = num / Q; const int phase = (int)(num % Q);
-    const int taps = 2 * W + 1;
-    const float* hp = h + (size_t)phase * taps;
-    float acc = 0.f;
-    for (int k = 0; k < taps; k++) {
-        const long i = n0 - W + k;
-        const float v = (i >= 0 && i < n_in) ? x[i] : 0.f;
-        acc = fmaf(v, hp[k], acc);
+__global__ __launch_bounds__(256) void resample_matrix_kernel(const double* __restrict__ H, int new_len, int fft_in, int fft_out, float* __restrict__ At) {
+    const long total = (long)fft_in * 2 * fft_out;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int n = (int)(e / (2 * fft_out)), m = (int)(e % (2 * fft_out));
+    const long P = 2L * fft_in * fft_out;
+    long d = ((long)m * fft_in - (long)n * fft_out) % P; if (d < 0) d += P;
+    double s1, c1; sincospi(2.0 * (double)d / (double)P, &s1, &c1);
+    double c = 1.0, s = 0.0, acc = H[0];
+    for (int k = 1; k < new_len; k++) {
+        const double cn = c * c1 - s * s1, sn = s * c1 + c * s1; c = cn; s = sn;
+        acc += 2.0 * (H[2 * k] * c - H[2 * k + 1] * s);
     }
-    out[m] = acc;
+    At[e] = (float)acc;
 }
-hipError_t launch_resample(const float* x, long n_in, const float* h, int P, int Q, int W, float* out, long n_out, hipStream_t s) {
+__global__ __launch_bounds__(256) void resample_apply_kernel(const float* __restrict__ x, long n_in, const float* __restrict__ At, int fft_in, int fft_out, int delay,
+                                                             float* __restrict__ out, long n_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const long j = i + delay, c = j / fft_out; const int m = (int)(j - c * fft_out);
+    const int ld = 2 * fft_out;
+    float a0 = 0.f, a1 = 0.f;
+    {
+        const long base = c * fft_in; const int cnt = (int)max(0L, min((long)fft_in, n_in - base));
+        const float* xp = x + base; const float* ap = At + m;
+        for (int n = 0; n < cnt; n++) a0 = fmaf(xp[n], ap[(size_t)n * ld], a0);
+    }
+    if (c > 0) {
+        const long base = (c - 1) * fft_in; const int cnt = (int)max(0L, min((long)fft_in, n_in - base));
+        const float* xp = x + base; const float* ap = At + fft_out + m;
+        for (int n = 0; n < cnt; n++) a1 = fmaf(xp[n], ap[(size_t)n * ld], a1);
+    }
+    out[i] = a0 + a1;
+}
+hipError_t launch_resample_matrix(const double* H, int new_len, int fft_in, int fft_out, float* At, hipStream_t s) {
+    const long total = (long)fft_in * 2 * fft_out;
+    resample_matrix_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(H, new_len, fft_in, fft_out, At);
+    return hipGetLastError();
+}
+hipError_t launch_resample(const float* x, long n_in, const float* At, int fft_in, int fft_out, int delay, float* out, long n_out, hipStream_t s) {
     if (n_out <= 0) return hipSuccess;
-    resample_kernel<<<dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s>>>(x, n_in, h, P, Q, W, out, n_out);
+    resample_apply_kernel<<<dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s>>>(x, n_in, At, fft_in, fft_out, delay, out, n_out);
     return hipGetLastError();
 }
 
