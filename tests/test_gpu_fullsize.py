@@ -184,6 +184,31 @@ def test_full_batch16_vs_oracle_golden(pkg, full):
     print(f"batch-16 golden: all 16 rows agree with the oracle for {stop}/108 steps ({int((outs[0] == rids).sum())} ids equal)")
 
 
+def test_full_ragged_batch_groups_retire(pkg, full):
+    """A ragged batch wider than one 16-row group at FULL size: vox_transcribe_batch runs the rows longest first and RETIRES a group's layer chain
+    once its longest member is done.  The 16 s golden clip sits in the caller's LAST slot between 3..9 s clips: it must still reproduce the oracle's
+    ids in that slot, the 16-row batch of the same clip, and the run with retirement / sorting switched off (rows are independent of their group)."""
+    m, _, _ = full
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_16s_oracle.npz"))
+    t = pkg.TimeEmbedding(3072).embed(6.0)
+    rids, top1, top2, amax = g["ids"], g["top1"], g["top2"], float(g["logit_absmax"])
+    safe = (top1 - top2) > 10 * TOL * max(1.0, amax)
+    stop = len(rids) if safe.all() else int(np.argmin(safe))
+    secs = [3.0 + 0.37 * (i % 17) for i in range(21)]                     # 3 .. 8.9 s, not sorted
+    clips = [pkg.synth.synth_audio(s, seed=500 + i) for i, s in enumerate(secs)] + [pkg.synth.synth_audio(16.0, seed=1234)]
+    outs = m.transcribe_batch(clips, t)                                   # 22 rows: groups of 16 + 6; the short group retires after ~40 steps
+    assert len(outs) == 22 and len(outs[-1]) == 108
+    assert (outs[-1][:stop] == rids[:stop]).all(), "the golden clip (caller's last slot) differs from the oracle before its first near-tie"
+    os.environ["VOX_BATCH_NO_RETIRE"] = "1"; os.environ["VOX_BATCH_NO_SORT"] = "1"
+    try:
+        ref = m.transcribe_batch(clips, t)
+    finally:
+        del os.environ["VOX_BATCH_NO_RETIRE"]; del os.environ["VOX_BATCH_NO_SORT"]
+    for r, (a, b) in enumerate(zip(outs, ref)):
+        assert len(a) == len(b) and (a == b).all(), f"slot {r}: retiring / sorting changed the ids"
+    print(f"ragged full-size batch: 22 rows identical with and without group retirement; golden clip agrees with the oracle for {stop}/108 steps")
+
+
 def test_full_16s_clip_f32_vs_oracle_golden(pkg):
     """BASELINE configs[0-1] at FULL size: the f32 SafeTensors path (VoxtralModelLoader -> transcribe_f32_with_model, bin/transcribe.rs:362-438;
     dense bf16 weights exact on device, f32 activations / accumulation) on the 16 s bench clip against the CPU oracle's golden

@@ -217,6 +217,28 @@ def test_transcribe_batch_wide_and_fallback_paths(pkg, ctx, tiny, monkeypatch):
         m.transcribe_batch([clips[0]] * 65, t)                # batch size limit (1..64)
 
 
+def test_transcribe_batch_ragged_groups_retire(pkg, ctx, tiny, monkeypatch):
+    """40 utterances of very different lengths in arbitrary order (three 16-row groups): rows run longest first and a group is retired when its longest
+    member is done -- every caller slot must get exactly the ids of the run without sorting / retirement, the single-stream ids (up to a near-tie), and
+    the right count."""
+    m, _, _ = tiny
+    t = pkg.TimeEmbedding(256).embed(6.0)
+    secs = [0.4 + 0.23 * ((7 * i) % 19) for i in range(40)]               # 0.4 .. 4.5 s, arbitrary order
+    clips = [pkg.synth.synth_audio(s, seed=900 + i) for i, s in enumerate(secs)]
+    outs = m.transcribe_batch(clips, t)
+    tm = m.timings(); assert tm["decode_tokens"] == sum(len(o) for o in outs)
+    monkeypatch.setenv("VOX_BATCH_NO_RETIRE", "1"); monkeypatch.setenv("VOX_BATCH_NO_SORT", "1")
+    ref = m.transcribe_batch(clips, t)
+    monkeypatch.delenv("VOX_BATCH_NO_RETIRE"); monkeypatch.delenv("VOX_BATCH_NO_SORT")
+    assert len(outs) == len(ref) == 40 and len({len(o) for o in outs}) > 8          # really ragged
+    for r, (a, b) in enumerate(zip(outs, ref)):
+        assert len(a) == len(b) and (a == b).all(), f"slot {r}: retiring / sorting changed the ids"
+    n_same = check_batch_rows(pkg, ctx, m, clips, t, outs, TOL)
+    print(f"ragged batch with retiring groups: {n_same}/40 sequences identical to single-stream end to end")
+    again = m.transcribe_batch(clips, t)
+    assert all((a == b).all() for a, b in zip(outs, again))               # deterministic (graphs are re-captured per call)
+
+
 def test_transcribe_exactly_prefix_len(pkg, orc, tiny):
     """S == 38 decoder positions (= PREFIX_LEN): the reference prefills, predicts the first token and returns ONE id (gguf/model.rs:887-889
     only returns empty below 38; the decode loop :938 is empty).  T = 606 mel frames -> 303 -> 152 encoder rows -> 38."""

@@ -1798,9 +1798,8 @@ extern "C" int32_t vox_transcribe_audio(vox_model* m, const float* samples, size
 // Every utterance runs the whole hot path; encode + 38-token prefill are per utterance, the decode loop is batched: one step
 // advances all sequences (rows of one skinny MFMA GEMM per linear, so the Q4 weights are streamed once per step for the
 // whole batch), per-sequence positions / KV-cache slices / audio rows live on the device, the step is hipGraph-replayed.
-extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
-                                        int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind) {
-    ARGCHK(m && samples && n_samples && t_embed && out_ids && caps && n_ids, "null argument"); ARGCHK(n > 0 && n <= 64, "batch size %d out of range (1..64)", n);
+static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
+                                     int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of) {      // slot_of[i]: the caller's slot of row i (error messages)
     VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
@@ -1813,11 +1812,11 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     // sequence lengths (pure function of the sample count: pad.rs + mel.rs:175-182 + conv.rs:47-48 + adapter.rs:114)
     std::vector<int> S(n), T(n); int Smax = 0;
     for (int i = 0; i < n; i++) {
-        ARGCHK(samples[i] && n_samples[i] > 0, "empty audio in batch slot %d", i);
+        ARGCHK(samples[i] && n_samples[i] > 0, "empty audio in batch slot %d", slot_of[i]);
         const size_t left = pad_left(&pc), total = left + n_samples[i] + pad_right(&pc, n_samples[i] + left);
         T[i] = (int)(total / 160); S[i] = conv_len(conv_len(T[i])) / c.reshape_factor; Smax = std::max(Smax, S[i]);
         const int cnt_i = S[i] >= PREFIX_LEN ? std::max(S[i] - PREFIX_LEN, 1) : 0;     // S == 38 still emits its first token (model.rs:922-926)
-        ARGCHK(caps[i] >= cnt_i, "out_ids[%d] capacity %d < %d", i, caps[i], cnt_i);
+        ARGCHK(caps[i] >= cnt_i, "out_ids[%d] capacity %d < %d", slot_of[i], caps[i], cnt_i);
     }
     ARGCHK(Smax <= m->dec_rope_len, "sequence too long for the decoder RoPE table");
     const int max_seq = std::max((Smax + 63) / 64 * 64, 64), tstride = std::max(Smax, PREFIX_LEN) + 2;
@@ -1905,23 +1904,30 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, b_h.as<float>(), s,
                                          use_xf ? b_xf1.as<uint16_t>() : nullptr, use_xf ? m->dec[0].attn_norm : nullptr, use_xf ? b_ssq.as<float>() : nullptr,
                                          (long)(xf_bytes(D) / 2), parts_D * 16));
-    auto step = [&]() -> int32_t {
+    // `active`: bit gi = group gi still has a sequence that needs this step.  A group whose sequences have all reached their last position is RETIRED: its layer
+    // chain is not launched any more (its rows idle in place in the argmax / embedding kernel, whose token write is guarded by the sequence length) -- a ragged
+    // batch pays for each group only as long as that group's longest member runs, not for the batch's longest member in every group.
+    auto step = [&](uint32_t active) -> int32_t {
         float* h = b_h.as<float>(); float* xn = b_xn.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>(); float* act = b_act.as<float>();
         if (use_xf) {
-            // groups are independent sequences: group gi > 0 runs its whole layer chain on a side stream (fork / join with events, which
+            // groups are independent sequences: every active group but the first runs its whole layer chain on a side stream (fork / join with events, which
             // a stream capture records as parallel graph branches), so the latency-bound skinny kernels of different groups overlap
-            const bool fork = n_grp > 1 && !knob_str("VOX_BATCH_SERIAL_GROUPS");
+            int n_act = 0; for (int gi = 0; gi < n_grp; gi++) n_act += (active >> gi) & 1u;
+            const bool fork = n_act > 1 && !knob_str("VOX_BATCH_SERIAL_GROUPS");
             if (fork) {
                 if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
-                for (int i = 0; i < n_grp - 1 && i < 3; i++) {
+                for (int i = 0; i < n_act - 1 && i < 3; i++) {
                     if (!cx->aux[i]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking));
                     if (!cx->ev_join[i]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[i], hipEventDisableTiming));
                 }
                 HIPCHK(hipEventRecord(cx->ev_fork, s));
-                for (int i = 0; i < n_grp - 1 && i < 3; i++) HIPCHK(hipStreamWaitEvent(cx->aux[i], cx->ev_fork, 0));
+                for (int i = 0; i < n_act - 1 && i < 3; i++) HIPCHK(hipStreamWaitEvent(cx->aux[i], cx->ev_fork, 0));
             }
+            int k_act = 0;      // index among the active groups: 0 runs on the main stream
             for (int gi = 0; gi < n_grp; gi++) {
-                hipStream_t sg = (fork && gi > 0) ? cx->aux[gi - 1] : s;
+                if (!((active >> gi) & 1u)) continue;
+                const int ka = k_act++;
+                hipStream_t sg = (fork && ka > 0) ? cx->aux[ka - 1] : s;
                 const int r0 = gi * 16, ng = std::min(16, n - r0);
                 uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)gi * (xf_bytes(QD) / 2);
                 uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)gi * (xf_bytes(F) / 2); float* ssq = b_ssq.as<float>() + (size_t)gi * parts_D * 16;
@@ -1946,7 +1952,7 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
                 }
                 { GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = b_logits.as<float>() + (size_t)r0 * V; g.out_stride = V;
                   g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, sg)); }
-                if (fork && gi > 0) { HIPCHK(hipEventRecord(cx->ev_join[gi - 1], sg)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[gi - 1], 0)); }
+                if (fork && ka > 0) { HIPCHK(hipEventRecord(cx->ev_join[ka - 1], sg)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[ka - 1], 0)); }
             }
             HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s,
                                              b_xf1.as<uint16_t>(), m->dec[0].attn_norm, b_ssq.as<float>(), (long)(xf_bytes(D) / 2), parts_D * 16));
@@ -1970,28 +1976,42 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s));
         return VOX_OK;
     };
-    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int replays = 0;
-    if (steps > 0) {
-        VOXCHK(step());                                          // eager first step
-        if (steps > 1 && knob_str("VOX_BATCH_NO_GRAPH")) { for (int i = 1; i < steps; i++) VOXCHK(step()); }   // measurement knob (profilers)
-        else if (steps > 1) {
+    // steps of group gi = those of its longest member; with the rows sorted by length (vox_transcribe_batch does that) the groups retire last to first
+    std::vector<int> steps_g(n_grp, 0);
+    for (int i = 0; i < n; i++) steps_g[i / 16] = std::max(steps_g[i / 16], S[i] - PREFIX_LEN - 1);
+    const bool retire = use_xf && !knob_str("VOX_BATCH_NO_RETIRE");
+    auto active_at = [&](int t) { uint32_t a = 0; for (int gi = 0; gi < n_grp; gi++) if (!retire || t < steps_g[gi]) a |= 1u << gi; return a; };
+    // one instantiated graph per set of active groups (<= n_grp of them when the rows are sorted), captured when the set first occurs
+    struct Graphs {
+        hipStream_t s; std::vector<std::pair<uint32_t, hipGraphExec_t>> ex; std::vector<hipGraph_t> gr;
+        ~Graphs() { (void)hipStreamSynchronize(s); for (auto& e : ex) if (e.second) (void)hipGraphExecDestroy(e.second); for (auto g : gr) if (g) (void)hipGraphDestroy(g); }
+        hipGraphExec_t find(uint32_t a) const { for (auto& e : ex) if (e.first == a) return e.second; return nullptr; }
+    } graphs; graphs.s = s;
+    int replays = 0;
+    const bool no_graph = knob_str("VOX_BATCH_NO_GRAPH") != nullptr;      // measurement knob (profilers)
+    for (int t = 0; t < steps; t++) {
+        const uint32_t act = active_at(t);
+        if (t == 0 || no_graph) { VOXCHK(step(act)); continue; }         // eager first step
+        hipGraphExec_t ge = graphs.find(act);
+        if (!ge) {
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int32_t r = step();
+            const int32_t r = step(act);
+            hipGraph_t graph = nullptr;
             const hipError_t ce = hipStreamEndCapture(s, &graph);
-            if (r != VOX_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
+            if (graph) graphs.gr.push_back(graph);
+            if (r != VOX_OK) return r;
             HIPCHK(ce);
-            hipError_t ie = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
-            if (ie != hipSuccess) { (void)hipGraphDestroy(graph); return fail(VOX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
-            for (int i = 1; i < steps; i++) { if (hipGraphLaunch(gexec, s) != hipSuccess) { (void)hipGraphExecDestroy(gexec); (void)hipGraphDestroy(graph); return fail(VOX_ERR_HIP, "hipGraphLaunch failed"); } }
-            replays = steps - 1;
+            const hipError_t ie = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+            if (ie != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+            graphs.ex.emplace_back(act, ge);
         }
+        if (hipGraphLaunch(ge, s) != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphLaunch failed");
+        replays++;
     }
     std::vector<int32_t> host_tok((size_t)n * tstride);
     HIPCHK(hipMemcpyAsync(host_tok.data(), d_tok, host_tok.size() * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (gexec) (void)hipGraphExecDestroy(gexec);
-    if (graph) (void)hipGraphDestroy(graph);
     int total = 0;
     for (int i = 0; i < n; i++) {
         const int cnt = S[i] >= PREFIX_LEN ? std::max(S[i] - PREFIX_LEN, 1) : 0;
@@ -2001,6 +2021,24 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     m->timings.preprocess_ms = pre_ms; m->timings.encode_ms = enc_ms; m->timings.decode_ms = now_ms() - t1; m->timings.total_ms = now_ms() - t0;
     m->timings.decode_tokens = total; m->timings.graph_replays = replays;
     return VOX_OK;
+}
+
+// Entry point: rows are processed LONGEST FIRST (a stable sort of the caller's slots by sample count; sequence length is monotone in it), so that the
+// 16-row groups of the decode loop retire last to first (see `step` above) -- results are per row and land in the caller's slot i whatever the internal order.
+extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
+                                        int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind) {
+    ARGCHK(m && samples && n_samples && t_embed && out_ids && caps && n_ids, "null argument"); ARGCHK(n > 0 && n <= 64, "batch size %d out of range (1..64)", n);
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    if (n > 16 && !knob_str("VOX_BATCH_NO_SORT"))
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_samples[a] > n_samples[b]; });
+    bool identity = true; for (int i = 0; i < n; i++) identity = identity && order[i] == i;
+    if (identity) return transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, order.data());
+    std::vector<const float*> p_s(n); std::vector<size_t> p_n(n); std::vector<int32_t*> p_o(n); std::vector<int32_t> p_c(n), p_k(n, 0);
+    for (int i = 0; i < n; i++) { const int o = order[i]; p_s[i] = samples[o]; p_n[i] = n_samples[o]; p_o[i] = out_ids[o]; p_c[i] = caps[o]; }
+    const int32_t r = transcribe_batch_impl(m, n, p_s.data(), p_n.data(), t_embed, p_o.data(), p_c.data(), p_k.data(), mem_kind, order.data());
+    if (r == VOX_OK) for (int i = 0; i < n; i++) n_ids[order[i]] = p_k[i];
+    return r;
 }
 
 extern "C" int32_t vox_embed_tokens_from_ids(vox_model* m, const int32_t* ids, int32_t n, float* out) {
