@@ -1459,6 +1459,7 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
     // wo / w2 (EPI_RESID) as two-dimensional GEMMs whose K-slice planes are summed by the RMSNorm that follows (one launch less per GEMM): `pend` = slices of the
     // previous layer's w2 still waiting in the plane buffer.  VOX_PREFILL_NO_SUMK=1: finishing kernels instead.
     const bool fuse_fin = norm_xf && knob_str("VOX_PREFILL_NO_SUMK") == nullptr;
+    const bool fuse_fin2 = fuse_fin && knob_str("VOX_PREFILL_NO_FUSED_FIN") == nullptr;      // finishing kernels of q|k|v (+ RoPE + cache write) and w1|w3 (+ SwiGLU -> XF tiles)
     auto planes_gemm = [&](const Q4W& w, const float* in, int K, int KZ) -> int32_t {      // in [M][K] f32 -> XF tiles -> planes
         HIPCHK(launch_xf_rows(in, K, M, K, cx->xf_scratch, s));
         GemmParams p{}; p.w = w; p.xf = reinterpret_cast<const uint4*>(cx->xf_scratch); p.M = M; p.kz_scratch = cx->kz_scratch; p.kz_scratch_bytes = cx->kz_scratch_bytes;
@@ -1468,18 +1469,28 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
     int pend = 0;
     for (int l = 0; l < c.dec_layers; l++) {
         const DecLayer& L = m->dec[l]; float* kl = kc->k + (size_t)l * lf; float* vl = kc->v + (size_t)l * lf;
+        bool rope_done = false, act_in_xf = false;
         if (norm_xf && xf_ok(L.wqkv.w)) {
             if (pend) HIPCHK(launch_rms_norm_xf_sumk(x, D, M, D, cx->kz_scratch, pend, L.attn_norm, nullptr, c.norm_eps, cx->xf_scratch, s));      // + the previous layer's w2
             else HIPCHK(launch_rms_norm_xf(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, cx->xf_scratch, s));
             pend = 0;
-            VOXCHK(linear_xf(L.wqkv.w, qkv, W, EPI_STORE));
+            // q|k|v as a two-dimensional GEMM whose finishing kernel also applies RoPE and writes the k / v rows into the cache (three launches less per layer)
+            const int kz_qkv = fuse_fin2 && cx->kz_scratch && W == QD + 2 * KD ? q4_skinny_mt2_plan(L.wqkv.w, M) : 0;
+            if (kz_qkv && (size_t)kz_qkv * M * W * 4 <= cx->kz_scratch_bytes) {
+                GemmParams p{}; p.w = L.wqkv.w; p.xf = reinterpret_cast<const uint4*>(cx->xf_scratch); p.M = M; p.kz_scratch = cx->kz_scratch; p.kz_scratch_bytes = cx->kz_scratch_bytes;
+                HIPCHK(launch_q4_skinny_mt2_planes(p, kz_qkv, s));
+                HIPCHK(launch_splitk_finish_rope_kv(cx->kz_scratch, kz_qkv, M, W, qkv, W, QD, KV, hd, off, m->dec_cos, m->dec_sin, kl, vl, kc->max_seq * hd, s));
+                rope_done = true;
+            } else VOXCHK(linear_xf(L.wqkv.w, qkv, W, EPI_STORE));
         } else {
             if (pend) { HIPCHK(launch_splitk_finish_resid(cx->kz_scratch, pend, M, D, x, D, s)); pend = 0; }
             HIPCHK(launch_rms_norm(x, D, M, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
             VOXCHK(q4_linear_dev(cx, L.wqkv.w, nullptr, xn, D, M, qkv, W));
         }
-        HIPCHK(launch_rope(qkv, M, W, QD + KD, hd, off, m->dec_cos, m->dec_sin, s, seq_rows));
-        HIPCHK(launch_kv_store(qkv, M, W, QD, KV, hd, off, kl, vl, kc->max_seq * hd, s, seq_rows, kv_seq_stride));
+        if (!rope_done) {
+            HIPCHK(launch_rope(qkv, M, W, QD + KD, hd, off, m->dec_cos, m->dec_sin, s, seq_rows));
+            HIPCHK(launch_kv_store(qkv, M, W, QD, KV, hd, off, kl, vl, kc->max_seq * hd, s, seq_rows, kv_seq_stride));
+        }
         AttnParams ap{}; ap.q = qkv; ap.q_stride = W; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd;
         ap.out = att; ap.out_stride = QD; ap.M = Mq; ap.kv_len = off + Mq; ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = off; ap.window = c.dec_window;
         ap.q_seq_stride = seq_rows * W; ap.out_seq_stride = seq_rows * QD; ap.kv_seq_stride = kv_seq_stride;
@@ -1488,7 +1499,16 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
         if (kz_wo && (size_t)kz_wo * M * D * 4 <= cx->kz_scratch_bytes) {
             VOXCHK(planes_gemm(L.wo.w, att, QD, kz_wo));
             HIPCHK(launch_rms_norm_xf_sumk(x, D, M, D, cx->kz_scratch, kz_wo, L.ffn_norm, L.ada_mul, c.norm_eps, cx->xf_scratch, s));      // x += wo(att); norm then Ada x*(1+s) (model.rs:382-385)
-            VOXCHK(linear_xf(L.w13.w, ffn, F, EPI_SWIGLU));
+            // w1|w3 as planes whose finishing kernel writes SiLU(gate) * up straight into the XF tiles w2 reads (no f32 activations, no conversion launch)
+            const int kz_13 = fuse_fin2 && L.w13.w.N == 2 * F && F % 128 == 0 && F <= 16384 && L.w2.w.N == D ? q4_skinny_mt2_plan(L.w13.w, M) : 0;
+            const int kz_w2n = kz_13 ? q4_skinny_mt2_plan(L.w2.w, M) : 0;
+            if (kz_13 && kz_w2n && (size_t)kz_13 * M * 2 * F * 4 <= cx->kz_scratch_bytes && (size_t)kz_w2n * M * D * 4 <= cx->kz_scratch_bytes && (size_t)((M + 15) / 16) * F * 64 <= cx->xf_scratch_bytes &&
+                (l + 1 == c.dec_layers || xf_ok(m->dec[l + 1].wqkv.w))) {
+                GemmParams p{}; p.w = L.w13.w; p.xf = reinterpret_cast<const uint4*>(cx->xf_scratch); p.M = M; p.kz_scratch = cx->kz_scratch; p.kz_scratch_bytes = cx->kz_scratch_bytes;
+                HIPCHK(launch_q4_skinny_mt2_planes(p, kz_13, s));
+                HIPCHK(launch_splitk_finish_swiglu_xf(cx->kz_scratch, kz_13, M, 2 * F, nullptr, cx->xf_scratch, s));
+                act_in_xf = true;
+            } else VOXCHK(linear_xf(L.w13.w, ffn, F, EPI_SWIGLU));
         } else {
             VOXCHK(q4_linear_dev(cx, L.wo.w, nullptr, att, QD, M, x, D, EPI_RESID, x, D));
             if (norm_xf && xf_ok(L.w13.w)) {
@@ -1500,7 +1520,10 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
             }
         }
         const int kz_w2 = fuse_fin && cx->kz_scratch && L.w2.w.N == D && F % 128 == 0 && F <= 16384 ? q4_skinny_mt2_plan(L.w2.w, M) : 0;
-        if (kz_w2 && (size_t)kz_w2 * M * D * 4 <= cx->kz_scratch_bytes && (l + 1 == c.dec_layers || xf_ok(m->dec[l + 1].wqkv.w))) {
+        if (act_in_xf) {      // (conditions checked where the activations were written)
+            GemmParams p{}; p.w = L.w2.w; p.xf = reinterpret_cast<const uint4*>(cx->xf_scratch); p.M = M; p.kz_scratch = cx->kz_scratch; p.kz_scratch_bytes = cx->kz_scratch_bytes;
+            HIPCHK(launch_q4_skinny_mt2_planes(p, kz_w2, s)); pend = kz_w2;
+        } else if (kz_w2 && (size_t)kz_w2 * M * D * 4 <= cx->kz_scratch_bytes && (l + 1 == c.dec_layers || xf_ok(m->dec[l + 1].wqkv.w))) {
             VOXCHK(planes_gemm(L.w2.w, ffn, F, kz_w2)); pend = kz_w2;
         } else VOXCHK(q4_linear_dev(cx, L.w2.w, nullptr, ffn, F, M, x, D, EPI_RESID, x, D));
     }

@@ -104,6 +104,9 @@ int q4_skinny_mt2_plan(const Q4W& w, int M);                                    
 hipError_t launch_xf_rows(const float* x, int x_stride, int M, int K, uint16_t* xf, hipStream_t s);        // f32 rows -> XF tiles
 hipError_t launch_q4_skinny_mt2_planes(const GemmParams& p, int KZ, hipStream_t s);                         // p.xf in, planes [KZ][M][N] -> p.kz_scratch
 hipError_t launch_splitk_finish_resid(const float* planes, int KZ, int M, int N, float* x, int x_stride, hipStream_t s);
+hipError_t launch_splitk_finish_swiglu_xf(const float* planes, int KZ, int M, int N, const float* bias, uint16_t* xf, hipStream_t s);      // planes -> SwiGLU -> XF tiles (K' = N / 2)
+hipError_t launch_splitk_finish_rope_kv(const float* planes, int KZ, int M, int N, float* q_out, int q_stride, int n_q, int n_kv, int hd, int pos_off,
+                                        const float* cos_t, const float* sin_t, float* kc, float* vc, int head_stride, hipStream_t s);           // planes -> RoPE -> q rows + KV cache
 hipError_t launch_rms_norm_xf_sumk(float* x, int x_stride, int rows, int dim, const float* planes, int kz, const float* gamma, const float* mul, float eps, uint16_t* xf, hipStream_t s);
 hipError_t launch_rms_norm_xf(const float* x, int x_stride, int rows, int dim, const float* gamma, const float* mul,
                               float eps, uint16_t* xf, hipStream_t s);   // rows <= 16 -> XF fragment planes

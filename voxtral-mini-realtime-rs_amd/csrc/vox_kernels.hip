@@ -1825,6 +1825,59 @@ hipError_t launch_q4_skinny_mt2_planes(const GemmParams& p_in, int KZ, hipStream
     if (mt == 3) return skinny_mt2_kernel_launch<3, 1>(p, KZ, nst, s);
     return hipErrorInvalidValue;
 }
+// Finishing steps of the 38-token prefill folded into what used to follow them (one launch instead of two / three; same arithmetic, same order):
+//  * w1|w3: sum of the planes -> SiLU(gate) * up -> straight into the XF tiles of w2's input (was: f32 rows, then xf_rows_kernel)
+__global__ __launch_bounds__(256) void splitk_finish_swiglu_xf_kernel(const float* __restrict__ planes, int KZ, int M, int N, const float* __restrict__ bias, uint16_t* __restrict__ xf) {
+    const int K2 = N >> 1, k4 = K2 >> 2;
+    const long total = (long)M * k4; const size_t plane = (size_t)M * N, tile_stride = (size_t)2 * (K2 >> 7) * 256 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / k4), k = (int)(i % k4) * 4, n = 2 * k;
+        const float4* p0 = reinterpret_cast<const float4*>(planes + (size_t)row * N + n);
+        float4 a = p0[0], b = p0[1];
+        if (KZ > 1) { plane_sum_add(a, p0 + (plane >> 2), plane >> 2, KZ - 1); plane_sum_add(b, p0 + (plane >> 2) + 1, plane >> 2, KZ - 1); }
+        if (bias) { const float4 ba = *reinterpret_cast<const float4*>(bias + n), bb = *reinterpret_cast<const float4*>(bias + n + 4); a = a + ba; b = b + bb; }
+        xf_store4(xf + (size_t)(row >> 4) * tile_stride, K2, row & 15, k, make_float4(silu_f(a.x) * a.y, silu_f(a.z) * a.w, silu_f(b.x) * b.y, silu_f(b.z) * b.w));
+    }
+}
+//  * q|k|v: sum of the planes -> RoPE on the q and k pairs (rope_kernel's formulas) -> q rows to the f32 buffer the attention reads, k / v rows straight into
+//    the cache (was: f32 rows, rope_kernel in place, kv_store_kernel).  One sequence; row m sits at position pos_off + m.
+__global__ __launch_bounds__(256) void splitk_finish_rope_kv_kernel(const float* __restrict__ planes, int KZ, int M, int N, float* __restrict__ q_out, int q_stride, int n_q, int n_kv, int hd,
+                                                                   int pos_off, const float* __restrict__ cos_t, const float* __restrict__ sin_t, float* __restrict__ kc, float* __restrict__ vc,
+                                                                   int head_stride) {
+    const int n4 = N >> 2, kd = n_kv * hd;
+    const long total = (long)M * n4; const size_t plane = (size_t)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+        const float4* p0 = reinterpret_cast<const float4*>(planes + (size_t)m * N + n);
+        float4 v = p0[0];
+        if (KZ > 1) plane_sum_add(v, p0 + (plane >> 2), plane >> 2, KZ - 1);
+        const int pos = pos_off + m;
+        if (n < n_q + kd) {
+            const size_t ti = (size_t)pos * (hd >> 1) + ((n % hd) >> 1);
+            const float c0 = cos_t[ti], s0 = sin_t[ti], c1 = cos_t[ti + 1], s1 = sin_t[ti + 1];
+            v = make_float4(v.x * c0 - v.y * s0, v.x * s0 + v.y * c0, v.z * c1 - v.w * s1, v.z * s1 + v.w * c1);
+        }
+        if (n < n_q) *reinterpret_cast<float4*>(q_out + (size_t)m * q_stride + n) = v;
+        else {
+            const int cidx = n < n_q + kd ? n - n_q : n - n_q - kd;
+            float* dst = (n < n_q + kd ? kc : vc) + (size_t)(cidx / hd) * head_stride + (size_t)pos * hd + (cidx % hd);
+            *reinterpret_cast<float4*>(dst) = v;
+        }
+    }
+}
+hipError_t launch_splitk_finish_swiglu_xf(const float* planes, int KZ, int M, int N, const float* bias, uint16_t* xf, hipStream_t s) {
+    if (KZ < 1 || M < 1 || M > 48 || N % 256) return hipErrorInvalidValue;
+    const long total = (long)M * (N >> 3);
+    splitk_finish_swiglu_xf_kernel<<<(int)std::min<long>((total + 255) / 256, 2048), 256, 0, s>>>(planes, KZ, M, N, bias, xf);
+    return hipGetLastError();
+}
+hipError_t launch_splitk_finish_rope_kv(const float* planes, int KZ, int M, int N, float* q_out, int q_stride, int n_q, int n_kv, int hd, int pos_off,
+                                        const float* cos_t, const float* sin_t, float* kc, float* vc, int head_stride, hipStream_t s) {
+    if (KZ < 1 || M < 1 || N % 4 || hd % 4 || n_q % hd || N != n_q + 2 * n_kv * hd) return hipErrorInvalidValue;
+    const long total = (long)M * (N >> 2);
+    splitk_finish_rope_kv_kernel<<<(int)std::min<long>((total + 255) / 256, 2048), 256, 0, s>>>(planes, KZ, M, N, q_out, q_stride, n_q, n_kv, hd, pos_off, cos_t, sin_t, kc, vc, head_stride);
+    return hipGetLastError();
+}
 hipError_t launch_splitk_finish_resid(const float* planes, int KZ, int M, int N, float* x, int x_stride, hipStream_t s) {      // x += sum of the planes
     const long total = (long)M * N;
     splitk_finish_kernel<EPI_RESID><<<(int)std::min<long>((total + 255) / 256, 2048), 256, 0, s>>>(planes, KZ, M, N, nullptr, x, x_stride, x, x_stride);
