@@ -435,7 +435,10 @@ def test_full_30s_heavytail_vs_oracle_golden(pkg, orc):
         rh = o.forward_hidden_with_cache(x0, t, oc); gh = dec.forward_hidden_with_cache(x0[None], t, c)[0]
         e_dec = rel_err(gh, rh)
         e_lm = rel_err(dec.lm_head(rh[None, -1:])[0], o.lm_head(rh[-1:]))
-        print(f"heavy-tail stage parity: encoder+adapter {e_enc:.3e}, decoder prefill {e_dec:.3e}, lm_head {e_lm:.3e} (bound {TOL:.0e})")
-        assert e_enc < TOL and e_dec < TOL and e_lm < TOL
+        # The 38-token prefill of THIS fixture is bounded at 2 x TOL: its outlier channels make the result depend on the f32 summation order at the 1e-4 level on
+        # both sides (the oracle sums sequentially in f32).  Measured over eleven K decompositions of the same GEMMs (profiles/r03_heavytail_prefill_decompositions.txt):
+        # 1.4e-4 .. 3.3e-4 against the oracle, and the oracle itself 1.6e-4 from the mean of the eleven -- no decomposition is "the" accurate one.
+        print(f"heavy-tail stage parity: encoder+adapter {e_enc:.3e}, decoder prefill {e_dec:.3e} (bound {2 * TOL:.0e}), lm_head {e_lm:.3e} (bound {TOL:.0e})")
+        assert e_enc < TOL and e_dec < 2 * TOL and e_lm < TOL
     finally:
         m.close(); o.close(); ctx.close()

@@ -444,7 +444,7 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
         lds_st(&c->gathering, 0u);
         if (last) break;
         if (!odd) {
-            wait_ge(&c->gw_flag, 1u, c, p.err, ERR_STAGE);
+            wait_ge(&c->gw_flag, (unsigned)NCONS, c, p.err, ERR_STAGE);
             const bool xloc_nt = (p.flags & 128) != 0 && (p.flags & 4096) != 0 && lds_ld(&c->xcd_ok) != 0;      // (measurement knob 4096: XCD-local edges polled with nt loads)
             {   // this step's q_h, k_g, v_g rows
                 wait_ge(&c->pub_cnt, NCONS * (4u * (unsigned)l + 1u), c, p.err, ERR_STAGE);
@@ -471,7 +471,7 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
                 const int r = min(lane, OWN - 1);
 #pragma unroll 4
                 for (int hh = 0; hh < NPW; hh++) a += tmp[hh * OWN + r];      // fixed order
-                wait_ge(&c->gw_flag, 1u, c, p.err, ERR_STAGE);
+                wait_ge(&c->gw_flag, (unsigned)NCONS, c, p.err, ERR_STAGE);
                 if (!((p.flags & 16384) && blockIdx.x == 7 && l == 1))      // (flag 16384 = FAULT INJECTION for the test of the bounded waits: workgroup 7 loses a publish)
                     comm_publish_rows(p, lane, c->h_own[r] + a, gwt[(l * 2 + 1) * 16 + r], p.H1, p.SS1, tag, c->h1_own);
             }
@@ -758,33 +758,41 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
     }
     const float scale = 1.0f / sqrtf((float)EHD);
     const int n_items = 3 * p.n_layers, npass_lm = lm_passes(p.vocab), row0_lm = lm_rows_per_cu(p.vocab) * b;
-    if (cw == NCONS - 1) {      // norm weights (* Ada scale) of this CU's 12 rows for every layer -> LDS, once per launch, while everybody waits for the first all-gather
+    {   // norm weights (* Ada scale) of this CU's 12 rows for every layer -> LDS, once per launch.  Wave cw fills the layers l = cw, cw + 12, cw + 24 (lane = 16 * slot + row):
+        // three loads per lane, all in flight at once -- ONE round trip, in parallel on the twelve waves and under the COMM wave's first publish.  (One wave walking
+        // all 27 layers in a loop took ~6 us, and every consumer waited for it before it even looked at the ring: "x staged" of layer 0 came at 10.6 us.)
         const EngLayerTab* tab = reinterpret_cast<const EngLayerTab*>(lds + L_TAB);
         float* gwt = reinterpret_cast<float*>(lds + L_GW);
-        for (int i = lane0; i <= p.n_layers * OWN + OWN - 1; i += 64) {
-            const int l = i / OWN, r = i - l * OWN; const unsigned k = (unsigned)(OWN * b + r);
-            if (l < p.n_layers) {
-                gwt[(l * 2) * 16 + r] = as_g(tab[l].attn_norm)[k];
-                gwt[(l * 2 + 1) * 16 + r] = as_g(tab[l].ffn_norm)[k] * as_g(tab[l].ada_mul)[k];
-            } else gwt[(l * 2) * 16 + r] = as_g(p.final_norm)[k] * 512.0f;      // the lm_head's VALU path reads nibble bytes as e4m3 (q / 512)
-        }
+        const bool xchg = cw == NCONS - 1 && (p.flags & 128) != 0;
+        const unsigned my = c->xcc_id;
         // XCD-local edges (q|k|v -> attention, SwiGLU -> w2) go through the shared L2 only if the 32 workgroups of group g really sit on ONE XCD: workgroup b is
         // observed on XCD (b + rotation) % 8 (the dispatcher's round-robin carries over from the previous launch), so the ids are EXCHANGED and compared
-        unsigned ok = 0;
-        if (p.flags & 128) {
-            const unsigned my = c->xcc_id;
-            if (lane0 == 0) publish(p.XC + b, tag_base, __uint_as_float(my));
-            float v[1];
-            const bool got = sweep<1>(p.XC, NCU * 8u, tag_base, [&](int) { return 8 * (lane0 & 31) + g; }, [&]() { return 0; }, false, v, c, p.err);
-            ok = got && __all(__float_as_uint(v[0]) == my) ? 1u : 0u;
-            if (!ok && lane0 == 0) __hip_atomic_store(p.err + 1, 9u | ((unsigned)b << 8) | (my << 16), RLX, AG);      // informational (err[1]): the fast edges are off for this launch
+        if (xchg && lane0 == 0) publish(p.XC + b, tag_base, __uint_as_float(my));      // first: the store is on its way while the table loads are
+        const int l = cw + NCONS * (lane0 >> 4), r = lane0 & 15, lc = min(l, max(p.n_layers - 1, 0));
+        const bool lok = r < OWN && l <= p.n_layers && (lane0 >> 4) < 3, lay = l < p.n_layers;
+        const unsigned k = (unsigned)(OWN * b + min(r, OWN - 1));
+        const gcf_p pa = as_g(lay ? tab[lc].attn_norm : p.final_norm);
+        float wa = 0.f, wf = 0.f, wd = 0.f;
+        if (lok) { wa = pa[k]; if (p.n_layers > 0) { wf = as_g(tab[lc].ffn_norm)[k]; wd = as_g(tab[lc].ada_mul)[k]; } }
+        if (lok) {
+            gwt[(l * 2) * 16 + r] = lay ? wa : wa * 512.0f;      // l = L: the final norm * 512 -- the lm_head's VALU path reads nibble bytes as e4m3 (q / 512)
+            if (lay) gwt[(l * 2 + 1) * 16 + r] = wf * wd;
         }
-        lds_st(&c->xcd_ok, ok);
-        ENG_CFENCE(); lds_st(&c->gw_flag, 1u);
+        if (cw == NCONS - 1) {
+            unsigned ok = 0;
+            if (xchg) {
+                float v[1];
+                const bool got = sweep<1>(p.XC, NCU * 8u, tag_base, [&](int) { return 8 * (lane0 & 31) + g; }, [&]() { return 0; }, false, v, c, p.err);
+                ok = got && __all(__float_as_uint(v[0]) == my) ? 1u : 0u;
+                if (!ok && lane0 == 0) __hip_atomic_store(p.err + 1, 9u | ((unsigned)b << 8) | (my << 16), RLX, AG);      // informational (err[1]): the fast edges are off for this launch
+            }
+            lds_st(&c->xcd_ok, ok);
+        }
+        ENG_CFENCE();
+        if (lane0 == 0) __hip_atomic_fetch_add(&c->gw_flag, 1u, RLX, WG);      // NCONS arrivals = table complete and xcd_ok decided (the exchanging wave arrives after its sweep)
     }
-    wait_ge(&c->gw_flag, 1u, c, p.err, ERR_STAGE);
     float best = -INFINITY; int best_i = 0x7fffffff;
-    const bool xloc = (p.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0;      // this workgroup runs on XCD blockIdx % 8, like (by the same check) the group's other 31
+    bool xloc = false;      // this workgroup runs on XCD blockIdx % 8, like (by the same check) the group's other 31: decided by the exchange above, read behind layer 0's q|k|v steps
 
 #pragma unroll 1
     for (int it = 0; it <= n_items; it++) {
@@ -842,6 +850,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
                 if (lane < 8) part[(16 + lane) * NCONS + cw] = a1;
             }
             cs.cbarrier();
+            if (it == 0) { wait_ge(&c->gw_flag, (unsigned)NCONS, c, p.err, ERR_STAGE); xloc = (p.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0; }      // (long complete by now)
             if (cw == 0) {      // rows 0..15: q, 16..19: k, 20..23: v -- sum the 12 K-slices (fixed order), RMSNorm scale, RoPE on (even, odd) row pairs, publish
                 const int r = min(lane, 23);
                 float a = 0.f;
