@@ -1,6 +1,6 @@
 // engine_bench -- stand-alone check + timing of the persistent decode-step engine (csrc/vox_engine.hip) against the per-operator kernels
 // (csrc/vox_kernels.hip: the path the product used before, and keeps for other geometries).  Not product code; links the two object files.
-//   engine_bench [n_layers=26] [pos=100] [reps=40] [tl_layer=-1] [flags=0] [pace_ticks=0]
+//   engine_bench [n_layers=26] [pos=100] [reps=40] [tl_layer=-1] [flags=0] [pace_ticks=0] [rates=0] [loader_pace=-1] [time_flagged=0]
 // Synthetic Q4 weights (random nibbles, f16 scales ~ N(0, 0.02) weights), random residual stream / KV cache.  Checks, in one run:
 //   * LDS-DMA reaches LDS addresses >= 64 KiB (the ring needs it);
 //   * v_cvt_pk_f32_fp8 of bytes 0..15 is q * 2^-9 (the consumer's nibble conversion);
@@ -251,6 +251,36 @@ int main(int argc, char** argv) {
     auto again = d2h(logits_eng, V);
     printf("  run-to-run: %s\n", memcmp(again.data(), eng_logits.data(), (size_t)V * 4) == 0 ? "bit-identical" : "DIFFERENT");
     check_err("second launch");
+    {   // ---- flags 65536: the step input formed at launch start (argmax over the previous launch's partials + embedding + audio row) against the three-launch
+        // form (engine, argmax_embed_kernel, engine): same token, same position bookkeeping, BIT-identical logits of the following step
+        float* audio = make_f32((size_t)(max_seq + 8) * D, 7001u, 0.0f, 1.0f);
+        int* d_tok = dalloc<int>(max_seq + 8); CHK(hipMemset(d_tok, 0, (max_seq + 8) * 4));
+        int* d_pos2 = dalloc<int>(1); CHK(hipMemcpy(d_pos2, &pos, 4, hipMemcpyHostToDevice));
+        float* h2 = dalloc<float>(D); float* pvk = dalloc<float>(256); int* pik = dalloc<int>(256);
+        CHK(hipMemcpy(pvk, pv2, 1024, hipMemcpyDeviceToDevice)); CHK(hipMemcpy(pik, pi2, 1024, hipMemcpyDeviceToDevice));      // partials of the step just run
+        CHK(launch_argmax_embed(pv2, pi2, 256, d_tok, d_pos2, tok, audio, D, h2, s));
+        EngParams e2 = ep; e2.h_in = h2; e2.pos_ptr = d_pos2; e2.logits_out = logits_eng;
+        CHK(launch_decode_engine(e2, s)); CHK(hipStreamSynchronize(s));
+        auto la = d2h(logits_eng, V); int tok_a, pos_a; CHK(hipMemcpy(&tok_a, d_tok + pos + 1, 4, hipMemcpyDeviceToHost)); CHK(hipMemcpy(&pos_a, d_pos2, 4, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(pv2, pvk, 1024, hipMemcpyDeviceToDevice)); CHK(hipMemcpy(pi2, pik, 1024, hipMemcpyDeviceToDevice));
+        CHK(hipMemset(d_tok, 0, (max_seq + 8) * 4)); CHK(hipMemcpy(d_pos2, &pos, 4, hipMemcpyHostToDevice)); CHK(hipMemset(logits_eng, 0, (size_t)V * 4));
+        EngParams e3 = ep; e3.h_in = nullptr; e3.pos_ptr = d_pos2; e3.pos_rw = d_pos2; e3.tokens = d_tok; e3.tok_qs = tok.qs; e3.tok_sc = tok.sc; e3.tok_nb = tok.nb; e3.audio = audio;
+        e3.logits_out = logits_eng; e3.flags = ep.flags | 65536;
+        CHK(launch_decode_engine(e3, s)); CHK(hipStreamSynchronize(s));
+        auto lb = d2h(logits_eng, V); int tok_b, pos_b; CHK(hipMemcpy(&tok_b, d_tok + pos + 1, 4, hipMemcpyDeviceToHost)); CHK(hipMemcpy(&pos_b, d_pos2, 4, hipMemcpyDeviceToHost));
+        printf("  argmax at launch start: token %d vs %d, position %d vs %d, next step's logits %s (max|diff| %.3g)  %s\n", tok_b, tok_a, pos_b, pos_a,
+               memcmp(la.data(), lb.data(), (size_t)V * 4) == 0 ? "bit-identical" : "DIFFERENT", maxdiff(la, lb), tok_a == tok_b && pos_a == pos_b && pos_b == pos + 1 && memcmp(la.data(), lb.data(), (size_t)V * 4) == 0 ? "ok" : "MISMATCH");
+        check_err("argmax-at-start launches");
+        if (argc > 9 && atoi(argv[9])) {      // time the flagged launch (position advances: a few hundred launches stay inside the cache)
+            e3.logits_out = nullptr; CHK(hipMemcpy(d_pos2, &pos, 4, hipMemcpyHostToDevice));
+            hipEvent_t a0, a1; CHK(hipEventCreate(&a0)); CHK(hipEventCreate(&a1));
+            const int nrep = std::min(reps, max_seq - pos - 4);
+            CHK(hipEventRecord(a0, s)); for (int i = 0; i < nrep; i++) CHK(launch_decode_engine(e3, s)); CHK(hipEventRecord(a1, s)); CHK(hipEventSynchronize(a1));
+            float ms2; CHK(hipEventElapsedTime(&ms2, a0, a1)); printf("  flagged launches: %.1f us per step (%d launches, positions %d..)\n", ms2 * 1000 / nrep, nrep, pos + 1);
+            check_err("flagged timing loop");
+        }
+        // the plain launches below run at `pos` again: the rows written at pos + 1 are never read by them
+    }
     ep.logits_out = nullptr;
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) CHK(launch_decode_engine(ep, s));

@@ -686,7 +686,7 @@ struct vox_model {
     int eng_flags = 128 | 512 | 1, eng_pace = 50;      // XCD-local edges; probe-less all-gather, swept 0.5 us after the CU's own rows went out; one LDS-DMA packet in flight while the CU polls memory
     unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
-    hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0;
+    hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0, graph_mode = 0;
     const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
     vox_timings timings{};
 };
@@ -1612,12 +1612,15 @@ static int32_t engine_prepare(vox_model* m) {
     return VOX_OK;
 }
 static bool engine_active(const vox_model* m) { return m->eng_on && m->eng_ready && m->cache && m->eng_tab_cache == m->cache && m->eng_tab_k == m->cache->k && m->cache->max_seq <= 1024; }
-static EngParams engine_params(vox_model* m, float* logits_out) {
+static EngParams engine_params(vox_model* m, float* logits_out, bool argmax_in = false) {
     const vox_model_cfg& c = m->cfg;
     EngParams ep{}; ep.stream = m->eng_stream; ep.cu_stride = eng_stream_bytes(c.dec_layers, c.vocab) / 256; ep.layers = m->eng_tab; ep.n_layers = c.dec_layers; ep.h_in = m->d_h; ep.final_norm = m->dec_norm;
     ep.pos_ptr = m->d_pos; ep.pos_off = 0; ep.rope_cos = m->dec_cos; ep.rope_sin = m->dec_sin; ep.max_seq = m->cache->max_seq; ep.window = c.dec_window; ep.eps = c.norm_eps;
     eng_state_carve(m->eng_state, &ep); ep.part_val = m->d_part_val; ep.part_idx = m->d_part_idx; ep.logits_out = logits_out; ep.vocab = c.vocab; ep.tl = nullptr; ep.tl_layer = -1;
     ep.flags = m->eng_flags; ep.pace_ticks = (m->eng_flags & 512) ? 0 : m->eng_pace; ep.ag_delay_ticks = (m->eng_flags & 512) ? m->eng_pace : 0;
+    if (argmax_in) {      // the launch forms its own input: argmax of the previous launch's partials, token -> d_tokens, embedding + audio row (vox_engine.hip comm_next_input)
+        ep.flags |= 65536; ep.h_in = nullptr; ep.tokens = m->d_tokens; ep.pos_rw = m->d_pos; ep.tok_qs = m->tok.w.qs; ep.tok_sc = m->tok.w.sc; ep.tok_nb = m->tok.w.nb; ep.audio = m->d_audio;
+    }
     return ep;
 }
 
@@ -1657,8 +1660,12 @@ static int32_t ensure_decode_state(vox_model* m, int S) {
 
 // one full sync-free decode step. On entry d_h holds the step's input embedding (audio[cur] + embed(token[cur])):
 // 26 layers -> final norm + lm_head (argmax partials) -> fused tail: token[cur+1], cur++, next step's d_h.
-static int32_t decode_step_enqueue(vox_model* m, float* logits_out) {
+// mode 0: the step and the launch that turns its argmax partials into the next token + input (every path).  Engine only -- mode 1: the engine launch alone, its
+// partials left for whoever comes next; mode 2: an engine launch that BEGINS with the argmax of the previous launch's partials (flags 65536): a chain
+// [mode 1] [mode 2] ... [mode 2] [argmax_final] is the same token sequence as mode 0 steps with one launch per token instead of two.
+static int32_t decode_step_enqueue(vox_model* m, float* logits_out, int mode = 0) {
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    if (mode != 0) { HIPCHK(launch_decode_engine(engine_params(m, logits_out, mode == 2), s)); return VOX_OK; }
     if (engine_active(m)) {      // one launch: 26 layers + final norm + lm_head + per-CU argmax partials
         HIPCHK(launch_decode_engine(engine_params(m, logits_out), s));
         HIPCHK(launch_argmax_embed(m->d_part_val, m->d_part_idx, 256, m->d_tokens, m->d_pos, m->tok.w, m->d_audio, c.dec_dim, m->d_h, s));
@@ -1722,12 +1729,19 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     } else if (steps > 0) {
         // Replayed graphs: one step per graph by default.  VOX_DECODE_UNROLL=U (measurement knob) also builds a U-step graph for the bulk of
         // the steps; measured in round 2 (profiles/r02_decode_knobs.txt): no gain -- graph boundaries are not where the time goes.
-        int U = 1; { const char* e = knob_str("VOX_DECODE_UNROLL"); if (e && atoi(e) >= 1 && atoi(e) <= 32) U = atoi(e); }
-        if (m->graph_cache != m->cache || m->graph_audio != m->d_audio || m->graph_unroll != U) { graphs_destroy(m); m->graph_cache = m->cache; m->graph_audio = m->d_audio; m->graph_unroll = U; }
+        // Engine path: the replayed launches take their input from the previous launch's argmax partials themselves (mode 2), so a step is ONE launch; the
+        // utterance's first step runs eagerly as a plain launch (mode 1) and one argmax_final behind the last step writes the last token.  VOX_ENGINE_ARGMAX_IN=0:
+        // the two-launch step (measurement knob).  With one or two launches per step the graph boundaries show: 8 steps per graph by default (engine path).
+        const bool chain = engine_active(m) && !(knob_str("VOX_ENGINE_ARGMAX_IN") && knob_str("VOX_ENGINE_ARGMAX_IN")[0] == '0');
+        const int step_mode = chain ? 2 : 0;
+        int U = engine_active(m) ? 8 : 1; { const char* e = knob_str("VOX_DECODE_UNROLL"); if (e && atoi(e) >= 1 && atoi(e) <= 32) U = atoi(e); }
+        if (m->graph_cache != m->cache || m->graph_audio != m->d_audio || m->graph_unroll != U || m->graph_mode != step_mode) {
+            graphs_destroy(m); m->graph_cache = m->cache; m->graph_audio = m->d_audio; m->graph_unroll = U; m->graph_mode = step_mode;
+        }
         auto capture = [&](int which, int n_steps) -> int32_t {
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             int32_t r = VOX_OK;
-            for (int i = 0; i < n_steps && r == VOX_OK; i++) r = decode_step_enqueue(m, nullptr);
+            for (int i = 0; i < n_steps && r == VOX_OK; i++) r = decode_step_enqueue(m, nullptr, step_mode);
             hipError_t ce = hipStreamEndCapture(s, &m->graph[which]);
             if (r != VOX_OK) return r;
             HIPCHK(ce);
@@ -1735,15 +1749,16 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
             return VOX_OK;
         };
         int done = 0;
+        if (chain) { VOXCHK(decode_step_enqueue(m, nullptr, 1)); done = 1; }       // the utterance's first step: its input is in d_h
         if (!m->graph_exec[0]) {
-            VOXCHK(decode_step_enqueue(m, nullptr));                               // eager first step (also warms function attributes)
+            if (!chain) { VOXCHK(decode_step_enqueue(m, nullptr)); done = 1; }     // eager first step (also warms function attributes)
             HIPCHK(hipStreamSynchronize(s));
             VOXCHK(capture(0, 1));
-            done = 1;
         }
         if (U > 1 && !m->graph_exec[1] && steps - done >= 2 * U) VOXCHK(capture(1, U));      // only worth building for long enough utterances
         while (U > 1 && m->graph_exec[1] && steps - done >= U) { HIPCHK(hipGraphLaunch(m->graph_exec[1], s)); done += U; m->timings.graph_replays += U; }
         while (done < steps) { HIPCHK(hipGraphLaunch(m->graph_exec[0], s)); done++; m->timings.graph_replays++; }
+        if (chain) HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, 256, m->d_tokens, m->d_pos, 1, 1, s));      // the last step's token
     }
     HIPCHK(hipMemcpyAsync(out_ids, m->d_tokens + PREFIX_LEN, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     if (logits_host) HIPCHK(hipMemcpyAsync(logits_host, d_logits_all, (size_t)n * c.vocab * 4, hipMemcpyDeviceToHost, s));

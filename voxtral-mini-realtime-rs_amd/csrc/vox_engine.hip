@@ -196,6 +196,8 @@ __device__ __forceinline__ void lds_st(unsigned* p, unsigned v) { __hip_atomic_s
 
 template <int CTRL>
 __device__ __forceinline__ float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+template <int CTRL>
+__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 __device__ __forceinline__ float rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ float row16_sum_e(float v) { v += dppf<0xB1>(v); v += dppf<0x4E>(v); v += dppf<0x141>(v); v += dppf<0x140>(v); return v; }
 __device__ __forceinline__ float row16_max_e(float v) { v = fmaxf(v, dppf<0xB1>(v)); v = fmaxf(v, dppf<0x4E>(v)); v = fmaxf(v, dppf<0x141>(v)); v = fmaxf(v, dppf<0x140>(v)); return v; }
@@ -413,6 +415,34 @@ __device__ __forceinline__ void comm_publish_rows(const EngParams& p, int lane, 
     if (lane == 0) publish(ssq + b, tag, sq);
 }
 
+// flags 65536: the step's input is formed HERE instead of by a separate launch behind every step (argmax_embed_kernel: 4.7 us + a kernel boundary per token).  Every CU
+// reduces the previous launch's 256 argmax partials itself (4 per lane, lowest vocabulary index wins ties: argmax_embed_kernel's order) and builds its own 12 rows
+// of audio[pos] + embed(token) with embed_row's arithmetic ((nibble - 8) * d, then the audio row added: separate roundings).  Returns lane r's raw row (r < 12).
+constexpr int ENGF_ARGMAX_IN = 65536;
+__device__ __forceinline__ float comm_next_input(const EngParams& p, int lane, unsigned own_k) {
+    float xv[4]; int xi[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { xv[u] = as_g(p.part_val)[lane + 64 * u]; xi[u] = ((const __attribute__((address_space(1))) int*)(uintptr_t)p.part_idx)[lane + 64 * u]; }
+    const int cur = __builtin_amdgcn_readfirstlane(*p.pos_rw) + 1;
+    const float au = as_g(p.audio)[(size_t)cur * ED + own_k];      // does not depend on the token: in flight with the partials
+    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (xv[u] > bv || (xv[u] == bv && xi[u] < bi)) { bv = xv[u]; bi = xi[u]; }
+#define ENG_AMAX_STEP(CTRL) { const float ov = dppf<CTRL>(bv); const int oi = dppi<CTRL>(bi); if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } }
+    ENG_AMAX_STEP(0xB1) ENG_AMAX_STEP(0x4E) ENG_AMAX_STEP(0x141) ENG_AMAX_STEP(0x140)      // every lane of a 16-lane row holds the row's best (the order is total: any tree gives the same result)
+#undef ENG_AMAX_STEP
+    float v0 = rlf(bv, 0); int token = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+    for (int r = 1; r < 4; r++) { const float ov = rlf(bv, 16 * r); const int oi = __builtin_amdgcn_readlane(bi, 16 * r); if (ov > v0 || (ov == v0 && oi < token)) { v0 = ov; token = oi; } }
+    if (blockIdx.x == 0 && lane == 0) p.tokens[cur] = token;
+    const unsigned c = own_k >> 5, e = own_k & 31;
+    const size_t blk = (size_t)token * (size_t)p.tok_nb + c;
+    const unsigned byte = ((const __attribute__((address_space(1))) unsigned char*)(uintptr_t)p.tok_qs)[blk * 16 + (e & 15)];
+    const float d = __half2float(__ushort_as_half(((const __attribute__((address_space(1))) unsigned short*)(uintptr_t)p.tok_sc)[blk]));
+    const int nib = e < 16 ? (int)(byte & 15u) : (int)(byte >> 4);
+    return __fadd_rn(au, __fmul_rn(__fsub_rn((float)nib, 8.0f), d));
+}
+
 // ONE rolled loop over the 2 L + 1 all-gathers of the step: stage 2 l = layer l's input (-> q|k|v), stage 2 l + 1 = its post-attention stream (-> w1|w3),
 // stage 2 L = the final norm's input (-> lm_head); the small edges that follow each all-gather hang off the loop body.
 __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned char* lds, const int lane0, const Tl& tl) {
@@ -428,7 +458,8 @@ __device__ __forceinline__ void eng_comm(const EngParams& p, EngCtl* c, unsigned
     // the step's input joins the granule protocol: every CU publishes its 12 rows of h_in, so layer 0 takes the same all-gather as every other layer
     {
         const float g0 = ld_gf(make_srd(p.n_layers > 0 ? tab[0].attn_norm : p.final_norm, ED * 4u), own_k) * (p.n_layers > 0 ? 1.0f : 512.0f);
-        comm_publish_rows(p, lane0, ld_gf(make_srd(p.h_in, ED * 4u), own_k), g0, p.H0, p.SS0, tag_base, c->h_own);
+        const float hraw = (p.flags & ENGF_ARGMAX_IN) ? comm_next_input(p, lane0, own_k) : ld_gf(make_srd(p.h_in, ED * 4u), own_k);
+        comm_publish_rows(p, lane0, hraw, g0, p.H0, p.SS0, tag_base, c->h_own);
     }
 #pragma unroll 1
     for (int st = 0; st <= 2 * p.n_layers; st++) {
@@ -617,8 +648,6 @@ __device__ __forceinline__ float mstep(const RecR& r, const StepCtx& cx, float a
 }
 __device__ __forceinline__ float mstep(const unsigned char* rec, bool half, int lane, const StepCtx& cx, float acc) { return mstep(rec_read(rec, half, lane), cx, acc); }
 __device__ __forceinline__ float g01_sum(float v, int lane) { return v + __shfl(v, (lane + 16) & 63); }      // block 0 + block 1 partial of tile row n (valid in lanes 0..15)
-template <int CTRL>
-__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 // Four consecutive elements of a 32-element block (8 consecutive lanes = one block, this lane: elements [4 (lane & 7), +4)) -> digit planes + block info
 __device__ __forceinline__ void to_digits(const float (&v)[4], int lane, unsigned char* plane_blk, float2* binfo_blk) {
     float mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -747,7 +776,7 @@ __device__ __forceinline__ void eng_consumer(const EngParams& p, EngCtl* c, unsi
     const float* qkvn = reinterpret_cast<const float*>(lds + L_QKVN);
     float* sc = reinterpret_cast<float*>(lds + L_SC); float2* po = reinterpret_cast<float2*>(lds + L_PO); float* pl = reinterpret_cast<float*>(lds + L_PL);
     const unsigned tag_base = (*p.serial + 1u) * 64u;
-    const int pos = *p.pos_ptr + p.pos_off;
+    const int pos = *p.pos_ptr + p.pos_off + ((p.flags & ENGF_ARGMAX_IN) ? 1 : 0);      // (65536: this launch advances the position itself)
     const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0, n_old = pos - j_lo, last_old = max(n_old - 1, 0);
     // q|k|v epilogue (wave 0, lane r < 24 = the CU's row r: 16 of q, 4 of k, 4 of v): the RoPE factor of the row's pair -- the same in every layer
     const int half = EHD / 2;
@@ -1148,7 +1177,10 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams 
     } else if (wave == 1) {
         if (ENG_ROLES & 2) eng_comm(p, c, lds, lane, tl);
         // the last workgroup-independent act of the launch: bump the serial (every workgroup has read it long before any lm_head input existed)
-        if (blockIdx.x == 0 && lane == 0) { const unsigned sv = *p.serial; asm volatile("" ::: "memory"); *p.serial = sv + 1u; }
+        if (blockIdx.x == 0 && lane == 0) {
+            const unsigned sv = *p.serial; asm volatile("" ::: "memory"); *p.serial = sv + 1u;
+            if (p.flags & ENGF_ARGMAX_IN) { const int pv_ = *p.pos_rw; asm volatile("" ::: "memory"); *p.pos_rw = pv_ + 1; }      // likewise: every workgroup read the position when it started
+        }
     } else {
         if (ENG_ROLES & 4) eng_consumer(p, c, lds, wave - 2, lane, tl);
     }

@@ -196,6 +196,9 @@ struct EngParams {
     unsigned long long* XC;                           // [256] XCC id of every workgroup (start-up exchange)
     unsigned* serial; unsigned* err;                  // launch serial (tags never repeat), first failure code (0 = ok)
     float* part_val; int* part_idx;                   // [256] per-CU argmax partials
+    // flags 65536 (the product's graph-replayed steps): the launch BEGINS with the argmax over the previous launch's 256 partials (read back from part_val / part_idx),
+    // writes tokens[*pos_rw + 1], runs at that position on its own input rows audio[position] + embed(token) (h_in is not read) and leaves *pos_rw = its position
+    int* tokens; int* pos_rw; const uint4* tok_qs; const uint16_t* tok_sc; int tok_nb; const float* audio;
     float* logits_out;                                // optional [vocab]
     int vocab;
     unsigned long long* tl; int tl_layer;             // timeline stamps [256][32] of layer tl_layer (null: off)
@@ -203,7 +206,7 @@ struct EngParams {
                                                       // edges as plain stores through the shared L2 (placement verified per launch); 512: all-gathers swept ag_delay_ticks
                                                       // after the CU's own publish instead of probe-then-sweep.  Measurement / diagnostic: 2 loader re-reads one packet,
                                                       // 4 probe before small sweeps, 32 no LDS-DMA (wrong results), 64 loader pauses while polling, 1024 / 2048 loader depth
-                                                      // 2 / 1, 4096 nt polls on XCD-local edges, 16384 FAULT INJECTION (workgroup 7 loses a publish: the timeout test)
+                                                      // 2 / 1, 4096 nt polls on XCD-local edges, 16384 FAULT INJECTION (workgroup 7 loses a publish: the timeout test); 65536: see tokens / pos_rw above
     int ag_delay_ticks;                               // flags 512: 10-ns ticks between the CU's own publish and the all-gather sweep
     int pace_ticks;                                   // loader: minimum 10-ns ticks between two packet issues inside the layers (0: none)
 };
