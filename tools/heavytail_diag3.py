@@ -22,11 +22,10 @@ ref_audio = o.encode_audio(mel)
 dec = m.decoder(); ids = np.array([1] + [32] * 37, dtype=np.int32)
 x0 = ref_audio[:38] + o.embed_tokens(ids)
 oc = o.cache(64); rh = o.forward_hidden_with_cache(x0, t, oc)
-KEYS = ("VOX_NO_SKINNY_MT", "VOX_PREFILL_KERNEL", "VOX_SKINNY_MT2_GENERIC", "VOX_SKINNY_MT2", "VOX_PREFILL_NO_FUSED_FIN", "VOX_PREFILL_NO_SUMK")
+KEYS = ("VOX_NO_SKINNY_MT", "VOX_PREFILL_KERNEL", "VOX_SKINNY_MT2", "VOX_PREFILL_NO_FUSED_FIN", "VOX_PREFILL_NO_SUMK")
 outs = {}
 for label, env in [("32x128 kernel, no K split", {"VOX_NO_SKINNY_MT": "1"}), ("one-dimensional skinny kernel (4 waves split K)", {"VOX_PREFILL_KERNEL": "1"}),
-                   ("2-D generic, automatic slices (round-3 default until now)", {"VOX_SKINNY_MT2_GENERIC": "1"}),
-                   ("2-D default (4 / 8 / 12-step slices)", {}), ("2-D default, separate finishing kernels", {"VOX_PREFILL_NO_FUSED_FIN": "1"})] + \
+                   ("2-D default (automatic slices, fused finishing kernels)", {}), ("2-D default, separate finishing kernels", {"VOX_PREFILL_NO_FUSED_FIN": "1"})] + \
                   [(f"2-D, {k} slices forced", {"VOX_SKINNY_MT2": str(k)}) for k in (2, 3, 4, 6, 8, 12)]:
     for k in KEYS:
         os.environ.pop(k, None)

@@ -15,9 +15,9 @@ ref = None
 for label, env in (("32x128 MFMA kernel, 3 passes over the weights (round 1)", {"VOX_NO_SKINNY_MT": "1"}),
                    ("q4_skinny_mt_kernel<3,*> (rows from L2 per wave)", {"VOX_PREFILL_KERNEL": "1"}),
                    ("q4_gemm_kernel<3,NT,tile-ordered B> (48-row tile)", {"VOX_PREFILL_KERNEL": "2"}),
-                   ("2-D kernel, generic K loop (one step of prefetch; <= 8 slices)", {"VOX_SKINNY_MT2_GENERIC": "1"}),
-                   ("default: 2-D kernel, straight-line 4 / 8 / 12-step slices", {})):
-    for k in ("VOX_NO_SKINNY_MT", "VOX_PREFILL_KERNEL", "VOX_SKINNY_MT2_GENERIC"):
+                   ("default: 2-D kernel, fused finishing kernels", {})) + \
+                  tuple((f"2-D kernel, {k} slices forced for every operator", {"VOX_SKINNY_MT2": k}) for k in sys.argv[1:]):
+    for k in ("VOX_NO_SKINNY_MT", "VOX_PREFILL_KERNEL", "VOX_SKINNY_MT2"):
         os.environ.pop(k, None)
     os.environ.update(env)
     c = dec.create_cache_preallocated(64)

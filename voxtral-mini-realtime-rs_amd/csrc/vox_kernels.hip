@@ -97,7 +97,6 @@ __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erf
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 ld_nt_u4(const uint4* p) {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -1539,8 +1538,8 @@ __global__ __launch_bounds__(256) void q4_skinny_mt_kernel(const GemmParams p) {
 // profiles/r02_pmc_prefill.txt).  Here a workgroup = 4 * NTW n-tiles (one per wave) x ONE K slice (blockIdx.y of p.ksplit): its four waves walk the SAME K steps, so
 // the XF lines they request are the same lines (one L2 read per workgroup and step), and the activation traffic drops by the number of K slices.  Slice z writes its
 // partial sums to plane z; splitk_finish_kernel adds the planes in a fixed order and applies the epilogue.
-template <int MT, int NTW, int NSTEPS = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q4_skinny_mt2_kernel(const GemmParams p) {
+template <int MT, int NTW>
+__global__ __launch_bounds__(256) void q4_skinny_mt2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint4 xlds[];      // [buf 2][fragment MT * 8][64 lanes]: the XF block of one K step, shared by the four waves
     constexpr int NF = MT * 8, FPW = NF / 4;                          // fragments per step (m-tile, block j, hi / lo), per wave
     const int nb = p.w.nb, N = p.w.N, M = p.M, nq = nb >> 2;
@@ -1565,77 +1564,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 #pragma unroll
         for (int t = 0; t < NTW; t++) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16x8 m136 = as_bf16x8(make_uint4(0xC308C308u, 0xC308C308u, 0xC308C308u, 0xC308C308u));
-    if constexpr (NSTEPS > 0) {
-        // The workgroup owns EXACTLY NSTEPS K steps (the launcher picks the number of K slices accordingly): straight-line code, no loop-carried register copies.
-        // vmcnt retires loads IN ORDER: waiting for a young load also waits for every older one.  The generic loop below requests step q + 1's weights (HBM)
-        // and THEN its activation fragments (L2) and consumes the fragments at the end of step q -- a full HBM round trip per K step (~2 us against 0.6 us of
-        // MFMAs).  Here the weights wait in a register ring DW steps deep, the fragments two steps deep, and every request is issued in consumption
-        // order: x(q + 2) before w(q + DW); nothing that is waited for has a younger HBM load in front of it.
-        // (native vector types: as `uint4` -- a struct, copied by memcpy -- fragments that live from one step to the next stayed in scratch.)
-        constexpr int DW = 4;
-        u32x4_t wr[DW][NTW]; v2u_t sr[DW][NTW]; u32x4_t xr[2][FPW];
-        // (the step index is made opaque per request: left visible, the address arithmetic of ALL steps is hoisted to the top -- 256 VGPRs and scratch)
-#define VOX_WREQ(U_, ST_) { int qq_ = q0 + (ST_); asm volatile("" : "+s"(qq_));                                                 \
-            _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                                   \
-                wr[U_][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wq[t] + 64 * qq_));                      \
-                sr[U_][t] = *reinterpret_cast<const v2u_t*>(ws[t] + 64 * qq_); } }
-#define VOX_XREQ(B_, ST_) { int qq_ = q0 + (ST_); asm volatile("" : "+s"(qq_));                                                 \
-            _Pragma("unroll") for (int i = 0; i < FPW; i++) xr[B_][i] = *reinterpret_cast<const u32x4_t*>(xsrc[i] + (size_t)qq_ * 256); }
-        VOX_XREQ(0, 0) VOX_WREQ(0, 0)
-        if (NSTEPS > 1) { VOX_XREQ(1, 1) }
-#pragma unroll
-        for (int u = 1; u < DW; u++) if (u < NSTEPS) { VOX_WREQ(u, u) }
-#pragma unroll
-        for (int i = 0; i < FPW; i++) *reinterpret_cast<u32x4_t*>(&xlds[(wave + 4 * i) * 64 + lane]) = xr[0][i];
-        __syncthreads();
-#pragma unroll
-        for (int st = 0; st < NSTEPS; st++) {
-            const int u = st % DW, buf = st & 1;
-            bf16x8 bw[NTW][4]; float dsc[NTW][4];
-#pragma unroll
-            for (int t = 0; t < NTW; t++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    bw[t][j] = as_bf16x8(q4_dword_to_bf16x8_biased(wr[u][t][j]));
-                    const uint32_t sc2 = sr[u][t][j >> 1];
-                    dsc[t][j] = f16_bits_to_f32((uint16_t)((j & 1) ? (sc2 >> 16) : (sc2 & 0xFFFFu)));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (st + 2 < NSTEPS) { VOX_XREQ(buf, st + 2) }          // xr[buf] held x(st): in LDS since the end of step st - 1
-            if (st + DW < NSTEPS) { VOX_WREQ(u, st + DW) }          // this ring slot's next occupant
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const bf16x8 ah = as_bf16x8(xlds[(buf * NF + mt * 8 + j * 2) * 64 + lane]), al = as_bf16x8(xlds[(buf * NF + mt * 8 + j * 2 + 1) * 64 + lane]);
-                    f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, m136, cs, 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < NTW; t++) {
-                        f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bw[t][j], cs, 0, 0, 0);
-                        tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw[t][j], tt, 0, 0, 0);
-                        const float d = dsc[t][j];
-                        acc[mt][t] = __builtin_elementwise_fma((f32x4){d, d, d, d}, tt, acc[mt][t]);
-                    }
-                }
-            }
-            // pin the step's scale FMAs HERE: in one straight-line block the instruction selector is free to sink all of them to the end of the kernel
-            // (it did: every MFMA result of every step stayed live -- 256 VGPRs and 1.5 KB of scratch)
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int t = 0; t < NTW; t++) asm volatile("" : "+v"(acc[mt][t]));
-            if (st + 1 < NSTEPS) {
-#pragma unroll
-                for (int i = 0; i < FPW; i++) *reinterpret_cast<u32x4_t*>(&xlds[((buf ^ 1) * NF + wave + 4 * i) * 64 + lane]) = xr[buf ^ 1][i];
-                __syncthreads();
-            }
-        }
-#undef VOX_WREQ
-#undef VOX_XREQ
-    } else {
     uint4 wv[NTW]; uint2 sv[NTW]; uint4 xr[FPW];
 #pragma unroll
     for (int t = 0; t < NTW; t++) { wv[t] = ld_nt_u4(wq[t] + 64 * q0); sv[t] = *reinterpret_cast<const uint2*>(ws[t] + 64 * q0); }
@@ -1686,7 +1614,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
         for (int t = 0; t < NTW; t++) { wv[t] = wn[t]; sv[t] = sn[t]; }
         __syncthreads();
     }
-    }
     float* plane = p.out + (size_t)kz * M * N;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
@@ -1732,44 +1659,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         }
     }
 }
-// K slices of the two-dimensional kernel.  Its pipelined form wants every slice to own exactly 4, 8 or 12 K steps: among those decompositions the FEWEST slices that
-// still give >= 384 workgroups (q|k|v 24 steps -> 6 x 4, wo 32 -> 8 x 4, w1|w3 24 -> 2 x 12, w2 72 -> 9 x 8); otherwise (or VOX_SKINNY_MT2_GENERIC=1: measurement
-// knob) the generic loop with up to 8 slices.  VOX_SKINNY_MT2=k forces k slices.  *nsteps = steps per slice of the pipelined form, 0 = generic.
-static int mt2_slices(int nq, int wg1, int* nsteps) {
-    const int force = env_int("VOX_SKINNY_MT2"); const bool pipe = !env_int("VOX_SKINNY_MT2_GENERIC");
-    *nsteps = 0;
-    if (force > 0) {
-        const int KZ = std::min(force, nq);
-        if (pipe && nq % KZ == 0 && (nq / KZ == 4 || nq / KZ == 8 || nq / KZ == 12)) *nsteps = nq / KZ;
-        return KZ;
-    }
-    if (pipe) {
-        int best = 0;
-        for (int st = 12; st >= 4; st -= 4) {
-            if (nq % st || nq / st > 16) continue;
-            best = nq / st; *nsteps = st;
-            if ((long)wg1 * best >= 384) break;
-        }
-        if (best) return best;
-    }
-    return std::min(std::min(8, nq), std::max(1, (384 + wg1 - 1) / wg1));
-}
 template <int MT, int NTW>
-static hipError_t skinny_mt2_kernel_launch(const GemmParams& p, int KZ, int nsteps, hipStream_t s) {      // p.ksplit / p.out already set
-    const int n_tiles = (p.w.N + 15) / 16;
-    const dim3 grid((n_tiles + 4 * NTW - 1) / (4 * NTW), KZ); const size_t lds = (size_t)2 * MT * 8 * 64 * 16;
-    switch (nsteps) {
-    case 4: q4_skinny_mt2_kernel<MT, NTW, 4><<<grid, dim3(256), lds, s>>>(p); break;
-    case 8: q4_skinny_mt2_kernel<MT, NTW, 8><<<grid, dim3(256), lds, s>>>(p); break;
-    case 12: q4_skinny_mt2_kernel<MT, NTW, 12><<<grid, dim3(256), lds, s>>>(p); break;
-    default: q4_skinny_mt2_kernel<MT, NTW, 0><<<grid, dim3(256), lds, s>>>(p); break;
-    }
-    return hipGetLastError();
-}
-template <int MT, int NTW>
-static hipError_t skinny_mt2_launch(const GemmParams& p_in, int epi, int KZ, int nsteps, hipStream_t s) {
+static hipError_t skinny_mt2_launch(const GemmParams& p_in, int epi, int KZ, hipStream_t s) {
     GemmParams p = p_in; p.ksplit = KZ; p.out = p_in.kz_scratch;
-    hipError_t e = skinny_mt2_kernel_launch<MT, NTW>(p, KZ, nsteps, s); if (e != hipSuccess) return e;
+    const int n_tiles = (p.w.N + 15) / 16;
+    q4_skinny_mt2_kernel<MT, NTW><<<dim3((n_tiles + 4 * NTW - 1) / (4 * NTW), KZ), dim3(256), (size_t)2 * MT * 8 * 64 * 16, s>>>(p);
+    hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
     const long total = (long)p.M * p.w.N; const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
     switch (epi) {
     case EPI_STORE: splitk_finish_kernel<EPI_STORE><<<blocks, 256, 0, s>>>(p_in.kz_scratch, KZ, p.M, p.w.N, p.bias, nullptr, 0, p_in.out, p_in.out_stride); break;
@@ -1807,7 +1702,9 @@ static hipError_t skinny_mt_launch(const GemmParams& p, int epi, hipStream_t s) 
 int q4_skinny_mt2_plan(const Q4W& w, int M) {      // K slices the 2-D kernel would use for this operator, 0 = not applicable
     if (w.fmt != WFMT_Q4_0 || !w.qt || !w.st || w.nb % 4 || w.N % 2 || M <= 16 || M > 48 || env_int("VOX_SKINNY_MT2") < 0) return 0;
     const int tiles = (w.N + 15) / 16, nq = w.nb / 4, wg1 = (tiles + 3) / 4;
-    int nsteps; return mt2_slices(nq, wg1, &nsteps);
+    int KZ = std::min(std::min(8, nq), std::max(1, (384 + wg1 - 1) / wg1));
+    { const int e = env_int("VOX_SKINNY_MT2"); if (e > 0) KZ = std::min(e, nq); }
+    return KZ;
 }
 hipError_t launch_xf_rows(const float* x, int x_stride, int M, int K, uint16_t* xf, hipStream_t s) {      // f32 rows -> ceil(M / 16) XF tiles
     const int mt = (M + 15) / 16; const long total = (long)mt * 16 * (K >> 2);
@@ -1819,11 +1716,10 @@ hipError_t launch_q4_skinny_mt2_planes(const GemmParams& p_in, int KZ, hipStream
     GemmParams p = p_in; p.ksplit = KZ; p.out = p_in.kz_scratch;
     const int mt = (p.M + 15) / 16, n_tiles = (p.w.N + 15) / 16;
     if (!p.xf || !p.kz_scratch || (size_t)KZ * p.M * p.w.N * 4 > p.kz_scratch_bytes || KZ < 1) return hipErrorInvalidValue;
-    const int nq = p.w.nb / 4, nst = (nq % KZ == 0 && !env_int("VOX_SKINNY_MT2_GENERIC")) ? nq / KZ : 0;      // pipelined form when the slices are 4, 8 or 12 steps each
-    (void)n_tiles;
-    if (mt == 2) return skinny_mt2_kernel_launch<2, 1>(p, KZ, nst, s);
-    if (mt == 3) return skinny_mt2_kernel_launch<3, 1>(p, KZ, nst, s);
-    return hipErrorInvalidValue;
+    if (mt == 2) q4_skinny_mt2_kernel<2, 1><<<dim3((n_tiles + 3) / 4, KZ), dim3(256), (size_t)2 * 2 * 8 * 64 * 16, s>>>(p);
+    else if (mt == 3) q4_skinny_mt2_kernel<3, 1><<<dim3((n_tiles + 3) / 4, KZ), dim3(256), (size_t)2 * 3 * 8 * 64 * 16, s>>>(p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 // Finishing steps of the 38-token prefill folded into what used to follow them (one launch instead of two / three; same arithmetic, same order):
 //  * w1|w3: sum of the planes -> SiLU(gate) * up -> straight into the XF tiles of w2's input (was: f32 rows, then xf_rows_kernel)
@@ -1899,9 +1795,10 @@ static hipError_t launch_q4_skinny_mt(const GemmParams& p_in, int epi, hipStream
     if (p.xf && p.kz_scratch && p.w.N % 2 == 0 && env_int("VOX_SKINNY_MT2") >= 0) {
         if (!env_int("VOX_SKINNY_MT_NTW")) ntw = 1;      // one n-tile per wave here (w1|w3 with two: 3.32 vs 3.23 ms per prefill, profiles/r03_prefill_2d_kernel.txt)
         const int nq = p.w.nb / 4, wg1 = (tiles + 4 * ntw - 1) / (4 * ntw);
-        int nst; const int KZ = mt2_slices(nq, wg1, &nst);
+        int KZ = std::min(std::min(8, nq), std::max(1, (384 + wg1 - 1) / wg1));
+        { const int e = env_int("VOX_SKINNY_MT2"); if (e > 0) KZ = std::min(e, nq); }
         if ((size_t)KZ * p.M * p.w.N * 4 <= p.kz_scratch_bytes) {
-#define VOX_MT2(M_, N_) if (mt == M_ && ntw == N_) return skinny_mt2_launch<M_, N_>(p, epi, KZ, nst, s)
+#define VOX_MT2(M_, N_) if (mt == M_ && ntw == N_) return skinny_mt2_launch<M_, N_>(p, epi, KZ, s)
             VOX_MT2(2, 1); VOX_MT2(2, 2); VOX_MT2(3, 1); VOX_MT2(3, 2);
 #undef VOX_MT2
         }
