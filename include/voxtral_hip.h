@@ -210,7 +210,9 @@ int32_t vox_transcribe_audio(vox_model* m, const float* samples, size_t n, const
 /* Batched transcription (BASELINE.json config "Batch=16 x 16 s utterances"; extension -- the reference's callers loop over files,
  * bin/transcribe.rs:112-126).  n <= 64 independent utterances, each through the whole path of vox_transcribe_audio; the decode
  * loop advances all sequences per step so the weights are streamed once per step for the whole batch.  samples[i] / out_ids[i]
- * are per-utterance buffers (samples host or device per mem_kind, ids always host); n_ids[i] receives S_i - 38 (or 0). */
+ * are per-utterance buffers (samples host or device per mem_kind, ids always host); n_ids[i] receives S_i - 38 (or 0).
+ * Batches may be ragged: internally the rows run longest first and a 16-row group stops being computed once its longest
+ * member is done; results always land in the caller's slot i. */
 int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
                              int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind);
 
