@@ -2,7 +2,7 @@
 # One parametrised GPU-box runner (replaces round 1's gpu_run1..19.sh):  gpurun --timeout T -- 'bash tools/gpu_session.sh step [step ...]'
 # Every step is wrapped in its own `timeout`, logs under gpurun_out/ (merged back by gpurun); steps never abort the session.
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-TAG=${VOX_TAG:-r02}
+TAG=${VOX_TAG:-r03}
 step_tests()     { timeout 900 python -m pytest tests -m gpu -x -q ${VOX_PYTEST_ARGS:-} > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/${TAG}_pytest_gpu.log; }
 step_tests_all() { timeout 900 python -m pytest tests -m gpu -q -rA ${VOX_PYTEST_ARGS:-} > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|FAILED|full-size|batch" $OUT/${TAG}_pytest_gpu.log | tail -30; }
 step_smoke()     { timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/${TAG}_smoke.log; }

@@ -236,13 +236,16 @@ int main(int argc, char** argv) {
     printf("  argmax ref %d (%.6f)  engine %d (%.6f)  %s\n", ref_arg, ref_logits[ref_arg], eng_arg, eng_best, ref_arg == eng_arg ? "ok" : "DIFFERENT");
     {
         unsigned t0, t1;
-        auto g_h0 = granules(ep.H0, D, &t0, &t1); printf("  H0 tags %u..%u\n", t0, t1); report("layer-stack output h", ref_h, g_h0);
+        // the owners publish their rows ALREADY multiplied by the consumer's norm weight (the final norm * 512 behind the last layer): compare like with like
+        auto g_h0 = granules(ep.H0, D, &t0, &t1); printf("  H0 tags %u..%u\n", t0, t1);
+        { auto fn = d2h(final_norm, D); std::vector<float> exp_h(D); for (int i = 0; i < D; i++) exp_h[i] = ref_h[i] * fn[i] * 512.0f; report("layer-stack output h * final norm * 512", exp_h, g_h0); }
         std::vector<float> kr = d2h(kc_ref, (size_t)n_layers * lf), ke = d2h(kc_eng, (size_t)n_layers * lf), vr = d2h(vc_ref, (size_t)n_layers * lf), ve = d2h(vc_eng, (size_t)n_layers * lf);
         report("K cache (all rows, new row at pos)", kr, ke); report("V cache", vr, ve);
         if (n_layers == 1) {
             auto g = granules(ep.G, QD + 2 * KD, &t0, &t1); printf("  G tags %u..%u\n", t0, t1);
             std::vector<float> gq(g.begin(), g.begin() + QD); report("q (RoPE applied)", ref_q, gq);
-            auto g_h1 = granules(ep.H1, D, &t0, &t1); printf("  H1 tags %u..%u\n", t0, t1); report("h1 = h + wo(attention)", ref_h1, g_h1);
+            auto g_h1 = granules(ep.H1, D, &t0, &t1); printf("  H1 tags %u..%u\n", t0, t1);
+            { auto fw = d2h(L[0].ffn_norm, D), ad = d2h(L[0].ada, D); std::vector<float> e1(D); for (int i = 0; i < D; i++) e1[i] = ref_h1[i] * (fw[i] * ad[i]); report("(h + wo(attention)) * ffn_norm * Ada", e1, g_h1); }
             auto g_a = granules(ep.A, F, &t0, &t1); printf("  A tags %u..%u\n", t0, t1); report("SwiGLU activations", ref_act, g_a);
         }
     }
