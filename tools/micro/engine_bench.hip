@@ -254,6 +254,7 @@ int main(int argc, char** argv) {
     auto again = d2h(logits_eng, V);
     printf("  run-to-run: %s\n", memcmp(again.data(), eng_logits.data(), (size_t)V * 4) == 0 ? "bit-identical" : "DIFFERENT");
     check_err("second launch");
+    EngParams e3_keep{}; int* d_pos2_keep = nullptr;
     {   // ---- flags 65536: the step input formed at launch start (argmax over the previous launch's partials + embedding + audio row) against the three-launch
         // form (engine, argmax_embed_kernel, engine): same token, same position bookkeeping, BIT-identical logits of the following step
         float* audio = make_f32((size_t)(max_seq + 8) * D, 7001u, 0.0f, 1.0f);
@@ -282,6 +283,7 @@ int main(int argc, char** argv) {
             float ms2; CHK(hipEventElapsedTime(&ms2, a0, a1)); printf("  flagged launches: %.1f us per step (%d launches, positions %d..)\n", ms2 * 1000 / nrep, nrep, pos + 1);
             check_err("flagged timing loop");
         }
+        e3_keep = e3; e3_keep.logits_out = nullptr; d_pos2_keep = d_pos2;
         // the plain launches below run at `pos` again: the rows written at pos + 1 are never read by them
     }
     ep.logits_out = nullptr;
@@ -294,7 +296,12 @@ int main(int argc, char** argv) {
     check_err("timing loop");
     if (tl_layer >= 0) {
         ep.tl = tlbuf; ep.tl_layer = tl_layer;
+        if (argc > 9 && atoi(argv[9]) == 2) {      // timeline of a launch that forms its own input (flags 65536)
+            CHK(hipMemcpy(d_pos2_keep, &pos, 4, hipMemcpyHostToDevice)); e3_keep.tl = tlbuf; e3_keep.tl_layer = tl_layer;
+            CHK(launch_decode_engine(e3_keep, s)); CHK(hipStreamSynchronize(s)); printf("(timeline of a flags-65536 launch)\n");
+        } else {
         CHK(launch_decode_engine(ep, s)); CHK(hipStreamSynchronize(s));
+        }
         std::vector<unsigned long long> tb(256 * 32); CHK(hipMemcpy(tb.data(), tlbuf, tb.size() * 8, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull; for (int b = 0; b < 256; b++) if (tb[b * 32 + 19]) t0 = std::min(t0, tb[b * 32 + 19]);
         const char* names[32] = {"cons: x(q|k|v) staged", "cons: q|k|v done", "cons: q,k,v gathered", "cons: attention done", "cons: wo done", "cons: x(w13) staged", "cons: w1|w3 done", "cons: x(w2) staged",
