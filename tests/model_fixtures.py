@@ -102,10 +102,11 @@ def dense_head_sha(path, nbytes=64 << 20):
         return hashlib.sha256(f.read(nbytes)).digest()
 
 
-def full_dense_safetensors(seed=7):
-    """The full-size synthetic BF16 SafeTensors checkpoint of the f32 path (8.9 GB, written in a few seconds, cached in the temp dir)."""
+def full_dense_safetensors(seed=7, heavy_tail=False):
+    """The full-size synthetic BF16 SafeTensors checkpoint of the f32 path (8.9 GB, written in a few seconds, cached in the temp dir);
+    heavy_tail: the stress statistics of synth.dense_checkpoint_tensors."""
     S = load_package().synth
-    st = os.path.join(cache_dir(), f"full_dense_seed{seed}.safetensors")
+    st = os.path.join(cache_dir(), f"full_dense{'_heavytail' if heavy_tail else ''}_seed{seed}.safetensors")
     if not os.path.exists(st):
-        S.write_fast_dense_checkpoint(st + ".tmp", None, S.ModelDims(), seed=seed); os.replace(st + ".tmp", st)
+        S.write_fast_dense_checkpoint(st + ".tmp", None, S.ModelDims(), seed=seed, heavy_tail=heavy_tail); os.replace(st + ".tmp", st)
     return st

@@ -247,6 +247,43 @@ def test_full_16s_clip_f32_vs_oracle_golden(pkg):
     m.close(); ctx.close()
 
 
+def test_full_30s_f32_heavytail_vs_oracle_golden(pkg):
+    """The f32 SafeTensors path under the STRESS statistics (tests/golden/make_fullsize_f32_heavytail_golden.py: power-of-two Student-t(4) block scales, six
+    outlier channels x 64 in the decoder's residual stream, final norm centred on 5 => |logit| in the hundreds) on the 30 s clip (234 decoder positions): dense
+    bf16 weights exact on device, activations through the hi/lo-bf16 MFMA GEMMs (encoder, prefill) and the f32 GEMV chain (decode).  Ids identical to the CPU
+    oracle up to a near-tie; top logits within 2e-2 of the largest |logit| end to end (the same conditioning statement as the Q4 stress golden)."""
+    import hashlib
+    gp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_30s_f32_heavytail_oracle.npz")
+    if not os.path.exists(gp):
+        pytest.skip("heavy-tailed f32 golden not generated yet (tests/golden/make_fullsize_f32_heavytail_golden.py)")
+    g = np.load(gp)
+    st = full_dense_safetensors(int(g["seed"]), heavy_tail=True)
+    assert os.path.getsize(st) == int(g["st_size"]) and dense_head_sha(st) == g["st_head_sha256"].tobytes()      # same weights
+    x = pkg.synth.synth_audio(float(g["seconds"]), seed=4321)
+    assert hashlib.sha256(x.tobytes()).digest() == g["audio_sha256"].tobytes()                                    # same clip
+    ctx = pkg.Context(0)
+    m = pkg.VoxtralModelLoader.from_file(st).load(ctx)
+    try:
+        t = pkg.TimeEmbedding(3072).embed(6.0)
+        mel = pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x)))
+        assert mel.shape[0] == int(g["mel_frames"])
+        ids, lg = m.transcribe_streaming(np.ascontiguousarray(mel.T)[None], t, return_logits=True)
+        rids, top1, top2, amax = g["ids"], g["top1"], g["top2"], float(g["logit_absmax"])
+        assert len(ids) == len(rids) > 100 and amax > 15.0
+        agree = ids == rids
+        stop = len(ids) if agree.all() else int(np.argmin(agree))
+        if stop < len(ids):
+            assert top1[stop] - top2[stop] <= 2e-2 * amax, f"f32 heavy-tail ids differ at step {stop} with a clear margin {top1[stop] - top2[stop]}"
+        assert stop >= 1
+        err = float(np.abs(lg[:stop].max(axis=1) - top1[:stop]).max())
+        assert err <= 2e-2 * amax, (err, amax)
+        ids_a = m.transcribe_audio(x, t)                                          # product path: device mel + graph replay
+        assert (ids_a[:stop] == rids[:stop]).all() and (m.transcribe_audio(x, t) == ids_a).all()
+        print(f"heavy-tail f32 golden: ids agree for {stop}/{len(ids)} steps; max top-logit error {err:.3e} at |logit| max {amax:.1f}")
+    finally:
+        m.close(); ctx.close()
+
+
 def test_full_fused_attention_equals_separate_launches(pkg, full, monkeypatch):
     """Full size, 16 s clip, eager logits path: the fused q|k|v + attention launch (opt-in, VOX_FUSED_ATTN=1) against the default two-launch path -- bit-identical logits for all 108
     steps (26 layers x 32 heads x 107 steps of cross-workgroup hand-offs under real streaming load; a stale read would show here)."""

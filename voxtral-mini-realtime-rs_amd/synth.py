@@ -361,20 +361,33 @@ def _bf16_bits_to_f16_bits(b: np.ndarray) -> np.ndarray:
     return (b & np.uint16(0x8000)) | (e.astype(np.uint16) << np.uint16(10)) | ((b & np.uint16(0x7F)) << np.uint16(3))
 
 
-def dense_checkpoint_tensors(dims: ModelDims, seed: int = 7):
+def dense_checkpoint_tensors(dims: ModelDims, seed: int = 7, heavy_tail: bool = False):
     """Yield (name, shape, kind, bf16 bit patterns) of the synthetic dense (f32-path) checkpoint with the published tensor names and
-    shapes; linear / conv / bias values come from the fast bit-level generator, norm weights are 1 + N(0, sigma^2) rounded to bf16."""
+    shapes; linear / conv / bias values come from the fast bit-level generator, norm weights are 1 + N(0, sigma^2) rounded to bf16.
+    ``heavy_tail``: the stress statistics of write_synthetic_gguf(heavy_tail=True) in bf16-exact form -- every 32-element block of a 2-D linear is scaled by
+    a POWER OF TWO 2^round(log2(0.3 + |Student-t(4)|)) clipped to 2^-2 .. 2^4, the decoder's wo / w2 rows that feed HEAVY_OUTLIER_CHANNELS by 2^6 more, the
+    final norm is centred on 5: an exponent add on the bit patterns, so the values stay exact in bf16 AND in the oracle's f16 copy (exponents 2^-8 .. 2^4)."""
     for idx, (name, shape, kind, sigma) in enumerate(tensor_manifest(dims)):
         rng = np.random.default_rng([seed, idx, 99])
         ne = int(np.prod(shape))
         if kind == "norm":
-            bits = f32_to_bf16_bits((1.0 + sigma * rng.standard_normal(ne)).astype(np.float32))
+            centre = 5.0 if (heavy_tail and name == "norm.weight") else 1.0
+            bits = f32_to_bf16_bits((centre + sigma * rng.standard_normal(ne)).astype(np.float32))
         else:
             bits = _fast_bf16_bits(rng, ne, sigma)
+            if heavy_tail and kind == "q4" and len(shape) == 2 and int(shape[1]) % 32 == 0:
+                rt = np.random.default_rng([seed, idx, 4])
+                k = np.clip(np.rint(np.log2(0.3 + np.abs(rt.standard_t(4, ne // 32)))), -2, 4).astype(np.int32)
+                if name.startswith("layers.") and (name.endswith("attention.wo.weight") or name.endswith("feed_forward.w2.weight")):
+                    nbr = int(shape[1]) // 32
+                    for ch in HEAVY_OUTLIER_CHANNELS:
+                        if ch < int(shape[0]):
+                            k[ch * nbr:(ch + 1) * nbr] += 6
+                bits = (bits.astype(np.int32) + (np.repeat(k, 32) << 7)).astype(np.uint16)      # exponent field += k (base exponents 2^-6: no carry into the sign)
         yield name, shape, kind, bits
 
 
-def write_fast_dense_checkpoint(st_path: str | None, gguf_path: str | None, dims: ModelDims, seed: int = 7):
+def write_fast_dense_checkpoint(st_path: str | None, gguf_path: str | None, dims: ModelDims, seed: int = 7, heavy_tail: bool = False):
     """The SAME synthetic dense model twice: `st_path` = BF16 SafeTensors (what VoxtralModelLoader reads, like the published
     consolidated.safetensors), `gguf_path` = a dense GGUF for the CPU oracle (2-D linears as F16 -- exact, see _bf16_bits_to_f16_bits --
     everything else as F32).  Either path may be None.  Full size: 8.9 GB each, a few seconds per file."""
@@ -389,7 +402,7 @@ def write_fast_dense_checkpoint(st_path: str | None, gguf_path: str | None, dims
         hb = json.dumps(hdr, separators=(",", ":")).encode(); hb += b" " * ((8 - len(hb) % 8) % 8)
         with open(st_path, "wb") as f:
             f.write(struct.pack("<Q", len(hb))); f.write(hb)
-            for name, shape, kind, bits in dense_checkpoint_tensors(dims, seed):
+            for name, shape, kind, bits in dense_checkpoint_tensors(dims, seed, heavy_tail):
                 f.write(np.ascontiguousarray(bits).tobytes())
     if gguf_path:
         def gen(name, shape, kind, bits):
@@ -397,7 +410,7 @@ def write_fast_dense_checkpoint(st_path: str | None, gguf_path: str | None, dims
                 return GGML_F16, _bf16_bits_to_f16_bits(bits)
             return GGML_F32, bf16_bits_to_f32(bits)
         # write_gguf wants the dtype up front: linears (kind q4 in the manifest) are the F16 ones
-        it = dense_checkpoint_tensors(dims, seed)
+        it = dense_checkpoint_tensors(dims, seed, heavy_tail)
         def lazy(entry):
             name, shape, kind, sigma = entry
             def make():
