@@ -367,6 +367,34 @@ def test_full_decode_engine_vs_per_operator_path(pkg, full, seconds, seed):
     assert np.array_equal(ids_g, ids_e) and np.array_equal(ids_og, ids_o)
 
 
+def test_full_decode_loop_and_prefill_knob_paths(pkg, full, monkeypatch):
+    """The measurement knobs that select the OLDER forms of two round-3 changes still give the product's results at full size: the two-launch decode step
+    (VOX_ENGINE_ARGMAX_IN=0: engine launch + argmax / embedding launch) and one step per graph (VOX_DECODE_UNROLL=1) -> identical ids; the prefill's separate
+    finishing / RoPE / cache-write / conversion launches (VOX_PREFILL_NO_FUSED_FIN=1) -> the same hidden states to rounding (the fused kernels restate the same
+    arithmetic; FMA contraction may differ by an ulp per element, which 26 layers carry to a few 1e-5)."""
+    m, _, ctx = full
+    if not m.set_decode_engine(True):
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    t = pkg.TimeEmbedding(3072).embed(6.0); x = pkg.synth.synth_audio(6.0, seed=77)
+    ids = m.transcribe_audio(x, t); assert len(ids) > 30
+    for env in ({"VOX_ENGINE_ARGMAX_IN": "0"}, {"VOX_DECODE_UNROLL": "1"}, {"VOX_ENGINE_ARGMAX_IN": "0", "VOX_DECODE_UNROLL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = m.transcribe_audio(x, t)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(got, ids), f"{env}: ids differ from the default decode loop"
+    assert np.array_equal(m.transcribe_audio(x, t), ids)
+    dec = m.decoder(); x0 = (0.5 * np.random.default_rng(3).standard_normal((1, 38, 3072))).astype(np.float32)
+    c = dec.create_cache_preallocated(64); a = dec.forward_hidden_with_cache(x0, t, c); c.close()
+    monkeypatch.setenv("VOX_PREFILL_NO_FUSED_FIN", "1")
+    c = dec.create_cache_preallocated(64); b = dec.forward_hidden_with_cache(x0, t, c); c.close()
+    monkeypatch.delenv("VOX_PREFILL_NO_FUSED_FIN")
+    err = float(np.abs(a - b).max() / np.abs(b).max())
+    print(f"prefill, fused vs separate finishing launches: max rel diff {err:.2e}")
+    assert err <= TOL                     # (ulp-level differences of the RoPE / SwiGLU expressions' contraction, carried through 26 layers: 3.6e-5 measured)
+
+
 def test_full_decode_engine_lost_publish_times_out_loudly_and_falls_back(pkg, full, monkeypatch):
     """Every wait inside the engine is bounded (20 ms): with one workgroup's publish suppressed (fault-injection flag 16384) the launch must END, the call must fail
     loudly (not return wrong ids), and the model must keep working on the per-operator path afterwards -- with the ids of the healthy engine."""
