@@ -1173,8 +1173,14 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams 
 #endif
     if (wave == 0) {
         tl(19);
+#ifdef ENG_PRIO_LOADER
+        __builtin_amdgcn_s_setprio(ENG_PRIO_LOADER);
+#endif
         if (ENG_ROLES & 1) eng_loader(p, c, (unsigned)(uintptr_t)(lds + L_RING), lane, tl);
     } else if (wave == 1) {
+#ifdef ENG_PRIO_COMM
+        __builtin_amdgcn_s_setprio(ENG_PRIO_COMM);
+#endif
         if (ENG_ROLES & 2) eng_comm(p, c, lds, lane, tl);
         // the last workgroup-independent act of the launch: bump the serial (every workgroup has read it long before any lm_head input existed)
         if (blockIdx.x == 0 && lane == 0) {
@@ -1182,6 +1188,9 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams 
             if (p.flags & ENGF_ARGMAX_IN) { const int pv_ = *p.pos_rw; asm volatile("" ::: "memory"); *p.pos_rw = pv_ + 1; }      // likewise: every workgroup read the position when it started
         }
     } else {
+#ifdef ENG_PRIO_CONS
+        __builtin_amdgcn_s_setprio(ENG_PRIO_CONS);
+#endif
         if (ENG_ROLES & 4) eng_consumer(p, c, lds, wave - 2, lane, tl);
     }
 }
