@@ -341,8 +341,10 @@ def main():
                            "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_us": dom["avg_us"],
                            "all_decode_gemvs": per,
-                           "all_decode_gemvs_note": "decode_engine = the whole step (26 layers + lm_head) as the ONE launch the product replays per token; the five GEMV rows are the "
-                                                    "per-operator launches it replaces (stand-alone, 26 layers cycled), kept for comparison",
+                           "all_decode_gemvs_note": "decode_engine = the whole step (26 layers + lm_head) as the ONE launch the product replays per token -- and the only one: a replayed launch "
+                                                    "forms its own input from the previous launch's argmax partials; the five GEMV rows are the per-operator launches it replaces "
+                                                    "(stand-alone, 26 layers cycled), kept for comparison",
+                           "decode_step_launches": 1 if engine else 4 * cfg.dec_layers + 2,
                            "decode_step_gemv_GBps": round(per_step_bytes / per_step_us / 1e3, 1),
                            "decode_step_algorithmic_bytes": int(per_step_bytes),
                            "decode_step_measured_ms": round(stage_ms["decode_ms"] / max(n_ids, 1), 4),
