@@ -1945,6 +1945,46 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     // `active`: bit gi = group gi still has a sequence that needs this step.  A group whose sequences have all reached their last position is RETIRED: its layer
     // chain is not launched any more (its rows idle in place in the argmax / embedding kernel, whose token write is guarded by the sequence length) -- a ragged
     // batch pays for each group only as long as that group's longest member runs, not for the batch's longest member in every group.
+    // one group's layer chain + lm_head on stream sg (XF step).  The groups of a step run in LOCK-STEP (forked and joined per step, one argmax / next-input launch
+    // for all rows): letting every group replay its own chain of steps on its own stream -- no join, groups drifting freely -- was measured 12 % SLOWER on the
+    // 647-clip corpus (8 520 -> 7 630 tok/s, profiles/r03_batch_independent_groups.txt): groups in lock-step find each other's weights in L2 / MALL, drifting
+    // groups stream them from HBM once each.
+    auto group_chain = [&](int gi, hipStream_t sg) -> int32_t {
+        float* h = b_h.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>();
+        const int r0 = gi * 16, ng = std::min(16, n - r0);
+        uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)gi * (xf_bytes(QD) / 2);
+        uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)gi * (xf_bytes(F) / 2); float* ssq = b_ssq.as<float>() + (size_t)gi * parts_D * 16;
+        float* hg = h + (size_t)r0 * D; float* qg = qkv + (size_t)r0 * W; const int* pg = d_pos + r0;
+        for (int l = 0; l < c.dec_layers; l++) {
+            const DecLayer& L = m->dec[l];
+            float* kl = b_k.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride;
+            { GemmParams g{}; g.w = L.wqkv.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = qg; g.out_stride = W;
+              g.ssq_part = ssq; g.n_part = l == 0 ? 1 : parts_D; g.norm_eps = c.norm_eps;
+              g.pos = pg; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd;
+              HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, sg)); }
+            AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
+            ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = pg; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
+            ap.out_xf = xf2; ap.prefer_gqa = n_grp > 1 || knob_str("VOX_ATTN_GQA") != nullptr; ap.no_xcd_remap = knob_str("VOX_ATTN_NO_XCD") != nullptr; ap.spec_rows = max_seq;
+            HIPCHK(launch_attn_decode(ap, hd, max_seq, sg, ng));
+            { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
+              g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
+            { GemmParams g{}; g.w = L.w13.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = (float*)xf3; g.out_stride = F;
+              g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU_XF, sg)); }
+            { GemmParams g{}; g.w = L.w2.w; g.xf = (const uint4*)xf3; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
+              g.xf_out = xf1; g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
+        }
+        { GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = b_logits.as<float>() + (size_t)r0 * V; g.out_stride = V;
+          g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, sg)); }
+        return VOX_OK;
+    };
+    auto ensure_aux = [&](int n_streams) -> int32_t {
+        if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < n_streams && i < 3; i++) {
+            if (!cx->aux[i]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking));
+            if (!cx->ev_join[i]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[i], hipEventDisableTiming));
+        }
+        return VOX_OK;
+    };
     auto step = [&](uint32_t active) -> int32_t {
         float* h = b_h.as<float>(); float* xn = b_xn.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>(); float* act = b_act.as<float>();
         if (use_xf) {
@@ -1953,11 +1993,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
             int n_act = 0; for (int gi = 0; gi < n_grp; gi++) n_act += (active >> gi) & 1u;
             const bool fork = n_act > 1 && !knob_str("VOX_BATCH_SERIAL_GROUPS");
             if (fork) {
-                if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
-                for (int i = 0; i < n_act - 1 && i < 3; i++) {
-                    if (!cx->aux[i]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking));
-                    if (!cx->ev_join[i]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[i], hipEventDisableTiming));
-                }
+                VOXCHK(ensure_aux(n_act - 1));
                 HIPCHK(hipEventRecord(cx->ev_fork, s));
                 for (int i = 0; i < n_act - 1 && i < 3; i++) HIPCHK(hipStreamWaitEvent(cx->aux[i], cx->ev_fork, 0));
             }
@@ -1966,30 +2002,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
                 if (!((active >> gi) & 1u)) continue;
                 const int ka = k_act++;
                 hipStream_t sg = (fork && ka > 0) ? cx->aux[ka - 1] : s;
-                const int r0 = gi * 16, ng = std::min(16, n - r0);
-                uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)gi * (xf_bytes(QD) / 2);
-                uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)gi * (xf_bytes(F) / 2); float* ssq = b_ssq.as<float>() + (size_t)gi * parts_D * 16;
-                float* hg = h + (size_t)r0 * D; float* qg = qkv + (size_t)r0 * W; const int* pg = d_pos + r0;
-                for (int l = 0; l < c.dec_layers; l++) {
-                    const DecLayer& L = m->dec[l];
-                    float* kl = b_k.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride;
-                    { GemmParams g{}; g.w = L.wqkv.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = qg; g.out_stride = W;
-                      g.ssq_part = ssq; g.n_part = l == 0 ? 1 : parts_D; g.norm_eps = c.norm_eps;
-                      g.pos = pg; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd;
-                      HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, sg)); }
-                    AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = att; ap.n_heads = H; ap.n_kv_heads = KV;
-                    ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = pg; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride;
-                    ap.out_xf = xf2; ap.prefer_gqa = n_grp > 1 || knob_str("VOX_ATTN_GQA") != nullptr; ap.no_xcd_remap = knob_str("VOX_ATTN_NO_XCD") != nullptr; ap.spec_rows = max_seq;
-                    HIPCHK(launch_attn_decode(ap, hd, max_seq, sg, ng));
-                    { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
-                      g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
-                    { GemmParams g{}; g.w = L.w13.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = (float*)xf3; g.out_stride = F;
-                      g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU_XF, sg)); }
-                    { GemmParams g{}; g.w = L.w2.w; g.xf = (const uint4*)xf3; g.M = ng; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
-                      g.xf_out = xf1; g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
-                }
-                { GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = b_logits.as<float>() + (size_t)r0 * V; g.out_stride = V;
-                  g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, sg)); }
+                VOXCHK(group_chain(gi, sg));
                 if (fork && ka > 0) { HIPCHK(hipEventRecord(cx->ev_join[ka - 1], sg)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[ka - 1], 0)); }
             }
             HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s,
@@ -2021,10 +2034,10 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     auto active_at = [&](int t) { uint32_t a = 0; for (int gi = 0; gi < n_grp; gi++) if (!retire || t < steps_g[gi]) a |= 1u << gi; return a; };
     // one instantiated graph per set of active groups (<= n_grp of them when the rows are sorted), captured when the set first occurs
     struct Graphs {
-        hipStream_t s; std::vector<std::pair<uint32_t, hipGraphExec_t>> ex; std::vector<hipGraph_t> gr;
-        ~Graphs() { (void)hipStreamSynchronize(s); for (auto& e : ex) if (e.second) (void)hipGraphExecDestroy(e.second); for (auto g : gr) if (g) (void)hipGraphDestroy(g); }
+        hipStream_t s; vox_ctx* cx; std::vector<std::pair<uint32_t, hipGraphExec_t>> ex; std::vector<hipGraph_t> gr;
+        ~Graphs() { (void)hipStreamSynchronize(s); for (auto a : cx->aux) if (a) (void)hipStreamSynchronize(a); for (auto& e : ex) if (e.second) (void)hipGraphExecDestroy(e.second); for (auto g : gr) if (g) (void)hipGraphDestroy(g); }
         hipGraphExec_t find(uint32_t a) const { for (auto& e : ex) if (e.first == a) return e.second; return nullptr; }
-    } graphs; graphs.s = s;
+    } graphs; graphs.s = s; graphs.cx = cx;
     int replays = 0;
     const bool no_graph = knob_str("VOX_BATCH_NO_GRAPH") != nullptr;      // measurement knob (profilers)
     for (int t = 0; t < steps; t++) {
