@@ -51,3 +51,26 @@ def test_ggml_scheme_and_errors(pkg, tmp_path):
         E.read_safetensors(str(bad))
     assert E.is_q4_tensor("layers.0.attention.wq.weight", (512, 256)) and not E.is_q4_tensor("layers.0.attention_norm.weight", (256,))
     assert not E.is_q4_tensor("norm.weight", (256,)) and not E.is_q4_tensor("x.conv_layers.0.conv.weight", (128, 128, 3)) and not E.is_q4_tensor("a.bias", (64,))
+
+
+def test_heavy_tail_dense_generator_is_exact_in_bf16_and_f16():
+    """The stress checkpoint of the f32 path (synth.dense_checkpoint_tensors(heavy_tail=True), tests/golden/make_fullsize_f32_heavytail_golden.py): block scales are
+    powers of two, so every value is a bf16 number AND survives the oracle's f16 copy exactly; outlier rows are 64 x larger; the plain generator is unchanged."""
+    import numpy as np
+    from __graft_entry__ import load_package
+    S = load_package().synth
+    dims = S.tiny_dims()
+    plain = {n: b for n, _, _, b in S.dense_checkpoint_tensors(dims, 8)}
+    seen = 0
+    for name, shape, kind, bits in S.dense_checkpoint_tensors(dims, 8, heavy_tail=True):
+        f = S.bf16_bits_to_f32(bits)
+        assert np.array_equal(S.f32_to_bf16_bits(f), bits)                                   # bf16-exact by construction
+        if kind == "q4" and len(shape) == 2 and int(shape[1]) % 32 == 0:
+            f16 = S._bf16_bits_to_f16_bits(bits).view(np.float16).astype(np.float32)
+            assert np.array_equal(f16, f)                                                    # ... and exact in the oracle's f16 copy
+            ratio = np.abs(f) / np.abs(S.bf16_bits_to_f32(plain[name]))
+            lg = np.log2(ratio); assert np.array_equal(lg, np.rint(lg)) and lg.min() >= -2 and lg.max() <= 10      # power-of-two block scales
+            seen += 1
+        elif kind != "norm":
+            assert np.array_equal(bits, plain[name])
+    assert seen > 4
