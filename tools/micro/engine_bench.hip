@@ -61,6 +61,23 @@ __global__ __launch_bounds__(64) void dma_probe_kernel(const unsigned* src, unsi
     __syncthreads();
     for (int t = 0; t < 4; t++) for (int i = lane; i < 256; i += 64) out[256 * t + i] = reinterpret_cast<unsigned*>(lds + offs[t])[i];
 }
+// the four-line form of the loader: one M0 write, instruction offsets 0 / 1024 / 2048 / 3072 -- do the offsets move the LDS address too?
+__global__ __launch_bounds__(64) void dma4_probe_kernel(const unsigned* src, unsigned* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 160 * 1024 / 4; i += 64) reinterpret_cast<unsigned*>(lds)[i] = 0xdeadbeefu;
+    __syncthreads();
+    unsigned keep; const unsigned voff = lane * 16;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)lds + 70u * 1024));
+    const unsigned long long g = (unsigned long long)src;
+    const unsigned long long gs = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(g >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)g);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:2048 nt\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(gs) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = lane; i < 1024; i += 64) out[i] = reinterpret_cast<unsigned*>(lds + 70 * 1024)[i];
+}
 typedef float f2v __attribute__((ext_vector_type(2)));
 __global__ void fp8_probe_kernel(float* out) {
     const unsigned q = threadIdx.x & 15;
@@ -138,6 +155,12 @@ int main(int argc, char** argv) {
         CHK(hipDeviceSynchronize());
         std::vector<unsigned> a(1024), b(1024); CHK(hipMemcpy(a.data(), src, 4096, hipMemcpyDeviceToHost)); CHK(hipMemcpy(b.data(), out, 4096, hipMemcpyDeviceToHost));
         for (int t = 0; t < 4; t++) { int bad = 0; for (int i = 0; i < 256; i++) bad += a[256 * t + i] != b[256 * t + i]; printf("LDS-DMA probe, LDS offset %6d KiB: %s (%d / 256 words differ)\n", t == 0 ? 1 : t == 1 ? 60 : t == 2 ? 100 : 150, bad ? "FAIL" : "ok", bad); }
+        {
+            CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(dma4_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CHK(hipMemset(out, 0, 4096)); dma4_probe_kernel<<<1, 64, 160 * 1024>>>(src, out); CHK(hipDeviceSynchronize());
+            CHK(hipMemcpy(b.data(), out, 4096, hipMemcpyDeviceToHost)); int bad4 = 0; for (int i = 0; i < 1024; i++) bad4 += a[i] != b[i];
+            printf("LDS-DMA probe, four lines with instruction offsets 0..3072 behind one M0 write: %s (%d / 1024 words differ)\n", bad4 ? "FAIL" : "ok", bad4);
+        }
         float* fo = dalloc<float>(64); fp8_probe_kernel<<<1, 64>>>(fo); CHK(hipDeviceSynchronize());
         auto f = d2h(fo, 64); int bad = 0;
         for (int q = 0; q < 16; q++) bad += f[4 * q] != q / 512.0f || f[4 * q + 1] != (15 - q) / 512.0f || f[4 * q + 2] != q / 512.0f || f[4 * q + 3] != (15 - q) / 512.0f;

@@ -251,6 +251,17 @@ __device__ __forceinline__ void dma_line(unsigned voff, unsigned lds_dst_, u64 g
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(gsrc) : "memory");
 }
+// four consecutive 1 KiB lines with ONE M0 write: the instruction offset (0 / 1024 / 2048 / 3072) is added to the global address AND to the LDS address (probed in
+// tools/micro/engine_bench).  The loader wave is a lone wave issuing ~one instruction per 8 cycles: at 11 scalar instructions per line (M0 save / set / restore,
+// address updates, loop) a layer's 259 lines cost ~6 us of pure issue time -- this form needs 10 per four lines.
+__device__ __forceinline__ void dma_lines4(unsigned voff, unsigned lds_dst_, u64 gsrc_) {
+    unsigned keep;
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_);
+    const u64 gsrc = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(gsrc_ >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gsrc_);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:2048 nt\n\tglobal_load_lds_dwordx4 %1, %3 offset:3072 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(gsrc) : "memory");      // (leaving M0 unsaved / unrestored was measured: no faster)
+}
 __device__ __forceinline__ void wait_vmcnt(int n) {      // n = DMA lines allowed to stay in flight (younger packets)
     switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -274,8 +285,9 @@ struct Loader {
         if (nfl == 2) { wait_vmcnt(l1); publish_slot(s0); s0 = s1; l0 = l1; nfl = 1; }
         if (nfl == 1) { wait_vmcnt(0); publish_slot(s0); nfl = 0; }
     }
-    __device__ __forceinline__ void issue(u64 gsrc, int bytes, int lane, bool nodma) {
-        const int full = bytes >> 10, tail = (bytes & 1023) >> 4, lines = full + (tail ? 1 : 0);      // tail: lanes of the last, partial LDS-DMA instruction
+    template <int bytes>      // 13824 or 20736: the line loop is straight-line code (a lone wave issues ~one instruction per 8 cycles: every scalar instruction of this loop is streaming time)
+    __device__ __forceinline__ void issue(u64 gsrc, int lane, bool nodma) {
+        constexpr int full = bytes >> 10, tail = (bytes & 1023) >> 4, lines = full + (tail ? 1 : 0);      // tail: lanes of the last, partial LDS-DMA instruction
         const int slot = (int)(P % NSLOT); const unsigned k = P / NSLOT;
         if (k > 0 && lds_ld(&c->ring_done[slot]) < NCONS * k) {
             flush();                                   // publish what has landed before blocking: the consumers may be waiting for exactly that
@@ -290,8 +302,10 @@ struct Loader {
         if (pace) { while (wall_clock64() - t_last < pace) __builtin_amdgcn_s_sleep(1); t_last = wall_clock64(); }
         const unsigned dst = ring_lds + (unsigned)slot * SLOT_BYTES;
         if (!nodma) {
-#pragma unroll 1
-            for (int i = 0; i < full; i++) dma_line(voff, dst + (unsigned)i * 1024u, gsrc + (u64)i * 1024u);
+#pragma unroll
+            for (int i = 0; i + 4 <= full; i += 4) dma_lines4(voff, dst + (unsigned)i * 1024u, gsrc + (u64)i * 1024u);
+#pragma unroll
+            for (int i = full & ~3; i < full; i++) dma_line(voff, dst + (unsigned)i * 1024u, gsrc + (u64)i * 1024u);
             if (lane < tail) dma_line(voff, dst + (unsigned)full * 1024u, gsrc + (u64)full * 1024u);      // EXEC-masked: only `tail` lanes write
         }
         P++;
@@ -323,7 +337,8 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
             if (r < PK_LAYER_M) bytes = PK_M;
             if (r == 0 && (int)l == p.tl_layer) tl(16);
         } else { ld.pace = 0; ld.pause_ticks = 0; ld.depth = 3; }      // no edge left to protect: the lm_head streams at full depth
-        ld.issue(fake ? base + (u64)blockIdx.x * PK_A : base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes, bytes, lane, nodma);
+        const u64 src = fake ? base + (u64)blockIdx.x * PK_A : base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes;
+        if (bytes == PK_M) ld.issue<PK_M>(src, lane, nodma); else ld.issue<PK_A>(src, lane, nodma);
         off += (u64)bytes;
         if (++r == PK_LAYER) { if ((int)l == p.tl_layer) tl(17); r = 0; l++; }
     }
