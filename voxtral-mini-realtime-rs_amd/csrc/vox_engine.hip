@@ -9,7 +9,8 @@
 // Geometry (fixed: the real Voxtral decoder -- D 3072, 32 query heads / 8 KV heads x 128, FFN 9216; other shapes keep the per-operator path):
 //   grid = 256 workgroups (one per CU, all resident) x 896 threads = 14 waves (<= 128 VGPRs):
 //     wave 0       LOADER   global_load_lds_dwordx4 ... nt: this CU's step records of q|k|v, wo, w1|w3, w2 of every layer, then the lm_head rows, as 13.5 / 20 KiB
-//                           packets into a ring of six LDS slots; 1-3 packets in flight; waits only for free slots.
+//                           packets into a ring of six LDS slots; 1-3 packets in flight; waits only for free slots.  The wave is ISSUE-bound (a lone wave issues about
+//                           one instruction per 8 cycles): four 1 KiB lines per M0 write, the packet's line loop is straight-line code.
 //     wave 1       COMM     sweeps granules written by other CUs into LDS (q|k|v of the head, the XCD group's SwiGLU outputs, partial planes of the CU's 12 residual
 //                           rows), reduces partial sums in a FIXED order (deterministic), publishes the CU's 12 rows (already multiplied by the next norm weight).
 //     waves 2..13  CONSUMERS  layer operators as EXACT integer dot products on v_mfma_i32_16x16x64_i8: B = Q4 nibbles as int8, A = the activation in per-block fixed
