@@ -110,3 +110,26 @@ def full_dense_safetensors(seed=7, heavy_tail=False):
     if not os.path.exists(st):
         S.write_fast_dense_checkpoint(st + ".tmp", None, S.ModelDims(), seed=seed, heavy_tail=heavy_tail); os.replace(st + ".tmp", st)
     return st
+
+
+# ---- synthetic checkpoint tensors for the reference's per-component forward script (tests/golden/make_component_golden.py): real shapes, regenerable by name
+COMPONENT_SEED = 20260925
+_ENC = "mm_streams_embeddings.embedding_module.whisper_encoder."
+COMPONENT_SHAPES = {
+    _ENC + "transformer.layers.0.feed_forward.w1.weight": (5120, 1280), _ENC + "transformer.layers.0.feed_forward.w2.weight": (1280, 5120),
+    _ENC + "transformer.layers.0.feed_forward.w3.weight": (5120, 1280),
+    _ENC + "conv_layers.0.conv.weight": (1280, 128, 3), _ENC + "conv_layers.0.conv.bias": (1280,),
+    _ENC + "conv_layers.1.conv.weight": (1280, 1280, 3), _ENC + "conv_layers.1.conv.bias": (1280,),
+    _ENC + "transformer.layers.0.attention.wq.weight": (2048, 1280), _ENC + "transformer.layers.0.attention.wk.weight": (2048, 1280),
+    _ENC + "transformer.layers.0.attention.wv.weight": (2048, 1280), _ENC + "transformer.layers.0.attention.wo.weight": (1280, 2048),
+    _ENC + "transformer.layers.0.attention.wq.bias": (2048,), _ENC + "transformer.layers.0.attention.wv.bias": (2048,), _ENC + "transformer.layers.0.attention.wo.bias": (1280,),
+    "layers.0.ada_rms_norm_t_cond.0.weight": (32, 3072), "layers.0.ada_rms_norm_t_cond.2.weight": (3072, 32),
+}
+
+
+def component_weight(name):
+    """The synthetic tensor `name` of COMPONENT_SHAPES: N(0, sigma^2) f32, sigma = 0.03 (weights) / 0.02 (biases); numpy default_rng keyed by (seed, crc32(name))."""
+    import zlib
+    shape = COMPONENT_SHAPES[name]
+    rng = np.random.default_rng([COMPONENT_SEED, zlib.crc32(name.encode())])
+    return ((0.02 if name.endswith(".bias") else 0.03) * rng.standard_normal(shape)).astype(np.float32)

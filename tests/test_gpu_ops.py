@@ -1,6 +1,8 @@
 """GPU parity of the operator boundary (Q4Tensor / q4_matmul / Q4Linear / log-mel) against the CPU oracle.
 Every call goes through the C ABI of libvoxtral_hip.so.  Inputs are the reference's own deterministic
 sin/cos generators where the reference has a test for the case (gguf/tests.rs, tests/gguf_integration.rs)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -223,6 +225,27 @@ def test_attention_vs_oracle(pkg, orc, ctx, M, kv, H, KV, hd, off, win):
     assert err < 2e-5, err
     with pytest.raises(pkg.VoxError):
         attention(ctx, q, k, v, H, KV, offset=kv, window=win)       # queries outside the key range
+
+
+def test_attention_block_vs_reference_python_component_golden(pkg, orc, ctx):
+    """The HIP attention core inside the reference's OWN per-component vector (scripts/reference_forward.py test_attention, run on synthetic weights of the real shapes by
+    tests/golden/make_component_golden.py -- what the reference's Rust test_attention_vs_reference loads): projections, RoPE and the output projection through the oracle's
+    f32 operators (pinned to the same vector on CPU, tests/test_oracle_components.py), the attention itself on the GPU."""
+    from importlib import import_module
+    from model_fixtures import component_weight
+    attention = import_module(pkg.__name__ + ".gguf").attention
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_python_components.npz"))
+    ENC = "mm_streams_embeddings.embedding_module.whisper_encoder."
+    x = g["attn_input"][0]; S, H, hd = x.shape[0], 32, 64; L = orc.lib()
+    w = {k: component_weight(ENC + f"transformer.layers.0.attention.{k}.weight") for k in ("wq", "wk", "wv", "wo")}
+    b = {k: component_weight(ENC + f"transformer.layers.0.attention.{k}.bias") for k in ("wq", "wv", "wo")}
+    q = np.ascontiguousarray((orc.reference_matmul(x, w["wq"]) + b["wq"]).reshape(S, H, hd)); k = np.ascontiguousarray(orc.reference_matmul(x, w["wk"]).reshape(S, H, hd))
+    v = orc.reference_matmul(x, w["wv"]) + b["wv"]
+    L.orc_rope(q, S, H, hd, 0, 1e6); L.orc_rope(k, S, H, hd, 0, 1e6)
+    att = attention(ctx, q.reshape(S, H * hd), k.reshape(S, H * hd), v, H, H)
+    out = orc.reference_matmul(att, w["wo"]) + b["wo"]
+    err = np.abs(out - g["attn_output"][0]).max() / np.abs(g["attn_output"][0]).max()
+    assert err < 2e-4, err
 
 
 def test_attention_f32_switch_vs_oracle(pkg, orc, ctx, monkeypatch):
