@@ -1,0 +1,825 @@
+// vox_engine_b16.hip -- persistent decode-LAYER engine for a group of <= 16 sequences on gfx950 (MI355X): the 26 decoder layers of one batched decode step as ONE launch.
+//
+// What it replaces: the 26 x 5 dependent launches of the batched decode step (vox_api.cpp `group_chain`; reference: gguf/model.rs:938-960 run for B > 1 sequences -- the
+// reference itself is batch-1, BASELINE configs[3] asks for 16 utterances).  Those launches run at 0.14 of the HBM peak: five kernel boundaries per layer, and every workgroup
+// of every GEMM re-reads the whole 16-row activation block from L2.  Here the weights come through the SAME per-CU packet stream and LDS ring as the
+// single-stream engine (vox_engine.hip, vox_engine_common.h: one loader wave per CU, LDS-DMA, consumption order), so no workgroup ever re-reads a weight or an activation
+// from L2, and the CU <-> row decomposition is the same:
+//   CU b = (g = b % 8: KV head / XCD, j = b / 8): query head h = 4 g + j / 8, slice s = j % 8
+//     q|k|v   16 + 4 + 4 weight rows x K 3072 (K split over the 12 consumer waves)            -> RoPE at each sequence's own position -> granules G, KV cache
+//     attn    head h of sequences 2 s, 2 s + 1 (six waves each: per-wave online softmax over its keys, combined through LDS)   -> XO (A fragments of wo)
+//     wo      rows [384 s, +384) x head h's 128 columns -> partial plane h of PW; the owner of columns [12 b, +12) sums the 32 planes + residual     -> XH1
+//     w1|w3   72 interleaved rows (36 SwiGLU outputs) x K 3072                                  -> XA (A fragments of w2, read inside the XCD group)
+//     w2      rows [96 j, +96) x the group's 1152 columns -> partial plane g of P2; the owner sums the 8 planes + residual                           -> XH0
+// Arithmetic = the batched skinny kernels' (q4_skinny_kernel): v_mfma_f32_16x16x32_bf16, A = 16 sequences x 32 columns as bf16 hi + lo (x ~ hi + lo to 2^-17), B = the Q4
+// nibbles as EXACT bf16 integers 128 + q (bits 0x4300 | q, two v_perm_b32 per four weights), the -136 sum(x) correction as the MFMA's C operand (one MFMA pair against a
+// constant bf16(-136) per block, kept in LDS), the f16 block scale applied to the f32 result.  One step record (16 rows x 64 columns, written for the int8 MFMA of the
+// single-stream engine) feeds two bf16 MFMA pairs: v_permlane32_swap moves the high nibbles of lane groups 0, 1 to groups 2, 3 and the low nibbles of groups 2, 3 to groups
+// 0, 1, after which each register pair holds ONE Q4 block in natural column order (lane group y = columns 8 y .. 8 y + 7).
+// The activations never touch LDS: a wave's K slice (256 columns x 16 sequences, hi + lo = 16 KB) is loaded straight into 64 VGPRs as MFMA A fragments, because the
+// producers publish them in fragment order: XH / XA / XO = [32-column block][hi, lo][lane (y, m)] x 16 bytes.
+// Edges carry kilobytes, not 8-byte granules: payload with write-through (sc1) stores, s_waitcnt vmcnt(0), then ONE flag word per producing CU (MI355X_MICROARCH.md
+// handoff-flag / publish-large); the COMM wave polls the flags (a 16-byte load per lane covers all 256), the consumer waves then fetch their slices.  The small q|k|v edge
+// keeps the tagged 8-byte granules.  Edges inside one XCD group (q|k|v, attention output, SwiGLU output) use plain stores when the start-up check finds the group on one XCD.
+// Tags / flags = (launch serial + 1) * 64 + layer + 1 as in the single-stream engine; every spin is bounded (20 ms) and fails the launch loudly (*err).
+// The final norm's input leaves the launch in the launch-based path's own format (XF planes of h * final_norm + 256 partial sums of squares), so the step's tail --
+// the 16-row lm_head GEMM and the argmax / next-embedding kernel -- is unchanged.
+#include "vox_kernels.h"
+
+#include <hip/hip_fp16.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace vox {
+namespace {
+
+#include "vox_engine_common.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 16;                                   // sequences per launch (one MFMA m-tile)
+constexpr int BNSLOT = 4;                                // ring slots (the partial-sum planes of w1|w3 need 54 KB of LDS at 16 rows)
+constexpr int NBLK = ED / 32;                            // 96 column blocks of the residual stream
+constexpr int FRAG = 1024;                               // one (block, plane) fragment line: 64 lanes x 16 bytes
+constexpr int XH_BYTES = NBLK * 2 * FRAG;                // 196608
+constexpr int XO_HEAD = 4 * 2 * FRAG;                    // 8192: one head's attention output (4 blocks)
+constexpr int XA_GROUP = 36 * 2 * FRAG;                  // 73728: one XCD group's SwiGLU outputs (36 blocks)
+constexpr int G_ROW = EQD + 2 * EKD;                     // 6144 granules per sequence
+constexpr int PH = 5;                                    // publish phases per layer counted in pub_cnt: q|k|v, attention, wo, w1|w3, w2
+
+struct BCtl {
+    unsigned ring_ready[8], ring_done[8];
+    unsigned cbar, dead, gathering, gw_flag;
+    unsigned xcd_ok, xcc_id, ag_flag, pub_cnt;
+    unsigned qkv_flag, wo_flag, xa_flag, rs_flag;      // rs_flag: all-gather stages whose RMSNorm scales are in LDS
+    unsigned tbar[2], pad1[2];
+};
+// ---- LDS map ----
+constexpr int BL_RING = 0;
+constexpr int BL_PART = BL_RING + BNSLOT * SLOT_BYTES;   // cross-wave partial sums of the operator in flight (time-shared; see the ordering argument at each use)
+constexpr int PART_WAVE = 4 * 1024 + 512;                //   q|k|v / w1|w3: [wave][tile][lane] float4, the 8-row tile as [y][n < 8]
+constexpr int PART_BYTES = NCONS * PART_WAVE;            //   55296; w2: [tile 6][K slice 6][lane] float4 = 36864
+constexpr int BL_ATT = BL_PART + 24576;                  //   attention scratch (behind q|k|v's partials, which the two finishing waves may still be reading)
+constexpr int BL_PO = BL_ATT;                            //     [12][128] f32 partial outputs
+constexpr int BL_ML = BL_PO + NCONS * 128 * 4;           //     [12][2] {running max, running sum}
+constexpr int BL_OF = BL_ML + 128;                       //     [2][128] f32 final outputs
+constexpr int BL_QKVN = BL_PART + PART_BYTES;            // [2 sequences][q 128 | k 128 | v 128] f32 of this step
+constexpr int BL_CB = BL_QKVN + 2 * 384 * 4;             // [12 waves][8 blocks][16 m] f32: -136 * sum over the block of x[m][.]; after w1|w3's barrier: SwiGLU outputs [16 m][36] f32
+constexpr int BL_OWN = BL_CB + NCONS * 8 * 64;           // [12 n][16 m] f32 residual stream of the CU's columns, [12][16] post-attention stream
+constexpr int BL_RSTD = BL_OWN + 2 * OWN * BM * 4;       // [2][16] RMSNorm scales of the two all-gathers
+constexpr int BL_ROPE = BL_RSTD + 2 * BM * 4;            // q: cos [8 pairs][16 m], sin [8][16]; k: cos [2][16], sin [2][16]
+constexpr int BL_POS = BL_ROPE + (2 * 8 * BM + 2 * 2 * BM) * 4;      // [16] int positions
+constexpr int BL_TAB = BL_POS + BM * 4;
+constexpr int MAX_LAYERS = 32;
+constexpr int BL_GW = BL_TAB + MAX_LAYERS * (int)sizeof(EngLayerTab);      // [MAX_LAYERS + 1][2][16] norm weights of the CU's 12 columns
+constexpr int BL_CTL = BL_GW + (MAX_LAYERS + 1) * 32 * 4;
+constexpr int BL_TOTAL = BL_CTL + (int)sizeof(BCtl);
+static_assert(BL_TOTAL <= 160 * 1024, "LDS budget");
+static_assert(BL_OF + 2 * 128 * 4 <= BL_PART + PART_BYTES && 6 * 6 * 1024 <= PART_BYTES && BM * 36 * 4 <= NCONS * 8 * 64, "time-shared regions");
+static_assert(BL_QKVN % 16 == 0 && BL_CB % 16 == 0 && BL_OWN % 16 == 0 && BL_RSTD % 16 == 0 && BL_ROPE % 16 == 0 && BL_TAB % 16 == 0 && BL_CTL % 16 == 0 && BL_ATT % 16 == 0, "aligned carve");
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) { const f32x2_t v = {a, b}; union { bf16x2_t b; unsigned u; } c; c.b = __builtin_convertvector(v, bf16x2_t); return c.u; }
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {      // x ~ hi + lo (two bf16), as vox_kernels.hip
+    hi = cvt_pk_bf16(a, b);
+    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ u32x4 ld_frag(srd_t sd, unsigned off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sd, (int)off, 0, 16)); }      // sc1: never this CU's L1
+__device__ __forceinline__ void st_u32(srd_t sd, unsigned off, unsigned v, bool local) { if (local) __builtin_amdgcn_raw_buffer_store_b32(v, sd, (int)off, 0, 0); else __builtin_amdgcn_raw_buffer_store_b32(v, sd, (int)off, 0, 16); }
+__device__ __forceinline__ void st_u64(srd_t sd, unsigned off, unsigned a, unsigned b, bool local) {
+    v2u_t x; x.x = a; x.y = b;
+    if (local) __builtin_amdgcn_raw_buffer_store_b64(x, sd, (int)off, 0, 0); else __builtin_amdgcn_raw_buffer_store_b64(x, sd, (int)off, 0, 16);
+}
+__device__ __forceinline__ void st_f4(srd_t sd, unsigned off, f32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sd, (int)off, 0, 16); }
+__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// fragment address of (block, plane, lane group y, sequence m) inside an XH / XA / XO buffer
+__device__ __forceinline__ unsigned frag_off(int blk, int plane, int y, int m) { return (unsigned)(((blk * 2 + plane) * 64 + y * 16 + m) * 16); }
+
+// one step record (16 or 8 weight rows x 64 columns = Q4 blocks 2 T, 2 T + 1) against the step's two activation blocks: acc[m][n] += sum_k x[m][k] * w[n][k]
+__device__ __forceinline__ f32x4 step16(const unsigned char* rec, bool half, int lane, bf16x8 ah0, bf16x8 al0, bf16x8 ah1, bf16x8 al1, f32x4 c0, f32x4 c1, f32x4 acc) {
+    const int n = lane & 15, g = lane >> 4;
+    uint2 q = make_uint2(0u, 0u);
+    float s0 = 0.f, s1 = 0.f;
+    if (!half) {
+        q = reinterpret_cast<const uint2*>(rec)[lane];
+        const unsigned short* scp = reinterpret_cast<const unsigned short*>(rec + REC_SC);
+        s0 = __half2float(__ushort_as_half(scp[n])); s1 = __half2float(__ushort_as_half(scp[16 + n]));
+    } else if (n < 8) {
+        q = reinterpret_cast<const uint2*>(rec)[g * 8 + n];
+        const unsigned short* scp = reinterpret_cast<const unsigned short*>(rec + REC_H_SC);
+        s0 = __half2float(__ushort_as_half(scp[n])); s1 = __half2float(__ushort_as_half(scp[8 + n]));
+    }
+    const unsigned lox = q.x & 0x0F0F0F0Fu, loy = q.y & 0x0F0F0F0Fu, hix = (q.x >> 4) & 0x0F0F0F0Fu, hiy = (q.y >> 4) & 0x0F0F0F0Fu;
+    // lanes 32..63 of `lo` <-> lanes 0..31 of `hi`: first result = block 2 T in every lane group (y < 2: own low nibbles = columns 8 y ..; y >= 2: the high nibbles of group
+    // y - 2 = columns 16 + 8 (y - 2) ..), second result = block 2 T + 1 (y < 2: the low nibbles of group y + 2; y >= 2: own high nibbles)
+    const auto sx = __builtin_amdgcn_permlane32_swap(lox, hix, false, false);
+    const auto sy = __builtin_amdgcn_permlane32_swap(loy, hiy, false, false);
+    const unsigned c43 = 0x43434343u;
+    u32x4 b0, b1;
+    b0.x = __builtin_amdgcn_perm(sx[0], c43, 0x00050004u); b0.y = __builtin_amdgcn_perm(sx[0], c43, 0x00070006u);
+    b0.z = __builtin_amdgcn_perm(sy[0], c43, 0x00050004u); b0.w = __builtin_amdgcn_perm(sy[0], c43, 0x00070006u);
+    b1.x = __builtin_amdgcn_perm(sx[1], c43, 0x00050004u); b1.y = __builtin_amdgcn_perm(sx[1], c43, 0x00070006u);
+    b1.z = __builtin_amdgcn_perm(sy[1], c43, 0x00050004u); b1.w = __builtin_amdgcn_perm(sy[1], c43, 0x00070006u);
+    f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, as_bf16x8(b0), c0, 0, 0, 0);
+    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, as_bf16x8(b0), d0, 0, 0, 0);
+    f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, as_bf16x8(b1), c1, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, as_bf16x8(b1), d1, 0, 0, 0);
+    acc = __builtin_elementwise_fma((f32x4){s0, s0, s0, s0}, d0, acc);
+    acc = __builtin_elementwise_fma((f32x4){s1, s1, s1, s1}, d1, acc);
+    __builtin_amdgcn_sched_barrier(0);      // one record at a time: hoisting the next records' LDS reads (operands, correction rows) costs registers the wave does not have
+    return acc;
+}
+// -136 * sum_k x[m][k] of one block, in the accumulator layout (the same value in every column n)
+__device__ __forceinline__ f32x4 corr16(bf16x8 ah, bf16x8 al) {
+    u32x4 mm; mm.x = mm.y = mm.z = mm.w = 0xC308C308u;      // bf16(-136) x 8
+    const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(mm), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(mm), s, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LOADER wave: the layer packets of the single-stream engine's stream, four ring slots
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void b16_loader(const EngBParams& p, BCtl* c, unsigned ring_lds, int lane, const Tl& tl) {
+    Loader<BCtl, BNSLOT> ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = (p.flags & 1) != 0; ld.pace = 0;
+    if (p.flags & 1024) ld.depth = 2;
+    if (p.flags & 2048) ld.depth = 1;
+    const bool nodma = (p.flags & 32) != 0;
+    const u64 base = (u64)p.stream;
+    const unsigned n_pk = (unsigned)p.n_layers * PK_LAYER;
+    unsigned l = 0, r = 0; u64 off = 0;
+#pragma unroll 1
+    for (unsigned pk = 0; pk < n_pk; pk++) {
+        const int bytes = r < PK_LAYER_M ? PK_M : PK_A;
+        if (r == 0 && (int)l == p.tl_layer) tl(16);
+        const u64 src = base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes;
+        if (bytes == PK_M) ld.issue<PK_M>(src, lane, nodma); else ld.issue<PK_A>(src, lane, nodma);
+        off += (u64)bytes;
+        if (++r == PK_LAYER) { if ((int)l == p.tl_layer) tl(17); r = 0; l++; }
+    }
+    ld.flush();
+    tl(18);
+}
+
+// ------------------------------------------------------------------------------------------------
+// COMM wave
+// ------------------------------------------------------------------------------------------------
+// poll n flag words (n <= 256, a multiple of 4 or < 4 ... one 16-byte load per lane covers four) until every one equals `tag`.  idx(i) = word index of flag i.
+template <class IdxF>
+__device__ __forceinline__ bool poll_flags(const unsigned* base_, unsigned words, int n, IdxF idx, unsigned tag, int lane, BCtl* c, unsigned* err) {
+    const srd_t sd = make_srd(base_, words * 4u);
+    u64 t0 = 0;
+    const unsigned off = (unsigned)idx(min(lane, n - 1)) * 4u;
+    for (;;) {
+        const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(sd, (int)off, 0, 16);
+        if (__all(f == tag)) return true;
+        if (sweep_bail(t0, tag, c, err)) return false;
+    }
+}
+// all 256 flags of an all-gather: four per lane, one 16-byte load
+__device__ __forceinline__ bool poll_flags256(const unsigned* base_, unsigned tag, int lane, BCtl* c, unsigned* err) {
+    const srd_t sd = make_srd(base_, NCU * 4u);
+    u64 t0 = 0;
+    for (;;) {
+        const u32x4 f = ld_frag(sd, (unsigned)lane * 16u);
+        if (__all(f.x == tag && f.y == tag && f.z == tag && f.w == tag)) return true;
+        if (sweep_bail(t0, tag, c, err)) return false;
+    }
+}
+// RMSNorm scales of an all-gathered stream: 256 per-CU partial sums of squares per sequence, summed in a FIXED order (u ascending, then the butterfly) -> rstd[16] in LDS
+__device__ __forceinline__ void comm_rstd(const float* ss, float eps, int lane, float* rstd_out) {
+    const srd_t sd = make_srd(ss, NCU * BM * 4u);
+    const int q = lane >> 2, mq = lane & 3;
+    u32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = ld_frag(sd, (unsigned)(((16 * q + u) * BM + 4 * mq) * 4));
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 16; u++) { a[0] += __uint_as_float(v[u].x); a[1] += __uint_as_float(v[u].y); a[2] += __uint_as_float(v[u].z); a[3] += __uint_as_float(v[u].w); }
+#pragma unroll
+    for (int sft = 4; sft < 64; sft <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] += __shfl_xor(a[i], sft, 64);
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) rstd_out[4 * mq + i] = 1.0f / sqrtf(a[i] / (float)ED + eps);
+    }
+}
+// the owner's side of an all-gather: own[n][m] (raw residual stream of columns 12 b + n) -> fragment pieces of own * gw (bf16 hi + lo, four columns = 8 bytes per store),
+// the CU's partial sums of squares, drained, flag
+__device__ __forceinline__ void comm_publish_rows(const EngBParams& p, int lane, const float* own, const float* gw, unsigned char* xh, float* ss, unsigned* flags, unsigned tag) {
+    const int b = blockIdx.x, m = lane & 15, t = lane >> 4;
+    const srd_t xd = make_srd(xh, XH_BYTES), sd = make_srd(ss, NCU * BM * 4u), fd = make_srd(flags, NCU * 4u);
+    float sq = 0.f;
+    if (t < 3) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float raw = own[(4 * t + i) * BM + m]; sq = fmaf(raw, raw, sq); v[i] = raw * gw[4 * t + i]; }
+        unsigned h0, l0, h1, l1; split_pair(v[0], v[1], h0, l0); split_pair(v[2], v[3], h1, l1);
+        const int col = OWN * b + 4 * t, blk = col >> 5, y = (col & 31) >> 3, hf = (col >> 2) & 1;
+        st_u64(xd, frag_off(blk, 0, y, m) + 8u * hf, h0, h1, false);
+        st_u64(xd, frag_off(blk, 1, y, m) + 8u * hf, l0, l1, false);
+    }
+    sq += __shfl(sq, (lane + 16) & 63, 64) + __shfl(sq, (lane + 32) & 63, 64);      // lanes 0..15: t = 0, 1, 2 (t = 3 contributes 0 through lane + 48 -> not added)
+    if (lane < 16) st_u32(sd, (unsigned)((b * BM + m) * 4), __float_as_uint(sq), false);
+    drain_vm();
+    if (lane == 0) st_u32(fd, (unsigned)b * 4u, tag, false);
+}
+// the layer stack's output: h * final_norm in the launch-based lm_head's XF format (xf_store4 in vox_kernels.hip) + the CU's partial sums of squares (plain stores: the
+// kernel boundary publishes them)
+__device__ __forceinline__ void comm_publish_final(const EngBParams& p, int lane, const float* own, const float* gw) {
+    const int b = blockIdx.x, m = lane & 15, t = lane >> 4;
+    float sq = 0.f;
+    if (t < 3) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float raw = own[(4 * t + i) * BM + m]; sq = fmaf(raw, raw, sq); v[i] = raw * gw[4 * t + i]; }
+        const int k = OWN * b + 4 * t, q = k >> 7, j = (k >> 5) & 3, e = k & 31, hf = e >> 4, g = (e & 15) >> 2;
+        const size_t base = ((size_t)((q * 4 + j) * 64 + g * 16 + m)) * 8 + 2 * hf, plane = (size_t)(ED >> 7) * 256 * 8;
+        unsigned hi, lo;
+        split_pair(v[0], v[2], hi, lo); *reinterpret_cast<unsigned*>(p.xf_out + base) = hi; *reinterpret_cast<unsigned*>(p.xf_out + plane + base) = lo;
+        split_pair(v[1], v[3], hi, lo); *reinterpret_cast<unsigned*>(p.xf_out + base + 4) = hi; *reinterpret_cast<unsigned*>(p.xf_out + plane + base + 4) = lo;
+    }
+    sq += __shfl(sq, (lane + 16) & 63, 64) + __shfl(sq, (lane + 32) & 63, 64);
+    if (lane < 16) p.ssq_out[b * BM + m] = sq;
+}
+// sum NP partial planes of the CU's 12 columns x 16 sequences (planes[pl][col][m], plane pl's producer-side index given by plane_idx) + the residual -> dst[n][m]
+template <int NP, class PlaneF>
+__device__ __forceinline__ void comm_reduce(const float* planes, unsigned bytes, PlaneF plane_base, int lane, const float* resid, float* dst) {
+    const srd_t sd = make_srd(planes, bytes);
+    const int n12 = min(lane >> 2, OWN - 1), mq = lane & 3;
+    const unsigned lo_ = (unsigned)((OWN * blockIdx.x + n12) * BM + 4 * mq) * 4u;
+    f32x4 a = *reinterpret_cast<const f32x4*>(resid + n12 * BM + 4 * mq);
+#pragma unroll
+    for (int r0 = 0; r0 < NP; r0 += 16) {
+        u32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16 && r0 + u < NP; u++) v[u] = ld_frag(sd, (unsigned)plane_base(r0 + u) + lo_);
+#pragma unroll
+        for (int u = 0; u < 16 && r0 + u < NP; u++) a += __builtin_bit_cast(f32x4, v[u]);      // fixed order
+    }
+    if (lane < 4 * OWN) *reinterpret_cast<f32x4*>(dst + n12 * BM + 4 * mq) = a;
+}
+
+__device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned char* lds, const int lane0, const Tl& tl) {
+    const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
+    float* qkvn = reinterpret_cast<float*>(lds + BL_QKVN);
+    float* own0 = reinterpret_cast<float*>(lds + BL_OWN); float* own1 = own0 + OWN * BM;
+    float* rstd = reinterpret_cast<float*>(lds + BL_RSTD);
+    const float* gwt = reinterpret_cast<const float*>(lds + BL_GW);
+    const unsigned tag_base = (unsigned)__builtin_amdgcn_readfirstlane((int)((*p.serial + 1u) * 64u));
+    const int L = p.n_layers;
+    {   // the step's input rows of this CU's 12 columns (rows >= n_rows: zeros)
+        const int n12 = min(lane0 >> 2, OWN - 1), mq = lane0 & 3;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; r++) if (4 * mq + r < p.n_rows) v[r] = as_g(p.h_in)[(size_t)(4 * mq + r) * p.h_stride + OWN * b + n12];
+        if (lane0 < 4 * OWN) *reinterpret_cast<f32x4*>(own0 + n12 * BM + 4 * mq) = v;
+        wait_ge(&c->gw_flag, (unsigned)NCONS, c, p.err, ERR_STAGE);
+        ENG_CFENCE();
+        if (L > 0) comm_publish_rows(p, lane0, own0, gwt, p.XH0, p.SS0, p.F0, tag_base);
+        else comm_publish_final(p, lane0, own0, gwt);
+    }
+    const bool xloc = (p.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0;
+#pragma unroll 1
+    for (int st = 0; st < 2 * L; st++) {
+        int lane = lane0; asm volatile("" : "+v"(lane));
+        const int l = st >> 1; const bool odd = st & 1, T = l == p.tl_layer;
+        const unsigned tag = tag_base + (unsigned)l + 1u;
+        const unsigned pc0 = (unsigned)(NCONS * PH * l);
+        // ---- all-gather: every owner's flag, the RMSNorm scales, release the consumer waves
+        if (T) tl(odd ? 20 : 8);
+        lds_st(&c->gathering, 1u);
+        poll_flags256(odd ? p.F1 : p.F0, odd ? tag : tag - 1u, lane, c, p.err);
+        if (T) tl(odd ? 21 : 9);
+        lds_st(&c->ag_flag, (unsigned)st + 1u);
+        comm_rstd(odd ? p.SS1 : p.SS0, p.eps, lane, rstd + (odd ? BM : 0));
+        ENG_CFENCE(); lds_st(&c->rs_flag, (unsigned)st + 1u);
+        lds_st(&c->gathering, 0u);
+        if (!odd) {
+            {   // this step's q (head h), k, v (KV head g) rows of the CU's two sequences
+                wait_ge(&c->pub_cnt, pc0 + NCONS, c, p.err, ERR_STAGE);
+                lds_st(&c->gathering, 1u);
+                float v[12];
+                sweep<12>(p.G, BM * G_ROW * 8u, tag, [&](int u) { const int i = lane + 64 * u, t = i / 384, r = i - 384 * t, seg = r >> 7, e = r & 127;
+                                                                 return (2 * s + t) * G_ROW + (seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e); },
+                          [&]() { return 0; }, false, v, c, p.err);
+                lds_st(&c->gathering, 0u);
+#pragma unroll
+                for (int u = 0; u < 12; u++) qkvn[lane + 64 * u] = v[u];
+                ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u);
+            }
+            if (T) tl(10);
+            {   // attention outputs of head h: this CU's flag, then the eight slice-CUs'
+                wait_ge(&c->pub_cnt, pc0 + 2 * NCONS, c, p.err, ERR_STAGE);
+                if (lane == 0) st_u32(make_srd(p.FO, NCU * 4u), (unsigned)(h * 8 + s) * 4u, tag, xloc);
+                lds_st(&c->gathering, 1u);
+                poll_flags(p.FO, NCU, 8, [&](int i) { return h * 8 + i; }, tag, lane, c, p.err);
+                lds_st(&c->gathering, 0u);
+                lds_st(&c->wo_flag, (unsigned)l + 1u);
+            }
+            if (T) tl(11);
+            {   // wo: this CU's plane is stored (12 waves drained) -> flag; the 32 planes of the CU's 12 columns -> post-attention stream
+                wait_ge(&c->pub_cnt, pc0 + 3 * NCONS, c, p.err, ERR_STAGE);
+                if (lane == 0) st_u32(make_srd(p.FW, NCU * 4u), (unsigned)(h * 8 + s) * 4u, tag, false);
+                if (T) tl(12);
+                lds_st(&c->gathering, 1u);
+                poll_flags(p.FW, NCU, 32, [&](int i) { return i * 8 + (b >> 5); }, tag, lane, c, p.err);
+                if (T) tl(13);
+                comm_reduce<NPW>(p.PW, NPW * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own0, own1);
+                lds_st(&c->gathering, 0u);
+                ENG_CFENCE();
+                if (!((p.flags & 16384) && b == 7 && l == 1))      // (flag 16384 = FAULT INJECTION: workgroup 7 loses a publish)
+                    comm_publish_rows(p, lane, own1, gwt + (l * 2 + 1) * 16, p.XH1, p.SS1, p.F1, tag);
+            }
+            if (T) tl(14);
+        } else {
+            {   // SwiGLU outputs of the XCD group: this CU's flag, then the group's 32
+                wait_ge(&c->pub_cnt, pc0 + 4 * NCONS, c, p.err, ERR_STAGE);
+                if (lane == 0) st_u32(make_srd(p.FA, NCU * 4u), (unsigned)(g * 32 + j) * 4u, tag, xloc);
+                lds_st(&c->gathering, 1u);
+                poll_flags(p.FA, NCU, 32, [&](int i) { return g * 32 + i; }, tag, lane, c, p.err);
+                lds_st(&c->gathering, 0u);
+                lds_st(&c->xa_flag, (unsigned)l + 1u);
+            }
+            if (T) tl(22);
+            {   // w2: flag, the 8 planes -> the layer's output; published as the next layer's q|k|v input, or (last layer) as the lm_head launch's input
+                wait_ge(&c->pub_cnt, pc0 + 5 * NCONS, c, p.err, ERR_STAGE);
+                if (lane == 0) st_u32(make_srd(p.F2, NCU * 4u), (unsigned)(g * 32 + j) * 4u, tag, false);
+                if (T) tl(23);
+                lds_st(&c->gathering, 1u);
+                poll_flags(p.F2, NCU, 8, [&](int i) { return i * 32 + (b >> 3); }, tag, lane, c, p.err);
+                if (T) tl(24);
+                comm_reduce<NP2>(p.P2, NP2 * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own1, own0);
+                lds_st(&c->gathering, 0u);
+                ENG_CFENCE();
+                if (l + 1 < L) comm_publish_rows(p, lane, own0, gwt + ((l + 1) * 2) * 16, p.XH0, p.SS0, p.F0, tag);
+                else comm_publish_final(p, lane, own0, gwt + (L * 2) * 16);
+            }
+            if (T) tl(25);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CONSUMER waves
+// ------------------------------------------------------------------------------------------------
+// Every phase of a layer is a SEPARATELY COMPILED (noinline) function.  Inlined into one loop body the phases fit individually (q|k|v and w1|w3: 128 VGPRs with the wave's 64
+// registers of A fragments; attention: 114) but the combination spilled 180 VGPRs into the hot loops -- hipcc carries loop-invariant state of every phase across all the
+// others.  A call boundary ends every live range: the only state a phase receives is (consumer wave, lane, layer); packet and barrier counters are functions of the layer,
+// the launch parameters are read from the kernarg segment with scalar loads, LDS is addressed from its base.
+#define B16_PHASE __device__ __attribute__((noinline))
+constexpr int CB_LAYER = 4;      // workgroup barriers among the consumer waves per layer
+__device__ __forceinline__ EngBParams kparams() {      // by value from the constant address space: the fields a phase uses become scalar loads
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(4))) EngBParams*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return EngBParams{};
+#endif
+}
+__device__ __forceinline__ unsigned char* lds_base() { extern __shared__ __attribute__((aligned(16))) unsigned char lds_[]; return lds_; }
+__device__ __forceinline__ unsigned b16_tag_base(const EngBParams& p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)((*p.serial + 1u) * 64u)); }
+
+struct BCons {
+    const EngBParams& p; BCtl* c; unsigned char* lds; int cw, lane;
+    __device__ __forceinline__ BCons(const EngBParams& p_, unsigned char* lds_, int cw_, int lane_) : p(p_), c(reinterpret_cast<BCtl*>(lds_ + BL_CTL)), lds(lds_), cw(cw_), lane(lane_) {}
+    __device__ __forceinline__ void cbarrier(unsigned target) {      // target = NCONS * (barriers so far)
+        ENG_CFENCE();
+        if (lane == 0) __hip_atomic_fetch_add(&c->cbar, 1u, RLX, WG);
+        wait_ge(&c->cbar, target, c, p.err, ERR_CBAR);
+    }
+    __device__ __forceinline__ void tbarrier(int team, unsigned target) {      // the six waves of an attention team
+        ENG_CFENCE();
+        if (lane == 0) __hip_atomic_fetch_add(&c->tbar[team], 1u, RLX, WG);
+        wait_ge(&c->tbar[team], target, c, p.err, ERR_CBAR);
+    }
+    __device__ __forceinline__ void published() { ENG_CFENCE(); if (lane == 0) __hip_atomic_fetch_add(&c->pub_cnt, 1u, RLX, WG); }
+    __device__ __forceinline__ const unsigned char* slot_wait(unsigned pk, int share_bytes, int& slot) {
+        slot = (int)(pk % BNSLOT); const unsigned k = pk / BNSLOT;
+        wait_ge(&c->ring_ready[slot], k + 1u, c, p.err, ERR_RING);
+        return lds + BL_RING + slot * SLOT_BYTES + cw * share_bytes;
+    }
+    __device__ __forceinline__ void slot_release(int slot) { ENG_CFENCE(); if (lane == 0) __hip_atomic_fetch_add(&c->ring_done[slot], 1u, RLX, WG); }
+    // NB activation blocks blk0 .. blk0 + NB - 1 of a fragment buffer -> registers (hi, lo), and their -136 sum(x) rows -> this wave's CB lines
+    template <int NB>
+    __device__ __forceinline__ void load_a(const unsigned char* buf, unsigned bytes, int blk0, bf16x8 (&ah)[NB], bf16x8 (&al)[NB]) {
+        const srd_t sd = make_srd(buf, bytes);
+        u32x4 rh[NB], rl[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) { rh[i] = ld_frag(sd, (unsigned)(((blk0 + i) * 2) * FRAG + lane * 16)); rl[i] = ld_frag(sd, (unsigned)(((blk0 + i) * 2 + 1) * FRAG + lane * 16)); }
+        float* cb = reinterpret_cast<float*>(lds + BL_CB) + cw * 8 * BM;
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            ah[i] = as_bf16x8(rh[i]); al[i] = as_bf16x8(rl[i]);
+            const f32x4 cs = corr16(ah[i], al[i]);
+            if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(cb + i * BM + 4 * (lane >> 4)) = cs;
+        }
+    }
+    __device__ __forceinline__ f32x4 cb_read(int i) const { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds + BL_CB) + (cw * 8 + i) * BM + 4 * (lane >> 4)); }
+};
+#define B16_PROLOGUE                                                                                                          \
+    const EngBParams p = kparams(); unsigned char* lds = lds_base();                                                          \
+    const int cw = __builtin_amdgcn_readfirstlane(cw_), l = __builtin_amdgcn_readfirstlane(l_);                               \
+    BCtl* c = reinterpret_cast<BCtl*>(lds + BL_CTL); BCons cs(p, lds, cw, lane);                                             \
+    const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7, n = lane & 15, y = lane >> 4;           \
+    const unsigned tag = b16_tag_base(p) + (unsigned)l + 1u, P0 = (unsigned)l * PK_LAYER;                                     \
+    const bool xloc = (p.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0;                                                       \
+    const EngLayerTab* Lt = reinterpret_cast<const EngLayerTab*>(lds + BL_TAB) + l;                                           \
+    Tl tl; tl.on = p.tl != nullptr && lane == 0 && l == p.tl_layer && cw == 0; tl.buf = p.tl ? p.tl + (size_t)blockIdx.x * 32 : nullptr; \
+    (void)g; (void)j; (void)h; (void)s; (void)n; (void)y; (void)tag; (void)P0; (void)xloc; (void)Lt;
+
+// ================= q|k|v: 16 + 8 weight rows x K 3072, K split over the 12 waves =================
+B16_PHASE void ph_qkv(int cw_, int lane, int l_) {
+    B16_PROLOGUE
+    unsigned char* part = lds + BL_PART;
+    {
+        wait_ge(&c->ag_flag, 2u * (unsigned)l + 1u, c, p.err, ERR_STAGE);
+        bf16x8 ah[8], al[8];
+        cs.load_a<8>(p.XH0, XH_BYTES, 8 * cw, ah, al);
+        tl(0);
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pk = 0; pk < 2; pk++) {
+            int sl; const unsigned char* bb = cs.slot_wait(P0 + pk, 2 * REC, sl);
+#pragma unroll
+            for (int r = 0; r < 2; r++) { const int i0 = 2 * (2 * pk + r); a0 = step16(bb + r * REC, false, lane, ah[i0], al[i0], ah[i0 + 1], al[i0 + 1], cs.cb_read(i0), cs.cb_read(i0 + 1), a0); }
+            cs.slot_release(sl);
+        }
+        {
+            int sl; const unsigned char* bb = cs.slot_wait(P0 + 2, 4 * REC_H, sl);
+#pragma unroll
+            for (int r = 0; r < 4; r++) a1 = step16(bb + r * REC_H, true, lane, ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], cs.cb_read(2 * r), cs.cb_read(2 * r + 1), a1);
+            cs.slot_release(sl);
+        }
+        *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + lane * 16) = a0;
+        if (n < 8) *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 1024 + (y * 8 + n) * 16) = a1;
+    }
+    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 1)));
+    if (cw < 2) {      // wave 0: the 16 q rows; wave 1: 4 k + 4 v rows -- sum the 12 K slices (fixed order), RMSNorm scale, RoPE at each sequence's position, publish
+        const float* rstd = reinterpret_cast<const float*>(lds + BL_RSTD);
+        const float* ropef = reinterpret_cast<const float*>(lds + BL_ROPE);      // q cos [8][16] | q sin [8][16] | k cos [2][16] | k sin [2][16]
+        const int* posl = reinterpret_cast<const int*>(lds + BL_POS);
+        const int nn = cw == 0 ? n : (n & 7);
+        wait_ge(&c->rs_flag, 2u * (unsigned)l + 1u, c, p.err, ERR_STAGE);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NCONS; w++) a += *reinterpret_cast<const f32x4*>(part + w * PART_WAVE + (cw == 0 ? lane * 16 : 1024 + (y * 8 + nn) * 16));
+        a *= *reinterpret_cast<const f32x4*>(rstd + 4 * y);
+        const bool rot = cw == 0 || nn < 4;
+        const float* rcp = ropef + (cw == 0 ? 0 : 16 * BM) + (nn >> 1) * BM + 4 * y;
+        const f32x4 rc = rot ? *reinterpret_cast<const f32x4*>(rcp) : (f32x4){1.f, 1.f, 1.f, 1.f};
+        const f32x4 rs = rot ? *reinterpret_cast<const f32x4*>(rcp + (cw == 0 ? 8 * BM : 2 * BM)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const srd_t gd = make_srd(p.G, BM * G_ROW * 8u);
+        const gf_p kc = as_g(Lt->kc), vc = as_g(Lt->vc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float o = dppf<0xB1>(a[r]);
+            const float yv = (nn & 1) ? fmaf(o, rs[r], a[r] * rc[r]) : fmaf(-o, rs[r], a[r] * rc[r]);      // interleaved-pair RoPE (rope.rs:99-141); identity for v
+            const int m = 4 * y + r;
+            if (cw == 0) st_u64(gd, (unsigned)(m * G_ROW + 128 * h + 16 * s + n) * 8u, __float_as_uint(yv), tag, xloc);
+            else if (n < 8) {
+                const int col = 128 * g + 4 * j + (nn & 3);
+                st_u64(gd, (unsigned)(m * G_ROW + (nn < 4 ? EQD : EQD + EKD) + col) * 8u, __float_as_uint(yv), tag, xloc);
+                if (m < p.n_rows) (nn < 4 ? kc : vc)[(size_t)m * p.kv_seq_stride + (size_t)g * p.max_seq * EHD + (size_t)posl[m] * EHD + 4 * j + (nn & 3)] = yv;      // the cache rows later steps read
+            }
+        }
+    }
+    cs.published();
+    tl(1);
+}
+
+// ================= attention: head h of sequence 2 s + team, six waves, per-wave online softmax over the wave's keys =================
+B16_PHASE void ph_attn(int cw_, int lane, int l_) {
+    B16_PROLOGUE
+    const int* posl = reinterpret_cast<const int*>(lds + BL_POS);
+    const float* qkvn = reinterpret_cast<const float*>(lds + BL_QKVN);
+    float* po = reinterpret_cast<float*>(lds + BL_PO); float* ml = reinterpret_cast<float*>(lds + BL_ML); float* ofin = reinterpret_cast<float*>(lds + BL_OF);
+    const int team = cw / 6, tw = cw - 6 * team, msq = 2 * s + team;
+    const bool seq_ok = msq < p.n_rows;
+    const float scale = 1.0f / sqrtf((float)EHD);
+    const int pos = __builtin_amdgcn_readfirstlane(posl[msq]);
+    const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0, n_old = seq_ok ? pos - j_lo : 0, last_old = max(n_old - 1, 0);
+    // uniform bases in SGPRs (the table lives in LDS: a ds_read result is a VGPR to the compiler) -> one 32-bit VGPR offset per load
+    const size_t kvo = (size_t)min(msq, max(p.n_rows - 1, 0)) * p.kv_seq_stride + (size_t)g * p.max_seq * EHD;
+    const u64 kcb = (u64)(uintptr_t)Lt->kc, vcb = (u64)(uintptr_t)Lt->vc;
+    const gf_p kc = (gf_p)(uintptr_t)(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kcb >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kcb)) + kvo;
+    const gf_p vc = (gf_p)(uintptr_t)(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(vcb >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)vcb)) + kvo;
+    const int part_ = lane & 7, kk = lane >> 3;
+    // a ROUND = 96 keys of the team = 16 per wave (two sub-passes of 8): K as 8 lanes x 16 columns per key, V as 64 lanes x 2 columns per key; all 64 registers
+    // of a round are requested at once.  Round 0 does not depend on this step: it is in flight while the q|k|v edge resolves.
+    const int nround = (n_old + 95) / 96;
+    float4 kA[2][4]; float2 vA[2][8];
+    auto kvload = [&](int r) {
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+            const int k0 = 96 * r + 48 * sp + 8 * tw;
+            const unsigned ko = (unsigned)(j_lo + min(k0 + kk, last_old)) * EHD + part_ * 16;
+#pragma unroll
+            for (int e = 0; e < 4; e++) kA[sp][e] = ldg4(kc + (ko + 4 * e));
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const fv2 v = *(const __attribute__((address_space(1))) fv2*)(vc + ((unsigned)(j_lo + min(k0 + e, last_old)) * EHD + lane * 2)); vA[sp][e] = make_float2(v.x, v.y); }
+        }
+    };
+    if (nround > 0) kvload(0);
+    wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+    tl(2);
+    const float* qn = qkvn + team * 384;
+    float qv[16];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const float4 v = *reinterpret_cast<const float4*>(qn + part_ * 16 + 4 * e); qv[4 * e] = v.x; qv[4 * e + 1] = v.y; qv[4 * e + 2] = v.z; qv[4 * e + 3] = v.w; }
+    auto dot16 = [&](const float4 (&kq)[4]) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { sacc = fmaf(qv[4 * e], kq[e].x, sacc); sacc = fmaf(qv[4 * e + 1], kq[e].y, sacc); sacc = fmaf(qv[4 * e + 2], kq[e].z, sacc); sacc = fmaf(qv[4 * e + 3], kq[e].w, sacc); }
+        return group8_sum_e(sacc);
+    };
+    float m_run = -INFINITY, l_run = 0.f; float2 o = make_float2(0.f, 0.f);
+#pragma unroll 1
+    for (int r = 0; r < nround; r++) {
+        if (r > 0) kvload(r);
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+            const int i = 96 * r + 48 * sp + 8 * tw + kk;
+            const float sv = i < n_old ? dot16(kA[sp]) * scale : -INFINITY;
+            const float pm = wave_max_e(sv);
+            if (pm > -INFINITY) {
+                const float mn = fmaxf(m_run, pm), alpha = expf(m_run - mn), pe = expf(sv - mn);
+                l_run *= alpha; o.x *= alpha; o.y *= alpha;
+#pragma unroll
+                for (int e = 0; e < 8; e++) { const float pr_ = rlf(pe, 8 * e); l_run += pr_; o.x = fmaf(pr_, vA[sp][e].x, o.x); o.y = fmaf(pr_, vA[sp][e].y, o.y); }
+                m_run = mn;
+            }
+        }
+    }
+    if (tw == 0) {      // the new key (this step's k / v row)
+        float4 kq[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) kq[e] = *reinterpret_cast<const float4*>(qn + 128 + part_ * 16 + 4 * e);
+        const float sv = dot16(kq) * scale;      // the same in every lane group
+        const float mn = fmaxf(m_run, sv), alpha = expf(m_run - mn), pe = expf(sv - mn);
+        const float2 vv = *reinterpret_cast<const float2*>(qn + 256 + lane * 2);
+        l_run = l_run * alpha + pe; o.x = fmaf(pe, vv.x, o.x * alpha); o.y = fmaf(pe, vv.y, o.y * alpha);
+        m_run = mn;
+    }
+    *reinterpret_cast<float2*>(po + cw * 128 + lane * 2) = o;
+    if (lane == 0) { ml[2 * cw] = m_run; ml[2 * cw + 1] = l_run; }
+    cs.tbarrier(team, (unsigned)(6 * (l + 1)));
+    if (tw == 0) {      // combine the team's six partials (fixed order), normalise, publish head h's output of sequence msq as wo's A fragments (hi + lo)
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 6; w++) M = fmaxf(M, ml[2 * (6 * team + w)]);
+        float Ls = 0.f; float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 6; w++) {
+            const float f = expf(ml[2 * (6 * team + w)] - M);
+            const float2 ov = *reinterpret_cast<const float2*>(po + (6 * team + w) * 128 + lane * 2);
+            Ls = fmaf(ml[2 * (6 * team + w) + 1], f, Ls); acc.x = fmaf(ov.x, f, acc.x); acc.y = fmaf(ov.y, f, acc.y);
+        }
+        const float inv = seq_ok ? 1.0f / Ls : 0.f;
+        *reinterpret_cast<float2*>(ofin + team * 128 + lane * 2) = make_float2(acc.x * inv, acc.y * inv);
+        ENG_CFENCE();
+        if (lane < 16) {      // lane = octet of the head's 128 columns
+            const float4 v0 = *reinterpret_cast<const float4*>(ofin + team * 128 + 8 * lane), v1 = *reinterpret_cast<const float4*>(ofin + team * 128 + 8 * lane + 4);
+            unsigned hq[4], lq[4];
+            split_pair(v0.x, v0.y, hq[0], lq[0]); split_pair(v0.z, v0.w, hq[1], lq[1]); split_pair(v1.x, v1.y, hq[2], lq[2]); split_pair(v1.z, v1.w, hq[3], lq[3]);
+            u32x4 hi, lo; hi.x = hq[0]; hi.y = hq[1]; hi.z = hq[2]; hi.w = hq[3]; lo.x = lq[0]; lo.y = lq[1]; lo.z = lq[2]; lo.w = lq[3];
+            const srd_t od = make_srd(p.XO + (size_t)h * XO_HEAD, XO_HEAD);
+            const unsigned o0 = frag_off(lane >> 2, 0, lane & 3, msq), o1 = frag_off(lane >> 2, 1, lane & 3, msq);
+            if (xloc) { __builtin_amdgcn_raw_buffer_store_b128(hi, od, (int)o0, 0, 0); __builtin_amdgcn_raw_buffer_store_b128(lo, od, (int)o1, 0, 0); }
+            else { __builtin_amdgcn_raw_buffer_store_b128(hi, od, (int)o0, 0, 16); __builtin_amdgcn_raw_buffer_store_b128(lo, od, (int)o1, 0, 16); }
+        }
+        drain_vm();
+    }
+    cs.published();
+    tl(3);
+}
+
+// ================= wo: rows [384 s, +384) x head h's 128 columns -> plane h =================
+B16_PHASE void ph_wo(int cw_, int lane, int l_) {
+    B16_PROLOGUE
+    wait_ge(&c->wo_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+    bf16x8 ah[4], al[4];
+    cs.load_a<4>(p.XO + (size_t)h * XO_HEAD, XO_HEAD, 0, ah, al);
+    tl(4);
+    const srd_t pd = make_srd(p.PW + (size_t)h * ED * BM, ED * BM * 4u);
+#pragma unroll
+    for (int i = 0; i < WO_PK; i++) {
+        int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + i, 2 * REC, sl);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = step16(bb, false, lane, ah[0], al[0], ah[1], al[1], cs.cb_read(0), cs.cb_read(1), a);
+        a = step16(bb + REC, false, lane, ah[2], al[2], ah[3], al[3], cs.cb_read(2), cs.cb_read(3), a);
+        cs.slot_release(sl);
+        st_f4(pd, (unsigned)((384 * s + 16 * (2 * cw + i) + n) * BM + 4 * y) * 4u, a);
+    }
+    drain_vm();
+    cs.published();
+    tl(5);
+}
+
+// ================= w1|w3: 72 interleaved gate / up rows x K 3072 -> 36 SwiGLU outputs x 16 sequences =================
+B16_PHASE void ph_w13(int cw_, int lane, int l_) {
+    B16_PROLOGUE
+    unsigned char* part = lds + BL_PART;
+    float* sg = reinterpret_cast<float*>(lds + BL_CB);           // SwiGLU outputs [16 m][36] (the CB lines are dead behind the first barrier)
+    {
+        wait_ge(&c->ag_flag, 2u * (unsigned)l + 2u, c, p.err, ERR_STAGE);
+        bf16x8 ah[8], al[8];
+        cs.load_a<8>(p.XH1, XH_BYTES, 8 * cw, ah, al);
+        tl(6);
+#pragma unroll 1
+        for (int ti = 0; ti < 4; ti++) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pk = 0; pk < 2; pk++) {
+                int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + WO_PK + 2 * ti + pk, 2 * REC, sl);
+#pragma unroll
+                for (int r = 0; r < 2; r++) { const int i0 = 2 * (2 * pk + r); a = step16(bb + r * REC, false, lane, ah[i0], al[i0], ah[i0 + 1], al[i0 + 1], cs.cb_read(i0), cs.cb_read(i0 + 1), a); }
+                cs.slot_release(sl);
+            }
+            *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + ti * 1024 + lane * 16) = a;
+        }
+        {
+            int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + WO_PK + 8, 4 * REC_H, sl);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; r++) a = step16(bb + r * REC_H, true, lane, ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], cs.cb_read(2 * r), cs.cb_read(2 * r + 1), a);
+            cs.slot_release(sl);
+            if (n < 8) *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 4096 + (y * 8 + n) * 16) = a;
+        }
+    }
+    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 2)));      // (also: every wave is through with its CB lines -> the region becomes the SwiGLU scratch)
+    if (cw < 5) {       // wave t finishes tile t: K slices summed in a fixed order, RMSNorm scale, SiLU(gate) * up -> sg[m][col]
+        const float* rstd = reinterpret_cast<const float*>(lds + BL_RSTD);
+        const bool hf = cw == 4;
+        wait_ge(&c->rs_flag, 2u * (unsigned)l + 2u, c, p.err, ERR_STAGE);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NCONS; w++) a += *reinterpret_cast<const f32x4*>(part + w * PART_WAVE + (hf ? 4096 + (y * 8 + (n & 7)) * 16 : cw * 1024 + lane * 16));
+        a *= *reinterpret_cast<const f32x4*>(rstd + BM + 4 * y);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float up = dppf<0xB1>(a[r]);
+            if ((n & 1) == 0 && (!hf || n < 8)) sg[(4 * y + r) * 36 + 8 * cw + (n >> 1)] = silu_e(a[r]) * up;
+        }
+    }
+    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 3)));
+    if (cw < 3 && lane < 48) {      // 144 pieces of four columns x one sequence -> bf16 hi + lo, 8 bytes each, into the group's fragment buffer
+        const int it = 48 * cw + lane, m = it & 15, hc = it >> 4;
+        const float4 v = *reinterpret_cast<const float4*>(sg + m * 36 + 4 * hc);
+        unsigned h0, l0, h1, l1; split_pair(v.x, v.y, h0, l0); split_pair(v.z, v.w, h1, l1);
+        const int col = 36 * j + 4 * hc, blk = col >> 5, yy = (col & 31) >> 3, hh = (col >> 2) & 1;
+        const srd_t ad = make_srd(p.XA + (size_t)g * XA_GROUP, XA_GROUP);
+        st_u64(ad, frag_off(blk, 0, yy, m) + 8u * hh, h0, h1, xloc);
+        st_u64(ad, frag_off(blk, 1, yy, m) + 8u * hh, l0, l1, xloc);
+        drain_vm();
+    }
+    cs.published();
+    tl(7);
+}
+
+// ================= w2: rows [96 j, +96) x the XCD group's 1152 columns -> plane g =================
+B16_PHASE void ph_w2(int cw_, int lane, int l_) {
+    B16_PROLOGUE
+    unsigned char* part = lds + BL_PART;
+    {
+        const int ksl = cw % 6, tg = cw / 6;
+        wait_ge(&c->xa_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+        bf16x8 ah[6], al[6];
+        cs.load_a<6>(p.XA + (size_t)g * XA_GROUP, XA_GROUP, 6 * ksl, ah, al);
+        tl(26);
+#pragma unroll
+        for (int i = 0; i < W2_PK; i++) {
+            int sl; const unsigned char* bb = cs.slot_wait(P0 + PK_LAYER_M + i, 3 * REC, sl);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; k++) a = step16(bb + k * REC, false, lane, ah[2 * k], al[2 * k], ah[2 * k + 1], al[2 * k + 1], cs.cb_read(2 * k), cs.cb_read(2 * k + 1), a);
+            cs.slot_release(sl);
+            *reinterpret_cast<f32x4*>(part + ((3 * tg + i) * 6 + ksl) * 1024 + lane * 16) = a;
+        }
+    }
+    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 4)));
+    if (cw < 6) {      // wave t finishes tile t
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 6; w++) a += *reinterpret_cast<const f32x4*>(part + (cw * 6 + w) * 1024 + lane * 16);
+        st_f4(make_srd(p.P2 + (size_t)g * ED * BM, ED * BM * 4u), (unsigned)((96 * j + 16 * cw + n) * BM + 4 * y) * 4u, a);
+        drain_vm();
+    }
+    cs.published();
+    tl(15);
+}
+
+__device__ __forceinline__ void b16_consumer(const EngBParams& p, BCtl* c, unsigned char* lds, int cw, const int lane0, const Tl& tl) {
+    const int b = blockIdx.x, g = b & 7, j = b >> 3, s = j & 7;
+    float* ropef = reinterpret_cast<float*>(lds + BL_ROPE);      // q cos [8][16] | q sin [8][16] | k cos [2][16] | k sin [2][16]
+    int* posl = reinterpret_cast<int*>(lds + BL_POS);
+    const unsigned tag_base = b16_tag_base(p);
+    const int half = EHD / 2;
+    {   // start-up: positions, RoPE factors (wave 0: the CU's 8 q pairs; wave 1: its 2 k pairs), norm-weight table, XCD check
+        if (cw == 0) {
+            const int m = lane0 & 15;
+            const int pm = m < p.n_rows ? p.pos[m] : 0;
+            if (lane0 < 16) posl[m] = pm;
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const int pr = 2 * (lane0 >> 4) + u; ropef[pr * BM + m] = p.rope_cos[(size_t)pm * half + 8 * s + pr]; ropef[8 * BM + pr * BM + m] = p.rope_sin[(size_t)pm * half + 8 * s + pr]; }
+        }
+        if (cw == 1 && lane0 < 32) {
+            const int m = lane0 & 15, pr = lane0 >> 4;
+            const int pm = m < p.n_rows ? p.pos[m] : 0;
+            ropef[16 * BM + pr * BM + m] = p.rope_cos[(size_t)pm * half + 2 * j + pr]; ropef[18 * BM + pr * BM + m] = p.rope_sin[(size_t)pm * half + 2 * j + pr];
+        }
+        const EngLayerTab* tab = reinterpret_cast<const EngLayerTab*>(lds + BL_TAB);
+        float* gwt = reinterpret_cast<float*>(lds + BL_GW);
+        const bool xchg = cw == NCONS - 1 && (p.flags & 128) != 0;
+        const unsigned my = c->xcc_id;
+        if (xchg && lane0 == 0) publish(p.XC + b, tag_base, __uint_as_float(my));
+        const int l = cw + NCONS * (lane0 >> 4), r = lane0 & 15, lc = min(l, max(p.n_layers - 1, 0));
+        const bool lok = r < OWN && l <= p.n_layers && (lane0 >> 4) < 3, lay = l < p.n_layers;
+        const unsigned k = (unsigned)(OWN * b + min(r, OWN - 1));
+        const gcf_p pa = as_g(lay ? tab[lc].attn_norm : p.final_norm);
+        float wa = 0.f, wf = 0.f, wd = 0.f;
+        if (lok) { wa = pa[k]; if (p.n_layers > 0) { wf = as_g(tab[lc].ffn_norm)[k]; wd = as_g(tab[lc].ada_mul)[k]; } }
+        if (lok) { gwt[(l * 2) * 16 + r] = wa; if (lay) gwt[(l * 2 + 1) * 16 + r] = wf * wd; }
+        if (cw == NCONS - 1) {
+            unsigned ok = 0;
+            if (xchg) {
+                float v[1];
+                const bool got = sweep<1>(p.XC, NCU * 8u, tag_base, [&](int) { return 8 * (lane0 & 31) + g; }, [&]() { return 0; }, false, v, c, p.err);
+                ok = got && __all(__float_as_uint(v[0]) == my) ? 1u : 0u;
+                if (!ok && lane0 == 0) __hip_atomic_store(p.err + 1, 9u | ((unsigned)b << 8) | (my << 16), RLX, AG);
+            }
+            lds_st(&c->xcd_ok, ok);
+        }
+        ENG_CFENCE();
+        if (lane0 == 0) __hip_atomic_fetch_add(&c->gw_flag, 1u, RLX, WG);
+    }
+    wait_ge(&c->gw_flag, (unsigned)NCONS, c, p.err, ERR_STAGE);
+#pragma unroll 1
+    for (int l = 0; l < p.n_layers; l++) {
+        ph_qkv(cw, lane0, l);
+        ph_attn(cw, lane0, l);
+        ph_wo(cw, lane0, l);
+        ph_w13(cw, lane0, l);
+        ph_w2(cw, lane0, l);
+    }
+}
+
+__global__ __launch_bounds__(NTHR, 1) void decode_engine_b16_kernel(const EngBParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    BCtl* c = reinterpret_cast<BCtl*>(lds + BL_CTL);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < (int)(sizeof(BCtl) / 4)) reinterpret_cast<unsigned*>(c)[tid] = 0u;
+    for (int i = tid; i < p.n_layers * (int)(sizeof(EngLayerTab) / 8); i += NTHR) reinterpret_cast<u64*>(lds + BL_TAB)[i] = reinterpret_cast<const u64*>(p.layers)[i];
+    if (tid == 0) c->xcc_id = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));      // HW_REG_XCC_ID
+    __syncthreads();
+    Tl tl; tl.on = p.tl != nullptr && lane == 0; tl.buf = p.tl ? p.tl + (size_t)blockIdx.x * 32 : nullptr;
+#ifndef B16_ROLES
+#define B16_ROLES 7
+#endif
+    if (wave == 0) { tl(19); if (B16_ROLES & 1) b16_loader(p, c, (unsigned)(uintptr_t)(lds + BL_RING), lane, tl); }
+    else if (wave == 1) {
+        if (B16_ROLES & 2) b16_comm(p, c, lds, lane, tl);
+        if (blockIdx.x == 0 && lane == 0) { const unsigned sv = *p.serial; asm volatile("" ::: "memory"); *p.serial = sv + 1u; }
+    } else if (B16_ROLES & 4) b16_consumer(p, c, lds, wave - 2, lane, tl);
+}
+
+}  // namespace
+
+// state block: XH0 | XH1 | SS0 | SS1 | G | XO | PW | XA | P2 | F0 F1 FO FW FA F2 | XC | serial | err
+static constexpr size_t BS_XH0 = 0, BS_XH1 = BS_XH0 + XH_BYTES, BS_SS0 = BS_XH1 + XH_BYTES, BS_SS1 = BS_SS0 + (size_t)NCU * BM * 4, BS_G = BS_SS1 + (size_t)NCU * BM * 4,
+                        BS_XO = BS_G + (size_t)BM * G_ROW * 8, BS_PW = BS_XO + (size_t)ENH * XO_HEAD, BS_XA = BS_PW + (size_t)NPW * ED * BM * 4, BS_P2 = BS_XA + (size_t)ENKV * XA_GROUP,
+                        BS_F = BS_P2 + (size_t)NP2 * ED * BM * 4, BS_XC = BS_F + 6 * 1024, BS_SERIAL = BS_XC + (size_t)NCU * 8, BS_ERR = BS_SERIAL + 256, BS_TOTAL = BS_ERR + 256;
+size_t engb_state_bytes() { return BS_TOTAL; }
+void engb_state_carve(unsigned char* st, EngBParams* p) {
+    p->XH0 = st + BS_XH0; p->XH1 = st + BS_XH1; p->SS0 = reinterpret_cast<float*>(st + BS_SS0); p->SS1 = reinterpret_cast<float*>(st + BS_SS1);
+    p->G = reinterpret_cast<unsigned long long*>(st + BS_G); p->XO = st + BS_XO; p->PW = reinterpret_cast<float*>(st + BS_PW); p->XA = st + BS_XA; p->P2 = reinterpret_cast<float*>(st + BS_P2);
+    unsigned* f = reinterpret_cast<unsigned*>(st + BS_F);
+    p->F0 = f; p->F1 = f + 256; p->FO = f + 512; p->FW = f + 768; p->FA = f + 1024; p->F2 = f + 1280;
+    p->XC = reinterpret_cast<unsigned long long*>(st + BS_XC); p->serial = reinterpret_cast<unsigned*>(st + BS_SERIAL); p->err = reinterpret_cast<unsigned*>(st + BS_ERR);
+}
+int engb_lds_bytes() { return BL_TOTAL; }
+
+hipError_t launch_decode_engine_b16(const EngBParams& p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (p.n_rows < 1 || p.n_rows > BM || p.n_layers < 0 || p.n_layers > MAX_LAYERS) return hipErrorInvalidValue;
+    decode_engine_b16_kernel<<<dim3(NCU), dim3(NTHR), BL_TOTAL, s>>>(p);
+    return hipGetLastError();
+}
+// resident workgroups per CU the runtime grants this kernel (the engine needs its 256 workgroups co-resident: >= 1 on a 256-CU device)
+hipError_t engb_occupancy(int* blocks_per_cu) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(decode_engine_b16_kernel), NTHR, BL_TOTAL);
+}
+
+}  // namespace vox

@@ -219,6 +219,37 @@ void eng_state_carve(unsigned char* state, EngParams* p);      // point p's gran
 hipError_t launch_decode_engine(const EngParams& p, hipStream_t s);
 int eng_lds_bytes();
 
+// ---- persistent decode-layer engine for a group of <= 16 sequences (vox_engine_b16.hip): the 26 decoder layers of one batched decode step as ONE launch of 256 workgroups
+// (one per CU) x 14 waves on the single-stream engine's packet stream.  Replaces the 26 x 5 launches of the batched step (gguf/model.rs:938-960 for B > 1); the step's tail
+// (16-row lm_head GEMM, argmax / next embedding) stays launch-based and reads xf_out / ssq_out.
+struct EngBParams {
+    const unsigned char* stream;                      // the packet stream built by launch_eng_pack (layer part)
+    const EngLayerTab* layers; int n_layers;          // device array; kc / vc: the GROUP's first sequence, [sequence][n_kv][max_seq][hd]
+    long kv_seq_stride;                               // floats between two sequences' cache slices
+    const float* h_in; int h_stride; int n_rows;      // [n_rows][D] the step's input rows (sequences n_rows..15 of the tile are zeros)
+    const float* final_norm;                          // [D]
+    const int* pos;                                   // [n_rows] position of every sequence
+    const float* rope_cos; const float* rope_sin;     // [max_pos][hd/2]
+    int max_seq, window; float eps;
+    unsigned char *XH0, *XH1;                         // all-gathered streams as MFMA A fragments: [96 blocks][hi, lo][64 lanes] x 16 B
+    float *SS0, *SS1;                                 // [256 CUs][16] partial sums of squares
+    unsigned long long* G;                            // [16][6144] q|k|v granules {value, tag}
+    unsigned char* XO;                                // [32 heads][4 blocks][hi, lo][64] x 16 B attention outputs
+    float* PW;                                        // [32 planes][3072][16] wo partial products
+    unsigned char* XA;                                // [8 groups][36 blocks][hi, lo][64] x 16 B SwiGLU outputs
+    float* P2;                                        // [8 planes][3072][16] w2 partial products
+    unsigned *F0, *F1, *FO, *FW, *FA, *F2;            // [256] flag words per edge
+    unsigned long long* XC; unsigned* serial; unsigned* err;
+    uint16_t* xf_out; float* ssq_out;                 // the layer stack's output: XF planes of h * final_norm (xf_store4 layout) + [256][16] partial sums of squares
+    unsigned long long* tl; int tl_layer;             // timeline stamps [256][32] of layer tl_layer (null: off)
+    int flags;                                        // 1: thin loader while the CU polls; 32: no LDS-DMA (diagnostic, wrong results); 128: plain stores on XCD-local edges (placement verified per launch); 1024 / 2048: loader depth 2 / 1; 16384: fault injection
+};
+size_t engb_state_bytes();
+void engb_state_carve(unsigned char* state, EngBParams* p);      // point p's edge buffers / flags / serial / err into a zero-initialised state block
+hipError_t launch_decode_engine_b16(const EngBParams& p, hipStream_t s);
+hipError_t engb_occupancy(int* blocks_per_cu);
+int engb_lds_bytes();
+
 // ---- measurement knobs: VOX_* environment snapshot (taken at vox_ctx_create / vox_debug_reload_knobs); launch paths never call getenv
 void knobs_reload();
 const char* knob_str(const char* name);      // nullptr when unset
