@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("VOX_LIB") or os.path.join(PKG_DIR, "libvoxtral_hip.so")   # VOX_LIB: measurement builds (ablations)
-SOURCES = ["vox_kernels.hip", "vox_engine.hip", "vox_api.cpp"]
+SOURCES = ["vox_kernels.hip", "vox_engine.hip", "vox_engine_b16.hip", "vox_api.cpp"]
 HEADERS = ["vox_kernels.h", "vox_engine_common.h", os.path.join("..", "..", "include", "voxtral_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]

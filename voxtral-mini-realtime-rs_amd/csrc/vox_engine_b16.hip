@@ -369,11 +369,17 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
 // ------------------------------------------------------------------------------------------------
 // CONSUMER waves
 // ------------------------------------------------------------------------------------------------
-// Every phase of a layer is a SEPARATELY COMPILED (noinline) function.  Inlined into one loop body the phases fit individually (q|k|v and w1|w3: 128 VGPRs with the wave's 64
-// registers of A fragments; attention: 114) but the combination spilled 180 VGPRs into the hot loops -- hipcc carries loop-invariant state of every phase across all the
-// others.  A call boundary ends every live range: the only state a phase receives is (consumer wave, lane, layer); packet and barrier counters are functions of the layer,
-// the launch parameters are read from the kernarg segment with scalar loads, LDS is addressed from its base.
+// Every phase of a layer is its own function of (consumer wave, lane, layer) and NOTHING else: packet and barrier counters are functions of the layer, the launch
+// parameters are re-read from the kernarg segment with scalar loads, LDS is addressed from its base, and the lane index is made opaque at every phase entry.  Written as
+// one loop body with shared state, hipcc hoisted every phase's loop-invariant, lane-derived values out of the layer loop and carried them across all the other phases:
+// 180 VGPRs spilled into the hot loops (each phase alone fits: q|k|v and w1|w3 128 VGPRs with the wave's 64 registers of A fragments, attention 114).  Calling the
+// phases (noinline) also ends every live range but costs 48 callee-saved VGPRs stored and reloaded per call -- 1.4 MB of scratch traffic per CU and layer; -DB16_NOINLINE
+// keeps that form for comparison.
+#ifndef B16_NOINLINE
+#define B16_PHASE __device__ __forceinline__
+#else
 #define B16_PHASE __device__ __attribute__((noinline))
+#endif
 constexpr int CB_LAYER = 4;      // workgroup barriers among the consumer waves per layer
 __device__ __forceinline__ EngBParams kparams() {      // by value from the constant address space: the fields a phase uses become scalar loads
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -423,6 +429,7 @@ struct BCons {
     __device__ __forceinline__ f32x4 cb_read(int i) const { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds + BL_CB) + (cw * 8 + i) * BM + 4 * (lane >> 4)); }
 };
 #define B16_PROLOGUE                                                                                                          \
+    asm volatile("" : "+v"(lane));      /* opaque per phase: lane-derived addresses are recomputed, never hoisted out of the layer loop and carried (spilled) across phases */ \
     const EngBParams p = kparams(); unsigned char* lds = lds_base();                                                          \
     const int cw = __builtin_amdgcn_readfirstlane(cw_), l = __builtin_amdgcn_readfirstlane(l_);                               \
     BCtl* c = reinterpret_cast<BCtl*>(lds + BL_CTL); BCons cs(p, lds, cw, lane);                                             \
