@@ -356,9 +356,11 @@ def main():
             ptrs = [ctx.upload(c) for c in clips]; lens = [c.size for c in clips]
             model.transcribe_batch(None, t_embed, device_ptrs=ptrs, n_samples=lens)                       # warm-up
             reps = 3; ctx.synchronize(); tb = time.perf_counter()
+            eng_on, eng_n0 = model.set_batch_engine()
             for _ in range(reps):
                 outs = model.transcribe_batch(None, t_embed, device_ptrs=ptrs, n_samples=lens)
             ctx.synchronize(); bdt = (time.perf_counter() - tb) / reps
+            eng_on, eng_n1 = model.set_batch_engine()
             tmb = model.timings(); ntok = sum(len(o) for o in outs)
             step_ms = tmb["decode_ms"] / max(ntok // args.batch, 1)
             out["batch"] = {"workload": f"{args.batch} x {args.seconds:g} s clips, Q4_0 (BASELINE configs[3])", "batch": args.batch,
@@ -366,7 +368,8 @@ def main():
                             "stage_ms": {k: round(tmb[k], 2) for k in ("preprocess_ms", "encode_ms", "decode_ms")},
                             "decode_step_ms": round(step_ms, 4),
                             "decode_step_weight_GBps": round(per_step_bytes / 1e9 / (step_ms / 1e3), 1),
-                            "decode_step_frac_of_hbm_peak": round(per_step_bytes / 1e9 / (step_ms / 1e3) / HBM_PEAK_GBS, 4)}
+                            "decode_step_frac_of_hbm_peak": round(per_step_bytes / 1e9 / (step_ms / 1e3) / HBM_PEAK_GBS, 4),
+                            "decode_layer_engine": bool(eng_on), "engine_launches_per_batch": (eng_n1 - eng_n0) // reps}
             for pp in ptrs:
                 ctx.free(pp)
         if world == 1 and not args.no_f32:

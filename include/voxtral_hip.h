@@ -193,6 +193,11 @@ int32_t vox_model_set_t_embed(vox_model* m, const float* t_embed_host);
  * which other geometries / dense checkpoints always use.  *active_or_null reports whether the engine will be used.  Results of both paths agree to
  * summation-order noise (same ids; tests/test_gpu_fullsize.py).  Environment VOX_ENGINE=0 sets the default to off at load time. */
 int32_t vox_model_set_decode_engine(vox_model* m, int32_t on, int32_t* active_or_null);
+/* Batched decode loop of vox_transcribe_batch (BASELINE configs[3]; the reference's model.rs:938-960 is batch-1): by default the 26 decoder layers of every 16-row
+ * group run as ONE launch of the batched decode-layer engine per step (same eligibility as above); on = 0 selects the launch-based step (5 launches per layer and
+ * group), on < 0 only queries.  *active_or_null: will the engine be used; *launches_or_null: engine launches enqueued so far (eager + graph replays).  A hand-off
+ * timeout inside the engine re-runs the batch on the launch-based step and switches the engine off for the model.  Environment VOX_BATCH_ENGINE=0: off at load time. */
+int32_t vox_model_set_batch_engine(vox_model* m, int32_t on, int32_t* active_or_null, uint64_t* launches_or_null);
 
 /* Q4VoxtralModel::encode_audio, gguf/model.rs:783-788: mel [128][T] -> [S][dec_dim]; *S = floor(S_enc/4) */
 int32_t vox_encode_audio(vox_model* m, const float* mel_128xT, int32_t T, float* out, int32_t cap_rows,

@@ -685,6 +685,10 @@ struct vox_model {
     const vox_cache* eng_tab_cache = nullptr; const float* eng_tab_k = nullptr; std::vector<EngLayerTab> eng_tab_host;      // (cache object, its K base) the device layer table was built for
     int eng_flags = 128 | 512 | 1, eng_pace = 50;      // XCD-local edges; probe-less all-gather, swept 0.5 us after the CU's own rows went out; one LDS-DMA packet in flight while the CU polls memory
     unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
+    // batched decode-layer engine (vox_engine_b16.hip): one launch per 16-row group and step on the same packet stream; per-group edge buffers + layer tables
+    bool engb_ok = false; unsigned char* engb_state[4] = {nullptr, nullptr, nullptr, nullptr}; EngLayerTab* engb_tab[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool engb_on = true; unsigned long long engb_launches = 0;
+    int engb_flags = 128 | 1; unsigned engb_err_host[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0, graph_mode = 0;
     const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
@@ -1071,7 +1075,8 @@ static void model_release(vox_model* m) {
     graphs_destroy(m);
     if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_state, (void*)m->eng_tab})
+                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_state, (void*)m->eng_tab, (void*)m->engb_state[0], (void*)m->engb_state[1], (void*)m->engb_state[2], (void*)m->engb_state[3],
+                    (void*)m->engb_tab[0], (void*)m->engb_tab[1], (void*)m->engb_tab[2], (void*)m->engb_tab[3]})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -1113,6 +1118,12 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
         for (int i = 0; ok && i < c.dec_layers; i++) { const DecLayer& L = m->dec[i]; for (const Lin* w : {&L.wqkv, &L.wo, &L.w13, &L.w2}) if (w->w.fmt != WFMT_Q4_0 || !w->w.qs || !w->w.sc || w->bias) ok = false; }
         if (ok && (m->tok.w.fmt != WFMT_Q4_0 || !m->tok.w.qs)) ok = false;
         m->eng_ok = ok; m->eng_on = ok;
+        {   // the batched engine needs its 256 workgroups co-resident: ask the runtime (a CU mask or a debugger can take CUs away without changing multiProcessorCount)
+            const char* bv = knob_str("VOX_BATCH_ENGINE"); int occ = 0;
+            m->engb_ok = ok && !(bv && bv[0] == '0') && engb_occupancy(&occ) == hipSuccess && occ >= 1;
+            (void)hipGetLastError();
+            if (const char* f = knob_str("VOX_BATCH_ENGINE_FLAGS")) m->engb_flags = atoi(f);
+        }
         if (const char* f = knob_str("VOX_ENGINE_FLAGS")) m->eng_flags = atoi(f);      // measurement knobs of tools/micro/engine_bench (loader depth / probe / XCD-local edges)
         if (const char* f = knob_str("VOX_ENGINE_PACE")) m->eng_pace = atoi(f);
     }
@@ -1586,21 +1597,40 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
 }
 
 // decode engine: per-CU weight stream (a second copy of the decoder's Q4 bytes in consumption order, built on the GPU from the row planes), granule state, layer table
+// the engines' weight stream (shared by the single-stream and the batched engine), packed on the GPU from the row planes at first use.  An allocation failure is not an
+// error of the call: the engines are switched off and the launch-based paths serve it.
+static int32_t engine_stream_prepare(vox_model* m) {
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    if (m->eng_ready || !m->eng_ok) return VOX_OK;
+    const size_t sb = eng_stream_bytes(c.dec_layers, c.vocab);
+    if (!m->eng_stream) {
+        hipError_t e = hipMalloc((void**)&m->eng_stream, sb);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->eng_state, eng_state_bytes());
+        if (e == hipSuccess) e = hipMalloc((void**)&m->eng_tab, sizeof(EngLayerTab) * 32);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (m->eng_stream) (void)hipFree(m->eng_stream); if (m->eng_state) (void)hipFree(m->eng_state); if (m->eng_tab) (void)hipFree(m->eng_tab);
+            m->eng_stream = nullptr; m->eng_state = nullptr; m->eng_tab = nullptr; m->eng_ok = false; m->eng_on = false; m->engb_ok = false;
+            fprintf(stderr, "[voxtral_hip] decode engine: allocating the %.2f GB weight stream failed (%s); the launch-based decode paths are used\n", sb / 1e9, hipGetErrorString(e));
+            return VOX_OK;
+        }
+    }
+    HIPCHK(hipMemsetAsync(m->eng_stream, 0, sb, s)); HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), s));
+    for (int l = 0; l < c.dec_layers; l++) {
+        const DecLayer& L = m->dec[l];
+        HIPCHK(launch_eng_pack(L.wqkv.w, 0, l, c.dec_layers, m->eng_stream, c.vocab, s)); HIPCHK(launch_eng_pack(L.wo.w, 1, l, c.dec_layers, m->eng_stream, c.vocab, s));
+        HIPCHK(launch_eng_pack(L.w13.w, 2, l, c.dec_layers, m->eng_stream, c.vocab, s)); HIPCHK(launch_eng_pack(L.w2.w, 3, l, c.dec_layers, m->eng_stream, c.vocab, s));
+    }
+    HIPCHK(launch_eng_pack(m->tok.w, 4, 0, c.dec_layers, m->eng_stream, c.vocab, s));
+    m->eng_ready = true; m->eng_tab_cache = nullptr;
+    return VOX_OK;
+}
+// decode engine: per-CU weight stream (a second copy of the decoder's Q4 bytes in consumption order, built on the GPU from the row planes), granule state, layer table
 static int32_t engine_prepare(vox_model* m) {
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
     if (!m->eng_ok || !m->eng_on || !m->cache || m->cache->max_seq > 1024) return VOX_OK;      // long caches keep the per-operator path (attention scores live in LDS)
-    if (!m->eng_ready) {
-        const size_t sb = eng_stream_bytes(c.dec_layers, c.vocab);
-        if (!m->eng_stream) { HIPCHK(hipMalloc((void**)&m->eng_stream, sb)); HIPCHK(hipMalloc((void**)&m->eng_state, eng_state_bytes())); HIPCHK(hipMalloc((void**)&m->eng_tab, sizeof(EngLayerTab) * 32)); }
-        HIPCHK(hipMemsetAsync(m->eng_stream, 0, sb, s)); HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), s));
-        for (int l = 0; l < c.dec_layers; l++) {
-            const DecLayer& L = m->dec[l];
-            HIPCHK(launch_eng_pack(L.wqkv.w, 0, l, c.dec_layers, m->eng_stream, c.vocab, s)); HIPCHK(launch_eng_pack(L.wo.w, 1, l, c.dec_layers, m->eng_stream, c.vocab, s));
-            HIPCHK(launch_eng_pack(L.w13.w, 2, l, c.dec_layers, m->eng_stream, c.vocab, s)); HIPCHK(launch_eng_pack(L.w2.w, 3, l, c.dec_layers, m->eng_stream, c.vocab, s));
-        }
-        HIPCHK(launch_eng_pack(m->tok.w, 4, 0, c.dec_layers, m->eng_stream, c.vocab, s));
-        m->eng_ready = true; m->eng_tab_cache = nullptr;
-    }
+    VOXCHK(engine_stream_prepare(m));
+    if (!m->eng_ready) return VOX_OK;
     if (m->eng_tab_cache != m->cache || m->eng_tab_k != m->cache->k) {      // (a re-allocated cache object can land on the old heap address: compare the device pointer too)
         const size_t lf = cache_layer_floats(m, m->cache);
         m->eng_tab_host.resize(c.dec_layers);
@@ -1610,6 +1640,19 @@ static int32_t engine_prepare(vox_model* m) {
         m->eng_tab_cache = m->cache; m->eng_tab_k = m->cache->k;
     }
     return VOX_OK;
+}
+// batched engine: the stream + one edge-buffer block and layer table per 16-row group
+static bool engb_prepare(vox_model* m, int n_grp) {
+    if (!m->engb_ok || !m->engb_on || n_grp > 4) return false;
+    if (engine_stream_prepare(m) != VOX_OK || !m->eng_ready) return false;
+    for (int gi = 0; gi < n_grp; gi++) {
+        if (m->engb_state[gi]) continue;
+        hipError_t e = hipMalloc((void**)&m->engb_state[gi], engb_state_bytes());
+        if (e == hipSuccess) e = hipMalloc((void**)&m->engb_tab[gi], sizeof(EngLayerTab) * 32);
+        if (e == hipSuccess) e = hipMemsetAsync(m->engb_state[gi], 0, engb_state_bytes(), m->ctx->stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); if (m->engb_state[gi]) { (void)hipFree(m->engb_state[gi]); m->engb_state[gi] = nullptr; } return false; }
+    }
+    return true;
 }
 static bool engine_active(const vox_model* m) { return m->eng_on && m->eng_ready && m->cache && m->eng_tab_cache == m->cache && m->eng_tab_k == m->cache->k && m->cache->max_seq <= 1024; }
 static EngParams engine_params(vox_model* m, float* logits_out, bool argmax_in = false) {
@@ -1629,6 +1672,14 @@ extern "C" int32_t vox_model_set_decode_engine(vox_model* m, int32_t on, int32_t
     const bool want = on != 0 && m->eng_ok;
     if (want != m->eng_on) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); graphs_destroy(m); m->eng_on = want; }      // the captured decode graph holds the other path's launches
     if (active) *active = m->eng_on ? 1 : 0;
+    return VOX_OK;
+}
+
+extern "C" int32_t vox_model_set_batch_engine(vox_model* m, int32_t on, int32_t* active, uint64_t* launches) {
+    ARGCHK(m, "null argument");
+    if (on >= 0) m->engb_on = on != 0;
+    if (active) *active = m->engb_ok && m->engb_on ? 1 : 0;
+    if (launches) *launches = m->engb_launches;
     return VOX_OK;
 }
 
@@ -1837,7 +1888,7 @@ extern "C" int32_t vox_transcribe_audio(vox_model* m, const float* samples, size
 // advances all sequences (rows of one skinny MFMA GEMM per linear, so the Q4 weights are streamed once per step for the
 // whole batch), per-sequence positions / KV-cache slices / audio rows live on the device, the step is hipGraph-replayed.
 static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
-                                     int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of) {      // slot_of[i]: the caller's slot of row i (error messages)
+                                     int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of, bool allow_engine = true) {      // slot_of[i]: the caller's slot of row i (error messages)
     VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
@@ -1938,6 +1989,22 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     // GEMM); RoPE + KV-cache write are the q|k|v GEMM's epilogue.
     const int parts_D = q4_skinny_resid_xf_parts(D);
     if (use_xf) { HIPCHK(b_ssq.alloc_pooled(cx, (size_t)parts_D * 16 * 4 * n_grp)); HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4 * n_grp, s)); }
+    // Batched decode-layer ENGINE (vox_engine_b16.hip): the 26 layers of a 16-row group as ONE persistent launch on the single-stream engine's packet stream; the group's
+    // 5 x 26 launches remain as the fallback (other geometries, dense checkpoints, VOX_BATCH_ENGINE=0, a hand-off timeout).  The launch owns all 256 CUs, so the groups of
+    // a step run back to back on the main stream instead of on forked streams.
+    const bool use_eng = allow_engine && use_xf && steps > 0 && engb_prepare(m, n_grp);
+    DevBuf b_ssq_e;
+    std::vector<EngLayerTab> eng_tabs;
+    if (use_eng) {
+        HIPCHK(b_ssq_e.alloc_pooled(cx, (size_t)(256 + 16) * 16 * 4 * n_grp));
+        eng_tabs.resize((size_t)n_grp * c.dec_layers);
+        for (int gi = 0; gi < n_grp; gi++) {
+            for (int l = 0; l < c.dec_layers; l++)
+                eng_tabs[(size_t)gi * c.dec_layers + l] = EngLayerTab{m->dec[l].attn_norm, m->dec[l].ffn_norm, m->dec[l].ada_mul, b_k.as<float>() + (size_t)l * layer_stride + (size_t)gi * 16 * seq_stride,
+                                                                      b_v.as<float>() + (size_t)l * layer_stride + (size_t)gi * 16 * seq_stride};
+            HIPCHK(hipMemcpyAsync(m->engb_tab[gi], eng_tabs.data() + (size_t)gi * c.dec_layers, sizeof(EngLayerTab) * c.dec_layers, hipMemcpyHostToDevice, s));
+        }
+    }
     if (tail_logits_ready)      // first generated token of every utterance + the first step's input (and, XF step, its folded first RMSNorm)
         HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, b_h.as<float>(), s,
                                          use_xf ? b_xf1.as<uint16_t>() : nullptr, use_xf ? m->dec[0].attn_norm : nullptr, use_xf ? b_ssq.as<float>() : nullptr,
@@ -1949,12 +2016,25 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     // for all rows): letting every group replay its own chain of steps on its own stream -- no join, groups drifting freely -- was measured 12 % SLOWER on the
     // 647-clip corpus (8 520 -> 7 630 tok/s, profiles/r03_batch_independent_groups.txt): groups in lock-step find each other's weights in L2 / MALL, drifting
     // groups stream them from HBM once each.
+    int eng_per_step = 0;      // engine launches enqueued by the last call of `step` (graph replays repeat them)
     auto group_chain = [&](int gi, hipStream_t sg) -> int32_t {
         float* h = b_h.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>();
         const int r0 = gi * 16, ng = std::min(16, n - r0);
         uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)gi * (xf_bytes(QD) / 2);
         uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)gi * (xf_bytes(F) / 2); float* ssq = b_ssq.as<float>() + (size_t)gi * parts_D * 16;
         float* hg = h + (size_t)r0 * D; float* qg = qkv + (size_t)r0 * W; const int* pg = d_pos + r0;
+        if (use_eng) {
+            float* ssq_e = b_ssq_e.as<float>() + (size_t)gi * (256 + 16) * 16; float* ssq_f = ssq_e + 256 * 16;
+            EngBParams ep{}; ep.stream = m->eng_stream; ep.layers = m->engb_tab[gi]; ep.n_layers = c.dec_layers; ep.kv_seq_stride = (long)seq_stride; ep.h_in = hg; ep.h_stride = D; ep.n_rows = ng;
+            ep.final_norm = m->dec_norm; ep.pos = pg; ep.rope_cos = m->dec_cos; ep.rope_sin = m->dec_sin; ep.max_seq = max_seq; ep.window = c.dec_window; ep.eps = c.norm_eps;
+            engb_state_carve(m->engb_state[gi], &ep); ep.xf_out = xf1; ep.ssq_out = ssq_e; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = m->engb_flags;
+            HIPCHK(launch_decode_engine_b16(ep, sg));
+            eng_per_step++;
+            HIPCHK(launch_engb_ssq_fold(ssq_e, ssq_f, sg));
+            GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)xf1; g.M = ng; g.out = b_logits.as<float>() + (size_t)r0 * V; g.out_stride = V;
+            g.ssq_part = ssq_f; g.n_part = 16; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, sg));
+            return VOX_OK;
+        }
         for (int l = 0; l < c.dec_layers; l++) {
             const DecLayer& L = m->dec[l];
             float* kl = b_k.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride + (size_t)r0 * seq_stride;
@@ -1986,12 +2066,13 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
         return VOX_OK;
     };
     auto step = [&](uint32_t active) -> int32_t {
+        eng_per_step = 0;
         float* h = b_h.as<float>(); float* xn = b_xn.as<float>(); float* qkv = b_qkv.as<float>(); float* att = b_att.as<float>(); float* act = b_act.as<float>();
         if (use_xf) {
             // groups are independent sequences: every active group but the first runs its whole layer chain on a side stream (fork / join with events, which
             // a stream capture records as parallel graph branches), so the latency-bound skinny kernels of different groups overlap
             int n_act = 0; for (int gi = 0; gi < n_grp; gi++) n_act += (active >> gi) & 1u;
-            const bool fork = n_act > 1 && !knob_str("VOX_BATCH_SERIAL_GROUPS");
+            const bool fork = n_act > 1 && !use_eng && !knob_str("VOX_BATCH_SERIAL_GROUPS");
             if (fork) {
                 VOXCHK(ensure_aux(n_act - 1));
                 HIPCHK(hipEventRecord(cx->ev_fork, s));
@@ -2005,8 +2086,9 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
                 VOXCHK(group_chain(gi, sg));
                 if (fork && ka > 0) { HIPCHK(hipEventRecord(cx->ev_join[ka - 1], sg)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[ka - 1], 0)); }
             }
-            HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s,
-                                             b_xf1.as<uint16_t>(), m->dec[0].attn_norm, b_ssq.as<float>(), (long)(xf_bytes(D) / 2), parts_D * 16));
+            if (use_eng) HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s));      // the engine reads the f32 rows
+            else HIPCHK(launch_argmax_embed_batch(b_logits.as<float>(), n, V, d_tok, tstride, d_pos, b_len.as<int>(), m->tok.w, d_audio, (long)audio_rows * D, D, h, s,
+                                                  b_xf1.as<uint16_t>(), m->dec[0].attn_norm, b_ssq.as<float>(), (long)(xf_bytes(D) / 2), parts_D * 16));
             return VOX_OK;
         }
         for (int l = 0; l < c.dec_layers; l++) {
@@ -2042,7 +2124,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     const bool no_graph = knob_str("VOX_BATCH_NO_GRAPH") != nullptr;      // measurement knob (profilers)
     for (int t = 0; t < steps; t++) {
         const uint32_t act = active_at(t);
-        if (t == 0 || no_graph) { VOXCHK(step(act)); continue; }         // eager first step
+        if (t == 0 || no_graph) { VOXCHK(step(act)); m->engb_launches += (unsigned)eng_per_step; continue; }         // eager first step
         hipGraphExec_t ge = graphs.find(act);
         if (!ge) {
             HIPCHK(hipStreamSynchronize(s));
@@ -2059,10 +2141,21 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
         }
         if (hipGraphLaunch(ge, s) != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphLaunch failed");
         replays++;
+        if (use_eng) { int na = 0; for (int gi = 0; gi < n_grp; gi++) na += (act >> gi) & 1u; m->engb_launches += (unsigned)na; }
     }
     std::vector<int32_t> host_tok((size_t)n * tstride);
     HIPCHK(hipMemcpyAsync(host_tok.data(), d_tok, host_tok.size() * 4, hipMemcpyDeviceToHost, s));
+    if (use_eng) for (int gi = 0; gi < n_grp; gi++) { EngBParams ep{}; engb_state_carve(m->engb_state[gi], &ep); HIPCHK(hipMemcpyAsync(m->engb_err_host[gi], ep.err, 8, hipMemcpyDeviceToHost, s)); }
     HIPCHK(hipStreamSynchronize(s));
+    if (use_eng) for (int gi = 0; gi < n_grp; gi++) if (m->engb_err_host[gi][0]) {
+        // a bounded hand-off wait expired inside the engine (the launch needs all 256 CUs to itself): the ids of this call are not trustworthy.  Say so, switch the batched
+        // engine off for this model and serve the call again on the launch-based step.
+        const unsigned e = m->engb_err_host[gi][0];
+        fprintf(stderr, "[voxtral_hip] batched decode engine: hand-off timeout (code %u, workgroup %u, group %d); re-running the batch on the launch-based step\n", e & 0xff, (e >> 8) & 0xff, gi);
+        for (int gj = 0; gj < 4; gj++) if (m->engb_state[gj]) (void)hipMemsetAsync(m->engb_state[gj], 0, engb_state_bytes(), s);
+        m->engb_ok = false;
+        return transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, false);
+    }
     int total = 0;
     for (int i = 0; i < n; i++) {
         const int cnt = S[i] >= PREFIX_LEN ? std::max(S[i] - PREFIX_LEN, 1) : 0;

@@ -56,7 +56,7 @@ struct BCtl {
     unsigned cbar, dead, gathering, gw_flag;
     unsigned xcd_ok, xcc_id, ag_flag, pub_cnt;
     unsigned qkv_flag, wo_flag, xa_flag, rs_flag;      // rs_flag: all-gather stages whose RMSNorm scales are in LDS
-    unsigned tbar[2], pad1[2];
+    unsigned tbar[2], red_cnt, pad1;      // red_cnt: helper waves through with their share of the wo plane sum (4 per layer)
 };
 // ---- LDS map ----
 constexpr int BL_RING = 0;
@@ -131,7 +131,6 @@ __device__ __forceinline__ f32x4 step16(const unsigned char* rec, bool half, int
     d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, as_bf16x8(b1), d1, 0, 0, 0);
     acc = __builtin_elementwise_fma((f32x4){s0, s0, s0, s0}, d0, acc);
     acc = __builtin_elementwise_fma((f32x4){s1, s1, s1, s1}, d1, acc);
-    __builtin_amdgcn_sched_barrier(0);      // one record at a time: hoisting the next records' LDS reads (operands, correction rows) costs registers the wave does not have
     return acc;
 }
 // -136 * sum_k x[m][k] of one block, in the accumulator layout (the same value in every column n)
@@ -315,24 +314,23 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
                 ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u);
             }
             if (T) tl(10);
-            {   // attention outputs of head h: this CU's flag, then the eight slice-CUs'
-                wait_ge(&c->pub_cnt, pc0 + 2 * NCONS, c, p.err, ERR_STAGE);
-                if (lane == 0) st_u32(make_srd(p.FO, NCU * 4u), (unsigned)(h * 8 + s) * 4u, tag, xloc);
+            {   // attention outputs of head h: one flag per sequence, written by the team that computed it
+                wait_ge(&c->pub_cnt, pc0 + 2 * NCONS, c, p.err, ERR_STAGE);      // (own CU through: nothing can be complete much earlier -- no polling while it computes)
                 lds_st(&c->gathering, 1u);
-                poll_flags(p.FO, NCU, 8, [&](int i) { return h * 8 + i; }, tag, lane, c, p.err);
+                poll_flags(p.FO, 512, BM, [&](int i) { return h * BM + i; }, tag, lane, c, p.err);
                 lds_st(&c->gathering, 0u);
                 lds_st(&c->wo_flag, (unsigned)l + 1u);
             }
             if (T) tl(11);
-            {   // wo: this CU's plane is stored (12 waves drained) -> flag; the 32 planes of the CU's 12 columns -> post-attention stream
-                wait_ge(&c->pub_cnt, pc0 + 3 * NCONS, c, p.err, ERR_STAGE);
-                if (lane == 0) st_u32(make_srd(p.FW, NCU * 4u), (unsigned)(h * 8 + s) * 4u, tag, false);
-                if (T) tl(12);
-                lds_st(&c->gathering, 1u);
-                poll_flags(p.FW, NCU, 32, [&](int i) { return i * 8 + (b >> 5); }, tag, lane, c, p.err);
+            {   // wo: consumer waves 0..3 sum eight planes each of the CU's 12 columns (they poll the producing waves' flags themselves); fixed-order sum of the four + residual
+                wait_ge(&c->red_cnt, 4u * ((unsigned)l + 1u), c, p.err, ERR_STAGE);
                 if (T) tl(13);
-                comm_reduce<NPW>(p.PW, NPW * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own0, own1);
-                lds_st(&c->gathering, 0u);
+                const float* red = reinterpret_cast<const float*>(lds + BL_PART);
+                const int n12 = min(lane >> 2, OWN - 1), mq = lane & 3;
+                f32x4 a = *reinterpret_cast<const f32x4*>(own0 + n12 * BM + 4 * mq);
+#pragma unroll
+                for (int w = 0; w < 4; w++) a += *reinterpret_cast<const f32x4*>(red + w * OWN * BM + n12 * BM + 4 * mq);
+                if (lane < 4 * OWN) *reinterpret_cast<f32x4*>(own1 + n12 * BM + 4 * mq) = a;
                 ENG_CFENCE();
                 if (!((p.flags & 16384) && b == 7 && l == 1))      // (flag 16384 = FAULT INJECTION: workgroup 7 loses a publish)
                     comm_publish_rows(p, lane, own1, gwt + (l * 2 + 1) * 16, p.XH1, p.SS1, p.F1, tag);
@@ -348,12 +346,12 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
                 lds_st(&c->xa_flag, (unsigned)l + 1u);
             }
             if (T) tl(22);
-            {   // w2: flag, the 8 planes -> the layer's output; published as the next layer's q|k|v input, or (last layer) as the lm_head launch's input
+            {   // w2: the 8 planes (each finishing wave of a producer flags its own tile) -> the layer's output; published as the next layer's q|k|v input, or (last layer)
+                // as the lm_head launch's input
                 wait_ge(&c->pub_cnt, pc0 + 5 * NCONS, c, p.err, ERR_STAGE);
-                if (lane == 0) st_u32(make_srd(p.F2, NCU * 4u), (unsigned)(g * 32 + j) * 4u, tag, false);
                 if (T) tl(23);
                 lds_st(&c->gathering, 1u);
-                poll_flags(p.F2, NCU, 8, [&](int i) { return i * 32 + (b >> 3); }, tag, lane, c, p.err);
+                { const int c0 = (OWN * b) % 96; poll_flags(p.F2, 1536, 16, [&](int i) { return ((i >> 1) * 32 + (b >> 3)) * 6 + (((i & 1) ? c0 + OWN - 1 : c0) >> 4); }, tag, lane, c, p.err); }
                 if (T) tl(24);
                 comm_reduce<NP2>(p.P2, NP2 * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own1, own0);
                 lds_st(&c->gathering, 0u);
@@ -601,6 +599,7 @@ B16_PHASE void ph_attn(int cw_, int lane, int l_) {
             else { __builtin_amdgcn_raw_buffer_store_b128(hi, od, (int)o0, 0, 16); __builtin_amdgcn_raw_buffer_store_b128(lo, od, (int)o1, 0, 16); }
         }
         drain_vm();
+        if (lane == 0) st_u32(make_srd(p.FO, 512 * 4u), (unsigned)(h * BM + msq) * 4u, tag, xloc);
     }
     cs.published();
     tl(3);
@@ -624,8 +623,26 @@ B16_PHASE void ph_wo(int cw_, int lane, int l_) {
         st_f4(pd, (unsigned)((384 * s + 16 * (2 * cw + i) + n) * BM + 4 * y) * 4u, a);
     }
     drain_vm();
+    if (lane == 0) st_u32(make_srd(p.FW, 3072 * 4u), (unsigned)((h * 8 + s) * NCONS + cw) * 4u, tag, false);
     cs.published();
     tl(5);
+    if (cw < 4) {      // helper: the planes of heads [8 cw, +8) of the CU's 12 columns x 16 sequences, summed in head order -> red[cw] (the COMM wave adds the four + the residual)
+        const int c0 = (OWN * b) % 384;      // the CU's columns inside a producer's 384-row slice: tile(s) c0 / 16 .. (c0 + 11) / 16, written by wave tile / 2
+        poll_flags(p.FW, 3072, 16, [&](int i) { return ((8 * cw + (i >> 1)) * 8 + (b >> 5)) * NCONS + ((((i & 1) ? c0 + OWN - 1 : c0) >> 4) >> 1); }, tag, lane, c, p.err);
+        float* red = reinterpret_cast<float*>(lds + BL_PART) + cw * OWN * BM;
+        const srd_t sd = make_srd(p.PW, NPW * ED * BM * 4u);
+        const int n12 = min(lane >> 2, OWN - 1), mq = lane & 3;
+        const unsigned lo_ = (unsigned)((OWN * b + n12) * BM + 4 * mq) * 4u;
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = ld_frag(sd, (unsigned)(8 * cw + u) * (ED * BM * 4u) + lo_);
+        f32x4 a = __builtin_bit_cast(f32x4, v[0]);
+#pragma unroll
+        for (int u = 1; u < 8; u++) a += __builtin_bit_cast(f32x4, v[u]);
+        if (lane < 4 * OWN) *reinterpret_cast<f32x4*>(red + n12 * BM + 4 * mq) = a;
+        ENG_CFENCE();
+        if (lane == 0) __hip_atomic_fetch_add(&c->red_cnt, 1u, RLX, WG);
+    }
 }
 
 // ================= w1|w3: 72 interleaved gate / up rows x K 3072 -> 36 SwiGLU outputs x 16 sequences =================
@@ -716,6 +733,7 @@ B16_PHASE void ph_w2(int cw_, int lane, int l_) {
         for (int w = 0; w < 6; w++) a += *reinterpret_cast<const f32x4*>(part + (cw * 6 + w) * 1024 + lane * 16);
         st_f4(make_srd(p.P2 + (size_t)g * ED * BM, ED * BM * 4u), (unsigned)((96 * j + 16 * cw + n) * BM + 4 * y) * 4u, a);
         drain_vm();
+        if (lane == 0) st_u32(make_srd(p.F2, 1536 * 4u), (unsigned)((g * 32 + j) * 6 + cw) * 4u, tag, false);
     }
     cs.published();
     tl(15);
@@ -795,18 +813,29 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_b16_kernel(const EngBPa
     } else if (B16_ROLES & 4) b16_consumer(p, c, lds, wave - 2, lane, tl);
 }
 
+// 256 per-CU partial sums of squares -> 16 (fixed order), the count the launch-based lm_head GEMM's prologue takes
+__global__ __launch_bounds__(256) void engb_ssq_fold_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    const int m = threadIdx.x & 15, q = threadIdx.x >> 4;
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; u++) a += in[(16 * q + u) * BM + m];
+    out[q * BM + m] = a;
+}
+
 }  // namespace
+
+hipError_t launch_engb_ssq_fold(const float* in, float* out, hipStream_t s) { engb_ssq_fold_kernel<<<dim3(1), dim3(256), 0, s>>>(in, out); return hipGetLastError(); }
 
 // state block: XH0 | XH1 | SS0 | SS1 | G | XO | PW | XA | P2 | F0 F1 FO FW FA F2 | XC | serial | err
 static constexpr size_t BS_XH0 = 0, BS_XH1 = BS_XH0 + XH_BYTES, BS_SS0 = BS_XH1 + XH_BYTES, BS_SS1 = BS_SS0 + (size_t)NCU * BM * 4, BS_G = BS_SS1 + (size_t)NCU * BM * 4,
                         BS_XO = BS_G + (size_t)BM * G_ROW * 8, BS_PW = BS_XO + (size_t)ENH * XO_HEAD, BS_XA = BS_PW + (size_t)NPW * ED * BM * 4, BS_P2 = BS_XA + (size_t)ENKV * XA_GROUP,
-                        BS_F = BS_P2 + (size_t)NP2 * ED * BM * 4, BS_XC = BS_F + 6 * 1024, BS_SERIAL = BS_XC + (size_t)NCU * 8, BS_ERR = BS_SERIAL + 256, BS_TOTAL = BS_ERR + 256;
+                        BS_F = BS_P2 + (size_t)NP2 * ED * BM * 4, BS_XC = BS_F + (256 + 256 + 512 + 3072 + 256 + 1536) * 4, BS_SERIAL = BS_XC + (size_t)NCU * 8, BS_ERR = BS_SERIAL + 256, BS_TOTAL = BS_ERR + 256;
 size_t engb_state_bytes() { return BS_TOTAL; }
 void engb_state_carve(unsigned char* st, EngBParams* p) {
     p->XH0 = st + BS_XH0; p->XH1 = st + BS_XH1; p->SS0 = reinterpret_cast<float*>(st + BS_SS0); p->SS1 = reinterpret_cast<float*>(st + BS_SS1);
     p->G = reinterpret_cast<unsigned long long*>(st + BS_G); p->XO = st + BS_XO; p->PW = reinterpret_cast<float*>(st + BS_PW); p->XA = st + BS_XA; p->P2 = reinterpret_cast<float*>(st + BS_P2);
     unsigned* f = reinterpret_cast<unsigned*>(st + BS_F);
-    p->F0 = f; p->F1 = f + 256; p->FO = f + 512; p->FW = f + 768; p->FA = f + 1024; p->F2 = f + 1280;
+    p->F0 = f; p->F1 = f + 256; p->FO = f + 512; p->FW = f + 1024; p->FA = f + 4096; p->F2 = f + 4352;      // [256] [256] [32 heads][16 sequences] [256 CUs][12 waves] [256] [256 CUs][6 tiles]
     p->XC = reinterpret_cast<unsigned long long*>(st + BS_XC); p->serial = reinterpret_cast<unsigned*>(st + BS_SERIAL); p->err = reinterpret_cast<unsigned*>(st + BS_ERR);
 }
 int engb_lds_bytes() { return BL_TOTAL; }

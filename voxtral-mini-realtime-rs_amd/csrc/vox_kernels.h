@@ -238,7 +238,7 @@ struct EngBParams {
     float* PW;                                        // [32 planes][3072][16] wo partial products
     unsigned char* XA;                                // [8 groups][36 blocks][hi, lo][64] x 16 B SwiGLU outputs
     float* P2;                                        // [8 planes][3072][16] w2 partial products
-    unsigned *F0, *F1, *FO, *FW, *FA, *F2;            // [256] flag words per edge
+    unsigned *F0, *F1, *FO, *FW, *FA, *F2;            // flag words: F0 / F1 / FA [256 CUs], FO [32 heads][16 sequences], FW [256 CUs][12 waves], F2 [256 CUs][6 tiles]
     unsigned long long* XC; unsigned* serial; unsigned* err;
     uint16_t* xf_out; float* ssq_out;                 // the layer stack's output: XF planes of h * final_norm (xf_store4 layout) + [256][16] partial sums of squares
     unsigned long long* tl; int tl_layer;             // timeline stamps [256][32] of layer tl_layer (null: off)
@@ -248,6 +248,7 @@ size_t engb_state_bytes();
 void engb_state_carve(unsigned char* state, EngBParams* p);      // point p's edge buffers / flags / serial / err into a zero-initialised state block
 hipError_t launch_decode_engine_b16(const EngBParams& p, hipStream_t s);
 hipError_t engb_occupancy(int* blocks_per_cu);
+hipError_t launch_engb_ssq_fold(const float* ssq256, float* ssq16, hipStream_t s);      // [256][16] -> [16][16] partial sums of squares (fixed order)
 int engb_lds_bytes();
 
 // ---- measurement knobs: VOX_* environment snapshot (taken at vox_ctx_create / vox_debug_reload_knobs); launch paths never call getenv

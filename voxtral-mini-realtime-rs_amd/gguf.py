@@ -338,6 +338,11 @@ class Q4VoxtralModel:
         """Persistent decode-step engine (one launch per token) on / off; returns whether it is active (it needs the real decoder geometry on a 256-CU device)."""
         a = C.c_int32(); check(lib().vox_model_set_decode_engine(self.h, 1 if on else 0, C.byref(a))); return bool(a.value)
 
+    def set_batch_engine(self, on=None):
+        """Batched decode-layer engine (one launch per 16-row group and step) on / off (None: query); returns (active, engine launches enqueued so far)."""
+        a = C.c_int32(); n = C.c_uint64()
+        check(lib().vox_model_set_batch_engine(self.h, -1 if on is None else (1 if on else 0), C.byref(a), C.byref(n))); return bool(a.value), int(n.value)
+
     def weight_bytes(self):
         v = C.c_uint64(); check(lib().vox_model_weight_bytes(self.h, C.byref(v))); return v.value
 
