@@ -252,10 +252,10 @@ int main(int argc, char** argv) {
         const char* names[32] = {"cons: A(q|k|v) in registers", "cons: q|k|v published (wave 0)", "cons: q,k,v of the sequences staged", "cons: attention published (wave 0)", "cons: A(wo) in registers", "cons: wo plane stored (wave 0)",
                                  "cons: A(w13) in registers", "cons: SwiGLU published (wave 0)", "comm: h all-gather: poll start", "comm: h all-gather: flags in", "comm: q|k|v granules swept", "comm: attention flags in",
                                  "comm: wo flag written", "comm: wo plane flags in", "comm: h1 published", "cons: w2 plane stored (wave 0)", "load: layer's first packet issued", "load: layer's last packet issued", "load: stream done", "kernel start",
-                                 "comm: h1 all-gather: poll start", "comm: h1 all-gather: flags in", "comm: SwiGLU flags in", "comm: w2 flag written", "comm: w2 plane flags in", "comm: h2 published", "cons: A(w2) in registers", "", "", "", "", ""};
-        const int order[27] = {19, 16, 8, 9, 0, 1, 10, 2, 3, 11, 4, 5, 12, 13, 14, 20, 21, 6, 7, 22, 26, 15, 23, 24, 25, 17, 18};
+                                 "comm: h1 all-gather: poll start", "comm: h1 all-gather: flags in", "comm: SwiGLU flags in", "comm: w2 flag written", "comm: w2 plane flags in", "comm: h2 published", "cons: A(w2) in registers", "cons(w13): GEMM done (wave 0)", "cons(w13): barrier 1 passed", "cons(w13): SwiGLU in LDS (wave 0)", "cons(w13): barrier 2 passed", ""};
+        const int order[31] = {19, 16, 8, 9, 0, 1, 10, 2, 3, 11, 4, 5, 12, 13, 14, 20, 21, 6, 27, 28, 29, 30, 7, 22, 26, 15, 23, 24, 25, 17, 18};
         printf("timeline of layer %d (us since the first workgroup started; min / median / max over the 256 CUs):\n", tl_layer);
-        for (int oi = 0; oi < 27; oi++) {
+        for (int oi = 0; oi < 31; oi++) {
             const int e = order[oi]; std::vector<double> v;
             for (int b = 0; b < 256; b++) if (tb[b * 32 + e]) v.push_back((double)(tb[b * 32 + e] - t0) / 100.0);
             if (v.empty()) continue;

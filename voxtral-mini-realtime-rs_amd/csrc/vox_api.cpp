@@ -688,7 +688,7 @@ struct vox_model {
     // batched decode-layer engine (vox_engine_b16.hip): one launch per 16-row group and step on the same packet stream; per-group edge buffers + layer tables
     bool engb_ok = false; unsigned char* engb_state[4] = {nullptr, nullptr, nullptr, nullptr}; EngLayerTab* engb_tab[4] = {nullptr, nullptr, nullptr, nullptr};
     bool engb_on = true; unsigned long long engb_launches = 0;
-    int engb_flags = 128 | 1; unsigned engb_err_host[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int engb_flags = 128 | 1 | 64 | 2048; unsigned engb_err_host[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0, graph_mode = 0;
     const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;

@@ -100,20 +100,26 @@ __device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" :
 // fragment address of (block, plane, lane group y, sequence m) inside an XH / XA / XO buffer
 __device__ __forceinline__ unsigned frag_off(int blk, int plane, int y, int m) { return (unsigned)(((blk * 2 + plane) * 64 + y * 16 + m) * 16); }
 
-// one step record (16 or 8 weight rows x 64 columns = Q4 blocks 2 T, 2 T + 1) against the step's two activation blocks: acc[m][n] += sum_k x[m][k] * w[n][k]
-__device__ __forceinline__ f32x4 step16(const unsigned char* rec, bool half, int lane, bf16x8 ah0, bf16x8 al0, bf16x8 ah1, bf16x8 al1, f32x4 c0, f32x4 c1, f32x4 acc) {
+// one step record (16 or 8 weight rows x 64 columns = Q4 blocks 2 T, 2 T + 1) as a lane holds it: 8 bytes of nibbles + the two f16 block scales of its row.  Records do not
+// depend on the step's activations: a wave copies them from the ring into REGISTERS while it waits for an edge and frees the ring slots for the loader.
+struct RawRec { uint2 q; unsigned sc; };      // sc: the two f16 scale bit patterns (block 2 T | block 2 T + 1 << 16)
+__device__ __forceinline__ RawRec rec_load(const unsigned char* rec, bool half, int lane) {
     const int n = lane & 15, g = lane >> 4;
-    uint2 q = make_uint2(0u, 0u);
-    float s0 = 0.f, s1 = 0.f;
+    RawRec r; r.q = make_uint2(0u, 0u); r.sc = 0u;
     if (!half) {
-        q = reinterpret_cast<const uint2*>(rec)[lane];
+        r.q = reinterpret_cast<const uint2*>(rec)[lane];
         const unsigned short* scp = reinterpret_cast<const unsigned short*>(rec + REC_SC);
-        s0 = __half2float(__ushort_as_half(scp[n])); s1 = __half2float(__ushort_as_half(scp[16 + n]));
+        r.sc = (unsigned)scp[n] | ((unsigned)scp[16 + n] << 16);
     } else if (n < 8) {
-        q = reinterpret_cast<const uint2*>(rec)[g * 8 + n];
+        r.q = reinterpret_cast<const uint2*>(rec)[g * 8 + n];
         const unsigned short* scp = reinterpret_cast<const unsigned short*>(rec + REC_H_SC);
-        s0 = __half2float(__ushort_as_half(scp[n])); s1 = __half2float(__ushort_as_half(scp[8 + n]));
+        r.sc = (unsigned)scp[n] | ((unsigned)scp[8 + n] << 16);
     }
+    return r;
+}
+// the record against the step's two activation blocks: acc[m][n] += sum_k x[m][k] * w[n][k]
+__device__ __forceinline__ f32x4 rec_mma(const RawRec& r, bf16x8 ah0, bf16x8 al0, bf16x8 ah1, bf16x8 al1, f32x4 c0, f32x4 c1, f32x4 acc) {
+    const uint2 q = r.q;
     const unsigned lox = q.x & 0x0F0F0F0Fu, loy = q.y & 0x0F0F0F0Fu, hix = (q.x >> 4) & 0x0F0F0F0Fu, hiy = (q.y >> 4) & 0x0F0F0F0Fu;
     // lanes 32..63 of `lo` <-> lanes 0..31 of `hi`: first result = block 2 T in every lane group (y < 2: own low nibbles = columns 8 y ..; y >= 2: the high nibbles of group
     // y - 2 = columns 16 + 8 (y - 2) ..), second result = block 2 T + 1 (y < 2: the low nibbles of group y + 2; y >= 2: own high nibbles)
@@ -129,6 +135,7 @@ __device__ __forceinline__ f32x4 step16(const unsigned char* rec, bool half, int
     d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, as_bf16x8(b0), d0, 0, 0, 0);
     f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, as_bf16x8(b1), c1, 0, 0, 0);
     d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, as_bf16x8(b1), d1, 0, 0, 0);
+    const float s0 = __half2float(__ushort_as_half((unsigned short)(r.sc & 0xFFFFu))), s1 = __half2float(__ushort_as_half((unsigned short)(r.sc >> 16)));
     acc = __builtin_elementwise_fma((f32x4){s0, s0, s0, s0}, d0, acc);
     acc = __builtin_elementwise_fma((f32x4){s1, s1, s1, s1}, d1, acc);
     return acc;
@@ -147,6 +154,7 @@ __device__ __forceinline__ void b16_loader(const EngBParams& p, BCtl* c, unsigne
     Loader<BCtl, BNSLOT> ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = (p.flags & 1) != 0; ld.pace = 0;
     if (p.flags & 1024) ld.depth = 2;
     if (p.flags & 2048) ld.depth = 1;
+    if (p.flags & 64) ld.pause_ticks = 300;      // nothing new in flight while this CU's COMM wave polls / sums / publishes (bounded: 3 us)
     const bool nodma = (p.flags & 32) != 0;
     const u64 base = (u64)p.stream;
     const unsigned n_pk = (unsigned)p.n_layers * PK_LAYER;
@@ -427,6 +435,7 @@ struct BCons {
     __device__ __forceinline__ f32x4 cb_read(int i) const { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds + BL_CB) + (cw * 8 + i) * BM + 4 * (lane >> 4)); }
 };
 #define B16_PROLOGUE                                                                                                          \
+    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      /* the lane index from the EXEC mask (all 64 lanes are active here): no register lives across phases */ \
     asm volatile("" : "+v"(lane));      /* opaque per phase: lane-derived addresses are recomputed, never hoisted out of the layer loop and carried (spilled) across phases */ \
     const EngBParams p = kparams(); unsigned char* lds = lds_base();                                                          \
     const int cw = __builtin_amdgcn_readfirstlane(cw_), l = __builtin_amdgcn_readfirstlane(l_);                               \
@@ -443,24 +452,27 @@ B16_PHASE void ph_qkv(int cw_, int lane, int l_) {
     B16_PROLOGUE
     unsigned char* part = lds + BL_PART;
     {
+        // this wave's 8 step records (K-steps 4 cw .. 4 cw + 3 of the 16-row q tile and of the 8-row k|v tile) -> registers BEFORE the input exists; the slots are free again
+        RawRec rq[4];
+#pragma unroll
+        for (int pk = 0; pk < 2; pk++) {
+            int sl; const unsigned char* bb = cs.slot_wait(P0 + pk, 2 * REC, sl);
+            rq[2 * pk] = rec_load(bb, false, lane); rq[2 * pk + 1] = rec_load(bb + REC, false, lane);
+            cs.slot_release(sl);
+        }
         wait_ge(&c->ag_flag, 2u * (unsigned)l + 1u, c, p.err, ERR_STAGE);
         bf16x8 ah[8], al[8];
         cs.load_a<8>(p.XH0, XH_BYTES, 8 * cw, ah, al);
         tl(0);
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        int sl2; const unsigned char* b2 = cs.slot_wait(P0 + 2, 4 * REC_H, sl2);      // the 8-row tile's records stay in the ring (landed long ago)
 #pragma unroll
-        for (int pk = 0; pk < 2; pk++) {
-            int sl; const unsigned char* bb = cs.slot_wait(P0 + pk, 2 * REC, sl);
-#pragma unroll
-            for (int r = 0; r < 2; r++) { const int i0 = 2 * (2 * pk + r); a0 = step16(bb + r * REC, false, lane, ah[i0], al[i0], ah[i0 + 1], al[i0 + 1], cs.cb_read(i0), cs.cb_read(i0 + 1), a0); }
-            cs.slot_release(sl);
+        for (int r = 0; r < 4; r++) {
+            const f32x4 c0 = cs.cb_read(2 * r), c1 = cs.cb_read(2 * r + 1);
+            a0 = rec_mma(rq[r], ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], c0, c1, a0);
+            a1 = rec_mma(rec_load(b2 + r * REC_H, true, lane), ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], c0, c1, a1);
         }
-        {
-            int sl; const unsigned char* bb = cs.slot_wait(P0 + 2, 4 * REC_H, sl);
-#pragma unroll
-            for (int r = 0; r < 4; r++) a1 = step16(bb + r * REC_H, true, lane, ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], cs.cb_read(2 * r), cs.cb_read(2 * r + 1), a1);
-            cs.slot_release(sl);
-        }
+        cs.slot_release(sl2);
         *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + lane * 16) = a0;
         if (n < 8) *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 1024 + (y * 8 + n) * 16) = a1;
     }
@@ -608,19 +620,27 @@ B16_PHASE void ph_attn(int cw_, int lane, int l_) {
 // ================= wo: rows [384 s, +384) x head h's 128 columns -> plane h =================
 B16_PHASE void ph_wo(int cw_, int lane, int l_) {
     B16_PROLOGUE
+    RawRec rw[4];      // tiles 2 cw, 2 cw + 1, two K-steps each: in registers before the attention outputs exist
+#pragma unroll
+    for (int i = 0; i < WO_PK; i++) {
+        int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + i, 2 * REC, sl);
+        rw[2 * i] = rec_load(bb, false, lane); rw[2 * i + 1] = rec_load(bb + REC, false, lane);
+        cs.slot_release(sl);
+    }
     wait_ge(&c->wo_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
     bf16x8 ah[4], al[4];
     cs.load_a<4>(p.XO + (size_t)h * XO_HEAD, XO_HEAD, 0, ah, al);
     tl(4);
     const srd_t pd = make_srd(p.PW + (size_t)h * ED * BM, ED * BM * 4u);
+    {
+        const f32x4 c0 = cs.cb_read(0), c1 = cs.cb_read(1), c2 = cs.cb_read(2), c3 = cs.cb_read(3);
 #pragma unroll
-    for (int i = 0; i < WO_PK; i++) {
-        int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + i, 2 * REC, sl);
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        a = step16(bb, false, lane, ah[0], al[0], ah[1], al[1], cs.cb_read(0), cs.cb_read(1), a);
-        a = step16(bb + REC, false, lane, ah[2], al[2], ah[3], al[3], cs.cb_read(2), cs.cb_read(3), a);
-        cs.slot_release(sl);
-        st_f4(pd, (unsigned)((384 * s + 16 * (2 * cw + i) + n) * BM + 4 * y) * 4u, a);
+        for (int i = 0; i < WO_PK; i++) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = rec_mma(rw[2 * i], ah[0], al[0], ah[1], al[1], c0, c1, a);
+            a = rec_mma(rw[2 * i + 1], ah[2], al[2], ah[3], al[3], c2, c3, a);
+            st_f4(pd, (unsigned)((384 * s + 16 * (2 * cw + i) + n) * BM + 4 * y) * 4u, a);
+        }
     }
     drain_vm();
     if (lane == 0) st_u32(make_srd(p.FW, 3072 * 4u), (unsigned)((h * 8 + s) * NCONS + cw) * 4u, tag, false);
@@ -651,32 +671,47 @@ B16_PHASE void ph_w13(int cw_, int lane, int l_) {
     unsigned char* part = lds + BL_PART;
     float* sg = reinterpret_cast<float*>(lds + BL_CB);           // SwiGLU outputs [16 m][36] (the CB lines are dead behind the first barrier)
     {
+        // tile 0's and tile 1's records (8 of the wave's 20) wait in registers while the post-attention stream is still on its way; afterwards one tile is fetched ahead
+        // of the one being multiplied
+        const unsigned PW13 = P0 + QKV_PK + WO_PK;
+        RawRec ra[4], rb[4];
+        auto fetch_tile = [&](int ti, RawRec (&rr)[4]) {
+#pragma unroll
+            for (int pk = 0; pk < 2; pk++) {
+                int sl; const unsigned char* bb = cs.slot_wait(PW13 + 2 * ti + pk, 2 * REC, sl);
+                rr[2 * pk] = rec_load(bb, false, lane); rr[2 * pk + 1] = rec_load(bb + REC, false, lane);
+                cs.slot_release(sl);
+            }
+        };
+        auto fetch_half = [&](RawRec (&rr)[4]) {
+            int sl; const unsigned char* bb = cs.slot_wait(PW13 + 8, 4 * REC_H, sl);
+#pragma unroll
+            for (int r = 0; r < 4; r++) rr[r] = rec_load(bb + r * REC_H, true, lane);
+            cs.slot_release(sl);
+        };
+        fetch_tile(0, ra); fetch_tile(1, rb);
         wait_ge(&c->ag_flag, 2u * (unsigned)l + 2u, c, p.err, ERR_STAGE);
         bf16x8 ah[8], al[8];
         cs.load_a<8>(p.XH1, XH_BYTES, 8 * cw, ah, al);
         tl(6);
-#pragma unroll 1
-        for (int ti = 0; ti < 4; ti++) {
+        auto mul_tile = [&](const RawRec (&rr)[4]) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int pk = 0; pk < 2; pk++) {
-                int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + WO_PK + 2 * ti + pk, 2 * REC, sl);
-#pragma unroll
-                for (int r = 0; r < 2; r++) { const int i0 = 2 * (2 * pk + r); a = step16(bb + r * REC, false, lane, ah[i0], al[i0], ah[i0 + 1], al[i0 + 1], cs.cb_read(i0), cs.cb_read(i0 + 1), a); }
-                cs.slot_release(sl);
-            }
-            *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + ti * 1024 + lane * 16) = a;
-        }
-        {
-            int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + WO_PK + 8, 4 * REC_H, sl);
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; r++) a = step16(bb + r * REC_H, true, lane, ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], cs.cb_read(2 * r), cs.cb_read(2 * r + 1), a);
-            cs.slot_release(sl);
-            if (n < 8) *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 4096 + (y * 8 + n) * 16) = a;
-        }
+            for (int r = 0; r < 4; r++) a = rec_mma(rr[r], ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], cs.cb_read(2 * r), cs.cb_read(2 * r + 1), a);
+            return a;
+        };
+        { const f32x4 a = mul_tile(ra); *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 0 * 1024 + lane * 16) = a; }
+        fetch_tile(2, ra);
+        { const f32x4 a = mul_tile(rb); *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 1 * 1024 + lane * 16) = a; }
+        fetch_tile(3, rb);
+        { const f32x4 a = mul_tile(ra); *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 2 * 1024 + lane * 16) = a; }
+        fetch_half(ra);
+        { const f32x4 a = mul_tile(rb); *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 3 * 1024 + lane * 16) = a; }
+        { const f32x4 a = mul_tile(ra); if (n < 8) *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 4096 + (y * 8 + n) * 16) = a; }
     }
+    tl(27);
     cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 2)));      // (also: every wave is through with its CB lines -> the region becomes the SwiGLU scratch)
+    tl(28);
     if (cw < 5) {       // wave t finishes tile t: K slices summed in a fixed order, RMSNorm scale, SiLU(gate) * up -> sg[m][col]
         const float* rstd = reinterpret_cast<const float*>(lds + BL_RSTD);
         const bool hf = cw == 4;
@@ -691,7 +726,9 @@ B16_PHASE void ph_w13(int cw_, int lane, int l_) {
             if ((n & 1) == 0 && (!hf || n < 8)) sg[(4 * y + r) * 36 + 8 * cw + (n >> 1)] = silu_e(a[r]) * up;
         }
     }
+    tl(29);
     cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 3)));
+    tl(30);
     if (cw < 3 && lane < 48) {      // 144 pieces of four columns x one sequence -> bf16 hi + lo, 8 bytes each, into the group's fragment buffer
         const int it = 48 * cw + lane, m = it & 15, hc = it >> 4;
         const float4 v = *reinterpret_cast<const float4*>(sg + m * 36 + 4 * hc);
@@ -712,17 +749,23 @@ B16_PHASE void ph_w2(int cw_, int lane, int l_) {
     unsigned char* part = lds + BL_PART;
     {
         const int ksl = cw % 6, tg = cw / 6;
+        RawRec r2[9];      // this wave's 3 K-steps of its 3 tiles -> registers while the SwiGLU outputs of the XCD group are still being exchanged
+#pragma unroll
+        for (int i = 0; i < W2_PK; i++) {
+            int sl; const unsigned char* bb = cs.slot_wait(P0 + PK_LAYER_M + i, 3 * REC, sl);
+#pragma unroll
+            for (int k = 0; k < 3; k++) r2[3 * i + k] = rec_load(bb + k * REC, false, lane);
+            cs.slot_release(sl);
+        }
         wait_ge(&c->xa_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
         bf16x8 ah[6], al[6];
         cs.load_a<6>(p.XA + (size_t)g * XA_GROUP, XA_GROUP, 6 * ksl, ah, al);
         tl(26);
 #pragma unroll
         for (int i = 0; i < W2_PK; i++) {
-            int sl; const unsigned char* bb = cs.slot_wait(P0 + PK_LAYER_M + i, 3 * REC, sl);
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 3; k++) a = step16(bb + k * REC, false, lane, ah[2 * k], al[2 * k], ah[2 * k + 1], al[2 * k + 1], cs.cb_read(2 * k), cs.cb_read(2 * k + 1), a);
-            cs.slot_release(sl);
+            for (int k = 0; k < 3; k++) a = rec_mma(r2[3 * i + k], ah[2 * k], al[2 * k], ah[2 * k + 1], al[2 * k + 1], cs.cb_read(2 * k), cs.cb_read(2 * k + 1), a);
             *reinterpret_cast<f32x4*>(part + ((3 * tg + i) * 6 + ksl) * 1024 + lane * 16) = a;
         }
     }

@@ -242,7 +242,8 @@ struct EngBParams {
     unsigned long long* XC; unsigned* serial; unsigned* err;
     uint16_t* xf_out; float* ssq_out;                 // the layer stack's output: XF planes of h * final_norm (xf_store4 layout) + [256][16] partial sums of squares
     unsigned long long* tl; int tl_layer;             // timeline stamps [256][32] of layer tl_layer (null: off)
-    int flags;                                        // 1: thin loader while the CU polls; 32: no LDS-DMA (diagnostic, wrong results); 128: plain stores on XCD-local edges (placement verified per launch); 1024 / 2048: loader depth 2 / 1; 16384: fault injection
+    int flags;                                        // product default 2241 = 1 | 64 | 128 | 2048.  1: one LDS-DMA packet in flight while the CU's COMM wave polls; 64: none issued meanwhile (bounded 3 us); 128: plain stores on XCD-local
+                                                      // edges (placement verified per launch); 1024 / 2048: loader depth 2 / 1; 32: no LDS-DMA (diagnostic, wrong results); 16384: fault injection
 };
 size_t engb_state_bytes();
 void engb_state_carve(unsigned char* state, EngBParams* p);      // point p's edge buffers / flags / serial / err into a zero-initialised state block
