@@ -1991,8 +1991,9 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     if (use_xf) { HIPCHK(b_ssq.alloc_pooled(cx, (size_t)parts_D * 16 * 4 * n_grp)); HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4 * n_grp, s)); }
     // Batched decode-layer ENGINE (vox_engine_b16.hip): the 26 layers of a 16-row group as ONE persistent launch on the single-stream engine's packet stream; the group's
     // 5 x 26 launches remain as the fallback (other geometries, dense checkpoints, VOX_BATCH_ENGINE=0, a hand-off timeout).  The launch owns all 256 CUs, so the groups of
-    // a step run back to back on the main stream instead of on forked streams.
-    const bool use_eng = allow_engine && use_xf && steps > 0 && engb_prepare(m, n_grp);
+    // a step would run back to back instead of on forked streams -- measured on the 647-clip corpus in 64-clip batches (four groups): 6 770 tok/s against 8 540 for the
+    // forked launch chains (profiles/r04_b16_fleurs_engine_vs_launches.txt), so batches wider than one group keep the launches (VOX_BATCH_ENGINE_WIDE=1: engine for every width).
+    const bool use_eng = allow_engine && use_xf && steps > 0 && (n_grp == 1 || knob_str("VOX_BATCH_ENGINE_WIDE")) && engb_prepare(m, n_grp);
     DevBuf b_ssq_e;
     std::vector<EngLayerTab> eng_tabs;
     if (use_eng) {
