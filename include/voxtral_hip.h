@@ -170,8 +170,10 @@ int32_t vox_q4_model_load_ex(vox_ctx* ctx, const char* gguf_path, uint32_t flags
  * the reader is only read during the call and stays owned by the caller. */
 int32_t vox_q4_model_load_gguf(vox_ctx* ctx, vox_gguf* g, uint32_t flags, vox_model** out);
 /* VoxtralModelLoader::from_file(..).load(), models/loader.rs:35-78: the f32 SafeTensors path (F32 / F16 / BF16 tensors,
- * models/weights.rs:16-66).  Same vox_model handle and the same forward entry points as the Q4 model.  Linear weights are
- * stored as bf16 on device: exact for the published BF16 checkpoint; F32/F16 inputs must hold bf16-representable values. */
+ * models/weights.rs:16-66).  Same vox_model handle and the same forward entry points as the Q4 model.  A linear weight whose values
+ * are all bf16-representable (the published checkpoint is BF16) is stored as one bf16 plane; any other F32 / F16 tensor keeps its EXACT
+ * values on device (f32 plane for the decode GEMV and the embedding lookup, bf16 hi + lo planes for the MFMA GEMMs) -- tested at full size
+ * against the oracle (tests/test_gpu_f32_path.py, test_gpu_fullsize.py: 108 / 108 and 196 / 196 greedy ids). */
 int32_t vox_f32_model_load(vox_ctx* ctx, const char* safetensors_path, vox_model** out);
 int32_t vox_model_free(vox_model* m);
 int32_t vox_model_config(const vox_model* m, vox_model_cfg* out);
@@ -183,6 +185,10 @@ int32_t vox_model_arena(const vox_model* m, void** dev_ptr, uint64_t* nbytes);
  * Q4 model) have been written into a VOX_LOAD_LAYOUT_ONLY model, rebuild what is derived from them on this GPU (the tile-ordered copies
  * of the Q4 linears; the decode engine's weight stream is packed lazily at the first decode step on every rank). */
 int32_t vox_model_arena_finalize(vox_model* m);
+/* Device memory the model holds besides caches and workspaces, bytes: out[0] weight arena (= vox_model_weight_bytes), out[1] its primary part (what a multi-GPU start-up
+ * broadcasts), out[2] the decode engines' weight stream (a third copy of the decoder's Q4 bytes in consumption order; 0 until the first decode step builds it),
+ * out[3] the engines' edge buffers (single-stream granules + one block per 16-row group of the batched engine). */
+int32_t vox_model_memory(const vox_model* m, uint64_t out[4]);
 
 /* the delay conditioning used by every decoder call: t_embed = TimeEmbedding(dec_dim).embed(delay)
  * (bin/transcribe.rs:104-105).  Ada scales 1 + w2(gelu(w0 t_embed)) (gguf/model.rs:250-255) are
@@ -191,12 +197,14 @@ int32_t vox_model_set_t_embed(vox_model* m, const float* t_embed_host);
 /* Single-stream decode loop of transcribe_streaming (gguf/model.rs:938-960): by default every step is ONE launch of the persistent decode engine
  * (all 26 layers + final norm + lm_head; real decoder geometry, Q4 weights, 256-CU device); on = 0 selects the per-operator launches (4 per layer),
  * which other geometries / dense checkpoints always use.  *active_or_null reports whether the engine will be used.  Results of both paths agree to
- * summation-order noise (same ids; tests/test_gpu_fullsize.py).  Environment VOX_ENGINE=0 sets the default to off at load time. */
+ * summation-order noise (same ids; tests/test_gpu_fullsize.py).  The engine's 256 workgroups wait for each other with bounded (20 ms) waits: if the GPU is shared and a wait expires,
+ * the utterance is decoded again on the per-operator launches (a warning on stderr), the engine is re-armed for the next utterance and switched off after three such
+ * strikes.  Environment VOX_ENGINE=0 sets the default to off at load time. */
 int32_t vox_model_set_decode_engine(vox_model* m, int32_t on, int32_t* active_or_null);
 /* Batched decode loop of vox_transcribe_batch (BASELINE configs[3]; the reference's model.rs:938-960 is batch-1): by default the 26 decoder layers of every 16-row
  * group run as ONE launch of the batched decode-layer engine per step (same eligibility as above); on = 0 selects the launch-based step (5 launches per layer and
  * group), on < 0 only queries.  *active_or_null: will the engine be used; *launches_or_null: engine launches enqueued so far (eager + graph replays).  A hand-off
- * timeout inside the engine re-runs the batch on the launch-based step and switches the engine off for the model.  Environment VOX_BATCH_ENGINE=0: off at load time. */
+ * timeout inside the engine re-runs the batch on the launch-based step (a warning on stderr); three such strikes switch the engine off for the model.  Environment VOX_BATCH_ENGINE=0: off at load time. */
 int32_t vox_model_set_batch_engine(vox_model* m, int32_t on, int32_t* active_or_null, uint64_t* launches_or_null);
 
 /* Q4VoxtralModel::encode_audio, gguf/model.rs:783-788: mel [128][T] -> [S][dec_dim]; *S = floor(S_enc/4) */
@@ -253,6 +261,9 @@ int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out);
 /* The VOX_* measurement knobs (kernel-selection overrides used by tools/ and by the A/B tests) are read from the environment ONCE, at vox_ctx_create;
  * this re-reads them (tests that flip a knob between two calls).  Not part of the reference surface. */
 int32_t vox_debug_reload_knobs(void);
+/* Test hook: launch `workgroups` x 1024-thread workgroups that spin for `micros` microseconds on a side stream of the context and return at once (vox_ctx_synchronize does
+ * not wait for them; vox_ctx_destroy does).  Used to test the decode engines against a GPU that is not theirs alone (tests/test_gpu_fullsize.py). */
+int32_t vox_debug_occupy(vox_ctx* ctx, int32_t workgroups, int32_t micros);
 
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -------- */
 /* Launch the decode-step Q4 GEMV of decoder layer `layer` (`which`: 0 qkv, 1 wo, 2 w1w3, 3 w2, 4 lm_head; 5 = the whole step as one decode-engine launch)

@@ -184,6 +184,59 @@ def test_full_batch16_vs_oracle_golden(pkg, full):
     print(f"batch-16 golden: all 16 rows agree with the oracle for {stop}/108 steps ({int((outs[0] == rids).sum())} ids equal)")
 
 
+def test_full_peaked_golden_all_ids_single_batch16_ragged(pkg):
+    """A full-size Q4 golden with COMFORTABLE margins (tests/golden/make_fullsize_peaked_golden.py: peaked logit distribution, |logit| up to 64, smallest top-2 margin of the
+    oracle's 108 steps 1.28 = 100 x the stated tolerance): every path must reproduce ALL 108 oracle ids -- single stream on the decode engine (eager with logits, graph
+    replay) and on the per-operator launches, 16 rows of the clip through vox_transcribe_batch on the batched decode-layer engine and on the launch-based step, and a ragged
+    22-row batch with the clip in the caller's last slot.  (The 16 s golden of the bench model has its first near-tie at step 14: tests on it can only assert 14 ids.)"""
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_16s_peaked_oracle.npz"))
+    path = os.path.join(cache_dir(), "full_q4_peaked_seed44.gguf")
+    if not os.path.exists(path):
+        pkg.synth.write_synthetic_gguf(path + ".tmp", pkg.synth.ModelDims(), seed=44, peaked=True); os.replace(path + ".tmp", path)
+    hs = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            hs.update(chunk)
+    assert hs.digest() == g["gguf_sha256"].tobytes()
+    x = pkg.synth.synth_audio(16.0, seed=7049)
+    assert hashlib.sha256(x.tobytes()).digest() == g["audio_sha256"].tobytes()
+    rids, top1, top2, amax = g["ids"], g["top1"], g["top2"], float(g["logit_absmax"])
+    assert len(rids) == 108 and float((top1 - top2).min()) > 50 * TOL * amax          # the fixture's point: no near-tie anywhere
+    ctx = pkg.Context(0); m = pkg.Q4ModelLoader.from_file(path).load(ctx)
+    try:
+        t = pkg.TimeEmbedding(3072).embed(6.0)
+        mel = np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
+        for engine in (True, False):
+            if m.set_decode_engine(engine) != engine:
+                continue
+            ids, lg = m.transcribe_streaming(mel, t, return_logits=True)
+            assert np.array_equal(ids, rids), f"single stream (engine={engine}): ids differ from the oracle"
+            err = float(np.abs(np.sort(lg, axis=1)[:, -1] - top1).max())
+            assert err <= 1e-2 * amax, (engine, err)
+            assert np.array_equal(m.transcribe_streaming(mel, t), rids)              # graph-replayed decode loop
+            assert np.array_equal(m.transcribe_audio(x, t), rids)                    # device front-end
+            print(f"peaked golden, single stream (engine={engine}): 108 / 108 ids, max top-logit error {err:.3e} at |logit| max {amax:.1f}")
+        m.set_decode_engine(True)
+        for batch_engine in (True, False):
+            active, n0 = m.set_batch_engine(batch_engine)
+            if active != batch_engine:
+                continue
+            outs = m.transcribe_batch([x] * 16, t)
+            assert len(outs) == 16 and all(np.array_equal(o, rids) for o in outs), f"batch of 16 (engine={batch_engine}): a row differs from the oracle"
+            _, n1 = m.set_batch_engine()
+            assert (n1 - n0 == 107) if batch_engine else (n1 == n0)                  # one engine launch per decode step, none on the launch-based step
+            short = [pkg.synth.synth_audio(3.0 + 0.37 * (i % 17), seed=600 + i) for i in range(21)]
+            ragged = m.transcribe_batch(short + [x], t)                              # 22 rows, two groups: the launch-based step (the engine serves one-group batches)
+            assert np.array_equal(ragged[-1], rids)
+            five = m.transcribe_batch(short[:4] + [x], t)                            # a ragged ONE-group batch: idle rows + rows that finish early
+            assert np.array_equal(five[-1], rids) and all(np.array_equal(a, b) for a, b in zip(five[:4], ragged[:4]))
+            print(f"peaked golden, batch (engine={batch_engine}): 16 / 16 rows, ragged 22-row and 5-row batches: all 108 ids")
+        m.set_batch_engine(True)
+    finally:
+        m.close(); ctx.close()
+
+
 def test_full_ragged_batch_groups_retire(pkg, full):
     """A ragged batch wider than one 16-row group at FULL size: vox_transcribe_batch runs the rows longest first and RETIRES a group's layer chain
     once its longest member is done.  The 16 s golden clip sits in the caller's LAST slot between 3..9 s clips: it must still reproduce the oracle's
@@ -276,7 +329,7 @@ def test_full_30s_f32_heavytail_vs_oracle_golden(pkg):
             assert top1[stop] - top2[stop] <= 2e-2 * amax, f"f32 heavy-tail ids differ at step {stop} with a clear margin {top1[stop] - top2[stop]}"
         assert stop >= 1
         err = float(np.abs(lg[:stop].max(axis=1) - top1[:stop]).max())
-        assert err <= 2e-2 * amax, (err, amax)
+        assert err <= 1e-2 * amax, (err, amax)
         ids_a = m.transcribe_audio(x, t)                                          # product path: device mel + graph replay
         assert (ids_a[:stop] == rids[:stop]).all() and (m.transcribe_audio(x, t) == ids_a).all()
         print(f"heavy-tail f32 golden: ids agree for {stop}/{len(ids)} steps; max top-logit error {err:.3e} at |logit| max {amax:.1f}")
@@ -395,9 +448,10 @@ def test_full_decode_loop_and_prefill_knob_paths(pkg, full, monkeypatch):
     assert err <= TOL                     # (ulp-level differences of the RoPE / SwiGLU expressions' contraction, carried through 26 layers: 3.6e-5 measured)
 
 
-def test_full_decode_engine_lost_publish_times_out_loudly_and_falls_back(pkg, full, monkeypatch):
-    """Every wait inside the engine is bounded (20 ms): with one workgroup's publish suppressed (fault-injection flag 16384) the launch must END, the call must fail
-    loudly (not return wrong ids), and the model must keep working on the per-operator path afterwards -- with the ids of the healthy engine."""
+def test_full_decode_engine_lost_publish_times_out_and_the_utterance_is_served_anyway(pkg, full, monkeypatch, capfd):
+    """Every wait inside the engine is bounded (20 ms): with one workgroup's publish suppressed (fault-injection flag 16384) the launch must END, the call must NOT return
+    wrong ids -- the same utterance is decoded again on the per-operator path (a warning on stderr says so) -- the engine is re-armed for the next utterance, and after three
+    strikes it is switched off for the life of the model.  Ids = those of the healthy engine throughout."""
     m0, _, ctx = full
     if not m0.set_decode_engine(True):
         pytest.skip("decode engine not available on this device (needs 256 CUs)")
@@ -409,14 +463,44 @@ def test_full_decode_engine_lost_publish_times_out_loudly_and_falls_back(pkg, fu
     monkeypatch.delenv("VOX_ENGINE_FLAGS")
     try:
         import time
-        t0 = time.time()
-        with pytest.raises(pkg.VoxError, match="hand-off timeout"):
-            b.transcribe_audio(x, t)
-        assert time.time() - t0 < 30.0                                   # bounded: a few 20 ms waits per launch, not a hang
-        assert not b.set_decode_engine(True)                             # the engine stays off for this model
-        assert np.array_equal(b.transcribe_audio(x, t), good)            # per-operator path
+        for strike in (1, 2, 3):
+            t0 = time.time()
+            assert np.array_equal(b.transcribe_audio(x, t), good)        # served by the re-run on the per-operator launches
+            assert time.time() - t0 < 30.0                               # bounded: a few 20 ms waits per launch, not a hang
+            err = capfd.readouterr().err
+            assert "hand-off timeout" in err and f"strike {strike} of 3" in err
+            assert b.set_decode_engine(True) == (strike < 3)             # re-armed twice, off for good after the third strike
+        assert np.array_equal(b.transcribe_audio(x, t), good)            # per-operator path from now on, silently
+        assert "hand-off timeout" not in capfd.readouterr().err
     finally:
         b.close()
+
+
+def test_full_engines_on_a_gpu_that_is_not_theirs_alone(pkg, full, capfd):
+    """The engines' workgroups wait for each other, so all 256 must be resident: a long kernel on ANOTHER stream (64 x 1024-thread workgroups spinning for 60 ms --
+    vox_debug_occupy) takes CUs away while an utterance / a batch is decoded.  Required: correct ids (whichever path produced them), no hang, and a working engine
+    afterwards (the single-stream engine is re-armed after a timeout; it may also simply have waited the spin out, which is fine)."""
+    m, _, ctx = full
+    if not m.set_decode_engine(True):
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    x = pkg.synth.synth_audio(3.0, seed=9); t = pkg.TimeEmbedding(3072).embed(6.0)
+    good = m.transcribe_audio(x, t)
+    good_b = m.transcribe_batch([x] * 3, t)
+    import time
+    t0 = time.time()
+    ctx.occupy(64, 60000)
+    ids = m.transcribe_audio(x, t)
+    assert np.array_equal(ids, good)
+    ctx.occupy(64, 60000)
+    outs = m.transcribe_batch([x] * 3, t)
+    assert all(np.array_equal(a, b_) for a, b_ in zip(outs, good_b))
+    assert time.time() - t0 < 60.0
+    err = capfd.readouterr().err
+    print("stderr during the occupied runs:", err.strip()[:400] or "(nothing: the engines waited the spin out or were not disturbed)")
+    time.sleep(0.1); ctx.synchronize()
+    assert m.set_decode_engine(True)                                     # still armed (at most two strikes here)
+    assert np.array_equal(m.transcribe_audio(x, t), good)
+    assert "hand-off timeout" not in capfd.readouterr().err              # ... and healthy again once the GPU is its own
 
 
 def test_full_layout_only_arena_copy_start_up(pkg, full):
@@ -447,7 +531,7 @@ def test_full_30s_heavytail_vs_oracle_golden(pkg, orc):
       (a) end to end: all ids identical to the oracle's (up to a near-tie), on the decode engine and on the per-operator path; engine vs per-operator logits <= 2e-4 max;
       (b) stage by stage on the ORACLE's intermediate values: encoder + adapter output and lm_head within the stated 2e-4, the 38-token decoder prefill within 4e-4
           (the f32 summation-order noise of this fixture, measured: see the assertion);
-      (c) end-to-end top logits within 2e-2 of the largest |logit|: this synthetic decoder is ill-conditioned (measured: a 5.6e-5 relative perturbation of its input -- the
+      (c) end-to-end top logits within 1e-2 of the largest |logit| (SURVEY section 8(c)'s eps_q4; measured 7.4e-3): this synthetic decoder is ill-conditioned (measured: a 5.6e-5 relative perturbation of its input -- the
           two encoders' f32 summation-order noise -- moves its hidden state by 2.0e-3), so (b) is the precision statement and (c) only bounds the amplification."""
     import hashlib
     gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_30s_heavytail_oracle.npz")
@@ -481,7 +565,7 @@ def test_full_30s_heavytail_vs_oracle_golden(pkg, orc):
                 assert top1[stop] - top2[stop] <= 2e-2 * amax, f"engine={engine}: ids differ at step {stop} with a clear margin"
             assert stop >= 1
             err = float(np.abs(lg[:stop].max(axis=1) - top1[:stop]).max())
-            assert err <= 2e-2 * amax, (engine, err, amax)                                             # (c)
+            assert err <= 1e-2 * amax, (engine, err, amax)                                             # (c) SURVEY section 8(c)'s eps_q4 (measured 7.4e-3: conditioning, see the docstring)
             print(f"heavy-tail golden (engine={engine}): ids agree for {stop}/{len(ids)} steps; max top-logit error {err:.3e} at |logit| max {amax:.1f}")
             ids_b = m.transcribe_batch([x], t)[0]
             assert (ids_b[:stop] == rids[:stop]).all()

@@ -97,6 +97,8 @@ SIGNATURES = {
     "vox_model_arena": (i32, [vp, P(vp), P(u64)]),
     "vox_model_set_t_embed": (i32, [vp, vp]),
     "vox_model_set_decode_engine": (i32, [vp, i32, P(i32)]),
+    "vox_debug_occupy": (i32, [vp, i32, i32]),
+    "vox_model_memory": (i32, [vp, P(C.c_uint64)]),
     "vox_model_set_batch_engine": (i32, [vp, i32, P(i32), P(C.c_uint64)]),
     "vox_model_arena_finalize": (i32, [vp]),
     "vox_generate_step_with_cache": (i32, [vp, vp, i32, vp, vp, vp]),

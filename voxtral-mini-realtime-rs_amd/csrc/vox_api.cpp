@@ -107,13 +107,20 @@ extern "C" int32_t vox_ctx_create(int32_t device, vox_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(VOX_ERR_HIP, "no HIP device available (libvoxtral_hip has no CPU fallback)"); }
     ARGCHK(device >= 0 && device < n, "device %d out of range (have %d)", device, n);
     HIPCHK(hipSetDevice(device));
-    knobs_reload();      // the VOX_* measurement knobs are read here, once: no launch path calls getenv
+    knobs_load_once();      // the VOX_* measurement knobs are snapshotted ONCE per process (std::call_once): no launch path calls getenv, and a second context created
+                            // while another thread transcribes does not touch the table (vox_debug_reload_knobs replaces it: tests only)
     vox_ctx* c = new vox_ctx(); c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(VOX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = c; return VOX_OK;
 }
 extern "C" int32_t vox_debug_reload_knobs(void) { knobs_reload(); return VOX_OK; }
+extern "C" int32_t vox_debug_occupy(vox_ctx* c, int32_t workgroups, int32_t micros) {
+    ARGCHK(c && workgroups > 0 && workgroups <= 4096 && micros > 0 && micros <= 2000000, "bad argument"); VOXCHK(ctx_bind(c));
+    if (!c->aux[2]) HIPCHK(hipStreamCreateWithFlags(&c->aux[2], hipStreamNonBlocking));
+    HIPCHK(launch_occupy(workgroups, micros, c->aux[2]));
+    return VOX_OK;
+}
 extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
     if (!c) return VOX_OK;
     (void)hipSetDevice(c->device);
@@ -685,9 +692,10 @@ struct vox_model {
     const vox_cache* eng_tab_cache = nullptr; const float* eng_tab_k = nullptr; std::vector<EngLayerTab> eng_tab_host;      // (cache object, its K base) the device layer table was built for
     int eng_flags = 128 | 512 | 1, eng_pace = 50;      // XCD-local edges; probe-less all-gather, swept 0.5 us after the CU's own rows went out; one LDS-DMA packet in flight while the CU polls memory
     unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
+    int eng_strikes = 0; bool eng_suspended = false;      // hand-off timeouts so far (3: the engine is switched off for good); suspended: the current utterance is being re-run on the per-operator path
     // batched decode-layer engine (vox_engine_b16.hip): one launch per 16-row group and step on the same packet stream; per-group edge buffers + layer tables
     bool engb_ok = false; unsigned char* engb_state[4] = {nullptr, nullptr, nullptr, nullptr}; EngLayerTab* engb_tab[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool engb_on = true; unsigned long long engb_launches = 0;
+    bool engb_on = true; unsigned long long engb_launches = 0; int engb_strikes = 0;
     int engb_flags = 128 | 1 | 64 | 2048; unsigned engb_err_host[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0, graph_mode = 0;
@@ -1117,6 +1125,8 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
         hipDeviceProp_t prop; if (ok && (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess || prop.multiProcessorCount != 256)) ok = false;
         for (int i = 0; ok && i < c.dec_layers; i++) { const DecLayer& L = m->dec[i]; for (const Lin* w : {&L.wqkv, &L.wo, &L.w13, &L.w2}) if (w->w.fmt != WFMT_Q4_0 || !w->w.qs || !w->w.sc || w->bias) ok = false; }
         if (ok && (m->tok.w.fmt != WFMT_Q4_0 || !m->tok.w.qs)) ok = false;
+        // co-residency: the engine's 256 workgroups wait for each other; ask the runtime whether one workgroup (896 threads, 154 KB of LDS) fits per CU at all
+        if (ok) { int occ = 0; if (eng_occupancy(&occ) != hipSuccess || occ < 1) { ok = false; (void)hipGetLastError(); } }
         m->eng_ok = ok; m->eng_on = ok;
         {   // the batched engine needs its 256 workgroups co-resident: ask the runtime (a CU mask or a debugger can take CUs away without changing multiProcessorCount)
             const char* bv = knob_str("VOX_BATCH_ENGINE"); int occ = 0;
@@ -1157,6 +1167,14 @@ extern "C" int32_t vox_f32_model_load(vox_ctx* ctx, const char* path, vox_model*
 
 extern "C" int32_t vox_model_config(const vox_model* m, vox_model_cfg* out) { ARGCHK(m && out, "null argument"); *out = m->cfg; return VOX_OK; }
 extern "C" int32_t vox_model_weight_bytes(const vox_model* m, uint64_t* out) { ARGCHK(m && out, "null argument"); *out = m->arena_bytes; return VOX_OK; }
+extern "C" int32_t vox_model_memory(const vox_model* m, uint64_t out[4]) {
+    ARGCHK(m && out, "null argument");
+    out[0] = m->arena_bytes; out[1] = m->arena_primary_bytes;
+    out[2] = m->eng_stream ? eng_stream_bytes(m->cfg.dec_layers, m->cfg.vocab) : 0;
+    out[3] = m->eng_state ? eng_state_bytes() : 0;
+    for (int gi = 0; gi < 4; gi++) if (m->engb_state[gi]) out[3] += engb_state_bytes();
+    return VOX_OK;
+}
 extern "C" int32_t vox_model_arena(const vox_model* m, void** p, uint64_t* n) { ARGCHK(m && p && n, "null argument"); *p = m->arena; *n = m->arena_primary_bytes; return VOX_OK; }
 // receiver side of a multi-GPU start-up: the primary part of the arena has been filled (vox_model_arena + a broadcast); rebuild everything derived from it on
 // this GPU -- the tile-ordered copies of the Q4 linears (the decode engine's weight stream is built lazily at the first decode step either way)
@@ -1251,8 +1269,9 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     {
         const Q4W& w2 = m->enc[0].w2.w;
         const long wgs = (long)((w2.N + 127) / 128) * ((Mtot + 31) / 32);
-        if (w2.fmt == WFMT_Q4_0 && w2.qt && w2.st && w2.nb % 16 == 0 && Mtot > 48 && wgs < 1024 && D % 4 == 0 && D <= 4096) ksp = 4;
-        if (const char* e = knob_str("VOX_ENC_SPLITK")) ksp = atoi(e) > 1 ? atoi(e) : 0;
+        const bool geom_ok = w2.fmt == WFMT_Q4_0 && w2.qt && w2.st && w2.nb % 16 == 0 && Mtot > 48 && D % 4 == 0 && D <= 4096;      // what the split-K GEMM + summing norm can run at all
+        if (geom_ok && wgs < 1024) ksp = 4;
+        if (const char* e = knob_str("VOX_ENC_SPLITK")) ksp = geom_ok && atoi(e) > 1 ? std::min(atoi(e), w2.nb / 4) : 0;      // the knob picks the slice count on an eligible geometry, it never forces an ineligible one
         for (int l = 0; ksp && l < c.enc_layers; l++) if (m->enc[l].w2.w.fmt != WFMT_Q4_0 || !m->enc[l].w2.w.qt || m->enc[l].w2.w.nb / 4 < ksp) ksp = 0;
     }
     int ksp_wo = ksp ? 2 : 0;      // the same for wo (K = QD: 10 K-steps), two slices (7.85 -> 7.76 ms per clip; four: 7.93; profiles/r03_enc_splitk.txt); VOX_ENC_SPLITK_WO overrides
@@ -1628,7 +1647,7 @@ static int32_t engine_stream_prepare(vox_model* m) {
 // decode engine: per-CU weight stream (a second copy of the decoder's Q4 bytes in consumption order, built on the GPU from the row planes), granule state, layer table
 static int32_t engine_prepare(vox_model* m) {
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
-    if (!m->eng_ok || !m->eng_on || !m->cache || m->cache->max_seq > 1024) return VOX_OK;      // long caches keep the per-operator path (attention scores live in LDS)
+    if (!m->eng_ok || !m->eng_on || m->eng_suspended || !m->cache || m->cache->max_seq > 1024) return VOX_OK;      // long caches keep the per-operator path (attention scores live in LDS)
     VOXCHK(engine_stream_prepare(m));
     if (!m->eng_ready) return VOX_OK;
     if (m->eng_tab_cache != m->cache || m->eng_tab_k != m->cache->k) {      // (a re-allocated cache object can land on the old heap address: compare the device pointer too)
@@ -1654,7 +1673,7 @@ static bool engb_prepare(vox_model* m, int n_grp) {
     }
     return true;
 }
-static bool engine_active(const vox_model* m) { return m->eng_on && m->eng_ready && m->cache && m->eng_tab_cache == m->cache && m->eng_tab_k == m->cache->k && m->cache->max_seq <= 1024; }
+static bool engine_active(const vox_model* m) { return m->eng_on && !m->eng_suspended && m->eng_ready && m->cache && m->eng_tab_cache == m->cache && m->eng_tab_k == m->cache->k && m->cache->max_seq <= 1024; }
 static EngParams engine_params(vox_model* m, float* logits_out, bool argmax_in = false) {
     const vox_model_cfg& c = m->cfg;
     EngParams ep{}; ep.stream = m->eng_stream; ep.cu_stride = eng_stream_bytes(c.dec_layers, c.vocab) / 256; ep.layers = m->eng_tab; ep.n_layers = c.dec_layers; ep.h_in = m->d_h; ep.final_norm = m->dec_norm;
@@ -1745,6 +1764,8 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     if (S < PREFIX_LEN) { m->timings.decode_ms = 0; return VOX_OK; }               // model.rs:887-889
     const int n = std::max(S - PREFIX_LEN, 1);                                      // S == 38: prefill + first token only (model.rs:922-926,938)
     ARGCHK(cap >= n, "out_ids capacity %d < %d", cap, n);
+    bool eng_failed = false; int steps = 0;
+    auto decode_once = [&]() -> int32_t {
     VOXCHK(ensure_decode_state(m, S));
     VOXCHK(engine_prepare(m));
     if (engine_active(m)) {      // tags = (launch serial + 1) * 64 + layer + 1 are 32-bit: restart the serial long before they wrap (never inside a captured graph)
@@ -1769,7 +1790,7 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     const int pos_init = PREFIX_LEN;
     HIPCHK(hipMemcpyAsync(m->d_pos, &pos_init, 4, hipMemcpyHostToDevice, s));
     HIPCHK(launch_argmax_final(m->d_part_val, m->d_part_idx, m->n_parts, m->d_tokens, m->d_pos, 0, 0, s));   // tokens[38]
-    const int steps = std::max(S - PREFIX_LEN - 1, 0);                            // pos = 39 .. S-1 (model.rs:938)
+    steps = std::max(S - PREFIX_LEN - 1, 0);                            // pos = 39 .. S-1 (model.rs:938)
     stage.begin("decode");
     // attn_wo accumulators: every step leaves them cleared (w2 does it); once per utterance they are cleared outright, so a call that failed
     // half-way through a layer cannot leak into the next one
@@ -1817,10 +1838,24 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     if (eng_used) { EngParams ep = engine_params(m, nullptr); HIPCHK(hipMemcpyAsync(m->eng_err_host, ep.err, 8, hipMemcpyDeviceToHost, s)); }
     HIPCHK(hipStreamSynchronize(s));
     stage.end();
-    if (eng_used && m->eng_err_host[0]) {      // a bounded hand-off wait expired inside the engine: the ids of this call are not trustworthy.  Fail loudly, fall back for later calls.
+    if (eng_used && m->eng_err_host[0]) { eng_failed = true; return VOX_OK; }
+    return VOX_OK;
+    };
+    VOXCHK(decode_once());
+    if (eng_failed) {
+        // A bounded hand-off wait expired inside the engine: its 256 workgroups were not co-resident for 20 ms (another kernel on the GPU, a CU mask, a debugger).  The ids
+        // of that attempt are not trustworthy -- the SAME utterance is decoded again on the per-operator launches (the encoder output is still in place), the engine is
+        // re-armed for the next utterance, and after three strikes it is switched off for the life of the model.
         const unsigned e = m->eng_err_host[0];
-        (void)hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), s); m->eng_launches = 0; m->eng_ok = false; m->eng_ready = false; graphs_destroy(m);
-        return fail(VOX_ERR_HIP, "decode engine: hand-off timeout (code %u, workgroup %u); the per-operator path is used from now on", e & 0xff, (e >> 8) & 0xff);
+        m->eng_strikes++;
+        fprintf(stderr, "[voxtral_hip] decode engine: hand-off timeout (code %u, workgroup %u), strike %d of 3; this utterance is decoded again on the per-operator path%s\n",
+                e & 0xff, (e >> 8) & 0xff, m->eng_strikes, m->eng_strikes >= 3 ? ", the engine is switched off" : "");
+        HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), s)); m->eng_launches = 0; graphs_destroy(m);
+        if (m->eng_strikes >= 3) { m->eng_ok = false; m->eng_on = false; }
+        m->eng_suspended = true; eng_failed = false;
+        const int32_t r = decode_once();
+        m->eng_suspended = false; graphs_destroy(m);      // (the graph captured during the re-run holds the per-operator launches)
+        if (r != VOX_OK) return r;
     }
     m->cache->len = PREFIX_LEN + steps;
     *n_ids = n; m->timings.decode_tokens = n;
@@ -2149,12 +2184,14 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     if (use_eng) for (int gi = 0; gi < n_grp; gi++) { EngBParams ep{}; engb_state_carve(m->engb_state[gi], &ep); HIPCHK(hipMemcpyAsync(m->engb_err_host[gi], ep.err, 8, hipMemcpyDeviceToHost, s)); }
     HIPCHK(hipStreamSynchronize(s));
     if (use_eng) for (int gi = 0; gi < n_grp; gi++) if (m->engb_err_host[gi][0]) {
-        // a bounded hand-off wait expired inside the engine (the launch needs all 256 CUs to itself): the ids of this call are not trustworthy.  Say so, switch the batched
-        // engine off for this model and serve the call again on the launch-based step.
+        // a bounded hand-off wait expired inside the engine (the launch needs all 256 CUs to itself): the ids of this call are not trustworthy.  Say so and serve the call
+        // again on the launch-based step; after three strikes the batched engine is switched off for this model.
         const unsigned e = m->engb_err_host[gi][0];
-        fprintf(stderr, "[voxtral_hip] batched decode engine: hand-off timeout (code %u, workgroup %u, group %d); re-running the batch on the launch-based step\n", e & 0xff, (e >> 8) & 0xff, gi);
+        m->engb_strikes++;
+        fprintf(stderr, "[voxtral_hip] batched decode engine: hand-off timeout (code %u, workgroup %u, group %d), strike %d of 3; re-running the batch on the launch-based step%s\n",
+                e & 0xff, (e >> 8) & 0xff, gi, m->engb_strikes, m->engb_strikes >= 3 ? ", the engine is switched off" : "");
         for (int gj = 0; gj < 4; gj++) if (m->engb_state[gj]) (void)hipMemsetAsync(m->engb_state[gj], 0, engb_state_bytes(), s);
-        m->engb_ok = false;
+        if (m->engb_strikes >= 3) m->engb_ok = false;      // (otherwise re-armed for the next batch)
         return transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, false);
     }
     int total = 0;
@@ -2251,11 +2288,13 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
     ARGCHK(m && avg_us && bytes_per_launch && iters > 0 && which >= 0 && which <= 5, "bad argument"); VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
     VOXCHK(ensure_decode_state(m, 64));
-    if (which == 5) {      // the whole decode step as ONE launch of the persistent engine (positions 64..: the engine reads the position word like the product does)
+    if (which == 5) {      // the whole decode step as ONE launch of the persistent engine, at the positions the 16 s bench clip decodes at (38 .. 145: four equal shares at 40, 75,
+        // 110, 145 -- the step gets longer with the position, a single low position would overstate the in-product rate)
         if (!m->t_embed_set) { std::vector<float> te(c.dec_dim); vox_time_embedding(6.0f, c.dec_dim, te.data()); VOXCHK(vox_model_set_t_embed(m, te.data())); }
         VOXCHK(engine_prepare(m));
         if (!engine_active(m)) return fail(VOX_ERR_UNSUPPORTED, "decode engine not active for this model / device");
-        const int p64 = 64; HIPCHK(hipMemcpyAsync(m->d_pos, &p64, 4, hipMemcpyHostToDevice, s));
+        static const int bench_pos[4] = {40, 75, 110, 145};
+        HIPCHK(hipMemcpyAsync(m->d_pos, &bench_pos[0], 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemsetAsync(m->d_h, 0, (size_t)c.dec_dim * 4, s));
         double bytes = 0; for (const Q4W* w : {&m->dec[0].wqkv.w, &m->dec[0].wo.w, &m->dec[0].w13.w, &m->dec[0].w2.w}) bytes += (double)w->N * w->nb * 18.0;
         *bytes_per_launch = bytes * c.dec_layers + (double)m->tok.w.N * m->tok.w.nb * 18.0;
@@ -2264,7 +2303,11 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
         for (int i = 0; i < 3; i++) HIPCHK(launch_decode_engine(ep, s));
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; i++) HIPCHK(launch_decode_engine(ep, s));
+        for (int q = 0; q < 4; q++) {
+            const int pq = std::min(bench_pos[q], m->cache->max_seq - 2);
+            HIPCHK(hipMemcpyAsync(m->d_pos, &pq, 4, hipMemcpyHostToDevice, s));      // (pageable host source: staged at call time)
+            for (int i = q * iters / 4; i < (q + 1) * iters / 4; i++) HIPCHK(launch_decode_engine(ep, s));
+        }
         HIPCHK(hipEventRecord(e1, s)); HIPCHK(hipEventSynchronize(e1));
         float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -181,6 +181,7 @@ __device__ __forceinline__ float comm_next_input(const EngParams& p, int lane, u
 #pragma unroll
     for (int r = 1; r < 4; r++) { const float ov = rlf(bv, 16 * r); const int oi = __builtin_amdgcn_readlane(bi, 16 * r); if (ov > v0 || (ov == v0 && oi < token)) { v0 = ov; token = oi; } }
     if (blockIdx.x == 0 && lane == 0) p.tokens[cur] = token;
+    token = (unsigned)token < (unsigned)p.vocab ? token : 0;      // the previous launch may have timed out before it wrote its partials: never read the embedding out of bounds
     const unsigned c = own_k >> 5, e = own_k & 31;
     const size_t blk = (size_t)token * (size_t)p.tok_nb + c;
     const unsigned byte = ((const __attribute__((address_space(1))) unsigned char*)(uintptr_t)p.tok_qs)[blk * 16 + (e & 15)];
@@ -977,6 +978,13 @@ hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsign
     if (op == EOP_LM) eng_pack_lm_kernel<<<dim3(lm_passes(vocab), NCU), dim3(64), 0, s>>>(w, stream, (size_t)n_layers * LAYER_BYTES, vocab);
     else eng_pack_kernel<<<dim3(op_packets(op) * NCONS * 4, NCU), dim3(64), 0, s>>>(w, op, stream, (size_t)layer * LAYER_BYTES + off_bytes);
     return hipGetLastError();
+}
+
+// resident workgroups per CU the runtime grants this kernel: the engine's 256 workgroups spin on each other and must all be resident (>= 1 per CU on a 256-CU device)
+hipError_t eng_occupancy(int* blocks_per_cu) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(decode_engine_kernel), NTHR, L_TOTAL);
 }
 
 hipError_t launch_decode_engine(const EngParams& p, hipStream_t s) {

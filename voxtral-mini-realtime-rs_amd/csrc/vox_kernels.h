@@ -174,6 +174,7 @@ hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int*
                                      const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s,
                                      uint16_t* xf = nullptr, const float* xf_w = nullptr, float* ssq_out = nullptr,     // xf: also h * xf_w as XF planes + sum of squares,
                                      long xf_group_stride = 0, int ssq_group_stride = 0);                                 // per group of 16 sequences (strides in elements)
+hipError_t launch_occupy(int workgroups, int micros, hipStream_t s);      // test hook: spin `workgroups` x 1024 threads for `micros` us
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
 hipError_t launch_gelu(float* x, long n, hipStream_t s);
 
@@ -217,6 +218,7 @@ size_t eng_state_bytes();                             // granule buffers + seria
 hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsigned char* stream, int vocab, hipStream_t s);
 void eng_state_carve(unsigned char* state, EngParams* p);      // point p's granule buffers / serial / err into a zero-initialised state block
 hipError_t launch_decode_engine(const EngParams& p, hipStream_t s);
+hipError_t eng_occupancy(int* blocks_per_cu);      // resident workgroups per CU the runtime grants decode_engine_kernel
 int eng_lds_bytes();
 
 // ---- persistent decode-layer engine for a group of <= 16 sequences (vox_engine_b16.hip): the 26 decoder layers of one batched decode step as ONE launch of 256 workgroups
@@ -253,7 +255,8 @@ hipError_t launch_engb_ssq_fold(const float* ssq256, float* ssq16, hipStream_t s
 int engb_lds_bytes();
 
 // ---- measurement knobs: VOX_* environment snapshot (taken at vox_ctx_create / vox_debug_reload_knobs); launch paths never call getenv
-void knobs_reload();
+void knobs_load_once();      // vox_ctx_create: build the snapshot if it does not exist yet (thread-safe)
+void knobs_reload();         // vox_debug_reload_knobs (tests): replace the snapshot
 const char* knob_str(const char* name);      // nullptr when unset
 
 // ---- timeline instrumentation (measurement builds only, -DVOX_TIMELINE): every q4_gemv / attn_decode launch gets the next slot and its

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <unordered_map>
 
 namespace vox {
@@ -497,18 +498,26 @@ static hipError_t ensure_dyn_lds(Kern kern, size_t lds, bool* done) {
 static hipError_t launch_dense_gemv(const GemvParams& p, int ny, int pro, int epi, hipStream_t s);
 // Measurement knobs (VOX_*): the environment is read ONCE -- at vox_ctx_create, or by vox_debug_reload_knobs() for the tests that flip a knob at run time -- into a
 // table; no launch path calls getenv.  Lookups are read-only between reloads (a reload while another thread launches is the caller's race, as with setenv itself).
-static std::unordered_map<std::string, std::string>& knob_table() { static std::unordered_map<std::string, std::string> t; return t; }
-static bool g_knobs_loaded = false;
-void knobs_reload() {
-    auto& t = knob_table(); t.clear();
+// The table is an IMMUTABLE snapshot: it is built once (first vox_ctx_create / first knob_str) and afterwards only ever REPLACED as a whole by vox_debug_reload_knobs (tests;
+// documented as not thread-safe against running launches).  Launch paths hold c_str() pointers into it, so a second vox_ctx_create on another thread -- one context per
+// GPU in one process -- must not clear and rebuild it (round-3 advisor finding: data race + use-after-free).
+static std::unordered_map<std::string, std::string>* g_knob_snap = nullptr;
+static std::once_flag g_knob_once;
+static std::unordered_map<std::string, std::string>* knobs_build() {
+    auto* t = new std::unordered_map<std::string, std::string>();
     for (char** e = environ; e && *e; ++e)
-        if (!strncmp(*e, "VOX_", 4)) { const char* eq = strchr(*e, '='); if (eq) t.emplace(std::string(*e, eq - *e), std::string(eq + 1)); }
-    g_knobs_loaded = true;
+        if (!strncmp(*e, "VOX_", 4)) { const char* eq = strchr(*e, '='); if (eq) t->emplace(std::string(*e, eq - *e), std::string(eq + 1)); }
+    return t;
+}
+void knobs_load_once() { std::call_once(g_knob_once, [] { g_knob_snap = knobs_build(); }); }
+void knobs_reload() {      // tests only: the old snapshot is leaked on purpose (pointers into it may still be held)
+    knobs_load_once();
+    g_knob_snap = knobs_build();
 }
 const char* knob_str(const char* name) {
-    if (!g_knobs_loaded) knobs_reload();
-    auto& t = knob_table(); auto it = t.find(name);
-    return it == t.end() ? nullptr : it->second.c_str();
+    knobs_load_once();
+    const auto* t = g_knob_snap; auto it = t->find(name);
+    return it == t->end() ? nullptr : it->second.c_str();
 }
 static int env_int(const char* name) { const char* v = knob_str(name); return v ? atoi(v) : 0; }
 
@@ -3297,6 +3306,7 @@ hipError_t launch_absmax(const float* x, long n, float target, float* scale_out,
 // one token-embedding row (Q4_0 row dequant, gguf/model.rs:584-618, or dense bf16 row, models/decoder.rs:250-262)
 // plus the audio embedding of the same position (gguf/model.rs:898-902, :942-948); 256 threads cooperate.
 __device__ __forceinline__ void embed_row(const Q4W& tok, int id, const float* __restrict__ arow, float* __restrict__ o, int D) {
+    id = (unsigned)id < (unsigned)tok.N ? id : 0;      // an argmax over NaN logits (a decode engine that timed out half-way leaves garbage behind) yields no index: never read out of bounds
     if (tok.fmt == WFMT_F32) {
         const float4* w = reinterpret_cast<const float4*>(tok.qt) + (size_t)id * (D >> 2);
         for (int c = threadIdx.x; c < (D >> 2); c += blockDim.x) {
@@ -3577,6 +3587,17 @@ hipError_t launch_resample(const float* x, long n_in, const float* At, int fft_i
 
 __global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+// test hook (vox_debug_occupy): workgroups that do nothing but hold their CUs for `ticks` s_memrealtime ticks (100 MHz)
+__global__ __launch_bounds__(1024) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned n = 0;
+    while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(8); n++; }
+    if (sink && n == 0xFFFFFFFFu) *sink = n;
+}
+hipError_t launch_occupy(int workgroups, int micros, hipStream_t s) {
+    occupy_kernel<<<dim3(workgroups), dim3(1024), 0, s>>>((unsigned long long)micros * 100ull, nullptr);
+    return hipGetLastError();
 }
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s) {
     int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;

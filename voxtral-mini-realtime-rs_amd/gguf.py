@@ -30,6 +30,10 @@ class Context:
         check(lib().vox_ctx_create(device, C.byref(self.h)))
         self.device = device
 
+    def occupy(self, workgroups: int, micros: int):
+        """Test hook: `workgroups` x 1024 threads spin for `micros` us on a side stream (returns at once)."""
+        check(lib().vox_debug_occupy(self.h, workgroups, micros))
+
     def synchronize(self):
         check(lib().vox_ctx_synchronize(self.h))
 
@@ -337,6 +341,10 @@ class Q4VoxtralModel:
     def set_decode_engine(self, on: bool) -> bool:
         """Persistent decode-step engine (one launch per token) on / off; returns whether it is active (it needs the real decoder geometry on a 256-CU device)."""
         a = C.c_int32(); check(lib().vox_model_set_decode_engine(self.h, 1 if on else 0, C.byref(a))); return bool(a.value)
+
+    def memory(self):
+        """Device bytes: weight arena, its primary (broadcast) part, the decode engines' weight stream, the engines' edge buffers."""
+        v = (C.c_uint64 * 4)(); check(lib().vox_model_memory(self.h, v)); return {"arena": v[0], "arena_primary": v[1], "engine_stream": v[2], "engine_state": v[3]}
 
     def set_batch_engine(self, on=None):
         """Batched decode-layer engine (one launch per 16-row group and step) on / off (None: query); returns (active, engine launches enqueued so far)."""

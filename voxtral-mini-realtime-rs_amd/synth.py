@@ -13,6 +13,7 @@ reference's test quantiser (``src/gguf/tests.rs:24-87``); it is host-side toolin
 """
 from __future__ import annotations
 
+import os
 import struct
 from dataclasses import dataclass, asdict
 
@@ -187,10 +188,15 @@ def write_gguf(path: str, tensors, version: int = 3):
 
 
 HEAVY_OUTLIER_CHANNELS = (7, 301, 1024, 1777, 2048, 3000)      # residual-stream channels whose producers (decoder wo / w2 rows) are scaled x50
+PEAKED_TOKENS = tuple(1021 + 5003 * i for i in range(int(os.environ.get('VOX_SYNTH_PEAKED_N', '24'))))     # `peaked`: the vocabulary rows whose block scales are multiplied by PEAKED_GAIN
+PEAKED_GAIN = float(os.environ.get('VOX_SYNTH_PEAKED_GAIN', '5'))      # (the environment overrides exist for tools/peaked_seed_search.py only)
 
 
-def write_synthetic_gguf(path: str, dims: ModelDims, seed: int = 42, dense_override=None, heavy_tail: bool = False):
-    """Write a synthetic Q4_0 GGUF for ``dims``.  Deterministic in (dims, seed, heavy_tail).
+def write_synthetic_gguf(path: str, dims: ModelDims, seed: int = 42, dense_override=None, heavy_tail: bool = False, peaked: bool = False):
+    """Write a synthetic Q4_0 GGUF for ``dims``.  Deterministic in (dims, seed, heavy_tail, peaked).
+    ``peaked``: a PEAKED logit distribution -- the block scales of twelve rows of the tied embedding / lm_head matrix (PEAKED_TOKENS) are multiplied by PEAKED_GAIN and
+    the final norm weight is centred on 3, so every step's argmax is one of twelve loud tokens with |logit| ~ 30 and a top-2 margin that is a sizeable fraction of the
+    largest logit (random Gaussian logits over 131 072 rows put a near-tie into almost every 100-step transcript, which caps what an ids-equal test can assert).
     ``dense_override``: optional {name: float32 array} quantised with the reference quantiser
     instead of the random generator.
     ``heavy_tail``: realistic statistics instead of N(0, sigma^2) -- every Q4 block scale is multiplied by 0.3 + |Student-t(nu=4)| (clipped at 20: outlier
@@ -218,9 +224,16 @@ def write_synthetic_gguf(path: str, dims: ModelDims, seed: int = 42, dense_overr
                                 if ch < int(shape[0]):
                                     d[ch * nbr:(ch + 1) * nbr] *= 50.0
                     b[:, 0:2] = np.minimum(d, 6.0e4).astype(np.float16).view(np.uint8).reshape(-1, 2)
+                if peaked and name == TOK:
+                    b = blk.reshape(-1, 18); nbr = int(shape[1]) // 32
+                    d = b[:, 0:2].copy().view(np.float16).astype(np.float32).reshape(-1)
+                    for tk in PEAKED_TOKENS:
+                        if tk < int(shape[0]):
+                            d[tk * nbr:(tk + 1) * nbr] *= PEAKED_GAIN
+                    b[:, 0:2] = np.minimum(d, 6.0e4).astype(np.float16).view(np.uint8).reshape(-1, 2)
                 return blk
             if kind == "norm":
-                centre = 5.0 if (heavy_tail and name == "norm.weight") else 1.0
+                centre = 5.0 if (heavy_tail and name == "norm.weight") else 3.0 if (peaked and name == "norm.weight") else 1.0
                 return (centre + sigma * rng.standard_normal(ne)).astype(np.float32)
             return (sigma * rng.standard_normal(ne)).astype(np.float32)
         return make
