@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line.  Extras in the same line (never `value`):
   `f32`         BASELINE configs[1]: the same clip through the f32 SafeTensors path (dense bf16 weights, N = 1)
   `fleurs_like` BASELINE configs[4] stand-in: 647 clips with FLEURS-like durations sharded LPT over the ranks, 64-clip length-bucketed batches per rank (--fleurs-batch)
                 (replaces bin/transcribe.rs:112-126's serial loop); aggregate RTF, tok/s, LPT imbalance (every N)
+  `piecewise`   the reference's metric loop (bin/e2e_bench.rs:179-224) call for call through the C ABI from C (tools/e2e_piecewise.c), N = 1
   `roofline`    dominant decode kernel, HIP events on the library stream + committed PMC traffic;  `cpu_baseline`  CPU oracle, bounded sample
 """
 from __future__ import annotations
@@ -110,6 +111,30 @@ def f32_extra(pkg, ctx, t_embed, seconds, reps=3):
             "checkpoint_write_s": round(t_gen, 1), "load_s": round(t_load, 1)}
 
 
+def piecewise_extra(pkg, gguf_path, x, ref_ids, reps=3):
+    """The reference's OWN metric loop (bin/e2e_bench.rs:179-224: embed_tokens_from_ids -> + audio row -> forward_hidden_with_cache -> lm_head -> argmax -> scalar read-back,
+    per token) replayed call for call through the C ABI by a plain C11 program (tools/e2e_piecewise.c; its own process and model load, gcc-built here): what a drop-in
+    `e2e-bench` over this library reports -- next to `value`, which is the fused vox_transcribe_audio path."""
+    import subprocess, tempfile
+    d = tempfile.mkdtemp(prefix="vox_pw_"); exe = os.path.join(d, "e2e_piecewise"); wav = os.path.join(d, "clip.f32")
+    pkg_dir = os.path.dirname(pkg.build.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "e2e_piecewise.c"), "-o", exe,
+                           "-L" + pkg_dir, "-lvoxtral_hip", "-lm", "-Wl,-rpath," + pkg_dir])
+    np.asarray(x, dtype=np.float32).tofile(wav)
+    r = subprocess.run([exe, gguf_path, wav, str(reps)], capture_output=True, text=True, timeout=900)
+    if r.returncode not in (0, 3):
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    ids = res.pop("ids")
+    a, b = res["lm_head+argmax"], res["lm_head_argmax"]
+    return {"workload": "bin/e2e_bench.rs:138-254 call for call over include/voxtral_hip.h from C11 (tools/e2e_piecewise.c): host preprocess, encode_audio, then per token "
+                        "embed_tokens_from_ids -> tensor add -> forward_hidden_with_cache (one decode-engine launch) -> lm_head -> argmax + read-back, on device pointers",
+            "tok_per_s": a["tok_per_s"], "decode_ms": a["decode_ms"], "encode_ms": a["encode_ms"], "preprocess_ms": res["preprocess_ms"], "rtf": a["rtf"], "decode_tokens": a["decode_tokens"],
+            "tok_per_s_with_lm_head_argmax": b["tok_per_s"], "decode_engine": res["decode_engine"], "reps": res["reps"],
+            "ids_equal_fused_path": bool(a["ids_equal_transcribe_audio"] and b["ids_equal_transcribe_audio"] and list(map(int, ref_ids)) == ids),
+            "note": "tok_per_s = ids / decode-stage seconds as bin/e2e_bench.rs:236-240 (prefill included), the reference's definition"}
+
+
 def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch, simulate_world=0, bcast_bytes=0):
     """BASELINE configs[4] stand-in (no FLEURS offline): `n_clips` synthetic clips with FLEURS-like durations, LPT-sharded over the ranks
     (shard.run_sharded), each rank running `batch`-clip length-bucketed batches (64: four concurrent 16-row groups) through vox_transcribe_batch; results gathered in input order.
@@ -194,6 +219,7 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("VOX_CPU_BASELINE_S", "16.0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=16, help="also report BASELINE configs[3] (B utterances through vox_transcribe_batch) at N=1; 0 = skip")
+    ap.add_argument("--no-piecewise", action="store_true", help="skip the piecewise extra (the reference's e2e-bench decode loop call for call through the C ABI, tools/e2e_piecewise.c, N = 1)")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 SafeTensors extra (BASELINE configs[1], N = 1)")
     ap.add_argument("--fleurs-clips", type=int, default=647, help="clips of the FLEURS-like sharded extra (BASELINE configs[4] stand-in); 0 = skip")
     ap.add_argument("--simulate-world", type=int, default=8, help="N = 1 only: also run each of W ranks' share of the FLEURS-like corpus serially on this GPU and report the predicted 1 -> W scaling (0 = skip)")
@@ -381,6 +407,11 @@ def main():
                             "decode_layer_engine": bool(eng_on), "engine_launches_per_batch": (eng_n1 - eng_n0) // reps}
             for pp in ptrs:
                 ctx.free(pp)
+        if world == 1 and not args.no_piecewise:
+            try:
+                out["piecewise"] = piecewise_extra(pkg, path, x, ids)
+            except Exception as e:
+                out["piecewise"] = {"error": str(e)}
         if world == 1 and not args.no_f32:
             try:
                 out["f32"] = f32_extra(pkg, ctx, t_embed, args.seconds)

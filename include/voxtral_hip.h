@@ -250,6 +250,26 @@ int32_t vox_embed_tokens_from_ids(vox_model* m, const int32_t* ids, int32_t n, f
 int32_t vox_forward_hidden_with_cache(vox_model* m, const float* x_MxD, int32_t M, const float* t_embed,
                                       vox_cache* cache, float* out_MxD);                              /* host in/out */
 int32_t vox_lm_head(vox_model* m, const float* hidden_MxD, int32_t M, float* logits_MxV);            /* host in/out */
+/* Device-resident forms of the same surface (mem_kind as everywhere else; VOX_MEM_DEVICE copies nothing and synchronises nothing), for a caller that drives
+ * decode piece by piece the way bin/e2e_bench.rs:179-224 and web/bindings.rs:357-424 do on Burn tensors:
+ *     embed_tokens_from_ids -> audio_pos + text_embed -> forward_hidden_with_cache -> lm_head -> argmax(2) -> into_scalar
+ * All workspaces are model-owned (no allocation per call).  A single-row forward_hidden_with_cache against a decoder cache of <= 1024 rows runs as ONE launch of the
+ * persistent decode engine when that is active (vox_model_set_decode_engine) -- the launch that also computes the row's lm_head; vox_lm_head_ex / vox_lm_head_argmax
+ * on the hidden buffer it handed out (`*hidden_ws`, READ-ONLY for the caller, valid until the next decoder call on the model) then return those logits / that token
+ * instead of streaming the lm_head again.  Any other hidden pointer is multiplied for real.  Engine hand-off timeouts (shared GPU) surface as VOX_ERR_HIP at the next
+ * synchronising call (vox_lm_head_argmax, host-kind outputs); the cache length is rolled back where the failing call itself advanced it, repeat the step.
+ * ids are always host memory (the reference passes &[i32]). */
+int32_t vox_embed_tokens_from_ids_ex(vox_model* m, const int32_t* ids_host, int32_t n, float* out_nxD, int32_t mem_kind);
+/* `audio_pos + text_embed` (bin/e2e_bench.rs:212, gguf/model.rs:902,946): out[i] = a[i] + b[i] on the context's stream */
+int32_t vox_tensor_add(vox_ctx* ctx, const float* a, const float* b, size_t n, float* out, int32_t mem_kind);
+/* out_MxD_or_null: where to copy the rows (may be NULL with VOX_MEM_DEVICE when hidden_ws_or_null is given); *hidden_ws_or_null: the model-owned device buffer holding them */
+int32_t vox_forward_hidden_with_cache_ex(vox_model* m, const float* x_MxD, int32_t M, const float* t_embed, vox_cache* cache, float* out_MxD_or_null,
+                                         const float** hidden_ws_or_null, int32_t mem_kind);
+int32_t vox_lm_head_ex(vox_model* m, const float* hidden_MxD, int32_t M, float* logits_MxV, int32_t mem_kind);
+/* `logits.argmax(2)` + the scalar read-back (bin/e2e_bench.rs:219-220; lowest index wins ties): ids_host[M]; synchronises the stream */
+int32_t vox_argmax_rows(vox_ctx* ctx, const float* logits_MxV, int32_t M, int32_t V, int32_t* ids_host, int32_t mem_kind);
+/* lm_head + argmax + read-back in one call: M token ids come back instead of M x 512 KB of logits; synchronises the stream */
+int32_t vox_lm_head_argmax(vox_model* m, const float* hidden_MxD, int32_t M, int32_t* ids_host, int32_t mem_kind);
 /* Q4VoxtralModel::generate_step_with_cache, gguf/model.rs:857-867 (text tokens only: embed -> decoder against the cache -> final norm -> lm_head) in one call;
  * token_ids[n] host, logits[n][vocab] host; the cache advances by n. */
 int32_t vox_generate_step_with_cache(vox_model* m, const int32_t* token_ids, int32_t n, const float* t_embed, vox_cache* cache, float* logits_nxV);

@@ -153,6 +153,31 @@ def _build_abi_smoke(tmp):
     return exe
 
 
+def _build_e2e_piecewise(tmp):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.join(root, "voxtral-mini-realtime-rs_amd")
+    exe = os.path.join(str(tmp), "e2e_piecewise")
+    r = subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "e2e_piecewise.c"), "-o", exe,
+                        "-L" + pkg_dir, "-lvoxtral_hip", "-lm", "-Wl,-rpath," + pkg_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_e2e_piecewise_c_program_builds_and_fails_cleanly_without_a_gpu(pkg, tmp_path):
+    """tools/e2e_piecewise.c (the reference's e2e-bench decode loop over the device-resident decoder surface) is valid C11 against the header and links; with no
+    usable device it stops at vox_ctx_create with the library's message -- no CPU path behind the ABI."""
+    import subprocess
+    import numpy as np
+    exe = _build_e2e_piecewise(tmp_path)
+    wav = tmp_path / "x.f32"; np.zeros(1600, np.float32).tofile(str(wav))
+    n = __import__("ctypes").c_int32(-1)
+    if pkg.lib().vox_device_count(__import__("ctypes").byref(n)) == 0 and n.value > 0:
+        return      # a GPU box: the device run is tests/test_gpu_model.py / test_gpu_fullsize.py
+    r = subprocess.run([exe, "/nonexistent.gguf", str(wav)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "vox_ctx_create" in r.stderr
+
+
 def test_header_is_valid_c11_and_links(pkg, tmp_path):
     """include/voxtral_hip.h through a real C compiler: tests/abi_smoke.c (C11, -Wall -Wextra -Werror) includes the header, calls ~25 entry points with the declared
     types and links against libvoxtral_hip.so -- ctypes only checks names, this catches header / implementation signature drift.  Without a GPU the program runs the

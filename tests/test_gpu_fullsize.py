@@ -420,6 +420,112 @@ def test_full_decode_engine_vs_per_operator_path(pkg, full, seconds, seed):
     assert np.array_equal(ids_g, ids_e) and np.array_equal(ids_og, ids_o)
 
 
+def _piecewise_loop(pkg, m, ctx, mel, t, fused):
+    """bin/e2e_bench.rs:158-231 on device pointers through the C ABI's device-resident decoder surface."""
+    D, V = m.config.dec_dim, m.config.vocab
+    audio = m.encode_audio(mel)[0]; S = audio.shape[0]
+    d_audio = ctx.upload(audio); d_text = ctx.alloc(38 * D * 4); d_in = ctx.alloc(38 * D * 4); d_log = ctx.alloc(38 * V * 4)
+    dec = m.decoder(); cache = dec.create_cache_preallocated(S)
+    try:
+        dec.embed_tokens_from_ids_dev(np.array([1] + [32] * 37, np.int32), d_text)
+        pkg.tensor_add_dev(ctx, d_audio, d_text, 38 * D, d_in)
+        hid = dec.forward_hidden_with_cache_dev(d_in, 38, t, cache)
+        if fused:
+            tok = int(dec.lm_head_argmax(hid, 38)[-1])
+        else:
+            dec.lm_head_dev(hid, 38, d_log); tok = int(pkg.argmax_rows_dev(ctx, d_log + 37 * V * 4, 1, V)[0])
+        gen = [tok]; last_logits = None
+        for pos in range(39, S):
+            dec.embed_tokens_from_ids_dev(np.array([gen[-1]], np.int32), d_text)
+            pkg.tensor_add_dev(ctx, d_audio + (pos - 1) * D * 4, d_text, D, d_in)
+            hid = dec.forward_hidden_with_cache_dev(d_in, 1, t, cache)
+            if fused:
+                gen.append(int(dec.lm_head_argmax(hid, 1)[0]))
+            else:
+                dec.lm_head_dev(hid, 1, d_log); gen.append(int(pkg.argmax_rows_dev(ctx, d_log, 1, V)[0]))
+        if not fused:
+            last_logits = ctx.download(d_log, (V,)); last_hidden = ctx.download(hid, (D,))
+            return np.array(gen, np.int32), last_logits, last_hidden
+        return np.array(gen, np.int32), None, None
+    finally:
+        cache.close()
+        for p_ in (d_audio, d_text, d_in, d_log):
+            ctx.free(p_)
+
+
+@pytest.mark.parametrize("engine", [True, False])
+def test_full_piecewise_decoder_surface_equals_transcribe_streaming(pkg, full, engine):
+    """The reference's own decode loop (bin/e2e_bench.rs:179-224: embed_tokens_from_ids -> + audio row -> forward_hidden_with_cache -> lm_head -> argmax) on the
+    device-resident C-ABI surface gives the ids of the fused vox_transcribe_streaming, with the decode engine (a single-row forward_hidden_with_cache = ONE engine launch
+    that also produces the logits lm_head returns) and on the per-operator launches; vox_lm_head_argmax agrees with lm_head + argmax; the hidden row the engine hands
+    out multiplies (for real, through the GEMM) to the logits it produced itself."""
+    m, _, ctx = full
+    if m.set_decode_engine(engine) != engine:
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    t = pkg.TimeEmbedding(3072).embed(6.0); mel = _mel_of(pkg, ctx, 16.0, 1234)
+    ref = m.transcribe_streaming(mel, t)
+    ids_a, lg, hid = _piecewise_loop(pkg, m, ctx, mel, t, fused=False)
+    ids_b, _, _ = _piecewise_loop(pkg, m, ctx, mel, t, fused=True)
+    assert len(ref) == 108 and np.array_equal(ids_a, ref) and np.array_equal(ids_b, ref)
+    # the handed-out hidden row from ANOTHER buffer: multiplied for real by the Q4 operator -> the logits the engine launch produced itself
+    d_h = ctx.upload(hid); d_l = ctx.alloc(131072 * 4)
+    m.decoder().lm_head_dev(d_h, 1, d_l); real = ctx.download(d_l, (131072,)); ctx.free(d_h); ctx.free(d_l)
+    top = float(np.abs(real).max()); err = float(np.abs(real - lg).max())
+    print(f"piecewise loop (engine {engine}): 108 ids equal; engine-made logits vs lm_head GEMM of the handed-out hidden row: {err:.2e} (largest |logit| {top:.2f})")
+    assert err <= 2e-4 * top and int(real.argmax()) == int(lg.argmax())
+
+
+def test_full_e2e_piecewise_c_program(pkg, full, tmp_path):
+    """tools/e2e_piecewise.c: the reference's e2e-bench loop, call for call, from plain C11 over include/voxtral_hip.h (its own process, its own model load): both variants'
+    ids equal vox_transcribe_audio's; prints the tok/s a drop-in e2e-bench would report."""
+    import json, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); pkg_dir = os.path.dirname(pkg.build.LIB_PATH)
+    exe = str(tmp_path / "e2e_piecewise")
+    r = subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "e2e_piecewise.c"), "-o", exe,
+                        "-L" + pkg_dir, "-lvoxtral_hip", "-lm", "-Wl,-rpath," + pkg_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    x = pkg.synth.synth_audio(16.0, seed=1234); wav = str(tmp_path / "clip.f32"); x.astype(np.float32).tofile(wav)
+    path = os.path.join(cache_dir(), "full_q4_seed42.gguf")
+    r = subprocess.run([exe, path, wav, "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = res["lm_head+argmax"], res["lm_head_argmax"]
+    print(f"e2e_piecewise (C, engine {res['decode_engine']}): call-for-call {a['tok_per_s']:.0f} tok/s (decode {a['decode_ms']:.1f} ms, encode {a['encode_ms']:.1f} ms), "
+          f"with vox_lm_head_argmax {b['tok_per_s']:.0f} tok/s")
+    assert a["ids_equal_transcribe_audio"] and b["ids_equal_transcribe_audio"] and a["decode_tokens"] == 108
+    m, _, ctx = full
+    assert np.array_equal(np.array(res["ids"], np.int32), m.transcribe_audio(x, pkg.TimeEmbedding(3072).embed(6.0)))
+
+
+@pytest.mark.parametrize("engine", [True, False])
+def test_full_single_decode_launch_vs_oracle_all_logits(pkg, orc, full, engine):
+    """The oracle's own decoder state -> ONE decode step of the HIP path -> the hidden row and ALL 131 072 logits against the oracle (<= 2e-4 of the largest), for the
+    persistent engine (one launch = 26 layers + final norm + lm_head) and for the per-operator launches: prefill on the oracle's audio embeddings, then three steps fed
+    with the ORACLE's token and audio rows (no error is carried from step to step)."""
+    m, o, _ = full
+    if m.set_decode_engine(engine) != engine:
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    x = pkg.synth.synth_audio(1.2, seed=77); t = pkg.TimeEmbedding(3072).embed(6.0)
+    xn = x.copy(); orc.lib().orc_peak_normalize(xn, xn.size, 0.95)
+    mel = np.ascontiguousarray(orc.mel_compute_log(orc.pad_audio(xn)).T)
+    ref_audio = o.encode_audio(mel)
+    dec = m.decoder(); ids = np.array([1] + [32] * 37, dtype=np.int32)
+    x0 = ref_audio[:38] + o.embed_tokens(ids)
+    oc = o.cache(64); c = dec.create_cache_preallocated(64)
+    rh = o.forward_hidden_with_cache(x0, t, oc); dec.forward_hidden_with_cache(x0[None], t, c)
+    tok = int(o.lm_head(rh[-1:]).argmax()); worst_h = worst_l = 0.0
+    for step in range(3):
+        xs = ref_audio[38 + step:39 + step] + o.embed_tokens(np.array([tok], np.int32))
+        rh = o.forward_hidden_with_cache(xs, t, oc); gh = dec.forward_hidden_with_cache(xs[None], t, c)[0]
+        rl = o.lm_head(rh); gl = dec.lm_head(gh[None])[0]      # engine: the logits of the SAME launch (the rows handed back are recognised); per-operator: the GEMV
+        worst_h = max(worst_h, rel_err(gh, rh)); worst_l = max(worst_l, rel_err(gl, rl))
+        assert gl.shape == (1, 131072) and int(gl.argmax()) == int(rl.argmax())
+        tok = int(rl.argmax())
+    o.cache_free(oc)
+    print(f"one decode launch vs oracle (engine {engine}): hidden {worst_h:.2e}, all 131072 logits {worst_l:.2e} of the largest")
+    assert worst_h < TOL and worst_l < TOL
+
+
 def test_full_decode_loop_and_prefill_knob_paths(pkg, full, monkeypatch):
     """The measurement knobs that select the OLDER forms of two round-3 changes still give the product's results at full size: the two-launch decode step
     (VOX_ENGINE_ARGMAX_IN=0: engine launch + argmax / embedding launch) and one step per graph (VOX_DECODE_UNROLL=1) -> identical ids; the prefill's separate

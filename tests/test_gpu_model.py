@@ -334,6 +334,19 @@ def test_abi_smoke_c_program_on_device(pkg, tmp_path):
     assert "device path ok" in r.stdout, r.stdout
 
 
+def test_e2e_piecewise_c_program_on_device_tiny(pkg, tmp_path):
+    """tools/e2e_piecewise.c on the tiny model (per-operator launches: the engine needs the real geometry): the reference's decode loop call for call over the
+    device-resident decoder surface reproduces vox_transcribe_audio's ids, with lm_head + argmax and with vox_lm_head_argmax."""
+    import json, subprocess
+    from test_abi_cpu import _build_e2e_piecewise
+    path, _ = tiny_gguf()
+    wav = tmp_path / "clip.f32"; pkg.synth.synth_audio(6.0, seed=5).astype(np.float32).tofile(str(wav))
+    r = subprocess.run([_build_e2e_piecewise(tmp_path), path, str(wav), "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["lm_head+argmax"]["ids_equal_transcribe_audio"] and res["lm_head_argmax"]["ids_equal_transcribe_audio"] and res["lm_head+argmax"]["decode_tokens"] > 20
+
+
 def test_generate_step_with_cache_equals_composed_calls(pkg, tiny):
     """Q4VoxtralModel::generate_step_with_cache (gguf/model.rs:857-867) as ONE C-ABI call against embed_tokens_from_ids -> forward_hidden_with_cache -> lm_head:
     the same kernels in the same order, so the logits are bit-identical, for a multi-token prefix and for single-token steps; the cache advances alike."""

@@ -120,6 +120,12 @@ SIGNATURES = {
     "vox_embed_tokens_from_ids": (i32, [vp, vp, i32, vp]),
     "vox_forward_hidden_with_cache": (i32, [vp, vp, i32, vp, vp, vp]),
     "vox_lm_head": (i32, [vp, vp, i32, vp]),
+    "vox_embed_tokens_from_ids_ex": (i32, [vp, vp, i32, vp, i32]),
+    "vox_tensor_add": (i32, [vp, vp, vp, sz, vp, i32]),
+    "vox_forward_hidden_with_cache_ex": (i32, [vp, vp, i32, vp, vp, vp, P(vp), i32]),
+    "vox_lm_head_ex": (i32, [vp, vp, i32, vp, i32]),
+    "vox_argmax_rows": (i32, [vp, vp, i32, i32, vp, i32]),
+    "vox_lm_head_argmax": (i32, [vp, vp, i32, vp, i32]),
     "vox_get_stage_timings": (i32, [vp, P(Timings)]),
     "vox_bench_decode_gemv": (i32, [vp, i32, i32, P(C.c_double), P(C.c_double), P(C.c_char_p)]),
     "vox_debug_timeline_start": (i32, [vp, i32, i32]),

@@ -700,6 +700,13 @@ struct vox_model {
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0, graph_mode = 0;
     const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
+    // piecewise decoder surface (embed_tokens_from_ids / forward_hidden_with_cache / lm_head on caller-owned caches): model-owned workspaces, and the decode engine's
+    // layer table for the caller's cache.  pw_memo: row 0 of pw_hidden is the final norm's output of an engine launch that ALSO produced that row's logits (pw_logits)
+    // and argmax partials (pw_part_*), so lm_head on that very buffer has nothing left to compute.
+    float *pw_x = nullptr, *pw_hidden = nullptr, *pw_logits = nullptr; size_t pw_x_cap = 0, pw_hidden_cap = 0, pw_logits_cap = 0;
+    float* pw_part_val = nullptr; int* pw_part_idx = nullptr; int* pw_ids = nullptr; int pw_ids_cap = 0; int* pw_zero = nullptr;
+    EngLayerTab* pw_tab = nullptr; const vox_cache* pw_tab_cache = nullptr; const float* pw_tab_k = nullptr;
+    bool pw_memo = false, pw_eng_used = false;
     vox_timings timings{};
 };
 
@@ -1084,7 +1091,7 @@ static void model_release(vox_model* m) {
     if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
                     (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_state, (void*)m->eng_tab, (void*)m->engb_state[0], (void*)m->engb_state[1], (void*)m->engb_state[2], (void*)m->engb_state[3],
-                    (void*)m->engb_tab[0], (void*)m->engb_tab[1], (void*)m->engb_tab[2], (void*)m->engb_tab[3]})
+                    (void*)m->engb_tab[0], (void*)m->engb_tab[1], (void*)m->engb_tab[2], (void*)m->engb_tab[3], (void*)m->pw_x, (void*)m->pw_hidden, (void*)m->pw_logits, (void*)m->pw_part_val, (void*)m->pw_part_idx, (void*)m->pw_ids, (void*)m->pw_zero, (void*)m->pw_tab})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -2223,40 +2230,191 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     return r;
 }
 
-extern "C" int32_t vox_embed_tokens_from_ids(vox_model* m, const int32_t* ids, int32_t n, float* out) {
+// ------------------------------------------------------------------------------------------------
+// Piecewise decoder surface: the loop of bin/e2e_bench.rs:179-224 and web/bindings.rs:357-424 drives decode as
+//   embed_tokens_from_ids -> (+ audio row) -> forward_hidden_with_cache -> lm_head -> argmax -> scalar read-back
+// on device-resident tensors.  The `_ex` entries take mem_kind like the rest of the header (VOX_MEM_DEVICE: nothing is copied, nothing is synchronised), use
+// model-owned workspaces (no hipMalloc / hipFree per call), and a single-row forward_hidden_with_cache on an engine-eligible cache is ONE launch of the decode
+// engine -- which computes that row's lm_head as well; lm_head / lm_head_argmax on the hidden buffer it returned find the logits already there.
+// ------------------------------------------------------------------------------------------------
+static int32_t pw_ids_dev(vox_model* m, const int32_t* ids, int n) {      // host token ids -> m->pw_ids (range-checked)
+    const vox_model_cfg& c = m->cfg;
+    for (int i = 0; i < n; i++) ARGCHK(ids[i] >= 0 && ids[i] < c.vocab, "token id %d out of range", ids[i]);
+    if (m->pw_ids_cap < n) {
+        if (m->pw_ids) HIPCHK(hipFree(m->pw_ids));
+        m->pw_ids = nullptr; m->pw_ids_cap = 0;
+        const int cap = std::max(n, 64); HIPCHK(hipMalloc((void**)&m->pw_ids, (size_t)cap * 4)); m->pw_ids_cap = cap;
+    }
+    HIPCHK(hipMemcpyAsync(m->pw_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, m->ctx->stream));
+    return VOX_OK;
+}
+// is the decode engine usable for ONE row against the caller's cache?  Builds the engine's layer table for that cache on first use.
+static bool pw_engine_ready(vox_model* m, vox_cache* kc) {
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    if (!m->eng_ok || !m->eng_on || m->eng_suspended || kc->max_seq > 1024 || kc->len >= kc->max_seq) return false;
+    if (engine_stream_prepare(m) != VOX_OK || !m->eng_ready) return false;
+    if (!m->pw_tab) {
+        if (hipMalloc((void**)&m->pw_tab, sizeof(EngLayerTab) * 32) != hipSuccess) { (void)hipGetLastError(); m->pw_tab = nullptr; return false; }
+        if (hipMalloc((void**)&m->pw_part_val, 256 * 4) != hipSuccess || hipMalloc((void**)&m->pw_part_idx, 256 * 4) != hipSuccess || hipMalloc((void**)&m->pw_zero, 4) != hipSuccess ||
+            hipMemsetAsync(m->pw_zero, 0, 4, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
+    if (!m->pw_part_val || !m->pw_part_idx || !m->pw_zero) return false;
+    if (m->pw_tab_cache != kc || m->pw_tab_k != kc->k) {
+        const size_t lf = cache_layer_floats(m, kc);
+        std::vector<EngLayerTab> tab(c.dec_layers);
+        for (int l = 0; l < c.dec_layers; l++) tab[l] = EngLayerTab{m->dec[l].attn_norm, m->dec[l].ffn_norm, m->dec[l].ada_mul, kc->k + (size_t)l * lf, kc->v + (size_t)l * lf};
+        if (hipMemcpyAsync(m->pw_tab, tab.data(), sizeof(EngLayerTab) * c.dec_layers, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return false; }
+        m->pw_tab_cache = kc; m->pw_tab_k = kc->k;
+    }
+    return true;
+}
+static EngParams pw_engine_params(vox_model* m, const vox_cache* kc, const float* x) {
+    const vox_model_cfg& c = m->cfg;
+    EngParams ep{}; ep.stream = m->eng_stream; ep.cu_stride = eng_stream_bytes(c.dec_layers, c.vocab) / 256; ep.layers = m->pw_tab; ep.n_layers = c.dec_layers; ep.h_in = x; ep.final_norm = m->dec_norm;
+    ep.pos_ptr = m->pw_zero; ep.pos_off = kc->len; ep.rope_cos = m->dec_cos; ep.rope_sin = m->dec_sin; ep.max_seq = kc->max_seq; ep.window = c.dec_window; ep.eps = c.norm_eps;
+    eng_state_carve(m->eng_state, &ep); ep.part_val = m->pw_part_val; ep.part_idx = m->pw_part_idx; ep.logits_out = m->pw_logits; ep.vocab = c.vocab; ep.tl = nullptr; ep.tl_layer = -1;
+    ep.flags = m->eng_flags; ep.pace_ticks = (m->eng_flags & 512) ? 0 : m->eng_pace; ep.ag_delay_ticks = (m->eng_flags & 512) ? m->eng_pace : 0;
+    return ep;
+}
+// after a stream synchronisation that covered a copy of the engine's error word into eng_err_host: a hand-off timeout fails the call loudly (the cache row of that step is
+// rewritten when the caller repeats it), counts a strike and re-arms the engine; three strikes switch it off for the model
+static int32_t pw_engine_verdict(vox_model* m) {
+    if (!m->pw_eng_used) return VOX_OK;
+    m->pw_eng_used = false;
+    const unsigned e = m->eng_err_host[0];
+    if (!e) return VOX_OK;
+    m->eng_strikes++; m->pw_memo = false;
+    HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), m->ctx->stream)); m->eng_launches = 0; graphs_destroy(m);
+    if (m->eng_strikes >= 3) { m->eng_ok = false; m->eng_on = false; }
+    return fail(VOX_ERR_HIP, "decode engine: hand-off timeout (code %u, workgroup %u), strike %d of 3: the GPU is shared; repeat the step%s", e & 0xff, (e >> 8) & 0xff, m->eng_strikes,
+                m->eng_strikes >= 3 ? " (the engine is now switched off, the per-operator launches serve it)" : "");
+}
+static int32_t pw_sync(vox_model* m) {      // synchronise the stream; if an engine launch is outstanding, fetch its verdict with the same wait
+    hipStream_t s = m->ctx->stream;
+    if (m->pw_eng_used) { EngParams ep{}; eng_state_carve(m->eng_state, &ep); HIPCHK(hipMemcpyAsync(m->eng_err_host, ep.err, 8, hipMemcpyDeviceToHost, s)); }
+    HIPCHK(hipStreamSynchronize(s));
+    return pw_engine_verdict(m);
+}
+
+extern "C" int32_t vox_embed_tokens_from_ids_ex(vox_model* m, const int32_t* ids, int32_t n, float* out, int32_t mem_kind) {
     ARGCHK(m && ids && out && n > 0, "bad argument"); VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
-    for (int i = 0; i < n; i++) ARGCHK(ids[i] >= 0 && ids[i] < c.vocab, "token id %d out of range", ids[i]);
-    DevBuf di, dx; HIPCHK(di.alloc((size_t)n * 4)); HIPCHK(dx.alloc((size_t)n * c.dec_dim * 4));
-    HIPCHK(hipMemcpyAsync(di.p, ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(launch_embed(m->tok.w, di.as<int>(), n, nullptr, c.dec_dim, nullptr, 0, 0, dx.as<float>(), s));
-    HIPCHK(hipMemcpyAsync(out, dx.p, (size_t)n * c.dec_dim * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    VOXCHK(pw_ids_dev(m, ids, n));
+    float* dx = out;
+    if (mem_kind != VOX_MEM_DEVICE) { VOXCHK(ensure(&m->pw_x, &m->pw_x_cap, (size_t)n * c.dec_dim)); dx = m->pw_x; }
+    HIPCHK(launch_embed(m->tok.w, m->pw_ids, n, nullptr, c.dec_dim, nullptr, 0, 0, dx, s));
+    if (mem_kind != VOX_MEM_DEVICE) { HIPCHK(hipMemcpyAsync(out, dx, (size_t)n * c.dec_dim * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
+    return VOX_OK;
+}
+extern "C" int32_t vox_embed_tokens_from_ids(vox_model* m, const int32_t* ids, int32_t n, float* out) { return vox_embed_tokens_from_ids_ex(m, ids, n, out, VOX_MEM_HOST); }
+
+// `audio_pos + text_embed` (e2e_bench.rs:212, model.rs:902,946) on the context's stream
+extern "C" int32_t vox_tensor_add(vox_ctx* c, const float* a, const float* b, size_t n, float* out, int32_t mem_kind) {
+    ARGCHK(c && a && b && out && n > 0, "bad argument"); VOXCHK(ctx_bind(c));
+    if (mem_kind == VOX_MEM_DEVICE) { HIPCHK(launch_add_rows(a, b, out, (long)n, c->stream)); return VOX_OK; }
+    for (size_t i = 0; i < n; i++) out[i] = a[i] + b[i];
     return VOX_OK;
 }
 
-extern "C" int32_t vox_forward_hidden_with_cache(vox_model* m, const float* x, int32_t M, const float* t_embed, vox_cache* kc, float* out) {
-    ARGCHK(m && x && t_embed && kc && out && M > 0, "bad argument"); ARGCHK(kc->m == m && kc->kind == 0, "cache belongs to another model or is an encoder cache"); VOXCHK(ctx_bind(m->ctx));
-    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+extern "C" int32_t vox_forward_hidden_with_cache_ex(vox_model* m, const float* x, int32_t M, const float* t_embed, vox_cache* kc, float* out, const float** hidden_ws,
+                                                    int32_t mem_kind) {
+    ARGCHK(m && x && t_embed && kc && (out || hidden_ws) && M > 0, "bad argument"); ARGCHK(kc->m == m && kc->kind == 0, "cache belongs to another model or is an encoder cache"); VOXCHK(ctx_bind(m->ctx));
+    ARGCHK(mem_kind == VOX_MEM_DEVICE || out, "a host result needs an output buffer");
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream; const int D = c.dec_dim;
     ARGCHK(kc->len + M <= kc->max_seq, "KV cache overflow: %d + %d > %d", kc->len, M, kc->max_seq);
     VOXCHK(vox_model_set_t_embed(m, t_embed));
-    DevBuf dx, dy; HIPCHK(dx.alloc((size_t)M * c.dec_dim * 4)); HIPCHK(dy.alloc((size_t)M * c.dec_dim * 4));
-    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)M * c.dec_dim * 4, hipMemcpyHostToDevice, s));
-    if (M == 1) { if (m->d_wo_acc) HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * c.dec_dim * 8, s)); VOXCHK(decoder_step_dev(m, dx.as<float>(), kc, nullptr, kc->len)); }
-    else VOXCHK(decoder_prefill_dev(m, dx.as<float>(), M, kc, kc->len));
+    m->pw_memo = false;
+    // the residual stream is updated in place by the layer stack: always work on the model's copy of the input rows
+    VOXCHK(ensure(&m->pw_x, &m->pw_x_cap, (size_t)M * D)); VOXCHK(ensure(&m->pw_hidden, &m->pw_hidden_cap, (size_t)M * D));
+    const bool eng = M == 1 && pw_engine_ready(m, kc);
+    if (eng) VOXCHK(ensure(&m->pw_logits, &m->pw_logits_cap, (size_t)c.vocab));
+    const float* xin = x;
+    if (mem_kind != VOX_MEM_DEVICE) { HIPCHK(hipMemcpyAsync(m->pw_x, x, (size_t)M * D * 4, hipMemcpyHostToDevice, s)); xin = m->pw_x; }
+    if (eng) {      // one launch: 26 layers against the caller's cache + final norm + lm_head (logits + argmax partials)
+        if (m->eng_launches + 16 > (1ull << 25)) { HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), s)); m->eng_launches = 0; }
+        m->eng_launches += 1;
+        const EngParams ep = pw_engine_params(m, kc, xin);
+        HIPCHK(launch_decode_engine(ep, s));
+        HIPCHK(launch_eng_hidden(ep, m->pw_hidden, s));
+        m->pw_memo = true; m->pw_eng_used = true;
+    } else {
+        if (xin != m->pw_x) HIPCHK(hipMemcpyAsync(m->pw_x, xin, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+        if (M == 1) { if (m->d_wo_acc) HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * D * 8, s)); VOXCHK(decoder_step_dev(m, m->pw_x, kc, nullptr, kc->len)); }
+        else VOXCHK(decoder_prefill_dev(m, m->pw_x, M, kc, kc->len));
+        HIPCHK(launch_rms_norm(m->pw_x, D, M, D, m->dec_norm, nullptr, c.norm_eps, m->pw_hidden, D, s));   // model.rs:676
+    }
     kc->len += M;
-    HIPCHK(launch_rms_norm(dx.as<float>(), c.dec_dim, M, c.dec_dim, m->dec_norm, nullptr, c.norm_eps, dy.as<float>(), c.dec_dim, s));   // model.rs:676
-    HIPCHK(hipMemcpyAsync(out, dy.p, (size_t)M * c.dec_dim * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    if (hidden_ws) *hidden_ws = m->pw_hidden;
+    if (out && out != m->pw_hidden) HIPCHK(hipMemcpyAsync(out, m->pw_hidden, (size_t)M * D * 4, mem_kind == VOX_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    if (mem_kind != VOX_MEM_DEVICE) {
+        const int32_t r = pw_sync(m);
+        if (r != VOX_OK) { kc->len -= M; return r; }
+    }
+    return VOX_OK;
+}
+extern "C" int32_t vox_forward_hidden_with_cache(vox_model* m, const float* x, int32_t M, const float* t_embed, vox_cache* kc, float* out) {
+    return vox_forward_hidden_with_cache_ex(m, x, M, t_embed, kc, out, nullptr, VOX_MEM_HOST);
+}
+
+// does `hidden` name the row whose logits the engine launch of the last forward_hidden_with_cache already produced?
+static bool pw_memo_hit(const vox_model* m, const float* hidden, int M, int mem_kind) { return m->pw_memo && M == 1 && mem_kind == VOX_MEM_DEVICE && hidden == m->pw_hidden; }
+
+extern "C" int32_t vox_lm_head_ex(vox_model* m, const float* hidden, int32_t M, float* logits, int32_t mem_kind) {
+    ARGCHK(m && hidden && logits && M > 0, "bad argument"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+    if (pw_memo_hit(m, hidden, M, mem_kind)) {      // computed by the engine launch that produced `hidden`
+        if (logits != m->pw_logits) HIPCHK(hipMemcpyAsync(logits, m->pw_logits, (size_t)c.vocab * 4, hipMemcpyDeviceToDevice, s));
+        return VOX_OK;
+    }
+    const float* hx = hidden; float* ly = logits;
+    if (mem_kind != VOX_MEM_DEVICE) {
+        // (a host caller that passes back the rows forward_hidden_with_cache handed out gets the same engine-made logits: compare the bytes, 12 KB)
+        if (m->pw_memo && M == 1) {
+            std::vector<float> hh(c.dec_dim); HIPCHK(hipMemcpyAsync(hh.data(), m->pw_hidden, (size_t)c.dec_dim * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+            if (!std::memcmp(hh.data(), hidden, (size_t)c.dec_dim * 4)) {
+                HIPCHK(hipMemcpyAsync(logits, m->pw_logits, (size_t)c.vocab * 4, hipMemcpyDeviceToHost, s));
+                return pw_sync(m);
+            }
+        }
+        VOXCHK(ensure(&m->pw_x, &m->pw_x_cap, (size_t)M * c.dec_dim)); VOXCHK(ensure(&m->pw_logits, &m->pw_logits_cap, (size_t)M * c.vocab));
+        m->pw_memo = false;      // pw_logits is about to be overwritten
+        HIPCHK(hipMemcpyAsync(m->pw_x, hidden, (size_t)M * c.dec_dim * 4, hipMemcpyHostToDevice, s)); hx = m->pw_x; ly = m->pw_logits;
+    }
+    VOXCHK(q4_linear_dev(m->ctx, m->tok.w, nullptr, hx, c.dec_dim, M, ly, c.vocab));
+    if (mem_kind != VOX_MEM_DEVICE) { HIPCHK(hipMemcpyAsync(logits, ly, (size_t)M * c.vocab * 4, hipMemcpyDeviceToHost, s)); return pw_sync(m); }
+    return VOX_OK;
+}
+extern "C" int32_t vox_lm_head(vox_model* m, const float* hidden, int32_t M, float* logits) { return vox_lm_head_ex(m, hidden, M, logits, VOX_MEM_HOST); }
+
+// `logits.argmax(2)` + the scalar read-back (e2e_bench.rs:219-220): ids always host; synchronises the stream
+extern "C" int32_t vox_argmax_rows(vox_ctx* c, const float* logits, int32_t M, int32_t V, int32_t* ids, int32_t mem_kind) {
+    ARGCHK(c && logits && ids && M > 0 && V > 0, "bad argument"); VOXCHK(ctx_bind(c));
+    if (mem_kind != VOX_MEM_DEVICE) {
+        for (int r = 0; r < M; r++) { const float* row = logits + (size_t)r * V; int b = 0; for (int i = 1; i < V; i++) if (row[i] > row[b]) b = i; ids[r] = b; }
+        return VOX_OK;
+    }
+    DevBuf di; HIPCHK(di.alloc_pooled(c, (size_t)M * 4));
+    HIPCHK(launch_argmax_rows(logits, M, V, di.as<int>(), c->stream));
+    HIPCHK(hipMemcpyAsync(ids, di.p, (size_t)M * 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
     return VOX_OK;
 }
 
-extern "C" int32_t vox_lm_head(vox_model* m, const float* hidden, int32_t M, float* logits) {
-    ARGCHK(m && hidden && logits && M > 0, "bad argument"); VOXCHK(ctx_bind(m->ctx));
+// lm_head + argmax in one call: the token id comes back, not 512 KB of logits per row.  ids host; synchronises.
+extern "C" int32_t vox_lm_head_argmax(vox_model* m, const float* hidden, int32_t M, int32_t* ids, int32_t mem_kind) {
+    ARGCHK(m && hidden && ids && M > 0, "bad argument"); VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
-    DevBuf dx, dy; HIPCHK(dx.alloc((size_t)M * c.dec_dim * 4)); HIPCHK(dy.alloc((size_t)M * c.vocab * 4));
-    HIPCHK(hipMemcpyAsync(dx.p, hidden, (size_t)M * c.dec_dim * 4, hipMemcpyHostToDevice, s));
-    VOXCHK(q4_linear_dev(m->ctx, m->tok.w, nullptr, dx.as<float>(), c.dec_dim, M, dy.as<float>(), c.vocab));
-    HIPCHK(hipMemcpyAsync(logits, dy.p, (size_t)M * c.vocab * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
-    return VOX_OK;
+    if (m->pw_ids_cap < M) { if (m->pw_ids) HIPCHK(hipFree(m->pw_ids)); m->pw_ids = nullptr; m->pw_ids_cap = 0; const int cap = std::max(M, 64); HIPCHK(hipMalloc((void**)&m->pw_ids, (size_t)cap * 4)); m->pw_ids_cap = cap; }
+    if (pw_memo_hit(m, hidden, M, mem_kind)) {
+        HIPCHK(launch_argmax_final(m->pw_part_val, m->pw_part_idx, 256, m->pw_ids, nullptr, 0, 0, s));
+    } else {
+        const float* hx = hidden;
+        if (mem_kind != VOX_MEM_DEVICE) { VOXCHK(ensure(&m->pw_x, &m->pw_x_cap, (size_t)M * c.dec_dim)); HIPCHK(hipMemcpyAsync(m->pw_x, hidden, (size_t)M * c.dec_dim * 4, hipMemcpyHostToDevice, s)); hx = m->pw_x; }
+        VOXCHK(ensure(&m->pw_logits, &m->pw_logits_cap, (size_t)M * c.vocab)); m->pw_memo = false;
+        VOXCHK(q4_linear_dev(m->ctx, m->tok.w, nullptr, hx, c.dec_dim, M, m->pw_logits, c.vocab));
+        HIPCHK(launch_argmax_rows(m->pw_logits, M, c.vocab, m->pw_ids, s));
+    }
+    HIPCHK(hipMemcpyAsync(ids, m->pw_ids, (size_t)M * 4, hipMemcpyDeviceToHost, s));
+    return pw_sync(m);
 }
 
 // Q4VoxtralModel::generate_step_with_cache (gguf/model.rs:857-867): decoder.forward_with_cache(token_ids) = embed + layers against the cache + final norm, then lm_head --
@@ -2264,19 +2422,20 @@ extern "C" int32_t vox_lm_head(vox_model* m, const float* hidden, int32_t M, flo
 extern "C" int32_t vox_generate_step_with_cache(vox_model* m, const int32_t* token_ids, int32_t n, const float* t_embed, vox_cache* kc, float* logits) {
     ARGCHK(m && token_ids && t_embed && kc && logits && n > 0, "bad argument"); ARGCHK(kc->m == m && kc->kind == 0, "cache belongs to another model or is an encoder cache"); VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
-    for (int i = 0; i < n; i++) ARGCHK(token_ids[i] >= 0 && token_ids[i] < c.vocab, "token id %d out of range", token_ids[i]);
     ARGCHK(kc->len + n <= kc->max_seq, "KV cache overflow: %d + %d > %d", kc->len, n, kc->max_seq);
-    VOXCHK(vox_model_set_t_embed(m, t_embed));
-    DevBuf di, dx, dn, dy; HIPCHK(di.alloc((size_t)n * 4)); HIPCHK(dx.alloc((size_t)n * c.dec_dim * 4)); HIPCHK(dn.alloc((size_t)n * c.dec_dim * 4)); HIPCHK(dy.alloc((size_t)n * c.vocab * 4));
-    HIPCHK(hipMemcpyAsync(di.p, token_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(launch_embed(m->tok.w, di.as<int>(), n, nullptr, c.dec_dim, nullptr, 0, 0, dx.as<float>(), s));
-    if (n == 1) { if (m->d_wo_acc) HIPCHK(hipMemsetAsync(m->d_wo_acc, 0, (size_t)c.dec_layers * c.dec_dim * 8, s)); VOXCHK(decoder_step_dev(m, dx.as<float>(), kc, nullptr, kc->len)); }
-    else VOXCHK(decoder_prefill_dev(m, dx.as<float>(), n, kc, kc->len));
-    kc->len += n;
-    HIPCHK(launch_rms_norm(dx.as<float>(), c.dec_dim, n, c.dec_dim, m->dec_norm, nullptr, c.norm_eps, dn.as<float>(), c.dec_dim, s));
-    VOXCHK(q4_linear_dev(m->ctx, m->tok.w, nullptr, dn.as<float>(), c.dec_dim, n, dy.as<float>(), c.vocab));
-    HIPCHK(hipMemcpyAsync(logits, dy.p, (size_t)n * c.vocab * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
-    return VOX_OK;
+    VOXCHK(pw_ids_dev(m, token_ids, n));
+    VOXCHK(ensure(&m->pw_x, &m->pw_x_cap, (size_t)n * c.dec_dim));
+    HIPCHK(launch_embed(m->tok.w, m->pw_ids, n, nullptr, c.dec_dim, nullptr, 0, 0, m->pw_x, s));
+    const float* hid = nullptr;
+    VOXCHK(vox_forward_hidden_with_cache_ex(m, m->pw_x, n, t_embed, kc, nullptr, &hid, VOX_MEM_DEVICE));      // n == 1 on an eligible cache: one engine launch, logits included
+    if (!pw_memo_hit(m, hid, n, VOX_MEM_DEVICE)) {
+        VOXCHK(ensure(&m->pw_logits, &m->pw_logits_cap, (size_t)n * c.vocab));
+        VOXCHK(q4_linear_dev(m->ctx, m->tok.w, nullptr, hid, c.dec_dim, n, m->pw_logits, c.vocab));
+    }
+    HIPCHK(hipMemcpyAsync(logits, m->pw_logits, (size_t)n * c.vocab * 4, hipMemcpyDeviceToHost, s));
+    const int32_t r = pw_sync(m);
+    if (r != VOX_OK) kc->len -= n;
+    return r;
 }
 
 extern "C" int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out) { ARGCHK(m && out, "null argument"); *out = m->timings; return VOX_OK; }

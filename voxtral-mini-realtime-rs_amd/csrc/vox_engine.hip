@@ -942,7 +942,25 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams 
     }
 }
 
+// the final norm's output of the launch that has just ended (see launch_eng_hidden)
+__global__ __launch_bounds__(256) void eng_hidden_kernel(const u64* __restrict__ H, const u64* __restrict__ SS, float eps, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int t = threadIdx.x;
+    red[t] = __uint_as_float((unsigned)SS[t]);
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    const float rstd = 1.0f / sqrtf(red[0] / (float)ED + eps);
+    const int k = blockIdx.x * 256 + t;
+    out[k] = __uint_as_float((unsigned)H[k]) * (1.0f / 512.0f) * rstd;
+}
+
 }  // namespace
+
+hipError_t launch_eng_hidden(const EngParams& p, float* out, hipStream_t s) {
+    const bool even = ((2 * p.n_layers) & 1) == 0;      // stage 2 L is always even: H0 / SS0
+    eng_hidden_kernel<<<dim3(ED / 256), dim3(256), 0, s>>>(even ? p.H0 : p.H1, even ? p.SS0 : p.SS1, p.eps, out);
+    return hipGetLastError();
+}
 
 bool eng_geometry_ok(int D, int n_heads, int n_kv, int hd, int ffn, int vocab, int max_seq) {
     return D == ED && n_heads == ENH && n_kv == ENKV && hd == EHD && ffn == EF && vocab > 0 && vocab % NCU == 0 && max_seq > 0 && max_seq <= SC_MAX;

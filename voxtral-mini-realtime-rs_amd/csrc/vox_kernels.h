@@ -177,6 +177,7 @@ hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int*
 hipError_t launch_occupy(int workgroups, int micros, hipStream_t s);      // test hook: spin `workgroups` x 1024 threads for `micros` us
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
 hipError_t launch_gelu(float* x, long n, hipStream_t s);
+hipError_t launch_argmax_rows(const float* x, int rows, int V, int* out, hipStream_t s);      // out[r] = argmax of row r (lowest index wins ties)
 
 // ---- persistent decode-step engine (vox_engine.hip): the whole single-stream decode step -- 26 layers + final norm + tied lm_head + argmax
 // partials -- as ONE launch of 256 workgroups (one per CU) x 8 waves: wave 0 streams this CU's slice of every Q4 operator, in consumption order,
@@ -218,6 +219,9 @@ size_t eng_state_bytes();                             // granule buffers + seria
 hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsigned char* stream, int vocab, hipStream_t s);
 void eng_state_carve(unsigned char* state, EngParams* p);      // point p's granule buffers / serial / err into a zero-initialised state block
 hipError_t launch_decode_engine(const EngParams& p, hipStream_t s);
+// after a launch without flags 65536 has ended: the final norm's OUTPUT of that step (what forward_hidden_with_cache returns, gguf/model.rs:676) from the launch's own last
+// all-gather (H0 = h * final_norm * 512 granules, SS0 = 256 partial sums of squares) -> out[3072]
+hipError_t launch_eng_hidden(const EngParams& p, float* out, hipStream_t s);
 hipError_t eng_occupancy(int* blocks_per_cu);      // resident workgroups per CU the runtime grants decode_engine_kernel
 int eng_lds_bytes();
 

@@ -3607,6 +3607,38 @@ hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, h
 __global__ void gelu_kernel(float* __restrict__ x, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = gelu_f(x[i]);
 }
+// argmax of every row of x [rows][V] (lowest index wins ties, NaN never wins): `logits.argmax(2)` of the piecewise decode loop (bin/e2e_bench.rs:219).  One
+// 1024-thread workgroup per row, float4 loads; a 131 072-column row is 512 KB = a few microseconds.
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restrict__ x, int V, int* __restrict__ out) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const float* row = x + (size_t)blockIdx.x * V;
+    float v = -INFINITY; int idx = 0x7fffffff;
+    const int V4 = ((reinterpret_cast<uintptr_t>(row) & 15) == 0) ? V >> 2 : 0;
+    for (int i = threadIdx.x; i < V4; i += 1024) {
+        const float4 q = reinterpret_cast<const float4*>(row)[i];
+        const float e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (e[u] > v) { v = e[u]; idx = 4 * i + u; }      // ascending index per thread: strict > keeps the lowest
+    }
+    for (int i = 4 * V4 + threadIdx.x; i < V; i += 1024) { const float e = row[i]; if (e > v || (e == v && i < idx)) { v = e; idx = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(idx, o);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = v; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) if (bv[w] > v || (bv[w] == v && bi[w] < idx)) { v = bv[w]; idx = bi[w]; }
+        out[blockIdx.x] = idx == 0x7fffffff ? 0 : idx;
+    }
+}
+hipError_t launch_argmax_rows(const float* x, int rows, int V, int* out, hipStream_t s) {
+    if (rows <= 0 || V <= 0) return hipErrorInvalidValue;
+    argmax_rows_kernel<<<dim3(rows), dim3(1024), 0, s>>>(x, V, out);
+    return hipGetLastError();
+}
 hipError_t launch_gelu(float* x, long n, hipStream_t s) {
     int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     gelu_kernel<<<dim3(blocks), dim3(256), 0, s>>>(x, n);

@@ -317,6 +317,40 @@ class Q4LanguageModel:
         return out.reshape(shp[:-1] + (self._m.config.vocab,))
 
 
+    # ---- device-resident forms (VOX_MEM_DEVICE): raw device pointers in, nothing copied, nothing synchronised -- the loop of bin/e2e_bench.rs:179-224 on "tensors"
+    def embed_tokens_from_ids_dev(self, ids, out_ptr):
+        ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1)
+        check(lib().vox_embed_tokens_from_ids_ex(self._m.h, _ptr(ids), ids.size, C.c_void_p(out_ptr), 1))
+
+    def forward_hidden_with_cache_dev(self, x_ptr, rows, t_embed, caches: LayerCaches, out_ptr=None):
+        """-> device pointer of the model-owned hidden rows (read-only; valid until the next decoder call).  One row on an engine-eligible cache = one engine launch."""
+        ws = C.c_void_p()
+        check(lib().vox_forward_hidden_with_cache_ex(self._m.h, C.c_void_p(x_ptr), rows, _ptr(_f32(t_embed).reshape(-1)), caches.h,
+                                                     None if out_ptr is None else C.c_void_p(out_ptr), C.byref(ws), 1))
+        return ws.value
+
+    def lm_head_dev(self, hidden_ptr, rows, logits_ptr):
+        check(lib().vox_lm_head_ex(self._m.h, C.c_void_p(hidden_ptr), rows, C.c_void_p(logits_ptr), 1))
+
+    def lm_head_argmax(self, hidden_ptr, rows):
+        """lm_head + argmax(2) + read-back: `rows` token ids (host)."""
+        ids = np.zeros(rows, dtype=np.int32)
+        check(lib().vox_lm_head_argmax(self._m.h, C.c_void_p(hidden_ptr), rows, _ptr(ids), 1))
+        return ids
+
+
+def tensor_add_dev(ctx, a_ptr, b_ptr, n, out_ptr):
+    """out = a + b on device pointers (n floats), on the context's stream"""
+    check(lib().vox_tensor_add(ctx.h, C.c_void_p(a_ptr), C.c_void_p(b_ptr), n, C.c_void_p(out_ptr), 1))
+
+
+def argmax_rows_dev(ctx, logits_ptr, rows, vocab):
+    """`logits.argmax(2)` + scalar read-back of device logits [rows][vocab] -> host ids; synchronises the stream"""
+    ids = np.zeros(rows, dtype=np.int32)
+    check(lib().vox_argmax_rows(ctx.h, C.c_void_p(logits_ptr), rows, vocab, _ptr(ids), 1))
+    return ids
+
+
 class Q4VoxtralModel:
     """gguf/model.rs:759-989"""
 
