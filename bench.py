@@ -261,24 +261,13 @@ def main():
     path = full_gguf_path(pkg, args.seed, rank, barrier)
 
     t0 = time.time()
-    loader = pkg.Q4ModelLoader.from_file(path)
-    if world > 1:
-        # rank 0 parses + repacks; the PRIMARY part of the device arena (the Q4 row planes + f32 tensors: 2.5 GB) reaches the other ranks by ONE RCCL
-        # broadcast over xGMI; every rank derives the rest on its own GPU (tile-ordered copies: arena_finalize; the decode engine's stream: first decode step)
-        model = loader.load(ctx, layout_only=(rank != 0))
-        ptr, nbytes = model.arena(); bcast_bytes = int(nbytes)
-        stage = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local}")
-        if rank == 0:
-            ctx.copy(stage.data_ptr(), ptr, nbytes)
-        torch.cuda.synchronize(); tb = time.time()
-        dist.broadcast(stage, src=0)
-        torch.cuda.synchronize(); bcast_s = time.time() - tb
-        if rank != 0:
-            ctx.copy(ptr, stage.data_ptr(), nbytes)
-            model.arena_finalize()
-        del stage
-    else:
-        model = loader.load(ctx); bcast_s = 0.0; bcast_bytes = 0
+    # N > 1: rank 0 parses + repacks; the PRIMARY part of the device arena (the Q4 row planes + f32 tensors: 2.5 GB) reaches the other ranks by ONE RCCL broadcast over
+    # xGMI issued on the arena memory itself; every rank derives the rest on its own GPU (shard.load_replicated -- the same start-up cli.py / wer.py --gpus N use)
+    import importlib
+    shard_mod = importlib.import_module(pkg.__name__ + ".shard")
+    bst = {}
+    model = shard_mod.load_replicated(pkg, ctx, path, rank, world, local=local, stats=bst)
+    bcast_s = float(bst.get("seconds", 0.0)); bcast_bytes = int(bst.get("bytes", 0))
     load_s = time.time() - t0
     cfg = model.config
     t_embed = pkg.TimeEmbedding(cfg.dec_dim).embed(6.0)
@@ -346,6 +335,12 @@ def main():
         }
         if fleurs is not None:
             out["fleurs_like"] = fleurs
+            if "error" not in fleurs:
+                # STRONG scaling, first-class next to the weak-scaling `value`: the fixed 647-clip FLEURS-like corpus (BASELINE configs[4] stand-in) sharded over the N ranks --
+                # total work fixed as N grows; the driver's per-N lines give the configs[4] curve directly (tok/s at N / tok/s at 1)
+                out["strong_scaling"] = {"metric": "fleurs_like_corpus_tok_per_s", "value": fleurs["tok_per_s"], "unit": "tok/s", "n_gpus": world, "scaling": "strong",
+                                         "wall_s": fleurs["wall_s"], "rtf": fleurs["rtf"], "clips": fleurs["clips"], "audio_s": fleurs["audio_s"],
+                                         "predicted_8gpu_scaling_from_one_gpu": (fleurs.get("simulated_world") or {}).get("predicted_scaling")}
         # ---- roofline of the dominant kernel: the fused gate/up Q4 GEMV (w1|w3, 26 launches per token), HIP events on our stream
         names = ["qkv", "wo", "w1w3", "w2", "lm_head"]; per = {}
         per_step_us = 0.0; per_step_bytes = 0.0

@@ -630,6 +630,26 @@ def test_full_layout_only_arena_copy_start_up(pkg, full):
         b.close()
 
 
+def test_full_load_replicated_rccl_world1(pkg, full):
+    """The multi-GPU start-up the product uses (shard.load_replicated: cli.py / wer.py / bench.py --gpus N) with a REAL RCCL process group on this one GPU (world 1, `nccl`
+    backend; tests/rccl_startup_worker.py, its own process so torch's HIP runtime is loaded first): RCCL initialises, the broadcast executes on the library's arena memory
+    (zero-copy torch view), a layout-only model filled by a broadcast and finalised decodes the same 108 ids as the model that parsed the file -- and as this process's."""
+    import json, subprocess, sys
+    shard = pkg.shard
+    path = os.path.join(cache_dir(), "full_q4_seed42.gguf")
+    env = dict(os.environ); env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_startup_worker.py"), path, str(shard.free_port())],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    m, _, ctx = full
+    x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
+    ids = [int(v) for v in m.transcribe_audio(x, t)]
+    print(f"RCCL world-1 start-up: backend {res['backend']} {res['nccl_version']}, broadcast of {res['stats']['bytes'] / 1e9:.2f} GB in {res['stats']['seconds']:.3f} s")
+    assert res["backend"] == "nccl" and res["stats"]["broadcast"] and 2.4e9 < res["stats"]["bytes"] < 2.7e9
+    assert len(ids) == 108 and res["ids_a"] == ids and res["ids_b"] == ids
+
+
 def test_full_30s_heavytail_vs_oracle_golden(pkg, orc):
     """Stress statistics at full size against the CPU oracle (tests/golden/make_fullsize_heavytail_golden.py): Student-t(4) block scales, six x50 outlier channels in
     the decoder's residual stream, |logit| up to 200, on a 30 s clip (234 decoder positions; the encoder's 750-frame window bites).  Exercises the hi/lo-bf16 splits of the

@@ -153,3 +153,70 @@ def test_length_buckets_are_balanced(pkg):
     assert all(costs[b[0][k]] >= costs[b[0][k + 1]] for k in range(40))                      # still sorted by length
     assert shard.length_buckets([], costs, 64) == [] and [len(x) for x in shard.length_buckets(list(range(64)), costs, 64)] == [64]
     assert [len(x) for x in shard.length_buckets(list(range(130)), [1.0] * 130, 64)] == [44, 43, 43]
+
+
+def _replicated_worker(rank, world, port, pkg_dir, q):
+    """Fake loader / model / context with a HOST arena: the start-up protocol of shard.load_replicated without a GPU."""
+    import importlib.util
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("shard", os.path.join(pkg_dir, "shard.py"))
+    shard = importlib.util.module_from_spec(spec); spec.loader.exec_module(shard)
+    events = []
+
+    class FakeModel:
+        def __init__(self, layout_only):
+            self.buf = np.zeros(4096, np.uint8) if layout_only else (np.arange(4096) % 251).astype(np.uint8)      # rank 0 "parsed the file"
+            self.finalized = False
+
+        def arena(self):
+            return self.buf.ctypes.data, self.buf.nbytes
+
+        def arena_finalize(self):
+            events.append("finalize"); self.finalized = True
+
+    class FakeLoader:
+        def load(self, ctx, layout_only=False):
+            events.append("layout_only" if layout_only else "full_load"); self.m = FakeModel(layout_only); return self.m
+
+    class FakeCtx:
+        def synchronize(self):
+            events.append("sync")
+
+    ld = FakeLoader(); st = {}
+    m = shard.load_replicated(None, FakeCtx(), "unused.gguf", rank, world, loader=ld, stats=st,
+                              as_tensor=lambda p, n: torch.from_numpy(np.ctypeslib.as_array((__import__("ctypes").c_uint8 * n).from_address(p))))
+    q.put((rank, events, int(m.buf.astype(np.int64).sum()), m.finalized, st))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_load_replicated_protocol_world2_gloo(pkg):
+    """shard.load_replicated (the multi-GPU start-up of cli.py / wer.py / bench.py --gpus N) on CPU, world 2, gloo, with a fake loader whose arena is host memory:
+    rank 0 loads the file, rank 1 only lays the arena out; ONE broadcast issued on the arena memory itself (no staging buffer) makes rank 1's arena equal to rank 0's;
+    only the receiver rebuilds the derived copies; the library stream is synchronised before the collective.  Without a process group (world 1) it is a plain load."""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    shard = __import__("importlib").import_module(pkg.__name__ + ".shard")
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = shard.free_port()
+    ps = [ctx.Process(target=_replicated_worker, args=(r, 2, port, os.path.dirname(pkg.__file__), q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = {}
+    for _ in ps:
+        rank, events, chk, fin, st = q.get(timeout=180); res[rank] = (events, chk, fin, st)
+    for p in ps:
+        p.join(timeout=60); assert p.exitcode == 0
+    want = int((np.arange(4096) % 251).sum())
+    assert res[0][0] == ["full_load", "sync"] and res[1][0] == ["layout_only", "sync", "finalize"]
+    assert res[0][1] == want and res[1][1] == want and res[1][2] and not res[0][2]
+    assert res[0][3]["bytes"] == 4096 and res[0][3]["broadcast"] and res[1][3]["broadcast"]
+
+    class L:
+        def load(self, ctx, layout_only=False):
+            assert not layout_only; return "model"
+    st = {}
+    assert shard.load_replicated(None, None, "x", 0, 1, loader=L(), stats=st) == "model" and st == {"bytes": 0, "seconds": 0.0, "broadcast": False}
+    with pytest.raises(RuntimeError):
+        shard.load_replicated(None, None, "x", 0, 2, loader=L())

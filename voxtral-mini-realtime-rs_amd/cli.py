@@ -131,15 +131,30 @@ def main(argv=None):
         rc, out = pkg.shard.spawn_ranks(a.gpus, os.path.abspath(__file__), list(argv if argv is not None else sys.argv[1:]), capture=True)
         sys.stdout.write(out); sys.stdout.flush()
         return rc
+    own_group = False
     if world > 1:
         a.device = int(os.environ.get("LOCAL_RANK", rank))
+        if a.gguf:
+            # torch BEFORE the first call into libvoxtral_hip.so (it bundles its own libamdhip64: one HIP runtime per process), then RCCL for the start-up broadcast
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(a.device)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if not dist.is_initialized():
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", a.device)); own_group = True
     tok_path = a.tokenizer or os.path.join(a.model, "tekken.json")
     if not os.path.exists(tok_path):
         log(f"Error: Tokenizer not found at {tok_path}"); return 1
     tokenizer = pkg.VoxtralTokenizer.from_file(tok_path)
     ctx = pkg.Context(a.device)
     t0 = time.time()
-    if a.gguf:
+    if a.gguf and world > 1:
+        # N replicas: rank 0 reads the file, the packed weights reach the other GPUs with ONE RCCL broadcast over xGMI (shard.load_replicated) instead of N file reads
+        st = {}
+        log(f"[rank {rank}] Loading Q4 GGUF model from {a.gguf} ({'file' if rank == 0 else 'layout only + broadcast'})")
+        model = pkg.shard.load_replicated(pkg, ctx, a.gguf, rank, world, local=a.device, stats=st)
+        log(f"[rank {rank}] weight broadcast: {st.get('bytes', 0) / 1e9:.2f} GB in {st.get('seconds', 0.0):.3f}s")
+    elif a.gguf:
         log(f"Loading Q4 GGUF model from {a.gguf}"); model = pkg.Q4ModelLoader.from_file(a.gguf).load(ctx)
     else:
         st = os.path.join(a.model, "consolidated.safetensors")
@@ -196,6 +211,9 @@ def main(argv=None):
     else:
         for i in range(len(paths)):
             print(one(i), flush=True)
+    if own_group:
+        import torch.distributed as dist
+        dist.barrier(); dist.destroy_process_group()
     return rc
 
 

@@ -77,6 +77,56 @@ def run_sharded(items: Sequence, costs: Sequence[float], work: Callable, rank: i
     return out
 
 
+class _DevSpan:
+    """A raw device allocation as a __cuda_array_interface__ object, so torch can wrap it without a copy (`torch.as_tensor(span, device=...)`)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _arena_tensor(ptr: int, nbytes: int, local: int):
+    import torch
+    return torch.as_tensor(_DevSpan(ptr, nbytes), device=f"cuda:{local}")
+
+
+def load_replicated(pkg, ctx, path, rank: int, world: int, local: int | None = None, group=None, loader=None, as_tensor=None, stats: dict | None = None):
+    """Multi-GPU start-up of the replicas (SURVEY.md section 8e; replaces N independent `Q4ModelLoader::from_file(..).load()` calls, bin/transcribe.rs:88-100):
+    rank 0 parses + repacks the GGUF; every other rank only lays the device arena out (VOX_LOAD_LAYOUT_ONLY: header parse, no tensor data read, no upload); the
+    PRIMARY part of the arena (everything parsed from the file: 2.5 GB for the Q4 model) travels with ONE `torch.distributed.broadcast` -- RCCL over xGMI on GPUs --
+    issued directly on the arena memory (wrapped as a torch tensor through __cuda_array_interface__, no staging copy); each receiver then rebuilds the derived copies on
+    its own GPU (vox_model_arena_finalize; the decode engines' weight stream is packed at the first decode step on every rank).  No collective ever enters the data path.
+    world == 1 with an initialised process group still issues the broadcast (a one-rank RCCL broadcast: the single-GPU test of this plumbing).
+    `loader` / `as_tensor` are injection points for the CPU (gloo) test of the protocol.  Returns the model; `stats` receives bytes / seconds of the broadcast."""
+    import time
+    loader = loader or pkg.Q4ModelLoader.from_file(path)
+    dist = None
+    if world > 1 or group is not None:
+        import torch.distributed as dist_
+        dist = dist_ if dist_.is_initialized() else None
+        if world > 1 and dist is None:
+            raise RuntimeError("load_replicated: world > 1 needs an initialised torch.distributed process group")
+    if dist is None:
+        if stats is not None:
+            stats.update(bytes=0, seconds=0.0, broadcast=False)
+        return loader.load(ctx)
+    local = rank if local is None else local
+    model = loader.load(ctx, layout_only=(rank != 0))
+    ptr, nbytes = model.arena()
+    t = (as_tensor or (lambda p, n: _arena_tensor(p, n, local)))(ptr, nbytes)
+    ctx.synchronize()                      # rank 0's uploads / repack kernels ran on the library's stream; the collective runs on torch's
+    t0 = time.time()
+    dist.broadcast(t, src=0, group=group)
+    if t.is_cuda:
+        import torch
+        torch.cuda.synchronize(t.device)
+    dt = time.time() - t0
+    if rank != 0:
+        model.arena_finalize()
+    if stats is not None:
+        stats.update(bytes=int(nbytes), seconds=dt, broadcast=True)
+    return model
+
+
 def free_port() -> int:
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
