@@ -641,7 +641,9 @@ def test_full_load_replicated_rccl_world1(pkg, full):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_startup_worker.py"), path, str(shard.free_port())],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    res = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"ids_a"')]
+    assert lines, "no result line from the worker:\n" + r.stdout[-1500:] + "\n--- stderr ---\n" + r.stderr[-3000:]
+    res = json.loads(lines[-1])
     m, _, ctx = full
     x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
     ids = [int(v) for v in m.transcribe_audio(x, t)]

@@ -120,6 +120,8 @@ int main(int argc, char** argv) {
         CHK(launch_eng_pack(L[l].wqkv, 0, l, n_layers, stream, V, s)); CHK(launch_eng_pack(L[l].wo, 1, l, n_layers, stream, V, s));
         CHK(launch_eng_pack(L[l].w13, 2, l, n_layers, stream, V, s)); CHK(launch_eng_pack(L[l].w2, 3, l, n_layers, stream, V, s));
     }
+    unsigned char* stream_wo = dalloc<unsigned char>(engb_wo_stream_bytes(n_layers)); CHK(hipMemset(stream_wo, 0, engb_wo_stream_bytes(n_layers)));
+    for (int l = 0; l < n_layers; l++) CHK(launch_eng_pack(L[l].wo, 5, l, n_layers, stream_wo, V, s));      // wo in the XCD-group K split (the batched engine's own stream)
     unsigned char* state = dalloc<unsigned char>(engb_state_bytes()); CHK(hipMemset(state, 0, engb_state_bytes()));
     std::vector<EngLayerTab> tab(n_layers);
     for (int l = 0; l < n_layers; l++) tab[l] = EngLayerTab{L[l].attn_norm, L[l].ffn_norm, L[l].ada, kc + (size_t)l * lf, vc + (size_t)l * lf};
@@ -128,7 +130,7 @@ int main(int argc, char** argv) {
     uint16_t* xf_out = dalloc<uint16_t>(xf_u16); float* ssq_out = dalloc<float>(256 * BM);
     CHK(hipMemset(xf_out, 0, xf_u16 * 2)); CHK(hipMemset(ssq_out, 0, 256 * BM * 4));
     unsigned long long* tlbuf = dalloc<unsigned long long>(256 * 32); CHK(hipMemset(tlbuf, 0, 256 * 32 * 8));
-    EngBParams ep{}; ep.stream = stream; ep.layers = d_tab; ep.n_layers = n_layers; ep.kv_seq_stride = (long)seq_stride; ep.h_in = h_in; ep.h_stride = D; ep.n_rows = n_rows;
+    EngBParams ep{}; ep.stream = stream; ep.stream_wo = stream_wo; ep.layers = d_tab; ep.n_layers = n_layers; ep.kv_seq_stride = (long)seq_stride; ep.h_in = h_in; ep.h_stride = D; ep.n_rows = n_rows;
     ep.final_norm = final_norm; ep.pos = d_pos; ep.rope_cos = rope_c; ep.rope_sin = rope_s; ep.max_seq = max_seq; ep.window = window; ep.eps = eps;
     engb_state_carve(state, &ep); ep.xf_out = xf_out; ep.ssq_out = ssq_out; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = flags;
     CHK(hipStreamSynchronize(s));

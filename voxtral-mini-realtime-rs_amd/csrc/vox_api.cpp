@@ -694,6 +694,7 @@ struct vox_model {
     unsigned long long eng_launches = 0; unsigned eng_err_host[2] = {0, 0};
     int eng_strikes = 0; bool eng_suspended = false;      // hand-off timeouts so far (3: the engine is switched off for good); suspended: the current utterance is being re-run on the per-operator path
     // batched decode-layer engine (vox_engine_b16.hip): one launch per 16-row group and step on the same packet stream; per-group edge buffers + layer tables
+    unsigned char* eng_wob = nullptr;      // the batched engine's wo stream (XCD-group K split, launch_eng_pack op 5): 7 MB per layer
     bool engb_ok = false; unsigned char* engb_state[4] = {nullptr, nullptr, nullptr, nullptr}; EngLayerTab* engb_tab[4] = {nullptr, nullptr, nullptr, nullptr};
     bool engb_on = true; unsigned long long engb_launches = 0; int engb_strikes = 0;
     int engb_flags = 128 | 1 | 64 | 2048; unsigned engb_err_host[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -1090,7 +1091,7 @@ static void model_release(vox_model* m) {
     graphs_destroy(m);
     if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_state, (void*)m->eng_tab, (void*)m->engb_state[0], (void*)m->engb_state[1], (void*)m->engb_state[2], (void*)m->engb_state[3],
+                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_wob, (void*)m->eng_state, (void*)m->eng_tab, (void*)m->engb_state[0], (void*)m->engb_state[1], (void*)m->engb_state[2], (void*)m->engb_state[3],
                     (void*)m->engb_tab[0], (void*)m->engb_tab[1], (void*)m->engb_tab[2], (void*)m->engb_tab[3], (void*)m->pw_x, (void*)m->pw_hidden, (void*)m->pw_logits, (void*)m->pw_part_val, (void*)m->pw_part_idx, (void*)m->pw_ids, (void*)m->pw_zero, (void*)m->pw_tab})
         if (p) (void)hipFree(p);
     delete m;
@@ -1177,7 +1178,7 @@ extern "C" int32_t vox_model_weight_bytes(const vox_model* m, uint64_t* out) { A
 extern "C" int32_t vox_model_memory(const vox_model* m, uint64_t out[4]) {
     ARGCHK(m && out, "null argument");
     out[0] = m->arena_bytes; out[1] = m->arena_primary_bytes;
-    out[2] = m->eng_stream ? eng_stream_bytes(m->cfg.dec_layers, m->cfg.vocab) : 0;
+    out[2] = (m->eng_stream ? eng_stream_bytes(m->cfg.dec_layers, m->cfg.vocab) : 0) + (m->eng_wob ? engb_wo_stream_bytes(m->cfg.dec_layers) : 0);
     out[3] = m->eng_state ? eng_state_bytes() : 0;
     for (int gi = 0; gi < 4; gi++) if (m->engb_state[gi]) out[3] += engb_state_bytes();
     return VOX_OK;
@@ -1190,6 +1191,7 @@ extern "C" int32_t vox_model_arena_finalize(vox_model* m) {
     for (Q4W* w : m->tiled) HIPCHK(launch_q4_tile_build(*w, const_cast<uint4*>(w->qt), const_cast<uint16_t*>(w->st), m->ctx->stream));
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
     m->eng_ready = false; m->eng_tab_cache = nullptr;      // a stream packed from an earlier arena content is stale
+    if (m->eng_wob) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); (void)hipFree(m->eng_wob); m->eng_wob = nullptr; }
     graphs_destroy(m);
     return VOX_OK;
 }
@@ -1671,6 +1673,13 @@ static int32_t engine_prepare(vox_model* m) {
 static bool engb_prepare(vox_model* m, int n_grp) {
     if (!m->engb_ok || !m->engb_on || n_grp > 4) return false;
     if (engine_stream_prepare(m) != VOX_OK || !m->eng_ready) return false;
+    if (!m->eng_wob) {      // wo once more, in the batched engine's XCD-group K split (184 MB for 26 layers)
+        const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
+        hipError_t e = hipMalloc((void**)&m->eng_wob, engb_wo_stream_bytes(c.dec_layers));
+        if (e == hipSuccess) e = hipMemsetAsync(m->eng_wob, 0, engb_wo_stream_bytes(c.dec_layers), s);
+        for (int l = 0; l < c.dec_layers && e == hipSuccess; l++) e = launch_eng_pack(m->dec[l].wo.w, 5, l, c.dec_layers, m->eng_wob, c.vocab, s);
+        if (e != hipSuccess) { (void)hipGetLastError(); if (m->eng_wob) { (void)hipFree(m->eng_wob); m->eng_wob = nullptr; } m->engb_ok = false; return false; }
+    }
     for (int gi = 0; gi < n_grp; gi++) {
         if (m->engb_state[gi]) continue;
         hipError_t e = hipMalloc((void**)&m->engb_state[gi], engb_state_bytes());
@@ -2068,7 +2077,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
         float* hg = h + (size_t)r0 * D; float* qg = qkv + (size_t)r0 * W; const int* pg = d_pos + r0;
         if (use_eng) {
             float* ssq_e = b_ssq_e.as<float>() + (size_t)gi * (256 + 16) * 16; float* ssq_f = ssq_e + 256 * 16;
-            EngBParams ep{}; ep.stream = m->eng_stream; ep.layers = m->engb_tab[gi]; ep.n_layers = c.dec_layers; ep.kv_seq_stride = (long)seq_stride; ep.h_in = hg; ep.h_stride = D; ep.n_rows = ng;
+            EngBParams ep{}; ep.stream = m->eng_stream; ep.stream_wo = m->eng_wob; ep.layers = m->engb_tab[gi]; ep.n_layers = c.dec_layers; ep.kv_seq_stride = (long)seq_stride; ep.h_in = hg; ep.h_stride = D; ep.n_rows = ng;
             ep.final_norm = m->dec_norm; ep.pos = pg; ep.rope_cos = m->dec_cos; ep.rope_sin = m->dec_sin; ep.max_seq = max_seq; ep.window = c.dec_window; ep.eps = c.norm_eps;
             engb_state_carve(m->engb_state[gi], &ep); ep.xf_out = xf1; ep.ssq_out = ssq_e; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = m->engb_flags;
             HIPCHK(launch_decode_engine_b16(ep, sg));

@@ -990,10 +990,12 @@ hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsign
     case EOP_W13: off_bytes = OFF_W13; N = 2 * EF; K = ED; break;
     case EOP_W2: off_bytes = OFF_W2; N = ED; K = EF; break;
     case EOP_LM: off_bytes = 0; N = vocab; K = ED; break;
+    case EOP_WOB: off_bytes = 0; N = ED; K = EQD; break;      // `stream` = the batched engine's wo stream ([layer][packet][CU][bytes])
     default: return hipErrorInvalidValue;
     }
     if (w.N != N || w.K != K) return hipErrorInvalidValue;
     if (op == EOP_LM) eng_pack_lm_kernel<<<dim3(lm_passes(vocab), NCU), dim3(64), 0, s>>>(w, stream, (size_t)n_layers * LAYER_BYTES, vocab);
+    else if (op == EOP_WOB) eng_pack_kernel<<<dim3(op_packets(op) * NCONS * 4, NCU), dim3(64), 0, s>>>(w, op, stream, (size_t)layer * WOB_LAYER_BYTES);
     else eng_pack_kernel<<<dim3(op_packets(op) * NCONS * 4, NCU), dim3(64), 0, s>>>(w, op, stream, (size_t)layer * LAYER_BYTES + off_bytes);
     return hipGetLastError();
 }

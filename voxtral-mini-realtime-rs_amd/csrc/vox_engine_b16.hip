@@ -7,8 +7,9 @@
 // from L2, and the CU <-> row decomposition is the same:
 //   CU b = (g = b % 8: KV head / XCD, j = b / 8): query head h = 4 g + j / 8, slice s = j % 8
 //     q|k|v   16 + 4 + 4 weight rows x K 3072 (K split over the 12 consumer waves)            -> RoPE at each sequence's own position -> granules G, KV cache
-//     attn    head h of sequences 2 s, 2 s + 1 (six waves each: per-wave online softmax over its keys, combined through LDS)   -> XO (A fragments of wo)
-//     wo      rows [384 s, +384) x head h's 128 columns -> partial plane h of PW; the owner of columns [12 b, +12) sums the 32 planes + residual     -> XH1
+//     attn    head h of sequences 2 s, 2 s + 1 (six waves each: per-wave online softmax over its keys, combined through LDS)   -> XO (A fragments of wo, read inside the XCD group)
+//     wo      rows [96 j, +96) x the 512 columns of the group's four heads (its OWN stream, EOP_WOB: the single-stream engine splits wo by head) -> partial plane g of PW;
+//             the owner of columns [12 b, +12) sums the 8 planes + residual                                                                       -> XH1
 //     w1|w3   72 interleaved rows (36 SwiGLU outputs) x K 3072                                  -> XA (A fragments of w2, read inside the XCD group)
 //     w2      rows [96 j, +96) x the group's 1152 columns -> partial plane g of P2; the owner sums the 8 planes + residual                           -> XH0
 // Arithmetic = the batched skinny kernels' (q4_skinny_kernel): v_mfma_f32_16x16x32_bf16, A = 16 sequences x 32 columns as bf16 hi + lo (x ~ hi + lo to 2^-17), B = the Q4
@@ -56,7 +57,7 @@ struct BCtl {
     unsigned cbar, dead, gathering, gw_flag;
     unsigned xcd_ok, xcc_id, ag_flag, pub_cnt;
     unsigned qkv_flag, wo_flag, xa_flag, rs_flag;      // rs_flag: all-gather stages whose RMSNorm scales are in LDS
-    unsigned tbar[2], red_cnt, pad1;      // red_cnt: helper waves through with their share of the wo plane sum (4 per layer)
+    unsigned tbar[2], pad0, pad1;
 };
 // ---- LDS map ----
 constexpr int BL_RING = 0;
@@ -163,7 +164,9 @@ __device__ __forceinline__ void b16_loader(const EngBParams& p, BCtl* c, unsigne
     for (unsigned pk = 0; pk < n_pk; pk++) {
         const int bytes = r < PK_LAYER_M ? PK_M : PK_A;
         if (r == 0 && (int)l == p.tl_layer) tl(16);
-        const u64 src = base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes;
+        const bool wo_pk = r >= (unsigned)QKV_PK && r < (unsigned)(QKV_PK + WO_PK);      // wo: the XCD-group split lives in its own stream, [layer][packet][CU][bytes]
+        const u64 src = wo_pk ? (u64)p.stream_wo + (u64)NCU * ((u64)l * WOB_LAYER_BYTES + (u64)(r - QKV_PK) * PK_M) + (u64)blockIdx.x * (u64)PK_M
+                              : base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes;
         if (bytes == PK_M) ld.issue<PK_M>(src, lane, nodma); else ld.issue<PK_A>(src, lane, nodma);
         off += (u64)bytes;
         if (++r == PK_LAYER) { if ((int)l == p.tl_layer) tl(17); r = 0; l++; }
@@ -325,20 +328,19 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
             {   // attention outputs of head h: one flag per sequence, written by the team that computed it
                 wait_ge(&c->pub_cnt, pc0 + 2 * NCONS, c, p.err, ERR_STAGE);      // (own CU through: nothing can be complete much earlier -- no polling while it computes)
                 lds_st(&c->gathering, 1u);
-                poll_flags(p.FO, 512, BM, [&](int i) { return h * BM + i; }, tag, lane, c, p.err);
+                poll_flags(p.FO, 512, 4 * BM, [&](int i) { return 4 * g * BM + i; }, tag, lane, c, p.err);      // the group's four heads x 16 sequences: wo's K range on this CU
                 lds_st(&c->gathering, 0u);
                 lds_st(&c->wo_flag, (unsigned)l + 1u);
             }
             if (T) tl(11);
-            {   // wo: consumer waves 0..3 sum eight planes each of the CU's 12 columns (they poll the producing waves' flags themselves); fixed-order sum of the four + residual
-                wait_ge(&c->red_cnt, 4u * ((unsigned)l + 1u), c, p.err, ERR_STAGE);
+            {   // wo: the 8 planes (one per XCD group; each finishing wave of a producer flags its own tile) of the CU's 12 columns, fixed-order sum + residual -> the
+                // post-attention stream, published as the w1|w3 input
+                wait_ge(&c->pub_cnt, pc0 + 3 * NCONS, c, p.err, ERR_STAGE);
+                lds_st(&c->gathering, 1u);
+                { const int c0 = (OWN * b) % 96; poll_flags(p.FW, 1536, 16, [&](int i) { return ((i >> 1) * 32 + (b >> 3)) * 6 + (((i & 1) ? c0 + OWN - 1 : c0) >> 4); }, tag, lane, c, p.err); }
                 if (T) tl(13);
-                const float* red = reinterpret_cast<const float*>(lds + BL_PART);
-                const int n12 = min(lane >> 2, OWN - 1), mq = lane & 3;
-                f32x4 a = *reinterpret_cast<const f32x4*>(own0 + n12 * BM + 4 * mq);
-#pragma unroll
-                for (int w = 0; w < 4; w++) a += *reinterpret_cast<const f32x4*>(red + w * OWN * BM + n12 * BM + 4 * mq);
-                if (lane < 4 * OWN) *reinterpret_cast<f32x4*>(own1 + n12 * BM + 4 * mq) = a;
+                comm_reduce<NPWB>(p.PW, NPWB * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own0, own1);
+                lds_st(&c->gathering, 0u);
                 ENG_CFENCE();
                 if (!((p.flags & 16384) && b == 7 && l == 1))      // (flag 16384 = FAULT INJECTION: workgroup 7 loses a publish)
                     comm_publish_rows(p, lane, own1, gwt + (l * 2 + 1) * 16, p.XH1, p.SS1, p.F1, tag);
@@ -386,7 +388,7 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
 #else
 #define B16_PHASE __device__ __attribute__((noinline))
 #endif
-constexpr int CB_LAYER = 4;      // workgroup barriers among the consumer waves per layer
+constexpr int CB_LAYER = 5;      // workgroup barriers among the consumer waves per layer: q|k|v, wo, w1|w3 (2), w2
 __device__ __forceinline__ EngBParams kparams() {      // by value from the constant address space: the fields a phase uses become scalar loads
 #if defined(__HIP_DEVICE_COMPILE__)
     return *(const __attribute__((address_space(4))) EngBParams*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -617,52 +619,39 @@ B16_PHASE void ph_attn(int cw_, int lane, int l_) {
     tl(3);
 }
 
-// ================= wo: rows [384 s, +384) x head h's 128 columns -> plane h =================
+// ================= wo: rows [96 j, +96) x the 512 columns of the XCD group's four heads -> plane g =================
 B16_PHASE void ph_wo(int cw_, int lane, int l_) {
     B16_PROLOGUE
-    RawRec rw[4];      // tiles 2 cw, 2 cw + 1, two K-steps each: in registers before the attention outputs exist
-#pragma unroll
-    for (int i = 0; i < WO_PK; i++) {
-        int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + i, 2 * REC, sl);
-        rw[2 * i] = rec_load(bb, false, lane); rw[2 * i + 1] = rec_load(bb + REC, false, lane);
-        cs.slot_release(sl);
-    }
-    wait_ge(&c->wo_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
-    bf16x8 ah[4], al[4];
-    cs.load_a<4>(p.XO + (size_t)h * XO_HEAD, XO_HEAD, 0, ah, al);
-    tl(4);
-    const srd_t pd = make_srd(p.PW + (size_t)h * ED * BM, ED * BM * 4u);
+    unsigned char* part = lds + BL_PART;
     {
-        const f32x4 c0 = cs.cb_read(0), c1 = cs.cb_read(1), c2 = cs.cb_read(2), c3 = cs.cb_read(3);
+        const int tile = cw % 6, kh = cw / 6;
+        RawRec rw[4];      // tile cw % 6, K-steps 4 (cw / 6) .. + 3: in registers before the attention outputs exist
 #pragma unroll
         for (int i = 0; i < WO_PK; i++) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = rec_mma(rw[2 * i], ah[0], al[0], ah[1], al[1], c0, c1, a);
-            a = rec_mma(rw[2 * i + 1], ah[2], al[2], ah[3], al[3], c2, c3, a);
-            st_f4(pd, (unsigned)((384 * s + 16 * (2 * cw + i) + n) * BM + 4 * y) * 4u, a);
+            int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + i, 2 * REC, sl);
+            rw[2 * i] = rec_load(bb, false, lane); rw[2 * i + 1] = rec_load(bb + REC, false, lane);
+            cs.slot_release(sl);
         }
+        wait_ge(&c->wo_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+        bf16x8 ah[8], al[8];
+        cs.load_a<8>(p.XO + (size_t)(4 * g) * XO_HEAD, 4 * XO_HEAD, 8 * kh, ah, al);      // heads 4 g .. 4 g + 3 are contiguous: 16 blocks, this wave's half
+        tl(4);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; r++) a = rec_mma(rw[r], ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], cs.cb_read(2 * r), cs.cb_read(2 * r + 1), a);
+        // (q|k|v's partials in this region are dead: its finishing waves published before attention could start; w1|w3 writes here only after the h1 all-gather, which
+        // needs every wo tile of every CU stored)
+        *reinterpret_cast<f32x4*>(part + (tile * 2 + kh) * 1024 + lane * 16) = a;
     }
-    drain_vm();
-    if (lane == 0) st_u32(make_srd(p.FW, 3072 * 4u), (unsigned)((h * 8 + s) * NCONS + cw) * 4u, tag, false);
+    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 2)));
+    if (cw < 6) {      // wave t finishes tile t: the two K halves in a fixed order
+        const f32x4 a = *reinterpret_cast<const f32x4*>(part + (cw * 2) * 1024 + lane * 16) + *reinterpret_cast<const f32x4*>(part + (cw * 2 + 1) * 1024 + lane * 16);
+        st_f4(make_srd(p.PW + (size_t)g * ED * BM, ED * BM * 4u), (unsigned)((96 * j + 16 * cw + n) * BM + 4 * y) * 4u, a);
+        drain_vm();
+        if (lane == 0) st_u32(make_srd(p.FW, 1536 * 4u), (unsigned)((g * 32 + j) * 6 + cw) * 4u, tag, false);
+    }
     cs.published();
     tl(5);
-    if (cw < 4) {      // helper: the planes of heads [8 cw, +8) of the CU's 12 columns x 16 sequences, summed in head order -> red[cw] (the COMM wave adds the four + the residual)
-        const int c0 = (OWN * b) % 384;      // the CU's columns inside a producer's 384-row slice: tile(s) c0 / 16 .. (c0 + 11) / 16, written by wave tile / 2
-        poll_flags(p.FW, 3072, 16, [&](int i) { return ((8 * cw + (i >> 1)) * 8 + (b >> 5)) * NCONS + ((((i & 1) ? c0 + OWN - 1 : c0) >> 4) >> 1); }, tag, lane, c, p.err);
-        float* red = reinterpret_cast<float*>(lds + BL_PART) + cw * OWN * BM;
-        const srd_t sd = make_srd(p.PW, NPW * ED * BM * 4u);
-        const int n12 = min(lane >> 2, OWN - 1), mq = lane & 3;
-        const unsigned lo_ = (unsigned)((OWN * b + n12) * BM + 4 * mq) * 4u;
-        u32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = ld_frag(sd, (unsigned)(8 * cw + u) * (ED * BM * 4u) + lo_);
-        f32x4 a = __builtin_bit_cast(f32x4, v[0]);
-#pragma unroll
-        for (int u = 1; u < 8; u++) a += __builtin_bit_cast(f32x4, v[u]);
-        if (lane < 4 * OWN) *reinterpret_cast<f32x4*>(red + n12 * BM + 4 * mq) = a;
-        ENG_CFENCE();
-        if (lane == 0) __hip_atomic_fetch_add(&c->red_cnt, 1u, RLX, WG);
-    }
 }
 
 // ================= w1|w3: 72 interleaved gate / up rows x K 3072 -> 36 SwiGLU outputs x 16 sequences =================
@@ -710,7 +699,7 @@ B16_PHASE void ph_w13(int cw_, int lane, int l_) {
         { const f32x4 a = mul_tile(ra); if (n < 8) *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 4096 + (y * 8 + n) * 16) = a; }
     }
     tl(27);
-    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 2)));      // (also: every wave is through with its CB lines -> the region becomes the SwiGLU scratch)
+    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 3)));      // (also: every wave is through with its CB lines -> the region becomes the SwiGLU scratch)
     tl(28);
     if (cw < 5) {       // wave t finishes tile t: K slices summed in a fixed order, RMSNorm scale, SiLU(gate) * up -> sg[m][col]
         const float* rstd = reinterpret_cast<const float*>(lds + BL_RSTD);
@@ -727,7 +716,7 @@ B16_PHASE void ph_w13(int cw_, int lane, int l_) {
         }
     }
     tl(29);
-    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 3)));
+    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 4)));
     tl(30);
     if (cw < 3 && lane < 48) {      // 144 pieces of four columns x one sequence -> bf16 hi + lo, 8 bytes each, into the group's fragment buffer
         const int it = 48 * cw + lane, m = it & 15, hc = it >> 4;
@@ -769,7 +758,7 @@ B16_PHASE void ph_w2(int cw_, int lane, int l_) {
             *reinterpret_cast<f32x4*>(part + ((3 * tg + i) * 6 + ksl) * 1024 + lane * 16) = a;
         }
     }
-    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 4)));
+    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 5)));
     if (cw < 6) {      // wave t finishes tile t
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -871,14 +860,15 @@ hipError_t launch_engb_ssq_fold(const float* in, float* out, hipStream_t s) { en
 
 // state block: XH0 | XH1 | SS0 | SS1 | G | XO | PW | XA | P2 | F0 F1 FO FW FA F2 | XC | serial | err
 static constexpr size_t BS_XH0 = 0, BS_XH1 = BS_XH0 + XH_BYTES, BS_SS0 = BS_XH1 + XH_BYTES, BS_SS1 = BS_SS0 + (size_t)NCU * BM * 4, BS_G = BS_SS1 + (size_t)NCU * BM * 4,
-                        BS_XO = BS_G + (size_t)BM * G_ROW * 8, BS_PW = BS_XO + (size_t)ENH * XO_HEAD, BS_XA = BS_PW + (size_t)NPW * ED * BM * 4, BS_P2 = BS_XA + (size_t)ENKV * XA_GROUP,
+                        BS_XO = BS_G + (size_t)BM * G_ROW * 8, BS_PW = BS_XO + (size_t)ENH * XO_HEAD, BS_XA = BS_PW + (size_t)NPWB * ED * BM * 4, BS_P2 = BS_XA + (size_t)ENKV * XA_GROUP,
                         BS_F = BS_P2 + (size_t)NP2 * ED * BM * 4, BS_XC = BS_F + (256 + 256 + 512 + 3072 + 256 + 1536) * 4, BS_SERIAL = BS_XC + (size_t)NCU * 8, BS_ERR = BS_SERIAL + 256, BS_TOTAL = BS_ERR + 256;
 size_t engb_state_bytes() { return BS_TOTAL; }
+size_t engb_wo_stream_bytes(int n_layers) { return (size_t)n_layers * WOB_LAYER_BYTES * NCU + 1024; }
 void engb_state_carve(unsigned char* st, EngBParams* p) {
     p->XH0 = st + BS_XH0; p->XH1 = st + BS_XH1; p->SS0 = reinterpret_cast<float*>(st + BS_SS0); p->SS1 = reinterpret_cast<float*>(st + BS_SS1);
     p->G = reinterpret_cast<unsigned long long*>(st + BS_G); p->XO = st + BS_XO; p->PW = reinterpret_cast<float*>(st + BS_PW); p->XA = st + BS_XA; p->P2 = reinterpret_cast<float*>(st + BS_P2);
     unsigned* f = reinterpret_cast<unsigned*>(st + BS_F);
-    p->F0 = f; p->F1 = f + 256; p->FO = f + 512; p->FW = f + 1024; p->FA = f + 4096; p->F2 = f + 4352;      // [256] [256] [32 heads][16 sequences] [256 CUs][12 waves] [256] [256 CUs][6 tiles]
+    p->F0 = f; p->F1 = f + 256; p->FO = f + 512; p->FW = f + 1024; p->FA = f + 4096; p->F2 = f + 4352;      // [256] [256] [32 heads][16 sequences] [256 CUs][6 tiles] (3072 words kept) [256] [256 CUs][6 tiles]
     p->XC = reinterpret_cast<unsigned long long*>(st + BS_XC); p->serial = reinterpret_cast<unsigned*>(st + BS_SERIAL); p->err = reinterpret_cast<unsigned*>(st + BS_ERR);
 }
 int engb_lds_bytes() { return BL_TOTAL; }
@@ -890,7 +880,7 @@ hipError_t launch_decode_engine_b16(const EngBParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (p.n_rows < 1 || p.n_rows > BM || p.n_layers < 0 || p.n_layers > MAX_LAYERS) return hipErrorInvalidValue;
+    if (p.n_rows < 1 || p.n_rows > BM || p.n_layers < 0 || p.n_layers > MAX_LAYERS || !p.stream_wo) return hipErrorInvalidValue;
     decode_engine_b16_kernel<<<dim3(NCU), dim3(NTHR), BL_TOTAL, s>>>(p);
     return hipGetLastError();
 }

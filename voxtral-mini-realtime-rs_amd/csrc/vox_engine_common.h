@@ -34,9 +34,14 @@ static_assert(LAYER_BYTES == 255744, "layer bytes");
 constexpr int SC_MAX = 1024;                          // attention scores in LDS: cache rows per KV head (max_seq) <= 1024
 constexpr int OWN = ED / NCU;                         // 12 rows of the residual stream per CU
 constexpr int NPW = ENH, NP2 = ENKV;                  // partial planes of wo (one per head) / w2 (one per XCD group: the whole 1152-column slice in one CU)
+constexpr int NPWB = ENKV;                            // batched engine: wo planes, one per XCD group (EOP_WOB)
+constexpr size_t WOB_LAYER_BYTES = (size_t)WO_PK * PK_M;      // per CU and layer
 constexpr u64 TIMEOUT_TICKS = 2000000;                // s_memrealtime ticks (100 MHz): 20 ms
 
-enum { EOP_QKV = 0, EOP_WO = 1, EOP_W13 = 2, EOP_W2 = 3, EOP_LM = 4 };
+enum { EOP_QKV = 0, EOP_WO = 1, EOP_W13 = 2, EOP_W2 = 3, EOP_LM = 4, EOP_WOB = 5 };
+// EOP_WOB: wo for the BATCHED engine, K split by XCD group instead of by head (its own small stream, [layer][packet 2][CU][13824] -- the single-stream engine keeps EOP_WO,
+// whose per-head split needs no attention edge at one row): CU (g, j) multiplies rows [96 j, +96) (6 tiles) by the 512 columns of the group's four heads (8 K-steps) ->
+// 8 partial planes like w2 instead of 32.  Same packet geometry as EOP_WO (2 packets x 12 waves x 2 records): wave w owns tile w % 6, K-steps 4 (w / 6) .. + 3.
 enum { ERR_RING = 1, ERR_STAGE = 2, ERR_SWEEP = 3, ERR_CBAR = 4, ERR_SLOT = 5 };
 
 __host__ __device__ inline int lm_rows_per_cu(int vocab) { return vocab / NCU; }
@@ -45,7 +50,7 @@ __host__ __device__ inline int lm_packets(int vocab) { return (lm_passes(vocab) 
 __host__ __device__ inline size_t cu_stream_bytes(int n_layers, int vocab) { return (size_t)n_layers * LAYER_BYTES + (size_t)lm_packets(vocab) * PK_A + 1024; }      // + 1 KiB: the stream is read in whole 16-byte lanes only, the pad keeps the allocation comfortable
 
 // ---- record addressing (shared by the pack kernel and -- implicitly, through the same formulas -- the consumer waves) ----
-__host__ __device__ inline int op_packets(int op) { return op == EOP_QKV ? QKV_PK : op == EOP_WO ? WO_PK : op == EOP_W13 ? W13_PK : W2_PK; }
+__host__ __device__ inline int op_packets(int op) { return op == EOP_QKV ? QKV_PK : (op == EOP_WO || op == EOP_WOB) ? WO_PK : op == EOP_W13 ? W13_PK : W2_PK; }
 __host__ __device__ inline int op_pk_bytes(int op) { return op == EOP_W2 ? PK_A : PK_M; }
 __host__ __device__ inline bool pk_half_tile(int op, int pk) { return (op == EOP_QKV && pk == 2) || (op == EOP_W13 && pk == 8); }
 __host__ __device__ inline int pk_steps(int op, int pk) { return op == EOP_W2 ? 3 : pk_half_tile(op, pk) ? 4 : 2; }      // records per wave in the packet
@@ -54,18 +59,19 @@ __host__ __device__ inline void rec_src(int op, int pk, int w, int s, int* tile,
     if (op == EOP_QKV) { if (pk < 2) { *tile = 0; *T = 4 * w + 2 * pk + s; } else { *tile = 1; *T = 4 * w + s; } }
     else if (op == EOP_W13) { if (pk < 8) { *tile = pk >> 1; *T = 4 * w + 2 * (pk & 1) + s; } else { *tile = 4; *T = 4 * w + s; } }
     else if (op == EOP_W2) { *tile = 3 * (w / 6) + pk; *T = 3 * (w % 6) + s; }
+    else if (op == EOP_WOB) { *tile = w % 6; *T = 4 * (w / 6) + 2 * pk + s; }
     else { *tile = 2 * w + pk; *T = s; }
 }
 __host__ __device__ inline int tile_row(int op, int b, int tile, int n) {      // weight-matrix row of tile row n on CU b
     const int g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
     if (op == EOP_QKV) return tile == 0 ? 128 * h + 16 * s + n : n < 4 ? EQD + 128 * g + 4 * j + n : EQD + EKD + 128 * g + 4 * j + (n - 4);
     if (op == EOP_W13) return 2 * (1152 * g + 36 * j) + 16 * tile + n;      // interleaved gate / up rows: SwiGLU output i = rows 2 i, 2 i + 1
-    if (op == EOP_W2) return 96 * j + 16 * tile + n;
+    if (op == EOP_W2 || op == EOP_WOB) return 96 * j + 16 * tile + n;
     return 384 * s + 16 * tile + n;
 }
 __host__ __device__ inline int step_blk0(int op, int b, int T) {      // first Q4 block (of two) of K-step T
     const int g = b & 7, j = b >> 3, h = 4 * g + (j >> 3);
-    return op == EOP_W2 ? 36 * g + 2 * T : op == EOP_WO ? 4 * h + 2 * T : 2 * T;
+    return op == EOP_W2 ? 36 * g + 2 * T : op == EOP_WO ? 4 * h + 2 * T : op == EOP_WOB ? 16 * g + 2 * T : 2 * T;
 }
 
 

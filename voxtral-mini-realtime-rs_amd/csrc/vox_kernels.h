@@ -215,7 +215,7 @@ struct EngParams {
 bool eng_geometry_ok(int D, int n_heads, int n_kv, int hd, int ffn, int vocab, int max_seq);
 size_t eng_stream_bytes(int n_layers, int vocab);     // total bytes of the engine weight copy (all 256 CU streams)
 size_t eng_state_bytes();                             // granule buffers + serial + err
-// op: 0 q|k|v (fused [6144][3072]), 1 wo, 2 w1|w3 (row-interleaved), 3 w2, 4 tied lm_head; layer ignored for op 4
+// op: 0 q|k|v (fused [6144][3072]), 1 wo, 2 w1|w3 (row-interleaved), 3 w2, 4 tied lm_head; layer ignored for op 4; 5: wo for the batched engine into ITS stream (EngBParams::stream_wo)
 hipError_t launch_eng_pack(const Q4W& w, int op, int layer, int n_layers, unsigned char* stream, int vocab, hipStream_t s);
 void eng_state_carve(unsigned char* state, EngParams* p);      // point p's granule buffers / serial / err into a zero-initialised state block
 hipError_t launch_decode_engine(const EngParams& p, hipStream_t s);
@@ -230,6 +230,7 @@ int eng_lds_bytes();
 // (16-row lm_head GEMM, argmax / next embedding) stays launch-based and reads xf_out / ssq_out.
 struct EngBParams {
     const unsigned char* stream;                      // the packet stream built by launch_eng_pack (layer part)
+    const unsigned char* stream_wo;                   // wo in the XCD-group K split (launch_eng_pack op 5 per layer; engb_wo_stream_bytes): [layer][packet 2][CU][13824]
     const EngLayerTab* layers; int n_layers;          // device array; kc / vc: the GROUP's first sequence, [sequence][n_kv][max_seq][hd]
     long kv_seq_stride;                               // floats between two sequences' cache slices
     const float* h_in; int h_stride; int n_rows;      // [n_rows][D] the step's input rows (sequences n_rows..15 of the tile are zeros)
@@ -241,10 +242,10 @@ struct EngBParams {
     float *SS0, *SS1;                                 // [256 CUs][16] partial sums of squares
     unsigned long long* G;                            // [16][6144] q|k|v granules {value, tag}
     unsigned char* XO;                                // [32 heads][4 blocks][hi, lo][64] x 16 B attention outputs
-    float* PW;                                        // [32 planes][3072][16] wo partial products
+    float* PW;                                        // [8 planes][3072][16] wo partial products (one plane per XCD group)
     unsigned char* XA;                                // [8 groups][36 blocks][hi, lo][64] x 16 B SwiGLU outputs
     float* P2;                                        // [8 planes][3072][16] w2 partial products
-    unsigned *F0, *F1, *FO, *FW, *FA, *F2;            // flag words: F0 / F1 / FA [256 CUs], FO [32 heads][16 sequences], FW [256 CUs][12 waves], F2 [256 CUs][6 tiles]
+    unsigned *F0, *F1, *FO, *FW, *FA, *F2;            // flag words: F0 / F1 / FA [256 CUs], FO [32 heads][16 sequences], FW / F2 [256 CUs][6 tiles]
     unsigned long long* XC; unsigned* serial; unsigned* err;
     uint16_t* xf_out; float* ssq_out;                 // the layer stack's output: XF planes of h * final_norm (xf_store4 layout) + [256][16] partial sums of squares
     unsigned long long* tl; int tl_layer;             // timeline stamps [256][32] of layer tl_layer (null: off)
@@ -252,6 +253,7 @@ struct EngBParams {
                                                       // edges (placement verified per launch); 1024 / 2048: loader depth 2 / 1; 32: no LDS-DMA (diagnostic, wrong results); 16384: fault injection
 };
 size_t engb_state_bytes();
+size_t engb_wo_stream_bytes(int n_layers);            // bytes of the batched engine's wo stream (all 256 CUs)
 void engb_state_carve(unsigned char* state, EngBParams* p);      // point p's edge buffers / flags / serial / err into a zero-initialised state block
 hipError_t launch_decode_engine_b16(const EngBParams& p, hipStream_t s);
 hipError_t engb_occupancy(int* blocks_per_cu);
