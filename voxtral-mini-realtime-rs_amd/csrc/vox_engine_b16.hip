@@ -142,8 +142,9 @@ __device__ __forceinline__ f32x4 rec_mma(const RawRec& r, bf16x8 ah0, bf16x8 al0
     return acc;
 }
 // -136 * sum_k x[m][k] of one block, in the accumulator layout (the same value in every column n)
-__device__ __forceinline__ f32x4 corr16(bf16x8 ah, bf16x8 al) {
-    u32x4 mm; mm.x = mm.y = mm.z = mm.w = 0xC308C308u;      // bf16(-136) x 8
+// (mm = bf16(-136) x 8 comes from the caller, materialised per load_a: as a constant in here hipcc hoisted the four registers out of the layer loop, spilled them and
+// reloaded them -- scratch_load + s_waitcnt vmcnt(0) -- in front of the first MFMA of every operator)
+__device__ __forceinline__ f32x4 corr16(bf16x8 ah, bf16x8 al, u32x4 mm) {
     const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(mm), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(mm), s, 0, 0, 0);
 }
@@ -180,26 +181,33 @@ __device__ __forceinline__ void b16_loader(const EngBParams& p, BCtl* c, unsigne
 // ------------------------------------------------------------------------------------------------
 // poll n flag words (n <= 256, a multiple of 4 or < 4 ... one 16-byte load per lane covers four) until every one equals `tag`.  idx(i) = word index of flag i.
 template <class IdxF>
-__device__ __forceinline__ bool poll_flags(const unsigned* base_, unsigned words, int n, IdxF idx, unsigned tag, int lane, BCtl* c, unsigned* err) {
-    const srd_t sd = make_srd(base_, words * 4u);
+__device__ __forceinline__ bool poll_flags(const unsigned* base_, unsigned words, int n, IdxF idx, unsigned tag, int lane, BCtl* c, unsigned* err, unsigned stride = 4u) {
+    const srd_t sd = make_srd(base_, words * stride);
     u64 t0 = 0;
-    const unsigned off = (unsigned)idx(min(lane, n - 1)) * 4u;
+    const unsigned off = (unsigned)idx(min(lane, n - 1)) * stride;
     for (;;) {
         const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(sd, (int)off, 0, 16);
         if (__all(f == tag)) return true;
         if (sweep_bail(t0, tag, c, err)) return false;
     }
 }
-// all 256 flags of an all-gather: four per lane, one 16-byte load
+// all 256 flags of an all-gather, FSTRIDE bytes apart (one dword each): 256 CUs write them within a microsecond of each other and every CU polls all of them; packed
+// into 1 KB (32 writers per 128-byte line) the last flag became visible 3.0 us after its store, as bytes in 256 B (128 writers per line) 7 us -- same-line write-through
+// stores serialise at the memory side (profiles/r04_b16_flag_spacing.txt)
+constexpr int FSTRIDE = 16;
+constexpr unsigned PSTRIDE = 16u;      // the plane flags (FW / F2: [256 CUs][6 tiles]) likewise: one flag per 16 bytes instead of 32 per 128-byte line
 __device__ __forceinline__ bool poll_flags256(const unsigned* base_, unsigned tag, int lane, BCtl* c, unsigned* err) {
-    const srd_t sd = make_srd(base_, NCU * 4u);
+    const srd_t sd = make_srd(base_, NCU * FSTRIDE);
     u64 t0 = 0;
     for (;;) {
-        const u32x4 f = ld_frag(sd, (unsigned)lane * 16u);
-        if (__all(f.x == tag && f.y == tag && f.z == tag && f.w == tag)) return true;
+        unsigned f[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) f[u] = __builtin_amdgcn_raw_buffer_load_b32(sd, (lane + 64 * u) * FSTRIDE, 0, 16);
+        if (__all(f[0] == tag && f[1] == tag && f[2] == tag && f[3] == tag)) return true;
         if (sweep_bail(t0, tag, c, err)) return false;
     }
 }
+__device__ __forceinline__ void st_flag_ag(const unsigned* base_, unsigned idx, unsigned tag) { __builtin_amdgcn_raw_buffer_store_b32(tag, make_srd(base_, NCU * FSTRIDE), (int)(idx * FSTRIDE), 0, 16); }
 // RMSNorm scales of an all-gathered stream: 256 per-CU partial sums of squares per sequence, summed in a FIXED order (u ascending, then the butterfly) -> rstd[16] in LDS
 __device__ __forceinline__ void comm_rstd(const float* ss, float eps, int lane, float* rstd_out) {
     const srd_t sd = make_srd(ss, NCU * BM * 4u);
@@ -224,7 +232,7 @@ __device__ __forceinline__ void comm_rstd(const float* ss, float eps, int lane, 
 // the CU's partial sums of squares, drained, flag
 __device__ __forceinline__ void comm_publish_rows(const EngBParams& p, int lane, const float* own, const float* gw, unsigned char* xh, float* ss, unsigned* flags, unsigned tag) {
     const int b = blockIdx.x, m = lane & 15, t = lane >> 4;
-    const srd_t xd = make_srd(xh, XH_BYTES), sd = make_srd(ss, NCU * BM * 4u), fd = make_srd(flags, NCU * 4u);
+    const srd_t xd = make_srd(xh, XH_BYTES), sd = make_srd(ss, NCU * BM * 4u);
     float sq = 0.f;
     if (t < 3) {
         float v[4];
@@ -238,7 +246,7 @@ __device__ __forceinline__ void comm_publish_rows(const EngBParams& p, int lane,
     sq += __shfl(sq, (lane + 16) & 63, 64) + __shfl(sq, (lane + 32) & 63, 64);      // lanes 0..15: t = 0, 1, 2 (t = 3 contributes 0 through lane + 48 -> not added)
     if (lane < 16) st_u32(sd, (unsigned)((b * BM + m) * 4), __float_as_uint(sq), false);
     drain_vm();
-    if (lane == 0) st_u32(fd, (unsigned)b * 4u, tag, false);
+    if (lane == 0) st_flag_ag(flags, (unsigned)b, tag);
 }
 // the layer stack's output: h * final_norm in the launch-based lm_head's XF format (xf_store4 in vox_kernels.hip) + the CU's partial sums of squares (plain stores: the
 // kernel boundary publishes them)
@@ -337,7 +345,7 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
                 // post-attention stream, published as the w1|w3 input
                 wait_ge(&c->pub_cnt, pc0 + 3 * NCONS, c, p.err, ERR_STAGE);
                 lds_st(&c->gathering, 1u);
-                { const int c0 = (OWN * b) % 96; poll_flags(p.FW, 1536, 16, [&](int i) { return ((i >> 1) * 32 + (b >> 3)) * 6 + (((i & 1) ? c0 + OWN - 1 : c0) >> 4); }, tag, lane, c, p.err); }
+                { const int c0 = (OWN * b) % 96; poll_flags(p.FW, 1536, 16, [&](int i) { return ((i >> 1) * 32 + (b >> 3)) * 6 + (((i & 1) ? c0 + OWN - 1 : c0) >> 4); }, tag, lane, c, p.err, PSTRIDE); }
                 if (T) tl(13);
                 comm_reduce<NPWB>(p.PW, NPWB * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own0, own1);
                 lds_st(&c->gathering, 0u);
@@ -361,7 +369,7 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
                 wait_ge(&c->pub_cnt, pc0 + 5 * NCONS, c, p.err, ERR_STAGE);
                 if (T) tl(23);
                 lds_st(&c->gathering, 1u);
-                { const int c0 = (OWN * b) % 96; poll_flags(p.F2, 1536, 16, [&](int i) { return ((i >> 1) * 32 + (b >> 3)) * 6 + (((i & 1) ? c0 + OWN - 1 : c0) >> 4); }, tag, lane, c, p.err); }
+                { const int c0 = (OWN * b) % 96; poll_flags(p.F2, 1536, 16, [&](int i) { return ((i >> 1) * 32 + (b >> 3)) * 6 + (((i & 1) ? c0 + OWN - 1 : c0) >> 4); }, tag, lane, c, p.err, PSTRIDE); }
                 if (T) tl(24);
                 comm_reduce<NP2>(p.P2, NP2 * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own1, own0);
                 lds_st(&c->gathering, 0u);
@@ -427,18 +435,19 @@ struct BCons {
 #pragma unroll
         for (int i = 0; i < NB; i++) { rh[i] = ld_frag(sd, (unsigned)(((blk0 + i) * 2) * FRAG + lane * 16)); rl[i] = ld_frag(sd, (unsigned)(((blk0 + i) * 2 + 1) * FRAG + lane * 16)); }
         float* cb = reinterpret_cast<float*>(lds + BL_CB) + cw * 8 * BM;
+        unsigned k136 = 0xC308C308u; asm volatile("" : "+v"(k136));      // bf16(-136) x 2, opaque: rebuilt here (4 v_mov), never carried across phases
+        u32x4 mm; mm.x = mm.y = mm.z = mm.w = k136;
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             ah[i] = as_bf16x8(rh[i]); al[i] = as_bf16x8(rl[i]);
-            const f32x4 cs = corr16(ah[i], al[i]);
+            const f32x4 cs = corr16(ah[i], al[i], mm);
             if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(cb + i * BM + 4 * (lane >> 4)) = cs;
         }
     }
     __device__ __forceinline__ f32x4 cb_read(int i) const { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds + BL_CB) + (cw * 8 + i) * BM + 4 * (lane >> 4)); }
 };
 #define B16_PROLOGUE                                                                                                          \
-    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      /* the lane index from the EXEC mask (all 64 lanes are active here): no register lives across phases */ \
-    asm volatile("" : "+v"(lane));      /* opaque per phase: lane-derived addresses are recomputed, never hoisted out of the layer loop and carried (spilled) across phases */ \
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));      /* the lane index from the EXEC mask (all 64 lanes are active here), as VOLATILE asm: the builtin form was computed once before the layer loop, spilled, and reloaded (scratch_load + vmcnt(0)) at every phase entry */ \
     const EngBParams p = kparams(); unsigned char* lds = lds_base();                                                          \
     const int cw = __builtin_amdgcn_readfirstlane(cw_), l = __builtin_amdgcn_readfirstlane(l_);                               \
     BCtl* c = reinterpret_cast<BCtl*>(lds + BL_CTL); BCons cs(p, lds, cw, lane);                                             \
@@ -648,7 +657,7 @@ B16_PHASE void ph_wo(int cw_, int lane, int l_) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(part + (cw * 2) * 1024 + lane * 16) + *reinterpret_cast<const f32x4*>(part + (cw * 2 + 1) * 1024 + lane * 16);
         st_f4(make_srd(p.PW + (size_t)g * ED * BM, ED * BM * 4u), (unsigned)((96 * j + 16 * cw + n) * BM + 4 * y) * 4u, a);
         drain_vm();
-        if (lane == 0) st_u32(make_srd(p.FW, 1536 * 4u), (unsigned)((g * 32 + j) * 6 + cw) * 4u, tag, false);
+        if (lane == 0) st_u32(make_srd(p.FW, 1536 * PSTRIDE), (unsigned)((g * 32 + j) * 6 + cw) * PSTRIDE, tag, false);
     }
     cs.published();
     tl(5);
@@ -664,18 +673,21 @@ B16_PHASE void ph_w13(int cw_, int lane, int l_) {
         // of the one being multiplied
         const unsigned PW13 = P0 + QKV_PK + WO_PK;
         RawRec ra[4], rb[4];
+        // (the two f16 scales of a record are kept as ONE register -- opaque to the compiler, which otherwise holds the halves in two: with eight records waiting in
+        // registers next to the 64 registers of A fragments that was 8 VGPRs too many, spilled and reloaded inside the multiply loop)
         auto fetch_tile = [&](int ti, RawRec (&rr)[4]) {
 #pragma unroll
             for (int pk = 0; pk < 2; pk++) {
                 int sl; const unsigned char* bb = cs.slot_wait(PW13 + 2 * ti + pk, 2 * REC, sl);
                 rr[2 * pk] = rec_load(bb, false, lane); rr[2 * pk + 1] = rec_load(bb + REC, false, lane);
+                asm volatile("" : "+v"(rr[2 * pk].sc)); asm volatile("" : "+v"(rr[2 * pk + 1].sc));
                 cs.slot_release(sl);
             }
         };
         auto fetch_half = [&](RawRec (&rr)[4]) {
             int sl; const unsigned char* bb = cs.slot_wait(PW13 + 8, 4 * REC_H, sl);
 #pragma unroll
-            for (int r = 0; r < 4; r++) rr[r] = rec_load(bb + r * REC_H, true, lane);
+            for (int r = 0; r < 4; r++) { rr[r] = rec_load(bb + r * REC_H, true, lane); asm volatile("" : "+v"(rr[r].sc)); }
             cs.slot_release(sl);
         };
         fetch_tile(0, ra); fetch_tile(1, rb);
@@ -765,7 +777,7 @@ B16_PHASE void ph_w2(int cw_, int lane, int l_) {
         for (int w = 0; w < 6; w++) a += *reinterpret_cast<const f32x4*>(part + (cw * 6 + w) * 1024 + lane * 16);
         st_f4(make_srd(p.P2 + (size_t)g * ED * BM, ED * BM * 4u), (unsigned)((96 * j + 16 * cw + n) * BM + 4 * y) * 4u, a);
         drain_vm();
-        if (lane == 0) st_u32(make_srd(p.F2, 1536 * 4u), (unsigned)((g * 32 + j) * 6 + cw) * 4u, tag, false);
+        if (lane == 0) st_u32(make_srd(p.F2, 1536 * PSTRIDE), (unsigned)((g * 32 + j) * 6 + cw) * PSTRIDE, tag, false);
     }
     cs.published();
     tl(15);
@@ -861,14 +873,14 @@ hipError_t launch_engb_ssq_fold(const float* in, float* out, hipStream_t s) { en
 // state block: XH0 | XH1 | SS0 | SS1 | G | XO | PW | XA | P2 | F0 F1 FO FW FA F2 | XC | serial | err
 static constexpr size_t BS_XH0 = 0, BS_XH1 = BS_XH0 + XH_BYTES, BS_SS0 = BS_XH1 + XH_BYTES, BS_SS1 = BS_SS0 + (size_t)NCU * BM * 4, BS_G = BS_SS1 + (size_t)NCU * BM * 4,
                         BS_XO = BS_G + (size_t)BM * G_ROW * 8, BS_PW = BS_XO + (size_t)ENH * XO_HEAD, BS_XA = BS_PW + (size_t)NPWB * ED * BM * 4, BS_P2 = BS_XA + (size_t)ENKV * XA_GROUP,
-                        BS_F = BS_P2 + (size_t)NP2 * ED * BM * 4, BS_XC = BS_F + (256 + 256 + 512 + 3072 + 256 + 1536) * 4, BS_SERIAL = BS_XC + (size_t)NCU * 8, BS_ERR = BS_SERIAL + 256, BS_TOTAL = BS_ERR + 256;
+                        BS_F = BS_P2 + (size_t)NP2 * ED * BM * 4, BS_XC = BS_F + 21248 * 4, BS_SERIAL = BS_XC + (size_t)NCU * 8, BS_ERR = BS_SERIAL + 256, BS_TOTAL = BS_ERR + 256;
 size_t engb_state_bytes() { return BS_TOTAL; }
 size_t engb_wo_stream_bytes(int n_layers) { return (size_t)n_layers * WOB_LAYER_BYTES * NCU + 1024; }
 void engb_state_carve(unsigned char* st, EngBParams* p) {
     p->XH0 = st + BS_XH0; p->XH1 = st + BS_XH1; p->SS0 = reinterpret_cast<float*>(st + BS_SS0); p->SS1 = reinterpret_cast<float*>(st + BS_SS1);
     p->G = reinterpret_cast<unsigned long long*>(st + BS_G); p->XO = st + BS_XO; p->PW = reinterpret_cast<float*>(st + BS_PW); p->XA = st + BS_XA; p->P2 = reinterpret_cast<float*>(st + BS_P2);
     unsigned* f = reinterpret_cast<unsigned*>(st + BS_F);
-    p->F0 = f; p->F1 = f + 256; p->FO = f + 512; p->FW = f + 1024; p->FA = f + 4096; p->F2 = f + 4352;      // [256] [256] [32 heads][16 sequences] [256 CUs][6 tiles] (3072 words kept) [256] [256 CUs][6 tiles]
+    p->FO = f; p->FA = f + 512; p->FW = f + 768; p->F2 = f + 6912; p->F0 = f + 13056; p->F1 = f + 17152;      // words: FO [32 heads][16 sequences], FA [256], FW / F2 [256 CUs][6 tiles] x 16 B, F0 / F1 [256] x <= 64 B
     p->XC = reinterpret_cast<unsigned long long*>(st + BS_XC); p->serial = reinterpret_cast<unsigned*>(st + BS_SERIAL); p->err = reinterpret_cast<unsigned*>(st + BS_ERR);
 }
 int engb_lds_bytes() { return BL_TOTAL; }
