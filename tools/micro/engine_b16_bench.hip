@@ -122,7 +122,7 @@ int main(int argc, char** argv) {
     }
     unsigned char* stream_wo = dalloc<unsigned char>(engb_wo_stream_bytes(n_layers)); CHK(hipMemset(stream_wo, 0, engb_wo_stream_bytes(n_layers)));
     for (int l = 0; l < n_layers; l++) CHK(launch_eng_pack(L[l].wo, 5, l, n_layers, stream_wo, V, s));      // wo in the XCD-group K split (the batched engine's own stream)
-    unsigned char* state = dalloc<unsigned char>(engb_state_bytes()); CHK(hipMemset(state, 0, engb_state_bytes()));
+    unsigned char* state = dalloc<unsigned char>(engb_state_bytes()); CHK(engb_state_init(state, s)); CHK(hipStreamSynchronize(s));
     std::vector<EngLayerTab> tab(n_layers);
     for (int l = 0; l < n_layers; l++) tab[l] = EngLayerTab{L[l].attn_norm, L[l].ffn_norm, L[l].ada, kc + (size_t)l * lf, vc + (size_t)l * lf};
     EngLayerTab* d_tab = dalloc<EngLayerTab>(std::max(n_layers, 1)); CHK(hipMemcpy(d_tab, tab.data(), n_layers * sizeof(EngLayerTab), hipMemcpyHostToDevice));

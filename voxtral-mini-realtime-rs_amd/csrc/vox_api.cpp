@@ -1684,7 +1684,7 @@ static bool engb_prepare(vox_model* m, int n_grp) {
         if (m->engb_state[gi]) continue;
         hipError_t e = hipMalloc((void**)&m->engb_state[gi], engb_state_bytes());
         if (e == hipSuccess) e = hipMalloc((void**)&m->engb_tab[gi], sizeof(EngLayerTab) * 32);
-        if (e == hipSuccess) e = hipMemsetAsync(m->engb_state[gi], 0, engb_state_bytes(), m->ctx->stream);
+        if (e == hipSuccess) e = engb_state_init(m->engb_state[gi], m->ctx->stream);
         if (e != hipSuccess) { (void)hipGetLastError(); if (m->engb_state[gi]) { (void)hipFree(m->engb_state[gi]); m->engb_state[gi] = nullptr; } return false; }
     }
     return true;
@@ -2206,7 +2206,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
         m->engb_strikes++;
         fprintf(stderr, "[voxtral_hip] batched decode engine: hand-off timeout (code %u, workgroup %u, group %d), strike %d of 3; re-running the batch on the launch-based step%s\n",
                 e & 0xff, (e >> 8) & 0xff, gi, m->engb_strikes, m->engb_strikes >= 3 ? ", the engine is switched off" : "");
-        for (int gj = 0; gj < 4; gj++) if (m->engb_state[gj]) (void)hipMemsetAsync(m->engb_state[gj], 0, engb_state_bytes(), s);
+        for (int gj = 0; gj < 4; gj++) if (m->engb_state[gj]) (void)engb_state_init(m->engb_state[gj], s);
         if (m->engb_strikes >= 3) m->engb_ok = false;      // (otherwise re-armed for the next batch)
         return transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, false);
     }

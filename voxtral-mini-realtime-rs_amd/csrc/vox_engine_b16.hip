@@ -267,6 +267,38 @@ __device__ __forceinline__ void comm_publish_final(const EngBParams& p, int lane
     if (lane < 16) p.ssq_out[b * BM + m] = sq;
 }
 // sum NP partial planes of the CU's 12 columns x 16 sequences (planes[pl][col][m], plane pl's producer-side index given by plane_idx) + the residual -> dst[n][m]
+// The partial planes carry their own validity: a slot holds PLANE_EMPTY (all ones: a NaN no product can be) until its producer stores the tile, and the owner -- the
+// only reader -- puts PLANE_EMPTY back once it has summed the slot.  The owner polls the DATA: one round trip instead of flag sweep + payload load, and the producers
+// neither drain their stores nor write flags (a 16-byte store becomes visible as a whole; every dword is checked anyway).  The owner's resets are drained by the
+// publish that follows them, long before the next layer's producers can write the slots again.
+constexpr unsigned PLANE_EMPTY = 0xFFFFFFFFu;
+template <int NP, class PlaneF>
+__device__ __forceinline__ bool comm_reduce_poll(float* planes, unsigned bytes, PlaneF plane_base, int lane, const float* resid, float* dst, unsigned tag, BCtl* c, unsigned* err) {
+    static_assert(NP <= 8, "one batch of loads");
+    const srd_t sd = make_srd(planes, bytes);
+    const int n12 = min(lane >> 2, OWN - 1), mq = lane & 3;
+    const unsigned lo_ = (unsigned)((OWN * blockIdx.x + n12) * BM + 4 * mq) * 4u;
+    u32x4 v[NP]; u64 t0 = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < NP; u++) v[u] = ld_frag(sd, (unsigned)plane_base(u) + lo_);
+#pragma unroll
+        for (int u = 0; u < NP; u++) ok &= v[u].x != PLANE_EMPTY && v[u].y != PLANE_EMPTY && v[u].z != PLANE_EMPTY && v[u].w != PLANE_EMPTY;
+        if (__all(ok)) break;
+        if (sweep_bail(t0, tag, c, err)) return false;
+    }
+    f32x4 a = *reinterpret_cast<const f32x4*>(resid + n12 * BM + 4 * mq);
+#pragma unroll
+    for (int u = 0; u < NP; u++) a += __builtin_bit_cast(f32x4, v[u]);      // fixed order
+    if (lane < 4 * OWN) {
+        *reinterpret_cast<f32x4*>(dst + n12 * BM + 4 * mq) = a;
+        const u32x4 e = {PLANE_EMPTY, PLANE_EMPTY, PLANE_EMPTY, PLANE_EMPTY};
+#pragma unroll
+        for (int u = 0; u < NP; u++) __builtin_amdgcn_raw_buffer_store_b128(e, sd, (int)((unsigned)plane_base(u) + lo_), 0, 16);
+    }
+    return true;
+}
 template <int NP, class PlaneF>
 __device__ __forceinline__ void comm_reduce(const float* planes, unsigned bytes, PlaneF plane_base, int lane, const float* resid, float* dst) {
     const srd_t sd = make_srd(planes, bytes);
@@ -345,9 +377,8 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
                 // post-attention stream, published as the w1|w3 input
                 wait_ge(&c->pub_cnt, pc0 + 3 * NCONS, c, p.err, ERR_STAGE);
                 lds_st(&c->gathering, 1u);
-                { const int c0 = (OWN * b) % 96; poll_flags(p.FW, 1536, 16, [&](int i) { return ((i >> 1) * 32 + (b >> 3)) * 6 + (((i & 1) ? c0 + OWN - 1 : c0) >> 4); }, tag, lane, c, p.err, PSTRIDE); }
+                comm_reduce_poll<NPWB>(p.PW, NPWB * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own0, own1, tag, c, p.err);
                 if (T) tl(13);
-                comm_reduce<NPWB>(p.PW, NPWB * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own0, own1);
                 lds_st(&c->gathering, 0u);
                 ENG_CFENCE();
                 if (!((p.flags & 16384) && b == 7 && l == 1))      // (flag 16384 = FAULT INJECTION: workgroup 7 loses a publish)
@@ -369,9 +400,8 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
                 wait_ge(&c->pub_cnt, pc0 + 5 * NCONS, c, p.err, ERR_STAGE);
                 if (T) tl(23);
                 lds_st(&c->gathering, 1u);
-                { const int c0 = (OWN * b) % 96; poll_flags(p.F2, 1536, 16, [&](int i) { return ((i >> 1) * 32 + (b >> 3)) * 6 + (((i & 1) ? c0 + OWN - 1 : c0) >> 4); }, tag, lane, c, p.err, PSTRIDE); }
+                comm_reduce_poll<NP2>(p.P2, NP2 * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own1, own0, tag, c, p.err);
                 if (T) tl(24);
-                comm_reduce<NP2>(p.P2, NP2 * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own1, own0);
                 lds_st(&c->gathering, 0u);
                 ENG_CFENCE();
                 if (l + 1 < L) comm_publish_rows(p, lane, own0, gwt + ((l + 1) * 2) * 16, p.XH0, p.SS0, p.F0, tag);
@@ -655,9 +685,7 @@ B16_PHASE void ph_wo(int cw_, int lane, int l_) {
     cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 2)));
     if (cw < 6) {      // wave t finishes tile t: the two K halves in a fixed order
         const f32x4 a = *reinterpret_cast<const f32x4*>(part + (cw * 2) * 1024 + lane * 16) + *reinterpret_cast<const f32x4*>(part + (cw * 2 + 1) * 1024 + lane * 16);
-        st_f4(make_srd(p.PW + (size_t)g * ED * BM, ED * BM * 4u), (unsigned)((96 * j + 16 * cw + n) * BM + 4 * y) * 4u, a);
-        drain_vm();
-        if (lane == 0) st_u32(make_srd(p.FW, 1536 * PSTRIDE), (unsigned)((g * 32 + j) * 6 + cw) * PSTRIDE, tag, false);
+        st_f4(make_srd(p.PW + (size_t)g * ED * BM, ED * BM * 4u), (unsigned)((96 * j + 16 * cw + n) * BM + 4 * y) * 4u, a);      // the owner polls the slots themselves (comm_reduce_poll)
     }
     cs.published();
     tl(5);
@@ -776,8 +804,6 @@ B16_PHASE void ph_w2(int cw_, int lane, int l_) {
 #pragma unroll
         for (int w = 0; w < 6; w++) a += *reinterpret_cast<const f32x4*>(part + (cw * 6 + w) * 1024 + lane * 16);
         st_f4(make_srd(p.P2 + (size_t)g * ED * BM, ED * BM * 4u), (unsigned)((96 * j + 16 * cw + n) * BM + 4 * y) * 4u, a);
-        drain_vm();
-        if (lane == 0) st_u32(make_srd(p.F2, 1536 * PSTRIDE), (unsigned)((g * 32 + j) * 6 + cw) * PSTRIDE, tag, false);
     }
     cs.published();
     tl(15);
@@ -882,6 +908,13 @@ void engb_state_carve(unsigned char* st, EngBParams* p) {
     unsigned* f = reinterpret_cast<unsigned*>(st + BS_F);
     p->FO = f; p->FA = f + 512; p->FW = f + 768; p->F2 = f + 6912; p->F0 = f + 13056; p->F1 = f + 17152;      // words: FO [32 heads][16 sequences], FA [256], FW / F2 [256 CUs][6 tiles] x 16 B, F0 / F1 [256] x <= 64 B
     p->XC = reinterpret_cast<unsigned long long*>(st + BS_XC); p->serial = reinterpret_cast<unsigned*>(st + BS_SERIAL); p->err = reinterpret_cast<unsigned*>(st + BS_ERR);
+}
+// zero the block, then mark every partial-plane slot empty (comm_reduce_poll)
+hipError_t engb_state_init(unsigned char* st, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(st, 0, BS_TOTAL, s);
+    if (e == hipSuccess) e = hipMemsetAsync(st + BS_PW, 0xFF, (size_t)NPWB * ED * BM * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(st + BS_P2, 0xFF, (size_t)NP2 * ED * BM * 4, s);
+    return e;
 }
 int engb_lds_bytes() { return BL_TOTAL; }
 

@@ -254,7 +254,8 @@ struct EngBParams {
 };
 size_t engb_state_bytes();
 size_t engb_wo_stream_bytes(int n_layers);            // bytes of the batched engine's wo stream (all 256 CUs)
-void engb_state_carve(unsigned char* state, EngBParams* p);      // point p's edge buffers / flags / serial / err into a zero-initialised state block
+void engb_state_carve(unsigned char* state, EngBParams* p);      // point p's edge buffers / flags / serial / err into a state block prepared by engb_state_init
+hipError_t engb_state_init(unsigned char* state, hipStream_t s);      // zeros + the partial planes marked empty: before the first launch and after a failed one
 hipError_t launch_decode_engine_b16(const EngBParams& p, hipStream_t s);
 hipError_t engb_occupancy(int* blocks_per_cu);
 hipError_t launch_engb_ssq_fold(const float* ssq256, float* ssq16, hipStream_t s);      // [256][16] -> [16][16] partial sums of squares (fixed order)
