@@ -145,6 +145,19 @@ int32_t vox_q4_matmul(vox_ctx* ctx, const vox_q4* w, const float* x, int32_t B, 
 int32_t vox_q4_linear_forward(vox_ctx* ctx, const vox_q4* w, const float* bias_or_null, const float* x,
                               int32_t B, int32_t M, float* out, int32_t mem_kind);
 
+/* ---- dense (f32 SafeTensors path) layer operators on their own (src/models/layers) ------ */
+/* The device form of an F32 burn `Linear` weight [N][K] as models/weights.rs:16-66 loads it: the exact f32 plane + bf16 hi / lo planes (what vox_f32_model_load builds
+ * for a checkpoint that is not bf16-representable).  w_other_or_null: a second [N][K] tensor interleaved row by row with the first (row 2 i = w[i], 2 i + 1 =
+ * other[i]) -- the fused gate | up operand SwiGLU::forward (models/layers/swiglu.rs:72-77) runs on.  The handle is a vox_q4: vox_q4_tensor_shape / _free apply,
+ * vox_q4_linear_forward / vox_q4_matmul multiply by it. */
+int32_t vox_dense_tensor_from_f32(vox_ctx* ctx, const float* w_NxK, const float* w_other_or_null, int64_t N, int64_t K, vox_q4** out);
+/* Linear::forward with a fused epilogue, Q4 or dense weight: 0 none, 1 GELU (the Ada t_cond MLP, models/layers/rms_norm.rs:109-118), 2 SwiGLU over interleaved
+ * gate / up rows: out[.][i] = silu(row 2 i) * row 2 i + 1, N / 2 columns (swiglu.rs:72-77; no bias). */
+int32_t vox_linear_forward_ex(vox_ctx* ctx, const vox_q4* w, const float* bias_or_null, const float* x, int32_t B, int32_t M, float* out, int32_t epilogue, int32_t mem_kind);
+/* ConvDownsampler::forward, models/layers/conv.rs:78-83: gelu(conv1d k = 3, s = 2, p = 1) twice; x [C][L], w1 [O][C][3], w2 [O][O][3] -> out [O][L2], L2 = ((L + 1) / 2 + 1) / 2
+ * (host pointers; the im2col MFMA path the encoder's conv stem runs on). */
+int32_t vox_conv_downsample(vox_ctx* ctx, const float* x_CxL, int32_t C, int32_t L, const float* w1, const float* b1, const float* w2, const float* b2, int32_t O, float* out_OxL2);
+
 /* ---- model-forward surface (src/gguf/loader.rs, src/gguf/model.rs) ---------------------- */
 typedef struct {
     int32_t enc_layers, enc_dim, enc_heads, enc_head_dim, enc_ffn, enc_window;

@@ -248,6 +248,53 @@ def test_attention_block_vs_reference_python_component_golden(pkg, orc, ctx):
     assert err < 2e-4, err
 
 
+def _component_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_python_components.npz"))
+
+
+def test_swiglu_hip_operators_vs_reference_python_component_golden(pkg, ctx):
+    """The reference's own SwiGLU vector (scripts/reference_forward.py:86-88 run on synthetic weights of the real encoder shapes; what models/layers/swiglu.rs:101
+    test_swiglu_vs_reference loads) through the HIP operators of the f32 path: w1 | w3 as ONE interleaved dense operand with the fused SiLU(gate) * up epilogue
+    (the product's own FFN form), then w2 -- 10 rows x 1280 -> 5120 -> 1280."""
+    from model_fixtures import component_weight, rel_err
+    g = _component_golden(); ENC = "mm_streams_embeddings.embedding_module.whisper_encoder."
+    w1, w2, w3 = (component_weight(ENC + f"transformer.layers.0.feed_forward.w{i}.weight") for i in (1, 2, 3))
+    w13 = pkg.Q4Tensor.from_f32(w1, ctx, other=w3); t2 = pkg.Q4Tensor.from_f32(w2, ctx)
+    h = pkg.linear_forward(w13, g["swiglu_input"], epilogue=2)
+    assert h.shape == (1, 10, 5120)
+    out = pkg.linear_forward(t2, h)
+    e = rel_err(out[0], g["swiglu_output"][0]); print(f"SwiGLU (HIP dense operators) vs the reference's vector: {e:.2e}")
+    assert e < 2e-4
+    w13.close(); t2.close()
+
+
+def test_conv_downsampler_hip_vs_reference_python_component_golden(pkg, ctx):
+    """The reference's own ConvDownsampler vector (reference_forward.py:185-192; models/layers/conv.rs:78-83): 128 x 100 mel frames -> 1280 x 25 through the conv stem's
+    im2col GEMMs on the matrix cores (dense2_gemm_kernel, bf16 hi + lo weight planes, GELU epilogue) -- the path encode_audio runs."""
+    from model_fixtures import component_weight, rel_err
+    g = _component_golden(); ENC = "mm_streams_embeddings.embedding_module.whisper_encoder."
+    w1, b1 = component_weight(ENC + "conv_layers.0.conv.weight"), component_weight(ENC + "conv_layers.0.conv.bias")
+    w2, b2 = component_weight(ENC + "conv_layers.1.conv.weight"), component_weight(ENC + "conv_layers.1.conv.bias")
+    out = pkg.conv_downsample(ctx, g["conv_input"][0], w1, b1, w2, b2)
+    assert out.shape == g["conv_output"][0].shape == (1280, 25)
+    e = rel_err(out, g["conv_output"][0]); print(f"conv downsampler (HIP im2col MFMA path) vs the reference's vector: {e:.2e}")
+    assert e < 2e-4
+
+
+def test_ada_modulation_hip_vs_reference_python_component_golden(pkg, ctx):
+    """The reference's own Ada-modulation vector (reference_forward.py:308-317; models/layers/rms_norm.rs:109-118): scale = w2 gelu(w0 t) through the HIP single-row
+    operators with the fused GELU epilogue (the launches vox_model_set_t_embed issues), then x * (1 + scale)."""
+    from model_fixtures import component_weight, rel_err
+    g = _component_golden()
+    w0, w2 = component_weight("layers.0.ada_rms_norm_t_cond.0.weight"), component_weight("layers.0.ada_rms_norm_t_cond.2.weight")
+    t0 = pkg.Q4Tensor.from_f32(w0, ctx); t2 = pkg.Q4Tensor.from_f32(w2, ctx)
+    hid = pkg.linear_forward(t0, g["ada_rms_norm_t_embed"], epilogue=1)
+    scale = pkg.linear_forward(t2, hid)[0]
+    assert rel_err(scale, g["ada_rms_norm_scale"][0]) < 2e-4
+    assert rel_err(g["ada_rms_norm_input"][0] * (1.0 + scale), g["ada_rms_norm_output"][0]) < 2e-4
+    t0.close(); t2.close()
+
+
 def test_attention_f32_switch_vs_oracle(pkg, orc, ctx, monkeypatch):
     """VOX_ATTN_F32=1 (the all-f32 VALU attention kept beside the MFMA kernel as a cross-check) on the decoder-prefill and a windowed encoder shape."""
     from importlib import import_module

@@ -14,4 +14,4 @@ from . import wer  # noqa: F401  (WER / CER harness, scripts/eval_wer.py)
 from . import export  # noqa: F401  (SafeTensors -> Q4_0 GGUF)
 from . import shard  # noqa: F401  (multi-GPU: LPT sharding of independent utterances; torch imported lazily)
 from .models import VoxtralModel, VoxtralModelLoader  # noqa: F401
-from .gguf import (Context, device_count, GgufReader, Q4Tensor, Q4Linear, q4_matmul, Q4ModelLoader, Q4VoxtralModel, tensor_add_dev, argmax_rows_dev)  # noqa: F401
+from .gguf import (Context, device_count, GgufReader, Q4Tensor, Q4Linear, q4_matmul, Q4ModelLoader, Q4VoxtralModel, tensor_add_dev, argmax_rows_dev, linear_forward, conv_downsample)  # noqa: F401

@@ -87,6 +87,9 @@ SIGNATURES = {
     "vox_q4_tensor_free": (i32, [vp]),
     "vox_q4_matmul": (i32, [vp, vp, vp, i32, i32, vp, i32]),
     "vox_q4_linear_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, i32]),
+    "vox_dense_tensor_from_f32": (i32, [vp, vp, vp, i64, i64, P(vp)]),
+    "vox_linear_forward_ex": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32]),
+    "vox_conv_downsample": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp]),
     "vox_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32]),
     "vox_q4_model_load": (i32, [vp, C.c_char_p, P(vp)]),
     "vox_q4_model_load_ex": (i32, [vp, C.c_char_p, u32, P(vp)]),

@@ -624,6 +624,73 @@ extern "C" int32_t vox_q4_matmul(vox_ctx* c, const vox_q4* w, const float* x, in
     return vox_q4_linear_forward(c, w, nullptr, x, B, M, out, mem_kind);
 }
 
+// ---- dense (f32-path) operators of models/layers on their own: what the f32 SafeTensors model runs, reachable per operator so that the reference's own
+// per-component vectors (scripts/reference_forward.py; models/layers/swiglu.rs:101, conv.rs, rms_norm.rs tests) go through the HIP kernels, not only through the oracle
+static uint16_t bf16_rne(float f) { uint32_t u; std::memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); }
+static void bf16_split(const float* w, size_t n, uint16_t* hi, uint16_t* lo) {
+    for (size_t e = 0; e < n; e++) { const uint16_t hb = bf16_rne(w[e]); const uint32_t hu = (uint32_t)hb << 16; float hf; std::memcpy(&hf, &hu, 4); hi[e] = hb; lo[e] = bf16_rne(w[e] - hf); }
+}
+extern "C" int32_t vox_dense_tensor_from_f32(vox_ctx* c, const float* w, const float* w_other, int64_t N, int64_t K, vox_q4** out) {
+    ARGCHK(c && w && out, "null argument"); ARGCHK(N > 0 && K > 0 && K % 32 == 0, "dense tensor [%lld][%lld]: K must be a positive multiple of 32", (long long)N, (long long)K);
+    VOXCHK(ctx_bind(c));
+    const int64_t Ntot = w_other ? 2 * N : N; const size_t ne = (size_t)Ntot * K;
+    std::vector<float> host(ne);
+    for (int64_t r = 0; r < N; r++) {
+        std::memcpy(host.data() + (size_t)(w_other ? 2 * r : r) * K, w + (size_t)r * K, (size_t)K * 4);
+        if (w_other) std::memcpy(host.data() + (size_t)(2 * r + 1) * K, w_other + (size_t)r * K, (size_t)K * 4);      // interleaved gate / up rows (the fused w1|w3 operand)
+    }
+    std::vector<uint16_t> h2(ne), l2(ne); bf16_split(host.data(), ne, h2.data(), l2.data());
+    vox_q4* q = new vox_q4{c, Q4W{}, nullptr, nullptr};
+    auto bail = [&](hipError_t e) { (void)hipGetLastError(); (void)hipFree(q->qs_mem); (void)hipFree(q->sc_mem); (void)hipFree(q->qt_mem); delete q; return fail(VOX_ERR_HIP, "dense tensor upload: %s", hipGetErrorString(e)); };
+    hipError_t e = hipMalloc(&q->qs_mem, ne * 2); if (e == hipSuccess) e = hipMalloc(&q->sc_mem, ne * 2); if (e == hipSuccess) e = hipMalloc(&q->qt_mem, ne * 4);
+    if (e == hipSuccess) e = hipMemcpy(q->qs_mem, h2.data(), ne * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(q->sc_mem, l2.data(), ne * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(q->qt_mem, host.data(), ne * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(e);
+    q->w = Q4W{(const uint4*)q->qs_mem, (const uint16_t*)q->sc_mem, (int)Ntot, (int)K, (int)(K / 32), WFMT_F32}; q->w.qt = (const uint4*)q->qt_mem;      // the f32 model's WFMT_F32 operand (Loader::linear)
+    *out = q; return VOX_OK;
+}
+extern "C" int32_t vox_linear_forward_ex(vox_ctx* c, const vox_q4* w, const float* bias, const float* x, int32_t B, int32_t M, float* out, int32_t epilogue, int32_t mem_kind) {
+    ARGCHK(c && w && x && out, "null argument"); ARGCHK(B > 0 && M > 0, "bad batch/rows"); VOXCHK(ctx_bind(c));
+    ARGCHK(epilogue == 0 || epilogue == 1 || epilogue == 2, "epilogue %d: 0 none, 1 GELU, 2 SwiGLU over interleaved gate / up rows", epilogue);
+    const int epi = epilogue == 1 ? EPI_GELU : epilogue == 2 ? EPI_SWIGLU : EPI_STORE;
+    const int rows = B * M, K = w->w.K, N = w->w.N, No = epilogue == 2 ? N / 2 : N;
+    ARGCHK(epilogue != 2 || (N % 2 == 0 && !bias), "SwiGLU epilogue needs an even number of interleaved rows and no bias");
+    if (mem_kind == VOX_MEM_DEVICE) return q4_linear_dev(c, w->w, bias, x, K, rows, out, No, epi);
+    DevBuf dx, dy, db; HIPCHK(dx.alloc((size_t)rows * K * 4)); HIPCHK(dy.alloc((size_t)rows * No * 4));
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)rows * K * 4, hipMemcpyHostToDevice, c->stream));
+    if (bias) { HIPCHK(db.alloc((size_t)N * 4)); HIPCHK(hipMemcpyAsync(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice, c->stream)); }
+    VOXCHK(q4_linear_dev(c, w->w, bias ? db.as<float>() : nullptr, dx.as<float>(), K, rows, dy.as<float>(), No, epi));
+    HIPCHK(hipMemcpyAsync(out, dy.p, (size_t)rows * No * 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+    return VOX_OK;
+}
+// ConvDownsampler::forward (models/layers/conv.rs:78-83): gelu(conv1d k3 s2 p1) twice, x [C][L] -> [O][L2], on the product's im2col MFMA path (conv_stem_dev)
+extern "C" int32_t vox_conv_downsample(vox_ctx* c, const float* x, int32_t C, int32_t L, const float* w1, const float* b1, const float* w2, const float* b2, int32_t O, float* out) {
+    ARGCHK(c && x && w1 && b1 && w2 && b2 && out && C > 0 && L > 0 && O > 0, "bad argument"); ARGCHK((3 * C) % 128 == 0 && (3 * O) % 128 == 0, "3 * channels must be a multiple of 128");
+    VOXCHK(ctx_bind(c)); hipStream_t s = c->stream;
+    const int T1 = (L + 2 - 3) / 2 + 1, S = (T1 + 2 - 3) / 2 + 1;      // models/layers/conv.rs:47-48
+    auto planes = [&](const float* w, int Co, int Ci, DevBuf& hi, DevBuf& lo, Q4W* q) -> int32_t {      // W'[co][kk * Ci + ci] = w[co][ci][kk] as bf16 hi + lo (Loader::conv_planes)
+        const size_t K = (size_t)3 * Ci; std::vector<float> r((size_t)Co * K);
+        for (int co = 0; co < Co; co++) for (int ci = 0; ci < Ci; ci++) for (int kk = 0; kk < 3; kk++) r[(size_t)co * K + (size_t)kk * Ci + ci] = w[((size_t)co * Ci + ci) * 3 + kk];
+        std::vector<uint16_t> h(r.size()), l(r.size()); bf16_split(r.data(), r.size(), h.data(), l.data());
+        HIPCHK(hi.alloc(h.size() * 2)); HIPCHK(lo.alloc(l.size() * 2));
+        HIPCHK(hipMemcpy(hi.p, h.data(), h.size() * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(lo.p, l.data(), l.size() * 2, hipMemcpyHostToDevice));
+        *q = Q4W{(const uint4*)hi.p, (const uint16_t*)lo.p, Co, (int)K, (int)(K / 32), WFMT_BF16X2}; return VOX_OK;
+    };
+    DevBuf h1, l1, h2, l2, dx, dm, d1, dy, dyt, db1, db2; Q4W g1{}, g2{};
+    VOXCHK(planes(w1, O, C, h1, l1, &g1)); VOXCHK(planes(w2, O, O, h2, l2, &g2));
+    HIPCHK(dx.alloc((size_t)C * L * 4)); HIPCHK(dm.alloc((size_t)(L + 2) * C * 4)); HIPCHK(d1.alloc((size_t)(T1 + 2) * O * 4)); HIPCHK(dy.alloc((size_t)S * O * 4)); HIPCHK(dyt.alloc((size_t)S * O * 4));
+    HIPCHK(db1.alloc((size_t)O * 4)); HIPCHK(db2.alloc((size_t)O * 4));
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)C * L * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(db1.p, b1, (size_t)O * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(db2.p, b2, (size_t)O * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(dm.p, 0, (size_t)(L + 2) * C * 4, s)); HIPCHK(hipMemsetAsync(d1.p, 0, (size_t)(T1 + 2) * O * 4, s));
+    HIPCHK(launch_transpose(dx.as<float>(), C, L, dm.as<float>() + C, s));      // [C][L] -> token-major, one zero row either side
+    { GemmParams g{}; g.w = g1; g.x = dm.as<float>(); g.x_stride = 2 * C; g.M = T1; g.out = d1.as<float>() + O; g.out_stride = O; g.bias = db1.as<float>(); HIPCHK(launch_dense2_gemm(g, EPI_GELU, s)); }
+    { GemmParams g{}; g.w = g2; g.x = d1.as<float>(); g.x_stride = 2 * O; g.M = S; g.out = dy.as<float>(); g.out_stride = O; g.bias = db2.as<float>(); HIPCHK(launch_dense2_gemm(g, EPI_GELU, s)); }
+    HIPCHK(launch_transpose(dy.as<float>(), S, O, dyt.as<float>(), s));      // token-major [S][O] -> the layer's [O][S]
+    HIPCHK(hipMemcpyAsync(out, dyt.p, (size_t)S * O * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+    return VOX_OK;
+}
+
 // causal (+ sliding-window) multi-head / grouped-query attention core on host or device buffers
 // (gguf/model.rs:100-120,125-198; masking.rs:9-107).  q [M][n_heads*hd], k/v [kv_len][n_kv*hd] (token-major), query m at
 // position offset+m sees keys j <= offset+m with offset+m-j <= window (window < 0: no window).  out [M][n_heads*hd].

@@ -20,8 +20,10 @@
 // The activations never touch LDS: a wave's K slice (256 columns x 16 sequences, hi + lo = 16 KB) is loaded straight into 64 VGPRs as MFMA A fragments, because the
 // producers publish them in fragment order: XH / XA / XO = [32-column block][hi, lo][lane (y, m)] x 16 bytes.
 // Edges carry kilobytes, not 8-byte granules: payload with write-through (sc1) stores, s_waitcnt vmcnt(0), then ONE flag word per producing CU (MI355X_MICROARCH.md
-// handoff-flag / publish-large); the COMM wave polls the flags (a 16-byte load per lane covers all 256), the consumer waves then fetch their slices.  The small q|k|v edge
-// keeps the tagged 8-byte granules.  Edges inside one XCD group (q|k|v, attention output, SwiGLU output) use plain stores when the start-up check finds the group on one XCD.
+// handoff-flag / publish-large); the COMM wave polls the flags, the consumer waves then fetch their slices.  The all-gather flags sit 16 bytes apart: 256 CUs write
+// theirs within a microsecond, and write-through stores into ONE 128-byte line complete one after the other at the memory side (profiles/r04_b16_flag_spacing.txt).
+// The partial planes of wo / w2 need no flags at all: a slot is "empty" (all ones) until its producer stores it, the owner polls the slots and puts the marker back.
+// The small q|k|v edge keeps the tagged 8-byte granules.  Edges inside one XCD group (q|k|v, attention output, SwiGLU output) use plain stores when the start-up check finds the group on one XCD.
 // Tags / flags = (launch serial + 1) * 64 + layer + 1 as in the single-stream engine; every spin is bounded (20 ms) and fails the launch loudly (*err).
 // The final norm's input leaves the launch in the launch-based path's own format (XF planes of h * final_norm + 256 partial sums of squares), so the step's tail --
 // the 16-row lm_head GEMM and the argmax / next-embedding kernel -- is unchanged.
@@ -195,7 +197,6 @@ __device__ __forceinline__ bool poll_flags(const unsigned* base_, unsigned words
 // into 1 KB (32 writers per 128-byte line) the last flag became visible 3.0 us after its store, as bytes in 256 B (128 writers per line) 7 us -- same-line write-through
 // stores serialise at the memory side (profiles/r04_b16_flag_spacing.txt)
 constexpr int FSTRIDE = 16;
-constexpr unsigned PSTRIDE = 16u;      // the plane flags (FW / F2: [256 CUs][6 tiles]) likewise: one flag per 16 bytes instead of 32 per 128-byte line
 __device__ __forceinline__ bool poll_flags256(const unsigned* base_, unsigned tag, int lane, BCtl* c, unsigned* err) {
     const srd_t sd = make_srd(base_, NCU * FSTRIDE);
     u64 t0 = 0;

@@ -245,7 +245,8 @@ struct EngBParams {
     float* PW;                                        // [8 planes][3072][16] wo partial products (one plane per XCD group)
     unsigned char* XA;                                // [8 groups][36 blocks][hi, lo][64] x 16 B SwiGLU outputs
     float* P2;                                        // [8 planes][3072][16] w2 partial products
-    unsigned *F0, *F1, *FO, *FW, *FA, *F2;            // flag words: F0 / F1 / FA [256 CUs], FO [32 heads][16 sequences], FW / F2 [256 CUs][6 tiles]
+    unsigned *F0, *F1, *FO, *FW, *FA, *F2;            // flag words: F0 / F1 [256 CUs], 16 bytes apart (same-line write-through stores serialise); FO [32 heads][16 sequences], FA [256 CUs] (XCD-local); FW / F2: unused
+                                                      // since the partial planes carry their own validity (empty = all ones)
     unsigned long long* XC; unsigned* serial; unsigned* err;
     uint16_t* xf_out; float* ssq_out;                 // the layer stack's output: XF planes of h * final_norm (xf_store4 layout) + [256][16] partial sums of squares
     unsigned long long* tl; int tl_layer;             // timeline stamps [256][32] of layer tl_layer (null: off)

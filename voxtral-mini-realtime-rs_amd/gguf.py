@@ -173,6 +173,15 @@ class Q4Tensor:
         check(lib().vox_q4_tensor_from_bytes(ctx.h, _ptr(raw), raw.size, n, k, C.byref(h)))
         return cls(ctx, h, [n, k])
 
+    @classmethod
+    def from_f32(cls, w, ctx: Context, other=None):
+        """Dense f32-path weight [N, K] (models/weights.rs:16-66) in the f32 model's device format; `other`: a second [N, K] tensor interleaved row by row
+        (the fused gate | up operand of SwiGLU, models/layers/swiglu.rs:72-77)."""
+        w = _f32(w); n, k = w.shape; h = C.c_void_p()
+        o = None if other is None else _f32(other)
+        check(lib().vox_dense_tensor_from_f32(ctx.h, _ptr(w), None if o is None else _ptr(o), n, k, C.byref(h)))
+        return cls(ctx, h, [n if o is None else 2 * n, k])
+
     def shape(self):
         return list(self._shape)
 
@@ -206,6 +215,24 @@ def q4_matmul(x, weights: Q4Tensor):
         raise VoxError(1, f"q4_matmul: input K={k} != weight K={kw}")
     out = np.empty((b, m, n), dtype=np.float32)
     check(lib().vox_q4_matmul(weights.ctx.h, weights.h, _ptr(x), b, m, _ptr(out), 0))
+    return out
+
+
+def linear_forward(weights: Q4Tensor, x, bias=None, epilogue=0):
+    """Linear::forward with a fused epilogue (0 none, 1 GELU, 2 SwiGLU over interleaved gate / up rows -> N / 2 columns); x [B, M, K]."""
+    x = _f32(x); b, m, k = x.shape; n = weights.shape()[0]
+    out = np.empty((b, m, n // 2 if epilogue == 2 else n), dtype=np.float32)
+    bb = None if bias is None else _f32(bias)
+    check(lib().vox_linear_forward_ex(weights.ctx.h, weights.h, None if bb is None else _ptr(bb), _ptr(x), b, m, _ptr(out), epilogue, 0))
+    return out
+
+
+def conv_downsample(ctx, x, w1, b1, w2, b2):
+    """ConvDownsampler::forward (models/layers/conv.rs:78-83): x [C, L] -> [O, L2] through the conv stem's im2col MFMA path."""
+    x, w1, b1, w2, b2 = (_f32(a) for a in (x, w1, b1, w2, b2))
+    c_, l_ = x.shape; o_ = w1.shape[0]; l2 = ((l_ + 1) // 2 + 1) // 2
+    out = np.empty((o_, l2), dtype=np.float32)
+    check(lib().vox_conv_downsample(ctx.h, _ptr(x), c_, l_, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), o_, _ptr(out)))
     return out
 
 
