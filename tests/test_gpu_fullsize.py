@@ -582,6 +582,36 @@ def test_full_decode_engine_lost_publish_times_out_and_the_utterance_is_served_a
         b.close()
 
 
+def test_full_piecewise_surface_reports_an_engine_timeout_on_the_device_resident_path(pkg, full, monkeypatch):
+    """The piecewise decoder surface with one workgroup's publish suppressed (fault-injection flag 16384): a caller that stays on the device-resident entries -- whose only
+    synchronisation is vox_argmax_rows on the CONTEXT, not on the model -- must not be handed silently wrong logits: the engine's error word reaches the host through a
+    pinned buffer refreshed behind every launch, and the caller's NEXT decoder call fails loudly (VOX_ERR_HIP, "hand-off timeout", a strike); after three strikes the
+    per-operator launches serve the calls."""
+    m0, _, ctx = full
+    if not m0.set_decode_engine(True):
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    monkeypatch.setenv("VOX_ENGINE_FLAGS", str(128 | 512 | 1 | 16384))
+    path = os.path.join(cache_dir(), "full_q4_seed42.gguf")
+    b = pkg.Q4ModelLoader.from_file(path).load(ctx)
+    monkeypatch.delenv("VOX_ENGINE_FLAGS")
+    D, V = 3072, 131072
+    t = pkg.TimeEmbedding(D).embed(6.0); dec = b.decoder(); cache = dec.create_cache_preallocated(64)
+    d_x = ctx.upload((0.1 * np.random.default_rng(3).standard_normal(D)).astype(np.float32)); d_l = ctx.alloc(V * 4)
+    try:
+        strikes = 0
+        for step in range(8):
+            try:
+                hid = dec.forward_hidden_with_cache_dev(d_x, 1, t, cache)      # engine launch; the PREVIOUS launch's verdict is checked here
+                dec.lm_head_dev(hid, 1, d_l); pkg.argmax_rows_dev(ctx, d_l, 1, V)      # device-resident: synchronises the context only
+            except pkg.VoxError as e:
+                assert "hand-off timeout" in str(e); strikes += 1
+        assert strikes == 3 and not b.set_decode_engine(True)      # three launches failed loudly (each reported at the next call), then the engine is off for the model
+        hid = dec.forward_hidden_with_cache_dev(d_x, 1, t, cache)     # served by the per-operator launches now
+        assert np.isfinite(ctx.download(hid, (D,))).all()
+    finally:
+        cache.close(); ctx.free(d_x); ctx.free(d_l); b.close()
+
+
 def test_full_engines_on_a_gpu_that_is_not_theirs_alone(pkg, full, capfd):
     """The engines' workgroups wait for each other, so all 256 must be resident: a long kernel on ANOTHER stream (64 x 1024-thread workgroups spinning for 60 ms --
     vox_debug_occupy) takes CUs away while an utterance / a batch is decoded.  Required: correct ids (whichever path produced them), no hang, and a working engine

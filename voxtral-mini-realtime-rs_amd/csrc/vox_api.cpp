@@ -775,6 +775,7 @@ struct vox_model {
     float* pw_part_val = nullptr; int* pw_part_idx = nullptr; int* pw_ids = nullptr; int pw_ids_cap = 0; int* pw_zero = nullptr;
     EngLayerTab* pw_tab = nullptr; const vox_cache* pw_tab_cache = nullptr; const float* pw_tab_k = nullptr;
     bool pw_memo = false, pw_eng_used = false;
+    unsigned* pw_err_pin = nullptr;      // pinned host copy of the engine's error word, refreshed (async) behind every piecewise engine launch: checked without a device round trip
     vox_timings timings{};
 };
 
@@ -1161,6 +1162,7 @@ static void model_release(vox_model* m) {
                     (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_wob, (void*)m->eng_state, (void*)m->eng_tab, (void*)m->engb_state[0], (void*)m->engb_state[1], (void*)m->engb_state[2], (void*)m->engb_state[3],
                     (void*)m->engb_tab[0], (void*)m->engb_tab[1], (void*)m->engb_tab[2], (void*)m->engb_tab[3], (void*)m->pw_x, (void*)m->pw_hidden, (void*)m->pw_logits, (void*)m->pw_part_val, (void*)m->pw_part_idx, (void*)m->pw_ids, (void*)m->pw_zero, (void*)m->pw_tab})
         if (p) (void)hipFree(p);
+    if (m->pw_err_pin) (void)hipHostFree(m->pw_err_pin);
     delete m;
 }
 extern "C" int32_t vox_model_free(vox_model* m) { model_release(m); return VOX_OK; }
@@ -2332,9 +2334,10 @@ static bool pw_engine_ready(vox_model* m, vox_cache* kc) {
     if (!m->pw_tab) {
         if (hipMalloc((void**)&m->pw_tab, sizeof(EngLayerTab) * 32) != hipSuccess) { (void)hipGetLastError(); m->pw_tab = nullptr; return false; }
         if (hipMalloc((void**)&m->pw_part_val, 256 * 4) != hipSuccess || hipMalloc((void**)&m->pw_part_idx, 256 * 4) != hipSuccess || hipMalloc((void**)&m->pw_zero, 4) != hipSuccess ||
-            hipMemsetAsync(m->pw_zero, 0, 4, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+            hipMemsetAsync(m->pw_zero, 0, 4, s) != hipSuccess || hipHostMalloc((void**)&m->pw_err_pin, 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); m->pw_err_pin = nullptr; return false; }
+        m->pw_err_pin[0] = m->pw_err_pin[1] = 0u;
     }
-    if (!m->pw_part_val || !m->pw_part_idx || !m->pw_zero) return false;
+    if (!m->pw_part_val || !m->pw_part_idx || !m->pw_zero || !m->pw_err_pin) return false;
     if (m->pw_tab_cache != kc || m->pw_tab_k != kc->k) {
         const size_t lf = cache_layer_floats(m, kc);
         std::vector<EngLayerTab> tab(c.dec_layers);
@@ -2354,21 +2357,22 @@ static EngParams pw_engine_params(vox_model* m, const vox_cache* kc, const float
 }
 // after a stream synchronisation that covered a copy of the engine's error word into eng_err_host: a hand-off timeout fails the call loudly (the cache row of that step is
 // rewritten when the caller repeats it), counts a strike and re-arms the engine; three strikes switch it off for the model
+// (the error word reaches the host through a pinned buffer refreshed asynchronously behind every engine launch: a caller that stays on the device-resident entries
+// -- whose only synchronisation is vox_argmax_rows on the CONTEXT -- still gets the failure at its next decoder call, not silently wrong logits)
 static int32_t pw_engine_verdict(vox_model* m) {
-    if (!m->pw_eng_used) return VOX_OK;
-    m->pw_eng_used = false;
-    const unsigned e = m->eng_err_host[0];
+    if (!m->pw_err_pin) return VOX_OK;
+    const unsigned e = *(volatile unsigned*)m->pw_err_pin;
     if (!e) return VOX_OK;
+    m->pw_err_pin[0] = 0u; m->pw_eng_used = false;
     m->eng_strikes++; m->pw_memo = false;
     HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), m->ctx->stream)); m->eng_launches = 0; graphs_destroy(m);
     if (m->eng_strikes >= 3) { m->eng_ok = false; m->eng_on = false; }
     return fail(VOX_ERR_HIP, "decode engine: hand-off timeout (code %u, workgroup %u), strike %d of 3: the GPU is shared; repeat the step%s", e & 0xff, (e >> 8) & 0xff, m->eng_strikes,
                 m->eng_strikes >= 3 ? " (the engine is now switched off, the per-operator launches serve it)" : "");
 }
-static int32_t pw_sync(vox_model* m) {      // synchronise the stream; if an engine launch is outstanding, fetch its verdict with the same wait
-    hipStream_t s = m->ctx->stream;
-    if (m->pw_eng_used) { EngParams ep{}; eng_state_carve(m->eng_state, &ep); HIPCHK(hipMemcpyAsync(m->eng_err_host, ep.err, 8, hipMemcpyDeviceToHost, s)); }
-    HIPCHK(hipStreamSynchronize(s));
+static int32_t pw_sync(vox_model* m) {      // synchronise the stream (the pinned error word of an outstanding engine launch lands with the same wait), then the verdict
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    m->pw_eng_used = false;
     return pw_engine_verdict(m);
 }
 
@@ -2396,6 +2400,7 @@ extern "C" int32_t vox_forward_hidden_with_cache_ex(vox_model* m, const float* x
                                                     int32_t mem_kind) {
     ARGCHK(m && x && t_embed && kc && (out || hidden_ws) && M > 0, "bad argument"); ARGCHK(kc->m == m && kc->kind == 0, "cache belongs to another model or is an encoder cache"); VOXCHK(ctx_bind(m->ctx));
     ARGCHK(mem_kind == VOX_MEM_DEVICE || out, "a host result needs an output buffer");
+    VOXCHK(pw_engine_verdict(m));      // a hand-off timeout of an EARLIER engine step the caller has synchronised past since (free: a pinned host word)
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream; const int D = c.dec_dim;
     ARGCHK(kc->len + M <= kc->max_seq, "KV cache overflow: %d + %d > %d", kc->len, M, kc->max_seq);
     VOXCHK(vox_model_set_t_embed(m, t_embed));
@@ -2412,6 +2417,7 @@ extern "C" int32_t vox_forward_hidden_with_cache_ex(vox_model* m, const float* x
         const EngParams ep = pw_engine_params(m, kc, xin);
         HIPCHK(launch_decode_engine(ep, s));
         HIPCHK(launch_eng_hidden(ep, m->pw_hidden, s));
+        HIPCHK(hipMemcpyAsync(m->pw_err_pin, ep.err, 8, hipMemcpyDeviceToHost, s));      // pinned destination: truly asynchronous
         m->pw_memo = true; m->pw_eng_used = true;
     } else {
         if (xin != m->pw_x) HIPCHK(hipMemcpyAsync(m->pw_x, xin, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
