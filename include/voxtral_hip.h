@@ -287,6 +287,17 @@ int32_t vox_lm_head_argmax(vox_model* m, const float* hidden_MxD, int32_t M, int
  * token_ids[n] host, logits[n][vocab] host; the cache advances by n. */
 int32_t vox_generate_step_with_cache(vox_model* m, const int32_t* token_ids, int32_t n, const float* t_embed, vox_cache* cache, float* logits_nxV);
 
+/* Composite forwards, mel [128][T] -> logits [S][vocab] in one call (nothing leaves the device between the stages); *S = decoder positions = floor(S_enc / 4):
+ *   vox_forward             Q4VoxtralModel::forward            gguf/model.rs:820-830   the audio embeddings alone are the decoder input
+ *   vox_forward_streaming   Q4VoxtralModel::forward_streaming  gguf/model.rs:802-816   audio embeddings + embed(token_ids); n_ids must equal S (vox_num_audio_tokens tells it in advance)
+ *   vox_forward_with_cache  Q4VoxtralModel::forward_with_cache gguf/model.rs:833-843   encode_audio_with_cache + forward_hidden_with_cache against the caller's two caches
+ * mel / logits host or device per mem_kind; token ids and t_embed host. */
+int32_t vox_forward(vox_model* m, const float* mel_128xT, int32_t T, const float* t_embed, float* logits_SxV, int32_t cap_rows, int32_t* S, int32_t mem_kind);
+int32_t vox_forward_streaming(vox_model* m, const float* mel_128xT, int32_t T, const int32_t* token_ids, int32_t n_ids, const float* t_embed, float* logits_SxV,
+                              int32_t cap_rows, int32_t* S, int32_t mem_kind);
+int32_t vox_forward_with_cache(vox_model* m, const float* mel_128xT, int32_t T, const float* t_embed, vox_cache* enc_cache, vox_cache* dec_cache, float* logits_SxV,
+                               int32_t cap_rows, int32_t* S, int32_t mem_kind);
+
 /* stage timers, BenchmarkResult parity (bin/e2e_bench.rs:62-74): ms of the last transcribe call */
 typedef struct { double preprocess_ms, encode_ms, decode_ms, total_ms; int32_t decode_tokens; int32_t graph_replays; } vox_timings;
 int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out);

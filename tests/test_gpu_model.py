@@ -367,6 +367,36 @@ def test_generate_step_with_cache_equals_composed_calls(pkg, tiny):
     assert ca.seq_len() == cb.seq_len() == 7
 
 
+def test_composite_forwards_equal_composed_calls_and_the_oracle(pkg, orc, tiny):
+    """Q4VoxtralModel::forward / forward_streaming / forward_with_cache (gguf/model.rs:802-843: mel -> logits in one call) against the pieces they are made of
+    (encode_audio -> [+ embed] -> forward_hidden_with_cache on a fresh cache -> lm_head: bit-identical) and against the oracle's composition (<= 2e-4)."""
+    m, o = tiny[0], tiny[1]
+    t = pkg.TimeEmbedding(m.config.dec_dim).embed(6.0)
+    mel = fake_mel(700, seed=11); dec = m.decoder()
+    audio = m.encode_audio(mel[None])[0]; S = audio.shape[0]
+    ids = (np.arange(S) * 7 % 200 + 3).astype(np.int32)
+    # forward: audio embeddings alone
+    la = m.forward(mel[None], t)[0]
+    c = dec.create_cache_preallocated(max(S, 8)); lb = dec.lm_head(dec.forward_hidden_with_cache(audio[None], t, c))[0]
+    assert la.shape == (S, m.config.vocab) and np.array_equal(la, lb)
+    oc = o.cache(max(S, 8)); ra = o.encode_audio(mel); rl = o.lm_head(o.forward_hidden_with_cache(ra, t, oc)); o.cache_free(oc)
+    assert rel_err(la, rl) < 3e-4
+    # forward_streaming: + one token embedding per position
+    ls = m.forward_streaming(mel[None], ids, t)[0]
+    c2 = dec.create_cache_preallocated(max(S, 8)); x = audio + dec.embed_tokens_from_ids(ids, 1, S)[0]
+    assert np.array_equal(ls, dec.lm_head(dec.forward_hidden_with_cache(x[None], t, c2))[0])
+    with pytest.raises(pkg.VoxError):
+        m.forward_streaming(mel[None], ids[:-1], t)                      # one id per audio position
+    # forward_with_cache: two chunks through the streaming encoder and the cached decoder == the two-call composition on twin caches
+    ea, da = m.create_encoder_cache(), dec.create_cache_preallocated(256); eb, db = m.create_encoder_cache(), dec.create_cache_preallocated(256)
+    for lo_, hi_ in ((0, 352), (352, 700)):
+        chunk = np.ascontiguousarray(mel[:, lo_:hi_])
+        lw = m.forward_with_cache(chunk[None], t, ea, da)[0]
+        au = m.encode_audio_with_cache(chunk[None], eb)
+        assert np.array_equal(lw, dec.lm_head(dec.forward_hidden_with_cache(au, t, db))[0])
+    assert da.seq_len() == db.seq_len() > 0
+
+
 @pytest.mark.parametrize("scheme", ["reference", "ggml"])
 def test_exported_gguf_round_trip_on_device(pkg, orc, ctx, tmp_path, scheme):
     """SURVEY 8(f4) on the GPU: a dense checkpoint (SafeTensors) exported by export.py (reference test quantiser gguf/tests.rs:24-57, and llama.cpp's quantize_row_q4_0_ref)

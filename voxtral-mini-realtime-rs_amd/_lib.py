@@ -129,6 +129,9 @@ SIGNATURES = {
     "vox_lm_head_ex": (i32, [vp, vp, i32, vp, i32]),
     "vox_argmax_rows": (i32, [vp, vp, i32, i32, vp, i32]),
     "vox_lm_head_argmax": (i32, [vp, vp, i32, vp, i32]),
+    "vox_forward": (i32, [vp, vp, i32, vp, vp, i32, P(i32), i32]),
+    "vox_forward_streaming": (i32, [vp, vp, i32, vp, i32, vp, vp, i32, P(i32), i32]),
+    "vox_forward_with_cache": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, P(i32), i32]),
     "vox_get_stage_timings": (i32, [vp, P(Timings)]),
     "vox_bench_decode_gemv": (i32, [vp, i32, i32, P(C.c_double), P(C.c_double), P(C.c_char_p)]),
     "vox_debug_timeline_start": (i32, [vp, i32, i32]),

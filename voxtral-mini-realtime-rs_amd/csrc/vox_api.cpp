@@ -2520,6 +2520,68 @@ extern "C" int32_t vox_generate_step_with_cache(vox_model* m, const int32_t* tok
     return r;
 }
 
+// ---- composite forwards of Q4VoxtralModel (gguf/model.rs:802-843): mel -> logits in one call, composed of the pieces above -- nothing leaves the device in between.
+// mode 0: forward (audio embeddings alone are the decoder input, :820-830); 1: forward_streaming (audio + embed(token_ids), :802-816); 2: forward_with_cache
+// (encode_audio_with_cache + forward_hidden_with_cache against the caller's caches, :833-843).  logits [S][vocab]; *S = decoder positions.
+static int32_t forward_composite(vox_model* m, int mode, const float* mel, int32_t T, const int32_t* token_ids, int32_t n_ids, const float* t_embed, vox_cache* enc_cache,
+                                 vox_cache* dec_cache, float* logits, int32_t cap_rows, int32_t* S_out, int32_t mem_kind) {
+    ARGCHK(m && mel && t_embed && logits && S_out && T > 0, "bad argument"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream; const int D = c.dec_dim;
+    const float* d_mel = mel;
+    if (mem_kind == VOX_MEM_HOST) {
+        VOXCHK(ensure(&m->d_mel, &m->mel_cap, (size_t)c.n_mels * T));
+        HIPCHK(hipMemcpyAsync(m->d_mel, mel, (size_t)c.n_mels * T * 4, hipMemcpyHostToDevice, s)); d_mel = m->d_mel;
+    }
+    int S = 0;
+    if (mode == 2) {
+        ARGCHK(enc_cache && dec_cache && enc_cache->kind == 1 && enc_cache->m == m && dec_cache->kind == 0 && dec_cache->m == m, "forward_with_cache needs an encoder and a decoder cache of this model");
+        ARGCHK(cap_rows >= enc_rows(T) / c.reshape_factor, "logits capacity %d rows < %d", cap_rows, enc_rows(T) / c.reshape_factor);      // before anything is appended to the caches
+        ARGCHK(dec_cache->len + enc_rows(T) / c.reshape_factor <= dec_cache->max_seq, "decoder cache overflow");
+        VOXCHK(encode_with_cache_dev(m, d_mel, T, enc_cache, &S));
+    } else {
+        ARGCHK(cap_rows >= enc_rows(T) / c.reshape_factor, "logits capacity %d rows < %d", cap_rows, enc_rows(T) / c.reshape_factor);
+        VOXCHK(encode_dev(m, d_mel, T, &S));
+    }
+    *S_out = S;
+    if (S <= 0) { HIPCHK(hipStreamSynchronize(s)); return VOX_OK; }
+    const float* x = m->d_audio;      // [S][D]
+    if (mode == 1) {
+        ARGCHK(token_ids && n_ids == S, "forward_streaming: %d token ids for %d audio positions", n_ids, S);
+        VOXCHK(pw_ids_dev(m, token_ids, S));
+        // audio_embeds + text_embeds (:810-812): the embedding kernel adds the audio rows itself
+        VOXCHK(ensure(&m->pw_x, &m->pw_x_cap, (size_t)S * D));
+        HIPCHK(launch_embed(m->tok.w, m->pw_ids, S, m->d_audio, D, nullptr, 0, 0, m->pw_x, s));
+        x = m->pw_x;
+    }
+    vox_cache* kc = dec_cache; vox_cache* tmp = nullptr;
+    if (mode != 2) { VOXCHK(cache_alloc(m, std::max(S, 8), &tmp)); kc = tmp; }      // forward_hidden(.., offset 0): a cache of exactly this call's rows
+    const float* hid = nullptr;
+    int32_t r = vox_forward_hidden_with_cache_ex(m, x, S, t_embed, kc, nullptr, &hid, VOX_MEM_DEVICE);
+    if (r == VOX_OK) {
+        float* ly = logits;
+        if (mem_kind == VOX_MEM_HOST) { r = ensure(&m->pw_logits, &m->pw_logits_cap, (size_t)S * c.vocab); ly = m->pw_logits; m->pw_memo = false; }
+        if (r == VOX_OK && !(pw_memo_hit(m, hid, S, VOX_MEM_DEVICE) && ly == m->pw_logits)) {
+            if (pw_memo_hit(m, hid, S, VOX_MEM_DEVICE)) { if (hipMemcpyAsync(ly, m->pw_logits, (size_t)c.vocab * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) r = fail(VOX_ERR_HIP, "copy of the logits failed"); }
+            else r = q4_linear_dev(m->ctx, m->tok.w, nullptr, hid, D, S, ly, c.vocab);
+        }
+        if (r == VOX_OK && mem_kind == VOX_MEM_HOST && hipMemcpyAsync(logits, ly, (size_t)S * c.vocab * 4, hipMemcpyDeviceToHost, s) != hipSuccess) r = fail(VOX_ERR_HIP, "copy of the logits failed");
+    }
+    const int32_t rs = pw_sync(m);
+    if (tmp) (void)vox_cache_free(tmp);
+    return r != VOX_OK ? r : rs;
+}
+extern "C" int32_t vox_forward(vox_model* m, const float* mel, int32_t T, const float* t_embed, float* logits, int32_t cap_rows, int32_t* S, int32_t mem_kind) {
+    return forward_composite(m, 0, mel, T, nullptr, 0, t_embed, nullptr, nullptr, logits, cap_rows, S, mem_kind);
+}
+extern "C" int32_t vox_forward_streaming(vox_model* m, const float* mel, int32_t T, const int32_t* token_ids, int32_t n_ids, const float* t_embed, float* logits, int32_t cap_rows,
+                                         int32_t* S, int32_t mem_kind) {
+    return forward_composite(m, 1, mel, T, token_ids, n_ids, t_embed, nullptr, nullptr, logits, cap_rows, S, mem_kind);
+}
+extern "C" int32_t vox_forward_with_cache(vox_model* m, const float* mel, int32_t T, const float* t_embed, vox_cache* enc_cache, vox_cache* dec_cache, float* logits, int32_t cap_rows,
+                                          int32_t* S, int32_t mem_kind) {
+    return forward_composite(m, 2, mel, T, nullptr, 0, t_embed, enc_cache, dec_cache, logits, cap_rows, S, mem_kind);
+}
+
 extern "C" int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out) { ARGCHK(m && out, "null argument"); *out = m->timings; return VOX_OK; }
 
 // ---- measurement hook: average launch duration of one decode-step GEMV class, HIP events on the ctx stream

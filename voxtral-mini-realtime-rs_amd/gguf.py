@@ -399,6 +399,31 @@ class Q4VoxtralModel:
         check(lib().vox_generate_step_with_cache(self.h, _ptr(ids), ids.size, _ptr(_f32(t_embed).reshape(-1)), caches.h, _ptr(out)))
         return out
 
+    def _mel2(self, mel):
+        mel = _f32(mel); return mel.reshape(mel.shape[-2], mel.shape[-1])
+
+    def forward(self, mel, t_embed):
+        """gguf/model.rs:820-830: mel -> logits [1, S, vocab], the audio embeddings alone as decoder input."""
+        mel = self._mel2(mel); T = mel.shape[1]; cap = T // 16 + 2
+        out = np.empty((cap, self.config.vocab), dtype=np.float32); S = C.c_int32()
+        check(lib().vox_forward(self.h, _ptr(mel), T, _ptr(_f32(t_embed).reshape(-1)), _ptr(out), cap, C.byref(S), 0))
+        return out[:S.value][None].copy()
+
+    def forward_streaming(self, mel, token_ids, t_embed):
+        """gguf/model.rs:802-816: mel + one token id per audio position -> logits [1, S, vocab]."""
+        mel = self._mel2(mel); T = mel.shape[1]; cap = T // 16 + 2
+        ids = np.ascontiguousarray(token_ids, dtype=np.int32).reshape(-1)
+        out = np.empty((cap, self.config.vocab), dtype=np.float32); S = C.c_int32()
+        check(lib().vox_forward_streaming(self.h, _ptr(mel), T, _ptr(ids), ids.size, _ptr(_f32(t_embed).reshape(-1)), _ptr(out), cap, C.byref(S), 0))
+        return out[:S.value][None].copy()
+
+    def forward_with_cache(self, mel, t_embed, encoder_cache, decoder_cache):
+        """gguf/model.rs:833-843: one chunk through the streaming encoder and the cached decoder -> logits [1, S_chunk, vocab]."""
+        mel = self._mel2(mel); T = mel.shape[1]; cap = T // 16 + 2
+        out = np.empty((cap, self.config.vocab), dtype=np.float32); S = C.c_int32()
+        check(lib().vox_forward_with_cache(self.h, _ptr(mel), T, _ptr(_f32(t_embed).reshape(-1)), encoder_cache.h, decoder_cache.h, _ptr(out), cap, C.byref(S), 0))
+        return out[:S.value][None].copy()
+
     def set_decode_engine(self, on: bool) -> bool:
         """Persistent decode-step engine (one launch per token) on / off; returns whether it is active (it needs the real decoder geometry on a 256-CU device)."""
         a = C.c_int32(); check(lib().vox_model_set_decode_engine(self.h, 1 if on else 0, C.byref(a))); return bool(a.value)
