@@ -9,6 +9,8 @@ pkg = load_package(); ctx = pkg.Context(0); L = pkg.lib()
 rng = np.random.default_rng(0)
 KN = [(1280, 3840), (1280, 10240), (5120, 1280), (1280, 1280)]
 Ms = [800, 12800]
+if os.environ.get("VOX_AB_SHAPES") == "prefill":      # the batched decoder prefill: 16 x 38 rows
+    KN = [(3072, 6144), (4096, 3072), (3072, 18432), (9216, 3072)]; Ms = [608, 1216, 2432]
 tens = {kn: pkg.Q4Tensor.from_q4_bytes(pkg.synth.synth_q4_blocks(rng, kn[0] * kn[1], 0.02), [kn[1], kn[0]], ctx) for kn in KN}
 for m in Ms:
     row = []
