@@ -17,7 +17,7 @@ rank 0 parses the GGUF and the packed weight arena reaches the other ranks throu
 Rank 0 prints ONE JSON line.  Extras in the same line (never `value`):
   `batch`       BASELINE configs[3]: 16 clips through vox_transcribe_batch (N = 1)
   `f32`         BASELINE configs[1]: the same clip through the f32 SafeTensors path (dense bf16 weights, N = 1)
-  `fleurs_like` BASELINE configs[4] stand-in: 647 clips with FLEURS-like durations sharded LPT over the ranks, 64-clip length-bucketed batches per rank (--fleurs-batch)
+  `fleurs_like` BASELINE configs[4] stand-in: 647 clips with FLEURS-like durations sharded LPT over the ranks, each rank's share in ONE vox_transcribe_batch call (continuous batching; --fleurs-batch)
                 (replaces bin/transcribe.rs:112-126's serial loop); aggregate RTF, tok/s, LPT imbalance (every N)
   `piecewise`   the reference's metric loop (bin/e2e_bench.rs:179-224) call for call through the C ABI from C (tools/e2e_piecewise.c), N = 1
   `roofline`    dominant decode kernel, HIP events on the library stream + committed PMC traffic;  `cpu_baseline`  CPU oracle, bounded sample
@@ -137,7 +137,8 @@ def piecewise_extra(pkg, gguf_path, x, ref_ids, reps=3):
 
 def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch, simulate_world=0, bcast_bytes=0):
     """BASELINE configs[4] stand-in (no FLEURS offline): `n_clips` synthetic clips with FLEURS-like durations, LPT-sharded over the ranks
-    (shard.run_sharded), each rank running `batch`-clip length-bucketed batches (64: four concurrent 16-row groups) through vox_transcribe_batch; results gathered in input order.
+    (shard.run_sharded), each rank handing its share to vox_transcribe_batch in calls of <= `batch` clips (default: the whole share in one call -- continuous batching over
+    16 .. 64 decode slots; 64: the round-4 form, length-bucketed lock-step batches); results gathered in input order.
     Wall time = barrier .. barrier, max over ranks.  Replaces the reference's serial per-file loop (bin/transcribe.rs:112-126)."""
     import importlib
     shard = importlib.import_module(pkg.__name__ + ".shard")
@@ -204,7 +205,7 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
                "weight_broadcast_s_estimate": round(bcast_bytes / 100e9, 3),
                "note": "one-GPU bound on the N-GPU curve of this corpus (replicas only: no data-path collective); broadcast estimate at 100 GB/s per xGMI ring hop"}
     return {"simulated_world": sim, "workload": f"{n_clips} synthetic clips, FLEURS-like log-normal durations (median 10 s, 3..30 s, rng 7), host samples -> ids; LPT shards over {world} rank(s), "
-                        f"{batch}-clip length-bucketed batches (BASELINE configs[4] stand-in; no FLEURS / WER offline)",
+                        f"{'one vox_transcribe_batch call per rank (continuous batching)' if batch >= n_clips else f'{batch}-clip length-bucketed calls'} (BASELINE configs[4] stand-in; no FLEURS / WER offline)",
             "clips": n_clips, "audio_s": round(total_s, 1), "wall_s": round(dt, 3), "rtf": round(dt / total_s, 6), "tok_per_s": round(ntok / dt, 1),
             "ids": ntok, "lpt_imbalance": round(shard.imbalance(durs, parts), 4), "batch": batch}
 
@@ -223,7 +224,7 @@ def main():
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 SafeTensors extra (BASELINE configs[1], N = 1)")
     ap.add_argument("--fleurs-clips", type=int, default=647, help="clips of the FLEURS-like sharded extra (BASELINE configs[4] stand-in); 0 = skip")
     ap.add_argument("--simulate-world", type=int, default=8, help="N = 1 only: also run each of W ranks' share of the FLEURS-like corpus serially on this GPU and report the predicted 1 -> W scaling (0 = skip)")
-    ap.add_argument("--fleurs-batch", type=int, default=64, help="clips per vox_transcribe_batch call of the FLEURS-like extra (<= 64)")
+    ap.add_argument("--fleurs-batch", type=int, default=0, help="clips per vox_transcribe_batch call of the FLEURS-like extra; 0 (default) = a rank's whole share in ONE call (continuous batching over slots, round 5); 64 = the round-4 length-bucketed lock-step batches")
     ap.add_argument("--gemv-iters", type=int, default=260)
     args = ap.parse_args()
 
@@ -306,7 +307,7 @@ def main():
     fleurs = None
     if args.fleurs_clips > 0:
         try:
-            fleurs = fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, args.fleurs_clips, max(1, min(64, args.fleurs_batch)),
+            fleurs = fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, args.fleurs_clips, max(1, min(4096, args.fleurs_batch)) if args.fleurs_batch > 0 else 4096,
                                        simulate_world=args.simulate_world, bcast_bytes=model.arena()[1])
         except Exception as e:     # an extra never costs the headline line
             fleurs = {"error": str(e)} if rank == 0 else None

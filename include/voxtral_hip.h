@@ -247,6 +247,11 @@ int32_t vox_decoder_cache_create(vox_model* m, int32_t max_seq, vox_cache** out)
 int32_t vox_cache_free(vox_cache* c);
 int32_t vox_cache_seq_len(const vox_cache* c, int32_t* out);                         /* KVCache::seq_len */
 int32_t vox_cache_reset(vox_cache* c);
+/* KVCache::update on layer `layer` of a pre-allocated cache (models/layers/kv_cache.rs:116-136: slice_assign of k / v [1][heads][n_rows][head_dim] at rows pos ..
+ * pos + n_rows); the length shared by all layers (LayerCaches::seq_len, :242-244) becomes max(len, pos + n_rows).  heads = dec_kv_heads (decoder cache) / enc_heads. */
+int32_t vox_cache_update(vox_cache* c, int32_t layer, int32_t pos, const float* k_HxNxhd, const float* v_HxNxhd, int32_t n_rows, int32_t mem_kind);
+/* forget the rows from `len` on (0 <= len <= seq_len): the next forward appends at `len` again */
+int32_t vox_cache_truncate(vox_cache* c, int32_t len);
 /* Streaming encoder: Q4AudioEncoder::create_cache + Q4VoxtralModel::encode_audio_with_cache (gguf/model.rs:437-459,791-799; per layer
  * :299-317,125-174), eviction KVCache::apply_sliding_window (kv_cache.rs:176-203).  The chunk's conv output rows are run through the 32 layers
  * against the cached K / V (RoPE at the absolute stream position; the cache evicts rows older than the 750-row window by itself when a chunk
@@ -270,7 +275,10 @@ int32_t vox_lm_head(vox_model* m, const float* hidden_MxD, int32_t M, float* log
  * persistent decode engine when that is active (vox_model_set_decode_engine) -- the launch that also computes the row's lm_head; vox_lm_head_ex / vox_lm_head_argmax
  * on the hidden buffer it handed out (`*hidden_ws`, READ-ONLY for the caller, valid until the next decoder call on the model) then return those logits / that token
  * instead of streaming the lm_head again.  Any other hidden pointer is multiplied for real.  Engine hand-off timeouts (shared GPU) surface as VOX_ERR_HIP at the next
- * synchronising call (vox_lm_head_argmax, host-kind outputs); the cache length is rolled back where the failing call itself advanced it, repeat the step.
+ * synchronising call -- vox_lm_head_argmax, vox_argmax_rows, vox_ctx_synchronize, host-kind outputs -- i.e. in the step that failed when the caller reads a token per
+ * step as the reference's loop does.  The library remembers which rows of the cache it has not verified yet (the engine steps since the last synchronisation and
+ * anything appended behind them) and takes exactly those back: after the error vox_cache_seq_len() is the length before the failed step, REPEAT THE STEP (same
+ * token, same position) and the ids are those of an undisturbed run (tests/test_gpu_fullsize.py::test_full_piecewise_surface_recovers_from_an_engine_timeout).
  * ids are always host memory (the reference passes &[i32]). */
 int32_t vox_embed_tokens_from_ids_ex(vox_model* m, const int32_t* ids_host, int32_t n, float* out_nxD, int32_t mem_kind);
 /* `audio_pos + text_embed` (bin/e2e_bench.rs:212, gguf/model.rs:902,946): out[i] = a[i] + b[i] on the context's stream */

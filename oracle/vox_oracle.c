@@ -868,6 +868,14 @@ orc_cache* orc_cache_create(const orc_model* m, int max_seq) {
 void orc_cache_free(orc_cache* c) { if (c) { free(c->k); free(c->v); free(c); } }
 int  orc_cache_len(const orc_cache* c) { return c->len; }
 void orc_cache_reset(orc_cache* c) { c->len = 0; }
+/* KVCache::update on one layer (models/layers/kv_cache.rs:116-136): k / v [n_kv][n][hd] -> rows pos .. pos + n of the layer; len = max(len, pos + n) */
+void orc_cache_update(orc_cache* c, int layer, int pos, const float* k, const float* v, int n) {
+    for (int h = 0; h < c->n_kv; h++) for (int r = 0; r < n; r++) {
+        size_t dst = (((size_t)layer * c->max_seq + pos + r) * c->n_kv + h) * c->hd, src = ((size_t)h * n + r) * c->hd;
+        memcpy(c->k + dst, k + src, sizeof(float) * c->hd); memcpy(c->v + dst, v + src, sizeof(float) * c->hd);
+    }
+    if (pos + n > c->len) c->len = pos + n;
+}
 
 /* gguf/model.rs:665-677 -> :370-387 -> :125-174, :250-255, :220-224 */
 void orc_forward_hidden_with_cache(const orc_model* m, const float* xin, int M, const float* t_embed, orc_cache* kc, float* out) {

@@ -121,6 +121,7 @@ def lib():
         "orc_cache_free": (None, [vp]),
         "orc_cache_len": (C.c_int, [vp]),
         "orc_cache_reset": (None, [vp]),
+        "orc_cache_update": (None, [vp, C.c_int, C.c_int, f32p, f32p, C.c_int]),
         "orc_forward_hidden_with_cache": (None, [vp, f32p, C.c_int, f32p, vp, f32p]),
         "orc_lm_head": (None, [vp, f32p, C.c_int, f32p]),
         "orc_transcribe_streaming": (C.c_int, [vp, f32p, C.c_int, f32p, i32p, C.c_int, vp]),
@@ -286,6 +287,10 @@ class Model:
 
     def cache_free(self, c):
         lib().orc_cache_free(c)
+
+    def cache_update(self, c, layer, pos, k, v):
+        k = f32(k); v = f32(v)
+        lib().orc_cache_update(c, layer, pos, k, v, k.shape[1])
 
     def forward_hidden_with_cache(self, x, t_embed, cache):
         x = f32(x); M = x.shape[0]

@@ -35,6 +35,25 @@ def test_no_oracle_in_product(pkg):
     assert "oracle" not in out and "libamdhip64" in out
 
 
+def test_no_kernel_spills_or_scratch(pkg):
+    """Every kernel of the shipped gfx950 code objects: no VGPR spilled to scratch, no private segment (dense2_gemm_kernel<4,*> ran with 187-212 spilled
+    VGPRs and ~700 B of scratch per lane, a dead fused-attention GEMV instantiation with 93).  Read from the AMDGPU metadata notes of the library's embedded code
+    objects (tools/kernel_resources.py) -- no GPU needed.  SGPR spills into VGPR lanes are not memory traffic and are not counted."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import kernel_resources
+    rows = kernel_resources(pkg.build.LIB_PATH)
+    assert len(rows) >= 300
+    names = " ".join(r["demangled"] for r in rows)
+    for k in ("decode_engine_kernel", "decode_engine_b16_kernel", "q4_gemm_big_kernel", "dense2_gemm_kernel", "mel_kernel"):
+        assert k in names, k
+    bad = [(r["demangled"], r.get(".vgpr_spill_count", 0), r.get(".private_segment_fixed_size", 0)) for r in rows
+           if r.get(".vgpr_spill_count", 0) or r.get(".private_segment_fixed_size", 0) or str(r.get(".uses_dynamic_stack", False)).lower() == "true"]
+    assert not bad, bad
+    eng = [r for r in rows if "decode_engine" in r["demangled"]]
+    assert eng and all(r[".vgpr_count"] <= 128 for r in eng)      # 14 waves per CU need <= 128 VGPRs
+
+
 def test_compute_fails_loudly_without_gpu(pkg):
     n = C.c_int32(); pkg._lib.check(pkg.lib().vox_device_count(C.byref(n)))
     if n.value > 0:

@@ -237,6 +237,46 @@ def test_full_peaked_golden_all_ids_single_batch16_ragged(pkg):
         m.close(); ctx.close()
 
 
+def test_full_wide_batches_peaked_golden_64_lockstep_and_81_continuous(pkg, monkeypatch):
+    """VERDICT r4 items 2 / 3(a), full size, on the peaked golden (no near-tie anywhere: ALL 108 ids are asserted):
+    (a) a 64-row batch -- the width BASELINE configs[4] ran at in round 4 -- with the golden clip in the caller's slots 0, 31 and 63 among 3 .. 9 s clips, on the four forked
+        lock-step launch chains (VOX_BATCH_NO_CONTINUOUS=1: the widest batch asserted at full size before was 22 rows) and on the default path (continuous batching);
+    (b) an 81-row batch (a rank's share of the 647-clip corpus at 8 GPUs) in ONE call: continuous batching over slots, two encoder / prefill chunks, refilled slots --
+        golden clip in slots 0, 40 and 80; every other row equal to what the 64-row lock-step batch gave for the same clip (rows are independent of slot, group and batch)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_16s_peaked_oracle.npz"))
+    path = os.path.join(cache_dir(), "full_q4_peaked_seed44.gguf")
+    if not os.path.exists(path):
+        pkg.synth.write_synthetic_gguf(path + ".tmp", pkg.synth.ModelDims(), seed=44, peaked=True); os.replace(path + ".tmp", path)
+    x = pkg.synth.synth_audio(16.0, seed=7049); rids = g["ids"]
+    ctx = pkg.Context(0); m = pkg.Q4ModelLoader.from_file(path).load(ctx)
+    try:
+        t = pkg.TimeEmbedding(3072).embed(6.0)
+        short = [pkg.synth.synth_audio(3.0 + 0.37 * (i % 17), seed=700 + i) for i in range(78)]
+        b64 = list(short[:61]); b64.insert(0, x); b64.insert(31, x); b64.append(x); assert len(b64) == 64 and b64[31] is x
+        monkeypatch.setenv("VOX_BATCH_NO_CONTINUOUS", "1")
+        lock = m.transcribe_batch(b64, t)
+        monkeypatch.delenv("VOX_BATCH_NO_CONTINUOUS")
+        for sl in (0, 31, 63):
+            assert np.array_equal(lock[sl], rids), f"64-row lock-step batch: slot {sl} differs from the oracle"
+        cont = m.transcribe_batch(b64, t)
+        assert all(len(a) == len(b) and (a == b).all() for a, b in zip(cont, lock)), "64 rows: continuous batching and the lock-step batch disagree"
+        b81 = list(short); b81.insert(0, x); b81.insert(40, x); b81.append(x); assert len(b81) == 81 and b81[40] is x
+        o81 = m.transcribe_batch(b81, t)
+        tm = m.timings(); assert tm["decode_tokens"] == sum(len(o) for o in o81)
+        for sl in (0, 40, 80):
+            assert np.array_equal(o81[sl], rids), f"81-row continuous batch: slot {sl} differs from the oracle"
+        ref_of = {id(c): o for c, o in zip(b64, lock)}
+        n_cmp = 0
+        for c, o in zip(b81, o81):
+            if id(c) in ref_of:
+                assert np.array_equal(o, ref_of[id(c)]); n_cmp += 1
+        assert n_cmp >= 64
+        assert all((a == b).all() for a, b in zip(o81, m.transcribe_batch(b81, t)))      # deterministic
+        print(f"peaked golden: 64-row lock-step and continuous batches, 81-row continuous batch -- golden clip ALL 108 ids in every placed slot, {n_cmp} rows identical across the batches")
+    finally:
+        m.close(); ctx.close()
+
+
 def test_full_ragged_batch_groups_retire(pkg, full):
     """A ragged batch wider than one 16-row group at FULL size: vox_transcribe_batch runs the rows longest first and RETIRES a group's layer chain
     once its longest member is done.  The 16 s golden clip sits in the caller's LAST slot between 3..9 s clips: it must still reproduce the oracle's
@@ -337,21 +377,6 @@ def test_full_30s_f32_heavytail_vs_oracle_golden(pkg):
         m.close(); ctx.close()
 
 
-def test_full_fused_attention_equals_separate_launches(pkg, full, monkeypatch):
-    """Full size, 16 s clip, eager logits path: the fused q|k|v + attention launch (opt-in, VOX_FUSED_ATTN=1) against the default two-launch path -- bit-identical logits for all 108
-    steps (26 layers x 32 heads x 107 steps of cross-workgroup hand-offs under real streaming load; a stale read would show here)."""
-    m, _, ctx = full
-    m.set_decode_engine(False)      # these tests compare variants of the per-operator decode path
-    x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
-    mel = np.ascontiguousarray(pkg.MelSpectrogram.voxtral(ctx).compute_log(pkg.pad_audio(pkg.peak_normalize(x))).T)[None]
-    monkeypatch.setenv("VOX_NO_ATTN_WO", "1")          # both sides on the five-launch layer (attention and wo as separate launches)
-    ids_s, lg_s = m.transcribe_streaming(mel, t, return_logits=True)
-    monkeypatch.setenv("VOX_FUSED_ATTN", "1")
-    ids_f, lg_f = m.transcribe_streaming(mel, t, return_logits=True)
-    monkeypatch.delenv("VOX_FUSED_ATTN")
-    assert np.array_equal(ids_f, ids_s) and np.array_equal(lg_f, lg_s)
-
-
 def test_full_attention_wo_launch(pkg, full, monkeypatch):
     """Full size, 16 s clip: the default decode layer runs attention + wo as ONE launch whose 32-way K split is combined with int64 fixed-point
     atomics (attn_wo_kernel).  (a) order independence: two eager runs give bit-identical logits for all 108 steps although the 256 workgroups'
@@ -418,6 +443,72 @@ def test_full_decode_engine_vs_per_operator_path(pkg, full, seconds, seed):
     assert len(ids_e) == len(ids_o) and (seconds < 20 or len(ids_e) > 180)
     assert np.array_equal(ids_e, ids_o) and err <= 2e-4 * top
     assert np.array_equal(ids_g, ids_e) and np.array_equal(ids_og, ids_o)
+
+
+def test_full_decode_engine_long_positions_60s_unchunked(pkg, full):
+    """the reference's e2e-bench never chunks (bin/e2e_bench.rs:98-135) and the decoder window is 8 192, so a 60 s clip runs the engine to
+    position ~ 470 -- the third and later 192-key attention rounds (positions 384 ... 1024) that no test reached before (the longest was 234).  Engine == per-operator
+    launches: ids up to the first near-tie of the per-operator logits, logits <= 2e-4 of the largest on every step up to there; engine run-to-run bit-identical and
+    graph replay == eager."""
+    m, _, ctx = full
+    if not m.set_decode_engine(True):
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    t = pkg.TimeEmbedding(3072).embed(6.0); mel = _mel_of(pkg, ctx, 60.0, 606)
+    ids_e, lg_e = m.transcribe_streaming(mel, t, return_logits=True)
+    ids_e2 = m.transcribe_streaming(mel, t, return_logits=True)[0]
+    ids_g = m.transcribe_streaming(mel, t)
+    assert not m.set_decode_engine(False)
+    ids_o, lg_o = m.transcribe_streaming(mel, t, return_logits=True)
+    assert len(ids_e) == len(ids_o) and len(ids_e) > 420 and len(ids_e) + 38 <= 1024      # ~ 470 decoder positions, inside the engine's 1024-row cache limit
+    top = float(np.abs(lg_o).max())
+    first = check_greedy_ids(ids_e, ids_o, lg_o, TOL)
+    err = float(np.abs(lg_e[:first + 1] - lg_o[:first + 1]).max())
+    print(f"decode engine vs per-operator path, 60 s un-chunked ({len(ids_e)} ids, positions up to {len(ids_e) + 37}): ids agree for {first}/{len(ids_e)} steps, max |dlogit| {err:.3e} of {top:.2f}")
+    assert err <= TOL * top and first >= 384      # past the second 192-key round at the very least
+    assert np.array_equal(ids_e, ids_e2) and np.array_equal(ids_g, ids_e)
+
+
+@pytest.mark.parametrize("engine", [True, False])
+def test_full_single_decode_launch_at_position_700_vs_oracle(pkg, orc, full, engine):
+    """ONE decode step at position 700 against the oracle on every logit, with a SYNTHETIC cache -- the same N(0, 1) K rows (RoPE is already applied
+    to what a cache holds) and V rows written into the oracle's and the library's cache through KVCache::update (vox_cache_update / orc_cache_update), so no 700-row CPU
+    prefill is needed.  The engine's attention walks four 192-key rounds here; bound 2e-4 of the largest, as at position 38."""
+    m, o, _ = full
+    if m.set_decode_engine(engine) != engine:
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    P, KV, HD, D, L = 700, 8, 128, 3072, 26
+    t = pkg.TimeEmbedding(D).embed(6.0); dec = m.decoder()
+    oc = o.cache(768); c = dec.create_cache_preallocated(768)
+    try:
+        for l in range(L):
+            rng = np.random.default_rng([2026, l])
+            k = rng.standard_normal((KV, P, HD)).astype(np.float32); v = rng.standard_normal((KV, P, HD)).astype(np.float32)
+            o.cache_update(oc, l, 0, k, v); c.update(l, 0, k, v)
+        assert c.seq_len() == P and orc.lib().orc_cache_len(oc) == P
+        worst_h = worst_l = 0.0
+        for step in range(2):      # positions 700 and 701 (the second step attends to the first one's freshly written row)
+            xs = (0.3 * np.random.default_rng([77, step]).standard_normal((1, D))).astype(np.float32)
+            rh = o.forward_hidden_with_cache(xs, t, oc); gh = dec.forward_hidden_with_cache(xs[None], t, c)[0]
+            rl = o.lm_head(rh); gl = dec.lm_head(gh[None])[0]
+            worst_h = max(worst_h, rel_err(gh, rh)); worst_l = max(worst_l, rel_err(gl, rl))
+            assert int(gl.argmax()) == int(rl.argmax())
+        assert c.seq_len() == P + 2
+        c.truncate(P); assert c.seq_len() == P      # vox_cache_truncate: the next forward appends at 700 again ...
+        xs = (0.3 * np.random.default_rng([77, 0]).standard_normal((1, D))).astype(np.float32)
+        gh2 = dec.forward_hidden_with_cache(xs[None], t, c)[0]
+        o2 = o.cache(768)
+        try:
+            for l in range(L):
+                rng = np.random.default_rng([2026, l])
+                k = rng.standard_normal((KV, P, HD)).astype(np.float32); v = rng.standard_normal((KV, P, HD)).astype(np.float32)
+                o.cache_update(o2, l, 0, k, v)
+            assert rel_err(gh2, o.forward_hidden_with_cache(xs, t, o2)) < TOL      # ... and reproduces the first step
+        finally:
+            o.cache_free(o2)
+    finally:
+        o.cache_free(oc); c.close()
+    print(f"one decode launch at position {P} vs oracle (engine {engine}): hidden {worst_h:.2e}, all 131072 logits {worst_l:.2e} of the largest")
+    assert worst_h < TOL and worst_l < TOL
 
 
 def _piecewise_loop(pkg, m, ctx, mel, t, fused):
@@ -585,8 +676,8 @@ def test_full_decode_engine_lost_publish_times_out_and_the_utterance_is_served_a
 def test_full_piecewise_surface_reports_an_engine_timeout_on_the_device_resident_path(pkg, full, monkeypatch):
     """The piecewise decoder surface with one workgroup's publish suppressed (fault-injection flag 16384): a caller that stays on the device-resident entries -- whose only
     synchronisation is vox_argmax_rows on the CONTEXT, not on the model -- must not be handed silently wrong logits: the engine's error word reaches the host through a
-    pinned buffer refreshed behind every launch, and the caller's NEXT decoder call fails loudly (VOX_ERR_HIP, "hand-off timeout", a strike); after three strikes the
-    per-operator launches serve the calls."""
+    pinned buffer refreshed behind every launch, and the synchronising call of the SAME step fails loudly (round 5: vox_argmax_rows / vox_ctx_synchronize read the verdict of
+    the context's pending engine steps; VOX_ERR_HIP, "hand-off timeout", a strike); after three strikes the per-operator launches serve the calls."""
     m0, _, ctx = full
     if not m0.set_decode_engine(True):
         pytest.skip("decode engine not available on this device (needs 256 CUs)")
@@ -601,15 +692,70 @@ def test_full_piecewise_surface_reports_an_engine_timeout_on_the_device_resident
         strikes = 0
         for step in range(8):
             try:
-                hid = dec.forward_hidden_with_cache_dev(d_x, 1, t, cache)      # engine launch; the PREVIOUS launch's verdict is checked here
+                hid = dec.forward_hidden_with_cache_dev(d_x, 1, t, cache)      # engine launch (a verdict that landed since the last call is checked here too)
                 dec.lm_head_dev(hid, 1, d_l); pkg.argmax_rows_dev(ctx, d_l, 1, V)      # device-resident: synchronises the context only
             except pkg.VoxError as e:
                 assert "hand-off timeout" in str(e); strikes += 1
-        assert strikes == 3 and not b.set_decode_engine(True)      # three launches failed loudly (each reported at the next call), then the engine is off for the model
+        assert strikes == 3 and not b.set_decode_engine(True)      # three launches failed loudly, then the engine is off for the model
         hid = dec.forward_hidden_with_cache_dev(d_x, 1, t, cache)     # served by the per-operator launches now
         assert np.isfinite(ctx.download(hid, (D,))).all()
     finally:
         cache.close(); ctx.free(d_x); ctx.free(d_l); b.close()
+
+
+def test_full_piecewise_surface_recovers_from_an_engine_timeout(pkg, full, monkeypatch):
+    """VERDICT r4 item 3(c) / ADVICE r4: after an engine hand-off timeout on the device-resident piecewise path the header promises "repeat the step".  With every engine
+    launch of a second model made to fail (fault-injection flag 16384) a caller that reads a token per step (vox_argmax_rows on the context, as bin/e2e_bench.rs:219-220
+    does) sees the error in the step that failed, finds the cache length rolled back to that step's position, repeats the step -- and ends with EXACTLY the ids, the
+    hidden rows and the cache length of an undisturbed model fed the same rows (the failed launches' garbage K / V rows are overwritten in place: no stale row is ever
+    attended to).  Before round 5 the length stayed advanced and the repeated step appended behind a garbage row."""
+    m0, _, ctx = full
+    if not m0.set_decode_engine(True):
+        pytest.skip("decode engine not available on this device (needs 256 CUs)")
+    D, V, N = 3072, 131072, 12
+    t = pkg.TimeEmbedding(D).embed(6.0)
+    rows = (0.1 * np.random.default_rng(11).standard_normal((N, D))).astype(np.float32)
+    d_rows = ctx.upload(rows); d_l = ctx.alloc(V * 4)
+
+    def loop(model, expect_failures):
+        dec = model.decoder(); cache = dec.create_cache_preallocated(64)
+        ids, hids, fails = [], [], 0
+        try:
+            for i in range(N):
+                for attempt in range(6):
+                    assert cache.seq_len() == i
+                    try:
+                        hid = dec.forward_hidden_with_cache_dev(d_rows + 4 * D * i, 1, t, cache)
+                        dec.lm_head_dev(hid, 1, d_l); tok = pkg.argmax_rows_dev(ctx, d_l, 1, V)
+                    except pkg.VoxError as e:
+                        assert "hand-off timeout" in str(e) and "repeat the step" in str(e), str(e)
+                        assert cache.seq_len() == i, (cache.seq_len(), i)      # rolled back to the failed step's position
+                        fails += 1
+                        continue
+                    ids.append(int(tok[0])); hids.append(ctx.download(hid, (D,)).copy())
+                    break
+                else:
+                    raise AssertionError(f"step {i} never succeeded")
+            assert cache.seq_len() == N
+        finally:
+            cache.close()
+        assert (fails > 0) == expect_failures, fails
+        return np.array(ids), np.stack(hids), fails
+
+    m0.set_decode_engine(False)
+    ids_ref, hid_ref, _ = loop(m0, False)            # undisturbed, per-operator launches (what serves the faulty model once its engine is off)
+    m0.set_decode_engine(True)
+    ids_eng, hid_eng, _ = loop(m0, False)            # undisturbed, engine
+    monkeypatch.setenv("VOX_ENGINE_FLAGS", str(128 | 512 | 1 | 16384))
+    b = pkg.Q4ModelLoader.from_file(os.path.join(cache_dir(), "full_q4_seed42.gguf")).load(ctx)
+    monkeypatch.delenv("VOX_ENGINE_FLAGS")
+    try:
+        ids_b, hid_b, fails = loop(b, True)
+        assert fails == 3 and not b.set_decode_engine(True)      # three strikes, all on step 0, then the per-operator launches
+        assert np.array_equal(ids_b, ids_ref) and np.array_equal(hid_b, hid_ref)      # bit-identical to the undisturbed per-operator run: no garbage row was left behind
+        assert np.array_equal(ids_b, ids_eng) and np.abs(hid_b - hid_eng).max() <= 2e-4 * np.abs(hid_eng).max()
+    finally:
+        ctx.free(d_rows); ctx.free(d_l); b.close()
 
 
 def test_full_engines_on_a_gpu_that_is_not_theirs_alone(pkg, full, capfd):

@@ -214,7 +214,7 @@ def test_transcribe_batch_wide_and_fallback_paths(pkg, ctx, tiny, monkeypatch):
         check_batch_rows(pkg, ctx, m, clips[:16], t, noxf, TOL)
     print(f"batched paths: {n_same}/52 sequences identical to single-stream end to end (the rest diverge at a verified near-tie)")
     with pytest.raises(pkg.VoxError):
-        m.transcribe_batch([clips[0]] * 65, t)                # batch size limit (1..64)
+        m.transcribe_batch([clips[0]] * 4097, t)              # batch size limit (1..4096)
 
 
 def test_transcribe_batch_ragged_groups_retire(pkg, ctx, tiny, monkeypatch):
@@ -237,6 +237,38 @@ def test_transcribe_batch_ragged_groups_retire(pkg, ctx, tiny, monkeypatch):
     print(f"ragged batch with retiring groups: {n_same}/40 sequences identical to single-stream end to end")
     again = m.transcribe_batch(clips, t)
     assert all((a == b).all() for a, b in zip(outs, again))               # deterministic (graphs are re-captured per call)
+
+
+def test_transcribe_batch_continuous_slots(pkg, ctx, tiny, monkeypatch):
+    """Round 5: batches wider than one group run as CONTINUOUS batching over decode slots (vox_api.cpp transcribe_continuous_impl): every utterance is encoded and prefilled
+    up front, the host packs them longest-first onto 16 G slots, and a slot whose utterance gets its last token takes the next one of its queue inside the step's argmax /
+    next-input launch (argmax_embed_slots_kernel; cache slices picked per slot through kv_row).  90 utterances (two encoder chunks of <= 64) of 0.4 .. 4.5 s in arbitrary
+    order, some too short to take a decode step at all: every caller slot must get exactly the ids of (a) the lock-step batches of <= 64 (VOX_BATCH_NO_CONTINUOUS=1), (b) every
+    forced slot-group count 1 .. 4 (different packings, different slots: rows are independent of where they run), (c) the single-stream path up to a near-tie; deterministic."""
+    m, _, _ = tiny
+    t = pkg.TimeEmbedding(256).embed(6.0)
+    secs = [0.4 + 0.23 * ((7 * i) % 19) for i in range(90)]
+    secs[5] = 0.05; secs[41] = 0.12                                           # 76 + 17 pad tokens + almost nothing: S = 46 / 47 -> a handful of steps
+    clips = [pkg.synth.synth_audio(s, seed=1900 + i) for i, s in enumerate(secs)]
+    outs = m.transcribe_batch(clips, t)
+    tm = m.timings(); assert tm["decode_tokens"] == sum(len(o) for o in outs) and tm["graph_replays"] > 0
+    assert len(outs) == 90 and len({len(o) for o in outs}) > 8
+    monkeypatch.setenv("VOX_BATCH_NO_CONTINUOUS", "1")
+    ref = m.transcribe_batch(clips, t)                                        # two lock-step batches of 45
+    monkeypatch.delenv("VOX_BATCH_NO_CONTINUOUS")
+    for r, (a, b) in enumerate(zip(outs, ref)):
+        assert len(a) == len(b) and (a == b).all(), f"slot {r}: continuous batching changed the ids"
+    for G in (1, 2, 3, 4):
+        monkeypatch.setenv("VOX_BATCH_SLOT_GROUPS", str(G))
+        alt = m.transcribe_batch(clips, t)
+        assert all(len(a) == len(b) and (a == b).all() for a, b in zip(outs, alt)), f"{G} slot groups: ids differ"
+    monkeypatch.delenv("VOX_BATCH_SLOT_GROUPS")
+    n_same = check_batch_rows(pkg, ctx, m, clips[:24], t, outs[:24], TOL)
+    again = m.transcribe_batch(clips, t)
+    assert all((a == b).all() for a, b in zip(outs, again))
+    few = m.transcribe_batch(clips[:17], t)                                   # 17 utterances: the narrowest continuous batch
+    assert all((a == b).all() for a, b in zip(few, outs[:17]))
+    print(f"continuous batching, 90 ragged utterances: identical to the lock-step batches and for 1..4 slot groups; {n_same}/24 checked rows identical to single-stream end to end")
 
 
 def test_transcribe_exactly_prefix_len(pkg, orc, tiny):
@@ -296,31 +328,6 @@ def test_load_from_bytes_and_shards(pkg, ctx, tiny):
     assert (mb.transcribe_audio(x, t) == ref).all() and (ms.transcribe_audio(x, t) == ref).all()
     assert mb.weight_bytes() == m.weight_bytes() == ms.weight_bytes()
     mb.close(); ms.close()
-
-
-def test_fused_attention_equals_separate_launches(pkg, tiny, monkeypatch):
-    """The fused q|k|v GEMV + attention launch (EPI_ROPE_KV_ATTN: write-through q / k / v stores, per-head arrival counters, the last-arriving
-    workgroup runs the head) must give bit-identical hidden states and ids to the two-launch path (the default; the fused launch is opt-in, VOX_FUSED_ATTN=1, because it measured slower): same arithmetic, only
-    the hand-off differs.  Eager paths (no cached graph) so the knob takes effect per call."""
-    m, _, _ = tiny
-    t = pkg.TimeEmbedding(256).embed(6.0)
-    rng = np.random.default_rng(12); x = (0.5 * rng.standard_normal((30, 256))).astype(np.float32)
-    dec = m.decoder()
-
-    def run():
-        c = dec.create_cache_preallocated(64)
-        out = [dec.forward_hidden_with_cache(x[None, :6], t, c)[0]] + [dec.forward_hidden_with_cache(x[None, i:i + 1], t, c)[0] for i in range(6, 30)]
-        c.close()
-        mel = fake_mel(1144, seed=3)
-        ids, lg = m.transcribe_streaming(mel[None], t, return_logits=True)
-        return np.concatenate(out), ids, lg
-
-    b = run()                                             # default: two launches
-    monkeypatch.setenv("VOX_FUSED_ATTN", "1")
-    for _ in range(3):                                    # repeat: a stale hand-off would be intermittent
-        a = run()
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    monkeypatch.delenv("VOX_FUSED_ATTN")
 
 
 def test_abi_smoke_c_program_on_device(pkg, tmp_path):

@@ -39,7 +39,7 @@ def rust_type(c: str) -> str:
 def parse_header():
     src = open(HDR).read()
     body = src[src.index('extern "C" {') + 12: src.rindex("#ifdef __cplusplus")]
-    consts = re.findall(r"#define\s+(VOX_[A-Z_]+)\s+(\d+)", src)
+    consts = re.findall(r"#define\s+(VOX_[A-Z_]+)\s+(\d+)(u?)", src)      # a `u` suffix (flag bits passed as uint32_t) -> u32
     opaque = re.findall(r"typedef struct (vox_[a-z0-9_]+) \1;", body)
     nocom = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     structs = []
@@ -82,8 +82,8 @@ def generate() -> str:
         out.append("#[repr(C)] #[derive(Clone, Copy, Debug, Default)]")
         out.append(f"pub struct {name} {{ " + ", ".join(f"pub {KEYWORDS.get(n, n)}: {t}" for n, t in fields) + " }")
     out.append("")
-    for n, v in consts:
-        out.append(f"pub const {n}: i32 = {v};")
+    for n, v, u in consts:
+        out.append(f"pub const {n}: {'u32' if u else 'i32'} = {v};")
     out += ["", 'extern "C" {']
     for name, params, ret in funcs:
         ps = ", ".join(f"{KEYWORDS.get(n, n)}: {t}" for n, t in params)

@@ -113,6 +113,8 @@ SIGNATURES = {
     "vox_cache_free": (i32, [vp]),
     "vox_cache_seq_len": (i32, [vp, P(i32)]),
     "vox_cache_reset": (i32, [vp]),
+    "vox_cache_update": (i32, [vp, i32, i32, vp, vp, i32, i32]),
+    "vox_cache_truncate": (i32, [vp, i32]),
     "vox_resample_len": (i32, [sz, C.c_uint32, C.c_uint32, P(sz)]),
     "vox_resample": (i32, [vp, vp, sz, C.c_uint32, C.c_uint32, vp, sz, P(sz), i32]),
     "vox_resample_plan": (i32, [C.c_uint32, C.c_uint32, P(i32), P(i32), P(i32), P(C.c_float), vp, sz]),

@@ -21,7 +21,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace vox;
@@ -97,6 +99,7 @@ struct vox_ctx {
     uint16_t* xf_scratch = nullptr; size_t xf_scratch_bytes = 0;
     float* kz_scratch = nullptr; size_t kz_scratch_bytes = 0;      // K-slice planes of the 17..48-row GEMMs (q4_skinny_mt2_kernel): 8 x 48 x 18432 floats
     float* rs_matrix = nullptr; uint32_t rs_in = 0, rs_out = 0;    // block matrix of the last resampled rate pair (vox_resample)
+    struct vox_model* pw_model = nullptr;      // the model with decode-engine steps of the piecewise surface enqueued on `stream` and not yet verified (see pw_after_sync)
 };
 
 static int32_t ctx_bind(const vox_ctx* c) { HIPCHK(hipSetDevice(c->device)); return VOX_OK; }
@@ -136,7 +139,12 @@ extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
     (void)hipStreamDestroy(c->stream);
     delete c; return VOX_OK;
 }
-extern "C" int32_t vox_ctx_synchronize(vox_ctx* c) { ARGCHK(c, "null ctx"); VOXCHK(ctx_bind(c)); HIPCHK(hipStreamSynchronize(c->stream)); return VOX_OK; }
+static int32_t pw_after_sync(struct vox_model* m);      // (piecewise decoder surface, below)
+extern "C" int32_t vox_ctx_synchronize(vox_ctx* c) {
+    ARGCHK(c, "null ctx"); VOXCHK(ctx_bind(c)); HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->pw_model) return pw_after_sync(c->pw_model);      // unverified decode-engine steps of the piecewise surface: their verdict is due at every synchronisation
+    return VOX_OK;
+}
 extern "C" int32_t vox_ctx_stream(vox_ctx* c, void** s) { ARGCHK(c && s, "null argument"); *s = (void*)c->stream; return VOX_OK; }
 extern "C" int32_t vox_dev_alloc(vox_ctx* c, size_t nbytes, void** out) { ARGCHK(c && out, "null argument"); VOXCHK(ctx_bind(c)); HIPCHK(hipMalloc(out, nbytes ? nbytes : 1)); return VOX_OK; }
 extern "C" int32_t vox_dev_free(vox_ctx* c, void* p) { ARGCHK(c, "null ctx"); VOXCHK(ctx_bind(c)); if (p) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(p)); } return VOX_OK; }
@@ -726,7 +734,15 @@ struct EncLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqk
 struct DecLayer { const float *attn_norm = nullptr, *ffn_norm = nullptr; Lin wqkv, wo, w13, w2, ada0, ada2; float* ada_mul = nullptr; };
 
 struct vox_cache { vox_model* m; vox_ctx* ctx = nullptr; float *k = nullptr, *v = nullptr; int max_seq = 0, len = 0; size_t layer_stride = 0;
-                   int kind = 0, abs_pos = 0; };   // kind 0: decoder cache, 1: encoder (streaming) cache; abs_pos: positions seen so far (RoPE offset of the next chunk)   // layer_stride in floats   // per layer: [n_kv][max_seq][hd]
+                   int kind = 0, abs_pos = 0; uint64_t gen = 0; };   // kind 0: decoder cache, 1: encoder (streaming) cache; abs_pos: positions seen so far (RoPE offset of the next chunk)   // layer_stride in floats   // per layer: [n_kv][max_seq][hd]
+
+// Every caller-visible cache carries a generation number from one process-wide counter and is listed while it lives: code that remembers a cache across calls (the
+// piecewise engine's layer table, the record of unverified engine steps) keys on (address, generation) -- a freed cache's address may be handed out again by the
+// allocator, with another max_seq behind the same K base -- and asks cache_alive() before it dereferences one it did not receive in the current call.
+static std::mutex g_cache_mu; static std::unordered_map<const vox_cache*, uint64_t> g_cache_live; static uint64_t g_cache_gen = 0;
+static void cache_register(vox_cache* k) { std::lock_guard<std::mutex> l(g_cache_mu); k->gen = ++g_cache_gen; g_cache_live[k] = k->gen; }
+static void cache_unregister(const vox_cache* k) { std::lock_guard<std::mutex> l(g_cache_mu); g_cache_live.erase(k); }
+static bool cache_alive(const vox_cache* k, uint64_t gen) { std::lock_guard<std::mutex> l(g_cache_mu); auto it = g_cache_live.find(k); return it != g_cache_live.end() && it->second == gen; }
 
 struct vox_model {
     vox_ctx* ctx = nullptr; vox_model_cfg cfg{};
@@ -749,7 +765,6 @@ struct vox_model {
     int *d_tokens = nullptr, *d_pos = nullptr; int tokens_cap = 0;
     float* d_prefix = nullptr;                            // [38][dec_dim] prefill inputs (transcribe_dev)
     float *enc_cos_s = nullptr, *enc_sin_s = nullptr; int enc_rope_s_len = 0;   // RoPE tables for the streaming encoder (positions beyond the 4096-row load-time table)
-    unsigned* d_attn_cnt = nullptr; int attn_cnt_stride = 1024;   // [dec_layers][dec_heads][stride] arrival counters, 4 KB apart (VOX_ATTN_CNT_STRIDE, in uints) of the fused q|k|v + attention launch
     int* d_seq_len = nullptr; std::vector<int> h_seq_len;  // per-utterance encoder rows of a stacked batch
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
     float* d_h2 = nullptr; long long* d_wo_acc = nullptr;      // fused attention + wo decode launch: residual stream after wo; per-layer fixed-point accumulators [dec_layers][dec_dim]
@@ -764,6 +779,7 @@ struct vox_model {
     unsigned char* eng_wob = nullptr;      // the batched engine's wo stream (XCD-group K split, launch_eng_pack op 5): 7 MB per layer
     bool engb_ok = false; unsigned char* engb_state[4] = {nullptr, nullptr, nullptr, nullptr}; EngLayerTab* engb_tab[4] = {nullptr, nullptr, nullptr, nullptr};
     bool engb_on = true; unsigned long long engb_launches = 0; int engb_strikes = 0;
+    int batch_sessions = 0;      // parts the last vox_transcribe_batch call ran in
     int engb_flags = 128 | 1 | 64 | 2048; unsigned engb_err_host[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0, graph_mode = 0;
@@ -773,8 +789,11 @@ struct vox_model {
     // and argmax partials (pw_part_*), so lm_head on that very buffer has nothing left to compute.
     float *pw_x = nullptr, *pw_hidden = nullptr, *pw_logits = nullptr; size_t pw_x_cap = 0, pw_hidden_cap = 0, pw_logits_cap = 0;
     float* pw_part_val = nullptr; int* pw_part_idx = nullptr; int* pw_ids = nullptr; int pw_ids_cap = 0; int* pw_zero = nullptr;
-    EngLayerTab* pw_tab = nullptr; const vox_cache* pw_tab_cache = nullptr; const float* pw_tab_k = nullptr;
+    EngLayerTab* pw_tab = nullptr; const vox_cache* pw_tab_cache = nullptr; uint64_t pw_tab_gen = 0;      // the table is valid for exactly this (cache, generation)
     bool pw_memo = false, pw_eng_used = false;
+    // rows appended to a caller's cache by engine steps (and by anything run behind them) whose error word has not been read behind a stream synchronisation yet: a
+    // hand-off timeout found later takes exactly these rows back (cache length -= pw_pend_rows), so "repeat the step" appends at the failed position again
+    vox_cache* pw_pend_cache = nullptr; uint64_t pw_pend_gen = 0; int pw_pend_rows = 0; bool pw_verdict_failed = false;
     unsigned* pw_err_pin = nullptr;      // pinned host copy of the engine's error word, refreshed (async) behind every piecewise engine launch: checked without a device round trip
     vox_timings timings{};
 };
@@ -1157,9 +1176,10 @@ static void model_release(vox_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream);
     graphs_destroy(m);
-    if (m->cache) { (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
+    if (m->cache) { cache_unregister(m->cache); (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
+    if (m->ctx->pw_model == m) m->ctx->pw_model = nullptr;
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->d_attn_cnt, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_wob, (void*)m->eng_state, (void*)m->eng_tab, (void*)m->engb_state[0], (void*)m->engb_state[1], (void*)m->engb_state[2], (void*)m->engb_state[3],
+                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_wob, (void*)m->eng_state, (void*)m->eng_tab, (void*)m->engb_state[0], (void*)m->engb_state[1], (void*)m->engb_state[2], (void*)m->engb_state[3],
                     (void*)m->engb_tab[0], (void*)m->engb_tab[1], (void*)m->engb_tab[2], (void*)m->engb_tab[3], (void*)m->pw_x, (void*)m->pw_hidden, (void*)m->pw_logits, (void*)m->pw_part_val, (void*)m->pw_part_idx, (void*)m->pw_ids, (void*)m->pw_zero, (void*)m->pw_tab})
         if (p) (void)hipFree(p);
     if (m->pw_err_pin) (void)hipHostFree(m->pw_err_pin);
@@ -1190,11 +1210,8 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
     A((void**)&m->d_q, (size_t)qdim * 4 * 4); A((void**)&m->d_att, (size_t)qdim * 4 * 4); A((void**)&m->d_act, (size_t)c.dec_ffn * 4 * 4);
     A((void**)&m->d_h2, (size_t)c.dec_dim * 4); A((void**)&m->d_wo_acc, (size_t)c.dec_layers * c.dec_dim * 8);
     A((void**)&m->d_logits, (size_t)c.vocab * 4); A((void**)&m->d_part_val, (size_t)m->n_parts * 4 * 4); A((void**)&m->d_part_idx, (size_t)m->n_parts * 4 * 4);
-    { const char* e_ = knob_str("VOX_ATTN_CNT_STRIDE"); if (e_ && atoi(e_) >= 1 && atoi(e_) <= (1 << 16)) m->attn_cnt_stride = atoi(e_); }
-    const size_t cnt_bytes = (size_t)c.dec_layers * c.dec_heads * m->attn_cnt_stride * 4;
-    A((void**)&m->d_attn_cnt, cnt_bytes);
     if (e != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMalloc of decode buffers failed: %s", hipGetErrorString(e)); }
-    if (hipMemset(m->d_attn_cnt, 0, cnt_bytes) != hipSuccess || hipMemset(m->d_wo_acc, 0, (size_t)c.dec_layers * c.dec_dim * 8) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMemset failed"); }
+    if (hipMemset(m->d_wo_acc, 0, (size_t)c.dec_layers * c.dec_dim * 8) != hipSuccess) { model_release(m); return fail(VOX_ERR_HIP, "hipMemset failed"); }
     for (int i = 0; i < c.dec_layers; i++) m->dec[i].ada_mul = m->ada_mul + (size_t)i * c.dec_dim;
     // decode engine eligibility: the real Voxtral decoder geometry, every decoder linear Q4_0 without bias, a 256-CU device.  VOX_ENGINE=0 keeps the per-operator launches.
     {
@@ -1418,13 +1435,40 @@ static int32_t cache_alloc(vox_model* m, int max_seq, vox_cache** out) {
     if (hipMalloc((void**)&k->k, n) != hipSuccess || hipMalloc((void**)&k->v, n) != hipSuccess) { if (k->k) (void)hipFree(k->k); delete k; return fail(VOX_ERR_HIP, "hipMalloc of KV cache failed"); }
     HIPCHK(hipMemsetAsync(k->k, 0, n, m->ctx->stream)); HIPCHK(hipMemsetAsync(k->v, 0, n, m->ctx->stream));
     k->layer_stride = (size_t)c.dec_kv_heads * max_seq * c.dec_head_dim;
+    cache_register(k);
     *out = k; return VOX_OK;
 }
 extern "C" int32_t vox_decoder_cache_create(vox_model* m, int32_t max_seq, vox_cache** out) { ARGCHK(m && out, "null argument"); VOXCHK(ctx_bind(m->ctx)); return cache_alloc(m, max_seq, out); }
 extern "C" int32_t vox_cache_free(vox_cache* k) {
     if (!k) return VOX_OK;
     (void)hipSetDevice(k->ctx->device); (void)hipStreamSynchronize(k->ctx->stream);   // never dereferences k->m: the model may be gone
+    cache_unregister(k);
     (void)hipFree(k->k); (void)hipFree(k->v); delete k; return VOX_OK;
+}
+// KVCache::update on one layer of a pre-allocated cache (kv_cache.rs:116-136: slice_assign of k / v [1][heads][new_seq][hd] at rows pos .. pos + new_seq) -- for callers
+// that own their K / V (and for tests that need a cache at a position no prefill has reached).  The length shared by all layers (LayerCaches::seq_len,
+// kv_cache.rs:242-244) becomes max(len, pos + n_rows).
+extern "C" int32_t vox_cache_update(vox_cache* kc, int32_t layer, int32_t pos, const float* k, const float* v, int32_t n_rows, int32_t mem_kind) {
+    ARGCHK(kc && k && v && n_rows > 0 && pos >= 0, "bad argument"); VOXCHK(ctx_bind(kc->ctx));
+    const vox_model_cfg& c = kc->m->cfg;
+    const int L = kc->kind == 1 ? c.enc_layers : c.dec_layers, H = kc->kind == 1 ? c.enc_heads : c.dec_kv_heads, hd = kc->kind == 1 ? c.enc_head_dim : c.dec_head_dim;
+    ARGCHK(layer >= 0 && layer < L, "layer %d out of range (0..%d)", layer, L - 1);
+    ARGCHK(pos + n_rows <= kc->max_seq, "KV cache overflow: %d + %d > %d", pos, n_rows, kc->max_seq);
+    hipStream_t s = kc->ctx->stream; const hipMemcpyKind kind = mem_kind == VOX_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int h = 0; h < H; h++) {
+        const size_t dst = (size_t)layer * kc->layer_stride + ((size_t)h * kc->max_seq + pos) * hd, src = (size_t)h * n_rows * hd, nb = (size_t)n_rows * hd * 4;
+        HIPCHK(hipMemcpyAsync(kc->k + dst, k + src, nb, kind, s)); HIPCHK(hipMemcpyAsync(kc->v + dst, v + src, nb, kind, s));
+    }
+    if (mem_kind != VOX_MEM_DEVICE) HIPCHK(hipStreamSynchronize(s));      // the host buffers may be reused when the call returns
+    kc->len = std::max(kc->len, pos + n_rows);
+    return VOX_OK;
+}
+// forget every row from `len` on (0 <= len <= seq_len): the next forward appends at `len` again.  What a caller of the device-resident entries does after ITS OWN failed step;
+// the library's own engine timeouts roll the length back themselves (see vox_forward_hidden_with_cache_ex).
+extern "C" int32_t vox_cache_truncate(vox_cache* kc, int32_t len) {
+    ARGCHK(kc, "null cache"); ARGCHK(len >= 0 && len <= kc->len, "truncate to %d: the cache holds %d rows", len, kc->len);
+    if (kc->kind == 1) kc->abs_pos -= kc->len - len;
+    kc->len = len; return VOX_OK;
 }
 extern "C" int32_t vox_cache_seq_len(const vox_cache* k, int32_t* out) { ARGCHK(k && out, "null argument"); *out = k->len; return VOX_OK; }
 extern "C" int32_t vox_cache_reset(vox_cache* k) { ARGCHK(k, "null cache"); k->len = 0; k->abs_pos = 0; return VOX_OK; }
@@ -1446,6 +1490,7 @@ extern "C" int32_t vox_encoder_cache_create(vox_model* m, int32_t capacity_rows,
     if (hipMalloc((void**)&k->k, n) != hipSuccess || hipMalloc((void**)&k->v, n) != hipSuccess) { if (k->k) (void)hipFree(k->k); delete k; return fail(VOX_ERR_HIP, "hipMalloc of encoder KV cache failed"); }
     HIPCHK(hipMemsetAsync(k->k, 0, n, m->ctx->stream)); HIPCHK(hipMemsetAsync(k->v, 0, n, m->ctx->stream));
     k->layer_stride = (size_t)c.enc_heads * capacity_rows * c.enc_head_dim;
+    cache_register(k);
     *out = k; return VOX_OK;
 }
 extern "C" int32_t vox_cache_abs_pos(const vox_cache* k, int32_t* out) { ARGCHK(k && out, "null argument"); *out = k->kind == 1 ? k->abs_pos : k->len; return VOX_OK; }
@@ -1659,11 +1704,7 @@ static int32_t decoder_step_dev(vox_model* m, float* h, vox_cache* kc, const int
         p.w = L.wqkv.w; p.x = h; p.x_stride = D; p.out = m->d_q; p.out_stride = QD; p.gamma = L.attn_norm; p.eps = c.norm_eps;
         p.pos_ptr = pos_ptr; p.pos_off = pos_off; p.rope_cos = m->dec_cos; p.rope_sin = m->dec_sin; p.hd = hd; p.n_q = QD; p.n_k = KD;
         p.kcache = kl; p.vcache = vl; p.cache_head_stride = kc->max_seq * hd;
-        if (p.w.fmt == WFMT_Q4_0 && q4_gemv_attn_fusable(p.w.N, p.w.K, hd, QD, KD, kc->max_seq)) {
-            // one launch: q|k|v GEMV + RoPE + cache write, and the last workgroup to complete a query head's inputs runs that head's attention
-            p.attn_cnt = m->d_attn_cnt + (size_t)l * H * m->attn_cnt_stride; p.attn_cnt_stride = m->attn_cnt_stride; p.attn_out = m->d_att; p.attn_window = c.dec_window; p.attn_max_seq = kc->max_seq;
-            HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV_ATTN, 2, s));
-        } else {
+        {
             HIPCHK(launch_q4_gemv(p, 1, PRO_RMS, EPI_ROPE_KV, q4_gemv_default_R(p.w.N, p.w.K, EPI_ROPE_KV), s));
             AttnParams ap{}; ap.q = m->d_q; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd; ap.out = m->d_att;
             ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = pos_off; ap.window = c.dec_window; ap.pos_ptr = pos_ptr; ap.M = 1; ap.spec_rows = kc->max_seq;
@@ -1802,7 +1843,7 @@ static int32_t ensure_decode_state(vox_model* m, int S) {
     if (!m->cache || m->cache->max_seq < S) {
         int cap = std::max(S, 256); cap = std::min((cap + 255) / 256 * 256, m->dec_rope_len);
         ARGCHK(S <= cap, "sequence of %d decoder positions exceeds the RoPE table (%d)", S, m->dec_rope_len);
-        if (m->cache) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; m->cache = nullptr; m->eng_tab_cache = nullptr; m->eng_tab_k = nullptr; }
+        if (m->cache) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); cache_unregister(m->cache); (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; m->cache = nullptr; m->eng_tab_cache = nullptr; m->eng_tab_k = nullptr; }
         graphs_destroy(m);
         VOXCHK(cache_alloc(m, cap, &m->cache));
     }
@@ -1860,7 +1901,6 @@ static int32_t transcribe_dev(vox_model* m, const float* d_mel, int T, const flo
     std::vector<int32_t> prefix(PREFIX_LEN, STREAMING_PAD); prefix[0] = BOS;      // model.rs:891-892
     HIPCHK(hipMemcpyAsync(m->d_tokens, prefix.data(), PREFIX_LEN * 4, hipMemcpyHostToDevice, s));
     m->cache->len = 0;
-    HIPCHK(hipMemsetAsync(m->d_attn_cnt, 0, (size_t)c.dec_layers * c.dec_heads * m->attn_cnt_stride * 4, s));   // arrival counters: every fused launch adds a whole period; re-zeroed per utterance anyway
     // prefix inputs = audio[:38] + embed(prefix)  (model.rs:896-902)
     if (!m->d_prefix) HIPCHK(hipMalloc((void**)&m->d_prefix, (size_t)PREFIX_LEN * c.dec_dim * 4));   // model-owned: no hipMalloc/hipFree in the timed path
     float* px = m->d_prefix;
@@ -2007,6 +2047,7 @@ extern "C" int32_t vox_transcribe_audio(vox_model* m, const float* samples, size
 // Every utterance runs the whole hot path; encode + 38-token prefill are per utterance, the decode loop is batched: one step
 // advances all sequences (rows of one skinny MFMA GEMM per linear, so the Q4 weights are streamed once per step for the
 // whole batch), per-sequence positions / KV-cache slices / audio rows live on the device, the step is hipGraph-replayed.
+static const int32_t VOX_RETRY_ON_LAUNCHES = -1000;      // internal: transcribe_batch_impl's batched engine timed out; serve the batch on the launch-based step
 static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
                                      int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of, bool allow_engine = true) {      // slot_of[i]: the caller's slot of row i (error messages)
     VOXCHK(ctx_bind(m->ctx));
@@ -2277,7 +2318,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
                 e & 0xff, (e >> 8) & 0xff, gi, m->engb_strikes, m->engb_strikes >= 3 ? ", the engine is switched off" : "");
         for (int gj = 0; gj < 4; gj++) if (m->engb_state[gj]) (void)engb_state_init(m->engb_state[gj], s);
         if (m->engb_strikes >= 3) m->engb_ok = false;      // (otherwise re-armed for the next batch)
-        return transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, false);
+        return VOX_RETRY_ON_LAUNCHES;      // (the caller runs the batch again once this attempt's buffers and graphs are back in the pool: ADVICE r4 -- no recursion from inside this frame)
     }
     int total = 0;
     for (int i = 0; i < n; i++) {
@@ -2290,21 +2331,292 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     return VOX_OK;
 }
 
+// ---- continuous batching (round 5): wide batches -- a rank's whole share of a corpus (BASELINE configs[4]: 81 of the 647 FLEURS utterances at 8 GPUs) in ONE call.
+// The launch-based batch above decodes n rows in ceil(n / 16) lock-step groups and a group is as long as its longest member: a ragged 41-clip batch drains through
+// one and two half-empty groups at the full per-step cost (the round-4 one-GPU bound on configs[4]: 5.5 x at 8 GPUs).  Here the decode step runs over SLOTS:
+//   (A) every utterance is encoded and prefilled up front, in stacked chunks of <= 64 (the weights stream once per chunk): audio rows, a cache slice and the first decode
+//       input h0 per utterance stay on the device (212 992 B of K / V per position: 54 MB per utterance at 256 positions -- nothing next to 288 GB);
+//   (B) the host plans the whole decode statically -- token counts are a pure function of the sample count, there is no EOS (gguf/model.rs:936-960): utterances are
+//       packed longest-processing-time-first onto 16 G slots (G = 1..4 groups, chosen by the measured per-step cost of G lock-step groups), every slot gets its queue;
+//   (C) one decode step = the same four launches per layer and group as above, reading positions and CACHE SLICES per slot (GemmParams::kv_row, AttnParams::kv_row),
+//       + argmax_embed_slots_kernel, which hands a slot whose utterance just got its last token the next one of its queue in the same launch.  A group retires when its
+//       queues are empty.  Rows are independent of their slot, so the ids per utterance are those of every other path (tests/test_gpu_fullsize.py).
+// Step cost of G lock-step groups in ms (profiles/r04 tools/batch_width_sweep.py: 1.17 / 1.07 / 1.01 ms per group-step at 2 / 3 / 4 groups; one group on the launches 1.70):
+static const double kStepMs[5] = {0.0, 1.70, 2.34, 3.21, 4.04};
+struct SlotPlan { int G = 0; std::vector<std::vector<int>> queue; std::vector<int> steps_g; double cost_ms = 0.0; };
+// jobs: (decode steps, utterance) with steps >= 1.  LPT onto 16 G slots, slots ordered by load (so the groups retire last to first), G by the cost model.
+static SlotPlan plan_slots(const std::vector<std::pair<int, int>>& jobs_in, int force_G) {
+    std::vector<std::pair<int, int>> jobs = jobs_in;
+    std::stable_sort(jobs.begin(), jobs.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+    SlotPlan best;
+    const int g_max = std::max(1, std::min(4, ((int)jobs.size() + 15) / 16));
+    for (int G = 1; G <= g_max; G++) {
+        if (force_G > 0 && G != std::min(force_G, g_max)) continue;
+        const int Sl = 16 * G;
+        std::vector<long> load(Sl, 0); std::vector<std::vector<int>> q(Sl);
+        for (auto& j : jobs) { int b = 0; for (int s2 = 1; s2 < Sl; s2++) if (load[s2] < load[b]) b = s2; load[b] += j.first; q[b].push_back(j.second); }
+        std::vector<int> order(Sl); for (int i = 0; i < Sl; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] > load[b]; });
+        SlotPlan pl; pl.G = G; pl.queue.resize(Sl); pl.steps_g.assign(G, 0);
+        for (int i = 0; i < Sl; i++) { pl.queue[i] = q[order[i]]; pl.steps_g[i / 16] = std::max(pl.steps_g[i / 16], (int)load[order[i]]); }
+        for (int k = 0; k < G; k++) pl.cost_ms += (double)(pl.steps_g[k] - (k + 1 < G ? pl.steps_g[k + 1] : 0)) * kStepMs[k + 1];
+        if (best.G == 0 || pl.cost_ms <= best.cost_ms) best = pl;
+    }
+    return best;
+}
+static bool batch_xf_ok(const vox_model* m) {
+    const vox_model_cfg& c = m->cfg; const int D = c.dec_dim, QD = c.dec_heads * c.dec_head_dim, F = c.dec_ffn;
+    return m->tok.w.fmt == WFMT_Q4_0 && m->dec[0].wqkv.w.fmt == WFMT_Q4_0 && m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !knob_str("VOX_BATCH_NO_XF");
+}
+static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
+                                          int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of) {
+    VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
+    ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
+    const int PREFIX_LEN = 38, BOS = 1, STREAMING_PAD = 32, CHUNK = 64;
+    const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, W = QD + 2 * KD, F = c.dec_ffn, V = c.vocab, R = c.reshape_factor;
+    VOXCHK(vox_model_set_t_embed(m, t_embed));
+    m->timings = vox_timings{};
+    vox_pad_cfg pc; vox_pad_cfg_voxtral(&pc);
+    MelTables mt; VOXCHK(ctx_mel_tables(cx, &mt));
+    std::vector<int> S(n), T(n), len(n); int Smax = 0;
+    for (int i = 0; i < n; i++) {
+        ARGCHK(samples[i] && n_samples[i] > 0, "empty audio in batch slot %d", slot_of[i]);
+        const size_t left = pad_left(&pc), total = left + n_samples[i] + pad_right(&pc, n_samples[i] + left);
+        T[i] = (int)(total / 160); S[i] = conv_len(conv_len(T[i])) / R; Smax = std::max(Smax, S[i]);
+        const int cnt_i = S[i] >= PREFIX_LEN ? std::max(S[i] - PREFIX_LEN, 1) : 0;     // S == 38 still emits its first token (model.rs:922-926)
+        ARGCHK(caps[i] >= cnt_i, "out_ids[%d] capacity %d < %d", slot_of[i], caps[i], cnt_i);
+        len[i] = S[i] >= PREFIX_LEN ? std::max(S[i], PREFIX_LEN + 1) : 0;
+    }
+    ARGCHK(Smax <= m->dec_rope_len, "sequence too long for the decoder RoPE table");
+    const int max_seq = std::max((Smax + 63) / 64 * 64, 64), tstride = std::max(Smax, PREFIX_LEN) + 2;
+    const size_t seq_stride = (size_t)KV * max_seq * hd, layer_stride = (size_t)(n + 1) * seq_stride;      // slice n of every layer: the scratch slice idle slots write to and read
+    // per-chunk geometry of the stacked encoder: every chunk keeps its own row stride in the audio buffer
+    const int n_chunks = (n + CHUNK - 1) / CHUNK;
+    std::vector<int> arows(n_chunks); std::vector<size_t> aoff_c(n_chunks); std::vector<long> audio_off(n);
+    size_t audio_floats = 0, mel_max = 0, smp_max = 0;
+    for (int ci = 0; ci < n_chunks; ci++) {
+        const int c0 = ci * CHUNK, nc = std::min(CHUNK, n - c0);
+        arows[ci] = std::max(enc_row_budget(m, T.data() + c0, nc) / R, PREFIX_LEN + 1); aoff_c[ci] = audio_floats;
+        size_t mf = 0, sf = 0;
+        for (int i = c0; i < c0 + nc; i++) { audio_off[i] = (long)(aoff_c[ci] + (size_t)(i - c0) * arows[ci] * D); mf += (size_t)128 * T[i]; sf += n_samples[i]; }
+        audio_floats += (size_t)nc * arows[ci] * D; mel_max = std::max(mel_max, mf); smp_max = std::max(smp_max, sf);
+    }
+    // the decode plan (host only: lengths are known)
+    std::vector<std::pair<int, int>> jobs;
+    for (int i = 0; i < n; i++) if (len[i] > PREFIX_LEN + 1) jobs.emplace_back(len[i] - PREFIX_LEN - 1, i);
+    int force_G = 0; if (const char* e = knob_str("VOX_BATCH_SLOT_GROUPS")) force_G = std::max(0, std::min(4, atoi(e)));
+    const SlotPlan plan = plan_slots(jobs, force_G);
+    const int G = std::max(plan.G, 1), Sl = 16 * G;
+    int q_stride = 1; for (auto& q : plan.queue) q_stride = std::max(q_stride, (int)q.size() + 1);
+    std::vector<int> h_queue((size_t)Sl * q_stride, -1);
+    for (size_t sl = 0; sl < plan.queue.size(); sl++) for (size_t k = 0; k < plan.queue[sl].size(); k++) h_queue[sl * q_stride + k] = plan.queue[sl][k];
+    const int steps = plan.steps_g.empty() ? 0 : plan.steps_g[0];
+
+    DevBuf b_audio, b_k, b_v, b_tok, b_posc, b_len, b_h0, b_aoff, b_px, b_xn, b_lg0, b_mel, b_scale, b_smp;
+    DevBuf b_queue, b_sclip, b_sqpos, b_pos, b_kvrow, b_h, b_qkv, b_att, b_logits, b_xf1, b_xf2, b_xf3, b_ssq;
+    struct Drain { vox_ctx* c; ~Drain() { (void)hipStreamSynchronize(c->stream); for (auto a : c->aux) if (a) (void)hipStreamSynchronize(a); } } drain{cx};
+    HIPCHK(b_audio.alloc_pooled(cx, audio_floats * 4)); HIPCHK(b_k.alloc_pooled(cx, layer_stride * c.dec_layers * 4)); HIPCHK(b_v.alloc_pooled(cx, layer_stride * c.dec_layers * 4));
+    HIPCHK(b_tok.alloc_pooled(cx, (size_t)n * tstride * 4)); HIPCHK(b_posc.alloc_pooled(cx, (size_t)n * 4)); HIPCHK(b_len.alloc_pooled(cx, (size_t)n * 4));
+    HIPCHK(b_h0.alloc_pooled(cx, (size_t)n * D * 4)); HIPCHK(b_aoff.alloc_pooled(cx, (size_t)n * sizeof(long)));
+    const int ncm = std::min(n, CHUNK);
+    HIPCHK(b_px.alloc_pooled(cx, (size_t)ncm * PREFIX_LEN * D * 4)); HIPCHK(b_xn.alloc_pooled(cx, (size_t)ncm * D * 4)); HIPCHK(b_lg0.alloc_pooled(cx, (size_t)ncm * V * 4));
+    HIPCHK(b_mel.alloc_pooled(cx, std::max<size_t>(mel_max, 1) * 4)); HIPCHK(b_scale.alloc_pooled(cx, (size_t)ncm * 4));
+    if (mem_kind == VOX_MEM_HOST) HIPCHK(b_smp.alloc_pooled(cx, std::max<size_t>(smp_max, 1) * 4));
+    HIPCHK(hipMemsetAsync(b_audio.p, 0, audio_floats * 4, s)); HIPCHK(hipMemsetAsync(b_h0.p, 0, (size_t)n * D * 4, s));
+    float* d_audio = b_audio.as<float>(); int* d_tok = b_tok.as<int>();
+    {   // prefix tokens, positions and lengths of every utterance (gguf/model.rs:887-902)
+        std::vector<int32_t> prefix((size_t)n * tstride, 0); std::vector<int> pos0(n, PREFIX_LEN - 1);
+        for (int i = 0; i < n; i++) { prefix[(size_t)i * tstride] = BOS; for (int r = 1; r < PREFIX_LEN; r++) prefix[(size_t)i * tstride + r] = STREAMING_PAD; }
+        HIPCHK(hipMemcpyAsync(d_tok, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_posc.p, pos0.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(b_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_aoff.p, audio_off.data(), (size_t)n * sizeof(long), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));      // the host vectors go out of scope
+    }
+    // ---- (A) front-end, stacked encoder and stacked 38-token prefill, chunk by chunk
+    double pre_ms = 0.0, enc_ms = 0.0, pf_ms = 0.0; const double t0 = now_ms();
+    for (int ci = 0; ci < n_chunks; ci++) {
+        const int c0 = ci * CHUNK, nc = std::min(CHUNK, n - c0);
+        const double ta = now_ms();
+        std::vector<const float*> d_mels(nc);
+        size_t mo = 0, so = 0;
+        for (int i = c0; i < c0 + nc; i++) {
+            const float* d_s = samples[i];
+            if (mem_kind == VOX_MEM_HOST) { float* dst = b_smp.as<float>() + so; so += n_samples[i]; HIPCHK(hipMemcpyAsync(dst, samples[i], n_samples[i] * 4, hipMemcpyHostToDevice, s)); d_s = dst; }
+            const size_t left = pad_left(&pc), right = pad_right(&pc, n_samples[i] + left);
+            float* mel_i = b_mel.as<float>() + mo; mo += (size_t)128 * T[i]; d_mels[i - c0] = mel_i;
+            float* scale_i = b_scale.as<float>() + (i - c0);
+            HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, scale_i, s));
+            HIPCHK(launch_mel(d_s, (long)n_samples[i], (long)left, (long)right, scale_i, mt, mel_i, T[i], 1, s));
+        }
+        HIPCHK(hipStreamSynchronize(s)); const double tb = now_ms();
+        std::vector<int> S4(nc);
+        VOXCHK(encode_batch_dev(m, nc, d_mels.data(), T.data() + c0, d_audio + aoff_c[ci], arows[ci], S4.data()));
+        for (int i = 0; i < nc; i++) ARGCHK(S4[i] == S[c0 + i], "internal: sequence length mismatch (%d vs %d)", S4[i], S[c0 + i]);
+        HIPCHK(hipStreamSynchronize(s)); const double tc = now_ms();
+        float* px = b_px.as<float>();
+        for (int i = c0; i < c0 + nc; i++)
+            HIPCHK(launch_embed(m->tok.w, d_tok + (size_t)i * tstride, PREFIX_LEN, d_audio + audio_off[i], D, nullptr, 0, 0, px + (size_t)(i - c0) * PREFIX_LEN * D, s));
+        vox_cache view; view.m = m; view.ctx = cx; view.k = b_k.as<float>() + (size_t)c0 * seq_stride; view.v = b_v.as<float>() + (size_t)c0 * seq_stride; view.max_seq = max_seq; view.len = 0; view.layer_stride = layer_stride;
+        VOXCHK(decoder_prefill_dev(m, px, nc * PREFIX_LEN, &view, 0, nc, (long)seq_stride));
+        // logits of every utterance's last prefix row -> its first generated token and its first decode input h0 = audio[38] + embed(token)
+        HIPCHK(launch_rms_norm(px + (size_t)(PREFIX_LEN - 1) * D, PREFIX_LEN * D, nc, D, m->dec_norm, nullptr, c.norm_eps, b_xn.as<float>(), D, s));
+        { GemmParams g{}; g.w = m->tok.w; g.x = b_xn.as<float>(); g.x_stride = D; g.M = nc; g.out = b_lg0.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
+        HIPCHK(launch_argmax_embed_batch(b_lg0.as<float>(), nc, V, d_tok + (size_t)c0 * tstride, tstride, b_posc.as<int>() + c0, b_len.as<int>() + c0, m->tok.w, d_audio + aoff_c[ci], (long)arows[ci] * D, D,
+                                         b_h0.as<float>() + (size_t)c0 * D, s));
+        HIPCHK(hipStreamSynchronize(s)); const double td = now_ms();
+        pre_ms += tb - ta; enc_ms += tc - tb; pf_ms += td - tc;
+    }
+    const double t1 = now_ms();
+    // ---- (B) + (C): the slot decode
+    int replays = 0;
+    if (steps > 0) {
+        auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
+        const int parts_D = q4_skinny_resid_xf_parts(D);
+        HIPCHK(b_queue.alloc_pooled(cx, h_queue.size() * 4)); HIPCHK(b_sclip.alloc_pooled(cx, (size_t)Sl * 4)); HIPCHK(b_sqpos.alloc_pooled(cx, (size_t)Sl * 4));
+        HIPCHK(b_pos.alloc_pooled(cx, (size_t)Sl * 4)); HIPCHK(b_kvrow.alloc_pooled(cx, (size_t)Sl * 4)); HIPCHK(b_h.alloc_pooled(cx, (size_t)Sl * D * 4));
+        HIPCHK(b_qkv.alloc_pooled(cx, (size_t)Sl * W * 4)); HIPCHK(b_att.alloc_pooled(cx, (size_t)Sl * QD * 4)); HIPCHK(b_logits.alloc_pooled(cx, (size_t)Sl * V * 4));
+        HIPCHK(b_xf1.alloc_pooled(cx, xf_bytes(D) * G)); HIPCHK(b_xf2.alloc_pooled(cx, xf_bytes(QD) * G)); HIPCHK(b_xf3.alloc_pooled(cx, xf_bytes(F) * G));
+        HIPCHK(b_ssq.alloc_pooled(cx, (size_t)parts_D * 16 * 4 * G));
+        HIPCHK(hipMemsetAsync(b_xf1.p, 0, xf_bytes(D) * G, s)); HIPCHK(hipMemsetAsync(b_xf2.p, 0, xf_bytes(QD) * G, s)); HIPCHK(hipMemsetAsync(b_xf3.p, 0, xf_bytes(F) * G, s));
+        HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4 * G, s)); HIPCHK(hipMemsetAsync(b_h.p, 0, (size_t)Sl * D * 4, s)); HIPCHK(hipMemsetAsync(b_qkv.p, 0, (size_t)Sl * W * 4, s));
+        // the scratch cache slice (index n of every layer): zeros, so that an idle slot's attention stays finite
+        HIPCHK(hipMemset2DAsync(b_k.as<float>() + (size_t)n * seq_stride, layer_stride * 4, 0, seq_stride * 4, c.dec_layers, s));
+        HIPCHK(hipMemset2DAsync(b_v.as<float>() + (size_t)n * seq_stride, layer_stride * 4, 0, seq_stride * 4, c.dec_layers, s));
+        HIPCHK(hipMemcpyAsync(b_queue.p, h_queue.data(), h_queue.size() * 4, hipMemcpyHostToDevice, s));
+        int* d_pos = b_pos.as<int>(); int* d_kvrow = b_kvrow.as<int>();
+        SlotStepParams sp{};
+        sp.logits = b_logits.as<float>(); sp.vocab = V; sp.tokens = d_tok; sp.tok_stride = tstride; sp.clip_len = b_len.as<int>();
+        sp.slot_clip = b_sclip.as<int>(); sp.slot_qpos = b_sqpos.as<int>(); sp.queue = b_queue.as<int>(); sp.q_stride = q_stride;
+        sp.pos = d_pos; sp.kv_row = d_kvrow; sp.n_clips = n; sp.first_pos = PREFIX_LEN; sp.tok = m->tok.w; sp.audio = d_audio; sp.audio_off = b_aoff.as<long>(); sp.D = D;
+        sp.h0 = b_h0.as<float>(); sp.h = b_h.as<float>(); sp.xf = b_xf1.as<uint16_t>(); sp.xf_w = m->dec[0].attn_norm; sp.ssq_out = b_ssq.as<float>();
+        sp.xf_group_stride = (long)(xf_bytes(D) / 2); sp.ssq_group_stride = parts_D * 16;
+        sp.init = 1; HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); sp.init = 0;
+        auto group_chain = [&](int gi, hipStream_t sg) -> int32_t {
+            const int r0 = gi * 16;
+            uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)gi * (xf_bytes(QD) / 2);
+            uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)gi * (xf_bytes(F) / 2); float* ssq = b_ssq.as<float>() + (size_t)gi * parts_D * 16;
+            float* hg = b_h.as<float>() + (size_t)r0 * D; float* qg = b_qkv.as<float>() + (size_t)r0 * W; const int* pg = d_pos + r0; const int* rg = d_kvrow + r0;
+            for (int l = 0; l < c.dec_layers; l++) {
+                const DecLayer& L = m->dec[l];
+                float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;      // the layer's slab: slices are picked per slot
+                { GemmParams g{}; g.w = L.wqkv.w; g.xf = (const uint4*)xf1; g.M = 16; g.out = qg; g.out_stride = W;
+                  g.ssq_part = ssq; g.n_part = l == 0 ? 1 : parts_D; g.norm_eps = c.norm_eps;
+                  g.pos = pg; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd; g.kv_row = rg;
+                  HIPCHK(launch_q4_gemm(g, EPI_ROPE_KV, sg)); }
+                AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = b_att.as<float>(); ap.n_heads = H; ap.n_kv_heads = KV;
+                ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = pg; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride; ap.kv_row = rg;
+                ap.out_xf = xf2; ap.prefer_gqa = 1; ap.no_xcd_remap = knob_str("VOX_ATTN_NO_XCD") != nullptr; ap.spec_rows = 0;
+                HIPCHK(launch_attn_decode(ap, hd, max_seq, sg, 16));
+                { GemmParams g{}; g.w = L.wo.w; g.xf = (const uint4*)xf2; g.M = 16; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
+                  g.xf_out = xf1; g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
+                { GemmParams g{}; g.w = L.w13.w; g.xf = (const uint4*)xf1; g.M = 16; g.out = (float*)xf3; g.out_stride = F;
+                  g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_SWIGLU_XF, sg)); }
+                { GemmParams g{}; g.w = L.w2.w; g.xf = (const uint4*)xf3; g.M = 16; g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
+                  g.xf_out = xf1; g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; HIPCHK(launch_q4_gemm(g, EPI_RESID_XF, sg)); }
+            }
+            { GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)xf1; g.M = 16; g.out = b_logits.as<float>() + (size_t)r0 * V; g.out_stride = V;
+              g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, sg)); }
+            return VOX_OK;
+        };
+        auto step = [&](uint32_t active) -> int32_t {
+            int n_act = 0; for (int gi = 0; gi < G; gi++) n_act += (active >> gi) & 1u;
+            const bool fork = n_act > 1 && !knob_str("VOX_BATCH_SERIAL_GROUPS");
+            if (fork) {
+                if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+                for (int i = 0; i < n_act - 1 && i < 3; i++) {
+                    if (!cx->aux[i]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[i], hipStreamNonBlocking));
+                    if (!cx->ev_join[i]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[i], hipEventDisableTiming));
+                }
+                HIPCHK(hipEventRecord(cx->ev_fork, s));
+                for (int i = 0; i < n_act - 1 && i < 3; i++) HIPCHK(hipStreamWaitEvent(cx->aux[i], cx->ev_fork, 0));
+            }
+            int k_act = 0;
+            for (int gi = 0; gi < G; gi++) {
+                if (!((active >> gi) & 1u)) continue;
+                const int ka = k_act++;
+                hipStream_t sg = (fork && ka > 0) ? cx->aux[ka - 1] : s;
+                VOXCHK(group_chain(gi, sg));
+                if (fork && ka > 0) { HIPCHK(hipEventRecord(cx->ev_join[ka - 1], sg)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[ka - 1], 0)); }
+            }
+            HIPCHK(launch_argmax_embed_slots(sp, Sl, s));      // (retired groups' slots are idle: slot_clip < 0)
+            return VOX_OK;
+        };
+        auto active_at = [&](int t) { uint32_t a = 0; for (int gi = 0; gi < G; gi++) if (t < plan.steps_g[gi]) a |= 1u << gi; return a; };
+        struct Graphs {
+            hipStream_t s; vox_ctx* cx; std::vector<std::pair<uint32_t, hipGraphExec_t>> ex; std::vector<hipGraph_t> gr;
+            ~Graphs() { (void)hipStreamSynchronize(s); for (auto a : cx->aux) if (a) (void)hipStreamSynchronize(a); for (auto& e : ex) if (e.second) (void)hipGraphExecDestroy(e.second); for (auto g : gr) if (g) (void)hipGraphDestroy(g); }
+            hipGraphExec_t find(uint32_t a) const { for (auto& e : ex) if (e.first == a) return e.second; return nullptr; }
+        } graphs; graphs.s = s; graphs.cx = cx;
+        const bool no_graph = knob_str("VOX_BATCH_NO_GRAPH") != nullptr;
+        for (int t = 0; t < steps; t++) {
+            const uint32_t act = active_at(t);
+            if (t == 0 || no_graph) { VOXCHK(step(act)); continue; }
+            hipGraphExec_t ge = graphs.find(act);
+            if (!ge) {
+                HIPCHK(hipStreamSynchronize(s));
+                HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                const int32_t r = step(act);
+                hipGraph_t graph = nullptr;
+                const hipError_t ce = hipStreamEndCapture(s, &graph);
+                if (graph) graphs.gr.push_back(graph);
+                if (r != VOX_OK) return r;
+                HIPCHK(ce);
+                const hipError_t ie = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+                if (ie != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+                graphs.ex.emplace_back(act, ge);
+            }
+            if (hipGraphLaunch(ge, s) != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphLaunch failed");
+            replays++;
+        }
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    std::vector<int32_t> host_tok((size_t)n * tstride);
+    HIPCHK(hipMemcpyAsync(host_tok.data(), d_tok, host_tok.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    int total = 0;
+    for (int i = 0; i < n; i++) {
+        const int cnt = S[i] >= PREFIX_LEN ? std::max(S[i] - PREFIX_LEN, 1) : 0;
+        if (cnt > 0) std::memcpy(out_ids[i], host_tok.data() + (size_t)i * tstride + PREFIX_LEN, (size_t)cnt * 4);
+        n_ids[i] = cnt; total += cnt;
+    }
+    m->timings.preprocess_ms = pre_ms; m->timings.encode_ms = enc_ms; m->timings.decode_ms = pf_ms + (now_ms() - t1); m->timings.total_ms = now_ms() - t0;
+    m->timings.decode_tokens = total; m->timings.graph_replays = replays;
+    if (knob_str("VOX_BATCH_VERBOSE")) fprintf(stderr, "[voxtral_hip] continuous batch: %d utterances, %d slots, %d steps (plan %.1f ms), encode %.1f ms, prefill %.1f ms, decode %.1f ms\n", n, Sl, steps, plan.cost_ms, enc_ms, pf_ms, now_ms() - t1);
+    return VOX_OK;
+}
+
 // Entry point: rows are processed LONGEST FIRST (a stable sort of the caller's slots by sample count; sequence length is monotone in it), so that the
 // 16-row groups of the decode loop retire last to first (see `step` above) -- results are per row and land in the caller's slot i whatever the internal order.
+static int32_t transcribe_batch_launches(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
+                                         int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of) {
+    int32_t r = transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, true);
+    if (r == VOX_RETRY_ON_LAUNCHES) r = transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, false);
+    return r;
+}
 extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
                                         int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind) {
-    ARGCHK(m && samples && n_samples && t_embed && out_ids && caps && n_ids, "null argument"); ARGCHK(n > 0 && n <= 64, "batch size %d out of range (1..64)", n);
+    ARGCHK(m && samples && n_samples && t_embed && out_ids && caps && n_ids, "null argument"); ARGCHK(n > 0 && n <= 4096, "batch size %d out of range (1..4096)", n);
     std::vector<int> order(n);
     for (int i = 0; i < n; i++) order[i] = i;
     if (n > 16 && !knob_str("VOX_BATCH_NO_SORT"))
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_samples[a] > n_samples[b]; });
-    bool identity = true; for (int i = 0; i < n; i++) identity = identity && order[i] == i;
-    if (identity) return transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, order.data());
     std::vector<const float*> p_s(n); std::vector<size_t> p_n(n); std::vector<int32_t*> p_o(n); std::vector<int32_t> p_c(n), p_k(n, 0);
     for (int i = 0; i < n; i++) { const int o = order[i]; p_s[i] = samples[o]; p_n[i] = n_samples[o]; p_o[i] = out_ids[o]; p_c[i] = caps[o]; }
-    const int32_t r = transcribe_batch_impl(m, n, p_s.data(), p_n.data(), t_embed, p_o.data(), p_c.data(), p_k.data(), mem_kind, order.data());
-    if (r == VOX_OK) for (int i = 0; i < n; i++) n_ids[order[i]] = p_k[i];
+    // <= 16 rows: one group (the batched decode-layer engine).  Wider: continuous batching over slots, in sessions of <= 256 utterances (what bounds the resident K / V:
+    // 54 MB per utterance at 256 positions); VOX_BATCH_NO_CONTINUOUS=1 (or a geometry / checkpoint the XF step does not cover): lock-step batches of <= 64 rows.
+    const bool cont = n > 16 && batch_xf_ok(m) && !knob_str("VOX_BATCH_NO_CONTINUOUS");
+    const int part_max = cont ? 256 : 64, n_parts = (n + part_max - 1) / part_max;
+    m->batch_sessions = 0; vox_timings acc{}; int32_t r = VOX_OK;
+    for (int pi = 0, a = 0; pi < n_parts && r == VOX_OK; pi++) {
+        const int b = a + (n - a) / (n_parts - pi);      // equal contiguous parts of the sorted order
+        const int np = b - a;
+        r = cont ? transcribe_continuous_impl(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a)
+                 : transcribe_batch_launches(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a);
+        acc.preprocess_ms += m->timings.preprocess_ms; acc.encode_ms += m->timings.encode_ms; acc.decode_ms += m->timings.decode_ms; acc.total_ms += m->timings.total_ms;
+        acc.decode_tokens += m->timings.decode_tokens; acc.graph_replays += m->timings.graph_replays;
+        m->batch_sessions++; a = b;
+    }
+    if (r == VOX_OK) { m->timings = acc; for (int i = 0; i < n; i++) n_ids[order[i]] = p_k[i]; }
     return r;
 }
 
@@ -2338,12 +2650,12 @@ static bool pw_engine_ready(vox_model* m, vox_cache* kc) {
         m->pw_err_pin[0] = m->pw_err_pin[1] = 0u;
     }
     if (!m->pw_part_val || !m->pw_part_idx || !m->pw_zero || !m->pw_err_pin) return false;
-    if (m->pw_tab_cache != kc || m->pw_tab_k != kc->k) {
+    if (m->pw_tab_cache != kc || m->pw_tab_gen != kc->gen) {
         const size_t lf = cache_layer_floats(m, kc);
         std::vector<EngLayerTab> tab(c.dec_layers);
         for (int l = 0; l < c.dec_layers; l++) tab[l] = EngLayerTab{m->dec[l].attn_norm, m->dec[l].ffn_norm, m->dec[l].ada_mul, kc->k + (size_t)l * lf, kc->v + (size_t)l * lf};
         if (hipMemcpyAsync(m->pw_tab, tab.data(), sizeof(EngLayerTab) * c.dec_layers, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return false; }
-        m->pw_tab_cache = kc; m->pw_tab_k = kc->k;
+        m->pw_tab_cache = kc; m->pw_tab_gen = kc->gen;
     }
     return true;
 }
@@ -2364,16 +2676,32 @@ static int32_t pw_engine_verdict(vox_model* m) {
     const unsigned e = *(volatile unsigned*)m->pw_err_pin;
     if (!e) return VOX_OK;
     m->pw_err_pin[0] = 0u; m->pw_eng_used = false;
-    m->eng_strikes++; m->pw_memo = false;
+    m->eng_strikes++; m->pw_memo = false; m->pw_verdict_failed = true;
+    // take back every row that is not known to be good: the failed step's, and whatever was appended behind it before the failure was seen
+    int len_now = -1;
+    if (m->pw_pend_rows > 0 && m->pw_pend_cache && cache_alive(m->pw_pend_cache, m->pw_pend_gen)) { m->pw_pend_cache->len = std::max(m->pw_pend_cache->len - m->pw_pend_rows, 0); len_now = m->pw_pend_cache->len; }
+    m->pw_pend_rows = 0; m->pw_pend_cache = nullptr; if (m->ctx->pw_model == m) m->ctx->pw_model = nullptr;
     HIPCHK(hipMemsetAsync(m->eng_state, 0, eng_state_bytes(), m->ctx->stream)); m->eng_launches = 0; graphs_destroy(m);
     if (m->eng_strikes >= 3) { m->eng_ok = false; m->eng_on = false; }
-    return fail(VOX_ERR_HIP, "decode engine: hand-off timeout (code %u, workgroup %u), strike %d of 3: the GPU is shared; repeat the step%s", e & 0xff, (e >> 8) & 0xff, m->eng_strikes,
-                m->eng_strikes >= 3 ? " (the engine is now switched off, the per-operator launches serve it)" : "");
+    return fail(VOX_ERR_HIP, "decode engine: hand-off timeout (code %u, workgroup %u), strike %d of 3: the GPU is shared; the KV cache is back at length %d -- repeat the step%s", e & 0xff, (e >> 8) & 0xff, m->eng_strikes,
+                len_now, m->eng_strikes >= 3 ? " (the engine is now switched off, the per-operator launches serve it)" : "");
+}
+// behind a synchronisation of the stream: the pinned error word of every engine launch enqueued so far has landed -- read the verdict; clean: every pending row is verified
+static int32_t pw_after_sync(vox_model* m) {
+    m->pw_eng_used = false;
+    const int32_t r = pw_engine_verdict(m);
+    if (r == VOX_OK) { m->pw_pend_rows = 0; m->pw_pend_cache = nullptr; if (m->ctx->pw_model == m) m->ctx->pw_model = nullptr; }
+    return r;
 }
 static int32_t pw_sync(vox_model* m) {      // synchronise the stream (the pinned error word of an outstanding engine launch lands with the same wait), then the verdict
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
-    m->pw_eng_used = false;
-    return pw_engine_verdict(m);
+    return pw_after_sync(m);
+}
+// rows appended to `kc` by a step that cannot be verified yet (an engine launch, or anything behind one): remembered until the next synchronisation
+static int32_t pw_note_pending(vox_model* m, vox_cache* kc, int rows) {
+    if (m->pw_pend_rows > 0 && (m->pw_pend_cache != kc || m->pw_pend_gen != kc->gen)) VOXCHK(pw_sync(m));      // another cache's steps are outstanding: settle them first
+    m->pw_pend_cache = kc; m->pw_pend_gen = kc->gen; m->pw_pend_rows += rows; m->ctx->pw_model = m;
+    return VOX_OK;
 }
 
 extern "C" int32_t vox_embed_tokens_from_ids_ex(vox_model* m, const int32_t* ids, int32_t n, float* out, int32_t mem_kind) {
@@ -2425,12 +2753,14 @@ extern "C" int32_t vox_forward_hidden_with_cache_ex(vox_model* m, const float* x
         else VOXCHK(decoder_prefill_dev(m, m->pw_x, M, kc, kc->len));
         HIPCHK(launch_rms_norm(m->pw_x, D, M, D, m->dec_norm, nullptr, c.norm_eps, m->pw_hidden, D, s));   // model.rs:676
     }
+    const int len0 = kc->len;
+    if (eng || m->pw_pend_rows > 0) VOXCHK(pw_note_pending(m, kc, M));      // (before the length moves: a failure found by the settling sync leaves the cache as it was)
     kc->len += M;
     if (hidden_ws) *hidden_ws = m->pw_hidden;
     if (out && out != m->pw_hidden) HIPCHK(hipMemcpyAsync(out, m->pw_hidden, (size_t)M * D * 4, mem_kind == VOX_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     if (mem_kind != VOX_MEM_DEVICE) {
         const int32_t r = pw_sync(m);
-        if (r != VOX_OK) { kc->len -= M; return r; }
+        if (r != VOX_OK) { kc->len = std::min(kc->len, len0); return r; }      // (a hand-off timeout has already taken its pending rows back: never below that)
     }
     return VOX_OK;
 }
@@ -2478,6 +2808,7 @@ extern "C" int32_t vox_argmax_rows(vox_ctx* c, const float* logits, int32_t M, i
     DevBuf di; HIPCHK(di.alloc_pooled(c, (size_t)M * 4));
     HIPCHK(launch_argmax_rows(logits, M, V, di.as<int>(), c->stream));
     HIPCHK(hipMemcpyAsync(ids, di.p, (size_t)M * 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->pw_model) return pw_after_sync(c->pw_model);      // the reference loop's ONLY synchronisation (e2e_bench.rs:219-220): an engine hand-off timeout of this very step is reported here, with the cache rolled back
     return VOX_OK;
 }
 
@@ -2505,6 +2836,7 @@ extern "C" int32_t vox_generate_step_with_cache(vox_model* m, const int32_t* tok
     ARGCHK(m && token_ids && t_embed && kc && logits && n > 0, "bad argument"); ARGCHK(kc->m == m && kc->kind == 0, "cache belongs to another model or is an encoder cache"); VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
     ARGCHK(kc->len + n <= kc->max_seq, "KV cache overflow: %d + %d > %d", kc->len, n, kc->max_seq);
+    const int len0 = kc->len;
     VOXCHK(pw_ids_dev(m, token_ids, n));
     VOXCHK(ensure(&m->pw_x, &m->pw_x_cap, (size_t)n * c.dec_dim));
     HIPCHK(launch_embed(m->tok.w, m->pw_ids, n, nullptr, c.dec_dim, nullptr, 0, 0, m->pw_x, s));
@@ -2516,7 +2848,7 @@ extern "C" int32_t vox_generate_step_with_cache(vox_model* m, const int32_t* tok
     }
     HIPCHK(hipMemcpyAsync(logits, m->pw_logits, (size_t)n * c.vocab * 4, hipMemcpyDeviceToHost, s));
     const int32_t r = pw_sync(m);
-    if (r != VOX_OK) kc->len -= n;
+    if (r != VOX_OK) kc->len = std::min(kc->len, len0);
     return r;
 }
 
@@ -2555,9 +2887,10 @@ static int32_t forward_composite(vox_model* m, int mode, const float* mel, int32
     }
     vox_cache* kc = dec_cache; vox_cache* tmp = nullptr;
     if (mode != 2) { VOXCHK(cache_alloc(m, std::max(S, 8), &tmp)); kc = tmp; }      // forward_hidden(.., offset 0): a cache of exactly this call's rows
-    const float* hid = nullptr;
-    int32_t r = vox_forward_hidden_with_cache_ex(m, x, S, t_embed, kc, nullptr, &hid, VOX_MEM_DEVICE);
-    if (r == VOX_OK) {
+    auto decode_rows = [&]() -> int32_t {      // layers against the cache -> final norm -> lm_head -> logits on their way to the caller
+        const float* hid = nullptr;
+        int32_t r = vox_forward_hidden_with_cache_ex(m, x, S, t_embed, kc, nullptr, &hid, VOX_MEM_DEVICE);
+        if (r != VOX_OK) return r;
         float* ly = logits;
         if (mem_kind == VOX_MEM_HOST) { r = ensure(&m->pw_logits, &m->pw_logits_cap, (size_t)S * c.vocab); ly = m->pw_logits; m->pw_memo = false; }
         if (r == VOX_OK && !(pw_memo_hit(m, hid, S, VOX_MEM_DEVICE) && ly == m->pw_logits)) {
@@ -2565,8 +2898,19 @@ static int32_t forward_composite(vox_model* m, int mode, const float* mel, int32
             else r = q4_linear_dev(m->ctx, m->tok.w, nullptr, hid, D, S, ly, c.vocab);
         }
         if (r == VOX_OK && mem_kind == VOX_MEM_HOST && hipMemcpyAsync(logits, ly, (size_t)S * c.vocab * 4, hipMemcpyDeviceToHost, s) != hipSuccess) r = fail(VOX_ERR_HIP, "copy of the logits failed");
+        return r;
+    };
+    m->pw_verdict_failed = false;
+    int32_t r = decode_rows();
+    int32_t rs = pw_sync(m);
+    if (m->pw_verdict_failed) {
+        // an engine hand-off timeout (a one-row call on a shared GPU): the verdict has taken the decoder row back; the ENCODER cache of mode 2 cannot be rewound (it may have
+        // compacted itself), so the call is not failed -- the decoder rows run once more on the per-operator launches and the caller never sees a half-advanced pair of caches
+        m->pw_verdict_failed = false;
+        const bool sv = m->eng_suspended; m->eng_suspended = true;
+        r = decode_rows(); rs = pw_sync(m);
+        m->eng_suspended = sv;
     }
-    const int32_t rs = pw_sync(m);
     if (tmp) (void)vox_cache_free(tmp);
     return r != VOX_OK ? r : rs;
 }

@@ -23,9 +23,7 @@ enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1, WFMT_BF16X2 = 2, WFMT_F32 = 3 };
 // WFMT_F32: a dense F32 / F16 checkpoint tensor whose values are NOT bf16-representable (models/weights.rs:16-66 accepts any): qt = the exact f32
 // plane [N][K] (decode GEMV, embedding lookup), qs / sc = bf16 hi / lo planes (w ~= hi + lo to 2^-17; the MFMA GEMMs for > 4 rows).   // BF16X2: f32 weights as two dense bf16 planes, qs = hi [N][K], sc = lo [N][K] (conv stem)
 
-enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6, EPI_RESID_XF = 7, EPI_ROPE_KV_ATTN = 8 };
-// _ROPE_KV_ATTN (GEMV, one row): _ROPE_KV with write-through stores, then the workgroup that arrives LAST on a query head's counter (its q rows +
-// its KV head's k and v rows are complete) runs that head's single-query attention in the same launch -- one launch less per decoder layer
+enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6, EPI_RESID_XF = 7 };
 // (M <= 16 only) _SWIGLU_XF: SwiGLU written as XF planes; _RESID_XF: out = acc + resid as f32 AND as XF planes of out * xf_w (* xf_w2) plus
 // per-workgroup partial sums of squares -- the next RMSNorm is folded into its producer and its consumer (GemmParams::ssq_part)
 enum Pro { PRO_NONE = 0, PRO_RMS = 1, PRO_RMS_MUL = 2,      // RMS_MUL: RMSNorm then * mul (the cached Ada scale)
@@ -46,9 +44,6 @@ struct GemvParams {
     int n_q, n_k;                        // EPI_ROPE_KV: rows [0,n_q) q, [n_q,n_q+n_k) k, then v
     float* kcache; float* vcache; int cache_head_stride;    // [kv_head][max_seq][hd]
     float* part_val; int* part_idx;      // EPI_ARGMAX: per-workgroup (max, argmax)
-    // EPI_ROPE_KV_ATTN: per-query-head arrival counters attn_cnt[attn_cnt_stride * h] (far apart: device-scope atomics on neighbouring addresses
-    // serialise in one memory channel; monotonic: every launch adds 3*hd/8 per head), attention output [n_q], window, cache rows
-    unsigned* attn_cnt; int attn_cnt_stride; float* attn_out; int attn_window, attn_max_seq;
     int tl_slot;                         // timeline slot (measurement builds, -DVOX_TIMELINE; assigned by the launcher, -1 = off)
 };
 // rows_per_wave R in {1,2,4,8}; K tiles of 2048 chosen from K. Returns hipError_t.
@@ -58,7 +53,6 @@ int q4_gemv_default_R(int N, int K, int epi);
 int q4_gemv_grid(int N, int R);
 int q4_gemv_nwv(int K, int epi);        // waves per workgroup the launcher will use for this shape (4 / 6 / 12)
 int q4_gemv_grid_k(int N, int K, int R, int epi);
-bool q4_gemv_attn_fusable(int N, int K, int hd, int n_q, int n_k, int max_seq);   // may launch_q4_gemv(.., PRO_RMS, EPI_ROPE_KV_ATTN, R = 2, ..) be used?   // workgroups launched for an [N][K] GEMV at R rows per wave (== number of argmax partials)
 int dense_gemv_grid(int N);        // same, for WFMT_BF16 weights   // workgroups launched for N rows at R rows per wave (== number of argmax partials)
 
 // ---- Q4 GEMM on MFMA (prefill / encoder, rows of x > 4): out[M][N'] = epi( x[M][K] * W^T )
@@ -79,6 +73,7 @@ struct GemmParams {
     // EPI_ROPE_KV (M <= 16, one row per sequence): columns [0, n_q) -> RoPE -> out; [n_q, n_q + n_kv*hd) -> RoPE -> K cache; rest -> V cache,
     // all at position pos[m] of sequence m's cache slice
     const int* pos; const float* rope_cos; const float* rope_sin; int hd, n_q, n_kv; float* kc; float* vc; long kv_seq_stride; int kv_head_stride;
+    const int* kv_row;    // EPI_ROPE_KV, optional: row m writes into cache slice kv_row[m] instead of slice m (continuous batching: a SLOT of the step decodes whichever utterance it currently holds)
     int tl_slot;          // timeline slot (measurement builds, -DVOX_TIMELINE)
     // split-K (q4_gemm_kernel only, EPI_STORE): blockIdx.z = K slice; slice z writes its partial product to out + z * M * out_stride (bias in slice 0).
     // The consumer (launch_rms_norm_sumk) adds the slices in a fixed order -- for few-column GEMMs (the encoder's N = 1280 w2: 40 K-steps per workgroup)
@@ -127,6 +122,7 @@ struct AttnParams {
     const int* pos_ptr;                      // decode: position = *pos_ptr + offset, kv_len = position+1
     // batched decode (gridDim.y = sequences): sequence s reads pos_ptr[s] and its own q / out rows and KV-cache slice
     int pos_per_seq; int q_seq_stride, out_seq_stride; long kv_seq_stride;
+    const int* kv_row;    // batched decode, optional: sequence s reads cache slice kv_row[s] instead of slice s (attn_decode_gqa_kernel only: launch_attn_decode forces that kernel)
     // stacked prefill (gridDim.z = sequences): sequence z has seq_len[z] query rows (kv_len = offset + seq_len[z]); p.M = the maximum;
     // q / out / k / v of sequence z start q_seq_stride / out_seq_stride / kv_seq_stride floats after those of z-1
     const int* seq_len;
@@ -174,6 +170,19 @@ hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int*
                                      const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s,
                                      uint16_t* xf = nullptr, const float* xf_w = nullptr, float* ssq_out = nullptr,     // xf: also h * xf_w as XF planes + sum of squares,
                                      long xf_group_stride = 0, int ssq_group_stride = 0);                                 // per group of 16 sequences (strides in elements)
+// continuous batching: the argmax / next-input launch of a decode step over SLOTS (argmax_embed_slots_kernel)
+struct SlotStepParams {
+    const float* logits; int vocab;                    // [n_slots][vocab] (unused when init)
+    int* tokens; int tok_stride; const int* clip_len;  // per utterance: token rows [n_clips][tok_stride], sequence lengths
+    int* slot_clip; int* slot_qpos; const int* queue; int q_stride;      // per slot: current utterance (-1: none), index into its queue, queue [n_slots][q_stride] (-1 terminated)
+    int* pos; int* kv_row; int n_clips; int first_pos; // per slot: position of the last token written, cache slice (n_clips = the scratch slice of idle slots); first_pos = prefix length
+    Q4W tok; const float* audio; const long* audio_off; int D;           // audio rows of utterance c start at audio + audio_off[c] (floats), row stride D
+    const float* h0;                                   // [n_clips][D]: first decode input of every utterance
+    float* h;                                          // [n_slots][D]: the step's input rows
+    uint16_t* xf; const float* xf_w; float* ssq_out; long xf_group_stride; int ssq_group_stride;      // as launch_argmax_embed_batch
+    int init;                                          // 1: no argmax, every slot takes the head of its queue
+};
+hipError_t launch_argmax_embed_slots(const SlotStepParams& p, int n_slots, hipStream_t s);
 hipError_t launch_occupy(int workgroups, int micros, hipStream_t s);      // test hook: spin `workgroups` x 1024 threads for `micros` us
 hipError_t launch_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);
 hipError_t launch_gelu(float* x, long n, hipStream_t s);

@@ -183,13 +183,7 @@ __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh,
                                                    int pos, int window, float* __restrict__ sc, float* __restrict__ red, float4* __restrict__ osum, int tl_slot, int tlw,
                                                    int spec_rows = 0, Hook after_issue = Hook());
 
-// two adjacent floats: plain stores, or ONE 8-byte write-through (sc1) store -- visible to other workgroups of the same launch once the
-// storing wave has drained it (s_waitcnt vmcnt(0)) and published a flag / counter (MI355X_MICROARCH.md, inter-workgroup visibility, form R1)
-template <bool WT>
-__device__ __forceinline__ void st_pair(float* dst, float a, float b) {
-    if (WT) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else { dst[0] = a; dst[1] = b; }
-}
+__device__ __forceinline__ void st_pair(float* dst, float a, float b) { dst[0] = a; dst[1] = b; }
 
 // LDS image of x: chunk c (32 floats) holds its eight 16-byte pieces at piece index j ^ ((c>>1)&7):
 // lanes of one ds_read_b128 service group then hit 16 distinct 16-byte slots of the 256-byte bank row.
@@ -201,7 +195,7 @@ __device__ __forceinline__ int xs_piece(int c, int j) { return c * 8 + (j ^ ((c 
 // NWV = waves per workgroup (4, 6 or 12): the total number of waves (and so the row-group -> wave mapping) is the same for every NWV,
 // a bigger workgroup only shares one staged copy of the activation vector between more waves (768 / 512 / 256 workgroups re-read it).
 template <int P, int R, int PRO, int EPI, int NWV>
-__global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_gemv_kernel(const GemvParams p) {   // fused attention: 3 workgroups per CU must stay resident
+__global__ __launch_bounds__(64 * NWV, 1) void q4_gemv_kernel(const GemvParams p) {
     constexpr int NT = 64 * NWV;                                      // threads per workgroup
     constexpr int NX = (8 * P + R * NWV - 1) / (R * NWV);             // float4 activation pieces per thread (K/4 <= 512 P / R pieces)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -216,10 +210,7 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
     // persistent waves: wave w handles row groups g = w, w + n_waves, ... with the NEXT group's weight loads issued
     // before the current group is consumed, so HBM stays busy while the VALU works.
     const int rnb = R * nb, n_groups = N / R, n_waves = gridDim.x * NWV;
-    // fused attention: workgroups are dispatched in blockIdx order, so the k / v row blocks go FIRST and the q blocks last -- the last arriver
-    // of a head is then (almost always) one of its own 16 q workgroups: 32 heads finish on 32 different workgroups, in parallel.  (A k / v
-    // workgroup arriving last would have to run all G heads of its KV head one after the other.)
-    const int bx = EPI == EPI_ROPE_KV_ATTN ? (int)((blockIdx.x + (unsigned)(p.n_q / (NWV * R))) % gridDim.x) : (int)blockIdx.x;
+    const int bx = (int)blockIdx.x;
     int g = bx * NWV + wave;
     VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 0);
     if (p.zero_acc) {      // uniform; a handful of stores per workgroup
@@ -271,13 +262,13 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
 #endif
     // No weight request before the activation vector is staged: the vector is a cross-XCD read that otherwise queues behind the weight bursts of
     // the workgroups that started first (3 x 3 back-to-back pairs, tools/gemv_ablate.py: q|k|v 6.75 -> 6.20 us, w2 7.9 -> 7.6, wo 4.75 -> 4.65;
-    // w1|w3 and lm_head neutral).  The opt-in fused-attention epilogue keeps the old order (its measurements were taken with it).
+    // w1|w3 and lm_head neutral).
 #ifdef VOX_ABL_XFIRST_RESID_ONLY      /* measurement build: the earlier setting (only wo / w2 wait for the vector) */
     constexpr bool XFIRST = PRO == PRO_NONE && EPI == EPI_RESID;
 #elif defined(VOX_ABL_XFIRST_NO_SWIGLU)  /* measurement build: w1|w3 keeps the weights-with-vector order */
-    constexpr bool XFIRST = EPI != EPI_ROPE_KV_ATTN && EPI != EPI_SWIGLU;
+    constexpr bool XFIRST = EPI != EPI_SWIGLU;
 #else
-    constexpr bool XFIRST = EPI != EPI_ROPE_KV_ATTN;
+    constexpr bool XFIRST = true;
 #endif
     if (!XFIRST) { VOX_WLOAD(qa, da, min(g, n_groups - 1)) }
 #if defined(VOX_ABL_WFIRST) && !defined(VOX_ABL_NOX)       /* measurement build: weights issued BEFORE the activation loads */
@@ -341,7 +332,7 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
     const float rstd = PRO != PRO_NONE ? 1.0f / sqrtf(ssq / (float)K + p.eps) : 1.0f;
 
     float best = -INFINITY; int best_i = 0x7fffffff;   // EPI_ARGMAX running (max, first index) of this wave
-    constexpr bool ROPE = EPI == EPI_ROPE_KV || EPI == EPI_ROPE_KV_ATTN, WT = EPI == EPI_ROPE_KV_ATTN;
+    constexpr bool ROPE = EPI == EPI_ROPE_KV;
     const int pos = ROPE ? (p.pos_ptr ? *p.pos_ptr : 0) + p.pos_off : 0;
 
     // (4)+(5) consume one row group from registers (Q_, D_) and run its epilogue
@@ -389,14 +380,14 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
                         const int dd = n % hd;                                                                         \
                         const float c = p.rope_cos[(size_t)pos * half + (dd >> 1)], sn = p.rope_sin[(size_t)pos * half + (dd >> 1)]; \
                         const float ra = a * c - b * sn, rb = a * sn + b * c;                                          \
-                        if (n < p.n_q) st_pair<WT>(p.out + n, ra, rb);                                                 \
+                        if (n < p.n_q) st_pair(p.out + n, ra, rb);                                                 \
                         else {                                                                                         \
                             const int kn = n - p.n_q, kh = kn / hd;                                                    \
-                            st_pair<WT>(p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd, ra, rb);  \
+                            st_pair(p.kcache + (size_t)kh * p.cache_head_stride + (size_t)pos * hd + dd, ra, rb);  \
                         }                                                                                              \
                     } else {                                                                                           \
                         const int vn = n - p.n_q - p.n_k, vh = vn / hd, dd = vn % hd;                                  \
-                        st_pair<WT>(p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd, a, b);        \
+                        st_pair(p.vcache + (size_t)vh * p.cache_head_stride + (size_t)pos * hd + dd, a, b);        \
                     }                                                                                                  \
                 }                                                                                                      \
             }                                                                                                          \
@@ -436,41 +427,6 @@ __global__ __launch_bounds__(64 * NWV, EPI == EPI_ROPE_KV_ATTN ? 3 : 1) void q4_
 #undef VOX_DOT
 #undef VOX_REDUCE
     VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 3);
-    if (EPI == EPI_ROPE_KV_ATTN) {
-        // ---- fused single-query attention: no workgroup ever waits.  (a) every wave drains its write-through q / k / v stores, then the
-        // workgroup arrives on the counter of each query head its 8 rows feed (a q block: its own head; a k or v block: the G heads of its
-        // KV head).  A head's counter receives 3*hd/8 arrivals per launch; whoever brings it to a multiple of that runs the head.
-        static_assert(EPI != EPI_ROPE_KV_ATTN || (NWV == 4 && R == 2), "fused attention: 256-thread workgroups of 8 rows");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                   // also: the x staging area is dead from here on, the attention reuses it
-        const int hd = p.hd, G = p.n_q / p.n_k;            // G = query heads per KV head
-        float* sc = smem;                                  // [attn_max_seq] scores
-        float4* osum = reinterpret_cast<float4*>(smem + ((p.attn_max_seq + 3) & ~3));
-        float* red2 = reinterpret_cast<float*>(osum + 256);
-        int* s_my = reinterpret_cast<int*>(red2 + 8);      // [0] = number of heads this workgroup completed, then the heads
-        if (tid == 0) {
-            const int rows_wg = NWV * R, per_head = 3 * hd / rows_wg, row0 = bx * rows_wg;
-            int h0, nh;
-            if (row0 < p.n_q) { h0 = row0 / hd; nh = 1; }
-            else { h0 = (((row0 - p.n_q) % p.n_k) / hd) * G; nh = G; }
-            int cnt = 0;
-            for (int i = 0; i < nh; i++) {
-                const unsigned old = __hip_atomic_fetch_add(p.attn_cnt + (size_t)(h0 + i) * p.attn_cnt_stride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((old + 1) % (unsigned)per_head == 0) s_my[1 + cnt++] = h0 + i;
-            }
-            s_my[0] = cnt;
-        }
-        __syncthreads();
-        const int n_mine = s_my[0];
-        for (int i = 0; i < n_mine; i++) {                 // (b) uniform per workgroup; zero iterations for all but the last arrivers
-            const int h = s_my[1 + i], kvh = h / G;
-            const float4 r4 = attn_decode_core<128, true, true>(p.out + (size_t)h * hd, p.kcache + (size_t)kvh * p.cache_head_stride, p.vcache + (size_t)kvh * p.cache_head_stride,
-                                                          hd, pos, p.attn_window, sc, red2, osum, -1, 0);
-            if (tid < 32) *reinterpret_cast<float4*>(p.attn_out + (size_t)h * hd + tid * 4) = r4;
-            __syncthreads();
-        }
-        VOX_TL(p.tl_slot, blockIdx.x * NWV + wave, 3);     // (timeline builds: wave exit including the attention tail)
-    }
     if (EPI == EPI_ARGMAX) {
         if (lane == 0) { red[NWV + wave] = best; reinterpret_cast<int*>(red)[2 * NWV + wave] = best_i; }
         __syncthreads();
@@ -535,7 +491,6 @@ static inline int passes_for(int K, int R) { return (R * (K / 32) + 63) / 64; }
 // rows per wave. Prefers the R that fills every pass exactly (R*nb % 64 == 0). Tuning knobs (measurement only):
 // VOX_GEMV_R / VOX_GEMV_R_PAIR / VOX_GEMV_R_ARGMAX override the choice when the (R, P) pair is instantiated.
 int q4_gemv_default_R(int N, int K, int epi) {
-    if (epi == EPI_ROPE_KV_ATTN) return 2;
     const bool pair = (epi == EPI_SWIGLU || epi == EPI_ROPE_KV);
     const int e = env_int(epi == EPI_ARGMAX ? "VOX_GEMV_R_ARGMAX" : pair ? "VOX_GEMV_R_PAIR" : "VOX_GEMV_R");
     if (e && N % e == 0 && gemv_has(e, passes_for(K, e)) && (!pair || e % 2 == 0)) return e;
@@ -562,7 +517,7 @@ int dense_gemv_grid(int N);
 int q4_gemv_nwv(int K, int epi) {
     const int e = env_int("VOX_GEMV_NWV");
     if (e == 4 || e == 6 || e == 12) return e;
-    if (epi == EPI_ARGMAX || epi == EPI_ROPE_KV || epi == EPI_ROPE_KV_ATTN) return 4;
+    if (epi == EPI_ARGMAX || epi == EPI_ROPE_KV) return 4;
     return (K >= 4096 || epi == EPI_SWIGLU) ? 12 : 4;
 }
 static int q4_gemv_grid_w(int N, int R, int nwv) {
@@ -581,26 +536,12 @@ int q4_gemv_grid(int N, int R) { return q4_gemv_grid_w(N, R, 4); }
 static bool gemv_fat_shape(int K, int R) { const int P = passes_for(K, R); return (R == 2 && P == 3) || (R == 1 && (P == 2 || P == 5)); }
 int q4_gemv_grid_k(int N, int K, int R, int epi) { return q4_gemv_grid_w(N, R, gemv_fat_shape(K, R) ? q4_gemv_nwv(K, epi) : 4); }
 
-static size_t gemv_attn_lds(int max_seq) { return ((size_t)((max_seq + 3) & ~3) + 256 * 4 + 8 + 16) * sizeof(float); }
-bool q4_gemv_attn_fusable(int N, int K, int hd, int n_q, int n_k, int max_seq) {
-    // OPT-IN (VOX_FUSED_ATTN=1).  Correct (bit-identical to two launches, tests/test_gpu_model.py::test_fused_attention_equals_separate_launches) but
-    // SLOWER on MI355X: the hand-off costs what it saves -- draining the write-through q / k / v stores + one returning device-scope atomic
-    // (~1.6 us) replace a ~1.9 us kernel boundary, and the last arriver then runs the head's dependent chain (q, K -> scores -> V) alone
-    // while the chip idles: 22.5 us per layer against 6.8 + 1.9 + 4.6 for two launches (profiles/r02_fused_attention_timeline.txt).
-    if (!env_int("VOX_FUSED_ATTN")) return false;
-    if (hd != 128 || n_k <= 0 || n_q % n_k || n_q / n_k > 8 || N != n_q + 2 * n_k || N % 8 || n_q % 8 || n_k % 8 || K % 32) return false;
-    if (max_seq > 4096) return false;                                        // LDS for the score row
-    if (!gemv_has(2, passes_for(K, 2))) return false;
-    return q4_gemv_grid_w(N, 2, 4) * 8 == N;                                 // one row group per wave: workgroup b <-> rows 8b .. 8b+7
-}
+// (Round 2 also built a fused q|k|v GEMV + attention launch -- write-through q / k / v stores, per-head arrival counters, the last-arriving workgroup runs the head.  It was
+// bit-identical to two launches and SLOWER (22.5 us per layer against 6.8 + 1.9 + 4.6, profiles/r02_fused_attention_timeline.txt) and spilled 93 VGPRs; removed in round 5.)
 template <int P, int R, int PRO, int EPI, int NWV>
 static hipError_t gemv_launch_w(const GemvParams& p, int ny, hipStream_t s) {
     dim3 grid(q4_gemv_grid_w(p.w.N, R, NWV), ny);
     size_t lds = (size_t)(p.w.K + p.w.nb + 4 * NWV) * sizeof(float);
-    if (EPI == EPI_ROPE_KV_ATTN) {
-        if (ny != 1 || !p.attn_cnt || !p.attn_out || !q4_gemv_attn_fusable(p.w.N, p.w.K, p.hd, p.n_q, p.n_k, p.attn_max_seq)) return hipErrorInvalidValue;
-        lds = lds > gemv_attn_lds(p.attn_max_seq) ? lds : gemv_attn_lds(p.attn_max_seq);
-    }
     auto kern = q4_gemv_kernel<P, R, PRO, EPI, NWV>;
     static bool attr_done = false;
     hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
@@ -634,7 +575,6 @@ static hipError_t gemv_dispatch_pe(const GemvParams& p, int ny, int pro, int epi
         if (pro == PRO_RMS_MUL_SUM && epi == EPI_SWIGLU && P == 3 && R == 2) return gemv_launch_t<3, 2, PRO_RMS_MUL_SUM, EPI_SWIGLU>(p, ny, s);
         if (pro == PRO_NONE && epi == EPI_SWIGLU) return gemv_launch_t<P, R2, PRO_NONE, EPI_SWIGLU>(p, ny, s);
         if (pro == PRO_RMS && epi == EPI_ROPE_KV) return gemv_launch_t<P, R2, PRO_RMS, EPI_ROPE_KV>(p, ny, s);
-        if (pro == PRO_RMS && epi == EPI_ROPE_KV_ATTN && R == 2) return gemv_launch_w<P, 2, PRO_RMS, EPI_ROPE_KV_ATTN, 4>(p, ny, s);
     }
 #undef VOX_CASE
     return hipErrorInvalidValue;
@@ -996,11 +936,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     const int m0 = blockIdx.y * (16 * MT), n0 = blockIdx.x * (64 * NT);
     const int KSP = p.ksplit > 1 ? p.ksplit : 1, kz = blockIdx.z;                               // split-K: this workgroup's K steps [qb, qe)
     const int qb = (int)((long)nq * kz / KSP), qe = (int)((long)nq * (kz + 1) / KSP);
-    // staging role: fragment f = tid + 256*i -> (row sm = f>>4, block j = (f>>2)&3, group g = f&3)
+    // staging role: fragment f = tid + 256*i -> (row sm = 16 (f>>8) + (f&15), block j = (f>>6)&3, group g = (f>>4)&3): the 64 lanes of a wave write 64 CONSECUTIVE
+    // 16-byte slots per plane (slot = base + lane).  Until round 5 the map was (sm = f>>4, j = (f>>2)&3, g = f&3): the 16 lanes of a row group then wrote slots 16 and
+    // 128 apart -- the same four banks, a 16-way conflict on every ds_write_b128 (PMC, profiles/r04_pmc_batch16.txt: 11 conflict cycles per LDS instruction, 10 % of the
+    // kernel waiting on LDS).  Same fragments, same values, same order of arithmetic.
     const float* xrow[MT]; int slot[MT], xo_a[MT], xo_b[MT];
 #pragma unroll
     for (int i = 0; i < MT; i++) {
-        const int f = tid + 256 * i, sm = f >> 4, j = (f >> 2) & 3, g = f & 3;
+        const int f = tid + 256 * i, sm = 16 * (f >> 8) + (f & 15), j = (f >> 6) & 3, g = (f >> 4) & 3;
         xrow[i] = p.x + (size_t)min(m0 + sm, M - 1) * p.x_stride;
         slot[i] = (j * MT + (sm >> 4)) * 64 + g * 16 + (sm & 15);
         xo_a[i] = 32 * j + (FMT == WFMT_Q4_0 ? 4 * g : 8 * g); xo_b[i] = 32 * j + (FMT == WFMT_Q4_0 ? 16 + 4 * g : 8 * g + 4);
@@ -1247,7 +1190,7 @@ __global__ __launch_bounds__(NTW == 3 ? 256 : 512, NTW == 3 ? 3 : 1) void q4_ski
     // branch around a load makes hipcc drain vmcnt).  vmcnt retires IN ORDER and these words were written by the previous launches on other XCDs
     // (memory round trips): the straight-line path requests them BEHIND its first K step's operands, so that step does not wait for them.
     float pv[12]; const int prow = tid & 15, pch = tid >> 4, nch = blockDim.x >> 4;
-    float pre_res[4] = {0.f, 0.f, 0.f, 0.f}; float pre_xw = 0.f; int pre_pos[4] = {0, 0, 0, 0};
+    float pre_res[4] = {0.f, 0.f, 0.f, 0.f}; float pre_xw = 0.f; int pre_pos[4] = {0, 0, 0, 0}; int pre_row[4] = {0, 0, 0, 0};
 #define VOX_PRELOADS                                                                                       \
     {                                                                                                      \
         if (PRO) {                                                                                         \
@@ -1264,6 +1207,7 @@ __global__ __launch_bounds__(NTW == 3 ? 256 : 512, NTW == 3 ? 3 : 1) void q4_ski
         if (EPI == EPI_RESID_XF) { pre_xw = p.xf_w[n0_]; if (p.xf_w2) pre_xw *= p.xf_w2[n0_]; }            \
         if (EPI == EPI_ROPE_KV) {                                                                          \
             _Pragma("unroll") for (int r = 0; r < 4; r++) pre_pos[r] = p.pos[min(4 * g + r, M - 1)];       \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) pre_row[r] = p.kv_row ? p.kv_row[min(4 * g + r, M - 1)] : min(4 * g + r, M - 1); \
         }                                                                                                  \
     }
     constexpr bool STRAIGHT = STEPS > 0 && TILED && XIN;
@@ -1386,16 +1330,17 @@ __global__ __launch_bounds__(NTW == 3 ? 256 : 512, NTW == 3 ? 3 : 1) void q4_ski
                 const float other = dpp_mov<0xB1>(v);          // the pair partner (interleaved RoPE pairs, rope.rs:77-141)
                 if (m < M && nok) {
                     const int ps = pre ? pre_pos[r] : p.pos[m], kd = p.n_kv * p.hd;
+                    const int cr = pre ? pre_row[r] : (p.kv_row ? p.kv_row[m] : m);      // cache slice of row m
                     if (n < p.n_q + kd) {
                         const int dd = n % p.hd;
                         const size_t ti = (size_t)ps * (p.hd >> 1) + (dd >> 1);
                         const float c = p.rope_cos[ti], sn = p.rope_sin[ti];
                         const float o = (n & 1) ? other * sn + v * c : v * c - other * sn;
                         if (n < p.n_q) p.out[(size_t)m * p.out_stride + n] = o;
-                        else p.kc[(size_t)m * p.kv_seq_stride + (size_t)((n - p.n_q) / p.hd) * p.kv_head_stride + (size_t)ps * p.hd + dd] = o;
+                        else p.kc[(size_t)cr * p.kv_seq_stride + (size_t)((n - p.n_q) / p.hd) * p.kv_head_stride + (size_t)ps * p.hd + dd] = o;
                     } else {
                         const int vn = n - p.n_q - kd;
-                        p.vc[(size_t)m * p.kv_seq_stride + (size_t)(vn / p.hd) * p.kv_head_stride + (size_t)ps * p.hd + (vn % p.hd)] = v;
+                        p.vc[(size_t)cr * p.kv_seq_stride + (size_t)(vn / p.hd) * p.kv_head_stride + (size_t)ps * p.hd + (vn % p.hd)] = v;
                     }
                 }
             } else if (m < M && nok) {
@@ -2048,11 +1993,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 }
 hipError_t launch_dense2_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.w.fmt != WFMT_BF16X2 || p.w.K % 128 || (p.x_stride % 4) || p.M <= 0) return hipErrorInvalidValue;
-    const long wg4 = (long)((p.w.N + 255) / 256) * ((p.M + 63) / 64);
+    // wide form = 64 x 128 workgroups (two n-tiles per wave).  Four n-tiles per wave (64 x 256) kept the current AND the prefetched hi + lo B fragments of four tiles in
+    // registers -- 256 VGPRs for B alone: 187-212 spilled VGPRs, ~700 B of scratch per lane (round-4 disassembly); two tiles fit (tools/kernel_resources.py: no scratch).
+    const long wg2 = (long)((p.w.N + 127) / 128) * ((p.M + 63) / 64);
     const size_t lds = (size_t)2 * 4 * 4 * 64 * sizeof(uint4);      // 32 KB
-    const bool wide = wg4 >= 200;
-    dim3 grid(wide ? (p.w.N + 255) / 256 : (p.w.N + 63) / 64, (p.M + 63) / 64);
-#define VOX_D2(E_) case E_: if (wide) dense2_gemm_kernel<4, E_><<<grid, dim3(256), lds, s>>>(p); else dense2_gemm_kernel<1, E_><<<grid, dim3(256), lds, s>>>(p); break;
+    const bool wide = wg2 >= 400;
+    dim3 grid(wide ? (p.w.N + 127) / 128 : (p.w.N + 63) / 64, (p.M + 63) / 64);
+#define VOX_D2(E_) case E_: if (wide) dense2_gemm_kernel<2, E_><<<grid, dim3(256), lds, s>>>(p); else dense2_gemm_kernel<1, E_><<<grid, dim3(256), lds, s>>>(p); break;
     switch (epi) { VOX_D2(EPI_STORE) VOX_D2(EPI_GELU) VOX_D2(EPI_RESID) VOX_D2(EPI_SWIGLU) default: return hipErrorInvalidValue; }
 #undef VOX_D2
     return hipGetLastError();
@@ -2132,13 +2079,7 @@ static hipError_t launch_q4_skinny(const GemmParams& p_in, int epi, hipStream_t 
     if (epi == EPI_RESID_XF) ntw = 1;       // its partial sums of squares are per workgroup = per 16-column tile
     { const int e = env_int("VOX_SKINNY_KS"); if (e == 1 || e == 2 || e == 4 || e == 8) ks = e; }
     const bool tiled = p.w.qt && p.w.st && !env_int("VOX_SKINNY_NO_TILE");
-    // three n-tiles per wave when that makes the grid a whole number of workgroups per CU and four does not (w1|w3: 2304 tiles -> 768 = 3 x 256
-    // instead of 576): only the straight-line decode-step instantiation exists for it.  VOX_SKINNY_NO_NTW3=1: measurement knob.
-    if (ntw == 4 && ks == 4 && tiled && p.xf && p.ssq_part && epi == EPI_SWIGLU_XF && nq == 24 && tiles % 3 == 0 && env_int("VOX_SKINNY_NTW3") &&
-        p.n_part >= 1 && p.n_part <= 12 * 16 && !env_int("VOX_SKINNY_NO_STEPS")) {
-        q4_skinny_kernel<3, EPI_SWIGLU_XF, 1, 1, 1, 6><<<dim3(tiles / 3), dim3(256), (size_t)4 * 3 * 64 * 4 * sizeof(float), s>>>(p);
-        return hipGetLastError();
-    }
+    // (three n-tiles per wave for w1|w3 -- 768 = 3 x 256 workgroups instead of 576 -- was a round-2 knob: no faster, 15 spilled VGPRs; removed in round 5)
     if (ntw == 4) return tiled ? skinny_launch_n<4, 1>(p, epi, ks, s) : skinny_launch_n<4, 0>(p, epi, ks, s);
     if (ntw == 2) return tiled ? skinny_launch_n<2, 1>(p, epi, ks, s) : skinny_launch_n<2, 0>(p, epi, ks, s);
     return tiled ? skinny_launch_n<1, 1>(p, epi, ks, s) : skinny_launch_n<1, 0>(p, epi, ks, s);
@@ -2227,7 +2168,8 @@ hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
         // (profiles/r01_gemm_sweep.txt).  VOX_GEMM_BIG: 0 auto, 1 force, -1 off (measurement knob)
         const int big = env_int("VOX_GEMM_BIG");
         const long wg14 = (long)((p.w.N + 255) / 256) * ((p.M + 63) / 64);
-        if (p.ksplit <= 1 && (big == 1 || (big == 0 && wg14 >= 200))) return gemm_big_launch<1, 4>(p, epi, s);
+        int big_min = 200; { const int e = env_int("VOX_GEMM_BIG_MIN_WG"); if (e > 0) big_min = e; }      // measurement knob: workgroups of 64 x 256 from which the big kernel takes over
+        if (p.ksplit <= 1 && (big == 1 || (big == 0 && wg14 >= big_min))) return gemm_big_launch<1, 4>(p, epi, s);
     }
     return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, s);
 }
@@ -2720,8 +2662,7 @@ hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n
 // single-query GQA attention against the cache (gguf/model.rs:125-174 with q_len == 1): one workgroup per
 // q-head, KV heads are NOT expanded (model.rs:177-197 materialises x4; here q-head h reads kv-head h/group).
 // ------------------------------------------------------------------------------------------------
-// One query head against its KV head's cache rows [j_lo, pos], 256 threads; shared by attn_decode_kernel and by the fused
-// q|k|v GEMV + attention kernel (q4_gemv_kernel<.., EPI_ROPE_KV_ATTN>).  NT: every q / K / V load is non-temporal (bypasses this CU's L1,
+// One query head against its KV head's cache rows [j_lo, pos], 256 threads; shared by attn_decode_kernel and attn_wo_kernel.  NT: every q / K / V load is non-temporal (bypasses this CU's L1,
 // served by L2 / memory): required when the rows were written by OTHER workgroups of the SAME launch (write-through stores).
 // Returns the normalised output float4 for threads tid < HD/4 (column tid); sc: n floats, red: 8 floats, osum: 256 float4 of LDS.
 template <bool NT>
@@ -2730,7 +2671,7 @@ __device__ __forceinline__ float4 ldf4(const float* p) {
     return *reinterpret_cast<const float4*>(p);
 }
 // LATE_V: the V rows of the first NPRE*32 keys are requested only after their K rows have been consumed (the K registers are reused:
-// ~half the VGPRs, one more round trip that overlaps the softmax) -- the fused GEMV + attention kernel needs 3 waves per SIMD.
+// ~half the VGPRs, one more round trip that overlaps the softmax) -- for callers that need 3 waves per SIMD (none today).
 // SPEC: the K / V rows of the first NPRE*32 keys are requested at rows 0 .. NPRE*32-1 of the cache (clamped to its spec_rows rows) WITHOUT
 // knowing pos -- the position word was written by the previous step's argmax kernel (another XCD: a memory round trip), and with the row
 // indices depending on it the kernel was pos -> K -> softmax -> V; now pos, q, K and V are four independent requests in flight together.
@@ -2759,7 +2700,7 @@ __device__ __forceinline__ float4 attn_decode_core(const float* __restrict__ qh,
     }
     // The first NPRE*32 keys (every 16 s clip: <= 146 positions) are handled with ALL their K and V loads issued up front, before any
     // arithmetic: the kernel is a chain of dependent round trips (q -> K -> softmax -> V) and this collapses the K and V trips into one.
-    constexpr int NPRE = LATE_V ? 4 : 5, COLS = HD / 4, GROUPS = 256 / COLS;      // LATE_V (fused kernel): 128 keys up front, the register budget is 168
+    constexpr int NPRE = LATE_V ? 4 : 5, COLS = HD / 4, GROUPS = 256 / COLS;      // LATE_V: 128 keys up front
     static_assert(4 * GROUPS == 32 || HD != 128, "prefetch tiling assumes 32 keys per P.V iteration for HD = 128");
     const int grp = tid / COLS, col = tid % COLS;
     float4 kpre[NPRE][PER / 4], vpre[NPRE][4];
@@ -2916,8 +2857,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     int pos;
     if (SPEC) pos = (p.pos_ptr ? __builtin_nontemporal_load(p.pos_ptr + (p.pos_per_seq ? seq : 0) + (tid & p.spec_zero)) : 0) + p.offset;
     else pos = (p.pos_ptr ? p.pos_ptr[p.pos_per_seq ? seq : 0] : 0) + p.offset;
-    const float* kb = p.k + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
-    const float* vb = p.v + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const int crow = p.kv_row ? p.kv_row[seq] : seq;      // cache slice of this sequence (continuous batching: the utterance the slot holds)
+    const float* kb = p.k + (size_t)crow * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const float* vb = p.v + (size_t)crow * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
     const float* qrow = p.q + (size_t)seq * p.q_seq_stride;
     float* orow = p.out + (size_t)seq * p.out_seq_stride;
     const int tlw = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave; (void)tlw;
@@ -2946,8 +2888,9 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const AttnParams p
     const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0;
     const int n = len - j_lo;
     const float scale = 1.0f / sqrtf((float)HD);
-    const float* kb = p.k + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
-    const float* vb = p.v + (size_t)seq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const int crow = p.kv_row ? p.kv_row[seq] : seq;      // cache slice of this sequence (continuous batching: the utterance the slot holds)
+    const float* kb = p.k + (size_t)crow * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const float* vb = p.v + (size_t)crow * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
     const float* qrow = p.q + (size_t)seq * p.q_seq_stride + (size_t)kvh * G * HD;
     const int ks = tid >> 3, part = tid & 7;
     const int grp = tid / COLS, col = tid % COLS;
@@ -3286,7 +3229,18 @@ hipError_t launch_mel(const float* audio, long n, long left, long right, const f
 __global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ x, long n, float target, float* __restrict__ scale_out) {
     __shared__ float red[16];
     float m = 0.f;
-    for (long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(x[i]));
+    // max is exact and order-independent: 16-byte loads, four per thread in flight (the scalar loop was a chain of 250 dependent round trips per thread: 65 us for a 16 s clip)
+    const long head = min(n, (long)(((16 - ((uintptr_t)x & 15)) & 15) >> 2)), n4 = (n - head) >> 2;
+    for (long i = threadIdx.x; i < head; i += 1024) m = fmaxf(m, fabsf(x[i]));
+    const float4* x4 = reinterpret_cast<const float4*>(x + head);
+    for (long i = threadIdx.x; i < n4; i += 4096) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = x4[min(i + 1024 * u, n4 - 1)];      // clamped: a repeated element does not change a maximum
+#pragma unroll
+        for (int u = 0; u < 4; u++) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+    for (long i = head + 4 * n4 + threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(x[i]));
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -3523,6 +3477,84 @@ hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int*
                                      uint16_t* xf, const float* xf_w, float* ssq_out, long xf_group_stride, int ssq_group_stride) {
     argmax_embed_batch_kernel<<<dim3(n), dim3(1024), 0, s>>>(logits, vocab, tokens, tok_stride, pos, seq_len, tok, audio, audio_seq_stride, D, h, xf, xf_w, ssq_out,
                                                              xf_group_stride, ssq_group_stride);
+    return hipGetLastError();
+}
+
+// ---- continuous batching (vox_transcribe_batch, wide batches): the decode step runs over SLOTS, not over utterances.  Slot s decodes the utterance
+// slot_clip[s]; when that utterance gets its last token the slot takes the next one of its (host-planned, static: token counts are a pure function of the audio
+// length, there is no EOS -- gguf/model.rs:936-960) queue in the SAME launch: position = the prefix length, cache slice = the new utterance's (kv_row[s]), input row
+// = the utterance's first decode input h0 (audio[38] + embed(first token), computed behind its prefill).  No host round trip, no idle step: the groups of a ragged
+// batch stay full until the queues run dry.  One workgroup per slot; `init` = 1: no argmax, every slot takes the head of its queue.
+__global__ __launch_bounds__(1024) void argmax_embed_slots_kernel(const SlotStepParams p) {
+    __shared__ float bv[1024];
+    __shared__ int bi[1024];
+    __shared__ int s_tok, s_cur, s_c, s_mode;      // mode 0: next position of the same utterance; 1: the slot switched to utterance s_c; 2: the slot's queue is empty
+    const int sl = blockIdx.x, nt = blockDim.x, D = p.D;
+    const int c = p.init ? -1 : p.slot_clip[sl];
+    if (!p.init && c < 0) return;                   // idle slot (uniform per workgroup): its input row and XF rows stay zero
+    if (!p.init) {
+        const float* lg = p.logits + (size_t)sl * p.vocab;
+        float v = -INFINITY; int idx = 0x7fffffff;
+        const int v4 = p.vocab >> 2;
+        for (int i = threadIdx.x; i < v4; i += nt) {            // ascending i per thread: first max wins (lowest index on ties, like argmax_embed_batch_kernel)
+            const float4 x = reinterpret_cast<const float4*>(lg)[i];
+            if (x.x > v) { v = x.x; idx = 4 * i; } if (x.y > v) { v = x.y; idx = 4 * i + 1; }
+            if (x.z > v) { v = x.z; idx = 4 * i + 2; } if (x.w > v) { v = x.w; idx = 4 * i + 3; }
+        }
+        for (int i = 4 * v4 + threadIdx.x; i < p.vocab; i += nt) { const float x = lg[i]; if (x > v) { v = x; idx = i; } }
+        bv[threadIdx.x] = v; bi[threadIdx.x] = idx;
+        __syncthreads();
+        for (int st = nt >> 1; st > 0; st >>= 1) {
+            if (threadIdx.x < st) {
+                const float x = bv[threadIdx.x + st]; const int ii = bi[threadIdx.x + st];
+                if (x > bv[threadIdx.x] || (x == bv[threadIdx.x] && ii < bi[threadIdx.x])) { bv[threadIdx.x] = x; bi[threadIdx.x] = ii; }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        bool take_next = p.init != 0; int q = -1;
+        if (!p.init) {
+            const int cur = p.pos[sl] + 1;            // the position the step just produced (pos = index of the last token written)
+            p.tokens[(size_t)c * p.tok_stride + cur] = bi[0];
+            if (cur + 1 < p.clip_len[c]) { p.pos[sl] = cur; s_cur = cur; s_tok = bi[0]; s_c = c; s_mode = 0; }
+            else { take_next = true; q = p.slot_qpos[sl]; }
+        }
+        if (take_next) {
+            q += 1;
+            const int c2 = q < p.q_stride ? p.queue[(size_t)sl * p.q_stride + q] : -1;
+            p.slot_qpos[sl] = q; p.slot_clip[sl] = c2; p.kv_row[sl] = c2 >= 0 ? c2 : p.n_clips; p.pos[sl] = p.first_pos;
+            s_c = c2; s_mode = c2 >= 0 ? 1 : 2; s_cur = p.first_pos; s_tok = 0;
+        }
+    }
+    __syncthreads();
+    float* hrow = p.h + (size_t)sl * D;
+    if (s_mode == 0) embed_row(p.tok, s_tok, p.audio + p.audio_off[s_c] + (size_t)s_cur * D, hrow, D);
+    else {
+        const float4* src = s_mode == 1 ? reinterpret_cast<const float4*>(p.h0 + (size_t)s_c * D) : nullptr;
+        for (int i = threadIdx.x; i < (D >> 2); i += nt) reinterpret_cast<float4*>(hrow)[i] = src ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.xf) {     // the first layer's RMSNorm folded in, exactly as argmax_embed_batch_kernel does for its rows (group = slot / 16, row = slot % 16)
+        uint16_t* xf = p.xf + (size_t)(sl >> 4) * p.xf_group_stride; float* ssq_out = p.ssq_out + (size_t)(sl >> 4) * p.ssq_group_stride;
+        const int row = sl & 15;
+        __syncthreads();
+        float ss = 0.f;
+        for (int k = threadIdx.x; k < (D >> 2); k += nt) {
+            float4 v = reinterpret_cast<const float4*>(hrow)[k]; const float4 gm = reinterpret_cast<const float4*>(p.xf_w)[k];
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
+            xf_store4(xf, D, row, 4 * k, v);
+        }
+        ss = wave_sum(ss);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) bv[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) { float a = 0.f; for (int w = 0; w < (nt >> 6); w++) a += bv[w]; ssq_out[row] = a; }
+    }
+}
+hipError_t launch_argmax_embed_slots(const SlotStepParams& p, int n_slots, hipStream_t s) {
+    if (n_slots <= 0 || !p.slot_clip || !p.slot_qpos || !p.queue || !p.pos || !p.kv_row || !p.h || !p.h0 || !p.tokens || !p.clip_len || !p.audio || !p.audio_off || (!p.init && !p.logits) || (p.D & 3)) return hipErrorInvalidValue;
+    argmax_embed_slots_kernel<<<dim3(n_slots), dim3(1024), 0, s>>>(p);
     return hipGetLastError();
 }
 

@@ -283,6 +283,14 @@ class LayerCaches:
     def reset(self):
         check(lib().vox_cache_reset(self.h))
 
+    def update(self, layer, pos, k, v):
+        """KVCache::update on one layer (kv_cache.rs:116-136): k / v [kv_heads][n][head_dim] host arrays -> rows pos .. pos + n"""
+        k = _f32(k); v = _f32(v); assert k.shape == v.shape and k.ndim == 3
+        check(lib().vox_cache_update(self.h, layer, pos, _ptr(k), _ptr(v), k.shape[1], 0))
+
+    def truncate(self, n):
+        check(lib().vox_cache_truncate(self.h, n))
+
     def close(self):
         if self.h:
             lib().vox_cache_free(self.h); self.h = None
