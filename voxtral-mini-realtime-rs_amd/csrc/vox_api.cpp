@@ -766,6 +766,7 @@ struct vox_model {
     float* d_prefix = nullptr;                            // [38][dec_dim] prefill inputs (transcribe_dev)
     float *enc_cos_s = nullptr, *enc_sin_s = nullptr; int enc_rope_s_len = 0;   // RoPE tables for the streaming encoder (positions beyond the 4096-row load-time table)
     int* d_seq_len = nullptr; std::vector<int> h_seq_len;  // per-utterance encoder rows of a stacked batch
+    int *d_seq_off = nullptr, *d_row_pos = nullptr; size_t row_pos_cap = 0; std::vector<int> h_seq_off, h_row_pos;      // packed stack: start row per utterance, position per row
     float *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_logits = nullptr, *d_part_val = nullptr; int* d_part_idx = nullptr;
     float* d_h2 = nullptr; long long* d_wo_acc = nullptr;      // fused attention + wo decode launch: residual stream after wo; per-layer fixed-point accumulators [dec_layers][dec_dim]
     int n_parts = 0, argmax_R = 8;
@@ -1179,7 +1180,7 @@ static void model_release(vox_model* m) {
     if (m->cache) { cache_unregister(m->cache); (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
     if (m->ctx->pw_model == m) m->ctx->pw_model = nullptr;
     for (void* p : {(void*)m->arena, (void*)m->ada_mul, (void*)m->ws, (void*)m->d_audio, (void*)m->d_mel, (void*)m->d_samples, (void*)m->d_tokens, (void*)m->d_pos,
-                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_prefix, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_wob, (void*)m->eng_state, (void*)m->eng_tab, (void*)m->engb_state[0], (void*)m->engb_state[1], (void*)m->engb_state[2], (void*)m->engb_state[3],
+                    (void*)m->d_h, (void*)m->d_h2, (void*)m->d_wo_acc, (void*)m->d_q, (void*)m->d_att, (void*)m->d_act, (void*)m->d_logits, (void*)m->d_part_val, (void*)m->d_part_idx, (void*)m->d_seq_len, (void*)m->d_seq_off, (void*)m->d_row_pos, (void*)m->d_prefix, (void*)m->enc_cos_s, (void*)m->enc_sin_s, (void*)m->eng_stream, (void*)m->eng_wob, (void*)m->eng_state, (void*)m->eng_tab, (void*)m->engb_state[0], (void*)m->engb_state[1], (void*)m->engb_state[2], (void*)m->engb_state[3],
                     (void*)m->engb_tab[0], (void*)m->engb_tab[1], (void*)m->engb_tab[2], (void*)m->engb_tab[3], (void*)m->pw_x, (void*)m->pw_hidden, (void*)m->pw_logits, (void*)m->pw_part_val, (void*)m->pw_part_idx, (void*)m->pw_ids, (void*)m->pw_zero, (void*)m->pw_tab})
         if (p) (void)hipFree(p);
     if (m->pw_err_pin) (void)hipHostFree(m->pw_err_pin);
@@ -1344,17 +1345,28 @@ static int32_t conv_stem_dev(vox_model* m, const float* d_mel, int T, float* c1,
     }
     return VOX_OK;
 }
-static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels, const int* T, float* audio_out, int audio_rows, int* S4_out) {
+// PACKED form (audio_off_out != nullptr; the continuous batch): no utterance is padded to the longest of the stack -- utterance i owns rp_i = S_enc_i rounded up to a multiple
+// of the reshape factor (>= 4 * 40) rows, back to back; RoPE takes the position of every row from a table, attention the start row of every utterance (AttnParams::
+// seq_row_off), the adapter's [rows / 4][4 D] view stays aligned because every start row is a multiple of 4.  audio_out receives packed_rows / 4 rows; audio_off_out[i] =
+// the float offset of utterance i's first row.  A ragged stack costs its own frames, not n x the longest (a rank's 64 longest clips of the FLEURS-like corpus span 9 .. 30 s:
+// 401 ms padded, profiles/r05_continuous_sweep.txt).
+static int enc_packed_rows_of(const vox_model* m, int T) { const int R = m->cfg.reshape_factor; return std::max((enc_rows(T) + R - 1) / R * R, R * 40); }
+static long enc_packed_rows(const vox_model* m, const int* T, int n) { long r = 0; for (int i = 0; i < n; i++) r += enc_packed_rows_of(m, T[i]); return r; }
+static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels, const int* T, float* audio_out, int audio_rows, int* S4_out, long* audio_off_out = nullptr) {
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     const int D = c.enc_dim, H = c.enc_heads, hd = c.enc_head_dim, QD = H * hd, F = c.enc_ffn, R = c.reshape_factor;
+    const bool packed = audio_off_out != nullptr;
+    ARGCHK(!packed || n <= 64, "internal: packed encoder stack of %d utterances", n);
     const int S_pad = enc_row_budget(m, T, n);
     int T1max = 0; bool any = false;
     std::vector<int> S(n);
     for (int i = 0; i < n; i++) { S[i] = enc_rows(T[i]); S4_out[i] = S[i] / R; T1max = std::max(T1max, conv_len(T[i])); any = any || S4_out[i] > 0; }
     if (!any || S_pad <= 0) return VOX_OK;
     ARGCHK(S_pad <= m->enc_rope_len, "audio too long for the encoder RoPE table (%d > %d positions); chunk it (--max-mel-frames)", S_pad, m->enc_rope_len);
-    const int Mtot = n * S_pad, M4 = n == 1 ? S4_out[0] : Mtot / R;          // adapter rows
-    ARGCHK(n == 1 || audio_rows >= S_pad / R, "internal: audio row budget %d < %d", audio_rows, S_pad / R);
+    std::vector<int> roff(n + 1, 0);      // packed: first row of every utterance
+    if (packed) for (int i = 0; i < n; i++) roff[i + 1] = roff[i] + enc_packed_rows_of(m, T[i]);
+    const int Mtot = packed ? roff[n] : n * S_pad, M4 = packed ? Mtot / R : n == 1 ? S4_out[0] : Mtot / R;          // adapter rows
+    ARGCHK(packed || n == 1 || audio_rows >= S_pad / R, "internal: audio row budget %d < %d", audio_rows, S_pad / R);
     int Tmax = 0; for (int i = 0; i < n; i++) Tmax = std::max(Tmax, T[i]);
     (void)T1max;
     const size_t c1_floats = conv_scratch_floats(m, Tmax);
@@ -1376,8 +1388,8 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     VOXCHK(ensure(&m->ws, &m->ws_floats, need));
     float* c1 = m->ws; float* x = c1 + c1_floats / 64 * 64; float* xn = x + (size_t)Mtot * D; float* qkv = xn + (size_t)Mtot * D;
     float* att = qkv + (size_t)Mtot * QD * 3; float* ffn = att + (size_t)Mtot * QD; float* ah = ffn + (size_t)Mtot * F; float* w2p = ah + (size_t)(M4 + 1) * m->ad0.w.N;
-    const int* d_len = nullptr;
-    if (n > 1) {
+    const int* d_len = nullptr; const int* d_roff = nullptr; const int* d_rpos = nullptr;
+    if (n > 1 || packed) {
         HIPCHK(hipMemsetAsync(x, 0, (size_t)Mtot * D * 4, s));               // scratch rows: finite values
         HIPCHK(hipMemsetAsync(att, 0, (size_t)Mtot * QD * 4, s));            // rows >= seq_len[i] are never written by attention
         if (!m->d_seq_len) HIPCHK(hipMalloc((void**)&m->d_seq_len, 64 * sizeof(int)));
@@ -1385,20 +1397,30 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
         HIPCHK(hipMemcpyAsync(m->d_seq_len, m->h_seq_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         d_len = m->d_seq_len;
     }
+    if (packed) {      // start rows and the position of every row (host-built, uploaded behind the stream; the host vectors are model members: they outlive the copies)
+        if (!m->d_seq_off) HIPCHK(hipMalloc((void**)&m->d_seq_off, 64 * sizeof(int)));
+        if (m->row_pos_cap < (size_t)Mtot) { if (m->d_row_pos) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(m->d_row_pos)); } m->d_row_pos = nullptr; m->row_pos_cap = 0;
+                                              HIPCHK(hipMalloc((void**)&m->d_row_pos, (size_t)Mtot * sizeof(int))); m->row_pos_cap = (size_t)Mtot; }
+        HIPCHK(hipStreamSynchronize(s));      // (the previous stack's copies out of these host vectors have completed)
+        m->h_seq_off.assign(roff.begin(), roff.begin() + n); m->h_row_pos.resize((size_t)Mtot);
+        for (int i = 0; i < n; i++) for (int r = roff[i]; r < roff[i + 1]; r++) m->h_row_pos[(size_t)r] = std::min(r - roff[i], m->enc_rope_len - 1);
+        HIPCHK(hipMemcpyAsync(m->d_seq_off, m->h_seq_off.data(), (size_t)n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(m->d_row_pos, m->h_row_pos.data(), (size_t)Mtot * 4, hipMemcpyHostToDevice, s));
+        d_roff = m->d_seq_off; d_rpos = m->d_row_pos;
+    }
     for (int i = 0; i < n; i++) {
         if (S[i] <= 0) continue;
-        VOXCHK(conv_stem_dev(m, d_mels[i], T[i], c1, x + (size_t)i * S_pad * D));
+        VOXCHK(conv_stem_dev(m, d_mels[i], T[i], c1, x + (packed ? (size_t)roff[i] : (size_t)i * S_pad) * D));
     }
-    const int seq_rows = n > 1 ? S_pad : 0;
+    const int seq_rows = packed ? 0 : n > 1 ? S_pad : 0;
     for (int l = 0; l < c.enc_layers; l++) {
         const EncLayer& L = m->enc[l];
         if (ksp && l > 0) HIPCHK(launch_rms_norm_sumk(x, D, Mtot, D, w2p, (size_t)Mtot * D, ksp, L.attn_norm, c.norm_eps, xn, D, s));      // + the previous layer's w2
         else HIPCHK(launch_rms_norm(x, D, Mtot, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
         VOXCHK(q4_linear_dev(cx, L.wqkv.w, L.wqkv.bias, xn, D, Mtot, qkv, 3 * QD));
-        HIPCHK(launch_rope(qkv, Mtot, 3 * QD, 2 * QD, hd, 0, m->enc_cos, m->enc_sin, s, seq_rows));
+        HIPCHK(launch_rope(qkv, Mtot, 3 * QD, 2 * QD, hd, 0, m->enc_cos, m->enc_sin, s, seq_rows, d_rpos));
         AttnParams ap{}; ap.q = qkv; ap.q_stride = 3 * QD; ap.k = qkv + QD; ap.v = qkv + 2 * QD; ap.kv_row_stride = 3 * QD; ap.kv_head_stride = hd;
         ap.out = att; ap.out_stride = QD; ap.M = S_pad; ap.kv_len = S_pad; ap.n_heads = H; ap.n_kv_heads = H; ap.offset = 0; ap.window = c.enc_window;
-        ap.seq_len = d_len; ap.q_seq_stride = S_pad * 3 * QD; ap.out_seq_stride = S_pad * QD; ap.kv_seq_stride = (long)S_pad * 3 * QD;
+        ap.seq_len = d_len; ap.q_seq_stride = S_pad * 3 * QD; ap.out_seq_stride = S_pad * QD; ap.kv_seq_stride = (long)S_pad * 3 * QD; ap.seq_row_off = d_roff;
         HIPCHK(launch_attn_prefill(ap, hd, s, n));
         if (ksp_wo) {      // (w2p is free here: the previous layer's w2 planes were consumed by this layer's first norm)
             VOXCHK(q4_linear_dev(cx, L.wo.w, L.wo.bias, att, QD, Mtot, w2p, D, EPI_STORE, nullptr, 0, ksp_wo));
@@ -1415,7 +1437,8 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     else HIPCHK(launch_rms_norm(x, D, Mtot, D, m->enc_norm, nullptr, c.norm_eps, xn, D, s));
     // reshape_encoder_output (models/adapter.rs:108-122): rows [0, 4*S4) of each utterance viewed as [S4][4D]; adapter (model.rs:745-749)
     VOXCHK(q4_linear_dev(cx, m->ad0.w, nullptr, xn, D * R, M4, ah, m->ad0.w.N, EPI_GELU));
-    if (n == 1 || audio_rows * R == S_pad) VOXCHK(q4_linear_dev(cx, m->ad2.w, nullptr, ah, m->ad0.w.N, M4, audio_out, c.dec_dim));
+    if (packed) { for (int i = 0; i < n; i++) audio_off_out[i] = (long)(roff[i] / R) * c.dec_dim; }
+    if (packed || n == 1 || audio_rows * R == S_pad) VOXCHK(q4_linear_dev(cx, m->ad2.w, nullptr, ah, m->ad0.w.N, M4, audio_out, c.dec_dim));
     else for (int i = 0; i < n; i++)      // wider per-utterance stride on the output side
         VOXCHK(q4_linear_dev(cx, m->ad2.w, nullptr, ah + (size_t)i * (S_pad / R) * m->ad0.w.N, m->ad0.w.N, S_pad / R, audio_out + (size_t)i * audio_rows * c.dec_dim, c.dec_dim));
     return VOX_OK;
@@ -2391,17 +2414,19 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     ARGCHK(Smax <= m->dec_rope_len, "sequence too long for the decoder RoPE table");
     const int max_seq = std::max((Smax + 63) / 64 * 64, 64), tstride = std::max(Smax, PREFIX_LEN) + 2;
     const size_t seq_stride = (size_t)KV * max_seq * hd, layer_stride = (size_t)(n + 1) * seq_stride;      // slice n of every layer: the scratch slice idle slots write to and read
-    // per-chunk geometry of the stacked encoder: every chunk keeps its own row stride in the audio buffer
+    // the stacked encoder runs in chunks of <= 64 utterances, PACKED (encode_batch_dev: every utterance its own rows, no padding to the longest): the audio rows of
+    // utterance i start audio_off[i] floats into the audio buffer
     const int n_chunks = (n + CHUNK - 1) / CHUNK;
-    std::vector<int> arows(n_chunks); std::vector<size_t> aoff_c(n_chunks); std::vector<long> audio_off(n);
+    std::vector<size_t> aoff_c(n_chunks); std::vector<long> audio_off(n);
     size_t audio_floats = 0, mel_max = 0, smp_max = 0;
     for (int ci = 0; ci < n_chunks; ci++) {
         const int c0 = ci * CHUNK, nc = std::min(CHUNK, n - c0);
-        arows[ci] = std::max(enc_row_budget(m, T.data() + c0, nc) / R, PREFIX_LEN + 1); aoff_c[ci] = audio_floats;
-        size_t mf = 0, sf = 0;
-        for (int i = c0; i < c0 + nc; i++) { audio_off[i] = (long)(aoff_c[ci] + (size_t)(i - c0) * arows[ci] * D); mf += (size_t)128 * T[i]; sf += n_samples[i]; }
-        audio_floats += (size_t)nc * arows[ci] * D; mel_max = std::max(mel_max, mf); smp_max = std::max(smp_max, sf);
+        aoff_c[ci] = audio_floats;
+        size_t mf = 0, sf = 0; long rows = 0;
+        for (int i = c0; i < c0 + nc; i++) { audio_off[i] = (long)(aoff_c[ci] + (size_t)(rows / R) * D); rows += enc_packed_rows_of(m, T[i]); mf += (size_t)128 * T[i]; sf += n_samples[i]; }
+        audio_floats += (size_t)(rows / R) * D; mel_max = std::max(mel_max, mf); smp_max = std::max(smp_max, sf);
     }
+    audio_floats += (size_t)(PREFIX_LEN + 2) * D;      // slack behind the last utterance: a (never occurring, see test_audio_entry_points_never_reach_prefix_len_edge) S < 39 reads a row past its own
     // the decode plan (host only: lengths are known)
     std::vector<std::pair<int, int>> jobs;
     for (int i = 0; i < n; i++) if (len[i] > PREFIX_LEN + 1) jobs.emplace_back(len[i] - PREFIX_LEN - 1, i);
@@ -2449,9 +2474,9 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             HIPCHK(launch_mel(d_s, (long)n_samples[i], (long)left, (long)right, scale_i, mt, mel_i, T[i], 1, s));
         }
         HIPCHK(hipStreamSynchronize(s)); const double tb = now_ms();
-        std::vector<int> S4(nc);
-        VOXCHK(encode_batch_dev(m, nc, d_mels.data(), T.data() + c0, d_audio + aoff_c[ci], arows[ci], S4.data()));
-        for (int i = 0; i < nc; i++) ARGCHK(S4[i] == S[c0 + i], "internal: sequence length mismatch (%d vs %d)", S4[i], S[c0 + i]);
+        std::vector<int> S4(nc); std::vector<long> aoff_rel(nc);
+        VOXCHK(encode_batch_dev(m, nc, d_mels.data(), T.data() + c0, d_audio + aoff_c[ci], 0, S4.data(), aoff_rel.data()));
+        for (int i = 0; i < nc; i++) ARGCHK(S4[i] == S[c0 + i] && (long)aoff_c[ci] + aoff_rel[i] == audio_off[c0 + i], "internal: sequence length / audio offset mismatch (%d vs %d)", S4[i], S[c0 + i]);
         HIPCHK(hipStreamSynchronize(s)); const double tc = now_ms();
         float* px = b_px.as<float>();
         for (int i = c0; i < c0 + nc; i++)
@@ -2461,14 +2486,14 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         // logits of every utterance's last prefix row -> its first generated token and its first decode input h0 = audio[38] + embed(token)
         HIPCHK(launch_rms_norm(px + (size_t)(PREFIX_LEN - 1) * D, PREFIX_LEN * D, nc, D, m->dec_norm, nullptr, c.norm_eps, b_xn.as<float>(), D, s));
         { GemmParams g{}; g.w = m->tok.w; g.x = b_xn.as<float>(); g.x_stride = D; g.M = nc; g.out = b_lg0.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
-        HIPCHK(launch_argmax_embed_batch(b_lg0.as<float>(), nc, V, d_tok + (size_t)c0 * tstride, tstride, b_posc.as<int>() + c0, b_len.as<int>() + c0, m->tok.w, d_audio + aoff_c[ci], (long)arows[ci] * D, D,
-                                         b_h0.as<float>() + (size_t)c0 * D, s));
+        HIPCHK(launch_argmax_embed_batch(b_lg0.as<float>(), nc, V, d_tok + (size_t)c0 * tstride, tstride, b_posc.as<int>() + c0, b_len.as<int>() + c0, m->tok.w, d_audio, 0, D,
+                                         b_h0.as<float>() + (size_t)c0 * D, s, nullptr, nullptr, nullptr, 0, 0, b_aoff.as<long>() + c0));
         HIPCHK(hipStreamSynchronize(s)); const double td = now_ms();
         pre_ms += tb - ta; enc_ms += tc - tb; pf_ms += td - tc;
     }
     const double t1 = now_ms();
     // ---- (B) + (C): the slot decode
-    int replays = 0;
+    int replays = 0, n_captures = 0; double capture_ms = 0.0;
     if (steps > 0) {
         auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
         const int parts_D = q4_skinny_resid_xf_parts(D);
@@ -2541,7 +2566,14 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             HIPCHK(launch_argmax_embed_slots(sp, Sl, s));      // (retired groups' slots are idle: slot_clip < 0)
             return VOX_OK;
         };
-        auto active_at = [&](int t) { uint32_t a = 0; for (int gi = 0; gi < G; gi++) if (t < plan.steps_g[gi]) a |= 1u << gi; return a; };
+        // a group retires when its queues are empty -- but every distinct set of active groups is a graph capture + instantiation (~10 ms): a group that would retire
+        // fewer than kRetireSlack steps before the next longer one keeps running with idle slots instead (harmless: idle rows compute on zeros)
+        const int kRetireSlack = 12;
+        std::vector<int> run_g(plan.steps_g.begin(), plan.steps_g.end());
+        for (int gi = 1; gi < G; gi++) {      // walk from the longest group down: snap a group to the previous one's run length when it is close
+            if (run_g[gi - 1] - plan.steps_g[gi] < kRetireSlack) run_g[gi] = run_g[gi - 1];
+        }
+        auto active_at = [&](int t) { uint32_t a = 0; for (int gi = 0; gi < G; gi++) if (t < run_g[gi]) a |= 1u << gi; return a; };
         struct Graphs {
             hipStream_t s; vox_ctx* cx; std::vector<std::pair<uint32_t, hipGraphExec_t>> ex; std::vector<hipGraph_t> gr;
             ~Graphs() { (void)hipStreamSynchronize(s); for (auto a : cx->aux) if (a) (void)hipStreamSynchronize(a); for (auto& e : ex) if (e.second) (void)hipGraphExecDestroy(e.second); for (auto g : gr) if (g) (void)hipGraphDestroy(g); }
@@ -2554,6 +2586,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             hipGraphExec_t ge = graphs.find(act);
             if (!ge) {
                 HIPCHK(hipStreamSynchronize(s));
+                const double tg = now_ms();
                 HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 const int32_t r = step(act);
                 hipGraph_t graph = nullptr;
@@ -2564,6 +2597,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
                 const hipError_t ie = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
                 if (ie != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
                 graphs.ex.emplace_back(act, ge);
+                capture_ms += now_ms() - tg; n_captures++;
             }
             if (hipGraphLaunch(ge, s) != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphLaunch failed");
             replays++;
@@ -2581,7 +2615,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     }
     m->timings.preprocess_ms = pre_ms; m->timings.encode_ms = enc_ms; m->timings.decode_ms = pf_ms + (now_ms() - t1); m->timings.total_ms = now_ms() - t0;
     m->timings.decode_tokens = total; m->timings.graph_replays = replays;
-    if (knob_str("VOX_BATCH_VERBOSE")) fprintf(stderr, "[voxtral_hip] continuous batch: %d utterances, %d slots, %d steps (plan %.1f ms), encode %.1f ms, prefill %.1f ms, decode %.1f ms\n", n, Sl, steps, plan.cost_ms, enc_ms, pf_ms, now_ms() - t1);
+    if (knob_str("VOX_BATCH_VERBOSE")) fprintf(stderr, "[voxtral_hip] continuous batch: %d utterances, %d slots, %d steps (plan %.1f ms), front-end %.1f ms, encode %.1f ms (%d chunks), prefill %.1f ms, decode %.1f ms of which %d graph captures %.1f ms\n", n, Sl, steps, plan.cost_ms, pre_ms, enc_ms, n_chunks, pf_ms, now_ms() - t1, n_captures, capture_ms);
     return VOX_OK;
 }
 

@@ -107,8 +107,9 @@ hipError_t launch_rms_norm_xf(const float* x, int x_stride, int rows, int dim, c
                               float eps, uint16_t* xf, hipStream_t s);   // rows <= 16 -> XF fragment planes
 // interleaved-pair RoPE in place on columns [0, n_rot) of buf[M][stride]; row m has position pos_off + m
 // (seq_rows > 0: stacked sequences of seq_rows rows each, positions restart per sequence)
+// (row_pos != nullptr: ragged sequences packed back to back, row m has position pos_off + row_pos[m])
 hipError_t launch_rope(float* buf, int M, int stride, int n_rot, int hd, int pos_off, const float* cos_t,
-                       const float* sin_t, hipStream_t s, int seq_rows = 0);
+                       const float* sin_t, hipStream_t s, int seq_rows = 0, const int* row_pos = nullptr);
 // copy k (columns [k_col, k_col+n_kv*hd)) and v (next n_kv*hd columns) of buf rows into the cache at pos_off+m
 hipError_t launch_kv_store(const float* buf, int M, int stride, int k_col, int n_kv, int hd, int pos_off,
                            float* kcache, float* vcache, int cache_head_stride, hipStream_t s, int seq_rows = 0, long kv_seq_stride = 0);
@@ -126,6 +127,7 @@ struct AttnParams {
     // stacked prefill (gridDim.z = sequences): sequence z has seq_len[z] query rows (kv_len = offset + seq_len[z]); p.M = the maximum;
     // q / out / k / v of sequence z start q_seq_stride / out_seq_stride / kv_seq_stride floats after those of z-1
     const int* seq_len;
+    const int* seq_row_off;   // stacked prefill, optional (MFMA kernel only): sequence z starts seq_row_off[z] ROWS into q / k / v / out (ragged sequences packed back to back) instead of z * the sequence strides
     uint16_t* out_xf;     // batched decode: write the output rows (row = sequence) as XF fragment planes instead of out
     int prefer_gqa;       // batched decode: one workgroup per (KV head, sequence) serving its 4 query heads (wide batches)
     int no_xcd_remap;     // measurement knob: keep the linear (head, sequence) workgroup order in attn_decode_kernel
@@ -169,7 +171,8 @@ hipError_t launch_rope_kv_batch(float* qkv, int n, int stride, int n_q, int n_kv
 hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int* tokens, int tok_stride, int* pos, const int* seq_len, Q4W tok,
                                      const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s,
                                      uint16_t* xf = nullptr, const float* xf_w = nullptr, float* ssq_out = nullptr,     // xf: also h * xf_w as XF planes + sum of squares,
-                                     long xf_group_stride = 0, int ssq_group_stride = 0);                                 // per group of 16 sequences (strides in elements)
+                                     long xf_group_stride = 0, int ssq_group_stride = 0,                                  // per group of 16 sequences (strides in elements)
+                                     const long* audio_off = nullptr);      // optional: sequence s reads its audio rows at audio + audio_off[s] (floats) instead of audio + s * audio_seq_stride
 // continuous batching: the argmax / next-input launch of a decode step over SLOTS (argmax_embed_slots_kernel)
 struct SlotStepParams {
     const float* logits; int vocab;                    // [n_slots][vocab] (unused when init)

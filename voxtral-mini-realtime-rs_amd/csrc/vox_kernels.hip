@@ -2311,13 +2311,13 @@ hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, cons
 // RoPE (interleaved pairs) + KV store for the multi-row paths
 // ------------------------------------------------------------------------------------------------
 __global__ void rope_kernel(float* __restrict__ buf, int M, int stride, int n_rot, int hd, int pos_off,
-                            const float* __restrict__ cos_t, const float* __restrict__ sin_t, int seq_rows) {
+                            const float* __restrict__ cos_t, const float* __restrict__ sin_t, int seq_rows, const int* __restrict__ row_pos) {
     const int half_cols = n_rot >> 1;
     const long total = (long)M * half_cols;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / half_cols), pc = (int)(i % half_cols);
         const int col = pc * 2, j = (col % hd) >> 1;
-        const size_t ti = (size_t)(pos_off + (seq_rows > 0 ? m % seq_rows : m)) * (hd >> 1) + j;   // stacked sequences restart at 0
+        const size_t ti = (size_t)(pos_off + (row_pos ? row_pos[m] : seq_rows > 0 ? m % seq_rows : m)) * (hd >> 1) + j;   // stacked sequences restart at 0 (row_pos: packed ragged sequences, position per row)
         const float c = cos_t[ti], sn = sin_t[ti];
         float* p = buf + (size_t)m * stride + col;
         const float xr = p[0], xi = p[1];
@@ -2325,10 +2325,10 @@ __global__ void rope_kernel(float* __restrict__ buf, int M, int stride, int n_ro
     }
 }
 hipError_t launch_rope(float* buf, int M, int stride, int n_rot, int hd, int pos_off, const float* cos_t, const float* sin_t,
-                       hipStream_t s, int seq_rows) {
+                       hipStream_t s, int seq_rows, const int* row_pos) {
     const long total = (long)M * (n_rot / 2);
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-    rope_kernel<<<dim3(blocks), dim3(256), 0, s>>>(buf, M, stride, n_rot, hd, pos_off, cos_t, sin_t, seq_rows);
+    rope_kernel<<<dim3(blocks), dim3(256), 0, s>>>(buf, M, stride, n_rot, hd, pos_off, cos_t, sin_t, seq_rows, row_pos);
     return hipGetLastError();
 }
 
@@ -2494,7 +2494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 
     bf16x8 qh[KS], ql[KS];
     {
-        const float* qp = p.q + (size_t)sq * p.q_seq_stride + (size_t)mq * p.q_stride + h * HD + 8 * g;
+        const float* qp = p.q + (p.seq_row_off ? (size_t)p.seq_row_off[sq] * p.q_stride : (size_t)sq * p.q_seq_stride) + (size_t)mq * p.q_stride + h * HD + 8 * g;      // seq_row_off: ragged sequences packed back to back
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const float4 a = *reinterpret_cast<const float4*>(qp + ks * 32), b = *reinterpret_cast<const float4*>(qp + ks * 32 + 4);
@@ -2510,8 +2510,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     int j_lo = 0;
     if (p.window >= 0) j_lo = max(0, p.offset + m0 - p.window);
     const int j_hi = min(kv_len - 1, p.offset + last_m);   // inclusive
-    const float* kbase = p.k + (size_t)sq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
-    const float* vbase = p.v + (size_t)sq * p.kv_seq_stride + (size_t)kvh * p.kv_head_stride;
+    const size_t kvso = p.seq_row_off ? (size_t)p.seq_row_off[sq] * p.kv_row_stride : (size_t)sq * p.kv_seq_stride;
+    const float* kbase = p.k + kvso + (size_t)kvh * p.kv_head_stride;
+    const float* vbase = p.v + kvso + (size_t)kvh * p.kv_head_stride;
 
     // register-staged software pipeline: the global loads of tile t+1 are in flight while tile t is being multiplied
     constexpr int NK = (64 * (HD / 4)) / 256, NV = (32 * (HD / 4)) / 256;
@@ -2621,7 +2622,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
     if (m < M) {
         const float inv = 1.0f / lsum;
-        float* op = p.out + (size_t)sq * p.out_seq_stride + (size_t)m * p.out_stride + h * HD + 4 * g;
+        float* op = p.out + (p.seq_row_off ? (size_t)p.seq_row_off[sq] * p.out_stride : (size_t)sq * p.out_seq_stride) + (size_t)m * p.out_stride + h * HD + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < DT; dt++)
             *reinterpret_cast<float4*>(op + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
@@ -3423,7 +3424,7 @@ __global__ __launch_bounds__(1024) void argmax_embed_batch_kernel(const float* _
                                                                  int tok_stride, int* __restrict__ pos, const int* __restrict__ seq_len, Q4W tok,
                                                                  const float* __restrict__ audio, long audio_seq_stride, int D, float* __restrict__ h,
                                                                  uint16_t* __restrict__ xf, const float* __restrict__ xf_w, float* __restrict__ ssq_out,
-                                                                 long xf_group_stride, int ssq_group_stride) {
+                                                                 long xf_group_stride, int ssq_group_stride, const long* __restrict__ audio_off) {
     __shared__ float bv[1024];
     __shared__ int bi[1024];
     __shared__ int s_tok, s_cur;
@@ -3452,7 +3453,7 @@ __global__ __launch_bounds__(1024) void argmax_embed_batch_kernel(const float* _
         s_cur = cur; s_tok = tokens[(size_t)sq * tok_stride + cur];
     }
     __syncthreads();
-    embed_row(tok, s_tok, audio + (size_t)sq * audio_seq_stride + (size_t)s_cur * D, h + (size_t)sq * D, D);
+    embed_row(tok, s_tok, audio + (audio_off ? (size_t)audio_off[sq] : (size_t)sq * audio_seq_stride) + (size_t)s_cur * D, h + (size_t)sq * D, D);      // audio_off: packed audio rows (no common stride)
     if (xf) {     // the first layer's RMSNorm folded in: XF planes of h * gamma and the row's sum of squares (one partial);
         // sequences are processed in groups of 16 rows, each group with its own XF planes / partial-sum block
         xf += (size_t)(sq >> 4) * xf_group_stride; ssq_out += (size_t)(sq >> 4) * ssq_group_stride;
@@ -3474,9 +3475,9 @@ __global__ __launch_bounds__(1024) void argmax_embed_batch_kernel(const float* _
 }
 hipError_t launch_argmax_embed_batch(const float* logits, int n, int vocab, int* tokens, int tok_stride, int* pos, const int* seq_len, Q4W tok,
                                      const float* audio, long audio_seq_stride, int D, float* h, hipStream_t s,
-                                     uint16_t* xf, const float* xf_w, float* ssq_out, long xf_group_stride, int ssq_group_stride) {
+                                     uint16_t* xf, const float* xf_w, float* ssq_out, long xf_group_stride, int ssq_group_stride, const long* audio_off) {
     argmax_embed_batch_kernel<<<dim3(n), dim3(1024), 0, s>>>(logits, vocab, tokens, tok_stride, pos, seq_len, tok, audio, audio_seq_stride, D, h, xf, xf_w, ssq_out,
-                                                             xf_group_stride, ssq_group_stride);
+                                                             xf_group_stride, ssq_group_stride, audio_off);
     return hipGetLastError();
 }
 
