@@ -290,13 +290,22 @@ def main():
     ctx.synchronize(); torch.cuda.synchronize(); barrier()
     elapsed_local = time.perf_counter() - t0
     elapsed = elapsed_local
-    per_rank_ms = [elapsed_local * 1e3 / max(args.steps, 1)]
+    per_rank_ms = [elapsed_local * 1e3 / max(args.steps, 1)]; per_rank_bcast_s = [bcast_s]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        tt = torch.tensor([elapsed, bcast_s], dtype=torch.float64, device=f"cuda:{local}")
         allt = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
-        per_rank_ms = [float(v.item()) * 1e3 / max(args.steps, 1) for v in allt]
-        elapsed = max(float(v.item()) for v in allt)
+        per_rank_ms = [float(v[0].item()) * 1e3 / max(args.steps, 1) for v in allt]
+        per_rank_bcast_s = [float(v[1].item()) for v in allt]
+        elapsed = max(float(v[0].item()) for v in allt)
+    # what the collective layer actually saw (a line that says how many ranks RCCL had, not only how many were asked for)
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rccl = None
+    dist_info = {"world_size_seen": dist.get_world_size() if world > 1 else 1, "backend": str(dist.get_backend()) if world > 1 else None, "rccl_version": rccl,
+                 "weight_broadcast_s_per_rank": [round(v, 3) for v in per_rank_bcast_s], "broadcast_ordered_by_event": bool(bst.get("ordered_by_event", False)),
+                 "gpus_visible": torch.cuda.device_count()}
     n_ids = int(len(ids))
     steps = max(args.steps, 1)
     for k in stage_ms:
@@ -330,7 +339,7 @@ def main():
             "decode_tok_per_s_ref_def": round(n_ids / (stage_ms["decode_ms"] / 1e3), 2) if stage_ms["decode_ms"] > 0 else None,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
-            "load_s": round(load_s, 2), "weight_broadcast_s": round(bcast_s, 3), "weight_broadcast_bytes": bcast_bytes, "weight_bytes": model.weight_bytes(), "device_memory": model.memory(),
+            "distributed": dist_info, "load_s": round(load_s, 2), "weight_broadcast_s": round(bcast_s, 3), "weight_broadcast_bytes": bcast_bytes, "weight_bytes": model.weight_bytes(), "device_memory": model.memory(),
             "note": "value = ids emitted by all ranks / max-over-ranks wall time of the whole pipeline; decode_tok_per_s_ref_def follows "
                     "bin/e2e_bench.rs:236-240 (ids / decode-stage time); vs_baseline divides by the reference's 19.4 tok/s measured on a DGX Spark GB10",
         }
@@ -400,7 +409,7 @@ def main():
                             "decode_step_ms": round(step_ms, 4),
                             "decode_step_weight_GBps": round(per_step_bytes / 1e9 / (step_ms / 1e3), 1),
                             "decode_step_frac_of_hbm_peak": round(per_step_bytes / 1e9 / (step_ms / 1e3) / HBM_PEAK_GBS, 4),
-                            "decode_layer_engine": bool(eng_on), "engine_launches_per_batch": (eng_n1 - eng_n0) // reps}
+                            "decode_layer_engine": bool(eng_on) and (eng_n1 - eng_n0) > 0, "engine_launches_per_batch": (eng_n1 - eng_n0) // reps}
             for pp in ptrs:
                 ctx.free(pp)
         if world == 1 and not args.no_piecewise:

@@ -79,14 +79,23 @@ def file_costs(paths):
 
 def sharded_lines(pkg, paths, one, rank, world, group=None):
     """N > 1 ranks: every rank transcribes its longest-first share of `paths` with `one(index) -> text`; rank 0 returns every line in input order
-    (None elsewhere).  The only collective is the final gather of the text lines (gloo: no GPU buffer involved)."""
+    (None elsewhere).  The only collective is the final gather of the text lines, and it runs over GLOO whatever the default group is: with `--gguf --gpus N` the
+    default group is RCCL (the start-up weight broadcast), whose object collectives stage through GPU buffers and fall under the NCCL watchdog's 10-minute collective
+    timeout -- a rank that is still transcribing a long share must not be killed by the ranks that wait for it.  A gloo subgroup is created for the gather
+    (every rank calls this function, so every rank takes part in new_group)."""
+    import datetime
     import torch.distributed as dist
     own = not dist.is_initialized()
     if own:
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(hours=12))
+    sub = None
     try:
+        if group is None and not own and dist.get_backend() != "gloo":
+            sub = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=12)); group = sub
         return pkg.shard.run_sharded(list(range(len(paths))), file_costs(paths), one, rank, world, group=group)
     finally:
+        if sub is not None:
+            dist.destroy_process_group(sub)
         if own:
             dist.barrier(); dist.destroy_process_group()
 

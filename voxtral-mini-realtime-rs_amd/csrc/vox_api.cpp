@@ -2364,8 +2364,8 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
 //   (C) one decode step = the same four launches per layer and group as above, reading positions and CACHE SLICES per slot (GemmParams::kv_row, AttnParams::kv_row),
 //       + argmax_embed_slots_kernel, which hands a slot whose utterance just got its last token the next one of its queue in the same launch.  A group retires when its
 //       queues are empty.  Rows are independent of their slot, so the ids per utterance are those of every other path (tests/test_gpu_fullsize.py).
-// Step cost of G lock-step groups in ms (profiles/r04 tools/batch_width_sweep.py: 1.17 / 1.07 / 1.01 ms per group-step at 2 / 3 / 4 groups; one group on the launches 1.70):
-static const double kStepMs[5] = {0.0, 1.70, 2.34, 3.21, 4.04};
+// Step cost of G lock-step groups in ms, measured on the FLEURS-like corpus (profiles/r05_continuous_sweep.txt: decode time net of graph captures / steps; 3 interpolated):
+static const double kStepMs[5] = {0.0, 1.84, 2.08, 2.75, 3.40};
 struct SlotPlan { int G = 0; std::vector<std::vector<int>> queue; std::vector<int> steps_g; double cost_ms = 0.0; };
 // jobs: (decode steps, utterance) with steps >= 1.  LPT onto 16 G slots, slots ordered by load (so the groups retire last to first), G by the cost model.
 static SlotPlan plan_slots(const std::vector<std::pair<int, int>>& jobs_in, int force_G) {
@@ -2636,10 +2636,20 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_samples[a] > n_samples[b]; });
     std::vector<const float*> p_s(n); std::vector<size_t> p_n(n); std::vector<int32_t*> p_o(n); std::vector<int32_t> p_c(n), p_k(n, 0);
     for (int i = 0; i < n; i++) { const int o = order[i]; p_s[i] = samples[o]; p_n[i] = n_samples[o]; p_o[i] = out_ids[o]; p_c[i] = caps[o]; }
-    // <= 16 rows: one group (the batched decode-layer engine).  Wider: continuous batching over slots, in sessions of <= 256 utterances (what bounds the resident K / V:
-    // 54 MB per utterance at 256 positions); VOX_BATCH_NO_CONTINUOUS=1 (or a geometry / checkpoint the XF step does not cover): lock-step batches of <= 64 rows.
+    // <= 16 rows: one group (the batched decode-layer engine).  Wider: continuous batching over slots, in sessions whose resident K / V stays under 64 GB (212 992 B per
+    // position and utterance: 54 MB at 256 positions -> 1 174 utterances; every session pays its own tail and graph captures, so the 647-clip corpus is ONE session);
+    // VOX_BATCH_NO_CONTINUOUS=1 (or a geometry / checkpoint the XF step does not cover): lock-step batches of <= 64 rows.
     const bool cont = n > 16 && batch_xf_ok(m) && !knob_str("VOX_BATCH_NO_CONTINUOUS");
-    const int part_max = cont ? 256 : 64, n_parts = (n + part_max - 1) / part_max;
+    int part_max = 64;
+    if (cont) {
+        const vox_model_cfg& c = m->cfg; vox_pad_cfg pc; vox_pad_cfg_voxtral(&pc);
+        const size_t left = pad_left(&pc), total = left + p_n[0] + pad_right(&pc, p_n[0] + left);      // the longest utterance (rows are sorted) sets max_seq
+        const int Smax = conv_len(conv_len((int)(total / 160))) / c.reshape_factor, max_seq = std::max((Smax + 63) / 64 * 64, 64);
+        const double per_clip = 2.0 * c.dec_layers * (double)c.dec_kv_heads * max_seq * c.dec_head_dim * 4.0;
+        part_max = (int)std::max(64.0, std::min(4096.0, 64e9 / per_clip));
+        if (const char* e = knob_str("VOX_BATCH_SESSION_MAX")) part_max = std::max(17, atoi(e));      // measurement knob
+    }
+    const int n_parts = (n + part_max - 1) / part_max;
     m->batch_sessions = 0; vox_timings acc{}; int32_t r = VOX_OK;
     for (int pi = 0, a = 0; pi < n_parts && r == VOX_OK; pi++) {
         const int b = a + (n - a) / (n_parts - pi);      // equal contiguous parts of the sorted order

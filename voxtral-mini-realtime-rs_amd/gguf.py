@@ -501,8 +501,8 @@ class Q4VoxtralModel:
         return ids[:n.value].copy()
 
     def transcribe_batch(self, samples_list, t_embed, device_ptrs=None, n_samples=None):
-        """Batched whole-path transcription of independent utterances (<= 64): list of float32 sample arrays (or device
-        pointers + lengths) -> list of id arrays.  Decode steps are batched so weights stream once per step."""
+        """Batched whole-path transcription of independent utterances (<= 4096; wider than 16: continuous batching over decode slots): list of float32 sample arrays
+        (or device pointers + lengths) -> list of id arrays.  Decode steps are batched so weights stream once per step."""
         t = _f32(t_embed).reshape(-1)
         if device_ptrs is None:
             arrs = [_f32(x) for x in samples_list]; n = len(arrs)

@@ -113,7 +113,19 @@ def load_replicated(pkg, ctx, path, rank: int, world: int, local: int | None = N
     model = loader.load(ctx, layout_only=(rank != 0))
     ptr, nbytes = model.arena()
     t = (as_tensor or (lambda p, n: _arena_tensor(p, n, local)))(ptr, nbytes)
-    ctx.synchronize()                      # rank 0's uploads / repack kernels ran on the library's stream; the collective runs on torch's
+    # rank 0's uploads / repack kernels ran on the LIBRARY's stream, the collective runs on torch's current stream: order the two on the device (torch's stream waits
+    # for an event recorded on the library's stream, wrapped as an ExternalStream) instead of blocking the host on the whole context; a host synchronisation remains
+    # only where there is no device stream to order against (the CPU / gloo test of this protocol)
+    ordered = False
+    if getattr(t, "is_cuda", False) and hasattr(ctx, "stream"):
+        try:
+            import torch
+            ext = torch.cuda.ExternalStream(int(ctx.stream()), device=t.device)
+            torch.cuda.current_stream(t.device).wait_stream(ext); ordered = True
+        except Exception:
+            ordered = False
+    if not ordered:
+        ctx.synchronize()
     t0 = time.time()
     dist.broadcast(t, src=0, group=group)
     if t.is_cuda:
@@ -123,7 +135,7 @@ def load_replicated(pkg, ctx, path, rank: int, world: int, local: int | None = N
     if rank != 0:
         model.arena_finalize()
     if stats is not None:
-        stats.update(bytes=int(nbytes), seconds=dt, broadcast=True)
+        stats.update(bytes=int(nbytes), seconds=dt, broadcast=True, ordered_by_event=ordered, world_size=dist.get_world_size(group), backend=str(dist.get_backend(group)))
     return model
 
 

@@ -177,7 +177,7 @@ def main(argv=None):
     ap.add_argument("--manifest", required=True); ap.add_argument("--dataset", default="manifest")
     ap.add_argument("--gguf"); ap.add_argument("--model"); ap.add_argument("--tokenizer")
     ap.add_argument("--delay", type=int, default=6); ap.add_argument("--output"); ap.add_argument("--limit", type=int)
-    ap.add_argument("--batch", type=int, default=16); ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=1024); ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--gpus", type=int, default=1, help="shard the corpus over N GPUs (cli --gpus N: one process per GPU, transcriptions gathered in corpus order)")
     a = ap.parse_args(argv)
     if not a.gguf and not a.model:
