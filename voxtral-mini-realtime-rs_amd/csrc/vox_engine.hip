@@ -105,7 +105,6 @@ static_assert(L_XS % 16 == 0 && L_XA % 16 == 0 && L_QKVN % 16 == 0 && L_PO % 16 
 
 // ONE rolled loop over the step's packets (the kernel's code must stay small: the instruction cache is shared by two CUs and every layer walks
 // through all three roles' code -- a 100 KB kernel ran 13 % slower than a 68 KB one with the same structure)
-constexpr int ENGF_LM_DMA2 = 131072;      // flags: lm_head phase -- the COMM wave is a second LDS-DMA wave (eng_loader_lm_odd)
 __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsigned ring_lds, int lane, const Tl& tl) {
     Loader<EngCtl, NSLOT> ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = (p.flags & 1) != 0; ld.pace = (u64)p.pace_ticks;
     const bool fake = (p.flags & 2) != 0;      // diagnostic: every packet re-reads one packet (L2 hits, no HBM traffic; results wrong)
@@ -115,7 +114,6 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
     if (p.flags & 2048) ld.depth = 1;
     const u64 base = (u64)p.stream;
     const unsigned n_layer_pk = (unsigned)p.n_layers * PK_LAYER, n_pk = n_layer_pk + (unsigned)lm_packets(p.vocab);
-    const bool dual = (p.flags & ENGF_LM_DMA2) != 0 && (n_layer_pk % 2u) == 0u;      // lm_head phase: the COMM wave streams the odd packets (eng_loader_lm_odd)
     unsigned l = 0, r = 0;                       // layer, packet within the layer
     u64 off = 0;                                 // byte offset of the next packet in this CU's stream (packets are stored in consumption order)
 #pragma unroll 1
@@ -124,10 +122,7 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
         if (pk < n_layer_pk) {
             if (r < PK_LAYER_M) bytes = PK_M;
             if (r == 0 && (int)l == p.tl_layer) tl(16);
-        } else {
-            ld.pace = 0; ld.pause_ticks = 0; ld.depth = 3;      // no edge left to protect: the lm_head streams at full depth
-            if (dual) { if ((pk - n_layer_pk) & 1u) { off += (u64)bytes; continue; } ld.P = pk; }      // (ring slot and fill count follow from the packet index: ld.P is set per packet)
-        }
+        } else { ld.pace = 0; ld.pause_ticks = 0; ld.depth = 3; }      // no edge left to protect: the lm_head streams at full depth
         const u64 src = fake ? base + (u64)blockIdx.x * PK_A : base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes;
         if (bytes == PK_M) ld.issue<PK_M>(src, lane, nodma); else ld.issue<PK_A>(src, lane, nodma);
         off += (u64)bytes;
@@ -137,25 +132,6 @@ __device__ __forceinline__ void eng_loader(const EngParams& p, EngCtl* c, unsign
     tl(18);
 }
 
-
-// lm_head phase, flag ENGF_LM_DMA2: a SECOND LDS-DMA wave.  The phase is pure streaming (885 KB per CU, no edge left) and one wave can keep at most 63 one-KiB lines in
-// flight (the 6-bit vmcnt): 62 KB per CU at ~2.5 us of latency = 5.3 TB/s over the chip (44 of the step's 600 us).  The COMM wave has nothing left to do once the final
-// all-gather is out, so it takes the ODD packets of the phase (the loader keeps the even ones): with an even number of layer packets and an even ring the two waves
-// own disjoint ring slots -- each slot's ready counter still has ONE writer -- and each wave counts its own vmcnt.  Inside the layers a second DMA wave lost (round 4:
-// DMA traffic next to an edge costs the edge more than the look-ahead returns), hence gated by phase.
-__device__ __forceinline__ void eng_loader_lm_odd(const EngParams& p, EngCtl* c, unsigned ring_lds, int lane) {
-    const unsigned n_layer_pk = (unsigned)p.n_layers * PK_LAYER, n_lm = (unsigned)lm_packets(p.vocab);
-    if (!(p.flags & ENGF_LM_DMA2) || (n_layer_pk % 2u) != 0u || (p.flags & 2)) return;
-    Loader<EngCtl, NSLOT> ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = false; ld.pace = 0; ld.depth = 3;
-    const bool nodma = false;
-    const u64 base = (u64)p.stream + (u64)NCU * ((u64)p.n_layers * LAYER_BYTES) + (u64)blockIdx.x * (u64)PK_A;
-#pragma unroll 1
-    for (unsigned i = 1; i < n_lm; i += 2) {
-        ld.P = n_layer_pk + i;
-        ld.issue<PK_A>(base + (u64)NCU * ((u64)i * PK_A), lane, nodma);
-    }
-    ld.flush();
-}
 
 // All-gather of a staged activation vector: the owners publish their 12 rows ALREADY multiplied by the consumer's norm weight (* Ada scale) * 512,
 // plus one partial sum of squares per CU, so the sweep is granules -> LDS with no other memory operand (the per-layer norm vectors take microseconds to
@@ -953,7 +929,6 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_kernel(const EngParams 
         __builtin_amdgcn_s_setprio(ENG_PRIO_COMM);
 #endif
         if (ENG_ROLES & 2) eng_comm(p, c, lds, lane, tl);
-        if ((ENG_ROLES & 3) == 3) eng_loader_lm_odd(p, c, (unsigned)(uintptr_t)(lds + L_RING), lane);
         // the last workgroup-independent act of the launch: bump the serial (every workgroup has read it long before any lm_head input existed)
         if (blockIdx.x == 0 && lane == 0) {
             const unsigned sv = *p.serial; asm volatile("" ::: "memory"); *p.serial = sv + 1u;
