@@ -53,6 +53,7 @@ def build_all(verbose: bool = False, force: bool = False, tag: str | None = None
 
 
 VARIANTS = {"timeline": ["-DVOX_TIMELINE"],      # measurement builds (tools/timeline.py)
+            "gemm_oldstage": ["-DVOX_GEMM_OLD_STAGING"],      # q4_gemm_kernel with the pre-round-5 LDS staging map (16-way bank conflicts on the writes): same-box A/B
             # GEMV ablations (tools/gemv_ablate.py; results are wrong by construction, only the timing is read)
             "abl_noscale": ["-DVOX_ABL_NOSCALE"], "abl_nox": ["-DVOX_ABL_NOX"], "abl_wfirst": ["-DVOX_ABL_WFIRST"],      # (abl_wfirst predates the x-first default and is a no-op now)
             "abl_noconsume": ["-DVOX_ABL_NOCONSUME"], "abl_xfirst_resid": ["-DVOX_ABL_XFIRST_RESID_ONLY"], "abl_xfirst_noswiglu": ["-DVOX_ABL_XFIRST_NO_SWIGLU"], "abl_noreduce": ["-DVOX_ABL_NOREDUCE"],

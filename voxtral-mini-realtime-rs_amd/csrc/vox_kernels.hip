@@ -936,20 +936,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     const int m0 = blockIdx.y * (16 * MT), n0 = blockIdx.x * (64 * NT);
     const int KSP = p.ksplit > 1 ? p.ksplit : 1, kz = blockIdx.z;                               // split-K: this workgroup's K steps [qb, qe)
     const int qb = (int)((long)nq * kz / KSP), qe = (int)((long)nq * (kz + 1) / KSP);
-    // staging role: fragment f = tid + 256*i -> (row sm = 16 (f>>8) + (f&15), block j = (f>>6)&3, group g = (f>>4)&3): the 64 lanes of a wave write 64 CONSECUTIVE
-    // 16-byte slots per plane (slot = base + lane).  Until round 5 the map was (sm = f>>4, j = (f>>2)&3, g = f&3): the 16 lanes of a row group then wrote slots 16 and
-    // 128 apart -- the same four banks, a 16-way conflict on every ds_write_b128 (PMC, profiles/r04_pmc_batch16.txt: 11 conflict cycles per LDS instruction, 10 % of the
-    // kernel waiting on LDS).  Same fragments, same values, same order of arithmetic.
+    // staging role: fragment f = tid + 256*i -> (row sm = f>>4, block j = (f>>2)&3, group g = f&3): the 16 lanes of a row group read 256 contiguous bytes of their row.
+    // Round 5: fragment (g, m) of block j lives at slot g*16 + (m ^ (4j + g)) of its (j, m-tile) block instead of g*16 + m -- the 16 writers of a row (same m, all (j, g))
+    // used to hit slots 16 and 128 apart = the same four banks, a 16-way conflict on every ds_write_b128 (PMC: 11 conflict cycles per LDS instruction); XOR-ed with 16
+    // distinct values they cover all 64 banks, and the readers (lane (g, m) reads its own permuted slot) still sweep 16 consecutive 16-byte slots per lane group.
+    // (Remapping the THREADS to consecutive slots instead -- 16 rows per load instruction -- removed the conflicts too and was 3 % slower: profiles/r05_gemm_staging_ab.txt.)
     const float* xrow[MT]; int slot[MT], xo_a[MT], xo_b[MT];
 #pragma unroll
     for (int i = 0; i < MT; i++) {
-        const int f = tid + 256 * i, sm = 16 * (f >> 8) + (f & 15), j = (f >> 6) & 3, g = (f >> 4) & 3;
+        const int f = tid + 256 * i, sm = f >> 4, j = (f >> 2) & 3, g = f & 3;
         xrow[i] = p.x + (size_t)min(m0 + sm, M - 1) * p.x_stride;
+#ifdef VOX_GEMM_OLD_STAGING      /* measurement build (build.py gemm_oldstage): the pre-round-5 layout, for the same-box A/B in profiles/r05_gemm_staging_ab.txt */
         slot[i] = (j * MT + (sm >> 4)) * 64 + g * 16 + (sm & 15);
+#else
+        slot[i] = (j * MT + (sm >> 4)) * 64 + g * 16 + ((sm & 15) ^ (4 * j + g));
+#endif
         xo_a[i] = 32 * j + (FMT == WFMT_Q4_0 ? 4 * g : 8 * g); xo_b[i] = 32 * j + (FMT == WFMT_Q4_0 ? 16 + 4 * g : 8 * g + 4);
     }
     // MFMA role
     const int wg = lane >> 4;
+    int rdl[4];      // where this lane's A fragment of block j sits inside its 64-slot block (see the staging map)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#ifdef VOX_GEMM_OLD_STAGING
+        rdl[j] = lane;
+#else
+        rdl[j] = (lane & 48) | ((lane & 15) ^ (4 * j + wg));
+#endif
+    }
     const uint32_t* wq[NT]; const uint16_t* ws[NT]; const uint4* wd16[NT]; const uint4* wqt[NT]; int wn[NT]; bool wok[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -1022,8 +1036,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
                 }
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
-                    const bf16x8 ah = as_bf16x8(glds[buf * BUF + (j * MT + i) * 64 + lane]);
-                    const bf16x8 al = as_bf16x8(glds[buf * BUF + PLANE + (j * MT + i) * 64 + lane]);
+                    const bf16x8 ah = as_bf16x8(glds[buf * BUF + (j * MT + i) * 64 + rdl[j]]);
+                    const bf16x8 al = as_bf16x8(glds[buf * BUF + PLANE + (j * MT + i) * 64 + rdl[j]]);
                     f32x4 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bw, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw, tt, 0, 0, 0);
                     acc[t][i][0] = fmaf(d, tt[0], acc[t][i][0]); acc[t][i][1] = fmaf(d, tt[1], acc[t][i][1]);
