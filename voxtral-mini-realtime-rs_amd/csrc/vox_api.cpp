@@ -2417,10 +2417,12 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     // the stacked encoder runs in chunks of <= 64 utterances, PACKED (encode_batch_dev: every utterance its own rows, no padding to the longest): the audio rows of
     // utterance i start audio_off[i] floats into the audio buffer
     const int n_chunks = (n + CHUNK - 1) / CHUNK;
+    std::vector<int> chunk0(n_chunks + 1, 0);      // balanced: 81 utterances run as 41 + 40, not 64 + 17 (a 17-row stack runs its GEMMs at a fraction of a 41-row stack's rate)
+    for (int ci = 0; ci < n_chunks; ci++) chunk0[ci + 1] = chunk0[ci] + (n - chunk0[ci]) / (n_chunks - ci);
     std::vector<size_t> aoff_c(n_chunks); std::vector<long> audio_off(n);
     size_t audio_floats = 0, mel_max = 0, smp_max = 0;
     for (int ci = 0; ci < n_chunks; ci++) {
-        const int c0 = ci * CHUNK, nc = std::min(CHUNK, n - c0);
+        const int c0 = chunk0[ci], nc = chunk0[ci + 1] - c0;
         aoff_c[ci] = audio_floats;
         size_t mf = 0, sf = 0; long rows = 0;
         for (int i = c0; i < c0 + nc; i++) { audio_off[i] = (long)(aoff_c[ci] + (size_t)(rows / R) * D); rows += enc_packed_rows_of(m, T[i]); mf += (size_t)128 * T[i]; sf += n_samples[i]; }
@@ -2460,7 +2462,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     // ---- (A) front-end, stacked encoder and stacked 38-token prefill, chunk by chunk
     double pre_ms = 0.0, enc_ms = 0.0, pf_ms = 0.0; const double t0 = now_ms();
     for (int ci = 0; ci < n_chunks; ci++) {
-        const int c0 = ci * CHUNK, nc = std::min(CHUNK, n - c0);
+        const int c0 = chunk0[ci], nc = chunk0[ci + 1] - c0;
         const double ta = now_ms();
         std::vector<const float*> d_mels(nc);
         size_t mo = 0, so = 0;
@@ -2505,8 +2507,10 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         HIPCHK(hipMemsetAsync(b_xf1.p, 0, xf_bytes(D) * G, s)); HIPCHK(hipMemsetAsync(b_xf2.p, 0, xf_bytes(QD) * G, s)); HIPCHK(hipMemsetAsync(b_xf3.p, 0, xf_bytes(F) * G, s));
         HIPCHK(hipMemsetAsync(b_ssq.p, 0, (size_t)parts_D * 16 * 4 * G, s)); HIPCHK(hipMemsetAsync(b_h.p, 0, (size_t)Sl * D * 4, s)); HIPCHK(hipMemsetAsync(b_qkv.p, 0, (size_t)Sl * W * 4, s));
         // the scratch cache slice (index n of every layer): zeros, so that an idle slot's attention stays finite
-        HIPCHK(hipMemset2DAsync(b_k.as<float>() + (size_t)n * seq_stride, layer_stride * 4, 0, seq_stride * 4, c.dec_layers, s));
-        HIPCHK(hipMemset2DAsync(b_v.as<float>() + (size_t)n * seq_stride, layer_stride * 4, 0, seq_stride * 4, c.dec_layers, s));
+        for (int l = 0; l < c.dec_layers; l++) {      // (one memset per layer: the pitch of a 2-D memset would be the layer stride -- tens of GB for a corpus-sized session)
+            HIPCHK(hipMemsetAsync(b_k.as<float>() + (size_t)l * layer_stride + (size_t)n * seq_stride, 0, seq_stride * 4, s));
+            HIPCHK(hipMemsetAsync(b_v.as<float>() + (size_t)l * layer_stride + (size_t)n * seq_stride, 0, seq_stride * 4, s));
+        }
         HIPCHK(hipMemcpyAsync(b_queue.p, h_queue.data(), h_queue.size() * 4, hipMemcpyHostToDevice, s));
         int* d_pos = b_pos.as<int>(); int* d_kvrow = b_kvrow.as<int>();
         SlotStepParams sp{};
