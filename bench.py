@@ -193,6 +193,8 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
         # longest-first share serially, time each; predicted_scaling = T(all clips on one rank) / max_r T(share r).  The start-up broadcast (primary arena over
         # xGMI) is reported beside it, not folded in: it is paid once per process, not per corpus.
         sparts = shard.lpt_partition(durs, simulate_world); per = []
+        for grp in shard.length_buckets(sparts[0], durs, batch):      # untimed warm-up at a share's size (workspace pool; the real N-GPU run warms up the same way above)
+            batch_work(grp)
         for r in range(simulate_world):
             ctx.synchronize(); t1 = time.perf_counter()
             for grp in shard.length_buckets(sparts[r], durs, batch):

@@ -2417,8 +2417,8 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     // the stacked encoder runs in chunks of <= 64 utterances, PACKED (encode_batch_dev: every utterance its own rows, no padding to the longest): the audio rows of
     // utterance i start audio_off[i] floats into the audio buffer
     const int n_chunks = (n + CHUNK - 1) / CHUNK;
-    std::vector<int> chunk0(n_chunks + 1, 0);      // balanced: 81 utterances run as 41 + 40, not 64 + 17 (a 17-row stack runs its GEMMs at a fraction of a 41-row stack's rate)
-    for (int ci = 0; ci < n_chunks; ci++) chunk0[ci + 1] = chunk0[ci] + (n - chunk0[ci]) / (n_chunks - ci);
+    std::vector<int> chunk0(n_chunks + 1, 0);      // full chunks first (81 utterances = 64 + 17: measured against 41 + 40 the packed encoder costs the same, 247 ms, the stacked prefill 57 instead of 66 ms)
+    for (int ci = 0; ci < n_chunks; ci++) chunk0[ci + 1] = std::min(n, chunk0[ci] + CHUNK);
     std::vector<size_t> aoff_c(n_chunks); std::vector<long> audio_off(n);
     size_t audio_floats = 0, mel_max = 0, smp_max = 0;
     for (int ci = 0; ci < n_chunks; ci++) {
@@ -2457,6 +2457,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         for (int i = 0; i < n; i++) { prefix[(size_t)i * tstride] = BOS; for (int r = 1; r < PREFIX_LEN; r++) prefix[(size_t)i * tstride + r] = STREAMING_PAD; }
         HIPCHK(hipMemcpyAsync(d_tok, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_posc.p, pos0.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(b_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_aoff.p, audio_off.data(), (size_t)n * sizeof(long), hipMemcpyHostToDevice, s));
+        HIPCHK(b_queue.alloc_pooled(cx, h_queue.size() * 4)); HIPCHK(hipMemcpyAsync(b_queue.p, h_queue.data(), h_queue.size() * 4, hipMemcpyHostToDevice, s));      // (the slot queues too: no pageable copy may sit behind phase A)
         HIPCHK(hipStreamSynchronize(s));      // the host vectors go out of scope
     }
     // ---- (A) front-end, stacked encoder and stacked 38-token prefill, chunk by chunk
@@ -2490,16 +2491,20 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         { GemmParams g{}; g.w = m->tok.w; g.x = b_xn.as<float>(); g.x_stride = D; g.M = nc; g.out = b_lg0.as<float>(); g.out_stride = V; HIPCHK(launch_q4_gemm(g, EPI_STORE, s)); }
         HIPCHK(launch_argmax_embed_batch(b_lg0.as<float>(), nc, V, d_tok + (size_t)c0 * tstride, tstride, b_posc.as<int>() + c0, b_len.as<int>() + c0, m->tok.w, d_audio, 0, D,
                                          b_h0.as<float>() + (size_t)c0 * D, s, nullptr, nullptr, nullptr, 0, 0, b_aoff.as<long>() + c0));
-        HIPCHK(hipStreamSynchronize(s)); const double td = now_ms();
+        // (the last chunk's prefill is not waited for here when a decode follows: the decode's buffers are set up and its graphs captured -- host work, ~6-10 ms per
+        // distinct set of active groups -- while the GPU is still busy with it; the prefill timer closes behind that)
+        const bool defer = ci == n_chunks - 1 && steps > 0;
+        if (!defer) HIPCHK(hipStreamSynchronize(s));
+        const double td = now_ms();
         pre_ms += tb - ta; enc_ms += tc - tb; pf_ms += td - tc;
     }
-    const double t1 = now_ms();
+    double t1 = now_ms();
     // ---- (B) + (C): the slot decode
     int replays = 0, n_captures = 0; double capture_ms = 0.0;
     if (steps > 0) {
         auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
         const int parts_D = q4_skinny_resid_xf_parts(D);
-        HIPCHK(b_queue.alloc_pooled(cx, h_queue.size() * 4)); HIPCHK(b_sclip.alloc_pooled(cx, (size_t)Sl * 4)); HIPCHK(b_sqpos.alloc_pooled(cx, (size_t)Sl * 4));
+        HIPCHK(b_sclip.alloc_pooled(cx, (size_t)Sl * 4)); HIPCHK(b_sqpos.alloc_pooled(cx, (size_t)Sl * 4));
         HIPCHK(b_pos.alloc_pooled(cx, (size_t)Sl * 4)); HIPCHK(b_kvrow.alloc_pooled(cx, (size_t)Sl * 4)); HIPCHK(b_h.alloc_pooled(cx, (size_t)Sl * D * 4));
         HIPCHK(b_qkv.alloc_pooled(cx, (size_t)Sl * W * 4)); HIPCHK(b_att.alloc_pooled(cx, (size_t)Sl * QD * 4)); HIPCHK(b_logits.alloc_pooled(cx, (size_t)Sl * V * 4));
         HIPCHK(b_xf1.alloc_pooled(cx, xf_bytes(D) * G)); HIPCHK(b_xf2.alloc_pooled(cx, xf_bytes(QD) * G)); HIPCHK(b_xf3.alloc_pooled(cx, xf_bytes(F) * G));
@@ -2511,7 +2516,6 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             HIPCHK(hipMemsetAsync(b_k.as<float>() + (size_t)l * layer_stride + (size_t)n * seq_stride, 0, seq_stride * 4, s));
             HIPCHK(hipMemsetAsync(b_v.as<float>() + (size_t)l * layer_stride + (size_t)n * seq_stride, 0, seq_stride * 4, s));
         }
-        HIPCHK(hipMemcpyAsync(b_queue.p, h_queue.data(), h_queue.size() * 4, hipMemcpyHostToDevice, s));
         int* d_pos = b_pos.as<int>(); int* d_kvrow = b_kvrow.as<int>();
         SlotStepParams sp{};
         sp.logits = b_logits.as<float>(); sp.vocab = V; sp.tokens = d_tok; sp.tok_stride = tstride; sp.clip_len = b_len.as<int>();
@@ -2584,26 +2588,40 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             hipGraphExec_t find(uint32_t a) const { for (auto& e : ex) if (e.first == a) return e.second; return nullptr; }
         } graphs; graphs.s = s; graphs.cx = cx;
         const bool no_graph = knob_str("VOX_BATCH_NO_GRAPH") != nullptr;
-        for (int t = 0; t < steps; t++) {
-            const uint32_t act = active_at(t);
-            if (t == 0 || no_graph) { VOXCHK(step(act)); continue; }
-            hipGraphExec_t ge = graphs.find(act);
-            if (!ge) {
-                HIPCHK(hipStreamSynchronize(s));
-                const double tg = now_ms();
-                HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                const int32_t r = step(act);
-                hipGraph_t graph = nullptr;
-                const hipError_t ce = hipStreamEndCapture(s, &graph);
-                if (graph) graphs.gr.push_back(graph);
-                if (r != VOX_OK) return r;
-                HIPCHK(ce);
-                const hipError_t ie = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
-                if (ie != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
-                graphs.ex.emplace_back(act, ge);
-                capture_ms += now_ms() - tg; n_captures++;
+        // the step's kernels raise their dynamic-LDS limits at their first launch (hipFuncSetAttribute: not something to do inside a capture): the first continuous batch
+        // of a process runs its first step eagerly, every later one replays graphs from step 0 on
+        static bool step_kernels_warm = false;
+        int t_start = 0;
+        if (!step_kernels_warm && !no_graph) { VOXCHK(step(active_at(0))); step_kernels_warm = true; t_start = 1; }
+        auto capture = [&](uint32_t act, hipGraphExec_t* out) -> int32_t {
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int32_t r = step(act);
+            hipGraph_t graph = nullptr;
+            const hipError_t ce = hipStreamEndCapture(s, &graph);
+            if (graph) graphs.gr.push_back(graph);
+            if (r != VOX_OK) return r;
+            HIPCHK(ce);
+            const hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+            if (ie != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+            return VOX_OK;
+        };
+        if (!no_graph) {      // one graph per distinct set of active groups, captured NOW: the stream still holds the last chunk's prefill, the GPU is busy while the host records
+            const double tg = now_ms();
+            for (int t = t_start; t < steps; t++) {
+                const uint32_t act = active_at(t);
+                if (graphs.find(act)) continue;
+                hipGraphExec_t ge = nullptr;
+                VOXCHK(capture(act, &ge));
+                graphs.ex.emplace_back(act, ge); n_captures++;
             }
-            if (hipGraphLaunch(ge, s) != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphLaunch failed");
+            capture_ms = now_ms() - tg;
+        }
+        HIPCHK(hipStreamSynchronize(s));      // phase A (and the set-up behind it) is done: the prefill timer closes here, the decode timer starts
+        { const double tn = now_ms(); pf_ms += tn - t1; t1 = tn; }
+        for (int t = t_start; t < steps; t++) {
+            const uint32_t act = active_at(t);
+            if (no_graph) { VOXCHK(step(act)); continue; }
+            if (hipGraphLaunch(graphs.find(act), s) != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphLaunch failed");
             replays++;
         }
         HIPCHK(hipStreamSynchronize(s));
@@ -2619,7 +2637,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     }
     m->timings.preprocess_ms = pre_ms; m->timings.encode_ms = enc_ms; m->timings.decode_ms = pf_ms + (now_ms() - t1); m->timings.total_ms = now_ms() - t0;
     m->timings.decode_tokens = total; m->timings.graph_replays = replays;
-    if (knob_str("VOX_BATCH_VERBOSE")) fprintf(stderr, "[voxtral_hip] continuous batch: %d utterances, %d slots, %d steps (plan %.1f ms), front-end %.1f ms, encode %.1f ms (%d chunks), prefill %.1f ms, decode %.1f ms of which %d graph captures %.1f ms\n", n, Sl, steps, plan.cost_ms, pre_ms, enc_ms, n_chunks, pf_ms, now_ms() - t1, n_captures, capture_ms);
+    if (knob_str("VOX_BATCH_VERBOSE")) fprintf(stderr, "[voxtral_hip] continuous batch: %d utterances, %d slots, %d steps (plan %.1f ms), front-end %.1f ms, encode %.1f ms (%d chunks), prefill %.1f ms (%d graph captures, %.1f ms of host time, under the last chunk's), decode %.1f ms\n", n, Sl, steps, plan.cost_ms, pre_ms, enc_ms, n_chunks, pf_ms, n_captures, capture_ms, now_ms() - t1);
     return VOX_OK;
 }
 
