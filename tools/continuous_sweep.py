@@ -37,14 +37,17 @@ def report(tag, idx, bucket):
 
 
 share = parts[0]
-os.environ["VOX_BATCH_NO_CONTINUOUS"] = "1"
-t_lock = report("rank share, lock-step 64-clip buckets (round 4)", share, 64)
-t_all_lock = report("whole corpus, lock-step 64-clip buckets (round 4)", list(range(n_clips)), 64)
-del os.environ["VOX_BATCH_NO_CONTINUOUS"]
-for G in (1, 2, 3, 4):
-    os.environ["VOX_BATCH_SLOT_GROUPS"] = str(G)
-    report(f"rank share, continuous, {G} slot group(s) forced", share, 4096)
-del os.environ["VOX_BATCH_SLOT_GROUPS"]
+quick = bool(os.environ.get("VOX_SWEEP_QUICK"))      # only the planner's-choice lines (A/B of a knob, e.g. VOX_BATCH_CHUNK)
+t_lock = t_all_lock = float("nan")
+if not quick:
+    os.environ["VOX_BATCH_NO_CONTINUOUS"] = "1"
+    t_lock = report("rank share, lock-step 64-clip buckets (round 4)", share, 64)
+    t_all_lock = report("whole corpus, lock-step 64-clip buckets (round 4)", list(range(n_clips)), 64)
+    del os.environ["VOX_BATCH_NO_CONTINUOUS"]
+    for G in (1, 2, 3, 4):
+        os.environ["VOX_BATCH_SLOT_GROUPS"] = str(G)
+        report(f"rank share, continuous, {G} slot group(s) forced", share, 4096)
+    del os.environ["VOX_BATCH_SLOT_GROUPS"]
 t_cont = report("rank share, continuous, planner's choice", share, 4096)
 t_all = report("whole corpus, continuous, planner's choice", list(range(n_clips)), 4096)
 per = []

@@ -1356,7 +1356,7 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     const int D = c.enc_dim, H = c.enc_heads, hd = c.enc_head_dim, QD = H * hd, F = c.enc_ffn, R = c.reshape_factor;
     const bool packed = audio_off_out != nullptr;
-    ARGCHK(!packed || n <= 64, "internal: packed encoder stack of %d utterances", n);
+    ARGCHK(n <= 128, "internal: encoder stack of %d utterances", n);
     const int S_pad = enc_row_budget(m, T, n);
     int T1max = 0; bool any = false;
     std::vector<int> S(n);
@@ -1392,13 +1392,13 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
     if (n > 1 || packed) {
         HIPCHK(hipMemsetAsync(x, 0, (size_t)Mtot * D * 4, s));               // scratch rows: finite values
         HIPCHK(hipMemsetAsync(att, 0, (size_t)Mtot * QD * 4, s));            // rows >= seq_len[i] are never written by attention
-        if (!m->d_seq_len) HIPCHK(hipMalloc((void**)&m->d_seq_len, 64 * sizeof(int)));
+        if (!m->d_seq_len) HIPCHK(hipMalloc((void**)&m->d_seq_len, 128 * sizeof(int)));
         m->h_seq_len.assign(S.begin(), S.end());
         HIPCHK(hipMemcpyAsync(m->d_seq_len, m->h_seq_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         d_len = m->d_seq_len;
     }
     if (packed) {      // start rows and the position of every row (host-built, uploaded behind the stream; the host vectors are model members: they outlive the copies)
-        if (!m->d_seq_off) HIPCHK(hipMalloc((void**)&m->d_seq_off, 64 * sizeof(int)));
+        if (!m->d_seq_off) HIPCHK(hipMalloc((void**)&m->d_seq_off, 128 * sizeof(int)));
         if (m->row_pos_cap < (size_t)Mtot) { if (m->d_row_pos) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(m->d_row_pos)); } m->d_row_pos = nullptr; m->row_pos_cap = 0;
                                               HIPCHK(hipMalloc((void**)&m->d_row_pos, (size_t)Mtot * sizeof(int))); m->row_pos_cap = (size_t)Mtot; }
         HIPCHK(hipStreamSynchronize(s));      // (the previous stack's copies out of these host vectors have completed)
@@ -2396,7 +2396,8 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
-    const int PREFIX_LEN = 38, BOS = 1, STREAMING_PAD = 32, CHUNK = 64;
+    const int PREFIX_LEN = 38, BOS = 1, STREAMING_PAD = 32;
+    int CHUNK = 128; if (const char* e = knob_str("VOX_BATCH_CHUNK")) CHUNK = std::max(1, std::min(128, atoi(e)));      // utterances per encoder / prefill stack (measurement knob; 64 until the round-5 sweep)
     const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, W = QD + 2 * KD, F = c.dec_ffn, V = c.vocab, R = c.reshape_factor;
     VOXCHK(vox_model_set_t_embed(m, t_embed));
     m->timings = vox_timings{};
@@ -2414,10 +2415,10 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     ARGCHK(Smax <= m->dec_rope_len, "sequence too long for the decoder RoPE table");
     const int max_seq = std::max((Smax + 63) / 64 * 64, 64), tstride = std::max(Smax, PREFIX_LEN) + 2;
     const size_t seq_stride = (size_t)KV * max_seq * hd, layer_stride = (size_t)(n + 1) * seq_stride;      // slice n of every layer: the scratch slice idle slots write to and read
-    // the stacked encoder runs in chunks of <= 64 utterances, PACKED (encode_batch_dev: every utterance its own rows, no padding to the longest): the audio rows of
+    // the stacked encoder runs in chunks of <= 128 utterances, PACKED (encode_batch_dev: every utterance its own rows, no padding to the longest): the audio rows of
     // utterance i start audio_off[i] floats into the audio buffer
     const int n_chunks = (n + CHUNK - 1) / CHUNK;
-    std::vector<int> chunk0(n_chunks + 1, 0);      // full chunks first (81 utterances = 64 + 17: measured against 41 + 40 the packed encoder costs the same, 247 ms, the stacked prefill 57 instead of 66 ms)
+    std::vector<int> chunk0(n_chunks + 1, 0);      // full chunks first (measured on 81 utterances: 64 + 17 against 41 + 40 -- the packed encoder costs the same, 247 ms, the stacked prefill 57 instead of 66 ms)
     for (int ci = 0; ci < n_chunks; ci++) chunk0[ci + 1] = std::min(n, chunk0[ci] + CHUNK);
     std::vector<size_t> aoff_c(n_chunks); std::vector<long> audio_off(n);
     size_t audio_floats = 0, mel_max = 0, smp_max = 0;
