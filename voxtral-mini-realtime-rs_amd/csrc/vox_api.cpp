@@ -2397,7 +2397,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
     const int PREFIX_LEN = 38, BOS = 1, STREAMING_PAD = 32;
-    int CHUNK = 128; if (const char* e = knob_str("VOX_BATCH_CHUNK")) CHUNK = std::max(1, std::min(128, atoi(e)));      // utterances per encoder / prefill stack (measurement knob; 64 until the round-5 sweep)
+    int CHUNK = 64; if (const char* e = knob_str("VOX_BATCH_CHUNK")) CHUNK = std::max(1, std::min(128, atoi(e)));      // utterances per encoder / prefill stack (measurement knob: 128 measured equal to 64, profiles/r05_continuous_sweep.txt)
     const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, W = QD + 2 * KD, F = c.dec_ffn, V = c.vocab, R = c.reshape_factor;
     VOXCHK(vox_model_set_t_embed(m, t_embed));
     m->timings = vox_timings{};
@@ -2415,7 +2415,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     ARGCHK(Smax <= m->dec_rope_len, "sequence too long for the decoder RoPE table");
     const int max_seq = std::max((Smax + 63) / 64 * 64, 64), tstride = std::max(Smax, PREFIX_LEN) + 2;
     const size_t seq_stride = (size_t)KV * max_seq * hd, layer_stride = (size_t)(n + 1) * seq_stride;      // slice n of every layer: the scratch slice idle slots write to and read
-    // the stacked encoder runs in chunks of <= 128 utterances, PACKED (encode_batch_dev: every utterance its own rows, no padding to the longest): the audio rows of
+    // the stacked encoder runs in chunks of <= 64 utterances, PACKED (encode_batch_dev: every utterance its own rows, no padding to the longest): the audio rows of
     // utterance i start audio_off[i] floats into the audio buffer
     const int n_chunks = (n + CHUNK - 1) / CHUNK;
     std::vector<int> chunk0(n_chunks + 1, 0);      // full chunks first (measured on 81 utterances: 64 + 17 against 41 + 40 -- the packed encoder costs the same, 247 ms, the stacked prefill 57 instead of 66 ms)
