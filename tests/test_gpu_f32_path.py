@@ -76,6 +76,11 @@ def test_f32_transcribe_batch(pkg, pair):
     outs = m.transcribe_batch(clips, t)
     check_batch_rows(pkg, ctx, m, clips, t, outs, TOL)                          # every row: single-stream ids up to its first near-tie
     assert all((a == b).all() for a, b in zip(outs, m.transcribe_batch(clips, t)))
+    # wider than 64 on a checkpoint the XF step does not cover (dense weights): vox_transcribe_batch serves it as lock-step batches of <= 64 in its sorted order
+    many = [pkg.synth.synth_audio(0.6 + 0.11 * ((5 * i) % 13), seed=400 + i) for i in range(70)]
+    wide = m.transcribe_batch(many, t)
+    assert len(wide) == 70 and m.timings()["decode_tokens"] == sum(len(o) for o in wide)
+    check_batch_rows(pkg, ctx, m, [many[i] for i in (0, 13, 69)], t, [wide[i] for i in (0, 13, 69)], TOL)
 
 
 @pytest.mark.parametrize("dtype", ["F32", "F16"])

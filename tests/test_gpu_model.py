@@ -268,6 +268,13 @@ def test_transcribe_batch_continuous_slots(pkg, ctx, tiny, monkeypatch):
     assert all((a == b).all() for a, b in zip(outs, again))
     few = m.transcribe_batch(clips[:17], t)                                   # 17 utterances: the narrowest continuous batch
     assert all((a == b).all() for a, b in zip(few, outs[:17]))
+    ptrs = [ctx.upload(c) for c in clips[:40]]                                # device-resident samples (VOX_MEM_DEVICE), two and a half groups
+    try:
+        dev = m.transcribe_batch(None, t, device_ptrs=ptrs, n_samples=[c.size for c in clips[:40]])
+        assert all((a == b).all() for a, b in zip(dev, outs[:40]))
+    finally:
+        for p_ in ptrs:
+            ctx.free(p_)
     print(f"continuous batching, 90 ragged utterances: identical to the lock-step batches and for 1..4 slot groups; {n_same}/24 checked rows identical to single-stream end to end")
 
 
