@@ -74,6 +74,32 @@ def test_cli_end_to_end(pkg, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_wide_batch_is_continuous_batching_and_keeps_the_lines(pkg, tmp_path):
+    """`voxtral-transcribe --batch N` with more un-chunked files than one 16-row group: one vox_transcribe_batch call = continuous batching over decode slots (round 5);
+    stdout must be, line for line and in input order, what the one-by-one run prints (transcribe.rs:112-126's contract)."""
+    import contextlib, io
+    S = pkg.synth
+    cli = __import__("importlib").import_module(pkg.__name__ + ".cli")
+    gguf = str(tmp_path / "m.gguf"); S.write_synthetic_gguf(gguf, S.tiny_dims(vocab=2048), seed=5)
+    tok = str(tmp_path / "tekken.json"); json.dump(_tekken(1200), open(tok, "w"))
+    wavs = []
+    for i in range(37):
+        p = str(tmp_path / f"w{i}.wav"); _write_wav(p, S.synth_audio(0.5 + 0.21 * ((5 * i) % 13), seed=300 + i)); wavs.append(p)
+    args = ["--gguf", gguf, "--tokenizer", tok] + sum((["--audio", w] for w in wavs), [])
+
+    def run(extra):
+        buf = io.StringIO(); err = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(err):
+            rc = cli.main(args + extra)
+        return rc, buf.getvalue(), err.getvalue()
+
+    rc1, out1, _ = run([])
+    rc2, out2, err2 = run(["--batch", "1024"])
+    assert rc1 == 0 and rc2 == 0 and out1 == out2 and len(out1.split("\n")) == 38
+    assert "batch of 37" in err2
+
+
+@pytest.mark.gpu
 def test_wer_harness_end_to_end(pkg, tmp_path, capsys):
     """wer.main (scripts/eval_wer.py flow: manifest -> one in-process `voxtral-transcribe` run -> normalise -> WER / CER -> JSON report)."""
     S = pkg.synth

@@ -2,7 +2,7 @@
 # One parametrised GPU-box runner (replaces round 1's gpu_run1..19.sh):  gpurun --timeout T -- 'bash tools/gpu_session.sh step [step ...]'
 # Every step is wrapped in its own `timeout`, logs under gpurun_out/ (merged back by gpurun); steps never abort the session.
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-TAG=${VOX_TAG:-r03}
+TAG=${VOX_TAG:-r05}
 step_tests()     { timeout 900 python -m pytest tests -m gpu -x -q ${VOX_PYTEST_ARGS:-} > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/${TAG}_pytest_gpu.log; }
 step_tests_all() { timeout 900 python -m pytest tests -m gpu -q -rA ${VOX_PYTEST_ARGS:-} > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|FAILED|full-size|batch" $OUT/${TAG}_pytest_gpu.log | tail -30; }
 step_smoke()     { timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/${TAG}_smoke.log; }
@@ -37,5 +37,6 @@ step_traffic()   { # HBM bytes per launch of the dominant decode GEMV: FETCH_SIZ
 step_ablate()    { # what each part of q4_gemv_kernel costs: product build, then every abl_* measurement build present
                    python tools/gemv_ablate.py 2>/dev/null | tail -1 | tee $OUT/${TAG}_gemv_ablate.txt
                    for l in voxtral-mini-realtime-rs_amd/libvoxtral_hip_abl_*.so; do VOX_LIB=$REPO/$l timeout 120 python tools/gemv_ablate.py 2>/dev/null | tail -1 | tee -a $OUT/${TAG}_gemv_ablate.txt; done; }
+step_continuous() { timeout 600 python tools/continuous_sweep.py ${VOX_WORLD:-8} ${VOX_CLIPS:-647} > $OUT/${TAG}_continuous_sweep.log 2>&1; echo "continuous rc=$?"; grep -v "continuous batch:" $OUT/${TAG}_continuous_sweep.log | tail -12; }
 step_batch()     { timeout 300 python tools/batch_prof.py ${VOX_BENCH_BATCH:-16} 2>&1 | tail -4; }
 for s in "$@"; do echo "=== $s"; t0=$(date +%s); step_$s; echo "--- $s took $(( $(date +%s) - t0 )) s"; done
