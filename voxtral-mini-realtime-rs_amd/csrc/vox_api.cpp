@@ -2669,7 +2669,13 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         const size_t left = pad_left(&pc), total = left + p_n[0] + pad_right(&pc, p_n[0] + left);      // the longest utterance (rows are sorted) sets max_seq
         const int Smax = conv_len(conv_len((int)(total / 160))) / c.reshape_factor, max_seq = std::max((Smax + 63) / 64 * 64, 64);
         const double per_clip = 2.0 * c.dec_layers * (double)c.dec_kv_heads * max_seq * c.dec_head_dim * 4.0;
-        part_max = (int)std::max(64.0, std::min(4096.0, 64e9 / per_clip));
+        double budget = 64e9;
+        {   // ... and under half of what the device has free right now (a shared GPU, other models resident): the pooled buffers of earlier calls count as free for this purpose
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t pooled = 0; for (const auto& e : m->ctx->pool) if (!e.used) pooled += e.cap; budget = std::min(budget, 0.5 * (double)(free_b + pooled)); }
+            else (void)hipGetLastError();
+        }
+        part_max = (int)std::max(17.0, std::min(4096.0, budget / per_clip));
         if (const char* e = knob_str("VOX_BATCH_SESSION_MAX")) part_max = std::max(17, atoi(e));      // measurement knob
     }
     const int n_parts = (n + part_max - 1) / part_max;
