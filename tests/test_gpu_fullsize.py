@@ -277,6 +277,58 @@ def test_full_wide_batches_peaked_golden_64_lockstep_and_81_continuous(pkg, monk
         m.close(); ctx.close()
 
 
+def test_full_continuous_batch_engine_forms_two_groups_per_launch(pkg, monkeypatch, capfd):
+    """The steps of a wide batch with one or two active slot groups go through the batched decode-layer engine: TWO groups per launch (decode_engine_b16_kernel<2>: group B's
+    phase runs while group A's hand-off resolves; cache slices per slot through EngBParams::kv_row), one group per launch once the second group has retired.  Full size,
+    peaked checkpoint (no near-tie: every id is asserted): (a) a ragged 40-row batch -- 32 slots, refilled -- on the engine forms == on the forked launch chains
+    (VOX_BATCH_CONT_NO_ENGINE=1) == the golden ids for the golden clip; the engine's launch counter moves by one launch per decode step; (b) a second model whose two-group
+    launch loses a publish (fault-injection flag 16384): the launch ends on its bounded wait, the call says so on stderr and serves the session again on the launch
+    chains -- same ids -- and the model is re-armed."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_16s_peaked_oracle.npz"))
+    path = os.path.join(cache_dir(), "full_q4_peaked_seed44.gguf")
+    if not os.path.exists(path):
+        pkg.synth.write_synthetic_gguf(path + ".tmp", pkg.synth.ModelDims(), seed=44, peaked=True); os.replace(path + ".tmp", path)
+    x = pkg.synth.synth_audio(16.0, seed=7049); rids = g["ids"]
+    t = pkg.TimeEmbedding(3072).embed(6.0)
+    clips = [pkg.synth.synth_audio(2.5 + 0.41 * (i % 19), seed=1700 + i) for i in range(39)]; clips.insert(17, x)
+    monkeypatch.setenv("VOX_BATCH_SLOT_GROUPS", "2")      # (the planner alone would serve 40 short rows from ONE group's 16 slots: the one-group launch at 1.17 ms per step)
+    ctx = pkg.Context(0); m = pkg.Q4ModelLoader.from_file(path).load(ctx)
+    try:
+        active, n0 = m.set_batch_engine(True)
+        if not active:
+            pytest.skip("batched decode engine not available on this device (needs 256 CUs)")
+        eng = m.transcribe_batch(clips, t)
+        _, n1 = m.set_batch_engine()
+        steps = m.timings()["graph_replays"]
+        assert n1 - n0 >= steps > 50, f"{n1 - n0} engine launches for {steps} replayed steps"      # every step of this 2-group session is ONE engine launch (+ the eager first step of a process)
+        monkeypatch.setenv("VOX_BATCH_CONT_NO_ENGINE", "1")
+        ref = m.transcribe_batch(clips, t)
+        _, n2 = m.set_batch_engine()
+        monkeypatch.delenv("VOX_BATCH_CONT_NO_ENGINE")
+        assert n2 == n1                                                      # none on the launch chains
+        assert len(eng) == 40 and all(len(a) == len(b) and (a == b).all() for a, b in zip(eng, ref)), "engine forms and launch chains disagree"
+        assert np.array_equal(eng[17], rids), "the golden clip (slot 17) differs from the oracle"
+        assert all((a == b).all() for a, b in zip(eng, m.transcribe_batch(clips, t)))      # run to run
+        capfd.readouterr()
+        monkeypatch.setenv("VOX_BATCH_ENGINE_FLAGS2", str(128 | 1024 | 16384))
+        b = pkg.Q4ModelLoader.from_file(path).load(ctx)
+        monkeypatch.delenv("VOX_BATCH_ENGINE_FLAGS2")
+        try:
+            import time
+            t0 = time.time()
+            out = b.transcribe_batch(clips, t)
+            assert time.time() - t0 < 60.0                                   # bounded waits, not a hang
+            err = capfd.readouterr().err
+            assert "continuous batch" in err and "hand-off timeout" in err and "strike 1 of 3" in err
+            assert all((a == r).all() for a, r in zip(out, ref)), "the re-run on the launch chains gave other ids"
+            assert b.set_batch_engine()[0]                                   # re-armed
+        finally:
+            b.close()
+        print(f"continuous batch, 40 rows: engine forms (two groups per launch, {n1 - n0} launches) == launch chains == golden; a lost publish is survived")
+    finally:
+        m.close(); ctx.close()
+
+
 def test_full_ragged_batch_groups_retire(pkg, full):
     """A ragged batch wider than one 16-row group at FULL size: vox_transcribe_batch runs the rows longest first and RETIRES a group's layer chain
     once its longest member is done.  The 16 s golden clip sits in the caller's LAST slot between 3..9 s clips: it must still reproduce the oracle's

@@ -37,6 +37,13 @@ def report(tag, idx, bucket):
 
 
 share = parts[0]
+if os.environ.get("VOX_SWEEP_STEP_COST"):      # the cost model's inputs: a rank share on 1..4 forced slot groups, engine forms (<= 2 active groups) on and off
+    for eng in (1, 0):
+        if not eng: os.environ["VOX_BATCH_CONT_NO_ENGINE"] = "1"
+        for G in (1, 2, 3, 4):
+            os.environ["VOX_BATCH_SLOT_GROUPS"] = str(G)
+            report(f"rank share, {G} slot group(s) forced, engine forms {'on' if eng else 'off'}", share, 4096)
+    m.close(); ctx.close(); sys.exit(0)
 quick = bool(os.environ.get("VOX_SWEEP_QUICK"))      # only the planner's-choice lines (A/B of a knob, e.g. VOX_BATCH_CHUNK)
 t_lock = t_all_lock = float("nan")
 if not quick:

@@ -12,3 +12,6 @@ B=../../voxtral-mini-realtime-rs_amd/build
 # engine_b16_bench: the batched decode-layer engine against a CPU restatement (OpenMP on the host side)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fopenmp -c -o engine_b16_bench.o engine_b16_bench.hip 2>&1 | grep -v "argument unused"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fopenmp -o engine_b16_bench engine_b16_bench.o $B/vox_kernels.o $B/vox_engine.o $B/vox_engine_b16.o 2>&1 | grep -v "argument unused"; echo "built engine_b16_bench"
+# engine_b32_bench: the two-group launch + cache-slice indirection against the one-group launch
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -c -o engine_b32_bench.o engine_b32_bench.hip 2>&1 | grep -v "argument unused"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -o engine_b32_bench engine_b32_bench.o $B/vox_kernels.o $B/vox_engine.o $B/vox_engine_b16.o 2>&1 | grep -v "argument unused"; echo "built engine_b32_bench"

@@ -781,7 +781,9 @@ struct vox_model {
     bool engb_ok = false; unsigned char* engb_state[4] = {nullptr, nullptr, nullptr, nullptr}; EngLayerTab* engb_tab[4] = {nullptr, nullptr, nullptr, nullptr};
     bool engb_on = true; unsigned long long engb_launches = 0; int engb_strikes = 0;
     int batch_sessions = 0;      // parts the last vox_transcribe_batch call ran in
-    int engb_flags = 128 | 1 | 64 | 2048; unsigned engb_err_host[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int engb_flags = 128 | 1 | 64 | 2048;
+    int engb_flags2 = 128 | 1024;      // two-group launch: loader depth 2, never paused or thinned -- with two chains interleaved the stream is what a phase waits for (profiles/r05_b32_engine.txt: 61.4 us per layer against 65.4 with the one-group flags)
+    unsigned engb_err_host[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     // decode graphs: [0] = one step, [1] = graph_unroll steps (fewer graph boundaries); both bake cache / audio / token pointers in
     hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; int graph_unroll = 0, graph_mode = 0;
     const vox_cache* graph_cache = nullptr; const float* graph_audio = nullptr;
@@ -1228,6 +1230,7 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
             m->engb_ok = ok && !(bv && bv[0] == '0') && engb_occupancy(&occ) == hipSuccess && occ >= 1;
             (void)hipGetLastError();
             if (const char* f = knob_str("VOX_BATCH_ENGINE_FLAGS")) m->engb_flags = atoi(f);
+            if (const char* f = knob_str("VOX_BATCH_ENGINE_FLAGS2")) m->engb_flags2 = atoi(f);
         }
         if (const char* f = knob_str("VOX_ENGINE_FLAGS")) m->eng_flags = atoi(f);      // measurement knobs of tools/micro/engine_bench (loader depth / probe / XCD-local edges)
         if (const char* f = knob_str("VOX_ENGINE_PACE")) m->eng_pace = atoi(f);
@@ -1806,6 +1809,7 @@ static int32_t engine_prepare(vox_model* m) {
 static bool engb_prepare(vox_model* m, int n_grp) {
     if (!m->engb_ok || !m->engb_on || n_grp > 4) return false;
     if (engine_stream_prepare(m) != VOX_OK || !m->eng_ready) return false;
+    if (engb_prepare_kernels() != hipSuccess) { (void)hipGetLastError(); m->engb_ok = false; return false; }
     if (!m->eng_wob) {      // wo once more, in the batched engine's XCD-group K split (184 MB for 26 layers)
         const vox_model_cfg& c = m->cfg; hipStream_t s = m->ctx->stream;
         hipError_t e = hipMalloc((void**)&m->eng_wob, engb_wo_stream_bytes(c.dec_layers));
@@ -2366,9 +2370,12 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
 //       queues are empty.  Rows are independent of their slot, so the ids per utterance are those of every other path (tests/test_gpu_fullsize.py).
 // Step cost of G lock-step groups in ms, measured on the FLEURS-like corpus (profiles/r05_continuous_sweep.txt: decode time net of graph captures / steps; 3 interpolated):
 static const double kStepMs[5] = {0.0, 1.84, 2.08, 2.75, 3.40};
+// ... with the batched decode-layer engine serving the steps of <= 2 active groups (one group: decode_engine_b16_kernel<1>, 1.06 ms + tail; two: the two-group launch,
+// 1.60 ms + tail; three and four groups stay on the forked launch chains -- a two-group launch + a one- or two-group launch back to back: 2.9 / 3.4 ms against 2.75 / 3.40)
+static const double kStepMsEng[5] = {0.0, 1.17, 1.77, 2.75, 3.40};
 struct SlotPlan { int G = 0; std::vector<std::vector<int>> queue; std::vector<int> steps_g; double cost_ms = 0.0; };
 // jobs: (decode steps, utterance) with steps >= 1.  LPT onto 16 G slots, slots ordered by load (so the groups retire last to first), G by the cost model.
-static SlotPlan plan_slots(const std::vector<std::pair<int, int>>& jobs_in, int force_G) {
+static SlotPlan plan_slots(const std::vector<std::pair<int, int>>& jobs_in, int force_G, const double* step_ms) {
     std::vector<std::pair<int, int>> jobs = jobs_in;
     std::stable_sort(jobs.begin(), jobs.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
     SlotPlan best;
@@ -2382,7 +2389,7 @@ static SlotPlan plan_slots(const std::vector<std::pair<int, int>>& jobs_in, int 
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] > load[b]; });
         SlotPlan pl; pl.G = G; pl.queue.resize(Sl); pl.steps_g.assign(G, 0);
         for (int i = 0; i < Sl; i++) { pl.queue[i] = q[order[i]]; pl.steps_g[i / 16] = std::max(pl.steps_g[i / 16], (int)load[order[i]]); }
-        for (int k = 0; k < G; k++) pl.cost_ms += (double)(pl.steps_g[k] - (k + 1 < G ? pl.steps_g[k + 1] : 0)) * kStepMs[k + 1];
+        for (int k = 0; k < G; k++) pl.cost_ms += (double)(pl.steps_g[k] - (k + 1 < G ? pl.steps_g[k + 1] : 0)) * step_ms[k + 1];
         if (best.G == 0 || pl.cost_ms <= best.cost_ms) best = pl;
     }
     return best;
@@ -2392,7 +2399,7 @@ static bool batch_xf_ok(const vox_model* m) {
     return m->tok.w.fmt == WFMT_Q4_0 && m->dec[0].wqkv.w.fmt == WFMT_Q4_0 && m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !knob_str("VOX_BATCH_NO_XF");
 }
 static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
-                                          int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of) {
+                                          int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of, bool allow_engine) {
     VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
@@ -2434,7 +2441,10 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     std::vector<std::pair<int, int>> jobs;
     for (int i = 0; i < n; i++) if (len[i] > PREFIX_LEN + 1) jobs.emplace_back(len[i] - PREFIX_LEN - 1, i);
     int force_G = 0; if (const char* e = knob_str("VOX_BATCH_SLOT_GROUPS")) force_G = std::max(0, std::min(4, atoi(e)));
-    const SlotPlan plan = plan_slots(jobs, force_G);
+    // the steps of one or two active groups go through the batched decode-layer engine (vox_engine_b16.hip: one launch per step for the 26 layers of both groups, cache
+    // slices per slot through EngBParams::kv_row); wider steps, other geometries, VOX_BATCH_ENGINE=0 and the re-run after a hand-off timeout use the launch chains
+    const bool use_eng = allow_engine && !jobs.empty() && !knob_str("VOX_BATCH_CONT_NO_ENGINE") && engb_prepare(m, 2);
+    const SlotPlan plan = plan_slots(jobs, force_G, use_eng ? kStepMsEng : kStepMs);
     const int G = std::max(plan.G, 1), Sl = 16 * G;
     int q_stride = 1; for (auto& q : plan.queue) q_stride = std::max(q_stride, (int)q.size() + 1);
     std::vector<int> h_queue((size_t)Sl * q_stride, -1);
@@ -2442,7 +2452,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     const int steps = plan.steps_g.empty() ? 0 : plan.steps_g[0];
 
     DevBuf b_audio, b_k, b_v, b_tok, b_posc, b_len, b_h0, b_aoff, b_px, b_xn, b_lg0, b_mel, b_scale, b_smp;
-    DevBuf b_queue, b_sclip, b_sqpos, b_pos, b_kvrow, b_h, b_qkv, b_att, b_logits, b_xf1, b_xf2, b_xf3, b_ssq;
+    DevBuf b_queue, b_sclip, b_sqpos, b_pos, b_kvrow, b_h, b_qkv, b_att, b_logits, b_xf1, b_xf2, b_xf3, b_ssq, b_ssq_e;
     struct Drain { vox_ctx* c; ~Drain() { (void)hipStreamSynchronize(c->stream); for (auto a : c->aux) if (a) (void)hipStreamSynchronize(a); } } drain{cx};
     HIPCHK(b_audio.alloc_pooled(cx, audio_floats * 4)); HIPCHK(b_k.alloc_pooled(cx, layer_stride * c.dec_layers * 4)); HIPCHK(b_v.alloc_pooled(cx, layer_stride * c.dec_layers * 4));
     HIPCHK(b_tok.alloc_pooled(cx, (size_t)n * tstride * 4)); HIPCHK(b_posc.alloc_pooled(cx, (size_t)n * 4)); HIPCHK(b_len.alloc_pooled(cx, (size_t)n * 4));
@@ -2459,6 +2469,9 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         HIPCHK(hipMemcpyAsync(d_tok, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_posc.p, pos0.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(b_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, s)); HIPCHK(hipMemcpyAsync(b_aoff.p, audio_off.data(), (size_t)n * sizeof(long), hipMemcpyHostToDevice, s));
         HIPCHK(b_queue.alloc_pooled(cx, h_queue.size() * 4)); HIPCHK(hipMemcpyAsync(b_queue.p, h_queue.data(), h_queue.size() * 4, hipMemcpyHostToDevice, s));      // (the slot queues too: no pageable copy may sit behind phase A)
+        std::vector<EngLayerTab> tab(c.dec_layers);      // the engine's layer table, one for every group: the layers' slabs (cache slices are picked per slot)
+        for (int l = 0; l < c.dec_layers; l++) tab[l] = EngLayerTab{m->dec[l].attn_norm, m->dec[l].ffn_norm, m->dec[l].ada_mul, b_k.as<float>() + (size_t)l * layer_stride, b_v.as<float>() + (size_t)l * layer_stride};
+        if (use_eng) HIPCHK(hipMemcpyAsync(m->engb_tab[0], tab.data(), sizeof(EngLayerTab) * c.dec_layers, hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));      // the host vectors go out of scope
     }
     // ---- (A) front-end, stacked encoder and stacked 38-token prefill, chunk by chunk
@@ -2518,6 +2531,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             HIPCHK(hipMemsetAsync(b_v.as<float>() + (size_t)l * layer_stride + (size_t)n * seq_stride, 0, seq_stride * 4, s));
         }
         int* d_pos = b_pos.as<int>(); int* d_kvrow = b_kvrow.as<int>();
+        if (use_eng) HIPCHK(b_ssq_e.alloc_pooled(cx, (size_t)(256 + 16) * 16 * 4 * G));      // per group: the launch's 256 partial sums of squares + their fold
         SlotStepParams sp{};
         sp.logits = b_logits.as<float>(); sp.vocab = V; sp.tokens = d_tok; sp.tok_stride = tstride; sp.clip_len = b_len.as<int>();
         sp.slot_clip = b_sclip.as<int>(); sp.slot_qpos = b_sqpos.as<int>(); sp.queue = b_queue.as<int>(); sp.q_stride = q_stride;
@@ -2552,8 +2566,44 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
               g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, sg)); }
             return VOX_OK;
         };
+        int eng_per_step = 0;      // engine launches enqueued by the last call of `step`
+        auto engine_params = [&](int gi, int blk, bool two = false) {
+            const int r0 = gi * 16;
+            EngBParams ep{}; ep.stream = m->eng_stream; ep.stream_wo = m->eng_wob; ep.layers = m->engb_tab[0]; ep.n_layers = c.dec_layers; ep.kv_seq_stride = (long)seq_stride;
+            ep.h_in = b_h.as<float>() + (size_t)r0 * D; ep.h_stride = D; ep.n_rows = 16; ep.final_norm = m->dec_norm; ep.pos = d_pos + r0; ep.kv_row = d_kvrow + r0;
+            ep.rope_cos = m->dec_cos; ep.rope_sin = m->dec_sin; ep.max_seq = max_seq; ep.window = c.dec_window; ep.eps = c.norm_eps;
+            engb_state_carve(m->engb_state[blk], &ep);      // (an edge-buffer block belongs to a launch, not to a group: tags carry the block's launch serial)
+            ep.xf_out = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); ep.ssq_out = b_ssq_e.as<float>() + (size_t)gi * (256 + 16) * 16; ep.tl = nullptr; ep.tl_layer = -1; ep.flags = two ? m->engb_flags2 : m->engb_flags;
+            return ep;
+        };
+        auto engine_tail = [&](int gi, hipStream_t sg) -> int32_t {      // the launch's 256 partial sums of squares -> 16, then the group's lm_head
+            float* ssq_e = b_ssq_e.as<float>() + (size_t)gi * (256 + 16) * 16; float* ssq_f = ssq_e + 256 * 16;
+            HIPCHK(launch_engb_ssq_fold(ssq_e, ssq_f, sg));
+            GemmParams g{}; g.w = m->tok.w; g.xf = (const uint4*)(b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2)); g.M = 16; g.out = b_logits.as<float>() + (size_t)gi * 16 * V; g.out_stride = V;
+            g.ssq_part = ssq_f; g.n_part = 16; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, sg));
+            return VOX_OK;
+        };
         auto step = [&](uint32_t active) -> int32_t {
             int n_act = 0; for (int gi = 0; gi < G; gi++) n_act += (active >> gi) & 1u;
+            eng_per_step = 0;
+            if (use_eng && n_act <= 2) {
+                int ga = -1, gb = -1; for (int gi = 0; gi < G; gi++) if ((active >> gi) & 1u) { if (ga < 0) ga = gi; else gb = gi; }
+                if (gb < 0) HIPCHK(launch_decode_engine_b16(engine_params(ga, 0), s));
+                else HIPCHK(launch_decode_engine_b16x2(engine_params(ga, 0, true), engine_params(gb, 1, true), s));
+                eng_per_step = 1;
+                if (gb >= 0) {      // the second group's tail on a side stream
+                    if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+                    if (!cx->aux[0]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[0], hipStreamNonBlocking));
+                    if (!cx->ev_join[0]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[0], hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(cx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cx->aux[0], cx->ev_fork, 0));
+                    VOXCHK(engine_tail(gb, cx->aux[0]));
+                    HIPCHK(hipEventRecord(cx->ev_join[0], cx->aux[0]));
+                }
+                VOXCHK(engine_tail(ga, s));
+                if (gb >= 0) HIPCHK(hipStreamWaitEvent(s, cx->ev_join[0], 0));
+                HIPCHK(launch_argmax_embed_slots(sp, Sl, s));
+                return VOX_OK;
+            }
             const bool fork = n_act > 1 && !knob_str("VOX_BATCH_SERIAL_GROUPS");
             if (fork) {
                 if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
@@ -2593,7 +2643,8 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         // of a process runs its first step eagerly, every later one replays graphs from step 0 on
         static bool step_kernels_warm = false;
         int t_start = 0;
-        if (!step_kernels_warm && !no_graph) { VOXCHK(step(active_at(0))); step_kernels_warm = true; t_start = 1; }
+        if (!step_kernels_warm && !no_graph) { VOXCHK(step(active_at(0))); m->engb_launches += (unsigned)eng_per_step; step_kernels_warm = true; t_start = 1; }
+        std::vector<std::pair<uint32_t, int>> eng_in_graph;      // engine launches per replay of every captured set
         auto capture = [&](uint32_t act, hipGraphExec_t* out) -> int32_t {
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             const int32_t r = step(act);
@@ -2613,7 +2664,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
                 if (graphs.find(act)) continue;
                 hipGraphExec_t ge = nullptr;
                 VOXCHK(capture(act, &ge));
-                graphs.ex.emplace_back(act, ge); n_captures++;
+                graphs.ex.emplace_back(act, ge); eng_in_graph.emplace_back(act, eng_per_step); n_captures++;
             }
             capture_ms = now_ms() - tg;
         }
@@ -2621,11 +2672,24 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         { const double tn = now_ms(); pf_ms += tn - t1; t1 = tn; }
         for (int t = t_start; t < steps; t++) {
             const uint32_t act = active_at(t);
-            if (no_graph) { VOXCHK(step(act)); continue; }
+            if (no_graph) { VOXCHK(step(act)); m->engb_launches += (unsigned)eng_per_step; continue; }
             if (hipGraphLaunch(graphs.find(act), s) != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphLaunch failed");
             replays++;
+            for (auto& e : eng_in_graph) if (e.first == act) m->engb_launches += (unsigned)e.second;
         }
+        if (use_eng) for (int blk = 0; blk < 2; blk++) { EngBParams ep{}; engb_state_carve(m->engb_state[blk], &ep); HIPCHK(hipMemcpyAsync(m->engb_err_host[blk], ep.err, 8, hipMemcpyDeviceToHost, s)); }
         HIPCHK(hipStreamSynchronize(s));
+        if (use_eng) for (int blk = 0; blk < 2; blk++) if (m->engb_err_host[blk][0]) {
+            // a bounded hand-off wait expired inside an engine launch (it needs all 256 CUs to itself): the ids of this session are not trustworthy.  Say so and serve the
+            // session again on the launch chains; after three strikes the batched engine is switched off for this model.
+            const unsigned e = m->engb_err_host[blk][0];
+            m->engb_strikes++;
+            fprintf(stderr, "[voxtral_hip] batched decode engine (continuous batch): hand-off timeout (code %u, workgroup %u), strike %d of 3; re-running the session on the launch-based step%s\n",
+                    e & 0xff, (e >> 8) & 0xff, m->engb_strikes, m->engb_strikes >= 3 ? ", the engine is switched off" : "");
+            for (int gj = 0; gj < 4; gj++) if (m->engb_state[gj]) (void)engb_state_init(m->engb_state[gj], s);
+            if (m->engb_strikes >= 3) m->engb_ok = false;
+            return VOX_RETRY_ON_LAUNCHES;
+        }
     }
     std::vector<int32_t> host_tok((size_t)n * tstride);
     HIPCHK(hipMemcpyAsync(host_tok.data(), d_tok, host_tok.size() * 4, hipMemcpyDeviceToHost, s));
@@ -2683,8 +2747,10 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
     for (int pi = 0, a = 0; pi < n_parts && r == VOX_OK; pi++) {
         const int b = a + (n - a) / (n_parts - pi);      // equal contiguous parts of the sorted order
         const int np = b - a;
-        r = cont ? transcribe_continuous_impl(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a)
-                 : transcribe_batch_launches(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a);
+        if (cont) {
+            r = transcribe_continuous_impl(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a, true);
+            if (r == VOX_RETRY_ON_LAUNCHES) r = transcribe_continuous_impl(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a, false);
+        } else r = transcribe_batch_launches(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a);
         acc.preprocess_ms += m->timings.preprocess_ms; acc.encode_ms += m->timings.encode_ms; acc.decode_ms += m->timings.decode_ms; acc.total_ms += m->timings.total_ms;
         acc.decode_tokens += m->timings.decode_tokens; acc.graph_replays += m->timings.graph_replays;
         m->batch_sessions++; a = b;

@@ -25,6 +25,14 @@
 // The partial planes of wo / w2 need no flags at all: a slot is "empty" (all ones) until its producer stores it, the owner polls the slots and puts the marker back.
 // The small q|k|v edge keeps the tagged 8-byte granules.  Edges inside one XCD group (q|k|v, attention output, SwiGLU output) use plain stores when the start-up check finds the group on one XCD.
 // Tags / flags = (launch serial + 1) * 64 + layer + 1 as in the single-stream engine; every spin is bounded (20 ms) and fails the launch loudly (*err).
+// TWO GROUPS PER LAUNCH (NG = 2, round 5; the wide batch's slot groups, vox_api.cpp transcribe_continuous_impl): every phase of a layer runs for group A, then for group B,
+// on the same waves -- B computes while A's edge resolves and the other way round (the launch is bound by its hand-offs, not by the matrix pipe or HBM: section 3.3c of
+// DESIGN.md).  The loader streams every operator's packets twice (the ring cannot hold an operator; the second pass comes out of L2 / MALL), each group has its own edge
+// buffers, flags and launch serial (two state blocks), its own COMM-owned LDS (residual columns, RMSNorm scales, q / k / v of the step, RoPE factors, positions), and the
+// COMM wave serves the two chains in the same A, B order.  Every counter that is a function of the layer for one group (ring packet index, barrier and publish counts)
+// becomes a function of (layer, phase, group) in that one global order.  The time-shared LDS regions keep their single copy: a wave may run one phase ahead of the finishing
+// waves of the previous phase (there is no edge between A's phase and B's), so before its first store into a time-shared region a wave waits until all twelve have
+// published the previous phase (`guard`: one LDS poll, satisfied long before in the common case).  Cache slices are picked per sequence (EngBParams::kv_row, KVR = true).
 // The final norm's input leaves the launch in the launch-based path's own format (XF planes of h * final_norm + 256 partial sums of squares), so the step's tail --
 // the 16-row lm_head GEMM and the argmax / next-embedding kernel -- is unchanged.
 #include "vox_kernels.h"
@@ -57,9 +65,9 @@ constexpr int PH = 5;                                    // publish phases per l
 struct BCtl {
     unsigned ring_ready[8], ring_done[8];
     unsigned cbar, dead, gathering, gw_flag;
-    unsigned xcd_ok, xcc_id, ag_flag, pub_cnt;
-    unsigned qkv_flag, wo_flag, xa_flag, rs_flag;      // rs_flag: all-gather stages whose RMSNorm scales are in LDS
-    unsigned tbar[2], pad0, pad1;
+    unsigned xcd_ok, xcc_id, pub_cnt, pad0;
+    unsigned ag_flag[2], rs_flag[2], qkv_flag[2], wo_flag[2], xa_flag[2];      // per group; rs_flag: all-gather stages whose RMSNorm scales are in LDS
+    unsigned tbar[2];
 };
 // ---- LDS map ----
 constexpr int BL_RING = 0;
@@ -80,8 +88,22 @@ constexpr int BL_TAB = BL_POS + BM * 4;
 constexpr int MAX_LAYERS = 32;
 constexpr int BL_GW = BL_TAB + MAX_LAYERS * (int)sizeof(EngLayerTab);      // [MAX_LAYERS + 1][2][16] norm weights of the CU's 12 columns
 constexpr int BL_CTL = BL_GW + (MAX_LAYERS + 1) * 32 * 4;
-constexpr int BL_TOTAL = BL_CTL + (int)sizeof(BCtl);
-static_assert(BL_TOTAL <= 160 * 1024, "LDS budget");
+constexpr int BL_KVR = BL_CTL + (int)sizeof(BCtl);      // [16] int cache slice of every sequence (KVR form)
+constexpr int BL_TOTAL = BL_KVR + BM * 4;
+// the second group's COMM-owned regions (NG = 2): q|k|v of the step, residual columns, RMSNorm scales, RoPE factors, positions, cache slices
+constexpr int G1_QKVN = 0, G1_OWN = G1_QKVN + 2 * 384 * 4, G1_RSTD = G1_OWN + 2 * OWN * BM * 4, G1_ROPE = G1_RSTD + 2 * BM * 4, G1_POS = G1_ROPE + (2 * 8 * BM + 2 * 2 * BM) * 4,
+              G1_KVR = G1_POS + BM * 4, G1_BYTES = G1_KVR + BM * 4;
+constexpr int BL_G1 = BL_TOTAL, BL_TOTAL2 = BL_G1 + G1_BYTES;
+static_assert(BL_TOTAL2 <= 160 * 1024, "LDS budget");
+static_assert(BL_KVR % 16 == 0 && BL_G1 % 16 == 0 && G1_OWN % 16 == 0 && G1_RSTD % 16 == 0 && G1_ROPE % 16 == 0 && G1_POS % 16 == 0, "aligned carve (second group)");
+// group q's copy of a COMM-owned region (q is wave-uniform; NG = 1: q is the constant 0)
+__device__ __forceinline__ int lg(int base0, int rel1, int q) { return q == 0 ? base0 : BL_G1 + rel1; }
+#define L_QKVN(q) lg(BL_QKVN, G1_QKVN, q)
+#define L_OWN(q) lg(BL_OWN, G1_OWN, q)
+#define L_RSTD(q) lg(BL_RSTD, G1_RSTD, q)
+#define L_ROPE(q) lg(BL_ROPE, G1_ROPE, q)
+#define L_POS(q) lg(BL_POS, G1_POS, q)
+#define L_KVR(q) lg(BL_KVR, G1_KVR, q)
 static_assert(BL_OF + 2 * 128 * 4 <= BL_PART + PART_BYTES && 6 * 6 * 1024 <= PART_BYTES && BM * 36 * 4 <= NCONS * 8 * 64, "time-shared regions");
 static_assert(BL_QKVN % 16 == 0 && BL_CB % 16 == 0 && BL_OWN % 16 == 0 && BL_RSTD % 16 == 0 && BL_ROPE % 16 == 0 && BL_TAB % 16 == 0 && BL_CTL % 16 == 0 && BL_ATT % 16 == 0, "aligned carve");
 
@@ -151,9 +173,22 @@ __device__ __forceinline__ f32x4 corr16(bf16x8 ah, bf16x8 al, u32x4 mm) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(mm), s, 0, 0, 0);
 }
 
+// the kernel's arguments: one parameter block per group, back to back in the kernarg segment
+template <int NG> struct EngBArgs { EngBParams g[NG]; };
+__device__ __forceinline__ EngBParams kparams(int q) {      // group q's block by value from the constant address space: the fields a phase uses become scalar loads
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ((const __attribute__((address_space(4))) EngBParams*)__builtin_amdgcn_kernarg_segment_ptr())[q];
+#else
+    (void)q; return EngBParams{};
+#endif
+}
+__device__ __forceinline__ unsigned char* lds_base() { extern __shared__ __attribute__((aligned(16))) unsigned char lds_[]; return lds_; }
+__device__ __forceinline__ unsigned b16_tag_base(const EngBParams& p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)((*p.serial + 1u) * 64u)); }
+
 // ------------------------------------------------------------------------------------------------
 // LOADER wave: the layer packets of the single-stream engine's stream, four ring slots
 // ------------------------------------------------------------------------------------------------
+template <int NG>
 __device__ __forceinline__ void b16_loader(const EngBParams& p, BCtl* c, unsigned ring_lds, int lane, const Tl& tl) {
     Loader<BCtl, BNSLOT> ld; ld.c = c; ld.err = p.err; ld.ring_lds = ring_lds; ld.voff = (unsigned)lane * 16u; ld.thin = (p.flags & 1) != 0; ld.pace = 0;
     if (p.flags & 1024) ld.depth = 2;
@@ -161,18 +196,42 @@ __device__ __forceinline__ void b16_loader(const EngBParams& p, BCtl* c, unsigne
     if (p.flags & 64) ld.pause_ticks = 300;      // nothing new in flight while this CU's COMM wave polls / sums / publishes (bounded: 3 us)
     const bool nodma = (p.flags & 32) != 0;
     const u64 base = (u64)p.stream;
-    const unsigned n_pk = (unsigned)p.n_layers * PK_LAYER;
-    unsigned l = 0, r = 0; u64 off = 0;
+    if (NG == 1) {
+        const unsigned n_pk = (unsigned)p.n_layers * PK_LAYER;
+        unsigned l = 0, r = 0; u64 off = 0;
 #pragma unroll 1
-    for (unsigned pk = 0; pk < n_pk; pk++) {
-        const int bytes = r < PK_LAYER_M ? PK_M : PK_A;
-        if (r == 0 && (int)l == p.tl_layer) tl(16);
-        const bool wo_pk = r >= (unsigned)QKV_PK && r < (unsigned)(QKV_PK + WO_PK);      // wo: the XCD-group split lives in its own stream, [layer][packet][CU][bytes]
-        const u64 src = wo_pk ? (u64)p.stream_wo + (u64)NCU * ((u64)l * WOB_LAYER_BYTES + (u64)(r - QKV_PK) * PK_M) + (u64)blockIdx.x * (u64)PK_M
-                              : base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes;
-        if (bytes == PK_M) ld.issue<PK_M>(src, lane, nodma); else ld.issue<PK_A>(src, lane, nodma);
-        off += (u64)bytes;
-        if (++r == PK_LAYER) { if ((int)l == p.tl_layer) tl(17); r = 0; l++; }
+        for (unsigned pk = 0; pk < n_pk; pk++) {
+            const int bytes = r < PK_LAYER_M ? PK_M : PK_A;
+            if (r == 0 && (int)l == p.tl_layer) tl(16);
+            const bool wo_pk = r >= (unsigned)QKV_PK && r < (unsigned)(QKV_PK + WO_PK);      // wo: the XCD-group split lives in its own stream, [layer][packet][CU][bytes]
+            const u64 src = wo_pk ? (u64)p.stream_wo + (u64)NCU * ((u64)l * WOB_LAYER_BYTES + (u64)(r - QKV_PK) * PK_M) + (u64)blockIdx.x * (u64)PK_M
+                                  : base + (u64)NCU * off + (u64)blockIdx.x * (u64)bytes;
+            if (bytes == PK_M) ld.issue<PK_M>(src, lane, nodma); else ld.issue<PK_A>(src, lane, nodma);
+            off += (u64)bytes;
+            if (++r == PK_LAYER) { if ((int)l == p.tl_layer) tl(17); r = 0; l++; }
+        }
+    } else {
+        // NG groups: every operator's packets NG times in a row (group A's pass, then group B's: the consumption order of the interleaved phases)
+#pragma unroll 1
+        for (unsigned l = 0; l < (unsigned)p.n_layers; l++) {
+            if ((int)l == p.tl_layer) tl(16);
+#pragma unroll 1
+            for (int seg = 0; seg < 4; seg++) {      // q|k|v, wo, w1|w3, w2
+                const int r0 = seg == 0 ? 0 : seg == 1 ? QKV_PK : seg == 2 ? QKV_PK + WO_PK : PK_LAYER_M, npk = seg == 0 ? QKV_PK : seg == 1 ? WO_PK : seg == 2 ? W13_PK : W2_PK;
+                const u64 seg_src = seg == 1 ? (u64)p.stream_wo + (u64)NCU * ((u64)l * WOB_LAYER_BYTES) + (u64)blockIdx.x * (u64)PK_M
+                                  : seg == 3 ? base + (u64)NCU * ((u64)l * LAYER_BYTES + (u64)OFF_W2) + (u64)blockIdx.x * (u64)PK_A
+                                             : base + (u64)NCU * ((u64)l * LAYER_BYTES + (u64)r0 * PK_M) + (u64)blockIdx.x * (u64)PK_M;
+#pragma unroll 1
+                for (int q = 0; q < NG; q++) {
+#pragma unroll 1
+                    for (int i = 0; i < npk; i++) {
+                        if (seg == 3) ld.issue<PK_A>(seg_src + (u64)NCU * (u64)i * PK_A, lane, nodma);
+                        else ld.issue<PK_M>(seg_src + (u64)NCU * (u64)i * PK_M, lane, nodma);
+                    }
+                }
+            }
+            if ((int)l == p.tl_layer) tl(17);
+        }
     }
     ld.flush();
     tl(18);
@@ -317,15 +376,19 @@ __device__ __forceinline__ void comm_reduce(const float* planes, unsigned bytes,
     if (lane < 4 * OWN) *reinterpret_cast<f32x4*>(dst + n12 * BM + 4 * mq) = a;
 }
 
-__device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned char* lds, const int lane0, const Tl& tl) {
+// One function per edge, each of (group q, layer l): the COMM wave serves the groups' chains in the order the consumer waves run their phases (A, B per phase).
+// pub(k) = the publish count at which all twelve consumer waves of THIS CU have left phase k (0 q|k|v .. 4 w2) of (l, q).
+template <int NG>
+__device__ __forceinline__ void b16_comm(BCtl* c, unsigned char* lds, const int lane0, const Tl& tl0) {
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7;
-    float* qkvn = reinterpret_cast<float*>(lds + BL_QKVN);
-    float* own0 = reinterpret_cast<float*>(lds + BL_OWN); float* own1 = own0 + OWN * BM;
-    float* rstd = reinterpret_cast<float*>(lds + BL_RSTD);
     const float* gwt = reinterpret_cast<const float*>(lds + BL_GW);
-    const unsigned tag_base = (unsigned)__builtin_amdgcn_readfirstlane((int)((*p.serial + 1u) * 64u));
-    const int L = p.n_layers;
-    {   // the step's input rows of this CU's 12 columns (rows >= n_rows: zeros)
+    const EngBParams p0 = kparams(0);
+    const int L = p0.n_layers;
+#pragma unroll 1
+    for (int q = 0; q < NG; q++) {   // the step's input rows of this CU's 12 columns (rows >= n_rows: zeros)
+        const EngBParams p = kparams(q);
+        float* own0 = reinterpret_cast<float*>(lds + L_OWN(q));
+        const unsigned tag_base = b16_tag_base(p);
         const int n12 = min(lane0 >> 2, OWN - 1), mq = lane0 & 3;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -336,78 +399,108 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
         if (L > 0) comm_publish_rows(p, lane0, own0, gwt, p.XH0, p.SS0, p.F0, tag_base);
         else comm_publish_final(p, lane0, own0, gwt);
     }
-    const bool xloc = (p.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0;
-#pragma unroll 1
-    for (int st = 0; st < 2 * L; st++) {
-        int lane = lane0; asm volatile("" : "+v"(lane));
-        const int l = st >> 1; const bool odd = st & 1, T = l == p.tl_layer;
-        const unsigned tag = tag_base + (unsigned)l + 1u;
-        const unsigned pc0 = (unsigned)(NCONS * PH * l);
-        // ---- all-gather: every owner's flag, the RMSNorm scales, release the consumer waves
+    const bool xloc = (p0.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0;
+    const unsigned tb0 = b16_tag_base(p0), tb1 = NG > 1 ? b16_tag_base(kparams(NG - 1)) : 0u;      // the groups' launch serials (two state blocks)
+    auto tagb = [&](int q) { return q == 0 ? tb0 : tb1; };
+    auto pub = [&](int l, int k, int q) { return (unsigned)NCONS * ((unsigned)(NG * PH) * (unsigned)l + (unsigned)(NG * k + q) + 1u); };
+    // ---- all-gather (stage st = 2 l + odd): every owner's flag, the RMSNorm scales, release the consumer waves
+    auto ev_gather = [&](int l, bool odd, int q) {
+        int lane = lane0; asm volatile("" : "+v"(lane));      // opaque per edge: nothing lane-derived is carried from one edge to the next (the wave has no registers to spare)
+        const EngBParams p = kparams(q);
+        const unsigned tag = tagb(q) + (unsigned)l + 1u, st = 2u * (unsigned)l + (odd ? 1u : 0u);
+        const bool T = l == p.tl_layer; Tl tl = tl0; tl.buf += (size_t)q * (NCU * 32);
+        float* rstd = reinterpret_cast<float*>(lds + L_RSTD(q));
         if (T) tl(odd ? 20 : 8);
         lds_st(&c->gathering, 1u);
         poll_flags256(odd ? p.F1 : p.F0, odd ? tag : tag - 1u, lane, c, p.err);
         if (T) tl(odd ? 21 : 9);
-        lds_st(&c->ag_flag, (unsigned)st + 1u);
+        lds_st(&c->ag_flag[q], st + 1u);
         comm_rstd(odd ? p.SS1 : p.SS0, p.eps, lane, rstd + (odd ? BM : 0));
-        ENG_CFENCE(); lds_st(&c->rs_flag, (unsigned)st + 1u);
+        ENG_CFENCE(); lds_st(&c->rs_flag[q], st + 1u);
         lds_st(&c->gathering, 0u);
-        if (!odd) {
-            {   // this step's q (head h), k, v (KV head g) rows of the CU's two sequences
-                wait_ge(&c->pub_cnt, pc0 + NCONS, c, p.err, ERR_STAGE);
-                lds_st(&c->gathering, 1u);
-                float v[12];
-                sweep<12>(p.G, BM * G_ROW * 8u, tag, [&](int u) { const int i = lane + 64 * u, t = i / 384, r = i - 384 * t, seg = r >> 7, e = r & 127;
-                                                                 return (2 * s + t) * G_ROW + (seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e); },
-                          [&]() { return 0; }, false, v, c, p.err);
-                lds_st(&c->gathering, 0u);
+    };
+#pragma unroll 1
+    for (int l = 0; l < L; l++) {
+#pragma unroll 1
+        for (int q = 0; q < NG; q++) ev_gather(l, false, q);
+#pragma unroll 1
+        for (int q = 0; q < NG; q++) {   // this step's q (head h), k, v (KV head g) rows of the CU's two sequences
+            int lane = lane0; asm volatile("" : "+v"(lane));
+            const EngBParams p = kparams(q);
+            const unsigned tag = tagb(q) + (unsigned)l + 1u;
+            float* qkvn = reinterpret_cast<float*>(lds + L_QKVN(q));
+            wait_ge(&c->pub_cnt, pub(l, 0, q), c, p.err, ERR_STAGE);
+            lds_st(&c->gathering, 1u);
+            float v[12];
+            sweep<12>(p.G, BM * G_ROW * 8u, tag, [&](int u) { const int i = lane + 64 * u, t = i / 384, r = i - 384 * t, seg = r >> 7, e = r & 127;
+                                                             return (2 * s + t) * G_ROW + (seg == 0 ? 128 * h + e : (seg == 1 ? EQD : EQD + EKD) + 128 * g + e); },
+                      [&]() { return 0; }, false, v, c, p.err);
+            lds_st(&c->gathering, 0u);
 #pragma unroll
-                for (int u = 0; u < 12; u++) qkvn[lane + 64 * u] = v[u];
-                ENG_CFENCE(); lds_st(&c->qkv_flag, (unsigned)l + 1u);
-            }
-            if (T) tl(10);
-            {   // attention outputs of head h: one flag per sequence, written by the team that computed it
-                wait_ge(&c->pub_cnt, pc0 + 2 * NCONS, c, p.err, ERR_STAGE);      // (own CU through: nothing can be complete much earlier -- no polling while it computes)
-                lds_st(&c->gathering, 1u);
-                poll_flags(p.FO, 512, 4 * BM, [&](int i) { return 4 * g * BM + i; }, tag, lane, c, p.err);      // the group's four heads x 16 sequences: wo's K range on this CU
-                lds_st(&c->gathering, 0u);
-                lds_st(&c->wo_flag, (unsigned)l + 1u);
-            }
-            if (T) tl(11);
-            {   // wo: the 8 planes (one per XCD group; each finishing wave of a producer flags its own tile) of the CU's 12 columns, fixed-order sum + residual -> the
-                // post-attention stream, published as the w1|w3 input
-                wait_ge(&c->pub_cnt, pc0 + 3 * NCONS, c, p.err, ERR_STAGE);
-                lds_st(&c->gathering, 1u);
-                comm_reduce_poll<NPWB>(p.PW, NPWB * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own0, own1, tag, c, p.err);
-                if (T) tl(13);
-                lds_st(&c->gathering, 0u);
-                ENG_CFENCE();
-                if (!((p.flags & 16384) && b == 7 && l == 1))      // (flag 16384 = FAULT INJECTION: workgroup 7 loses a publish)
-                    comm_publish_rows(p, lane, own1, gwt + (l * 2 + 1) * 16, p.XH1, p.SS1, p.F1, tag);
-            }
+            for (int u = 0; u < 12; u++) qkvn[lane + 64 * u] = v[u];
+            ENG_CFENCE(); lds_st(&c->qkv_flag[q], (unsigned)l + 1u);
+            if (l == p.tl_layer) { Tl tl = tl0; tl.buf += (size_t)q * (NCU * 32); tl(10); }
+        }
+#pragma unroll 1
+        for (int q = 0; q < NG; q++) {   // attention outputs of head h: one flag per sequence, written by the team that computed it
+            int lane = lane0; asm volatile("" : "+v"(lane));
+            const EngBParams p = kparams(q);
+            const unsigned tag = tagb(q) + (unsigned)l + 1u;
+            wait_ge(&c->pub_cnt, pub(l, 1, q), c, p.err, ERR_STAGE);      // (own CU through: nothing can be complete much earlier -- no polling while it computes)
+            lds_st(&c->gathering, 1u);
+            poll_flags(p.FO, 512, 4 * BM, [&](int i) { return 4 * g * BM + i; }, tag, lane, c, p.err);      // the group's four heads x 16 sequences: wo's K range on this CU
+            lds_st(&c->gathering, 0u);
+            lds_st(&c->wo_flag[q], (unsigned)l + 1u);
+            if (l == p.tl_layer) { Tl tl = tl0; tl.buf += (size_t)q * (NCU * 32); tl(11); }
+        }
+#pragma unroll 1
+        for (int q = 0; q < NG; q++) {   // wo: the 8 planes (one per XCD group) of the CU's 12 columns, fixed-order sum + residual -> the post-attention stream, published as the w1|w3 input
+            int lane = lane0; asm volatile("" : "+v"(lane));
+            const EngBParams p = kparams(q);
+            const unsigned tag = tagb(q) + (unsigned)l + 1u;
+            float* own0 = reinterpret_cast<float*>(lds + L_OWN(q)); float* own1 = own0 + OWN * BM;
+            const bool T = l == p.tl_layer; Tl tl = tl0; tl.buf += (size_t)q * (NCU * 32);
+            wait_ge(&c->pub_cnt, pub(l, 2, q), c, p.err, ERR_STAGE);
+            lds_st(&c->gathering, 1u);
+            comm_reduce_poll<NPWB>(p.PW, NPWB * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own0, own1, tag, c, p.err);
+            if (T) tl(13);
+            lds_st(&c->gathering, 0u);
+            ENG_CFENCE();
+            if (!((p.flags & 16384) && b == 7 && l == 1 && q == 0))      // (flag 16384 = FAULT INJECTION: workgroup 7 loses a publish)
+                comm_publish_rows(p, lane, own1, gwt + (l * 2 + 1) * 16, p.XH1, p.SS1, p.F1, tag);
             if (T) tl(14);
-        } else {
-            {   // SwiGLU outputs of the XCD group: this CU's flag, then the group's 32
-                wait_ge(&c->pub_cnt, pc0 + 4 * NCONS, c, p.err, ERR_STAGE);
-                if (lane == 0) st_u32(make_srd(p.FA, NCU * 4u), (unsigned)(g * 32 + j) * 4u, tag, xloc);
-                lds_st(&c->gathering, 1u);
-                poll_flags(p.FA, NCU, 32, [&](int i) { return g * 32 + i; }, tag, lane, c, p.err);
-                lds_st(&c->gathering, 0u);
-                lds_st(&c->xa_flag, (unsigned)l + 1u);
-            }
-            if (T) tl(22);
-            {   // w2: the 8 planes (each finishing wave of a producer flags its own tile) -> the layer's output; published as the next layer's q|k|v input, or (last layer)
-                // as the lm_head launch's input
-                wait_ge(&c->pub_cnt, pc0 + 5 * NCONS, c, p.err, ERR_STAGE);
-                if (T) tl(23);
-                lds_st(&c->gathering, 1u);
-                comm_reduce_poll<NP2>(p.P2, NP2 * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own1, own0, tag, c, p.err);
-                if (T) tl(24);
-                lds_st(&c->gathering, 0u);
-                ENG_CFENCE();
-                if (l + 1 < L) comm_publish_rows(p, lane, own0, gwt + ((l + 1) * 2) * 16, p.XH0, p.SS0, p.F0, tag);
-                else comm_publish_final(p, lane, own0, gwt + (L * 2) * 16);
-            }
+        }
+#pragma unroll 1
+        for (int q = 0; q < NG; q++) ev_gather(l, true, q);
+#pragma unroll 1
+        for (int q = 0; q < NG; q++) {   // SwiGLU outputs of the XCD group: this CU's flag, then the group's 32
+            int lane = lane0; asm volatile("" : "+v"(lane));
+            const EngBParams p = kparams(q);
+            const unsigned tag = tagb(q) + (unsigned)l + 1u;
+            wait_ge(&c->pub_cnt, pub(l, 3, q), c, p.err, ERR_STAGE);
+            if (lane == 0) st_u32(make_srd(p.FA, NCU * 4u), (unsigned)(g * 32 + j) * 4u, tag, xloc);
+            lds_st(&c->gathering, 1u);
+            poll_flags(p.FA, NCU, 32, [&](int i) { return g * 32 + i; }, tag, lane, c, p.err);
+            lds_st(&c->gathering, 0u);
+            lds_st(&c->xa_flag[q], (unsigned)l + 1u);
+            if (l == p.tl_layer) { Tl tl = tl0; tl.buf += (size_t)q * (NCU * 32); tl(22); }
+        }
+#pragma unroll 1
+        for (int q = 0; q < NG; q++) {   // w2: the 8 planes -> the layer's output; published as the next layer's q|k|v input, or (last layer) as the lm_head launch's input
+            int lane = lane0; asm volatile("" : "+v"(lane));
+            const EngBParams p = kparams(q);
+            const unsigned tag = tagb(q) + (unsigned)l + 1u;
+            float* own0 = reinterpret_cast<float*>(lds + L_OWN(q)); float* own1 = own0 + OWN * BM;
+            const bool T = l == p.tl_layer; Tl tl = tl0; tl.buf += (size_t)q * (NCU * 32);
+            wait_ge(&c->pub_cnt, pub(l, 4, q), c, p.err, ERR_STAGE);
+            if (T) tl(23);
+            lds_st(&c->gathering, 1u);
+            comm_reduce_poll<NP2>(p.P2, NP2 * ED * BM * 4u, [&](int pl) { return (unsigned)pl * (ED * BM * 4u); }, lane, own1, own0, tag, c, p.err);
+            if (T) tl(24);
+            lds_st(&c->gathering, 0u);
+            ENG_CFENCE();
+            if (l + 1 < L) comm_publish_rows(p, lane, own0, gwt + ((l + 1) * 2) * 16, p.XH0, p.SS0, p.F0, tag);
+            else comm_publish_final(p, lane, own0, gwt + (L * 2) * 16);
             if (T) tl(25);
         }
     }
@@ -428,15 +521,6 @@ __device__ __forceinline__ void b16_comm(const EngBParams& p, BCtl* c, unsigned 
 #define B16_PHASE __device__ __attribute__((noinline))
 #endif
 constexpr int CB_LAYER = 5;      // workgroup barriers among the consumer waves per layer: q|k|v, wo, w1|w3 (2), w2
-__device__ __forceinline__ EngBParams kparams() {      // by value from the constant address space: the fields a phase uses become scalar loads
-#if defined(__HIP_DEVICE_COMPILE__)
-    return *(const __attribute__((address_space(4))) EngBParams*)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-    return EngBParams{};
-#endif
-}
-__device__ __forceinline__ unsigned char* lds_base() { extern __shared__ __attribute__((aligned(16))) unsigned char lds_[]; return lds_; }
-__device__ __forceinline__ unsigned b16_tag_base(const EngBParams& p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)((*p.serial + 1u) * 64u)); }
 
 struct BCons {
     const EngBParams& p; BCtl* c; unsigned char* lds; int cw, lane;
@@ -458,13 +542,17 @@ struct BCons {
         return lds + BL_RING + slot * SLOT_BYTES + cw * share_bytes;
     }
     __device__ __forceinline__ void slot_release(int slot) { ENG_CFENCE(); if (lane == 0) __hip_atomic_fetch_add(&c->ring_done[slot], 1u, RLX, WG); }
-    // NB activation blocks blk0 .. blk0 + NB - 1 of a fragment buffer -> registers (hi, lo), and their -136 sum(x) rows -> this wave's CB lines
+    // NB activation blocks blk0 .. blk0 + NB - 1 of a fragment buffer -> registers (hi, lo), and their -136 sum(x) rows -> this wave's CB lines.  Two halves: the loads
+    // (a_issue) and what needs their data (a_finish).  One group per launch: both behind the records, which wait in registers for the edge.  Two groups: the edge has
+    // usually resolved while the other group's phase ran, so the loads go out FIRST and the records are fetched from the ring under their latency.
     template <int NB>
-    __device__ __forceinline__ void load_a(const unsigned char* buf, unsigned bytes, int blk0, bf16x8 (&ah)[NB], bf16x8 (&al)[NB]) {
+    __device__ __forceinline__ void a_issue(const unsigned char* buf, unsigned bytes, int blk0, u32x4 (&rh)[NB], u32x4 (&rl)[NB]) {
         const srd_t sd = make_srd(buf, bytes);
-        u32x4 rh[NB], rl[NB];
 #pragma unroll
         for (int i = 0; i < NB; i++) { rh[i] = ld_frag(sd, (unsigned)(((blk0 + i) * 2) * FRAG + lane * 16)); rl[i] = ld_frag(sd, (unsigned)(((blk0 + i) * 2 + 1) * FRAG + lane * 16)); }
+    }
+    template <int NB>
+    __device__ __forceinline__ void a_finish(const u32x4 (&rh)[NB], const u32x4 (&rl)[NB], bf16x8 (&ah)[NB], bf16x8 (&al)[NB]) {
         float* cb = reinterpret_cast<float*>(lds + BL_CB) + cw * 8 * BM;
         unsigned k136 = 0xC308C308u; asm volatile("" : "+v"(k136));      // bf16(-136) x 2, opaque: rebuilt here (4 v_mov), never carried across phases
         u32x4 mm; mm.x = mm.y = mm.z = mm.w = k136;
@@ -479,32 +567,41 @@ struct BCons {
 };
 #define B16_PROLOGUE                                                                                                          \
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));      /* the lane index from the EXEC mask (all 64 lanes are active here), as VOLATILE asm: the builtin form was computed once before the layer loop, spilled, and reloaded (scratch_load + vmcnt(0)) at every phase entry */ \
-    const EngBParams p = kparams(); unsigned char* lds = lds_base();                                                          \
+    const int q = NG > 1 ? __builtin_amdgcn_readfirstlane(q_) : 0;                                                            \
+    const EngBParams p = kparams(q); unsigned char* lds = lds_base();                                                         \
     const int cw = __builtin_amdgcn_readfirstlane(cw_), l = __builtin_amdgcn_readfirstlane(l_);                               \
     BCtl* c = reinterpret_cast<BCtl*>(lds + BL_CTL); BCons cs(p, lds, cw, lane);                                             \
     const int b = blockIdx.x, g = b & 7, j = b >> 3, h = 4 * g + (j >> 3), s = j & 7, n = lane & 15, y = lane >> 4;           \
-    const unsigned tag = b16_tag_base(p) + (unsigned)l + 1u, P0 = (unsigned)l * PK_LAYER;                                     \
+    const unsigned tag = b16_tag_base(p) + (unsigned)l + 1u;                                                                  \
+    /* the one global order of the launch: phases, consumer barriers and ring packets before layer l (NG groups per phase) */  \
+    const unsigned ordL = (unsigned)l * (NG * PH), cbL = (unsigned)l * (NG * CB_LAYER), pkL = (unsigned)l * (NG * PK_LAYER);  \
     const bool xloc = (p.flags & 128) != 0 && lds_ld(&c->xcd_ok) != 0;                                                       \
     const EngLayerTab* Lt = reinterpret_cast<const EngLayerTab*>(lds + BL_TAB) + l;                                           \
-    Tl tl; tl.on = p.tl != nullptr && lane == 0 && l == p.tl_layer && cw == 0; tl.buf = p.tl ? p.tl + (size_t)blockIdx.x * 32 : nullptr; \
-    (void)g; (void)j; (void)h; (void)s; (void)n; (void)y; (void)tag; (void)P0; (void)xloc; (void)Lt;
+    Tl tl; tl.on = p.tl != nullptr && lane == 0 && l == p.tl_layer && cw == 0; tl.buf = p.tl ? p.tl + (size_t)blockIdx.x * 32 + (size_t)q * (NCU * 32) : nullptr;      /* (group B's stamps: a second [256][32] table) */ \
+    (void)g; (void)j; (void)h; (void)s; (void)n; (void)y; (void)tag; (void)ordL; (void)cbL; (void)pkL; (void)xloc; (void)Lt;
+// NG > 1: before a wave's first store into a time-shared LDS region of phase k, all twelve waves have left the previous phase of the global order (its finishing waves
+// may still have been reading the region: there is no cross-CU edge between group A's phase and group B's).  One LDS poll; the records, the edge and the MFMAs come first.
+#define B16_GUARD(k) do { if (NG > 1) wait_ge(&c->pub_cnt, (unsigned)NCONS * (ordL + (unsigned)(NG * (k)) + (unsigned)q), c, p.err, ERR_CBAR); } while (0)
 
 // ================= q|k|v: 16 + 8 weight rows x K 3072, K split over the 12 waves =================
-B16_PHASE void ph_qkv(int cw_, int lane, int l_) {
+template <int NG, bool KVR>
+B16_PHASE void ph_qkv(int cw_, int lane, int l_, int q_) {
     B16_PROLOGUE
     unsigned char* part = lds + BL_PART;
+    const unsigned P0 = pkL + (unsigned)(q * QKV_PK);
     {
         // this wave's 8 step records (K-steps 4 cw .. 4 cw + 3 of the 16-row q tile and of the 8-row k|v tile) -> registers BEFORE the input exists; the slots are free again
-        RawRec rq[4];
+        RawRec rq[4]; u32x4 xh[8], xl[8];
+        if (NG > 1) { wait_ge(&c->ag_flag[q], 2u * (unsigned)l + 1u, c, p.err, ERR_STAGE); cs.a_issue<8>(p.XH0, XH_BYTES, 8 * cw, xh, xl); }
 #pragma unroll
         for (int pk = 0; pk < 2; pk++) {
             int sl; const unsigned char* bb = cs.slot_wait(P0 + pk, 2 * REC, sl);
             rq[2 * pk] = rec_load(bb, false, lane); rq[2 * pk + 1] = rec_load(bb + REC, false, lane);
             cs.slot_release(sl);
         }
-        wait_ge(&c->ag_flag, 2u * (unsigned)l + 1u, c, p.err, ERR_STAGE);
+        if (NG == 1) { wait_ge(&c->ag_flag[q], 2u * (unsigned)l + 1u, c, p.err, ERR_STAGE); cs.a_issue<8>(p.XH0, XH_BYTES, 8 * cw, xh, xl); }
         bf16x8 ah[8], al[8];
-        cs.load_a<8>(p.XH0, XH_BYTES, 8 * cw, ah, al);
+        cs.a_finish<8>(xh, xl, ah, al);
         tl(0);
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
         int sl2; const unsigned char* b2 = cs.slot_wait(P0 + 2, 4 * REC_H, sl2);      // the 8-row tile's records stay in the ring (landed long ago)
@@ -515,16 +612,18 @@ B16_PHASE void ph_qkv(int cw_, int lane, int l_) {
             a1 = rec_mma(rec_load(b2 + r * REC_H, true, lane), ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], c0, c1, a1);
         }
         cs.slot_release(sl2);
+        B16_GUARD(0);
         *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + lane * 16) = a0;
         if (n < 8) *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 1024 + (y * 8 + n) * 16) = a1;
     }
-    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 1)));
+    cs.cbarrier((unsigned)NCONS * (cbL + (unsigned)q + 1u));
     if (cw < 2) {      // wave 0: the 16 q rows; wave 1: 4 k + 4 v rows -- sum the 12 K slices (fixed order), RMSNorm scale, RoPE at each sequence's position, publish
-        const float* rstd = reinterpret_cast<const float*>(lds + BL_RSTD);
-        const float* ropef = reinterpret_cast<const float*>(lds + BL_ROPE);      // q cos [8][16] | q sin [8][16] | k cos [2][16] | k sin [2][16]
-        const int* posl = reinterpret_cast<const int*>(lds + BL_POS);
+        const float* rstd = reinterpret_cast<const float*>(lds + L_RSTD(q));
+        const float* ropef = reinterpret_cast<const float*>(lds + L_ROPE(q));      // q cos [8][16] | q sin [8][16] | k cos [2][16] | k sin [2][16]
+        const int* posl = reinterpret_cast<const int*>(lds + L_POS(q));
+        const int* kvr = reinterpret_cast<const int*>(lds + L_KVR(q));
         const int nn = cw == 0 ? n : (n & 7);
-        wait_ge(&c->rs_flag, 2u * (unsigned)l + 1u, c, p.err, ERR_STAGE);
+        wait_ge(&c->rs_flag[q], 2u * (unsigned)l + 1u, c, p.err, ERR_STAGE);
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < NCONS; w++) a += *reinterpret_cast<const f32x4*>(part + w * PART_WAVE + (cw == 0 ? lane * 16 : 1024 + (y * 8 + nn) * 16));
@@ -544,7 +643,7 @@ B16_PHASE void ph_qkv(int cw_, int lane, int l_) {
             else if (n < 8) {
                 const int col = 128 * g + 4 * j + (nn & 3);
                 st_u64(gd, (unsigned)(m * G_ROW + (nn < 4 ? EQD : EQD + EKD) + col) * 8u, __float_as_uint(yv), tag, xloc);
-                if (m < p.n_rows) (nn < 4 ? kc : vc)[(size_t)m * p.kv_seq_stride + (size_t)g * p.max_seq * EHD + (size_t)posl[m] * EHD + 4 * j + (nn & 3)] = yv;      // the cache rows later steps read
+                if (m < p.n_rows) (nn < 4 ? kc : vc)[(size_t)(KVR ? kvr[m] : m) * p.kv_seq_stride + (size_t)g * p.max_seq * EHD + (size_t)posl[m] * EHD + 4 * j + (nn & 3)] = yv;      // the cache rows later steps read
             }
         }
     }
@@ -553,10 +652,11 @@ B16_PHASE void ph_qkv(int cw_, int lane, int l_) {
 }
 
 // ================= attention: head h of sequence 2 s + team, six waves, per-wave online softmax over the wave's keys =================
-B16_PHASE void ph_attn(int cw_, int lane, int l_) {
+template <int NG, bool KVR>
+B16_PHASE void ph_attn(int cw_, int lane, int l_, int q_) {
     B16_PROLOGUE
-    const int* posl = reinterpret_cast<const int*>(lds + BL_POS);
-    const float* qkvn = reinterpret_cast<const float*>(lds + BL_QKVN);
+    const int* posl = reinterpret_cast<const int*>(lds + L_POS(q));
+    const float* qkvn = reinterpret_cast<const float*>(lds + L_QKVN(q));
     float* po = reinterpret_cast<float*>(lds + BL_PO); float* ml = reinterpret_cast<float*>(lds + BL_ML); float* ofin = reinterpret_cast<float*>(lds + BL_OF);
     const int team = cw / 6, tw = cw - 6 * team, msq = 2 * s + team;
     const bool seq_ok = msq < p.n_rows;
@@ -564,7 +664,8 @@ B16_PHASE void ph_attn(int cw_, int lane, int l_) {
     const int pos = __builtin_amdgcn_readfirstlane(posl[msq]);
     const int j_lo = p.window >= 0 ? max(0, pos - p.window) : 0, n_old = seq_ok ? pos - j_lo : 0, last_old = max(n_old - 1, 0);
     // uniform bases in SGPRs (the table lives in LDS: a ds_read result is a VGPR to the compiler) -> one 32-bit VGPR offset per load
-    const size_t kvo = (size_t)min(msq, max(p.n_rows - 1, 0)) * p.kv_seq_stride + (size_t)g * p.max_seq * EHD;
+    const int kvrow = KVR ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lds + L_KVR(q))[msq]) : min(msq, max(p.n_rows - 1, 0));      // (KVR: rows >= n_rows hold a valid slice too, see the start-up)
+    const size_t kvo = (size_t)kvrow * p.kv_seq_stride + (size_t)g * p.max_seq * EHD;
     const u64 kcb = (u64)(uintptr_t)Lt->kc, vcb = (u64)(uintptr_t)Lt->vc;
     const gf_p kc = (gf_p)(uintptr_t)(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kcb >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kcb)) + kvo;
     const gf_p vc = (gf_p)(uintptr_t)(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(vcb >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)vcb)) + kvo;
@@ -585,7 +686,7 @@ B16_PHASE void ph_attn(int cw_, int lane, int l_) {
         }
     };
     if (nround > 0) kvload(0);
-    wait_ge(&c->qkv_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+    wait_ge(&c->qkv_flag[q], (unsigned)l + 1u, c, p.err, ERR_STAGE);
     tl(2);
     const float* qn = qkvn + team * 384;
     float qv[16];
@@ -625,9 +726,10 @@ B16_PHASE void ph_attn(int cw_, int lane, int l_) {
         l_run = l_run * alpha + pe; o.x = fmaf(pe, vv.x, o.x * alpha); o.y = fmaf(pe, vv.y, o.y * alpha);
         m_run = mn;
     }
+    B16_GUARD(1);
     *reinterpret_cast<float2*>(po + cw * 128 + lane * 2) = o;
     if (lane == 0) { ml[2 * cw] = m_run; ml[2 * cw + 1] = l_run; }
-    cs.tbarrier(team, (unsigned)(6 * (l + 1)));
+    cs.tbarrier(team, 6u * ((unsigned)(NG * l + q) + 1u));
     if (tw == 0) {      // combine the team's six partials (fixed order), normalise, publish head h's output of sequence msq as wo's A fragments (hi + lo)
         float M = -INFINITY;
 #pragma unroll
@@ -660,30 +762,34 @@ B16_PHASE void ph_attn(int cw_, int lane, int l_) {
 }
 
 // ================= wo: rows [96 j, +96) x the 512 columns of the XCD group's four heads -> plane g =================
-B16_PHASE void ph_wo(int cw_, int lane, int l_) {
+template <int NG, bool KVR>
+B16_PHASE void ph_wo(int cw_, int lane, int l_, int q_) {
     B16_PROLOGUE
     unsigned char* part = lds + BL_PART;
+    const unsigned P0 = pkL + (unsigned)(NG * QKV_PK + q * WO_PK);
     {
         const int tile = cw % 6, kh = cw / 6;
-        RawRec rw[4];      // tile cw % 6, K-steps 4 (cw / 6) .. + 3: in registers before the attention outputs exist
+        RawRec rw[4]; u32x4 xh[8], xl[8];      // tile cw % 6, K-steps 4 (cw / 6) .. + 3: in registers before the attention outputs exist
+        if (NG > 1) { wait_ge(&c->wo_flag[q], (unsigned)l + 1u, c, p.err, ERR_STAGE); cs.a_issue<8>(p.XO + (size_t)(4 * g) * XO_HEAD, 4 * XO_HEAD, 8 * kh, xh, xl); }
 #pragma unroll
         for (int i = 0; i < WO_PK; i++) {
-            int sl; const unsigned char* bb = cs.slot_wait(P0 + QKV_PK + i, 2 * REC, sl);
+            int sl; const unsigned char* bb = cs.slot_wait(P0 + i, 2 * REC, sl);
             rw[2 * i] = rec_load(bb, false, lane); rw[2 * i + 1] = rec_load(bb + REC, false, lane);
             cs.slot_release(sl);
         }
-        wait_ge(&c->wo_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+        if (NG == 1) { wait_ge(&c->wo_flag[q], (unsigned)l + 1u, c, p.err, ERR_STAGE); cs.a_issue<8>(p.XO + (size_t)(4 * g) * XO_HEAD, 4 * XO_HEAD, 8 * kh, xh, xl); }      // heads 4 g .. 4 g + 3 are contiguous: 16 blocks, this wave's half
         bf16x8 ah[8], al[8];
-        cs.load_a<8>(p.XO + (size_t)(4 * g) * XO_HEAD, 4 * XO_HEAD, 8 * kh, ah, al);      // heads 4 g .. 4 g + 3 are contiguous: 16 blocks, this wave's half
+        cs.a_finish<8>(xh, xl, ah, al);
         tl(4);
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; r++) a = rec_mma(rw[r], ah[2 * r], al[2 * r], ah[2 * r + 1], al[2 * r + 1], cs.cb_read(2 * r), cs.cb_read(2 * r + 1), a);
         // (q|k|v's partials in this region are dead: its finishing waves published before attention could start; w1|w3 writes here only after the h1 all-gather, which
         // needs every wo tile of every CU stored)
+        B16_GUARD(2);
         *reinterpret_cast<f32x4*>(part + (tile * 2 + kh) * 1024 + lane * 16) = a;
     }
-    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 2)));
+    cs.cbarrier((unsigned)NCONS * (cbL + (unsigned)(NG + q) + 1u));
     if (cw < 6) {      // wave t finishes tile t: the two K halves in a fixed order
         const f32x4 a = *reinterpret_cast<const f32x4*>(part + (cw * 2) * 1024 + lane * 16) + *reinterpret_cast<const f32x4*>(part + (cw * 2 + 1) * 1024 + lane * 16);
         st_f4(make_srd(p.PW + (size_t)g * ED * BM, ED * BM * 4u), (unsigned)((96 * j + 16 * cw + n) * BM + 4 * y) * 4u, a);      // the owner polls the slots themselves (comm_reduce_poll)
@@ -693,14 +799,17 @@ B16_PHASE void ph_wo(int cw_, int lane, int l_) {
 }
 
 // ================= w1|w3: 72 interleaved gate / up rows x K 3072 -> 36 SwiGLU outputs x 16 sequences =================
-B16_PHASE void ph_w13(int cw_, int lane, int l_) {
+template <int NG, bool KVR>
+B16_PHASE void ph_w13(int cw_, int lane, int l_, int q_) {
     B16_PROLOGUE
     unsigned char* part = lds + BL_PART;
-    float* sg = reinterpret_cast<float*>(lds + BL_CB);           // SwiGLU outputs [16 m][36] (the CB lines are dead behind the first barrier)
+    // SwiGLU outputs [16 m][36].  One group: in the CB lines, which are dead behind the first barrier.  NG > 1: the other group's pass writes ITS CB lines while waves 0..2
+    // still read these -> in the group's own q / k / v block instead (3 KB, dead between the group's attention and the next layer's granule sweep)
+    float* sg = reinterpret_cast<float*>(lds + (NG == 1 ? BL_CB : L_QKVN(q)));
     {
         // tile 0's and tile 1's records (8 of the wave's 20) wait in registers while the post-attention stream is still on its way; afterwards one tile is fetched ahead
         // of the one being multiplied
-        const unsigned PW13 = P0 + QKV_PK + WO_PK;
+        const unsigned PW13 = pkL + (unsigned)(NG * (QKV_PK + WO_PK) + q * W13_PK);
         RawRec ra[4], rb[4];
         // (the two f16 scales of a record are kept as ONE register -- opaque to the compiler, which otherwise holds the halves in two: with eight records waiting in
         // registers next to the 64 registers of A fragments that was 8 VGPRs too many, spilled and reloaded inside the multiply loop)
@@ -719,11 +828,14 @@ B16_PHASE void ph_w13(int cw_, int lane, int l_) {
             for (int r = 0; r < 4; r++) { rr[r] = rec_load(bb + r * REC_H, true, lane); asm volatile("" : "+v"(rr[r].sc)); }
             cs.slot_release(sl);
         };
+        u32x4 xh[8], xl[8];
+        if (NG > 1) { wait_ge(&c->ag_flag[q], 2u * (unsigned)l + 2u, c, p.err, ERR_STAGE); cs.a_issue<8>(p.XH1, XH_BYTES, 8 * cw, xh, xl); }
         fetch_tile(0, ra); fetch_tile(1, rb);
-        wait_ge(&c->ag_flag, 2u * (unsigned)l + 2u, c, p.err, ERR_STAGE);
+        if (NG == 1) { wait_ge(&c->ag_flag[q], 2u * (unsigned)l + 2u, c, p.err, ERR_STAGE); cs.a_issue<8>(p.XH1, XH_BYTES, 8 * cw, xh, xl); }
         bf16x8 ah[8], al[8];
-        cs.load_a<8>(p.XH1, XH_BYTES, 8 * cw, ah, al);
+        cs.a_finish<8>(xh, xl, ah, al);
         tl(6);
+        B16_GUARD(3);
         auto mul_tile = [&](const RawRec (&rr)[4]) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -740,12 +852,12 @@ B16_PHASE void ph_w13(int cw_, int lane, int l_) {
         { const f32x4 a = mul_tile(ra); if (n < 8) *reinterpret_cast<f32x4*>(part + cw * PART_WAVE + 4096 + (y * 8 + n) * 16) = a; }
     }
     tl(27);
-    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 3)));      // (also: every wave is through with its CB lines -> the region becomes the SwiGLU scratch)
+    cs.cbarrier((unsigned)NCONS * (cbL + (unsigned)(2 * NG + 2 * q) + 1u));      // (also: every wave is through with its CB lines -> the region becomes the SwiGLU scratch)
     tl(28);
     if (cw < 5) {       // wave t finishes tile t: K slices summed in a fixed order, RMSNorm scale, SiLU(gate) * up -> sg[m][col]
-        const float* rstd = reinterpret_cast<const float*>(lds + BL_RSTD);
+        const float* rstd = reinterpret_cast<const float*>(lds + L_RSTD(q));
         const bool hf = cw == 4;
-        wait_ge(&c->rs_flag, 2u * (unsigned)l + 2u, c, p.err, ERR_STAGE);
+        wait_ge(&c->rs_flag[q], 2u * (unsigned)l + 2u, c, p.err, ERR_STAGE);
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < NCONS; w++) a += *reinterpret_cast<const f32x4*>(part + w * PART_WAVE + (hf ? 4096 + (y * 8 + (n & 7)) * 16 : cw * 1024 + lane * 16));
@@ -757,7 +869,7 @@ B16_PHASE void ph_w13(int cw_, int lane, int l_) {
         }
     }
     tl(29);
-    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 4)));
+    cs.cbarrier((unsigned)NCONS * (cbL + (unsigned)(2 * NG + 2 * q) + 2u));
     tl(30);
     if (cw < 3 && lane < 48) {      // 144 pieces of four columns x one sequence -> bf16 hi + lo, 8 bytes each, into the group's fragment buffer
         const int it = 48 * cw + lane, m = it & 15, hc = it >> 4;
@@ -774,23 +886,27 @@ B16_PHASE void ph_w13(int cw_, int lane, int l_) {
 }
 
 // ================= w2: rows [96 j, +96) x the XCD group's 1152 columns -> plane g =================
-B16_PHASE void ph_w2(int cw_, int lane, int l_) {
+template <int NG, bool KVR>
+B16_PHASE void ph_w2(int cw_, int lane, int l_, int q_) {
     B16_PROLOGUE
     unsigned char* part = lds + BL_PART;
+    const unsigned P0 = pkL + (unsigned)(NG * PK_LAYER_M + q * W2_PK);
     {
         const int ksl = cw % 6, tg = cw / 6;
-        RawRec r2[9];      // this wave's 3 K-steps of its 3 tiles -> registers while the SwiGLU outputs of the XCD group are still being exchanged
+        RawRec r2[9]; u32x4 xh[6], xl[6];      // this wave's 3 K-steps of its 3 tiles -> registers while the SwiGLU outputs of the XCD group are still being exchanged
+        if (NG > 1) { wait_ge(&c->xa_flag[q], (unsigned)l + 1u, c, p.err, ERR_STAGE); cs.a_issue<6>(p.XA + (size_t)g * XA_GROUP, XA_GROUP, 6 * ksl, xh, xl); }
 #pragma unroll
         for (int i = 0; i < W2_PK; i++) {
-            int sl; const unsigned char* bb = cs.slot_wait(P0 + PK_LAYER_M + i, 3 * REC, sl);
+            int sl; const unsigned char* bb = cs.slot_wait(P0 + i, 3 * REC, sl);
 #pragma unroll
             for (int k = 0; k < 3; k++) r2[3 * i + k] = rec_load(bb + k * REC, false, lane);
             cs.slot_release(sl);
         }
-        wait_ge(&c->xa_flag, (unsigned)l + 1u, c, p.err, ERR_STAGE);
+        if (NG == 1) { wait_ge(&c->xa_flag[q], (unsigned)l + 1u, c, p.err, ERR_STAGE); cs.a_issue<6>(p.XA + (size_t)g * XA_GROUP, XA_GROUP, 6 * ksl, xh, xl); }
         bf16x8 ah[6], al[6];
-        cs.load_a<6>(p.XA + (size_t)g * XA_GROUP, XA_GROUP, 6 * ksl, ah, al);
+        cs.a_finish<6>(xh, xl, ah, al);
         tl(26);
+        B16_GUARD(4);
 #pragma unroll
         for (int i = 0; i < W2_PK; i++) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -799,7 +915,7 @@ B16_PHASE void ph_w2(int cw_, int lane, int l_) {
             *reinterpret_cast<f32x4*>(part + ((3 * tg + i) * 6 + ksl) * 1024 + lane * 16) = a;
         }
     }
-    cs.cbarrier((unsigned)(NCONS * (CB_LAYER * l + 5)));
+    cs.cbarrier((unsigned)NCONS * (cbL + (unsigned)(4 * NG + q) + 1u));
     if (cw < 6) {      // wave t finishes tile t
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -810,25 +926,34 @@ B16_PHASE void ph_w2(int cw_, int lane, int l_) {
     tl(15);
 }
 
-__device__ __forceinline__ void b16_consumer(const EngBParams& p, BCtl* c, unsigned char* lds, int cw, const int lane0, const Tl& tl) {
+template <int NG, bool KVR>
+__device__ __forceinline__ void b16_consumer(BCtl* c, unsigned char* lds, int cw, const int lane0_) {
     const int b = blockIdx.x, g = b & 7, j = b >> 3, s = j & 7;
-    float* ropef = reinterpret_cast<float*>(lds + BL_ROPE);      // q cos [8][16] | q sin [8][16] | k cos [2][16] | k sin [2][16]
-    int* posl = reinterpret_cast<int*>(lds + BL_POS);
+    const EngBParams p = kparams(0);
     const unsigned tag_base = b16_tag_base(p);
     const int half = EHD / 2;
-    {   // start-up: positions, RoPE factors (wave 0: the CU's 8 q pairs; wave 1: its 2 k pairs), norm-weight table, XCD check
-        if (cw == 0) {
-            const int m = lane0 & 15;
-            const int pm = m < p.n_rows ? p.pos[m] : 0;
-            if (lane0 < 16) posl[m] = pm;
+    {   // start-up: positions, RoPE factors (wave 0: the CU's 8 q pairs; wave 1: its 2 k pairs), cache slices, norm-weight table, XCD check
+#pragma unroll 1
+        for (int q = 0; q < NG; q++) {
+            int lane0 = lane0_; asm volatile("" : "+v"(lane0));
+            const EngBParams pq = kparams(q);
+            float* ropef = reinterpret_cast<float*>(lds + L_ROPE(q));      // q cos [8][16] | q sin [8][16] | k cos [2][16] | k sin [2][16]
+            int* posl = reinterpret_cast<int*>(lds + L_POS(q));
+            if (cw == 0) {
+                const int m = lane0 & 15;
+                const int pm = m < pq.n_rows ? pq.pos[m] : 0;
+                if (lane0 < 16) posl[m] = pm;
 #pragma unroll
-            for (int u = 0; u < 2; u++) { const int pr = 2 * (lane0 >> 4) + u; ropef[pr * BM + m] = p.rope_cos[(size_t)pm * half + 8 * s + pr]; ropef[8 * BM + pr * BM + m] = p.rope_sin[(size_t)pm * half + 8 * s + pr]; }
+                for (int u = 0; u < 2; u++) { const int pr = 2 * (lane0 >> 4) + u; ropef[pr * BM + m] = pq.rope_cos[(size_t)pm * half + 8 * s + pr]; ropef[8 * BM + pr * BM + m] = pq.rope_sin[(size_t)pm * half + 8 * s + pr]; }
+            }
+            if (cw == 1 && lane0 < 32) {
+                const int m = lane0 & 15, pr = lane0 >> 4;
+                const int pm = m < pq.n_rows ? pq.pos[m] : 0;
+                ropef[16 * BM + pr * BM + m] = pq.rope_cos[(size_t)pm * half + 2 * j + pr]; ropef[18 * BM + pr * BM + m] = pq.rope_sin[(size_t)pm * half + 2 * j + pr];
+            }
+            if (KVR && cw == 2 && lane0 < 16) reinterpret_cast<int*>(lds + L_KVR(q))[lane0] = pq.kv_row[min(lane0, max(pq.n_rows - 1, 0))];      // (rows past n_rows: the last live row's slice -- their attention reads key 0 of it and is discarded)
         }
-        if (cw == 1 && lane0 < 32) {
-            const int m = lane0 & 15, pr = lane0 >> 4;
-            const int pm = m < p.n_rows ? p.pos[m] : 0;
-            ropef[16 * BM + pr * BM + m] = p.rope_cos[(size_t)pm * half + 2 * j + pr]; ropef[18 * BM + pr * BM + m] = p.rope_sin[(size_t)pm * half + 2 * j + pr];
-        }
+        int lane0 = lane0_; asm volatile("" : "+v"(lane0));
         const EngLayerTab* tab = reinterpret_cast<const EngLayerTab*>(lds + BL_TAB);
         float* gwt = reinterpret_cast<float*>(lds + BL_GW);
         const bool xchg = cw == NCONS - 1 && (p.flags & 128) != 0;
@@ -855,19 +980,35 @@ __device__ __forceinline__ void b16_consumer(const EngBParams& p, BCtl* c, unsig
         if (lane0 == 0) __hip_atomic_fetch_add(&c->gw_flag, 1u, RLX, WG);
     }
     wait_ge(&c->gw_flag, (unsigned)NCONS, c, p.err, ERR_STAGE);
+    const int lane0 = lane0_;
 #pragma unroll 1
     for (int l = 0; l < p.n_layers; l++) {
-        ph_qkv(cw, lane0, l);
-        ph_attn(cw, lane0, l);
-        ph_wo(cw, lane0, l);
-        ph_w13(cw, lane0, l);
-        ph_w2(cw, lane0, l);
+        if (NG == 1) {
+            ph_qkv<1, KVR>(cw, lane0, l, 0);
+            ph_attn<1, KVR>(cw, lane0, l, 0);
+            ph_wo<1, KVR>(cw, lane0, l, 0);
+            ph_w13<1, KVR>(cw, lane0, l, 0);
+            ph_w2<1, KVR>(cw, lane0, l, 0);
+        } else {      // group A's phase, then group B's: one computes while the other's edge resolves
+#pragma unroll 1
+            for (int q = 0; q < NG; q++) ph_qkv<NG, KVR>(cw, lane0, l, q);
+#pragma unroll 1
+            for (int q = 0; q < NG; q++) ph_attn<NG, KVR>(cw, lane0, l, q);
+#pragma unroll 1
+            for (int q = 0; q < NG; q++) ph_wo<NG, KVR>(cw, lane0, l, q);
+#pragma unroll 1
+            for (int q = 0; q < NG; q++) ph_w13<NG, KVR>(cw, lane0, l, q);
+#pragma unroll 1
+            for (int q = 0; q < NG; q++) ph_w2<NG, KVR>(cw, lane0, l, q);
+        }
     }
 }
 
-__global__ __launch_bounds__(NTHR, 1) void decode_engine_b16_kernel(const EngBParams p) {
+template <int NG, bool KVR>
+__global__ __launch_bounds__(NTHR, 1) void decode_engine_b16_kernel(const EngBArgs<NG> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     BCtl* c = reinterpret_cast<BCtl*>(lds + BL_CTL);
+    const EngBParams& p = a.g[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < (int)(sizeof(BCtl) / 4)) reinterpret_cast<unsigned*>(c)[tid] = 0u;
     for (int i = tid; i < p.n_layers * (int)(sizeof(EngLayerTab) / 8); i += NTHR) reinterpret_cast<u64*>(lds + BL_TAB)[i] = reinterpret_cast<const u64*>(p.layers)[i];
@@ -877,11 +1018,14 @@ __global__ __launch_bounds__(NTHR, 1) void decode_engine_b16_kernel(const EngBPa
 #ifndef B16_ROLES
 #define B16_ROLES 7
 #endif
-    if (wave == 0) { tl(19); if (B16_ROLES & 1) b16_loader(p, c, (unsigned)(uintptr_t)(lds + BL_RING), lane, tl); }
+    if (wave == 0) { tl(19); if (B16_ROLES & 1) b16_loader<NG>(p, c, (unsigned)(uintptr_t)(lds + BL_RING), lane, tl); }
     else if (wave == 1) {
-        if (B16_ROLES & 2) b16_comm(p, c, lds, lane, tl);
-        if (blockIdx.x == 0 && lane == 0) { const unsigned sv = *p.serial; asm volatile("" ::: "memory"); *p.serial = sv + 1u; }
-    } else if (B16_ROLES & 4) b16_consumer(p, c, lds, wave - 2, lane, tl);
+        if (B16_ROLES & 2) b16_comm<NG>(c, lds, lane, tl);
+        if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NG; q++) { unsigned* sp = a.g[q].serial; const unsigned sv = *sp; asm volatile("" ::: "memory"); *sp = sv + 1u; }
+        }
+    } else if (B16_ROLES & 4) b16_consumer<NG, KVR>(c, lds, wave - 2, lane);
 }
 
 // 256 per-CU partial sums of squares -> 16 (fixed order), the count the launch-based lm_head GEMM's prologue takes
@@ -918,23 +1062,45 @@ hipError_t engb_state_init(unsigned char* st, hipStream_t s) {
     return e;
 }
 int engb_lds_bytes() { return BL_TOTAL; }
+int engb_lds_bytes2() { return BL_TOTAL2; }
 
-hipError_t launch_decode_engine_b16(const EngBParams& p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    if (p.n_rows < 1 || p.n_rows > BM || p.n_layers < 0 || p.n_layers > MAX_LAYERS || !p.stream_wo) return hipErrorInvalidValue;
-    decode_engine_b16_kernel<<<dim3(NCU), dim3(NTHR), BL_TOTAL, s>>>(p);
+// the three forms raise their dynamic-LDS limit once, all together (hipFuncSetAttribute is not something to do inside a stream capture: vox_api.cpp calls this from
+// engb_prepare, before any graph holds a launch)
+static bool g_engb_attr_done = false;
+hipError_t engb_prepare_kernels() {
+    if (g_engb_attr_done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) g_engb_attr_done = true;
+    return e;
+}
+template <int NG, bool KVR>
+static hipError_t engb_launch(const EngBArgs<NG>& a, int lds_bytes, hipStream_t s) {
+    hipError_t e = engb_prepare_kernels();
+    if (e != hipSuccess) return e;
+    decode_engine_b16_kernel<NG, KVR><<<dim3(NCU), dim3(NTHR), lds_bytes, s>>>(a);
     return hipGetLastError();
+}
+static bool engb_params_ok(const EngBParams& p) { return p.n_rows >= 1 && p.n_rows <= BM && p.n_layers >= 0 && p.n_layers <= MAX_LAYERS && p.stream_wo != nullptr; }
+hipError_t launch_decode_engine_b16(const EngBParams& p, hipStream_t s) {
+    if (!engb_params_ok(p)) return hipErrorInvalidValue;
+    EngBArgs<1> a; a.g[0] = p;
+    return p.kv_row ? engb_launch<1, true>(a, BL_TOTAL, s) : engb_launch<1, false>(a, BL_TOTAL, s);
+}
+// two groups through one launch: the same weights, layer table (cache slabs: slices are picked through kv_row), RoPE tables and flags; each group its own state block
+hipError_t launch_decode_engine_b16x2(const EngBParams& ga, const EngBParams& gb, hipStream_t s) {
+    if (!engb_params_ok(ga) || !engb_params_ok(gb) || !ga.kv_row || !gb.kv_row) return hipErrorInvalidValue;
+    if (ga.stream != gb.stream || ga.stream_wo != gb.stream_wo || ga.layers != gb.layers || ga.n_layers != gb.n_layers || ga.flags != gb.flags || ga.serial == gb.serial ||
+        ga.kv_seq_stride != gb.kv_seq_stride || ga.max_seq != gb.max_seq) return hipErrorInvalidValue;
+    EngBArgs<2> a; a.g[0] = ga; a.g[1] = gb; a.g[1].err = ga.err; a.g[1].tl = ga.tl; a.g[1].tl_layer = ga.tl_layer;      // one error word per launch (group A's block)
+    return engb_launch<2, true>(a, BL_TOTAL2, s);
 }
 // resident workgroups per CU the runtime grants this kernel (the engine needs its 256 workgroups co-resident: >= 1 on a 256-CU device)
 hipError_t engb_occupancy(int* blocks_per_cu) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = engb_prepare_kernels();
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(decode_engine_b16_kernel), NTHR, BL_TOTAL);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(decode_engine_b16_kernel<2, true>), NTHR, BL_TOTAL2);
 }
 
 }  // namespace vox

@@ -248,6 +248,7 @@ struct EngBParams {
     const float* h_in; int h_stride; int n_rows;      // [n_rows][D] the step's input rows (sequences n_rows..15 of the tile are zeros)
     const float* final_norm;                          // [D]
     const int* pos;                                   // [n_rows] position of every sequence
+    const int* kv_row;                                // null: sequence m's cache slice is slice m of kc / vc; else slice kv_row[m] (device-resident: the wide batch's slots change utterances between launches)
     const float* rope_cos; const float* rope_sin;     // [max_pos][hd/2]
     int max_seq, window; float eps;
     unsigned char *XH0, *XH1;                         // all-gathered streams as MFMA A fragments: [96 blocks][hi, lo][64 lanes] x 16 B
@@ -270,9 +271,14 @@ size_t engb_wo_stream_bytes(int n_layers);            // bytes of the batched en
 void engb_state_carve(unsigned char* state, EngBParams* p);      // point p's edge buffers / flags / serial / err into a state block prepared by engb_state_init
 hipError_t engb_state_init(unsigned char* state, hipStream_t s);      // zeros + the partial planes marked empty: before the first launch and after a failed one
 hipError_t launch_decode_engine_b16(const EngBParams& p, hipStream_t s);
+// TWO groups (2 x <= 16 sequences) through ONE launch, phase by phase: group B computes while group A's hand-off resolves.  Same weights / layer table / RoPE tables / flags,
+// kv_row set in both, one state block (engb_state_bytes) per group; a timeout is reported in group A's err word.
+hipError_t launch_decode_engine_b16x2(const EngBParams& a, const EngBParams& b, hipStream_t s);
 hipError_t engb_occupancy(int* blocks_per_cu);
+hipError_t engb_prepare_kernels();                    // the dynamic-LDS limits of the three launch forms (once; never inside a stream capture)
 hipError_t launch_engb_ssq_fold(const float* ssq256, float* ssq16, hipStream_t s);      // [256][16] -> [16][16] partial sums of squares (fixed order)
 int engb_lds_bytes();
+int engb_lds_bytes2();                                // ... of the two-group launch
 
 // ---- measurement knobs: VOX_* environment snapshot (taken at vox_ctx_create / vox_debug_reload_knobs); launch paths never call getenv
 void knobs_load_once();      // vox_ctx_create: build the snapshot if it does not exist yet (thread-safe)
