@@ -214,12 +214,14 @@ int32_t vox_model_set_t_embed(vox_model* m, const float* t_embed_host);
  * the utterance is decoded again on the per-operator launches (a warning on stderr), the engine is re-armed for the next utterance and switched off after three such
  * strikes.  Environment VOX_ENGINE=0 sets the default to off at load time. */
 int32_t vox_model_set_decode_engine(vox_model* m, int32_t on, int32_t* active_or_null);
-/* Batched decode loop of vox_transcribe_batch (BASELINE configs[3]; the reference's model.rs:938-960 is batch-1): for a batch of ONE 16-row group (n <= 16) the 26
- * decoder layers run as ONE launch of the batched decode-layer engine per step (same eligibility as above); wider batches always take the launch-based step (4 launches
- * per layer and group, the groups' chains forked on side streams: measured faster than back-to-back engine launches).  on = 0 selects the
- * launch-based step for every width, on < 0 only queries.  *active_or_null: is the engine armed for one-group batches; *launches_or_null: engine launches enqueued so
- * far (eager + graph replays) -- the number that says whether a given call used it.  A hand-off timeout inside the engine re-runs the batch on the launch-based step (a
- * warning on stderr); three such strikes switch the engine off for the model.  Environment VOX_BATCH_ENGINE=0: off at load time. */
+/* Batched decode loop of vox_transcribe_batch (BASELINE configs[3] / [4]; the reference's model.rs:938-960 is batch-1): the 26 decoder layers of a step run as ONE
+ * launch of the batched decode-layer engine (same eligibility as above) whenever one or two 16-row groups are active -- a batch of n <= 16 rows (one group per
+ * launch), and in a wider batch's continuous decode the steps with one or two active slot groups (TWO groups per launch: group B's phase runs while group A's
+ * hand-off resolves; DESIGN.md sections 3.3c / 3.3e).  Steps with three or four active groups take the launch-based step (4 launches per layer and group, the groups'
+ * chains forked on side streams: measured faster than engine launches back to back).  on = 0 selects the launch-based step everywhere, on < 0 only queries.
+ * *active_or_null: is the engine armed; *launches_or_null: engine launches enqueued so far (eager + graph replays) -- the number that says whether a given call used
+ * it.  A hand-off timeout inside the engine re-runs the batch (the session, for a wide batch) on the launch-based step (a warning on stderr); three such strikes
+ * switch the engine off for the model.  Environment VOX_BATCH_ENGINE=0: off at load time. */
 int32_t vox_model_set_batch_engine(vox_model* m, int32_t on, int32_t* active_or_null, uint64_t* launches_or_null);
 
 /* Q4VoxtralModel::encode_audio, gguf/model.rs:783-788: mel [128][T] -> [S][dec_dim]; *S = floor(S_enc/4) */
@@ -242,7 +244,8 @@ int32_t vox_transcribe_audio(vox_model* m, const float* samples, size_t n, const
  * n <= 16: one 16-row group, one decode-layer engine launch per step.  n > 16: CONTINUOUS BATCHING -- every utterance is encoded (stacked, packed: no padding to the
  * longest) and prefilled up front; the decode step then runs over 16 .. 64 SLOTS, and a slot whose utterance has its last token takes the next utterance of its
  * host-planned queue inside the same step (token counts are a pure function of the sample count: there is no EOS, gguf/model.rs:936-960), so the groups stay full
- * until the queues run dry.  Ids per utterance do not depend on n, on the slot or on the neighbours (tested at full size). */
+ * until the queues run dry; steps with one or two active groups are one engine launch for all their layers (vox_model_set_batch_engine).  Ids per utterance do not
+ * depend on n, on the slot or on the neighbours (tested at full size). */
 int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
                              int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind);
 

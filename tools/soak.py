@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Soak test of the persistent engines' hand-off protocols (flags 16 bytes apart, partial planes that carry their own validity, tagged granules): the same batch of 16 clips
-and the same single clip transcribed REPS times; every repetition must reproduce the first one's ids bit for bit and no hand-off timeout may be reported.
+and the same single clip transcribed REPS times; every repetition must reproduce the first one's ids bit for bit and no hand-off timeout may be reported.  Then the
+two-group launches (round 5): a ragged 48-clip batch on 32 slots -- two groups per launch while both are active, one group per launch behind that, slots refilled,
+positions up to ~430 -- REPS times against the ids of the launch chains (the interleaved groups time-share LDS regions behind a publish-count guard: a race would show here).
 python tools/soak.py [reps=30]"""
 import os, sys, time
 import numpy as np
@@ -22,4 +24,16 @@ for r in range(reps):
 n_eng = m.set_batch_engine()[1] - eng0
 print(f"soak: {reps} x (16 ragged clips through the batched engine + the longest clip single-stream): {n_eng} batched-engine launches, {sum(len(o) for o in ref)} ids per batch, "
       f"mismatching results {bad}, engine still active {m.set_batch_engine()[0]} / {m.set_decode_engine(True)}, {time.time() - t0:.1f} s")
-sys.exit(1 if bad or not m.set_batch_engine()[0] else 0)
+wide = [pkg.synth.synth_audio(3.0 + 0.56 * ((7 * i) % 48), seed=900 + i) for i in range(48)]      # 3 .. 29.3 s
+os.environ["VOX_BATCH_SLOT_GROUPS"] = "2"; os.environ["VOX_BATCH_CONT_NO_ENGINE"] = "1"
+ref2 = m.transcribe_batch(wide, t)                                   # the forked launch chains
+del os.environ["VOX_BATCH_CONT_NO_ENGINE"]
+eng1 = m.set_batch_engine()[1]; t1 = time.time(); bad2 = 0
+for r in range(reps):
+    out = m.transcribe_batch(wide, t)
+    bad2 += sum(not np.array_equal(a, b) for a, b in zip(out, ref2))
+n_eng2 = m.set_batch_engine()[1] - eng1
+del os.environ["VOX_BATCH_SLOT_GROUPS"]
+print(f"soak: {reps} x (48 ragged clips, 32 slots, continuous batch on the engine forms) against the launch chains' ids: {n_eng2} engine launches (two groups per launch while both are active), "
+      f"{sum(len(o) for o in ref2)} ids per batch, mismatching results {bad2}, engine still active {m.set_batch_engine()[0]}, {time.time() - t1:.1f} s")
+sys.exit(1 if bad or bad2 or not m.set_batch_engine()[0] else 0)
