@@ -15,7 +15,9 @@ tens = {kn: pkg.Q4Tensor.from_q4_bytes(pkg.synth.synth_q4_blocks(rng, kn[0] * kn
 for m in Ms:
     row = []
     for k, n in KN:
-        x = np.random.default_rng(m + k).standard_normal((m, k)).astype(np.float32); dx = ctx.upload(x); dy = ctx.alloc(m * n * 4)
+        x = np.random.default_rng(m + k).standard_normal((m, k)).astype(np.float32)
+        if os.environ.get('VOX_AB_ZERO'): x[:] = 0.0      # (DVFS probe: same instruction stream, no toggling operands)
+        dx = ctx.upload(x); dy = ctx.alloc(m * n * 4)
         t = tens[(k, n)]
         for _ in range(2):
             L.vox_q4_matmul(ctx.h, t.h, C.c_void_p(dx), 1, m, C.c_void_p(dy), 1)

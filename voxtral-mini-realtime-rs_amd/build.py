@@ -53,7 +53,11 @@ def build_all(verbose: bool = False, force: bool = False, tag: str | None = None
 
 
 VARIANTS = {"timeline": ["-DVOX_TIMELINE"],      # measurement builds (tools/timeline.py)
-            "gemm_oldstage": ["-DVOX_GEMM_OLD_STAGING"],      # q4_gemm_kernel with the pre-round-5 LDS staging map (16-way bank conflicts on the writes): same-box A/B
+            "gemm_oldstage": ["-DVOX_GEMM_OLD_STAGING"],
+            # q4_gemm_big_kernel, round-5 A/Bs (tools/gemm_big_ab.py, profiles/r05_gemm_big_slots.txt): the round-4 loop nest (one chain in flight, packed scale FMAs, single A-plane
+            # buffer), the single-buffer form of the product loop, the hand-ordered slot form, and its timing-only ablations (wrong results)
+            "big_serial": ["-DVOX_GEMM_BIG_SERIAL", "-DVOX_GEMM_BIG_PKFMA", "-DVOX_GEMM_BIG_SBUF"], "big_sbuf": ["-DVOX_GEMM_BIG_SBUF"], "big_slots": ["-DVOX_GEMM_BIG_SLOTS"],
+            "big_slots_nomfma": ["-DVOX_GEMM_BIG_SLOTS", "-DVOX_ABL_S_NOMFMA"], "big_slots_nofma": ["-DVOX_GEMM_BIG_SLOTS", "-DVOX_ABL_S_NOFMA"], "big_slots_nods": ["-DVOX_GEMM_BIG_SLOTS", "-DVOX_ABL_S_NODS"],      # q4_gemm_kernel with the pre-round-5 LDS staging map (16-way bank conflicts on the writes): same-box A/B
             # GEMV ablations (tools/gemv_ablate.py; results are wrong by construction, only the timing is read)
             "abl_noscale": ["-DVOX_ABL_NOSCALE"], "abl_nox": ["-DVOX_ABL_NOX"], "abl_wfirst": ["-DVOX_ABL_WFIRST"],      # (abl_wfirst predates the x-first default and is a no-op now)
             "abl_noconsume": ["-DVOX_ABL_NOCONSUME"], "abl_xfirst_resid": ["-DVOX_ABL_XFIRST_RESID_ONLY"], "abl_xfirst_noswiglu": ["-DVOX_ABL_XFIRST_NO_SWIGLU"], "abl_noreduce": ["-DVOX_ABL_NOREDUCE"],

@@ -1777,6 +1777,39 @@ static hipError_t launch_q4_skinny_mt(const GemmParams& p_in, int epi, hipStream
     return hipErrorInvalidValue;
 }
 
+// split_pair with its two subtractions kept SCALAR: packed (v_pk_add_f32) they need (a, b) in a register pair -- for the slotted GEMM's staging that was a round of v_mov
+// from freshly loaded registers at the end of every K step, each behind an s_waitcnt on a load issued moments earlier
+__device__ __forceinline__ void split_pair_np(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = cvt_pk_bf16(a, b);
+    float ra = a - __uint_as_float(hi << 16); asm("" : "+v"(ra));
+    const float rb = b - __uint_as_float(hi & 0xFFFF0000u);
+    lo = cvt_pk_bf16(ra, rb);
+}
+// acc += d * t as FOUR v_fma_f32 (VOX_GEMM_BIG_PKFMA: as the f32x4 elementwise fma, which hipcc lowers to two v_pk_fma_f32): beside MFMAs a packed f32 VALU instruction
+// costs ~22 cycles more than the two plain FMAs it replaces (MI355X_MICROARCH.md, per-instruction constants), and plain v_fma_f32 is 2 cycles per wave on gfx950.  The empty
+// asm keeps the SLP vectoriser from re-packing the four scalars.
+__device__ __forceinline__ f32x4 scale_fma(float d, f32x4 t, f32x4 acc) {
+#ifdef VOX_GEMM_BIG_PKFMA
+    return __builtin_elementwise_fma((f32x4){d, d, d, d}, t, acc);
+#else
+    // (d opaque as an f32 register: with the f16 -> f32 conversion visible hipcc fuses it into v_fma_mix_f32, which measured as the most expensive instruction of the K
+    // step -- removing the 256 of them took a third off the kernel, profiles/r05_gemm_big_slots.txt)
+    float dd = d; asm("" : "+v"(dd));
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { float a = fmaf(dd, t[r], acc[r]); asm("" : "+v"(a)); o[r] = a; }
+    return o;
+#endif
+}
+
+typedef __amdgpu_buffer_rsrc_t vsrd_t;
+typedef unsigned vu32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned vu32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vsrd_t vmake_srd(const void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ float4 vbuf_f4(vsrd_t sd, unsigned voff, unsigned soff) { const vu32x4_t v = __builtin_bit_cast(vu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sd, (int)voff, (int)soff, 0)); return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+__device__ __forceinline__ uint4 vbuf_u4(vsrd_t sd, unsigned voff, unsigned soff) { const vu32x4_t v = __builtin_bit_cast(vu32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sd, (int)voff, (int)soff, 0)); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 vbuf_u2(vsrd_t sd, unsigned voff, unsigned soff) { const vu32x2_t v = __builtin_bit_cast(vu32x2_t, __builtin_amdgcn_raw_buffer_load_b64(sd, (int)voff, (int)soff, 0)); return make_uint2(v.x, v.y); }
+
 // ---- large-M MFMA GEMM (batched encoder / long prefill): workgroup tile (64*WGM) x (64*WGN), four waves in a WGM x WGN grid,
 // every wave owns a 64 x 64 output block = 4 m-tiles x 4 n-tiles (16 accumulators), K step 128 (four Q4 blocks).
 //  * A (activations): f32 rows -> bf16 hi+lo planes in LDS, MFMA-fragment order, written 1 KB-contiguous per wave
@@ -1798,6 +1831,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * (64 * WGN);
     const int n_tiles = (N + 15) >> 4;
+#if !defined(VOX_GEMM_BIG_SERIAL)
+    // Addressing = buffer loads: ONE 32-bit byte offset per lane for the A rows (wave w stages rows 16 w + li of the workgroup's 64, K slots 32 u + 4 g: pair (j = u, i = w)),
+    // one for the weight tiles and one for their scales, the n-tile as a wave-uniform SGPR offset -- 64-bit per-lane pointers (4 rows + 4 tiles + 4 scale rows = 24 VGPRs)
+    // left the pipelined loop below 10 VGPRs short.  Out-of-range tiles / K slots read zeros (buffer bounds), the epilogue's guards drop their results.
+    static_assert(WGM == 1, "the staging map below is written for 64-row workgroups");
+    const vsrd_t xsrd = vmake_srd(p.x, (unsigned)min((size_t)0xFFFFFFF0u, ((size_t)(M - 1) * p.x_stride + (size_t)p.w.K) * 4));
+    const vsrd_t qsrd = vmake_srd(p.w.qt, (unsigned)((size_t)n_tiles * nq * 1024)), ssrd = vmake_srd(p.w.st, (unsigned)((size_t)n_tiles * nq * 128));
+    const unsigned xo = (unsigned)(((size_t)min(m0 + 16 * wave + li, M - 1) * p.x_stride + 4 * g) * 4);
+    const unsigned qo = (unsigned)lane * 16u, so = (unsigned)li * 8u;
+    const int tile0 = __builtin_amdgcn_readfirstlane((n0 >> 4) + wn * 4);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 xa[NU], xb[NU]; uint4 bw[4], bwn[4]; uint2 bs[4], bsn[4];
+#define VOX_ALOAD(Q_)                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < NU; u++) {                                                           \
+        xa[u] = vbuf_f4(xsrd, xo + (unsigned)(Q_) * 512u + (unsigned)u * 128u, 0);                             \
+        xb[u] = vbuf_f4(xsrd, xo + (unsigned)(Q_) * 512u + (unsigned)u * 128u + 64u, 0); }
+#define VOX_BLOAD(W_, S_, Q_)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                            \
+        W_[t] = vbuf_u4(qsrd, qo + (unsigned)(Q_) * 1024u, (unsigned)(tile0 + t) * (unsigned)nq * 1024u);      \
+        S_[t] = vbuf_u2(ssrd, so + (unsigned)(Q_) * 128u, (unsigned)(tile0 + t) * (unsigned)nq * 128u); }
+#else
     // staging role: wave handles pairs {wave + 4u}; lane (g, li) stages row 16*i + li, K slots of group g
     const float* xrow[NU];
 #pragma unroll
@@ -1825,22 +1883,185 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 #define VOX_BLOAD(W_, S_, Q_)                                                                                  \
     _Pragma("unroll") for (int t = 0; t < 4; t++) {                                                            \
         W_[t] = wq[t][(size_t)64 * (Q_)]; S_[t] = *reinterpret_cast<const uint2*>(ws[t] + 64 * (Q_)); }
+#endif
     VOX_ALOAD(0)
     VOX_BLOAD(bw, bs, 0)
     // B operand of the correction MFMA: bf16(-136) in every slot (0xC308, exact), so  sum_k x~_k * (-136)  comes out of the matrix core directly
     const bf16x8 m136 = as_bf16x8(make_uint4(0xC308C308u, 0xC308C308u, 0xC308C308u, 0xC308C308u));
+#define VOX_STAGE(BUF_)                                                                                        \
+    _Pragma("unroll") for (int u = 0; u < NU; u++) {     /* K-slot order of the bit-trick B fragment: {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3} */ \
+        uint4 hi, lo;                                                                                          \
+        split_pair(xa[u].x, xa[u].z, hi.x, lo.x); split_pair(xb[u].x, xb[u].z, hi.y, lo.y);                    \
+        split_pair(xa[u].y, xa[u].w, hi.z, lo.z); split_pair(xb[u].y, xb[u].w, hi.w, lo.w);                    \
+        (BUF_)[(wave + 4 * u) * 64 + lane] = hi; (BUF_)[PLANE + (wave + 4 * u) * 64 + lane] = lo; }
+#if defined(VOX_GEMM_BIG_SLOTS)
+    // HAND-ORDERED K step (round 5): a wave issues in order, so its VALU work only runs under its own MFMAs if the two alternate in the instruction stream -- PMC on the
+    // loop-nest form (profiles/r05_pmc_gemm_big.txt): matrix pipe 44 % busy, VALU 47 % busy, next to no overlap (both workgroups of a CU drift into lock-step: all waves
+    // convert, then all multiply).  The K step is 16 groups (block jj, m-tile i) of ten MFMA SLOTS; every slot = one MFMA + the VALU / LDS / VMEM work that is independent
+    // of it, fenced by sched_barrier(0) so that hipcc keeps the order:
+    //   slots 0-3  hi MFMA of n-tile t                 + the PREVIOUS group's four scale FMAs of n-tile t (its lo MFMA is >= 4 slots old); slot 0: the next group's A fragments (ds_read)
+    //   slot  4    correction MFMA a of the NEXT group + one split_pair of the next K step's staging (double-buffered planes)
+    //   slots 5, 6 lo MFMA of n-tiles 0, 1             + (last m-tile of a block) the next block's nibbles -> bf16 IN PLACE: the fragment's last reader has just issued
+    //   slot  7    correction MFMA b of the next group + the staging's ds_writes and the A loads of the K step after next (their registers are free again)
+    //   slots 8, 9 lo MFMA of n-tiles 2, 3             + next block's n-tiles 2, 3
+    // Dependent MFMAs are >= 3 slots apart, every VALU reads MFMA results >= 4 slots old: no s_nop padding.
+    VOX_STAGE(blds)
+    __syncthreads();
+    { const int q1 = min(1, nq - 1); VOX_ALOAD(q1) VOX_BLOAD(bwn, bsn, q1) }
+    bf16x8 bf[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) bf[t] = as_bf16x8(q4_dword_to_bf16x8_biased(bw[t].x));
+    f32x4 T[2][4]; bf16x8 AH[2], AL[2]; f32x4 cs[2];
+#define VOX_SB() __builtin_amdgcn_sched_barrier(0)
+#if defined(VOX_ABL_S_NOMFMA)      /* timing-only ablations of the slotted loop (wrong results) */
+#define VOX_MF(A_, B_, C_) (C_)
+#else
+#define VOX_MF(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, C_, 0, 0, 0)
+#endif
+#if defined(VOX_ABL_S_NOFMA)
+#define VOX_SF(D_, T_, ACC_) (T_)
+#else
+#define VOX_SF(D_, T_, ACC_) scale_fma(D_, T_, ACC_)
+#endif
+#if defined(VOX_ABL_S_NODS)
+#define VOX_LDSR(EXPR_) as_bf16x8(make_uint4(0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u))
+#else
+#define VOX_LDSR(EXPR_) as_bf16x8(EXPR_)
+#endif
+#define VOX_DSC(JJ_, t_) f16_bits_to_f32((uint16_t)((((JJ_) & 2) ? BS[t_].y : BS[t_].x) >> (((JJ_) & 1) ? 16 : 0)))
+    // (the K loop runs two steps per trip with the roles of the two weight-register sets swapped: a rotating copy at the end of a step made hipcc land the next loads in
+    // temporaries and wait for ALL outstanding loads before the barrier)
+    auto kstep = [&](const int q, uint4 (&BW)[4], uint2 (&BS)[4], uint4 (&BN)[4]) __attribute__((always_inline)) {
+        uint4* const cur = blds + (q & 1) * (2 * PLANE);
+        uint4* const nxt = blds + ((q + 1) & 1) * (2 * PLANE);
+        const int q2 = min(q + 2, nq - 1);
+        AH[0] = VOX_LDSR(cur[(wm * 4) * 64 + lane]); AL[0] = VOX_LDSR(cur[PLANE + (wm * 4) * 64 + lane]);
+        AH[1] = VOX_LDSR(cur[(wm * 4 + 1) * 64 + lane]);
+        cs[0] = VOX_MF(AH[0], m136, ((f32x4){0.f, 0.f, 0.f, 0.f}));
+        cs[0] = VOX_MF(AL[0], m136, cs[0]);
+        uint4 shi, slo;
+        VOX_SB();
+#pragma unroll
+        for (int gI = 0; gI < 16; gI++) {
+            const int jj = gI >> 2, i = gI & 3, P = gI & 1, Q = P ^ 1, jp = (gI - 1) >> 2, ip = (gI - 1) & 3, u = gI >> 2, part = gI & 3;
+            // ---- slots 0-3
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                T[P][t] = VOX_MF(AH[P], bf[t], cs[P]);
+                if (gI > 0) acc[t][ip] = VOX_SF(VOX_DSC(jp, t), T[Q][t], acc[t][ip]);
+                if (t == 0 && gI < 15) {      // the next group's lo fragment: its register's last reader (the previous group's lo MFMA of n-tile 3) has just issued; first use 7 slots away
+                    const int jn = (gI + 1) >> 2, in_ = (gI + 1) & 3;
+                    AL[Q] = VOX_LDSR(cur[PLANE + (jn * MTB + wm * 4 + in_) * 64 + lane]);
+                }
+                VOX_SB();
+            }
+            // ---- slot 4
+            if (gI < 15) cs[Q] = VOX_MF(AH[Q], m136, ((f32x4){0.f, 0.f, 0.f, 0.f}));
+            if (gI < 14) {      // the hi fragment of the group after next, into the register this group's hi MFMAs have just finished with: ten slots ahead of its first use
+                const int jn = (gI + 2) >> 2, in_ = (gI + 2) & 3;
+                AH[P] = VOX_LDSR(cur[(jn * MTB + wm * 4 + in_) * 64 + lane]);
+            }
+            if (part == 0) split_pair_np(xa[u].x, xa[u].z, shi.x, slo.x);
+            else if (part == 1) split_pair_np(xb[u].x, xb[u].z, shi.y, slo.y);
+            else if (part == 2) split_pair_np(xa[u].y, xa[u].w, shi.z, slo.z);
+            else split_pair_np(xb[u].y, xb[u].w, shi.w, slo.w);
+            VOX_SB();
+            // ---- slots 5, 6
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                T[P][t] = VOX_MF(AL[P], bf[t], T[P][t]);
+                if (i == 3) bf[t] = as_bf16x8(q4_dword_to_bf16x8_biased(jj == 0 ? BW[t].y : jj == 1 ? BW[t].z : jj == 2 ? BW[t].w : BN[t].x));
+                VOX_SB();
+            }
+            // ---- slot 7
+            if (gI < 15) cs[Q] = VOX_MF(AL[Q], m136, cs[Q]);
+            if (part == 3) {
+                nxt[(wave + 4 * u) * 64 + lane] = shi; nxt[PLANE + (wave + 4 * u) * 64 + lane] = slo;
+                xa[u] = vbuf_f4(xsrd, xo + (unsigned)q2 * 512u + (unsigned)u * 128u, 0);
+                xb[u] = vbuf_f4(xsrd, xo + (unsigned)q2 * 512u + (unsigned)u * 128u + 64u, 0);
+            }
+            VOX_SB();
+            // ---- slots 8, 9
+#pragma unroll
+            for (int t = 2; t < 4; t++) {
+                T[P][t] = VOX_MF(AL[P], bf[t], T[P][t]);
+                if (i == 3) bf[t] = as_bf16x8(q4_dword_to_bf16x8_biased(jj == 0 ? BW[t].y : jj == 1 ? BW[t].z : jj == 2 ? BW[t].w : BN[t].x));
+                VOX_SB();
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t][3] = VOX_SF(VOX_DSC(3, t), T[1][t], acc[t][3]);      // the last group's scale FMAs
+        VOX_BLOAD(BW, BS, q2)                                     // this step's weight registers are free: the step after next lands in them
+        __syncthreads();                                          // every wave is done with this step's planes, the next step's are complete
+    };
+    for (int q = 0; q < nq; q += 2) {
+        kstep(q, bw, bs, bwn);
+        if (q + 1 < nq) kstep(q + 1, bwn, bsn, bw);
+    }
+#undef VOX_SB
+#undef VOX_DSC
+#undef VOX_MF
+#undef VOX_SF
+#undef VOX_LDSR
+#elif !defined(VOX_GEMM_BIG_SBUF)
+    // double-buffered A planes (2 x 32 KB per workgroup, two workgroups per CU): K step q + 1 is staged into the other buffer BEFORE step q's MFMAs, one barrier per K step
+    VOX_STAGE(blds)
+    __syncthreads();
+    { const int q1 = min(1, nq - 1); VOX_ALOAD(q1) VOX_BLOAD(bwn, bsn, q1) }
+    for (int q = 0; q < nq; q++) {
+        uint4* const cur = blds + (q & 1) * (2 * PLANE);
+        uint4* const nxt = blds + ((q + 1) & 1) * (2 * PLANE);
+        if (q + 1 < nq) { VOX_STAGE(nxt) }                      // (last read in step q - 1, behind that step's barrier)
+        if (q > 0) { const int q1 = min(q + 1, nq - 1); VOX_BLOAD(bwn, bsn, q1) }
+        { const int q2 = min(q + 2, nq - 1); VOX_ALOAD(q2) }
+#define blds cur
+#else
     for (int q = 0; q < nq; q++) {
         __syncthreads();                                          // every wave is done reading the previous K step
-#pragma unroll
-        for (int u = 0; u < NU; u++) {                            // K-slot order of the bit-trick B fragment: {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3}
-            uint4 hi, lo;
-            split_pair(xa[u].x, xa[u].z, hi.x, lo.x); split_pair(xb[u].x, xb[u].z, hi.y, lo.y);
-            split_pair(xa[u].y, xa[u].w, hi.z, lo.z); split_pair(xb[u].y, xb[u].w, hi.w, lo.w);
-            blds[(wave + 4 * u) * 64 + lane] = hi; blds[PLANE + (wave + 4 * u) * 64 + lane] = lo;
-        }
+        VOX_STAGE(blds)
         __syncthreads();
         { const int q1 = min(q + 1, nq - 1); VOX_ALOAD(q1) VOX_BLOAD(bwn, bsn, q1) }      // unconditional (clamped) prefetch
         __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !defined(VOX_GEMM_BIG_SLOTS)
+#if !defined(VOX_GEMM_BIG_SERIAL) && !defined(VOX_ABL_BIG_NOCS) && !defined(VOX_ABL_BIG_NOFMA)
+        // SOFTWARE-PIPELINED over the 16 (block j, m-tile i) groups of a K step: a group's ten MFMAs (correction pair, then the four n-tiles' hi MFMAs, then their lo MFMAs --
+        // four independent chains, so a lo MFMA finds its hi result ready) are issued BEFORE the previous group's eight scale FMAs.  Written group by group -- MFMA, dependent
+        // MFMA, dependent FMA per n-tile -- hipcc kept that order and padded every FMA with s_nop 7: one chain in flight per wave, the matrix pipe 38 % busy (round-1 PMC).
+        f32x4 tp[4] = {}; float dp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            bf16x8 bf[4]; float d[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t w_ = jj == 0 ? bw[t].x : jj == 1 ? bw[t].y : jj == 2 ? bw[t].z : bw[t].w;
+                bf[t] = as_bf16x8(q4_dword_to_bf16x8_biased(w_));
+                const uint32_t pr = (jj & 2) ? bs[t].y : bs[t].x;
+                d[t] = f16_bits_to_f32((uint16_t)((jj & 1) ? (pr >> 16) : (pr & 0xFFFFu)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bf16x8 ah = as_bf16x8(blds[(jj * MTB + wm * 4 + i) * 64 + lane]);
+                const bf16x8 al = as_bf16x8(blds[PLANE + (jj * MTB + wm * 4 + i) * 64 + lane]);
+                f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, m136, cs, 0, 0, 0);
+                f32x4 tn[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) tn[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bf[t], cs, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; t++) tn[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bf[t], tn[t], 0, 0, 0);
+                if (jj > 0 || i > 0) {      // the previous group's scale FMAs, under this group's MFMAs
+                    const int ip = i > 0 ? i - 1 : 3;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[t][ip] = scale_fma(dp[t], tp[t], acc[t][ip]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) { tp[t] = tn[t]; dp[t] = d[t]; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t][3] = scale_fma(dp[t], tp[t], acc[t][3]);
+#else
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             bf16x8 bf[4]; float d[4];
@@ -1872,14 +2093,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 #ifdef VOX_ABL_BIG_NOFMA     /* measurement build: accumulate in the matrix core, no block scale */
                     acc[t][i] = tt;
 #else
-                    acc[t][i] = __builtin_elementwise_fma((f32x4){d[t], d[t], d[t], d[t]}, tt, acc[t][i]);
+                    acc[t][i] = scale_fma(d[t], tt, acc[t][i]);
 #endif
                 }
             }
         }
+#endif
 #pragma unroll
         for (int t = 0; t < 4; t++) { bw[t] = bwn[t]; bs[t] = bsn[t]; }
+#if !defined(VOX_GEMM_BIG_SBUF)
+#undef blds
+        __syncthreads();                                          // every wave is done with this step's buffer, the next step's is complete
+#endif
     }
+#endif      // !VOX_GEMM_BIG_SLOTS
+#undef VOX_STAGE
 #undef VOX_ALOAD
 #undef VOX_BLOAD
 #pragma unroll
@@ -1906,7 +2134,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 template <int WGM, int WGN>
 static hipError_t gemm_big_launch(const GemmParams& p, int epi, hipStream_t s) {
     dim3 grid((p.w.N + 64 * WGN - 1) / (64 * WGN), (p.M + 64 * WGM - 1) / (64 * WGM));
+#if !defined(VOX_GEMM_BIG_SBUF) || defined(VOX_GEMM_BIG_SLOTS)
+    const size_t lds = (size_t)2 * 2 * 4 * (4 * WGM) * 64 * sizeof(uint4);      // two buffers of WGM * 32 KB
+#else
     const size_t lds = (size_t)2 * 4 * (4 * WGM) * 64 * sizeof(uint4);      // WGM * 32 KB
+#endif
 #define VOX_E(E_) case E_: { auto kern = q4_gemm_big_kernel<WGM, WGN, E_>; static bool done = false;          \
         hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;                       \
         kern<<<grid, dim3(256), lds, s>>>(p); break; }
