@@ -156,6 +156,7 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
     ok = 1; err = None; res = None; dt = 0.0
     if world > 1:
         dist.barrier()
+    eng_n0 = model.set_batch_engine()[1]
     ctx.synchronize(); t0 = time.perf_counter()
     try:
         mine = []
@@ -164,6 +165,7 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
     except Exception as e:
         ok = 0; err = str(e)
     ctx.synchronize(); dt = time.perf_counter() - t0
+    eng_corpus = model.set_batch_engine()[1] - eng_n0      # rank 0's engine launches inside the timed region (steps with <= 2 active slot groups: one launch each)
     if world > 1:
         import torch
         tt = torch.tensor([dt, float(ok)], dtype=torch.float64, device=f"cuda:{torch.cuda.current_device()}")
@@ -195,12 +197,14 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
         sparts = shard.lpt_partition(durs, simulate_world); per = []
         for grp in shard.length_buckets(sparts[0], durs, batch):      # untimed warm-up at a share's size (workspace pool; the real N-GPU run warms up the same way above)
             batch_work(grp)
+        eng_share = []
         for r in range(simulate_world):
+            e0 = model.set_batch_engine()[1]
             ctx.synchronize(); t1 = time.perf_counter()
             for grp in shard.length_buckets(sparts[r], durs, batch):
                 batch_work(grp)
-            ctx.synchronize(); per.append(time.perf_counter() - t1)
-        sim = {"world": simulate_world, "per_rank_s": [round(v, 3) for v in per], "clips_per_rank": [len(q) for q in sparts],
+            ctx.synchronize(); per.append(time.perf_counter() - t1); eng_share.append(model.set_batch_engine()[1] - e0)
+        sim = {"world": simulate_world, "engine_launches_per_rank": eng_share, "per_rank_s": [round(v, 3) for v in per], "clips_per_rank": [len(q) for q in sparts],
                "batches_per_rank": [[len(g) for g in shard.length_buckets(q, durs, batch)] for q in sparts][:2],
                "predicted_wall_s": round(max(per), 3), "predicted_scaling": round(dt / max(per), 2), "predicted_efficiency": round(dt / max(per) / simulate_world, 3),
                "lpt_imbalance": round(shard.imbalance(durs, sparts), 4), "weight_broadcast_bytes": int(bcast_bytes),
@@ -209,7 +213,7 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
     return {"simulated_world": sim, "workload": f"{n_clips} synthetic clips, FLEURS-like log-normal durations (median 10 s, 3..30 s, rng 7), host samples -> ids; LPT shards over {world} rank(s), "
                         f"{'one vox_transcribe_batch call per rank (continuous batching)' if batch >= n_clips else f'{batch}-clip length-bucketed calls'} (BASELINE configs[4] stand-in; no FLEURS / WER offline)",
             "clips": n_clips, "audio_s": round(total_s, 1), "wall_s": round(dt, 3), "rtf": round(dt / total_s, 6), "tok_per_s": round(ntok / dt, 1),
-            "ids": ntok, "lpt_imbalance": round(shard.imbalance(durs, parts), 4), "batch": batch}
+            "ids": ntok, "lpt_imbalance": round(shard.imbalance(durs, parts), 4), "batch": batch, "engine_launches": int(eng_corpus), "batch_engine_active": bool(model.set_batch_engine()[0])}
 
 
 def main():
