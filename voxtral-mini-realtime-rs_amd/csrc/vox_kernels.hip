@@ -2415,7 +2415,9 @@ hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
         const int big = env_int("VOX_GEMM_BIG");
         const long wg14 = (long)((p.w.N + 255) / 256) * ((p.M + 63) / 64);
         int big_min = 200; { const int e = env_int("VOX_GEMM_BIG_MIN_WG"); if (e > 0) big_min = e; }      // measurement knob: workgroups of 64 x 256 from which the big kernel takes over
-        if (p.ksplit <= 1 && (big == 1 || (big == 0 && wg14 >= big_min))) return gemm_big_launch<1, 4>(p, epi, s);
+        // (the big kernel addresses its operands through 32-bit buffer offsets: activations, tiles and scales each below 4 GB -- beyond that the 32 x 128 kernel's 64-bit pointers serve)
+        const bool fits32 = ((size_t)(p.M - 1) * p.x_stride + (size_t)p.w.K) * 4 < 0xFFFFFFF0ull && (size_t)((p.w.N + 15) / 16) * (p.w.nb / 4) * 1024 < 0xFFFFFFF0ull;
+        if (p.ksplit <= 1 && fits32 && (big == 1 || (big == 0 && wg14 >= big_min))) return gemm_big_launch<1, 4>(p, epi, s);
     }
     return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, s);
 }
