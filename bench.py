@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line.  Extras in the same line (never `value`):
   `f32`         BASELINE configs[1]: the same clip through the f32 SafeTensors path (dense bf16 weights, N = 1)
   `fleurs_like` BASELINE configs[4] stand-in: 647 clips with FLEURS-like durations sharded LPT over the ranks, each rank's share in ONE vox_transcribe_batch call (continuous batching; --fleurs-batch)
                 (replaces bin/transcribe.rs:112-126's serial loop); aggregate RTF, tok/s, LPT imbalance (every N)
+  `fleurs_like_cli`  the same corpus on the reference CLI's semantics (bin/transcribe.rs:207-265, --max-mel-frames 1200): file normalised once, 1200-frame chunks as units (every N)
   `piecewise`   the reference's metric loop (bin/e2e_bench.rs:179-224) call for call through the C ABI from C (tools/e2e_piecewise.c), N = 1
   `roofline`    dominant decode kernel, HIP events on the library stream + committed PMC traffic;  `cpu_baseline`  CPU oracle, bounded sample
 """
@@ -135,7 +136,7 @@ def piecewise_extra(pkg, gguf_path, x, ref_ids, reps=3):
             "note": "tok_per_s = ids / decode-stage seconds as bin/e2e_bench.rs:236-240 (prefill included), the reference's definition"}
 
 
-def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch, simulate_world=0, bcast_bytes=0):
+def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch, simulate_world=0, bcast_bytes=0, chunk_frames=0):
     """BASELINE configs[4] stand-in (no FLEURS offline): `n_clips` synthetic clips with FLEURS-like durations, LPT-sharded over the ranks
     (shard.run_sharded), each rank handing its share to vox_transcribe_batch in calls of <= `batch` clips (default: the whole share in one call -- continuous batching over
     16 .. 64 decode slots; 64: the round-4 form, length-bucketed lock-step batches); results gathered in input order.
@@ -144,11 +145,31 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
     shard = importlib.import_module(pkg.__name__ + ".shard")
     durs = shard.fleurs_like_durations(n_clips, seed=7)
     parts = shard.lpt_partition(durs, world)
-    clips = {i: pkg.synth.synth_audio(durs[i], seed=9000 + i) for i in parts[rank]}      # every rank synthesises only its share (host, untimed)
+    need = set(parts[rank])
+    if world == 1 and simulate_world > 1:
+        need = set(range(n_clips))
+    clips = {i: pkg.synth.synth_audio(durs[i], seed=9000 + i) for i in sorted(need)}      # every rank synthesises only its share (host, untimed)
+    plans = None
+    if chunk_frames > 0:
+        # the reference CLI's pipeline (bin/transcribe.rs:207-265; what scripts/eval_wer.py:182-200 runs, i.e. what the published WER is defined on): the FILE is
+        # peak-normalised once, split at --max-mel-frames (default 1200 = 192 000 samples), every chunk an independent unit -- here ALL chunks of a rank's files in
+        # one vox_transcribe_batch_ex call, the file peaks reduced on the device (norm_group = file)
+        cc = pkg.ChunkConfig.voxtral().with_max_frames(chunk_frames)
+        plans = {i: (pkg.chunk_plan(clips[i].size, cc) if pkg.needs_chunking(clips[i].size, cc) else [(0, clips[i].size)]) for i in clips}
 
     def batch_work(idx_list):
-        outs = model.transcribe_batch([clips[i] for i in idx_list], t_embed)
-        return [len(o) for o in outs]
+        if plans is None:
+            outs = model.transcribe_batch([clips[i] for i in idx_list], t_embed)
+            return [len(o) for o in outs]
+        units, grp, owner = [], [], []
+        for i in idx_list:
+            for a, b in plans[i]:
+                units.append(clips[i][a:b]); grp.append(i); owner.append(i)
+        outs = model.transcribe_batch(units, t_embed, norm_group=grp)
+        per = {i: 0 for i in idx_list}
+        for i, o in zip(owner, outs):
+            per[i] += len(o)
+        return [per[i] for i in idx_list]
 
     model.transcribe_batch([clips[i] for i in parts[rank][:min(batch, len(parts[rank]))]], t_embed)      # warm-up: workspaces + kernels
     # a rank that throws inside the sharded section would leave the others in a collective until the NCCL timeout; so every rank runs its local
@@ -210,7 +231,11 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
                "lpt_imbalance": round(shard.imbalance(durs, sparts), 4), "weight_broadcast_bytes": int(bcast_bytes),
                "weight_broadcast_s_estimate": round(bcast_bytes / 100e9, 3),
                "note": "one-GPU bound on the N-GPU curve of this corpus (replicas only: no data-path collective); broadcast estimate at 100 GB/s per xGMI ring hop"}
-    return {"simulated_world": sim, "workload": f"{n_clips} synthetic clips, FLEURS-like log-normal durations (median 10 s, 3..30 s, rng 7), host samples -> ids; LPT shards over {world} rank(s), "
+    n_units = sum(len(plans[i]) for i in range(n_clips)) if (plans is not None and len(plans) == n_clips) else (None if plans is not None else n_clips)
+    pipe = (f"reference CLI pipeline (bin/transcribe.rs:207-265, --max-mel-frames {chunk_frames}): file peak-normalised once, split into {chunk_frames}-frame chunks, every chunk a unit "
+            f"of the batch (vox_transcribe_batch_ex, norm_group = file)") if chunk_frames > 0 else "un-chunked e2e-bench pipeline (bin/e2e_bench.rs:98-135)"
+    return {"simulated_world": sim, "pipeline": pipe, "units": n_units, "chunk_frames": int(chunk_frames),
+            "workload": f"{n_clips} synthetic clips, FLEURS-like log-normal durations (median 10 s, 3..30 s, rng 7), host samples -> ids; LPT shards over {world} rank(s), "
                         f"{'one vox_transcribe_batch call per rank (continuous batching)' if batch >= n_clips else f'{batch}-clip length-bucketed calls'} (BASELINE configs[4] stand-in; no FLEURS / WER offline)",
             "clips": n_clips, "audio_s": round(total_s, 1), "wall_s": round(dt, 3), "rtf": round(dt / total_s, 6), "tok_per_s": round(ntok / dt, 1),
             "ids": ntok, "lpt_imbalance": round(shard.imbalance(durs, parts), 4), "batch": batch, "engine_launches": int(eng_corpus), "batch_engine_active": bool(model.set_batch_engine()[0])}
@@ -231,6 +256,8 @@ def main():
     ap.add_argument("--fleurs-clips", type=int, default=647, help="clips of the FLEURS-like sharded extra (BASELINE configs[4] stand-in); 0 = skip")
     ap.add_argument("--simulate-world", type=int, default=8, help="N = 1 only: also run each of W ranks' share of the FLEURS-like corpus serially on this GPU and report the predicted 1 -> W scaling (0 = skip)")
     ap.add_argument("--fleurs-batch", type=int, default=0, help="clips per vox_transcribe_batch call of the FLEURS-like extra; 0 (default) = a rank's whole share in ONE call (continuous batching over slots, round 5); 64 = the round-4 length-bucketed lock-step batches")
+    ap.add_argument("--cli-chunk-frames", type=int, default=1200, help="also run the FLEURS-like corpus on the reference CLI's pipeline: files split into chunks of this many mel frames "
+                    "(bin/transcribe.rs:55-57 default 1200), every chunk a unit of the batch (`fleurs_like_cli`); 0 = skip")
     ap.add_argument("--gemv-iters", type=int, default=260)
     args = ap.parse_args()
 
@@ -326,6 +353,13 @@ def main():
                                        simulate_world=args.simulate_world, bcast_bytes=model.arena()[1])
         except Exception as e:     # an extra never costs the headline line
             fleurs = {"error": str(e)} if rank == 0 else None
+    fleurs_cli = None
+    if args.fleurs_clips > 0 and args.cli_chunk_frames > 0:
+        try:      # the same corpus on the reference CLI's semantics (1200-frame chunks as units): the pipeline wer.py / `voxtral-transcribe --batch` run
+            fleurs_cli = fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, args.fleurs_clips, 4096, simulate_world=args.simulate_world, bcast_bytes=model.arena()[1],
+                                           chunk_frames=args.cli_chunk_frames)
+        except Exception as e:
+            fleurs_cli = {"error": str(e)} if rank == 0 else None
 
     out = None
     if rank == 0:
@@ -349,6 +383,10 @@ def main():
             "note": "value = ids emitted by all ranks / max-over-ranks wall time of the whole pipeline; decode_tok_per_s_ref_def follows "
                     "bin/e2e_bench.rs:236-240 (ids / decode-stage time); vs_baseline divides by the reference's 19.4 tok/s measured on a DGX Spark GB10",
         }
+        if fleurs_cli is not None:
+            out["fleurs_like_cli"] = fleurs_cli
+            if fleurs is not None and "error" not in fleurs and "error" not in fleurs_cli:
+                out["fleurs_like_cli"]["tok_per_s_vs_unchunked"] = round(fleurs_cli["tok_per_s"] / fleurs["tok_per_s"], 3)
         if fleurs is not None:
             out["fleurs_like"] = fleurs
             if "error" not in fleurs:

@@ -248,6 +248,14 @@ int32_t vox_transcribe_audio(vox_model* m, const float* samples, size_t n, const
  * depend on n, on the slot or on the neighbours (tested at full size). */
 int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
                              int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind);
+/* The same call with the CLI's normalisation semantics (bin/transcribe.rs:207-265): the reference peak-normalises the FILE once, splits it into chunks of
+ * --max-mel-frames (default 1200, :55-57; audio/chunk.rs:125-166) and transcribes every chunk as an independent unit (own padding, own 38-token prefix), joining the
+ * chunk texts with " " (:261-275).  Here a chunk is a unit of this call: units naming the same norm_group[i] >= 0 share ONE peak scale 0.95 / max|x| taken over all of
+ * them (the chunks tile their file, so that is the file's peak: one device reduction per unit folded per group, exact); norm_group[i] < 0: the unit is used as handed
+ * over (the caller normalised it); norm_group == NULL: every unit normalises itself (= vox_transcribe_batch, the un-chunked e2e-bench pipeline).  Units may be views
+ * into one file buffer (host or device).  Ids per unit equal vox_transcribe_streaming's on the chunk's mel (tests/test_gpu_fullsize.py, test_tokenizer_cli.py). */
+int32_t vox_transcribe_batch_ex(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const int32_t* norm_group_or_null, const float* t_embed,
+                                int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind);
 
 /* Q4LanguageModel pieces used directly by e2e-bench / WASM (gguf/model.rs:566,665,680,711) */
 int32_t vox_decoder_cache_create(vox_model* m, int32_t max_seq, vox_cache** out);   /* create_cache_preallocated */
@@ -257,7 +265,9 @@ int32_t vox_cache_reset(vox_cache* c);
 /* KVCache::update on layer `layer` of a pre-allocated cache (models/layers/kv_cache.rs:116-136: slice_assign of k / v [1][heads][n_rows][head_dim] at rows pos ..
  * pos + n_rows); the length shared by all layers (LayerCaches::seq_len, :242-244) becomes max(len, pos + n_rows).  heads = dec_kv_heads (decoder cache) / enc_heads. */
 int32_t vox_cache_update(vox_cache* c, int32_t layer, int32_t pos, const float* k_HxNxhd, const float* v_HxNxhd, int32_t n_rows, int32_t mem_kind);
-/* forget the rows from `len` on (0 <= len <= seq_len): the next forward appends at `len` again */
+/* forget the rows from `len` on (0 <= len <= seq_len): the next forward appends at `len` again.  vox_cache_update / _truncate / _reset first settle the decoder steps of
+ * this cache that have not been verified yet (see vox_forward_hidden_with_cache_ex): a hand-off timeout found then is THIS call's error (VOX_ERR_HIP) and ALL steps since
+ * the last synchronisation are taken back. */
 int32_t vox_cache_truncate(vox_cache* c, int32_t len);
 /* Streaming encoder: Q4AudioEncoder::create_cache + Q4VoxtralModel::encode_audio_with_cache (gguf/model.rs:437-459,791-799; per layer
  * :299-317,125-174), eviction KVCache::apply_sliding_window (kv_cache.rs:176-203).  The chunk's conv output rows are run through the 32 layers

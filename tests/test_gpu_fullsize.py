@@ -277,6 +277,42 @@ def test_full_wide_batches_peaked_golden_64_lockstep_and_81_continuous(pkg, monk
         m.close(); ctx.close()
 
 
+def test_full_chunked_files_are_units_of_the_wide_batch(pkg):
+    """VERDICT r5 item 1 at FULL size, on the peaked checkpoint: the reference's CLI semantics (bin/transcribe.rs:207-265, default --max-mel-frames 1200) -- the FILE is
+    peak-normalised once, split at 192 000 samples, every chunk an independent unit.  A 30 s, a 25 s and the 16 s golden-clip file (-> 3 + 3 + 2 chunks) among 12 short
+    files = 20 units in ONE vox_transcribe_batch_ex call (continuous batching; group peaks reduced on the device from the raw samples): every unit's ids must be those of
+    the serial CLI path on the same chunk -- pad -> log-mel -> transcribe_streaming of the host-normalised file's slice (cli.transcribe_one) -- up to a near-tie of the
+    serial path's own logits, and identical to the call made on host-normalised slices (norm_group -1, what cli.py --batch passes)."""
+    path = os.path.join(cache_dir(), "full_q4_peaked_seed44.gguf")
+    if not os.path.exists(path):
+        pkg.synth.write_synthetic_gguf(path + ".tmp", pkg.synth.ModelDims(), seed=44, peaked=True); os.replace(path + ".tmp", path)
+    S = pkg.synth; t = pkg.TimeEmbedding(3072).embed(6.0)
+    files = [0.4 * S.synth_audio(30.0, seed=9101), 0.7 * S.synth_audio(25.0, seed=9102), 0.25 * S.synth_audio(16.0, seed=7049)]
+    files += [(0.1 + 0.05 * i) * S.synth_audio(3.0 + 0.7 * i, seed=9200 + i) for i in range(12)]
+    cfg = pkg.ChunkConfig.voxtral().with_max_frames(1200)
+    raw, nrm, grp = [], [], []
+    for fi, x in enumerate(files):
+        xn = pkg.peak_normalize(x, 0.95)
+        plan = pkg.chunk_plan(x.size, cfg) if pkg.needs_chunking(x.size, cfg) else [(0, x.size)]
+        for a, b in plan:
+            raw.append(x[a:b]); nrm.append(xn[a:b]); grp.append(fi)
+    assert len(raw) == 20 and [c.size for c in raw[:8]] == [192000, 192000, 96000, 192000, 192000, 16000, 192000, 64000]      # SURVEY section 8 table: chunk A / chunk B of a 16 s file
+    ctx = pkg.Context(0); m = pkg.Q4ModelLoader.from_file(path).load(ctx)
+    try:
+        outs = m.transcribe_batch(raw, t, norm_group=grp)
+        assert [len(o) for o in outs[6:8]] == [83, 33]                                        # SURVEY section 8: CLI default chunk A / chunk B emit 83 / 33 ids
+        as_is = m.transcribe_batch(nrm, t, norm_group=[-1] * len(nrm))
+        assert all(len(a) == len(b) and (a == b).all() for a, b in zip(outs, as_is)), "device-side file peaks != host-normalised files"
+        mel = pkg.MelSpectrogram.voxtral(ctx); n_same = 0
+        for u, c in enumerate(nrm):
+            rids, rlg = m.transcribe_streaming(np.ascontiguousarray(mel.compute_log(pkg.pad_audio(c)).T)[None], t, return_logits=True)
+            n_same += int(check_greedy_ids(outs[u], rids, rlg, TOL) == len(rids))
+        assert n_same >= 18, n_same
+        print(f"chunks as units at full size: 20 units of 15 files, {n_same}/20 identical to the serial CLI path end to end (the rest up to a near-tie)")
+    finally:
+        m.close(); ctx.close()
+
+
 def test_full_continuous_batch_engine_forms_two_groups_per_launch(pkg, monkeypatch, capfd):
     """The steps of a wide batch with one or two active slot groups go through the batched decode-layer engine: TWO groups per launch (decode_engine_b16_kernel<2>: group B's
     phase runs while group A's hand-off resolves; cache slices per slot through EngBParams::kv_row), one group per launch once the second group has retired.  Full size,

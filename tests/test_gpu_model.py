@@ -278,6 +278,53 @@ def test_transcribe_batch_continuous_slots(pkg, ctx, tiny, monkeypatch):
     print(f"continuous batching, 90 ragged utterances: identical to the lock-step batches and for 1..4 slot groups; {n_same}/24 checked rows identical to single-stream end to end")
 
 
+def test_transcribe_batch_ex_chunks_share_their_files_peak(pkg, ctx, tiny):
+    """vox_transcribe_batch_ex: the reference's CLI peak-normalises the FILE, then chunks it (bin/transcribe.rs:207-226) -- a chunk is normalised by its
+    file's peak, not its own.  Units = the 600-frame chunks of five files with different peaks (one of them with a SILENT chunk, one silent altogether) + short files, in one
+    call: (a) norm_group = file index on the RAW samples (group peaks reduced on the device), host and device pointers, (b) norm_group = -1 on host-normalised samples --
+    both must give, unit for unit, exactly the ids of the same call made on separately normalised copies, which equal the serial path (pad -> log-mel ->
+    transcribe_streaming per chunk, cli.transcribe_one) up to a near-tie; and normalising every chunk by ITS OWN peak (norm_group None) must differ somewhere."""
+    m, _, _ = tiny
+    t = pkg.TimeEmbedding(256).embed(6.0); S = pkg.synth
+    cfg = pkg.ChunkConfig.voxtral().with_max_frames(600)                       # 6 s chunks
+    files = [0.31 * S.synth_audio(14.0, seed=41), 0.8 * S.synth_audio(7.5, seed=42), 0.11 * S.synth_audio(19.0, seed=43)]
+    files[0][:96000] *= np.float32(1e-4)      # a first chunk 80 dB below the file's peak: under the FILE's scale its log-mel sits at the floor, under its own it would be full scale
+    q = 0.5 * S.synth_audio(13.0, seed=44); q[:96000] = 0.0; files.append(q)                      # a file whose FIRST chunk is silent (its own peak would give scale 1)
+    files.append(np.zeros(100000, np.float32))                                                   # a silent file: scale 1 (audio/io.rs:61-63)
+    files += [(0.05 + 0.04 * i) * S.synth_audio(1.0 + 0.5 * i, seed=50 + i) for i in range(9)]
+    raw, nrm, grp = [], [], []
+    for fi, x in enumerate(files):
+        xn = pkg.peak_normalize(x, 0.95)
+        plan = pkg.chunk_plan(x.size, cfg) if pkg.needs_chunking(x.size, cfg) else [(0, x.size)]
+        for a, b in plan:
+            raw.append(x[a:b]); nrm.append(xn[a:b]); grp.append(1000 + 7 * fi)                    # arbitrary (non-dense) group ids
+    assert len(raw) == 3 + 2 + 4 + 3 + 2 + 9 and len(raw) > 16
+    by_group = m.transcribe_batch(raw, t, norm_group=grp)
+    as_is = m.transcribe_batch(nrm, t, norm_group=[-1] * len(nrm))
+    for u, (a, b) in enumerate(zip(by_group, as_is)):
+        assert len(a) == len(b) and (a == b).all(), f"unit {u}: device-side group normalisation != host-normalised file"
+    ptrs = [ctx.upload(np.ascontiguousarray(c)) for c in raw]
+    try:
+        dev = m.transcribe_batch(None, t, device_ptrs=ptrs, n_samples=[c.size for c in raw], norm_group=grp)
+        assert all((a == b).all() for a, b in zip(dev, by_group))
+    finally:
+        for p_ in ptrs:
+            ctx.free(p_)
+    mixed = m.transcribe_batch(raw[:5] + nrm[5:], t, norm_group=grp[:5] + [-1] * (len(raw) - 5))   # groups and as-is units in one call
+    assert all((a == b).all() for a, b in zip(mixed, by_group))
+    few = m.transcribe_batch(raw[:5], t, norm_group=grp[:5])                                       # <= 16 units: the one-group path; files 0 and 1 complete
+    assert all((a == b).all() for a, b in zip(few, by_group[:5]))
+    mel = pkg.MelSpectrogram.voxtral(ctx); n_same = 0
+    for u, c in enumerate(nrm):                                                                    # the serial CLI path, chunk by chunk
+        rids, rlg = m.transcribe_streaming(np.ascontiguousarray(mel.compute_log(pkg.pad_audio(c)).T)[None], t, return_logits=True)
+        n_same += int(check_greedy_ids(by_group[u], rids, rlg, TOL) == len(rids))
+    own = m.transcribe_batch(raw, t)
+    assert (own[0] != by_group[0]).any(), "normalising file 0's quiet first chunk by its own peak must change its ids"
+    with pytest.raises(ValueError):
+        m.transcribe_batch(raw, t, norm_group=grp[:-1])
+    print(f"vox_transcribe_batch_ex: {len(raw)} chunk units of {len(files)} files; device group peaks == host-normalised files; {n_same}/{len(raw)} units identical to the serial path end to end")
+
+
 def test_transcribe_exactly_prefix_len(pkg, orc, tiny):
     """S == 38 decoder positions (= PREFIX_LEN): the reference prefills, predicts the first token and returns ONE id (gguf/model.rs:887-889
     only returns empty below 38; the decode loop :938 is empty).  T = 606 mel frames -> 303 -> 152 encoder rows -> 38."""

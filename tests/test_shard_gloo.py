@@ -145,6 +145,45 @@ def test_cli_sharded_lines_world2_gloo(pkg, tmp_path):
     assert res[0][0] == [f"file{i}@rank{owner[i]}" for i in range(11)]
 
 
+def _cli_units_worker(rank, world, port, pkg_dir, q):
+    import importlib, os, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(pkg_dir))
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    cli = importlib.import_module(pkg.__name__ + ".cli")
+    # the unit table every rank derives from the headers: file 0 = three chunks, file 1 = one unit, file 2 = two chunks, file 3 = one unit
+    units = [(0, 0, 0, 192000), (0, 1, 192000, 384000), (0, 2, 384000, 480000), (1, 0, 0, 80000), (2, 0, 0, 192000), (2, 1, 192000, 200000), (3, 0, 0, 150000)]
+    calls = []
+    def runner(us):                              # the fake model: a unit's text names the unit and the rank; the tail chunk of file 2 decodes to nothing; file 3 fails
+        calls.append(list(us))
+        return [None if i == 3 else ("" if (i, k) == (2, 1) else f"f{i}c{k}@{rank}") for i, k, _, _ in us]
+    texts = cli.sharded_units(pkg, units, runner, 1024, rank, world)
+    lines = cli.join_units(4, units, texts) if texts is not None else None
+    q.put((rank, lines, calls))
+
+
+def test_cli_sharded_units_world2_gloo(pkg):
+    """`voxtral-transcribe --batch N --gpus 2` data path on CPU (gloo, world 2, fake model): CHUNKS are the units of work (bin/transcribe.rs:210-265) -- partitioned
+    longest-first by their length over the ranks (a file's chunks may sit on different ranks), every rank hands its share to the runner in one call, rank 0 re-joins
+    every file's non-empty chunk texts with one space (:261-275); a file with a failed unit is left to the one-by-one path."""
+    import multiprocessing as mp, os
+    shard = __import__("importlib").import_module(pkg.__name__ + ".shard")
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = shard.free_port()
+    ps = [ctx.Process(target=_cli_units_worker, args=(r, 2, port, os.path.dirname(os.path.abspath(pkg.__file__)), q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = {}
+    for _ in ps:
+        r, lines, calls = q.get(timeout=120); res[r] = (lines, calls)
+    [p.join(60) for p in ps]
+    costs = [192000.0, 192000.0, 96000.0, 80000.0, 192000.0, 8000.0, 150000.0]
+    parts = shard.lpt_partition(costs, 2)
+    assert res[1][0] is None and all(len(res[r][1]) == 1 and len(res[r][1][0]) == len(parts[r]) for r in range(2))      # ONE runner call per rank with its whole share
+    own = {u: r for r in range(2) for u in parts[r]}
+    assert res[0][0] == {0: f"f0c0@{own[0]} f0c1@{own[1]} f0c2@{own[2]}", 1: f"f1c0@{own[3]}", 2: f"f2c0@{own[4]}"}      # file 3 (failed unit) absent -> one-by-one path
+    assert len({own[0], own[1], own[2]}) == 2                                                                             # file 0's chunks really were split over both ranks
+
+
 def test_length_buckets_are_balanced(pkg):
     shard = __import__("importlib").import_module(pkg.__name__ + ".shard")
     costs = [float(i % 17) for i in range(81)]

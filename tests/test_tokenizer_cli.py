@@ -50,6 +50,24 @@ def test_wav_loader(pkg, tmp_path):
         cli.resample_to_16k(r, 8000)
 
 
+def test_unit_table_splits_files_like_the_reference_cli(pkg, tmp_path):
+    """cli.unit_table: the units of work of a file list from the WAV headers alone -- a file that fits --max-mel-frames is one unit, a longer one is its chunks
+    (bin/transcribe.rs:210-226, audio/chunk.rs:125-157: 1200 frames = 192 000 samples, no overlap, tail chunk kept), at the length the file has at 16 kHz."""
+    cli = __import__("importlib").import_module(pkg.__name__ + ".cli")
+    z = np.zeros(1, np.float32)
+    for name, n, sr in (("a", 80000, 16000), ("b", 480000, 16000), ("c", 192000, 16000), ("d", 192001, 16000), ("e", 120000, 8000)):
+        _write_wav(str(tmp_path / f"{name}.wav"), np.resize(z, n), sr=sr)
+    (tmp_path / "empty.wav").write_bytes(b"")
+    paths = [str(tmp_path / f"{n}.wav") for n in ("a", "b", "missing", "c", "d", "e", "empty")]
+    cfg = pkg.ChunkConfig.voxtral().with_max_frames(1200)
+    u = cli.unit_table(pkg, paths, cfg)
+    assert u == [(0, 0, 0, 80000), (1, 0, 0, 192000), (1, 1, 192000, 384000), (1, 2, 384000, 480000), (3, 0, 0, 192000),
+                 (4, 0, 0, 192000), (4, 1, 192000, 192001), (5, 0, 0, 192000), (5, 1, 192000, 240000)]      # e: 120 000 samples at 8 kHz = 240 000 at 16 kHz
+    lines = cli.join_units(7, u, ["x", "p", "", "q", "c", "d", None, "e1", "e2"])
+    assert lines == {0: "x", 1: "p q", 3: "c", 5: "e1 e2"}                                                      # empty chunk texts are dropped (transcribe.rs:263-265)
+    assert 4 not in lines                                                                                        # a failed unit leaves its file to the one-by-one path
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end(pkg, tmp_path):
     """One line per input on stdout, logs on stderr (transcribe.rs:61-64,125); chunked long input; missing file -> empty line."""
@@ -68,9 +86,41 @@ def test_cli_end_to_end(pkg, tmp_path):
     assert all(w.startswith("w") for w in lines[0].split()) and all(w.startswith("w") for w in lines[1].split())
     r2 = subprocess.run(cmd[:-4] + ["--audio", str(tmp_path / "a.wav")], capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0 and r2.stdout.split("\n")[0] == lines[0]           # deterministic, same text
-    # --batch (extension): un-chunked files go through vox_transcribe_batch, chunked ones one by one; same lines in the same order
+    # --batch (extension): every file's chunks are units of ONE vox_transcribe_batch_ex call (a.wav + the two chunks of b.wav); same lines in the same order
     r3 = subprocess.run(cmd + ["--batch", "4"], capture_output=True, text=True, timeout=300)
-    assert r3.returncode == 1 and r3.stdout == r.stdout and "batch of 1" in r3.stderr
+    assert r3.returncode == 1 and r3.stdout == r.stdout and "batch of 3" in r3.stderr
+
+
+@pytest.mark.gpu
+def test_cli_batch_makes_chunks_units_of_work_and_keeps_the_serial_lines(pkg, tmp_path):
+    """with the reference's default --max-mel-frames 1200 every file longer than 12 s is split (bin/transcribe.rs:55-57,210-226); `--batch` must hand
+    ALL chunks of all files to vox_transcribe_batch_ex as units (the file peak-normalised once, :207) and print exactly the one-by-one path's lines -- here 30 s, 25 s and
+    13 s files among short ones, more units than one 16-row group (continuous batching), and with --batch 8 a file's chunks split over several calls."""
+    import contextlib, io
+    S = pkg.synth
+    cli = __import__("importlib").import_module(pkg.__name__ + ".cli")
+    gguf = str(tmp_path / "m.gguf"); S.write_synthetic_gguf(gguf, S.tiny_dims(vocab=2048), seed=5)
+    tok = str(tmp_path / "tekken.json"); json.dump(_tekken(1200), open(tok, "w"))
+    secs = [30.0, 2.0, 25.0, 13.0, 12.0, 12.01] + [1.0 + 0.45 * ((7 * i) % 11) for i in range(14)]
+    wavs = []
+    for i, sec in enumerate(secs):
+        p = str(tmp_path / f"w{i}.wav"); _write_wav(p, (0.2 + 0.03 * (i % 5)) * S.synth_audio(sec, seed=800 + i)); wavs.append(p)      # different peaks per file
+    args = ["--gguf", gguf, "--tokenizer", tok] + sum((["--audio", w] for w in wavs), [])
+    n_units = len(cli.unit_table(pkg, wavs, pkg.ChunkConfig.voxtral().with_max_frames(1200)))
+    assert n_units == len(secs) + 2 + 2 + 1 + 1                                     # 30 s -> 3, 25 s -> 3, 13 s -> 2, 12.01 s -> 2 units
+
+    def run(extra):
+        buf = io.StringIO(); err = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(err):
+            rc = cli.main(args + extra)
+        return rc, buf.getvalue(), err.getvalue()
+
+    rc1, out1, err1 = run([])
+    assert rc1 == 0 and "chunk 3/3" in err1 and len(out1.split("\n")) == len(secs) + 1 and all(out1.split("\n")[:-1])
+    rc2, out2, err2 = run(["--batch", "1024"])
+    assert rc2 == 0 and out2 == out1 and f"batch of {n_units}" in err2 and "chunk " not in err2      # no file went through the serial loop
+    rc3, out3, err3 = run(["--batch", "8"])
+    assert rc3 == 0 and out3 == out1 and err3.count("batch of ") == (n_units + 7) // 8
 
 
 @pytest.mark.gpu

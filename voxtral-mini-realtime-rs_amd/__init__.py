@@ -7,7 +7,7 @@ src/models); all compute lives in csrc/ -> libvoxtral_hip.so.  There is no CPU f
 from . import synth  # noqa: F401  (numpy-only tooling: synthetic GGUF / audio)
 from . import build  # noqa: F401
 from ._lib import lib, VoxError  # noqa: F401
-from .audio import (PadConfig, ChunkConfig, MelSpectrogram, pad_audio, chunk_audio, needs_chunking,  # noqa: F401
+from .audio import (PadConfig, ChunkConfig, MelSpectrogram, pad_audio, chunk_audio, chunk_plan, needs_chunking, resample_len,  # noqa: F401
                     peak_normalize, resample, resample_to_16k, resample_plan, TimeEmbedding)
 from .tokenizer import VoxtralTokenizer  # noqa: F401
 from . import wer  # noqa: F401  (WER / CER harness, scripts/eval_wer.py)

@@ -109,6 +109,7 @@ SIGNATURES = {
     "vox_transcribe_streaming": (i32, [vp, vp, i32, vp, vp, i32, P(i32), vp, i32]),
     "vox_transcribe_audio": (i32, [vp, vp, sz, vp, vp, i32, P(i32), i32]),
     "vox_transcribe_batch": (i32, [vp, i32, P(vp), P(sz), vp, P(vp), P(i32), P(i32), i32]),
+    "vox_transcribe_batch_ex": (i32, [vp, i32, P(vp), P(sz), vp, vp, P(vp), P(i32), P(i32), i32]),
     "vox_decoder_cache_create": (i32, [vp, i32, P(vp)]),
     "vox_cache_free": (i32, [vp]),
     "vox_cache_seq_len": (i32, [vp, P(i32)]),

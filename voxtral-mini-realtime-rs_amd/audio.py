@@ -102,6 +102,16 @@ def needs_chunking(num_samples, config: ChunkConfig):
     return bool(out.value)
 
 
+def chunk_plan(num_samples, config: ChunkConfig):
+    """The chunk boundaries alone (audio/chunk.rs:125-157): [(start_sample, end_sample)] -- what the batched driver needs to make every chunk a unit of work
+    without copying samples (cli.py)."""
+    c = config._c(); n = C.c_size_t()
+    check(lib().vox_chunk_plan(int(num_samples), C.byref(c), None, 0, C.byref(n)))
+    arr = (_lib.Chunk * max(n.value, 1))()
+    check(lib().vox_chunk_plan(int(num_samples), C.byref(c), arr, n.value, C.byref(n)))
+    return [(int(arr[i].start_sample), int(arr[i].end_sample)) for i in range(n.value)]
+
+
 def chunk_audio(samples, config: ChunkConfig):
     """audio/chunk.rs:159-161"""
     x = _f32(samples); c = config._c(); n = C.c_size_t()
@@ -110,6 +120,12 @@ def chunk_audio(samples, config: ChunkConfig):
     check(lib().vox_chunk_plan(x.size, C.byref(c), arr, n.value, C.byref(n)))
     return [AudioChunk(x[arr[i].start_sample:arr[i].end_sample].copy(), arr[i].start_sample, arr[i].end_sample,
                        arr[i].index, bool(arr[i].is_last)) for i in range(n.value)]
+
+
+def resample_len(num_samples, sample_rate, target_rate=16000):
+    """length of `resample`'s output (audio/resample.rs:33-34: ceil(n * ratio))"""
+    n = C.c_size_t(); check(lib().vox_resample_len(int(num_samples), int(sample_rate), int(target_rate), C.byref(n)))
+    return int(num_samples) if sample_rate == target_rate else n.value
 
 
 def resample(ctx, samples, sample_rate, target_rate=16000):

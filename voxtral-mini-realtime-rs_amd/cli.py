@@ -77,12 +77,83 @@ def file_costs(paths):
     return [float(os.path.getsize(p)) if os.path.exists(p) else 0.0 for p in paths]
 
 
-def sharded_lines(pkg, paths, one, rank, world, group=None):
-    """N > 1 ranks: every rank transcribes its longest-first share of `paths` with `one(index) -> text`; rank 0 returns every line in input order
-    (None elsewhere).  The only collective is the final gather of the text lines, and it runs over GLOO whatever the default group is: with `--gguf --gpus N` the
-    default group is RCCL (the start-up weight broadcast), whose object collectives stage through GPU buffers and fall under the NCCL watchdog's 10-minute collective
-    timeout -- a rank that is still transcribing a long share must not be killed by the ranks that wait for it.  A gloo subgroup is created for the gather
-    (every rank calls this function, so every rank takes part in new_group)."""
+def unit_table(pkg, paths, chunk_cfg):
+    """The units of work of a file list, from the WAV headers alone (so every rank derives the same table without decoding anything): every file is split exactly like
+    bin/transcribe.rs:210-226 -- one unit if it fits `max_mel_frames`, its chunks otherwise -- at the length it will have at 16 kHz.
+    -> [(file index, chunk index, start_sample, end_sample)], file-major.  Unreadable / empty files contribute nothing: their line (and their error) comes from the
+    one-by-one path."""
+    units = []
+    for i, p in enumerate(paths):
+        try:
+            with wave.open(p, "rb") as w:
+                n, sr = w.getnframes(), w.getframerate()
+            n16 = pkg.resample_len(n, sr) if sr != 16000 else n
+            if n16 <= 0:
+                continue
+            plan = pkg.chunk_plan(n16, chunk_cfg) if pkg.needs_chunking(n16, chunk_cfg) else [(0, n16)]
+            units.extend((i, k, a, b) for k, (a, b) in enumerate(plan) if b > a)
+        except Exception:
+            pass
+    return units
+
+
+class UnitRunner:
+    """Transcribes units (file, chunk, start, end) through vox_transcribe_batch_ex.  A file is loaded, resampled and peak-normalised ONCE, as a file
+    (bin/transcribe.rs:197-207); its chunks are views into it handed over as already normalised (norm_group < 0), so a file's chunks may sit in different calls or
+    on different ranks and still carry the file's scale.  Returns the text of every unit (None = failed: the file falls back to the one-by-one path)."""
+
+    def __init__(self, pkg, ctx, model, tokenizer, paths, t_embed):
+        self.pkg, self.ctx, self.model, self.tok, self.paths, self.t_embed = pkg, ctx, model, tokenizer, paths, t_embed
+        self.files = {}
+
+    def samples(self, i):
+        if i not in self.files:
+            try:
+                x, sr = load_wav(self.paths[i])
+                if sr != 16000:
+                    x = resample_to_16k(x, sr, self.ctx, self.pkg)
+                self.files[i] = self.pkg.peak_normalize(x, 0.95)
+            except Exception as e:
+                log(f"  (batched path) cannot read {self.paths[i]}: {e}"); self.files[i] = None
+        return self.files[i]
+
+    def __call__(self, units):
+        views, keep = [], []
+        for u, (i, k, a, b) in enumerate(units):
+            x = self.samples(i)
+            if x is not None and b <= x.size:      # (a header that lied about the length: leave the file to the one-by-one path)
+                views.append(x[a:b]); keep.append(u)
+        out = [None] * len(units)
+        if not views:
+            return out
+        try:
+            t1 = time.time(); ids = self.model.transcribe_batch(views, self.t_embed, norm_group=[-1] * len(views))
+            log(f"batch of {len(views)}: {time.time() - t1:.3f}s")
+            for u, r in zip(keep, ids):
+                out[u] = self.tok.decode([t for t in r if t >= 1000]).strip()           # :309-318, per chunk
+        except Exception as e:
+            log(f"batched path failed ({e}); falling back to one by one")
+        for i in {units[u][0] for u in keep}:      # a file whose units are all done is dropped from memory
+            self.files.pop(i, None)
+        return out
+
+
+def join_units(n_files, units, unit_texts):
+    """bin/transcribe.rs:261-275: a file's line = its non-empty chunk texts joined by one space.  -> {file index: line} for the files whose units ALL came back."""
+    per = {}
+    for (i, k, _, _), t in zip(units, unit_texts):
+        per.setdefault(i, []).append((k, t))
+    lines = {}
+    for i, lst in per.items():
+        if all(t is not None for _, t in lst):
+            lines[i] = " ".join(t for _, t in sorted(lst) if t)
+    return lines
+
+
+def _gloo_gather(fn):
+    """Run `fn(group)` -- which ends in ONE gather of python objects -- over a GLOO group whatever the default group is: with `--gguf --gpus N` the default group is
+    RCCL (the start-up weight broadcast), whose object collectives stage through GPU buffers and fall under the NCCL watchdog's 10-minute collective timeout -- a rank
+    that is still transcribing a long share must not be killed by the ranks that wait for it.  Every rank calls this, so every rank takes part in new_group."""
     import datetime
     import torch.distributed as dist
     own = not dist.is_initialized()
@@ -90,14 +161,31 @@ def sharded_lines(pkg, paths, one, rank, world, group=None):
         dist.init_process_group("gloo", timeout=datetime.timedelta(hours=12))
     sub = None
     try:
-        if group is None and not own and dist.get_backend() != "gloo":
+        group = None
+        if not own and dist.get_backend() != "gloo":
             sub = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=12)); group = sub
-        return pkg.shard.run_sharded(list(range(len(paths))), file_costs(paths), one, rank, world, group=group)
+        return fn(group)
     finally:
         if sub is not None:
             dist.destroy_process_group(sub)
         if own:
             dist.barrier(); dist.destroy_process_group()
+
+
+def sharded_lines(pkg, paths, one, rank, world, group=None):
+    """N > 1 ranks: every rank transcribes its longest-first share of `paths` with `one(index) -> text`; rank 0 returns every line in input order
+    (None elsewhere).  The only collective is the final gather of the text lines (over gloo: _gloo_gather)."""
+    if group is not None:
+        return pkg.shard.run_sharded(list(range(len(paths))), file_costs(paths), one, rank, world, group=group)
+    return _gloo_gather(lambda g: pkg.shard.run_sharded(list(range(len(paths))), file_costs(paths), one, rank, world, group=g))
+
+
+def sharded_units(pkg, units, runner, batch, rank, world, group=None):
+    """N > 1 ranks, chunks as units of work: the units are LPT-partitioned by their length (decode cost ~ samples), every rank hands its share to `runner` in calls of
+    <= `batch` units; rank 0 returns every unit's text in table order (None elsewhere)."""
+    costs = [float(b - a) for _, _, a, b in units]
+    run = lambda g: pkg.shard.run_sharded(units, costs, None, rank, world, group=g, batch=max(batch, 2), batch_work=runner)
+    return run(group) if (group is not None or world == 1) else _gloo_gather(run)
 
 
 def main(argv=None):
@@ -112,8 +200,8 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--gpus", type=int, default=1, help="extension: shard the input files over N GPUs of this node (one process per GPU, longest-first "
                     "assignment, no collective in the data path; stdout keeps one line per input in input order)")
-    ap.add_argument("--batch", type=int, default=1, help="extension: transcribe up to N un-chunked files per vox_transcribe_batch call "
-                    "(same ids as one by one; output order unchanged)")
+    ap.add_argument("--batch", type=int, default=1, help="extension: every file is split into its --max-mel-frames chunks and up to N chunks go into one "
+                    "vox_transcribe_batch_ex call (continuous batching; same ids per chunk and the same lines as one by one; output order unchanged)")
     a = ap.parse_args(argv)
     if a.audio_list and a.audio:
         ap.error("--audio-list conflicts with --audio")
@@ -175,32 +263,13 @@ def main(argv=None):
     rc = 0
     texts = {}
     if a.batch > 1:
-        # files that fit one chunk go through the batched path in groups of similar length; chunked / failing files fall back below
-        units = []
-        mine = set(pkg.shard.lpt_partition(file_costs(paths), world)[rank]) if world > 1 else None
-        for i, p in enumerate(paths):
-            if mine is not None and i not in mine:
-                continue
-            try:
-                x, sr = load_wav(p)
-                if sr != 16000:
-                    x = resample_to_16k(x, sr, ctx, pkg)
-                # NOT peak-normalised here: vox_transcribe_batch normalises on the device (absmax reduction + scale inside the mel
-                # kernel) exactly once, like the one-by-one path does on the host (transcribe.rs:207)
-                if not pkg.needs_chunking(x.size, chunk_cfg) and x.size > 0:
-                    units.append((i, x))
-            except Exception:
-                pass
-        units.sort(key=lambda u: -u[1].size)
-        for k in range(0, len(units), a.batch):
-            grp = units[k:k + a.batch]
-            try:
-                t1 = time.time(); outs = model.transcribe_batch([x for _, x in grp], t_embed)
-                log(f"batch of {len(grp)}: {time.time() - t1:.3f}s")
-                for (i, _), ids in zip(grp, outs):
-                    texts[i] = tokenizer.decode([t for t in ids if t >= 1000]).strip()
-            except Exception as e:
-                log(f"batched path failed ({e}); falling back to one by one")
+        # every file -> its chunks (transcribe.rs:210-226); ALL units of this rank's share go to vox_transcribe_batch_ex in calls of <= --batch units (continuous batching
+        # over decode slots); a file's line = its chunk texts joined by " " (:261-275).  Files with a failed unit fall back to the one-by-one path below.
+        units = unit_table(pkg, paths, chunk_cfg)
+        runner = UnitRunner(pkg, ctx, model, tokenizer, paths, t_embed)
+        unit_texts = sharded_units(pkg, units, runner, a.batch, rank, world) if units else []
+        if unit_texts is not None:      # (rank 0, or the only rank)
+            texts = join_units(len(paths), units, unit_texts)
     def one(i):
         nonlocal rc
         if i in texts:
@@ -212,7 +281,11 @@ def main(argv=None):
         except Exception as e:      # per-utterance failure isolates to that line (empty), eval_wer.py:211-223 tolerates it
             log(f"Error transcribing {p}: {e}"); text = ""; rc = 1
         return text
-    if world > 1:
+    if world > 1 and a.batch > 1:
+        if rank == 0:      # the units were sharded above; what is left (unreadable files, failed units) is rank 0's
+            for i in range(len(paths)):
+                print(one(i), flush=True)
+    elif world > 1:
         lines = sharded_lines(pkg, paths, one, rank, world)
         if rank == 0:
             for text in lines:

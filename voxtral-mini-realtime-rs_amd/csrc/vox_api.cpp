@@ -95,6 +95,7 @@ struct vox_ctx {
     std::vector<PoolEntry> pool;
     // side streams + fork/join events: independent 16-row groups of a wide batched decode step run concurrently
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    uint32_t warm_forms = 0;      // continuous batch: step forms whose kernels have run once on this context's device (bit 0 launch chains, bit 1 engine + tail)
     // XF tiles of a 17..48-row GEMM input (the 38-token prefill): 3 tiles x K columns x 64 B; sized once for K <= 16384, reused by every such GEMM of the stream
     uint16_t* xf_scratch = nullptr; size_t xf_scratch_bytes = 0;
     float* kz_scratch = nullptr; size_t kz_scratch_bytes = 0;      // K-slice planes of the 17..48-row GEMMs (q4_skinny_mt2_kernel): 8 x 48 x 18432 floats
@@ -1474,8 +1475,17 @@ extern "C" int32_t vox_cache_free(vox_cache* k) {
 // KVCache::update on one layer of a pre-allocated cache (kv_cache.rs:116-136: slice_assign of k / v [1][heads][new_seq][hd] at rows pos .. pos + new_seq) -- for callers
 // that own their K / V (and for tests that need a cache at a position no prefill has reached).  The length shared by all layers (LayerCaches::seq_len,
 // kv_cache.rs:242-244) becomes max(len, pos + n_rows).
+// The piecewise decoder surface remembers the rows of a cache it has not verified yet (engine steps since the last synchronisation; see pw_note_pending below).  An entry
+// point that moves the cache's length by hand settles them first: a hand-off timeout found LATER would otherwise subtract a stale row count from the new length.
+// A failure found here is reported by this call (VOX_ERR_HIP; the cache is back at the length before the failed step, nothing else was changed).
+static int32_t pw_sync(vox_model* m);
+static int32_t cache_settle_pending(vox_cache* kc) {
+    vox_model* m = kc->m;
+    if (m && m->pw_pend_rows > 0 && m->pw_pend_cache == kc) { VOXCHK(ctx_bind(kc->ctx)); VOXCHK(pw_sync(m)); }
+    return VOX_OK;
+}
 extern "C" int32_t vox_cache_update(vox_cache* kc, int32_t layer, int32_t pos, const float* k, const float* v, int32_t n_rows, int32_t mem_kind) {
-    ARGCHK(kc && k && v && n_rows > 0 && pos >= 0, "bad argument"); VOXCHK(ctx_bind(kc->ctx));
+    ARGCHK(kc && k && v && n_rows > 0 && pos >= 0, "bad argument"); VOXCHK(ctx_bind(kc->ctx)); VOXCHK(cache_settle_pending(kc));
     const vox_model_cfg& c = kc->m->cfg;
     const int L = kc->kind == 1 ? c.enc_layers : c.dec_layers, H = kc->kind == 1 ? c.enc_heads : c.dec_kv_heads, hd = kc->kind == 1 ? c.enc_head_dim : c.dec_head_dim;
     ARGCHK(layer >= 0 && layer < L, "layer %d out of range (0..%d)", layer, L - 1);
@@ -1492,12 +1502,16 @@ extern "C" int32_t vox_cache_update(vox_cache* kc, int32_t layer, int32_t pos, c
 // forget every row from `len` on (0 <= len <= seq_len): the next forward appends at `len` again.  What a caller of the device-resident entries does after ITS OWN failed step;
 // the library's own engine timeouts roll the length back themselves (see vox_forward_hidden_with_cache_ex).
 extern "C" int32_t vox_cache_truncate(vox_cache* kc, int32_t len) {
-    ARGCHK(kc, "null cache"); ARGCHK(len >= 0 && len <= kc->len, "truncate to %d: the cache holds %d rows", len, kc->len);
+    ARGCHK(kc, "null cache"); VOXCHK(cache_settle_pending(kc)); ARGCHK(len >= 0 && len <= kc->len, "truncate to %d: the cache holds %d rows", len, kc->len);
     if (kc->kind == 1) kc->abs_pos -= kc->len - len;
     kc->len = len; return VOX_OK;
 }
 extern "C" int32_t vox_cache_seq_len(const vox_cache* k, int32_t* out) { ARGCHK(k && out, "null argument"); *out = k->len; return VOX_OK; }
-extern "C" int32_t vox_cache_reset(vox_cache* k) { ARGCHK(k, "null cache"); k->len = 0; k->abs_pos = 0; return VOX_OK; }
+extern "C" int32_t vox_cache_reset(vox_cache* k) {
+    ARGCHK(k, "null cache");
+    (void)cache_settle_pending(k);      // (a failed verdict only shortens a cache that is being emptied anyway: the strike is counted, the reset goes through)
+    k->len = 0; k->abs_pos = 0; return VOX_OK;
+}
 
 static size_t cache_layer_floats(const vox_model* m, const vox_cache* k) { (void)m; return k->layer_stride; }
 
@@ -2076,7 +2090,8 @@ extern "C" int32_t vox_transcribe_audio(vox_model* m, const float* samples, size
 // whole batch), per-sequence positions / KV-cache slices / audio rows live on the device, the step is hipGraph-replayed.
 static const int32_t VOX_RETRY_ON_LAUNCHES = -1000;      // internal: transcribe_batch_impl's batched engine timed out; serve the batch on the launch-based step
 static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
-                                     int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of, bool allow_engine = true) {      // slot_of[i]: the caller's slot of row i (error messages)
+                                     int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of, bool allow_engine = true,
+                                     const float* const* unit_scale = nullptr) {      // unit_scale[i]: device float the front-end multiplies unit i by (vox_transcribe_batch_ex: the peak scale of the unit's FILE); null = every unit normalises itself      // slot_of[i]: the caller's slot of row i (error messages)
     VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
@@ -2126,8 +2141,8 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
             }
             const size_t left = pad_left(&pc), right = pad_right(&pc, n_samples[i] + left);
             float* mel_i = b_mel.as<float>() + mo; mo += (size_t)128 * T[i]; d_mels[i] = mel_i;
-            float* scale_i = b_scale.as<float>() + i;
-            HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, scale_i, s));
+            const float* scale_i = unit_scale ? unit_scale[i] : b_scale.as<float>() + i;
+            if (!unit_scale) HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, b_scale.as<float>() + i, s));
             HIPCHK(launch_mel(d_s, (long)n_samples[i], (long)left, (long)right, scale_i, mt, mel_i, T[i], 1, s));
         }
     }
@@ -2399,7 +2414,8 @@ static bool batch_xf_ok(const vox_model* m) {
     return m->tok.w.fmt == WFMT_Q4_0 && m->dec[0].wqkv.w.fmt == WFMT_Q4_0 && m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !knob_str("VOX_BATCH_NO_XF");
 }
 static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
-                                          int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of, bool allow_engine) {
+                                          int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of, bool allow_engine,
+                                          const float* const* unit_scale = nullptr) {
     VOXCHK(ctx_bind(m->ctx));
     const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
     ARGCHK(c.n_mels == 128, "the log-mel front-end produces 128 bins; model expects %d", c.n_mels);
@@ -2486,8 +2502,8 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             if (mem_kind == VOX_MEM_HOST) { float* dst = b_smp.as<float>() + so; so += n_samples[i]; HIPCHK(hipMemcpyAsync(dst, samples[i], n_samples[i] * 4, hipMemcpyHostToDevice, s)); d_s = dst; }
             const size_t left = pad_left(&pc), right = pad_right(&pc, n_samples[i] + left);
             float* mel_i = b_mel.as<float>() + mo; mo += (size_t)128 * T[i]; d_mels[i - c0] = mel_i;
-            float* scale_i = b_scale.as<float>() + (i - c0);
-            HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, scale_i, s));
+            const float* scale_i = unit_scale ? unit_scale[i] : b_scale.as<float>() + (i - c0);
+            if (!unit_scale) HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, b_scale.as<float>() + (i - c0), s));
             HIPCHK(launch_mel(d_s, (long)n_samples[i], (long)left, (long)right, scale_i, mt, mel_i, T[i], 1, s));
         }
         HIPCHK(hipStreamSynchronize(s)); const double tb = now_ms();
@@ -2538,7 +2554,6 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         sp.pos = d_pos; sp.kv_row = d_kvrow; sp.n_clips = n; sp.first_pos = PREFIX_LEN; sp.tok = m->tok.w; sp.audio = d_audio; sp.audio_off = b_aoff.as<long>(); sp.D = D;
         sp.h0 = b_h0.as<float>(); sp.h = b_h.as<float>(); sp.xf = b_xf1.as<uint16_t>(); sp.xf_w = m->dec[0].attn_norm; sp.ssq_out = b_ssq.as<float>();
         sp.xf_group_stride = (long)(xf_bytes(D) / 2); sp.ssq_group_stride = parts_D * 16;
-        sp.init = 1; HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); sp.init = 0;
         auto group_chain = [&](int gi, hipStream_t sg) -> int32_t {
             const int r0 = gi * 16;
             uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)gi * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)gi * (xf_bytes(QD) / 2);
@@ -2639,11 +2654,26 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             hipGraphExec_t find(uint32_t a) const { for (auto& e : ex) if (e.first == a) return e.second; return nullptr; }
         } graphs; graphs.s = s; graphs.cx = cx;
         const bool no_graph = knob_str("VOX_BATCH_NO_GRAPH") != nullptr;
-        // the step's kernels raise their dynamic-LDS limits at their first launch (hipFuncSetAttribute: not something to do inside a capture): the first continuous batch
-        // of a process runs its first step eagerly, every later one replays graphs from step 0 on
-        static bool step_kernels_warm = false;
-        int t_start = 0;
-        if (!step_kernels_warm && !no_graph) { VOXCHK(step(active_at(0))); m->engb_launches += (unsigned)eng_per_step; step_kernels_warm = true; t_start = 1; }
+        // The step's kernels raise their dynamic-LDS limits at their first launch on a device (hipFuncSetAttribute: not something to do inside a capture).  A step comes in
+        // two FORMS with different kernels -- the forked launch chains and the engine launch + its tail -- and a plan may use both; the limits are per DEVICE, so the flag is
+        // the context's, not the process's (a second vox_ctx on another GPU, or the launch chains after an engine-timeout re-run, met their first launch inside
+        // a capture).  Every form this plan will capture and that this context has not run yet takes ONE eager step on all-idle slots first (slot_clip -1: the argmax /
+        // next-input launch returns at once; zero rows against the zeroed scratch slice; nothing of the session's state moves); every real step is then a graph replay.
+        const int t_start = 0;
+        {
+            auto form_of = [&](uint32_t a) { int na = 0; for (int gi = 0; gi < G; gi++) na += (a >> gi) & 1u; return (use_eng && na <= 2) ? 2u : 1u; };
+            bool idle_set = false;
+            for (int t = 0; t < steps && !no_graph; t++) {
+                const uint32_t act = active_at(t), f = form_of(act);
+                if (cx->warm_forms & f) continue;
+                if (!idle_set) {
+                    HIPCHK(hipMemsetAsync(b_sclip.p, 0xFF, (size_t)Sl * 4, s)); HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d_pos, PREFIX_LEN, Sl, s)); HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d_kvrow, n, Sl, s));
+                    idle_set = true;
+                }
+                VOXCHK(step(act)); m->engb_launches += (unsigned)eng_per_step; cx->warm_forms |= f;
+            }
+        }
+        sp.init = 1; HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); sp.init = 0;      // every slot takes the first utterance of its queue
         std::vector<std::pair<uint32_t, int>> eng_in_graph;      // engine launches per replay of every captured set
         auto capture = [&](uint32_t act, hipGraphExec_t* out) -> int32_t {
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -2709,20 +2739,58 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
 // Entry point: rows are processed LONGEST FIRST (a stable sort of the caller's slots by sample count; sequence length is monotone in it), so that the
 // 16-row groups of the decode loop retire last to first (see `step` above) -- results are per row and land in the caller's slot i whatever the internal order.
 static int32_t transcribe_batch_launches(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
-                                         int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of) {
-    int32_t r = transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, true);
-    if (r == VOX_RETRY_ON_LAUNCHES) r = transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, false);
+                                         int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of, const float* const* unit_scale) {
+    int32_t r = transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, true, unit_scale);
+    if (r == VOX_RETRY_ON_LAUNCHES) r = transcribe_batch_impl(m, n, samples, n_samples, t_embed, out_ids, caps, n_ids, mem_kind, slot_of, false, unit_scale);
     return r;
 }
 extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
                                         int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind) {
-    ARGCHK(m && samples && n_samples && t_embed && out_ids && caps && n_ids, "null argument"); ARGCHK(n > 0 && n <= 4096, "batch size %d out of range (1..4096)", n);
+    return vox_transcribe_batch_ex(m, n, samples, n_samples, nullptr, t_embed, out_ids, caps, n_ids, mem_kind);
+}
+// norm_group: the reference's CLI peak-normalises the FILE once (bin/transcribe.rs:207) and then splits it into chunks (:210-226); every chunk is an independent unit
+// of work from there on (:231-265).  Units that name the same group >= 0 share ONE peak scale = 0.95 / max|x| over all of them (chunks tile their file, so that is the
+// file's peak); group < 0: the unit is used as handed over (already normalised by the caller); norm_group == NULL: every unit normalises itself (un-chunked e2e-bench).
+extern "C" int32_t vox_transcribe_batch_ex(vox_model* m, int32_t n, const float* const* samples_in, const size_t* n_samples, const int32_t* norm_group, const float* t_embed,
+                                           int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind_in) {
+    ARGCHK(m && samples_in && n_samples && t_embed && out_ids && caps && n_ids, "null argument"); ARGCHK(n > 0 && n <= 4096, "batch size %d out of range (1..4096)", n);
+    const float* const* samples = samples_in; int32_t mem_kind = mem_kind_in;
+    DevBuf b_all, b_gmax, b_ugrp, b_uscale;      // (declared before everything that launches on them; the impls drain the streams before they return)
+    std::vector<const float*> dev_s; std::vector<const float*> scale_of;      // per unit (caller's order): device samples, device scale cell
+    if (norm_group) {
+        VOXCHK(ctx_bind(m->ctx)); vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
+        std::vector<int> ug(n); std::vector<int32_t> ids; ids.reserve(n);      // dense group index per unit
+        {
+            std::vector<std::pair<int32_t, int>> seen;      // (caller's id, dense index), sorted by id
+            std::vector<int32_t> uniq; for (int i = 0; i < n; i++) if (norm_group[i] >= 0) uniq.push_back(norm_group[i]);
+            std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            for (int i = 0; i < n; i++) ug[i] = norm_group[i] < 0 ? -1 : (int)(std::lower_bound(uniq.begin(), uniq.end(), norm_group[i]) - uniq.begin());
+            ids = uniq;
+        }
+        for (int i = 0; i < n; i++) ARGCHK(samples_in[i] && n_samples[i] > 0, "empty audio in batch slot %d", i);
+        if (mem_kind_in == VOX_MEM_HOST) {      // the peaks are reduced on the device: the whole call's samples go up once, here (4 B per sample: 0.4 GB for a 647-clip corpus)
+            size_t tot = 0; for (int i = 0; i < n; i++) tot += (n_samples[i] + 3) & ~(size_t)3;
+            HIPCHK(b_all.alloc_pooled(cx, tot * 4));
+            dev_s.resize(n); size_t o = 0;
+            for (int i = 0; i < n; i++) { float* d = b_all.as<float>() + o; o += (n_samples[i] + 3) & ~(size_t)3; HIPCHK(hipMemcpyAsync(d, samples_in[i], n_samples[i] * 4, hipMemcpyHostToDevice, s)); dev_s[i] = d; }
+            samples = dev_s.data(); mem_kind = VOX_MEM_DEVICE;
+        }
+        const size_t ng = std::max<size_t>(ids.size(), 1);
+        HIPCHK(b_gmax.alloc_pooled(cx, ng * 4)); HIPCHK(b_ugrp.alloc_pooled(cx, (size_t)n * 4)); HIPCHK(b_uscale.alloc_pooled(cx, (size_t)n * 4));
+        HIPCHK(hipMemsetAsync(b_gmax.p, 0, ng * 4, s)); HIPCHK(hipMemcpyAsync(b_ugrp.p, ug.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        for (int i = 0; i < n; i++) if (ug[i] >= 0) HIPCHK(launch_absmax_group(samples[i], (long)n_samples[i], b_gmax.as<unsigned>() + ug[i], s));
+        HIPCHK(launch_group_scale(b_gmax.as<unsigned>(), b_ugrp.as<int>(), n, 0.95f, b_uscale.as<float>(), s));
+        HIPCHK(hipStreamSynchronize(s));      // `ug` (pageable) goes out of scope; the scales are ready for every session below
+        scale_of.resize(n); for (int i = 0; i < n; i++) scale_of[i] = b_uscale.as<float>() + i;
+    }
+    struct DrainAll { vox_model* m; bool on; ~DrainAll() { if (on) { (void)hipStreamSynchronize(m->ctx->stream); } } } drain_all{m, norm_group != nullptr};
     std::vector<int> order(n);
     for (int i = 0; i < n; i++) order[i] = i;
     if (n > 16 && !knob_str("VOX_BATCH_NO_SORT"))
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_samples[a] > n_samples[b]; });
-    std::vector<const float*> p_s(n); std::vector<size_t> p_n(n); std::vector<int32_t*> p_o(n); std::vector<int32_t> p_c(n), p_k(n, 0);
-    for (int i = 0; i < n; i++) { const int o = order[i]; p_s[i] = samples[o]; p_n[i] = n_samples[o]; p_o[i] = out_ids[o]; p_c[i] = caps[o]; }
+    std::vector<const float*> p_s(n), p_sc(n, nullptr); std::vector<size_t> p_n(n); std::vector<int32_t*> p_o(n); std::vector<int32_t> p_c(n), p_k(n, 0);
+    for (int i = 0; i < n; i++) { const int o = order[i]; p_s[i] = samples[o]; p_n[i] = n_samples[o]; p_o[i] = out_ids[o]; p_c[i] = caps[o]; if (norm_group) p_sc[i] = scale_of[o]; }
+    const float* const* usc = norm_group ? p_sc.data() : nullptr;
     // <= 16 rows: one group (the batched decode-layer engine).  Wider: continuous batching over slots, in sessions whose resident K / V stays under 64 GB (212 992 B per
     // position and utterance: 54 MB at 256 positions -> 1 174 utterances; every session pays its own tail and graph captures, so the 647-clip corpus is ONE session);
     // VOX_BATCH_NO_CONTINUOUS=1 (or a geometry / checkpoint the XF step does not cover): lock-step batches of <= 64 rows.
@@ -2732,14 +2800,17 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         const vox_model_cfg& c = m->cfg; vox_pad_cfg pc; vox_pad_cfg_voxtral(&pc);
         const size_t left = pad_left(&pc), total = left + p_n[0] + pad_right(&pc, p_n[0] + left);      // the longest utterance (rows are sorted) sets max_seq
         const int Smax = conv_len(conv_len((int)(total / 160))) / c.reshape_factor, max_seq = std::max((Smax + 63) / 64 * 64, 64);
-        const double per_clip = 2.0 * c.dec_layers * (double)c.dec_kv_heads * max_seq * c.dec_head_dim * 4.0;
+        // resident per utterance: its K / V slices + its audio rows ([max_seq][dec_dim] f32) + token / input rows; beside them ONE encoder / prefill stack of <= 64 utterances
+        // lives at a time (packed encoder workspace ~ 80 MB per 30 s utterance: activations, q|k|v, FFN rows in f32 + XF planes; logits of the chunk): a fixed reserve
+        const double per_clip = 2.0 * c.dec_layers * (double)c.dec_kv_heads * max_seq * c.dec_head_dim * 4.0 + (double)max_seq * c.dec_dim * 4.0 + (double)p_n[0] * 4.0;
+        const double reserve = 64.0 * 80e6 + 64.0 * (double)c.vocab * 4.0 + 1e9;
         double budget = 64e9;
         {   // ... and under half of what the device has free right now (a shared GPU, other models resident): the pooled buffers of earlier calls count as free for this purpose
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { size_t pooled = 0; for (const auto& e : m->ctx->pool) if (!e.used) pooled += e.cap; budget = std::min(budget, 0.5 * (double)(free_b + pooled)); }
             else (void)hipGetLastError();
         }
-        part_max = (int)std::max(17.0, std::min(4096.0, budget / per_clip));
+        part_max = (int)std::max(17.0, std::min(4096.0, (budget - std::min(reserve, 0.5 * budget)) / per_clip));
         if (const char* e = knob_str("VOX_BATCH_SESSION_MAX")) part_max = std::max(17, atoi(e));      // measurement knob
     }
     const int n_parts = (n + part_max - 1) / part_max;
@@ -2748,9 +2819,9 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
         const int b = a + (n - a) / (n_parts - pi);      // equal contiguous parts of the sorted order
         const int np = b - a;
         if (cont) {
-            r = transcribe_continuous_impl(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a, true);
-            if (r == VOX_RETRY_ON_LAUNCHES) r = transcribe_continuous_impl(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a, false);
-        } else r = transcribe_batch_launches(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a);
+            r = transcribe_continuous_impl(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a, true, usc ? usc + a : nullptr);
+            if (r == VOX_RETRY_ON_LAUNCHES) r = transcribe_continuous_impl(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a, false, usc ? usc + a : nullptr);
+        } else r = transcribe_batch_launches(m, np, p_s.data() + a, p_n.data() + a, t_embed, p_o.data() + a, p_c.data() + a, p_k.data() + a, mem_kind, order.data() + a, usc ? usc + a : nullptr);
         acc.preprocess_ms += m->timings.preprocess_ms; acc.encode_ms += m->timings.encode_ms; acc.decode_ms += m->timings.decode_ms; acc.total_ms += m->timings.total_ms;
         acc.decode_tokens += m->timings.decode_tokens; acc.graph_replays += m->timings.graph_replays;
         m->batch_sessions++; a = b;
@@ -3039,6 +3110,9 @@ static int32_t forward_composite(vox_model* m, int mode, const float* mel, int32
         if (r == VOX_OK && mem_kind == VOX_MEM_HOST && hipMemcpyAsync(logits, ly, (size_t)S * c.vocab * 4, hipMemcpyDeviceToHost, s) != hipSuccess) r = fail(VOX_ERR_HIP, "copy of the logits failed");
         return r;
     };
+    // settle whatever earlier piecewise steps left unverified BEFORE this call's rows: a failed verdict found behind decode_rows() must be about THIS call's rows for the
+    // silent re-run below to be right -- an earlier step's failure belongs to its owner (whose cache was just shortened) and is reported
+    if (m->pw_pend_rows > 0) { const int32_t r0 = pw_sync(m); if (r0 != VOX_OK) { if (tmp) (void)vox_cache_free(tmp); return r0; } }
     m->pw_verdict_failed = false;
     int32_t r = decode_rows();
     int32_t rs = pw_sync(m);

@@ -1008,11 +1008,12 @@ hipError_t eng_occupancy(int* blocks_per_cu) {
 }
 
 hipError_t launch_decode_engine(const EngParams& p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DevOnce attr_done;
+    const int dev = vox_current_device();
+    if (!attr_done.done(dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done.set(dev);
     }
     decode_engine_kernel<<<dim3(NCU), dim3(NTHR), L_TOTAL, s>>>(p);
     return hipGetLastError();

@@ -1066,13 +1066,14 @@ int engb_lds_bytes2() { return BL_TOTAL2; }
 
 // the three forms raise their dynamic-LDS limit once, all together (hipFuncSetAttribute is not something to do inside a stream capture: vox_api.cpp calls this from
 // engb_prepare, before any graph holds a launch)
-static bool g_engb_attr_done = false;
+static DevOnce g_engb_attr_done;
 hipError_t engb_prepare_kernels() {
-    if (g_engb_attr_done) return hipSuccess;
+    const int dev = vox_current_device();
+    if (g_engb_attr_done.done(dev)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_engine_b16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) g_engb_attr_done = true;
+    if (e == hipSuccess) g_engb_attr_done.set(dev);
     return e;
 }
 template <int NG, bool KVR>

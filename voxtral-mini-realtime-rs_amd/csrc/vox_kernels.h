@@ -2,6 +2,14 @@
 // Everything here is internal to libvoxtral_hip.so; the public boundary is include/voxtral_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+// "done once per DEVICE" flag for per-kernel attributes (hipFuncSetAttribute applies to the current device: one vox_ctx per GPU in one process)
+struct DevOnce {
+    std::atomic<uint64_t> mask{0};
+    bool done(int dev) const { return (mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull; }
+    void set(int dev) { mask.fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
+static inline int vox_current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
 #include <stdint.h>
 
 namespace vox {
@@ -155,6 +163,9 @@ hipError_t launch_mel(const float* audio, long n, long left, long right, const f
 hipError_t launch_resample_matrix(const double* H, int new_len, int fft_in, int fft_out, float* At, hipStream_t s);      // H: new_len (re, im) pairs; At: [fft_in][2 fft_out]
 hipError_t launch_resample(const float* x, long n_in, const float* At, int fft_in, int fft_out, int delay, float* out, long n_out, hipStream_t s);
 hipError_t launch_absmax(const float* x, long n, float target_peak, float* scale_out, hipStream_t s);
+// group peaks: every unit folds max|x| into its group's cell (zeroed by the caller); unit_scale[i] = target / peak of unit i's group (1 for a silent group or group < 0)
+hipError_t launch_absmax_group(const float* x, long n, unsigned* group_max_cell, hipStream_t s);
+hipError_t launch_group_scale(const unsigned* group_max, const int* unit_group, int n, float target, float* unit_scale, hipStream_t s);
 
 // h[i][:] = (audio ? audio[(a_base+i)][:] : 0) + dequant(tok[ids[id_base+i]]) ; bases add *pos_ptr if given
 hipError_t launch_embed(Q4W tok, const int* ids, int n, const float* audio, int D, const int* pos_ptr, int id_off,

@@ -444,10 +444,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void q4_gemv_kernel(const GemvParams p
 
 // raise the dynamic-LDS limit once per kernel (not on every launch: launches may be inside a graph capture)
 template <class Kern>
-static hipError_t ensure_dyn_lds(Kern kern, size_t lds, bool* done) {
-    if (lds <= 48 * 1024 || *done) return hipSuccess;
+static hipError_t ensure_dyn_lds(Kern kern, size_t lds, DevOnce* done) {
+    if (lds <= 48 * 1024) return hipSuccess;
+    const int dev = vox_current_device();
+    if (done->done(dev)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) *done = true;
+    if (e == hipSuccess) done->set(dev);
     return e;
 }
 
@@ -543,7 +545,7 @@ static hipError_t gemv_launch_w(const GemvParams& p, int ny, hipStream_t s) {
     dim3 grid(q4_gemv_grid_w(p.w.N, R, NWV), ny);
     size_t lds = (size_t)(p.w.K + p.w.nb + 4 * NWV) * sizeof(float);
     auto kern = q4_gemv_kernel<P, R, PRO, EPI, NWV>;
-    static bool attr_done = false;
+    static DevOnce attr_done;
     hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
     if (e != hipSuccess) return e;
     kern<<<grid, dim3(64 * NWV), lds, s>>>(p);
@@ -2139,7 +2141,7 @@ static hipError_t gemm_big_launch(const GemmParams& p, int epi, hipStream_t s) {
 #else
     const size_t lds = (size_t)2 * 4 * (4 * WGM) * 64 * sizeof(uint4);      // WGM * 32 KB
 #endif
-#define VOX_E(E_) case E_: { auto kern = q4_gemm_big_kernel<WGM, WGN, E_>; static bool done = false;          \
+#define VOX_E(E_) case E_: { auto kern = q4_gemm_big_kernel<WGM, WGN, E_>; static DevOnce done;          \
         hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;                       \
         kern<<<grid, dim3(256), lds, s>>>(p); break; }
     switch (epi) { VOX_E(EPI_STORE) VOX_E(EPI_RESID) VOX_E(EPI_GELU) VOX_E(EPI_SWIGLU) default: return hipErrorInvalidValue; }
@@ -2336,7 +2338,7 @@ static hipError_t gemm_launch_mn(const GemmParams& p, int epi, hipStream_t s) {
     if (p.ksplit > 1 && (epi != EPI_STORE || p.ksplit > p.w.nb / 4)) return hipErrorInvalidValue;
     dim3 grid((p.w.N + 64 * NT - 1) / (64 * NT), (p.M + 16 * MT - 1) / (16 * MT), p.ksplit > 1 ? p.ksplit : 1);
     const size_t lds = (size_t)2 * 2 * 4 * MT * 64 * sizeof(uint4);     // MT * 16 KB
-#define VOX_E(E_) case E_: { auto kern = q4_gemm_kernel<MT, NT, E_, FMT, TB>; static bool done = false;      \
+#define VOX_E(E_) case E_: { auto kern = q4_gemm_kernel<MT, NT, E_, FMT, TB>; static DevOnce done;      \
         hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;                       \
         kern<<<grid, dim3(256), lds, s>>>(p); break; }
     switch (epi) { VOX_E(EPI_STORE) VOX_E(EPI_RESID) VOX_E(EPI_GELU) VOX_E(EPI_SWIGLU) default: return hipErrorInvalidValue; }
@@ -2417,7 +2419,9 @@ hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
         int big_min = 200; { const int e = env_int("VOX_GEMM_BIG_MIN_WG"); if (e > 0) big_min = e; }      // measurement knob: workgroups of 64 x 256 from which the big kernel takes over
         // (the big kernel addresses its operands through 32-bit buffer offsets: activations, tiles and scales each below 4 GB -- beyond that the 32 x 128 kernel's 64-bit pointers serve)
         const bool fits32 = ((size_t)(p.M - 1) * p.x_stride + (size_t)p.w.K) * 4 < 0xFFFFFFF0ull && (size_t)((p.w.N + 15) / 16) * (p.w.nb / 4) * 1024 < 0xFFFFFFF0ull;
-        if (p.ksplit <= 1 && fits32 && (big == 1 || (big == 0 && wg14 >= big_min))) return gemm_big_launch<1, 4>(p, epi, s);
+        // N % 256 == 0: the kernel hands its n-tile index to the buffer loads as the SGPR offset, which the hardware leaves out of the bounds check -- a partial last
+        // column tile would read past the tile planes (every Voxtral N is a multiple of 256, other shapes take the 32 x 128 kernel)
+        if (p.ksplit <= 1 && fits32 && p.w.N % 256 == 0 && (big == 1 || (big == 0 && wg14 >= big_min))) return gemm_big_launch<1, 4>(p, epi, s);
     }
     return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, s);
 }
@@ -2880,7 +2884,7 @@ template <int HD>
 static hipError_t attn_prefill_mfma_launch(const AttnParams& p, hipStream_t s, int n_seq) {
     constexpr size_t lds = ((size_t)2 * 64 * (HD + 8) + (size_t)2 * HD * 72) * sizeof(uint16_t);
     auto kern = attn_prefill_mfma_kernel<HD>;
-    static bool attr_done = false;
+    static DevOnce attr_done;
     hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
     if (e != hipSuccess) return e;
     kern<<<dim3((p.M + 63) / 64, p.n_heads, n_seq), dim3(256), lds, s>>>(p);
@@ -2899,7 +2903,7 @@ hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n
         attn_prefill_kernel<64><<<grid, dim3(256), lds, s>>>(p);
     } else if (hd == 128) {
         auto kern = attn_prefill_kernel<128>;
-        static bool attr_done = false;
+        static DevOnce attr_done;
         hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
         if (e != hipSuccess) return e;
         kern<<<grid, dim3(256), lds, s>>>(p);
@@ -3311,7 +3315,7 @@ hipError_t launch_attn_wo(const AttnParams& p_in, const Q4W& wo, long long* acc,
     if (!attn_wo_supported(p_in, wo, 128, max_seq) || !acc) return hipErrorInvalidValue;
     AttnParams p = p_in; p.tl_slot = tl_take_slot(1, 0, p.n_heads, 128);
     const size_t lds = (size_t)max_seq * sizeof(float);
-    static bool attr_done = false;
+    static DevOnce attr_done;
     auto kern = attn_wo_kernel<6>;       // 8 row slices per head = 256 workgroups (4 slices: 1.05 ms per step, 16: 0.975, 8: 0.94 -- profiles/r02_attn_wo.txt)
     hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
     if (e != hipSuccess) return e;
@@ -3324,7 +3328,7 @@ hipError_t launch_attn_decode(const AttnParams& p_in, int hd, int max_seq, hipSt
     const size_t lds = (size_t)max_seq * sizeof(float);
     if (hd == 128 && p.prefer_gqa && p.n_heads == 4 * p.n_kv_heads && p.kv_head_stride == max_seq * 128 && !env_int("VOX_ATTN_NO_GQA")) {
         auto kern = attn_decode_gqa_kernel<4>;      // many sequences: one workgroup per (KV head, sequence), K/V fetched once for its 4 query heads
-        static bool attr_done = false;
+        static DevOnce attr_done;
         hipError_t e = ensure_dyn_lds(kern, 4 * lds, &attr_done);
         if (e != hipSuccess) return e;
         kern<<<dim3(p.n_kv_heads, n_seq), dim3(256), 4 * lds, s>>>(p);
@@ -3336,13 +3340,13 @@ hipError_t launch_attn_decode(const AttnParams& p_in, int hd, int max_seq, hipSt
     if (!env_int("VOX_ATTN_SPEC")) p.spec_rows = 0;
     if (hd == 128 && p.spec_rows > 0) {
         auto kern = attn_decode_kernel<128, true>;
-        static bool attr_done = false;
+        static DevOnce attr_done;
         hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
         if (e != hipSuccess) return e;
         kern<<<dim3(p.n_heads, n_seq), dim3(256), lds, s>>>(p);
     } else if (hd == 128) {
         auto kern = attn_decode_kernel<128, false>;
-        static bool attr_done = false;
+        static DevOnce attr_done;
         hipError_t e = ensure_dyn_lds(kern, lds, &attr_done);
         if (e != hipSuccess) return e;
         kern<<<dim3(p.n_heads, n_seq), dim3(256), lds, s>>>(p);
@@ -3500,6 +3504,49 @@ __global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ 
 }
 hipError_t launch_absmax(const float* x, long n, float target, float* scale_out, hipStream_t s) {
     absmax_kernel<<<dim3(1), dim3(1024), 0, s>>>(x, n, target, scale_out);
+    return hipGetLastError();
+}
+
+// Peak of a GROUP of units (the 1200-frame chunks of one file: the reference normalises the FILE once, bin/transcribe.rs:207, then chunks it, :210-226): every unit
+// folds its max|x| into its group's cell (non-negative floats order like their bit patterns; a maximum is exact and order-independent, so the atomics are deterministic),
+// then unit_scale[i] = target / max of its group (1 if the group is silent, audio/io.rs:61-63); group < 0 = the unit is used as it is (scale 1).
+__global__ __launch_bounds__(1024) void absmax_group_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ group_max) {
+    __shared__ float red[16];
+    float m = 0.f;
+    const long head = min(n, (long)(((16 - ((uintptr_t)x & 15)) & 15) >> 2)), n4 = (n - head) >> 2;
+    for (long i = threadIdx.x; i < head; i += 1024) m = fmaxf(m, fabsf(x[i]));
+    const float4* x4 = reinterpret_cast<const float4*>(x + head);
+    for (long i = threadIdx.x; i < n4; i += 4096) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = x4[min(i + 1024 * u, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+    for (long i = head + 4 * n4 + threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; i++) m = fmaxf(m, red[i]);
+        atomicMax(group_max, __float_as_uint(m));
+    }
+}
+__global__ void group_scale_kernel(const unsigned* __restrict__ group_max, const int* __restrict__ unit_group, int n, float target, float* __restrict__ unit_scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = unit_group[i];
+    float sc = 1.0f;
+    if (g >= 0) { const float m = __uint_as_float(group_max[g]); sc = m < 1e-10f ? 1.0f : target / m; }
+    unit_scale[i] = sc;
+}
+hipError_t launch_absmax_group(const float* x, long n, unsigned* group_max_cell, hipStream_t s) {
+    absmax_group_kernel<<<dim3(1), dim3(1024), 0, s>>>(x, n, group_max_cell);
+    return hipGetLastError();
+}
+hipError_t launch_group_scale(const unsigned* group_max, const int* unit_group, int n, float target, float* unit_scale, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    group_scale_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(group_max, unit_group, n, target, unit_scale);
     return hipGetLastError();
 }
 

@@ -500,9 +500,11 @@ class Q4VoxtralModel:
         check(lib().vox_transcribe_audio(self.h, ptr, n_samples, _ptr(t), _ptr(ids), cap, C.byref(n), kind))
         return ids[:n.value].copy()
 
-    def transcribe_batch(self, samples_list, t_embed, device_ptrs=None, n_samples=None):
+    def transcribe_batch(self, samples_list, t_embed, device_ptrs=None, n_samples=None, norm_group=None):
         """Batched whole-path transcription of independent utterances (<= 4096; wider than 16: continuous batching over decode slots): list of float32 sample arrays
-        (or device pointers + lengths) -> list of id arrays.  Decode steps are batched so weights stream once per step."""
+        (or device pointers + lengths) -> list of id arrays.  Decode steps are batched so weights stream once per step.
+        norm_group (vox_transcribe_batch_ex): per unit, the id of the FILE whose peak normalises it (the CLI's semantics: normalise the file, then chunk it,
+        bin/transcribe.rs:207-226); < 0 = use the unit as it is; None = every unit normalises itself."""
         t = _f32(t_embed).reshape(-1)
         if device_ptrs is None:
             arrs = [_f32(x) for x in samples_list]; n = len(arrs)
@@ -512,7 +514,13 @@ class Q4VoxtralModel:
         caps = [int(lens[i]) // 1280 + 128 for i in range(n)]
         outs = [np.zeros(cp, dtype=np.int32) for cp in caps]
         optrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs]); ccaps = (C.c_int32 * n)(*caps); nids = (C.c_int32 * n)()
-        check(lib().vox_transcribe_batch(self.h, n, ptrs, lens, _ptr(t), optrs, ccaps, nids, kind))
+        if norm_group is None:
+            check(lib().vox_transcribe_batch(self.h, n, ptrs, lens, _ptr(t), optrs, ccaps, nids, kind))
+        else:
+            if len(norm_group) != n:
+                raise ValueError("norm_group needs one entry per unit")
+            grp = (C.c_int32 * n)(*[int(g) for g in norm_group])
+            check(lib().vox_transcribe_batch_ex(self.h, n, ptrs, lens, grp, _ptr(t), optrs, ccaps, nids, kind))
         return [outs[i][:nids[i]].copy() for i in range(n)]
 
     def timings(self):

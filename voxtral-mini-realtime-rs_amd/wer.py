@@ -170,7 +170,7 @@ def load_manifest(path: str):
 
 
 def main(argv=None):
-    """`python -m ... wer --manifest corpus.tsv --gguf model.gguf --tokenizer tekken.json [--delay 6] [--batch 16]`: the eval_wer.py flow
+    """`python -m ... wer --manifest corpus.tsv --gguf model.gguf --tokenizer tekken.json [--delay 6] [--batch 1024]`: the eval_wer.py flow
     (:345-399) with the model loaded once in-process; prints the report, writes wer_<dataset>.json."""
     import argparse, io, contextlib, os, wave
     ap = argparse.ArgumentParser(description="WER evaluation for Voxtral (MI355X HIP path)")
