@@ -341,6 +341,10 @@ int32_t vox_debug_occupy(vox_ctx* ctx, int32_t workgroups, int32_t micros);
 int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t iters, double* avg_us, double* bytes_per_launch,
                               const char** kernel_name);
 
+/* The wide decode step's operators on their own (tools/wide_bench.py): operator `which` (0 q|k|v, 1 wo, 2 w1|w3, 3 w2, 4 lm_head) over `mt` = 2..4 slot groups of 16 rows,
+ * `iters` launches cycling the layers; out_us[0] the GEMM launch, [1] its finishing launch, [2] both, [3] the same operator as `mt` 16-row launches back to back. */
+int32_t vox_bench_wide(vox_model* m, int32_t which, int32_t mt, int32_t iters, double out_us[4]);
+
 /* Measurement builds only (the library compiled with -DVOX_TIMELINE; VOX_ERR_UNSUPPORTED otherwise): every decode-step GEMV /
  * attention launch after _start takes the next of `n_slots` slots and each of its first `n_waves` waves stamps the 100 MHz
  * s_memrealtime counter at 4 points; _fetch copies out[n_slots][n_waves][4] back and switches the instrumentation off. */

@@ -272,6 +272,14 @@ def test_full_wide_batches_peaked_golden_64_lockstep_and_81_continuous(pkg, monk
                 assert np.array_equal(o, ref_of[id(c)]); n_cmp += 1
         assert n_cmp >= 64
         assert all((a == b).all() for a, b in zip(o81, m.transcribe_batch(b81, t)))      # deterministic
+        # round 6: the WIDE step (2..4 active slot groups as ONE GEMM per operator, launch_q4_wide) on forced 3 and 4 slot groups: same ids, golden clip ALL 108
+        for G, wmin in ((4, 2), (3, 3), (4, 4)):
+            monkeypatch.setenv("VOX_BATCH_SLOT_GROUPS", str(G)); monkeypatch.setenv("VOX_BATCH_WIDE_MIN", str(wmin))
+            w81 = m.transcribe_batch(b81, t)
+            for sl in (0, 40, 80):
+                assert np.array_equal(w81[sl], rids), f"wide step ({G} groups, from {wmin}): slot {sl} differs from the oracle"
+            assert all(len(a) == len(b) and (a == b).all() for a, b in zip(w81, o81)), f"wide step ({G} groups, from {wmin}) and the default path disagree"
+        monkeypatch.delenv("VOX_BATCH_SLOT_GROUPS"); monkeypatch.delenv("VOX_BATCH_WIDE_MIN")
         print(f"peaked golden: 64-row lock-step and continuous batches, 81-row continuous batch -- golden clip ALL 108 ids in every placed slot, {n_cmp} rows identical across the batches")
     finally:
         m.close(); ctx.close()
@@ -288,6 +296,7 @@ def test_full_chunked_files_are_units_of_the_wide_batch(pkg):
         pkg.synth.write_synthetic_gguf(path + ".tmp", pkg.synth.ModelDims(), seed=44, peaked=True); os.replace(path + ".tmp", path)
     S = pkg.synth; t = pkg.TimeEmbedding(3072).embed(6.0)
     files = [0.4 * S.synth_audio(30.0, seed=9101), 0.7 * S.synth_audio(25.0, seed=9102), 0.25 * S.synth_audio(16.0, seed=7049)]
+    files[0][:192000] *= np.float32(1e-3)      # a first chunk 60 dB below its file's peak: under the FILE's scale most of its log-mel sits at the floor
     files += [(0.1 + 0.05 * i) * S.synth_audio(3.0 + 0.7 * i, seed=9200 + i) for i in range(12)]
     cfg = pkg.ChunkConfig.voxtral().with_max_frames(1200)
     raw, nrm, grp = [], [], []
@@ -303,6 +312,9 @@ def test_full_chunked_files_are_units_of_the_wide_batch(pkg):
         assert [len(o) for o in outs[6:8]] == [83, 33]                                        # CLI default chunk A / chunk B emit 83 / 33 ids
         as_is = m.transcribe_batch(nrm, t, norm_group=[-1] * len(nrm))
         assert all(len(a) == len(b) and (a == b).all() for a, b in zip(outs, as_is)), "device-side file peaks != host-normalised files"
+        own = m.transcribe_batch(raw, t)                                                        # every chunk normalised by ITS OWN peak: not the reference's arithmetic
+        assert (own[0] != outs[0]).any(), "the quiet first chunk of file 0 must decode differently under its own peak than under its file's"
+        assert all((a == b).all() for a, b in zip(own[8:], outs[8:]))                           # un-chunked files: the file IS the unit
         mel = pkg.MelSpectrogram.voxtral(ctx); n_same = 0
         for u, c in enumerate(nrm):
             rids, rlg = m.transcribe_streaming(np.ascontiguousarray(mel.compute_log(pkg.pad_audio(c)).T)[None], t, return_logits=True)

@@ -137,6 +137,7 @@ SIGNATURES = {
     "vox_forward_with_cache": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, P(i32), i32]),
     "vox_get_stage_timings": (i32, [vp, P(Timings)]),
     "vox_bench_decode_gemv": (i32, [vp, i32, i32, P(C.c_double), P(C.c_double), P(C.c_char_p)]),
+    "vox_bench_wide": (i32, [vp, i32, i32, i32, P(C.c_double)]),
     "vox_debug_timeline_start": (i32, [vp, i32, i32]),
     "vox_debug_timeline_fetch": (i32, [vp, vp, sz, P(i32), vp]),
 }

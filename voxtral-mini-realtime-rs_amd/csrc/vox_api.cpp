@@ -95,7 +95,7 @@ struct vox_ctx {
     std::vector<PoolEntry> pool;
     // side streams + fork/join events: independent 16-row groups of a wide batched decode step run concurrently
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    uint32_t warm_forms = 0;      // continuous batch: step forms whose kernels have run once on this context's device (bit 0 launch chains, bit 1 engine + tail)
+    uint32_t warm_forms = 0;      // continuous batch: step forms whose kernels have run once on this context's device (bit 0 launch chains, bit 1 engine + tail, bits 2..4 the wide step at 2 / 3 / 4 groups)
     // XF tiles of a 17..48-row GEMM input (the 38-token prefill): 3 tiles x K columns x 64 B; sized once for K <= 16384, reused by every such GEMM of the stream
     uint16_t* xf_scratch = nullptr; size_t xf_scratch_bytes = 0;
     float* kz_scratch = nullptr; size_t kz_scratch_bytes = 0;      // K-slice planes of the 17..48-row GEMMs (q4_skinny_mt2_kernel): 8 x 48 x 18432 floats
@@ -2387,7 +2387,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
 static const double kStepMs[5] = {0.0, 1.84, 2.08, 2.75, 3.40};
 // ... with the batched decode-layer engine serving the steps of <= 2 active groups (one group: decode_engine_b16_kernel<1>, 1.06 ms + tail; two: the two-group launch,
 // 1.60 ms + tail; three and four groups stay on the forked launch chains -- a two-group launch + a one- or two-group launch back to back: 2.9 / 3.4 ms against 2.75 / 3.40)
-static const double kStepMsEng[5] = {0.0, 1.17, 1.77, 2.75, 3.40};
+static const double kStepMsEng[5] = {0.0, 1.17, 1.77, 2.75, 3.15};      // (four groups: the wide step, round 6)
 struct SlotPlan { int G = 0; std::vector<std::vector<int>> queue; std::vector<int> steps_g; double cost_ms = 0.0; };
 // jobs: (decode steps, utterance) with steps >= 1.  LPT onto 16 G slots, slots ordered by load (so the groups retire last to first), G by the cost model.
 static SlotPlan plan_slots(const std::vector<std::pair<int, int>>& jobs_in, int force_G, const double* step_ms) {
@@ -2581,6 +2581,54 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
               g.ssq_part = ssq; g.n_part = parts_D; g.norm_eps = c.norm_eps; HIPCHK(launch_q4_gemm(g, EPI_STORE, sg)); }
             return VOX_OK;
         };
+        // WIDE step (round 6): the layer operators of 2..4 active slot groups as ONE GEMM each (launch_q4_wide: one weight fetch and one nibble -> bf16 conversion per K
+        // step for all groups, the groups' XF planes staged through LDS once per workgroup, K split over workgroups + a finishing launch with the step's epilogue), the
+        // attention of all groups in one launch, the lm_head as one GEMM.  Active groups are always a prefix 0 .. n_act - 1 (the slots are ordered by load).
+        // Measured (tools/wide_probe.py, 24 s clips, every slot busy; profiles/r06_wide_step.txt): 64 slots 3.26 ms per step against 3.55 on four forked chains, 48 slots
+        // 3.11 against 3.04 -- the wide step serves the steps with >= wide_min active groups, 4 by default (VOX_BATCH_WIDE_MIN=2 / 3: measurement knob and tests).
+        int wide_min = 4; if (const char* e = knob_str("VOX_BATCH_WIDE_MIN")) wide_min = std::max(2, std::min(5, atoi(e)));
+        bool wide_ok = !knob_str("VOX_BATCH_NO_WIDE") && G >= wide_min && hd == 128;
+        size_t planes_bytes = 0;
+        if (wide_ok) {
+            for (int mtw = wide_min; mtw <= G && wide_ok; mtw++) {
+                const struct { const Q4W* w; int epi; } ops[5] = {{&m->dec[0].wqkv.w, EPI_ROPE_KV}, {&m->dec[0].wo.w, EPI_RESID_XF}, {&m->dec[0].w13.w, EPI_SWIGLU_XF}, {&m->dec[0].w2.w, EPI_RESID_XF}, {&m->tok.w, EPI_STORE}};
+                for (auto& o : ops) { WidePlan pl; if (!q4_wide_plan(*o.w, mtw, o.epi, &pl)) { wide_ok = false; break; } if (o.epi != EPI_STORE) planes_bytes = std::max(planes_bytes, q4_wide_planes_bytes(*o.w, mtw, pl)); }
+            }
+            for (int l = 1; l < c.dec_layers && wide_ok; l++) { const DecLayer& L = m->dec[l]; const DecLayer& L0 = m->dec[0];
+                if (L.wqkv.w.N != L0.wqkv.w.N || L.wqkv.w.K != L0.wqkv.w.K || L.w13.w.N != L0.w13.w.N || L.w2.w.K != L0.w2.w.K || !L.wqkv.w.qt || !L.wo.w.qt || !L.w13.w.qt || !L.w2.w.qt || L.wqkv.bias || L.wo.bias || L.w13.bias || L.w2.bias) wide_ok = false; }
+        }
+        DevBuf b_planes;
+        if (wide_ok) HIPCHK(b_planes.alloc_pooled(cx, planes_bytes));
+        auto wide_chain = [&](int mtw, hipStream_t sg) -> int32_t {
+            uint16_t* xf1 = b_xf1.as<uint16_t>(); uint16_t* xf2 = b_xf2.as<uint16_t>(); uint16_t* xf3 = b_xf3.as<uint16_t>(); float* ssq = b_ssq.as<float>();
+            float* hg = b_h.as<float>(); float* qg = b_qkv.as<float>();
+            auto base = [&](const Q4W& w, const uint16_t* xin, int K) {
+                GemmParams g{}; g.w = w; g.xf = (const uint4*)xin; g.xf_gstride = (long)(xf_bytes(K) / 16); g.M = 16 * mtw; g.wide_mt = mtw;
+                g.kz_scratch = b_planes.as<float>(); g.kz_scratch_bytes = planes_bytes; g.norm_eps = c.norm_eps; return g;
+            };
+            for (int l = 0; l < c.dec_layers; l++) {
+                const DecLayer& L = m->dec[l];
+                float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;
+                { GemmParams g = base(L.wqkv.w, xf1, D); g.out = qg; g.out_stride = W; g.ssq_part = ssq; g.ssq_part_gstride = (long)parts_D * 16; g.n_part = l == 0 ? 1 : parts_D;
+                  g.pos = d_pos; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd; g.kv_row = d_kvrow;
+                  HIPCHK(launch_q4_wide(g, EPI_ROPE_KV, sg)); }
+                AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = b_att.as<float>(); ap.n_heads = H; ap.n_kv_heads = KV;
+                ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride; ap.kv_row = d_kvrow;
+                ap.out_xf = xf2; ap.out_xf_gstride = (long)(xf_bytes(QD) / 2); ap.prefer_gqa = 1; ap.no_xcd_remap = knob_str("VOX_ATTN_NO_XCD") != nullptr; ap.spec_rows = 0;
+                HIPCHK(launch_attn_decode(ap, hd, max_seq, sg, 16 * mtw));
+                { GemmParams g = base(L.wo.w, xf2, QD); g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
+                  g.xf_out = xf1; g.xf_out_gstride = (long)(xf_bytes(D) / 2); g.xf_w = L.ffn_norm; g.xf_w2 = L.ada_mul; g.ssq_out = ssq; g.ssq_out_gstride = (long)parts_D * 16;
+                  HIPCHK(launch_q4_wide(g, EPI_RESID_XF, sg)); }
+                { GemmParams g = base(L.w13.w, xf1, D); g.out = (float*)xf3; g.out_stride = F; g.xf_out_gstride = (long)(xf_bytes(F) / 2);
+                  g.ssq_part = ssq; g.ssq_part_gstride = (long)parts_D * 16; g.n_part = parts_D; HIPCHK(launch_q4_wide(g, EPI_SWIGLU_XF, sg)); }
+                { GemmParams g = base(L.w2.w, xf3, F); g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
+                  g.xf_out = xf1; g.xf_out_gstride = (long)(xf_bytes(D) / 2); g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; g.ssq_out_gstride = (long)parts_D * 16;
+                  HIPCHK(launch_q4_wide(g, EPI_RESID_XF, sg)); }
+            }
+            { GemmParams g = base(m->tok.w, xf1, D); g.out = b_logits.as<float>(); g.out_stride = V; g.ssq_part = ssq; g.ssq_part_gstride = (long)parts_D * 16; g.n_part = parts_D;
+              HIPCHK(launch_q4_wide(g, EPI_STORE, sg)); }
+            return VOX_OK;
+        };
         int eng_per_step = 0;      // engine launches enqueued by the last call of `step`
         auto engine_params = [&](int gi, int blk, bool two = false) {
             const int r0 = gi * 16;
@@ -2618,6 +2666,10 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
                 if (gb >= 0) HIPCHK(hipStreamWaitEvent(s, cx->ev_join[0], 0));
                 HIPCHK(launch_argmax_embed_slots(sp, Sl, s));
                 return VOX_OK;
+            }
+            if (wide_ok && n_act >= wide_min) {      // (steps with one group, or two when the engine serves them, never get here)
+                bool prefix = true; for (int gi = 0; gi < n_act; gi++) if (!((active >> gi) & 1u)) prefix = false;
+                if (prefix) { VOXCHK(wide_chain(n_act, s)); HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); return VOX_OK; }
             }
             const bool fork = n_act > 1 && !knob_str("VOX_BATCH_SERIAL_GROUPS");
             if (fork) {
@@ -2661,7 +2713,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         // next-input launch returns at once; zero rows against the zeroed scratch slice; nothing of the session's state moves); every real step is then a graph replay.
         const int t_start = 0;
         {
-            auto form_of = [&](uint32_t a) { int na = 0; for (int gi = 0; gi < G; gi++) na += (a >> gi) & 1u; return (use_eng && na <= 2) ? 2u : 1u; };
+            auto form_of = [&](uint32_t a) { int na = 0; for (int gi = 0; gi < G; gi++) na += (a >> gi) & 1u; return (use_eng && na <= 2) ? 2u : (wide_ok && na >= wide_min ? 4u << (na - 2) : 1u); };
             bool idle_set = false;
             for (int t = 0; t < steps && !no_graph; t++) {
                 const uint32_t act = active_at(t), f = form_of(act);
@@ -3142,6 +3194,89 @@ extern "C" int32_t vox_forward_with_cache(vox_model* m, const float* mel, int32_
 extern "C" int32_t vox_get_stage_timings(const vox_model* m, vox_timings* out) { ARGCHK(m && out, "null argument"); *out = m->timings; return VOX_OK; }
 
 // ---- measurement hook: average launch duration of one decode-step GEMV class, HIP events on the ctx stream
+// measurement hook of the wide decode step (tools/wide_bench.py): operator `which` (0 q|k|v, 1 wo, 2 w1|w3, 3 w2, 4 lm_head) for `mt` slot groups, `iters` launches cycling the
+// layers (weights HBM-cold); out_us[0] the GEMM launch alone, [1] the finishing launch alone, [2] both back to back, [3] the same operator as `mt` launches of the 16-row
+// skinny kernel back to back on one stream (what a forked chain issues per group)
+extern "C" int32_t vox_bench_wide(vox_model* m, int32_t which, int32_t mt, int32_t iters, double out_us[4]) {
+    ARGCHK(m && out_us && iters > 0 && which >= 0 && which <= 4 && mt >= 2 && mt <= 4, "bad argument"); VOXCHK(ctx_bind(m->ctx));
+    const vox_model_cfg& c = m->cfg; vox_ctx* cx = m->ctx; hipStream_t s = cx->stream;
+    const int D = c.dec_dim, H = c.dec_heads, KV = c.dec_kv_heads, hd = c.dec_head_dim, QD = H * hd, KD = KV * hd, W = QD + 2 * KD, F = c.dec_ffn, V = c.vocab, Sl = 16 * mt, max_seq = 256;
+    ARGCHK(batch_xf_ok(m), "the model has no tile-ordered Q4 weights");
+    if (!m->t_embed_set) { std::vector<float> te(D); vox_time_embedding(6.0f, D, te.data()); VOXCHK(vox_model_set_t_embed(m, te.data())); }
+    auto xf_bytes = [](int K) { return (size_t)2 * (K / 128) * 256 * 16; };
+    const int parts_D = q4_skinny_resid_xf_parts(D);
+    const size_t seq_stride = (size_t)KV * max_seq * hd;
+    DevBuf b_xf, b_xfo, b_ssq, b_h, b_qkv, b_k, b_v, b_pos, b_row, b_planes, b_logits;
+    size_t planes_bytes = 0;
+    const Q4W* w0[5] = {&m->dec[0].wqkv.w, &m->dec[0].wo.w, &m->dec[0].w13.w, &m->dec[0].w2.w, &m->tok.w};
+    const int epis[5] = {EPI_ROPE_KV, EPI_RESID_XF, EPI_SWIGLU_XF, EPI_RESID_XF, EPI_STORE};
+    WidePlan pl; ARGCHK(q4_wide_plan(*w0[which], mt, epis[which], &pl), "no wide plan for this shape");
+    planes_bytes = q4_wide_planes_bytes(*w0[which], mt, pl);
+    HIPCHK(b_xf.alloc(xf_bytes(F) * 4)); HIPCHK(b_xfo.alloc(xf_bytes(F) * 4)); HIPCHK(b_ssq.alloc((size_t)parts_D * 16 * 4 * 4)); HIPCHK(b_h.alloc((size_t)Sl * D * 4)); HIPCHK(b_qkv.alloc((size_t)Sl * W * 4));
+    HIPCHK(b_k.alloc((size_t)Sl * seq_stride * 4)); HIPCHK(b_v.alloc((size_t)Sl * seq_stride * 4)); HIPCHK(b_pos.alloc((size_t)Sl * 4)); HIPCHK(b_row.alloc((size_t)Sl * 4)); HIPCHK(b_planes.alloc(std::max<size_t>(planes_bytes, 16)));
+    if (which == 4) HIPCHK(b_logits.alloc((size_t)Sl * V * 4));
+    {   // random bf16 activations (hi planes ~ N(0,1)-ish magnitudes, lo planes small): all-zero operands run at a higher clock (DVFS), which would flatter the kernel
+        std::vector<uint16_t> hx(xf_bytes(F) * 4 / 2); uint32_t r = 12345u;
+        for (auto& v : hx) { r = r * 1664525u + 1013904223u; v = (uint16_t)(((r >> 16) & 0x8000u) | 0x3F00u | ((r >> 8) & 0xFFu)); }      // +-[0.5, 2)
+        HIPCHK(hipMemcpy(b_xf.p, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+        std::vector<float> one((size_t)parts_D * 16 * 4, 3.0f); HIPCHK(hipMemcpy(b_ssq.p, one.data(), one.size() * 4, hipMemcpyHostToDevice));
+        std::vector<int> pos(Sl, 100), row(Sl); for (int i = 0; i < Sl; i++) row[i] = i;
+        HIPCHK(hipMemcpy(b_pos.p, pos.data(), (size_t)Sl * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(b_row.p, row.data(), (size_t)Sl * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(b_h.p, 0, (size_t)Sl * D * 4));
+    }
+    auto params = [&](int l, bool wide, int gi) {
+        const DecLayer& L = m->dec[l % c.dec_layers];
+        const Q4W& w = which == 0 ? L.wqkv.w : which == 1 ? L.wo.w : which == 2 ? L.w13.w : which == 3 ? L.w2.w : m->tok.w;
+        const int K = w.K;
+        GemmParams g{}; g.w = w; g.norm_eps = c.norm_eps;
+        const size_t go = wide ? 0 : (size_t)gi;      // skinny launches: group gi's planes / rows
+        g.xf = (const uint4*)((const uint8_t*)b_xf.p + go * xf_bytes(K)); g.M = wide ? Sl : 16;
+        if (wide) { g.xf_gstride = (long)(xf_bytes(K) / 16); g.wide_mt = mt; g.kz_scratch = b_planes.as<float>(); g.kz_scratch_bytes = planes_bytes; }
+        float* ssq = b_ssq.as<float>() + go * parts_D * 16; float* hg = b_h.as<float>() + go * 16 * D;
+        switch (which) {
+        case 0: g.out = b_qkv.as<float>() + go * 16 * W; g.out_stride = W; g.ssq_part = ssq; g.ssq_part_gstride = (long)parts_D * 16; g.n_part = parts_D; g.pos = b_pos.as<int>() + go * 16; g.kv_row = b_row.as<int>() + go * 16;
+                g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = b_k.as<float>(); g.vc = b_v.as<float>(); g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd; break;
+        case 1: case 3: g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D; g.xf_out = (uint16_t*)((uint8_t*)b_xfo.p + go * xf_bytes(D)); g.xf_out_gstride = (long)(xf_bytes(D) / 2); g.xf_w = L.ffn_norm; g.xf_w2 = which == 1 ? L.ada_mul : nullptr;
+                g.ssq_out = ssq; g.ssq_out_gstride = (long)parts_D * 16; break;
+        case 2: g.out = (float*)((uint8_t*)b_xfo.p + go * xf_bytes(F)); g.out_stride = F; g.xf_out_gstride = (long)(xf_bytes(F) / 2); g.ssq_part = ssq; g.ssq_part_gstride = (long)parts_D * 16; g.n_part = parts_D; break;
+        default: g.out = b_logits.as<float>() + go * 16 * V; g.out_stride = V; g.ssq_part = ssq; g.ssq_part_gstride = (long)parts_D * 16; g.n_part = parts_D; break;
+        }
+        return g;
+    };
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto timed = [&](int mode, double* us) -> int32_t {
+        for (int rep = 0; rep < 2; rep++) {      // (first repetition: warm-up)
+            HIPCHK(hipEventRecord(e0, s));
+            for (int i = 0; i < iters; i++) {
+                if (mode < 3) { const GemmParams g = params(i, true, 0); HIPCHK(launch_q4_wide(g, epis[which] | (mode == 0 ? 0x100 : mode == 1 ? 0x200 : 0), s)); }
+                else for (int gi = 0; gi < mt; gi++) { const GemmParams g = params(i, false, gi); HIPCHK(launch_q4_gemm(g, epis[which], s)); }
+            }
+            HIPCHK(hipEventRecord(e1, s)); HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); *us = (double)ms * 1000.0 / iters;
+        }
+        return VOX_OK;
+    };
+    if (const char* tl = knob_str("VOX_WIDE_TL")) {      // in-kernel timeline of ONE GEMM launch (layer atoi(tl)): s_memrealtime stamps (100 MHz) of wave 0 of every workgroup
+        const int n_wg = ((w0[which]->N / 16 + 4 * pl.ntw - 1) / (4 * pl.ntw)) * pl.kz;
+        DevBuf b_tl; HIPCHK(b_tl.alloc((size_t)n_wg * 64)); HIPCHK(hipMemset(b_tl.p, 0, (size_t)n_wg * 64));
+        GemmParams g = params(atoi(tl), true, 0); g.bias = (const float*)b_tl.p;
+        setenv("VOX_WIDE_ABL", "8", 1); vox_debug_reload_knobs();
+        HIPCHK(launch_q4_wide(g, epis[which] | 0x100, s)); HIPCHK(hipStreamSynchronize(s));
+        unsetenv("VOX_WIDE_ABL"); vox_debug_reload_knobs();
+        std::vector<unsigned long long> h((size_t)n_wg * 8); HIPCHK(hipMemcpy(h.data(), b_tl.p, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull; for (int i = 0; i < n_wg; i++) if (h[(size_t)i * 8]) t0 = std::min(t0, h[(size_t)i * 8]);
+        static const char* nm[8] = {"entry", "prologue issued", "A(0) in registers + cs", "first barrier passed", "step 0 done", "step 1 done", "all steps done", "stored"};
+        fprintf(stderr, "[wide timeline] operator %d, %d workgroups, %d steps per slice; microseconds after the first workgroup's entry: min / median / max over workgroups\n", which, n_wg, pl.sps);
+        for (int k = 0; k < 8; k++) { std::vector<double> v; for (int i = 0; i < n_wg; i++) if (h[(size_t)i * 8 + k]) v.push_back((double)(h[(size_t)i * 8 + k] - t0) * 0.01); if (v.empty()) continue; std::sort(v.begin(), v.end());
+            fprintf(stderr, "  %-24s %7.2f %7.2f %7.2f\n", nm[k], v.front(), v[v.size() / 2], v.back()); }
+    }
+    out_us[1] = 0.0;
+    VOXCHK(timed(0, &out_us[0])); if (which != 4) VOXCHK(timed(1, &out_us[1])); VOXCHK(timed(2, &out_us[2])); VOXCHK(timed(3, &out_us[3]));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIPCHK(hipStreamSynchronize(s));
+    return VOX_OK;
+}
+
 extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t iters, double* avg_us, double* bytes_per_launch, const char** kernel_name) {
     const bool warm = (which & 0x100) != 0;   // measurement variant: same layer every launch (weights stay in L2 / Infinity Cache)
     which &= 0xff;

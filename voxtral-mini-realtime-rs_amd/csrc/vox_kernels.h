@@ -87,7 +87,17 @@ struct GemmParams {
     // The consumer (launch_rms_norm_sumk) adds the slices in a fixed order -- for few-column GEMMs (the encoder's N = 1280 w2: 40 K-steps per workgroup)
     int ksplit;
     float* kz_scratch; size_t kz_scratch_bytes;      // 17..48 rows: room for the K-slice planes of q4_skinny_mt2_kernel ([ksplit][M][N] f32); null: the one-dimensional kernel
+    // wide decode step (launch_q4_wide): M = 16 * wide_mt rows = wide_mt slot groups of 16; rows of consecutive groups are consecutive in out / resid / pos / kv_row,
+    // the XF planes and the partial sums of squares of group g start g * (the group stride) after group 0's
+    int wide_mt; long xf_gstride /* uint4 */, xf_out_gstride /* uint16 */, ssq_part_gstride, ssq_out_gstride /* floats */;
 };
+// ---- wide decode step (round 6): 32 / 48 / 64 rows (2..4 slot groups of a continuous batch) through ONE weight fetch and ONE nibble -> bf16 conversion per K step.
+// GEMM (q4_wide_kernel: the groups' XF planes staged through LDS once per workgroup, K split over workgroups into planes) + a finishing launch that sums the planes in a
+// fixed order and applies the batched step's epilogues (EPI_ROPE_KV / EPI_RESID_XF / EPI_SWIGLU_XF); EPI_STORE with one K slice (the lm_head) stores directly.
+struct WidePlan { int kz, sps, ntw; };      // K slices, K steps (128 columns) per slice, n-tiles per wave
+bool q4_wide_plan(const Q4W& w, int mt, int epi, WidePlan* pl);
+size_t q4_wide_planes_bytes(const Q4W& w, int mt, const WidePlan& pl);
+hipError_t launch_q4_wide(const GemmParams& p, int epi, hipStream_t s);      // p.xf (+ xf_gstride), p.wide_mt, p.kz_scratch (planes); epilogue fields as launch_q4_gemm's XF step
 hipError_t launch_q4_tile_build(Q4W w, uint4* qt, uint16_t* st, hipStream_t s);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s);
 // dense f32-class GEMM on two bf16 weight planes (w.fmt == WFMT_BF16X2; the conv stem as an im2col GEMM); epi: EPI_STORE / EPI_GELU
@@ -137,6 +147,7 @@ struct AttnParams {
     const int* seq_len;
     const int* seq_row_off;   // stacked prefill, optional (MFMA kernel only): sequence z starts seq_row_off[z] ROWS into q / k / v / out (ragged sequences packed back to back) instead of z * the sequence strides
     uint16_t* out_xf;     // batched decode: write the output rows (row = sequence) as XF fragment planes instead of out
+    long out_xf_gstride;  // ... more than 16 sequences in one launch (attn_decode_gqa_kernel): sequence s is row s % 16 of the planes out_xf + (s / 16) * out_xf_gstride (uint16 units)
     int prefer_gqa;       // batched decode: one workgroup per (KV head, sequence) serving its 4 query heads (wide batches)
     int no_xcd_remap;     // measurement knob: keep the linear (head, sequence) workgroup order in attn_decode_kernel
     int tl_slot;          // timeline slot (measurement builds, -DVOX_TIMELINE)

@@ -448,7 +448,10 @@ static hipError_t ensure_dyn_lds(Kern kern, size_t lds, DevOnce* done) {
     if (lds <= 48 * 1024) return hipSuccess;
     const int dev = vox_current_device();
     if (done->done(dev)) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (the limit covers static + dynamic LDS: a kernel that also declares __shared__ arrays may only ask for the remainder)
+    hipFuncAttributes fa; size_t stat = 0;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) == hipSuccess) stat = fa.sharedSizeBytes; else (void)hipGetLastError();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - std::min<size_t>(stat, 96 * 1024)));
     if (e == hipSuccess) done->set(dev);
     return e;
 }
@@ -1367,6 +1370,308 @@ __global__ __launch_bounds__(NTW == 3 ? 256 : 512, NTW == 3 ? 3 : 1) void q4_ski
         }
     }
     VOX_TL(p.tl_slot, tlw, 3);
+}
+
+// ---- WIDE decode step (round 6): 32 / 48 / 64 rows -- MT slot groups of a continuous batch -- as ONE GEMM per operator.  The forked per-group chains
+// of q4_skinny_kernel fetch, convert (nibble -> bf16, block scales) and correct (-136 sum x) every weight tile once PER GROUP, and every workgroup pulls its group's whole
+// XF block through its L1: four concurrent chains move ~1.3 GB per layer through the L1s for 65 MB of weights and the step cost grows linearly with the groups
+// (1.84 / 2.08 / 2.75 / 3.40 ms for 1..4).  Here:
+//  * workgroup = 4 waves, wave w owns NTW n-tiles of the workgroup's n-range; all four walk the SAME K slice (blockIdx.y: K steps [z * sps, +sps)), so each K step's
+//    activations -- the MT groups' bf16 hi + lo A fragments, MT x 8 KB -- are fetched from L2 ONCE per workgroup into a double-buffered LDS stage (every thread moves
+//    2 MT uint4: global -> registers one step ahead -> ds_write_b128, all 1 KB-contiguous per wave: conflict-free) and read back by all waves as MFMA operands;
+//  * a wave converts its weight dwords to B fragments once per K step and multiplies them with the MT groups' fragments: same exact-integer arithmetic as the skinny
+//    kernel (bf16 128 + q operands, -136 sum x as the first MFMA pair of every (group, block), f16 block scale on the f32 result);
+//  * weights come through a 4-deep register ring issued in consumption order (vmcnt retires in order: the A loads of step s + 2 are requested before the weights of
+//    step s + 4, see the skinny kernel's notes);
+//  * K is split ACROSS workgroups (the N = 3072 operators have 192 n-tiles: split-K inside a workgroup is what makes every workgroup re-read the whole XF block): slice
+//    z stores its accumulators as plane z, in accumulator layout ([z][group][n-tile][lane] float4: 1 KB per wave store), and wide_finish_kernel sums the planes in a
+//    fixed order (deterministic) and applies the step's epilogue.  One K slice (the lm_head: 8192 n-tiles) stores the logits directly.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8 v4_as_bf16x8(u32x4_t v) { union { u32x4_t u; bf16x8 b; } c; c.u = v; return c.b; }
+// Run-time step loop, unrolled by two (register buffers with static indices), every load unconditional with a clamped step index: a branch around a load makes hipcc
+// drain vmcnt at the join.  (Tried and dropped: the slice's steps as straight-line code per step count -- hipcc hoists the address arithmetic and the loads of all steps
+// to the top, 1 - 13 KB of scratch per lane, 10 x slower.)
+template <int MT, int NTW, bool DIRECT>
+__global__ __launch_bounds__(256, 2) void q4_wide_kernel(const GemmParams p, const int sps, float* __restrict__ planes) {
+    constexpr int SPS = 0;
+    unsigned long long* tlb = (SPS == 0 && (p.ksplit & 8)) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias)) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define VOX_WTL(I_) { if (SPS == 0 && tlb && threadIdx.x == 0) tlb[I_] = __builtin_amdgcn_s_memrealtime(); }
+    VOX_WTL(0)
+    const int abl = p.ksplit;      // measurement only (tools/wide_bench.py, VOX_WIDE_ABL): 1 no MFMA work, 2 no A loads past the prologue, 4 no weight loads past it (results wrong)
+    extern __shared__ __attribute__((aligned(16))) u32x4_t wlds[];      // [2 stages][MT][hi, lo][4 j][64 lanes]
+    __shared__ float s_rstd[MT * 16]; __shared__ float s_pp[16 * 16];
+    __shared__ __attribute__((aligned(16))) float s_cs[2][MT][4][4][4];      // [stage][group][block j][lane group g][4 rows]: the -136 sum(x) correction of every (row, block) of the step
+    constexpr int STAGE = MT * 8 * 64, NA = 2 * MT;      // uint4 per stage; uint4 per thread and stage
+    const int N = p.w.N, nq = p.w.nb >> 2, n_tiles = (N + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int tile0 = ((int)blockIdx.x * 4 + wave) * NTW, q0 = (int)blockIdx.y * sps;
+    const uint4* wq[NTW]; const uint16_t* ws[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const size_t T = (size_t)min(tile0 + t, n_tiles - 1);
+        wq[t] = p.w.qt + (T * nq + q0) * 64 + lane; ws[t] = p.w.st + ((T * nq + q0) * 16 + li) * 4;
+    }
+    // this thread's share of an A stage: uint4 i = tid + 256 u of the stage, line = i >> 6 = (group, hi / lo, j)
+    const u32x4_t* asrc[NA];      // (native vector types below: arrays of the uint4 STRUCT with conditional writes end up in scratch)
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+        const int i = tid + 256 * u, line = i >> 6, mt = line >> 3, hl = (line >> 2) & 1, j = line & 3;
+        asrc[u] = reinterpret_cast<const u32x4_t*>(p.xf) + (size_t)mt * p.xf_gstride + (size_t)hl * nq * 256 + ((size_t)q0 * 4 + j) * 64 + (i & 63);
+    }
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4_t areg[1][NA]; u32x4_t wr[2][NTW]; u32x2_t sr[2][NTW];      // A: one step ahead (an L2 / MALL hit: ~1.5 us against a ~2 us step), weights two (generic loop) or four steps
+#define VOX_AISSUE(B_, S_) { _Pragma("unroll") for (int u = 0; u < NA; u++) areg[0][u] = asrc[u][(size_t)(S_) * 256]; }
+#define VOX_WISSUE(B_, S_) { _Pragma("unroll") for (int t = 0; t < NTW; t++) { wr[B_][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wq[t] + 64 * (S_))); sr[B_][t] = *reinterpret_cast<const u32x2_t*>(ws[t] + 64 * (S_)); } }
+    VOX_AISSUE(0, 0) VOX_WISSUE(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    VOX_WTL(1)
+    { const int s1 = min(1, sps - 1); VOX_WISSUE(1, s1) }
+    __builtin_amdgcn_sched_barrier(0);
+    if (DIRECT) {      // fused RMSNorm, consumer side (as q4_skinny_kernel PRO): rstd of every row from the producer's partial sums of squares; requested behind the first operands
+        const int prow = tid & 15, pch = tid >> 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            float a = 0.f;
+            for (int pi = pch; pi < p.n_part; pi += 16) a += p.ssq_part[(size_t)mt * p.ssq_part_gstride + (size_t)pi * 16 + prow];
+            s_pp[pch * 16 + prow] = a;
+            __syncthreads();
+            if (tid < 16) { float b = 0.f; for (int c = 0; c < 16; c++) b += s_pp[c * 16 + tid]; s_rstd[mt * 16 + tid] = 1.0f / sqrtf(b / (float)p.w.K + p.norm_eps); }
+            __syncthreads();
+        }
+    }
+    const bf16x8 m136 = as_bf16x8(make_uint4(0xC308C308u, 0xC308C308u, 0xC308C308u, 0xC308C308u));
+#define VOX_WSTEP(K_, S_)                                                                                          \
+    {                                                                                                              \
+        u32x4_t* stg = wlds + ((K_) & 1) * STAGE;                                                                    \
+        /* the uint4 this thread stages are exactly the A fragments (group u / 2, hi / lo u & 1) of block j = wave for its lane: the correction -136 sum_k x_k of every  \
+           (row, block) -- one MFMA pair against a constant B, the same for every n-tile -- is computed ONCE per workgroup here, from registers, and published with the stage */ \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {                                                        \
+            f32x4 c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v4_as_bf16x8(areg[0][2 * mt]), m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v4_as_bf16x8(areg[0][2 * mt + 1]), m136, c_, 0, 0, 0); \
+            if (li == 0) *reinterpret_cast<f32x4*>(&s_cs[(K_) & 1][mt][wave][g][0]) = c_;                          \
+        }                                                                                                          \
+        _Pragma("unroll") for (int u = 0; u < NA; u++) stg[tid + 256 * u] = areg[0][u];                     \
+        if ((S_) == 0) VOX_WTL(2)                                                                                  \
+        __syncthreads();      /* stage (K_ & 1) holds step S_; every wave is done with step S_ - 1 (the other stage) */ \
+        if ((S_) == 0) VOX_WTL(3)                                                                                  \
+        uint32_t dw[NTW][4]; u32x2_t sv[NTW];                                                                        \
+        _Pragma("unroll") for (int t = 0; t < NTW; t++) { dw[t][0] = wr[K_][t].x; dw[t][1] = wr[K_][t].y; dw[t][2] = wr[K_][t].z; dw[t][3] = wr[K_][t].w; sv[t] = sr[K_][t]; } \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        { const int sa = min((S_) + 1, sps - 1), sn = min((S_) + 2, sps - 1); if (!(abl & 2)) VOX_AISSUE(0, sa) if (!(abl & 4)) VOX_WISSUE((K_) & 1, sn) }      /* in consumption order: A one step ahead, the weights two */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        if (!(abl & 1)) {                                                                                          \
+            /* groups in sets of MH (all MT, or two at MT 4 x NTW 2, which sits at the 256-register limit): the set's chains are interleaved -- every MFMA's input comes \
+               from MH * NTW MFMAs earlier, not from the one before it -- and, where the registers allow (PF), block j + 1's fragments are requested before block j is multiplied */ \
+            constexpr int MH = MT * NTW >= 8 ? MT / 2 : MT, NH = MT / MH; constexpr bool PF = NH == 1;              \
+            u32x4_t fr[PF ? 2 : 1][MH][2]; f32x4 csr[PF ? 2 : 1][MH];                                              \
+            if (PF) { _Pragma("unroll") for (int mt = 0; mt < MH; mt++) { fr[0][mt][0] = stg[((mt * 2 + 0) * 4 + 0) * 64 + lane]; fr[0][mt][1] = stg[((mt * 2 + 1) * 4 + 0) * 64 + lane]; \
+                                                                           csr[0][mt] = *reinterpret_cast<const f32x4*>(&s_cs[(K_) & 1][mt][0][g][0]); } } \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                        \
+                bf16x8 bw[NTW]; float d[NTW];                                                                      \
+                _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                  \
+                    bw[t] = as_bf16x8(q4_dword_to_bf16x8_biased(dw[t][j]));                                        \
+                    const uint32_t sc2 = (j >> 1) ? sv[t].y : sv[t].x;                                             \
+                    d[t] = f16_bits_to_f32((uint16_t)((j & 1) ? (sc2 >> 16) : (sc2 & 0xFFFFu)));                   \
+                }                                                                                                  \
+                _Pragma("unroll") for (int h = 0; h < NH; h++) {                                                   \
+                    constexpr int dummy_ = 0; (void)dummy_;                                                        \
+                    const int cur = PF ? (j & 1) : 0;                                                              \
+                    if (!PF) { _Pragma("unroll") for (int mt = 0; mt < MH; mt++) { const int mg_ = h * MH + mt; fr[0][mt][0] = stg[((mg_ * 2 + 0) * 4 + j) * 64 + lane]; fr[0][mt][1] = stg[((mg_ * 2 + 1) * 4 + j) * 64 + lane]; \
+                                                                                    csr[0][mt] = *reinterpret_cast<const f32x4*>(&s_cs[(K_) & 1][mg_][j][g][0]); } } \
+                    else if (j < 3) { _Pragma("unroll") for (int mt = 0; mt < MH; mt++) { fr[(j + 1) & 1][mt][0] = stg[((mt * 2 + 0) * 4 + j + 1) * 64 + lane]; fr[(j + 1) & 1][mt][1] = stg[((mt * 2 + 1) * 4 + j + 1) * 64 + lane]; \
+                                                                                           csr[(j + 1) & 1][mt] = *reinterpret_cast<const f32x4*>(&s_cs[(K_) & 1][mt][j + 1][g][0]); } } \
+                    f32x4 tt[MH][NTW];                                                                             \
+                    _Pragma("unroll") for (int mt = 0; mt < MH; mt++)                                              \
+                        _Pragma("unroll") for (int t = 0; t < NTW; t++) tt[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v4_as_bf16x8(fr[cur][mt][0]), bw[t], csr[cur][mt], 0, 0, 0); \
+                    _Pragma("unroll") for (int mt = 0; mt < MH; mt++)                                              \
+                        _Pragma("unroll") for (int t = 0; t < NTW; t++) tt[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v4_as_bf16x8(fr[cur][mt][1]), bw[t], tt[mt][t], 0, 0, 0); \
+                    _Pragma("unroll") for (int mt = 0; mt < MH; mt++)                                              \
+                        _Pragma("unroll") for (int t = 0; t < NTW; t++) acc[h * MH + mt][t] = __builtin_elementwise_fma((f32x4){d[t], d[t], d[t], d[t]}, tt[mt][t], acc[h * MH + mt][t]); \
+                }                                                                                                  \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+    for (int s0 = 0; s0 < sps; s0 += 2) {
+        VOX_WSTEP(0, s0)
+        if (s0 == 0) VOX_WTL(4)
+        if (s0 + 1 < sps) VOX_WSTEP(1, s0 + 1)
+        if (s0 == 0) VOX_WTL(5)
+    }
+    VOX_WTL(6)
+#undef VOX_WSTEP
+#undef VOX_AISSUE
+#undef VOX_WISSUE
+    if (DIRECT) {      // one K slice: out[row][n] = rstd[row] * acc (the lm_head's logits)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const float4 rs = *reinterpret_cast<const float4*>(s_rstd + mt * 16 + 4 * g);
+            const float rr[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+            for (int t = 0; t < NTW; t++) {
+                const int n = (tile0 + t) * 16 + li;
+                if (tile0 + t < n_tiles && n < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) p.out[(size_t)(mt * 16 + 4 * g + r) * p.out_stride + n] = acc[mt][t][r] * rr[r];
+                }
+            }
+        }
+    } else {
+        const int z = blockIdx.y;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int t = 0; t < NTW; t++)
+                if (tile0 + t < n_tiles)
+                    *reinterpret_cast<float4*>(planes + ((((size_t)z * MT + mt) * n_tiles + tile0 + t) * 64 + lane) * 4) = make_float4(acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]);
+    }
+    VOX_WTL(7)
+#undef VOX_WTL
+}
+// finishing launch of the wide step: wave = one (group, n-tile): the K-slice planes summed in slice order (all loads in flight), then q4_skinny_kernel's epilogue for
+// that tile, on the group's rows / XF planes / partial sums of squares.  grid (ceil(n_tiles / 4), MT).
+template <int EPI, int PRO>
+__global__ __launch_bounds__(256) void wide_finish_kernel(const GemmParams p, const float* __restrict__ planes, const int KZ) {
+    __shared__ float s_rstd[16]; __shared__ float s_pp[16 * 16];
+    const int N = p.w.N, n_tiles = (N + 15) >> 4, MT = gridDim.y, mt = blockIdx.y, M = 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int T = min((int)blockIdx.x * 4 + wave, n_tiles - 1); const bool tile_ok = (int)blockIdx.x * 4 + wave < n_tiles;
+    const float* src = planes + (((size_t)mt * n_tiles + T) * 64 + lane) * 4; const size_t zstride = (size_t)MT * n_tiles * 256;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z0 = 0; z0 < KZ; z0 += 8) {      // eight plane loads in flight (a run-time trip count alone made the compiler issue load - wait - add)
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const float4*>(src + (size_t)min(z0 + u, KZ - 1) * zstride);
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (z0 + u < KZ) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+    }
+    // the group's operands: rows 16 mt .. 16 mt + 15 of the row-major buffers, its own XF planes and partial sums
+    const int row0 = mt * 16;
+    if (PRO) {
+        const int prow = tid & 15, pch = tid >> 4; float a = 0.f;
+        const float* sp = p.ssq_part + (size_t)mt * p.ssq_part_gstride + prow;
+        for (int p0 = 0; p0 < p.n_part; p0 += 16 * 12) {      // twelve partials per thread in flight (unconditional clamped loads)
+            float pv[12];
+#pragma unroll
+            for (int u = 0; u < 12; u++) { const int pi = p0 + pch + 16 * u; const float v = sp[(size_t)min(pi, p.n_part - 1) * 16]; pv[u] = pi < p.n_part ? v : 0.f; }
+            a += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7])) + ((pv[8] + pv[9]) + (pv[10] + pv[11]));
+        }
+        s_pp[pch * 16 + prow] = a;
+        __syncthreads();
+        if (tid < 16) { float b = 0.f; for (int c = 0; c < 16; c++) b += s_pp[c * 16 + tid]; s_rstd[tid] = 1.0f / sqrtf(b / (float)p.w.K + p.norm_eps); }
+        __syncthreads();
+        const float4 rs = *reinterpret_cast<const float4*>(s_rstd + 4 * g); sum.x *= rs.x; sum.y *= rs.y; sum.z *= rs.z; sum.w *= rs.w;
+    }
+    if (!tile_ok) return;      // (after the barriers)
+    const int n = T * 16 + li; const bool nok = n < N;
+    const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+    const float vals[4] = {sum.x + bias, sum.y + bias, sum.z + bias, sum.w + bias};
+    float xw = 0.f;
+    if (EPI == EPI_RESID_XF && nok) { xw = p.xf_w[n]; if (p.xf_w2) xw *= p.xf_w2[n]; }
+    uint16_t* xf_out = EPI == EPI_RESID_XF ? p.xf_out + (size_t)mt * p.xf_out_gstride : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int m = 4 * g + r, mg = row0 + m;      // row inside the group / in the row-major buffers
+        float v = vals[r];
+        if (EPI == EPI_SWIGLU_XF) {
+            const float a = silu_f(v) * dpp_mov<0xB1>(v);
+            const float b = __shfl(a, lane + 4, 64);
+            const int k = n >> 1;
+            if (m < M && nok && !(n & 1) && !(k & 2)) {
+                uint32_t hi, lo; split_pair(a, b, hi, lo);
+                const int K2 = N >> 1, qq = k >> 7, jj = (k >> 5) & 3, e = k & 31, half = e >> 4, gg = (e & 15) >> 2, tt = e & 3;
+                const size_t base = ((size_t)((qq * 4 + jj) * 64 + gg * 16 + m)) * 8 + 2 * half + 4 * (tt & 1);
+                uint16_t* xo = reinterpret_cast<uint16_t*>(p.out) + (size_t)mt * p.xf_out_gstride;
+                *reinterpret_cast<uint32_t*>(xo + base) = hi; *reinterpret_cast<uint32_t*>(xo + (size_t)(K2 >> 7) * 256 * 8 + base) = lo;
+            }
+        } else if (EPI == EPI_RESID_XF) {
+            const bool ok = m < M && nok;
+            if (ok) { v = v + p.resid[(size_t)mg * p.resid_stride + n]; p.out[(size_t)mg * p.out_stride + n] = v; } else v = 0.f;
+            const float ss = row16_sum(v * v);
+            if (li == 0) p.ssq_out[(size_t)mt * p.ssq_out_gstride + (size_t)T * 16 + m] = ss;
+            const float a = v * xw, b = dpp_mov<0x4E>(a);
+            if (ok && !(li & 2)) {
+                uint32_t hi, lo; split_pair(a, b, hi, lo);
+                const int qq = n >> 7, jj = (n >> 5) & 3, e = n & 31, half = e >> 4, gg = (e & 15) >> 2, tt = e & 3;
+                const size_t base = ((size_t)((qq * 4 + jj) * 64 + gg * 16 + m)) * 8 + 2 * half + 4 * (tt & 1);
+                *reinterpret_cast<uint32_t*>(xf_out + base) = hi; *reinterpret_cast<uint32_t*>(xf_out + (size_t)(N >> 7) * 256 * 8 + base) = lo;
+            }
+        } else if (EPI == EPI_ROPE_KV) {
+            const float other = dpp_mov<0xB1>(v);
+            if (m < M && nok) {
+                const int ps = p.pos[mg], kd = p.n_kv * p.hd;
+                const int cr = p.kv_row ? p.kv_row[mg] : mg;
+                if (n < p.n_q + kd) {
+                    const int dd = n % p.hd;
+                    const size_t ti = (size_t)ps * (p.hd >> 1) + (dd >> 1);
+                    const float c = p.rope_cos[ti], sn = p.rope_sin[ti];
+                    const float o = (n & 1) ? other * sn + v * c : v * c - other * sn;
+                    if (n < p.n_q) p.out[(size_t)mg * p.out_stride + n] = o;
+                    else p.kc[(size_t)cr * p.kv_seq_stride + (size_t)((n - p.n_q) / p.hd) * p.kv_head_stride + (size_t)ps * p.hd + dd] = o;
+                } else {
+                    const int vn = n - p.n_q - kd;
+                    p.vc[(size_t)cr * p.kv_seq_stride + (size_t)(vn / p.hd) * p.kv_head_stride + (size_t)ps * p.hd + (vn % p.hd)] = v;
+                }
+            }
+        } else if (m < M && nok) {
+            p.out[(size_t)mg * p.out_stride + n] = v;
+        }
+    }
+}
+// plan of one wide GEMM: n-tiles per wave, K slices.  Enough workgroups to fill the chip twice over where the shape allows (2 workgroups of 4 waves per CU), slices of
+// whole K steps.  VOX_WIDE_FORCE="N:ntw:kz" overrides one weight shape (measurement knob).
+bool q4_wide_plan(const Q4W& w, int mt, int epi, WidePlan* pl) {
+    if (mt < 2 || mt > 4 || w.fmt != WFMT_Q4_0 || !w.qt || !w.st || w.nb % 4 || w.N % 16) return false;
+    if (epi != EPI_STORE && epi != EPI_ROPE_KV && epi != EPI_RESID_XF && epi != EPI_SWIGLU_XF) return false;
+    const int nq = w.nb / 4, tiles = w.N / 16;
+    int ntw = tiles >= 384 ? 2 : 1, kz = 1;
+    if (epi != EPI_STORE) {
+        const int ranges = (tiles + 4 * ntw - 1) / (4 * ntw);
+        for (int d = 1; d <= nq; d++) if (nq % d == 0) { kz = d; if ((long)ranges * d >= 320) break; }
+        if (kz > 24) { for (int d = 24; d >= 1; d--) if (nq % d == 0) { kz = d; break; } }
+    }
+    if (const char* f = knob_str("VOX_WIDE_FORCE")) { int fn = 0, fw = 0, fk = 0; if (sscanf(f, "%d:%d:%d", &fn, &fw, &fk) == 3 && fn == w.N && (fw == 1 || fw == 2) && fk >= 1 && fk <= 24 && nq % fk == 0 && (epi != EPI_STORE || fk == 1)) { ntw = fw; kz = fk; } }
+    pl->ntw = ntw; pl->kz = kz; pl->sps = nq / kz;
+    return true;
+}
+size_t q4_wide_planes_bytes(const Q4W& w, int mt, const WidePlan& pl) { return pl.kz > 1 || true ? (size_t)pl.kz * mt * ((w.N + 15) / 16) * 256 * sizeof(float) : 0; }
+template <int MT, int NTW, bool DIRECT>
+static hipError_t wide_launch(const GemmParams& p, const WidePlan& pl, hipStream_t s) {
+    const int tiles = (p.w.N + 15) / 16;
+    dim3 grid((tiles + 4 * NTW - 1) / (4 * NTW), pl.kz);
+    const size_t lds = (size_t)2 * MT * 8 * 64 * sizeof(uint4);
+    auto kern = q4_wide_kernel<MT, NTW, DIRECT>; static DevOnce done;
+    hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;
+    if (knob_str("VOX_WIDE_DEBUG")) { static bool said = false; if (!said) { said = true; int occ = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds);
+        hipFuncAttributes fa{}; (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)); fprintf(stderr, "[wide] MT %d NTW %d direct %d: grid %u x %u, %d steps per slice, lds %zu + %zu static, %d regs, occupancy %d workgroups / CU\n", MT, NTW, (int)DIRECT, grid.x, grid.y, pl.sps, lds, (size_t)fa.sharedSizeBytes, fa.numRegs, occ); } }
+    kern<<<grid, dim3(256), lds, s>>>(p, pl.sps, p.kz_scratch);
+    return hipGetLastError();
+}
+hipError_t launch_q4_wide(const GemmParams& p, int epi_stage, hipStream_t s) {      // epi | 0x100: the GEMM launch only, epi | 0x200: the finishing launch only (measurement hook)
+    const int epi = epi_stage & 0xff; const bool only_gemm = (epi_stage & 0x100) != 0, only_finish = (epi_stage & 0x200) != 0;
+    WidePlan pl;
+    const int MT = p.wide_mt;
+    if (!p.xf || p.M != 16 * MT || !q4_wide_plan(p.w, MT, epi, &pl)) return hipErrorInvalidValue;
+    const bool direct = epi == EPI_STORE;
+    GemmParams pa = p; pa.ksplit = env_int("VOX_WIDE_ABL");
+    if (direct) { if (!p.out || !p.ssq_part || p.n_part < 1) return hipErrorInvalidValue; }
+    else if (!p.kz_scratch || p.kz_scratch_bytes < q4_wide_planes_bytes(p.w, MT, pl)) return hipErrorInvalidValue;
+    hipError_t e = hipErrorInvalidValue;
+#define VOX_W(M_, N_) if (MT == M_ && pl.ntw == N_) e = direct ? wide_launch<M_, N_, true>(pa, pl, s) : wide_launch<M_, N_, false>(pa, pl, s);
+    if (only_finish) e = hipSuccess; else { VOX_W(2, 1) VOX_W(2, 2) VOX_W(3, 1) VOX_W(3, 2) VOX_W(4, 1) VOX_W(4, 2) }
+#undef VOX_W
+    if (e != hipSuccess || direct || only_gemm) return e;
+    dim3 fgrid(((p.w.N + 15) / 16 + 3) / 4, MT);
+    switch (epi) {
+    case EPI_ROPE_KV: if (!p.ssq_part || !p.pos || !p.kc || !p.vc) return hipErrorInvalidValue; wide_finish_kernel<EPI_ROPE_KV, 1><<<fgrid, dim3(256), 0, s>>>(p, p.kz_scratch, pl.kz); break;
+    case EPI_SWIGLU_XF: if (!p.ssq_part) return hipErrorInvalidValue; wide_finish_kernel<EPI_SWIGLU_XF, 1><<<fgrid, dim3(256), 0, s>>>(p, p.kz_scratch, pl.kz); break;
+    case EPI_RESID_XF: if (!p.xf_out || !p.xf_w || !p.ssq_out || !p.resid) return hipErrorInvalidValue; wide_finish_kernel<EPI_RESID_XF, 0><<<fgrid, dim3(256), 0, s>>>(p, p.kz_scratch, pl.kz); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 // ---- skinny MFMA GEMM for 17..48 rows (the 38-token decoder prefill, gguf/model.rs:908-923): MT m-tiles of 16 rows share ONE weight fetch.
@@ -3119,7 +3424,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     VOX_TL(p.tl_slot, tlw, 0);
     const float4 r4 = attn_decode_core<HD, false, false, SPEC>(qrow + h * HD, kb, vb, p.kv_row_stride, pos, p.window, sc, red, osum, p.tl_slot, tlw, p.spec_rows);
     if (tid < HD / 4) {
-        if (p.out_xf) xf_store4(p.out_xf, p.n_heads * HD, seq, h * HD + tid * 4, r4);       // batched decode: A-fragments of the wo GEMM
+        if (p.out_xf) xf_store4(p.out_xf + (size_t)(seq >> 4) * p.out_xf_gstride, p.n_heads * HD, seq & 15, h * HD + tid * 4, r4);       // batched decode: A-fragments of the wo GEMM
         else *reinterpret_cast<float4*>(orow + h * HD + tid * 4) = r4;
     }
     VOX_TL(p.tl_slot, tlw, 3);
@@ -3245,7 +3550,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const AttnParams p
             const float inv = 1.0f / sum[hh];
             const float4 r4 = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
             const int h = kvh * G + hh;
-            if (p.out_xf) xf_store4(p.out_xf, p.n_heads * HD, seq, h * HD + tid * 4, r4);
+            if (p.out_xf) xf_store4(p.out_xf + (size_t)(seq >> 4) * p.out_xf_gstride, p.n_heads * HD, seq & 15, h * HD + tid * 4, r4);
             else *reinterpret_cast<float4*>(p.out + (size_t)seq * p.out_seq_stride + h * HD + tid * 4) = r4;
         }
     }
