@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line.  Extras in the same line (never `value`):
   `fleurs_like` BASELINE configs[4] stand-in: 647 clips with FLEURS-like durations sharded LPT over the ranks, each rank's share in ONE vox_transcribe_batch call (continuous batching; --fleurs-batch)
                 (replaces bin/transcribe.rs:112-126's serial loop); aggregate RTF, tok/s, LPT imbalance (every N)
   `fleurs_like_cli`  the same corpus on the reference CLI's semantics (bin/transcribe.rs:207-265, --max-mel-frames 1200): file normalised once, 1200-frame chunks as units (every N)
+  `streaming_encoder`  per-chunk latency of the streaming encoder (gguf/model.rs:437-459) for 1 s and 12 s chunks, N = 1
   `piecewise`   the reference's metric loop (bin/e2e_bench.rs:179-224) call for call through the C ABI from C (tools/e2e_piecewise.c), N = 1
   `roofline`    dominant decode kernel, HIP events on the library stream + committed PMC traffic;  `cpu_baseline`  CPU oracle, bounded sample
 """
@@ -110,6 +111,30 @@ def f32_extra(pkg, ctx, t_embed, seconds, reps=3):
             "weight_bytes": wb, "decode_step_bytes": dec_bytes, "decode_step_weight_GBps": round(dec_bytes / 1e9 / step_s, 1) if step_s else None,
             "decode_step_frac_of_hbm_peak": round(dec_bytes / 1e9 / step_s / HBM_PEAK_GBS, 4) if step_s else None,
             "checkpoint_write_s": round(t_gen, 1), "load_s": round(t_load, 1)}
+
+
+def streaming_encoder_extra(pkg, ctx, model, chunk_frames=(100, 1200), seconds=120.0):
+    """SURVEY section 8(f2) -- the "realtime" in the reference's name: Q4VoxtralModel::encode_audio_with_cache (gguf/model.rs:437-459,791-799) fed chunk by chunk.
+    Per-chunk latency of vox_encode_audio_with_cache (host mel in -> host audio embeddings out, synchronous: what a streaming caller waits for) for 100-frame (1 s of
+    audio) and 1200-frame (12 s, the CLI's chunk) chunks of a `seconds`-long stream -- long enough that the 750-row sliding window evicts (steady state)."""
+    out = {}
+    rng = np.random.default_rng(11)
+    for cf in chunk_frames:
+        n_chunks = max(int(seconds * 100 // cf), 6)
+        mel = (0.6 * rng.standard_normal((128, cf * n_chunks)) + 0.3).astype(np.float32)
+        cache = model.create_encoder_cache()
+        lat = []
+        for i in range(n_chunks):
+            ch = np.ascontiguousarray(mel[:, i * cf:(i + 1) * cf])
+            t0 = time.perf_counter(); emb = model.encode_audio_with_cache(ch[None], cache); lat.append((time.perf_counter() - t0) * 1e3)
+        warm = lat[2:] if len(lat) > 4 else lat
+        out[f"chunk_{cf}_frames"] = {"chunk_audio_s": cf / 100.0, "chunks": n_chunks, "rows_per_chunk": int(emb.shape[1]), "latency_ms_mean": round(float(np.mean(warm)), 3),
+                                     "latency_ms_p50": round(float(np.median(warm)), 3), "latency_ms_max": round(float(np.max(warm)), 3), "first_chunk_ms": round(lat[0], 3),
+                                     "rtf": round(float(np.mean(warm)) / 1e3 / (cf / 100.0), 5), "cache_rows_at_end": int(cache.seq_len()), "stream_rows": int(cache.abs_pos())}
+        cache.close() if hasattr(cache, "close") else None
+    out["workload"] = (f"{seconds:g} s stream through vox_encode_audio_with_cache, chunk by chunk (conv stem -> 32 layers against the cached K / V, window 750, evicting -> adapter); "
+                       "latency = one synchronous call, host mel in, host embeddings out")
+    return out
 
 
 def piecewise_extra(pkg, gguf_path, x, ref_ids, reps=3):
@@ -456,6 +481,11 @@ def main():
                             "decode_layer_engine": bool(eng_on) and (eng_n1 - eng_n0) > 0, "engine_launches_per_batch": (eng_n1 - eng_n0) // reps}
             for pp in ptrs:
                 ctx.free(pp)
+        if world == 1:
+            try:
+                out["streaming_encoder"] = streaming_encoder_extra(pkg, ctx, model)
+            except Exception as e:
+                out["streaming_encoder"] = {"error": str(e)}
         if world == 1 and not args.no_piecewise:
             try:
                 out["piecewise"] = piecewise_extra(pkg, path, x, ids)

@@ -198,6 +198,12 @@ int32_t vox_model_arena(const vox_model* m, void** dev_ptr, uint64_t* nbytes);
  * Q4 model) have been written into a VOX_LOAD_LAYOUT_ONLY model, rebuild what is derived from them on this GPU (the tile-ordered copies
  * of the Q4 linears; the decode engine's weight stream is packed lazily at the first decode step on every rank). */
 int32_t vox_model_arena_finalize(vox_model* m);
+/* In-process multi-GPU start-up (one host thread + one vox_ctx + one replica per GPU: the shape SURVEY.md section 8(e) gives the reference's serial loop,
+ * bin/transcribe.rs:112-126): one more replica of a loaded Q4 model on `dst_ctx` -- another GPU or the same one -- without the file and without a collective library.
+ * The destination arena is laid out from the source's tensor manifest, its primary part is copied device to device (hipMemcpyPeerAsync: xGMI between two GPUs) and the
+ * derived copies are rebuilt on the destination (as vox_model_arena_finalize).  The replica is independent of the source afterwards (own arena, own workspaces); distinct
+ * contexts may be driven from distinct host threads concurrently (tests/test_gpu_model.py::test_two_contexts_two_threads). */
+int32_t vox_model_replicate(const vox_model* src, vox_ctx* dst_ctx, vox_model** out);
 /* Device memory the model holds besides caches and workspaces, bytes: out[0] weight arena (= vox_model_weight_bytes), out[1] its primary part (what a multi-GPU start-up
  * broadcasts), out[2] the decode engines' weight stream (a third copy of the decoder's Q4 bytes in consumption order; 0 until the first decode step builds it),
  * out[3] the engines' edge buffers (single-stream granules + one block per 16-row group of the batched engine). */

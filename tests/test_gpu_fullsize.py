@@ -156,7 +156,8 @@ def test_full_16s_clip_vs_oracle_golden(pkg, full):
     stop = len(ids) if agree.all() else int(np.argmin(agree))
     if stop < len(ids):
         assert top1[stop] - top2[stop] <= 10 * TOL * max(1.0, amax), f"ids differ at step {stop} with a clear margin"
-    assert stop >= 1
+    near = (top1 - top2) <= 10 * TOL * max(1.0, amax); first_tie = int(np.argmax(near)) if near.any() else len(rids)
+    assert stop >= first_tie, f"ids agree for {stop} steps only; the oracle's first near-tie is at step {first_tie}"      # (measured: all 108)
     assert np.abs(lg[:stop].max(axis=1) - top1[:stop]).max() <= TOL * max(1.0, amax)
     assert np.abs(lg[0, :4096] - g["logits_step0"]).max() <= TOL * max(1.0, amax)
     # the product path (device mel + graph replay) and the batch path give the same ids up to that point
@@ -430,7 +431,8 @@ def test_full_16s_clip_f32_vs_oracle_golden(pkg):
     stop = len(ids) if agree.all() else int(np.argmin(agree))
     if stop < len(ids):
         assert top1[stop] - top2[stop] <= 10 * TOL * max(1.0, amax), f"f32 ids differ at step {stop} with a clear margin {top1[stop] - top2[stop]}"
-    assert stop >= 1
+    near = (top1 - top2) <= 10 * TOL * max(1.0, amax); first_tie = int(np.argmax(near)) if near.any() else len(rids)
+    assert stop >= first_tie, f"f32 ids agree for {stop} steps only; the oracle's first near-tie is at step {first_tie}"      # (measured: all 108)
     assert np.abs(lg[:stop].max(axis=1) - top1[:stop]).max() <= TOL * max(1.0, amax)
     assert np.abs(lg[0, :4096] - g["logits_step0"]).max() <= TOL * max(1.0, amax)
     ids_a = m.transcribe_audio(x, t)                                          # product path: device mel + graph replay
@@ -467,7 +469,8 @@ def test_full_30s_f32_heavytail_vs_oracle_golden(pkg):
         stop = len(ids) if agree.all() else int(np.argmin(agree))
         if stop < len(ids):
             assert top1[stop] - top2[stop] <= 2e-2 * amax, f"f32 heavy-tail ids differ at step {stop} with a clear margin {top1[stop] - top2[stop]}"
-        assert stop >= 1
+        near = (top1 - top2) <= 2e-2 * amax; first_tie = int(np.argmax(near)) if near.any() else len(rids)
+        assert stop >= first_tie, f"f32 heavy-tail ids agree for {stop} steps only; the oracle's first near-tie is at step {first_tie}"      # (measured: all 196)
         err = float(np.abs(lg[:stop].max(axis=1) - top1[:stop]).max())
         assert err <= 1e-2 * amax, (err, amax)
         ids_a = m.transcribe_audio(x, t)                                          # product path: device mel + graph replay
@@ -906,6 +909,29 @@ def test_full_layout_only_arena_copy_start_up(pkg, full):
         b.close()
 
 
+def test_full_model_replicate_second_context(pkg, full):
+    """vox_model_replicate at full size: a second context on this GPU gets its replica from the loaded model alone -- arena laid out from the
+    tensor manifest (no file), the 2.5 GB primary part copied device to device (hipMemcpyPeerAsync between two GPUs; a plain device copy here), derived copies
+    rebuilt there -- and decodes the same 108 ids on the engine path and on the batch path; the source keeps working."""
+    m, _, ctx = full
+    ctx2 = pkg.Context(0)
+    try:
+        import time
+        t0 = time.time(); r = m.replicate(ctx2); dt = time.time() - t0
+        try:
+            assert r.arena()[1] == m.arena()[1] and r.arena()[0] != m.arena()[0] and r.weight_bytes() == m.weight_bytes()
+            x = pkg.synth.synth_audio(16.0, seed=1234); t = pkg.TimeEmbedding(3072).embed(6.0)
+            ids_a = m.transcribe_audio(x, t); ids_r = r.transcribe_audio(x, t)
+            assert len(ids_a) == 108 and np.array_equal(ids_a, ids_r)
+            rb = r.transcribe_batch([x, x], t)
+            assert np.array_equal(rb[0], m.transcribe_batch([x, x], t)[0]) and np.array_equal(rb[0], rb[1])
+            print(f"vox_model_replicate: 2.5 GB primary arena + derived copies in {dt:.2f} s, same 108 ids")
+        finally:
+            r.close()
+    finally:
+        ctx2.close()
+
+
 def test_full_load_replicated_rccl_world1(pkg, full):
     """The multi-GPU start-up the product uses (shard.load_replicated: cli.py / wer.py / bench.py --gpus N) with a REAL RCCL process group on this one GPU (world 1, `nccl`
     backend; tests/rccl_startup_worker.py, its own process so torch's HIP runtime is loaded first): RCCL initialises, the broadcast executes on the library's arena memory
@@ -967,7 +993,8 @@ def test_full_30s_heavytail_vs_oracle_golden(pkg, orc):
             stop = len(ids) if agree.all() else int(np.argmin(agree))
             if stop < len(ids):
                 assert top1[stop] - top2[stop] <= 2e-2 * amax, f"engine={engine}: ids differ at step {stop} with a clear margin"
-            assert stop >= 1
+            near = (top1 - top2) <= 2e-2 * amax; first_tie = int(np.argmax(near)) if near.any() else len(rids)
+            assert stop >= first_tie, f"engine={engine}: ids agree for {stop} steps only; the oracle's first near-tie is at step {first_tie}"      # (measured: all 196)
             err = float(np.abs(lg[:stop].max(axis=1) - top1[:stop]).max())
             assert err <= 1e-2 * amax, (engine, err, amax)                                             # (c) SURVEY section 8(c)'s eps_q4 (measured 7.4e-3: conditioning, see the docstring)
             print(f"heavy-tail golden (engine={engine}): ids agree for {stop}/{len(ids)} steps; max top-logit error {err:.3e} at |logit| max {amax:.1f}")

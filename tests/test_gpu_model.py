@@ -332,6 +332,45 @@ def test_transcribe_batch_ex_chunks_share_their_files_peak(pkg, ctx, tiny):
     print(f"vox_transcribe_batch_ex: {len(raw)} chunk units of {len(files)} files; device group peaks == host-normalised files; {n_same}/{len(raw)} units identical to the serial path end to end")
 
 
+def test_two_contexts_two_threads_and_model_replicate(pkg, ctx, tiny):
+    """The header promises "a handle is not thread-safe, distinct contexts are independent" (include/voxtral_hip.h:15-16) and SURVEY.md section 8(e) describes the
+    in-process multi-GPU shape -- one host thread + one vox_ctx + one model replica per GPU (what a Rust `voxtral-transcribe`, bin/transcribe.rs:60-128, would do).
+    Without a second GPU: TWO contexts on device 0, each with its own replica (the second made by vox_model_replicate: layout from the manifest, device-to-device copy
+    of the primary arena, derived copies rebuilt -- no file, no collective), driven CONCURRENTLY from two host threads on the per-operator path (the persistent engines
+    need the whole GPU to themselves): single-stream transcriptions, a batch and a wide continuous batch per thread; every result must equal the serial run's."""
+    import threading
+    m, _, _ = tiny
+    t = pkg.TimeEmbedding(256).embed(6.0); S = pkg.synth
+    ctx2 = pkg.Context(0)
+    m2 = m.replicate(ctx2)
+    try:
+        assert m2.weight_bytes() == m.weight_bytes() and m2.arena()[0] != m.arena()[0]
+        for mm in (m, m2):
+            mm.set_decode_engine(False); mm.set_batch_engine(False)
+        clips = [S.synth_audio(0.6 + 0.17 * ((3 * i) % 11), seed=3100 + i) for i in range(40)]
+        work = {0: clips[:20], 1: clips[20:]}
+        def job(mm, mine):
+            return [mm.transcribe_audio(x, t) for x in mine[:6]], mm.transcribe_batch(mine[:9], t), mm.transcribe_batch(mine, t)
+        serial = {k: job(m, work[k]) for k in (0, 1)}                       # reference: everything on the first context, one after the other
+        assert all((a == b).all() for a, b in zip(job(m2, work[1])[2], serial[1][2]))      # the replica alone gives the same ids
+        res, err = {}, []
+        def run(k, mm):
+            try:
+                for _ in range(3):
+                    res[k] = job(mm, work[k])
+            except Exception as e:                                          # noqa: BLE001
+                err.append(e)
+        th = [threading.Thread(target=run, args=(0, m)), threading.Thread(target=run, args=(1, m2))]
+        [x.start() for x in th]; [x.join(300) for x in th]
+        assert not err, err
+        for k in (0, 1):
+            for got, want in zip(res[k], serial[k]):
+                assert len(got) == len(want) and all(len(a) == len(b) and (a == b).all() for a, b in zip(got, want)), f"thread {k}: concurrent result differs from the serial run"
+    finally:
+        m.set_decode_engine(True); m.set_batch_engine(True)
+        m2.close(); ctx2.close()
+
+
 def test_transcribe_exactly_prefix_len(pkg, orc, tiny):
     """S == 38 decoder positions (= PREFIX_LEN): the reference prefills, predicts the first token and returns ONE id (gguf/model.rs:887-889
     only returns empty below 38; the decode loop :938 is empty).  T = 606 mel frames -> 303 -> 152 encoder rows -> 38."""

@@ -745,8 +745,10 @@ static void cache_register(vox_cache* k) { std::lock_guard<std::mutex> l(g_cache
 static void cache_unregister(const vox_cache* k) { std::lock_guard<std::mutex> l(g_cache_mu); g_cache_live.erase(k); }
 static bool cache_alive(const vox_cache* k, uint64_t gen) { std::lock_guard<std::mutex> l(g_cache_mu); auto it = g_cache_live.find(k); return it != g_cache_live.end() && it->second == gen; }
 
+struct TensorMeta { std::vector<uint64_t> shape; int dtype = 0; uint64_t nbytes = 0; };
 struct vox_model {
     vox_ctx* ctx = nullptr; vox_model_cfg cfg{};
+    std::map<std::string, TensorMeta> manifest; bool is_q4 = false;      // name -> shape / dtype of every tensor the loader looked up (vox_model_replicate lays a second arena out from it, without the file)
     uint8_t* arena = nullptr; uint64_t arena_bytes = 0, arena_primary_bytes = 0;      // [0, primary): everything parsed from the file; [primary, bytes): copies derived from it on the GPU
     std::vector<Q4W*> tiled;                                 // Q4 linears that own a tile-ordered copy in the derived part
     const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_norm = nullptr, *dec_norm = nullptr;
@@ -835,6 +837,17 @@ struct GgufSource : TensorSource {
         out->dtype = (int)t->dtype; out->data = g->data(t); out->nbytes = t->nbytes; return true;
     }
     uint64_t max_q4_bytes() const override { uint64_t m = 0; for (auto& t : g->tensors) if (t.dtype == 2) m = std::max<uint64_t>(m, t.nbytes); return m; }
+};
+// what a load looked up: (name -> shape, dtype) of every tensor the loader asked for.  Kept with the model so that a replica's arena can be laid out without the file.
+struct RecordingSource : TensorSource {
+    const TensorSource* in; mutable std::map<std::string, TensorMeta> seen;
+    explicit RecordingSource(const TensorSource* s) : in(s) {}
+    bool find(const std::string& name, TensorView* out) const override { if (!in->find(name, out)) return false; TensorMeta& t = seen[name]; t.shape = out->shape; t.dtype = out->dtype; t.nbytes = out->nbytes; return true; }
+    uint64_t max_q4_bytes() const override { return in->max_q4_bytes(); }
+};
+struct ManifestSource : TensorSource {      // shapes only (data == nullptr): good for VOX_LOAD_LAYOUT_ONLY builds, which never touch tensor data
+    const std::map<std::string, TensorMeta>* m;
+    bool find(const std::string& name, TensorView* out) const override { auto it = m->find(name); if (it == m->end()) return false; out->shape = it->second.shape; out->dtype = it->second.dtype; out->data = nullptr; out->nbytes = it->second.nbytes; return true; }
 };
 // SafeTensors: u64 header length, JSON header {"name": {"dtype": "BF16", "shape": [..], "data_offsets": [a, b]}, ...}, raw data
 // (models/weights.rs:16-66 load_tensor accepts F32 / F16 / BF16).
@@ -1192,8 +1205,9 @@ static void model_release(vox_model* m) {
 extern "C" int32_t vox_model_free(vox_model* m) { model_release(m); return VOX_OK; }
 
 // shared tail of both loaders: plan the arena, fill it, allocate the decode-step buffers
-static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool layout_only, vox_model** out) {
+static int32_t model_build(vox_ctx* ctx, const TensorSource* src_in, bool q4, bool layout_only, vox_model** out) {
     vox_model* m = new vox_model(); m->ctx = ctx;
+    RecordingSource rec(src_in); const TensorSource* src = &rec;
     std::map<std::string, bool> fmt_cache;
     Loader plan{m, src, Arena{}, false}; plan.fmt_cache = &fmt_cache;
     if (!plan.run(q4)) { std::string e = plan.err; model_release(m); return fail(VOX_ERR_IO, "%s", e.c_str()); }
@@ -1236,6 +1250,7 @@ static int32_t model_build(vox_ctx* ctx, const TensorSource* src, bool q4, bool 
         if (const char* f = knob_str("VOX_ENGINE_FLAGS")) m->eng_flags = atoi(f);      // measurement knobs of tools/micro/engine_bench (loader depth / probe / XCD-local edges)
         if (const char* f = knob_str("VOX_ENGINE_PACE")) m->eng_pace = atoi(f);
     }
+    m->manifest = std::move(rec.seen); m->is_q4 = q4;
     *out = m; return VOX_OK;
 }
 
@@ -1285,6 +1300,28 @@ extern "C" int32_t vox_model_arena_finalize(vox_model* m) {
     if (m->eng_wob) { HIPCHK(hipStreamSynchronize(m->ctx->stream)); (void)hipFree(m->eng_wob); m->eng_wob = nullptr; }
     graphs_destroy(m);
     return VOX_OK;
+}
+
+// One more replica of a loaded Q4 model on another context (another GPU, or the same one) WITHOUT the file and without a collective library: the destination arena is
+// laid out from the source model's tensor manifest, the primary part (everything parsed from the file: 2.5 GB) is copied device to device -- hipMemcpyPeerAsync over
+// xGMI between two GPUs -- and the derived copies are rebuilt on the destination GPU (vox_model_arena_finalize).  What a one-process, one-thread-per-GPU host
+// (the shape a Rust `voxtral-transcribe`, bin/transcribe.rs:60-128, would take) needs instead of an RCCL broadcast.
+extern "C" int32_t vox_model_replicate(const vox_model* src, vox_ctx* dst_ctx, vox_model** out) {
+    ARGCHK(src && dst_ctx && out, "null argument");
+    if (!src->is_q4 || src->manifest.empty()) return fail(VOX_ERR_UNSUPPORTED, "vox_model_replicate: Q4 (GGUF) models only");
+    VOXCHK(ctx_bind(src->ctx)); HIPCHK(hipStreamSynchronize(src->ctx->stream));      // the source arena is complete (uploads / repack kernels of a fresh load)
+    VOXCHK(ctx_bind(dst_ctx));
+    ManifestSource ms; ms.m = &src->manifest;
+    vox_model* d = nullptr;
+    VOXCHK(model_build(dst_ctx, &ms, true, true, &d));
+    if (d->arena_primary_bytes != src->arena_primary_bytes || d->arena_bytes != src->arena_bytes) { model_release(d); return fail(VOX_ERR_INVALID, "internal: replica arena layout differs from the source's"); }
+    hipError_t e = src->ctx->device == dst_ctx->device ? hipMemcpyAsync(d->arena, src->arena, src->arena_primary_bytes, hipMemcpyDeviceToDevice, dst_ctx->stream)
+                                                       : hipMemcpyPeerAsync(d->arena, dst_ctx->device, src->arena, src->ctx->device, src->arena_primary_bytes, dst_ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dst_ctx->stream);
+    if (e != hipSuccess) { model_release(d); return fail(VOX_ERR_HIP, "vox_model_replicate: device copy failed: %s", hipGetErrorString(e)); }
+    const int32_t r = vox_model_arena_finalize(d);
+    if (r != VOX_OK) { model_release(d); return r; }
+    *out = d; return VOX_OK;
 }
 
 // Ada scales: 1 + w2(gelu(w0 t_embed)) (gguf/model.rs:250-255) -- loop-invariant for a fixed delay, computed once.

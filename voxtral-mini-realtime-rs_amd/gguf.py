@@ -452,6 +452,12 @@ class Q4VoxtralModel:
         p = C.c_void_p(); n = C.c_uint64(); check(lib().vox_model_arena(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def replicate(self, dst_ctx):
+        """vox_model_replicate: one more replica of this Q4 model on `dst_ctx` (another GPU or the same one) -- layout from the tensor manifest, one device-to-device
+        copy of the primary arena, derived copies rebuilt there; no file, no collective library."""
+        h = C.c_void_p(); check(lib().vox_model_replicate(self.h, dst_ctx.h, C.byref(h)))
+        return type(self)(dst_ctx, h)
+
     def arena_finalize(self):
         """Receiver side of the multi-GPU start-up: the bytes of arena() have been written (e.g. by an RCCL broadcast); rebuild the derived copies on this GPU."""
         check(lib().vox_model_arena_finalize(self.h))
