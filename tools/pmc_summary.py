@@ -9,10 +9,10 @@ for d in sys.argv[1:]:
             k = r.get("Kernel_Name", "?"); c = r.get("Counter_Name"); v = float(r.get("Counter_Value", 0) or 0)
             a = acc[k][c]; a[0] += v; a[1] += 1
 def short(k):
-    k = k.replace("void vox::", "").replace("vox::", "")
+    k = k.replace("(anonymous namespace)::", "").replace("void vox::", "").replace("vox::", "")
     return k[:k.index("(")] if "(" in k else k
 rows = sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", kv[1].get("SQ_BUSY_CYCLES", [0, 1]))[0])
-for k, cs in rows[:14]:
+for k, cs in rows[:int(os.environ.get("VOX_PMC_TOP", "22"))]:
     m = {c: v[0] / max(v[1], 1) for c, v in cs.items()}
     n = max(v[1] for v in cs.values())
     print(f"== {short(k)}   dispatches {n}")
@@ -27,6 +27,8 @@ for k, cs in rows[:14]:
         print("   " + "  ".join(extra))
     if "TCC_HIT_sum" in m:
         print(f"   L2 hit rate {m['TCC_HIT_sum'] / max(m['TCC_HIT_sum'] + m.get('TCC_MISS_sum', 0), 1):.3f}")
+    if "WRITE_SIZE" in m:
+        print(f"   WRITE_SIZE = {m['WRITE_SIZE'] / 1e3:.3f} MB per dispatch (KB units, uncalibrated on gfx950)")
     if "FETCH_SIZE" in m:
         print(f"   FETCH_SIZE x2 (gfx950 correction) = {2 * m['FETCH_SIZE'] / 1e3:.3f} MB per dispatch (FETCH_SIZE is in KB)")
     if "TCP_TCC_READ_REQ_LATENCY_sum" in m and m.get("TCP_TCC_READ_REQ_sum"):
