@@ -479,6 +479,22 @@ def main():
                             "decode_step_weight_GBps": round(per_step_bytes / 1e9 / (step_ms / 1e3), 1),
                             "decode_step_frac_of_hbm_peak": round(per_step_bytes / 1e9 / (step_ms / 1e3) / HBM_PEAK_GBS, 4),
                             "decode_layer_engine": bool(eng_on) and (eng_n1 - eng_n0) > 0, "engine_launches_per_batch": (eng_n1 - eng_n0) // reps}
+            # roofline of the batched step: ALGORITHMIC bytes per step = the decoder's Q4 blocks + the tied lm_head once + the K / V rows the step's
+            # attention reads (f32, 212 992 B per position and row at the real geometry; positions 38 .. S - 1, mean taken), divided by the measured step time; `traffic` =
+            # the committed PMC figure of the engine launch (fabric bytes, Infinity-Cache hits included; profiles/r06_pmc_batch_engines.txt) + the lm_head's algorithmic bytes
+            n_steps = max(ntok // args.batch - 1, 1); mean_pos = PREFIX_LEN + n_steps / 2.0
+            kv_bytes = args.batch * mean_pos * 2.0 * cfg.dec_layers * cfg.dec_kv_heads * cfg.dec_head_dim * 4.0
+            alg = per_step_bytes + kv_bytes
+            eng_traffic = None
+            try:
+                eng_traffic = int(json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["hbm_bytes_per_launch"]["decode_engine_b16_kernel<1, false>"])
+            except Exception:
+                pass
+            out["batch"]["roofline"] = {"bound": "hbm", "kernel": "decode_engine_b16_kernel<1, false> + lm_head + argmax (one batched decode step)", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_step": int(alg), "of_which_kv_bytes": int(kv_bytes), "achieved": round(alg / 1e9 / (step_ms / 1e3), 1),
+                                        "frac": round(alg / 1e9 / (step_ms / 1e3) / HBM_PEAK_GBS, 4),
+                                        "traffic": (eng_traffic + int(per["lm_head"]["bytes"])) if eng_traffic else None,
+                                        "traffic_source": "profiles/r06_pmc_batch_engines.txt (engine launch, FETCH_SIZE x 2) + the lm_head's algorithmic bytes"}
             for pp in ptrs:
                 ctx.free(pp)
         if world == 1:

@@ -2195,11 +2195,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     VOX_BLOAD(bw, bs, 0)
     // B operand of the correction MFMA: bf16(-136) in every slot (0xC308, exact), so  sum_k x~_k * (-136)  comes out of the matrix core directly
     const bf16x8 m136 = as_bf16x8(make_uint4(0xC308C308u, 0xC308C308u, 0xC308C308u, 0xC308C308u));
+#if !defined(VOX_GEMM_BIG_SERIAL) && !defined(VOX_GEMM_BIG_SLOTS) && !defined(VOX_GEMM_BIG_SBUF) && !defined(VOX_ABL_BIG_NOCS) && !defined(VOX_ABL_BIG_NOFMA) && !defined(VOX_GEMM_BIG_OWNCS)
+#define VOX_BIG_SHARED_CS 1
+    // round 6: the -136 sum(x) correction of a (row, block) is the same for all four waves (they share the workgroup's 64 rows) -- it is computed ONCE per workgroup, by the
+    // wave that stages the fragment (what it has just split IS the MFMA A operand of (block u, m-tile wave) for its lane), and published with the planes: 8 correction MFMAs
+    // per wave and K step instead of 32 (160 -> 136 MFMAs per step; VOX_GEMM_BIG_OWNCS build: every wave its own, the round-5 form)
+    __shared__ __attribute__((aligned(16))) float s_bcs[2][4][MTB][4][4];      // [buffer][block j][m-tile][lane group g][4 rows]
+#define VOX_STAGE_CS(BUF_, U_, HI_, LO_) {                                                                     \
+        f32x4 c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(HI_), m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+        c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(LO_), m136, c_, 0, 0, 0);                       \
+        if (li == 0) *reinterpret_cast<f32x4*>(&s_bcs[(BUF_) == blds ? 0 : 1][U_][wave][g][0]) = c_; }
+#else
+#define VOX_STAGE_CS(BUF_, U_, HI_, LO_)
+#endif
 #define VOX_STAGE(BUF_)                                                                                        \
     _Pragma("unroll") for (int u = 0; u < NU; u++) {     /* K-slot order of the bit-trick B fragment: {4g, 4g+2, 16+4g, 16+4g+2, 4g+1, 4g+3, 16+4g+1, 16+4g+3} */ \
         uint4 hi, lo;                                                                                          \
         split_pair(xa[u].x, xa[u].z, hi.x, lo.x); split_pair(xb[u].x, xb[u].z, hi.y, lo.y);                    \
         split_pair(xa[u].y, xa[u].w, hi.z, lo.z); split_pair(xb[u].y, xb[u].w, hi.w, lo.w);                    \
+        VOX_STAGE_CS(BUF_, u, hi, lo)                                                                          \
         (BUF_)[(wave + 4 * u) * 64 + lane] = hi; (BUF_)[PLANE + (wave + 4 * u) * 64 + lane] = lo; }
 #if defined(VOX_GEMM_BIG_SLOTS)
     // HAND-ORDERED K step (round 5): a wave issues in order, so its VALU work only runs under its own MFMAs if the two alternate in the instruction stream -- PMC on the
@@ -2350,8 +2364,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
             for (int i = 0; i < 4; i++) {
                 const bf16x8 ah = as_bf16x8(blds[(jj * MTB + wm * 4 + i) * 64 + lane]);
                 const bf16x8 al = as_bf16x8(blds[PLANE + (jj * MTB + wm * 4 + i) * 64 + lane]);
+#ifdef VOX_BIG_SHARED_CS
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(&s_bcs[q & 1][jj][wm * 4 + i][g][0]);
+#else
                 f32x4 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, m136, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, m136, cs, 0, 0, 0);
+#endif
                 f32x4 tn[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) tn[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bf[t], cs, 0, 0, 0);
@@ -2415,6 +2433,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
     }
 #endif      // !VOX_GEMM_BIG_SLOTS
 #undef VOX_STAGE
+#undef VOX_STAGE_CS
+#undef VOX_BIG_SHARED_CS
 #undef VOX_ALOAD
 #undef VOX_BLOAD
 #pragma unroll
