@@ -1423,13 +1423,14 @@ __global__ __launch_bounds__(256, 2) void q4_wide_kernel(const GemmParams p, con
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int t = 0; t < NTW; t++) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x4_t areg[1][NA]; u32x4_t wr[2][NTW]; u32x2_t sr[2][NTW];      // A: one step ahead (an L2 / MALL hit: ~1.5 us against a ~2 us step), weights two (generic loop) or four steps
+    constexpr int WD = MT * NTW >= 16 ? 1 : 2;      // weight register ring: two steps ahead, one at MT 4 x NTW 4 (the registers; a step is >= 2 us there: one step covers an HBM round trip)
+    u32x4_t areg[1][NA]; u32x4_t wr[WD][NTW]; u32x2_t sr[WD][NTW];      // A: one step ahead (an L2 / MALL hit: ~1.5 us against a ~2 us step), weights two (generic loop) or four steps
 #define VOX_AISSUE(B_, S_) { _Pragma("unroll") for (int u = 0; u < NA; u++) areg[0][u] = asrc[u][(size_t)(S_) * 256]; }
 #define VOX_WISSUE(B_, S_) { _Pragma("unroll") for (int t = 0; t < NTW; t++) { wr[B_][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wq[t] + 64 * (S_))); sr[B_][t] = *reinterpret_cast<const u32x2_t*>(ws[t] + 64 * (S_)); } }
     VOX_AISSUE(0, 0) VOX_WISSUE(0, 0)
     __builtin_amdgcn_sched_barrier(0);
     VOX_WTL(1)
-    { const int s1 = min(1, sps - 1); VOX_WISSUE(1, s1) }
+    if (WD == 2) { const int s1 = min(1, sps - 1); VOX_WISSUE(1, s1) }
     __builtin_amdgcn_sched_barrier(0);
     if (DIRECT) {      // fused RMSNorm, consumer side (as q4_skinny_kernel PRO): rstd of every row from the producer's partial sums of squares; requested behind the first operands
         const int prow = tid & 15, pch = tid >> 4;
@@ -1459,14 +1460,14 @@ __global__ __launch_bounds__(256, 2) void q4_wide_kernel(const GemmParams p, con
         __syncthreads();      /* stage (K_ & 1) holds step S_; every wave is done with step S_ - 1 (the other stage) */ \
         if ((S_) == 0) VOX_WTL(3)                                                                                  \
         uint32_t dw[NTW][4]; u32x2_t sv[NTW];                                                                        \
-        _Pragma("unroll") for (int t = 0; t < NTW; t++) { dw[t][0] = wr[K_][t].x; dw[t][1] = wr[K_][t].y; dw[t][2] = wr[K_][t].z; dw[t][3] = wr[K_][t].w; sv[t] = sr[K_][t]; } \
+        _Pragma("unroll") for (int t = 0; t < NTW; t++) { dw[t][0] = wr[(K_) % WD][t].x; dw[t][1] = wr[(K_) % WD][t].y; dw[t][2] = wr[(K_) % WD][t].z; dw[t][3] = wr[(K_) % WD][t].w; sv[t] = sr[(K_) % WD][t]; } \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
-        { const int sa = min((S_) + 1, sps - 1), sn = min((S_) + 2, sps - 1); if (!(abl & 2)) VOX_AISSUE(0, sa) if (!(abl & 4)) VOX_WISSUE((K_) & 1, sn) }      /* in consumption order: A one step ahead, the weights two */ \
+        { const int sa = min((S_) + 1, sps - 1), sn = min((S_) + WD, sps - 1); if (!(abl & 2)) VOX_AISSUE(0, sa) if (!(abl & 4)) VOX_WISSUE((K_) % WD, sn) }      /* in consumption order: A one step ahead, the weights two */ \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         if (!(abl & 1)) {                                                                                          \
             /* groups in sets of MH (all MT, or two at MT 4 x NTW 2, which sits at the 256-register limit): the set's chains are interleaved -- every MFMA's input comes \
                from MH * NTW MFMAs earlier, not from the one before it -- and, where the registers allow (PF), block j + 1's fragments are requested before block j is multiplied */ \
-            constexpr int MH = MT * NTW >= 8 ? MT / 2 : MT, NH = MT / MH; constexpr bool PF = NH == 1;              \
+            constexpr int MH = MT * NTW >= 12 ? 1 : (MT * NTW >= 8 ? MT / 2 : MT), NH = MT / MH; constexpr bool PF = NH == 1;      \
             u32x4_t fr[PF ? 2 : 1][MH][2]; f32x4 csr[PF ? 2 : 1][MH];                                              \
             if (PF) { _Pragma("unroll") for (int mt = 0; mt < MH; mt++) { fr[0][mt][0] = stg[((mt * 2 + 0) * 4 + 0) * 64 + lane]; fr[0][mt][1] = stg[((mt * 2 + 1) * 4 + 0) * 64 + lane]; \
                                                                            csr[0][mt] = *reinterpret_cast<const f32x4*>(&s_cs[(K_) & 1][mt][0][g][0]); } } \
@@ -1628,12 +1629,13 @@ bool q4_wide_plan(const Q4W& w, int mt, int epi, WidePlan* pl) {
     if (epi != EPI_STORE && epi != EPI_ROPE_KV && epi != EPI_RESID_XF && epi != EPI_SWIGLU_XF) return false;
     const int nq = w.nb / 4, tiles = w.N / 16;
     int ntw = tiles >= 384 ? 2 : 1, kz = 1;
+    if (epi == EPI_STORE && tiles >= 4096 && !knob_str("VOX_WIDE_LM_NTW2")) ntw = 4;      // the lm_head (8192 n-tiles): 512 workgroups = ONE round of resident workgroups instead of two, half the activation re-reads
     if (epi != EPI_STORE) {
         const int ranges = (tiles + 4 * ntw - 1) / (4 * ntw);
         for (int d = 1; d <= nq; d++) if (nq % d == 0) { kz = d; if ((long)ranges * d >= 320) break; }
         if (kz > 24) { for (int d = 24; d >= 1; d--) if (nq % d == 0) { kz = d; break; } }
     }
-    if (const char* f = knob_str("VOX_WIDE_FORCE")) { int fn = 0, fw = 0, fk = 0; if (sscanf(f, "%d:%d:%d", &fn, &fw, &fk) == 3 && fn == w.N && (fw == 1 || fw == 2) && fk >= 1 && fk <= 24 && nq % fk == 0 && (epi != EPI_STORE || fk == 1)) { ntw = fw; kz = fk; } }
+    if (const char* f = knob_str("VOX_WIDE_FORCE")) { int fn = 0, fw = 0, fk = 0; if (sscanf(f, "%d:%d:%d", &fn, &fw, &fk) == 3 && fn == w.N && (fw == 1 || fw == 2 || (fw == 4 && epi == EPI_STORE)) && fk >= 1 && fk <= 24 && nq % fk == 0 && (epi != EPI_STORE || fk == 1)) { ntw = fw; kz = fk; } }
     pl->ntw = ntw; pl->kz = kz; pl->sps = nq / kz;
     return true;
 }
@@ -1661,7 +1663,8 @@ hipError_t launch_q4_wide(const GemmParams& p, int epi_stage, hipStream_t s) {  
     else if (!p.kz_scratch || p.kz_scratch_bytes < q4_wide_planes_bytes(p.w, MT, pl)) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
 #define VOX_W(M_, N_) if (MT == M_ && pl.ntw == N_) e = direct ? wide_launch<M_, N_, true>(pa, pl, s) : wide_launch<M_, N_, false>(pa, pl, s);
-    if (only_finish) e = hipSuccess; else { VOX_W(2, 1) VOX_W(2, 2) VOX_W(3, 1) VOX_W(3, 2) VOX_W(4, 1) VOX_W(4, 2) }
+    if (only_finish) e = hipSuccess; else { VOX_W(2, 1) VOX_W(2, 2) VOX_W(3, 1) VOX_W(3, 2) VOX_W(4, 1) VOX_W(4, 2)
+        if (direct && pl.ntw == 4) { if (MT == 2) e = wide_launch<2, 4, true>(pa, pl, s); else if (MT == 3) e = wide_launch<3, 4, true>(pa, pl, s); else if (MT == 4) e = wide_launch<4, 4, true>(pa, pl, s); } }
 #undef VOX_W
     if (e != hipSuccess || direct || only_gemm) return e;
     dim3 fgrid(((p.w.N + 15) / 16 + 3) / 4, MT);
