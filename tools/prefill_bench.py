@@ -15,9 +15,12 @@ ref = None
 for label, env in (("32x128 MFMA kernel, 3 passes over the weights (round 1)", {"VOX_NO_SKINNY_MT": "1"}),
                    ("q4_skinny_mt_kernel<3,*> (rows from L2 per wave)", {"VOX_PREFILL_KERNEL": "1"}),
                    ("q4_gemm_kernel<3,NT,tile-ordered B> (48-row tile)", {"VOX_PREFILL_KERNEL": "2"}),
-                   ("default: 2-D kernel, fused finishing kernels", {})) + \
+                   ("round-3 form: q4_skinny_mt2_kernel + MFMA flash attention", {"VOX_PREFILL_WIDE": "0", "VOX_ATTN_NO_SMALL": "1"}),
+                   ("round 6, wide GEMMs only (MFMA flash attention)", {"VOX_ATTN_NO_SMALL": "1"}),
+                   ("round 6, short-sequence attention only (mt2 GEMMs)", {"VOX_PREFILL_WIDE": "0"}),
+                   ("default (round 6): q4_wide_kernel planes + short-sequence attention -> XF", {})) + \
                   tuple((f"2-D kernel, {k} slices forced for every operator", {"VOX_SKINNY_MT2": k}) for k in sys.argv[1:]):
-    for k in ("VOX_NO_SKINNY_MT", "VOX_PREFILL_KERNEL", "VOX_SKINNY_MT2"):
+    for k in ("VOX_NO_SKINNY_MT", "VOX_PREFILL_KERNEL", "VOX_SKINNY_MT2", "VOX_PREFILL_WIDE", "VOX_ATTN_NO_SMALL"):
         os.environ.pop(k, None)
     os.environ.update(env)
     c = dec.create_cache_preallocated(64)

@@ -1724,10 +1724,17 @@ static int32_t decoder_prefill_dev(vox_model* m, float* x, int M, vox_cache* kc,
         AttnParams ap{}; ap.q = qkv; ap.q_stride = W; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = kc->max_seq * hd;
         ap.out = att; ap.out_stride = QD; ap.M = Mq; ap.kv_len = off + Mq; ap.n_heads = H; ap.n_kv_heads = KV; ap.offset = off; ap.window = c.dec_window;
         ap.q_seq_stride = seq_rows * W; ap.out_seq_stride = seq_rows * QD; ap.kv_seq_stride = kv_seq_stride;
-        HIPCHK(launch_attn_prefill(ap, hd, s, n_seq));
         const int kz_wo = fuse_fin && cx->kz_scratch && xf_ok(L.w13.w) && L.wo.w.N == D && QD % 128 == 0 ? q4_skinny_mt2_plan(L.wo.w, M) : 0;
-        if (kz_wo && (size_t)kz_wo * M * D * 4 <= cx->kz_scratch_bytes) {
-            VOXCHK(planes_gemm(L.wo.w, att, QD, kz_wo));
+        const bool wo_planes = kz_wo && (size_t)kz_wo * M * D * 4 <= cx->kz_scratch_bytes;
+        // round 6: a short sequence from position 0 (the 38-token prefill) takes the short-sequence attention kernel, whose rows leave as the XF tiles the wo GEMM reads
+        // (no f32 round trip, no xf_rows launch) when that GEMM is the planes form
+        const bool att_xf = wo_planes && n_seq == 1 && (size_t)((M + 15) / 16) * QD * 64 <= cx->xf_scratch_bytes && attn_prefill_small_ok(ap, hd, n_seq);
+        if (att_xf) { ap.out_xf_tiles = cx->xf_scratch; ap.out_xf_tile_stride = (long)2 * (QD >> 7) * 256 * 8; }
+        HIPCHK(launch_attn_prefill(ap, hd, s, n_seq));
+        if (wo_planes) {
+            if (att_xf) { GemmParams pw{}; pw.w = L.wo.w; pw.xf = reinterpret_cast<const uint4*>(cx->xf_scratch); pw.M = M; pw.kz_scratch = cx->kz_scratch; pw.kz_scratch_bytes = cx->kz_scratch_bytes;
+                          HIPCHK(launch_q4_skinny_mt2_planes(pw, kz_wo, s)); }
+            else VOXCHK(planes_gemm(L.wo.w, att, QD, kz_wo));
             HIPCHK(launch_rms_norm_xf_sumk(x, D, M, D, cx->kz_scratch, kz_wo, L.ffn_norm, L.ada_mul, c.norm_eps, cx->xf_scratch, s));      // x += wo(att); norm then Ada x*(1+s) (model.rs:382-385)
             // w1|w3 as planes whose finishing kernel writes SiLU(gate) * up straight into the XF tiles w2 reads (no f32 activations, no conversion launch)
             const int kz_13 = fuse_fin2 && L.w13.w.N == 2 * F && F % 128 == 0 && F <= 16384 && L.w2.w.N == D ? q4_skinny_mt2_plan(L.w13.w, M) : 0;

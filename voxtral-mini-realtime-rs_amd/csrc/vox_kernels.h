@@ -90,6 +90,7 @@ struct GemmParams {
     // wide decode step (launch_q4_wide): M = 16 * wide_mt rows = wide_mt slot groups of 16; rows of consecutive groups are consecutive in out / resid / pos / kv_row,
     // the XF planes and the partial sums of squares of group g start g * (the group stride) after group 0's
     int wide_mt; long xf_gstride /* uint4 */, xf_out_gstride /* uint16 */, ssq_part_gstride, ssq_out_gstride /* floats */;
+    int wide_rows;        // > 0: q4_wide_kernel stores its K-slice planes ROW-MAJOR, [slice][wide_rows][N] f32 (rows < wide_rows only): the layout the 38-token prefill's finishing kernels read
 };
 // ---- wide decode step (round 6): 32 / 48 / 64 rows (2..4 slot groups of a continuous batch) through ONE weight fetch and ONE nibble -> bf16 conversion per K step.
 // GEMM (q4_wide_kernel: the groups' XF planes staged through LDS once per workgroup, K split over workgroups into planes) + a finishing launch that sums the planes in a
@@ -146,6 +147,7 @@ struct AttnParams {
     // q / out / k / v of sequence z start q_seq_stride / out_seq_stride / kv_seq_stride floats after those of z-1
     const int* seq_len;
     const int* seq_row_off;   // stacked prefill, optional (MFMA kernel only): sequence z starts seq_row_off[z] ROWS into q / k / v / out (ragged sequences packed back to back) instead of z * the sequence strides
+    uint16_t* out_xf_tiles; long out_xf_tile_stride;      // attn_prefill_small_kernel, optional: the output rows as XF tiles (tile = row / 16; stride in uint16 units) instead of `out`
     uint16_t* out_xf;     // batched decode: write the output rows (row = sequence) as XF fragment planes instead of out
     long out_xf_gstride;  // ... more than 16 sequences in one launch (attn_decode_gqa_kernel): sequence s is row s % 16 of the planes out_xf + (s / 16) * out_xf_gstride (uint16 units)
     int prefer_gqa;       // batched decode: one workgroup per (KV head, sequence) serving its 4 query heads (wide batches)
@@ -156,6 +158,7 @@ struct AttnParams {
                           // 160 rows before the position word has arrived (attn_decode_core SPEC).  0: indices derived from the position.
 };
 hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n_seq = 1);     // M > 1, causal (+window)
+bool attn_prefill_small_ok(const AttnParams& p, int hd, int n_seq);      // will launch_attn_prefill take the short-sequence kernel (<= 48 rows from position 0, f32; may write XF tiles: p.out_xf_tiles)?
 hipError_t launch_attn_decode(const AttnParams& p, int hd, int max_seq, hipStream_t s, int n_seq = 1);  // M == 1 per sequence
 // single sequence: attention + the wo linear in one launch; acc[wo.N] (int64, zero on entry) receives the product in 2^-32 fixed point (consumer: PRO_RMS_MUL_SUM)
 bool attn_wo_supported(const AttnParams& p, const Q4W& wo, int hd, int max_seq);

@@ -1520,6 +1520,18 @@ __global__ __launch_bounds__(256, 2) void q4_wide_kernel(const GemmParams p, con
                 }
             }
         }
+    } else if (p.wide_rows > 0) {      // the prefill's finishing kernels read [slice][row][N]
+        const int z = blockIdx.y, R = p.wide_rows;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int t = 0; t < NTW; t++) {
+                const int n = (tile0 + t) * 16 + li;
+                if (tile0 + t < n_tiles && n < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const int row = mt * 16 + 4 * g + r; if (row < R) planes[((size_t)z * R + row) * N + n] = acc[mt][t][r]; }
+                }
+            }
     } else {
         const int z = blockIdx.y;
 #pragma unroll
@@ -1977,8 +1989,15 @@ static hipError_t skinny_mt_launch(const GemmParams& p, int epi, hipStream_t s) 
     return hipGetLastError();
 }
 // The pieces of the two-dimensional 17..48-row GEMM for callers that fold the finishing sum into their next kernel (the decoder prefill):
+// round 6: the prefill's 17..48-row GEMMs run on q4_wide_kernel (the rows' XF tiles staged through LDS once per workgroup, corrections once per workgroup, the tiles'
+// MFMA chains interleaved; row-major planes for the same finishing kernels) with its own K split; VOX_PREFILL_WIDE=0: q4_skinny_mt2_kernel (the round-3 form)
+static bool prefill_wide_plan(const Q4W& w, int M, WidePlan* pl) {
+    const char* e = knob_str("VOX_PREFILL_WIDE");
+    return !(e && e[0] == '0') && env_int("VOX_SKINNY_MT2") == 0 && M > 16 && M <= 48 && w.N % 16 == 0 && q4_wide_plan(w, (M + 15) / 16, EPI_ROPE_KV, pl);
+}
 int q4_skinny_mt2_plan(const Q4W& w, int M) {      // K slices the 2-D kernel would use for this operator, 0 = not applicable
     if (w.fmt != WFMT_Q4_0 || !w.qt || !w.st || w.nb % 4 || w.N % 2 || M <= 16 || M > 48 || env_int("VOX_SKINNY_MT2") < 0) return 0;
+    { WidePlan pl; if (prefill_wide_plan(w, M, &pl)) return pl.kz; }
     const int tiles = (w.N + 15) / 16, nq = w.nb / 4, wg1 = (tiles + 3) / 4;
     int KZ = std::min(std::min(8, nq), std::max(1, (384 + wg1 - 1) / wg1));
     { const int e = env_int("VOX_SKINNY_MT2"); if (e > 0) KZ = std::min(e, nq); }
@@ -1994,6 +2013,11 @@ hipError_t launch_q4_skinny_mt2_planes(const GemmParams& p_in, int KZ, hipStream
     GemmParams p = p_in; p.ksplit = KZ; p.out = p_in.kz_scratch;
     const int mt = (p.M + 15) / 16, n_tiles = (p.w.N + 15) / 16;
     if (!p.xf || !p.kz_scratch || (size_t)KZ * p.M * p.w.N * 4 > p.kz_scratch_bytes || KZ < 1) return hipErrorInvalidValue;
+    { WidePlan pl;
+      if (prefill_wide_plan(p.w, p.M, &pl) && pl.kz == KZ) {
+          GemmParams q = p_in; q.wide_mt = mt; q.wide_rows = p.M; q.M = 16 * mt; q.xf_gstride = (long)2 * (p.w.nb / 4) * 256;
+          return launch_q4_wide(q, EPI_ROPE_KV | 0x100, s);      // the GEMM launch alone: the caller's finishing kernels read the planes
+      } }
     if (mt == 2) q4_skinny_mt2_kernel<2, 1><<<dim3((n_tiles + 3) / 4, KZ), dim3(256), (size_t)2 * 2 * 8 * 64 * 16, s>>>(p);
     else if (mt == 3) q4_skinny_mt2_kernel<3, 1><<<dim3((n_tiles + 3) / 4, KZ), dim3(256), (size_t)2 * 3 * 8 * 64 * 16, s>>>(p);
     else return hipErrorInvalidValue;
@@ -3218,7 +3242,82 @@ static hipError_t attn_prefill_mfma_launch(const AttnParams& p, hipStream_t s, i
     kern<<<dim3((p.M + 63) / 64, p.n_heads, n_seq), dim3(256), lds, s>>>(p);
     return hipGetLastError();
 }
+// ---- causal attention of a SHORT sequence from position 0 (<= 48 rows: the 38-token decoder prefill, gguf/model.rs:908-919 -> Q4Attention::forward_with_cache with an
+// empty cache, :125-174).  The 64-query MFMA tiles above cost 29 us per layer for 38 x 38 scores per head: one mostly masked tile, staged and converted per workgroup.  Here:
+// one workgroup per (query head, sequence), K and V rows of its KV head in LDS as f32 (2 x 25 KB), a wave per query row -- lane j scores key j (128 sequential f32 FMAs over
+// padded, conflict-free rows: the reference's own arithmetic, no bf16 anywhere), wave-shuffle softmax, then P . V with 32 lanes x 4 columns on each half of the keys.  The rows
+// can leave as XF tiles (the wo GEMM's A fragments): no f32 round trip, no xf_rows launch.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_prefill_small_kernel(const AttnParams p) {
+    constexpr int KROW = HD + 4, MAXR = 48;
+    extern __shared__ __attribute__((aligned(16))) float sms[];
+    float* Ks = sms; float* Vs = Ks + MAXR * KROW; float* Qs = Vs + MAXR * HD; float* Ps = Qs + 4 * HD;      // [48][HD + 4] | [48][HD] | [4 waves][HD] | [4 waves][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, sq = blockIdx.y, kvh = h / (p.n_heads / p.n_kv_heads);
+    const int M = p.seq_len ? p.seq_len[sq] : p.M;
+    const int r = 4 * (int)blockIdx.z + wave;                  // workgroup = four consecutive query rows (grid z), wave = one row
+    const int n_keys = min(M, 4 * (int)blockIdx.z + 4);        // causal: this workgroup's rows see keys 0 .. its last row
+    if (4 * (int)blockIdx.z >= M) {                            // XF tiles only: the rows behind the sequence are written as zeros (the GEMM multiplies whole tiles)
+        if (p.out_xf_tiles && lane < 32) xf_store4(p.out_xf_tiles + (size_t)(r >> 4) * p.out_xf_tile_stride, p.n_heads * HD, r & 15, h * HD + 4 * lane, make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+    }
+    const size_t kvso = (size_t)sq * p.kv_seq_stride;
+    const float* kbase = p.k + kvso + (size_t)kvh * p.kv_head_stride; const float* vbase = p.v + kvso + (size_t)kvh * p.kv_head_stride;
+    for (int i = tid; i < n_keys * (HD / 4); i += 256) {
+        const int j = i / (HD / 4), d4 = i % (HD / 4);
+        *reinterpret_cast<float4*>(Ks + j * KROW + 4 * d4) = *reinterpret_cast<const float4*>(kbase + (size_t)j * p.kv_row_stride + 4 * d4);
+        *reinterpret_cast<float4*>(Vs + j * HD + 4 * d4) = *reinterpret_cast<const float4*>(vbase + (size_t)j * p.kv_row_stride + 4 * d4);
+    }
+    float* qs = Qs + wave * HD; float* ps = Ps + wave * 64;
+    if (r < M) { const float* qp = p.q + (size_t)sq * p.q_seq_stride + (size_t)r * p.q_stride + h * HD; for (int d = lane; d < HD; d += 64) qs[d] = qp[d]; }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)HD);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < M) {
+        const float* kr = Ks + min(lane, n_keys - 1) * KROW;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four chains (a single one is 128 dependent FMAs)
+#pragma unroll 8
+        for (int d = 0; d < HD; d += 4) {
+            const float4 kv = *reinterpret_cast<const float4*>(kr + d), qv = *reinterpret_cast<const float4*>(qs + d);
+            s0 = fmaf(qv.x, kv.x, s0); s1 = fmaf(qv.y, kv.y, s1); s2 = fmaf(qv.z, kv.z, s2); s3 = fmaf(qv.w, kv.w, s3);
+        }
+        const bool vis = lane <= r && (p.window < 0 || r - lane <= p.window);
+        const float sc = vis ? ((s0 + s1) + (s2 + s3)) * scale : -INFINITY;
+        const float mx = wave_max(sc);
+        const float e = vis ? expf(sc - mx) : 0.f;
+        const float sum = wave_sum(e);
+        ps[lane] = e / sum;
+        __builtin_amdgcn_wave_barrier();
+        const int c = lane & 31, half = lane >> 5;
+        for (int j = half; j <= r; j += 2) {
+            const float pj = ps[j]; const float4 vv = *reinterpret_cast<const float4*>(Vs + j * HD + 4 * c);
+            o.x = fmaf(pj, vv.x, o.x); o.y = fmaf(pj, vv.y, o.y); o.z = fmaf(pj, vv.z, o.z); o.w = fmaf(pj, vv.w, o.w);
+        }
+        o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
+    }
+    if (lane < 32) {
+        const int col = h * HD + 4 * lane;
+        if (p.out_xf_tiles) xf_store4(p.out_xf_tiles + (size_t)(r >> 4) * p.out_xf_tile_stride, p.n_heads * HD, r & 15, col, o);      // (rows M .. of a started block: zeros)
+        else if (r < M) *reinterpret_cast<float4*>(p.out + (size_t)sq * p.out_seq_stride + (size_t)r * p.out_stride + col) = o;
+    }
+}
+bool attn_prefill_small_ok(const AttnParams& p, int hd, int n_seq) {
+    return hd == 128 && p.M >= 1 && p.M <= 48 && p.offset == 0 && p.kv_len == p.M && !p.seq_row_off && (p.window < 0 || p.window >= p.M) && (p.q_stride % 4) == 0 && (p.kv_row_stride % 4) == 0 &&
+           n_seq == 1 /* stacked prefills (64 sequences x 10 row blocks x 32 heads of tiny workgroups) measured 1 % slower than the z-stacked MFMA kernel */ &&
+           !env_int("VOX_ATTN_NO_SMALL") && !env_int("VOX_ATTN_F32");
+}
+static hipError_t attn_prefill_small_launch(const AttnParams& p, hipStream_t s, int n_seq) {
+    constexpr int HD = 128;
+    const size_t lds = (size_t)(48 * (HD + 4) + 48 * HD + 4 * HD + 4 * 64) * sizeof(float);
+    auto kern = attn_prefill_small_kernel<HD>; static DevOnce done;
+    hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;
+    const int rows = p.out_xf_tiles ? ((p.M + 15) / 16) * 16 : p.M;
+    kern<<<dim3(p.n_heads, n_seq, (rows + 3) / 4), dim3(256), lds, s>>>(p);
+    return hipGetLastError();
+}
 hipError_t launch_attn_prefill(const AttnParams& p, int hd, hipStream_t s, int n_seq) {
+    if (attn_prefill_small_ok(p, hd, n_seq)) return attn_prefill_small_launch(p, s, n_seq);
+    if (p.out_xf_tiles) return hipErrorInvalidValue;      // (XF output exists in the short-sequence kernel only: callers ask attn_prefill_small_ok first)
     const int f32_only = env_int("VOX_ATTN_F32");               // ablation / cross-check knob: the f32 VALU kernel (read from the knob table per launch: tests toggle it)
     if (!f32_only && (p.q_stride % 4) == 0 && (p.kv_row_stride % 4) == 0) {
         if (hd == 64) return attn_prefill_mfma_launch<64>(p, s, n_seq);
