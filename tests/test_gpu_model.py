@@ -371,6 +371,20 @@ def test_two_contexts_two_threads_and_model_replicate(pkg, ctx, tiny):
         m2.close(); ctx2.close()
 
 
+def test_wide_step_measurement_hook(pkg, tiny):
+    """vox_bench_wide (tools/wide_bench.py's hook): every operator of the wide step at 2, 3 and 4 slot groups launches and is timed on the tiny model's shapes too
+    (K = 256 / 512: one or two K steps per slice, the run-time step loop's shortest trips)."""
+    import ctypes as C
+    m, _, _ = tiny
+    for mt in (2, 3, 4):
+        for which in range(5):
+            out = (C.c_double * 4)()
+            assert pkg.lib().vox_bench_wide(m.h, which, mt, 2, out) == 0, (mt, which, pkg.lib().vox_last_error())
+            assert out[0] > 0 and out[2] > 0 and out[3] > 0 and (which == 4 or out[1] > 0)
+    out = (C.c_double * 4)()
+    assert pkg.lib().vox_bench_wide(m.h, 7, 2, 2, out) != 0 and pkg.lib().vox_bench_wide(m.h, 0, 5, 2, out) != 0      # bad operator / group count
+
+
 def test_transcribe_exactly_prefix_len(pkg, orc, tiny):
     """S == 38 decoder positions (= PREFIX_LEN): the reference prefills, predicts the first token and returns ONE id (gguf/model.rs:887-889
     only returns empty below 38; the decode loop :938 is empty).  T = 606 mel frames -> 303 -> 152 encoder rows -> 38."""
