@@ -95,6 +95,9 @@ struct vox_ctx {
     std::vector<PoolEntry> pool;
     // side streams + fork/join events: independent 16-row groups of a wide batched decode step run concurrently
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    // continuous batch, self-calibration of the planner (the step costs were constants measured on one box): milliseconds per step of 1..4 active groups as
+    // MEASURED on this context (HIP events around the runs of equal active sets of earlier sessions, exponentially averaged; [0] = engine forms on, [1] = off), 0 = not seen yet
+    double step_ms_meas[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; hipEvent_t ev_seg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t warm_forms = 0;      // continuous batch: step forms whose kernels have run once on this context's device (bit 0 launch chains, bit 1 engine + tail, bits 2..4 the wide step at 2 / 3 / 4 groups)
     // XF tiles of a 17..48-row GEMM input (the 38-token prefill): 3 tiles x K columns x 64 B; sized once for K <= 16384, reused by every such GEMM of the stream
     uint16_t* xf_scratch = nullptr; size_t xf_scratch_bytes = 0;
@@ -137,6 +140,7 @@ extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
     if (c->rs_matrix) (void)hipFree(c->rs_matrix);
     for (int i = 0; i < 3; i++) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (auto e : c->ev_seg) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c; return VOX_OK;
 }
@@ -2504,7 +2508,16 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     // the steps of one or two active groups go through the batched decode-layer engine (vox_engine_b16.hip: one launch per step for the 26 layers of both groups, cache
     // slices per slot through EngBParams::kv_row); wider steps, other geometries, VOX_BATCH_ENGINE=0 and the re-run after a hand-off timeout use the launch chains
     const bool use_eng = allow_engine && !jobs.empty() && !knob_str("VOX_BATCH_CONT_NO_ENGINE") && engb_prepare(m, 2);
-    const SlotPlan plan = plan_slots(jobs, force_G, use_eng ? kStepMsEng : kStepMs);
+    // step costs: the table above, corrected by what this context has measured -- a form seen before costs what it cost (clock, a shared GPU, another geometry), a form not
+    // seen yet the table's value times the mean measured / table ratio of the forms that were.  VOX_BATCH_NO_CALIB=1: the table alone.
+    double step_cost[5]; const double* base_cost = use_eng ? kStepMsEng : kStepMs; const bool calib = !knob_str("VOX_BATCH_NO_CALIB");
+    {
+        const double* meas = cx->step_ms_meas[use_eng ? 0 : 1]; double ratio = 0.0; int nr = 0;
+        for (int g2 = 1; g2 <= 4; g2++) if (calib && meas[g2] > 0.0) { ratio += meas[g2] / base_cost[g2]; nr++; }
+        ratio = nr ? std::min(4.0, std::max(0.25, ratio / nr)) : 1.0;
+        step_cost[0] = 0.0; for (int g2 = 1; g2 <= 4; g2++) step_cost[g2] = (calib && meas[g2] > 0.0) ? meas[g2] : base_cost[g2] * ratio;
+    }
+    const SlotPlan plan = plan_slots(jobs, force_G, step_cost);
     const int G = std::max(plan.G, 1), Sl = 16 * G;
     int q_stride = 1; for (auto& q : plan.queue) q_stride = std::max(q_stride, (int)q.size() + 1);
     std::vector<int> h_queue((size_t)Sl * q_stride, -1);
@@ -2796,13 +2809,23 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         }
         HIPCHK(hipStreamSynchronize(s));      // phase A (and the set-up behind it) is done: the prefill timer closes here, the decode timer starts
         { const double tn = now_ms(); pf_ms += tn - t1; t1 = tn; }
+        // (an event where the set of active groups changes: the runs in between are what the planner's next session on this context is priced with)
+        int seg_n[6] = {0, 0, 0, 0, 0, 0}, seg_act[6] = {0, 0, 0, 0, 0, 0}, n_seg = 0; uint32_t last_act = 0;
         for (int t = t_start; t < steps; t++) {
             const uint32_t act = active_at(t);
+            if (calib && !no_graph && act != last_act && n_seg < 5) {
+                if (!cx->ev_seg[n_seg]) HIPCHK(hipEventCreate(&cx->ev_seg[n_seg]));
+                HIPCHK(hipEventRecord(cx->ev_seg[n_seg], s));
+                int na = 0; for (int gi = 0; gi < G; gi++) na += (act >> gi) & 1u;
+                seg_act[n_seg] = na; n_seg++; last_act = act;
+            }
+            if (n_seg > 0) seg_n[n_seg - 1]++;
             if (no_graph) { VOXCHK(step(act)); m->engb_launches += (unsigned)eng_per_step; continue; }
             if (hipGraphLaunch(graphs.find(act), s) != hipSuccess) return fail(VOX_ERR_HIP, "hipGraphLaunch failed");
             replays++;
             for (auto& e : eng_in_graph) if (e.first == act) m->engb_launches += (unsigned)e.second;
         }
+        if (n_seg > 0) { if (!cx->ev_seg[n_seg]) HIPCHK(hipEventCreate(&cx->ev_seg[n_seg])); HIPCHK(hipEventRecord(cx->ev_seg[n_seg], s)); }
         if (use_eng) for (int blk = 0; blk < 2; blk++) { EngBParams ep{}; engb_state_carve(m->engb_state[blk], &ep); HIPCHK(hipMemcpyAsync(m->engb_err_host[blk], ep.err, 8, hipMemcpyDeviceToHost, s)); }
         HIPCHK(hipStreamSynchronize(s));
         if (use_eng) for (int blk = 0; blk < 2; blk++) if (m->engb_err_host[blk][0]) {
@@ -2816,6 +2839,13 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             if (m->engb_strikes >= 3) m->engb_ok = false;
             return VOX_RETRY_ON_LAUNCHES;
         }
+        for (int k = 0; k < n_seg; k++) {      // runs of >= 8 steps only: shorter ones are mostly their first replay
+            float ms = 0.f;
+            if (seg_n[k] >= 8 && seg_act[k] >= 1 && seg_act[k] <= 4 && hipEventElapsedTime(&ms, cx->ev_seg[k], cx->ev_seg[k + 1]) == hipSuccess && ms > 0.f) {
+                double& mm = cx->step_ms_meas[use_eng ? 0 : 1][seg_act[k]]; const double v = (double)ms / seg_n[k];
+                mm = mm > 0.0 ? 0.7 * mm + 0.3 * v : v;
+            } else (void)hipGetLastError();
+        }
     }
     std::vector<int32_t> host_tok((size_t)n * tstride);
     HIPCHK(hipMemcpyAsync(host_tok.data(), d_tok, host_tok.size() * 4, hipMemcpyDeviceToHost, s));
@@ -2828,7 +2858,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     }
     m->timings.preprocess_ms = pre_ms; m->timings.encode_ms = enc_ms; m->timings.decode_ms = pf_ms + (now_ms() - t1); m->timings.total_ms = now_ms() - t0;
     m->timings.decode_tokens = total; m->timings.graph_replays = replays;
-    if (knob_str("VOX_BATCH_VERBOSE")) fprintf(stderr, "[voxtral_hip] continuous batch: %d utterances, %d slots, %d steps (plan %.1f ms), front-end %.1f ms, encode %.1f ms (%d chunks), prefill %.1f ms (%d graph captures, %.1f ms of host time, under the last chunk's), decode %.1f ms\n", n, Sl, steps, plan.cost_ms, pre_ms, enc_ms, n_chunks, pf_ms, n_captures, capture_ms, now_ms() - t1);
+    if (knob_str("VOX_BATCH_VERBOSE")) fprintf(stderr, "[voxtral_hip] continuous batch: %d utterances, %d slots, %d steps (plan %.1f ms), front-end %.1f ms, encode %.1f ms (%d chunks), prefill %.1f ms (%d graph captures, %.1f ms of host time, under the last chunk's), decode %.1f ms; step costs used %.2f / %.2f / %.2f / %.2f ms\n", n, Sl, steps, plan.cost_ms, pre_ms, enc_ms, n_chunks, pf_ms, n_captures, capture_ms, now_ms() - t1, step_cost[1], step_cost[2], step_cost[3], step_cost[4]);
     return VOX_OK;
 }
 
