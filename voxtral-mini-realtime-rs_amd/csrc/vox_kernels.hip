@@ -1538,8 +1538,14 @@ __global__ __launch_bounds__(256, 2) void q4_wide_kernel(const GemmParams p, con
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int t = 0; t < NTW; t++)
-                if (tile0 + t < n_tiles)
-                    *reinterpret_cast<float4*>(planes + ((((size_t)z * MT + mt) * n_tiles + tile0 + t) * 64 + lane) * 4) = make_float4(acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]);
+                if (tile0 + t < n_tiles) {
+                    float* dst = planes + ((((size_t)z * MT + mt) * n_tiles + tile0 + t) * 64 + lane) * 4;
+                    // WRITE-THROUGH plane stores: plain stores leave 6 - 14 MB dirty in the XCD L2s, which the kernel boundary then writes back before the finishing launch
+                    // may start (MI355X_MICROARCH.md: boundary + B / 6 TB/s; publish-large: write-through wins) -- measured 102.5 -> 96.3 us per layer of GEMM + finishing
+                    // launches at four groups (VOX_WIDE_ABL=16: plain stores)
+                    if (!(p.ksplit & 16)) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(acc[mt][t]) : "memory");
+                    else *reinterpret_cast<float4*>(dst) = make_float4(acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]);
+                }
     }
     VOX_WTL(7)
 #undef VOX_WTL
