@@ -54,6 +54,21 @@ def test_no_kernel_spills_or_scratch(pkg):
     assert eng and all(r[".vgpr_count"] <= 128 for r in eng)      # 14 waves per CU need <= 128 VGPRs
 
 
+def test_no_packed_fp32_src1_swap(pkg):
+    """MI355X, found in round 6 (two contexts on one GPU gave different encoder outputs run to run): v_pk_mul / add / fma_f32 with op_sel taking SRC1's high dword for the low
+    lane returns a wrong low lane while another wave of the CU executes MFMAs -- tools/repro/pk_fp32_corun.cpp reproduces it without any library code (profiles/
+    r06_pk_fp32_corun.txt).  hipcc forms the encoding by itself from pair arithmetic, so every shipped code object is scanned for it (no GPU needed); a kernel that shows up
+    here gets VOX_NO_PK_F32 (csrc/vox_kernels.h) or a formulation that keeps the lanes straight."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import packed_src1_swaps, PK_SRC1_SWAP
+    assert PK_SRC1_SWAP.search("v_pk_mul_f32 v[12:13], v[12:13], v[10:11] op_sel:[0,1] op_sel_hi:[0,0]") and PK_SRC1_SWAP.search("v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,0,1]")
+    assert not PK_SRC1_SWAP.search("v_pk_mul_f32 v[8:9], v[0:1], v[4:5] op_sel:[1,0] op_sel_hi:[0,0]") and not PK_SRC1_SWAP.search("v_pk_fma_f32 v[2:3], v[6:7], v[2:3], v[20:21] op_sel:[0,0,1] op_sel_hi:[1,1,0]")
+    assert not PK_SRC1_SWAP.search("v_pk_fma_f32 v[14:15], v[16:17], v[10:11], v[12:13] op_sel_hi:[0,1,1] neg_lo:[0,0,1]")
+    hits = packed_src1_swaps(pkg.build.LIB_PATH)
+    assert not hits, hits[:8]
+
+
 def test_compute_fails_loudly_without_gpu(pkg):
     n = C.c_int32(); pkg._lib.check(pkg.lib().vox_device_count(C.byref(n)))
     if n.value > 0:

@@ -626,7 +626,7 @@ __device__ __forceinline__ float dot8_f32(const uint4 we, const uint4 wo, const 
 }
 // F32W: the weights are the exact f32 plane (WFMT_F32: 32 bytes per 8 weights instead of 16)
 template <int PRO, int EPI, int F32W = 0>
-__global__ __launch_bounds__(256) void dense_gemv_kernel(const GemvParams p) {
+__global__ __launch_bounds__(256) VOX_NO_PK_F32 void dense_gemv_kernel(const GemvParams p) {      // (VOX_NO_PK_F32: hipcc's horizontal add was a src1-swapped v_pk_add_f32, vox_kernels.h)
     constexpr int NX = 10, R = 2;                  // K <= 10240; one wave = one row pair
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = p.w.K, N = p.w.N, nc = K >> 3;   // 16-byte chunks (8 bf16) per row
@@ -2920,7 +2920,9 @@ hipError_t launch_rms_norm(const float* x, int x_stride, int rows, int dim, cons
 // ------------------------------------------------------------------------------------------------
 // RoPE (interleaved pairs) + KV store for the multi-row paths
 // ------------------------------------------------------------------------------------------------
-__global__ void rope_kernel(float* __restrict__ buf, int M, int stride, int n_rot, int hd, int pos_off,
+// (VOX_NO_PK_F32: hipcc's rotation was v_pk_mul_f32 op_sel:[0,1] -> v_pk_fma_f32; next to another stream's MFMA kernel ~2.6 % of the pairs lost their -xi * sin term: two
+// contexts on one GPU produced different encoder outputs run to run.  Same arithmetic, scalar: p0 = fma(xr, c, -(xi * sn)), p1 = fma(xi, c, xr * sn).)
+__global__ VOX_NO_PK_F32 void rope_kernel(float* __restrict__ buf, int M, int stride, int n_rot, int hd, int pos_off,
                             const float* __restrict__ cos_t, const float* __restrict__ sin_t, int seq_rows, const int* __restrict__ row_pos) {
     const int half_cols = n_rot >> 1;
     const long total = (long)M * half_cols;
