@@ -161,7 +161,7 @@ def piecewise_extra(pkg, gguf_path, x, ref_ids, reps=3):
             "note": "tok_per_s = ids / decode-stage seconds as bin/e2e_bench.rs:236-240 (prefill included), the reference's definition"}
 
 
-def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch, simulate_world=0, bcast_bytes=0, chunk_frames=0):
+def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch, simulate_world=0, bcast_bytes=0, chunk_frames=0, sessions=1):
     """BASELINE configs[4] stand-in (no FLEURS offline): `n_clips` synthetic clips with FLEURS-like durations, LPT-sharded over the ranks
     (shard.run_sharded), each rank handing its share to vox_transcribe_batch in calls of <= `batch` clips (default: the whole share in one call -- continuous batching over
     16 .. 64 decode slots; 64: the round-4 form, length-bucketed lock-step batches); results gathered in input order.
@@ -182,21 +182,25 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
         cc = pkg.ChunkConfig.voxtral().with_max_frames(chunk_frames)
         plans = {i: (pkg.chunk_plan(clips[i].size, cc) if pkg.needs_chunking(clips[i].size, cc) else [(0, clips[i].size)]) for i in clips}
 
+    # sessions > 1: the rank's share as `sessions` concurrent sessions on its GPU (shard.SessionPool: contexts + model replicas + host threads; batched engines off)
+    pool = shard.SessionPool(pkg, ctx, model, sessions) if sessions > 1 else None
+    runner = pool if pool is not None else model
+
     def batch_work(idx_list):
         if plans is None:
-            outs = model.transcribe_batch([clips[i] for i in idx_list], t_embed)
+            outs = runner.transcribe_batch([clips[i] for i in idx_list], t_embed)
             return [len(o) for o in outs]
         units, grp, owner = [], [], []
         for i in idx_list:
             for a, b in plans[i]:
                 units.append(clips[i][a:b]); grp.append(i); owner.append(i)
-        outs = model.transcribe_batch(units, t_embed, norm_group=grp)
+        outs = runner.transcribe_batch(units, t_embed, norm_group=grp)
         per = {i: 0 for i in idx_list}
         for i, o in zip(owner, outs):
             per[i] += len(o)
         return [per[i] for i in idx_list]
 
-    model.transcribe_batch([clips[i] for i in parts[rank][:min(batch, len(parts[rank]))]], t_embed)      # warm-up: workspaces + kernels
+    runner.transcribe_batch([clips[i] for i in parts[rank][:min(batch, len(parts[rank]))]], t_embed)      # warm-up: workspaces + kernels
     # a rank that throws inside the sharded section would leave the others in a collective until the NCCL timeout; so every rank runs its local
     # work under try/except, the ranks agree on success (one all_reduce) BEFORE any gather, and a failure anywhere skips the extra on every rank
     ok = 1; err = None; res = None; dt = 0.0
@@ -211,6 +215,8 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
     except Exception as e:
         ok = 0; err = str(e)
     ctx.synchronize(); dt = time.perf_counter() - t0
+    if pool is not None:
+        pool.close()
     eng_corpus = model.set_batch_engine()[1] - eng_n0      # rank 0's engine launches inside the timed region (steps with <= 2 active slot groups: one launch each)
     if world > 1:
         import torch
@@ -259,7 +265,7 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
     n_units = sum(len(plans[i]) for i in range(n_clips)) if (plans is not None and len(plans) == n_clips) else (None if plans is not None else n_clips)
     pipe = (f"reference CLI pipeline (bin/transcribe.rs:207-265, --max-mel-frames {chunk_frames}): file peak-normalised once, split into {chunk_frames}-frame chunks, every chunk a unit "
             f"of the batch (vox_transcribe_batch_ex, norm_group = file)") if chunk_frames > 0 else "un-chunked e2e-bench pipeline (bin/e2e_bench.rs:98-135)"
-    return {"simulated_world": sim, "pipeline": pipe, "units": n_units, "chunk_frames": int(chunk_frames),
+    return {"simulated_world": sim, "pipeline": pipe, "units": n_units, "chunk_frames": int(chunk_frames), "sessions_per_gpu": int(sessions),
             "workload": f"{n_clips} synthetic clips, FLEURS-like log-normal durations (median 10 s, 3..30 s, rng 7), host samples -> ids; LPT shards over {world} rank(s), "
                         f"{'one vox_transcribe_batch call per rank (continuous batching)' if batch >= n_clips else f'{batch}-clip length-bucketed calls'} (BASELINE configs[4] stand-in; no FLEURS / WER offline)",
             "clips": n_clips, "audio_s": round(total_s, 1), "wall_s": round(dt, 3), "rtf": round(dt / total_s, 6), "tok_per_s": round(ntok / dt, 1),
@@ -283,6 +289,8 @@ def main():
     ap.add_argument("--fleurs-batch", type=int, default=0, help="clips per vox_transcribe_batch call of the FLEURS-like extra; 0 (default) = a rank's whole share in ONE call (continuous batching over slots, round 5); 64 = the round-4 length-bucketed lock-step batches")
     ap.add_argument("--cli-chunk-frames", type=int, default=1200, help="also run the FLEURS-like corpus on the reference CLI's pipeline: files split into chunks of this many mel frames "
                     "(bin/transcribe.rs:55-57 default 1200), every chunk a unit of the batch (`fleurs_like_cli`); 0 = skip")
+    ap.add_argument("--corpus-sessions", type=int, default=2, help="also run the FLEURS-like corpus with this many concurrent sessions per GPU (shard.SessionPool: contexts + model replicas + "
+                    "host threads; `fleurs_like_sessions`); <= 1 = skip")
     ap.add_argument("--gemv-iters", type=int, default=260)
     args = ap.parse_args()
 
@@ -386,6 +394,13 @@ def main():
         except Exception as e:
             fleurs_cli = {"error": str(e)} if rank == 0 else None
 
+    fleurs_s = None
+    if args.fleurs_clips > 0 and args.corpus_sessions > 1:
+        try:      # the same corpus (un-chunked), every rank's share as `corpus_sessions` concurrent sessions on its GPU (overlap inside a rank's share)
+            fleurs_s = fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, args.fleurs_clips, 4096, simulate_world=0, bcast_bytes=model.arena()[1], sessions=args.corpus_sessions)
+        except Exception as e:
+            fleurs_s = {"error": str(e)} if rank == 0 else None
+
     out = None
     if rank == 0:
         out = {
@@ -412,6 +427,11 @@ def main():
             out["fleurs_like_cli"] = fleurs_cli
             if fleurs is not None and "error" not in fleurs and "error" not in fleurs_cli:
                 out["fleurs_like_cli"]["tok_per_s_vs_unchunked"] = round(fleurs_cli["tok_per_s"] / fleurs["tok_per_s"], 3)
+        if fleurs_s is not None:
+            out["fleurs_like_sessions"] = fleurs_s
+            if fleurs is not None and "error" not in fleurs and "error" not in fleurs_s:
+                out["fleurs_like_sessions"]["tok_per_s_vs_one_session"] = round(fleurs_s["tok_per_s"] / fleurs["tok_per_s"], 3)
+                out["fleurs_like_sessions"]["same_ids_as_one_session"] = bool(fleurs_s["ids"] == fleurs["ids"])
         if fleurs is not None:
             out["fleurs_like"] = fleurs
             if "error" not in fleurs:

@@ -59,6 +59,12 @@ int32_t vox_device_count(int32_t* n);
 int32_t vox_ctx_create(int32_t device, vox_ctx** out);
 int32_t vox_ctx_destroy(vox_ctx* ctx);
 int32_t vox_ctx_synchronize(vox_ctx* ctx);
+/* shared != 0: this context SHARES its GPU with other sessions (more contexts of this process -- one host thread each, see vox_model_replicate -- or other processes).
+ * The batch entry points then stay off the batched decode engines (their 256 persistent workgroups need the GPU to themselves: next to another session their bounded
+ * hand-off waits expire and the session is run twice) and the slot planner prices its steps with the table scaled by ONE measured factor instead of per-form
+ * measurements (which scatter under contention) and records none.  Results do not change.  Default 0.  (No reference counterpart: the reference runs one utterance at a
+ * time, bin/transcribe.rs:112-126; this is what a multi-threaded host sets on every context of a GPU it runs more than one session on.) */
+int32_t vox_ctx_set_shared(vox_ctx* ctx, int32_t shared);
 int32_t vox_ctx_stream(vox_ctx* ctx, void** hip_stream_out);   /* hipStream_t, for event timing */
 /* device memory helpers so non-HIP callers can use VOX_MEM_DEVICE */
 int32_t vox_dev_alloc(vox_ctx* ctx, size_t nbytes, void** out);

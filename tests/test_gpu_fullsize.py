@@ -932,6 +932,54 @@ def test_full_model_replicate_second_context(pkg, full):
         ctx2.close()
 
 
+def test_full_two_sessions_one_gpu_same_ids(pkg, full, monkeypatch):
+    """Two concurrent sessions on ONE GPU (shard.SessionPool: second context + vox_model_replicate + host thread) at full size: 140 clips of
+    3 .. 20 s, un-chunked and as CLI chunks with file peaks -- every unit's ids equal, bit for bit and twice in a row, the ids of the SAME two sessions run one after the
+    other (same inputs, same slot plans: VOX_BATCH_NO_CALIB pins the planner), and all but near-ties equal the one-session run's (a clip may meet the wide step in one
+    plan and the launch chains in another: different K-split orders).  This is the test that found the
+    MI355X packed-FP32 behaviour (csrc/vox_kernels.h VOX_NO_PK_F32): with rope_kernel's v_pk_mul_f32 op_sel:[0,1] the encoder output of a session changed whenever the other
+    session's MFMA kernels shared its CUs, and 2 - 4 % of the clips came back with other ids, differently every run."""
+    m, _, ctx = full
+    shard = pkg.shard
+    t = pkg.TimeEmbedding(3072).embed(6.0)
+    clips = [pkg.synth.synth_audio(3.0 + 17.0 * ((37 * i) % 101) / 100.0, seed=4000 + i) * (0.3 + 0.1 * (i % 5)) for i in range(140)]
+    was = m.set_batch_engine()[0]; m.set_batch_engine(False)      # (the pool runs without the batched engines; the launch chains and the wide step are bit-identical paths)
+    monkeypatch.setenv("VOX_BATCH_NO_CALIB", "1")
+    try:
+        ref = m.transcribe_batch(clips, t)
+        cc = pkg.ChunkConfig.voxtral().with_max_frames(1200)
+        units, grp = [], []
+        for i, x in enumerate(clips[:60]):
+            for a, b in (pkg.chunk_plan(x.size, cc) if pkg.needs_chunking(x.size, cc) else [(0, x.size)]):
+                units.append(x[a:b]); grp.append(i)
+        assert len(units) > 70
+        ref_u = m.transcribe_batch(units, t, norm_group=grp)
+        with shard.SessionPool(pkg, ctx, m, 2) as pool:
+            assert len(pool.models) == 2
+            parts = pool.split([float(x.size) for x in clips])
+            seq = [None] * len(clips)
+            for k in range(2):      # the two sessions one after the other, each on its own (context, model)
+                for i, o in zip(parts[k], pool.models[k].transcribe_batch([clips[i] for i in parts[k]], t)):
+                    seq[i] = o
+            for rep in range(2):
+                got = pool.transcribe_batch(clips, t)
+                bad = [i for i in range(len(clips)) if not np.array_equal(seq[i], got[i])]
+                assert not bad, (rep, bad[:10])
+            assert sum(int(np.array_equal(a, b)) for a, b in zip(ref, got)) >= len(clips) - 4
+            parts_u = pool.split([float(x.size) for x in units], grp)
+            assert all(len({k for k in range(2) for u in parts_u[k] if grp[u] == g}) == 1 for g in set(grp))      # a file's chunks stay in one session (device peak per call)
+            seq_u = [None] * len(units)
+            for k in range(2):
+                for i, o in zip(parts_u[k], pool.models[k].transcribe_batch([units[i] for i in parts_u[k]], t, norm_group=[grp[i] for i in parts_u[k]])):
+                    seq_u[i] = o
+            got_u = pool.transcribe_batch(units, t, norm_group=grp)
+            assert all(np.array_equal(a, b) for a, b in zip(seq_u, got_u))
+            assert sum(int(np.array_equal(a, b)) for a, b in zip(ref_u, got_u)) >= len(units) - 3
+        assert np.array_equal(m.transcribe_batch(clips[:20], t)[7], ref[7])      # the source model keeps working after the pool is gone
+    finally:
+        m.set_batch_engine(was)
+
+
 def test_full_load_replicated_rccl_world1(pkg, full):
     """The multi-GPU start-up the product uses (shard.load_replicated: cli.py / wer.py / bench.py --gpus N) with a REAL RCCL process group on this one GPU (world 1, `nccl`
     backend; tests/rccl_startup_worker.py, its own process so torch's HIP runtime is loaded first): RCCL initialises, the broadcast executes on the library's arena memory

@@ -259,3 +259,58 @@ def test_load_replicated_protocol_world2_gloo(pkg):
     assert shard.load_replicated(None, None, "x", 0, 1, loader=L(), stats=st) == "model" and st == {"bytes": 0, "seconds": 0.0, "broadcast": False}
     with pytest.raises(RuntimeError):
         shard.load_replicated(None, None, "x", 0, 2, loader=L())
+
+
+def test_session_pool_split_and_threads_cpu(pkg):
+    """shard.SessionPool without a GPU: fake models (ids = the unit's length) on fake contexts.  Units sharing a normalisation group stay in one session (the group's peak
+    is reduced over the units of ONE call), the split is balanced, results come back in input order, the pool's contexts are marked shared while it lives and the caller's context is un-marked
+    by close(), a failing session raises on the calling thread."""
+    import importlib, threading
+    shard = importlib.import_module(pkg.__name__ + ".shard")
+    calls = []
+
+    class Ctx:
+        device = 0
+        shared = False
+        def set_shared(self, on=True): self.shared = bool(on)
+        def synchronize(self): pass
+        def close(self): pass
+
+    class Model:
+        def __init__(self, fail=False): self.eng, self.fail, self.closed = True, fail, False
+        def set_batch_engine(self, on=None):
+            if on is not None: self.eng = bool(on)
+            return self.eng, 0
+        def replicate(self, c): return Model(self.fail)
+        def close(self): self.closed = True
+        def transcribe_batch(self, xs, t, norm_group=None):
+            if self.fail and threading.current_thread() is not threading.main_thread(): raise RuntimeError("boom")
+            calls.append((threading.current_thread().name, len(xs), None if norm_group is None else list(norm_group)))
+            return [np.full(2, len(x), np.int32) for x in xs]
+
+    class Pkg:
+        Context = staticmethod(lambda dev: Ctx())
+
+    m = Model(); c0 = Ctx(); pool = shard.SessionPool(Pkg, c0, m, 2)
+    assert len(pool.models) == 2 and all(c.shared for c in pool.ctxs)      # every context of the pool is marked shared (vox_ctx_set_shared: no batched engines, planner on the table)
+    xs = [np.zeros(n, np.float32) for n in (50, 30, 90, 10, 40, 40, 70, 20)]
+    grp = [0, 0, 1, -1, 2, 2, 3, -1]
+    parts = pool.split([float(x.size) for x in xs], grp)
+    assert sorted(parts[0] + parts[1]) == list(range(8))
+    for g in (0, 2):
+        owners = {k for k in range(2) for u in parts[k] if grp[u] == g}
+        assert len(owners) == 1
+    loads = [sum(xs[u].size for u in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 40
+    out = pool.transcribe_batch(xs, None, norm_group=grp)
+    assert [int(o[0]) for o in out] == [x.size for x in xs]
+    assert len({c[0] for c in calls}) == 2 and sorted(c[1] for c in calls) == sorted(len(p) for p in parts)       # two host threads, one call each
+    assert all(c[2] is not None and len(c[2]) == c[1] for c in calls)
+    calls.clear(); out = pool.transcribe_batch(xs[:3], None)      # fewer than 2 units per session: one plain call
+    assert len(calls) == 1 and calls[0][1] == 3 and [int(o[0]) for o in out] == [50, 30, 90]
+    rep = pool.models[1]; pool.close()
+    assert c0.shared is False and rep.closed and len(pool.models) == 1
+    bad = shard.SessionPool(Pkg, Ctx(), Model(fail=True), 2)
+    with pytest.raises(RuntimeError, match="boom"):
+        bad.transcribe_batch(xs, None)
+    bad.close()

@@ -121,6 +121,9 @@ def test_cli_batch_makes_chunks_units_of_work_and_keeps_the_serial_lines(pkg, tm
     assert rc2 == 0 and out2 == out1 and f"batch of {n_units}" in err2 and "chunk " not in err2      # no file went through the serial loop
     rc3, out3, err3 = run(["--batch", "8"])
     assert rc3 == 0 and out3 == out1 and err3.count("batch of ") == (n_units + 7) // 8
+    # two concurrent sessions on the GPU (shard.SessionPool: a second context + model replica + host thread): the same lines
+    rc4, out4, err4 = run(["--batch", "1024", "--sessions-per-gpu", "2"])
+    assert rc4 == 0 and out4 == out1 and "2 sessions on this GPU" in err4 and "chunk " not in err4
 
 
 @pytest.mark.gpu

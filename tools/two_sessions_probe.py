@@ -18,6 +18,8 @@ durs = shard.fleurs_like_durations(n, seed=7)
 clips = [pkg.synth.synth_audio(durs[i], seed=9000 + i) for i in range(n)]
 ctxs = [ctx] + [pkg.Context(0) for _ in range(S - 1)]
 models = [m] + [m.replicate(c) for c in ctxs[1:]]
+if os.environ.get("PROBE_SHARED"):      # vox_ctx_set_shared: no batched engines (a second session makes their bounded waits expire: a strike = a wasted re-run), planner on the scaled table
+    for c in ctxs: c.set_shared(True)
 parts = shard.lpt_partition(durs, S)
 
 def one():

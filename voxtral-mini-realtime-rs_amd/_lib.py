@@ -52,6 +52,7 @@ SIGNATURES = {
     "vox_ctx_destroy": (i32, [vp]),
     "vox_debug_reload_knobs": (i32, []),
     "vox_ctx_synchronize": (i32, [vp]),
+    "vox_ctx_set_shared": (i32, [vp, i32]),
     "vox_ctx_stream": (i32, [vp, P(vp)]),
     "vox_dev_alloc": (i32, [vp, sz, P(vp)]),
     "vox_dev_free": (i32, [vp, vp]),

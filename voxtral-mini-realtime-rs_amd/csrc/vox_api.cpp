@@ -101,6 +101,7 @@ struct vox_ctx {
     uint32_t warm_forms = 0;      // continuous batch: step forms whose kernels have run once on this context's device (bit 0 launch chains, bit 1 engine + tail, bits 2..4 the wide step at 2 / 3 / 4 groups)
     // XF tiles of a 17..48-row GEMM input (the 38-token prefill): 3 tiles x K columns x 64 B; sized once for K <= 16384, reused by every such GEMM of the stream
     uint16_t* xf_scratch = nullptr; size_t xf_scratch_bytes = 0;
+    bool shared = false;      // vox_ctx_set_shared: other sessions run on this GPU (no batched engines, planner on the scaled table)
     float* kz_scratch = nullptr; size_t kz_scratch_bytes = 0;      // K-slice planes of the 17..48-row GEMMs (q4_skinny_mt2_kernel): 8 x 48 x 18432 floats
     float* rs_matrix = nullptr; uint32_t rs_in = 0, rs_out = 0;    // block matrix of the last resampled rate pair (vox_resample)
     struct vox_model* pw_model = nullptr;      // the model with decode-engine steps of the piecewise surface enqueued on `stream` and not yet verified (see pw_after_sync)
@@ -150,6 +151,7 @@ extern "C" int32_t vox_ctx_synchronize(vox_ctx* c) {
     if (c->pw_model) return pw_after_sync(c->pw_model);      // unverified decode-engine steps of the piecewise surface: their verdict is due at every synchronisation
     return VOX_OK;
 }
+extern "C" int32_t vox_ctx_set_shared(vox_ctx* c, int32_t shared) { ARGCHK(c, "null context"); c->shared = shared != 0; return VOX_OK; }
 extern "C" int32_t vox_ctx_stream(vox_ctx* c, void** s) { ARGCHK(c && s, "null argument"); *s = (void*)c->stream; return VOX_OK; }
 extern "C" int32_t vox_dev_alloc(vox_ctx* c, size_t nbytes, void** out) { ARGCHK(c && out, "null argument"); VOXCHK(ctx_bind(c)); HIPCHK(hipMalloc(out, nbytes ? nbytes : 1)); return VOX_OK; }
 extern "C" int32_t vox_dev_free(vox_ctx* c, void* p) { ARGCHK(c, "null ctx"); VOXCHK(ctx_bind(c)); if (p) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(p)); } return VOX_OK; }
@@ -2244,7 +2246,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     // 5 x 26 launches remain as the fallback (other geometries, dense checkpoints, VOX_BATCH_ENGINE=0, a hand-off timeout).  The launch owns all 256 CUs, so the groups of
     // a step would run back to back instead of on forked streams -- measured on the 647-clip corpus in 64-clip batches (four groups): 6 770 tok/s against 8 540 for the
     // forked launch chains (profiles/r04_b16_fleurs_engine_vs_launches.txt), so batches wider than one group keep the launches (VOX_BATCH_ENGINE_WIDE=1: engine for every width).
-    const bool use_eng = allow_engine && use_xf && steps > 0 && (n_grp == 1 || knob_str("VOX_BATCH_ENGINE_WIDE")) && engb_prepare(m, n_grp);
+    const bool use_eng = allow_engine && !m->ctx->shared && use_xf && steps > 0 && (n_grp == 1 || knob_str("VOX_BATCH_ENGINE_WIDE")) && engb_prepare(m, n_grp);
     DevBuf b_ssq_e;
     std::vector<EngLayerTab> eng_tabs;
     if (use_eng) {
@@ -2432,7 +2434,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
 //       + argmax_embed_slots_kernel, which hands a slot whose utterance just got its last token the next one of its queue in the same launch.  A group retires when its
 //       queues are empty.  Rows are independent of their slot, so the ids per utterance are those of every other path (tests/test_gpu_fullsize.py).
 // Step cost of G lock-step groups in ms, measured on the FLEURS-like corpus (profiles/r05_continuous_sweep.txt: decode time net of graph captures / steps; 3 interpolated):
-static const double kStepMs[5] = {0.0, 1.84, 2.08, 2.75, 3.40};
+static const double kStepMs[5] = {0.0, 1.84, 2.08, 2.75, 3.15};      // (four groups: the wide step, round 6 -- 3.40 on four forked chains)
 // ... with the batched decode-layer engine serving the steps of <= 2 active groups (one group: decode_engine_b16_kernel<1>, 1.06 ms + tail; two: the two-group launch,
 // 1.60 ms + tail; three and four groups stay on the forked launch chains -- a two-group launch + a one- or two-group launch back to back: 2.9 / 3.4 ms against 2.75 / 3.40)
 static const double kStepMsEng[5] = {0.0, 1.17, 1.77, 2.75, 3.15};      // (four groups: the wide step, round 6)
@@ -2507,7 +2509,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     int force_G = 0; if (const char* e = knob_str("VOX_BATCH_SLOT_GROUPS")) force_G = std::max(0, std::min(4, atoi(e)));
     // the steps of one or two active groups go through the batched decode-layer engine (vox_engine_b16.hip: one launch per step for the 26 layers of both groups, cache
     // slices per slot through EngBParams::kv_row); wider steps, other geometries, VOX_BATCH_ENGINE=0 and the re-run after a hand-off timeout use the launch chains
-    const bool use_eng = allow_engine && !jobs.empty() && !knob_str("VOX_BATCH_CONT_NO_ENGINE") && engb_prepare(m, 2);
+    const bool use_eng = allow_engine && !cx->shared && !jobs.empty() && !knob_str("VOX_BATCH_CONT_NO_ENGINE") && engb_prepare(m, 2);
     // step costs: the table above, corrected by what this context has measured -- a form seen before costs what it cost (clock, a shared GPU, another geometry), a form not
     // seen yet the table's value times the mean measured / table ratio of the forms that were.  VOX_BATCH_NO_CALIB=1: the table alone.
     double step_cost[5]; const double* base_cost = use_eng ? kStepMsEng : kStepMs; const bool calib = !knob_str("VOX_BATCH_NO_CALIB");
@@ -2515,7 +2517,15 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         const double* meas = cx->step_ms_meas[use_eng ? 0 : 1]; double ratio = 0.0; int nr = 0;
         for (int g2 = 1; g2 <= 4; g2++) if (calib && meas[g2] > 0.0) { ratio += meas[g2] / base_cost[g2]; nr++; }
         ratio = nr ? std::min(4.0, std::max(0.25, ratio / nr)) : 1.0;
-        step_cost[0] = 0.0; for (int g2 = 1; g2 <= 4; g2++) step_cost[g2] = (calib && meas[g2] > 0.0) ? meas[g2] : base_cost[g2] * ratio;
+        // The common factor (clock, a GPU shared with another session) is taken as measured; a form's deviation from it is trusted within +-15 % only, and a step of more
+        // groups never costs less than one of fewer: next to a second session on the GPU (tools/two_sessions_probe.py) the per-form figures scatter (a 3-group step "measured"
+        // at 5.35 ms against 4.18 for four groups made the next session plan 48 slots instead of 64: 4.71 s instead of 3.77 s for the corpus)
+        step_cost[0] = 0.0;
+        for (int g2 = 1; g2 <= 4; g2++) {
+            const double common = base_cost[g2] * ratio;
+            step_cost[g2] = (calib && !cx->shared && meas[g2] > 0.0) ? common * std::min(1.15, std::max(0.85, meas[g2] / common)) : common;      // (a shared GPU: the common factor only)
+            step_cost[g2] = std::max(step_cost[g2], step_cost[g2 - 1]);
+        }
     }
     const SlotPlan plan = plan_slots(jobs, force_G, step_cost);
     const int G = std::max(plan.G, 1), Sl = 16 * G;
@@ -2839,7 +2849,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             if (m->engb_strikes >= 3) m->engb_ok = false;
             return VOX_RETRY_ON_LAUNCHES;
         }
-        for (int k = 0; k < n_seg; k++) {      // runs of >= 8 steps only: shorter ones are mostly their first replay
+        for (int k = 0; k < n_seg && !cx->shared; k++) {      // runs of >= 8 steps only: shorter ones are mostly their first replay (a shared GPU: nothing is recorded)
             float ms = 0.f;
             if (seg_n[k] >= 8 && seg_act[k] >= 1 && seg_act[k] <= 4 && hipEventElapsedTime(&ms, cx->ev_seg[k], cx->ev_seg[k + 1]) == hipSuccess && ms > 0.f) {
                 double& mm = cx->step_ms_meas[use_eng ? 0 : 1][seg_act[k]]; const double v = (double)ms / seg_n[k];

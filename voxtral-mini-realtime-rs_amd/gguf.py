@@ -34,6 +34,10 @@ class Context:
         """Test hook: `workgroups` x 1024 threads spin for `micros` us on a side stream (returns at once)."""
         check(lib().vox_debug_occupy(self.h, workgroups, micros))
 
+    def set_shared(self, shared: bool = True):
+        """vox_ctx_set_shared: this context shares its GPU with other sessions (no batched decode engines, slot planner on the scaled cost table); results unchanged."""
+        check(lib().vox_ctx_set_shared(self.h, 1 if shared else 0))
+
     def synchronize(self):
         check(lib().vox_ctx_synchronize(self.h))
 

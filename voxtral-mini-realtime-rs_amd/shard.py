@@ -165,3 +165,85 @@ def fleurs_like_durations(n: int = 647, seed: int = 7):
     import numpy as np
     rng = np.random.default_rng(seed)
     return [round(float(d), 2) for d in np.clip(rng.lognormal(np.log(10.0), 0.5, n), 3.0, 30.0)]
+
+
+class SessionPool:
+    """Overlap INSIDE a rank's share: S concurrent sessions on ONE GPU -- S contexts (own stream, workspaces, graphs), S model replicas
+    (vox_model_replicate: 2.5 GB each, device-to-device, no file), S host threads -- each running vox_transcribe_batch[_ex] over its part of the units.  One session
+    leaves the GPU idle wherever its launch-bound decode steps wait (a 64-slot step streams 2.1 GB of weights in 3.1 ms); a second session's encoder GEMMs, prefill
+    and steps fill those gaps: the 647-clip FLEURS-like corpus takes 3.77 s with two sessions against 4.52 s with one (tools/two_sessions_probe.py, same ids).
+    What a Rust host would do with one thread per (context, model) pair; results are per unit and do not depend on the split (every row of a batch is computed
+    independently, tests/test_gpu_fullsize.py::test_full_two_sessions_one_gpu_same_ids).
+
+    Every context of a pool with S > 1 is marked SHARED (vox_ctx_set_shared): the batch entry points stay off the batched decode engines -- their 256 persistent
+    workgroups need the GPU to themselves, a second session makes their bounded hand-off waits expire and every strike is a session run twice -- and the slot planner
+    prices its steps with the scaled table instead of per-form measurements that scatter under contention (one bad figure planned 48 slots instead of 64: 4.7 s
+    instead of 3.8 s)."""
+
+    def __init__(self, pkg, ctx, model, sessions: int = 2):
+        self.pkg, self.sessions = pkg, max(1, int(sessions))
+        self.ctxs, self.models, self._own = [ctx], [model], []
+        if self.sessions > 1:
+            for _ in range(self.sessions - 1):
+                c = pkg.Context(ctx.device); r = model.replicate(c)
+                self.ctxs.append(c); self.models.append(r); self._own.append((r, c))
+            for c in self.ctxs:
+                c.set_shared(True)
+
+    def split(self, weights: Sequence[float], groups: Sequence[int] | None = None) -> list[list[int]]:
+        """Unit indices per session: LPT over the units -- or over whole normalisation groups (units that share a group id >= 0 stay in one session: the group's
+        peak is reduced on the device over the units of ONE call)."""
+        if groups is None or all(g < 0 for g in groups):
+            return [sorted(p) for p in lpt_partition(list(weights), self.sessions)]
+        keys, members = {}, []
+        for u, g in enumerate(groups):
+            k = ("g", g) if g >= 0 else ("u", u)
+            if k not in keys:
+                keys[k] = len(members); members.append([])
+            members[keys[k]].append(u)
+        parts = lpt_partition([sum(weights[u] for u in mem) for mem in members], self.sessions)
+        return [sorted(u for gi in p for u in members[gi]) for p in parts]
+
+    def transcribe_batch(self, samples_list, t_embed, norm_group=None):
+        """Same contract as Q4VoxtralModel.transcribe_batch: ids per unit, in input order."""
+        n = len(samples_list)
+        if self.sessions == 1 or n < 2 * self.sessions:
+            return self.models[0].transcribe_batch(samples_list, t_embed, norm_group=norm_group)
+        import threading
+        parts = self.split([float(len(x)) for x in samples_list], norm_group)
+        res, errs = [None] * self.sessions, []
+
+        def work(k):
+            try:
+                idx = parts[k]
+                if idx:
+                    res[k] = self.models[k].transcribe_batch([samples_list[i] for i in idx], t_embed, norm_group=None if norm_group is None else [norm_group[i] for i in idx])
+                    self.ctxs[k].synchronize()
+            except Exception as e:      # noqa: BLE001 -- re-raised on the calling thread
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(self.sessions)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        out = [None] * n
+        for k in range(self.sessions):
+            for i, o in zip(parts[k], res[k] or []):
+                out[i] = o
+        return out
+
+    def close(self):
+        for r, c in self._own:
+            r.close(); c.close()
+        if self._own:
+            self.ctxs[0].set_shared(False)
+        self._own = []
+        self.ctxs, self.models = self.ctxs[:1], self.models[:1]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
