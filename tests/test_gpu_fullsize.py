@@ -956,6 +956,7 @@ def test_full_two_sessions_one_gpu_same_ids(pkg, full, monkeypatch):
         ref_u = m.transcribe_batch(units, t, norm_group=grp)
         with shard.SessionPool(pkg, ctx, m, 2) as pool:
             assert len(pool.models) == 2
+            pool.MIN_UNITS_PER_SESSION = 32      # (the default keeps shares this small on one session)
             parts = pool.split([float(x.size) for x in clips])
             seq = [None] * len(clips)
             for k in range(2):      # the two sessions one after the other, each on its own (context, model)

@@ -293,6 +293,8 @@ def test_session_pool_split_and_threads_cpu(pkg):
 
     m = Model(); c0 = Ctx(); pool = shard.SessionPool(Pkg, c0, m, 2)
     assert len(pool.models) == 2 and all(c.shared for c in pool.ctxs)      # every context of the pool is marked shared (vox_ctx_set_shared: no batched engines, planner on the table)
+    assert pool.MIN_UNITS_PER_SESSION >= 64      # small shares run as one session (measured: two sessions only pay off from ~250 units on)
+    pool.MIN_UNITS_PER_SESSION = 2
     xs = [np.zeros(n, np.float32) for n in (50, 30, 90, 10, 40, 40, 70, 20)]
     grp = [0, 0, 1, -1, 2, 2, 3, -1]
     parts = pool.split([float(x.size) for x in xs], grp)
@@ -310,7 +312,7 @@ def test_session_pool_split_and_threads_cpu(pkg):
     assert len(calls) == 1 and calls[0][1] == 3 and [int(o[0]) for o in out] == [50, 30, 90]
     rep = pool.models[1]; pool.close()
     assert c0.shared is False and rep.closed and len(pool.models) == 1
-    bad = shard.SessionPool(Pkg, Ctx(), Model(fail=True), 2)
+    bad = shard.SessionPool(Pkg, Ctx(), Model(fail=True), 2); bad.MIN_UNITS_PER_SESSION = 2
     with pytest.raises(RuntimeError, match="boom"):
         bad.transcribe_batch(xs, None)
     bad.close()

@@ -180,6 +180,10 @@ class SessionPool:
     prices its steps with the scaled table instead of per-form measurements that scatter under contention (one bad figure planned 48 slots instead of 64: 4.7 s
     instead of 3.8 s)."""
 
+    # Fewer units than this per session and the call runs as ONE session: a small share is bound by its longest clip's step count, and a second session only slows
+    # every step (same box, two sessions against one: 81 clips x0.82, 162 x0.86, 324 x1.16, 480 x1.20, 647 x1.20 -- tools/two_sessions_probe.py)
+    MIN_UNITS_PER_SESSION = 128
+
     def __init__(self, pkg, ctx, model, sessions: int = 2):
         self.pkg, self.sessions = pkg, max(1, int(sessions))
         self.ctxs, self.models, self._own = [ctx], [model], []
@@ -190,28 +194,30 @@ class SessionPool:
             for c in self.ctxs:
                 c.set_shared(True)
 
-    def split(self, weights: Sequence[float], groups: Sequence[int] | None = None) -> list[list[int]]:
+    def split(self, weights: Sequence[float], groups: Sequence[int] | None = None, sessions: int | None = None) -> list[list[int]]:
         """Unit indices per session: LPT over the units -- or over whole normalisation groups (units that share a group id >= 0 stay in one session: the group's
         peak is reduced on the device over the units of ONE call)."""
+        S = self.sessions if sessions is None else sessions
         if groups is None or all(g < 0 for g in groups):
-            return [sorted(p) for p in lpt_partition(list(weights), self.sessions)]
+            return [sorted(p) for p in lpt_partition(list(weights), S)]
         keys, members = {}, []
         for u, g in enumerate(groups):
             k = ("g", g) if g >= 0 else ("u", u)
             if k not in keys:
                 keys[k] = len(members); members.append([])
             members[keys[k]].append(u)
-        parts = lpt_partition([sum(weights[u] for u in mem) for mem in members], self.sessions)
+        parts = lpt_partition([sum(weights[u] for u in mem) for mem in members], S)
         return [sorted(u for gi in p for u in members[gi]) for p in parts]
 
     def transcribe_batch(self, samples_list, t_embed, norm_group=None):
         """Same contract as Q4VoxtralModel.transcribe_batch: ids per unit, in input order."""
         n = len(samples_list)
-        if self.sessions == 1 or n < 2 * self.sessions:
+        S = max(1, min(self.sessions, n // max(1, self.MIN_UNITS_PER_SESSION)))
+        if S == 1:
             return self.models[0].transcribe_batch(samples_list, t_embed, norm_group=norm_group)
         import threading
-        parts = self.split([float(len(x)) for x in samples_list], norm_group)
-        res, errs = [None] * self.sessions, []
+        parts = self.split([float(len(x)) for x in samples_list], norm_group, S)
+        res, errs = [None] * S, []
 
         def work(k):
             try:
@@ -221,7 +227,7 @@ class SessionPool:
                     self.ctxs[k].synchronize()
             except Exception as e:      # noqa: BLE001 -- re-raised on the calling thread
                 errs.append(e)
-        th = [threading.Thread(target=work, args=(k,)) for k in range(self.sessions)]
+        th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
         for t in th:
             t.start()
         for t in th:
@@ -229,7 +235,7 @@ class SessionPool:
         if errs:
             raise errs[0]
         out = [None] * n
-        for k in range(self.sessions):
+        for k in range(S):
             for i, o in zip(parts[k], res[k] or []):
                 out[i] = o
         return out

@@ -170,7 +170,7 @@ def load_manifest(path: str):
 
 
 def main(argv=None):
-    """`python -m ... wer --manifest corpus.tsv --gguf model.gguf --tokenizer tekken.json [--delay 6] [--batch 1024]`: the eval_wer.py flow
+    """`python -m ... wer --manifest corpus.tsv --gguf model.gguf --tokenizer tekken.json [--delay 6] [--batch 1024] [--sessions-per-gpu 2]`: the eval_wer.py flow
     (:345-399) with the model loaded once in-process; prints the report, writes wer_<dataset>.json."""
     import argparse, io, contextlib, os, wave
     ap = argparse.ArgumentParser(description="WER evaluation for Voxtral (MI355X HIP path)")
@@ -179,6 +179,7 @@ def main(argv=None):
     ap.add_argument("--delay", type=int, default=6); ap.add_argument("--output"); ap.add_argument("--limit", type=int)
     ap.add_argument("--batch", type=int, default=1024); ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--gpus", type=int, default=1, help="shard the corpus over N GPUs (cli --gpus N: one process per GPU, transcriptions gathered in corpus order)")
+    ap.add_argument("--sessions-per-gpu", type=int, default=1, help="concurrent sessions per GPU (cli --sessions-per-gpu: context + model replica + host thread each; same transcriptions)")
     a = ap.parse_args(argv)
     if not a.gguf and not a.model:
         ap.error("Either --gguf or --model is required")
@@ -191,6 +192,7 @@ def main(argv=None):
             durations.append(w.getnframes() / float(w.getframerate()))
     from . import cli
     args = ["--delay", str(a.delay), "--device", str(a.device), "--batch", str(a.batch)] + (["--gpus", str(a.gpus)] if a.gpus > 1 else [])
+    args += ["--sessions-per-gpu", str(a.sessions_per_gpu)] if a.sessions_per_gpu > 1 else []
     args += (["--gguf", a.gguf] if a.gguf else ["--model", a.model]) + (["--tokenizer", a.tokenizer] if a.tokenizer else [])
     for _, wav, _ in items:
         args += ["--audio", wav]
