@@ -65,6 +65,7 @@ def test_no_packed_fp32_src1_swap(pkg):
     assert PK_SRC1_SWAP.search("v_pk_mul_f32 v[12:13], v[12:13], v[10:11] op_sel:[0,1] op_sel_hi:[0,0]") and PK_SRC1_SWAP.search("v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,0,1]")
     assert not PK_SRC1_SWAP.search("v_pk_mul_f32 v[8:9], v[0:1], v[4:5] op_sel:[1,0] op_sel_hi:[0,0]") and not PK_SRC1_SWAP.search("v_pk_fma_f32 v[2:3], v[6:7], v[2:3], v[20:21] op_sel:[0,0,1] op_sel_hi:[1,1,0]")
     assert not PK_SRC1_SWAP.search("v_pk_fma_f32 v[14:15], v[16:17], v[10:11], v[12:13] op_sel_hi:[0,1,1] neg_lo:[0,0,1]")
+    assert PK_SRC1_SWAP.search("v_pk_mov_b32 v[2:3], v[70:71], v[70:71] op_sel:[1,0]") and not PK_SRC1_SWAP.search("v_pk_mov_b32 v[2:3], v[70:71], v[72:73] op_sel:[0,1]")
     hits = packed_src1_swaps(pkg.build.LIB_PATH)
     assert not hits, hits[:8]
 

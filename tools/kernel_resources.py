@@ -68,7 +68,7 @@ def kernel_resources(so_path: str, arch: str = "gfx950"):
     return rows
 
 
-PK_SRC1_SWAP = re.compile(r"v_pk_(?:mul|add|fma)_f32\b.*\bop_sel:\[[01],1")
+PK_SRC1_SWAP = re.compile(r"v_pk_(?:mul|add|fma)_f32\b.*\bop_sel:\[[01],1|v_pk_mov_b32\b.*\bop_sel:\[1,0\]")      # low lane <- src1.high; v_pk_mov_b32: low <- src0.high AND high <- src1.low
 
 
 def packed_src1_swaps(so_path: str, arch: str = "gfx950"):

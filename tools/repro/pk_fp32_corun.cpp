@@ -71,7 +71,26 @@ __global__ void enc_k(float* buf, int M, int stride, int n_rot, int hd, const fl
         else if (E == 7) { f32x2 a = {c * x.x, c * x.y}, u = {sn * x.x, -sn * x.y}; asm volatile("" : "+v"(u), "+v"(a)); asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(o) : "v"(a), "v"(u)); /* src1 swapped */ }
         else if (E == 8) { f32x2 c2 = {c, c}, u = {sn * x.x, -sn * x.y}; asm volatile("" : "+v"(u)); asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(o) : "v"(c2), "v"(x), "v"(u)); /* src2 swapped */ }
         else if (E == 9) { f32x2 xs = {x.y, x.x}, c2 = {c, c}, u = {-sn * x.y, sn * x.x}; asm volatile("" : "+v"(u), "+v"(xs)); asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(o) : "v"(xs), "v"(c2), "v"(u)); /* src0 swapped */ }
-        else { f32x2 xs = {x.y, x.x}, c2 = {c, c}, u = {-sn * x.y, sn * x.x}; asm volatile("" : "+v"(u), "+v"(xs)); asm volatile("v_pk_fma_f32 %0, %2, %1, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(o) : "v"(xs), "v"(c2), "v"(u)); /* src1 swapped */ }
+        else if (E == 10) { f32x2 xs = {x.y, x.x}, c2 = {c, c}, u = {-sn * x.y, sn * x.x}; asm volatile("" : "+v"(u), "+v"(xs)); asm volatile("v_pk_fma_f32 %0, %2, %1, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(o) : "v"(xs), "v"(c2), "v"(u)); /* src1 swapped */ }
+        else if (E == 12) { f32x2 s2 = {sn, 7.f}, xs = {x.y, x.x}, u; asm volatile("" : "+v"(xs)); asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel_hi:[1,0]" : "=v"(u) : "v"(s2), "v"(xs)); /* src1 = s2, lo broadcast: u = (xi sn, xr sn) */ o.x = __builtin_fmaf(c, x.x, -u.x); o.y = __builtin_fmaf(c, x.y, u.y); }
+        else if (E == 13) { f32x2 c2 = {c, 7.f}, u = {-sn * x.y, sn * x.x}; asm volatile("" : "+v"(u)); asm volatile("v_pk_fma_f32 %0, %2, %1, %3 op_sel_hi:[1,0,1]" : "=v"(o) : "v"(c2), "v"(x), "v"(u)); /* src1 = c2, lo broadcast */ }
+        else if (E == 14) { f32x2 s2 = {sn, 7.f}, xs = {x.y, x.x}, u; asm volatile("" : "+v"(xs)); asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(u) : "v"(s2), "v"(xs)); /* src0 = s2, lo broadcast */ o.x = __builtin_fmaf(c, x.x, -u.x); o.y = __builtin_fmaf(c, x.y, u.y); }
+        else if (E == 15) { f32x2 sx = {sn * x.x, 7.f}, c2 = {c, c}, xs = {-x.y / (x.x != 0.f ? x.x : 1.f), 1.f}; (void)xs; f32x2 u0 = {0.f, 0.f}; (void)u0;
+                            /* src2 lo broadcast: o = (c x.x + t, c x.y + t) with t = src2.lo; only o.y is the rotation's (t = sn xr); o.x is recomputed scalar */
+                            f32x2 r; asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(c2), "v"(x), "v"(sx)); o.y = r.y; o.x = __builtin_fmaf(c, x.x, -(sn * x.y)); }
+        else if (E == 16 || E == 17 || E == 18) { f32x2 a = {x.x, x.y}, b = {x.x, x.y}, sw; asm volatile("" : "+v"(a), "+v"(b));
+            if (E == 16) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(sw) : "v"(a), "v"(b));       /* (a.lo, b.hi): straight */
+            else if (E == 17) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(sw) : "v"(a), "v"(b));  /* (a.hi, b.hi): src0 crosses */
+            else asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(sw) : "v"(a), "v"(b));               /* (a.lo, b.lo): src1 crosses */
+            const float xr = sw.x == x.x ? x.x : sw.x, xi = E == 16 ? sw.y : x.y;      /* E 17: sw = (xi, xi); E 18: sw = (xr, xr) */
+            const float XR = E == 17 ? x.x : xr, XI = E == 17 ? sw.x : (E == 18 ? x.y : xi), chk = E == 17 ? sw.y - x.y : (E == 18 ? sw.y - x.x : 0.f);      /* chk != 0: the moved lane was wrong */
+            o.x = __builtin_fmaf(c, XR, -(sn * XI)) + chk * 1000.f; o.y = __builtin_fmaf(c, XI, sn * XR); }
+        else if (E == 19) { f32x2 a = {123.f, x.y}, b = {x.x, 456.f}, sw; asm volatile("" : "+v"(a), "+v"(b)); asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(sw) : "v"(a), "v"(b)); /* DISTINCT registers: sw = (a.hi, b.lo) = (xi, xr) */
+                            o.x = __builtin_fmaf(c, sw.y, -(sn * sw.x)); o.y = __builtin_fmaf(c, sw.x, sn * sw.y); }
+        else if (E == 20) { f32x2 s2 = {7.f, sn}, xs = {x.y, x.x}, u; asm volatile("" : "+v"(xs)); asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(u) : "v"(s2), "v"(xs)); /* src1 = s2, HI broadcast: u = (xi sn, xr sn) */ o.x = __builtin_fmaf(c, x.x, -u.x); o.y = __builtin_fmaf(c, x.y, u.y); }
+        else if (E == 21) { f32x2 s2 = {7.f, sn}, xs = {x.y, x.x}, u; asm volatile("" : "+v"(xs)); asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(u) : "v"(s2), "v"(xs)); /* src0 = s2, HI broadcast */ o.x = __builtin_fmaf(c, x.x, -u.x); o.y = __builtin_fmaf(c, x.y, u.y); }
+        else { f32x2 sw; asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]" : "=v"(sw) : "v"(x)); /* sw = (x.hi, x.lo): the only v_pk_mov_b32 form hipcc emits in the library */
+               o.x = __builtin_fmaf(c, sw.y, -(sn * sw.x)); o.y = __builtin_fmaf(c, sw.x, sn * sw.y); }
         *reinterpret_cast<f32x2*>(p) = o;
     }
 }
@@ -131,6 +150,17 @@ int main(int argc, char** argv) {
             case 18: enc_k<8><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
             case 19: enc_k<9><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
             case 20: enc_k<10><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 21: enc_k<11><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 22: enc_k<12><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 23: enc_k<13><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 24: enc_k<14><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 25: enc_k<15><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 26: enc_k<16><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 27: enc_k<17><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 28: enc_k<18><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 29: enc_k<19><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 30: enc_k<20><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
+            case 31: enc_k<21><<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
             default: rot_k<<<dim3(blocks), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st); break;
             }
             check_k<<<dim3(1024), dim3(256), 0, sv>>>(buf, M, stride, n_rot, hd, ct, st, base + it, bad);
@@ -150,9 +180,12 @@ int main(int argc, char** argv) {
             stop.store(true); t.join();
             printf("[%s] alone: %u wrong pairs; next to the MFMA loop: %u wrong pairs\n", vn[variant], w0, w);
         }
-        const char* en[11] = {"v_pk_mul_f32, straight lanes", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[0,0] (src1 swapped)", "v_pk_fma_f32, straight lanes", "v_pk_fma_f32 op_sel_hi:[0,1,1]", "v_pk_fma_f32 neg_lo / neg_hi on src2", "v_pk_add_f32, straight lanes",
-                              "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,0] (src0 swapped)", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (src1 swapped)", "v_pk_fma_f32 op_sel:[0,0,1] op_sel_hi:[1,1,0] (src2 swapped)", "v_pk_fma_f32 op_sel:[1,0,0] op_sel_hi:[0,1,1] (src0 swapped)", "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (src1 swapped)"};
-        for (variant = 10; variant < 21; variant++) {
+        const char* en[22] = {"v_pk_mul_f32, straight lanes", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[0,0] (src1 swapped)", "v_pk_fma_f32, straight lanes", "v_pk_fma_f32 op_sel_hi:[0,1,1]", "v_pk_fma_f32 neg_lo / neg_hi on src2", "v_pk_add_f32, straight lanes",
+                              "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,0] (src0 swapped)", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (src1 swapped)", "v_pk_fma_f32 op_sel:[0,0,1] op_sel_hi:[1,1,0] (src2 swapped)", "v_pk_fma_f32 op_sel:[1,0,0] op_sel_hi:[0,1,1] (src0 swapped)", "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (src1 swapped)", "v_pk_mov_b32 op_sel:[1,0] (lo <- src0.hi, hi <- src1.lo)",
+                              "v_pk_mul_f32 op_sel_hi:[1,0] (src1.lo broadcast)", "v_pk_fma_f32 op_sel_hi:[1,0,1] (src1.lo broadcast)", "v_pk_mul_f32 op_sel_hi:[0,1] (src0.lo broadcast)", "v_pk_fma_f32 op_sel_hi:[1,1,0] (src2.lo broadcast)",
+                              "v_pk_mov_b32 op_sel:[0,1] (straight)", "v_pk_mov_b32 op_sel:[1,1] (lo <- src0.hi)", "v_pk_mov_b32 op_sel:[0,0] (hi <- src1.lo)",
+                              "v_pk_mov_b32 op_sel:[1,0], DISTINCT source registers", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1] (src1.hi broadcast)", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[1,1] (src0.hi broadcast)"};
+        for (variant = (argc > 2 ? atoi(argv[2]) : 10); variant < 32; variant++) {
             const unsigned w0 = victim(70000 + 100 * variant);
             std::atomic<bool> stop{false};
             std::thread t([&] { while (!stop.load()) { for (int k = 0; k < 20; k++) mfma_k<<<dim3(2048), dim3(256), 0, sa>>>(junk, 2000); CK(hipStreamSynchronize(sa)); } });

@@ -728,7 +728,11 @@ B16_PHASE void ph_attn(int cw_, int lane, int l_, int q_) {
     }
     B16_GUARD(1);
     *reinterpret_cast<float2*>(po + cw * 128 + lane * 2) = o;
+#ifdef VOX_PK_AS_COMPILED
     if (lane == 0) { ml[2 * cw] = m_run; ml[2 * cw + 1] = l_run; }
+#else
+    if (lane == 0) { volatile float* mlv = ml; mlv[2 * cw] = m_run; mlv[2 * cw + 1] = l_run; }      // (two 4-byte stores: as one 8-byte store hipcc swapped the pair with v_pk_mov_b32 op_sel:[1,0] -- vox_kernels.h, VOX_NO_PK_F32)
+#endif
     cs.tbarrier(team, 6u * ((unsigned)(NG * l + q) + 1u));
     if (tw == 0) {      // combine the team's six partials (fixed order), normalise, publish head h's output of sequence msq as wo's A fragments (hi + lo)
         float M = -INFINITY;

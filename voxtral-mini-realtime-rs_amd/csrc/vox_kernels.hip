@@ -2862,7 +2862,7 @@ __global__ __launch_bounds__(256) void rms_norm_row_kernel(const float* __restri
     }
 }
 // x += sum of KS split-K partial planes (fixed order), written back; RMSNorm of the new row -> out.  One wave per row, dim <= 4096.
-__global__ __launch_bounds__(256) void rms_norm_sumk_kernel(float* __restrict__ x, int x_stride, int rows, int dim, const float* __restrict__ part, size_t part_stride, int ks,
+__global__ __launch_bounds__(256) VOX_NO_PK_F32 void rms_norm_sumk_kernel(float* __restrict__ x, int x_stride, int rows, int dim, const float* __restrict__ part, size_t part_stride, int ks,
                                                             const float* __restrict__ gamma, float eps, float* __restrict__ out, int out_stride) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
