@@ -183,6 +183,8 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
         plans = {i: (pkg.chunk_plan(clips[i].size, cc) if pkg.needs_chunking(clips[i].size, cc) else [(0, clips[i].size)]) for i in clips}
 
     # sessions > 1: the rank's share as `sessions` concurrent sessions on its GPU (shard.SessionPool: contexts + model replicas + host threads; batched engines off)
+    if sessions > 1 and len(parts[rank]) < sessions * shard.SessionPool.MIN_UNITS_PER_SESSION:
+        sessions = 1      # a share this small runs as one session anyway (SessionPool.MIN_UNITS_PER_SESSION): no replica is made for it
     pool = shard.SessionPool(pkg, ctx, model, sessions) if sessions > 1 else None
     runner = pool if pool is not None else model
 
