@@ -182,11 +182,13 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
         cc = pkg.ChunkConfig.voxtral().with_max_frames(chunk_frames)
         plans = {i: (pkg.chunk_plan(clips[i].size, cc) if pkg.needs_chunking(clips[i].size, cc) else [(0, clips[i].size)]) for i in clips}
 
-    # sessions > 1: the rank's share as `sessions` concurrent sessions on its GPU (shard.SessionPool: contexts + model replicas + host threads; batched engines off)
+    # sessions > 1: the rank's share as `sessions` concurrent sessions on its GPU -- vox_model_set_sessions: the library's own hidden contexts + model replicas + threads
+    # behind the SAME vox_transcribe_batch call (shard.SessionPool is the host-threads twin of it)
     if sessions > 1 and len(parts[rank]) < sessions * shard.SessionPool.MIN_UNITS_PER_SESSION:
-        sessions = 1      # a share this small runs as one session anyway (SessionPool.MIN_UNITS_PER_SESSION): no replica is made for it
-    pool = shard.SessionPool(pkg, ctx, model, sessions) if sessions > 1 else None
-    runner = pool if pool is not None else model
+        sessions = 1      # a share this small runs as one session anyway (128 units per session): no replica is made for it
+    if sessions > 1:
+        model.set_sessions(sessions)
+    runner = model
 
     def batch_work(idx_list):
         if plans is None:
@@ -217,8 +219,8 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
     except Exception as e:
         ok = 0; err = str(e)
     ctx.synchronize(); dt = time.perf_counter() - t0
-    if pool is not None:
-        pool.close()
+    if sessions > 1:
+        model.set_sessions(1)
     eng_corpus = model.set_batch_engine()[1] - eng_n0      # rank 0's engine launches inside the timed region (steps with <= 2 active slot groups: one launch each)
     if world > 1:
         import torch
@@ -291,8 +293,8 @@ def main():
     ap.add_argument("--fleurs-batch", type=int, default=0, help="clips per vox_transcribe_batch call of the FLEURS-like extra; 0 (default) = a rank's whole share in ONE call (continuous batching over slots, round 5); 64 = the round-4 length-bucketed lock-step batches")
     ap.add_argument("--cli-chunk-frames", type=int, default=1200, help="also run the FLEURS-like corpus on the reference CLI's pipeline: files split into chunks of this many mel frames "
                     "(bin/transcribe.rs:55-57 default 1200), every chunk a unit of the batch (`fleurs_like_cli`); 0 = skip")
-    ap.add_argument("--corpus-sessions", type=int, default=2, help="also run the FLEURS-like corpus with this many concurrent sessions per GPU (shard.SessionPool: contexts + model replicas + "
-                    "host threads; `fleurs_like_sessions`); <= 1 = skip")
+    ap.add_argument("--corpus-sessions", type=int, default=2, help="also run the FLEURS-like corpus with this many concurrent sessions per GPU (vox_model_set_sessions: hidden contexts + model replicas + "
+                    "library threads behind the same vox_transcribe_batch call; `fleurs_like_sessions`); <= 1 = skip")
     ap.add_argument("--gemv-iters", type=int, default=260)
     args = ap.parse_args()
 

@@ -332,6 +332,41 @@ def test_transcribe_batch_ex_chunks_share_their_files_peak(pkg, ctx, tiny):
     print(f"vox_transcribe_batch_ex: {len(raw)} chunk units of {len(files)} files; device group peaks == host-normalised files; {n_same}/{len(raw)} units identical to the serial path end to end")
 
 
+def test_model_set_sessions_splits_large_calls_and_keeps_every_units_ids(pkg, ctx, tiny):
+    """vox_model_set_sessions(m, 2): a batch call with >= 128 units per session runs as two concurrent sessions inside the library (hidden context + replica + library
+    thread); ids, their order and n_ids per unit equal the one-session call's -- un-chunked, with normalisation groups (a group's units stay in one session: its peak is a
+    device reduction per session) and with already-normalised units; smaller calls stay on one session; sessions = 1 frees the replicas; bad arguments fail."""
+    m, o, _ = tiny
+    t = pkg.TimeEmbedding(m.config.dec_dim).embed(6.0)
+    rng = np.random.default_rng(3)
+    clips = [pkg.synth.synth_audio(0.6 + 0.05 * (i % 23), seed=7000 + i) * float(0.2 + 0.8 * rng.random()) for i in range(300)]
+    grp = [i // 3 for i in range(300)]      # 100 "files" of three units
+    mixed = [g if g % 2 else -1 for g in grp]
+    ctx.set_shared(True)      # (the reference runs under the same rules the split sessions run under: launch chains, table costs)
+    try:
+        ref = m.transcribe_batch(clips, t); ref_g = m.transcribe_batch(clips, t, norm_group=grp); ref_m = m.transcribe_batch(clips, t, norm_group=mixed)
+    finally:
+        ctx.set_shared(False)
+    m.set_sessions(2)
+    try:
+        for rep in range(2):
+            got = m.transcribe_batch(clips, t)
+            assert len(got) == 300 and all(np.array_equal(a, b) for a, b in zip(ref, got)), rep
+        tm = m.timings(); assert tm["decode_tokens"] == sum(len(g) for g in got) and tm["total_ms"] > 0
+        assert all(np.array_equal(a, b) for a, b in zip(ref_g, m.transcribe_batch(clips, t, norm_group=grp)))
+        assert all(np.array_equal(a, b) for a, b in zip(ref_m, m.transcribe_batch(clips, t, norm_group=mixed)))
+        small = m.transcribe_batch(clips[:40], t)      # 40 units: one session
+        assert all(np.array_equal(a, b) for a, b in zip(ref[:40], small))
+        m.set_sessions(3); got3 = m.transcribe_batch(clips, t)      # 300 units / 128 = 2 sessions used of the 3
+        assert all(np.array_equal(a, b) for a, b in zip(ref, got3))
+    finally:
+        m.set_sessions(1)
+    assert all(np.array_equal(a, b) for a, b in zip(ref[:20], m.transcribe_batch(clips[:20], t)))      # the replicas are gone, the model works as before
+    for bad in (0, 5):
+        with pytest.raises(pkg.VoxError):
+            m.set_sessions(bad)
+
+
 def test_two_contexts_two_threads_and_model_replicate(pkg, ctx, tiny):
     """The header promises "a handle is not thread-safe, distinct contexts are independent" (include/voxtral_hip.h:15-16) and SURVEY.md section 8(e) describes the
     in-process multi-GPU shape -- one host thread + one vox_ctx + one model replica per GPU (what a Rust `voxtral-transcribe`, bin/transcribe.rs:60-128, would do).

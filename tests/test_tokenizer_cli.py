@@ -92,7 +92,7 @@ def test_cli_end_to_end(pkg, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_batch_makes_chunks_units_of_work_and_keeps_the_serial_lines(pkg, tmp_path, monkeypatch):
+def test_cli_batch_makes_chunks_units_of_work_and_keeps_the_serial_lines(pkg, tmp_path):
     """with the reference's default --max-mel-frames 1200 every file longer than 12 s is split (bin/transcribe.rs:55-57,210-226); `--batch` must hand
     ALL chunks of all files to vox_transcribe_batch_ex as units (the file peak-normalised once, :207) and print exactly the one-by-one path's lines -- here 30 s, 25 s and
     13 s files among short ones, more units than one 16-row group (continuous batching), and with --batch 8 a file's chunks split over several calls."""
@@ -122,8 +122,7 @@ def test_cli_batch_makes_chunks_units_of_work_and_keeps_the_serial_lines(pkg, tm
     rc3, out3, err3 = run(["--batch", "8"])
     assert rc3 == 0 and out3 == out1 and err3.count("batch of ") == (n_units + 7) // 8
     # two concurrent sessions on the GPU (shard.SessionPool: a second context + model replica + host thread): the same lines
-    monkeypatch.setattr(pkg.shard.SessionPool, "MIN_UNITS_PER_SESSION", 8)      # (default 128: a share this small would stay on one session)
-    rc4, out4, err4 = run(["--batch", "1024", "--sessions-per-gpu", "2"])
+    rc4, out4, err4 = run(["--batch", "1024", "--sessions-per-gpu", "2"])      # (28 units: the call itself stays on one session -- 128 units per session -- the replica is made and freed)
     assert rc4 == 0 and out4 == out1 and "2 sessions on this GPU" in err4 and "chunk " not in err4
 
 

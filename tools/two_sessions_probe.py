@@ -48,6 +48,22 @@ def many(concurrent=True):
         for i, o in zip(parts[k], res[k]): outs[i] = o
     return dt, outs
 
+if os.environ.get("PROBE_C_SESSIONS"):      # the library's own sessions (vox_model_set_sessions: hidden contexts + replicas + library threads) instead of this script's threads
+    def many(concurrent=True):
+        if not concurrent:
+            m.set_sessions(1); ctx.set_shared(True)
+            try:
+                res = [m.transcribe_batch([clips[i] for i in parts[k]], t) for k in range(S)]
+            finally:
+                ctx.set_shared(False)
+            outs = [None] * n
+            for k in range(S):
+                for i, o in zip(parts[k], res[k]): outs[i] = o
+            return 0.0, outs
+        m.set_sessions(S)
+        ctx.synchronize(); t0 = time.perf_counter(); outs = m.transcribe_batch(clips, t); ctx.synchronize(); dt = time.perf_counter() - t0
+        m.set_sessions(1)
+        return dt, outs
 one(); many()      # warm-up: workspaces, graphs' kernels, planner calibration
 for rep in range(2):
     d1, o1 = one(); dS, oS = many()

@@ -106,6 +106,7 @@ SIGNATURES = {
     "vox_model_set_batch_engine": (i32, [vp, i32, P(i32), P(C.c_uint64)]),
     "vox_model_arena_finalize": (i32, [vp]),
     "vox_model_replicate": (i32, [vp, vp, P(vp)]),
+    "vox_model_set_sessions": (i32, [vp, i32]),
     "vox_generate_step_with_cache": (i32, [vp, vp, i32, vp, vp, vp]),
     "vox_encode_audio": (i32, [vp, vp, i32, vp, i32, P(i32), i32]),
     "vox_transcribe_streaming": (i32, [vp, vp, i32, vp, vp, i32, P(i32), vp, i32]),

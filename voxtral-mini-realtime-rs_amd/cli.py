@@ -203,7 +203,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=1, help="extension: every file is split into its --max-mel-frames chunks and up to N chunks go into one "
                     "vox_transcribe_batch_ex call (continuous batching; same ids per chunk and the same lines as one by one; output order unchanged)")
     ap.add_argument("--sessions-per-gpu", type=int, default=1, help="extension (with --batch, Q4 GGUF): this many concurrent sessions on every GPU (own context + model replica + "
-                    "host thread each, shard.SessionPool): one session's launch-bound decode steps leave gaps a second session fills (647 FLEURS-like clips: 3.8 s against 4.5 s); same lines")
+                    "library thread each: vox_model_set_sessions): one session's launch-bound decode steps leave gaps a second session fills (647 FLEURS-like clips: 3.8 s against 4.5 s; "
+                    "calls with fewer than 128 units per session stay on one); same lines")
     a = ap.parse_args(argv)
     if a.audio_list and a.audio:
         ap.error("--audio-list conflicts with --audio")
@@ -268,17 +269,15 @@ def main(argv=None):
         # every file -> its chunks (transcribe.rs:210-226); ALL units of this rank's share go to vox_transcribe_batch_ex in calls of <= --batch units (continuous batching
         # over decode slots); a file's line = its chunk texts joined by " " (:261-275).  Files with a failed unit fall back to the one-by-one path below.
         units = unit_table(pkg, paths, chunk_cfg)
-        pool = None
-        if a.sessions_per_gpu > 1 and a.gguf:
-            import importlib
-            pool = importlib.import_module(pkg.__name__ + ".shard").SessionPool(pkg, ctx, model, a.sessions_per_gpu)
+        if a.sessions_per_gpu > 1 and a.gguf:      # vox_model_set_sessions: calls with >= 128 units per session run as that many concurrent sessions on this GPU
+            model.set_sessions(a.sessions_per_gpu)
             log(f"{a.sessions_per_gpu} sessions on this GPU (model replicated device to device)")
-        runner = UnitRunner(pkg, ctx, pool if pool is not None else model, tokenizer, paths, t_embed)
+        runner = UnitRunner(pkg, ctx, model, tokenizer, paths, t_embed)
         try:
             unit_texts = sharded_units(pkg, units, runner, a.batch, rank, world) if units else []
         finally:
-            if pool is not None:
-                pool.close()
+            if a.sessions_per_gpu > 1 and a.gguf:
+                model.set_sessions(1)
         if unit_texts is not None:      # (rank 0, or the only rank)
             texts = join_units(len(paths), units, unit_texts)
     def one(i):

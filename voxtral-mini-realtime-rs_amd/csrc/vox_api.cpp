@@ -24,6 +24,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 using namespace vox;
@@ -754,6 +755,7 @@ static bool cache_alive(const vox_cache* k, uint64_t gen) { std::lock_guard<std:
 struct TensorMeta { std::vector<uint64_t> shape; int dtype = 0; uint64_t nbytes = 0; };
 struct vox_model {
     vox_ctx* ctx = nullptr; vox_model_cfg cfg{};
+    std::vector<vox_model*> twins;      // vox_model_set_sessions: replicas on hidden contexts of the same device (owned: freed with the model)
     std::map<std::string, TensorMeta> manifest; bool is_q4 = false;      // name -> shape / dtype of every tensor the loader looked up (vox_model_replicate lays a second arena out from it, without the file)
     uint8_t* arena = nullptr; uint64_t arena_bytes = 0, arena_primary_bytes = 0;      // [0, primary): everything parsed from the file; [primary, bytes): copies derived from it on the GPU
     std::vector<Q4W*> tiled;                                 // Q4 linears that own a tile-ordered copy in the derived part
@@ -1197,6 +1199,8 @@ static void graphs_destroy(vox_model* m) {
 }
 static void model_release(vox_model* m) {
     if (!m) return;
+    for (vox_model* t : m->twins) { vox_ctx* tc = t->ctx; model_release(t); (void)vox_ctx_destroy(tc); }
+    m->twins.clear();
     (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream);
     graphs_destroy(m);
     if (m->cache) { cache_unregister(m->cache); (void)hipFree(m->cache->k); (void)hipFree(m->cache->v); delete m->cache; }
@@ -2887,9 +2891,76 @@ extern "C" int32_t vox_transcribe_batch(vox_model* m, int32_t n, const float* co
 // norm_group: the reference's CLI peak-normalises the FILE once (bin/transcribe.rs:207) and then splits it into chunks (:210-226); every chunk is an independent unit
 // of work from there on (:231-265).  Units that name the same group >= 0 share ONE peak scale = 0.95 / max|x| over all of them (chunks tile their file, so that is the
 // file's peak); group < 0: the unit is used as handed over (already normalised by the caller); norm_group == NULL: every unit normalises itself (un-chunked e2e-bench).
+static int32_t transcribe_batch_one_session(vox_model* m, int32_t n, const float* const* samples_in, const size_t* n_samples, const int32_t* norm_group, const float* t_embed,
+                                            int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind_in);
+// vox_model_set_sessions(m, S): batch calls with enough units run as S concurrent sessions on the model's GPU -- the calling thread on the model's own context, S - 1
+// library threads on hidden contexts with replicas of the model (vox_model_replicate, device to device) -- see the header.  Units of one normalisation group stay in one
+// session (the group's peak is reduced over the units of ONE session); LPT by sample count; every context involved is marked shared for the duration of the call.
+static const int kMinUnitsPerSession = 128;      // below: one session (a small share is bound by its longest clip; 81 clips x0.82, 162 x0.86, 324 x1.16, 647 x1.20 with two sessions)
+extern "C" int32_t vox_model_set_sessions(vox_model* m, int32_t sessions) {
+    ARGCHK(m, "null model"); ARGCHK(sessions >= 1 && sessions <= 4, "sessions %d out of range (1..4)", sessions);
+    if (sessions > 1 && (!m->is_q4 || m->manifest.empty())) return fail(VOX_ERR_UNSUPPORTED, "vox_model_set_sessions: Q4 (GGUF) models only");
+    while ((int)m->twins.size() > sessions - 1) { vox_model* t = m->twins.back(); m->twins.pop_back(); vox_ctx* tc = t->ctx; model_release(t); (void)vox_ctx_destroy(tc); }
+    while ((int)m->twins.size() < sessions - 1) {
+        vox_ctx* tc = nullptr; VOXCHK(vox_ctx_create(m->ctx->device, &tc)); tc->shared = true;
+        vox_model* t = nullptr; const int32_t r = vox_model_replicate(m, tc, &t);
+        if (r != VOX_OK) { std::string e = g_err; (void)vox_ctx_destroy(tc); return fail(r, "%s", e.c_str()); }
+        m->twins.push_back(t);
+    }
+    return ctx_bind(m->ctx);
+}
+static int32_t transcribe_batch_sessions(vox_model* m, int S, int32_t n, const float* const* samples, const size_t* n_samples, const int32_t* norm_group, const float* t_embed,
+                                         int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind) {
+    const double t0 = now_ms();
+    // groups of units (a normalisation group, or a unit on its own), heaviest first onto the least loaded session
+    std::vector<std::vector<int>> members; { std::map<int32_t, int> by_id;
+        for (int i = 0; i < n; i++) { if (norm_group && norm_group[i] >= 0) { auto it = by_id.find(norm_group[i]); if (it == by_id.end()) { by_id[norm_group[i]] = (int)members.size(); members.emplace_back(); it = by_id.find(norm_group[i]); } members[it->second].push_back(i); }
+                                      else members.push_back({i}); } }
+    std::vector<double> w(members.size(), 0.0); for (size_t g = 0; g < members.size(); g++) for (int i : members[g]) w[g] += (double)n_samples[i];
+    std::vector<int> gi(members.size()); for (size_t g = 0; g < gi.size(); g++) gi[g] = (int)g;
+    std::stable_sort(gi.begin(), gi.end(), [&](int a, int b) { return w[a] > w[b]; });
+    std::vector<std::vector<int>> part(S); std::vector<double> load(S, 0.0);
+    for (int g : gi) { int k = 0; for (int j = 1; j < S; j++) if (load[j] < load[k]) k = j; load[k] += w[g]; for (int i : members[g]) part[k].push_back(i); }
+    for (auto& p : part) std::sort(p.begin(), p.end());
+    struct Sub { std::vector<const float*> s; std::vector<size_t> ns; std::vector<int32_t> grp; std::vector<int32_t*> out; std::vector<int32_t> caps, nid; int32_t rc = VOX_OK; std::string err; vox_timings tm{}; };
+    std::vector<Sub> sub(S);
+    for (int k = 0; k < S; k++) for (int i : part[k]) { Sub& u = sub[k]; u.s.push_back(samples[i]); u.ns.push_back(n_samples[i]); if (norm_group) u.grp.push_back(norm_group[i]); u.out.push_back(out_ids[i]); u.caps.push_back(caps[i]); u.nid.push_back(0); }
+    auto run = [&](int k) {
+        Sub& u = sub[k]; vox_model* mk = k == 0 ? m : m->twins[(size_t)k - 1];
+        if (u.s.empty()) return;
+        u.rc = transcribe_batch_one_session(mk, (int32_t)u.s.size(), u.s.data(), u.ns.data(), norm_group ? u.grp.data() : nullptr, t_embed, u.out.data(), u.caps.data(), u.nid.data(), mem_kind);
+        if (u.rc != VOX_OK) u.err = g_err;      // (thread-local: read on the thread that failed)
+        u.tm = mk->timings;
+    };
+    const bool was_shared = m->ctx->shared; m->ctx->shared = true;      // (the twins' contexts always are)
+    std::vector<std::thread> th;
+    for (int k = 1; k < S; k++) th.emplace_back(run, k);
+    run(0);
+    for (auto& t : th) t.join();
+    m->ctx->shared = was_shared;
+    (void)ctx_bind(m->ctx);
+    for (int k = 0; k < S; k++) if (sub[k].rc != VOX_OK) return fail(sub[k].rc, "session %d of %d: %s", k, S, sub[k].err.c_str());
+    int total = 0;
+    for (int k = 0; k < S; k++) for (size_t j = 0; j < part[k].size(); j++) { n_ids[part[k][j]] = sub[k].nid[j]; total += sub[k].nid[j]; }
+    // stage times: the longest session's (they overlap); tokens and replays: the sum; total: this call's wall time
+    vox_timings tm = sub[0].tm;
+    for (int k = 1; k < S; k++) { tm.preprocess_ms = std::max(tm.preprocess_ms, sub[k].tm.preprocess_ms); tm.encode_ms = std::max(tm.encode_ms, sub[k].tm.encode_ms); tm.decode_ms = std::max(tm.decode_ms, sub[k].tm.decode_ms);
+                                  tm.graph_replays += sub[k].tm.graph_replays; }
+    tm.decode_tokens = total; tm.total_ms = now_ms() - t0; m->timings = tm;
+    return VOX_OK;
+}
 extern "C" int32_t vox_transcribe_batch_ex(vox_model* m, int32_t n, const float* const* samples_in, const size_t* n_samples, const int32_t* norm_group, const float* t_embed,
                                            int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind_in) {
     ARGCHK(m && samples_in && n_samples && t_embed && out_ids && caps && n_ids, "null argument"); ARGCHK(n > 0 && n <= 4096, "batch size %d out of range (1..4096)", n);
+    if (!m->twins.empty() && !knob_str("VOX_BATCH_ONE_SESSION")) {
+        const int S = std::min((int)m->twins.size() + 1, n / kMinUnitsPerSession);
+        if (S > 1) { for (int i = 0; i < n; i++) ARGCHK(samples_in[i] && n_samples[i] > 0, "empty audio in batch slot %d", i);
+                     return transcribe_batch_sessions(m, S, n, samples_in, n_samples, norm_group, t_embed, out_ids, caps, n_ids, mem_kind_in); }
+    }
+    return transcribe_batch_one_session(m, n, samples_in, n_samples, norm_group, t_embed, out_ids, caps, n_ids, mem_kind_in);
+}
+static int32_t transcribe_batch_one_session(vox_model* m, int32_t n, const float* const* samples_in, const size_t* n_samples, const int32_t* norm_group, const float* t_embed,
+                                            int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind_in) {
     const float* const* samples = samples_in; int32_t mem_kind = mem_kind_in;
     DevBuf b_all, b_gmax, b_ugrp, b_uscale;      // (declared before everything that launches on them; the impls drain the streams before they return)
     std::vector<const float*> dev_s; std::vector<const float*> scale_of;      // per unit (caller's order): device samples, device scale cell

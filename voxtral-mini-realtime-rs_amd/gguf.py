@@ -462,6 +462,11 @@ class Q4VoxtralModel:
         h = C.c_void_p(); check(lib().vox_model_replicate(self.h, dst_ctx.h, C.byref(h)))
         return type(self)(dst_ctx, h)
 
+    def set_sessions(self, sessions: int):
+        """vox_model_set_sessions: batch calls with >= 128 units per session run as `sessions` concurrent sessions on this model's GPU (hidden contexts + replicas +
+        library threads); 1 = off (replicas freed).  Same ids per unit."""
+        check(lib().vox_model_set_sessions(self.h, int(sessions)))
+
     def arena_finalize(self):
         """Receiver side of the multi-GPU start-up: the bytes of arena() have been written (e.g. by an RCCL broadcast); rebuild the derived copies on this GPU."""
         check(lib().vox_model_arena_finalize(self.h))
