@@ -2933,9 +2933,10 @@ static int32_t transcribe_batch_sessions(vox_model* m, int S, int32_t n, const f
         u.tm = mk->timings;
     };
     const bool was_shared = m->ctx->shared; m->ctx->shared = true;      // (the twins' contexts always are)
-    std::vector<std::thread> th;
-    for (int k = 1; k < S; k++) th.emplace_back(run, k);
+    std::vector<std::thread> th; std::vector<int> inline_k;      // (a session whose thread cannot be created runs on the calling thread, after its own)
+    for (int k = 1; k < S; k++) { try { th.emplace_back(run, k); } catch (...) { inline_k.push_back(k); } }
     run(0);
+    for (int k : inline_k) run(k);
     for (auto& t : th) t.join();
     m->ctx->shared = was_shared;
     (void)ctx_bind(m->ctx);
