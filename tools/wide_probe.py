@@ -15,7 +15,7 @@ secs = float(sys.argv[3]) if len(sys.argv) > 3 else 8.0
 clips = [pkg.synth.synth_audio(secs, seed=100 + i) for i in range(n)]
 os.environ["VOX_BATCH_SLOT_GROUPS"] = str(G); os.environ["VOX_BATCH_VERBOSE"] = "1"
 res = {}
-for tag, env in (("wide", {}), ("chains", {"VOX_BATCH_NO_WIDE": "1"})):
+for tag, env in (("wide", {"VOX_BATCH_NO_WIDE_SPLIT": "1"}), ("split2x2", {}), ("chains", {"VOX_BATCH_NO_WIDE": "1"})):      # one 4-group wide chain / two 2-group wide chains on two streams (the default at four groups) / four 16-row launch chains
     for k, v in env.items():
         os.environ[k] = v
     m.transcribe_batch(clips, t)
@@ -24,6 +24,7 @@ for tag, env in (("wide", {}), ("chains", {"VOX_BATCH_NO_WIDE": "1"})):
     print(f"{tag:7s} G={G} {n} clips: {dt * 1e3:.1f} ms, decode {tm['decode_ms']:.1f} ms, replays {tm['graph_replays']}, {tm['decode_ms'] / max(tm['graph_replays'], 1):.3f} ms per step (prefill included)", flush=True)
     for k in env:
         del os.environ[k]
-same = sum(int(len(a) == len(b) and (a == b).all()) for a, b in zip(res["wide"], res["chains"]))
-print(f"ids identical: {same}/{n}")
+for other in ("split2x2", "chains"):
+    same = sum(int(len(a) == len(b) and (a == b).all()) for a, b in zip(res["wide"], res[other]))
+    print(f"ids identical, wide vs {other}: {same}/{n}")
 m.close(); ctx.close()

@@ -2516,7 +2516,9 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     const bool use_eng = allow_engine && !cx->shared && !jobs.empty() && !knob_str("VOX_BATCH_CONT_NO_ENGINE") && engb_prepare(m, 2);
     // step costs: the table above, corrected by what this context has measured -- a form seen before costs what it cost (clock, a shared GPU, another geometry), a form not
     // seen yet the table's value times the mean measured / table ratio of the forms that were.  VOX_BATCH_NO_CALIB=1: the table alone.
-    double step_cost[5]; const double* base_cost = use_eng ? kStepMsEng : kStepMs; const bool calib = !knob_str("VOX_BATCH_NO_CALIB");
+    double base_tab[5]; for (int g2 = 0; g2 < 5; g2++) base_tab[g2] = (use_eng ? kStepMsEng : kStepMs)[g2];
+    if (!cx->shared && !knob_str("VOX_BATCH_NO_WIDE_SPLIT")) base_tab[4] = 2.95;      // four groups as two two-group wide chains on two streams (below): 3.12 -> 2.92 ms net of the prefill
+    double step_cost[5]; const double* base_cost = base_tab; const bool calib = !knob_str("VOX_BATCH_NO_CALIB");
     {
         const double* meas = cx->step_ms_meas[use_eng ? 0 : 1]; double ratio = 0.0; int nr = 0;
         for (int g2 = 1; g2 <= 4; g2++) if (calib && meas[g2] > 0.0) { ratio += meas[g2] / base_cost[g2]; nr++; }
@@ -2668,23 +2670,32 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             for (int l = 1; l < c.dec_layers && wide_ok; l++) { const DecLayer& L = m->dec[l]; const DecLayer& L0 = m->dec[0];
                 if (L.wqkv.w.N != L0.wqkv.w.N || L.wqkv.w.K != L0.wqkv.w.K || L.w13.w.N != L0.w13.w.N || L.w2.w.K != L0.w2.w.K || !L.wqkv.w.qt || !L.wo.w.qt || !L.w13.w.qt || !L.w2.w.qt || L.wqkv.bias || L.wo.bias || L.w13.bias || L.w2.bias) wide_ok = false; }
         }
+        // A four-group step as TWO two-group wide chains on two streams instead of one four-group chain: a third of a wide step is dependency gaps between its ~236 launches
+        // (profiles/r06_corpus_sessions.txt), and the two chains fill each other's -- every weight is streamed twice, which a step at 0.7 TB/s can afford: 64-slot step
+        // 3.49 -> 3.29 ms (prefill included), corpus 4.54 -> 4.37 s, same ids (profiles/r06_wide_split.txt).  NOT on a shared GPU (vox_ctx_set_shared / sessions): there the
+        // other session already fills the gaps and four concurrent chains only contend (two sessions: 3.80 s without, 4.46 s with).  VOX_BATCH_NO_WIDE_SPLIT=1: one chain.
+        const bool wide_split = wide_ok && G >= 4 && wide_min <= 4 && !cx->shared && !knob_str("VOX_BATCH_NO_WIDE_SPLIT");
+        if (wide_split) { for (int mtw = 2; mtw <= 2; mtw++) { const struct { const Q4W* w; int epi; } ops[4] = {{&m->dec[0].wqkv.w, EPI_ROPE_KV}, {&m->dec[0].wo.w, EPI_RESID_XF}, {&m->dec[0].w13.w, EPI_SWIGLU_XF}, {&m->dec[0].w2.w, EPI_RESID_XF}};
+            for (auto& o : ops) { WidePlan pl; if (q4_wide_plan(*o.w, mtw, o.epi, &pl)) planes_bytes = std::max(planes_bytes, q4_wide_planes_bytes(*o.w, mtw, pl)); } } }
         DevBuf b_planes;
-        if (wide_ok) HIPCHK(b_planes.alloc_pooled(cx, planes_bytes));
-        auto wide_chain = [&](int mtw, hipStream_t sg) -> int32_t {
-            uint16_t* xf1 = b_xf1.as<uint16_t>(); uint16_t* xf2 = b_xf2.as<uint16_t>(); uint16_t* xf3 = b_xf3.as<uint16_t>(); float* ssq = b_ssq.as<float>();
-            float* hg = b_h.as<float>(); float* qg = b_qkv.as<float>();
+        if (wide_ok) HIPCHK(b_planes.alloc_pooled(cx, planes_bytes * (wide_split ? 2 : 1)));
+        auto wide_chain = [&](int mtw, hipStream_t sg, int g0 = 0, int chain = 0) -> int32_t {      // groups g0 .. g0 + mtw - 1; `chain`: which half of the planes scratch
+            uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)g0 * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)g0 * (xf_bytes(QD) / 2); uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)g0 * (xf_bytes(F) / 2);
+            float* ssq = b_ssq.as<float>() + (size_t)g0 * parts_D * 16;
+            float* hg = b_h.as<float>() + (size_t)g0 * 16 * D; float* qg = b_qkv.as<float>() + (size_t)g0 * 16 * W;
+            const int* d_pos_g = d_pos + 16 * g0; const int* d_kvrow_g = d_kvrow + 16 * g0;
             auto base = [&](const Q4W& w, const uint16_t* xin, int K) {
                 GemmParams g{}; g.w = w; g.xf = (const uint4*)xin; g.xf_gstride = (long)(xf_bytes(K) / 16); g.M = 16 * mtw; g.wide_mt = mtw;
-                g.kz_scratch = b_planes.as<float>(); g.kz_scratch_bytes = planes_bytes; g.norm_eps = c.norm_eps; return g;
+                g.kz_scratch = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(b_planes.p) + (size_t)chain * planes_bytes); g.kz_scratch_bytes = planes_bytes; g.norm_eps = c.norm_eps; return g;
             };
             for (int l = 0; l < c.dec_layers; l++) {
                 const DecLayer& L = m->dec[l];
                 float* kl = b_k.as<float>() + (size_t)l * layer_stride; float* vl = b_v.as<float>() + (size_t)l * layer_stride;
                 { GemmParams g = base(L.wqkv.w, xf1, D); g.out = qg; g.out_stride = W; g.ssq_part = ssq; g.ssq_part_gstride = (long)parts_D * 16; g.n_part = l == 0 ? 1 : parts_D;
-                  g.pos = d_pos; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd; g.kv_row = d_kvrow;
+                  g.pos = d_pos_g; g.rope_cos = m->dec_cos; g.rope_sin = m->dec_sin; g.hd = hd; g.n_q = QD; g.n_kv = KV; g.kc = kl; g.vc = vl; g.kv_seq_stride = (long)seq_stride; g.kv_head_stride = max_seq * hd; g.kv_row = d_kvrow_g;
                   HIPCHK(launch_q4_wide(g, EPI_ROPE_KV, sg)); }
-                AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = b_att.as<float>(); ap.n_heads = H; ap.n_kv_heads = KV;
-                ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride; ap.kv_row = d_kvrow;
+                AttnParams ap{}; ap.q = qg; ap.k = kl; ap.v = vl; ap.kv_row_stride = hd; ap.kv_head_stride = max_seq * hd; ap.out = b_att.as<float>() + (size_t)g0 * 16 * QD; ap.n_heads = H; ap.n_kv_heads = KV;
+                ap.offset = 0; ap.window = c.dec_window; ap.pos_ptr = d_pos_g; ap.M = 1; ap.pos_per_seq = 1; ap.q_seq_stride = W; ap.out_seq_stride = QD; ap.kv_seq_stride = (long)seq_stride; ap.kv_row = d_kvrow_g;
                 ap.out_xf = xf2; ap.out_xf_gstride = (long)(xf_bytes(QD) / 2); ap.prefer_gqa = 1; ap.no_xcd_remap = knob_str("VOX_ATTN_NO_XCD") != nullptr; ap.spec_rows = 0;
                 HIPCHK(launch_attn_decode(ap, hd, max_seq, sg, 16 * mtw));
                 { GemmParams g = base(L.wo.w, xf2, QD); g.out = hg; g.out_stride = D; g.resid = hg; g.resid_stride = D;
@@ -2696,7 +2707,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
                   g.xf_out = xf1; g.xf_out_gstride = (long)(xf_bytes(D) / 2); g.xf_w = l + 1 < c.dec_layers ? m->dec[l + 1].attn_norm : m->dec_norm; g.xf_w2 = nullptr; g.ssq_out = ssq; g.ssq_out_gstride = (long)parts_D * 16;
                   HIPCHK(launch_q4_wide(g, EPI_RESID_XF, sg)); }
             }
-            { GemmParams g = base(m->tok.w, xf1, D); g.out = b_logits.as<float>(); g.out_stride = V; g.ssq_part = ssq; g.ssq_part_gstride = (long)parts_D * 16; g.n_part = parts_D;
+            { GemmParams g = base(m->tok.w, xf1, D); g.out = b_logits.as<float>() + (size_t)g0 * 16 * V; g.out_stride = V; g.ssq_part = ssq; g.ssq_part_gstride = (long)parts_D * 16; g.n_part = parts_D;
               HIPCHK(launch_q4_wide(g, EPI_STORE, sg)); }
             return VOX_OK;
         };
@@ -2740,6 +2751,15 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             }
             if (wide_ok && n_act >= wide_min) {      // (steps with one group, or two when the engine serves them, never get here)
                 bool prefix = true; for (int gi = 0; gi < n_act; gi++) if (!((active >> gi) & 1u)) prefix = false;
+                if (prefix && wide_split && n_act == 4) {
+                    if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
+                    if (!cx->aux[0]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[0], hipStreamNonBlocking));
+                    if (!cx->ev_join[0]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[0], hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(cx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cx->aux[0], cx->ev_fork, 0));
+                    VOXCHK(wide_chain(2, cx->aux[0], 2, 1)); HIPCHK(hipEventRecord(cx->ev_join[0], cx->aux[0]));
+                    VOXCHK(wide_chain(2, s, 0, 0)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[0], 0));
+                    HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); return VOX_OK;
+                }
                 if (prefix) { VOXCHK(wide_chain(n_act, s)); HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); return VOX_OK; }
             }
             const bool fork = n_act > 1 && !knob_str("VOX_BATCH_SERIAL_GROUPS");
