@@ -203,7 +203,7 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=1, help="extension: every file is split into its --max-mel-frames chunks and up to N chunks go into one "
                     "vox_transcribe_batch_ex call (continuous batching; same ids per chunk and the same lines as one by one; output order unchanged)")
     ap.add_argument("--sessions-per-gpu", type=int, default=1, help="extension (with --batch, Q4 GGUF): this many concurrent sessions on every GPU (own context + model replica + "
-                    "library thread each: vox_model_set_sessions): one session's launch-bound decode steps leave gaps a second session fills (647 FLEURS-like clips: 3.8 s against 4.5 s; "
+                    "library thread each: vox_model_set_sessions): one session's launch-bound decode steps leave gaps a second session fills (647 FLEURS-like clips: 3.7 s against 4.3 s; "
                     "calls with fewer than 128 units per session stay on one); same lines")
     a = ap.parse_args(argv)
     if a.audio_list and a.audio:

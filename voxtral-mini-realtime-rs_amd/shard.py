@@ -171,7 +171,7 @@ class SessionPool:
     """Overlap INSIDE a rank's share: S concurrent sessions on ONE GPU -- S contexts (own stream, workspaces, graphs), S model replicas
     (vox_model_replicate: 2.5 GB each, device-to-device, no file), S host threads -- each running vox_transcribe_batch[_ex] over its part of the units.  One session
     leaves the GPU idle wherever its launch-bound decode steps wait (a 64-slot step streams 2.1 GB of weights in 3.1 ms); a second session's encoder GEMMs, prefill
-    and steps fill those gaps: the 647-clip FLEURS-like corpus takes 3.77 s with two sessions against 4.52 s with one (tools/two_sessions_probe.py, same ids).
+    and steps fill those gaps: the 647-clip FLEURS-like corpus takes 3.73 s with two sessions against 4.33 s with one (profiles/r06_bench_n1.json; tools/two_sessions_probe.py, same ids).
     What a Rust host would do with one thread per (context, model) pair; results are per unit and do not depend on the split (every row of a batch is computed
     independently, tests/test_gpu_fullsize.py::test_full_two_sessions_one_gpu_same_ids).
 
