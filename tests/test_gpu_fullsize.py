@@ -274,7 +274,7 @@ def test_full_wide_batches_peaked_golden_64_lockstep_and_81_continuous(pkg, monk
         assert n_cmp >= 64
         assert all((a == b).all() for a, b in zip(o81, m.transcribe_batch(b81, t)))      # deterministic
         # round 6: the WIDE step (2..4 active slot groups as ONE GEMM per operator, launch_q4_wide) on forced 3 and 4 slot groups: same ids, golden clip ALL 108
-        for G, wmin in ((4, 2), (3, 3), (4, 4)):
+        for G, wmin in ((4, 2), (3, 3), (4, 4), (5, 4), (6, 4)):      # (5, 6 groups: 80 / 96 slots, two wide chains per step)
             monkeypatch.setenv("VOX_BATCH_SLOT_GROUPS", str(G)); monkeypatch.setenv("VOX_BATCH_WIDE_MIN", str(wmin))
             w81 = m.transcribe_batch(b81, t)
             for sl in (0, 40, 80):
@@ -979,6 +979,25 @@ def test_full_two_sessions_one_gpu_same_ids(pkg, full, monkeypatch):
         assert np.array_equal(m.transcribe_batch(clips[:20], t)[7], ref[7])      # the source model keeps working after the pool is gone
     finally:
         m.set_batch_engine(was)
+
+
+def test_full_128_slots_two_wide_chains(pkg, full, monkeypatch):
+    """More than four slot groups (end of round 6): 150 clips of 2 .. 8 s on up to 128 slots -- every step with n >= 4 active groups runs as two wide chains of ceil(n / 2) and
+    floor(n / 2) groups on two streams.  Same ids as on <= 64 slots (VOX_BATCH_MAX_GROUPS=4) except at near-ties (a clip meets the three-group launch chains at other steps),
+    reproducible call to call, and forced 7 and 8 groups agree with the planner's choice."""
+    m, _, ctx = full
+    t = pkg.TimeEmbedding(3072).embed(6.0)
+    clips = [pkg.synth.synth_audio(2.0 + 6.0 * ((29 * i) % 89) / 88.0, seed=8000 + i) * (0.25 + 0.15 * (i % 5)) for i in range(150)]
+    monkeypatch.setenv("VOX_BATCH_NO_CALIB", "1")
+    monkeypatch.setenv("VOX_BATCH_MAX_GROUPS", "4"); ref = m.transcribe_batch(clips, t); monkeypatch.delenv("VOX_BATCH_MAX_GROUPS")
+    a = m.transcribe_batch(clips, t); b = m.transcribe_batch(clips, t)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert sum(int(np.array_equal(x, y)) for x, y in zip(ref, a)) >= len(clips) - 4
+    for G in (7, 8):
+        monkeypatch.setenv("VOX_BATCH_SLOT_GROUPS", str(G))
+        g = m.transcribe_batch(clips, t)
+        assert sum(int(np.array_equal(x, y)) for x, y in zip(ref, g)) >= len(clips) - 4, G
+    monkeypatch.delenv("VOX_BATCH_SLOT_GROUPS")
 
 
 def test_full_model_set_sessions_two(pkg, full, monkeypatch):

@@ -258,10 +258,13 @@ def test_transcribe_batch_continuous_slots(pkg, ctx, tiny, monkeypatch):
     monkeypatch.delenv("VOX_BATCH_NO_CONTINUOUS")
     for r, (a, b) in enumerate(zip(outs, ref)):
         assert len(a) == len(b) and (a == b).all(), f"slot {r}: continuous batching changed the ids"
-    for G in (1, 2, 3, 4):
+    for G in (1, 2, 3, 4, 5, 6):      # (5, 6: 80 / 96 slots -- two wide chains of ceil / floor halves per step, end of round 6)
         monkeypatch.setenv("VOX_BATCH_SLOT_GROUPS", str(G))
         alt = m.transcribe_batch(clips, t)
         assert all(len(a) == len(b) and (a == b).all() for a, b in zip(outs, alt)), f"{G} slot groups: ids differ"
+    monkeypatch.setenv("VOX_BATCH_SLOT_GROUPS", "6"); monkeypatch.setenv("VOX_BATCH_VERBOSE", "1")
+    m.transcribe_batch(clips, t)
+    monkeypatch.delenv("VOX_BATCH_VERBOSE")
     # round 6: the WIDE step (launch_q4_wide: the active groups' layer operators as one GEMM + finishing launch each, one attention launch, one lm_head) at 2, 3 and 4 groups
     monkeypatch.setenv("VOX_BATCH_WIDE_MIN", "2"); monkeypatch.setenv("VOX_BATCH_CONT_NO_ENGINE", "1")
     for G in (2, 3, 4):

@@ -98,7 +98,7 @@ struct vox_ctx {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // continuous batch, self-calibration of the planner (the step costs were constants measured on one box): milliseconds per step of 1..4 active groups as
     // MEASURED on this context (HIP events around the runs of equal active sets of earlier sessions, exponentially averaged; [0] = engine forms on, [1] = off), 0 = not seen yet
-    double step_ms_meas[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; hipEvent_t ev_seg[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double step_ms_meas[2][9] = {{0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0}}; hipEvent_t ev_seg[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t warm_forms = 0;      // continuous batch: step forms whose kernels have run once on this context's device (bit 0 launch chains, bit 1 engine + tail, bits 2..4 the wide step at 2 / 3 / 4 groups)
     // XF tiles of a 17..48-row GEMM input (the 38-token prefill): 3 tiles x K columns x 64 B; sized once for K <= 16384, reused by every such GEMM of the stream
     uint16_t* xf_scratch = nullptr; size_t xf_scratch_bytes = 0;
@@ -2438,17 +2438,20 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
 //       + argmax_embed_slots_kernel, which hands a slot whose utterance just got its last token the next one of its queue in the same launch.  A group retires when its
 //       queues are empty.  Rows are independent of their slot, so the ids per utterance are those of every other path (tests/test_gpu_fullsize.py).
 // Step cost of G lock-step groups in ms, measured on the FLEURS-like corpus (profiles/r05_continuous_sweep.txt: decode time net of graph captures / steps; 3 interpolated):
-static const double kStepMs[5] = {0.0, 1.84, 2.08, 2.75, 3.15};      // (four groups: the wide step, round 6 -- 3.40 on four forked chains)
+// Five to eight groups (80 .. 128 slots, end of round 6): TWO wide chains on two streams, ceil(n / 2) and floor(n / 2) groups each -- measured with tools/wide_probe.py
+// (profiles/r06_wide_split.txt); only on a context that owns its GPU.
+static const int kMaxGroups = 8;
+static const double kStepMs[9] = {0.0, 1.84, 2.08, 2.75, 3.15, 3.55, 3.80, 4.35, 4.70};      // (four groups: the wide step, round 6 -- 3.40 on four forked chains)
 // ... with the batched decode-layer engine serving the steps of <= 2 active groups (one group: decode_engine_b16_kernel<1>, 1.06 ms + tail; two: the two-group launch,
 // 1.60 ms + tail; three and four groups stay on the forked launch chains -- a two-group launch + a one- or two-group launch back to back: 2.9 / 3.4 ms against 2.75 / 3.40)
-static const double kStepMsEng[5] = {0.0, 1.17, 1.77, 2.75, 3.15};      // (four groups: the wide step, round 6)
+static const double kStepMsEng[9] = {0.0, 1.17, 1.77, 2.75, 3.15, 3.55, 3.80, 4.35, 4.70};      // (four groups: the wide step, round 6)
 struct SlotPlan { int G = 0; std::vector<std::vector<int>> queue; std::vector<int> steps_g; double cost_ms = 0.0; };
 // jobs: (decode steps, utterance) with steps >= 1.  LPT onto 16 G slots, slots ordered by load (so the groups retire last to first), G by the cost model.
-static SlotPlan plan_slots(const std::vector<std::pair<int, int>>& jobs_in, int force_G, const double* step_ms) {
+static SlotPlan plan_slots(const std::vector<std::pair<int, int>>& jobs_in, int force_G, const double* step_ms, int max_groups = 4) {
     std::vector<std::pair<int, int>> jobs = jobs_in;
     std::stable_sort(jobs.begin(), jobs.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
     SlotPlan best;
-    const int g_max = std::max(1, std::min(4, ((int)jobs.size() + 15) / 16));
+    const int g_max = std::max(1, std::min(max_groups, ((int)jobs.size() + 15) / 16));
     for (int G = 1; G <= g_max; G++) {
         if (force_G > 0 && G != std::min(force_G, g_max)) continue;
         const int Sl = 16 * G;
@@ -2510,30 +2513,34 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     // the decode plan (host only: lengths are known)
     std::vector<std::pair<int, int>> jobs;
     for (int i = 0; i < n; i++) if (len[i] > PREFIX_LEN + 1) jobs.emplace_back(len[i] - PREFIX_LEN - 1, i);
-    int force_G = 0; if (const char* e = knob_str("VOX_BATCH_SLOT_GROUPS")) force_G = std::max(0, std::min(4, atoi(e)));
+    int force_G = 0; if (const char* e = knob_str("VOX_BATCH_SLOT_GROUPS")) force_G = std::max(0, std::min(kMaxGroups, atoi(e)));
+    // more than four groups = two wide chains per step: needs the wide step's geometry and a GPU of its own (on a shared one the other session fills the gaps)
+    int max_groups = 4;
+    if (!cx->shared && !knob_str("VOX_BATCH_NO_WIDE") && !knob_str("VOX_BATCH_NO_WIDE_SPLIT") && c.dec_head_dim == 128) { max_groups = kMaxGroups; if (const char* e = knob_str("VOX_BATCH_MAX_GROUPS")) max_groups = std::max(1, std::min(kMaxGroups, atoi(e))); }
+    if (force_G > max_groups) force_G = max_groups;
     // the steps of one or two active groups go through the batched decode-layer engine (vox_engine_b16.hip: one launch per step for the 26 layers of both groups, cache
     // slices per slot through EngBParams::kv_row); wider steps, other geometries, VOX_BATCH_ENGINE=0 and the re-run after a hand-off timeout use the launch chains
     const bool use_eng = allow_engine && !cx->shared && !jobs.empty() && !knob_str("VOX_BATCH_CONT_NO_ENGINE") && engb_prepare(m, 2);
     // step costs: the table above, corrected by what this context has measured -- a form seen before costs what it cost (clock, a shared GPU, another geometry), a form not
     // seen yet the table's value times the mean measured / table ratio of the forms that were.  VOX_BATCH_NO_CALIB=1: the table alone.
-    double base_tab[5]; for (int g2 = 0; g2 < 5; g2++) base_tab[g2] = (use_eng ? kStepMsEng : kStepMs)[g2];
+    double base_tab[9]; for (int g2 = 0; g2 < 9; g2++) base_tab[g2] = (use_eng ? kStepMsEng : kStepMs)[g2];
     if (!cx->shared && !knob_str("VOX_BATCH_NO_WIDE_SPLIT")) base_tab[4] = 2.95;      // four groups as two two-group wide chains on two streams (below): 3.12 -> 2.92 ms net of the prefill
-    double step_cost[5]; const double* base_cost = base_tab; const bool calib = !knob_str("VOX_BATCH_NO_CALIB");
+    double step_cost[9]; const double* base_cost = base_tab; const bool calib = !knob_str("VOX_BATCH_NO_CALIB");
     {
         const double* meas = cx->step_ms_meas[use_eng ? 0 : 1]; double ratio = 0.0; int nr = 0;
-        for (int g2 = 1; g2 <= 4; g2++) if (calib && meas[g2] > 0.0) { ratio += meas[g2] / base_cost[g2]; nr++; }
+        for (int g2 = 1; g2 <= kMaxGroups; g2++) if (calib && meas[g2] > 0.0) { ratio += meas[g2] / base_cost[g2]; nr++; }
         ratio = nr ? std::min(4.0, std::max(0.25, ratio / nr)) : 1.0;
         // The common factor (clock, a GPU shared with another session) is taken as measured; a form's deviation from it is trusted within +-15 % only, and a step of more
         // groups never costs less than one of fewer: next to a second session on the GPU (tools/two_sessions_probe.py) the per-form figures scatter (a 3-group step "measured"
         // at 5.35 ms against 4.18 for four groups made the next session plan 48 slots instead of 64: 4.71 s instead of 3.77 s for the corpus)
         step_cost[0] = 0.0;
-        for (int g2 = 1; g2 <= 4; g2++) {
+        for (int g2 = 1; g2 <= kMaxGroups; g2++) {
             const double common = base_cost[g2] * ratio;
             step_cost[g2] = (calib && !cx->shared && meas[g2] > 0.0) ? common * std::min(1.15, std::max(0.85, meas[g2] / common)) : common;      // (a shared GPU: the common factor only)
             step_cost[g2] = std::max(step_cost[g2], step_cost[g2 - 1]);
         }
     }
-    const SlotPlan plan = plan_slots(jobs, force_G, step_cost);
+    const SlotPlan plan = plan_slots(jobs, force_G, step_cost, max_groups);
     const int G = std::max(plan.G, 1), Sl = 16 * G;
     int q_stride = 1; for (auto& q : plan.queue) q_stride = std::max(q_stride, (int)q.size() + 1);
     std::vector<int> h_queue((size_t)Sl * q_stride, -1);
@@ -2663,7 +2670,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         bool wide_ok = !knob_str("VOX_BATCH_NO_WIDE") && G >= wide_min && hd == 128;
         size_t planes_bytes = 0;
         if (wide_ok) {
-            for (int mtw = wide_min; mtw <= G && wide_ok; mtw++) {
+            for (int mtw = std::min(wide_min, 2 + (G > 4 ? 0 : 2)); mtw <= std::min(G, 4) && wide_ok; mtw++) {      // (two chains: each of 2 .. 4 groups)
                 const struct { const Q4W* w; int epi; } ops[5] = {{&m->dec[0].wqkv.w, EPI_ROPE_KV}, {&m->dec[0].wo.w, EPI_RESID_XF}, {&m->dec[0].w13.w, EPI_SWIGLU_XF}, {&m->dec[0].w2.w, EPI_RESID_XF}, {&m->tok.w, EPI_STORE}};
                 for (auto& o : ops) { WidePlan pl; if (!q4_wide_plan(*o.w, mtw, o.epi, &pl)) { wide_ok = false; break; } if (o.epi != EPI_STORE) planes_bytes = std::max(planes_bytes, q4_wide_planes_bytes(*o.w, mtw, pl)); }
             }
@@ -2675,7 +2682,8 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         // 3.49 -> 3.29 ms (prefill included), corpus 4.54 -> 4.37 s, same ids (profiles/r06_wide_split.txt).  NOT on a shared GPU (vox_ctx_set_shared / sessions): there the
         // other session already fills the gaps and four concurrent chains only contend (two sessions: 3.80 s without, 4.46 s with).  VOX_BATCH_NO_WIDE_SPLIT=1: one chain.
         const bool wide_split = wide_ok && G >= 4 && wide_min <= 4 && !cx->shared && !knob_str("VOX_BATCH_NO_WIDE_SPLIT");
-        if (wide_split) { for (int mtw = 2; mtw <= 2; mtw++) { const struct { const Q4W* w; int epi; } ops[4] = {{&m->dec[0].wqkv.w, EPI_ROPE_KV}, {&m->dec[0].wo.w, EPI_RESID_XF}, {&m->dec[0].w13.w, EPI_SWIGLU_XF}, {&m->dec[0].w2.w, EPI_RESID_XF}};
+        if (G > 4 && !wide_split) return fail(VOX_ERR_INVALID, "internal: %d slot groups planned without the two-chain wide step", G);
+        if (wide_split) { for (int mtw = 2; mtw <= 4; mtw++) { const struct { const Q4W* w; int epi; } ops[4] = {{&m->dec[0].wqkv.w, EPI_ROPE_KV}, {&m->dec[0].wo.w, EPI_RESID_XF}, {&m->dec[0].w13.w, EPI_SWIGLU_XF}, {&m->dec[0].w2.w, EPI_RESID_XF}};
             for (auto& o : ops) { WidePlan pl; if (q4_wide_plan(*o.w, mtw, o.epi, &pl)) planes_bytes = std::max(planes_bytes, q4_wide_planes_bytes(*o.w, mtw, pl)); } } }
         DevBuf b_planes;
         if (wide_ok) HIPCHK(b_planes.alloc_pooled(cx, planes_bytes * (wide_split ? 2 : 1)));
@@ -2751,13 +2759,14 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             }
             if (wide_ok && n_act >= wide_min) {      // (steps with one group, or two when the engine serves them, never get here)
                 bool prefix = true; for (int gi = 0; gi < n_act; gi++) if (!((active >> gi) & 1u)) prefix = false;
-                if (prefix && wide_split && n_act == 4) {
+                if (prefix && wide_split && n_act >= 4) {      // two chains: groups 0 .. na - 1 on the session's stream, na .. n_act - 1 on a forked one
+                    const int na = (n_act + 1) / 2, nb = n_act - na;
                     if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
                     if (!cx->aux[0]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[0], hipStreamNonBlocking));
                     if (!cx->ev_join[0]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[0], hipEventDisableTiming));
                     HIPCHK(hipEventRecord(cx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cx->aux[0], cx->ev_fork, 0));
-                    VOXCHK(wide_chain(2, cx->aux[0], 2, 1)); HIPCHK(hipEventRecord(cx->ev_join[0], cx->aux[0]));
-                    VOXCHK(wide_chain(2, s, 0, 0)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[0], 0));
+                    VOXCHK(wide_chain(nb, cx->aux[0], na, 1)); HIPCHK(hipEventRecord(cx->ev_join[0], cx->aux[0]));
+                    VOXCHK(wide_chain(na, s, 0, 0)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[0], 0));
                     HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); return VOX_OK;
                 }
                 if (prefix) { VOXCHK(wide_chain(n_act, s)); HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); return VOX_OK; }
@@ -2844,10 +2853,10 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         HIPCHK(hipStreamSynchronize(s));      // phase A (and the set-up behind it) is done: the prefill timer closes here, the decode timer starts
         { const double tn = now_ms(); pf_ms += tn - t1; t1 = tn; }
         // (an event where the set of active groups changes: the runs in between are what the planner's next session on this context is priced with)
-        int seg_n[6] = {0, 0, 0, 0, 0, 0}, seg_act[6] = {0, 0, 0, 0, 0, 0}, n_seg = 0; uint32_t last_act = 0;
+        int seg_n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, seg_act[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, n_seg = 0; uint32_t last_act = 0;
         for (int t = t_start; t < steps; t++) {
             const uint32_t act = active_at(t);
-            if (calib && !no_graph && act != last_act && n_seg < 5) {
+            if (calib && !no_graph && act != last_act && n_seg < 9) {
                 if (!cx->ev_seg[n_seg]) HIPCHK(hipEventCreate(&cx->ev_seg[n_seg]));
                 HIPCHK(hipEventRecord(cx->ev_seg[n_seg], s));
                 int na = 0; for (int gi = 0; gi < G; gi++) na += (act >> gi) & 1u;
@@ -2875,7 +2884,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         }
         for (int k = 0; k < n_seg && !cx->shared; k++) {      // runs of >= 8 steps only: shorter ones are mostly their first replay (a shared GPU: nothing is recorded)
             float ms = 0.f;
-            if (seg_n[k] >= 8 && seg_act[k] >= 1 && seg_act[k] <= 4 && hipEventElapsedTime(&ms, cx->ev_seg[k], cx->ev_seg[k + 1]) == hipSuccess && ms > 0.f) {
+            if (seg_n[k] >= 8 && seg_act[k] >= 1 && seg_act[k] <= kMaxGroups && hipEventElapsedTime(&ms, cx->ev_seg[k], cx->ev_seg[k + 1]) == hipSuccess && ms > 0.f) {
                 double& mm = cx->step_ms_meas[use_eng ? 0 : 1][seg_act[k]]; const double v = (double)ms / seg_n[k];
                 mm = mm > 0.0 ? 0.7 * mm + 0.3 * v : v;
             } else (void)hipGetLastError();
@@ -2892,7 +2901,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     }
     m->timings.preprocess_ms = pre_ms; m->timings.encode_ms = enc_ms; m->timings.decode_ms = pf_ms + (now_ms() - t1); m->timings.total_ms = now_ms() - t0;
     m->timings.decode_tokens = total; m->timings.graph_replays = replays;
-    if (knob_str("VOX_BATCH_VERBOSE")) fprintf(stderr, "[voxtral_hip] continuous batch: %d utterances, %d slots, %d steps (plan %.1f ms), front-end %.1f ms, encode %.1f ms (%d chunks), prefill %.1f ms (%d graph captures, %.1f ms of host time, under the last chunk's), decode %.1f ms; step costs used %.2f / %.2f / %.2f / %.2f ms\n", n, Sl, steps, plan.cost_ms, pre_ms, enc_ms, n_chunks, pf_ms, n_captures, capture_ms, now_ms() - t1, step_cost[1], step_cost[2], step_cost[3], step_cost[4]);
+    if (knob_str("VOX_BATCH_VERBOSE")) fprintf(stderr, "[voxtral_hip] continuous batch: %d utterances, %d slots, %d steps (plan %.1f ms), front-end %.1f ms, encode %.1f ms (%d chunks), prefill %.1f ms (%d graph captures, %.1f ms of host time, under the last chunk's), decode %.1f ms; step costs used %.2f / %.2f / %.2f / %.2f / %.2f / %.2f / %.2f / %.2f ms\n", n, Sl, steps, plan.cost_ms, pre_ms, enc_ms, n_chunks, pf_ms, n_captures, capture_ms, now_ms() - t1, step_cost[1], step_cost[2], step_cost[3], step_cost[4], step_cost[5], step_cost[6], step_cost[7], step_cost[8]);
     return VOX_OK;
 }
 
