@@ -270,8 +270,9 @@ int32_t vox_transcribe_batch_ex(vox_model* m, int32_t n, const float* const* sam
                                 int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind);
 /* sessions = 2..4: vox_transcribe_batch / _ex calls with at least 128 units per session run as that many CONCURRENT sessions on the model's GPU -- the calling thread on the
  * model's context, the others on library threads with hidden contexts and replicas of the model (made here, device to device: 2.5 GB each; freed with the model or by
- * sessions = 1).  One session leaves the GPU idle wherever its launch-bound decode steps wait; a second one fills the gaps: 647 FLEURS-like clips 4.33 s -> 3.73 s on one
- * MI355X.  Units that share a norm_group stay in one session; every context involved counts as shared for the call (vox_ctx_set_shared); results are per
+ * sessions = 1).  One session leaves the GPU idle wherever its launch-bound decode steps wait; a second one fills the gaps: 647 FLEURS-like clips x 1.16 - 1.20 over a 64-slot session on one
+ * MI355X (the plain call now plans up to 128 slots as two chains per step -- the same overlap -- so sessions add ~1 % there: they are for one GPU shared by
+ * independent callers).  Units that share a norm_group stay in one session; every context involved counts as shared for the call (vox_ctx_set_shared); results are per
  * unit and do not depend on the split.  vox_get_stage_timings then reports the longest session's stage times and the call's wall time.  Smaller calls and every other
  * entry point are unchanged.  (No reference counterpart -- the reference transcribes one file at a time, bin/transcribe.rs:112-126; a host that prefers its own threads
  * uses vox_model_replicate + vox_ctx_set_shared instead.)  Q4 (GGUF) models. */
