@@ -164,7 +164,7 @@ def piecewise_extra(pkg, gguf_path, x, ref_ids, reps=3):
 def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batch, simulate_world=0, bcast_bytes=0, chunk_frames=0, sessions=1):
     """BASELINE configs[4] stand-in (no FLEURS offline): `n_clips` synthetic clips with FLEURS-like durations, LPT-sharded over the ranks
     (shard.run_sharded), each rank handing its share to vox_transcribe_batch in calls of <= `batch` clips (default: the whole share in one call -- continuous batching over
-    16 .. 64 decode slots; 64: the round-4 form, length-bucketed lock-step batches); results gathered in input order.
+    16 .. 128 decode slots; 64: the round-4 form, length-bucketed lock-step batches); results gathered in input order.
     Wall time = barrier .. barrier, max over ranks.  Replaces the reference's serial per-file loop (bin/transcribe.rs:112-126)."""
     import importlib
     shard = importlib.import_module(pkg.__name__ + ".shard")

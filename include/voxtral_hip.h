@@ -254,7 +254,7 @@ int32_t vox_transcribe_audio(vox_model* m, const float* samples, size_t n, const
  * many sequences per step so the weights are streamed once per step for all of them.  samples[i] / out_ids[i] are per-utterance buffers (samples host or device per
  * mem_kind, ids always host); n_ids[i] receives S_i - 38 (or 0).  Batches may be ragged and results always land in the caller's slot i.
  * n <= 16: one 16-row group, one decode-layer engine launch per step.  n > 16: CONTINUOUS BATCHING -- every utterance is encoded (stacked, packed: no padding to the
- * longest) and prefilled up front; the decode step then runs over 16 .. 64 SLOTS, and a slot whose utterance has its last token takes the next utterance of its
+ * longest) and prefilled up front; the decode step then runs over 16 .. 128 SLOTS, and a slot whose utterance has its last token takes the next utterance of its
  * host-planned queue inside the same step (token counts are a pure function of the sample count: there is no EOS, gguf/model.rs:936-960), so the groups stay full
  * until the queues run dry; steps with one or two active groups are one engine launch for all their layers (vox_model_set_batch_engine).  Ids per utterance do not
  * depend on n, on the slot or on the neighbours (tested at full size). */
