@@ -219,6 +219,7 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
     except Exception as e:
         ok = 0; err = str(e)
     ctx.synchronize(); dt = time.perf_counter() - t0
+    tm_last = model.timings()      # rank 0's LAST call inside the timed region (the whole share when it is one call): stage times, decode steps
     if sessions > 1:
         model.set_sessions(1)
     eng_corpus = model.set_batch_engine()[1] - eng_n0      # rank 0's engine launches inside the timed region (steps with <= 2 active slot groups: one launch each)
@@ -273,7 +274,10 @@ def fleurs_like_extra(pkg, ctx, model, t_embed, rank, world, dist, n_clips, batc
             "workload": f"{n_clips} synthetic clips, FLEURS-like log-normal durations (median 10 s, 3..30 s, rng 7), host samples -> ids; LPT shards over {world} rank(s), "
                         f"{'one vox_transcribe_batch call per rank (continuous batching)' if batch >= n_clips else f'{batch}-clip length-bucketed calls'} (BASELINE configs[4] stand-in; no FLEURS / WER offline)",
             "clips": n_clips, "audio_s": round(total_s, 1), "wall_s": round(dt, 3), "rtf": round(dt / total_s, 6), "tok_per_s": round(ntok / dt, 1),
-            "ids": ntok, "lpt_imbalance": round(shard.imbalance(durs, parts), 4), "batch": batch, "engine_launches": int(eng_corpus), "batch_engine_active": bool(model.set_batch_engine()[0])}
+            "ids": ntok, "lpt_imbalance": round(shard.imbalance(durs, parts), 4), "batch": batch, "engine_launches": int(eng_corpus), "batch_engine_active": bool(model.set_batch_engine()[0]),
+            # rank 0's last call: front-end / encoder / (prefill + decode steps) wall times and the number of decode steps (graph replays); with sessions: the longest session's stages, all replays
+            "last_call_stage_ms": {k: round(tm_last[k], 1) for k in ("preprocess_ms", "encode_ms", "decode_ms")}, "last_call_decode_steps": int(tm_last["graph_replays"]),
+            "last_call_ms_per_step_incl_prefill": round(tm_last["decode_ms"] / max(int(tm_last["graph_replays"]), 1), 3)}
 
 
 def main():

@@ -2686,7 +2686,8 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
         if (wide_split) { for (int mtw = 2; mtw <= 4; mtw++) { const struct { const Q4W* w; int epi; } ops[4] = {{&m->dec[0].wqkv.w, EPI_ROPE_KV}, {&m->dec[0].wo.w, EPI_RESID_XF}, {&m->dec[0].w13.w, EPI_SWIGLU_XF}, {&m->dec[0].w2.w, EPI_RESID_XF}};
             for (auto& o : ops) { WidePlan pl; if (q4_wide_plan(*o.w, mtw, o.epi, &pl)) planes_bytes = std::max(planes_bytes, q4_wide_planes_bytes(*o.w, mtw, pl)); } } }
         DevBuf b_planes;
-        if (wide_ok) HIPCHK(b_planes.alloc_pooled(cx, planes_bytes * (wide_split ? 2 : 1)));
+        int wide_chains = 2; if (const char* e = knob_str("VOX_BATCH_WIDE_CHAINS")) wide_chains = std::max(2, std::min(4, atoi(e)));      // measurement knob: more than two chains per step
+        if (wide_ok) HIPCHK(b_planes.alloc_pooled(cx, planes_bytes * (wide_split ? wide_chains : 1)));
         auto wide_chain = [&](int mtw, hipStream_t sg, int g0 = 0, int chain = 0) -> int32_t {      // groups g0 .. g0 + mtw - 1; `chain`: which half of the planes scratch
             uint16_t* xf1 = b_xf1.as<uint16_t>() + (size_t)g0 * (xf_bytes(D) / 2); uint16_t* xf2 = b_xf2.as<uint16_t>() + (size_t)g0 * (xf_bytes(QD) / 2); uint16_t* xf3 = b_xf3.as<uint16_t>() + (size_t)g0 * (xf_bytes(F) / 2);
             float* ssq = b_ssq.as<float>() + (size_t)g0 * parts_D * 16;
@@ -2760,13 +2761,17 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
             if (wide_ok && n_act >= wide_min) {      // (steps with one group, or two when the engine serves them, never get here)
                 bool prefix = true; for (int gi = 0; gi < n_act; gi++) if (!((active >> gi) & 1u)) prefix = false;
                 if (prefix && wide_split && n_act >= 4) {      // two chains: groups 0 .. na - 1 on the session's stream, na .. n_act - 1 on a forked one
-                    const int na = (n_act + 1) / 2, nb = n_act - na;
+                    const int nc = std::max(2, std::min(wide_chains, n_act / 2));      // chains of >= 2 groups, sizes balanced, the larger ones first
+                    int g0c[4], szc[4]; { int g0 = 0; for (int j = 0; j < nc; j++) { szc[j] = n_act / nc + (j < n_act % nc ? 1 : 0); g0c[j] = g0; g0 += szc[j]; } }
                     if (!cx->ev_fork) HIPCHK(hipEventCreateWithFlags(&cx->ev_fork, hipEventDisableTiming));
-                    if (!cx->aux[0]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[0], hipStreamNonBlocking));
-                    if (!cx->ev_join[0]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[0], hipEventDisableTiming));
-                    HIPCHK(hipEventRecord(cx->ev_fork, s)); HIPCHK(hipStreamWaitEvent(cx->aux[0], cx->ev_fork, 0));
-                    VOXCHK(wide_chain(nb, cx->aux[0], na, 1)); HIPCHK(hipEventRecord(cx->ev_join[0], cx->aux[0]));
-                    VOXCHK(wide_chain(na, s, 0, 0)); HIPCHK(hipStreamWaitEvent(s, cx->ev_join[0], 0));
+                    for (int j = 0; j < nc - 1; j++) {
+                        if (!cx->aux[j]) HIPCHK(hipStreamCreateWithFlags(&cx->aux[j], hipStreamNonBlocking));
+                        if (!cx->ev_join[j]) HIPCHK(hipEventCreateWithFlags(&cx->ev_join[j], hipEventDisableTiming));
+                    }
+                    HIPCHK(hipEventRecord(cx->ev_fork, s));
+                    for (int j = 1; j < nc; j++) { HIPCHK(hipStreamWaitEvent(cx->aux[j - 1], cx->ev_fork, 0)); VOXCHK(wide_chain(szc[j], cx->aux[j - 1], g0c[j], j)); HIPCHK(hipEventRecord(cx->ev_join[j - 1], cx->aux[j - 1])); }
+                    VOXCHK(wide_chain(szc[0], s, 0, 0));
+                    for (int j = 1; j < nc; j++) HIPCHK(hipStreamWaitEvent(s, cx->ev_join[j - 1], 0));
                     HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); return VOX_OK;
                 }
                 if (prefix) { VOXCHK(wide_chain(n_act, s)); HIPCHK(launch_argmax_embed_slots(sp, Sl, s)); return VOX_OK; }
