@@ -2470,6 +2470,19 @@ static bool batch_xf_ok(const vox_model* m) {
     const vox_model_cfg& c = m->cfg; const int D = c.dec_dim, QD = c.dec_heads * c.dec_head_dim, F = c.dec_ffn;
     return m->tok.w.fmt == WFMT_Q4_0 && m->dec[0].wqkv.w.fmt == WFMT_Q4_0 && m->tok.w.qt && m->dec[0].wqkv.w.qt && D % 128 == 0 && QD % 128 == 0 && F % 128 == 0 && !knob_str("VOX_BATCH_NO_XF");
 }
+// the wide step's geometry: every decoder layer the shape of layer 0, tile-ordered Q4 copies, no biases, plans for 2 .. 4 groups per chain
+static bool wide_geom_ok(const vox_model* m) {
+    const vox_model_cfg& c = m->cfg;
+    if (c.dec_head_dim != 128 || c.dec_layers < 1) return false;
+    const DecLayer& L0 = m->dec[0];
+    for (int mtw = 2; mtw <= 4; mtw++) {
+        const struct { const Q4W* w; int epi; } ops[5] = {{&L0.wqkv.w, EPI_ROPE_KV}, {&L0.wo.w, EPI_RESID_XF}, {&L0.w13.w, EPI_SWIGLU_XF}, {&L0.w2.w, EPI_RESID_XF}, {&m->tok.w, EPI_STORE}};
+        for (auto& o : ops) { WidePlan pl; if (!q4_wide_plan(*o.w, mtw, o.epi, &pl)) return false; }
+    }
+    for (int l = 0; l < c.dec_layers; l++) { const DecLayer& L = m->dec[l];
+        if (L.wqkv.w.N != L0.wqkv.w.N || L.wqkv.w.K != L0.wqkv.w.K || L.w13.w.N != L0.w13.w.N || L.w2.w.K != L0.w2.w.K || !L.wqkv.w.qt || !L.wo.w.qt || !L.w13.w.qt || !L.w2.w.qt || L.wqkv.bias || L.wo.bias || L.w13.bias || L.w2.bias) return false; }
+    return true;
+}
 static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* const* samples, const size_t* n_samples, const float* t_embed,
                                           int32_t* const* out_ids, const int32_t* caps, int32_t* n_ids, int32_t mem_kind, const int* slot_of, bool allow_engine,
                                           const float* const* unit_scale = nullptr) {
@@ -2516,7 +2529,7 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     int force_G = 0; if (const char* e = knob_str("VOX_BATCH_SLOT_GROUPS")) force_G = std::max(0, std::min(kMaxGroups, atoi(e)));
     // more than four groups = two wide chains per step: needs the wide step's geometry and a GPU of its own (on a shared one the other session fills the gaps)
     int max_groups = 4;
-    if (!cx->shared && !knob_str("VOX_BATCH_NO_WIDE") && !knob_str("VOX_BATCH_NO_WIDE_SPLIT") && c.dec_head_dim == 128) { max_groups = kMaxGroups; if (const char* e = knob_str("VOX_BATCH_MAX_GROUPS")) max_groups = std::max(1, std::min(kMaxGroups, atoi(e))); }
+    if (!cx->shared && !knob_str("VOX_BATCH_NO_WIDE") && !knob_str("VOX_BATCH_NO_WIDE_SPLIT") && wide_geom_ok(m)) { max_groups = kMaxGroups; if (const char* e = knob_str("VOX_BATCH_MAX_GROUPS")) max_groups = std::max(1, std::min(kMaxGroups, atoi(e))); }
     if (force_G > max_groups) force_G = max_groups;
     // the steps of one or two active groups go through the batched decode-layer engine (vox_engine_b16.hip: one launch per step for the 26 layers of both groups, cache
     // slices per slot through EngBParams::kv_row); wider steps, other geometries, VOX_BATCH_ENGINE=0 and the re-run after a hand-off timeout use the launch chains
