@@ -368,6 +368,17 @@ def test_model_set_sessions_splits_large_calls_and_keeps_every_units_ids(pkg, ct
     for bad in (0, 5):
         with pytest.raises(pkg.VoxError):
             m.set_sessions(bad)
+    # vox_ctx_set_shared on its own: a shared context stays off the batched decode engines (their persistent workgroups need the GPU to themselves), same ids
+    if m.set_batch_engine()[0]:
+        n0 = m.set_batch_engine()[1]
+        ctx.set_shared(True)
+        try:
+            sh = m.transcribe_batch(clips[:20], t)
+            assert m.set_batch_engine()[1] == n0
+        finally:
+            ctx.set_shared(False)
+        own = m.transcribe_batch(clips[:20], t)
+        assert m.set_batch_engine()[1] > n0 and all(np.array_equal(a, b) for a, b in zip(sh, own))
 
 
 def test_two_contexts_two_threads_and_model_replicate(pkg, ctx, tiny):
