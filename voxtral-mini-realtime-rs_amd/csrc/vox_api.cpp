@@ -96,6 +96,7 @@ struct vox_ctx {
     std::vector<PoolEntry> pool;
     // side streams + fork/join events: independent 16-row groups of a wide batched decode step run concurrently
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t fe_stream = nullptr; hipEvent_t ev_fe[2] = {nullptr, nullptr}, ev_enc[2] = {nullptr, nullptr};      // continuous batch: the next chunk's upload + log-mel under this chunk's encoder
     // continuous batch, self-calibration of the planner (the step costs were constants measured on one box): milliseconds per step of 1..4 active groups as
     // MEASURED on this context (HIP events around the runs of equal active sets of earlier sessions, exponentially averaged; [0] = engine forms on, [1] = off), 0 = not seen yet
     double step_ms_meas[2][9] = {{0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0}}; hipEvent_t ev_seg[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -143,6 +144,9 @@ extern "C" int32_t vox_ctx_destroy(vox_ctx* c) {
     for (int i = 0; i < 3; i++) { if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (auto e : c->ev_seg) if (e) (void)hipEventDestroy(e);
+    if (c->fe_stream) { (void)hipStreamSynchronize(c->fe_stream); (void)hipStreamDestroy(c->fe_stream); }
+    for (auto e : c->ev_fe) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_enc) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c; return VOX_OK;
 }
@@ -2172,7 +2176,7 @@ static int32_t transcribe_batch_impl(vox_model* m, int32_t n, const float* const
     DevBuf b_audio, b_k, b_v, b_tok, b_pos, b_len, b_h, b_xn, b_qkv, b_att, b_act, b_logits, b_px, b_mel, b_scale, b_smp, b_xf1, b_xf2, b_xf3, b_ssq;
     // pooled buffers go back to the pool in the DevBuf destructors: on EVERY exit path (early error returns included) the main and side
     // streams are drained first (this guard is declared after the buffers, so it is destroyed before them)
-    struct Drain { vox_ctx* c; ~Drain() { (void)hipStreamSynchronize(c->stream); for (auto a : c->aux) if (a) (void)hipStreamSynchronize(a); } } drain{cx};
+    struct Drain { vox_ctx* c; ~Drain() { (void)hipStreamSynchronize(c->stream); for (auto a : c->aux) if (a) (void)hipStreamSynchronize(a); if (c->fe_stream) (void)hipStreamSynchronize(c->fe_stream); } } drain{cx};
     HIPCHK(b_audio.alloc_pooled(cx, (size_t)n * audio_rows * D * 4)); HIPCHK(b_k.alloc_pooled(cx, layer_stride * c.dec_layers * 4)); HIPCHK(b_v.alloc_pooled(cx, layer_stride * c.dec_layers * 4));
     HIPCHK(b_tok.alloc_pooled(cx, (size_t)n * tstride * 4)); HIPCHK(b_pos.alloc_pooled(cx, (size_t)n * 4)); HIPCHK(b_len.alloc_pooled(cx, (size_t)n * 4));
     HIPCHK(b_h.alloc_pooled(cx, (size_t)n * D * 4)); HIPCHK(b_xn.alloc_pooled(cx, (size_t)n * D * 4)); HIPCHK(b_qkv.alloc_pooled(cx, (size_t)n * W * 4)); HIPCHK(b_att.alloc_pooled(cx, (size_t)n * QD * 4));
@@ -2568,8 +2572,15 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     HIPCHK(b_h0.alloc_pooled(cx, (size_t)n * D * 4)); HIPCHK(b_aoff.alloc_pooled(cx, (size_t)n * sizeof(long)));
     const int ncm = std::min(n, CHUNK);
     HIPCHK(b_px.alloc_pooled(cx, (size_t)ncm * PREFIX_LEN * D * 4)); HIPCHK(b_xn.alloc_pooled(cx, (size_t)ncm * D * 4)); HIPCHK(b_lg0.alloc_pooled(cx, (size_t)ncm * V * 4));
-    HIPCHK(b_mel.alloc_pooled(cx, std::max<size_t>(mel_max, 1) * 4)); HIPCHK(b_scale.alloc_pooled(cx, (size_t)ncm * 4));
-    if (mem_kind == VOX_MEM_HOST) HIPCHK(b_smp.alloc_pooled(cx, std::max<size_t>(smp_max, 1) * 4));
+    // front-end buffers TWICE: chunk ci + 1's samples go up and its log-mel is computed on a second stream while chunk ci's encoder runs (VOX_BATCH_NO_FE_OVERLAP=1: one stream)
+    const bool fe_overlap = n_chunks > 1 && !knob_str("VOX_BATCH_NO_FE_OVERLAP");
+    const size_t mel_half = std::max<size_t>(mel_max, 1), smp_half = std::max<size_t>(smp_max, 1);
+    HIPCHK(b_mel.alloc_pooled(cx, mel_half * 4 * (fe_overlap ? 2 : 1))); HIPCHK(b_scale.alloc_pooled(cx, (size_t)ncm * 4 * (fe_overlap ? 2 : 1)));
+    if (mem_kind == VOX_MEM_HOST) HIPCHK(b_smp.alloc_pooled(cx, smp_half * 4 * (fe_overlap ? 2 : 1)));
+    if (fe_overlap) {
+        if (!cx->fe_stream) HIPCHK(hipStreamCreateWithFlags(&cx->fe_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) { if (!cx->ev_fe[k]) HIPCHK(hipEventCreateWithFlags(&cx->ev_fe[k], hipEventDisableTiming)); if (!cx->ev_enc[k]) HIPCHK(hipEventCreateWithFlags(&cx->ev_enc[k], hipEventDisableTiming)); }
+    }
     HIPCHK(hipMemsetAsync(b_audio.p, 0, audio_floats * 4, s)); HIPCHK(hipMemsetAsync(b_h0.p, 0, (size_t)n * D * 4, s));
     float* d_audio = b_audio.as<float>(); int* d_tok = b_tok.as<int>();
     {   // prefix tokens, positions and lengths of every utterance (gguf/model.rs:887-902)
@@ -2585,24 +2596,41 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     }
     // ---- (A) front-end, stacked encoder and stacked 38-token prefill, chunk by chunk
     double pre_ms = 0.0, enc_ms = 0.0, pf_ms = 0.0; const double t0 = now_ms();
+    // front-end of chunk cj (samples up, peak, log-mel) into half cj & 1 of the buffers, on stream sf; returns the chunk's mel pointers
+    auto front_end = [&](int cj, hipStream_t sf, std::vector<const float*>& d_mels) -> int32_t {
+        const int c0 = chunk0[cj], nc = chunk0[cj + 1] - c0, half = fe_overlap ? (cj & 1) : 0;
+        d_mels.assign(nc, nullptr);
+        size_t mo = 0, so = 0;
+        float* smp0 = mem_kind == VOX_MEM_HOST ? b_smp.as<float>() + (size_t)half * smp_half : nullptr; float* mel0 = b_mel.as<float>() + (size_t)half * mel_half; float* sc0 = b_scale.as<float>() + (size_t)half * ncm;
+        for (int i = c0; i < c0 + nc; i++) {
+            const float* d_s = samples[i];
+            if (mem_kind == VOX_MEM_HOST) { float* dst = smp0 + so; so += n_samples[i]; HIPCHK(hipMemcpyAsync(dst, samples[i], n_samples[i] * 4, hipMemcpyHostToDevice, sf)); d_s = dst; }
+            const size_t left = pad_left(&pc), right = pad_right(&pc, n_samples[i] + left);
+            float* mel_i = mel0 + mo; mo += (size_t)128 * T[i]; d_mels[i - c0] = mel_i;
+            const float* scale_i = unit_scale ? unit_scale[i] : sc0 + (i - c0);
+            if (!unit_scale) HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, sc0 + (i - c0), sf));
+            HIPCHK(launch_mel(d_s, (long)n_samples[i], (long)left, (long)right, scale_i, mt, mel_i, T[i], 1, sf));
+        }
+        return VOX_OK;
+    };
+    std::vector<const float*> mels_cur, mels_next;
     for (int ci = 0; ci < n_chunks; ci++) {
         const int c0 = chunk0[ci], nc = chunk0[ci + 1] - c0;
         const double ta = now_ms();
-        std::vector<const float*> d_mels(nc);
-        size_t mo = 0, so = 0;
-        for (int i = c0; i < c0 + nc; i++) {
-            const float* d_s = samples[i];
-            if (mem_kind == VOX_MEM_HOST) { float* dst = b_smp.as<float>() + so; so += n_samples[i]; HIPCHK(hipMemcpyAsync(dst, samples[i], n_samples[i] * 4, hipMemcpyHostToDevice, s)); d_s = dst; }
-            const size_t left = pad_left(&pc), right = pad_right(&pc, n_samples[i] + left);
-            float* mel_i = b_mel.as<float>() + mo; mo += (size_t)128 * T[i]; d_mels[i - c0] = mel_i;
-            const float* scale_i = unit_scale ? unit_scale[i] : b_scale.as<float>() + (i - c0);
-            if (!unit_scale) HIPCHK(launch_absmax(d_s, (long)n_samples[i], 0.95f, b_scale.as<float>() + (i - c0), s));
-            HIPCHK(launch_mel(d_s, (long)n_samples[i], (long)left, (long)right, scale_i, mt, mel_i, T[i], 1, s));
-        }
-        HIPCHK(hipStreamSynchronize(s)); const double tb = now_ms();
+        if (!fe_overlap || ci == 0) { VOXCHK(front_end(ci, s, mels_cur)); HIPCHK(hipStreamSynchronize(s)); }
+        else { mels_cur.swap(mels_next); HIPCHK(hipStreamWaitEvent(s, cx->ev_fe[ci & 1], 0)); }      // (issued under the previous chunk's encoder, below)
+        std::vector<const float*>& d_mels = mels_cur;
+        const double tb = now_ms();
         std::vector<int> S4(nc); std::vector<long> aoff_rel(nc);
         VOXCHK(encode_batch_dev(m, nc, d_mels.data(), T.data() + c0, d_audio + aoff_c[ci], 0, S4.data(), aoff_rel.data()));
         for (int i = 0; i < nc; i++) ARGCHK(S4[i] == S[c0 + i] && (long)aoff_c[ci] + aoff_rel[i] == audio_off[c0 + i], "internal: sequence length / audio offset mismatch (%d vs %d)", S4[i], S[c0 + i]);
+        if (fe_overlap) {
+            HIPCHK(hipEventRecord(cx->ev_enc[ci & 1], s));      // this chunk's encoder has read half ci & 1 of the front-end buffers
+            if (ci + 1 < n_chunks) {      // the next chunk's front-end: its half was last read by chunk ci - 1's encoder
+                if (ci >= 1) HIPCHK(hipStreamWaitEvent(cx->fe_stream, cx->ev_enc[(ci + 1) & 1], 0));
+                VOXCHK(front_end(ci + 1, cx->fe_stream, mels_next)); HIPCHK(hipEventRecord(cx->ev_fe[(ci + 1) & 1], cx->fe_stream));
+            }
+        }
         HIPCHK(hipStreamSynchronize(s)); const double tc = now_ms();
         float* px = b_px.as<float>();
         for (int i = c0; i < c0 + nc; i++)
