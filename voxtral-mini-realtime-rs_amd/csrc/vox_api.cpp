@@ -1471,8 +1471,14 @@ static int32_t encode_batch_dev(vox_model* m, int n, const float* const* d_mels,
         const EncLayer& L = m->enc[l];
         if (ksp && l > 0) HIPCHK(launch_rms_norm_sumk(x, D, Mtot, D, w2p, (size_t)Mtot * D, ksp, L.attn_norm, c.norm_eps, xn, D, s));      // + the previous layer's w2
         else HIPCHK(launch_rms_norm(x, D, Mtot, D, L.attn_norm, nullptr, c.norm_eps, xn, D, s));
-        VOXCHK(q4_linear_dev(cx, L.wqkv.w, L.wqkv.bias, xn, D, Mtot, qkv, 3 * QD));
-        HIPCHK(launch_rope(qkv, Mtot, 3 * QD, 2 * QD, hd, 0, m->enc_cos, m->enc_sin, s, seq_rows, d_rpos));
+        if (Mtot > 48) {      // q|k|v with RoPE on the q and k columns: in the large-M GEMM's epilogue where that kernel runs, else store + rope_kernel (launch_q4_gemm, EPI_ROPE_ROWS)
+            GemmParams g{}; g.w = L.wqkv.w; g.x = xn; g.x_stride = D; g.M = Mtot; g.out = qkv; g.out_stride = 3 * QD; g.bias = L.wqkv.bias;
+            g.rope_cos = m->enc_cos; g.rope_sin = m->enc_sin; g.hd = hd; g.n_q = 2 * QD; g.pos = d_rpos; g.rope_seq_rows = seq_rows;
+            HIPCHK(launch_q4_gemm(g, EPI_ROPE_ROWS, s));
+        } else {
+            VOXCHK(q4_linear_dev(cx, L.wqkv.w, L.wqkv.bias, xn, D, Mtot, qkv, 3 * QD));
+            HIPCHK(launch_rope(qkv, Mtot, 3 * QD, 2 * QD, hd, 0, m->enc_cos, m->enc_sin, s, seq_rows, d_rpos));
+        }
         AttnParams ap{}; ap.q = qkv; ap.q_stride = 3 * QD; ap.k = qkv + QD; ap.v = qkv + 2 * QD; ap.kv_row_stride = 3 * QD; ap.kv_head_stride = hd;
         ap.out = att; ap.out_stride = QD; ap.M = S_pad; ap.kv_len = S_pad; ap.n_heads = H; ap.n_kv_heads = H; ap.offset = 0; ap.window = c.enc_window;
         ap.seq_len = d_len; ap.q_seq_stride = S_pad * 3 * QD; ap.out_seq_stride = S_pad * QD; ap.kv_seq_stride = (long)S_pad * 3 * QD; ap.seq_row_off = d_roff;

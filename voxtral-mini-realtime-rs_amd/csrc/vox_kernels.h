@@ -31,7 +31,8 @@ enum WFmt { WFMT_Q4_0 = 0, WFMT_BF16 = 1, WFMT_BF16X2 = 2, WFMT_F32 = 3 };
 // WFMT_F32: a dense F32 / F16 checkpoint tensor whose values are NOT bf16-representable (models/weights.rs:16-66 accepts any): qt = the exact f32
 // plane [N][K] (decode GEMV, embedding lookup), qs / sc = bf16 hi / lo planes (w ~= hi + lo to 2^-17; the MFMA GEMMs for > 4 rows).   // BF16X2: f32 weights as two dense bf16 planes, qs = hi [N][K], sc = lo [N][K] (conv stem)
 
-enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6, EPI_RESID_XF = 7 };
+enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_ROPE_KV = 3, EPI_ARGMAX = 4, EPI_GELU = 5, EPI_SWIGLU_XF = 6, EPI_RESID_XF = 7,
+           EPI_ROPE_ROWS = 8 };      // launch_q4_gemm only: store, with RoPE (interleaved pairs, rope.rs:77-141) on the first n_q columns, row m at position pos[m] (or m % rope_seq_rows, or m) -- the encoder's q|k|v operator
 // (M <= 16 only) _SWIGLU_XF: SwiGLU written as XF planes; _RESID_XF: out = acc + resid as f32 AND as XF planes of out * xf_w (* xf_w2) plus
 // per-workgroup partial sums of squares -- the next RMSNorm is folded into its producer and its consumer (GemmParams::ssq_part)
 enum Pro { PRO_NONE = 0, PRO_RMS = 1, PRO_RMS_MUL = 2,      // RMS_MUL: RMSNorm then * mul (the cached Ada scale)
@@ -89,6 +90,7 @@ struct GemmParams {
     float* kz_scratch; size_t kz_scratch_bytes;      // 17..48 rows: room for the K-slice planes of q4_skinny_mt2_kernel ([ksplit][M][N] f32); null: the one-dimensional kernel
     // wide decode step (launch_q4_wide): M = 16 * wide_mt rows = wide_mt slot groups of 16; rows of consecutive groups are consecutive in out / resid / pos / kv_row,
     // the XF planes and the partial sums of squares of group g start g * (the group stride) after group 0's
+    int rope_seq_rows;    // EPI_ROPE_ROWS without a position table: stacked sequences of this many rows restart at position 0 (0: row m sits at position m)
     int wide_mt; long xf_gstride /* uint4 */, xf_out_gstride /* uint16 */, ssq_part_gstride, ssq_out_gstride /* floats */;
     int wide_rows;        // > 0: q4_wide_kernel stores its K-slice planes ROW-MAJOR, [slice][wide_rows][N] f32 (rows < wide_rows only): the layout the 38-token prefill's finishing kernels read
 };

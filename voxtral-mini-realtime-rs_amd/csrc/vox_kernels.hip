@@ -2483,6 +2483,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
                 if (EPI == EPI_SWIGLU) {
                     const float other = dpp_mov<0xB1>(v);        // lane^1; rows interleaved: even n = gate, odd n = up
                     if (m < M && nok && !(n & 1)) p.out[(size_t)m * p.out_stride + (n >> 1)] = silu_f(v) * other;
+                } else if (EPI == EPI_ROPE_ROWS) {      // rope_kernel's arithmetic on the pair (n & ~1, n | 1) held by this lane and its neighbour: p0 = fma(xr, c, -(xi s)), p1 = fma(xi, c, xr s)
+                    const float other = dpp_mov<0xB1>(v);
+                    if (m < M && nok) {
+                        if (n < p.n_q) {
+                            const int pos = p.pos ? p.pos[m] : (p.rope_seq_rows > 0 ? m % p.rope_seq_rows : m);
+                            const size_t ti = (size_t)pos * (p.hd >> 1) + ((n % p.hd) >> 1);
+                            const float c = p.rope_cos[ti], sn = p.rope_sin[ti];
+                            const float os = __fmul_rn(other, sn);
+                            v = (n & 1) ? __fmaf_rn(v, c, os) : __fmaf_rn(v, c, -os);
+                        }
+                        p.out[(size_t)m * p.out_stride + n] = v;
+                    }
                 } else if (m < M && nok) {
                     if (EPI == EPI_RESID) v = v + p.resid[(size_t)m * p.resid_stride + n];
                     if (EPI == EPI_GELU) v = gelu_f(v);
@@ -2502,7 +2514,7 @@ static hipError_t gemm_big_launch(const GemmParams& p, int epi, hipStream_t s) {
 #define VOX_E(E_) case E_: { auto kern = q4_gemm_big_kernel<WGM, WGN, E_>; static DevOnce done;          \
         hipError_t e = ensure_dyn_lds(kern, lds, &done); if (e != hipSuccess) return e;                       \
         kern<<<grid, dim3(256), lds, s>>>(p); break; }
-    switch (epi) { VOX_E(EPI_STORE) VOX_E(EPI_RESID) VOX_E(EPI_GELU) VOX_E(EPI_SWIGLU) default: return hipErrorInvalidValue; }
+    switch (epi) { VOX_E(EPI_STORE) VOX_E(EPI_RESID) VOX_E(EPI_GELU) VOX_E(EPI_SWIGLU) VOX_E(EPI_ROPE_ROWS) default: return hipErrorInvalidValue; }
 #undef VOX_E
     return hipGetLastError();
 }
@@ -2747,7 +2759,19 @@ static hipError_t gemm_launch_f(const GemmParams& p, int epi, hipStream_t s) {
 #undef VOX_MN
     return hipErrorInvalidValue;
 }
+hipError_t launch_rope(float* buf, int M, int stride, int n_rot, int hd, int pos_off, const float* cos_t, const float* sin_t, hipStream_t s, int seq_rows, const int* row_pos);
+static hipError_t launch_q4_gemm_epi(const GemmParams& p, int epi, hipStream_t s, bool* fused_rope);
 hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
+    if (epi != EPI_ROPE_ROWS) return launch_q4_gemm_epi(p, epi, s, nullptr);
+    // the encoder's q|k|v: RoPE in the large-M kernel's epilogue (one launch and one pass over the rows less per layer); every other kernel stores and rope_kernel follows
+    if (!p.rope_cos || !p.rope_sin || p.hd <= 0 || p.n_q <= 0 || p.n_q > p.w.N || p.n_q % 2) return hipErrorInvalidValue;
+    bool fused = false;
+    hipError_t e = launch_q4_gemm_epi(p, EPI_ROPE_ROWS, s, &fused);
+    if (e != hipSuccess || fused) return e;
+    return launch_rope(p.out, p.M, p.out_stride, p.n_q, p.hd, 0, p.rope_cos, p.rope_sin, s, p.rope_seq_rows, p.pos);
+}
+static hipError_t launch_q4_gemm_epi(const GemmParams& p, int epi_in, hipStream_t s, bool* fused_rope) {
+    int epi = epi_in == EPI_ROPE_ROWS ? EPI_STORE : epi_in;      // (EPI_ROPE_ROWS: only the large-M kernel below takes it; the others store, the caller ropes)
     if (p.w.K % 32 || p.M <= 0) return hipErrorInvalidValue;
     if (p.ksplit > 1 && (p.M <= 48 || p.xf || p.w.nb % 4 || env_int("VOX_GEMM_K32") || p.w.fmt == WFMT_F32)) return hipErrorInvalidValue;      // split-K exists in q4_gemm_kernel only
     if (p.w.fmt == WFMT_F32) {      // true-f32 dense weights: bf16 hi + lo planes on the matrix cores (3 MFMAs per product, f32-class like the conv stem)
@@ -2779,7 +2803,10 @@ hipError_t launch_q4_gemm(const GemmParams& p, int epi, hipStream_t s) {
         const bool fits32 = ((size_t)(p.M - 1) * p.x_stride + (size_t)p.w.K) * 4 < 0xFFFFFFF0ull && (size_t)((p.w.N + 15) / 16) * (p.w.nb / 4) * 1024 < 0xFFFFFFF0ull;
         // N % 256 == 0: the kernel hands its n-tile index to the buffer loads as the SGPR offset, which the hardware leaves out of the bounds check -- a partial last
         // column tile would read past the tile planes (every Voxtral N is a multiple of 256, other shapes take the 32 x 128 kernel)
-        if (p.ksplit <= 1 && fits32 && p.w.N % 256 == 0 && (big == 1 || (big == 0 && wg14 >= big_min))) return gemm_big_launch<1, 4>(p, epi, s);
+        if (p.ksplit <= 1 && fits32 && p.w.N % 256 == 0 && (big == 1 || (big == 0 && wg14 >= big_min))) {
+            if (epi_in == EPI_ROPE_ROWS && !knob_str("VOX_NO_ROPE_FUSE")) { if (fused_rope) *fused_rope = true; return gemm_big_launch<1, 4>(p, EPI_ROPE_ROWS, s); }
+            return gemm_big_launch<1, 4>(p, epi, s);
+        }
     }
     return p.w.fmt == WFMT_BF16 ? gemm_launch_f<WFMT_BF16>(p, epi, s) : gemm_launch_f<WFMT_Q4_0>(p, epi, s);
 }
