@@ -459,8 +459,8 @@ def main():
         dom = per["w1w3"]
         engine = None
         if model.set_decode_engine(True):      # the product's decode step is ONE launch of the persistent engine: that launch is the dominant kernel (92 % of the clip's wall time)
-            # three passes of 40 launches, the MEDIAN pass reported (one pass taken right behind the corpus runs read 630 us on a box where rocprofv3 saw 607 over 792 launches)
-            passes = [model.bench_decode_gemv(5, 40) for _ in range(3)]
+            # three passes of 200 launches (graph replays of 50 per position quarter), the MEDIAN pass reported
+            passes = [model.bench_decode_gemv(5, 200) for _ in range(3)]      # (50 launches per position quarter: with 10 the first launch behind each quarter's event -- a clock ramp of ~250 us on some boxes -- read as +25 us per launch)
             us, nbytes, kname = sorted(passes, key=lambda p: p[0])[1]
             engine = {"avg_us": round(us, 2), "bytes": int(nbytes), "GBps": round(nbytes / us / 1e3, 1), "kernel": kname, "avg_us_passes": [round(p[0], 2) for p in passes]}
             per["decode_engine"] = engine; dom = engine

@@ -10,7 +10,7 @@ br = b["roofline"]
 p = os.path.join(ROOT, "DESIGN.md"); s = open(p).read()
 a = s.index("**Round-6 numbers** (1 × MI355X"); e = s.index("**Round-5 numbers** (1 × MI355X")
 new = f'''**Round-6 numbers** (1 × MI355X, `profiles/r06_bench_n1.json`, `r06_bench_kernel_stats.csv`, `r06_batch16_kernel_stats.csv`, `r06_share81_kernel_stats.csv`; box-to-box spread ≈ ± 2 %): single clip
-**RTF {d['rtf']:.4f}, {d['value']:.0f} tok/s** end-to-end (engine launch {r['avg_launch_us']:.1f} µs by HIP events — one event pair per position quarter around the launches only, median of three passes of 40 —
+**RTF {d['rtf']:.4f}, {d['value']:.0f} tok/s** end-to-end (engine launch {r['avg_launch_us']:.1f} µs by HIP events — one event pair per position quarter around a graph replay of 50 launches, median of three passes of 200 —
 {ravg:.1f} µs rocprofv3 average over {rcalls} launches of a second, profiled run on the same box = {r['achieved']/1000:.2f} TB/s = **{r['frac']:.2f} of 8 TB/s**, unchanged: no structural attempt was made on the single-stream engine this round — §7);
 piecewise C loop {d['piecewise']['tok_per_s']:.0f} tok/s; **batch 16: {b['tok_per_s']:.0f} tok/s**, {b['ms_per_batch']:.1f} ms per batch (encoder {b['stage_ms']['encode_ms']:.1f} ms, §3.2; decode step {b['decode_step_ms']:.3f} ms); the `batch.roofline` block prices the WHOLE
 batched step on algorithmic bytes incl. K / V: {br['algorithmic_bytes_per_step']/1e9:.2f} GB in {b['decode_step_ms']:.3f} ms = {br['achieved']/1000:.2f} TB/s = **{br['frac']:.2f}** (counter traffic {br['traffic']/1e9:.2f} GB: {br['traffic']/br['algorithmic_bytes_per_step']:.2f} ×); f32 path {d['f32']['tok_per_s']:.0f} tok/s.
@@ -31,7 +31,7 @@ a = s.index("| BASELINE config | result | dominant kernel: achieved / peak |"); 
 tbl = f'''| BASELINE config | result | dominant kernel: achieved / peak |
 |---|---|---|
 | [1] single 16 s clip, f32 SafeTensors path | RTF {d['f32']['rtf']:.4f} · {d['f32']['tok_per_s']:.0f} tok/s | decode step 0.52 of the HBM peak (unchanged) |
-| [2] single 16 s clip, Q4_0 (the `metric`) | RTF **{d['rtf']:.4f}** · **{d['value']:.0f} tok/s** end-to-end · piecewise C loop {d['piecewise']['tok_per_s']:.0f} tok/s · encode {d['stage_ms']['encode_ms']:.2f} ms, prefill 2.6 ms, decode step {r['decode_step_measured_ms']:.2f} ms | `decode_engine_kernel` {r['avg_launch_us']:.1f} µs per launch (HIP events, median of 3 passes; rocprofv3 {ravg:.1f} µs over {rcalls} launches of a profiled run on the same box) = {r['achieved']/1000:.2f} TB/s = **{r['frac']:.2f}** of the HBM peak — unchanged for the fourth round |
+| [2] single 16 s clip, Q4_0 (the `metric`) | RTF **{d['rtf']:.4f}** · **{d['value']:.0f} tok/s** end-to-end · piecewise C loop {d['piecewise']['tok_per_s']:.0f} tok/s · encode {d['stage_ms']['encode_ms']:.2f} ms, prefill 2.6 ms, decode step {r['decode_step_measured_ms']:.2f} ms | `decode_engine_kernel` {r['avg_launch_us']:.1f} µs per launch (HIP events around graph replays, median of 3 passes of 200; rocprofv3 {ravg:.1f} µs over {rcalls} launches of a profiled run on the same box) = {r['achieved']/1000:.2f} TB/s = **{r['frac']:.2f}** of the HBM peak — unchanged for the fourth round |
 | [3] 16 × 16 s clips, Q4_0 | **{b['tok_per_s']:.0f} tok/s** · {b['ms_per_batch']:.1f} ms per batch (encode {b['stage_ms']['encode_ms']:.1f} + decode {b['stage_ms']['decode_ms']:.1f}) · decode step {b['decode_step_ms']:.3f} ms | whole batched step on ALGORITHMIC bytes incl. K / V (`batch.roofline`): {br['algorithmic_bytes_per_step']/1e9:.2f} GB in {b['decode_step_ms']:.3f} ms = {br['achieved']/1000:.2f} TB/s = **{br['frac']:.2f}**; counter traffic {br['traffic']/1e9:.2f} GB = {br['traffic']/br['algorithmic_bytes_per_step']:.2f} × |
 | [4] 647 FLEURS-like clips, one GPU, ONE call — un-chunked pipeline | RTF {f['rtf']:.5f} · **{f['tok_per_s']:.0f} tok/s** · {f['wall_s']:.2f} s (round 5: 9 667) · rank share {f['simulated_world']['predicted_wall_s']:.3f} s → predicted 8-GPU scaling {f['simulated_world']['predicted_scaling']:.2f} × of the (now faster) one-GPU run | up to 128 decode slots; a step = one Q4 GEMM per operator for the groups of a chain, two chains of four groups on two streams: 4.70 ms per 128 slots (64 slots: 3.55 → 2.92 ms) |
 | [4] the same corpus as **two concurrent sessions of 64 slots** (`vox_model_set_sessions(m, 2)`: hidden context + model replica + library thread; `DESIGN.md` §3.3h) | RTF {fs['rtf']:.5f} · **{fs['tok_per_s']:.0f} tok/s** · {fs['wall_s']:.2f} s = × {fs['tok_per_s_vs_one_session']:.2f} of the one-session call, same ids | the same overlap as two chains: × 1.16–1.20 over a 64-slot session, next to nothing on top of 128 slots |

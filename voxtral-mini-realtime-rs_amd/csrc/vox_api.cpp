@@ -2579,7 +2579,9 @@ static int32_t transcribe_continuous_impl(vox_model* m, int32_t n, const float* 
     const int ncm = std::min(n, CHUNK);
     HIPCHK(b_px.alloc_pooled(cx, (size_t)ncm * PREFIX_LEN * D * 4)); HIPCHK(b_xn.alloc_pooled(cx, (size_t)ncm * D * 4)); HIPCHK(b_lg0.alloc_pooled(cx, (size_t)ncm * V * 4));
     // front-end buffers TWICE: chunk ci + 1's samples go up and its log-mel is computed on a second stream while chunk ci's encoder runs (VOX_BATCH_NO_FE_OVERLAP=1: one stream)
-    const bool fe_overlap = n_chunks > 1 && !knob_str("VOX_BATCH_NO_FE_OVERLAP");
+    // (not on a shared context: with two sessions uploading from two threads the second stream made each session's encoder stage 1.8 x longer under the HIP runtime that
+    // PyTorch bundles -- bench.py: 3.82 -> 4.55 s for the two-session corpus -- while the stand-alone runtime did not care)
+    const bool fe_overlap = n_chunks > 1 && !cx->shared && !knob_str("VOX_BATCH_NO_FE_OVERLAP");
     const size_t mel_half = std::max<size_t>(mel_max, 1), smp_half = std::max<size_t>(smp_max, 1);
     HIPCHK(b_mel.alloc_pooled(cx, mel_half * 4 * (fe_overlap ? 2 : 1))); HIPCHK(b_scale.alloc_pooled(cx, (size_t)ncm * 4 * (fe_overlap ? 2 : 1)));
     if (mem_kind == VOX_MEM_HOST) HIPCHK(b_smp.alloc_pooled(cx, smp_half * 4 * (fe_overlap ? 2 : 1)));
@@ -3535,17 +3537,27 @@ extern "C" int32_t vox_bench_decode_gemv(vox_model* m, int32_t which, int32_t it
         for (int i = 0; i < 3; i++) HIPCHK(launch_decode_engine(ep, s));
         // one event pair per quarter, around the LAUNCHES only: the position update between the quarters (a 4-byte copy from pageable host memory: 20 - 250 us depending on
         // the box) used to sit inside the timed region -- 603 us per launch on one box, 628 on another where rocprofv3 saw 605 (round 6)
+        // ... and the launches of a quarter go out as ONE graph replay, the way the product issues its steps (on some boxes ten plain launches in a row cost 25 us more per
+        // launch than the same ten in a graph: 629 against 603 us where the product's own steps took 596)
         hipEvent_t ev[8]; for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+        const int per_q = std::max(iters / 4, 1);
+        hipGraph_t gq = nullptr; hipGraphExec_t gx = nullptr;
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        hipError_t ce = hipSuccess; for (int i = 0; i < per_q && ce == hipSuccess; i++) ce = launch_decode_engine(ep, s);
+        const hipError_t ee = hipStreamEndCapture(s, &gq);
+        if (ce != hipSuccess || ee != hipSuccess || hipGraphInstantiate(&gx, gq, nullptr, nullptr, 0) != hipSuccess) { if (gq) (void)hipGraphDestroy(gq); for (auto& e : ev) (void)hipEventDestroy(e); return fail(VOX_ERR_HIP, "engine timing: graph capture failed"); }
         for (int q = 0; q < 4; q++) {
             const int pq = std::min(bench_pos[q], m->cache->max_seq - 2);
             HIPCHK(hipMemcpyAsync(m->d_pos, &pq, 4, hipMemcpyHostToDevice, s));      // (pageable host source: staged at call time)
             HIPCHK(hipEventRecord(ev[2 * q], s));
-            for (int i = q * iters / 4; i < (q + 1) * iters / 4; i++) HIPCHK(launch_decode_engine(ep, s));
+            HIPCHK(hipGraphLaunch(gx, s));
             HIPCHK(hipEventRecord(ev[2 * q + 1], s));
         }
         HIPCHK(hipEventSynchronize(ev[7]));
         float ms = 0.f; for (int q = 0; q < 4; q++) { float mq = 0.f; HIPCHK(hipEventElapsedTime(&mq, ev[2 * q], ev[2 * q + 1])); ms += mq; }
         for (auto& e : ev) (void)hipEventDestroy(e);
+        (void)hipGraphExecDestroy(gx); (void)hipGraphDestroy(gq);
+        iters = 4 * per_q;
         m->eng_launches += (unsigned long long)iters + 3;
         *avg_us = (double)ms * 1000.0 / iters;
         unsigned err2[2] = {0, 0}; HIPCHK(hipMemcpy(err2, ep.err, 8, hipMemcpyDeviceToHost));

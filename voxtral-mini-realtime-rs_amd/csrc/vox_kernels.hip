@@ -2488,7 +2488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
                     if (m < M && nok) {
                         if (n < p.n_q) {
                             const int pos = p.pos ? p.pos[m] : (p.rope_seq_rows > 0 ? m % p.rope_seq_rows : m);
-                            const size_t ti = (size_t)pos * (p.hd >> 1) + ((n % p.hd) >> 1);
+                            const size_t ti = (size_t)pos * (p.hd >> 1) + ((n & (p.hd - 1)) >> 1);      // (head_dim is a power of two: checked by the launcher)
                             const float c = p.rope_cos[ti], sn = p.rope_sin[ti];
                             const float os = __fmul_rn(other, sn);
                             v = (n & 1) ? __fmaf_rn(v, c, os) : __fmaf_rn(v, c, -os);
@@ -2804,7 +2804,9 @@ static hipError_t launch_q4_gemm_epi(const GemmParams& p, int epi_in, hipStream_
         // N % 256 == 0: the kernel hands its n-tile index to the buffer loads as the SGPR offset, which the hardware leaves out of the bounds check -- a partial last
         // column tile would read past the tile planes (every Voxtral N is a multiple of 256, other shapes take the 32 x 128 kernel)
         if (p.ksplit <= 1 && fits32 && p.w.N % 256 == 0 && (big == 1 || (big == 0 && wg14 >= big_min))) {
-            if (epi_in == EPI_ROPE_ROWS && !knob_str("VOX_NO_ROPE_FUSE")) { if (fused_rope) *fused_rope = true; return gemm_big_launch<1, 4>(p, EPI_ROPE_ROWS, s); }
+            // RoPE in the epilogue only where the grid is several workgroups per CU deep (stacked encoders): at one clip (240 workgroups) the epilogue's table loads are the
+            // tail of every CU's only workgroup -- +11 us per layer measured, against 3 us for rope_kernel
+            if (epi_in == EPI_ROPE_ROWS && wg14 >= 1024 && (p.hd & (p.hd - 1)) == 0 && !knob_str("VOX_NO_ROPE_FUSE")) { if (fused_rope) *fused_rope = true; return gemm_big_launch<1, 4>(p, EPI_ROPE_ROWS, s); }
             return gemm_big_launch<1, 4>(p, epi, s);
         }
     }
